@@ -1,0 +1,240 @@
+"""ctypes binding of the CPU oracle (oracle/libkbo_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  Product code (kbo_amd/) must never import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libkbo_oracle.so")
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("bases", "extend_calls", "rank_calls", "rank_blocks", "contracts", "lcs_reads")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class RLE(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("start", "end", "matches", "mismatches", "jumps", "gap_bases", "gap_opens")]
+
+    def as_tuple(self):
+        return tuple(int(getattr(self, n)) for n, _ in self._fields_)
+
+
+def build_lib():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        build_lib()
+    lib = C.CDLL(_LIB_PATH)
+    vp, u8p, u64p, i64p, u32p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), \
+        C.POINTER(C.c_int64), C.POINTER(C.c_uint32)
+    lib.ora_index_build.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t,
+                                    C.c_uint32, C.c_int, C.POINTER(vp)]
+    lib.ora_index_from_parts.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(vp), u64p,
+                                         vp, C.POINTER(vp)]
+    lib.ora_index_free.argtypes = [vp]
+    lib.ora_index_free.restype = None
+    lib.ora_index_k.argtypes = [vp]; lib.ora_index_k.restype = C.c_uint32
+    lib.ora_index_n_sets.argtypes = [vp]; lib.ora_index_n_sets.restype = C.c_uint64
+    lib.ora_index_n_kmers.argtypes = [vp]; lib.ora_index_n_kmers.restype = C.c_uint64
+    lib.ora_index_C.argtypes = [vp, u64p]; lib.ora_index_C.restype = None
+    lib.ora_index_bits.argtypes = [vp, C.c_int]; lib.ora_index_bits.restype = vp
+    lib.ora_index_lcs.argtypes = [vp]; lib.ora_index_lcs.restype = vp
+    lib.ora_index_access_kmer.argtypes = [vp, C.c_uint64, vp]
+    lib.ora_matching_statistics.argtypes = [vp, vp, C.c_size_t, vp, vp, vp, C.POINTER(Counters)]
+    lib.ora_log_rm_max_cdf.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t]
+    lib.ora_log_rm_max_cdf.restype = C.c_double
+    lib.ora_random_match_threshold.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.c_double]
+    lib.ora_random_match_threshold.restype = C.c_size_t
+    lib.ora_derandomize_ms_val.argtypes = [C.c_size_t, C.c_int64, C.c_size_t, C.c_size_t]
+    lib.ora_derandomize_ms_val.restype = C.c_int64
+    lib.ora_derandomize_ms_vec.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_size_t, vp]
+    lib.ora_translate_ms_val.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_size_t, u32p, u32p]
+    lib.ora_translate_ms_val.restype = None
+    lib.ora_translate_ms_vec.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_size_t, vp]
+    lib.ora_matches.argtypes = [vp, vp, C.c_size_t, C.c_double, vp]
+    lib.ora_run_lengths_gapped.argtypes = [vp, C.c_size_t, C.c_size_t, C.POINTER(RLE), C.c_size_t]
+    lib.ora_run_lengths_gapped.restype = C.c_size_t
+    lib.ora_relative_to_ref.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.ora_relative_to_ref.restype = None
+    lib.ora_matches_batch.argtypes = [vp, vp, vp, C.c_size_t, C.c_double, C.c_int, vp, vp,
+                                      C.POINTER(Counters)]
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+class OracleError(AssertionError):
+    """Mirrors a reference assert!/panic! (code in .code)."""
+
+    def __init__(self, code):
+        super().__init__(f"oracle error {code}")
+        self.code = code
+
+
+def _chk(rc):
+    if rc != 0:
+        raise OracleError(rc)
+
+
+def _bytes(x):
+    if isinstance(x, str):
+        x = x.encode()
+    return np.frombuffer(bytes(x), dtype=np.uint8) if not isinstance(x, np.ndarray) else \
+        np.ascontiguousarray(x, dtype=np.uint8)
+
+
+class Index:
+    """sbwt::SbwtIndexVariant + sbwt::LcsArray as produced by kbo::build (lib.rs:501-506)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def build(cls, seqs, k=31, add_revcomp=False):
+        seqs = [bytes(_bytes(s)) for s in seqs]
+        arr = (C.c_char_p * len(seqs))(*seqs)
+        lens = (C.c_size_t * len(seqs))(*[len(s) for s in seqs])
+        h = C.c_void_p()
+        _chk(lib().ora_index_build(arr, lens, len(seqs), k, int(add_revcomp), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_parts(cls, k, n_sets, n_kmers, rows, Carr, lcs):
+        rows = [np.ascontiguousarray(r, dtype=np.uint64) for r in rows]
+        ptrs = (C.c_void_p * 4)(*[r.ctypes.data for r in rows])
+        Cc = (C.c_uint64 * 4)(*[int(v) for v in Carr])
+        lcs = np.ascontiguousarray(lcs, dtype=np.uint8)
+        h = C.c_void_p()
+        _chk(lib().ora_index_from_parts(k, n_sets, n_kmers, ptrs, Cc, lcs.ctypes.data, C.byref(h)))
+        return cls(h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().ora_index_free(self._h)
+            self._h = None
+
+    @property
+    def k(self):
+        return int(lib().ora_index_k(self._h))
+
+    @property
+    def n_sets(self):
+        return int(lib().ora_index_n_sets(self._h))
+
+    @property
+    def n_kmers(self):
+        return int(lib().ora_index_n_kmers(self._h))
+
+    @property
+    def C(self):
+        out = (C.c_uint64 * 4)()
+        lib().ora_index_C(self._h, out)
+        return [int(v) for v in out]
+
+    def bits(self, c):
+        nw = (self.n_sets + 63) // 64
+        p = lib().ora_index_bits(self._h, c)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(nw,)).copy()
+
+    def lcs(self):
+        p = lib().ora_index_lcs(self._h)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.n_sets,)).copy()
+
+    def access_kmer(self, colex):
+        out = np.zeros(self.k, dtype=np.uint8)
+        _chk(lib().ora_index_access_kmer(self._h, colex, out.ctypes.data))
+        return out.tobytes()
+
+    def matching_statistics(self, query, counters=None):
+        """index::query_sbwt (index.rs:243-256) -> (d, lo, hi) uint64 arrays."""
+        q = _bytes(query)
+        n = len(q)
+        d = np.zeros(n, dtype=np.uint64); lo = np.zeros(n, dtype=np.uint64); hi = np.zeros(n, dtype=np.uint64)
+        _chk(lib().ora_matching_statistics(self._h, q.ctypes.data, n, d.ctypes.data, lo.ctypes.data,
+                                           hi.ctypes.data, C.byref(counters) if counters is not None else None))
+        return d, lo, hi
+
+    def matches(self, query, max_error_prob=1e-7):
+        q = _bytes(query)
+        out = np.zeros(len(q), dtype=np.uint8)
+        _chk(lib().ora_matches(self._h, q.ctypes.data, len(q), max_error_prob, out.ctypes.data))
+        return out.tobytes()
+
+    def matches_batch(self, concat, offsets, max_error_prob=1e-7, n_threads=1, want_d=False,
+                      counters=None):
+        concat = np.ascontiguousarray(concat, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        chars = np.zeros(len(concat), dtype=np.uint8)
+        d = np.zeros(len(concat), dtype=np.uint8) if want_d else None
+        _chk(lib().ora_matches_batch(self._h, concat.ctypes.data, offsets.ctypes.data, len(offsets) - 1,
+                                     max_error_prob, n_threads, chars.ctypes.data,
+                                     d.ctypes.data if want_d else None,
+                                     C.byref(counters) if counters is not None else None))
+        return (chars, d) if want_d else chars
+
+
+def log_rm_max_cdf(t, alphabet_size, n_kmers):
+    return float(lib().ora_log_rm_max_cdf(t, alphabet_size, n_kmers))
+
+
+def random_match_threshold(k, n_kmers, alphabet_size, max_error_prob):
+    return int(lib().ora_random_match_threshold(k, n_kmers, alphabet_size, max_error_prob))
+
+
+def derandomize_ms_val(curr, nxt, threshold, k):
+    return int(lib().ora_derandomize_ms_val(curr, nxt, threshold, k))
+
+
+def derandomize_ms_vec(noisy, k, threshold):
+    a = np.ascontiguousarray(noisy, dtype=np.uint64)
+    out = np.zeros(len(a), dtype=np.int64)
+    _chk(lib().ora_derandomize_ms_vec(a.ctypes.data, len(a), k, threshold, out.ctypes.data))
+    return out
+
+
+def translate_ms_val(curr, nxt, prev, threshold):
+    a, b = C.c_uint32(), C.c_uint32()
+    lib().ora_translate_ms_val(curr, nxt, prev, threshold, C.byref(a), C.byref(b))
+    return chr(a.value), chr(b.value)
+
+
+def translate_ms_vec(derand, k, threshold):
+    a = np.ascontiguousarray(derand, dtype=np.int64)
+    out = np.zeros(len(a), dtype=np.uint32)
+    _chk(lib().ora_translate_ms_vec(a.ctypes.data, len(a), k, threshold, out.ctypes.data))
+    return "".join(chr(v) for v in out)
+
+
+def run_lengths_gapped(aln, max_gap_len=0):
+    a = _bytes(aln)
+    n = lib().ora_run_lengths_gapped(a.ctypes.data, len(a), max_gap_len, None, 0)
+    buf = (RLE * max(n, 1))()
+    lib().ora_run_lengths_gapped(a.ctypes.data, len(a), max_gap_len, buf, n)
+    return [buf[i].as_tuple() for i in range(n)]
+
+
+def relative_to_ref(ref_seq, aln):
+    r, a = _bytes(ref_seq), _bytes(aln)
+    out = np.zeros(len(a), dtype=np.uint8)
+    lib().ora_relative_to_ref(r.ctypes.data, a.ctypes.data, len(a), out.ctypes.data)
+    return out.tobytes()

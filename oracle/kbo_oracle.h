@@ -1,0 +1,117 @@
+/*
+ * kbo_oracle.h — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C) of the k-bounded matching-statistics path of
+ * tmaklin/kbo v0.5.1:  matching_statistics -> derandomize_ms_vec ->
+ * translate_ms_vec (+ format::run_lengths_gapped / relative_to_ref).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (libkbo_hip.so) never links or calls it.
+ *
+ * PARITY PINNING: the upstream crate is Rust and its hot loop lives in the
+ * un-vendored dependency `sbwt = "0.3.4"` (reference Cargo.toml:18); neither
+ * can be compiled in this image (no rustc/cargo).  The restatement is pinned
+ * instead by every golden vector the reference's own tests/doctests hold for
+ * this path (tests/golden/, see tests/test_oracle_golden.py): MS values
+ * (index.rs:265-273), derandomize (derandomize.rs:298-379), translate
+ * (translate.rs:396-532), matches/map/find doctests (lib.rs:600-609, 647-717,
+ * 786-805), run_lengths (format.rs:295-330), plus the call/add_variants
+ * goldens that exercise intervals and access_kmer.
+ */
+#ifndef KBO_ORACLE_H
+#define KBO_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ora_index ora_index;
+
+/* Operation counters of the reference algorithm:
+ * used to derive the algorithmic bytes per query base. */
+typedef struct {
+    uint64_t bases;        /* query bases processed                        */
+    uint64_t extend_calls; /* extend_right invocations                     */
+    uint64_t rank_calls;   /* rank queries (2 per extend)                  */
+    uint64_t rank_blocks;  /* distinct 512-bit rank blocks touched/extend  */
+    uint64_t contracts;    /* contract_left invocations                    */
+    uint64_t lcs_reads;    /* LCS elements read by contract_left           */
+} ora_counters;
+
+/* ---- index (semantics of sbwt::SbwtIndex<SubsetMatrix> + LcsArray as built at
+ *      reference index.rs:56-99; abstract content per SURVEY.md §8(a) A0) ---- */
+int ora_index_build(const uint8_t *const *seqs, const size_t *lens, size_t n_seqs,
+                    uint32_t k, int add_revcomp, ora_index **out);
+int ora_index_from_parts(uint32_t k, uint64_t n_sets, uint64_t n_kmers,
+                         const uint64_t *const rows[4], const uint64_t C[4],
+                         const uint8_t *lcs, ora_index **out);
+void ora_index_free(ora_index *idx);
+uint32_t ora_index_k(const ora_index *idx);
+uint64_t ora_index_n_sets(const ora_index *idx);
+uint64_t ora_index_n_kmers(const ora_index *idx);
+void ora_index_C(const ora_index *idx, uint64_t C[4]);
+const uint64_t *ora_index_bits(const ora_index *idx, int c); /* ceil(n/64) words */
+const uint8_t *ora_index_lcs(const ora_index *idx);          /* n bytes          */
+/* sbwt access_kmer: writes k chars ('$','A','C','G','T') of row `colex`;
+ * only available for indexes made by ora_index_build. */
+int ora_index_access_kmer(const ora_index *idx, uint64_t colex, uint8_t *out_k);
+
+/* ---- A1/A2: StreamingIndex::matching_statistics via index::query_sbwt
+ *      (reference index.rs:243-256) ---- */
+int ora_matching_statistics(const ora_index *idx, const uint8_t *query, size_t len,
+                            uint64_t *d, uint64_t *lo, uint64_t *hi,
+                            ora_counters *ctr /* nullable, accumulated */);
+
+/* ---- A3: derandomize.rs:91-100, 127-145 ---- */
+double ora_log_rm_max_cdf(size_t t, size_t alphabet_size, size_t n_kmers);
+size_t ora_random_match_threshold(size_t k, size_t n_kmers, size_t alphabet_size,
+                                  double max_error_prob);
+/* ---- A4/A5: derandomize.rs:221-247, 269-288 ---- */
+int64_t ora_derandomize_ms_val(size_t curr_noisy_ms, int64_t next_derand_ms,
+                               size_t threshold, size_t k);
+int ora_derandomize_ms_vec(const uint64_t *noisy_ms, size_t len, size_t k,
+                           size_t threshold, int64_t *out);
+/* ---- A6: translate.rs:180-216, 263-293 (chars as Rust `char` = u32) ---- */
+void ora_translate_ms_val(int64_t curr, int64_t next, int64_t prev, size_t threshold,
+                          uint32_t *aln_curr, uint32_t *aln_next);
+int ora_translate_ms_vec(const int64_t *derand_ms, size_t len, size_t k,
+                         size_t threshold, uint32_t *out);
+
+/* ---- A7 glue: lib.rs:612-628 (matches) ; chars as bytes ---- */
+int ora_matches(const ora_index *idx, const uint8_t *query, size_t len,
+                double max_error_prob, uint8_t *chars_out);
+
+/* ---- format.rs:18-193, 266-287 ---- */
+typedef struct {
+    uint64_t start, end, matches, mismatches, jumps, gap_bases, gap_opens;
+} ora_rle;
+/* returns number of RLEs (writes at most cap) */
+size_t ora_run_lengths_gapped(const uint8_t *aln, size_t len, size_t max_gap_len,
+                              ora_rle *out, size_t cap);
+void ora_relative_to_ref(const uint8_t *ref_seq, const uint8_t *aln, size_t len,
+                         uint8_t *out);
+
+/* ---- batch driver used by bench.py's cpu_baseline leg: the same A1->A5->A6
+ *      chain over many reads, split over `n_threads` pthreads (reads are
+ *      independent; kbo itself is single-threaded per call, lib.rs:612-628).
+ *      offsets has n_reads+1 entries into concat.  chars_out/d_out nullable. */
+int ora_matches_batch(const ora_index *idx, const uint8_t *concat,
+                      const uint64_t *offsets, size_t n_reads, double max_error_prob,
+                      int n_threads, uint8_t *chars_out, uint8_t *d_out,
+                      ora_counters *ctr);
+
+/* error codes (mirror the reference's asserts) */
+#define ORA_OK 0
+#define ORA_E_EMPTY_QUERY (-1) /* index.rs:248 */
+#define ORA_E_LEN_LE_2 (-2)    /* derandomize.rs:276, translate.rs:270 */
+#define ORA_E_THRESHOLD (-3)   /* derandomize.rs:275, translate.rs:269 */
+#define ORA_E_BAD_ARG (-4)
+#define ORA_E_NOMEM (-5)
+
+#ifdef __cplusplus
+}
+#endif
+#endif
