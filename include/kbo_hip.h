@@ -1,0 +1,204 @@
+/*
+ * kbo_hip.h — C ABI of the MI355X-native k-bounded matching-statistics path of kbo.
+ *
+ * This is the drop-in boundary: every entry point below is what a binding of the
+ * reference crate (tmaklin/kbo v0.5.1, Rust) would call instead of its CPU path.
+ * Each declaration cites the reference interface it replaces (file:line under the
+ * reference's src/).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *   - return 0 (KBO_OK) or a negative KBO_E_* code; each code mirrors one of the
+ *     reference's assert!/panic! sites.  kbo_last_error() gives a thread-local text.
+ *   - the caller owns all in/out buffers; the index handle is immutable after
+ *     construction, so concurrent calls on one handle are allowed.
+ *   - "host" entry points take host pointers and do H2D/D2H themselves;
+ *     "*_dev" entry points take pointers that are already resident in the HBM of
+ *     the current HIP device plus a hipStream_t (passed as void*), enqueue their
+ *     kernels on that stream and return without synchronising.
+ *   - ALL matching-statistics work runs in the HIP kernels (gfx950).  There is no
+ *     CPU fallback: without a usable GPU the compute entry points fail with KBO_E_HIP.
+ */
+#ifndef KBO_HIP_H
+#define KBO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KBO_OK 0
+#define KBO_E_EMPTY_QUERY (-1)    /* index.rs:248   assert!(!query.is_empty())          */
+#define KBO_E_LEN_LE_2 (-2)       /* derandomize.rs:276, translate.rs:270  len > 2      */
+#define KBO_E_THRESHOLD_LE_1 (-3) /* derandomize.rs:275, translate.rs:269  threshold > 1*/
+#define KBO_E_BAD_ARG (-4)        /* derandomize.rs:96-97,133-137,274; null/invalid arg */
+#define KBO_E_NOMEM (-5)
+#define KBO_E_K_MISMATCH (-6)     /* lib.rs:559,729  k of index != k of opts            */
+#define KBO_E_HIP (-7)            /* HIP runtime error / no device / kernel image missing */
+#define KBO_E_UNSUPPORTED (-8)    /* valid in the reference, not (yet) built here        */
+#define KBO_E_MS_RANGE (-9)       /* derandomize.rs:229-230  noisy/derand value > k     */
+#define KBO_E_IO (-10)            /* index.rs:137,202 file open/read/write failure      */
+
+const char *kbo_last_error(void);
+const char *kbo_version(void);
+
+/* ------------------------------------------------------------------ options */
+
+/* kbo::BuildOpts (lib.rs:259-313).  Only k and add_revcomp change the index content;
+ * the remaining fields steer the sbwt crate's construction algorithm and are accepted
+ * for signature compatibility (num_threads is honoured by this builder too). */
+typedef struct {
+    uint32_t k;              /* 31    */
+    int32_t add_revcomp;     /* false */
+    uint32_t num_threads;    /* 1     */
+    uint32_t prefix_precalc; /* 8     */
+    int32_t build_select;    /* false */
+    uint32_t mem_gb;         /* 4     */
+    int32_t dedup_batches;   /* false */
+    const char *temp_dir;    /* NULL  */
+} kbo_build_opts;
+void kbo_build_opts_default(kbo_build_opts *o); /* lib.rs:300-313 */
+
+/* kbo::FindOpts (lib.rs:358-382) */
+typedef struct {
+    double max_error_prob; /* 1e-7 */
+    size_t max_gap_len;    /* 0    */
+} kbo_find_opts;
+void kbo_find_opts_default(kbo_find_opts *o);
+
+/* kbo::MapOpts (lib.rs:412-466).  fill_gaps / call_variants select the host-side
+ * refinement stages that follow the hot path (lib.rs:743-754). */
+typedef struct {
+    double max_error_prob; /* 1e-7 */
+    int32_t fill_gaps;     /* true */
+    int32_t call_variants; /* true */
+    int32_t format;        /* true */
+    kbo_build_opts sbwt_build_opts; /* build_select = true */
+} kbo_map_opts;
+void kbo_map_opts_default(kbo_map_opts *o);
+
+/* kbo::format::RLE (format.rs:18-33) */
+typedef struct {
+    uint64_t start, end, matches, mismatches, jumps, gap_bases, gap_opens;
+} kbo_rle;
+
+/* ------------------------------------------------------------------ index
+ * Opaque stand-in for (sbwt::SbwtIndexVariant, sbwt::LcsArray) — the pair returned by
+ * kbo::build (lib.rs:501-506) and consumed by every query function.  Owns the host
+ * copy and one device-resident copy per GPU it has been used on. */
+typedef struct kbo_index kbo_index_t;
+
+/* kbo::build / index::build_sbwt_from_vecs (lib.rs:501-506, index.rs:56-99). */
+int kbo_index_build(const uint8_t *const *seqs, const size_t *lens, size_t n_seqs,
+                    const kbo_build_opts *opts, kbo_index_t **out);
+
+/* Adopt an index built elsewhere (e.g. by the sbwt crate on the Rust side): the four
+ * SubsetMatrix rows as little-endian 64-bit words (bit i of word i/64 = row i), the C
+ * array and the LCS array as bytes.  Replaces handing &SbwtIndexVariant/&LcsArray to
+ * index::query_sbwt (index.rs:243-247). */
+int kbo_index_from_parts(uint32_t k, uint64_t n_sets, uint64_t n_kmers,
+                         const uint64_t *const rows[4], const uint64_t C[4],
+                         const uint8_t *lcs, kbo_index_t **out);
+/* Inverse of the above; rows[c] must hold ceil(n_sets/64) words, lcs n_sets bytes. */
+int kbo_index_export_parts(const kbo_index_t *idx, uint64_t *const rows[4], uint64_t C[4],
+                           uint8_t *lcs);
+void kbo_index_free(kbo_index_t *idx);
+
+size_t kbo_index_k(const kbo_index_t *idx);         /* SbwtIndex::k()       lib.rs:620 */
+uint64_t kbo_index_n_kmers(const kbo_index_t *idx); /* SbwtIndex::n_kmers() lib.rs:620 */
+uint64_t kbo_index_n_sets(const kbo_index_t *idx);  /* SbwtIndex::n_sets()             */
+
+/* index::serialize_sbwt / load_sbwt (index.rs:128-151, 195-212) — own flat,
+ * device-ready file format "<prefix>.kbohip" (NOT the sbwt crate's .sbwt/.lcs). */
+int kbo_index_save(const kbo_index_t *idx, const char *path);
+int kbo_index_load(const char *path, kbo_index_t **out);
+
+/* Upload (idempotent) the device layout to HIP device `device` (-1 = current). */
+int kbo_index_to_device(kbo_index_t *idx, int device);
+/* Bytes of the device-resident layout: rank blocks / LCS. */
+int kbo_index_device_bytes(const kbo_index_t *idx, uint64_t *rank_bytes, uint64_t *lcs_bytes);
+
+/* ------------------------------------------------------------------ A3 (host, f64)
+ * derandomize::log_rm_max_cdf (derandomize.rs:91-100) and
+ * derandomize::random_match_threshold (derandomize.rs:127-145). */
+int kbo_log_rm_max_cdf(size_t t, size_t alphabet_size, size_t n_kmers, double *out);
+int kbo_random_match_threshold(size_t k, size_t n_kmers, size_t alphabet_size,
+                               double max_error_prob, size_t *out);
+
+/* ------------------------------------------------------------------ single-sequence
+ * parity entry points with the reference's element widths (host pointers). */
+
+/* index::query_sbwt -> Vec<(usize, Range<usize>)> (index.rs:243-256).
+ * d/lo/hi each hold len elements; lo/hi may both be NULL. */
+int kbo_matching_statistics(kbo_index_t *idx, const uint8_t *query, size_t len, uint64_t *d,
+                            uint64_t *lo, uint64_t *hi);
+/* derandomize::derandomize_ms_vec (derandomize.rs:269-288). */
+int kbo_derandomize_ms_vec(const uint64_t *noisy_ms, size_t len, size_t k, size_t threshold,
+                           int64_t *out);
+/* derandomize::derandomize_ms_val (derandomize.rs:221-247) — scalar, host. */
+int kbo_derandomize_ms_val(size_t curr_noisy_ms, int64_t next_derand_ms, size_t threshold,
+                           size_t k, int64_t *out);
+/* translate::translate_ms_vec (translate.rs:263-293); chars as Rust `char` (u32). */
+int kbo_translate_ms_vec(const int64_t *derand_ms, size_t len, size_t k, size_t threshold,
+                         uint32_t *out);
+/* translate::translate_ms_val (translate.rs:180-216) — scalar, host. */
+int kbo_translate_ms_val(int64_t ms_curr, int64_t ms_next, int64_t ms_prev, size_t threshold,
+                         uint32_t *aln_curr, uint32_t *aln_next);
+/* kbo::matches (lib.rs:612-628): chars as Rust `char` (u32), len elements. */
+int kbo_matches(kbo_index_t *idx, const uint8_t *query, size_t len, double max_error_prob,
+                uint32_t *chars_out);
+/* kbo::map (lib.rs:720-761): out holds len bytes. */
+int kbo_map(kbo_index_t *query_idx, const uint8_t *ref_seq, size_t len, const kbo_map_opts *opts,
+            uint8_t *out);
+/* kbo::find (lib.rs:808-821): *out is allocated by the library (kbo_free). */
+int kbo_find(kbo_index_t *idx, const uint8_t *query, size_t len, const kbo_find_opts *opts,
+             kbo_rle **out, size_t *n_out);
+/* format::run_lengths_gapped (format.rs:143-193) and relative_to_ref (format.rs:266-287)
+ * on byte-wide alignment strings (host; sequential variable-length output). */
+int kbo_run_lengths_gapped(const uint8_t *aln, size_t len, size_t max_gap_len, kbo_rle **out,
+                           size_t *n_out);
+int kbo_relative_to_ref(const uint8_t *ref_seq, const uint8_t *aln, size_t len, uint8_t *out);
+void kbo_free(void *p);
+
+/* ------------------------------------------------------------------ batched entry points
+ * (new surface: the reference takes ONE sequence per call, lib.rs:612-617; batching over
+ * reads/contigs lives in kbo-cli).  `concat` holds all sequences back to back,
+ * offsets[i]..offsets[i+1] delimits sequence i (n_seqs+1 entries).  Compact element
+ * widths: d as u8 (d <= k <= 255), intervals as u32 (n_sets < 2^32), chars as u8. */
+int kbo_ms_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                 uint8_t *d_out, uint32_t *lo_out, uint32_t *hi_out);
+int kbo_matches_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offsets,
+                      size_t n_seqs, double max_error_prob, uint8_t *chars_out);
+/* map with fill_gaps=false, call_variants=false (lib.rs:735-738, 756-760) over a batch. */
+int kbo_map_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                  double max_error_prob, int format, uint8_t *out);
+/* find over a batch: RLEs of all sequences concatenated, rle_offsets[i]..[i+1] = sequence i
+ * (rle_offsets has n_seqs+1 entries, caller-allocated; *rles library-allocated). */
+int kbo_find_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                   const kbo_find_opts *opts, kbo_rle **rles, uint64_t *rle_offsets);
+
+/* ------------------------------------------------------------------ device-resident path
+ * Everything already in the HBM of the current device; kernels are enqueued on `stream`
+ * (a hipStream_t) and the call returns immediately.  d_concat must be 16-byte aligned,
+ * the other buffers 4-byte aligned; sequences shorter than 3 are skipped by the fused
+ * derandomize/translate kernel (the host entry points reject them like the reference).
+ * d_work is device scratch of at least kbo_work_bytes(n_seqs) bytes (16-byte aligned). */
+size_t kbo_work_bytes(size_t n_seqs);
+/* A1 over a batch: one work item per sequence (no chunking; meant for reads).
+ * total_bases = offsets[n_seqs] (known to the caller; avoids a device read-back). */
+int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets,
+                     size_t n_seqs, uint64_t total_bases, uint8_t *d_ms_out, uint32_t *d_lo_out,
+                     uint32_t *d_hi_out, void *d_work, void *stream);
+/* A5+A6 fused (+ optional format::relative_to_ref when d_ref != NULL): u8 MS -> u8 chars. */
+int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, size_t n_seqs,
+                             size_t k, size_t threshold, const uint8_t *d_ref, uint8_t *d_chars_out,
+                             void *stream);
+/* Kernel launch geometry used by the walk (persistent lanes): blocks x threads. */
+int kbo_walk_geometry(int *blocks, int *threads);
+int kbo_set_walk_blocks_per_cu(int blocks_per_cu); /* tuning knob, 0 = default */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KBO_HIP_H */

@@ -1,0 +1,130 @@
+"""ctypes loader for kbo_amd/libkbo_hip.so (the C ABI in include/kbo_hip.h).
+
+The product path has no CPU fallback: if the shared library (and, for compute
+calls, a gfx950 device) is missing, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkbo_hip.so")
+
+KBO_OK = 0
+ERROR_NAMES = {
+    -1: "KBO_E_EMPTY_QUERY", -2: "KBO_E_LEN_LE_2", -3: "KBO_E_THRESHOLD_LE_1", -4: "KBO_E_BAD_ARG",
+    -5: "KBO_E_NOMEM", -6: "KBO_E_K_MISMATCH", -7: "KBO_E_HIP", -8: "KBO_E_UNSUPPORTED",
+    -9: "KBO_E_MS_RANGE", -10: "KBO_E_IO",
+}
+
+
+class KboError(AssertionError):
+    """A reference assert!/panic! site (or a HIP failure) reported through the C ABI."""
+
+    def __init__(self, code, message):
+        super().__init__(f"{ERROR_NAMES.get(code, code)}: {message}")
+        self.code = code
+        self.message = message
+
+
+class BuildOpts(C.Structure):
+    """kbo::BuildOpts (lib.rs:259-313)."""
+    _fields_ = [("k", C.c_uint32), ("add_revcomp", C.c_int32), ("num_threads", C.c_uint32),
+                ("prefix_precalc", C.c_uint32), ("build_select", C.c_int32), ("mem_gb", C.c_uint32),
+                ("dedup_batches", C.c_int32), ("temp_dir", C.c_char_p)]
+
+
+class FindOpts(C.Structure):
+    """kbo::FindOpts (lib.rs:358-382)."""
+    _fields_ = [("max_error_prob", C.c_double), ("max_gap_len", C.c_size_t)]
+
+
+class MapOpts(C.Structure):
+    """kbo::MapOpts (lib.rs:412-466)."""
+    _fields_ = [("max_error_prob", C.c_double), ("fill_gaps", C.c_int32), ("call_variants", C.c_int32),
+                ("format", C.c_int32), ("sbwt_build_opts", BuildOpts)]
+
+
+class RLE(C.Structure):
+    """kbo::format::RLE (format.rs:18-33)."""
+    _fields_ = [(n, C.c_uint64) for n in
+                ("start", "end", "matches", "mismatches", "jumps", "gap_bases", "gap_opens")]
+
+    def as_tuple(self):
+        return tuple(int(getattr(self, n)) for n, _ in self._fields_)
+
+
+# every symbol include/kbo_hip.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "kbo_last_error", "kbo_version", "kbo_build_opts_default", "kbo_find_opts_default",
+    "kbo_map_opts_default", "kbo_index_build", "kbo_index_from_parts", "kbo_index_export_parts",
+    "kbo_index_free", "kbo_index_k", "kbo_index_n_kmers", "kbo_index_n_sets", "kbo_index_save",
+    "kbo_index_load", "kbo_index_to_device", "kbo_index_device_bytes", "kbo_log_rm_max_cdf",
+    "kbo_random_match_threshold", "kbo_matching_statistics", "kbo_derandomize_ms_vec",
+    "kbo_derandomize_ms_val", "kbo_translate_ms_vec", "kbo_translate_ms_val", "kbo_matches",
+    "kbo_map", "kbo_find", "kbo_run_lengths_gapped", "kbo_relative_to_ref", "kbo_free",
+    "kbo_ms_batch", "kbo_matches_batch", "kbo_map_batch", "kbo_find_batch", "kbo_work_bytes",
+    "kbo_ms_batch_dev", "kbo_derand_translate_dev", "kbo_walk_geometry",
+    "kbo_set_walk_blocks_per_cu",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libkbo_hip.so (raises if it has not been built: run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: the HIP extension has not been built "
+                           "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u64, u32, i64, dbl = C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_int64, C.c_double
+    L.kbo_last_error.restype = C.c_char_p
+    L.kbo_version.restype = C.c_char_p
+    L.kbo_build_opts_default.argtypes = [C.POINTER(BuildOpts)]
+    L.kbo_find_opts_default.argtypes = [C.POINTER(FindOpts)]
+    L.kbo_map_opts_default.argtypes = [C.POINTER(MapOpts)]
+    for f in (L.kbo_build_opts_default, L.kbo_find_opts_default, L.kbo_map_opts_default, L.kbo_index_free,
+              L.kbo_free):
+        f.restype = None
+    L.kbo_index_build.argtypes = [C.POINTER(C.c_char_p), C.POINTER(sz), sz, C.POINTER(BuildOpts), C.POINTER(vp)]
+    L.kbo_index_from_parts.argtypes = [u32, u64, u64, C.POINTER(vp), C.POINTER(u64), vp, C.POINTER(vp)]
+    L.kbo_index_export_parts.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), vp]
+    L.kbo_index_free.argtypes = [vp]
+    L.kbo_index_k.argtypes = [vp]; L.kbo_index_k.restype = sz
+    L.kbo_index_n_kmers.argtypes = [vp]; L.kbo_index_n_kmers.restype = u64
+    L.kbo_index_n_sets.argtypes = [vp]; L.kbo_index_n_sets.restype = u64
+    L.kbo_index_save.argtypes = [vp, C.c_char_p]
+    L.kbo_index_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.kbo_index_to_device.argtypes = [vp, C.c_int]
+    L.kbo_index_device_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.kbo_log_rm_max_cdf.argtypes = [sz, sz, sz, C.POINTER(dbl)]
+    L.kbo_random_match_threshold.argtypes = [sz, sz, sz, dbl, C.POINTER(sz)]
+    L.kbo_matching_statistics.argtypes = [vp, vp, sz, vp, vp, vp]
+    L.kbo_derandomize_ms_vec.argtypes = [vp, sz, sz, sz, vp]
+    L.kbo_derandomize_ms_val.argtypes = [sz, i64, sz, sz, C.POINTER(i64)]
+    L.kbo_translate_ms_vec.argtypes = [vp, sz, sz, sz, vp]
+    L.kbo_translate_ms_val.argtypes = [i64, i64, i64, sz, C.POINTER(u32), C.POINTER(u32)]
+    L.kbo_matches.argtypes = [vp, vp, sz, dbl, vp]
+    L.kbo_map.argtypes = [vp, vp, sz, C.POINTER(MapOpts), vp]
+    L.kbo_find.argtypes = [vp, vp, sz, C.POINTER(FindOpts), C.POINTER(C.POINTER(RLE)), C.POINTER(sz)]
+    L.kbo_run_lengths_gapped.argtypes = [vp, sz, sz, C.POINTER(C.POINTER(RLE)), C.POINTER(sz)]
+    L.kbo_relative_to_ref.argtypes = [vp, vp, sz, vp]
+    L.kbo_free.argtypes = [vp]
+    L.kbo_ms_batch.argtypes = [vp, vp, vp, sz, vp, vp, vp]
+    L.kbo_matches_batch.argtypes = [vp, vp, vp, sz, dbl, vp]
+    L.kbo_map_batch.argtypes = [vp, vp, vp, sz, dbl, C.c_int, vp]
+    L.kbo_find_batch.argtypes = [vp, vp, vp, sz, C.POINTER(FindOpts), C.POINTER(C.POINTER(RLE)), vp]
+    L.kbo_work_bytes.argtypes = [sz]; L.kbo_work_bytes.restype = sz
+    L.kbo_ms_batch_dev.argtypes = [vp, vp, vp, sz, u64, vp, vp, vp, vp, vp]
+    L.kbo_derand_translate_dev.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp]
+    L.kbo_walk_geometry.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.kbo_set_walk_blocks_per_cu.argtypes = [C.c_int]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != KBO_OK:
+        raise KboError(rc, lib().kbo_last_error().decode(errors="replace"))

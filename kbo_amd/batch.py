@@ -1,0 +1,109 @@
+"""Batched and device-resident entry points (new surface; the reference API takes one
+sequence per call, lib.rs:612-617, and leaves batching to kbo-cli)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi, derandomize
+from ._capi import check, lib
+
+
+def _prep(concat, offsets):
+    concat = np.ascontiguousarray(concat, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    return concat, offsets, len(offsets) - 1
+
+
+def ms_batch(sbwt, concat, offsets, want_intervals=False):
+    """kbo_ms_batch -> (d uint8, lo uint32 | None, hi uint32 | None)"""
+    concat, offsets, n = _prep(concat, offsets)
+    total = int(offsets[-1]) if n > 0 else 0
+    d = np.zeros(max(total, 1), dtype=np.uint8)
+    lo = np.zeros(max(total, 1), dtype=np.uint32) if want_intervals else None
+    hi = np.zeros(max(total, 1), dtype=np.uint32) if want_intervals else None
+    check(lib().kbo_ms_batch(sbwt._h, concat.ctypes.data, offsets.ctypes.data, n, d.ctypes.data,
+                             lo.ctypes.data if want_intervals else None,
+                             hi.ctypes.data if want_intervals else None))
+    return d[:total], (lo[:total] if want_intervals else None), (hi[:total] if want_intervals else None)
+
+
+def matches_batch(sbwt, concat, offsets, max_error_prob=1e-7):
+    """kbo::matches over every sequence of the batch -> uint8 chars"""
+    concat, offsets, n = _prep(concat, offsets)
+    total = int(offsets[-1]) if n > 0 else 0
+    out = np.zeros(max(total, 1), dtype=np.uint8)
+    check(lib().kbo_matches_batch(sbwt._h, concat.ctypes.data, offsets.ctypes.data, n, max_error_prob,
+                                  out.ctypes.data))
+    return out[:total]
+
+
+def map_batch(sbwt, concat, offsets, max_error_prob=1e-7, format=True):  # noqa: A002
+    """kbo::map with fill_gaps=false, call_variants=false over the batch -> uint8"""
+    concat, offsets, n = _prep(concat, offsets)
+    total = int(offsets[-1]) if n > 0 else 0
+    out = np.zeros(max(total, 1), dtype=np.uint8)
+    check(lib().kbo_map_batch(sbwt._h, concat.ctypes.data, offsets.ctypes.data, n, max_error_prob,
+                              int(format), out.ctypes.data))
+    return out[:total]
+
+
+def find_batch(sbwt, concat, offsets, find_opts=None):
+    """kbo::find over the batch -> (list of RLE tuples, rle_offsets uint64[n+1])"""
+    from . import FindOpts
+    o = find_opts if find_opts is not None else FindOpts()
+    co = _capi.FindOpts(o.max_error_prob, o.max_gap_len)
+    concat, offsets, n = _prep(concat, offsets)
+    ro = np.zeros(n + 1, dtype=np.uint64)
+    p = C.POINTER(_capi.RLE)()
+    check(lib().kbo_find_batch(sbwt._h, concat.ctypes.data, offsets.ctypes.data, n, C.byref(co),
+                               C.byref(p), ro.ctypes.data))
+    rles = [p[i].as_tuple() for i in range(int(ro[-1]))]
+    lib().kbo_free(p)
+    return rles, ro
+
+
+class DeviceBatch:
+    """A batch of reads resident in HBM (torch owns the memory, the C ABI gets raw
+    pointers and the torch stream).  run() = A1 walk kernel, then fused A5+A6 kernel."""
+
+    def __init__(self, sbwt, concat, offsets, device, max_error_prob=1e-7, want_intervals=False,
+                 format=False):  # noqa: A002
+        import torch
+        self.torch = torch
+        self.sbwt = sbwt
+        self.device = device
+        concat, offsets, n = _prep(concat, offsets)
+        self.n_seqs = n
+        self.total = int(offsets[-1])
+        self.k = sbwt.k()
+        self.threshold = derandomize.random_match_threshold(self.k, sbwt.n_kmers(), 4, max_error_prob)
+        pad = (self.total + 15) // 16 * 16 + 16
+        with torch.cuda.device(device):
+            sbwt.to_device(-1)
+            self.q = torch.zeros(pad, dtype=torch.uint8, device=device)
+            self.q[:self.total] = torch.from_numpy(concat).to(device)
+            self.off = torch.from_numpy(offsets.view(np.int64)).to(device)
+            self.ms = torch.zeros(pad, dtype=torch.uint8, device=device)
+            self.chars = torch.zeros(pad, dtype=torch.uint8, device=device)
+            self.work = torch.zeros(lib().kbo_work_bytes(n) // 8 + 2, dtype=torch.int64, device=device)
+            self.lo = torch.zeros(self.total, dtype=torch.int32, device=device) if want_intervals else None
+            self.hi = torch.zeros(self.total, dtype=torch.int32, device=device) if want_intervals else None
+        self.format = format
+
+    def walk(self, stream=None):
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        check(lib().kbo_ms_batch_dev(self.sbwt._h, self.q.data_ptr(), self.off.data_ptr(), self.n_seqs,
+                                     self.total, self.ms.data_ptr(),
+                                     self.lo.data_ptr() if self.lo is not None else None,
+                                     self.hi.data_ptr() if self.hi is not None else None,
+                                     self.work.data_ptr(), s.cuda_stream))
+
+    def derand_translate(self, stream=None):
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        check(lib().kbo_derand_translate_dev(self.ms.data_ptr(), self.off.data_ptr(), self.n_seqs, self.k,
+                                             self.threshold, self.q.data_ptr() if self.format else None,
+                                             self.chars.data_ptr(), s.cuda_stream))
+
+    def run(self, stream=None):
+        self.walk(stream)
+        self.derand_translate(stream)

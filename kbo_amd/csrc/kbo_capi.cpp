@@ -1,0 +1,797 @@
+// kbo_capi.cpp — the extern "C" boundary declared in include/kbo_hip.h.
+//
+// Host logic only: argument checks mirroring the reference's asserts, index ownership,
+// device-memory plumbing and kernel launches.  All matching-statistics / derandomize /
+// translate compute happens in ms_kernels.hip; nothing here falls back to the CPU.
+#include "../../include/kbo_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "sbwt_index.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+struct KboError : std::runtime_error {
+    int code;
+    KboError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define KBO_REQUIRE(cond, code, msg)                                                              \
+    do {                                                                                          \
+        if (!(cond)) throw KboError((code), (msg));                                               \
+    } while (0)
+
+#define HIP_OK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess)                                                                    \
+            throw KboError(KBO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));        \
+    } while (0)
+
+template <typename F> int guarded(F f)
+{
+    try {
+        f();
+        return KBO_OK;
+    } catch (const KboError &e) {
+        g_err = e.what();
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        g_err = "out of host memory";
+        return KBO_E_NOMEM;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return KBO_E_BAD_ARG;
+    }
+}
+
+// RAII device buffer
+struct DevBuf {
+    void *p = nullptr;
+    DevBuf() = default;
+    explicit DevBuf(size_t bytes) { alloc(bytes); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    void alloc(size_t bytes)
+    {
+        release();
+        hipError_t e = hipMalloc(&p, std::max<size_t>(bytes, 16));
+        if (e != hipSuccess) {
+            p = nullptr;
+            throw KboError(e == hipErrorOutOfMemory ? KBO_E_NOMEM : KBO_E_HIP,
+                           std::string("hipMalloc: ") + hipGetErrorString(e));
+        }
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    ~DevBuf() { release(); }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct DevCopy {
+    DevBuf rank, lcs;
+    uint64_t n_blocks = 0;
+};
+
+int g_blocks_per_cu = 0;
+
+int current_device()
+{
+    int dev = -1;
+    HIP_OK(hipGetDevice(&dev));
+    return dev;
+}
+
+} // namespace
+
+struct kbo_index {
+    kbo::HostIndex host;
+    std::mutex mu;
+    std::map<int, DevCopy *> dev;
+    uint64_t rank_bytes = 0, lcs_bytes = 0;
+    ~kbo_index()
+    {
+        for (auto &kv : dev) delete kv.second;
+    }
+};
+
+namespace {
+
+kbo::DevIndexView device_view(kbo_index *idx, int device)
+{
+    std::lock_guard<std::mutex> g(idx->mu);
+    auto it = idx->dev.find(device);
+    if (it == idx->dev.end()) {
+        KBO_REQUIRE(idx->host.n_sets < 0xFFFFFFF0ull, KBO_E_UNSUPPORTED,
+                    "n_sets >= 2^32: 64-bit device layout not built yet");
+        kbo::DeviceLayout lay;
+        kbo::make_device_layout(idx->host, lay);
+        int prev = current_device();
+        if (prev != device) HIP_OK(hipSetDevice(device));
+        DevCopy *dc = new DevCopy();
+        try {
+            const size_t per = lay.n_blocks * 16;
+            dc->rank.alloc(per * 4);
+            for (int c = 0; c < 4; c++)
+                HIP_OK(hipMemcpy(dc->rank.as<uint8_t>() + per * c, lay.rank[c].data(), per,
+                                 hipMemcpyHostToDevice));
+            dc->lcs.alloc(lay.lcs.size());
+            HIP_OK(hipMemcpy(dc->lcs.p, lay.lcs.data(), lay.lcs.size(), hipMemcpyHostToDevice));
+            dc->n_blocks = lay.n_blocks;
+            idx->rank_bytes = per * 4;
+            idx->lcs_bytes = lay.lcs.size();
+        } catch (...) {
+            delete dc;
+            if (prev != device) (void)hipSetDevice(prev);
+            throw;
+        }
+        if (prev != device) HIP_OK(hipSetDevice(prev));
+        it = idx->dev.emplace(device, dc).first;
+    }
+    DevCopy *dc = it->second;
+    kbo::DevIndexView v;
+    v.rank = dc->rank.as<uint4>();
+    v.n_blocks = (uint32_t)dc->n_blocks;
+    v.lcs16 = dc->lcs.as<uint4>();
+    v.n = (uint32_t)idx->host.n_sets;
+    v.k = idx->host.k;
+    return v;
+}
+
+int walk_blocks()
+{
+    int dev = current_device();
+    int cus = 0;
+    HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int per = g_blocks_per_cu > 0 ? g_blocks_per_cu : 8;
+    return std::max(1, cus) * per;
+}
+
+// ---- A3: derandomize.rs:91-145, f64, identical operation order -------------------------
+double powi_f64(double a, int b) // Rust f64::powi == llvm.powi == compiler-rt __powidf2
+{
+    const bool recip = b < 0;
+    double r = 1;
+    for (;;) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return recip ? 1 / r : r;
+}
+
+double log_rm_max_cdf(size_t t, size_t alphabet_size, size_t n_kmers)
+{
+    KBO_REQUIRE(n_kmers > 0, KBO_E_BAD_ARG, "n_kmers > 0 (derandomize.rs:96)");
+    KBO_REQUIRE(alphabet_size > 0, KBO_E_BAD_ARG, "alphabet_size > 0 (derandomize.rs:97)");
+    return (double)n_kmers *
+           std::log1p(-powi_f64(std::exp(std::log(1.0) - std::log((double)alphabet_size)), (int)t + 1));
+}
+
+size_t random_match_threshold(size_t k, size_t n_kmers, size_t alphabet_size, double p)
+{
+    KBO_REQUIRE(k > 0, KBO_E_BAD_ARG, "k > 0 (derandomize.rs:133)");
+    KBO_REQUIRE(n_kmers > 0, KBO_E_BAD_ARG, "n_kmers > 0 (derandomize.rs:134)");
+    KBO_REQUIRE(alphabet_size > 0, KBO_E_BAD_ARG, "alphabet_size > 0 (derandomize.rs:135)");
+    KBO_REQUIRE(p <= 1.0 && p > 0.0, KBO_E_BAD_ARG, "0 < max_error_prob <= 1 (derandomize.rs:136-137)");
+    for (size_t i = 1; i < k; i++)
+        if (log_rm_max_cdf(i, alphabet_size, n_kmers) > std::log1p(-p)) return i;
+    return k;
+}
+
+// ---- work decomposition ------------------------------------------------------------------
+// Reads become one item each.  Longer sequences are cut into chunks that restart the walk
+// k-1 bases upstream from the empty state (MS depends only on the last k bases).
+void make_items_host(const uint64_t *offsets, size_t n_seqs, uint32_t k, std::vector<kbo::WalkItem> &items)
+{
+    const uint64_t total = offsets[n_seqs] - offsets[0];
+    // aim for >= ~1M items when the input allows it, chunks of 128..4096 emitted bases
+    uint64_t chunk = std::min<uint64_t>(4096, std::max<uint64_t>(128, total >> 20));
+    chunk = std::max<uint64_t>(chunk, 4ull * k);
+    items.clear();
+    for (size_t s = 0; s < n_seqs; s++) {
+        const uint64_t b = offsets[s], e = offsets[s + 1];
+        for (uint64_t c0 = b; c0 < e; c0 += chunk) {
+            const uint64_t c1 = std::min(e, c0 + chunk);
+            const uint64_t warm = std::min<uint64_t>(c0 - b, k > 0 ? k - 1 : 0);
+            kbo::WalkItem it;
+            it.start = c0 - warm;
+            it.len = (uint32_t)(c1 - c0 + warm);
+            it.warm = (uint32_t)warm;
+            items.push_back(it);
+        }
+    }
+}
+
+void check_batch(const void *concat, const uint64_t *offsets, size_t n_seqs)
+{
+    KBO_REQUIRE(concat && offsets, KBO_E_BAD_ARG, "null concat/offsets");
+    KBO_REQUIRE(n_seqs > 0, KBO_E_EMPTY_QUERY, "no sequences");
+    KBO_REQUIRE(n_seqs < 0xFFFFFFFFull, KBO_E_UNSUPPORTED, "more than 2^32-1 sequences per call");
+    for (size_t s = 0; s < n_seqs; s++) {
+        KBO_REQUIRE(offsets[s + 1] >= offsets[s], KBO_E_BAD_ARG, "offsets not monotone");
+        KBO_REQUIRE(offsets[s + 1] > offsets[s], KBO_E_EMPTY_QUERY,
+                    "empty query (index.rs:248 assert!(!query.is_empty()))");
+        KBO_REQUIRE(offsets[s + 1] - offsets[s] < 0xFFFFFFFFull, KBO_E_UNSUPPORTED,
+                    "sequence longer than 2^32-1");
+    }
+    KBO_REQUIRE(offsets[0] == 0, KBO_E_BAD_ARG, "offsets[0] must be 0");
+}
+
+struct BatchOnDevice {
+    DevBuf q, off, items, ms, lo, hi;
+    uint64_t total = 0;
+};
+
+// upload + A1 over a host batch; leaves ms (and lo/hi) on the device
+void run_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                   bool want_ival, BatchOnDevice &B, hipStream_t stream)
+{
+    check_batch(concat, offsets, n_seqs);
+    KBO_REQUIRE(idx->host.k <= 255, KBO_E_UNSUPPORTED, "k > 255");
+    const int dev = current_device();
+    kbo::DevIndexView view = device_view(idx, dev);
+    const uint64_t total = offsets[n_seqs];
+    B.total = total;
+    std::vector<kbo::WalkItem> items;
+    make_items_host(offsets, n_seqs, idx->host.k, items);
+    KBO_REQUIRE(items.size() < 0xFFFFFFFFull, KBO_E_UNSUPPORTED, "too many work items");
+
+    const size_t padded = ((total + 15) / 16) * 16 + 16;
+    B.q.alloc(padded);
+    B.off.alloc((n_seqs + 1) * sizeof(uint64_t));
+    B.items.alloc(items.size() * sizeof(kbo::WalkItem));
+    B.ms.alloc(padded);
+    if (want_ival) {
+        B.lo.alloc(total * sizeof(uint32_t));
+        B.hi.alloc(total * sizeof(uint32_t));
+    }
+    HIP_OK(hipMemcpyAsync(B.q.p, concat, total, hipMemcpyHostToDevice, stream));
+    HIP_OK(hipMemcpyAsync(B.off.p, offsets, (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    HIP_OK(hipMemcpyAsync(B.items.p, items.data(), items.size() * sizeof(kbo::WalkItem),
+                          hipMemcpyHostToDevice, stream));
+    kbo::WalkArgs a;
+    a.ix = view;
+    a.q = B.q.as<uint8_t>();
+    a.q_bytes = total;
+    a.items = B.items.as<kbo::WalkItem>();
+    a.n_items = (uint32_t)items.size();
+    a.d_out = B.ms.as<uint8_t>();
+    a.lo_out = want_ival ? B.lo.as<uint32_t>() : nullptr;
+    a.hi_out = want_ival ? B.hi.as<uint32_t>() : nullptr;
+    HIP_OK(kbo::launch_ms_walk(a, walk_blocks(), stream));
+    // the items vector must outlive the async copy
+    HIP_OK(hipStreamSynchronize(stream));
+}
+
+void check_len_threshold(const uint64_t *offsets, size_t n_seqs, size_t k, size_t threshold)
+{
+    KBO_REQUIRE(k > 0, KBO_E_BAD_ARG, "k > 0 (derandomize.rs:274)");
+    KBO_REQUIRE(threshold > 1, KBO_E_THRESHOLD_LE_1, "threshold > 1 (derandomize.rs:275, translate.rs:269)");
+    for (size_t s = 0; s < n_seqs; s++)
+        KBO_REQUIRE(offsets[s + 1] - offsets[s] > 2, KBO_E_LEN_LE_2,
+                    "len > 2 (derandomize.rs:276, translate.rs:270)");
+}
+
+// kbo::matches over a batch (lib.rs:618-627); optional relative_to_ref (lib.rs:756-757)
+void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                        double max_error_prob, bool format, uint8_t *chars_out)
+{
+    KBO_REQUIRE(idx && chars_out, KBO_E_BAD_ARG, "null argument");
+    const size_t k = idx->host.k;
+    const size_t threshold = random_match_threshold(k, idx->host.n_kmers, 4, max_error_prob); // lib.rs:620
+    check_batch(concat, offsets, n_seqs);
+    check_len_threshold(offsets, n_seqs, k, threshold);
+    hipStream_t stream = nullptr;
+    BatchOnDevice B;
+    run_walk_host(idx, concat, offsets, n_seqs, false, B, stream);
+    DevBuf chars(((B.total + 15) / 16) * 16 + 16);
+    HIP_OK(kbo::launch_derand_translate(B.ms.as<uint8_t>(), B.off.as<uint64_t>(), (uint32_t)n_seqs,
+                                        (uint32_t)k, (uint32_t)threshold,
+                                        format ? B.q.as<uint8_t>() : nullptr, chars.as<uint8_t>(), nullptr,
+                                        stream));
+    HIP_OK(hipMemcpyAsync(chars_out, chars.p, B.total, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+}
+
+// format.rs:143-193, statement for statement (sequential, variable-length output: host)
+void run_lengths_gapped_impl(const uint8_t *aln, size_t len, size_t max_gap_len, std::vector<kbo_rle> &out)
+{
+    size_t i = 0;
+    bool match_start = false;
+    while (i < len) {
+        match_start = (aln[i] != '-' && aln[i] != ' ') && !match_start;
+        if (match_start) {
+            kbo_rle rle{(uint64_t)i, 0, 0, 0, 0, 0, 0};
+            size_t within_gap_bases = 0;
+            bool within_gap_start = false;
+            while (i < len && aln[i] != ' ') {
+                const bool is_true_gap = aln[i] == '-';
+                if (is_true_gap && !within_gap_start) {
+                    within_gap_start = true;
+                    rle.gap_opens += 1;
+                    within_gap_bases = 0;
+                }
+                if (!is_true_gap && within_gap_start) within_gap_start = false;
+                const bool is_match = aln[i] == 'M' || aln[i] == 'R' || aln[i] == 'I';
+                const bool is_gap = is_true_gap || aln[i] == 'D';
+                rle.matches += is_match;
+                rle.gap_bases += is_gap;
+                rle.mismatches += (!is_match && !is_gap);
+                rle.end = (is_match || !is_gap) ? i + 1 : rle.end;
+                // the reference indexes aln[i - 1] unguarded (format.rs:175) and would panic
+                // on an 'R' at position 0; guarded here
+                rle.jumps += (aln[i] == 'R' && i > 0 && aln[i - 1] == 'R');
+                within_gap_bases += (aln[i] == '-');
+                i += 1;
+                if (within_gap_bases > max_gap_len || (is_gap && i == len && rle.gap_opens > 0)) {
+                    rle.gap_opens -= 1;
+                    rle.gap_bases -= within_gap_bases;
+                    break;
+                }
+            }
+            out.push_back(rle);
+            match_start = false;
+        } else {
+            i += 1;
+        }
+    }
+}
+
+kbo_rle *copy_rles(const std::vector<kbo_rle> &v)
+{
+    kbo_rle *p = static_cast<kbo_rle *>(std::malloc(std::max<size_t>(1, v.size()) * sizeof(kbo_rle)));
+    if (!p) throw std::bad_alloc();
+    if (!v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(kbo_rle));
+    return p;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *kbo_last_error(void) { return g_err.c_str(); }
+const char *kbo_version(void) { return "kbo-hip 0.1.0 (gfx950)"; }
+
+void kbo_build_opts_default(kbo_build_opts *o)
+{
+    if (!o) return;
+    o->k = 31; o->add_revcomp = 0; o->num_threads = 1; o->prefix_precalc = 8;
+    o->build_select = 0; o->mem_gb = 4; o->dedup_batches = 0; o->temp_dir = nullptr;
+}
+void kbo_find_opts_default(kbo_find_opts *o)
+{
+    if (!o) return;
+    o->max_error_prob = 0.0000001; o->max_gap_len = 0;
+}
+void kbo_map_opts_default(kbo_map_opts *o)
+{
+    if (!o) return;
+    o->max_error_prob = 0.0000001; o->fill_gaps = 1; o->call_variants = 1; o->format = 1;
+    kbo_build_opts_default(&o->sbwt_build_opts);
+    o->sbwt_build_opts.build_select = 1;
+}
+
+int kbo_index_build(const uint8_t *const *seqs, const size_t *lens, size_t n_seqs,
+                    const kbo_build_opts *opts, kbo_index_t **out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(out, KBO_E_BAD_ARG, "null out");
+        *out = nullptr;
+        KBO_REQUIRE(seqs && lens && n_seqs > 0, KBO_E_BAD_ARG, "assert!(!slices.is_empty()) (index.rs:60)");
+        kbo_build_opts o;
+        if (opts) o = *opts; else kbo_build_opts_default(&o);
+        kbo::BuildParams p;
+        p.k = o.k; p.add_revcomp = o.add_revcomp != 0; p.num_threads = std::max(1u, o.num_threads);
+        kbo_index *idx = new kbo_index();
+        try {
+            kbo::build_host_index(seqs, lens, n_seqs, p, idx->host);
+        } catch (...) {
+            delete idx;
+            throw;
+        }
+        *out = idx;
+    });
+}
+
+int kbo_index_from_parts(uint32_t k, uint64_t n_sets, uint64_t n_kmers, const uint64_t *const rows[4],
+                         const uint64_t C[4], const uint8_t *lcs, kbo_index_t **out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(out, KBO_E_BAD_ARG, "null out");
+        *out = nullptr;
+        KBO_REQUIRE(rows && C && lcs && k > 0 && k <= 255 && n_sets > 0, KBO_E_BAD_ARG, "bad index parts");
+        kbo_index *idx = new kbo_index();
+        idx->host.k = k; idx->host.n_sets = n_sets; idx->host.n_kmers = n_kmers;
+        const size_t nw = (n_sets + 63) / 64;
+        for (int c = 0; c < 4; c++) {
+            idx->host.C[c] = C[c];
+            idx->host.rows[c].assign(rows[c], rows[c] + nw);
+            if (n_sets & 63) idx->host.rows[c][nw - 1] &= (1ull << (n_sets & 63)) - 1;
+        }
+        idx->host.lcs.assign(lcs, lcs + n_sets);
+        idx->host.lcs[0] = 0;
+        *out = idx;
+    });
+}
+
+int kbo_index_export_parts(const kbo_index_t *idx, uint64_t *const rows[4], uint64_t C[4], uint8_t *lcs)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && rows && C && lcs, KBO_E_BAD_ARG, "null argument");
+        const size_t nw = (idx->host.n_sets + 63) / 64;
+        for (int c = 0; c < 4; c++) {
+            C[c] = idx->host.C[c];
+            std::memcpy(rows[c], idx->host.rows[c].data(), nw * sizeof(uint64_t));
+        }
+        std::memcpy(lcs, idx->host.lcs.data(), idx->host.n_sets);
+    });
+}
+
+void kbo_index_free(kbo_index_t *idx) { delete idx; }
+size_t kbo_index_k(const kbo_index_t *idx) { return idx ? idx->host.k : 0; }
+uint64_t kbo_index_n_kmers(const kbo_index_t *idx) { return idx ? idx->host.n_kmers : 0; }
+uint64_t kbo_index_n_sets(const kbo_index_t *idx) { return idx ? idx->host.n_sets : 0; }
+
+int kbo_index_save(const kbo_index_t *idx, const char *path)
+{
+    int rc = guarded([&] {
+        KBO_REQUIRE(idx && path, KBO_E_BAD_ARG, "null argument");
+        kbo::save_host_index(idx->host, path);
+    });
+    return rc == KBO_E_BAD_ARG && idx && path ? KBO_E_IO : rc;
+}
+
+int kbo_index_load(const char *path, kbo_index_t **out)
+{
+    int rc = guarded([&] {
+        KBO_REQUIRE(path && out, KBO_E_BAD_ARG, "null argument");
+        *out = nullptr;
+        kbo_index *idx = new kbo_index();
+        try {
+            kbo::load_host_index(path, idx->host);
+        } catch (...) {
+            delete idx;
+            throw;
+        }
+        *out = idx;
+    });
+    return rc == KBO_E_BAD_ARG && path && out ? KBO_E_IO : rc;
+}
+
+int kbo_index_to_device(kbo_index_t *idx, int device)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx, KBO_E_BAD_ARG, "null index");
+        (void)device_view(idx, device < 0 ? current_device() : device);
+    });
+}
+
+int kbo_index_device_bytes(const kbo_index_t *idx, uint64_t *rank_bytes, uint64_t *lcs_bytes)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx, KBO_E_BAD_ARG, "null index");
+        const uint64_t nb = idx->host.n_sets / kbo::kRankRowsPerBlock + 2;
+        if (rank_bytes) *rank_bytes = nb * 16 * 4;
+        if (lcs_bytes) *lcs_bytes = ((idx->host.n_sets + 1 + 15) / 16) * 16 + 16;
+    });
+}
+
+int kbo_log_rm_max_cdf(size_t t, size_t alphabet_size, size_t n_kmers, double *out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(out, KBO_E_BAD_ARG, "null out");
+        *out = log_rm_max_cdf(t, alphabet_size, n_kmers);
+    });
+}
+
+int kbo_random_match_threshold(size_t k, size_t n_kmers, size_t alphabet_size, double max_error_prob,
+                               size_t *out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(out, KBO_E_BAD_ARG, "null out");
+        *out = random_match_threshold(k, n_kmers, alphabet_size, max_error_prob);
+    });
+}
+
+int kbo_ms_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                 uint8_t *d_out, uint32_t *lo_out, uint32_t *hi_out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && d_out, KBO_E_BAD_ARG, "null argument");
+        KBO_REQUIRE((lo_out == nullptr) == (hi_out == nullptr), KBO_E_BAD_ARG, "lo/hi must come together");
+        hipStream_t stream = nullptr;
+        BatchOnDevice B;
+        run_walk_host(idx, concat, offsets, n_seqs, lo_out != nullptr, B, stream);
+        HIP_OK(hipMemcpyAsync(d_out, B.ms.p, B.total, hipMemcpyDeviceToHost, stream));
+        if (lo_out) {
+            HIP_OK(hipMemcpyAsync(lo_out, B.lo.p, B.total * 4, hipMemcpyDeviceToHost, stream));
+            HIP_OK(hipMemcpyAsync(hi_out, B.hi.p, B.total * 4, hipMemcpyDeviceToHost, stream));
+        }
+        HIP_OK(hipStreamSynchronize(stream));
+    });
+}
+
+int kbo_matching_statistics(kbo_index_t *idx, const uint8_t *query, size_t len, uint64_t *d, uint64_t *lo,
+                            uint64_t *hi)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && query && d, KBO_E_BAD_ARG, "null argument");
+        KBO_REQUIRE(len > 0, KBO_E_EMPTY_QUERY, "assert!(!query.is_empty()) (index.rs:248)");
+        KBO_REQUIRE((lo == nullptr) == (hi == nullptr), KBO_E_BAD_ARG, "lo/hi must come together");
+        const uint64_t off[2] = {0, len};
+        std::vector<uint8_t> d8(len);
+        std::vector<uint32_t> lo32, hi32;
+        if (lo) { lo32.resize(len); hi32.resize(len); }
+        int rc = kbo_ms_batch(idx, query, off, 1, d8.data(), lo ? lo32.data() : nullptr,
+                              lo ? hi32.data() : nullptr);
+        if (rc) throw KboError(rc, g_err);
+        for (size_t i = 0; i < len; i++) d[i] = d8[i]; // widen to the reference's usize
+        if (lo)
+            for (size_t i = 0; i < len; i++) { lo[i] = lo32[i]; hi[i] = hi32[i]; }
+    });
+}
+
+int kbo_derandomize_ms_val(size_t curr, int64_t next, size_t threshold, size_t k, int64_t *out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(out, KBO_E_BAD_ARG, "null out");
+        KBO_REQUIRE(k > 0, KBO_E_BAD_ARG, "k > 0 (derandomize.rs:227)");
+        KBO_REQUIRE(threshold > 1, KBO_E_THRESHOLD_LE_1, "threshold > 1 (derandomize.rs:228)");
+        KBO_REQUIRE(curr <= k, KBO_E_MS_RANGE, "curr_noisy_ms <= k (derandomize.rs:229)");
+        KBO_REQUIRE(next <= (int64_t)k, KBO_E_MS_RANGE, "next_derand_ms <= k (derandomize.rs:230)");
+        int64_t run = next - 1;
+        if (curr == k) run = (int64_t)k;
+        if (curr > threshold && next < (int64_t)curr) run = (int64_t)curr;
+        *out = run;
+    });
+}
+
+int kbo_derandomize_ms_vec(const uint64_t *noisy, size_t len, size_t k, size_t threshold, int64_t *out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(noisy && out, KBO_E_BAD_ARG, "null argument");
+        KBO_REQUIRE(k > 0, KBO_E_BAD_ARG, "k > 0 (derandomize.rs:274)");
+        KBO_REQUIRE(threshold > 1, KBO_E_THRESHOLD_LE_1, "threshold > 1 (derandomize.rs:275)");
+        KBO_REQUIRE(len > 2, KBO_E_LEN_LE_2, "len > 2 (derandomize.rs:276)");
+        KBO_REQUIRE(k <= 255, KBO_E_UNSUPPORTED, "k > 255");
+        std::vector<uint8_t> n8(((len + 15) / 16) * 16 + 16, 0);
+        for (size_t i = 0; i < len; i++) {
+            KBO_REQUIRE(noisy[i] <= k, KBO_E_MS_RANGE, "curr_noisy_ms <= k (derandomize.rs:229)");
+            n8[i] = (uint8_t)noisy[i]; // narrow usize -> u8 (values <= k <= 255)
+        }
+        hipStream_t stream = nullptr;
+        const uint64_t off[2] = {0, len};
+        DevBuf dms(n8.size()), doff(sizeof(off)), dch(n8.size()), dder(len * sizeof(int32_t));
+        HIP_OK(hipMemcpyAsync(dms.p, n8.data(), n8.size(), hipMemcpyHostToDevice, stream));
+        HIP_OK(hipMemcpyAsync(doff.p, off, sizeof(off), hipMemcpyHostToDevice, stream));
+        HIP_OK(kbo::launch_derand_translate(dms.as<uint8_t>(), doff.as<uint64_t>(), 1, (uint32_t)k,
+                                            (uint32_t)std::min<size_t>(threshold, 0x7FFFFFFF), nullptr,
+                                            dch.as<uint8_t>(), dder.as<int32_t>(), stream));
+        std::vector<int32_t> d32(len);
+        HIP_OK(hipMemcpyAsync(d32.data(), dder.p, len * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        for (size_t i = 0; i < len; i++) out[i] = d32[i];
+    });
+}
+
+int kbo_translate_ms_val(int64_t curr, int64_t next, int64_t prev, size_t threshold, uint32_t *aln_curr,
+                         uint32_t *aln_next)
+{
+    return guarded([&] {
+        KBO_REQUIRE(aln_curr && aln_next, KBO_E_BAD_ARG, "null out");
+        KBO_REQUIRE(threshold > 1, KBO_E_THRESHOLD_LE_1, "threshold > 1 (translate.rs:186)");
+        *aln_next = ' ';
+        const int64_t t = (int64_t)threshold;
+        if (curr > t && next > 0 && next < t) { *aln_curr = 'R'; *aln_next = 'R'; }
+        else if (curr <= 0) *aln_curr = (next == 1 && prev > 0) ? 'X' : '-';
+        else *aln_curr = 'M';
+    });
+}
+
+int kbo_translate_ms_vec(const int64_t *derand, size_t len, size_t k, size_t threshold, uint32_t *out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(derand && out, KBO_E_BAD_ARG, "null argument");
+        KBO_REQUIRE(k > 0, KBO_E_BAD_ARG, "k > 0 (translate.rs:268)");
+        KBO_REQUIRE(threshold > 1, KBO_E_THRESHOLD_LE_1, "threshold > 1 (translate.rs:269)");
+        KBO_REQUIRE(len > 2, KBO_E_LEN_LE_2, "len > 2 (translate.rs:270)");
+        // the stencil only compares values with 0, 1, threshold and k: clamping i64 -> i32
+        // preserves every comparison as long as threshold and k fit in i32
+        const int64_t lim = 0x7FFFFFF0;
+        std::vector<int32_t> x(len);
+        for (size_t i = 0; i < len; i++) x[i] = (int32_t)std::max<int64_t>(-lim, std::min<int64_t>(lim, derand[i]));
+        const uint32_t t32 = (uint32_t)std::min<size_t>(threshold, (size_t)lim - 1);
+        const uint32_t k32 = (uint32_t)std::min<size_t>(k, (size_t)lim - 1);
+        hipStream_t stream = nullptr;
+        DevBuf dx(len * sizeof(int32_t)), dch(len);
+        HIP_OK(hipMemcpyAsync(dx.p, x.data(), len * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        HIP_OK(kbo::launch_translate(dx.as<int32_t>(), len, k32, t32, dch.as<uint8_t>(), stream));
+        std::vector<uint8_t> ch(len);
+        HIP_OK(hipMemcpyAsync(ch.data(), dch.p, len, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        for (size_t i = 0; i < len; i++) out[i] = ch[i]; // widen u8 -> Rust char
+    });
+}
+
+int kbo_matches_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                      double max_error_prob, uint8_t *chars_out)
+{
+    return guarded([&] { matches_batch_impl(idx, concat, offsets, n_seqs, max_error_prob, false, chars_out); });
+}
+
+int kbo_map_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                  double max_error_prob, int format, uint8_t *out)
+{
+    return guarded([&] { matches_batch_impl(idx, concat, offsets, n_seqs, max_error_prob, format != 0, out); });
+}
+
+int kbo_matches(kbo_index_t *idx, const uint8_t *query, size_t len, double max_error_prob, uint32_t *chars_out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && query && chars_out, KBO_E_BAD_ARG, "null argument");
+        KBO_REQUIRE(len > 0, KBO_E_EMPTY_QUERY, "assert!(!query.is_empty()) (index.rs:248)");
+        const uint64_t off[2] = {0, len};
+        std::vector<uint8_t> ch(len);
+        matches_batch_impl(idx, query, off, 1, max_error_prob, false, ch.data());
+        for (size_t i = 0; i < len; i++) chars_out[i] = ch[i];
+    });
+}
+
+int kbo_map(kbo_index_t *idx, const uint8_t *ref_seq, size_t len, const kbo_map_opts *opts, uint8_t *out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && ref_seq && out, KBO_E_BAD_ARG, "null argument");
+        kbo_map_opts o;
+        if (opts) o = *opts; else kbo_map_opts_default(&o);
+        if (o.call_variants)
+            KBO_REQUIRE(idx->host.k == o.sbwt_build_opts.k, KBO_E_K_MISMATCH,
+                        "assert!(sbwt.k() == map_opts.sbwt_build_opts.k) (lib.rs:729)");
+        KBO_REQUIRE(!o.fill_gaps && !o.call_variants, KBO_E_UNSUPPORTED,
+                    "map refinement (gap_filling::fill_gaps, call/add_variants) is outside the built hot path; "
+                    "set fill_gaps=0 and call_variants=0");
+        KBO_REQUIRE(len > 0, KBO_E_EMPTY_QUERY, "assert!(!query.is_empty()) (index.rs:248)");
+        const uint64_t off[2] = {0, len};
+        matches_batch_impl(idx, ref_seq, off, 1, o.max_error_prob, o.format != 0, out);
+    });
+}
+
+int kbo_run_lengths_gapped(const uint8_t *aln, size_t len, size_t max_gap_len, kbo_rle **out, size_t *n_out)
+{
+    return guarded([&] {
+        KBO_REQUIRE((aln || len == 0) && out && n_out, KBO_E_BAD_ARG, "null argument");
+        std::vector<kbo_rle> v;
+        run_lengths_gapped_impl(aln, len, max_gap_len, v);
+        *out = copy_rles(v);
+        *n_out = v.size();
+    });
+}
+
+int kbo_relative_to_ref(const uint8_t *ref_seq, const uint8_t *aln, size_t len, uint8_t *out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(ref_seq && aln && out, KBO_E_BAD_ARG, "null argument");
+        for (size_t i = 0; i < len; i++) { // format.rs:270-286
+            const uint8_t a = aln[i];
+            if (a == 'M' || a == 'R' || a == 'I') out[i] = ref_seq[i];
+            else if (a == 'X' || a == 'D') out[i] = '-';
+            else if (a != '-') out[i] = a;
+            else out[i] = '-';
+        }
+    });
+}
+
+int kbo_find_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                   const kbo_find_opts *opts, kbo_rle **rles, uint64_t *rle_offsets)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && rles && rle_offsets, KBO_E_BAD_ARG, "null argument");
+        kbo_find_opts o;
+        if (opts) o = *opts; else kbo_find_opts_default(&o);
+        check_batch(concat, offsets, n_seqs);
+        std::vector<uint8_t> aln(offsets[n_seqs]);
+        matches_batch_impl(idx, concat, offsets, n_seqs, o.max_error_prob, false, aln.data()); // lib.rs:815
+        std::vector<kbo_rle> all;
+        rle_offsets[0] = 0;
+        for (size_t s = 0; s < n_seqs; s++) { // lib.rs:816-820
+            run_lengths_gapped_impl(aln.data() + offsets[s], offsets[s + 1] - offsets[s], o.max_gap_len, all);
+            rle_offsets[s + 1] = all.size();
+        }
+        *rles = copy_rles(all);
+    });
+}
+
+int kbo_find(kbo_index_t *idx, const uint8_t *query, size_t len, const kbo_find_opts *opts, kbo_rle **out,
+             size_t *n_out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && query && out && n_out, KBO_E_BAD_ARG, "null argument");
+        KBO_REQUIRE(len > 0, KBO_E_EMPTY_QUERY, "assert!(!query.is_empty()) (index.rs:248)");
+        const uint64_t off[2] = {0, len};
+        uint64_t ro[2];
+        int rc = kbo_find_batch(idx, query, off, 1, opts, out, ro);
+        if (rc) throw KboError(rc, g_err);
+        *n_out = ro[1];
+    });
+}
+
+void kbo_free(void *p) { std::free(p); }
+
+size_t kbo_work_bytes(size_t n_seqs) { return std::max<size_t>(1, n_seqs) * sizeof(kbo::WalkItem); }
+
+int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs,
+                     uint64_t total_bases, uint8_t *d_ms_out, uint32_t *d_lo_out, uint32_t *d_hi_out,
+                     void *d_work, void *stream)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && d_concat && d_offsets && d_ms_out && d_work, KBO_E_BAD_ARG, "null argument");
+        KBO_REQUIRE(n_seqs > 0 && n_seqs < 0xFFFFFFFFull && total_bases > 0, KBO_E_EMPTY_QUERY, "empty batch");
+        KBO_REQUIRE(((uintptr_t)d_concat & 15) == 0 && ((uintptr_t)d_ms_out & 3) == 0 &&
+                        ((uintptr_t)d_work & 15) == 0,
+                    KBO_E_BAD_ARG, "d_concat/d_work must be 16-byte and d_ms_out 4-byte aligned");
+        KBO_REQUIRE((d_lo_out == nullptr) == (d_hi_out == nullptr), KBO_E_BAD_ARG, "lo/hi must come together");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        kbo::DevIndexView view = device_view(idx, current_device());
+        kbo::WalkItem *items = static_cast<kbo::WalkItem *>(d_work);
+        HIP_OK(kbo::launch_make_items(d_offsets, (uint32_t)n_seqs, items, s));
+        kbo::WalkArgs a;
+        a.ix = view;
+        a.q = d_concat;
+        a.q_bytes = total_bases;
+        a.items = items;
+        a.n_items = (uint32_t)n_seqs;
+        a.d_out = d_ms_out;
+        a.lo_out = d_lo_out;
+        a.hi_out = d_hi_out;
+        HIP_OK(kbo::launch_ms_walk(a, walk_blocks(), s));
+    });
+}
+
+int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, size_t n_seqs, size_t k,
+                             size_t threshold, const uint8_t *d_ref, uint8_t *d_chars_out, void *stream)
+{
+    return guarded([&] {
+        KBO_REQUIRE(d_ms && d_offsets && d_chars_out, KBO_E_BAD_ARG, "null argument");
+        KBO_REQUIRE(n_seqs > 0 && n_seqs < 0xFFFFFFFFull, KBO_E_EMPTY_QUERY, "empty batch");
+        KBO_REQUIRE(k > 0 && k <= 255, KBO_E_BAD_ARG, "k in 1..255");
+        KBO_REQUIRE(threshold > 1, KBO_E_THRESHOLD_LE_1, "threshold > 1 (derandomize.rs:275)");
+        KBO_REQUIRE(((uintptr_t)d_ms & 3) == 0 && ((uintptr_t)d_chars_out & 3) == 0 && ((uintptr_t)d_ref & 3) == 0,
+                    KBO_E_BAD_ARG, "device buffers must be 4-byte aligned");
+        HIP_OK(kbo::launch_derand_translate(d_ms, d_offsets, (uint32_t)n_seqs, (uint32_t)k, (uint32_t)threshold,
+                                            d_ref, d_chars_out, nullptr, static_cast<hipStream_t>(stream)));
+    });
+}
+
+int kbo_walk_geometry(int *blocks, int *threads)
+{
+    return guarded([&] {
+        if (blocks) *blocks = walk_blocks();
+        if (threads) *threads = kbo::kWalkThreads;
+    });
+}
+
+int kbo_set_walk_blocks_per_cu(int blocks_per_cu)
+{
+    g_blocks_per_cu = blocks_per_cu > 0 ? blocks_per_cu : 0;
+    return KBO_OK;
+}
+
+} // extern "C"

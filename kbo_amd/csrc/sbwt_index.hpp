@@ -1,0 +1,58 @@
+// sbwt_index.hpp — host-side abstract SBWT index (the content of
+// sbwt::SbwtIndex<SubsetMatrix> + sbwt::LcsArray that kbo::build returns,
+// reference lib.rs:501-506 / index.rs:56-99) and its MI355X device layout.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace kbo {
+
+// Abstract index content.  rows[c] is the subset-matrix row of character c
+// ("ACGT"[c]) as 64-bit words, bit (i & 63) of word (i >> 6) = row i.
+struct HostIndex {
+    uint32_t k = 0;
+    uint64_t n_sets = 0;  // SBWT rows (k-mers + dummy rows)
+    uint64_t n_kmers = 0; // distinct real k-mers
+    uint64_t C[4] = {0, 0, 0, 0};
+    std::vector<uint64_t> rows[4];
+    std::vector<uint8_t> lcs; // n_sets entries, LCS[0] = 0
+};
+
+struct BuildParams {
+    uint32_t k = 31;
+    bool add_revcomp = false;
+    uint32_t num_threads = 1;
+};
+
+// Sort-based construction (colex-sorted padded k-mer rows).  Throws std::runtime_error.
+void build_host_index(const uint8_t *const *seqs, const size_t *lens, size_t n_seqs,
+                      const BuildParams &p, HostIndex &out);
+
+// ---- device layout (32-bit positions: n_sets < 2^32 - 1) -------------------------
+//
+// Rank blocks: for each character c an array of 16-byte blocks, block b covering
+// rows [96 b, 96 b + 96):
+//     { cum, w0, w1, w2 }   cum = C[c] + popcount(B_c[0 .. 96 b)),  w* = the 96 row bits
+// so that   C[c] + rank_c(i) = cum + popcount(bits below (i - 96 b))   costs ONE
+// aligned 16-byte load.  n_blocks = n_sets / 96 + 2 (rank at i = n_sets is legal).
+//
+// LCS: one byte per row, lcs[n_sets] = 0 sentinel, zero-padded to a multiple of 16
+// plus one extra 16-byte window, so the contract-left scans are sentinel-terminated
+// (LCS[0] = 0 on the left, lcs[n_sets] = 0 on the right) and always read whole,
+// aligned 16-byte windows.
+constexpr uint32_t kRankRowsPerBlock = 96;
+
+struct DeviceLayout {
+    uint64_t n_blocks = 0;            // per character
+    std::vector<uint32_t> rank[4];    // 4 * n_blocks words each
+    std::vector<uint8_t> lcs;         // padded
+};
+void make_device_layout(const HostIndex &h, DeviceLayout &out);
+
+// flat file (own format, see kbo_capi.cpp)
+void save_host_index(const HostIndex &h, const std::string &path);
+void load_host_index(const std::string &path, HostIndex &h);
+
+} // namespace kbo

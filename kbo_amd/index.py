@@ -1,0 +1,114 @@
+"""Mirror of kbo::index (reference src/index.rs) over the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import check, lib
+
+
+def _u8(x):
+    if isinstance(x, np.ndarray):
+        return np.ascontiguousarray(x, dtype=np.uint8)
+    if isinstance(x, str):
+        x = x.encode()
+    return np.frombuffer(bytes(x), dtype=np.uint8)
+
+
+class SbwtIndexVariant:
+    """Stand-in for sbwt::SbwtIndexVariant::SubsetMatrix (+ its LcsArray): owns a kbo_index_t."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().kbo_index_free(h)
+
+    def k(self):
+        return int(lib().kbo_index_k(self._h))
+
+    def n_kmers(self):
+        return int(lib().kbo_index_n_kmers(self._h))
+
+    def n_sets(self):
+        return int(lib().kbo_index_n_sets(self._h))
+
+    def to_device(self, device=-1):
+        check(lib().kbo_index_to_device(self._h, device))
+        return self
+
+    def device_bytes(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        check(lib().kbo_index_device_bytes(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def export_parts(self):
+        """(rows[4] uint64 words, C[4], lcs bytes) — the abstract index content."""
+        n = self.n_sets()
+        nw = (n + 63) // 64
+        rows = [np.zeros(nw, dtype=np.uint64) for _ in range(4)]
+        ptrs = (C.c_void_p * 4)(*[r.ctypes.data for r in rows])
+        Carr = (C.c_uint64 * 4)()
+        lcs = np.zeros(n, dtype=np.uint8)
+        check(lib().kbo_index_export_parts(self._h, ptrs, Carr, lcs.ctypes.data))
+        return rows, [int(v) for v in Carr], lcs
+
+    @classmethod
+    def from_parts(cls, k, n_sets, n_kmers, rows, Carr, lcs):
+        rows = [np.ascontiguousarray(r, dtype=np.uint64) for r in rows]
+        ptrs = (C.c_void_p * 4)(*[r.ctypes.data for r in rows])
+        Cc = (C.c_uint64 * 4)(*[int(v) for v in Carr])
+        lcs = np.ascontiguousarray(lcs, dtype=np.uint8)
+        h = C.c_void_p()
+        check(lib().kbo_index_from_parts(k, n_sets, n_kmers, ptrs, Cc, lcs.ctypes.data, C.byref(h)))
+        return cls(h)
+
+
+class LcsArray:
+    """Stand-in for sbwt::LcsArray; the LCS bytes live inside the index handle."""
+
+    def __init__(self, sbwt):
+        self.sbwt = sbwt
+
+
+def build_sbwt_from_vecs(slices, build_options=None):
+    """index::build_sbwt_from_vecs (index.rs:56-99) -> (SbwtIndexVariant, LcsArray)."""
+    from . import BuildOpts
+    o = build_options if build_options is not None else BuildOpts()
+    seqs = [bytes(_u8(s)) for s in slices]
+    if not seqs:
+        raise _capi.KboError(-4, "assert!(!slices.is_empty()) (index.rs:60)")
+    arr = (C.c_char_p * len(seqs))(*seqs)
+    lens = (C.c_size_t * len(seqs))(*[len(s) for s in seqs])
+    co = o._to_c()
+    h = C.c_void_p()
+    check(lib().kbo_index_build(arr, lens, len(seqs), C.byref(co), C.byref(h)))
+    sbwt = SbwtIndexVariant(h)
+    return sbwt, LcsArray(sbwt)
+
+
+def serialize_sbwt(outfile_prefix, sbwt, lcs=None):
+    """index::serialize_sbwt (index.rs:128-151); own flat format `<prefix>.kbohip`."""
+    check(lib().kbo_index_save(sbwt._h, (outfile_prefix + ".kbohip").encode()))
+
+
+def load_sbwt(index_prefix):
+    """index::load_sbwt (index.rs:195-212)."""
+    h = C.c_void_p()
+    check(lib().kbo_index_load((index_prefix + ".kbohip").encode(), C.byref(h)))
+    sbwt = SbwtIndexVariant(h)
+    return sbwt, LcsArray(sbwt)
+
+
+def query_sbwt(query, sbwt, lcs=None):
+    """index::query_sbwt (index.rs:243-256) -> list of (d, range(l, r)) like Vec<(usize, Range<usize>)>."""
+    q = _u8(query)
+    n = len(q)
+    d = np.zeros(max(n, 1), dtype=np.uint64)
+    lo = np.zeros(max(n, 1), dtype=np.uint64)
+    hi = np.zeros(max(n, 1), dtype=np.uint64)
+    check(lib().kbo_matching_statistics(sbwt._h, q.ctypes.data, n, d.ctypes.data, lo.ctypes.data,
+                                        hi.ctypes.data))
+    return [(int(d[i]), range(int(lo[i]), int(hi[i]))) for i in range(n)]

@@ -1,0 +1,147 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol that
+include/kbo_hip.h declares, the host-only entry points (A3 threshold maths, scalar
+*_val functions, format) match the reference's goldens, argument checks mirror the
+reference's asserts, and compute entry points fail loudly without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import kbo_amd
+from kbo_amd import _capi, derandomize, format, translate
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported():
+    hdr = open(os.path.join(ROOT, "include", "kbo_hip.h")).read()
+    declared = set(re.findall(r"\b(kbo_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_capi.SYMBOLS)
+    L = C.CDLL(_capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_no_oracle_in_product():
+    """The product must not link or import the oracle."""
+    import subprocess
+    out = subprocess.run(["ldd", _capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "kbo_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "kbo_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_opts_defaults_match_reference():
+    # lib.rs:300-313, 344-353, 373-382, 398-407, 454-466
+    b = _capi.BuildOpts(); kbo_amd.lib().kbo_build_opts_default(C.byref(b))
+    assert (b.k, b.add_revcomp, b.num_threads, b.prefix_precalc, b.build_select, b.mem_gb,
+            b.dedup_batches, b.temp_dir) == (31, 0, 1, 8, 0, 4, 0, None)
+    f = _capi.FindOpts(); kbo_amd.lib().kbo_find_opts_default(C.byref(f))
+    assert (f.max_error_prob, f.max_gap_len) == (0.0000001, 0)
+    m = _capi.MapOpts(); kbo_amd.lib().kbo_map_opts_default(C.byref(m))
+    assert (m.max_error_prob, m.fill_gaps, m.call_variants, m.format, m.sbwt_build_opts.build_select,
+            m.sbwt_build_opts.k) == (0.0000001, 1, 1, 1, 1, 31)
+    assert kbo_amd.BuildOpts() == kbo_amd.BuildOpts(31, False, 1, 8, False, 4, False, None)
+    assert kbo_amd.CallOpts().sbwt_build_opts.build_select and kbo_amd.MapOpts().fill_gaps
+    assert kbo_amd.MatchOpts().max_error_prob == kbo_amd.FindOpts().max_error_prob == 1e-7
+
+
+def test_log_rm_max_cdf_golden(golden):  # derandomize.rs:298-304
+    g = golden["log_rm_max_cdf"]
+    for t, e in zip(g["t"], g["expected"]):
+        assert abs(derandomize.log_rm_max_cdf(t, g["alphabet_size"], g["n_kmers"]) - e) < g["tol"]
+
+
+def test_random_match_threshold_golden(golden, oracle):  # derandomize.rs:307-314
+    g = golden["random_match_threshold"]
+    assert [derandomize.random_match_threshold(g["k"], g["n_kmers"], g["alphabet_size"], p)
+            for p in g["max_error_prob"]] == g["expected"]
+    rng = np.random.default_rng(3)
+    for _ in range(300):  # product (C++) and oracle (C) restatements agree everywhere
+        k = int(rng.integers(2, 256)); n = int(rng.integers(1, 10**10)); p = float(10 ** -rng.uniform(0, 12))
+        assert derandomize.random_match_threshold(k, n, 4, p) == oracle.random_match_threshold(k, n, 4, p)
+    for bad in [(0, 10, 4, 0.1), (31, 0, 4, 0.1), (31, 10, 0, 0.1), (31, 10, 4, 0.0), (31, 10, 4, 1.5)]:
+        with pytest.raises(kbo_amd.KboError) as e:  # derandomize.rs:133-137
+            derandomize.random_match_threshold(*bad)
+        assert e.value.code == -4
+
+
+def test_scalar_vals_golden(golden):
+    for g in golden["derandomize_ms_val"]:  # derandomize.rs:317-370
+        assert derandomize.derandomize_ms_val(*g["args"]) == g["expected"]
+    for g in golden["translate_ms_val"]:  # translate.rs:396-498
+        assert list(translate.translate_ms_val(*g["args"])) == g["expected"]
+    with pytest.raises(kbo_amd.KboError) as e:  # derandomize.rs:229
+        derandomize.derandomize_ms_val(5, 1, 2, 3)
+    assert e.value.code == -9
+    with pytest.raises(kbo_amd.KboError) as e:  # translate.rs:186
+        translate.translate_ms_val(1, 1, 1, 1)
+    assert e.value.code == -3
+
+
+def test_format_golden(golden, oracle):  # format.rs:295-330
+    for g in golden["run_lengths"]:
+        got = format.run_lengths(g["aln"])
+        assert [[r.start, r.end, r.matches, r.mismatches, r.jumps, r.gap_bases, r.gap_opens] for r in got] \
+            == g["expected"]
+    rng = np.random.default_rng(5)
+    for _ in range(200):  # differential: product host RLE vs oracle restatement
+        aln = "".join(rng.choice(list("MMMMMM--XRR-"), size=int(rng.integers(1, 120))))
+        if aln[0] == "R":
+            aln = "M" + aln[1:]
+        for gap in (0, 1, 3, 50):
+            got = [(r.start, r.end, r.matches, r.mismatches, r.jumps, r.gap_bases, r.gap_opens)
+                   for r in format.run_lengths_gapped(aln, gap)]
+            assert got == oracle.run_lengths_gapped(aln, gap)
+        ref = "".join(rng.choice(list("ACGT"), size=len(aln)))
+        assert format.relative_to_ref(ref, aln) == oracle.relative_to_ref(ref, aln)
+    assert format.relative_to_ref("ACGTAC", "MRIXD-") == b"ACG---"
+    assert format.relative_to_ref("ACGT", "MGNM") == b"AGNT"
+
+
+def test_vector_arg_checks_need_no_gpu():
+    """len<=2 / threshold<=1 / k==0 are rejected before any device work
+    (derandomize.rs:274-276, translate.rs:268-270)."""
+    for fn, arg in ((derandomize.derandomize_ms_vec, [1, 2]), (translate.translate_ms_vec, [1, 2])):
+        with pytest.raises(kbo_amd.KboError) as e:
+            fn(arg, 3, 2)
+        assert e.value.code == -2
+        with pytest.raises(kbo_amd.KboError) as e:
+            fn([1, 2, 3], 3, 1)
+        assert e.value.code == -3
+        with pytest.raises(kbo_amd.KboError) as e:
+            fn([1, 2, 3], 0, 2)
+        assert e.value.code == -4
+    with pytest.raises(kbo_amd.KboError) as e:  # derandomize.rs:229 curr_noisy_ms <= k
+        derandomize.derandomize_ms_vec([1, 9, 3], 3, 2)
+    assert e.value.code == -9
+
+
+def test_empty_query_and_map_opts_checks():
+    sbwt, lcs = kbo_amd.build([b"ACGTACGTTGCA"], kbo_amd.BuildOpts(k=4))
+    with pytest.raises(kbo_amd.KboError) as e:  # index.rs:248
+        kbo_amd.index.query_sbwt(b"", sbwt, lcs)
+    assert e.value.code == -1
+    with pytest.raises(kbo_amd.KboError) as e:  # lib.rs:729
+        kbo_amd.map(b"ACGTACGT", sbwt, lcs, kbo_amd.MapOpts())
+    assert e.value.code == -6
+
+
+def test_compute_fails_loudly_without_gpu():
+    """No CPU fallback: on a machine without a HIP device every compute call is an error."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    sbwt, lcs = kbo_amd.build([b"ACGTACGTTGCA"], kbo_amd.BuildOpts(k=4))
+    for call in (lambda: kbo_amd.index.query_sbwt(b"ACGTAC", sbwt, lcs),
+                 lambda: kbo_amd.matches(b"ACGTAC", sbwt, lcs),
+                 lambda: derandomize.derandomize_ms_vec([1, 2, 3], 3, 2),
+                 lambda: translate.translate_ms_vec([1, 2, 3], 3, 2)):
+        with pytest.raises(kbo_amd.KboError) as e:
+            call()
+        assert e.value.code == -7

@@ -1,0 +1,261 @@
+"""Parity of the gfx950 HIP path (through the C ABI) with the CPU oracle and with the
+reference's golden vectors.  Bit-exact: everything on this path is integer/byte work."""
+import numpy as np
+import pytest
+
+import kbo_amd
+from kbo_amd import batch, derandomize, synth, translate
+
+pytestmark = pytest.mark.gpu
+
+
+def _ms_tuple(res):
+    return [d for d, _ in res], [r.start for _, r in res], [r.stop for _, r in res]
+
+
+# ------------------------------------------------------------------ reference goldens
+
+def test_query_sbwt_golden(golden):  # index.rs:264-275
+    for g in golden["ms"]:
+        sbwt, lcs = kbo_amd.build(g["ref_seqs"], kbo_amd.BuildOpts(k=g["k"]))
+        got = [x[0] for x in kbo_amd.index.query_sbwt(g["query"], sbwt, lcs)]
+        assert got == g["expected_ms"]
+
+
+def test_appendix_a_intervals():
+    sbwt, lcs = kbo_amd.build([b"AAAGAACCA-TCAGGGCG"], kbo_amd.BuildOpts(k=3))
+    got = kbo_amd.index.query_sbwt(b"CAAGCCACTCATTGGGTC", sbwt, lcs)
+    exp = [(1, 6, 10), (2, 3, 5), (2, 1, 3), (3, 10, 11), (2, 8, 9), (2, 7, 8), (3, 3, 4), (2, 6, 7),
+           (1, 15, 16), (2, 9, 10), (3, 4, 5), (1, 15, 16), (1, 15, 16), (1, 10, 15), (2, 13, 15),
+           (3, 14, 15), (1, 15, 16), (2, 9, 10)]
+    assert [(d, r.start, r.stop) for d, r in got] == exp
+
+
+def test_derandomize_ms_vec_golden(golden):  # derandomize.rs:373-379
+    for g in golden["derandomize_ms_vec"]:
+        assert derandomize.derandomize_ms_vec(g["noisy_ms"], g["k"], g["threshold"]) == g["expected"]
+
+
+def test_translate_ms_vec_golden(golden):  # translate.rs:501-532
+    for g in golden["translate_ms_vec"]:
+        assert "".join(translate.translate_ms_vec(g["derand_ms"], g["k"], g["threshold"])) == g["expected"]
+
+
+def test_matches_golden(golden):  # lib.rs:600-609
+    for g in golden["matches"]:
+        sbwt, lcs = kbo_amd.build(g["ref_seqs"], kbo_amd.BuildOpts(k=g["k"]))
+        got = kbo_amd.matches(g["query"], sbwt, lcs, kbo_amd.MatchOpts(g["max_error_prob"]))
+        assert "".join(got) == g["expected"]
+
+
+def test_map_golden_no_refinement(golden):  # lib.rs:670-717
+    for g in golden["map"]:
+        if g["fill_gaps"] or g["call_variants"]:
+            continue
+        opts = kbo_amd.BuildOpts(k=g["k"], build_select=True)
+        sbwt, lcs = kbo_amd.build(g["query_seqs"], opts)
+        mo = kbo_amd.MapOpts(max_error_prob=g["max_error_prob"], fill_gaps=False, call_variants=False,
+                             format=g["format"], sbwt_build_opts=opts)
+        assert kbo_amd.map(g["ref_seq"], sbwt, lcs, mo).decode() == g["expected"]
+
+
+def test_find_golden(golden):  # lib.rs:786-805
+    for g in golden["find"]:
+        sbwt, lcs = kbo_amd.build(g["ref_seqs"], kbo_amd.BuildOpts(k=g["k"]))
+        got = kbo_amd.find(g["query"], sbwt, lcs, kbo_amd.FindOpts(max_gap_len=g["max_gap_len"]))
+        assert [[r.start, r.end, r.matches, r.mismatches, r.jumps, r.gap_bases, r.gap_opens] for r in got] \
+            == g["expected"]
+
+
+# ------------------------------------------------------------------ differential vs oracle
+
+def _mutate(rng, seq, rate):
+    s = np.frombuffer(seq, dtype=np.uint8).copy()
+    hit = rng.random(len(s)) < rate
+    s[hit] = rng.choice(list(b"ACGT"), size=int(hit.sum()))
+    return s.tobytes()
+
+
+@pytest.mark.parametrize("k", [2, 3, 5, 8, 13, 21, 31, 32, 51, 63, 90, 200])
+def test_ms_vs_oracle_random(oracle, k):
+    rng = np.random.default_rng(500 + k)
+    refs = [rng.choice(list(b"ACGT"), size=int(rng.integers(k + 1, 3000))).astype(np.uint8).tobytes()
+            for _ in range(3)]
+    sbwt, lcs = kbo_amd.build(refs, kbo_amd.BuildOpts(k=k))
+    ora = oracle.Index.build(refs, k=k)
+    for trial in range(6):
+        src = refs[trial % 3]
+        a = int(rng.integers(0, max(1, len(src) - 10)))
+        q = _mutate(rng, src[a:a + int(rng.integers(1, 700))], [0.0, 0.01, 0.05, 0.3][trial % 4])
+        if trial == 5:
+            q = rng.choice(list(b"ACGT"), size=257).astype(np.uint8).tobytes()
+        d, lo, hi = ora.matching_statistics(q)
+        gd, glo, ghi = _ms_tuple(kbo_amd.index.query_sbwt(q, sbwt, lcs))
+        assert gd == d.tolist() and glo == lo.tolist() and ghi == hi.tolist()
+
+
+def test_ms_non_acgt_and_lowercase(oracle):
+    """Non-ACGT query bytes (unpinned upstream; build's choice = extend-right is empty)."""
+    refs = [b"ACGTTGCATGCATGCAAACCCGGGTTTACGTAGCTAGCTAGGATCGATCGTAGCTAGCTAGCATCGAT"]
+    sbwt, lcs = kbo_amd.build(refs, kbo_amd.BuildOpts(k=9))
+    ora = oracle.Index.build(refs, k=9)
+    q = b"ACGTTGCANGCATGCAAACCCGGGTTT$CGTAGCTAGCTAGGATCgatcGTAGCTAGC-AGCATCGAT\x00\xffACGT"
+    d, lo, hi = ora.matching_statistics(q)
+    gd, glo, ghi = _ms_tuple(kbo_amd.index.query_sbwt(q, sbwt, lcs))
+    assert gd == d.tolist() and glo == lo.tolist() and ghi == hi.tolist()
+
+
+def test_ms_index_missing_a_base(oracle):
+    """A query base that no row ends with drives d to 0 over the whole interval."""
+    refs = [b"ACACACCCAACCACAACACACCAC"]
+    sbwt, lcs = kbo_amd.build(refs, kbo_amd.BuildOpts(k=5))
+    ora = oracle.Index.build(refs, k=5)
+    q = b"ACACGTACCATTTTACACACC"
+    d, lo, hi = ora.matching_statistics(q)
+    gd, glo, ghi = _ms_tuple(kbo_amd.index.query_sbwt(q, sbwt, lcs))
+    assert gd == d.tolist() and glo == lo.tolist() and ghi == hi.tolist()
+
+
+def test_ms_repetitive_index(oracle):
+    """Repeats make (k-1)-suffix groups with several rows: the d==k contraction path."""
+    unit = b"ACGGTCATTGACCAGT"
+    refs = [unit * 20 + b"TTTT" + unit[3:] * 10, b"G" + unit * 5]
+    sbwt, lcs = kbo_amd.build(refs, kbo_amd.BuildOpts(k=12))
+    ora = oracle.Index.build(refs, k=12)
+    q = (unit * 6)[5:] + b"A" + unit * 3
+    d, lo, hi = ora.matching_statistics(q)
+    gd, glo, ghi = _ms_tuple(kbo_amd.index.query_sbwt(q, sbwt, lcs))
+    assert gd == d.tolist() and glo == lo.tolist() and ghi == hi.tolist()
+
+
+def test_long_sequence_is_chunked_exactly(oracle):
+    """Sequences longer than a chunk restart k-1 bases upstream: same output."""
+    g = synth.genome(200_000, seed=11)
+    sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=4))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    rng = np.random.default_rng(12)
+    q = _mutate(rng, g[50_000:110_000].tobytes(), 0.02)
+    q = q[:20_000] + rng.choice(list(b"ACGT"), size=5_000).astype(np.uint8).tobytes() + q[20_000:]
+    d, lo, hi = ora.matching_statistics(q)
+    gd, glo, ghi = batch.ms_batch(sbwt, np.frombuffer(q, dtype=np.uint8),
+                                  np.array([0, len(q)], dtype=np.uint64), want_intervals=True)
+    assert np.array_equal(gd, d.astype(np.uint8))
+    assert np.array_equal(glo, lo.astype(np.uint32)) and np.array_equal(ghi, hi.astype(np.uint32))
+    chars = batch.matches_batch(sbwt, np.frombuffer(q, dtype=np.uint8), np.array([0, len(q)], dtype=np.uint64))
+    assert chars.tobytes() == ora.matches(q)
+
+
+@pytest.mark.parametrize("k,t", [(3, 2), (7, 3), (31, 22), (31, 16), (51, 23), (200, 100), (5, 5)])
+def test_derand_translate_vs_oracle_fuzz(oracle, k, t):
+    """The fused kernel's closed-form translate vs the literal sequential oracle."""
+    rng = np.random.default_rng(k * 100 + t)
+    for trial in range(40):
+        n = int(rng.integers(3, 400))
+        mode = trial % 4
+        if mode == 0:
+            noisy = rng.integers(0, k + 1, size=n)
+        elif mode == 1:  # MS-like ramps
+            noisy = np.minimum(k, np.abs(np.cumsum(rng.choice([1, 1, 1, -k], size=n)) % (k + 1)))
+        elif mode == 2:
+            noisy = rng.choice([0, 1, t - 1, t, t + 1, k - 1, k], size=n)
+            noisy = np.clip(noisy, 0, k)
+        else:
+            noisy = np.full(n, k)
+            noisy[rng.random(n) < 0.1] = rng.integers(0, k + 1)
+        exp = oracle.derandomize_ms_vec(noisy, k, t)
+        assert derandomize.derandomize_ms_vec(noisy, k, t) == exp.tolist()
+        assert "".join(translate.translate_ms_vec(exp, k, t)) == oracle.translate_ms_vec(exp, k, t)
+
+
+def test_translate_arbitrary_i64(oracle):
+    rng = np.random.default_rng(9)
+    for _ in range(50):
+        n = int(rng.integers(3, 100))
+        x = rng.choice([-2**40, -5, -1, 0, 1, 2, 3, 4, 5, 30, 31, 2**40], size=n)
+        t = int(rng.integers(2, 8))
+        assert "".join(translate.translate_ms_vec(x, 31, t)) == oracle.translate_ms_vec(x, 31, t)
+
+
+def test_batch_reads_vs_oracle(oracle):
+    """Batched, ragged reads: d / chars / formatted map output identical to the oracle."""
+    g = synth.genome(100_000, seed=21)
+    sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=4))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    rng = np.random.default_rng(22)
+    reads = []
+    for r in range(3000):
+        L = int(rng.choice([3, 4, 5, 17, 31, 32, 100, 150, 151, 300]))
+        a = int(rng.integers(0, len(g) - L))
+        reads.append(_mutate(rng, g[a:a + L].tobytes(), [0, 0.01, 0.05][r % 3]))
+    concat = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    offsets = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+    exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
+    d, _, _ = batch.ms_batch(sbwt, concat, offsets)
+    assert np.array_equal(d, exp_d)
+    assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars)
+    mapped = batch.map_batch(sbwt, concat, offsets, format=True)
+    assert mapped.tobytes() == oracle.relative_to_ref(concat, exp_chars)
+    rles, ro = batch.find_batch(sbwt, concat, offsets, kbo_amd.FindOpts(max_gap_len=3))
+    for s in (0, 7, 1234, 2999):
+        exp = oracle.run_lengths_gapped(exp_chars[offsets[s]:offsets[s + 1]].tobytes(), 3)
+        assert [tuple(r) for r in rles[ro[s]:ro[s + 1]]] == exp
+
+
+def test_batch_rejects_like_reference():
+    sbwt, lcs = kbo_amd.build([b"ACGTACGTTGCAACGT"], kbo_amd.BuildOpts(k=4))
+    concat = np.frombuffer(b"ACGTAC", dtype=np.uint8)
+    with pytest.raises(kbo_amd.KboError) as e:  # derandomize.rs:276 len > 2
+        batch.matches_batch(sbwt, concat, np.array([0, 2, 6], dtype=np.uint64))
+    assert e.value.code == -2
+    with pytest.raises(kbo_amd.KboError) as e:  # index.rs:248 empty query
+        batch.ms_batch(sbwt, concat, np.array([0, 0, 6], dtype=np.uint64))
+    assert e.value.code == -1
+    with pytest.raises(kbo_amd.KboError) as e:
+        kbo_amd.matches(b"AC", sbwt, lcs)
+    assert e.value.code == -2
+
+
+def test_device_resident_path_matches_host_path(oracle):
+    """kbo_ms_batch_dev + kbo_derand_translate_dev on torch-owned HBM buffers."""
+    import torch
+    g = synth.genome(300_000, seed=31)
+    sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=4))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    concat, offsets = synth.reads(g, 20_000, 150, 0.01)
+    exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
+    dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"), want_intervals=True)
+    dev.run()
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.ms.cpu().numpy()[:len(concat)], exp_d)
+    assert np.array_equal(dev.chars.cpu().numpy()[:len(concat)], exp_chars)
+    d, lo, hi = ora.matching_statistics(concat[:150].tobytes())
+    assert np.array_equal(dev.lo.cpu().numpy()[:150], lo.astype(np.uint32).view(np.int32))
+    assert np.array_equal(dev.hi.cpu().numpy()[:150], hi.astype(np.uint32).view(np.int32))
+
+
+@pytest.mark.parametrize("sub_rate", [0.0, 0.01, 0.05])
+def test_full_size_properties(sub_rate):
+    """BASELINE C2 shape (5 Mbp index, 150 bp reads) at 200k reads: size-independent
+    properties — error-free reads are all 'M' with d ramping 1..k then k; MS never exceeds
+    min(i+1, k); d rises by at most 1 per base; outputs are idempotent across launches."""
+    import torch
+    g = synth.genome(5_000_000)
+    sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=8))
+    concat, offsets = synth.reads(g, 200_000, 150, sub_rate)
+    dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"))
+    dev.run()
+    torch.cuda.synchronize()
+    d = dev.ms.cpu().numpy()[:len(concat)].reshape(-1, 150).astype(np.int32)
+    ch = dev.chars.cpu().numpy()[:len(concat)].reshape(-1, 150)
+    ramp = np.minimum(np.arange(1, 151), 31)
+    assert np.all(d <= ramp[None, :]) and np.all(d >= 1)
+    assert np.all(d[:, 1:] - d[:, :-1] <= 1)
+    if sub_rate == 0.0:
+        assert np.all(d == ramp[None, :]) and np.all(ch == ord("M"))
+    else:
+        assert set(np.unique(ch)) <= set(b"M-XR")
+        assert (ch == ord("M")).mean() > 0.5
+    first = dev.chars.clone()
+    dev.run()
+    torch.cuda.synchronize()
+    assert torch.equal(first, dev.chars)
