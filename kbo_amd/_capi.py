@@ -75,6 +75,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch bundles its own libamdhip64.so.7; the dynamic loader keeps whichever copy
+    # of that SONAME arrives first for the whole process, and torch cannot initialise the
+    # GPU on top of /opt/rocm's copy.  When torch is installed, let it load its runtime
+    # first; the extension then binds to the same one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: the HIP extension has not been built "
                            "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
