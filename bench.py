@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--waves-per-cu", type=int, default=0)
     return ap.parse_args()
 
 
@@ -87,8 +87,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=device)  # RCCL; used for barrier + max only
 
-    if args.blocks_per_cu:
-        kbo_amd.lib().kbo_set_walk_blocks_per_cu(args.blocks_per_cu)
+    if args.waves_per_cu:
+        kbo_amd.lib().kbo_set_walk_waves_per_cu(args.waves_per_cu)
 
     # ---- inputs (deterministic); index replicated, reads sharded by rank
     genome = synth.genome(args.genome)

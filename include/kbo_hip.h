@@ -180,7 +180,8 @@ int kbo_find_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offs
 
 /* ------------------------------------------------------------------ device-resident path
  * Everything already in the HBM of the current device; kernels are enqueued on `stream`
- * (a hipStream_t) and the call returns immediately.  d_concat must be 16-byte aligned,
+ * (a hipStream_t) and the call returns immediately.  d_concat must be 16-byte aligned
+ * and have at least 16 readable bytes after its last base,
  * the other buffers 4-byte aligned; sequences shorter than 3 are skipped by the fused
  * derandomize/translate kernel (the host entry points reject them like the reference).
  * d_work is device scratch of at least kbo_work_bytes(n_seqs) bytes (16-byte aligned). */
@@ -194,9 +195,11 @@ int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *
 int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, size_t n_seqs,
                              size_t k, size_t threshold, const uint8_t *d_ref, uint8_t *d_chars_out,
                              void *stream);
-/* Kernel launch geometry used by the walk (persistent lanes): blocks x threads. */
-int kbo_walk_geometry(int *blocks, int *threads);
-int kbo_set_walk_blocks_per_cu(int blocks_per_cu); /* tuning knob, 0 = default */
+/* Walk launch geometry: upper bound on resident waves, and threads per workgroup. */
+int kbo_walk_geometry(int *max_waves, int *threads);
+int kbo_set_walk_waves_per_cu(int waves_per_cu); /* tuning knob, 0 = default (32) */
+int kbo_set_walk_threads(int threads);           /* tuning knob: workgroup size 64/128/256 */
+int kbo_set_walk_rare(int batch, int period);    /* tuning knob: rare-block batching */
 
 #ifdef __cplusplus
 }

@@ -77,7 +77,7 @@ class DeviceBatch:
         self.total = int(offsets[-1])
         self.k = sbwt.k()
         self.threshold = derandomize.random_match_threshold(self.k, sbwt.n_kmers(), 4, max_error_prob)
-        pad = (self.total + 15) // 16 * 16 + 16
+        pad = (self.total + 15) // 16 * 16 + 64
         with torch.cuda.device(device):
             sbwt.to_device(-1)
             self.q = torch.zeros(pad, dtype=torch.uint8, device=device)

@@ -86,11 +86,11 @@ struct DevBuf {
 };
 
 struct DevCopy {
-    DevBuf rank, lcs;
+    DevBuf arena; // rank blocks of A,C,G,T followed by the LCS windows
     uint64_t n_blocks = 0;
 };
 
-int g_blocks_per_cu = 0;
+int g_waves_per_cu = 0;
 
 int current_device()
 {
@@ -128,12 +128,17 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
         DevCopy *dc = new DevCopy();
         try {
             const size_t per = lay.n_blocks * 16;
-            dc->rank.alloc(per * 4);
+            // arena = rank blocks of A,C,G,T | one all-zero "null" block | LCS windows
+            const size_t arena_bytes = per * 4 + 16 + lay.lcs.size();
+            KBO_REQUIRE(arena_bytes < 0xFFFFFFF0ull, KBO_E_UNSUPPORTED,
+                        "index arena >= 4 GiB: 64-bit device offsets not built yet");
+            dc->arena.alloc(arena_bytes);
+            HIP_OK(hipMemset(dc->arena.p, 0, arena_bytes));
             for (int c = 0; c < 4; c++)
-                HIP_OK(hipMemcpy(dc->rank.as<uint8_t>() + per * c, lay.rank[c].data(), per,
+                HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + per * c, lay.rank[c].data(), per,
                                  hipMemcpyHostToDevice));
-            dc->lcs.alloc(lay.lcs.size());
-            HIP_OK(hipMemcpy(dc->lcs.p, lay.lcs.data(), lay.lcs.size(), hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + per * 4 + 16, lay.lcs.data(), lay.lcs.size(),
+                             hipMemcpyHostToDevice));
             dc->n_blocks = lay.n_blocks;
             idx->rank_bytes = per * 4;
             idx->lcs_bytes = lay.lcs.size();
@@ -147,20 +152,21 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
     }
     DevCopy *dc = it->second;
     kbo::DevIndexView v;
-    v.rank = dc->rank.as<uint4>();
+    v.arena = dc->arena.as<uint4>();
     v.n_blocks = (uint32_t)dc->n_blocks;
-    v.lcs16 = dc->lcs.as<uint4>();
+    v.lcs_off = (uint32_t)(dc->n_blocks * 4 + 1);
     v.n = (uint32_t)idx->host.n_sets;
     v.k = idx->host.k;
     return v;
 }
 
-int walk_blocks()
+// upper bound on resident walk waves: CUs x waves per CU (default 32 = 8 per SIMD)
+int walk_max_waves()
 {
     int dev = current_device();
     int cus = 0;
     HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    int per = g_blocks_per_cu > 0 ? g_blocks_per_cu : 8;
+    int per = g_waves_per_cu > 0 ? g_waves_per_cu : 32;
     return std::max(1, cus) * per;
 }
 
@@ -253,7 +259,8 @@ void run_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offset
     B.total = total;
     std::vector<kbo::WalkItem> items;
     make_items_host(offsets, n_seqs, idx->host.k, items);
-    KBO_REQUIRE(items.size() < 0xFFFFFFFFull, KBO_E_UNSUPPORTED, "too many work items");
+    KBO_REQUIRE(items.size() < (1ull << 28), KBO_E_UNSUPPORTED, "more than 2^28 work items per call");
+    KBO_REQUIRE(total < 0xFFFFFF00ull, KBO_E_UNSUPPORTED, "4 GiB or more of query per call: split the batch");
 
     const size_t padded = ((total + 15) / 16) * 16 + 16;
     B.q.alloc(padded);
@@ -274,10 +281,11 @@ void run_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offset
     a.q_bytes = total;
     a.items = B.items.as<kbo::WalkItem>();
     a.n_items = (uint32_t)items.size();
+    a.rounds = 0;
     a.d_out = B.ms.as<uint8_t>();
     a.lo_out = want_ival ? B.lo.as<uint32_t>() : nullptr;
     a.hi_out = want_ival ? B.hi.as<uint32_t>() : nullptr;
-    HIP_OK(kbo::launch_ms_walk(a, walk_blocks(), stream));
+    HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), stream));
     // the items vector must outlive the async copy
     HIP_OK(hipStreamSynchronize(stream));
 }
@@ -743,11 +751,15 @@ int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *
 {
     return guarded([&] {
         KBO_REQUIRE(idx && d_concat && d_offsets && d_ms_out && d_work, KBO_E_BAD_ARG, "null argument");
-        KBO_REQUIRE(n_seqs > 0 && n_seqs < 0xFFFFFFFFull && total_bases > 0, KBO_E_EMPTY_QUERY, "empty batch");
+        KBO_REQUIRE(n_seqs > 0 && total_bases > 0, KBO_E_EMPTY_QUERY, "empty batch");
+        KBO_REQUIRE(n_seqs < (1ull << 28) && total_bases < 0xFFFFFF00ull, KBO_E_UNSUPPORTED,
+                    "one launch covers < 2^28 sequences and < 4 GiB of query: split the batch");
         KBO_REQUIRE(((uintptr_t)d_concat & 15) == 0 && ((uintptr_t)d_ms_out & 3) == 0 &&
                         ((uintptr_t)d_work & 15) == 0,
                     KBO_E_BAD_ARG, "d_concat/d_work must be 16-byte and d_ms_out 4-byte aligned");
+#ifndef KBO_WALK_DEBUG
         KBO_REQUIRE((d_lo_out == nullptr) == (d_hi_out == nullptr), KBO_E_BAD_ARG, "lo/hi must come together");
+#endif
         hipStream_t s = static_cast<hipStream_t>(stream);
         kbo::DevIndexView view = device_view(idx, current_device());
         kbo::WalkItem *items = static_cast<kbo::WalkItem *>(d_work);
@@ -758,10 +770,11 @@ int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *
         a.q_bytes = total_bases;
         a.items = items;
         a.n_items = (uint32_t)n_seqs;
+        a.rounds = 0;
         a.d_out = d_ms_out;
         a.lo_out = d_lo_out;
         a.hi_out = d_hi_out;
-        HIP_OK(kbo::launch_ms_walk(a, walk_blocks(), s));
+        HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), s));
     });
 }
 
@@ -783,14 +796,26 @@ int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, siz
 int kbo_walk_geometry(int *blocks, int *threads)
 {
     return guarded([&] {
-        if (blocks) *blocks = walk_blocks();
+        if (blocks) *blocks = walk_max_waves();
         if (threads) *threads = kbo::kWalkThreads;
     });
 }
 
-int kbo_set_walk_blocks_per_cu(int blocks_per_cu)
+int kbo_set_walk_rare(int batch, int period)
 {
-    g_blocks_per_cu = blocks_per_cu > 0 ? blocks_per_cu : 0;
+    kbo::set_walk_rare(batch, period);
+    return KBO_OK;
+}
+
+int kbo_set_walk_threads(int threads)
+{
+    kbo::set_walk_threads(threads);
+    return KBO_OK;
+}
+
+int kbo_set_walk_waves_per_cu(int waves_per_cu)
+{
+    g_waves_per_cu = waves_per_cu > 0 ? waves_per_cu : 0;
     return KBO_OK;
 }
 

@@ -8,9 +8,9 @@ namespace kbo {
 
 // Device-resident index (32-bit positions).  Layout: sbwt_index.hpp.
 struct DevIndexView {
-    const uint4 *rank;    // 16-byte rank blocks, character c at rank + c * n_blocks
-    uint32_t n_blocks;    // blocks per character
-    const uint4 *lcs16;   // LCS bytes viewed as aligned 16-byte windows
+    const uint4 *arena;   // one allocation: rank blocks of A,C,G,T, then the LCS windows
+    uint32_t n_blocks;    // rank blocks per character (character c starts at c * n_blocks)
+    uint32_t lcs_off;     // arena index (16-byte units) of LCS window 0
     uint32_t n;           // n_sets
     uint32_t k;
 };
@@ -30,6 +30,9 @@ struct WalkArgs {
     uint64_t q_bytes;      // total bytes in q
     const WalkItem *items; // n_items
     uint32_t n_items;
+    uint32_t rounds;       // items per lane (set by launch_ms_walk)
+    uint32_t rare_batch;   // enter the rare block when this many lanes are blocked ...
+    uint32_t rare_mask;    // ... or when (iteration & rare_mask) == 0 and any lane is
     uint8_t *d_out;        // 1 byte per base, same indexing as q
     uint32_t *lo_out;      // optional (nullptr): interval start per base
     uint32_t *hi_out;      // optional: interval end per base
@@ -39,7 +42,7 @@ struct WalkArgs {
 hipError_t launch_make_items(const uint64_t *d_offsets, uint32_t n_seqs, WalkItem *d_items,
                              hipStream_t stream);
 // A1: k-bounded matching statistics over all items
-hipError_t launch_ms_walk(const WalkArgs &a, int blocks, hipStream_t stream);
+hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream);
 // A5+A6 (+ optional relative_to_ref when ref != nullptr, + optional i32 derandomised
 // values when derand_out != nullptr): one lane per sequence.
 hipError_t launch_derand_translate(const uint8_t *d_ms, const uint64_t *d_offsets, uint32_t n_seqs,
@@ -49,7 +52,9 @@ hipError_t launch_derand_translate(const uint8_t *d_ms, const uint64_t *d_offset
 hipError_t launch_translate(const int32_t *d_derand, uint64_t len, uint32_t k, uint32_t threshold,
                             uint8_t *d_chars_out, hipStream_t stream);
 
-constexpr int kWalkThreads = 256;
+constexpr int kWalkThreads = 64; // default workgroup size (waves are independent: no LDS, no barriers)
+void set_walk_threads(int threads); // tuning: 64, 128 or 256
+void set_walk_rare(int batch, int period); // tuning: rare-block batching
 constexpr uint32_t kRankRows = 96; // rows per 16-byte rank block (== kRankRowsPerBlock)
 
 } // namespace kbo

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""GPU-side tuning sweep of the walk kernel launch geometry on the C2 workload.
+Prints walk-kernel ms (min / median over repeats) per configuration."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import kbo_amd  # noqa: E402
+from kbo_amd import batch, synth  # noqa: E402
+
+G = int(os.environ.get("G", 5_000_000))
+R = int(os.environ.get("R", 1_000_000))
+g = synth.genome(G)
+sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=16))
+concat, offsets = synth.reads(g, R, 150, float(os.environ.get("SUB", 0.01)))
+dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"))
+stream = torch.cuda.current_stream()
+
+
+def time_walk(reps=8):
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream); dev.walk(stream); b.record(stream)
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return min(ts), float(np.median(ts))
+
+
+L = kbo_amd.lib()
+if os.environ.get("RARE"):
+    for wpc in (16, 32):
+        for batch, period in ((8, 4), (16, 8), (24, 8), (32, 16), (48, 16), (32, 32), (48, 64), (64, 64)):
+            L.kbo_set_walk_threads(64); L.kbo_set_walk_waves_per_cu(wpc); L.kbo_set_walk_rare(batch, period)
+            dev.walk(stream); torch.cuda.synchronize()
+            mn, med = time_walk()
+            print(f"waves/CU={wpc} batch={batch:2d} period={period:2d}  walk min {mn:.3f} ms median {med:.3f}", flush=True)
+    sys.exit(0)
+if os.environ.get("ONLY"):
+    L.kbo_set_walk_threads(64); L.kbo_set_walk_waves_per_cu(32)
+    dev.walk(stream); torch.cuda.synchronize()
+    print("only:", time_walk(4))
+    sys.exit(0)
+for threads in (64, 256):
+    for wpc in (8, 12, 16, 20, 24, 28, 32):
+        L.kbo_set_walk_threads(threads)
+        L.kbo_set_walk_waves_per_cu(wpc)
+        dev.walk(stream); torch.cuda.synchronize()
+        mn, med = time_walk()
+        print(f"threads={threads:3d} waves/CU={wpc:2d}  walk min {mn:.3f} ms  median {med:.3f} ms  -> {R*150/mn/1e6:.1f} Gbp/s", flush=True)
