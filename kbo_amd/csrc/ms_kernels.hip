@@ -395,49 +395,89 @@ __device__ __forceinline__ uint8_t translate_char(int xm, int xc, int xn, uint64
     return 'M';
 }
 
+// byte j (0..15) of a 16-byte block held in registers
+__device__ __forceinline__ uint32_t blk_byte(const uint4 &v, uint32_t j)
+{
+    const uint32_t lo = (j & 4u) ? v.y : v.x, hi = (j & 4u) ? v.w : v.z;
+    return (((j & 8u) ? hi : lo) >> ((j & 3u) * 8u)) & 0xFFu;
+}
+__device__ __forceinline__ void blk_set_word(uint4 &v, uint32_t w, uint32_t x)
+{
+    v.x = w == 0 ? x : v.x;
+    v.y = w == 1 ? x : v.y;
+    v.z = w == 2 ? x : v.z;
+    v.w = w == 3 ? x : v.w;
+}
+
+// One lane per sequence, right to left.  All three streams (MS in, optional reference in,
+// characters out) move in 16-byte blocks relative to the sequence start (unaligned global
+// accesses; the input buffers carry 16 bytes of slack, see include/kbo_hip.h).
 __global__ __launch_bounds__(256) void derand_translate_kernel(
     const uint8_t *__restrict__ ms, const uint64_t *__restrict__ off, uint32_t n_seqs, uint32_t k,
     uint32_t t, const uint8_t *__restrict__ ref, uint8_t *__restrict__ out, int32_t *__restrict__ derand_out)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seqs) return;
-    const uint64_t b = off[s], e = off[s + 1], len = e - b;
+    const uint64_t b = off[s], e = off[s + 1];
+    const uint32_t len = (uint32_t)(e - b);
     if (len < 3) return; // the host side rejects these (derandomize.rs:276)
     const int K = (int)k, T = (int)t;
-    const uint32_t *ms32 = reinterpret_cast<const uint32_t *>(ms);
-    const uint32_t *ref32 = reinterpret_cast<const uint32_t *>(ref);
-    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+    const uint8_t *msb = ms + b;
+    const uint8_t *refb = ref ? ref + b : nullptr;
+    uint8_t *outb = out + b;
 
-    uint64_t p = e - 1;
-    uint32_t mw = ms32[p >> 2];
-    uint32_t rw = ref ? ref32[p >> 2] : 0;
-    int a = (int)((mw >> ((uint32_t)(p & 3) * 8)) & 0xFFu);
-    int x_cur = a > T ? a : 0, x_next = x_cur, x_prev = K;
-    uint32_t obuf = 0;
+    uint32_t p = len - 1;
+    uint4 mblk = ld16u(msb, p & ~15u), rblk = make_uint4(0, 0, 0, 0), oblk = make_uint4(0, 0, 0, 0);
+    if (ref) rblk = ld16u(refb, p & ~15u);
+    uint4 mnext = mblk, rnext = rblk; // block below the current one, requested one block ahead
+    if (p >= 16u) {
+        mnext = ld16u(msb, (p & ~15u) - 16u);
+        if (ref) rnext = ld16u(refb, (p & ~15u) - 16u);
+    }
+    int a = (int)blk_byte(mblk, p & 15u);
+    int x_cur = a > T ? a : 0, x_next = x_cur, x_prev = K; // derandomize.rs:282
+    uint32_t ocur = 0;
     for (;;) {
-        if (p > b) {
-            const uint64_t q = p - 1;
-            if ((q & 3) == 3) mw = ms32[q >> 2];
-            a = (int)((mw >> ((uint32_t)(q & 3) * 8)) & 0xFFu);
+        if (p > 0) { // x[p-1] from noisy[p-1] and x[p] (derandomize.rs:233-246)
+            const uint32_t q = p - 1;
+            a = (int)blk_byte((q & 15u) == 15u ? mnext : mblk, q & 15u);
             x_prev = (a == K) ? K : ((a > T && x_cur < a) ? a : x_cur - 1);
         }
-        uint32_t ch = translate_char(x_prev, x_cur, x_next, p - b, len, K, T);
+        uint32_t ch = translate_char(x_prev, x_cur, x_next, p, len, K, T);
         if (ref) { // format::relative_to_ref: M,R keep the reference base, X and '-' become '-'
-            const uint32_t rb = (rw >> ((uint32_t)(p & 3) * 8)) & 0xFFu;
+            const uint32_t rb = blk_byte(rblk, p & 15u);
             ch = (ch == 'M' || ch == 'R') ? rb : (uint32_t)'-';
         }
-        obuf |= ch << ((uint32_t)(p & 3) * 8);
-        if (derand_out) derand_out[p] = x_cur;
-        if ((p & 3) == 0 || p == b) {
-            const uint64_t hi = min(p | 3ull, e - 1);
-            if ((p & 3) == 0 && hi == (p | 3ull)) out32[p >> 2] = obuf;
-            else
-                for (uint64_t w = p; w <= hi; w++) out[w] = (uint8_t)(obuf >> ((uint32_t)(w & 3) * 8));
-            obuf = 0;
+        ocur |= ch << ((p & 3u) * 8u);
+        if (derand_out) derand_out[b + p] = x_cur;
+        if ((p & 3u) == 0) {
+            blk_set_word(oblk, (p >> 2) & 3u, ocur);
+            ocur = 0;
+            if ((p & 15u) == 0) { // block complete down to its first byte
+                if (p + 16u <= len) st16u(outb, p, oblk);
+                else { // topmost, partial block of the sequence
+                    const uint32_t nb = len - p;
+                    const uint32_t wv[4] = {oblk.x, oblk.y, oblk.z, oblk.w};
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++) {
+                        if (nb >= 4u * j + 4u) st4u(outb + p + 4u * j, wv[j]);
+                        else {
+#pragma unroll
+                            for (uint32_t bb = 0; bb < 3; bb++)
+                                if (nb > 4u * j + bb) outb[p + 4u * j + bb] = (uint8_t)(wv[j] >> (8u * bb));
+                        }
+                    }
+                }
+                if (p == 0) break;
+                mblk = mnext;
+                rblk = rnext;
+                if (p >= 32u) {
+                    mnext = ld16u(msb, p - 32u);
+                    if (ref) rnext = ld16u(refb, p - 32u);
+                }
+            }
         }
-        if (p == b) break;
         p--;
-        if (ref && (p & 3) == 3) rw = ref32[p >> 2];
         x_next = x_cur;
         x_cur = x_prev;
     }
