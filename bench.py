@@ -60,6 +60,7 @@ def cpu_baseline_leg(args, genome, concat, offsets, gpu_d, gpu_chars):
         chars, d = oi.matches_batch(concat[:n1 * L], offsets[:n1 + 1], 1e-7, n_threads=cores, want_d=True)
     dt = (time.perf_counter() - t0) / passes
     # operation counts of the reference algorithm (separate, untimed, counted run)
+    ctr = ora.Counters()
     nc = min(n1, 50_000)
     oi.matches_batch(concat[:nc * L], offsets[:nc + 1], 1e-7, n_threads=cores, counters=ctr)
     c = ctr.as_dict()

@@ -116,7 +116,7 @@ int kbo_index_load(const char *path, kbo_index_t **out);
 
 /* Upload (idempotent) the device layout to HIP device `device` (-1 = current). */
 int kbo_index_to_device(kbo_index_t *idx, int device);
-/* Bytes of the device-resident layout: rank blocks / LCS. */
+/* Bytes of the device-resident layout: rank blocks / contraction entries {lcs,psv,nsv}. */
 int kbo_index_device_bytes(const kbo_index_t *idx, uint64_t *rank_bytes, uint64_t *lcs_bytes);
 
 /* ------------------------------------------------------------------ A3 (host, f64)

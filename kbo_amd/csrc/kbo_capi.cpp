@@ -128,8 +128,9 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
         DevCopy *dc = new DevCopy();
         try {
             const size_t per = lay.n_blocks * 16;
-            // arena = rank blocks of A,C,G,T | one all-zero "null" block | LCS windows
-            const size_t arena_bytes = per * 4 + 16 + lay.lcs.size();
+            // arena = rank blocks of A,C,G,T | one all-zero "null" block | contraction entries
+            const size_t ent_bytes = lay.ent.size() * sizeof(uint32_t);
+            const size_t arena_bytes = per * 4 + 16 + ent_bytes;
             KBO_REQUIRE(arena_bytes < 0xFFFFFFF0ull, KBO_E_UNSUPPORTED,
                         "index arena >= 4 GiB: 64-bit device offsets not built yet");
             dc->arena.alloc(arena_bytes);
@@ -137,11 +138,11 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
             for (int c = 0; c < 4; c++)
                 HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + per * c, lay.rank[c].data(), per,
                                  hipMemcpyHostToDevice));
-            HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + per * 4 + 16, lay.lcs.data(), lay.lcs.size(),
+            HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + per * 4 + 16, lay.ent.data(), ent_bytes,
                              hipMemcpyHostToDevice));
             dc->n_blocks = lay.n_blocks;
             idx->rank_bytes = per * 4;
-            idx->lcs_bytes = lay.lcs.size();
+            idx->lcs_bytes = ent_bytes;
         } catch (...) {
             delete dc;
             if (prev != device) (void)hipSetDevice(prev);
@@ -499,7 +500,7 @@ int kbo_index_device_bytes(const kbo_index_t *idx, uint64_t *rank_bytes, uint64_
         KBO_REQUIRE(idx, KBO_E_BAD_ARG, "null index");
         const uint64_t nb = idx->host.n_sets / kbo::kRankRowsPerBlock + 2;
         if (rank_bytes) *rank_bytes = nb * 16 * 4;
-        if (lcs_bytes) *lcs_bytes = ((idx->host.n_sets + 1 + 15) / 16) * 16 + 16;
+        if (lcs_bytes) *lcs_bytes = (3 * (idx->host.n_sets + 1) + 4) * sizeof(uint32_t);
     });
 }
 

@@ -31,7 +31,6 @@ enum : uint32_t {
     F_PF = 4u,    // next item's descriptor is in flight, its query words not yet requested
     // bits >= F_BLOCK take the lane out of the hot path until the rare block has run
     F_CON = 8u,   // needs contract-left
-    F_MK = 16u,   // contract-left depth m already known (continuing a scan)
     F_DONE = 32u, // finished its item, wants the next one
     F_FIN = 64u,  // no items left
     F_BLOCK = 8u
@@ -52,22 +51,6 @@ __device__ __forceinline__ uint32_t rank_eval(const uint4 &b, uint32_t o)
 
 __device__ __forceinline__ uint32_t div96(uint32_t i) { return __umulhi(i, 0xAAAAAAABu) >> 6; }
 
-// bit 7 of every byte of x that is < m (mm = m replicated into 4 bytes); full 0..255 range
-__device__ __forceinline__ uint32_t bytes_lt(uint32_t x, uint32_t mm)
-{
-    const uint32_t H = 0x80808080u;
-    uint32_t t = (x | H) - (mm & ~H);
-    uint32_t ge = ((x & ~mm) | (~(x ^ mm) & t)) & H;
-    return ge ^ H;
-}
-__device__ __forceinline__ uint32_t pack4(uint32_t h) { return (((h >> 7) * 0x00204081u) >> 21) & 0xFu; }
-// bit j set iff LCS byte j of the 16-byte window is < m
-__device__ __forceinline__ uint32_t lt_mask16(const uint4 &w, uint32_t m)
-{
-    uint32_t mm = m * 0x01010101u;
-    return pack4(bytes_lt(w.x, mm)) | (pack4(bytes_lt(w.y, mm)) << 4) |
-           (pack4(bytes_lt(w.z, mm)) << 8) | (pack4(bytes_lt(w.w, mm)) << 12);
-}
 // 'A','C','G','T' -> 0..3, anything else -> 4 (sbwt's DNA alphabet is exactly ACGT)
 __device__ __forceinline__ uint32_t decode_base(uint32_t ch)
 {
@@ -87,12 +70,35 @@ __device__ __forceinline__ uint4 ld16u(const uint8_t *base, uint32_t byte_off)
     __builtin_memcpy(&v, base + byte_off, 16);
     return v;
 }
+__device__ __forceinline__ uint3 ld12(const uint8_t *base, uint32_t byte_off)
+{
+    uint3 v;
+    __builtin_memcpy(&v, base + byte_off, 12);
+    return v;
+}
 // unaligned stores
 __device__ __forceinline__ void st16u(uint8_t *base, uint32_t byte_off, const uint4 &v)
 {
     __builtin_memcpy(base + byte_off, &v, 16);
 }
 __device__ __forceinline__ void st4u(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
+// store the first nb (1..15) bytes of a 16-byte block: whole words, then the trailing bytes
+__device__ __forceinline__ void st_partial(uint8_t *o, const uint4 &v, uint32_t nb)
+{
+#define KBO_ST_WORD(J, W)                                                                         \
+    if (nb >= 4u * (J) + 4u) st4u(o + 4u * (J), (W));                                             \
+    else {                                                                                        \
+        if (nb > 4u * (J) + 0u) o[4u * (J) + 0u] = (uint8_t)((W));                                 \
+        if (nb > 4u * (J) + 1u) o[4u * (J) + 1u] = (uint8_t)((W) >> 8);                            \
+        if (nb > 4u * (J) + 2u) o[4u * (J) + 2u] = (uint8_t)((W) >> 16);                           \
+    }
+    KBO_ST_WORD(0u, v.x)
+    KBO_ST_WORD(1u, v.y)
+    KBO_ST_WORD(2u, v.z)
+    KBO_ST_WORD(3u, v.w)
+#undef KBO_ST_WORD
+}
 
 // -------------------------------------------------------------------------------------
 // A1.  Semantics:
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
     const uint32_t q_end = (uint32_t)a.q_bytes;
     const uint32_t nblk = a.ix.n_blocks;
     const uint32_t null_blk = 4u * nblk; // all-zero rank block (non-ACGT bases)
-    const uint32_t lcs_byte0 = a.ix.lcs_off << 4; // arena byte offset of LCS[0]
+    const uint32_t ent_byte0 = a.ix.lcs_off << 4; // arena byte offset of contraction entry 0
 
     // this lane's items: first, first + 64, ...
     const uint64_t first64 = (uint64_t)wave * 64u * a.rounds + lane;
@@ -142,7 +148,8 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
     if (next_item < a.n_items) left = min(a.rounds, (a.n_items - 1u - next_item) / 64u + 1u);
 
     uint32_t flags = left ? F_DONE : F_FIN;
-    uint32_t l = 0, r = n, d = 0, m = 0, cb = 0;
+    uint32_t l = 0, r = n, d = 0, m = 0, cb = 0; // m: contraction targets known (rare block only)
+    uint32_t tgt_l = 0, tgt_r = 0; // contraction targets (rare block only)
     // Query and output are streamed in 16-byte blocks RELATIVE TO THE ITEM (unaligned global
     // accesses): i = base index inside the item; block i>>4, word (i>>2)&3, byte i&3.
     uint32_t i = 0, len = 0, warm = 0, start = 0;
@@ -168,78 +175,68 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
         const uint64_t hot = __ballot(flags < F_BLOCK);
         if (hot == 0 || (blocked != 0 && ((uint32_t)__popcll(blocked) >= a.rare_batch || (iter & a.rare_mask) == 0))) {
             dbg_rare++;
-            // ---- contract-left for every lane that asked for it (usually one pass)
-            // LCS windows are UNALIGNED 16-byte loads: wl = LCS[l-15 .. l], wr = LCS[r .. r+15]
-            // (the zero "null" block in front of the LCS bytes and the zero padding behind
-            // them are the scan sentinels), so LCS[l] and LCS[r] sit at fixed bytes.
+            // ---- contract-left for every lane that asked for it.
+            // The reference steps d-1, d-2, ... and re-tries the extension each time.  Two facts
+            // make that a short walk up the LCS interval tree:
+            //  (i) contract_left(I, t) leaves I unchanged for t > m = max(lcs[l], lcs[r]) and at
+            //      t = m moves exactly the side(s) whose boundary value is m, to psv[l] / nsv[r];
+            //  (ii) the extension stays empty until the interval reaches the nearest set bit of
+            //      B_c below l (row l - dl) or at/after r (row r + dr).
+            // So: climb one tree level per round (two 12-byte loads) until (ii) holds, then hand
+            // the lane back to the hot path, whose next extension succeeds at exactly the depth
+            // where the reference's loop stops.  If a nearest bit lies outside the loaded rank
+            // block, stop after one level (the hot path re-tries and comes back if needed).
+            if (flags & F_CON) {
+                const uint32_t bl = div96(l), br = div96(r);
+                const bool null_c = cb == null_blk;
+                const uint4 bA = ld16(arena, (null_c ? cb : cb + bl) << 4);
+                const uint4 bB = ld16(arena, (null_c ? cb : cb + br) << 4);
+                const uint32_t ol = l - bl * kRankRows, orr = r - br * kRankRows;
+                uint32_t dl = 0, dr = 0; // 0 = unknown
+                {
+                    const uint64_t X = ~0ull << (ol & 63u);
+                    const uint32_t xl = (uint32_t)X, xh = (uint32_t)(X >> 32);
+                    const bool big = ol >= 64u;
+                    const uint32_t y = bA.y & ~(big ? 0u : xl), z = bA.z & ~(big ? 0u : xh),
+                                   w = bA.w & ~(big ? xl : ~0u);
+                    int top = -1; // highest set bit strictly below ol
+                    if (y) top = 31 - __clz((int)y);
+                    if (z) top = 63 - __clz((int)z);
+                    if (w) top = 95 - __clz((int)w);
+                    if (top >= 0) dl = ol - (uint32_t)top;
+                }
+                {
+                    const uint64_t X = ~0ull << (orr & 63u);
+                    const uint32_t xl = (uint32_t)X, xh = (uint32_t)(X >> 32);
+                    const bool big = orr >= 64u;
+                    const uint32_t y = bB.y & (big ? 0u : xl), z = bB.z & (big ? 0u : xh),
+                                   w = bB.w & (big ? xl : ~0u);
+                    int low = -1; // lowest set bit at or above orr
+                    if (w) low = 64 + __ffs((int)w) - 1;
+                    if (z) low = 32 + __ffs((int)z) - 1;
+                    if (y) low = __ffs((int)y) - 1;
+                    if (low >= 0) dr = (uint32_t)low - orr + 1u; // rows to pass on the right
+                }
+                // targets: stop once l <= tgt_l or r >= tgt_r (0 / ~0 = unknown: single level)
+                m = (dl && dr) ? 1u : 0u;            // targets known?
+                tgt_l = l - dl;                  // row of the nearest set bit below l
+                tgt_r = r + dr;                  // one past the nearest set bit at/after r
+            }
             while (__ballot((flags & F_CON) != 0)) {
                 dbg_con++;
                 if (flags & F_CON) {
-                    const uint4 wl = ld16u(arena, lcs_byte0 + l - 15u);
-                    const uint4 wr = ld16u(arena, lcs_byte0 + r);
-                    if (!(flags & F_MK)) {
-                        // Final depth in one step.  The extension stays empty until the interval
-                        // reaches the nearest set bit of B_c below l (row l - dl) or at/after r
-                        // (row r + dr); contract_left reaches them at depths
-                        //   tL = min LCS[l-dl+1 .. l],  tR = min LCS[r .. r+dr]
-                        // so the loop of the reference ends exactly at depth max(tL, tR).  When a
-                        // nearest bit is outside the loaded block or window, fall back to the
-                        // one-level jump m = max(LCS[l], LCS[r]) (always a valid intermediate stop).
-                        const uint32_t bl = div96(l), br = div96(r);
-                        const bool null_c = cb == null_blk;
-                        const uint4 bA = ld16(arena, (null_c ? cb : cb + bl) << 4);
-                        const uint4 bB = ld16(arena, (null_c ? cb : cb + br) << 4);
-                        const uint32_t ol = l - bl * kRankRows, orr = r - br * kRankRows;
-                        uint32_t dl = 1000u, dr = 1000u;
-                        {
-                            const uint64_t X = ~0ull << (ol & 63u);
-                            const uint32_t xl = (uint32_t)X, xh = (uint32_t)(X >> 32);
-                            const bool big = ol >= 64u;
-                            const uint32_t y = bA.y & ~(big ? 0u : xl), z = bA.z & ~(big ? 0u : xh),
-                                           w = bA.w & ~(big ? xl : ~0u);
-                            int top = -1; // highest set bit strictly below ol
-                            if (y) top = 31 - __clz((int)y);
-                            if (z) top = 63 - __clz((int)z);
-                            if (w) top = 95 - __clz((int)w);
-                            if (top >= 0) dl = ol - (uint32_t)top;
-                        }
-                        {
-                            const uint64_t X = ~0ull << (orr & 63u);
-                            const uint32_t xl = (uint32_t)X, xh = (uint32_t)(X >> 32);
-                            const bool big = orr >= 64u;
-                            const uint32_t y = bB.y & (big ? 0u : xl), z = bB.z & (big ? 0u : xh),
-                                           w = bB.w & (big ? xl : ~0u);
-                            int low = -1; // lowest set bit at or above orr
-                            if (w) low = 64 + __ffs((int)w) - 1;
-                            if (z) low = 32 + __ffs((int)z) - 1;
-                            if (y) low = __ffs((int)y) - 1;
-                            if (low >= 0) dr = (uint32_t)low - orr;
-                        }
-                        const uint32_t lcs_l = wl.w >> 24, lcs_r = wr.x & 0xFFu;
-                        if (dl <= 4u && dr <= 3u) {
-                            // bytes l-3..l are wl.w (low to high); keep the top dl of them
-                            const uint32_t el = wl.w | (dl == 4u ? 0u : ((1u << (8u * (4u - dl))) - 1u));
-                            // bytes r..r+3 are wr.x; keep the low dr+1 of them
-                            const uint32_t er = wr.x | (dr == 3u ? 0u : (~0u << (8u * (dr + 1u))));
-                            const uint32_t tl = min(min(el & 0xFFu, (el >> 8) & 0xFFu), min((el >> 16) & 0xFFu, el >> 24));
-                            const uint32_t tr = min(min(er & 0xFFu, (er >> 8) & 0xFFu), min((er >> 16) & 0xFFu, er >> 24));
-                            m = max(tl, tr);
-                        } else {
-                            m = max(lcs_l, lcs_r);
-                        }
-                        d = m;
-                        flags |= F_MK;
-                    }
-                    if (m == 0) {
+                    const uint3 el = ld12(arena, ent_byte0 + l * 12u);
+                    const uint3 er = ld12(arena, ent_byte0 + r * 12u);
+                    const uint32_t lv = max(el.x, er.x);
+                    d = lv;
+                    if (lv == 0) {
                         l = 0;
                         r = n;
-                        flags &= ~(F_CON | F_MK);
+                        flags &= ~F_CON;
                     } else {
-                        const uint32_t ml = lt_mask16(wl, m), mr = lt_mask16(wr, m);
-                        // left: highest j with LCS[l-15+j] < m; right: lowest j with LCS[r+j] < m
-                        l = ml ? l - (uint32_t)__clz((int)ml) + 16u : l - 16u; // l-15+(31-clz)
-                        r = mr ? r + (uint32_t)__ffs((int)mr) - 1u : r + 16u;
-                        if (ml && mr) flags &= ~(F_CON | F_MK);
+                        l = el.x == lv ? el.y : l;
+                        r = er.x == lv ? er.z : r;
+                        if (!m || l <= tgt_l || r >= tgt_r) flags &= ~F_CON;
                     }
                 }
             }
@@ -313,18 +310,7 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
                         if ((e & 15u) == 15u) { // full block: one unaligned 16-byte store
                             st16u(a.d_out, start + warm + (e & ~15u), oblk);
                         } else if (fin_e) { // tail of the item: words, then bytes
-                            uint8_t *o = a.d_out + (start + warm + (e & ~15u));
-                            const uint32_t nb = (e & 15u) + 1u; // valid bytes in the block
-                            const uint32_t wv[4] = {oblk.x, oblk.y, oblk.z, oblk.w};
-#pragma unroll
-                            for (uint32_t j = 0; j < 4; j++) {
-                                if (nb >= 4u * j + 4u) st4u(o + 4u * j, wv[j]);
-                                else {
-#pragma unroll
-                                    for (uint32_t b = 0; b < 3; b++)
-                                        if (nb > 4u * j + b) o[4u * j + b] = (uint8_t)(wv[j] >> (8u * b));
-                                }
-                            }
+                            st_partial(a.d_out + (start + warm + (e & ~15u)), oblk, (e & 15u) + 1u);
                         }
                     }
                 }
@@ -395,23 +381,53 @@ __device__ __forceinline__ uint8_t translate_char(int xm, int xc, int xn, uint64
     return 'M';
 }
 
-// byte j (0..15) of a 16-byte block held in registers
-__device__ __forceinline__ uint32_t blk_byte(const uint4 &v, uint32_t j)
+// byte J (compile-time 0..15) of a 16-byte block held in registers
+template <int J> __device__ __forceinline__ uint32_t blk_byte(const uint4 &v)
 {
-    const uint32_t lo = (j & 4u) ? v.y : v.x, hi = (j & 4u) ? v.w : v.z;
-    return (((j & 8u) ? hi : lo) >> ((j & 3u) * 8u)) & 0xFFu;
+    const uint32_t w = (J >> 2) == 0 ? v.x : (J >> 2) == 1 ? v.y : (J >> 2) == 2 ? v.z : v.w;
+    return (w >> ((J & 3) * 8)) & 0xFFu;
 }
-__device__ __forceinline__ void blk_set_word(uint4 &v, uint32_t w, uint32_t x)
+template <int J> __device__ __forceinline__ void blk_or_byte(uint4 &v, uint32_t x)
 {
-    v.x = w == 0 ? x : v.x;
-    v.y = w == 1 ? x : v.y;
-    v.z = w == 2 ? x : v.z;
-    v.w = w == 3 ? x : v.w;
+    const uint32_t sh = x << ((J & 3) * 8);
+    if ((J >> 2) == 0) v.x |= sh;
+    else if ((J >> 2) == 1) v.y |= sh;
+    else if ((J >> 2) == 2) v.z |= sh;
+    else v.w |= sh;
 }
 
-// One lane per sequence, right to left.  All three streams (MS in, optional reference in,
-// characters out) move in 16-byte blocks relative to the sequence start (unaligned global
-// accesses; the input buffers carry 16 bytes of slack, see include/kbo_hip.h).
+struct DtState {
+    int x_cur, x_next, x_prev;
+};
+
+// one position of the right-to-left pass; J = byte inside the current 16-byte block
+template <int J>
+__device__ __forceinline__ void dt_step(DtState &st, const uint4 &cur, const uint4 &below, const uint4 &rcur,
+                                        uint4 &oblk, uint32_t p, uint32_t len, int K, int T, bool fmt,
+                                        int32_t *derand_out_p)
+{
+    if (p >= len) return; // only in the topmost block
+    if (p == len - 1) {   // derandomize.rs:282
+        const int a = (int)blk_byte<J>(cur);
+        st.x_cur = a > T ? a : 0;
+        st.x_next = st.x_cur;
+    }
+    if (p > 0) { // x[p-1] from noisy[p-1] and x[p] (derandomize.rs:233-246)
+        const int a = (int)(J > 0 ? blk_byte<(J + 15) & 15>(cur) : blk_byte<15>(below));
+        st.x_prev = (a == K) ? K : ((a > T && st.x_cur < a) ? a : st.x_cur - 1);
+    }
+    uint32_t ch = translate_char(st.x_prev, st.x_cur, st.x_next, p, len, K, T);
+    if (fmt) // format::relative_to_ref: M,R keep the reference base, X and '-' become '-'
+        ch = (ch == 'M' || ch == 'R') ? blk_byte<J>(rcur) : (uint32_t)'-';
+    blk_or_byte<J>(oblk, ch);
+    if (derand_out_p) *derand_out_p = st.x_cur;
+    st.x_next = st.x_cur;
+    st.x_cur = st.x_prev;
+}
+
+// One lane per sequence, right to left, one 16-byte block (relative to the sequence start,
+// unaligned global accesses) at a time with the block below it already in flight; inside a
+// block the 16 positions are unrolled so every byte access is a constant bit-field.
 __global__ __launch_bounds__(256) void derand_translate_kernel(
     const uint8_t *__restrict__ ms, const uint64_t *__restrict__ off, uint32_t n_seqs, uint32_t k,
     uint32_t t, const uint8_t *__restrict__ ref, uint8_t *__restrict__ out, int32_t *__restrict__ derand_out)
@@ -423,63 +439,31 @@ __global__ __launch_bounds__(256) void derand_translate_kernel(
     if (len < 3) return; // the host side rejects these (derandomize.rs:276)
     const int K = (int)k, T = (int)t;
     const uint8_t *msb = ms + b;
-    const uint8_t *refb = ref ? ref + b : nullptr;
+    const bool fmt = ref != nullptr;
+    const uint8_t *refb = fmt ? ref + b : msb;
     uint8_t *outb = out + b;
+    int32_t *dout = derand_out ? derand_out + b : nullptr;
 
-    uint32_t p = len - 1;
-    uint4 mblk = ld16u(msb, p & ~15u), rblk = make_uint4(0, 0, 0, 0), oblk = make_uint4(0, 0, 0, 0);
-    if (ref) rblk = ld16u(refb, p & ~15u);
-    uint4 mnext = mblk, rnext = rblk; // block below the current one, requested one block ahead
-    if (p >= 16u) {
-        mnext = ld16u(msb, (p & ~15u) - 16u);
-        if (ref) rnext = ld16u(refb, (p & ~15u) - 16u);
-    }
-    int a = (int)blk_byte(mblk, p & 15u);
-    int x_cur = a > T ? a : 0, x_next = x_cur, x_prev = K; // derandomize.rs:282
-    uint32_t ocur = 0;
-    for (;;) {
-        if (p > 0) { // x[p-1] from noisy[p-1] and x[p] (derandomize.rs:233-246)
-            const uint32_t q = p - 1;
-            a = (int)blk_byte((q & 15u) == 15u ? mnext : mblk, q & 15u);
-            x_prev = (a == K) ? K : ((a > T && x_cur < a) ? a : x_cur - 1);
+    const uint32_t nblk = (len + 15u) >> 4;
+    uint4 cur = ld16u(msb, 16u * (nblk - 1u));
+    uint4 rcur = fmt ? ld16u(refb, 16u * (nblk - 1u)) : make_uint4(0, 0, 0, 0);
+    DtState st{0, 0, K};
+    for (uint32_t bi = nblk; bi-- > 0;) {
+        uint4 below = cur, rbelow = rcur;
+        if (bi > 0) {
+            below = ld16u(msb, 16u * (bi - 1u));
+            if (fmt) rbelow = ld16u(refb, 16u * (bi - 1u));
         }
-        uint32_t ch = translate_char(x_prev, x_cur, x_next, p, len, K, T);
-        if (ref) { // format::relative_to_ref: M,R keep the reference base, X and '-' become '-'
-            const uint32_t rb = blk_byte(rblk, p & 15u);
-            ch = (ch == 'M' || ch == 'R') ? rb : (uint32_t)'-';
-        }
-        ocur |= ch << ((p & 3u) * 8u);
-        if (derand_out) derand_out[b + p] = x_cur;
-        if ((p & 3u) == 0) {
-            blk_set_word(oblk, (p >> 2) & 3u, ocur);
-            ocur = 0;
-            if ((p & 15u) == 0) { // block complete down to its first byte
-                if (p + 16u <= len) st16u(outb, p, oblk);
-                else { // topmost, partial block of the sequence
-                    const uint32_t nb = len - p;
-                    const uint32_t wv[4] = {oblk.x, oblk.y, oblk.z, oblk.w};
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; j++) {
-                        if (nb >= 4u * j + 4u) st4u(outb + p + 4u * j, wv[j]);
-                        else {
-#pragma unroll
-                            for (uint32_t bb = 0; bb < 3; bb++)
-                                if (nb > 4u * j + bb) outb[p + 4u * j + bb] = (uint8_t)(wv[j] >> (8u * bb));
-                        }
-                    }
-                }
-                if (p == 0) break;
-                mblk = mnext;
-                rblk = rnext;
-                if (p >= 32u) {
-                    mnext = ld16u(msb, p - 32u);
-                    if (ref) rnext = ld16u(refb, p - 32u);
-                }
-            }
-        }
-        p--;
-        x_next = x_cur;
-        x_cur = x_prev;
+        uint4 oblk = make_uint4(0, 0, 0, 0);
+        const uint32_t p0 = 16u * bi;
+#define KBO_DT(J) dt_step<J>(st, cur, below, rcur, oblk, p0 + J, len, K, T, fmt, dout ? dout + p0 + J : nullptr);
+        KBO_DT(15) KBO_DT(14) KBO_DT(13) KBO_DT(12) KBO_DT(11) KBO_DT(10) KBO_DT(9) KBO_DT(8)
+        KBO_DT(7) KBO_DT(6) KBO_DT(5) KBO_DT(4) KBO_DT(3) KBO_DT(2) KBO_DT(1) KBO_DT(0)
+#undef KBO_DT
+        if (p0 + 16u <= len) st16u(outb, p0, oblk);
+        else st_partial(outb + p0, oblk, len - p0); // topmost, partial block of the sequence
+        cur = below;
+        rcur = rbelow;
     }
 }
 

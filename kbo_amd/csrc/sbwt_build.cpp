@@ -391,9 +391,25 @@ void make_device_layout(const HostIndex &h, DeviceLayout &out)
             }
         }
     }
-    size_t padded = ((n + 1 + 15) / 16) * 16 + 16;
-    out.lcs.assign(padded, 0);
-    std::memcpy(out.lcs.data(), h.lcs.data(), n);
+    // previous / next strictly-smaller LCS value (monotone stack, O(n))
+    out.ent.assign(3 * (n + 1) + 4, 0);
+    auto lcs_at = [&](uint64_t i) -> uint32_t { return i < n ? h.lcs[i] : 0u; };
+    std::vector<uint32_t> stack;
+    stack.reserve(256);
+    for (uint64_t i = 0; i <= n; i++) {
+        const uint32_t v = lcs_at(i);
+        while (!stack.empty() && lcs_at(stack.back()) >= v) stack.pop_back();
+        out.ent[3 * i + 0] = v;
+        out.ent[3 * i + 1] = stack.empty() ? 0u : stack.back();
+        stack.push_back((uint32_t)i);
+    }
+    stack.clear();
+    for (uint64_t ii = n + 1; ii-- > 0;) {
+        const uint32_t v = lcs_at(ii);
+        while (!stack.empty() && lcs_at(stack.back()) >= v) stack.pop_back();
+        out.ent[3 * ii + 2] = stack.empty() ? (uint32_t)n : stack.back();
+        stack.push_back((uint32_t)ii);
+    }
 }
 
 // ---- flat index file: magic, k, n_sets, n_kmers, C[4], rows[4], lcs --------------

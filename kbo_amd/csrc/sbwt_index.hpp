@@ -38,16 +38,19 @@ void build_host_index(const uint8_t *const *seqs, const size_t *lens, size_t n_s
 // so that   C[c] + rank_c(i) = cum + popcount(bits below (i - 96 b))   costs ONE
 // aligned 16-byte load.  n_blocks = n_sets / 96 + 2 (rank at i = n_sets is legal).
 //
-// LCS: one byte per row, lcs[n_sets] = 0 sentinel, zero-padded to a multiple of 16
-// plus one extra 16-byte window, so the contract-left scans are sentinel-terminated
-// (LCS[0] = 0 on the left, lcs[n_sets] = 0 on the right) and always read whole,
-// aligned 16-byte windows.
+// Contraction entries: for every row i (plus a sentinel at i = n_sets) 12 bytes
+//     { lcs[i], psv[i], nsv[i] }
+// with psv[i] = largest j < i with lcs[j] < lcs[i] and nsv[i] = smallest j > i with
+// lcs[j] < lcs[i] (lcs[0] = 0 and the sentinel lcs[n_sets] = 0 bound both searches).
+// contract_left([l,r), m) for m = max(lcs[l], lcs[r]) is then
+//     l' = lcs[l] == m ? psv[l] : l,   r' = lcs[r] == m ? nsv[r] : r
+// — two 12-byte loads and two compares instead of the reference's linear LCS scans.
 constexpr uint32_t kRankRowsPerBlock = 96;
 
 struct DeviceLayout {
     uint64_t n_blocks = 0;            // per character
     std::vector<uint32_t> rank[4];    // 4 * n_blocks words each
-    std::vector<uint8_t> lcs;         // padded
+    std::vector<uint32_t> ent;        // 3 * (n_sets + 1) words: {lcs, psv, nsv} per row
 };
 void make_device_layout(const HostIndex &h, DeviceLayout &out);
 

@@ -92,4 +92,4 @@ def test_device_layout_sizes():
     rank_bytes, lcs_bytes = prod.device_bytes()
     n = prod.n_sets()
     assert rank_bytes == (n // 96 + 2) * 16 * 4
-    assert lcs_bytes >= n + 1 and lcs_bytes % 16 == 0
+    assert lcs_bytes == (3 * (n + 1) + 4) * 4
