@@ -191,10 +191,12 @@ size_t kbo_work_bytes(size_t n_seqs);
 int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets,
                      size_t n_seqs, uint64_t total_bases, uint8_t *d_ms_out, uint32_t *d_lo_out,
                      uint32_t *d_hi_out, void *d_work, void *stream);
-/* A5+A6 fused (+ optional format::relative_to_ref when d_ref != NULL): u8 MS -> u8 chars. */
+/* A5+A6 fused (+ optional format::relative_to_ref when d_ref != NULL): u8 MS -> u8 chars.
+ * max_seq_len = length of the longest sequence in the batch if the caller knows it (selects
+ * the LDS-staged kernel for short reads), 0 = unknown. */
 int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, size_t n_seqs,
                              size_t k, size_t threshold, const uint8_t *d_ref, uint8_t *d_chars_out,
-                             void *stream);
+                             size_t max_seq_len, void *stream);
 /* Walk launch geometry: upper bound on resident waves, and threads per workgroup. */
 int kbo_walk_geometry(int *max_waves, int *threads);
 int kbo_set_walk_waves_per_cu(int waves_per_cu); /* tuning knob, 0 = default (32) */

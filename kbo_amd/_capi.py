@@ -126,7 +126,7 @@ def lib():
     L.kbo_find_batch.argtypes = [vp, vp, vp, sz, C.POINTER(FindOpts), C.POINTER(C.POINTER(RLE)), vp]
     L.kbo_work_bytes.argtypes = [sz]; L.kbo_work_bytes.restype = sz
     L.kbo_ms_batch_dev.argtypes = [vp, vp, vp, sz, u64, vp, vp, vp, vp, vp]
-    L.kbo_derand_translate_dev.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp]
+    L.kbo_derand_translate_dev.argtypes = [vp, vp, sz, sz, sz, vp, vp, sz, vp]
     L.kbo_walk_geometry.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.kbo_set_walk_waves_per_cu.argtypes = [C.c_int]
     L.kbo_set_walk_threads.argtypes = [C.c_int]

@@ -75,6 +75,7 @@ class DeviceBatch:
         concat, offsets, n = _prep(concat, offsets)
         self.n_seqs = n
         self.total = int(offsets[-1])
+        self.max_len = int(np.max(np.diff(offsets.astype(np.int64)))) if n else 0
         self.k = sbwt.k()
         self.threshold = derandomize.random_match_threshold(self.k, sbwt.n_kmers(), 4, max_error_prob)
         pad = (self.total + 15) // 16 * 16 + 64
@@ -102,7 +103,7 @@ class DeviceBatch:
         s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
         check(lib().kbo_derand_translate_dev(self.ms.data_ptr(), self.off.data_ptr(), self.n_seqs, self.k,
                                              self.threshold, self.q.data_ptr() if self.format else None,
-                                             self.chars.data_ptr(), s.cuda_stream))
+                                             self.chars.data_ptr(), self.max_len, s.cuda_stream))
 
     def run(self, stream=None):
         self.walk(stream)

@@ -243,6 +243,13 @@ void check_batch(const void *concat, const uint64_t *offsets, size_t n_seqs)
     KBO_REQUIRE(offsets[0] == 0, KBO_E_BAD_ARG, "offsets[0] must be 0");
 }
 
+uint32_t max_len(const uint64_t *offsets, size_t n_seqs)
+{
+    uint64_t m = 0;
+    for (size_t s = 0; s < n_seqs; s++) m = std::max(m, offsets[s + 1] - offsets[s]);
+    return (uint32_t)std::min<uint64_t>(m, 0xFFFFFFFFu);
+}
+
 struct BatchOnDevice {
     DevBuf q, off, items, ms, lo, hi;
     uint64_t total = 0;
@@ -316,7 +323,7 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
     HIP_OK(kbo::launch_derand_translate(B.ms.as<uint8_t>(), B.off.as<uint64_t>(), (uint32_t)n_seqs,
                                         (uint32_t)k, (uint32_t)threshold,
                                         format ? B.q.as<uint8_t>() : nullptr, chars.as<uint8_t>(), nullptr,
-                                        stream));
+                                        max_len(offsets, n_seqs), stream));
     HIP_OK(hipMemcpyAsync(chars_out, chars.p, B.total, hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
 }
@@ -594,7 +601,7 @@ int kbo_derandomize_ms_vec(const uint64_t *noisy, size_t len, size_t k, size_t t
         HIP_OK(hipMemcpyAsync(doff.p, off, sizeof(off), hipMemcpyHostToDevice, stream));
         HIP_OK(kbo::launch_derand_translate(dms.as<uint8_t>(), doff.as<uint64_t>(), 1, (uint32_t)k,
                                             (uint32_t)std::min<size_t>(threshold, 0x7FFFFFFF), nullptr,
-                                            dch.as<uint8_t>(), dder.as<int32_t>(), stream));
+                                            dch.as<uint8_t>(), dder.as<int32_t>(), 0, stream));
         std::vector<int32_t> d32(len);
         HIP_OK(hipMemcpyAsync(d32.data(), dder.p, len * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         HIP_OK(hipStreamSynchronize(stream));
@@ -780,7 +787,8 @@ int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *
 }
 
 int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, size_t n_seqs, size_t k,
-                             size_t threshold, const uint8_t *d_ref, uint8_t *d_chars_out, void *stream)
+                             size_t threshold, const uint8_t *d_ref, uint8_t *d_chars_out,
+                             size_t max_seq_len, void *stream)
 {
     return guarded([&] {
         KBO_REQUIRE(d_ms && d_offsets && d_chars_out, KBO_E_BAD_ARG, "null argument");
@@ -790,7 +798,9 @@ int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, siz
         KBO_REQUIRE(((uintptr_t)d_ms & 3) == 0 && ((uintptr_t)d_chars_out & 3) == 0 && ((uintptr_t)d_ref & 3) == 0,
                     KBO_E_BAD_ARG, "device buffers must be 4-byte aligned");
         HIP_OK(kbo::launch_derand_translate(d_ms, d_offsets, (uint32_t)n_seqs, (uint32_t)k, (uint32_t)threshold,
-                                            d_ref, d_chars_out, nullptr, static_cast<hipStream_t>(stream)));
+                                            d_ref, d_chars_out, nullptr,
+                                            (uint32_t)std::min<size_t>(max_seq_len, 0xFFFFFFFFu),
+                                            static_cast<hipStream_t>(stream)));
     });
 }
 

@@ -44,10 +44,12 @@ hipError_t launch_make_items(const uint64_t *d_offsets, uint32_t n_seqs, WalkIte
 // A1: k-bounded matching statistics over all items
 hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream);
 // A5+A6 (+ optional relative_to_ref when ref != nullptr, + optional i32 derandomised
-// values when derand_out != nullptr): one lane per sequence.
+// values when derand_out != nullptr): one lane per sequence.  max_seq_len = length of the
+// longest sequence if known (0 = unknown); short reads take the LDS-staged kernel.
 hipError_t launch_derand_translate(const uint8_t *d_ms, const uint64_t *d_offsets, uint32_t n_seqs,
                                    uint32_t k, uint32_t threshold, const uint8_t *d_ref,
-                                   uint8_t *d_chars_out, int32_t *d_derand_out, hipStream_t stream);
+                                   uint8_t *d_chars_out, int32_t *d_derand_out, uint32_t max_seq_len,
+                                   hipStream_t stream);
 // A6 alone on clamped i32 derandomised values: one lane per position.
 hipError_t launch_translate(const int32_t *d_derand, uint64_t len, uint32_t k, uint32_t threshold,
                             uint8_t *d_chars_out, hipStream_t stream);
