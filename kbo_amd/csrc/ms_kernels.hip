@@ -30,10 +30,10 @@ enum : uint32_t {
     F_HAVE = 2u,  // next item (descriptor + first two query words) is prefetched
     F_PF = 4u,    // next item's descriptor is in flight, its query words not yet requested
     // bits >= F_BLOCK take the lane out of the hot path until the rare block has run
-    F_CON = 8u,   // needs contract-left
+    F_CON = 8u,   // contracting: loads contraction entries instead of rank blocks
     F_DONE = 32u, // finished its item, wants the next one
     F_FIN = 64u,  // no items left
-    F_BLOCK = 8u
+    F_BLOCK = 32u
 };
 
 // Rank inside one 16-byte block { base, w0, w1, w2 }: base + popcount of the o lowest of
@@ -68,12 +68,6 @@ __device__ __forceinline__ uint4 ld16u(const uint8_t *base, uint32_t byte_off)
 {
     uint4 v;
     __builtin_memcpy(&v, base + byte_off, 16);
-    return v;
-}
-__device__ __forceinline__ uint3 ld12(const uint8_t *base, uint32_t byte_off)
-{
-    uint3 v;
-    __builtin_memcpy(&v, base + byte_off, 12);
     return v;
 }
 // unaligned stores
@@ -180,75 +174,10 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
     for (uint32_t iter = 0;; iter++) {
         dbg_iter = iter;
         // ================================ rare block ================================
-        const uint64_t blocked = __ballot((flags & (F_CON | F_DONE)) != 0);
+        const uint64_t blocked = __ballot((flags & F_DONE) != 0);
         const uint64_t hot = __ballot(flags < F_BLOCK);
         if (hot == 0 || (blocked != 0 && ((uint32_t)__popcll(blocked) >= a.rare_batch || (iter & a.rare_mask) == 0))) {
             dbg_rare++;
-            // ---- contract-left for every lane that asked for it.
-            // The reference steps d-1, d-2, ... and re-tries the extension each time.  Two facts
-            // make that a short walk up the LCS interval tree:
-            //  (i) contract_left(I, t) leaves I unchanged for t > m = max(lcs[l], lcs[r]) and at
-            //      t = m moves exactly the side(s) whose boundary value is m, to psv[l] / nsv[r];
-            //  (ii) the extension stays empty until the interval reaches the nearest set bit of
-            //      B_c below l (row l - dl) or at/after r (row r + dr).
-            // So: climb one tree level per round (two 12-byte loads) until (ii) holds, then hand
-            // the lane back to the hot path, whose next extension succeeds at exactly the depth
-            // where the reference's loop stops.  If a nearest bit lies outside the loaded rank
-            // block, stop after one level (the hot path re-tries and comes back if needed).
-            if (flags & F_CON) {
-                const uint32_t bl = div96(l), br = div96(r);
-                const bool null_c = cb == null_blk;
-                const uint4 bA = ld16(arena, (null_c ? cb : cb + bl) << 4);
-                const uint4 bB = ld16(arena, (null_c ? cb : cb + br) << 4);
-                const uint32_t ol = l - bl * kRankRows, orr = r - br * kRankRows;
-                uint32_t dl = 0, dr = 0; // 0 = unknown
-                {
-                    const uint64_t X = ~0ull << (ol & 63u);
-                    const uint32_t xl = (uint32_t)X, xh = (uint32_t)(X >> 32);
-                    const bool big = ol >= 64u;
-                    const uint32_t y = bA.y & ~(big ? 0u : xl), z = bA.z & ~(big ? 0u : xh),
-                                   w = bA.w & ~(big ? xl : ~0u);
-                    int top = -1; // highest set bit strictly below ol
-                    if (y) top = 31 - __clz((int)y);
-                    if (z) top = 63 - __clz((int)z);
-                    if (w) top = 95 - __clz((int)w);
-                    if (top >= 0) dl = ol - (uint32_t)top;
-                }
-                {
-                    const uint64_t X = ~0ull << (orr & 63u);
-                    const uint32_t xl = (uint32_t)X, xh = (uint32_t)(X >> 32);
-                    const bool big = orr >= 64u;
-                    const uint32_t y = bB.y & (big ? 0u : xl), z = bB.z & (big ? 0u : xh),
-                                   w = bB.w & (big ? xl : ~0u);
-                    int low = -1; // lowest set bit at or above orr
-                    if (w) low = 64 + __ffs((int)w) - 1;
-                    if (z) low = 32 + __ffs((int)z) - 1;
-                    if (y) low = __ffs((int)y) - 1;
-                    if (low >= 0) dr = (uint32_t)low - orr + 1u; // rows to pass on the right
-                }
-                // targets: stop once l <= tgt_l or r >= tgt_r (0 / ~0 = unknown: single level)
-                m = (dl && dr) ? 1u : 0u;            // targets known?
-                tgt_l = l - dl;                  // row of the nearest set bit below l
-                tgt_r = r + dr;                  // one past the nearest set bit at/after r
-            }
-            while (__ballot((flags & F_CON) != 0)) {
-                dbg_con++;
-                if (flags & F_CON) {
-                    const uint3 el = ld12(arena, ent_byte0 + l * 12u);
-                    const uint3 er = ld12(arena, ent_byte0 + r * 12u);
-                    const uint32_t lv = max(el.x, er.x);
-                    d = lv;
-                    if (lv == 0) {
-                        l = 0;
-                        r = n;
-                        flags &= ~F_CON;
-                    } else {
-                        l = el.x == lv ? el.y : l;
-                        r = er.x == lv ? er.z : r;
-                        if (!m || l <= tgt_l || r >= tgt_r) flags &= ~F_CON;
-                    }
-                }
-            }
             // ---- request the first query block of the next item once its descriptor is here
             if (flags & F_PF) {
                 nq0 = ld16u(qb, nit.x);
@@ -284,62 +213,122 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
         }
 
         // ================================= hot path =================================
+        // A lane is either extending (two rank blocks) or contracting (two contraction
+        // entries {lcs, psv, nsv}); both kinds of load go through the same two load sites and
+        // are consumed one wait later, so contracting lanes never stall the wave.
+        //
+        // Contraction (bit-identical to the reference's d-1, d-2, ... loop):
+        //  (i) contract_left(I, t) leaves I unchanged for t > m = max(lcs[l], lcs[r]) and at
+        //      t = m moves exactly the side(s) whose boundary value is m, to psv[l] / nsv[r];
+        //  (ii) the extension stays empty until the interval reaches the nearest set bit of
+        //      B_c below l (row tgt_l) or passes the nearest one at/after r (row tgt_r - 1).
+        // So a failing lane climbs one LCS-interval-tree level per iteration until (ii) holds
+        // and then extends successfully at exactly the depth where the reference's loop stops.
+        // If a nearest bit lies outside the loaded rank block, it climbs a single level and
+        // re-tries the extension.
         if (flags < F_BLOCK) {
+            const bool con = (flags & F_CON) != 0;
             const uint32_t bl = div96(l), br = div96(r);
             const bool null_c = cb == null_blk;
-            const uint4 xA = ld16(arena, (null_c ? cb : cb + bl) << 4);
-            const uint4 xB = ld16(arena, (null_c ? cb : cb + br) << 4);
+            const uint32_t offA = con ? ent_byte0 + l * 12u : (null_c ? cb : cb + bl) << 4;
+            const uint32_t offB = con ? ent_byte0 + r * 12u : (null_c ? cb : cb + br) << 4;
+            const uint4 xA = ld16u(arena, offA);
+            const uint4 xB = ld16u(arena, offB);
             if (flags & F_QF) { // the query block after the current one (reads <= 16 bytes past the item)
                 qnxt = ld16u(qb, min(start + (i & ~15u) + 16u, q_end)); // stays within the 16-byte slack
                 flags &= ~F_QF;
             }
-            const uint32_t l2 = rank_eval(xA, l - bl * kRankRows), r2 = rank_eval(xB, r - br * kRankRows);
-            const bool ok = l2 < r2;
-            if (ok) {
-                l = l2;
-                r = r2;
-                d = min(d + 1, k);
-            }
-            if (ok || d == 0) {
-                if (i >= warm) { // emit: output byte e = i - warm of this item
-                    const uint32_t e = i - warm;
-                    ocur |= d << ((e & 3u) * 8u);
-                    if (IVAL) {
-                        a.lo_out[start + i] = l;
-                        a.hi_out[start + i] = r;
-                    }
-                    const bool fin_e = (i + 1 == len);
-                    if ((e & 3u) == 3u || fin_e) { // word complete (or item ends): move it into the block
-                        const uint32_t w = (e >> 2) & 3u;
-                        oblk.x = w == 0 ? ocur : oblk.x;
-                        oblk.y = w == 1 ? ocur : oblk.y;
-                        oblk.z = w == 2 ? ocur : oblk.z;
-                        oblk.w = w == 3 ? ocur : oblk.w;
-                        ocur = 0;
-                        if ((e & 15u) == 15u) { // full block: one unaligned 16-byte store
-                            st16u(a.d_out, start + warm + (e & ~15u), oblk);
-                        } else if (fin_e) { // tail of the item: words, then bytes
-                            st_partial(a.d_out + (start + warm + (e & ~15u)), oblk, (e & 15u) + 1u);
-                        }
-                    }
-                }
-                i++;
-                if (i == len) flags |= F_DONE;
-                else {
-                    if ((i & 3u) == 0) {
-                        if ((i & 15u) == 0) {
-                            qblk = qnxt;
-                            flags |= F_QF;
-                        }
-                        const uint32_t w = (i >> 2) & 3u;
-                        const uint32_t lo = (w & 1u) ? qblk.y : qblk.x, hi = (w & 1u) ? qblk.w : qblk.z;
-                        qcur = (w & 2u) ? hi : lo;
-                    }
-                    const uint32_t c = decode_base((qcur >> ((i & 3u) * 8u)) & 0xFFu);
-                    cb = c < 4u ? c * nblk : null_blk;
+            if (con) { // one level up the LCS interval tree
+                dbg_con++;
+                const uint32_t lv = max(xA.x, xB.x);
+                d = lv;
+                if (lv == 0) {
+                    l = 0;
+                    r = n;
+                    flags &= ~F_CON;
+                } else {
+                    l = xA.x == lv ? xA.y : l;
+                    r = xB.x == lv ? xB.z : r;
+                    if (!m || l <= tgt_l || r >= tgt_r) flags &= ~F_CON;
                 }
             } else {
-                flags |= F_CON;
+                const uint32_t ol = l - bl * kRankRows, orr = r - br * kRankRows;
+                const uint32_t l2 = rank_eval(xA, ol), r2 = rank_eval(xB, orr);
+                const bool ok = l2 < r2;
+                if (ok) {
+                    l = l2;
+                    r = r2;
+                    d = min(d + 1, k);
+                }
+                if (ok || d == 0) {
+                    if (i >= warm) { // emit: output byte e = i - warm of this item
+                        const uint32_t e = i - warm;
+                        ocur |= d << ((e & 3u) * 8u);
+                        if (IVAL) {
+                            a.lo_out[start + i] = l;
+                            a.hi_out[start + i] = r;
+                        }
+                        const bool fin_e = (i + 1 == len);
+                        if ((e & 3u) == 3u || fin_e) { // word complete (or item ends): move it into the block
+                            const uint32_t w = (e >> 2) & 3u;
+                            oblk.x = w == 0 ? ocur : oblk.x;
+                            oblk.y = w == 1 ? ocur : oblk.y;
+                            oblk.z = w == 2 ? ocur : oblk.z;
+                            oblk.w = w == 3 ? ocur : oblk.w;
+                            ocur = 0;
+                            if ((e & 15u) == 15u) { // full block: one unaligned 16-byte store
+                                st16u(a.d_out, start + warm + (e & ~15u), oblk);
+                            } else if (fin_e) { // tail of the item: words, then bytes
+                                st_partial(a.d_out + (start + warm + (e & ~15u)), oblk, (e & 15u) + 1u);
+                            }
+                        }
+                    }
+                    i++;
+                    if (i == len) flags |= F_DONE;
+                    else {
+                        if ((i & 3u) == 0) {
+                            if ((i & 15u) == 0) {
+                                qblk = qnxt;
+                                flags |= F_QF;
+                            }
+                            const uint32_t w = (i >> 2) & 3u;
+                            const uint32_t lo = (w & 1u) ? qblk.y : qblk.x, hi = (w & 1u) ? qblk.w : qblk.z;
+                            qcur = (w & 2u) ? hi : lo;
+                        }
+                        const uint32_t c = decode_base((qcur >> ((i & 3u) * 8u)) & 0xFFu);
+                        cb = c < 4u ? c * nblk : null_blk;
+                    }
+                } else { // empty extension at depth d > 0: contract.  Nearest set bits of B_c:
+                    uint32_t dl = 0, dr = 0; // 0 = not inside the loaded block
+                    {
+                        const uint64_t X = ~0ull << (ol & 63u);
+                        const uint32_t xl = (uint32_t)X, xh = (uint32_t)(X >> 32);
+                        const bool big = ol >= 64u;
+                        const uint32_t y = xA.y & ~(big ? 0u : xl), z = xA.z & ~(big ? 0u : xh),
+                                       w = xA.w & ~(big ? xl : ~0u);
+                        int top = -1; // highest set bit strictly below ol
+                        if (y) top = 31 - __clz((int)y);
+                        if (z) top = 63 - __clz((int)z);
+                        if (w) top = 95 - __clz((int)w);
+                        if (top >= 0) dl = ol - (uint32_t)top;
+                    }
+                    {
+                        const uint64_t X = ~0ull << (orr & 63u);
+                        const uint32_t xl = (uint32_t)X, xh = (uint32_t)(X >> 32);
+                        const bool big = orr >= 64u;
+                        const uint32_t y = xB.y & (big ? 0u : xl), z = xB.z & (big ? 0u : xh),
+                                       w = xB.w & (big ? xl : ~0u);
+                        int low = -1; // lowest set bit at or above orr
+                        if (w) low = 64 + __ffs((int)w) - 1;
+                        if (z) low = 32 + __ffs((int)z) - 1;
+                        if (y) low = __ffs((int)y) - 1;
+                        if (low >= 0) dr = (uint32_t)low - orr + 1u; // rows to pass on the right
+                    }
+                    m = (dl && dr) ? 1u : 0u; // targets known?
+                    tgt_l = l - dl;           // row of the nearest set bit below l
+                    tgt_r = r + dr;           // one past the nearest set bit at/after r
+                    flags |= F_CON;
+                }
             }
         }
     }
