@@ -14,7 +14,10 @@ from kbo_amd import batch, synth  # noqa: E402
 G = int(os.environ.get("G", 5_000_000))
 R = int(os.environ.get("R", 1_000_000))
 g = synth.genome(G)
-sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=16))
+import time as _t
+_t0 = _t.time()
+sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=32))
+print("build s", _t.time() - _t0, "n_sets", sbwt.n_sets(), "device bytes", sbwt.device_bytes(), flush=True)
 concat, offsets = synth.reads(g, R, 150, float(os.environ.get("SUB", 0.01)))
 dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"))
 stream = torch.cuda.current_stream()
