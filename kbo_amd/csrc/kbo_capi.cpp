@@ -307,6 +307,31 @@ void check_len_threshold(const uint64_t *offsets, size_t n_seqs, size_t k, size_
                     "len > 2 (derandomize.rs:276, translate.rs:270)");
 }
 
+// A5+A6 over a batch whose offsets are known on the host: reads -> LDS kernel, medium
+// sequences -> one lane each, very long sequences -> chunked scan (one at a time).
+void derand_translate_host_offsets(const uint8_t *d_ms, const uint64_t *d_off, const uint64_t *offsets, size_t n_seqs,
+                                   uint32_t k, uint32_t threshold, const uint8_t *d_ref, uint8_t *d_chars,
+                                   int32_t *d_derand, hipStream_t stream)
+{
+    const uint32_t mx = max_len(offsets, n_seqs);
+    HIP_OK(kbo::launch_derand_translate(d_ms, d_off, (uint32_t)n_seqs, k, threshold, d_ref, d_chars, d_derand, mx,
+                                        kbo::kLongSeq, stream));
+    if (mx <= kbo::kLongSeq) return;
+    size_t need = 0;
+    for (size_t s = 0; s < n_seqs; s++) {
+        const uint64_t len = offsets[s + 1] - offsets[s];
+        if (len > kbo::kLongSeq) need = std::max(need, kbo::derand_long_scratch_bytes(len, k, threshold));
+    }
+    DevBuf scratch(need);
+    for (size_t s = 0; s < n_seqs; s++) {
+        const uint64_t b = offsets[s], len = offsets[s + 1] - offsets[s];
+        if (len <= kbo::kLongSeq) continue;
+        HIP_OK(kbo::launch_derand_long(d_ms + b, (uint32_t)len, k, threshold, d_ref ? d_ref + b : nullptr, d_chars + b,
+                                       d_derand ? d_derand + b : nullptr, scratch.p, stream));
+    }
+    HIP_OK(hipStreamSynchronize(stream)); // scratch is released on return
+}
+
 // kbo::matches over a batch (lib.rs:618-627); optional relative_to_ref (lib.rs:756-757)
 void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                         double max_error_prob, bool format, uint8_t *chars_out)
@@ -320,10 +345,9 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
     BatchOnDevice B;
     run_walk_host(idx, concat, offsets, n_seqs, false, B, stream);
     DevBuf chars(((B.total + 15) / 16) * 16 + 16);
-    HIP_OK(kbo::launch_derand_translate(B.ms.as<uint8_t>(), B.off.as<uint64_t>(), (uint32_t)n_seqs,
-                                        (uint32_t)k, (uint32_t)threshold,
-                                        format ? B.q.as<uint8_t>() : nullptr, chars.as<uint8_t>(), nullptr,
-                                        max_len(offsets, n_seqs), stream));
+    derand_translate_host_offsets(B.ms.as<uint8_t>(), B.off.as<uint64_t>(), offsets, n_seqs, (uint32_t)k,
+                                  (uint32_t)threshold, format ? B.q.as<uint8_t>() : nullptr, chars.as<uint8_t>(),
+                                  nullptr, stream);
     HIP_OK(hipMemcpyAsync(chars_out, chars.p, B.total, hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
 }
@@ -599,9 +623,9 @@ int kbo_derandomize_ms_vec(const uint64_t *noisy, size_t len, size_t k, size_t t
         DevBuf dms(n8.size()), doff(sizeof(off)), dch(n8.size()), dder(len * sizeof(int32_t));
         HIP_OK(hipMemcpyAsync(dms.p, n8.data(), n8.size(), hipMemcpyHostToDevice, stream));
         HIP_OK(hipMemcpyAsync(doff.p, off, sizeof(off), hipMemcpyHostToDevice, stream));
-        HIP_OK(kbo::launch_derand_translate(dms.as<uint8_t>(), doff.as<uint64_t>(), 1, (uint32_t)k,
-                                            (uint32_t)std::min<size_t>(threshold, 0x7FFFFFFF), nullptr,
-                                            dch.as<uint8_t>(), dder.as<int32_t>(), 0, stream));
+        derand_translate_host_offsets(dms.as<uint8_t>(), doff.as<uint64_t>(), off, 1, (uint32_t)k,
+                                      (uint32_t)std::min<size_t>(threshold, 0x7FFFFFFF), nullptr,
+                                      dch.as<uint8_t>(), dder.as<int32_t>(), stream);
         std::vector<int32_t> d32(len);
         HIP_OK(hipMemcpyAsync(d32.data(), dder.p, len * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         HIP_OK(hipStreamSynchronize(stream));
@@ -799,7 +823,7 @@ int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, siz
                     KBO_E_BAD_ARG, "device buffers must be 4-byte aligned");
         HIP_OK(kbo::launch_derand_translate(d_ms, d_offsets, (uint32_t)n_seqs, (uint32_t)k, (uint32_t)threshold,
                                             d_ref, d_chars_out, nullptr,
-                                            (uint32_t)std::min<size_t>(max_seq_len, 0xFFFFFFFFu),
+                                            (uint32_t)std::min<size_t>(max_seq_len, 0xFFFFFFFFu), 0xFFFFFFFFu,
                                             static_cast<hipStream_t>(stream)));
     });
 }

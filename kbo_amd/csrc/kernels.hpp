@@ -49,7 +49,13 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream);
 hipError_t launch_derand_translate(const uint8_t *d_ms, const uint64_t *d_offsets, uint32_t n_seqs,
                                    uint32_t k, uint32_t threshold, const uint8_t *d_ref,
                                    uint8_t *d_chars_out, int32_t *d_derand_out, uint32_t max_seq_len,
-                                   hipStream_t stream);
+                                   uint32_t per_lane_max_len, hipStream_t stream);
+// A5+A6 for ONE very long sequence (pointers already offset to its first byte): chunked
+// three-level scan over per-chunk transition tables; d_scratch >= derand_long_scratch_bytes().
+size_t derand_long_scratch_bytes(uint64_t len, uint32_t k, uint32_t threshold);
+hipError_t launch_derand_long(const uint8_t *d_ms, uint32_t len, uint32_t k, uint32_t threshold, const uint8_t *d_ref,
+                              uint8_t *d_chars_out, int32_t *d_derand_out, void *d_scratch, hipStream_t stream);
+constexpr uint32_t kLongSeq = 1u << 16; // sequences longer than this take the chunked path
 // A6 alone on clamped i32 derandomised values: one lane per position.
 hipError_t launch_translate(const int32_t *d_derand, uint64_t len, uint32_t k, uint32_t threshold,
                             uint8_t *d_chars_out, hipStream_t stream);

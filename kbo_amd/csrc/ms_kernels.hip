@@ -428,13 +428,15 @@ __device__ __forceinline__ void dt_step(DtState &st, const uint4 &cur, const uin
 // block the 16 positions are unrolled so every byte access is a constant bit-field.
 __global__ __launch_bounds__(256) void derand_translate_kernel(
     const uint8_t *__restrict__ ms, const uint64_t *__restrict__ off, uint32_t n_seqs, uint32_t k,
-    uint32_t t, const uint8_t *__restrict__ ref, uint8_t *__restrict__ out, int32_t *__restrict__ derand_out)
+    uint32_t t, const uint8_t *__restrict__ ref, uint8_t *__restrict__ out, int32_t *__restrict__ derand_out,
+    uint32_t max_len)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seqs) return;
     const uint64_t b = off[s], e = off[s + 1];
     const uint32_t len = (uint32_t)(e - b);
-    if (len < 3) return; // the host side rejects these (derandomize.rs:276)
+    if (len < 3) return;       // the host side rejects these (derandomize.rs:276)
+    if (len > max_len) return; // longer sequences take the chunked path (launch_derand_long)
     const int K = (int)k, T = (int)t;
     const uint8_t *msb = ms + b;
     const bool fmt = ref != nullptr;
@@ -533,6 +535,122 @@ __global__ __launch_bounds__(64) void derand_translate_lds_kernel(
     }
 }
 
+// ---- one very long sequence: chunked derandomize ---------------------------------------
+// The recurrence x[i] = f(noisy[i], x[i+1]) only ever compares x with values in (t, k], so
+// for decisions x matters through the finite state  S(x) = x > t ? x - t : 0  (k - t + 1
+// states); a value <= t keeps counting down exactly until some position "fires" (reset
+// noisy == k, anchor noisy > t && x < noisy, or the last position's own rule).  Every chunk
+// of positions is therefore a function  x_in -> x_out  described by one entry per state:
+//     fired ? (exact x_out) : x_in - chunk_len
+// Tables compose exactly, which gives a three-level scan: per-chunk tables (parallel),
+// per-group tables (parallel over groups x states), one short sequential pass over the
+// groups, inputs per chunk (parallel over groups), and the final per-chunk pass that emits
+// characters (parallel).  Bit-identical to the sequential loop.
+constexpr uint32_t kDlChunk = 128;  // positions per chunk
+constexpr uint32_t kDlGroup = 128;  // chunks per group
+constexpr int32_t kDlPass = (int32_t)0x80000000; // table value: "not fired, x_out = x_in - len"
+
+__device__ __forceinline__ int dl_step(int a, int x, uint32_t p, uint32_t len, int K, int T, bool &fired)
+{
+    if (p == len - 1) { fired = true; return a > T ? a : 0; }   // derandomize.rs:282
+    if (a == K) { fired = true; return K; }                      // derandomize.rs:235-238
+    if (a > T && x < a) { fired = true; return a; }              // derandomize.rs:240-244
+    return x - 1;
+}
+__device__ __forceinline__ uint32_t dl_state(int x, int T) { return x > T ? (uint32_t)(x - T) : 0u; }
+__device__ __forceinline__ int dl_apply(int32_t entry, int x_in, uint32_t span) { return entry == kDlPass ? x_in - (int)span : entry; }
+
+// lane = (chunk, state)
+__global__ void dl_chunk_tables_kernel(const uint8_t *__restrict__ ms, uint32_t len, uint32_t k, uint32_t t,
+                                       uint32_t n_chunks, uint32_t n_states, int32_t *__restrict__ t1)
+{
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_chunks * n_states) return;
+    const uint32_t c = id / n_states, st = id % n_states;
+    const int K = (int)k, T = (int)t;
+    const uint32_t p0 = c * kDlChunk, p1 = min(len, p0 + kDlChunk);
+    int x = T + (int)st; // representative of the state (st == 0: any value <= t)
+    bool fired = false;
+    for (uint32_t p = p1; p-- > p0;) x = dl_step(ms[p], x, p, len, K, T, fired);
+    t1[id] = fired ? x : kDlPass;
+}
+
+// lane = (group, state): compose the chunk tables of the group, right to left
+__global__ void dl_group_tables_kernel(const int32_t *__restrict__ t1, uint32_t len, uint32_t t, uint32_t n_chunks,
+                                       uint32_t n_groups, uint32_t n_states, int32_t *__restrict__ t2)
+{
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_groups * n_states) return;
+    const uint32_t g = id / n_states, st = id % n_states;
+    const int T = (int)t;
+    const uint32_t c0 = g * kDlGroup, c1 = min(n_chunks, c0 + kDlGroup);
+    int x = T + (int)st;
+    bool fired = false;
+    for (uint32_t c = c1; c-- > c0;) {
+        const uint32_t span = min(len, (c + 1) * kDlChunk) - c * kDlChunk;
+        const int32_t e = t1[c * n_states + dl_state(x, T)];
+        fired = fired || e != kDlPass;
+        x = dl_apply(e, x, span);
+    }
+    t2[id] = fired ? x : kDlPass;
+}
+
+// one lane: exact x entering every group (from its right)
+__global__ void dl_top_kernel(const int32_t *__restrict__ t2, uint32_t len, uint32_t t, uint32_t n_groups,
+                              uint32_t n_states, int32_t *__restrict__ g_in)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const int T = (int)t;
+    int x = 0; // irrelevant: the last position's rule ignores it
+    for (uint32_t g = n_groups; g-- > 0;) {
+        g_in[g] = x;
+        const uint32_t p0 = g * kDlGroup * kDlChunk, p1 = min(len, p0 + kDlGroup * kDlChunk);
+        x = dl_apply(t2[g * n_states + dl_state(x, T)], x, p1 - p0);
+    }
+}
+
+// lane = group: exact x entering every chunk of the group
+__global__ void dl_chunk_inputs_kernel(const int32_t *__restrict__ t1, const int32_t *__restrict__ g_in, uint32_t len,
+                                       uint32_t t, uint32_t n_chunks, uint32_t n_groups, uint32_t n_states,
+                                       int32_t *__restrict__ c_in)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const int T = (int)t;
+    const uint32_t c0 = g * kDlGroup, c1 = min(n_chunks, c0 + kDlGroup);
+    int x = g_in[g];
+    for (uint32_t c = c1; c-- > c0;) {
+        c_in[c] = x;
+        const uint32_t span = min(len, (c + 1) * kDlChunk) - c * kDlChunk;
+        x = dl_apply(t1[c * n_states + dl_state(x, T)], x, span);
+    }
+}
+
+// lane = chunk: final pass with the exact incoming value; emits characters (and values)
+__global__ void dl_emit_kernel(const uint8_t *__restrict__ ms, const int32_t *__restrict__ c_in, uint32_t len, uint32_t k,
+                               uint32_t t, uint32_t n_chunks, const uint8_t *__restrict__ ref, uint8_t *__restrict__ out,
+                               int32_t *__restrict__ derand_out)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const int K = (int)k, T = (int)t;
+    const uint32_t p0 = c * kDlChunk, p1 = min(len, p0 + kDlChunk);
+    int x_next = c_in[c]; // x[p1] (unused when p1 == len)
+    bool fired = false;
+    int x_cur = dl_step(ms[p1 - 1], x_next, p1 - 1, len, K, T, fired);
+    if (p1 == len) x_next = x_cur;
+    for (uint32_t p = p1; p-- > p0;) {
+        int x_prev = K;
+        if (p > 0) x_prev = dl_step(ms[p - 1], x_cur, p - 1, len, K, T, fired);
+        uint32_t ch = translate_char(x_prev, x_cur, x_next, p, len, K, T);
+        if (ref) ch = (ch == 'M' || ch == 'R') ? ref[p] : (uint32_t)'-';
+        out[p] = (uint8_t)ch;
+        if (derand_out) derand_out[p] = x_cur;
+        x_next = x_cur;
+        x_cur = x_prev;
+    }
+}
+
 __global__ void translate_kernel(const int32_t *__restrict__ x, uint64_t len, uint32_t k, uint32_t t,
                                  uint8_t *__restrict__ out)
 {
@@ -588,7 +706,7 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
 hipError_t launch_derand_translate(const uint8_t *d_ms, const uint64_t *d_offsets, uint32_t n_seqs,
                                    uint32_t k, uint32_t threshold, const uint8_t *d_ref,
                                    uint8_t *d_chars_out, int32_t *d_derand_out, uint32_t max_seq_len,
-                                   hipStream_t stream)
+                                   uint32_t per_lane_max_len, hipStream_t stream)
 {
     if (n_seqs == 0) return hipSuccess;
     // short sequences: LDS-staged kernel (64 sequences per wave must fit the LDS budget)
@@ -599,7 +717,37 @@ hipError_t launch_derand_translate(const uint8_t *d_ms, const uint64_t *d_offset
         return hipGetLastError();
     }
     hipLaunchKernelGGL(derand_translate_kernel, dim3((n_seqs + 255) / 256), dim3(256), 0, stream, d_ms,
-                       d_offsets, n_seqs, k, threshold, d_ref, d_chars_out, d_derand_out);
+                       d_offsets, n_seqs, k, threshold, d_ref, d_chars_out, d_derand_out, per_lane_max_len);
+    return hipGetLastError();
+}
+
+size_t derand_long_scratch_bytes(uint64_t len, uint32_t k, uint32_t threshold)
+{
+    const uint64_t n_chunks = (len + kDlChunk - 1) / kDlChunk, n_groups = (n_chunks + kDlGroup - 1) / kDlGroup;
+    const uint64_t n_states = (uint64_t)(k > threshold ? k - threshold : 0) + 1;
+    return (size_t)((n_chunks * n_states + n_groups * n_states + n_groups + n_chunks) * sizeof(int32_t) + 64);
+}
+
+hipError_t launch_derand_long(const uint8_t *d_ms, uint32_t len, uint32_t k, uint32_t threshold, const uint8_t *d_ref,
+                              uint8_t *d_chars_out, int32_t *d_derand_out, void *d_scratch, hipStream_t stream)
+{
+    if (len < 3) return hipSuccess;
+    const uint32_t n_chunks = (len + kDlChunk - 1) / kDlChunk, n_groups = (n_chunks + kDlGroup - 1) / kDlGroup;
+    const uint32_t n_states = (k > threshold ? k - threshold : 0) + 1;
+    int32_t *t1 = static_cast<int32_t *>(d_scratch);
+    int32_t *t2 = t1 + (size_t)n_chunks * n_states;
+    int32_t *g_in = t2 + (size_t)n_groups * n_states;
+    int32_t *c_in = g_in + n_groups;
+    const uint32_t T = 256;
+    hipLaunchKernelGGL(dl_chunk_tables_kernel, dim3((n_chunks * n_states + T - 1) / T), dim3(T), 0, stream, d_ms, len, k,
+                       threshold, n_chunks, n_states, t1);
+    hipLaunchKernelGGL(dl_group_tables_kernel, dim3((n_groups * n_states + T - 1) / T), dim3(T), 0, stream, t1, len,
+                       threshold, n_chunks, n_groups, n_states, t2);
+    hipLaunchKernelGGL(dl_top_kernel, dim3(1), dim3(64), 0, stream, t2, len, threshold, n_groups, n_states, g_in);
+    hipLaunchKernelGGL(dl_chunk_inputs_kernel, dim3((n_groups + T - 1) / T), dim3(T), 0, stream, t1, g_in, len, threshold,
+                       n_chunks, n_groups, n_states, c_in);
+    hipLaunchKernelGGL(dl_emit_kernel, dim3((n_chunks + T - 1) / T), dim3(T), 0, stream, d_ms, c_in, len, k, threshold,
+                       n_chunks, d_ref, d_chars_out, d_derand_out);
     return hipGetLastError();
 }
 

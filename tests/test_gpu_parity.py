@@ -145,6 +145,35 @@ def test_long_sequence_is_chunked_exactly(oracle):
     assert chars.tobytes() == ora.matches(q)
 
 
+def test_very_long_sequence_chunked_derandomize(oracle):
+    """> 64 kbp sequences take the chunked three-level derandomize scan (and the chunked walk)."""
+    g = synth.genome(400_000, seed=41)
+    sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=4))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    rng = np.random.default_rng(42)
+    q = bytearray(_mutate(rng, g[20_000:320_000].tobytes(), 0.03))
+    q[100_000:140_000] = rng.choice(list(b"ACGT"), size=40_000).astype(np.uint8).tobytes()  # long gap
+    q = bytes(q)
+    assert "".join(kbo_amd.matches(q, sbwt, lcs)) == ora.matches(q).decode()
+    opts = kbo_amd.BuildOpts(k=31, build_select=True)
+    mo = kbo_amd.MapOpts(fill_gaps=False, call_variants=False, format=True, sbwt_build_opts=opts)
+    assert kbo_amd.map(q, sbwt, lcs, mo) == oracle.relative_to_ref(q, ora.matches(q))
+
+
+@pytest.mark.parametrize("k,t", [(31, 22), (31, 30), (9, 2), (255, 120)])
+def test_long_derandomize_vs_oracle_adversarial(oracle, k, t):
+    """Chunked scan on inputs that defeat any bounded look-back: long reset-free stretches,
+    the x == noisy 'dead zone' (noisy = t+1 repeated), ramps crossing chunk and group edges."""
+    rng = np.random.default_rng(k * 7 + t)
+    n = 70_000 + int(rng.integers(0, 5000))
+    pieces = [np.full(n // 5, t + 1), rng.integers(0, k + 1, size=n // 5),
+              np.minimum(k, np.arange(n // 5) % (k + 3)), rng.choice([t, t + 1, min(k, t + 2)], size=n // 5)]
+    noisy = np.concatenate(pieces + [np.full(n - sum(len(p) for p in pieces), 1)])
+    noisy = np.clip(noisy, 0, k)
+    exp = oracle.derandomize_ms_vec(noisy, k, t)
+    assert derandomize.derandomize_ms_vec(noisy, k, t) == exp.tolist()
+
+
 @pytest.mark.parametrize("k,t", [(3, 2), (7, 3), (31, 22), (31, 16), (51, 23), (200, 100), (5, 5)])
 def test_derand_translate_vs_oracle_fuzz(oracle, k, t):
     """The fused kernel's closed-form translate vs the literal sequential oracle."""
