@@ -39,6 +39,7 @@ extern "C" {
 #define KBO_E_UNSUPPORTED (-8)    /* valid in the reference, not (yet) built here        */
 #define KBO_E_MS_RANGE (-9)       /* derandomize.rs:229-230  noisy/derand value > k     */
 #define KBO_E_IO (-10)            /* index.rs:137,202 file open/read/write failure      */
+#define KBO_E_REF_PANIC (-11)     /* the reference would panic here (index/usize underflow, assert!) */
 
 const char *kbo_last_error(void);
 const char *kbo_version(void);
@@ -77,6 +78,23 @@ typedef struct {
     kbo_build_opts sbwt_build_opts; /* build_select = true */
 } kbo_map_opts;
 void kbo_map_opts_default(kbo_map_opts *o);
+
+/* kbo::CallOpts (lib.rs:318-353) */
+typedef struct {
+    double max_error_prob;          /* 1e-7 */
+    kbo_build_opts sbwt_build_opts; /* build_select = true */
+} kbo_call_opts;
+void kbo_call_opts_default(kbo_call_opts *o);
+
+/* kbo::variant_calling::Variant (variant_calling.rs:8-26).  Arrays returned by kbo_call live
+ * in one allocation: release the whole result with a single kbo_free(variants). */
+typedef struct {
+    uint64_t query_pos;
+    const uint8_t *query_chars;
+    size_t query_len;
+    const uint8_t *ref_chars;
+    size_t ref_len;
+} kbo_variant;
 
 /* kbo::format::RLE (format.rs:18-33) */
 typedef struct {
@@ -151,6 +169,21 @@ int kbo_matches(kbo_index_t *idx, const uint8_t *query, size_t len, double max_e
 /* kbo::map (lib.rs:720-761): out holds len bytes. */
 int kbo_map(kbo_index_t *query_idx, const uint8_t *ref_seq, size_t len, const kbo_map_opts *opts,
             uint8_t *out);
+/* kbo::call (lib.rs:547-573): builds an index of ref_seq, runs variant_calling::call_variants
+ * (variant_calling.rs:249-294; all MS passes on the GPU, k-mer walks of the sites batched). */
+int kbo_call(kbo_index_t *query_idx, const uint8_t *ref_seq, size_t len, const kbo_call_opts *opts,
+             kbo_variant **out, size_t *n_out);
+/* translate::add_variants (translate.rs:350-386) on Rust-char (u32) alignment strings, in place. */
+int kbo_add_variants(uint32_t *translation, size_t len, const kbo_variant *variants, size_t n_variants);
+/* gap_filling::fill_gaps (gap_filling.rs:444-526) preceded by the steps its callers run
+ * (lib.rs:735-747): query_sbwt, derandomize_ms_vec and translate_ms_vec with the GIVEN threshold
+ * on the GPU, then the host-side gap filling.  out holds len Rust chars. */
+int kbo_fill_gaps(kbo_index_t *query_idx, const uint8_t *ref_seq, size_t len, size_t threshold,
+                  double max_err_prob, uint32_t *out);
+/* gap_filling::nearest_unique_context (gap_filling.rs:127-151): kmer_out holds k bytes;
+ * *kmer_len is 0 when no unique interval was found. */
+int kbo_nearest_unique_context(kbo_index_t *idx, const uint8_t *ref_seq, size_t len, size_t range_start,
+                               size_t range_end, size_t *kmer_idx, uint8_t *kmer_out, size_t *kmer_len);
 /* kbo::find (lib.rs:808-821): *out is allocated by the library (kbo_free). */
 int kbo_find(kbo_index_t *idx, const uint8_t *query, size_t len, const kbo_find_opts *opts,
              kbo_rle **out, size_t *n_out);

@@ -12,7 +12,7 @@ from typing import Optional
 
 import numpy as np
 
-from . import _capi, derandomize, format, index, translate  # noqa: F401
+from . import _capi, derandomize, format, gap_filling, index, translate, variant_calling  # noqa: F401
 from ._capi import KboError, check, lib  # noqa: F401
 from .index import LcsArray, SbwtIndexVariant, _u8  # noqa: F401
 
@@ -98,3 +98,13 @@ def find(query_seq, sbwt, lcs=None, find_opts=None):
     p, n = C.POINTER(_capi.RLE)(), C.c_size_t()
     check(lib().kbo_find(sbwt._h, q.ctypes.data, len(q), C.byref(co), C.byref(p), C.byref(n)))
     return format._take_rles(p, n.value)
+
+
+def call(sbwt_query, lcs_query, ref_seq, call_opts=None):
+    """kbo::call (lib.rs:547-573) -> list of variant_calling.Variant"""
+    o = call_opts if call_opts is not None else CallOpts()
+    co = _capi.CallOpts(o.max_error_prob, o.sbwt_build_opts._to_c())
+    r = _u8(ref_seq)
+    p, n = C.POINTER(_capi.Variant)(), C.c_size_t()
+    check(lib().kbo_call(sbwt_query._h, r.ctypes.data, len(r), C.byref(co), C.byref(p), C.byref(n)))
+    return variant_calling._from_c(p, n.value)

@@ -13,7 +13,7 @@ KBO_OK = 0
 ERROR_NAMES = {
     -1: "KBO_E_EMPTY_QUERY", -2: "KBO_E_LEN_LE_2", -3: "KBO_E_THRESHOLD_LE_1", -4: "KBO_E_BAD_ARG",
     -5: "KBO_E_NOMEM", -6: "KBO_E_K_MISMATCH", -7: "KBO_E_HIP", -8: "KBO_E_UNSUPPORTED",
-    -9: "KBO_E_MS_RANGE", -10: "KBO_E_IO",
+    -9: "KBO_E_MS_RANGE", -10: "KBO_E_IO", -11: "KBO_E_REF_PANIC",
 }
 
 
@@ -44,6 +44,17 @@ class MapOpts(C.Structure):
                 ("format", C.c_int32), ("sbwt_build_opts", BuildOpts)]
 
 
+class CallOpts(C.Structure):
+    """kbo::CallOpts (lib.rs:318-353)."""
+    _fields_ = [("max_error_prob", C.c_double), ("sbwt_build_opts", BuildOpts)]
+
+
+class Variant(C.Structure):
+    """kbo::variant_calling::Variant (variant_calling.rs:8-26), C layout."""
+    _fields_ = [("query_pos", C.c_uint64), ("query_chars", C.POINTER(C.c_uint8)), ("query_len", C.c_size_t),
+                ("ref_chars", C.POINTER(C.c_uint8)), ("ref_len", C.c_size_t)]
+
+
 class RLE(C.Structure):
     """kbo::format::RLE (format.rs:18-33)."""
     _fields_ = [(n, C.c_uint64) for n in
@@ -56,7 +67,8 @@ class RLE(C.Structure):
 # every symbol include/kbo_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "kbo_last_error", "kbo_version", "kbo_build_opts_default", "kbo_find_opts_default",
-    "kbo_map_opts_default", "kbo_index_build", "kbo_index_from_parts", "kbo_index_export_parts",
+    "kbo_map_opts_default", "kbo_call_opts_default", "kbo_call", "kbo_add_variants", "kbo_fill_gaps",
+    "kbo_nearest_unique_context", "kbo_index_build", "kbo_index_from_parts", "kbo_index_export_parts",
     "kbo_index_free", "kbo_index_k", "kbo_index_n_kmers", "kbo_index_n_sets", "kbo_index_save",
     "kbo_index_load", "kbo_index_to_device", "kbo_index_device_bytes", "kbo_log_rm_max_cdf",
     "kbo_random_match_threshold", "kbo_matching_statistics", "kbo_derandomize_ms_vec",
@@ -93,8 +105,13 @@ def lib():
     L.kbo_build_opts_default.argtypes = [C.POINTER(BuildOpts)]
     L.kbo_find_opts_default.argtypes = [C.POINTER(FindOpts)]
     L.kbo_map_opts_default.argtypes = [C.POINTER(MapOpts)]
-    for f in (L.kbo_build_opts_default, L.kbo_find_opts_default, L.kbo_map_opts_default, L.kbo_index_free,
-              L.kbo_free):
+    L.kbo_call_opts_default.argtypes = [C.POINTER(CallOpts)]
+    L.kbo_call.argtypes = [vp, vp, sz, C.POINTER(CallOpts), C.POINTER(C.POINTER(Variant)), C.POINTER(sz)]
+    L.kbo_add_variants.argtypes = [vp, sz, C.POINTER(Variant), sz]
+    L.kbo_fill_gaps.argtypes = [vp, vp, sz, sz, dbl, vp]
+    L.kbo_nearest_unique_context.argtypes = [vp, vp, sz, sz, sz, C.POINTER(sz), vp, C.POINTER(sz)]
+    for f in (L.kbo_build_opts_default, L.kbo_find_opts_default, L.kbo_map_opts_default, L.kbo_call_opts_default,
+              L.kbo_index_free, L.kbo_free):
         f.restype = None
     L.kbo_index_build.argtypes = [C.POINTER(C.c_char_p), C.POINTER(sz), sz, C.POINTER(BuildOpts), C.POINTER(vp)]
     L.kbo_index_from_parts.argtypes = [u32, u64, u64, C.POINTER(vp), C.POINTER(u64), vp, C.POINTER(vp)]

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "refine.hpp"
 #include "sbwt_index.hpp"
 
 namespace {
@@ -50,6 +51,9 @@ template <typename F> int guarded(F f)
     } catch (const KboError &e) {
         g_err = e.what();
         return e.code;
+    } catch (const kbo::RefPanic &e) {
+        g_err = e.what();
+        return KBO_E_REF_PANIC;
     } catch (const std::bad_alloc &) {
         g_err = "out of host memory";
         return KBO_E_NOMEM;
@@ -352,6 +356,96 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
     HIP_OK(hipStreamSynchronize(stream));
 }
 
+// matching statistics with intervals of a list of sequences, batched on the GPU
+kbo::MsFn make_ms_fn(kbo_index *idx)
+{
+    return [idx](const std::vector<std::vector<uint8_t>> &seqs, std::vector<std::vector<kbo::MsVal>> &out) {
+        out.assign(seqs.size(), {});
+        if (seqs.empty()) return;
+        std::vector<uint64_t> off(seqs.size() + 1, 0);
+        for (size_t s = 0; s < seqs.size(); s++) off[s + 1] = off[s] + seqs[s].size();
+        std::vector<uint8_t> concat(off.back());
+        for (size_t s = 0; s < seqs.size(); s++) std::memcpy(concat.data() + off[s], seqs[s].data(), seqs[s].size());
+        hipStream_t stream = nullptr;
+        BatchOnDevice B;
+        run_walk_host(idx, concat.data(), off.data(), seqs.size(), true, B, stream);
+        std::vector<uint8_t> d(B.total);
+        std::vector<uint32_t> lo(B.total), hi(B.total);
+        HIP_OK(hipMemcpy(d.data(), B.ms.p, B.total, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(lo.data(), B.lo.p, B.total * 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(hi.data(), B.hi.p, B.total * 4, hipMemcpyDeviceToHost));
+        for (size_t s = 0; s < seqs.size(); s++) {
+            out[s].resize(seqs[s].size());
+            for (size_t i = 0; i < seqs[s].size(); i++) out[s][i] = kbo::MsVal{d[off[s] + i], lo[off[s] + i], hi[off[s] + i]};
+        }
+    };
+}
+
+// lib.rs:735-738 for one sequence with an explicit threshold: MS (with intervals) + A5 + A6 on the GPU
+void ms_and_translation(kbo_index *idx, const uint8_t *seq, size_t len, size_t threshold, std::vector<kbo::MsVal> &ms,
+                        std::vector<uint8_t> &chars)
+{
+    KBO_REQUIRE(len > 0, KBO_E_EMPTY_QUERY, "assert!(!query.is_empty()) (index.rs:248)");
+    const uint64_t off[2] = {0, len};
+    check_len_threshold(off, 1, idx->host.k, threshold);
+    hipStream_t stream = nullptr;
+    BatchOnDevice B;
+    run_walk_host(idx, seq, off, 1, true, B, stream);
+    DevBuf dch(((len + 15) / 16) * 16 + 16);
+    derand_translate_host_offsets(B.ms.as<uint8_t>(), B.off.as<uint64_t>(), off, 1, idx->host.k, (uint32_t)threshold,
+                                  nullptr, dch.as<uint8_t>(), nullptr, stream);
+    std::vector<uint8_t> d(len);
+    std::vector<uint32_t> lo(len), hi(len);
+    chars.resize(len);
+    HIP_OK(hipMemcpy(d.data(), B.ms.p, len, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(lo.data(), B.lo.p, len * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(hi.data(), B.hi.p, len * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(chars.data(), dch.p, len, hipMemcpyDeviceToHost));
+    ms.resize(len);
+    for (size_t i = 0; i < len; i++) ms[i] = kbo::MsVal{d[i], lo[i], hi[i]};
+}
+
+// kbo::call (lib.rs:547-573)
+std::vector<kbo::Variant> call_impl(kbo_index *query_idx, const uint8_t *ref_seq, size_t len, const kbo_call_opts &o)
+{
+    kbo_index ref_idx; // lib.rs:553: an index of ref_seq is built on every call
+    kbo::BuildParams p;
+    p.k = o.sbwt_build_opts.k;
+    p.add_revcomp = o.sbwt_build_opts.add_revcomp != 0;
+    p.num_threads = std::max(1u, o.sbwt_build_opts.num_threads);
+    const uint8_t *seqs[1] = {ref_seq};
+    const size_t lens[1] = {len};
+    kbo::build_host_index(seqs, lens, 1, p, ref_idx.host);
+    KBO_REQUIRE(ref_idx.host.k == query_idx->host.k, KBO_E_K_MISMATCH, "assert!(sbwt_ref.k() == sbwt_query.k()) (lib.rs:559)");
+    // variant_calling.rs:260 — callee's sbwt_ref is kbo's query index (lib.rs:561-568)
+    const size_t d = random_match_threshold(query_idx->host.k, query_idx->host.n_kmers, 4, o.max_error_prob);
+    kbo::HostNav nav(query_idx->host);
+    return kbo::call_variants(nav, make_ms_fn(query_idx), make_ms_fn(&ref_idx), query_idx->host.k, ref_seq, len, d);
+}
+
+kbo_variant *pack_variants(const std::vector<kbo::Variant> &v)
+{
+    size_t chars = 0;
+    for (const auto &x : v) chars += x.query_chars.size() + x.ref_chars.size();
+    const size_t head = std::max<size_t>(1, v.size()) * sizeof(kbo_variant);
+    uint8_t *mem = static_cast<uint8_t *>(std::malloc(head + chars + 1));
+    if (!mem) throw std::bad_alloc();
+    kbo_variant *out = reinterpret_cast<kbo_variant *>(mem);
+    uint8_t *cp = mem + head;
+    for (size_t i = 0; i < v.size(); i++) {
+        out[i].query_pos = v[i].query_pos;
+        out[i].query_chars = cp;
+        out[i].query_len = v[i].query_chars.size();
+        std::memcpy(cp, v[i].query_chars.data(), v[i].query_chars.size());
+        cp += v[i].query_chars.size();
+        out[i].ref_chars = cp;
+        out[i].ref_len = v[i].ref_chars.size();
+        std::memcpy(cp, v[i].ref_chars.data(), v[i].ref_chars.size());
+        cp += v[i].ref_chars.size();
+    }
+    return out;
+}
+
 // format.rs:143-193, statement for statement (sequential, variable-length output: host)
 void run_lengths_gapped_impl(const uint8_t *aln, size_t len, size_t max_gap_len, std::vector<kbo_rle> &out)
 {
@@ -421,6 +515,13 @@ void kbo_find_opts_default(kbo_find_opts *o)
 {
     if (!o) return;
     o->max_error_prob = 0.0000001; o->max_gap_len = 0;
+}
+void kbo_call_opts_default(kbo_call_opts *o)
+{
+    if (!o) return;
+    o->max_error_prob = 0.0000001;
+    kbo_build_opts_default(&o->sbwt_build_opts);
+    o->sbwt_build_opts.build_select = 1;
 }
 void kbo_map_opts_default(kbo_map_opts *o)
 {
@@ -705,12 +806,95 @@ int kbo_map(kbo_index_t *idx, const uint8_t *ref_seq, size_t len, const kbo_map_
         if (o.call_variants)
             KBO_REQUIRE(idx->host.k == o.sbwt_build_opts.k, KBO_E_K_MISMATCH,
                         "assert!(sbwt.k() == map_opts.sbwt_build_opts.k) (lib.rs:729)");
-        KBO_REQUIRE(!o.fill_gaps && !o.call_variants, KBO_E_UNSUPPORTED,
-                    "map refinement (gap_filling::fill_gaps, call/add_variants) is outside the built hot path; "
-                    "set fill_gaps=0 and call_variants=0");
         KBO_REQUIRE(len > 0, KBO_E_EMPTY_QUERY, "assert!(!query.is_empty()) (index.rs:248)");
-        const uint64_t off[2] = {0, len};
-        matches_batch_impl(idx, ref_seq, off, 1, o.max_error_prob, o.format != 0, out);
+        if (!o.fill_gaps && !o.call_variants) { // everything on the GPU, incl. relative_to_ref
+            const uint64_t off[2] = {0, len};
+            matches_batch_impl(idx, ref_seq, off, 1, o.max_error_prob, o.format != 0, out);
+            return;
+        }
+        const size_t threshold = random_match_threshold(idx->host.k, idx->host.n_kmers, 4, o.max_error_prob); // lib.rs:731
+        std::vector<kbo::MsVal> ms;
+        std::vector<uint8_t> refined;
+        ms_and_translation(idx, ref_seq, len, threshold, ms, refined);                                       // lib.rs:735-738
+        if (o.fill_gaps) {                                                                                   // lib.rs:743-747
+            kbo::HostNav nav(idx->host);
+            refined = kbo::fill_gaps(refined, ms, ref_seq, len, nav, threshold, o.max_error_prob);
+        }
+        if (o.call_variants) {                                                                               // lib.rs:749-754
+            kbo_call_opts co;
+            co.max_error_prob = o.max_error_prob;
+            co.sbwt_build_opts = o.sbwt_build_opts;
+            kbo::add_variants(refined, call_impl(idx, ref_seq, len, co));
+        }
+        if (o.format) {                                                                                      // lib.rs:756-760
+            int rc = kbo_relative_to_ref(ref_seq, refined.data(), len, out);
+            if (rc) throw KboError(rc, g_err);
+        } else {
+            std::memcpy(out, refined.data(), len);
+        }
+    });
+}
+
+int kbo_call(kbo_index_t *query_idx, const uint8_t *ref_seq, size_t len, const kbo_call_opts *opts, kbo_variant **out,
+             size_t *n_out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(query_idx && ref_seq && out && n_out, KBO_E_BAD_ARG, "null argument");
+        *out = nullptr;
+        *n_out = 0;
+        KBO_REQUIRE(len > 0, KBO_E_EMPTY_QUERY, "assert!(!query.is_empty()) (index.rs:248)");
+        kbo_call_opts o;
+        if (opts) o = *opts; else kbo_call_opts_default(&o);
+        std::vector<kbo::Variant> v = call_impl(query_idx, ref_seq, len, o);
+        *out = pack_variants(v);
+        *n_out = v.size();
+    });
+}
+
+int kbo_add_variants(uint32_t *translation, size_t len, const kbo_variant *variants, size_t n_variants)
+{
+    return guarded([&] {
+        KBO_REQUIRE(translation && (variants || n_variants == 0), KBO_E_BAD_ARG, "null argument");
+        std::vector<uint8_t> t(len);
+        for (size_t i = 0; i < len; i++) t[i] = (uint8_t)translation[i];
+        std::vector<kbo::Variant> v(n_variants);
+        for (size_t i = 0; i < n_variants; i++) {
+            v[i].query_pos = variants[i].query_pos;
+            v[i].query_chars.assign(variants[i].query_chars, variants[i].query_chars + variants[i].query_len);
+            v[i].ref_chars.assign(variants[i].ref_chars, variants[i].ref_chars + variants[i].ref_len);
+        }
+        kbo::add_variants(t, v);
+        for (size_t i = 0; i < len; i++) translation[i] = t[i];
+    });
+}
+
+int kbo_fill_gaps(kbo_index_t *idx, const uint8_t *ref_seq, size_t len, size_t threshold, double max_err_prob,
+                  uint32_t *out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && ref_seq && out, KBO_E_BAD_ARG, "null argument");
+        std::vector<kbo::MsVal> ms;
+        std::vector<uint8_t> tr;
+        ms_and_translation(idx, ref_seq, len, threshold, ms, tr);
+        kbo::HostNav nav(idx->host);
+        std::vector<uint8_t> refined = kbo::fill_gaps(tr, ms, ref_seq, len, nav, threshold, max_err_prob);
+        for (size_t i = 0; i < len; i++) out[i] = refined[i];
+    });
+}
+
+int kbo_nearest_unique_context(kbo_index_t *idx, const uint8_t *ref_seq, size_t len, size_t range_start,
+                               size_t range_end, size_t *kmer_idx, uint8_t *kmer_out, size_t *kmer_len)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && ref_seq && kmer_idx && kmer_out && kmer_len, KBO_E_BAD_ARG, "null argument");
+        std::vector<std::vector<uint8_t>> one(1, std::vector<uint8_t>(ref_seq, ref_seq + len));
+        std::vector<std::vector<kbo::MsVal>> ms;
+        make_ms_fn(idx)(one, ms);
+        kbo::HostNav nav(idx->host);
+        auto r = kbo::nearest_unique_context(ms[0], nav, range_start, range_end);
+        *kmer_idx = r.first;
+        *kmer_len = r.second.size();
+        std::memcpy(kmer_out, r.second.data(), r.second.size());
     });
 }
 

@@ -19,3 +19,13 @@ def translate_ms_vec(derand_ms, k, threshold):
     out = np.zeros(max(len(a), 1), dtype=np.uint32)
     check(lib().kbo_translate_ms_vec(a.ctypes.data, len(a), k, threshold, out.ctypes.data))
     return [chr(v) for v in out[:len(a)]]
+
+
+def add_variants(translation, variants):
+    """translate.rs:350-386 -> list of chars"""
+    from .variant_calling import _to_c
+    t = np.array([ord(c) for c in translation], dtype=np.uint32)
+    arr, keep = _to_c(variants)
+    check(lib().kbo_add_variants(t.ctypes.data, len(t), arr, len(variants)))
+    del keep
+    return [chr(v) for v in t]

@@ -130,6 +130,9 @@ def test_empty_query_and_map_opts_checks():
     with pytest.raises(kbo_amd.KboError) as e:  # lib.rs:729
         kbo_amd.map(b"ACGTACGT", sbwt, lcs, kbo_amd.MapOpts())
     assert e.value.code == -6
+    with pytest.raises(kbo_amd.KboError) as e:  # lib.rs:559
+        kbo_amd.call(sbwt, lcs, b"ACGTACGTACGTAGCTAGCTAGCATCGATCGACTAGCTAC", kbo_amd.CallOpts())
+    assert e.value.code == -6
 
 
 def test_compute_fails_loudly_without_gpu():

@@ -67,6 +67,70 @@ def test_find_golden(golden):  # lib.rs:786-805
             == g["expected"]
 
 
+# ------------------------------------------------------------------ refinement stages ("next" rows)
+
+def test_call_goldens(golden):
+    """variant_calling.rs:312-454 (index built from reference, query streamed) and the call()
+    doctest lib.rs:526-544."""
+    from kbo_amd.variant_calling import Variant
+    for g in golden["call_variants"]:
+        # run_variant_calling(query, reference, k, p): sbwt_ref from reference, query walked
+        opts = kbo_amd.BuildOpts(k=g["k"], build_select=True)
+        sbwt_ref, lcs_ref = kbo_amd.build([g["reference"]], opts)
+        got = kbo_amd.call(sbwt_ref, lcs_ref, g["query"], kbo_amd.CallOpts(g["max_error_prob"], opts))
+        exp = [Variant(p, list(q.encode()), list(r.encode())) for p, q, r in g["expected"]]
+        assert got == exp, g["src"]
+    for g in golden["call"]:
+        opts = kbo_amd.BuildOpts(k=g["k"], build_select=True)
+        sbwt_query, lcs_query = kbo_amd.build([g["query"]], opts)
+        got = kbo_amd.call(sbwt_query, lcs_query, g["reference"], kbo_amd.CallOpts(g["max_error_prob"], opts))
+        exp = [Variant(p, list(q.encode()), list(r.encode())) for p, q, r in g["expected"]]
+        assert got == exp, g["src"]
+
+
+def test_add_variants_goldens(golden):  # translate.rs:324-347, 535-676
+    for g in golden["add_variants"]:
+        k, threshold = g["k"], g["threshold"]
+        opts = kbo_amd.BuildOpts(k=k, build_select=True)
+        sbwt_query, lcs_query = kbo_amd.build([g["query"]], opts)
+        noisy = [x[0] for x in kbo_amd.index.query_sbwt(g["reference"], sbwt_query, lcs_query)]
+        derand = derandomize.derandomize_ms_vec(noisy, k, threshold)
+        translated = translate.translate_ms_vec(derand, k, threshold)
+        variants = kbo_amd.call(sbwt_query, lcs_query, g["reference"], kbo_amd.CallOpts(g["max_error_prob"], opts))
+        assert "".join(translate.add_variants(translated, variants)) == g["expected"], g["src"]
+
+
+def test_nearest_unique_context_golden(golden):  # gap_filling.rs:535-564
+    from kbo_amd import gap_filling
+    for g in golden["nearest_unique_context"]:
+        sbwt, lcs = kbo_amd.build([g["query"]], kbo_amd.BuildOpts(k=g["k"], build_select=True))
+        a, b = g["search_range"]
+        idx, kmer = gap_filling.nearest_unique_context(g["reference"], sbwt, range(a, b))
+        assert [idx, kmer.decode()] == g["expected"]
+
+
+def test_fill_gaps_goldens(golden):  # gap_filling.rs:419-441, 641-922
+    from kbo_amd import gap_filling
+    for g in golden["fill_gaps"]:
+        opts = kbo_amd.BuildOpts(k=g["k"], build_select=True)
+        sbwt, lcs = kbo_amd.build([g["query"]], opts)
+        t = g["threshold"]
+        if t is None:
+            t = derandomize.random_match_threshold(sbwt.k(), sbwt.n_kmers(), 4, g["max_err_prob"])
+        got = gap_filling.fill_gaps_from_sequences(g["reference"], sbwt, t, g["max_err_prob"])
+        assert "".join(got) == g["expected"], g["src"]
+
+
+def test_map_full_defaults_golden(golden):  # lib.rs:647-660
+    for g in golden["map"]:
+        if not (g["fill_gaps"] and g["call_variants"]):
+            continue
+        opts = kbo_amd.BuildOpts(k=g["k"], build_select=True)
+        sbwt, lcs = kbo_amd.build(g["query_seqs"], opts)
+        mo = kbo_amd.MapOpts(max_error_prob=g["max_error_prob"], sbwt_build_opts=opts)
+        assert kbo_amd.map(g["ref_seq"], sbwt, lcs, mo).decode() == g["expected"]
+
+
 # ------------------------------------------------------------------ differential vs oracle
 
 def _mutate(rng, seq, rate):
