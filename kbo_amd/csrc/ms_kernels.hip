@@ -129,6 +129,9 @@ __device__ __forceinline__ void st_partial(uint8_t *o, const uint4 &v, uint32_t 
 #ifndef KBO_ABLATE
 #define KBO_ABLATE 0
 #endif
+#ifndef KBO_NO_TARGETS
+#define KBO_NO_TARGETS 0
+#endif
 
 template <bool IVAL>
 __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
@@ -299,6 +302,10 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
                         cb = c < 4u ? c * nblk : null_blk;
                     }
                 } else { // empty extension at depth d > 0: contract.  Nearest set bits of B_c:
+#if KBO_NO_TARGETS
+                    m = 0;
+                    flags |= F_CON;
+#else
                     uint32_t dl = 0, dr = 0; // 0 = not inside the loaded block
                     {
                         const uint64_t X = ~0ull << (ol & 63u);
@@ -328,6 +335,7 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
                     tgt_l = l - dl;           // row of the nearest set bit below l
                     tgt_r = r + dr;           // one past the nearest set bit at/after r
                     flags |= F_CON;
+#endif
                 }
             }
         }
@@ -674,7 +682,7 @@ hipError_t launch_make_items(const uint64_t *d_offsets, uint32_t n_seqs, WalkIte
 }
 
 int g_walk_threads = kWalkThreads;
-int g_rare_batch = 8, g_rare_period = 4;
+int g_rare_batch = 32, g_rare_period = 16; // tuned on C2 (tools/sweep_walk.py RARE=1)
 void set_walk_rare(int batch, int period)
 {
     g_rare_batch = std::max(1, std::min(64, batch));

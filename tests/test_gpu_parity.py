@@ -88,6 +88,46 @@ def test_call_goldens(golden):
         assert got == exp, g["src"]
 
 
+def test_long_generated_variant_calling():
+    """Property test modelled on variant_calling.rs:467-553 (100 kbp, k=63, a variant every 25 bp,
+    p=1e-8).  The reference seeds crate `random`'s generator, which cannot be reproduced here,
+    so the inputs come from numpy; the asserted property is the same: calls are correct."""
+    from kbo_amd.variant_calling import Variant
+    rng = np.random.default_rng(123412)
+    nt = lambda: int(rng.choice(list(b"ACGT")))  # noqa: E731
+    n, spacing, k, p = 100_000, 25, 63, 1e-8
+    reference, query, truth = bytearray(), bytearray(), {}
+    for i in range(n):
+        if spacing < i < n - spacing and i % spacing == 0:
+            ql, rl = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            while ql == 0 and rl == 0:
+                ql, rl = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            qv, rv = [nt() for _ in range(ql)], [nt() for _ in range(rl)]
+            while qv and rv and (qv[0] == rv[0] or qv[-1] == rv[-1]):
+                qv[-1] = nt()
+                qv[0] = nt()
+            truth[len(query)] = Variant(len(query), list(qv), list(rv))
+            reference += bytes(rv)
+            query += bytes(qv)
+            ins = rv if (not qv and rv) else qv if (qv and not rv) else None
+            if ins is not None:
+                c = nt()
+                while c == ins[0] or c == ins[-1]:
+                    c = nt()
+                query.append(c)
+                reference.append(c)
+        else:
+            c = nt()
+            query.append(c)
+            reference.append(c)
+    opts = kbo_amd.BuildOpts(k=k, build_select=True)
+    sbwt_ref, lcs_ref = kbo_amd.build([bytes(reference)], opts)
+    calls = kbo_amd.call(sbwt_ref, lcs_ref, bytes(query), kbo_amd.CallOpts(p, opts))
+    assert len(calls) >= 0.99 * len(truth)
+    wrong = [c for c in calls if truth.get(c.query_pos) != c]
+    assert len(wrong) <= 0.002 * len(calls), wrong[:5]
+
+
 def test_add_variants_goldens(golden):  # translate.rs:324-347, 535-676
     for g in golden["add_variants"]:
         k, threshold = g["k"], g["threshold"]
