@@ -29,6 +29,15 @@ class RLE(C.Structure):
         return tuple(int(getattr(self, n)) for n, _ in self._fields_)
 
 
+class OVariant(C.Structure):
+    _fields_ = [("query_pos", C.c_uint64), ("query_chars", C.c_uint8 * 8), ("query_len", C.c_uint32),
+                ("ref_chars", C.c_uint8 * 8), ("ref_len", C.c_uint32), ("overflow", C.c_uint32)]
+
+    def as_tuple(self):
+        return (int(self.query_pos), bytes(self.query_chars[:self.query_len]).decode(),
+                bytes(self.ref_chars[:self.ref_len]).decode())
+
+
 def build_lib():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
@@ -70,6 +79,11 @@ def _load():
     lib.ora_relative_to_ref.restype = None
     lib.ora_matches_batch.argtypes = [vp, vp, vp, C.c_size_t, C.c_double, C.c_int, vp, vp,
                                       C.POINTER(Counters)]
+    lib.ora_call.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_double, C.POINTER(OVariant), C.c_size_t]
+    lib.ora_call.restype = C.c_long
+    lib.ora_add_variants.argtypes = [vp, C.c_size_t, C.POINTER(OVariant), C.c_size_t]
+    lib.ora_fill_gaps.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_size_t, C.c_double, vp]
+    lib.ora_map.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_double, C.c_int, C.c_int, C.c_int, vp]
     return lib
 
 
@@ -180,6 +194,34 @@ class Index:
         _chk(lib().ora_matches(self._h, q.ctypes.data, len(q), max_error_prob, out.ctypes.data))
         return out.tobytes()
 
+    def call(self, ref_seq, k, max_error_prob=1e-7):
+        """kbo::call (lib.rs:547-573) -> list of (query_pos, query_chars, ref_chars)"""
+        r = _bytes(ref_seq)
+        cap = len(r) // 2 + 16
+        buf = (OVariant * cap)()
+        n = lib().ora_call(self._h, r.ctypes.data, len(r), k, max_error_prob, buf, cap)
+        if n < 0:
+            raise OracleError(n)
+        return [buf[i].as_tuple() for i in range(n)], buf, n
+
+    def fill_gaps(self, translation, ref_seq, threshold, max_err_prob):
+        """gap_filling::fill_gaps on the oracle's own MS of ref_seq -> bytes"""
+        r = _bytes(ref_seq)
+        d, lo, hi = self.matching_statistics(r)
+        t = _bytes(translation)
+        out = np.zeros(len(r), dtype=np.uint8)
+        _chk(lib().ora_fill_gaps(self._h, t.ctypes.data, d.ctypes.data, lo.ctypes.data, hi.ctypes.data,
+                                 r.ctypes.data, len(r), threshold, max_err_prob, out.ctypes.data))
+        return out.tobytes()
+
+    def map(self, ref_seq, k, max_error_prob=1e-7, fill_gaps=True, call_variants=True, format=True):  # noqa: A002
+        """kbo::map (lib.rs:720-761) -> bytes"""
+        r = _bytes(ref_seq)
+        out = np.zeros(len(r), dtype=np.uint8)
+        _chk(lib().ora_map(self._h, r.ctypes.data, len(r), k, max_error_prob, int(fill_gaps), int(call_variants),
+                           int(format), out.ctypes.data))
+        return out.tobytes()
+
     def matches_batch(self, concat, offsets, max_error_prob=1e-7, n_threads=1, want_d=False,
                       counters=None):
         concat = np.ascontiguousarray(concat, dtype=np.uint8)
@@ -238,3 +280,9 @@ def relative_to_ref(ref_seq, aln):
     out = np.zeros(len(a), dtype=np.uint8)
     lib().ora_relative_to_ref(r.ctypes.data, a.ctypes.data, len(a), out.ctypes.data)
     return out.tobytes()
+
+
+def add_variants(translation, variant_buf, n):
+    t = np.frombuffer(bytes(_bytes(translation)), dtype=np.uint8).copy()
+    _chk(lib().ora_add_variants(t.ctypes.data, len(t), variant_buf, n))
+    return t.tobytes()

@@ -261,6 +261,23 @@ void ora_index_C(const ora_index *x, uint64_t C[4]) { memcpy(C, x->C, sizeof(x->
 const uint64_t *ora_index_bits(const ora_index *x, int c) { return x->bits[c & 3]; }
 const uint8_t *ora_index_lcs(const ora_index *x) { return x->lcs; }
 
+/* row of a full-length k-mer (chars ACGT$) by binary search over the stored sorted rows;
+ * used by kbo_oracle_refine.c as sbwt's search() for k-length patterns */
+int ora_index_find_kmer(const ora_index *x, const uint8_t *kmer, uint64_t *row)
+{
+    if (!x->rows) return 0;
+    uint8_t key[256];
+    for (uint32_t t = 0; t < x->k; t++) {
+        uint8_t ch = kmer[x->k - 1 - t];
+        int sy = ch == '$' ? 0 : sym_of(ch);
+        if (ch != '$' && sy == 0) return 0;
+        key[t] = (uint8_t)sy;
+    }
+    uint64_t p = lower_bound_prefix(x->rows, x->n, x->k, key, x->k);
+    if (p < x->n && memcmp(x->rows + p * x->k, key, x->k) == 0) { if (row) *row = p; return 1; }
+    return 0;
+}
+
 int ora_index_access_kmer(const ora_index *x, uint64_t colex, uint8_t *out_k)
 {
     if (!x->rows || colex >= x->n) return ORA_E_BAD_ARG;

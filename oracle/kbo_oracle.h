@@ -114,4 +114,32 @@ int ora_matches_batch(const ora_index *idx, const uint8_t *concat,
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- refinement stages ("next" rows of SURVEY.md §8(f)); see kbo_oracle_refine.c ---- */
+#ifdef __cplusplus
+extern "C" {
 #endif
+typedef struct {
+    uint64_t query_pos;
+    uint8_t query_chars[8]; uint32_t query_len; /* the reference's variants are short; longer ones set overflow */
+    uint8_t ref_chars[8]; uint32_t ref_len;
+    uint32_t overflow;
+} ora_variant;
+/* kbo::call (lib.rs:547-573) = variant_calling::call_variants (variant_calling.rs:249-294):
+ * returns the number of variants (writes at most cap), or a negative ORA_E_* code. */
+long ora_call(const ora_index *query_idx, const uint8_t *ref_seq, size_t len, uint32_t k, double max_error_prob,
+              ora_variant *out, size_t cap);
+/* translate::add_variants (translate.rs:350-386), in place on byte chars */
+int ora_add_variants(uint8_t *translation, size_t len, const ora_variant *v, size_t n);
+/* gap_filling::fill_gaps (gap_filling.rs:444-526) on byte chars; ms = (d, lo, hi) arrays */
+int ora_fill_gaps(const ora_index *idx, const uint8_t *translation, const uint64_t *d, const uint64_t *lo,
+                  const uint64_t *hi, const uint8_t *ref_seq, size_t len, size_t threshold, double max_err_prob,
+                  uint8_t *out);
+/* kbo::map (lib.rs:720-761) with all options */
+int ora_map(const ora_index *query_idx, const uint8_t *ref_seq, size_t len, uint32_t k, double max_error_prob,
+            int fill_gaps, int call_variants, int format, uint8_t *out);
+#define ORA_E_PANIC (-6) /* the reference would panic (index out of bounds / usize underflow / assert!) */
+#ifdef __cplusplus
+}
+#endif
+#endif /* KBO_ORACLE_H */

@@ -1,0 +1,361 @@
+/*
+ * kbo_oracle_refine.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE (see kbo_oracle.h).
+ *
+ * Plain-C restatement of the reference's refinement stages, written from the reference
+ * sources and independent of the product's C++ (kbo_amd/csrc/refine.cpp):
+ *   variant_calling.rs:46-294, translate.rs:350-386, gap_filling.rs:20-526, lib.rs:547-573,720-761.
+ * Index look-ups deliberately take a different route than the product: access_kmer reads the
+ * stored sorted rows, search() is a binary search over them (the product uses rank/select).
+ * Pinned by the reference goldens in tests/golden/kbo_golden.json (call_variants, call,
+ * add_variants, nearest_unique_context, fill_gaps, map).
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <setjmp.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "kbo_oracle.h"
+
+static __thread jmp_buf g_panic;
+#define PANIC() longjmp(g_panic, 1)
+#define USUB(a, b) ((b) > (a) ? (PANIC(), (size_t)0) : (size_t)((a) - (b)))
+#define MIN(a, b) ((a) < (b) ? (a) : (b))
+
+typedef struct { uint64_t d, lo, hi; } ms_t;
+
+typedef struct { uint8_t *p; size_t n, cap; } bytes;
+static void b_free(bytes *b) { free(b->p); b->p = NULL; b->n = b->cap = 0; }
+static void b_reserve(bytes *b, size_t c) { if (c > b->cap) { b->cap = c * 2 + 16; b->p = (uint8_t *)realloc(b->p, b->cap); } }
+static void b_assign(bytes *b, const uint8_t *s, size_t n) { b_reserve(b, n); if (n) memcpy(b->p, s, n); b->n = n; }
+static void b_push_front(bytes *b, uint8_t c) { b_reserve(b, b->n + 1); memmove(b->p + 1, b->p, b->n); b->p[0] = c; b->n++; }
+static int b_contains(const bytes *b, uint8_t c) { return b->n && memchr(b->p, c, b->n) != NULL; }
+
+/* sbwt search() for a full-length k-mer: row index via binary search over the sorted rows */
+extern int ora_index_find_kmer(const ora_index *idx, const uint8_t *kmer, uint64_t *row);
+
+static ms_t *ms_of(const ora_index *idx, const uint8_t *q, size_t len)
+{
+    uint64_t *d = (uint64_t *)malloc(3 * (len + 1) * sizeof(uint64_t));
+    if (ora_matching_statistics(idx, q, len, d, d + len, d + 2 * len, NULL) != 0) { free(d); PANIC(); }
+    ms_t *ms = (ms_t *)malloc((len + 1) * sizeof(ms_t));
+    for (size_t i = 0; i < len; i++) { ms[i].d = d[i]; ms[i].lo = d[len + i]; ms[i].hi = d[2 * len + i]; }
+    free(d);
+    return ms;
+}
+
+/* ---------------------------------------------------------------- variant_calling.rs */
+
+static void get_kmer_ending_at(const uint8_t *query, size_t end_pos, size_t k, uint8_t *out)
+{ /* :46-58 */
+    if (end_pos >= k - 1) memcpy(out, query + end_pos + 1 - k, k);
+    else {
+        size_t nd = k - 1 - end_pos;
+        memset(out, '$', nd);
+        memcpy(out + nd, query, end_pos + 1);
+    }
+}
+
+static int rightmost_peak(const ms_t *ms, size_t n, size_t thr, size_t *peak)
+{ /* :73-83 */
+    if (n == 0) PANIC();
+    for (size_t i = n - 1; i-- > 0;)
+        if (ms[i].d >= thr && ms[i].d > ms[i + 1].d) { *peak = i; return 1; }
+    return 0;
+}
+
+static int resolve_variant(const uint8_t *qk, const uint8_t *rk, size_t k, const ms_t *ms_vs_query, const ms_t *ms_vs_ref,
+                           size_t thr, ora_variant *v)
+{ /* :139-201 */
+    size_t csl = 0;
+    while (csl < k && qk[k - 1 - csl] == rk[k - 1 - csl]) csl++;
+    if (csl == 0) PANIC();
+    size_t qpeak, rpeak;
+    if (!rightmost_peak(ms_vs_ref, k, thr, &qpeak) || !rightmost_peak(ms_vs_query, k, thr, &rpeak)) return 0;
+    size_t sms = k - csl;
+    long qgap = (long)sms - (long)qpeak - 1, rgap = (long)sms - (long)rpeak - 1;
+    const uint8_t *qs = NULL, *rs = NULL;
+    size_t ql = 0, rl = 0;
+    if (qgap > 0 && rgap > 0) { qs = qk + qpeak + 1; ql = sms - qpeak - 1; rs = rk + rpeak + 1; rl = sms - rpeak - 1; }
+    else {
+        long qo = -qgap, ro = -rgap;
+        if (qo == ro) return 0;
+        size_t vl = (size_t)labs(qo - ro);
+        if (qo > ro) { if (rpeak + 1 + vl > k) PANIC(); rs = rk + rpeak + 1; rl = vl; }
+        else { if (qpeak + 1 + vl > k) PANIC(); qs = qk + qpeak + 1; ql = vl; }
+    }
+    v->overflow = (ql > 8 || rl > 8);
+    v->query_len = (uint32_t)ql; v->ref_len = (uint32_t)rl;
+    memcpy(v->query_chars, qs, MIN(ql, 8)); memcpy(v->ref_chars, rs, MIN(rl, 8));
+    return 1;
+}
+
+static long call_variants(const ora_index *sbwt_ref, const ora_index *sbwt_query, const uint8_t *query, size_t len,
+                          double p, ora_variant *out, size_t cap)
+{ /* :249-294 */
+    size_t k = ora_index_k(sbwt_ref);
+    if (k != ora_index_k(sbwt_query)) PANIC();
+    size_t d = ora_random_match_threshold(k, ora_index_n_kmers(sbwt_ref), 4, p);
+    ms_t *ms = ms_of(sbwt_ref, query, len);
+    uint8_t *qk = (uint8_t *)malloc(k), *rk = (uint8_t *)malloc(k);
+    long n = 0;
+    for (size_t i = 1; i < len; i++) {
+        if (ms[i].d < ms[i - 1].d && ms[i - 1].d >= d && ms[i].d < d) {
+            for (size_t j = i + 1; j < MIN(i + k + 1, len); j++) {
+                if (ms[j].d >= d && ms[j].hi - ms[j].lo == 1) {
+                    get_kmer_ending_at(query, j, k, qk);
+                    if (ora_index_access_kmer(sbwt_ref, ms[j].lo, rk) != 0) PANIC();
+                    ms_t *m1 = ms_of(sbwt_ref, qk, k), *m2 = ms_of(sbwt_query, rk, k);
+                    ora_variant v;
+                    memset(&v, 0, sizeof(v));
+                    if (resolve_variant(qk, rk, k, m2, m1, d, &v)) {
+                        v.query_pos = i;
+                        if ((size_t)n < cap && out) out[n] = v;
+                        n++;
+                    }
+                    free(m1); free(m2);
+                    break;
+                }
+            }
+        }
+    }
+    free(ms); free(qk); free(rk);
+    return n;
+}
+
+long ora_call(const ora_index *query_idx, const uint8_t *ref_seq, size_t len, uint32_t k, double max_error_prob,
+              ora_variant *out, size_t cap)
+{ /* lib.rs:547-573: an index of ref_seq is built; callee's sbwt_ref := kbo's query index */
+    if (len == 0) return ORA_E_EMPTY_QUERY;
+    ora_index *ref_idx = NULL;
+    const uint8_t *seqs[1] = {ref_seq};
+    size_t lens[1] = {len};
+    if (ora_index_build(seqs, lens, 1, k, 0, &ref_idx) != 0) return ORA_E_BAD_ARG;
+    long n;
+    if (setjmp(g_panic)) n = ORA_E_PANIC;
+    else n = call_variants(query_idx, ref_idx, ref_seq, len, max_error_prob, out, cap);
+    ora_index_free(ref_idx);
+    return n;
+}
+
+static void add_variants(uint8_t *refined, size_t len, const ora_variant *vars, size_t n)
+{ /* translate.rs:357-383 */
+    for (size_t t = 0; t < n; t++) {
+        const ora_variant *v = &vars[t];
+        size_t ql = v->query_len, rl = v->ref_len, qp = (size_t)v->query_pos;
+        if (ql == rl) { for (size_t i = 0; i < rl; i++) { if (qp + i >= len) PANIC(); refined[qp + i] = v->ref_chars[i]; } }
+        else if (ql == 0) { if (qp == 0 || qp >= len) PANIC(); refined[qp - 1] = 'I'; refined[qp] = 'I'; }
+        else if (rl == 0) { for (size_t i = 0; i < ql; i++) { if (qp + i >= len) PANIC(); refined[qp + i] = 'D'; } }
+        else {
+            int all_eq = 1;
+            for (size_t i = 1; i < rl; i++) all_eq = all_eq && v->ref_chars[i] == v->ref_chars[0];
+            uint8_t fill = all_eq ? v->ref_chars[0] : (uint8_t)'N';
+            for (size_t i = 0; i < ql; i++) { if (qp + i >= len) PANIC(); refined[qp + i] = fill; }
+        }
+    }
+}
+
+int ora_add_variants(uint8_t *translation, size_t len, const ora_variant *v, size_t n)
+{
+    if (setjmp(g_panic)) return ORA_E_PANIC;
+    add_variants(translation, len, v, n);
+    return ORA_OK;
+}
+
+/* ---------------------------------------------------------------- gap_filling.rs */
+
+static size_t count_right_overlaps(const bytes *kmer, const uint8_t *ref, size_t ref_len, size_t ref_match_end)
+{ /* :20-42 */
+    if (kmer->n == 0 || ref_len == 0 || ref_len < ref_match_end) PANIC();
+    size_t kp = kmer->n - 1, rp = USUB(ref_match_end, 1), m = 0;
+    while (kp > 0) {
+        if (rp >= ref_len) PANIC();
+        if (ref[rp] == kmer->p[kp]) m++; else break;
+        kp--;
+        rp = USUB(rp, 1);
+    }
+    return m;
+}
+
+static size_t count_left_overlaps(const bytes *kmer, const uint8_t *ref, size_t ref_len, size_t ref_match_start)
+{ /* :44-67 */
+    if (kmer->n == 0 || ref_len == 0 || !(ref_len > ref_match_start)) PANIC();
+    size_t kp = 0, rp = ref_match_start, m = 0;
+    while (kp < kmer->n) {
+        if (rp >= ref_len) PANIC();
+        if (ref[rp] == kmer->p[kp]) m++; else break;
+        kp++; rp++;
+    }
+    return m;
+}
+
+static size_t nearest_unique_context(const ora_index *idx, const ms_t *ms, size_t ms_len, size_t rs, size_t re, bytes *kmer)
+{ /* :127-151 */
+    size_t k = ora_index_k(idx);
+    if (k == 0 || ms_len == 0 || !(re >= rs) || !(re < ms_len)) PANIC();
+    kmer->n = 0;
+    size_t ki = re;
+    while (ki >= rs) {
+        if (ki >= ms_len) PANIC();
+        if (ms[ki].hi - ms[ki].lo == 1) {
+            b_reserve(kmer, k);
+            if (ora_index_access_kmer(idx, ms[ki].lo, kmer->p) != 0) PANIC();
+            kmer->n = k;
+            break;
+        }
+        ki = USUB(ki, 1);
+    }
+    return ki;
+}
+
+static void left_extend_kmer(const ora_index *idx, bytes *kmer, size_t max_ext)
+{ /* :205-232 */
+    if (kmer->n == 0) PANIC();
+    size_t ext = 0;
+    uint8_t *nk = (uint8_t *)malloc(kmer->n + max_ext + 2);
+    while (ext < max_ext) {
+        size_t keep = USUB(kmer->n, ext + 1);
+        int found = 0; uint8_t fc = 0;
+        for (int ci = 0; ci < 4; ci++) {
+            nk[0] = (uint8_t)"ACGT"[ci];
+            memcpy(nk + 1, kmer->p, keep);
+            uint64_t row;
+            /* new_kmer has exactly k characters here (see the length bookkeeping at :214) */
+            if (keep + 1 == ora_index_k(idx) && ora_index_find_kmer(idx, nk, &row)) { if (!found) fc = nk[0]; found++; }
+        }
+        if (found == 1) b_push_front(kmer, fc); else break; /* a full k-mer's interval always has length 1 */
+        ext++;
+    }
+    free(nk);
+}
+
+static void left_extend_over_gap(const ora_index *idx, const ms_t *ms, const uint8_t *ref, size_t ref_len, size_t lreq,
+                                 size_t rreq, size_t gs, size_t ge, size_t radius, bytes *kmer)
+{ /* :295-361 */
+    size_t k = ora_index_k(idx);
+    if (k == 0 || !(lreq <= gs) || ref_len < ge || !(rreq <= ref_len - ge) || !(ge > gs) || !(ge < ref_len)) PANIC();
+    size_t search_start = MIN(ge + radius, USUB(ref_len, 1));
+    size_t search_end = ge + rreq;
+    kmer->n = 0;
+    size_t ki = search_start;
+    while (ki >= search_end) {
+        ki = nearest_unique_context(idx, ms, ref_len, search_end, ki, kmer);
+        if (kmer->n) {
+            size_t want = USUB(USUB(search_start, ge - 1), USUB(search_start, ki));
+            size_t got = count_right_overlaps(kmer, ref, ref_len, ge + want);
+            size_t ref_start = gs > lreq ? gs - lreq : 0;
+            size_t lgot = count_left_overlaps(kmer, ref, ref_len, ref_start);
+            int should_extend = kmer->n < lreq + (ge - gs) + got;
+            if (got >= MIN(want, k) && lgot >= lreq) {
+                size_t s = lgot - lreq, e = USUB(kmer->n, USUB(got, rreq));
+                if (s > e) PANIC();
+                memmove(kmer->p, kmer->p + s, e - s); kmer->n = e - s;
+                return;
+            } else if (should_extend && got >= MIN(want, k) && lgot < lreq) {
+                size_t ext = USUB(lreq + (ge - gs) + got, k);
+                left_extend_kmer(idx, kmer, ext);
+                size_t lm = count_left_overlaps(kmer, ref, ref_len, ref_start);
+                if (lm >= lreq) {
+                    size_t s = lm - lreq, e = USUB(kmer->n, USUB(got, rreq));
+                    if (s > e) PANIC();
+                    memmove(kmer->p, kmer->p + s, e - s); kmer->n = e - s;
+                    return;
+                }
+            }
+            kmer->n = 0;
+        }
+        ki = USUB(ki, 1);
+    }
+}
+
+static void fill_gaps(const ora_index *idx, const uint8_t *translation, const ms_t *ms, const uint8_t *ref, size_t n,
+                      size_t threshold, double p, uint8_t *refined)
+{ /* :444-526 */
+    size_t k = ora_index_k(idx);
+    if (n == 0 || k == 0) PANIC();
+    memcpy(refined, translation, n);
+    bytes kmer = {0, 0, 0};
+    size_t i = threshold + 1;
+    while (i < USUB(n, threshold)) {
+        if (refined[i - 1] == '-' || refined[i - 1] == 'X') {
+            size_t start = i - 1;
+            while (i < n && refined[i] == '-') i++;
+            size_t end = MIN(i, n - threshold);
+            int owe = end - start + 2 * threshold <= k;
+            size_t radius = USUB(k, threshold * (size_t)owe);
+            left_extend_over_gap(idx, ms, ref, n, threshold, threshold, start, end, radius, &kmer);
+            int found = kmer.n && !b_contains(&kmer, '$');
+            size_t gap = end - start;
+            int no_indels = kmer.n == threshold + gap + threshold;
+            size_t a = MIN(threshold, kmer.n), b = MIN(threshold + gap, kmer.n), nm = MIN(b - a, gap);
+            size_t total = 0, consec = 0;
+            double lp = 0.0;
+            int first = 0, last = 0;
+            for (size_t j = 0; j < nm; j++) {
+                int m = kmer.p[a + j] == ref[start + j];
+                total += (size_t)m;
+                if (j == 0) first = m;
+                last = m;
+                if (j + 1 < nm) {
+                    int m2 = kmer.p[a + j + 1] == ref[start + j + 1];
+                    if (m && m2) consec++;
+                    else { if (consec > 0) lp += ora_log_rm_max_cdf(consec + 1, 4, 1); consec = 0; }
+                }
+            }
+            int fill_overlaps = lp > log1p(-p);
+            int fill_flanked = nm > 0 && !first && !last && total + 2 == gap;
+            if (found && no_indels && (owe || fill_overlaps || fill_flanked))
+                for (size_t j = 0; j < gap; j++)
+                    refined[start + j] = kmer.p[threshold + j] == ref[start + j] ? (uint8_t)'M' : kmer.p[threshold + j];
+        }
+        i++;
+    }
+    b_free(&kmer);
+}
+
+int ora_fill_gaps(const ora_index *idx, const uint8_t *translation, const uint64_t *d, const uint64_t *lo,
+                  const uint64_t *hi, const uint8_t *ref_seq, size_t len, size_t threshold, double max_err_prob, uint8_t *out)
+{
+    ms_t *ms = (ms_t *)malloc((len + 1) * sizeof(ms_t));
+    for (size_t i = 0; i < len; i++) { ms[i].d = d[i]; ms[i].lo = lo[i]; ms[i].hi = hi[i]; }
+    int rc = ORA_OK;
+    if (setjmp(g_panic)) rc = ORA_E_PANIC;
+    else fill_gaps(idx, translation, ms, ref_seq, len, threshold, max_err_prob, out);
+    free(ms);
+    return rc;
+}
+
+int ora_map(const ora_index *qi, const uint8_t *ref_seq, size_t len, uint32_t k, double p, int do_fill, int do_call,
+            int format, uint8_t *out)
+{ /* lib.rs:720-761 */
+    if (len == 0) return ORA_E_EMPTY_QUERY;
+    size_t threshold = ora_random_match_threshold(ora_index_k(qi), ora_index_n_kmers(qi), 4, p);
+    uint64_t *d = (uint64_t *)malloc(3 * (len + 1) * sizeof(uint64_t));
+    int64_t *der = (int64_t *)malloc((len + 1) * sizeof(int64_t));
+    uint32_t *tr = (uint32_t *)malloc((len + 1) * sizeof(uint32_t));
+    uint8_t *cur = (uint8_t *)malloc(len + 1), *tmp = (uint8_t *)malloc(len + 1);
+    int rc = ora_matching_statistics(qi, ref_seq, len, d, d + len, d + 2 * len, NULL);
+    if (!rc) rc = ora_derandomize_ms_vec(d, len, ora_index_k(qi), threshold, der);
+    if (!rc) rc = ora_translate_ms_vec(der, len, ora_index_k(qi), threshold, tr);
+    if (!rc) {
+        for (size_t i = 0; i < len; i++) cur[i] = (uint8_t)tr[i];
+        if (do_fill) {
+            rc = ora_fill_gaps(qi, cur, d, d + len, d + 2 * len, ref_seq, len, threshold, p, tmp);
+            if (!rc) memcpy(cur, tmp, len);
+        }
+    }
+    if (!rc && do_call) {
+        size_t cap = len / 2 + 16;
+        ora_variant *v = (ora_variant *)malloc(cap * sizeof(ora_variant));
+        long n = ora_call(qi, ref_seq, len, k, p, v, cap);
+        if (n < 0) rc = (int)n;
+        else rc = ora_add_variants(cur, len, v, (size_t)n);
+        free(v);
+    }
+    if (!rc) {
+        if (format) ora_relative_to_ref(ref_seq, cur, len, out);
+        else memcpy(out, cur, len);
+    }
+    free(d); free(der); free(tr); free(cur); free(tmp);
+    return rc;
+}

@@ -171,6 +171,48 @@ def test_map_full_defaults_golden(golden):  # lib.rs:647-660
         assert kbo_amd.map(g["ref_seq"], sbwt, lcs, mo).decode() == g["expected"]
 
 
+def _variant_pair(rng, n=3000, spacing=120):
+    """reference/query pair with substitutions, insertions and deletions every `spacing` bases"""
+    ref = rng.choice(list(b"ACGT"), size=n).astype(np.uint8).tobytes()
+    q = bytearray()
+    i = 0
+    while i < len(ref):
+        if i > 200 and i < len(ref) - 200 and i % spacing == 0:
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                q.append(b"ACGT"[(b"ACGT".index(ref[i]) + 1 + int(rng.integers(0, 3))) % 4]); i += 1
+            elif kind == 1:
+                q += rng.choice(list(b"ACGT"), size=int(rng.integers(1, 4))).astype(np.uint8).tobytes()
+            else:
+                i += int(rng.integers(1, 4))
+        else:
+            q.append(ref[i]); i += 1
+    return ref, bytes(q)
+
+
+@pytest.mark.parametrize("seed,k", [(1, 20), (2, 31), (3, 25)])
+def test_refinement_vs_oracle_random(oracle, seed, k):
+    """call / fill_gaps / full map: product (GPU MS + host C++ refinement) vs the independent
+    C oracle (CPU MS, row-based index look-ups) on random variant-laden sequences."""
+    from kbo_amd import gap_filling
+    rng = np.random.default_rng(seed)
+    ref, q = _variant_pair(rng)
+    opts = kbo_amd.BuildOpts(k=k, build_select=True)
+    sbwt, lcs = kbo_amd.build([q], opts)
+    ora = oracle.Index.build([q], k=k)
+    for p in (1e-3, 1e-7):
+        exp, _, _ = ora.call(ref, k, p)
+        got = kbo_amd.call(sbwt, lcs, ref, kbo_amd.CallOpts(p, opts))
+        assert [(v.query_pos, bytes(v.query_chars).decode(), bytes(v.ref_chars).decode()) for v in got] == exp
+        t = derandomize.random_match_threshold(k, sbwt.n_kmers(), 4, p)
+        d, _, _ = ora.matching_statistics(ref)
+        tr = oracle.translate_ms_vec(oracle.derandomize_ms_vec(d, k, t), k, t)
+        assert "".join(gap_filling.fill_gaps_from_sequences(ref, sbwt, t, p)) == ora.fill_gaps(tr, ref, t, p).decode()
+        for fg, cv, fmt in ((True, True, True), (True, False, False), (False, True, True), (True, True, False)):
+            mo = kbo_amd.MapOpts(max_error_prob=p, fill_gaps=fg, call_variants=cv, format=fmt, sbwt_build_opts=opts)
+            assert kbo_amd.map(ref, sbwt, lcs, mo) == ora.map(ref, k, p, fg, cv, fmt)
+
+
 # ------------------------------------------------------------------ differential vs oracle
 
 def _mutate(rng, seq, rate):

@@ -203,3 +203,43 @@ def test_revcomp_index(oracle):
     assert a.n_sets == b.n_sets and a.n_kmers == b.n_kmers
     assert all(np.array_equal(a.bits(c), b.bits(c)) for c in range(4))
     assert np.array_equal(a.lcs(), b.lcs())
+
+
+# ---------------------------------------------------------------- refinement stages (oracle/kbo_oracle_refine.c)
+
+def test_oracle_call_goldens(golden, oracle):  # variant_calling.rs:312-454, lib.rs:526-544
+    for g in golden["call_variants"]:
+        idx = oracle.Index.build([g["reference"]], k=g["k"])
+        got, _, _ = idx.call(g["query"], g["k"], g["max_error_prob"])
+        assert [list(v) for v in got] == g["expected"], g["src"]
+    for g in golden["call"]:
+        idx = oracle.Index.build([g["query"]], k=g["k"])
+        got, _, _ = idx.call(g["reference"], g["k"], g["max_error_prob"])
+        assert [list(v) for v in got] == g["expected"], g["src"]
+
+
+def test_oracle_add_variants_goldens(golden, oracle):  # translate.rs:324-347, 535-676
+    for g in golden["add_variants"]:
+        k, t = g["k"], g["threshold"]
+        idx = oracle.Index.build([g["query"]], k=k)
+        d, _, _ = idx.matching_statistics(g["reference"])
+        tr = oracle.translate_ms_vec(oracle.derandomize_ms_vec(d, k, t), k, t)
+        _, buf, n = idx.call(g["reference"], k, g["max_error_prob"])
+        assert oracle.add_variants(tr, buf, n).decode() == g["expected"], g["src"]
+
+
+def test_oracle_fill_gaps_goldens(golden, oracle):  # gap_filling.rs:419-441, 641-922
+    for g in golden["fill_gaps"]:
+        idx = oracle.Index.build([g["query"]], k=g["k"])
+        t = g["threshold"] if g["threshold"] is not None else \
+            oracle.random_match_threshold(g["k"], idx.n_kmers, 4, g["max_err_prob"])
+        d, _, _ = idx.matching_statistics(g["reference"])
+        tr = oracle.translate_ms_vec(oracle.derandomize_ms_vec(d, g["k"], t), g["k"], t)
+        assert idx.fill_gaps(tr, g["reference"], t, g["max_err_prob"]).decode() == g["expected"], g["src"]
+
+
+def test_oracle_map_goldens(golden, oracle):  # lib.rs:647-717
+    for g in golden["map"]:
+        idx = oracle.Index.build(g["query_seqs"], k=g["k"])
+        got = idx.map(g["ref_seq"], g["k"], g["max_error_prob"], g["fill_gaps"], g["call_variants"], g["format"])
+        assert got.decode() == g["expected"], g["src"]
