@@ -84,6 +84,14 @@ struct DevBuf {
     {
         if (p) (void)hipFree(p);
         p = nullptr;
+        cap = 0;
+    }
+    size_t cap = 0;
+    void ensure(size_t bytes) // grow-only: slot buffers are reused from slab to slab
+    {
+        if (bytes <= cap && p) return;
+        alloc(bytes);
+        cap = std::max<size_t>(bytes, 16);
     }
     ~DevBuf() { release(); }
     template <typename T> T *as() const { return static_cast<T *>(p); }
@@ -211,12 +219,24 @@ size_t random_match_threshold(size_t k, size_t n_kmers, size_t alphabet_size, do
 // ---- work decomposition ------------------------------------------------------------------
 // Reads become one item each.  Longer sequences are cut into chunks that restart the walk
 // k-1 bases upstream from the empty state (MS depends only on the last k bases).
+uint32_t max_len(const uint64_t *offsets, size_t n_seqs)
+{
+    uint64_t m = 0;
+    for (size_t s = 0; s < n_seqs; s++) m = std::max(m, offsets[s + 1] - offsets[s]);
+    return (uint32_t)std::min<uint64_t>(m, 0xFFFFFFFFu);
+}
+
+// emitted bases per chunk: aim for >= ~1M items when the input allows it, 128..4096 bases
+uint64_t walk_chunk(uint64_t total, uint32_t k)
+{
+    uint64_t chunk = std::min<uint64_t>(4096, std::max<uint64_t>(128, total >> 20));
+    return std::max<uint64_t>(chunk, 4ull * k);
+}
+
 void make_items_host(const uint64_t *offsets, size_t n_seqs, uint32_t k, std::vector<kbo::WalkItem> &items)
 {
     const uint64_t total = offsets[n_seqs] - offsets[0];
-    // aim for >= ~1M items when the input allows it, chunks of 128..4096 emitted bases
-    uint64_t chunk = std::min<uint64_t>(4096, std::max<uint64_t>(128, total >> 20));
-    chunk = std::max<uint64_t>(chunk, 4ull * k);
+    const uint64_t chunk = walk_chunk(total, k);
     items.clear();
     for (size_t s = 0; s < n_seqs; s++) {
         const uint64_t b = offsets[s], e = offsets[s + 1];
@@ -247,60 +267,117 @@ void check_batch(const void *concat, const uint64_t *offsets, size_t n_seqs)
     KBO_REQUIRE(offsets[0] == 0, KBO_E_BAD_ARG, "offsets[0] must be 0");
 }
 
-uint32_t max_len(const uint64_t *offsets, size_t n_seqs)
-{
-    uint64_t m = 0;
-    for (size_t s = 0; s < n_seqs; s++) m = std::max(m, offsets[s + 1] - offsets[s]);
-    return (uint32_t)std::min<uint64_t>(m, 0xFFFFFFFFu);
-}
-
 struct BatchOnDevice {
     DevBuf q, off, items, ms, lo, hi;
     uint64_t total = 0;
 };
 
-// upload + A1 over a host batch; leaves ms (and lo/hi) on the device
-void run_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
-                   bool want_ival, BatchOnDevice &B, hipStream_t stream)
+// upload + A1 over a host batch (asynchronous on `stream`); leaves ms (and lo/hi) on the device.
+// `items_keep` must stay alive until the stream has been synchronised.
+void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                       bool want_ival, BatchOnDevice &B, std::vector<kbo::WalkItem> &items_keep, hipStream_t stream)
 {
-    check_batch(concat, offsets, n_seqs);
     KBO_REQUIRE(idx->host.k <= 255, KBO_E_UNSUPPORTED, "k > 255");
     const int dev = current_device();
     kbo::DevIndexView view = device_view(idx, dev);
     const uint64_t total = offsets[n_seqs];
     B.total = total;
-    std::vector<kbo::WalkItem> items;
-    make_items_host(offsets, n_seqs, idx->host.k, items);
-    KBO_REQUIRE(items.size() < (1ull << 28), KBO_E_UNSUPPORTED, "more than 2^28 work items per call");
-    KBO_REQUIRE(total < 0xFFFFFF00ull, KBO_E_UNSUPPORTED, "4 GiB or more of query per call: split the batch");
+    // reads (nothing to chunk): the item list is derived from the offsets on the device;
+    // otherwise it is built here (chunks with k-1 warm-up bases) and uploaded
+    const uint64_t chunk = walk_chunk(total, idx->host.k);
+    const bool device_items = max_len(offsets, n_seqs) <= chunk;
+    size_t n_items = n_seqs;
+    if (!device_items) {
+        make_items_host(offsets, n_seqs, idx->host.k, items_keep);
+        n_items = items_keep.size();
+    }
+    KBO_REQUIRE(n_items < (1ull << 28), KBO_E_UNSUPPORTED, "more than 2^28 work items per launch");
+    KBO_REQUIRE(total < 0xFFFFFF00ull, KBO_E_UNSUPPORTED, "4 GiB or more of query in one launch");
 
     const size_t padded = ((total + 15) / 16) * 16 + 16;
-    B.q.alloc(padded);
-    B.off.alloc((n_seqs + 1) * sizeof(uint64_t));
-    B.items.alloc(items.size() * sizeof(kbo::WalkItem));
-    B.ms.alloc(padded);
+    B.q.ensure(padded);
+    B.off.ensure((n_seqs + 1) * sizeof(uint64_t));
+    B.items.ensure(n_items * sizeof(kbo::WalkItem));
+    B.ms.ensure(padded);
     if (want_ival) {
-        B.lo.alloc(total * sizeof(uint32_t));
-        B.hi.alloc(total * sizeof(uint32_t));
+        B.lo.ensure(total * sizeof(uint32_t));
+        B.hi.ensure(total * sizeof(uint32_t));
     }
     HIP_OK(hipMemcpyAsync(B.q.p, concat, total, hipMemcpyHostToDevice, stream));
     HIP_OK(hipMemcpyAsync(B.off.p, offsets, (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-    HIP_OK(hipMemcpyAsync(B.items.p, items.data(), items.size() * sizeof(kbo::WalkItem),
-                          hipMemcpyHostToDevice, stream));
+    if (device_items) HIP_OK(kbo::launch_make_items(B.off.as<uint64_t>(), (uint32_t)n_seqs, B.items.as<kbo::WalkItem>(), stream));
+    else
+        HIP_OK(hipMemcpyAsync(B.items.p, items_keep.data(), items_keep.size() * sizeof(kbo::WalkItem),
+                              hipMemcpyHostToDevice, stream));
     kbo::WalkArgs a;
     a.ix = view;
     a.q = B.q.as<uint8_t>();
     a.q_bytes = total;
     a.items = B.items.as<kbo::WalkItem>();
-    a.n_items = (uint32_t)items.size();
+    a.n_items = (uint32_t)n_items;
     a.rounds = 0;
     a.d_out = B.ms.as<uint8_t>();
     a.lo_out = want_ival ? B.lo.as<uint32_t>() : nullptr;
     a.hi_out = want_ival ? B.hi.as<uint32_t>() : nullptr;
     HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), stream));
-    // the items vector must outlive the async copy
-    HIP_OK(hipStreamSynchronize(stream));
 }
+
+void run_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                   bool want_ival, BatchOnDevice &B, hipStream_t stream)
+{
+    check_batch(concat, offsets, n_seqs);
+    std::vector<kbo::WalkItem> items;
+    enqueue_walk_host(idx, concat, offsets, n_seqs, want_ival, B, items, stream);
+    HIP_OK(hipStreamSynchronize(stream)); // the items vector must outlive the async copy
+}
+
+// ---- slabs: a host batch is processed in pieces of at most g_slab_bytes of query so that
+// (a) one launch stays below the 32-bit offset limits and (b) the H2D copy of slab i+1 and
+// the D2H copy of slab i-1 overlap the kernels of slab i (two streams, user buffers pinned
+// in place with hipHostRegister when that succeeds).
+size_t g_slab_bytes = 256ull << 20; // tools/bench_host.py: 12-15 Gbp/s host->host for 32..512 MiB slabs
+
+struct Slab {
+    size_t s0, s1;   // sequences [s0, s1)
+    uint64_t b0, b1; // bases [b0, b1)
+};
+
+std::vector<Slab> make_slabs(const uint64_t *offsets, size_t n_seqs, size_t max_bytes)
+{
+    std::vector<Slab> slabs;
+    size_t s0 = 0;
+    while (s0 < n_seqs) {
+        size_t s1 = s0 + 1;
+        while (s1 < n_seqs && offsets[s1 + 1] - offsets[s0] <= max_bytes) s1++;
+        slabs.push_back(Slab{s0, s1, offsets[s0], offsets[s1]});
+        s0 = s1;
+    }
+    return slabs;
+}
+
+struct HostPin { // pins a user buffer in place for the duration of a call (best effort)
+    void *p = nullptr;
+    HostPin(const void *ptr, size_t bytes)
+    {
+        if (bytes >= (8u << 20) && hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) == hipSuccess)
+            p = const_cast<void *>(ptr);
+        else (void)hipGetLastError();
+    }
+    ~HostPin() { if (p) (void)hipHostUnregister(p); }
+};
+
+struct StreamPair {
+    hipStream_t s[2] = {nullptr, nullptr};
+    StreamPair()
+    {
+        HIP_OK(hipStreamCreateWithFlags(&s[0], hipStreamNonBlocking));
+        HIP_OK(hipStreamCreateWithFlags(&s[1], hipStreamNonBlocking));
+    }
+    ~StreamPair()
+    {
+        for (auto x : s) if (x) (void)hipStreamDestroy(x);
+    }
+};
 
 void check_len_threshold(const uint64_t *offsets, size_t n_seqs, size_t k, size_t threshold)
 {
@@ -345,15 +422,33 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
     const size_t threshold = random_match_threshold(k, idx->host.n_kmers, 4, max_error_prob); // lib.rs:620
     check_batch(concat, offsets, n_seqs);
     check_len_threshold(offsets, n_seqs, k, threshold);
-    hipStream_t stream = nullptr;
-    BatchOnDevice B;
-    run_walk_host(idx, concat, offsets, n_seqs, false, B, stream);
-    DevBuf chars(((B.total + 15) / 16) * 16 + 16);
-    derand_translate_host_offsets(B.ms.as<uint8_t>(), B.off.as<uint64_t>(), offsets, n_seqs, (uint32_t)k,
-                                  (uint32_t)threshold, format ? B.q.as<uint8_t>() : nullptr, chars.as<uint8_t>(),
-                                  nullptr, stream);
-    HIP_OK(hipMemcpyAsync(chars_out, chars.p, B.total, hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipStreamSynchronize(stream));
+    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
+    const uint64_t total = offsets[n_seqs];
+    HostPin pin_in(concat, total), pin_out(chars_out, total);
+    StreamPair streams;
+    struct Slot {
+        BatchOnDevice B;
+        DevBuf chars;
+        std::vector<kbo::WalkItem> items;
+        std::vector<uint64_t> off;
+    } slot[2];
+    for (size_t i = 0; i < slabs.size(); i++) {
+        const Slab &sl = slabs[i];
+        Slot &S = slot[i & 1];
+        hipStream_t st = streams.s[i & 1];
+        HIP_OK(hipStreamSynchronize(st)); // slot buffers of slab i-2 are free again
+        const size_t ns = sl.s1 - sl.s0;
+        S.off.resize(ns + 1);
+        for (size_t j = 0; j <= ns; j++) S.off[j] = offsets[sl.s0 + j] - sl.b0;
+        enqueue_walk_host(idx, concat + sl.b0, S.off.data(), ns, false, S.B, S.items, st);
+        S.chars.ensure(((S.B.total + 15) / 16) * 16 + 16);
+        derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), S.off.data(), ns, (uint32_t)k,
+                                      (uint32_t)threshold, format ? S.B.q.as<uint8_t>() : nullptr,
+                                      S.chars.as<uint8_t>(), nullptr, st);
+        HIP_OK(hipMemcpyAsync(chars_out + sl.b0, S.chars.p, S.B.total, hipMemcpyDeviceToHost, st));
+    }
+    HIP_OK(hipStreamSynchronize(streams.s[0]));
+    HIP_OK(hipStreamSynchronize(streams.s[1]));
 }
 
 // matching statistics with intervals of a list of sequences, batched on the GPU
@@ -659,15 +754,25 @@ int kbo_ms_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offset
     return guarded([&] {
         KBO_REQUIRE(idx && d_out, KBO_E_BAD_ARG, "null argument");
         KBO_REQUIRE((lo_out == nullptr) == (hi_out == nullptr), KBO_E_BAD_ARG, "lo/hi must come together");
+        check_batch(concat, offsets, n_seqs);
         hipStream_t stream = nullptr;
-        BatchOnDevice B;
-        run_walk_host(idx, concat, offsets, n_seqs, lo_out != nullptr, B, stream);
-        HIP_OK(hipMemcpyAsync(d_out, B.ms.p, B.total, hipMemcpyDeviceToHost, stream));
-        if (lo_out) {
-            HIP_OK(hipMemcpyAsync(lo_out, B.lo.p, B.total * 4, hipMemcpyDeviceToHost, stream));
-            HIP_OK(hipMemcpyAsync(hi_out, B.hi.p, B.total * 4, hipMemcpyDeviceToHost, stream));
+        // intervals cost 8 more bytes per base on the device: smaller slabs
+        const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, lo_out ? g_slab_bytes / 4 : g_slab_bytes);
+        std::vector<uint64_t> off;
+        for (const Slab &sl : slabs) {
+            const size_t ns = sl.s1 - sl.s0;
+            off.resize(ns + 1);
+            for (size_t j = 0; j <= ns; j++) off[j] = offsets[sl.s0 + j] - sl.b0;
+            BatchOnDevice B;
+            std::vector<kbo::WalkItem> items;
+            enqueue_walk_host(idx, concat + sl.b0, off.data(), ns, lo_out != nullptr, B, items, stream);
+            HIP_OK(hipMemcpyAsync(d_out + sl.b0, B.ms.p, B.total, hipMemcpyDeviceToHost, stream));
+            if (lo_out) {
+                HIP_OK(hipMemcpyAsync(lo_out + sl.b0, B.lo.p, B.total * 4, hipMemcpyDeviceToHost, stream));
+                HIP_OK(hipMemcpyAsync(hi_out + sl.b0, B.hi.p, B.total * 4, hipMemcpyDeviceToHost, stream));
+            }
+            HIP_OK(hipStreamSynchronize(stream));
         }
-        HIP_OK(hipStreamSynchronize(stream));
     });
 }
 
@@ -1018,6 +1123,12 @@ int kbo_walk_geometry(int *blocks, int *threads)
         if (blocks) *blocks = walk_max_waves();
         if (threads) *threads = kbo::kWalkThreads;
     });
+}
+
+int kbo_set_slab_bytes(size_t bytes)
+{
+    g_slab_bytes = std::max<size_t>(1u << 16, std::min<size_t>(bytes, 0xF0000000ull));
+    return KBO_OK;
 }
 
 int kbo_set_walk_rare(int batch, int period)

@@ -27,7 +27,6 @@ typedef struct { uint64_t d, lo, hi; } ms_t;
 typedef struct { uint8_t *p; size_t n, cap; } bytes;
 static void b_free(bytes *b) { free(b->p); b->p = NULL; b->n = b->cap = 0; }
 static void b_reserve(bytes *b, size_t c) { if (c > b->cap) { b->cap = c * 2 + 16; b->p = (uint8_t *)realloc(b->p, b->cap); } }
-static void b_assign(bytes *b, const uint8_t *s, size_t n) { b_reserve(b, n); if (n) memcpy(b->p, s, n); b->n = n; }
 static void b_push_front(bytes *b, uint8_t c) { b_reserve(b, b->n + 1); memmove(b->p + 1, b->p, b->n); b->p[0] = c; b->n++; }
 static int b_contains(const bytes *b, uint8_t c) { return b->n && memchr(b->p, c, b->n) != NULL; }
 

@@ -376,6 +376,28 @@ def test_batch_reads_vs_oracle(oracle):
         assert [tuple(r) for r in rles[ro[s]:ro[s + 1]]] == exp
 
 
+def test_host_batches_in_slabs(oracle):
+    """Host batches larger than the slab size go through the two-stream slab pipeline."""
+    g = synth.genome(60_000, seed=51)
+    sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=2))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    concat, offsets = synth.reads(g, 5000, 100, 0.02)
+    long_q = g[1000:31000].copy()           # one sequence bigger than a slab
+    concat = np.concatenate([concat, long_q])
+    offsets = np.concatenate([offsets, [offsets[-1] + len(long_q)]]).astype(np.uint64)
+    exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
+    try:
+        kbo_amd.lib().kbo_set_slab_bytes(1 << 16)
+        assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars)
+        d, lo, hi = batch.ms_batch(sbwt, concat, offsets, want_intervals=True)
+        assert np.array_equal(d, exp_d)
+        d0, lo0, hi0 = ora.matching_statistics(concat[:100].tobytes())
+        assert np.array_equal(lo[:100], lo0.astype(np.uint32)) and np.array_equal(hi[:100], hi0.astype(np.uint32))
+        assert batch.map_batch(sbwt, concat, offsets, format=True).tobytes() == oracle.relative_to_ref(concat, exp_chars)
+    finally:
+        kbo_amd.lib().kbo_set_slab_bytes(256 << 20)
+
+
 def test_batch_rejects_like_reference():
     sbwt, lcs = kbo_amd.build([b"ACGTACGTTGCAACGT"], kbo_amd.BuildOpts(k=4))
     concat = np.frombuffer(b"ACGTAC", dtype=np.uint8)

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""End-to-end host->host rate of kbo_map_batch on the C2 workload (reads and output in host
+memory; PCIe-inclusive).  Not the bench.py metric — reported in DESIGN.md §7."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import kbo_amd  # noqa: E402
+from kbo_amd import batch, synth  # noqa: E402
+
+G, R = int(os.environ.get("G", 5_000_000)), int(os.environ.get("R", 4_000_000))
+g = synth.genome(G)
+sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=16))
+sbwt.to_device()
+concat, offsets = synth.reads(g, R, 150, 0.01)
+out = np.zeros(len(concat), dtype=np.uint8)  # allocated and touched once, outside the timed region
+L = kbo_amd.lib()
+for slab_mb in (32, 64, 128, 256, 512):
+    L.kbo_set_slab_bytes(slab_mb << 20)
+    best = 1e9
+    for _ in range(4):
+        t0 = time.perf_counter()
+        kbo_amd.check(L.kbo_map_batch(sbwt._h, concat.ctypes.data, offsets.ctypes.data, R, 1e-7, 1, out.ctypes.data))
+        best = min(best, time.perf_counter() - t0)
+    print(f"slab {slab_mb:4d} MiB: {R * 150 / best / 1e9:6.2f} Gbp/s host->host ({best * 1e3:.1f} ms for {R * 150 / 1e6:.0f} Mbp)", flush=True)
