@@ -230,113 +230,94 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
         // If a nearest bit lies outside the loaded rank block, it climbs a single level and
         // re-tries the extension.
         if (flags < F_BLOCK) {
+            // (written with selects rather than branches where the body is a few instructions:
+            // the SIMD issues one instruction of ANY kind per 4 cycles, so exec-mask bookkeeping
+            // around a short divergent body costs as much as the body)
             const bool con = (flags & F_CON) != 0;
             const uint32_t bl = div96(l), br = div96(r);
-            const bool null_c = cb == null_blk;
-            const uint32_t offA = con ? ent_byte0 + l * 12u : (null_c ? cb : cb + bl) << 4;
-            const uint32_t offB = con ? ent_byte0 + r * 12u : (null_c ? cb : cb + br) << 4;
-            const uint4 xA = ld16u(arena, offA);
-            const uint4 xB = ld16u(arena, offB);
+            const uint32_t bmask = cb == null_blk ? 0u : ~0u;
+            const uint32_t rkA = (cb + (bl & bmask)) << 4, rkB = (cb + (br & bmask)) << 4;
+            const uint32_t enA = ent_byte0 + ((l + (l << 1)) << 2), enB = ent_byte0 + ((r + (r << 1)) << 2);
+            const uint4 xA = ld16u(arena, con ? enA : rkA);
+            const uint4 xB = ld16u(arena, con ? enB : rkB);
             if (flags & F_QF) { // the query block after the current one (reads <= 16 bytes past the item)
                 qnxt = ld16u(qb, min(start + (i & ~15u) + 16u, q_end)); // stays within the 16-byte slack
                 flags &= ~F_QF;
             }
-            if (con) { // one level up the LCS interval tree
-                dbg_con++;
-                const uint32_t lv = max(xA.x, xB.x);
-                d = lv;
-                if (lv == 0) {
-                    l = 0;
-                    r = n;
-                    flags &= ~F_CON;
-                } else {
-                    l = xA.x == lv ? xA.y : l;
-                    r = xB.x == lv ? xB.z : r;
-                    if (!m || l <= tgt_l || r >= tgt_r) flags &= ~F_CON;
-                }
-            } else {
-                const uint32_t ol = l - bl * kRankRows, orr = r - br * kRankRows;
-                const uint32_t l2 = rank_eval(xA, ol), r2 = rank_eval(xB, orr);
-                const bool ok = l2 < r2;
-                if (ok) {
-                    l = l2;
-                    r = r2;
-                    d = min(d + 1, k);
-                }
-                if (ok || d == 0) {
-                    if (i >= warm) { // emit: output byte e = i - warm of this item
-                        const uint32_t e = i - warm;
-                        ocur |= d << ((e & 3u) * 8u);
-                        if (IVAL) {
-                            a.lo_out[start + i] = l;
-                            a.hi_out[start + i] = r;
+            // ---- contracting lanes: one level up the LCS interval tree
+            const uint32_t lv = max(xA.x, xB.x);
+            const bool root = lv == 0;
+            const uint32_t cl = root ? 0u : (xA.x == lv ? xA.y : l);
+            const uint32_t cr = root ? n : (xB.x == lv ? xB.z : r);
+            const bool cstop = root || !m || cl <= tgt_l || cr >= tgt_r;
+            // ---- extending lanes
+            const uint32_t ol = l - bl * kRankRows, orr = r - br * kRankRows;
+            const uint32_t l2 = rank_eval(xA, ol), r2 = rank_eval(xB, orr);
+            const bool ok = !con && l2 < r2;
+            const uint32_t d_ext = min(d + 1, k);
+            const bool accept = !con && (l2 < r2 || d == 0);
+            const bool fail = !con && !accept;
+            if (con) dbg_con++;
+            // nearest set bits of B_c around [l, r), used when the extension failed (searched only
+            // inside the 32-bit word that holds the position: set bits are a few rows apart, and a
+            // miss merely costs one extra extension attempt)
+            uint32_t dl, dr;
+            {
+                const uint32_t wsel = ol >> 5, pb = ol & 31u;
+                const uint32_t W = wsel == 0 ? xA.y : (wsel == 1 ? xA.z : xA.w);
+                const uint32_t below = W & ((1u << pb) - 1u);
+                dl = below ? pb - (31u - (uint32_t)__clz((int)below)) : 0u;
+            }
+            {
+                const uint32_t wsel = orr >> 5, pb = orr & 31u;
+                const uint32_t W = wsel == 0 ? xB.y : (wsel == 1 ? xB.z : xB.w);
+                const uint32_t above = W & (~0u << pb);
+                dr = above ? (uint32_t)__ffs((int)above) - pb : 0u; // (bit index - pb) + 1 rows to pass
+            }
+            m = fail ? ((dl && dr) ? 1u : 0u) : m;
+            tgt_l = fail ? l - dl : tgt_l; // row of the nearest set bit below l
+            tgt_r = fail ? r + dr : tgt_r; // one past the nearest set bit at/after r
+            // ---- new state
+            l = con ? cl : (ok ? l2 : l);
+            r = con ? cr : (ok ? r2 : r);
+            d = con ? lv : (ok ? d_ext : d);
+            flags = (con && cstop) ? (flags & ~F_CON) : (fail ? (flags | F_CON) : flags);
+            if (accept) {
+                if (i >= warm) { // emit: output byte e = i - warm of this item
+                    const uint32_t e = i - warm;
+                    ocur |= d << ((e & 3u) * 8u);
+                    if (IVAL) {
+                        a.lo_out[start + i] = l;
+                        a.hi_out[start + i] = r;
+                    }
+                    const bool fin_e = (i + 1 == len);
+                    if ((e & 3u) == 3u || fin_e) { // word complete (or item ends): move it into the block
+                        const uint32_t w = (e >> 2) & 3u;
+                        oblk.x = w == 0 ? ocur : oblk.x;
+                        oblk.y = w == 1 ? ocur : oblk.y;
+                        oblk.z = w == 2 ? ocur : oblk.z;
+                        oblk.w = w == 3 ? ocur : oblk.w;
+                        ocur = 0;
+                        if ((e & 15u) == 15u) { // full block: one unaligned 16-byte store
+                            st16u(a.d_out, start + warm + (e & ~15u), oblk);
+                        } else if (fin_e) { // tail of the item: words, then bytes
+                            st_partial(a.d_out + (start + warm + (e & ~15u)), oblk, (e & 15u) + 1u);
                         }
-                        const bool fin_e = (i + 1 == len);
-                        if ((e & 3u) == 3u || fin_e) { // word complete (or item ends): move it into the block
-                            const uint32_t w = (e >> 2) & 3u;
-                            oblk.x = w == 0 ? ocur : oblk.x;
-                            oblk.y = w == 1 ? ocur : oblk.y;
-                            oblk.z = w == 2 ? ocur : oblk.z;
-                            oblk.w = w == 3 ? ocur : oblk.w;
-                            ocur = 0;
-                            if ((e & 15u) == 15u) { // full block: one unaligned 16-byte store
-                                st16u(a.d_out, start + warm + (e & ~15u), oblk);
-                            } else if (fin_e) { // tail of the item: words, then bytes
-                                st_partial(a.d_out + (start + warm + (e & ~15u)), oblk, (e & 15u) + 1u);
-                            }
-                        }
                     }
-                    i++;
-                    if (i == len) flags |= F_DONE;
-                    else {
-                        if ((i & 3u) == 0) {
-                            if ((i & 15u) == 0) {
-                                qblk = qnxt;
-                                flags |= F_QF;
-                            }
-                            const uint32_t w = (i >> 2) & 3u;
-                            const uint32_t lo = (w & 1u) ? qblk.y : qblk.x, hi = (w & 1u) ? qblk.w : qblk.z;
-                            qcur = (w & 2u) ? hi : lo;
-                        }
-                        const uint32_t c = decode_base((qcur >> ((i & 3u) * 8u)) & 0xFFu);
-                        cb = c < 4u ? c * nblk : null_blk;
-                    }
-                } else { // empty extension at depth d > 0: contract.  Nearest set bits of B_c:
-#if KBO_NO_TARGETS
-                    m = 0;
-                    flags |= F_CON;
-#else
-                    uint32_t dl = 0, dr = 0; // 0 = not inside the loaded block
-                    {
-                        const uint64_t X = ~0ull << (ol & 63u);
-                        const uint32_t xl = (uint32_t)X, xh = (uint32_t)(X >> 32);
-                        const bool big = ol >= 64u;
-                        const uint32_t y = xA.y & ~(big ? 0u : xl), z = xA.z & ~(big ? 0u : xh),
-                                       w = xA.w & ~(big ? xl : ~0u);
-                        int top = -1; // highest set bit strictly below ol
-                        if (y) top = 31 - __clz((int)y);
-                        if (z) top = 63 - __clz((int)z);
-                        if (w) top = 95 - __clz((int)w);
-                        if (top >= 0) dl = ol - (uint32_t)top;
-                    }
-                    {
-                        const uint64_t X = ~0ull << (orr & 63u);
-                        const uint32_t xl = (uint32_t)X, xh = (uint32_t)(X >> 32);
-                        const bool big = orr >= 64u;
-                        const uint32_t y = xB.y & (big ? 0u : xl), z = xB.z & (big ? 0u : xh),
-                                       w = xB.w & (big ? xl : ~0u);
-                        int low = -1; // lowest set bit at or above orr
-                        if (w) low = 64 + __ffs((int)w) - 1;
-                        if (z) low = 32 + __ffs((int)z) - 1;
-                        if (y) low = __ffs((int)y) - 1;
-                        if (low >= 0) dr = (uint32_t)low - orr + 1u; // rows to pass on the right
-                    }
-                    m = (dl && dr) ? 1u : 0u; // targets known?
-                    tgt_l = l - dl;           // row of the nearest set bit below l
-                    tgt_r = r + dr;           // one past the nearest set bit at/after r
-                    flags |= F_CON;
-#endif
                 }
+                i++;
+                const bool fin = i == len;
+                const bool newblk = (i & 15u) == 0;
+                qblk.x = newblk ? qnxt.x : qblk.x;
+                qblk.y = newblk ? qnxt.y : qblk.y;
+                qblk.z = newblk ? qnxt.z : qblk.z;
+                qblk.w = newblk ? qnxt.w : qblk.w;
+                flags |= fin ? F_DONE : (newblk ? F_QF : 0u);
+                const uint32_t w = (i >> 2) & 3u;
+                const uint32_t lo = (w & 1u) ? qblk.y : qblk.x, hi = (w & 1u) ? qblk.w : qblk.z;
+                qcur = (w & 2u) ? hi : lo;
+                const uint32_t c = decode_base((qcur >> ((i & 3u) * 8u)) & 0xFFu);
+                cb = c < 4u ? c * nblk : null_blk;
             }
         }
     }
