@@ -98,11 +98,14 @@ struct DevBuf {
 };
 
 struct DevCopy {
-    DevBuf arena; // rank blocks of A,C,G,T followed by the LCS windows
+    DevBuf arena; // rank blocks of A,C,G,T | null block | contraction entries (32-bit build)
+    DevBuf ent;   // contraction entries as their own allocation (big build)
     uint64_t n_blocks = 0;
+    bool big = false;
 };
 
 int g_waves_per_cu = 0;
+bool g_force_big = false; // tests: use the 64-bit-offset entry layout regardless of size
 
 int current_device()
 {
@@ -140,18 +143,26 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
         DevCopy *dc = new DevCopy();
         try {
             const size_t per = lay.n_blocks * 16;
-            // arena = rank blocks of A,C,G,T | one all-zero "null" block | contraction entries
+            // arena = rank blocks of A,C,G,T | one all-zero "null" block | contraction entries.
+            // When that exceeds the 32-bit offset range (n_sets * 12 B of entries >= ~4 GiB) the
+            // entries get their own allocation and 64-bit offsets ("big" kernels).
             const size_t ent_bytes = lay.ent.size() * sizeof(uint32_t);
-            const size_t arena_bytes = per * 4 + 16 + ent_bytes;
-            KBO_REQUIRE(arena_bytes < 0xFFFFFFF0ull, KBO_E_UNSUPPORTED,
-                        "index arena >= 4 GiB: 64-bit device offsets not built yet");
+            const size_t rank_bytes = per * 4 + 16;
+            KBO_REQUIRE(rank_bytes < 0xFFFFFFF0ull, KBO_E_UNSUPPORTED, "rank blocks >= 4 GiB");
+            dc->big = g_force_big || rank_bytes + ent_bytes >= 0xFFFFFFF0ull;
+            const size_t arena_bytes = dc->big ? rank_bytes : rank_bytes + ent_bytes;
             dc->arena.alloc(arena_bytes);
             HIP_OK(hipMemset(dc->arena.p, 0, arena_bytes));
             for (int c = 0; c < 4; c++)
                 HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + per * c, lay.rank[c].data(), per,
                                  hipMemcpyHostToDevice));
-            HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + per * 4 + 16, lay.ent.data(), ent_bytes,
-                             hipMemcpyHostToDevice));
+            if (dc->big) {
+                dc->ent.alloc(ent_bytes + 16);
+                HIP_OK(hipMemcpy(dc->ent.p, lay.ent.data(), ent_bytes, hipMemcpyHostToDevice));
+            } else {
+                HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + rank_bytes, lay.ent.data(), ent_bytes,
+                                 hipMemcpyHostToDevice));
+            }
             dc->n_blocks = lay.n_blocks;
             idx->rank_bytes = per * 4;
             idx->lcs_bytes = ent_bytes;
@@ -168,6 +179,8 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
     v.arena = dc->arena.as<uint4>();
     v.n_blocks = (uint32_t)dc->n_blocks;
     v.lcs_off = (uint32_t)(dc->n_blocks * 4 + 1);
+    v.ent = dc->big ? dc->ent.as<uint8_t>() : nullptr;
+    v.big = dc->big ? 1u : 0u;
     v.n = (uint32_t)idx->host.n_sets;
     v.k = idx->host.k;
     return v;
@@ -1123,6 +1136,12 @@ int kbo_walk_geometry(int *blocks, int *threads)
         if (blocks) *blocks = walk_max_waves();
         if (threads) *threads = kbo::kWalkThreads;
     });
+}
+
+int kbo_set_force_big_layout(int on)
+{
+    g_force_big = on != 0; // applies to device copies made after the call
+    return KBO_OK;
 }
 
 int kbo_set_slab_bytes(size_t bytes)

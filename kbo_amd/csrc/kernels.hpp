@@ -10,7 +10,9 @@ namespace kbo {
 struct DevIndexView {
     const uint4 *arena;   // one allocation: rank blocks of A,C,G,T, then the LCS windows
     uint32_t n_blocks;    // rank blocks per character (character c starts at c * n_blocks)
-    uint32_t lcs_off;     // arena index (16-byte units) of LCS window 0
+    uint32_t lcs_off;     // arena index (16-byte units) of contraction entry 0 (32-bit build)
+    const uint8_t *ent;   // contraction entries as their own region (used when `big`)
+    uint32_t big;         // 1: entries are addressed with 64-bit offsets (n_sets * 12 B >= 4 GiB)
     uint32_t n;           // n_sets
     uint32_t k;
 };

@@ -133,7 +133,7 @@ __device__ __forceinline__ void st_partial(uint8_t *o, const uint4 &v, uint32_t 
 #define KBO_NO_TARGETS 0
 #endif
 
-template <bool IVAL>
+template <bool IVAL, bool BIG>
 __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
 {
     const uint32_t n = a.ix.n, k = a.ix.k;
@@ -237,9 +237,17 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
             const uint32_t bl = div96(l), br = div96(r);
             const uint32_t bmask = cb == null_blk ? 0u : ~0u;
             const uint32_t rkA = (cb + (bl & bmask)) << 4, rkB = (cb + (br & bmask)) << 4;
-            const uint32_t enA = ent_byte0 + ((l + (l << 1)) << 2), enB = ent_byte0 + ((r + (r << 1)) << 2);
-            const uint4 xA = ld16u(arena, con ? enA : rkA);
-            const uint4 xB = ld16u(arena, con ? enB : rkB);
+            uint4 xA, xB;
+            if (BIG) { // entries live in their own region, 64-bit offsets (n_sets * 12 B >= 4 GiB)
+                const uint8_t *pA = con ? a.ix.ent + (uint64_t)l * 12u : arena + rkA;
+                const uint8_t *pB = con ? a.ix.ent + (uint64_t)r * 12u : arena + rkB;
+                __builtin_memcpy(&xA, pA, 16);
+                __builtin_memcpy(&xB, pB, 16);
+            } else {
+                const uint32_t enA = ent_byte0 + ((l + (l << 1)) << 2), enB = ent_byte0 + ((r + (r << 1)) << 2);
+                xA = ld16u(arena, con ? enA : rkA);
+                xB = ld16u(arena, con ? enB : rkB);
+            }
             if (flags & F_QF) { // the query block after the current one (reads <= 16 bytes past the item)
                 qnxt = ld16u(qb, min(start + (i & ~15u) + 16u, q_end)); // stays within the 16-byte slack
                 flags &= ~F_QF;
@@ -687,8 +695,14 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
     const uint32_t threads = g_walk_threads;
     const uint32_t wpb = threads / 64;
     const dim3 grid((waves + wpb - 1) / wpb), block(threads);
-    if (a.lo_out && a.hi_out) hipLaunchKernelGGL(ms_walk_kernel<true>, grid, block, 0, stream, a);
-    else hipLaunchKernelGGL(ms_walk_kernel<false>, grid, block, 0, stream, a);
+    const bool ival = a.lo_out && a.hi_out;
+    if (a.ix.big) {
+        if (ival) hipLaunchKernelGGL((ms_walk_kernel<true, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((ms_walk_kernel<false, true>), grid, block, 0, stream, a);
+    } else {
+        if (ival) hipLaunchKernelGGL((ms_walk_kernel<true, false>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((ms_walk_kernel<false, false>), grid, block, 0, stream, a);
+    }
     return hipGetLastError();
 }
 

@@ -398,6 +398,27 @@ def test_host_batches_in_slabs(oracle):
         kbo_amd.lib().kbo_set_slab_bytes(256 << 20)
 
 
+def test_big_layout_parity(oracle):
+    """The 64-bit-offset entry layout (indexes whose contraction entries exceed 4 GiB, e.g. a
+    3 Gbp genome) exercised at small size: same results as the oracle."""
+    g = synth.genome(150_000, seed=61)
+    try:
+        kbo_amd.lib().kbo_set_force_big_layout(1)
+        sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=2))
+        ora = oracle.Index.build([g.tobytes()], k=31)
+        concat, offsets = synth.reads(g, 3000, 150, 0.03)
+        exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
+        d, lo, hi = batch.ms_batch(sbwt, concat, offsets, want_intervals=True)
+        assert np.array_equal(d, exp_d)
+        d0, lo0, hi0 = ora.matching_statistics(concat[:600].tobytes() )
+        assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars)
+        q = concat[:150].tobytes()
+        od, olo, ohi = ora.matching_statistics(q)
+        assert np.array_equal(lo[:150], olo.astype(np.uint32)) and np.array_equal(hi[:150], ohi.astype(np.uint32))
+    finally:
+        kbo_amd.lib().kbo_set_force_big_layout(0)
+
+
 def test_batch_rejects_like_reference():
     sbwt, lcs = kbo_amd.build([b"ACGTACGTTGCAACGT"], kbo_amd.BuildOpts(k=4))
     concat = np.frombuffer(b"ACGTAC", dtype=np.uint8)
