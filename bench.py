@@ -164,7 +164,7 @@ def main():
                 traffic = None
         rank_b, lcs_b = sbwt.device_bytes()
         result = {
-            "metric": "kbo map query throughput (k=31, 5 Mbp SBWT, bit-exact MS vs CPU)",
+            "metric": "query Mbp/sec for kbo map, k=31, 5 Mbp SBWT; bit-exact MS vs CPU",
             "value": round(world * bases * args.steps / elapsed / 1e6, 1),
             "unit": "Mbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
