@@ -262,6 +262,45 @@ def test_ms_index_missing_a_base(oracle):
     assert gd == d.tolist() and glo == lo.tolist() and ghi == hi.tolist()
 
 
+@pytest.mark.parametrize("k", [1, 2, 31, 255])
+def test_ms_edge_cases(oracle, k):
+    """Tiny / degenerate inputs: queries of length 1-3, all-N queries, an index that holds only
+    the root row (every sequence shorter than k), homopolymers, k at both ends of the range."""
+    rng = np.random.default_rng(k)
+    refs = [rng.choice(list(b"ACGT"), size=max(k + 5, 300)).astype(np.uint8).tobytes(), b"A" * (k + 40), b"ACG"]
+    sbwt, lcs = kbo_amd.build(refs, kbo_amd.BuildOpts(k=k))
+    ora = oracle.Index.build(refs, k=k)
+    queries = [b"A", b"CG", b"TTT", b"N", b"NNNNNNNN", b"A" * 100, refs[0][:k + 20], refs[0][3:3 + k] + b"N" + refs[0][:k],
+               b"acgt" * 5, refs[0][-k:] + b"T"]
+    for q in queries:
+        d, lo, hi = ora.matching_statistics(q)
+        gd, glo, ghi = _ms_tuple(kbo_amd.index.query_sbwt(q, sbwt, lcs))
+        assert gd == d.tolist() and glo == lo.tolist() and ghi == hi.tolist(), q
+    # index with no k-mer at all: only the root row
+    if k > 3:
+        empty, elcs = kbo_amd.build([b"ACG", b"T"], kbo_amd.BuildOpts(k=k))
+        assert empty.n_sets() == 1 and empty.n_kmers() == 0
+        got = kbo_amd.index.query_sbwt(b"ACGTACGT", empty, elcs)
+        assert [(d, r.start, r.stop) for d, r in got] == [(0, 0, 1)] * 8
+
+
+def test_matches_minimum_length_and_ragged(oracle):
+    """Sequences of exactly 3 bases (the shortest the reference accepts) next to longer ones."""
+    g = synth.genome(20_000, seed=71)
+    sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=11))
+    ora = oracle.Index.build([g.tobytes()], k=11)
+    lens = [3, 3, 4, 17, 3, 481, 480, 479, 16, 15, 33, 3]
+    reads = [g[100 * i:100 * i + L].tobytes() for i, L in enumerate(lens)]
+    concat = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    exp = ora.matches_batch(concat, offsets, 1e-3, n_threads=2)
+    assert np.array_equal(batch.matches_batch(sbwt, concat, offsets, 1e-3), exp)     # mixed: per-lane kernel (max 481)
+    short = [i for i, L in enumerate(lens) if L <= 480]
+    c2 = np.frombuffer(b"".join(reads[i] for i in short), dtype=np.uint8)
+    o2 = np.concatenate([[0], np.cumsum([lens[i] for i in short])]).astype(np.uint64)
+    assert np.array_equal(batch.matches_batch(sbwt, c2, o2, 1e-3), ora.matches_batch(c2, o2, 1e-3, n_threads=2))  # LDS kernel
+
+
 def test_ms_repetitive_index(oracle):
     """Repeats make (k-1)-suffix groups with several rows: the d==k contraction path."""
     unit = b"ACGGTCATTGACCAGT"
