@@ -16,6 +16,7 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.hpp"
@@ -105,6 +106,7 @@ struct DevCopy {
 };
 
 int g_waves_per_cu = 0;
+std::vector<int> g_devices; // devices the host batch entry points spread slabs over (empty = current)
 bool g_force_big = false; // tests: use the 64-bit-offset entry layout regardless of size
 
 int current_device()
@@ -438,30 +440,63 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
     const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
     const uint64_t total = offsets[n_seqs];
     HostPin pin_in(concat, total), pin_out(chars_out, total);
-    StreamPair streams;
-    struct Slot {
-        BatchOnDevice B;
-        DevBuf chars;
-        std::vector<kbo::WalkItem> items;
-        std::vector<uint64_t> off;
-    } slot[2];
-    for (size_t i = 0; i < slabs.size(); i++) {
-        const Slab &sl = slabs[i];
-        Slot &S = slot[i & 1];
-        hipStream_t st = streams.s[i & 1];
-        HIP_OK(hipStreamSynchronize(st)); // slot buffers of slab i-2 are free again
-        const size_t ns = sl.s1 - sl.s0;
-        S.off.resize(ns + 1);
-        for (size_t j = 0; j <= ns; j++) S.off[j] = offsets[sl.s0 + j] - sl.b0;
-        enqueue_walk_host(idx, concat + sl.b0, S.off.data(), ns, false, S.B, S.items, st);
-        S.chars.ensure(((S.B.total + 15) / 16) * 16 + 16);
-        derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), S.off.data(), ns, (uint32_t)k,
-                                      (uint32_t)threshold, format ? S.B.q.as<uint8_t>() : nullptr,
-                                      S.chars.as<uint8_t>(), nullptr, st);
-        HIP_OK(hipMemcpyAsync(chars_out + sl.b0, S.chars.p, S.B.total, hipMemcpyDeviceToHost, st));
+    // one worker per device (index replicated on each, slabs dealt round-robin, disjoint output
+    // slices: no exchange between devices); a single device runs on the calling thread
+    std::vector<int> devices = g_devices;
+    if (devices.empty()) devices.push_back(current_device());
+    const size_t nd = std::min(devices.size(), std::max<size_t>(1, slabs.size()));
+    auto worker = [&](size_t w) {
+        HIP_OK(hipSetDevice(devices[w]));
+        StreamPair streams;
+        struct Slot {
+            BatchOnDevice B;
+            DevBuf chars;
+            std::vector<kbo::WalkItem> items;
+            std::vector<uint64_t> off;
+        } slot[2];
+        size_t turn = 0;
+        for (size_t i = w; i < slabs.size(); i += nd, turn++) {
+            const Slab &sl = slabs[i];
+            Slot &S = slot[turn & 1];
+            hipStream_t st = streams.s[turn & 1];
+            HIP_OK(hipStreamSynchronize(st)); // slot buffers of the slab two turns ago are free again
+            const size_t ns = sl.s1 - sl.s0;
+            S.off.resize(ns + 1);
+            for (size_t j = 0; j <= ns; j++) S.off[j] = offsets[sl.s0 + j] - sl.b0;
+            enqueue_walk_host(idx, concat + sl.b0, S.off.data(), ns, false, S.B, S.items, st);
+            S.chars.ensure(((S.B.total + 15) / 16) * 16 + 16);
+            derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), S.off.data(), ns, (uint32_t)k,
+                                          (uint32_t)threshold, format ? S.B.q.as<uint8_t>() : nullptr,
+                                          S.chars.as<uint8_t>(), nullptr, st);
+            HIP_OK(hipMemcpyAsync(chars_out + sl.b0, S.chars.p, S.B.total, hipMemcpyDeviceToHost, st));
+        }
+        HIP_OK(hipStreamSynchronize(streams.s[0]));
+        HIP_OK(hipStreamSynchronize(streams.s[1]));
+    };
+    if (nd == 1) {
+        const int prev = current_device();
+        worker(0);
+        if (prev != devices[0]) HIP_OK(hipSetDevice(prev));
+        return;
     }
-    HIP_OK(hipStreamSynchronize(streams.s[0]));
-    HIP_OK(hipStreamSynchronize(streams.s[1]));
+    std::vector<std::thread> threads;
+    std::vector<std::string> errors(nd);
+    std::vector<int> codes(nd, KBO_OK);
+    for (size_t w = 0; w < nd; w++)
+        threads.emplace_back([&, w] {
+            try {
+                worker(w);
+            } catch (const KboError &e) {
+                codes[w] = e.code;
+                errors[w] = e.what();
+            } catch (const std::exception &e) {
+                codes[w] = KBO_E_HIP;
+                errors[w] = e.what();
+            }
+        });
+    for (auto &t : threads) t.join();
+    for (size_t w = 0; w < nd; w++)
+        if (codes[w] != KBO_OK) throw KboError(codes[w], errors[w]);
 }
 
 // matching statistics with intervals of a list of sequences, batched on the GPU
@@ -1135,6 +1170,17 @@ int kbo_walk_geometry(int *blocks, int *threads)
     return guarded([&] {
         if (blocks) *blocks = walk_max_waves();
         if (threads) *threads = kbo::kWalkThreads;
+    });
+}
+
+int kbo_set_devices(const int *devices, int n)
+{
+    return guarded([&] {
+        KBO_REQUIRE(n >= 0 && (devices || n == 0), KBO_E_BAD_ARG, "bad device list");
+        int count = 0;
+        HIP_OK(hipGetDeviceCount(&count));
+        for (int i = 0; i < n; i++) KBO_REQUIRE(devices[i] >= 0 && devices[i] < count, KBO_E_BAD_ARG, "no such device");
+        g_devices.assign(devices, devices + n);
     });
 }
 

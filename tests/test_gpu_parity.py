@@ -433,7 +433,13 @@ def test_host_batches_in_slabs(oracle):
         d0, lo0, hi0 = ora.matching_statistics(concat[:100].tobytes())
         assert np.array_equal(lo[:100], lo0.astype(np.uint32)) and np.array_equal(hi[:100], hi0.astype(np.uint32))
         assert batch.map_batch(sbwt, concat, offsets, format=True).tobytes() == oracle.relative_to_ref(concat, exp_chars)
+        # the same batch spread over a device list (two worker threads; here both on GPU 0)
+        import ctypes
+        devs = (ctypes.c_int * 2)(0, 0)
+        kbo_amd.check(kbo_amd.lib().kbo_set_devices(devs, 2))
+        assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars)
     finally:
+        kbo_amd.lib().kbo_set_devices(None, 0)
         kbo_amd.lib().kbo_set_slab_bytes(256 << 20)
 
 
