@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
         flags |= F_PF;
     }
 
-    uint32_t dbg_rare = 0, dbg_con = 0, dbg_iter = 0;
+    uint32_t dbg_rare = 0, dbg_con = 0, dbg_iter = 0, dbg_ext = 0, dbg_fail = 0;
     for (uint32_t iter = 0;; iter++) {
         dbg_iter = iter;
         // ================================ rare block ================================
@@ -266,6 +266,9 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
             const bool accept = !con && (l2 < r2 || d == 0);
             const bool fail = !con && !accept;
             if (con) dbg_con++;
+#ifdef KBO_WALK_DEBUG
+            dbg_ext += accept ? 1u : 0u; dbg_fail += fail ? 1u : 0u;
+#endif
             // nearest set bits of B_c around [l, r), used when the extension failed (searched only
             // inside the 32-bit word that holds the position: set bits are a few rows apart, and a
             // miss merely costs one extra extension attempt)
@@ -336,8 +339,13 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
         atomicAdd(a.hi_out + 2, dbg_con);
         atomicAdd(a.hi_out + 3, 1u);
     }
+    if (a.lo_out == nullptr && a.hi_out != nullptr) { // per-lane totals
+        atomicAdd(a.hi_out + 4, dbg_ext);
+        atomicAdd(a.hi_out + 5, dbg_fail);
+        atomicAdd(a.hi_out + 6, dbg_con);
+    }
 #endif
-    (void)dbg_rare; (void)dbg_con; (void)dbg_iter; (void)lane;
+    (void)dbg_rare; (void)dbg_con; (void)dbg_iter; (void)lane; (void)dbg_ext; (void)dbg_fail;
 }
 
 __global__ void make_items_kernel(const uint64_t *__restrict__ off, uint32_t n_seqs,
