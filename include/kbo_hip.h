@@ -236,11 +236,18 @@ int kbo_set_walk_waves_per_cu(int waves_per_cu); /* tuning knob, 0 = default (32
 int kbo_set_walk_threads(int threads);           /* tuning knob: workgroup size 64/128/256 */
 int kbo_set_walk_rare(int batch, int period);    /* tuning knob: rare-block batching */
 /* Devices the host batch entry points (kbo_matches_batch / kbo_map_batch / kbo_find_batch) spread
- * their slabs over: index replicated per device, one host thread + two streams per device, disjoint
- * output slices, no collective.  n = 0 restores the default (the current device). */
+ * their slabs over: index replicated per device, one submitting + one completing host thread and
+ * three stage streams (upload, kernels, download) per device, disjoint output slices, no collective.
+ * n = 0 restores the default (the current device). */
 int kbo_set_devices(const int *devices, int n);
+/* Host helper threads used by the host batch entry points for the staging copies between pageable
+ * user buffers and pinned memory (two teams of this size; default min(8, cores)). */
+int kbo_set_host_threads(int n);
+/* Frees the per-device scratch (streams, device buffers, pinned staging) the host batch entry
+ * points keep between calls. */
+int kbo_release_scratch(void);
 int kbo_set_force_big_layout(int on);            /* tests: force the 64-bit-offset contraction-entry layout */
-int kbo_set_slab_bytes(size_t bytes);            /* host batches are processed in slabs of at most this many query bytes (default 256 MiB) */
+int kbo_set_slab_bytes(size_t bytes);            /* host batches are processed in slabs of at most this many query bytes (default 32 MiB) */
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,11 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -241,17 +246,19 @@ uint32_t max_len(const uint64_t *offsets, size_t n_seqs)
     return (uint32_t)std::min<uint64_t>(m, 0xFFFFFFFFu);
 }
 
-// emitted bases per chunk: aim for >= ~1M items when the input allows it, 128..4096 bases
-uint64_t walk_chunk(uint64_t total, uint32_t k)
+// emitted bases per chunk: aim for >= ~1M items when the input allows it, 256..4096 bases
+// (every chunk after the first re-walks k-1 warm-up bases); a batch that already has enough
+// sequences to fill the device is only cut where a sequence is very long
+uint64_t walk_chunk(uint64_t total, size_t n_seqs, uint32_t k)
 {
-    uint64_t chunk = std::min<uint64_t>(4096, std::max<uint64_t>(128, total >> 20));
+    uint64_t chunk = n_seqs >= (1u << 19) ? 4096 : std::min<uint64_t>(4096, std::max<uint64_t>(256, total >> 20));
     return std::max<uint64_t>(chunk, 4ull * k);
 }
 
 void make_items_host(const uint64_t *offsets, size_t n_seqs, uint32_t k, std::vector<kbo::WalkItem> &items)
 {
     const uint64_t total = offsets[n_seqs] - offsets[0];
-    const uint64_t chunk = walk_chunk(total, k);
+    const uint64_t chunk = walk_chunk(total, n_seqs, k);
     items.clear();
     for (size_t s = 0; s < n_seqs; s++) {
         const uint64_t b = offsets[s], e = offsets[s + 1];
@@ -282,15 +289,35 @@ void check_batch(const void *concat, const uint64_t *offsets, size_t n_seqs)
     KBO_REQUIRE(offsets[0] == 0, KBO_E_BAD_ARG, "offsets[0] must be 0");
 }
 
+// KBO_TIMING=1 in the environment prints a phase breakdown of the host batch entry points to stderr
+struct PhaseClock {
+    bool on = std::getenv("KBO_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[kbo timing] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
 struct BatchOnDevice {
     DevBuf q, off, items, ms, lo, hi;
     uint64_t total = 0;
+    void release()
+    {
+        for (DevBuf *b : {&q, &off, &items, &ms, &lo, &hi}) b->release();
+    }
 };
 
 // upload + A1 over a host batch (asynchronous on `stream`); leaves ms (and lo/hi) on the device.
 // `items_keep` must stay alive until the stream has been synchronised.
 void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
-                       bool want_ival, BatchOnDevice &B, std::vector<kbo::WalkItem> &items_keep, hipStream_t stream)
+                       bool want_ival, BatchOnDevice &B, std::vector<kbo::WalkItem> &items_keep, hipStream_t stream,
+                       uint32_t longest = 0 /* longest sequence if the caller knows it */,
+                       hipStream_t copy_stream = nullptr /* uploads go here when given ... */,
+                       hipEvent_t copied = nullptr /* ... and `stream` waits for this event */)
 {
     KBO_REQUIRE(idx->host.k <= 255, KBO_E_UNSUPPORTED, "k > 255");
     const int dev = current_device();
@@ -299,8 +326,8 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
     B.total = total;
     // reads (nothing to chunk): the item list is derived from the offsets on the device;
     // otherwise it is built here (chunks with k-1 warm-up bases) and uploaded
-    const uint64_t chunk = walk_chunk(total, idx->host.k);
-    const bool device_items = max_len(offsets, n_seqs) <= chunk;
+    const uint64_t chunk = walk_chunk(total, n_seqs, idx->host.k);
+    const bool device_items = (longest ? longest : max_len(offsets, n_seqs)) <= chunk;
     size_t n_items = n_seqs;
     if (!device_items) {
         make_items_host(offsets, n_seqs, idx->host.k, items_keep);
@@ -318,12 +345,17 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
         B.lo.ensure(total * sizeof(uint32_t));
         B.hi.ensure(total * sizeof(uint32_t));
     }
-    HIP_OK(hipMemcpyAsync(B.q.p, concat, total, hipMemcpyHostToDevice, stream));
-    HIP_OK(hipMemcpyAsync(B.off.p, offsets, (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-    if (device_items) HIP_OK(kbo::launch_make_items(B.off.as<uint64_t>(), (uint32_t)n_seqs, B.items.as<kbo::WalkItem>(), stream));
-    else
+    hipStream_t up = copy_stream ? copy_stream : stream;
+    HIP_OK(hipMemcpyAsync(B.q.p, concat, total, hipMemcpyHostToDevice, up));
+    HIP_OK(hipMemcpyAsync(B.off.p, offsets, (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, up));
+    if (!device_items)
         HIP_OK(hipMemcpyAsync(B.items.p, items_keep.data(), items_keep.size() * sizeof(kbo::WalkItem),
-                              hipMemcpyHostToDevice, stream));
+                              hipMemcpyHostToDevice, up));
+    if (copy_stream) {
+        HIP_OK(hipEventRecord(copied, copy_stream));
+        HIP_OK(hipStreamWaitEvent(stream, copied, 0));
+    }
+    if (device_items) HIP_OK(kbo::launch_make_items(B.off.as<uint64_t>(), (uint32_t)n_seqs, B.items.as<kbo::WalkItem>(), stream));
     kbo::WalkArgs a;
     a.ix = view;
     a.q = B.q.as<uint8_t>();
@@ -350,7 +382,7 @@ void run_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offset
 // (a) one launch stays below the 32-bit offset limits and (b) the H2D copy of slab i+1 and
 // the D2H copy of slab i-1 overlap the kernels of slab i (two streams, user buffers pinned
 // in place with hipHostRegister when that succeeds).
-size_t g_slab_bytes = 256ull << 20; // tools/bench_host.py: 12-15 Gbp/s host->host for 32..512 MiB slabs
+size_t g_slab_bytes = 32ull << 20; // tools/bench_host.py: best of 8..128 MiB on the C2 reads
 
 struct Slab {
     size_t s0, s1;   // sequences [s0, s1)
@@ -362,35 +394,240 @@ std::vector<Slab> make_slabs(const uint64_t *offsets, size_t n_seqs, size_t max_
     std::vector<Slab> slabs;
     size_t s0 = 0;
     while (s0 < n_seqs) {
-        size_t s1 = s0 + 1;
-        while (s1 < n_seqs && offsets[s1 + 1] - offsets[s0] <= max_bytes) s1++;
+        // last s1 with offsets[s1] - offsets[s0] <= max_bytes (at least one sequence per slab)
+        size_t s1 = std::upper_bound(offsets + s0 + 1, offsets + n_seqs + 1, offsets[s0] + max_bytes) - offsets - 1;
+        s1 = std::max(s1, s0 + 1);
         slabs.push_back(Slab{s0, s1, offsets[s0], offsets[s1]});
         s0 = s1;
     }
     return slabs;
 }
 
-struct HostPin { // pins a user buffer in place for the duration of a call (best effort)
-    void *p = nullptr;
-    HostPin(const void *ptr, size_t bytes)
+// ---- host helper threads: staging copies and offset scans of the host batch entry points.
+// A process-wide team (leaked on purpose: its threads sleep on a condition variable until the
+// process ends); the calling thread takes part; one job at a time.
+class HostTeam {
+public:
+    static HostTeam &get() // staging copies into pinned memory, offset scans
     {
-        if (bytes >= (8u << 20) && hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) == hipSuccess)
-            p = const_cast<void *>(ptr);
-        else (void)hipGetLastError();
+        static HostTeam *team = new HostTeam();
+        return *team;
     }
-    ~HostPin() { if (p) (void)hipHostUnregister(p); }
+    static HostTeam &out() // copies out of pinned memory (runs next to get(): a second set of threads)
+    {
+        static HostTeam *team = new HostTeam();
+        return *team;
+    }
+    void set_threads(unsigned n) { want_ = std::max(1u, std::min(n, 64u)); }
+    // runs fn(0..n_tasks-1), returns when all are done
+    void run(size_t n_tasks, const std::function<void(size_t)> &fn)
+    {
+        if (n_tasks == 0) return;
+        if (n_tasks == 1 || want_ <= 1) {
+            for (size_t i = 0; i < n_tasks; i++) fn(i);
+            return;
+        }
+        std::lock_guard<std::mutex> one_job(job_mu_);
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            while (threads_.size() + 1 < want_) threads_.emplace_back([this] { loop(); });
+            fn_ = &fn;
+            next_ = 0;
+            total_ = n_tasks;
+            remaining_ = n_tasks;
+            gen_++;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(mu_);
+        done_cv_.wait(g, [&] { return remaining_ == 0; });
+        fn_ = nullptr;
+    }
+    void copy(void *dst, const void *src, size_t bytes)
+    {
+        const size_t piece = 2u << 20;
+        run((bytes + piece - 1) / piece, [&](size_t i) {
+            const size_t a = i * piece, b = std::min(bytes, a + piece);
+            std::memcpy(static_cast<char *>(dst) + a, static_cast<const char *>(src) + a, b - a);
+        });
+    }
+
+private:
+    void work()
+    {
+        for (;;) {
+            size_t i;
+            const std::function<void(size_t)> *fn;
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (!fn_ || next_ >= total_) return;
+                i = next_++;
+                fn = fn_;
+            }
+            (*fn)(i);
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (--remaining_ == 0) done_cv_.notify_all();
+            }
+        }
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+            }
+            work();
+        }
+    }
+    std::mutex job_mu_, mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> threads_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    size_t next_ = 0, total_ = 0, remaining_ = 0;
+    uint64_t gen_ = 0;
+    unsigned want_ = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
 };
 
-struct StreamPair {
-    hipStream_t s[2] = {nullptr, nullptr};
-    StreamPair()
-    {
-        HIP_OK(hipStreamCreateWithFlags(&s[0], hipStreamNonBlocking));
-        HIP_OK(hipStreamCreateWithFlags(&s[1], hipStreamNonBlocking));
+// one pass over the offsets of a batch: order, emptiness, shortest and longest sequence
+struct OffsetScan {
+    bool monotone = true;
+    uint64_t shortest = ~0ull, longest = 0;
+};
+OffsetScan scan_offsets(const uint64_t *offsets, size_t n_seqs)
+{
+    const size_t piece = 1u << 18;
+    const size_t n_tasks = (n_seqs + piece - 1) / piece;
+    std::vector<OffsetScan> part(n_tasks);
+    HostTeam::get().run(n_tasks, [&](size_t t) {
+        OffsetScan r;
+        const size_t a = t * piece, b = std::min(n_seqs, a + piece);
+        for (size_t s = a; s < b; s++) {
+            r.monotone &= offsets[s + 1] >= offsets[s];
+            const uint64_t len = offsets[s + 1] - offsets[s];
+            r.shortest = std::min(r.shortest, len);
+            r.longest = std::max(r.longest, len);
+        }
+        part[t] = r;
+    });
+    OffsetScan r;
+    for (const OffsetScan &x : part) {
+        r.monotone &= x.monotone;
+        r.shortest = std::min(r.shortest, x.shortest);
+        r.longest = std::max(r.longest, x.longest);
     }
-    ~StreamPair()
+    return r;
+}
+
+struct PinBuf { // pinned host staging memory, grow-only
+    void *p = nullptr;
+    size_t cap = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+    void ensure(size_t bytes)
     {
-        for (auto x : s) if (x) (void)hipStreamDestroy(x);
+        if (bytes <= cap && p) return;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipHostMalloc(&p, std::max<size_t>(bytes, 16), hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            throw KboError(KBO_E_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        }
+        cap = std::max<size_t>(bytes, 16);
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+bool is_pinned_host(const void *ptr) // memory the DMA engines can reach without staging
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+// ---- per-device scratch of the host batch entry points, kept between calls: slabs rotate
+// through kHostSlots slots, each with its own stream, device buffers and pinned staging, so
+// that the staging copy + H2D of slab i+1 and the D2H + copy-out of slab i-1 overlap the
+// kernels of slab i.
+constexpr int kHostSlots = 4;
+struct HostSlot {
+    BatchOnDevice B;
+    DevBuf chars;
+    PinBuf in, out, off;
+    std::vector<kbo::WalkItem> items;
+    hipEvent_t copied = nullptr, computed = nullptr, done = nullptr;
+    bool busy = false;     // a slab is in flight in this slot
+    uint64_t out_b0 = 0, out_bytes = 0;
+};
+struct HostCtx {
+    int dev = 0;
+    HostSlot slot[kHostSlots];
+    // one stream per stage, so that every stage runs one slab at a time, in order, next to the
+    // other two stages: upload (copy engine), kernels, download (copy kernel)
+    hipStream_t st_up = nullptr, st_run = nullptr, st_down = nullptr;
+    explicit HostCtx(int d) : dev(d)
+    {
+        for (hipStream_t *st : {&st_up, &st_run, &st_down}) HIP_OK(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+        for (HostSlot &S : slot)
+            for (hipEvent_t *e : {&S.copied, &S.computed, &S.done}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    ~HostCtx()
+    {
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(dev);
+        for (hipStream_t st : {st_up, st_run, st_down})
+            if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+        for (HostSlot &S : slot)
+            for (hipEvent_t e : {S.copied, S.computed, S.done})
+                if (e) (void)hipEventDestroy(e);
+        for (HostSlot &S : slot) { // buffers belong to `dev`
+            S.B.release();
+            S.chars.release();
+        }
+        (void)hipSetDevice(prev);
+    }
+};
+std::mutex g_ctx_mu;
+// leaked on purpose: destroying streams from a static destructor would run after the HIP runtime is gone
+std::vector<std::unique_ptr<HostCtx>> &g_ctx_pool = *new std::vector<std::unique_ptr<HostCtx>>();
+
+struct CtxLease { // takes a context of the device out of the pool (or makes one), puts it back
+    std::unique_ptr<HostCtx> ctx;
+    explicit CtxLease(int dev)
+    {
+        {
+            std::lock_guard<std::mutex> g(g_ctx_mu);
+            for (size_t i = 0; i < g_ctx_pool.size(); i++)
+                if (g_ctx_pool[i]->dev == dev) {
+                    ctx = std::move(g_ctx_pool[i]);
+                    g_ctx_pool.erase(g_ctx_pool.begin() + i);
+                    break;
+                }
+        }
+        if (!ctx) ctx.reset(new HostCtx(dev));
+    }
+    ~CtxLease()
+    {
+        bool busy = false; // an error may have left work in flight
+        for (HostSlot &S : ctx->slot) {
+            busy |= S.busy;
+            S.busy = false;
+        }
+        if (busy)
+            for (hipStream_t st : {ctx->st_up, ctx->st_run, ctx->st_down}) (void)hipStreamSynchronize(st);
+        std::lock_guard<std::mutex> g(g_ctx_mu);
+        g_ctx_pool.push_back(std::move(ctx));
     }
 };
 
@@ -407,9 +644,9 @@ void check_len_threshold(const uint64_t *offsets, size_t n_seqs, size_t k, size_
 // sequences -> one lane each, very long sequences -> chunked scan (one at a time).
 void derand_translate_host_offsets(const uint8_t *d_ms, const uint64_t *d_off, const uint64_t *offsets, size_t n_seqs,
                                    uint32_t k, uint32_t threshold, const uint8_t *d_ref, uint8_t *d_chars,
-                                   int32_t *d_derand, hipStream_t stream)
+                                   int32_t *d_derand, hipStream_t stream, uint32_t longest = 0)
 {
-    const uint32_t mx = max_len(offsets, n_seqs);
+    const uint32_t mx = longest ? longest : max_len(offsets, n_seqs);
     HIP_OK(kbo::launch_derand_translate(d_ms, d_off, (uint32_t)n_seqs, k, threshold, d_ref, d_chars, d_derand, mx,
                                         kbo::kLongSeq, stream));
     if (mx <= kbo::kLongSeq) return;
@@ -433,45 +670,164 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
                         double max_error_prob, bool format, uint8_t *chars_out)
 {
     KBO_REQUIRE(idx && chars_out, KBO_E_BAD_ARG, "null argument");
+    PhaseClock clk;
     const size_t k = idx->host.k;
     const size_t threshold = random_match_threshold(k, idx->host.n_kmers, 4, max_error_prob); // lib.rs:620
-    check_batch(concat, offsets, n_seqs);
-    check_len_threshold(offsets, n_seqs, k, threshold);
+    KBO_REQUIRE(concat && offsets, KBO_E_BAD_ARG, "null concat/offsets");
+    KBO_REQUIRE(n_seqs > 0, KBO_E_EMPTY_QUERY, "no sequences");
+    KBO_REQUIRE(n_seqs < 0xFFFFFFFFull, KBO_E_UNSUPPORTED, "more than 2^32-1 sequences per call");
+    KBO_REQUIRE(offsets[0] == 0, KBO_E_BAD_ARG, "offsets[0] must be 0");
+    const OffsetScan scan = scan_offsets(offsets, n_seqs);
+    KBO_REQUIRE(scan.monotone, KBO_E_BAD_ARG, "offsets not monotone");
+    KBO_REQUIRE(scan.shortest > 0, KBO_E_EMPTY_QUERY, "empty query (index.rs:248 assert!(!query.is_empty()))");
+    KBO_REQUIRE(scan.longest < 0xFFFFFFFFull, KBO_E_UNSUPPORTED, "sequence longer than 2^32-1");
+    KBO_REQUIRE(k > 0, KBO_E_BAD_ARG, "k > 0 (derandomize.rs:274)");
+    KBO_REQUIRE(threshold > 1, KBO_E_THRESHOLD_LE_1, "threshold > 1 (derandomize.rs:275, translate.rs:269)");
+    KBO_REQUIRE(scan.shortest > 2, KBO_E_LEN_LE_2, "len > 2 (derandomize.rs:276, translate.rs:270)");
+    clk.lap("argument checks");
     const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
-    const uint64_t total = offsets[n_seqs];
-    HostPin pin_in(concat, total), pin_out(chars_out, total);
+    // user buffers the DMA engines can reach directly are used in place, pageable ones are staged
+    const bool in_pinned = is_pinned_host(concat), out_pinned = is_pinned_host(chars_out);
+    clk.lap("slab list");
     // one worker per device (index replicated on each, slabs dealt round-robin, disjoint output
     // slices: no exchange between devices); a single device runs on the calling thread
     std::vector<int> devices = g_devices;
     if (devices.empty()) devices.push_back(current_device());
     const size_t nd = std::min(devices.size(), std::max<size_t>(1, slabs.size()));
+    HostTeam &team = HostTeam::get();
     auto worker = [&](size_t w) {
         HIP_OK(hipSetDevice(devices[w]));
-        StreamPair streams;
-        struct Slot {
-            BatchOnDevice B;
-            DevBuf chars;
-            std::vector<kbo::WalkItem> items;
-            std::vector<uint64_t> off;
-        } slot[2];
-        size_t turn = 0;
-        for (size_t i = w; i < slabs.size(); i += nd, turn++) {
-            const Slab &sl = slabs[i];
-            Slot &S = slot[turn & 1];
-            hipStream_t st = streams.s[turn & 1];
-            HIP_OK(hipStreamSynchronize(st)); // slot buffers of the slab two turns ago are free again
-            const size_t ns = sl.s1 - sl.s0;
-            S.off.resize(ns + 1);
-            for (size_t j = 0; j <= ns; j++) S.off[j] = offsets[sl.s0 + j] - sl.b0;
-            enqueue_walk_host(idx, concat + sl.b0, S.off.data(), ns, false, S.B, S.items, st);
-            S.chars.ensure(((S.B.total + 15) / 16) * 16 + 16);
-            derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), S.off.data(), ns, (uint32_t)k,
-                                          (uint32_t)threshold, format ? S.B.q.as<uint8_t>() : nullptr,
-                                          S.chars.as<uint8_t>(), nullptr, st);
-            HIP_OK(hipMemcpyAsync(chars_out + sl.b0, S.chars.p, S.B.total, hipMemcpyDeviceToHost, st));
+        CtxLease lease(devices[w]);
+        HostCtx &C = *lease.ctx;
+        // The calling thread stages and submits slabs; a second thread completes them in
+        // submission order (waits for the slab's event, copies the staged output to the user
+        // buffer), so the two host copies of a slab never queue behind each other.
+        std::mutex mu;
+        std::condition_variable cv;
+        size_t submitted = 0, drained = 0;
+        bool stop = false;
+        int drain_code = KBO_OK;
+        std::string drain_error;
+        std::thread drainer([&] {
+            try {
+                HIP_OK(hipSetDevice(devices[w]));
+                for (;;) {
+                    size_t turn;
+                    {
+                        std::unique_lock<std::mutex> g(mu);
+                        cv.wait(g, [&] { return drained < submitted || stop; });
+                        if (drained >= submitted) return;
+                        turn = drained;
+                    }
+                    HostSlot &S = C.slot[turn % kHostSlots];
+                    HIP_OK(hipEventSynchronize(S.done));
+                    if (!out_pinned) HostTeam::out().copy(chars_out + S.out_b0, S.out.p, S.out_bytes);
+                    S.busy = false;
+                    {
+                        std::lock_guard<std::mutex> g(mu);
+                        drained++;
+                    }
+                    cv.notify_all();
+                }
+            } catch (const KboError &e) {
+                std::lock_guard<std::mutex> g(mu);
+                drain_code = e.code;
+                drain_error = e.what();
+                drained = ~size_t(0) / 2; // releases the submitting thread
+                cv.notify_all();
+            } catch (const std::exception &e) {
+                std::lock_guard<std::mutex> g(mu);
+                drain_code = KBO_E_HIP;
+                drain_error = e.what();
+                drained = ~size_t(0) / 2;
+                cv.notify_all();
+            }
+        });
+        auto join_drainer = [&] {
+            {
+                std::lock_guard<std::mutex> g(mu);
+                stop = true;
+            }
+            cv.notify_all();
+            if (drainer.joinable()) drainer.join();
+        };
+        try {
+            size_t turn = 0;
+            for (size_t i = w; i < slabs.size(); i += nd, turn++) {
+                const Slab &sl = slabs[i];
+                HostSlot &S = C.slot[turn % kHostSlots];
+                {
+                    std::unique_lock<std::mutex> g(mu);
+                    cv.wait(g, [&] { return turn < drained + kHostSlots; }); // the slot is free again
+                    if (drain_code != KBO_OK) break;
+                }
+                if (w == 0) clk.lap("  wait for a free slot");
+                const size_t ns = sl.s1 - sl.s0;
+                const uint64_t bytes = sl.b1 - sl.b0;
+                // stage: slab-relative offsets (and the longest sequence of the slab), query bytes
+                S.off.ensure((ns + 1) * sizeof(uint64_t));
+                uint64_t *off = S.off.as<uint64_t>();
+                const size_t piece = 1u << 15, n_tasks = (ns + 1 + piece - 1) / piece;
+                std::vector<uint64_t> longest(n_tasks, 0);
+                team.run(n_tasks, [&](size_t t) {
+                    const size_t a = t * piece, b = std::min(ns + 1, a + piece);
+                    uint64_t m = 0;
+                    for (size_t j = a; j < b; j++) {
+                        off[j] = offsets[sl.s0 + j] - sl.b0;
+                        if (j < ns) m = std::max(m, offsets[sl.s0 + j + 1] - offsets[sl.s0 + j]);
+                    }
+                    longest[t] = m;
+                });
+                const uint32_t mx = (uint32_t)*std::max_element(longest.begin(), longest.end());
+                const uint8_t *src = concat + sl.b0;
+                if (!in_pinned) {
+                    S.in.ensure(bytes);
+                    team.copy(S.in.p, src, bytes);
+                    src = S.in.as<uint8_t>();
+                }
+                if (w == 0) clk.lap("  offsets + copy in");
+                enqueue_walk_host(idx, src, off, ns, false, S.B, S.items, C.st_run, mx, C.st_up, S.copied);
+                // D2H leg: hipMemcpyAsync on the download stream.  With one stream per stage the copy
+                // engines carry both directions at once (tools/bench_host.py: 37-40 Gbp/s host->host);
+                // the alternatives measured slower and stay selectable for experiments: KBO_D2H=kernel
+                // (a small kernel stores into pinned host memory, 28 Gbp/s), KBO_D2H=direct (A5/A6
+                // store to host memory themselves, 26 Gbp/s).
+                static const char *d2h_env = std::getenv("KBO_D2H");
+                static const int d2h_mode = !d2h_env ? 1 : (std::strcmp(d2h_env, "kernel") == 0 ? 0 : (std::strcmp(d2h_env, "direct") == 0 ? 2 : 1));
+                uint8_t *dst = chars_out + sl.b0;
+                if (!out_pinned) {
+                    S.out.ensure(bytes + 32);
+                    dst = S.out.as<uint8_t>();
+                }
+                const bool direct = d2h_mode == 2 && mx <= kbo::kLongSeq && (((uintptr_t)dst & 3) == 0);
+                if (!direct) S.chars.ensure(((S.B.total + 15) / 16) * 16 + 16);
+                derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, (uint32_t)k,
+                                              (uint32_t)threshold, format ? S.B.q.as<uint8_t>() : nullptr,
+                                              direct ? dst : S.chars.as<uint8_t>(), nullptr, C.st_run, mx);
+                HIP_OK(hipEventRecord(S.computed, C.st_run));
+                HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
+                if (!direct) {
+                    if (d2h_mode == 1) HIP_OK(hipMemcpyAsync(dst, S.chars.p, bytes, hipMemcpyDeviceToHost, C.st_down));
+                    else HIP_OK(kbo::launch_copy_to_host(S.chars.as<uint8_t>(), dst, bytes, C.st_down));
+                }
+                HIP_OK(hipEventRecord(S.done, C.st_down));
+                S.busy = true;
+                S.out_b0 = sl.b0;
+                S.out_bytes = bytes;
+                {
+                    std::lock_guard<std::mutex> g(mu);
+                    submitted++;
+                }
+                cv.notify_all();
+                if (w == 0) clk.lap("  enqueue");
+            }
+        } catch (...) {
+            join_drainer();
+            throw;
         }
-        HIP_OK(hipStreamSynchronize(streams.s[0]));
-        HIP_OK(hipStreamSynchronize(streams.s[1]));
+        join_drainer();
+        if (drain_code != KBO_OK) throw KboError(drain_code, drain_error);
+        if (w == 0) clk.lap("drain");
     };
     if (nd == 1) {
         const int prev = current_device();
@@ -1181,6 +1537,21 @@ int kbo_set_devices(const int *devices, int n)
         HIP_OK(hipGetDeviceCount(&count));
         for (int i = 0; i < n; i++) KBO_REQUIRE(devices[i] >= 0 && devices[i] < count, KBO_E_BAD_ARG, "no such device");
         g_devices.assign(devices, devices + n);
+    });
+}
+
+int kbo_set_host_threads(int n)
+{
+    HostTeam::get().set_threads(n < 1 ? 1u : (unsigned)n);
+    HostTeam::out().set_threads(n < 1 ? 1u : (unsigned)n);
+    return KBO_OK;
+}
+
+int kbo_release_scratch(void)
+{
+    return guarded([&] {
+        std::lock_guard<std::mutex> g(g_ctx_mu);
+        g_ctx_pool.clear();
     });
 }
 

@@ -41,6 +41,9 @@ struct WalkArgs {
 };
 
 // offsets (n_seqs+1) -> one item per sequence
+// device -> pinned host copy done by a small kernel instead of the copy engine
+hipError_t launch_copy_to_host(const uint8_t *d_src, uint8_t *h_dst, uint64_t bytes, hipStream_t stream);
+
 hipError_t launch_make_items(const uint64_t *d_offsets, uint32_t n_seqs, WalkItem *d_items,
                              hipStream_t stream);
 // A1: k-bounded matching statistics over all items

@@ -667,7 +667,28 @@ __global__ void translate_kernel(const int32_t *__restrict__ x, uint64_t len, ui
     out[p] = translate_char(xm, xc, xn, p, len, (int)k, (int)t);
 }
 
+// Copies `bytes` from device memory to pinned host memory with plain stores.  A small
+// grid-stride grid: it is PCIe-bound, leaves the copy engine to the opposite direction and
+// takes only a few wave slots per CU away from the walk kernel of the next slab.
+__global__ void copy_to_host_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint64_t bytes)
+{
+    const uint64_t n16 = bytes >> 4;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint4 v;
+        __builtin_memcpy(&v, src + (i << 4), 16);
+        __builtin_memcpy(dst + (i << 4), &v, 16);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (bytes & 15u)) dst[(n16 << 4) + threadIdx.x] = src[(n16 << 4) + threadIdx.x];
+}
+
 } // namespace
+
+hipError_t launch_copy_to_host(const uint8_t *d_src, uint8_t *h_dst, uint64_t bytes, hipStream_t stream)
+{
+    if (bytes == 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_to_host_kernel, dim3(256), dim3(256), 0, stream, d_src, h_dst, bytes);
+    return hipGetLastError();
+}
 
 hipError_t launch_make_items(const uint64_t *d_offsets, uint32_t n_seqs, WalkItem *d_items,
                              hipStream_t stream)

@@ -18,7 +18,7 @@ sbwt.to_device()
 concat, offsets = synth.reads(g, R, 150, 0.01)
 out = np.zeros(len(concat), dtype=np.uint8)  # allocated and touched once, outside the timed region
 L = kbo_amd.lib()
-for slab_mb in (32, 64, 128, 256, 512):
+for slab_mb in [int(x) for x in os.environ.get('SLABS', '32,64,128,256').split(',')]:
     L.kbo_set_slab_bytes(slab_mb << 20)
     best = 1e9
     for _ in range(4):
