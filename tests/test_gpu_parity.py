@@ -416,7 +416,8 @@ def test_batch_reads_vs_oracle(oracle):
 
 
 def test_host_batches_in_slabs(oracle):
-    """Host batches larger than the slab size go through the two-stream slab pipeline."""
+    """Host batches larger than the slab size go through the staged slab pipeline (more slabs than
+    slots, so staging buffers and device buffers are reused within one call)."""
     g = synth.genome(60_000, seed=51)
     sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=2))
     ora = oracle.Index.build([g.tobytes()], k=31)
@@ -440,7 +441,48 @@ def test_host_batches_in_slabs(oracle):
         assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars)
     finally:
         kbo_amd.lib().kbo_set_devices(None, 0)
-        kbo_amd.lib().kbo_set_slab_bytes(256 << 20)
+        kbo_amd.lib().kbo_set_slab_bytes(32 << 20)
+
+
+def test_host_batches_concurrent_callers_and_pinned_buffers(oracle):
+    """The handle is immutable, so several host threads may run batches on it at once (each call takes
+    its own scratch from the pool); buffers that are already pinned are used in place, not staged."""
+    import threading
+    import torch
+    g = synth.genome(80_000, seed=52)
+    sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=2))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    work = []
+    for t in range(4):
+        concat, offsets = synth.reads(g, 3000 + 500 * t, 120, 0.02, seed=100 + t)
+        work.append((concat, offsets, ora.matches_batch(concat, offsets, 1e-7, n_threads=2)))
+    got = [None] * len(work)
+    try:
+        kbo_amd.lib().kbo_set_slab_bytes(1 << 16)
+
+        def run(i):
+            got[i] = batch.matches_batch(sbwt, work[i][0], work[i][1])
+
+        for rep in range(3):
+            threads = [threading.Thread(target=run, args=(i,)) for i in range(len(work))]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            for i, (concat, offsets, exp) in enumerate(work):
+                assert np.array_equal(got[i], exp), f"thread {i} rep {rep}"
+        # pinned input and output (torch pinned tensors viewed as numpy): no staging copies
+        concat, offsets, exp = work[0]
+        pin_in = torch.empty(len(concat), dtype=torch.uint8).pin_memory()
+        pin_in.numpy()[:] = concat
+        pin_out = torch.zeros(len(concat), dtype=torch.uint8).pin_memory()
+        kbo_amd.check(kbo_amd.lib().kbo_matches_batch(sbwt._h, pin_in.data_ptr(), offsets.ctypes.data, len(offsets) - 1,
+                                                      1e-7, pin_out.data_ptr()))
+        assert np.array_equal(pin_out.numpy(), exp)
+        kbo_amd.check(kbo_amd.lib().kbo_release_scratch())
+        assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp)
+    finally:
+        kbo_amd.lib().kbo_set_slab_bytes(32 << 20)
 
 
 def test_big_layout_parity(oracle):

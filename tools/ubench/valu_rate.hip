@@ -31,7 +31,7 @@ DEFK(k_mad24, "v_mad_u32_u24 %0, %0, %6, %1\n v_mad_u32_u24 %1, %1, %6, %2\n v_m
 DEFK(k_mad64, "v_mad_u64_u32 %4, vcc, %0, %6, %4\n v_mad_u64_u32 %5, vcc, %1, %6, %5\n v_mad_u64_u32 %4, vcc, %2, %6, %4\n v_mad_u64_u32 %5, vcc, %3, %6, %5")
 DEFK(k_bcnt, "v_bcnt_u32_b32 %0, %0, %1\n v_bcnt_u32_b32 %1, %1, %2\n v_bcnt_u32_b32 %2, %2, %3\n v_bcnt_u32_b32 %3, %3, %0")
 DEFK(k_lshl64, "v_lshlrev_b64 %4, %0, %4\n v_lshlrev_b64 %5, %1, %5\n v_lshlrev_b64 %4, %2, %4\n v_lshlrev_b64 %5, %3, %5")
-DEFK(k_cndmask, "v_cndmask_b32 %0, %0, %6, vcc\n v_cndmask_b32 %1, %1, %6, vcc\n v_cndmask_b32 %2, %2, %6, vcc\n v_cndmask_b32 %3, %3, %6, vcc")
+DEFK(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc")
 DEFK(k_cmp_s, "v_cmp_lt_u32 s[10:11], %0, %1\n v_cmp_lt_u32 s[12:13], %1, %2\n v_cmp_lt_u32 s[10:11], %2, %3\n v_cmp_lt_u32 s[12:13], %3, %0")
 DEFK(k_lshl_add, "v_lshl_add_u32 %0, %0, 3, %1\n v_lshl_add_u32 %1, %1, 3, %2\n v_lshl_add_u32 %2, %2, 3, %3\n v_lshl_add_u32 %3, %3, 3, %0")
 DEFK(k_add3, "v_add3_u32 %0, %0, %1, %2\n v_add3_u32 %1, %1, %2, %3\n v_add3_u32 %2, %2, %3, %0\n v_add3_u32 %3, %3, %0, %1")
