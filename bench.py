@@ -155,14 +155,18 @@ def main():
         if b_alg is None:
             b_alg = 85.7  # SURVEY.md §8(d) figure for 1 % substitutions (used when the oracle leg is skipped)
         achieved = b_alg * bases / (walk_ms * 1e-3) / 1e9
+        # PMC traffic of the walk kernel, from the committed rocprofv3 passes of this exact workload
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("ms_walk_hbm_bytes_per_launch")
+                entry = json.load(open(tpath)).get("workloads", {}).get(f"{args.genome}x{args.reads}x{args.read_len}")
+                traffic = entry.get("ms_walk_hbm_bytes_per_launch") if entry else None
             except Exception:
                 traffic = None
         rank_b, lcs_b = sbwt.device_bytes()
+        pair_b = sbwt.device_pair_bytes()
+        resident = rank_b + lcs_b + pair_b < 200e6
         result = {
             "metric": "query Mbp/sec for kbo map, k=31, 5 Mbp SBWT; bit-exact MS vs CPU",
             "value": round(world * bases * args.steps / elapsed / 1e6, 1),
@@ -177,14 +181,16 @@ def main():
                                    f"{args.reads} x {args.read_len} bp reads per GPU, "
                                    f"{args.sub_rate * 100:g}% substitutions",
                        "index_n_sets": sbwt.n_sets(), "threshold": dev.threshold,
-                       "index_device_bytes": {"rank_blocks": rank_b, "lcs": lcs_b},
+                       "index_device_bytes": {"rank_blocks": rank_b, "lcs": lcs_b, "two_base_blocks": pair_b},
                        "parallelism": f"index replicated x{world}, reads sharded, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel": "ms_walk_kernel", "kernel_ms": round(walk_ms, 4),
                          "algorithmic_bytes_per_base": round(b_alg, 2),
-                         "note": "index is L2/Infinity-Cache resident at this config: algorithmic bytes "
-                                 "are served on-die, so measured HBM traffic is far below them"},
+                         "note": ("index is L2/Infinity-Cache resident at this config: algorithmic bytes "
+                                  "are served on-die, so measured HBM traffic is far below them") if resident else
+                                 ("index exceeds L2: the walk is bound by L2-miss line fills (about 56 G/s on "
+                                  "this part, 128 B each of which 16 B are used), see DESIGN.md section 6")},
             "kernels_ms": {"ms_walk": round(walk_ms, 4), "derand_translate": round(dt_ms, 4)},
             "cpu_baseline": cpu,
             "bit_exact_vs_oracle": exact,

@@ -136,6 +136,8 @@ int kbo_index_load(const char *path, kbo_index_t **out);
 int kbo_index_to_device(kbo_index_t *idx, int device);
 /* Bytes of the device-resident layout: rank blocks / contraction entries {lcs,psv,nsv}. */
 int kbo_index_device_bytes(const kbo_index_t *idx, uint64_t *rank_bytes, uint64_t *lcs_bytes);
+/* bytes of two-base extension blocks a device copy of this index carries (0 = none, see kbo_set_pair_steps) */
+uint64_t kbo_index_device_pair_bytes(const kbo_index_t *idx);
 
 /* ------------------------------------------------------------------ A3 (host, f64)
  * derandomize::log_rm_max_cdf (derandomize.rs:91-100) and
@@ -246,6 +248,10 @@ int kbo_set_host_threads(int n);
 /* Frees the per-device scratch (streams, device buffers, pinned staging) the host batch entry
  * points keep between calls. */
 int kbo_release_scratch(void);
+/* Two-base extension blocks (2.7 B per index row on the device): built for indexes with at least
+ * min_rows rows (default 24 Mi; 0 = always, UINT64_MAX = never; applies to device copies made after
+ * the call), used by the walk from matches at least min_depth deep (default 16; < 0 keeps it). */
+int kbo_set_pair_steps(uint64_t min_rows, int min_depth);
 int kbo_set_force_big_layout(int on);            /* tests: force the 64-bit-offset contraction-entry layout */
 int kbo_set_slab_bytes(size_t bytes);            /* host batches are processed in slabs of at most this many query bytes (default 32 MiB) */
 

@@ -108,11 +108,13 @@ struct DevCopy {
     DevBuf ent;   // contraction entries as their own allocation (big build)
     uint64_t n_blocks = 0;
     bool big = false;
+    uint32_t pair_off = 0; // arena index of the two-base extension blocks, 0 = none
 };
 
 int g_waves_per_cu = 0;
 std::vector<int> g_devices; // devices the host batch entry points spread slabs over (empty = current)
-bool g_force_big = false; // tests: use the 64-bit-offset entry layout regardless of size
+bool g_force_big = false;
+uint64_t g_pair_min_rows = 24ull << 20; // indexes with at least this many rows get two-base blocks on the device // tests: use the 64-bit-offset entry layout regardless of size
 
 int current_device()
 {
@@ -143,8 +145,13 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
     if (it == idx->dev.end()) {
         KBO_REQUIRE(idx->host.n_sets < 0xFFFFFFF0ull, KBO_E_UNSUPPORTED,
                     "n_sets >= 2^32: 64-bit device layout not built yet");
+        // two-base extension blocks: worth their 2.7 B/row once the one-base blocks stop fitting L2
+        // (the walk is then bound by line fills, and a two-base step needs one instead of two)
+        const size_t est_rank = (idx->host.n_sets / 96 + 2) * 64, est_ent = (idx->host.n_sets + 2) * 12;
+        const bool want_pairs = idx->host.n_sets >= g_pair_min_rows && !g_force_big &&
+                                est_rank * 5 + est_ent + 64 < 0xFFFFFFF0ull;
         kbo::DeviceLayout lay;
-        kbo::make_device_layout(idx->host, lay);
+        kbo::make_device_layout(idx->host, lay, want_pairs);
         int prev = current_device();
         if (prev != device) HIP_OK(hipSetDevice(device));
         DevCopy *dc = new DevCopy();
@@ -157,7 +164,9 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
             const size_t rank_bytes = per * 4 + 16;
             KBO_REQUIRE(rank_bytes < 0xFFFFFFF0ull, KBO_E_UNSUPPORTED, "rank blocks >= 4 GiB");
             dc->big = g_force_big || rank_bytes + ent_bytes >= 0xFFFFFFF0ull;
-            const size_t arena_bytes = dc->big ? rank_bytes : rank_bytes + ent_bytes;
+            const size_t pair_bytes = dc->big ? 0 : lay.pair.size() * sizeof(uint32_t);
+            const size_t base_bytes = ((dc->big ? rank_bytes : rank_bytes + ent_bytes) + 15) / 16 * 16;
+            const size_t arena_bytes = base_bytes + pair_bytes;
             dc->arena.alloc(arena_bytes);
             HIP_OK(hipMemset(dc->arena.p, 0, arena_bytes));
             for (int c = 0; c < 4; c++)
@@ -169,6 +178,10 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
             } else {
                 HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + rank_bytes, lay.ent.data(), ent_bytes,
                                  hipMemcpyHostToDevice));
+            }
+            if (pair_bytes) {
+                HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + base_bytes, lay.pair.data(), pair_bytes, hipMemcpyHostToDevice));
+                dc->pair_off = (uint32_t)(base_bytes / 16);
             }
             dc->n_blocks = lay.n_blocks;
             idx->rank_bytes = per * 4;
@@ -186,6 +199,7 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
     v.arena = dc->arena.as<uint4>();
     v.n_blocks = (uint32_t)dc->n_blocks;
     v.lcs_off = (uint32_t)(dc->n_blocks * 4 + 1);
+    v.pair_off = dc->pair_off;
     v.ent = dc->big ? dc->ent.as<uint8_t>() : nullptr;
     v.big = dc->big ? 1u : 0u;
     v.n = (uint32_t)idx->host.n_sets;
@@ -1135,6 +1149,12 @@ int kbo_index_device_bytes(const kbo_index_t *idx, uint64_t *rank_bytes, uint64_
     });
 }
 
+uint64_t kbo_index_device_pair_bytes(const kbo_index_t *idx)
+{
+    if (!idx || idx->host.n_sets < g_pair_min_rows || g_force_big) return 0;
+    return (idx->host.n_sets / kbo::kRankRowsPerBlock + 2) * 16 * 16;
+}
+
 int kbo_log_rm_max_cdf(size_t t, size_t alphabet_size, size_t n_kmers, double *out)
 {
     return guarded([&] {
@@ -1553,6 +1573,13 @@ int kbo_release_scratch(void)
         std::lock_guard<std::mutex> g(g_ctx_mu);
         g_ctx_pool.clear();
     });
+}
+
+int kbo_set_pair_steps(uint64_t min_rows, int min_depth)
+{
+    g_pair_min_rows = min_rows; // applies to device copies made after the call
+    if (min_depth >= 0) kbo::set_pair_min_depth(min_depth);
+    return KBO_OK;
 }
 
 int kbo_set_force_big_layout(int on)

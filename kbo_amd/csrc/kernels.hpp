@@ -11,6 +11,7 @@ struct DevIndexView {
     const uint4 *arena;   // one allocation: rank blocks of A,C,G,T, then the LCS windows
     uint32_t n_blocks;    // rank blocks per character (character c starts at c * n_blocks)
     uint32_t lcs_off;     // arena index (16-byte units) of contraction entry 0 (32-bit build)
+    uint32_t pair_off;    // arena index (16-byte units) of the two-base extension blocks, 0 = none
     const uint8_t *ent;   // contraction entries as their own region (used when `big`)
     uint32_t big;         // 1: entries are addressed with 64-bit offsets (n_sets * 12 B >= 4 GiB)
     uint32_t n;           // n_sets
@@ -35,15 +36,16 @@ struct WalkArgs {
     uint32_t rounds;       // items per lane (set by launch_ms_walk)
     uint32_t rare_batch;   // enter the rare block when this many lanes are blocked ...
     uint32_t rare_mask;    // ... or when (iteration & rare_mask) == 0 and any lane is
+    uint32_t pair_min_d;   // two-base steps only from matches at least this deep (set by launch_ms_walk)
     uint8_t *d_out;        // 1 byte per base, same indexing as q
     uint32_t *lo_out;      // optional (nullptr): interval start per base
     uint32_t *hi_out;      // optional: interval end per base
 };
 
-// offsets (n_seqs+1) -> one item per sequence
 // device -> pinned host copy done by a small kernel instead of the copy engine
 hipError_t launch_copy_to_host(const uint8_t *d_src, uint8_t *h_dst, uint64_t bytes, hipStream_t stream);
 
+// offsets (n_seqs+1) -> one item per sequence
 hipError_t launch_make_items(const uint64_t *d_offsets, uint32_t n_seqs, WalkItem *d_items,
                              hipStream_t stream);
 // A1: k-bounded matching statistics over all items
@@ -68,6 +70,7 @@ hipError_t launch_translate(const int32_t *d_derand, uint64_t len, uint32_t k, u
 constexpr int kWalkThreads = 64; // default workgroup size (waves are independent: no LDS, no barriers)
 void set_walk_threads(int threads); // tuning: 64, 128 or 256
 void set_walk_rare(int batch, int period); // tuning: rare-block batching
+void set_pair_min_depth(int d);            // tuning: depth from which two-base steps are tried
 constexpr uint32_t kRankRows = 96; // rows per 16-byte rank block (== kRankRowsPerBlock)
 
 } // namespace kbo

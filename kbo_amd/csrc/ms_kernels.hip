@@ -31,6 +31,7 @@ enum : uint32_t {
     F_PF = 4u,    // next item's descriptor is in flight, its query words not yet requested
     // bits >= F_BLOCK take the lane out of the hot path until the rare block has run
     F_CON = 8u,   // contracting: loads contraction entries instead of rank blocks
+    F_NOPAIR = 16u, // the two-base step failed for the current base: take it alone
     F_DONE = 32u, // finished its item, wants the next one
     F_FIN = 64u,  // no items left
     F_BLOCK = 32u
@@ -133,7 +134,35 @@ __device__ __forceinline__ void st_partial(uint8_t *o, const uint4 &v, uint32_t 
 #define KBO_NO_TARGETS 0
 #endif
 
-template <bool IVAL, bool BIG>
+// Appends the MS value of base i of the item to its output stream (16-byte item-relative blocks:
+// output byte e = i - warm).  fin_e: base i is the last one of the item.
+__device__ __forceinline__ void emit_ms(uint8_t *d_out, uint32_t start, uint32_t warm, uint32_t i, bool fin_e,
+                                        uint32_t dval, uint32_t &ocur, uint4 &oblk)
+{
+    const uint32_t e = i - warm;
+    ocur |= dval << ((e & 3u) * 8u);
+    if ((e & 3u) == 3u || fin_e) { // word complete (or item ends): move it into the block
+        const uint32_t w = (e >> 2) & 3u;
+        oblk.x = w == 0 ? ocur : oblk.x;
+        oblk.y = w == 1 ? ocur : oblk.y;
+        oblk.z = w == 2 ? ocur : oblk.z;
+        oblk.w = w == 3 ? ocur : oblk.w;
+        ocur = 0;
+        if ((e & 15u) == 15u) { // full block: one unaligned 16-byte store
+            st16u(d_out, start + warm + (e & ~15u), oblk);
+        } else if (fin_e) { // tail of the item: words, then bytes
+            st_partial(d_out + (start + warm + (e & ~15u)), oblk, (e & 15u) + 1u);
+        }
+    }
+}
+
+// PAIR: the index carries two-base extension blocks (DevIndexView::pair_off) and lanes that are deep
+// in a match extend by two bases per iteration: pair_extend(I, c1 c2) = extend(extend(I, c1), c2)
+// exactly (same block format, bit i of D_{c1c2} = B_c1[i] & B_c2[C[c1] + rank_c1(i)]), and a
+// non-empty result means neither step needed a contraction, so the two emitted values are
+// min(d+1, k) and min(d+2, k).  An empty result says nothing: the lane falls back to single steps
+// for that base.  Halves the line fills per base where the index does not fit L2.
+template <bool IVAL, bool BIG, bool PAIR>
 __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
 {
     const uint32_t n = a.ix.n, k = a.ix.k;
@@ -146,6 +175,7 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
     const uint32_t nblk = a.ix.n_blocks;
     const uint32_t null_blk = 4u * nblk; // all-zero rank block (non-ACGT bases)
     const uint32_t ent_byte0 = a.ix.lcs_off << 4; // arena byte offset of contraction entry 0
+    const uint32_t pair_blk0 = a.ix.pair_off;     // arena index of the first two-base block (PAIR)
 
     // this lane's items: first, first + 64, ...
     const uint64_t first64 = (uint64_t)wave * 64u * a.rounds + lane;
@@ -155,6 +185,7 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
 
     uint32_t flags = left ? F_DONE : F_FIN;
     uint32_t l = 0, r = n, d = 0, m = 0, cb = 0; // m: contraction targets known (rare block only)
+    uint32_t pcb = 0; // PAIR: first two-base block of (current base, next base), 0 = no pair step here
     uint32_t tgt_l = 0, tgt_r = 0; // contraction targets (rare block only)
     // Query and output are streamed in 16-byte blocks RELATIVE TO THE ITEM (unaligned global
     // accesses): i = base index inside the item; block i>>4, word (i>>2)&3, byte i&3.
@@ -197,6 +228,10 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
                     qcur = qblk.x;
                     const uint32_t c = decode_base(qcur & 0xFFu);
                     cb = c < 4u ? c * nblk : null_blk;
+                    if (PAIR) {
+                        const uint32_t c2 = len > 1u ? decode_base((qcur >> 8) & 0xFFu) : 4u;
+                        pcb = (c < 4u && c2 < 4u) ? pair_blk0 + (c * 4u + c2) * nblk : 0u;
+                    }
                     l = 0;
                     r = n;
                     d = 0;
@@ -236,7 +271,9 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
             const bool con = (flags & F_CON) != 0;
             const uint32_t bl = div96(l), br = div96(r);
             const uint32_t bmask = cb == null_blk ? 0u : ~0u;
-            const uint32_t rkA = (cb + (bl & bmask)) << 4, rkB = (cb + (br & bmask)) << 4;
+            const bool pair_try = PAIR && !con && pcb != 0u && !(flags & F_NOPAIR) && d >= a.pair_min_d;
+            const uint32_t xb = pair_try ? pcb : cb; // first block of the bit-vector this lane ranks in
+            const uint32_t rkA = (xb + (bl & bmask)) << 4, rkB = (xb + (br & bmask)) << 4;
             uint4 xA, xB;
             if (BIG) { // entries live in their own region, 64-bit offsets (n_sets * 12 B >= 4 GiB)
                 const uint8_t *pA = con ? a.ix.ent + (uint64_t)l * 12u : arena + rkA;
@@ -262,9 +299,11 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
             const uint32_t ol = l - bl * kRankRows, orr = r - br * kRankRows;
             const uint32_t l2 = rank_eval(xA, ol), r2 = rank_eval(xB, orr);
             const bool ok = !con && l2 < r2;
-            const uint32_t d_ext = min(d + 1, k);
-            const bool accept = !con && (l2 < r2 || d == 0);
-            const bool fail = !con && !accept;
+            const uint32_t d_one = min(d + 1, k);
+            const uint32_t d_ext = pair_try ? min(d + 2, k) : d_one;
+            const bool accept = !con && (l2 < r2 || (d == 0 && !pair_try));
+            const bool fail = !con && !accept && !pair_try; // a failed pair step proves nothing
+            if (PAIR) flags = (pair_try && !ok) ? (flags | F_NOPAIR) : ((accept && !pair_try) ? (flags & ~F_NOPAIR) : flags);
             if (con) dbg_con++;
 #ifdef KBO_WALK_DEBUG
             dbg_ext += accept ? 1u : 0u; dbg_fail += fail ? 1u : 0u;
@@ -295,26 +334,15 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
             flags = (con && cstop) ? (flags & ~F_CON) : (fail ? (flags | F_CON) : flags);
             if (accept) {
                 if (i >= warm) { // emit: output byte e = i - warm of this item
-                    const uint32_t e = i - warm;
-                    ocur |= d << ((e & 3u) * 8u);
                     if (IVAL) {
                         a.lo_out[start + i] = l;
                         a.hi_out[start + i] = r;
                     }
-                    const bool fin_e = (i + 1 == len);
-                    if ((e & 3u) == 3u || fin_e) { // word complete (or item ends): move it into the block
-                        const uint32_t w = (e >> 2) & 3u;
-                        oblk.x = w == 0 ? ocur : oblk.x;
-                        oblk.y = w == 1 ? ocur : oblk.y;
-                        oblk.z = w == 2 ? ocur : oblk.z;
-                        oblk.w = w == 3 ? ocur : oblk.w;
-                        ocur = 0;
-                        if ((e & 15u) == 15u) { // full block: one unaligned 16-byte store
-                            st16u(a.d_out, start + warm + (e & ~15u), oblk);
-                        } else if (fin_e) { // tail of the item: words, then bytes
-                            st_partial(a.d_out + (start + warm + (e & ~15u)), oblk, (e & 15u) + 1u);
-                        }
-                    }
+                    emit_ms(a.d_out, start, warm, i, i + 1 == len, pair_try ? d_one : d, ocur, oblk);
+                }
+                if (PAIR && pair_try) { // second base of the pair (same query word, never the item's first)
+                    i++;
+                    if (i >= warm) emit_ms(a.d_out, start, warm, i, i + 1 == len, d, ocur, oblk);
                 }
                 i++;
                 const bool fin = i == len;
@@ -329,6 +357,11 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
                 qcur = (w & 2u) ? hi : lo;
                 const uint32_t c = decode_base((qcur >> ((i & 3u) * 8u)) & 0xFFu);
                 cb = c < 4u ? c * nblk : null_blk;
+                if (PAIR) { // the base after it, when it sits in the same query word
+                    const uint32_t c2 = ((i & 3u) != 3u && i + 1u < len)
+                                            ? decode_base((qcur >> ((i & 3u) * 8u + 8u)) & 0xFFu) : 4u;
+                    pcb = (c < 4u && c2 < 4u) ? pair_blk0 + (c * 4u + c2) * nblk : 0u;
+                }
             }
         }
     }
@@ -701,6 +734,8 @@ hipError_t launch_make_items(const uint64_t *d_offsets, uint32_t n_seqs, WalkIte
 
 int g_walk_threads = kWalkThreads;
 int g_rare_batch = 32, g_rare_period = 16; // tuned on C2 (tools/sweep_walk.py RARE=1)
+int g_pair_min_depth = 16;                 // two-base steps only from matches at least this deep
+void set_pair_min_depth(int d) { g_pair_min_depth = d < 0 ? 0 : d; }
 void set_walk_rare(int batch, int period)
 {
     g_rare_batch = std::max(1, std::min(64, batch));
@@ -725,12 +760,14 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
     const uint32_t wpb = threads / 64;
     const dim3 grid((waves + wpb - 1) / wpb), block(threads);
     const bool ival = a.lo_out && a.hi_out;
+    a.pair_min_d = (uint32_t)g_pair_min_depth;
     if (a.ix.big) {
-        if (ival) hipLaunchKernelGGL((ms_walk_kernel<true, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((ms_walk_kernel<false, true>), grid, block, 0, stream, a);
+        if (ival) hipLaunchKernelGGL((ms_walk_kernel<true, true, false>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((ms_walk_kernel<false, true, false>), grid, block, 0, stream, a);
     } else {
-        if (ival) hipLaunchKernelGGL((ms_walk_kernel<true, false>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((ms_walk_kernel<false, false>), grid, block, 0, stream, a);
+        if (ival) hipLaunchKernelGGL((ms_walk_kernel<true, false, false>), grid, block, 0, stream, a);
+        else if (a.ix.pair_off) hipLaunchKernelGGL((ms_walk_kernel<false, false, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((ms_walk_kernel<false, false, false>), grid, block, 0, stream, a);
     }
     return hipGetLastError();
 }

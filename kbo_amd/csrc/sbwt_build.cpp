@@ -368,7 +368,7 @@ void build_host_index(const uint8_t *const *seqs, const size_t *lens, size_t n_s
     else build_impl<8>(seqs, lens, n_seqs, p, out);
 }
 
-void make_device_layout(const HostIndex &h, DeviceLayout &out)
+void make_device_layout(const HostIndex &h, DeviceLayout &out, bool with_pairs)
 {
     const uint64_t n = h.n_sets;
     out.n_blocks = n / kRankRowsPerBlock + 2;
@@ -410,6 +410,36 @@ void make_device_layout(const HostIndex &h, DeviceLayout &out)
         out.ent[3 * ii + 2] = stack.empty() ? (uint32_t)n : stack.back();
         stack.push_back((uint32_t)ii);
     }
+    out.pair.clear();
+    if (!with_pairs) return;
+    // two-base extension: the set bits of B_c1, in row order, map one to one onto the rows
+    // C[c1], C[c1]+1, ... (the extend-right bijection), so one sweep per c1 with a running target row
+    out.pair.assign(16 * out.n_blocks * 4, 0);
+    std::vector<std::thread> th;
+    for (int c1 = 0; c1 < 4; c1++)
+        th.emplace_back([&, c1] {
+            uint64_t target = h.C[c1];
+            for (uint64_t i = 0; i < n; i++) {
+                if (!bit(c1, i)) continue;
+                for (int c2 = 0; c2 < 4; c2++)
+                    if (bit(c2, target)) {
+                        uint32_t *blk = &out.pair[((uint64_t)(4 * c1 + c2) * out.n_blocks + i / kRankRowsPerBlock) * 4];
+                        const unsigned o = (unsigned)(i % kRankRowsPerBlock);
+                        blk[1 + o / 32] |= 1u << (o % 32);
+                    }
+                target++;
+            }
+            for (int c2 = 0; c2 < 4; c2++) {
+                uint64_t cum = h.C[c2];
+                for (uint64_t j = 0; j < h.C[c1]; j++) cum += bit(c2, j); // rank_c2(C[c1])
+                for (uint64_t b = 0; b < out.n_blocks; b++) {
+                    uint32_t *blk = &out.pair[((uint64_t)(4 * c1 + c2) * out.n_blocks + b) * 4];
+                    blk[0] = (uint32_t)cum;
+                    cum += (uint64_t)(__builtin_popcount(blk[1]) + __builtin_popcount(blk[2]) + __builtin_popcount(blk[3]));
+                }
+            }
+        });
+    for (auto &t : th) t.join();
 }
 
 // ---- flat index file: magic, k, n_sets, n_kmers, C[4], rows[4], lcs --------------

@@ -51,8 +51,12 @@ struct DeviceLayout {
     uint64_t n_blocks = 0;            // per character
     std::vector<uint32_t> rank[4];    // 4 * n_blocks words each
     std::vector<uint32_t> ent;        // 3 * (n_sets + 1) words: {lcs, psv, nsv} per row
+    // optional two-base extension blocks, same format as `rank`: pair p = 4*c1 + c2 occupies
+    // blocks [p * n_blocks, (p+1) * n_blocks); bit i of its bit-vector is
+    // B_c1[i] & B_c2[C[c1] + rank_c1(i)], its base count C[c2] + rank_c2(C[c1])
+    std::vector<uint32_t> pair;
 };
-void make_device_layout(const HostIndex &h, DeviceLayout &out);
+void make_device_layout(const HostIndex &h, DeviceLayout &out, bool with_pairs = false);
 
 // flat file (own format, see kbo_capi.cpp)
 void save_host_index(const HostIndex &h, const std::string &path);

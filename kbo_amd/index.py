@@ -44,6 +44,10 @@ class SbwtIndexVariant:
         check(lib().kbo_index_device_bytes(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
+    def device_pair_bytes(self):
+        """Bytes of two-base extension blocks in the device copies of this index (0 = none)."""
+        return int(lib().kbo_index_device_pair_bytes(self._h))
+
     def export_parts(self):
         """(rows[4] uint64 words, C[4], lcs bytes) — the abstract index content."""
         n = self.n_sets()

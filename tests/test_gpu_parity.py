@@ -485,6 +485,40 @@ def test_host_batches_concurrent_callers_and_pinned_buffers(oracle):
         kbo_amd.lib().kbo_set_slab_bytes(32 << 20)
 
 
+def test_two_base_steps_parity(oracle):
+    """Two-base extension blocks (built for large indexes) forced on at small size, tried from depth 1
+    and from depth 16: MS values, translations and intervals equal the oracle's, incl. non-ACGT bases,
+    reads shorter than a query word, repeats (k-mer groups with several rows) and chunked sequences."""
+    rng = np.random.default_rng(5)
+    g = synth.genome(120_000, seed=71)
+    rep = np.tile(g[:700], 30)                      # repeats: extensions that fail at full depth
+    ref = np.concatenate([g, rep, g[5000:9000]])
+    try:
+        for min_depth in (1, 16):
+            kbo_amd.check(kbo_amd.lib().kbo_set_pair_steps(0, min_depth))
+            for k in (5, 31, 64):
+                sbwt, lcs = kbo_amd.build([ref], kbo_amd.BuildOpts(k=k, num_threads=2))
+                ora = oracle.Index.build([ref.tobytes()], k=k)
+                concat, offsets = synth.reads(ref, 4000, 150, 0.03, seed=200 + k)
+                concat = concat.copy()
+                concat[rng.integers(0, len(concat), 300)] = ord("N")
+                lens = rng.integers(3, 40, 500)            # short and ragged reads
+                short = np.concatenate([ref[s:s + n] for s, n in zip(rng.integers(0, 100_000, 500), lens)])
+                long_q = ref[20_000:60_000].copy()          # chunked with k-1 warm-up
+                long_q[rng.integers(0, len(long_q), 400)] = ord("A")
+                concat = np.concatenate([concat, short, long_q])
+                offsets = np.concatenate([offsets, offsets[-1] + np.cumsum(lens), [offsets[-1] + lens.sum() + len(long_q)]]).astype(np.uint64)
+                exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
+                d, _, _ = batch.ms_batch(sbwt, concat, offsets)
+                assert np.array_equal(d, exp_d), (min_depth, k)
+                assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars), (min_depth, k)
+                d2, lo, hi = batch.ms_batch(sbwt, concat[:600], np.array([0, 600], dtype=np.uint64), want_intervals=True)
+                od, olo, ohi = ora.matching_statistics(concat[:600].tobytes())
+                assert np.array_equal(d2, od.astype(np.uint8)) and np.array_equal(lo, olo.astype(np.uint32)) and np.array_equal(hi, ohi.astype(np.uint32))
+    finally:
+        kbo_amd.check(kbo_amd.lib().kbo_set_pair_steps(24 << 20, 16))
+
+
 def test_big_layout_parity(oracle):
     """The 64-bit-offset entry layout (indexes whose contraction entries exceed 4 GiB, e.g. a
     3 Gbp genome) exercised at small size: same results as the oracle."""

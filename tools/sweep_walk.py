@@ -14,6 +14,33 @@ from kbo_amd import batch, synth  # noqa: E402
 G = int(os.environ.get("G", 5_000_000))
 R = int(os.environ.get("R", 1_000_000))
 g = synth.genome(G)
+if os.environ.get("PAIRS"):
+    # two-base steps on/off (and the depth from which they are tried): each setting needs a fresh device copy
+    concat, offsets = synth.reads(g, R, 150, float(os.environ.get("SUB", 0.01)))
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=32))
+    from kbo_amd import index as kindex
+    path = "/tmp/sweep_index"
+    kindex.serialize_sbwt(path, sbwt)
+    base = None
+    for setting in os.environ["PAIRS"].split(","):
+        min_depth = int(setting)
+        kbo_amd.lib().kbo_set_pair_steps((1 << 63) if min_depth < 0 else 0, max(min_depth, 0))
+        sbwt, _ = kindex.load_sbwt(path)
+        dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"))
+        stream = torch.cuda.current_stream()
+        ts = []
+        for _ in range(6):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream); dev.walk(stream); b.record(stream)
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        ms = dev.ms.clone()
+        if base is None:
+            base = ms
+        print(f"G={G} pairs {'off' if min_depth < 0 else 'from depth %d' % min_depth}: walk min {min(ts[1:]):.3f} ms median {float(np.median(ts[1:])):.3f}"
+              f"  -> {R*150/min(ts[1:])/1e6:.1f} Gbp/s  same MS as first: {bool(torch.equal(ms, base))}", flush=True)
+        del dev, sbwt
+    sys.exit(0)
 import time as _t
 _t0 = _t.time()
 sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=32))
