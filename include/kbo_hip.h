@@ -219,13 +219,17 @@ int kbo_find_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offs
  * and have at least 16 readable bytes after its last base,
  * the other buffers 4-byte aligned; sequences shorter than 3 are skipped by the fused
  * derandomize/translate kernel (the host entry points reject them like the reference).
- * d_work is device scratch of at least kbo_work_bytes(n_seqs) bytes (16-byte aligned). */
-size_t kbo_work_bytes(size_t n_seqs);
-/* A1 over a batch: one work item per sequence (no chunking; meant for reads).
- * total_bases = offsets[n_seqs] (known to the caller; avoids a device read-back). */
+ * d_work is device scratch of at least kbo_work_bytes(...) bytes for the batch (16-byte aligned). */
+size_t kbo_work_bytes(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k);
+/* A1 over a batch.  total_bases = offsets[n_seqs] (known to the caller; avoids a device read-back);
+ * max_seq_len = length of the longest sequence if the caller knows it, 0 = unknown.  Batches of reads
+ * get one work item per sequence; when max_seq_len is unknown or long, the item list is built on the
+ * device from the offsets: sequences are cut into chunks that restart the walk k-1 bases upstream
+ * (the MS of a base depends only on the k bases ending at it), so a few long sequences still fill the
+ * device.  Same results either way. */
 int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets,
-                     size_t n_seqs, uint64_t total_bases, uint8_t *d_ms_out, uint32_t *d_lo_out,
-                     uint32_t *d_hi_out, void *d_work, void *stream);
+                     size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint8_t *d_ms_out,
+                     uint32_t *d_lo_out, uint32_t *d_hi_out, void *d_work, size_t work_bytes, void *stream);
 /* A5+A6 fused (+ optional format::relative_to_ref when d_ref != NULL): u8 MS -> u8 chars.
  * max_seq_len = length of the longest sequence in the batch if the caller knows it (selects
  * the LDS-staged kernel for short reads), 0 = unknown. */

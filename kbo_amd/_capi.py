@@ -141,8 +141,8 @@ def lib():
     L.kbo_matches_batch.argtypes = [vp, vp, vp, sz, dbl, vp]
     L.kbo_map_batch.argtypes = [vp, vp, vp, sz, dbl, C.c_int, vp]
     L.kbo_find_batch.argtypes = [vp, vp, vp, sz, C.POINTER(FindOpts), C.POINTER(C.POINTER(RLE)), vp]
-    L.kbo_work_bytes.argtypes = [sz]; L.kbo_work_bytes.restype = sz
-    L.kbo_ms_batch_dev.argtypes = [vp, vp, vp, sz, u64, vp, vp, vp, vp, vp]
+    L.kbo_work_bytes.argtypes = [sz, u64, sz, C.c_uint32]; L.kbo_work_bytes.restype = sz
+    L.kbo_ms_batch_dev.argtypes = [vp, vp, vp, sz, u64, sz, vp, vp, vp, vp, sz, vp]
     L.kbo_derand_translate_dev.argtypes = [vp, vp, sz, sz, sz, vp, vp, sz, vp]
     L.kbo_walk_geometry.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.kbo_set_walk_waves_per_cu.argtypes = [C.c_int]

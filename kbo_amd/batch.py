@@ -86,7 +86,8 @@ class DeviceBatch:
             self.off = torch.from_numpy(offsets.view(np.int64)).to(device)
             self.ms = torch.zeros(pad, dtype=torch.uint8, device=device)
             self.chars = torch.zeros(pad, dtype=torch.uint8, device=device)
-            self.work = torch.zeros(lib().kbo_work_bytes(n) // 8 + 2, dtype=torch.int64, device=device)
+            self.work_bytes = int(lib().kbo_work_bytes(n, self.total, self.max_len, self.k))
+            self.work = torch.zeros(self.work_bytes // 8 + 2, dtype=torch.int64, device=device)
             self.lo = torch.zeros(self.total, dtype=torch.int32, device=device) if want_intervals else None
             self.hi = torch.zeros(self.total, dtype=torch.int32, device=device) if want_intervals else None
         self.format = format
@@ -94,10 +95,10 @@ class DeviceBatch:
     def walk(self, stream=None):
         s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
         check(lib().kbo_ms_batch_dev(self.sbwt._h, self.q.data_ptr(), self.off.data_ptr(), self.n_seqs,
-                                     self.total, self.ms.data_ptr(),
+                                     self.total, self.max_len, self.ms.data_ptr(),
                                      self.lo.data_ptr() if self.lo is not None else None,
                                      self.hi.data_ptr() if self.hi is not None else None,
-                                     self.work.data_ptr(), s.cuda_stream))
+                                     self.work.data_ptr(), self.work_bytes, s.cuda_stream))
 
     def derand_translate(self, stream=None):
         s = stream if stream is not None else self.torch.cuda.current_stream(self.device)

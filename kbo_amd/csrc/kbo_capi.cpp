@@ -1488,11 +1488,34 @@ int kbo_find(kbo_index_t *idx, const uint8_t *query, size_t len, const kbo_find_
 
 void kbo_free(void *p) { std::free(p); }
 
-size_t kbo_work_bytes(size_t n_seqs) { return std::max<size_t>(1, n_seqs) * sizeof(kbo::WalkItem); }
+namespace {
+// work buffer of kbo_ms_batch_dev: items, then the scan scratch of the chunked item list
+struct DevWork {
+    bool chunked;
+    uint32_t chunk, n_slots;
+    size_t bytes;
+};
+DevWork dev_work(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k)
+{
+    DevWork w;
+    w.chunk = (uint32_t)walk_chunk(total_bases, n_seqs, k);
+    w.chunked = max_seq_len == 0 || max_seq_len > w.chunk;
+    const uint64_t slots = w.chunked ? total_bases / w.chunk + n_seqs : n_seqs;
+    w.n_slots = (uint32_t)std::min<uint64_t>(slots, 0xFFFFFFFFu);
+    w.bytes = std::max<uint64_t>(1, slots) * sizeof(kbo::WalkItem);
+    if (w.chunked) w.bytes += kbo::chunk_items_scratch_words((uint32_t)n_seqs) * sizeof(uint32_t) + 16;
+    return w;
+}
+} // namespace
+
+size_t kbo_work_bytes(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k)
+{
+    return dev_work(n_seqs, total_bases, max_seq_len, k).bytes;
+}
 
 int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs,
-                     uint64_t total_bases, uint8_t *d_ms_out, uint32_t *d_lo_out, uint32_t *d_hi_out,
-                     void *d_work, void *stream)
+                     uint64_t total_bases, size_t max_seq_len, uint8_t *d_ms_out, uint32_t *d_lo_out,
+                     uint32_t *d_hi_out, void *d_work, size_t work_bytes, void *stream)
 {
     return guarded([&] {
         KBO_REQUIRE(idx && d_concat && d_offsets && d_ms_out && d_work, KBO_E_BAD_ARG, "null argument");
@@ -1508,13 +1531,23 @@ int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *
         hipStream_t s = static_cast<hipStream_t>(stream);
         kbo::DevIndexView view = device_view(idx, current_device());
         kbo::WalkItem *items = static_cast<kbo::WalkItem *>(d_work);
-        HIP_OK(kbo::launch_make_items(d_offsets, (uint32_t)n_seqs, items, s));
+        // reads: one item per sequence; batches that hold (or may hold) long sequences: chunks
+        const DevWork w = dev_work(n_seqs, total_bases, max_seq_len, idx->host.k);
+        KBO_REQUIRE(work_bytes >= w.bytes, KBO_E_BAD_ARG, "d_work is smaller than kbo_work_bytes() for this batch");
+        KBO_REQUIRE(total_bases / w.chunk + n_seqs < (1ull << 28), KBO_E_UNSUPPORTED, "more than 2^28 work items per launch");
+        if (w.chunked) {
+            uint32_t *scratch = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(d_work) +
+                                                            ((size_t)w.n_slots * sizeof(kbo::WalkItem) + 15) / 16 * 16);
+            HIP_OK(kbo::launch_make_chunk_items(d_offsets, (uint32_t)n_seqs, w.chunk, idx->host.k, w.n_slots, items, scratch, s));
+        } else {
+            HIP_OK(kbo::launch_make_items(d_offsets, (uint32_t)n_seqs, items, s));
+        }
         kbo::WalkArgs a;
         a.ix = view;
         a.q = d_concat;
         a.q_bytes = total_bases;
         a.items = items;
-        a.n_items = (uint32_t)n_seqs;
+        a.n_items = w.n_slots;
         a.rounds = 0;
         a.d_out = d_ms_out;
         a.lo_out = d_lo_out;

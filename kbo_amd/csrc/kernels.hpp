@@ -48,6 +48,11 @@ hipError_t launch_copy_to_host(const uint8_t *d_src, uint8_t *h_dst, uint64_t by
 // offsets (n_seqs+1) -> one item per sequence
 hipError_t launch_make_items(const uint64_t *d_offsets, uint32_t n_seqs, WalkItem *d_items,
                              hipStream_t stream);
+// offsets -> items of at most `chunk` emitted bases (+ k-1 warm-up bases), n_slots >= total/chunk + n_seqs item
+// slots are written (unused ones as empty items); d_scratch: chunk_items_scratch_words(n_seqs) u32
+size_t chunk_items_scratch_words(uint32_t n_seqs);
+hipError_t launch_make_chunk_items(const uint64_t *d_offsets, uint32_t n_seqs, uint32_t chunk, uint32_t k,
+                                   uint32_t n_slots, WalkItem *d_items, uint32_t *d_scratch, hipStream_t stream);
 // A1: k-bounded matching statistics over all items
 hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream);
 // A5+A6 (+ optional relative_to_ref when ref != nullptr, + optional i32 derandomised

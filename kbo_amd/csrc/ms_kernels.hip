@@ -394,6 +394,77 @@ __global__ void make_items_kernel(const uint64_t *__restrict__ off, uint32_t n_s
     items[s] = it;
 }
 
+// ---- items for batches with long sequences, built on the device -------------------------
+// Sequence s is cut into ceil(len / chunk) items; every item after the first re-walks k-1
+// warm-up bases (the MS of a base depends only on the k bases ending at it).  counts ->
+// exclusive prefix sums (two-level scan, 1024 values per block) -> one lane per item slot,
+// which finds its sequence by binary search; slots beyond the last item become empty items.
+constexpr uint32_t kScanBlock = 1024;
+
+__global__ void chunk_count_kernel(const uint64_t *__restrict__ off, uint32_t n_seqs, uint32_t chunk,
+                                   uint32_t *__restrict__ counts)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n_seqs) return;
+    counts[s] = s < n_seqs ? (uint32_t)((off[s + 1] - off[s] + chunk - 1) / chunk) : 0u;
+}
+
+// exclusive scan of `per` consecutive values per thread, 256 or 1024 threads per block, in place;
+// sums[blockIdx.x] = total of the block's values (when sums != nullptr)
+__global__ void scan_kernel(uint32_t *__restrict__ data, uint32_t n, uint32_t per, uint32_t *__restrict__ sums)
+{
+    __shared__ uint32_t sh[1024];
+    const uint32_t t = threadIdx.x, nt = blockDim.x;
+    const uint64_t base = ((uint64_t)blockIdx.x * nt + t) * per;
+    uint32_t local = 0;
+    for (uint32_t j = 0; j < per; j++)
+        if (base + j < n) local += data[base + j];
+    sh[t] = local;
+    __syncthreads();
+    for (uint32_t step = 1; step < nt; step <<= 1) { // Hillis-Steele inclusive scan of the thread sums
+        const uint32_t v = t >= step ? sh[t - step] : 0u;
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = sh[t] - local; // exclusive prefix of this thread inside the block
+    for (uint32_t j = 0; j < per; j++)
+        if (base + j < n) {
+            const uint32_t v = data[base + j];
+            data[base + j] = run;
+            run += v;
+        }
+    if (sums && t == nt - 1) sums[blockIdx.x] = sh[t];
+}
+
+__global__ void make_chunk_items_kernel(const uint64_t *__restrict__ off, const uint32_t *__restrict__ local,
+                                        const uint32_t *__restrict__ sums, uint32_t n_seqs, uint32_t chunk,
+                                        uint32_t k, uint32_t n_slots, WalkItem *__restrict__ items)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_slots) return;
+    auto first_item = [&](uint32_t s) { return sums[s / kScanBlock] + local[s]; }; // s in [0, n_seqs]
+    WalkItem it;
+    it.start = 0;
+    it.len = 0;
+    it.warm = 0;
+    if (t < first_item(n_seqs)) {
+        uint32_t lo = 0, hi = n_seqs; // largest s with first_item(s) <= t (empty sequences own no item)
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (first_item(mid) <= t) lo = mid;
+            else hi = mid;
+        }
+        const uint64_t b = off[lo], len = off[lo + 1] - b;
+        const uint64_t c0 = (uint64_t)(t - first_item(lo)) * chunk;
+        const uint64_t warm = min(c0, (uint64_t)(k > 0 ? k - 1 : 0));
+        it.start = b + c0 - warm;
+        it.len = (uint32_t)(min((uint64_t)chunk, len - c0) + warm);
+        it.warm = (uint32_t)warm;
+    }
+    items[t] = it;
+}
+
 // -------------------------------------------------------------------------------------
 // A5 + A6.  derandomize_ms_vec is a right-to-left recurrence (derandomize.rs:282-285):
 //     out[len-1] = noisy[len-1] > t ? noisy[len-1] : 0
@@ -729,6 +800,22 @@ hipError_t launch_make_items(const uint64_t *d_offsets, uint32_t n_seqs, WalkIte
     if (n_seqs == 0) return hipSuccess;
     hipLaunchKernelGGL(make_items_kernel, dim3((n_seqs + 255) / 256), dim3(256), 0, stream, d_offsets,
                        n_seqs, d_items);
+    return hipGetLastError();
+}
+
+size_t chunk_items_scratch_words(uint32_t n_seqs) { return (size_t)n_seqs + 1 + ((size_t)n_seqs + 1 + kScanBlock - 1) / kScanBlock; }
+
+hipError_t launch_make_chunk_items(const uint64_t *d_offsets, uint32_t n_seqs, uint32_t chunk, uint32_t k,
+                                   uint32_t n_slots, WalkItem *d_items, uint32_t *d_scratch, hipStream_t stream)
+{
+    if (n_seqs == 0 || n_slots == 0) return hipSuccess;
+    const uint32_t n = n_seqs + 1, nb = (n + kScanBlock - 1) / kScanBlock;
+    uint32_t *local = d_scratch, *sums = d_scratch + n;
+    hipLaunchKernelGGL(chunk_count_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_offsets, n_seqs, chunk, local);
+    hipLaunchKernelGGL(scan_kernel, dim3(nb), dim3(256), 0, stream, local, n, kScanBlock / 256, sums);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, sums, nb, (nb + 1023) / 1024, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(make_chunk_items_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, stream, d_offsets, local, sums,
+                       n_seqs, chunk, k, n_slots, d_items);
     return hipGetLastError();
 }
 

@@ -572,6 +572,47 @@ def test_device_resident_path_matches_host_path(oracle):
     assert np.array_equal(dev.hi.cpu().numpy()[:150], hi.astype(np.uint32).view(np.int32))
 
 
+@pytest.mark.parametrize("k", [7, 31, 101])
+def test_device_resident_long_sequences_are_chunked_on_the_device(oracle, k):
+    """kbo_ms_batch_dev with long / unknown-length sequences builds a chunked item list on the
+    device (counts, two-level scan, binary search): same MS, intervals and characters as the
+    oracle for a ragged mix of reads, contigs, one-base and empty-ish (3-base) sequences."""
+    import torch
+    rng = np.random.default_rng(k)
+    g = synth.genome(250_000, seed=33)
+    sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=k, num_threads=4))
+    ora = oracle.Index.build([g.tobytes()], k=k)
+    lens = np.concatenate([rng.integers(3, 400, 3000), rng.integers(1000, 30_000, 40), [3, 3, 70_000, 257, 256, 255]])
+    rng.shuffle(lens)
+    pieces = []
+    for n in lens:
+        s0 = int(rng.integers(0, len(g) - n))
+        p = g[s0:s0 + n].copy()
+        p[rng.random(n) < 0.02] = ord("T")
+        pieces.append(p)
+    concat = np.concatenate(pieces)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
+    for known_max in (True, False):
+        dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"), want_intervals=True)
+        if not known_max:  # the caller does not know the longest sequence
+            dev.max_len = 0
+            dev.work_bytes = int(kbo_amd.lib().kbo_work_bytes(dev.n_seqs, dev.total, 0, k))
+            dev.work = torch.zeros(dev.work_bytes // 8 + 2, dtype=torch.int64, device="cuda:0")
+        dev.run()
+        torch.cuda.synchronize()
+        assert np.array_equal(dev.ms.cpu().numpy()[:len(concat)], exp_d), known_max
+        assert np.array_equal(dev.chars.cpu().numpy()[:len(concat)], exp_chars), known_max
+        b = int(offsets[np.argmax(lens)])
+        d, lo, hi = ora.matching_statistics(concat[b:b + 5000].tobytes())
+        assert np.array_equal(dev.lo.cpu().numpy()[b:b + 5000], lo.astype(np.uint32).view(np.int32))
+        assert np.array_equal(dev.hi.cpu().numpy()[b:b + 5000], hi.astype(np.uint32).view(np.int32))
+    with pytest.raises(kbo_amd.KboError):  # work buffer sized for reads, batch holds long sequences
+        kbo_amd.check(kbo_amd.lib().kbo_ms_batch_dev(sbwt._h, dev.q.data_ptr(), dev.off.data_ptr(), dev.n_seqs, dev.total, 0,
+                                                     dev.ms.data_ptr(), None, None, dev.work.data_ptr(), 16 * dev.n_seqs,
+                                                     torch.cuda.current_stream().cuda_stream))
+
+
 @pytest.mark.parametrize("sub_rate", [0.0, 0.01, 0.05])
 def test_full_size_properties(sub_rate):
     """BASELINE C2 shape (5 Mbp index, 150 bp reads) at 200k reads: size-independent

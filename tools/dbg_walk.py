@@ -11,7 +11,7 @@ dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"))
 cnt = torch.zeros(16, dtype=torch.int32, device="cuda:0")
 s = torch.cuda.current_stream()
 kbo_amd.check(kbo_amd.lib().kbo_ms_batch_dev(sbwt._h, dev.q.data_ptr(), dev.off.data_ptr(), dev.n_seqs, dev.total,
-              dev.ms.data_ptr(), None, cnt.data_ptr(), dev.work.data_ptr(), s.cuda_stream))
+              dev.max_len, dev.ms.data_ptr(), None, cnt.data_ptr(), dev.work.data_ptr(), dev.work_bytes, s.cuda_stream))
 torch.cuda.synchronize()
 c = cnt.cpu().numpy()
 c = c.astype(np.int64)
