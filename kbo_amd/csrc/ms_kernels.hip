@@ -614,18 +614,52 @@ __global__ __launch_bounds__(64) void derand_translate_lds_kernel(
     if (s < n_seqs) {
         const uint32_t b = (uint32_t)(off[s] - base), len = (uint32_t)(off[s + 1] - off[s]);
         if (len >= 3) {
+            // Branch-free pass with the window (x_prev, x_cur, x_next) = x[p-1], x[p], x[p+1]:
+            //   in(v) = 0 < v < T, written (unsigned)(v - 1) < (unsigned)(T - 1);
+            //   'R' at p  <=>  (x[p-1] > T && in(x[p]) && 2 <= p < len-1)  ||  (x[p] > T && in(next));
+            // the two ends (p = len-1, where next = x[p]; p = 1 and 0, where prev = K and no 'R' is
+            // inherited from below) are peeled so that the middle of the sequence carries no
+            // position tests.  gt_* / in_* flags move down the window with the values.
             uint8_t *row = lds + b;
+            const uint32_t Tm1 = (uint32_t)(T - 1);
+            auto step = [&](int a, int x_cur) { return (a == K) ? K : ((a > T && x_cur < a) ? a : x_cur - 1); };
+            auto plain = [&](int x_cur, int next, int prev) -> uint32_t { // translate.rs:180-216 without the 'R' cases
+                return x_cur <= 0 ? ((next == 1 && prev > 0) ? (uint32_t)'X' : (uint32_t)'-') : (uint32_t)'M';
+            };
             int a = row[len - 1];
-            int x_cur = a > T ? a : 0, x_next = x_cur, x_prev = K; // derandomize.rs:282
-            for (uint32_t p = len; p-- > 0;) {
-                if (p > 0) { // derandomize.rs:233-246
-                    a = row[p - 1];
-                    x_prev = (a == K) ? K : ((a > T && x_cur < a) ? a : x_cur - 1);
-                }
-                row[p] = translate_char(x_prev, x_cur, x_next, p, len, K, T);
+            int x_cur = a > T ? a : 0; // derandomize.rs:282
+            int a_below = row[len - 2];
+            int x_prev = step(a_below, x_cur);
+            // p = len-1: next = x_cur itself; inherits 'R' from below (len-1 >= 2 always holds, but
+            // the rule needs pos < len-1, so it does not apply here)
+            bool in_cur = (uint32_t)(x_cur - 1) < Tm1, gt_cur = x_cur > T;
+            row[len - 1] = (uint8_t)((gt_cur && in_cur) ? (uint32_t)'R' : plain(x_cur, x_cur, x_prev));
+            int x_next = x_cur;
+            bool in_next = in_cur;
+            x_cur = x_prev;
+            gt_cur = x_cur > T;
+            in_cur = (uint32_t)(x_cur - 1) < Tm1;
+            a_below = row[len - 3];
+            for (uint32_t p = len - 2; p >= 2; p--) { // middle: 2 <= p <= len-2
+                x_prev = step(a_below, x_cur);
+                a_below = row[p - 2]; // p >= 2
+                const bool gt_prev = x_prev > T;
+                const bool is_r = (gt_prev && in_cur) || (gt_cur && in_next);
+                row[p] = (uint8_t)(is_r ? (uint32_t)'R' : plain(x_cur, x_next, x_prev));
                 x_next = x_cur;
+                in_next = in_cur;
                 x_cur = x_prev;
+                gt_cur = gt_prev;
+                in_cur = (uint32_t)(x_cur - 1) < Tm1;
             }
+            // p = 1: prev = K (translate.rs:277 tests pos > 1), no 'R' inherited (needs pos >= 2)
+            x_prev = step(a_below, x_cur); // a_below == row[0]
+            row[1] = (uint8_t)((gt_cur && in_next) ? (uint32_t)'R' : plain(x_cur, x_next, K));
+            // p = 0
+            x_next = x_cur;
+            in_next = in_cur;
+            x_cur = x_prev;
+            row[0] = (uint8_t)((x_cur > T && in_next) ? (uint32_t)'R' : plain(x_cur, x_next, K));
         }
     }
     __syncthreads();
