@@ -193,6 +193,11 @@ int kbo_find(kbo_index_t *idx, const uint8_t *query, size_t len, const kbo_find_
  * on byte-wide alignment strings (host; sequential variable-length output). */
 int kbo_run_lengths_gapped(const uint8_t *aln, size_t len, size_t max_gap_len, kbo_rle **out,
                            size_t *n_out);
+/* format::run_lengths_gapped over a batch of alignments on the GPU (one lane per alignment): runs of
+ * all sequences concatenated, rle_offsets[i]..[i+1] = alignment i (n_seqs+1 entries, caller-allocated;
+ * *rles library-allocated, release with kbo_free).  Same records as kbo_run_lengths_gapped. */
+int kbo_run_lengths_gapped_batch(const uint8_t *aln_concat, const uint64_t *offsets, size_t n_seqs,
+                                 size_t max_gap_len, kbo_rle **rles, uint64_t *rle_offsets);
 int kbo_relative_to_ref(const uint8_t *ref_seq, const uint8_t *aln, size_t len, uint8_t *out);
 void kbo_free(void *p);
 

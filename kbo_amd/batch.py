@@ -57,7 +57,11 @@ def find_batch(sbwt, concat, offsets, find_opts=None):
     p = C.POINTER(_capi.RLE)()
     check(lib().kbo_find_batch(sbwt._h, concat.ctypes.data, offsets.ctypes.data, n, C.byref(co),
                                C.byref(p), ro.ctypes.data))
-    rles = [p[i].as_tuple() for i in range(int(ro[-1]))]
+    total = int(ro[-1])
+    if total > 100_000:  # big batches: hand back the records as an [n_runs, 7] uint64 array
+        rles = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(total, 7)).copy()
+    else:
+        rles = [p[i].as_tuple() for i in range(total)]
     lib().kbo_free(p)
     return rles, ro
 

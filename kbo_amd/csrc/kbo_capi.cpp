@@ -582,6 +582,11 @@ struct HostSlot {
     hipEvent_t copied = nullptr, computed = nullptr, done = nullptr;
     bool busy = false;     // a slab is in flight in this slot
     uint64_t out_b0 = 0, out_bytes = 0;
+    // run-length output (kbo_find_batch): per-sequence first-run indices + block sums, the records,
+    // the number of runs (device word and its pinned copy), what the slab holds
+    DevBuf rle_scratch, rles, rle_total;
+    PinBuf rle_total_pin, rle_first_pin;
+    size_t rle_capacity = 0, slab_id = 0, n_seqs = 0;
 };
 struct HostCtx {
     int dev = 0;
@@ -607,7 +612,7 @@ struct HostCtx {
                 if (e) (void)hipEventDestroy(e);
         for (HostSlot &S : slot) { // buffers belong to `dev`
             S.B.release();
-            S.chars.release();
+            for (DevBuf *b : {&S.chars, &S.rle_scratch, &S.rles, &S.rle_total}) b->release();
         }
         (void)hipSetDevice(prev);
     }
@@ -679,11 +684,20 @@ void derand_translate_host_offsets(const uint8_t *d_ms, const uint64_t *d_off, c
     HIP_OK(hipStreamSynchronize(stream)); // scratch is released on return
 }
 
-// kbo::matches over a batch (lib.rs:618-627); optional relative_to_ref (lib.rs:756-757)
+// Where kbo_find_batch collects format::run_lengths_gapped of every slab (computed on the device
+// from the slab's characters, which then never leave it)
+struct RleSink {
+    size_t max_gap_len = 0;
+    std::vector<std::vector<kbo_rle>> runs;   // per slab
+    std::vector<std::vector<uint32_t>> first; // per slab: index of the first run of each sequence, +1 entry
+};
+
+// kbo::matches over a batch (lib.rs:618-627); optional relative_to_ref (lib.rs:756-757); with a sink
+// the characters are turned into run lengths on the device instead of being downloaded (lib.rs:816-820)
 void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
-                        double max_error_prob, bool format, uint8_t *chars_out)
+                        double max_error_prob, bool format, uint8_t *chars_out, RleSink *sink = nullptr)
 {
-    KBO_REQUIRE(idx && chars_out, KBO_E_BAD_ARG, "null argument");
+    KBO_REQUIRE(idx && (chars_out || sink), KBO_E_BAD_ARG, "null argument");
     PhaseClock clk;
     const size_t k = idx->host.k;
     const size_t threshold = random_match_threshold(k, idx->host.n_kmers, 4, max_error_prob); // lib.rs:620
@@ -701,7 +715,11 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
     clk.lap("argument checks");
     const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
     // user buffers the DMA engines can reach directly are used in place, pageable ones are staged
-    const bool in_pinned = is_pinned_host(concat), out_pinned = is_pinned_host(chars_out);
+    const bool in_pinned = is_pinned_host(concat), out_pinned = sink || is_pinned_host(chars_out);
+    if (sink) {
+        sink->runs.assign(slabs.size(), {});
+        sink->first.assign(slabs.size(), {});
+    }
     clk.lap("slab list");
     // one worker per device (index replicated on each, slabs dealt round-robin, disjoint output
     // slices: no exchange between devices); a single device runs on the calling thread
@@ -734,8 +752,37 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
                         turn = drained;
                     }
                     HostSlot &S = C.slot[turn % kHostSlots];
-                    HIP_OK(hipEventSynchronize(S.done));
-                    if (!out_pinned) HostTeam::out().copy(chars_out + S.out_b0, S.out.p, S.out_bytes);
+                    if (sink) {
+                        // the count is known once the slab's kernels are done: fetch exactly that many records
+                        HIP_OK(hipEventSynchronize(S.computed));
+                        const uint32_t total = *S.rle_total_pin.as<uint32_t>();
+                        if (total > S.rle_capacity) { // more runs than the speculative emit had room for
+                            S.rle_capacity = (size_t)total + total / 4 + 16;
+                            S.rles.ensure(S.rle_capacity * sizeof(kbo_rle));
+                            HIP_OK(kbo::launch_rle_emit(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)S.n_seqs,
+                                                        (uint32_t)std::min<size_t>(sink->max_gap_len, 0xFFFFFFFFu),
+                                                        S.rle_scratch.as<uint32_t>(), S.rles.as<uint64_t>(),
+                                                        (uint32_t)S.rle_capacity, C.st_down));
+                        }
+                        const size_t words = kbo::chunk_items_scratch_words((uint32_t)S.n_seqs);
+                        S.out.ensure(std::max<size_t>(16, (size_t)total * sizeof(kbo_rle)));
+                        S.rle_first_pin.ensure(words * sizeof(uint32_t));
+                        if (total)
+                            HIP_OK(hipMemcpyAsync(S.out.p, S.rles.p, (size_t)total * sizeof(kbo_rle), hipMemcpyDeviceToHost, C.st_down));
+                        HIP_OK(hipMemcpyAsync(S.rle_first_pin.p, S.rle_scratch.p, words * sizeof(uint32_t), hipMemcpyDeviceToHost, C.st_down));
+                        HIP_OK(hipEventRecord(S.done, C.st_down));
+                        HIP_OK(hipEventSynchronize(S.done));
+                        std::vector<kbo_rle> &runs = sink->runs[S.slab_id];
+                        runs.resize(total);
+                        if (total) HostTeam::out().copy(runs.data(), S.out.p, (size_t)total * sizeof(kbo_rle));
+                        std::vector<uint32_t> &first = sink->first[S.slab_id];
+                        first.resize(S.n_seqs + 1);
+                        const uint32_t *local = S.rle_first_pin.as<uint32_t>(), *sums = local + S.n_seqs + 1;
+                        for (size_t q = 0; q <= S.n_seqs; q++) first[q] = sums[q / 1024] + local[q];
+                    } else {
+                        HIP_OK(hipEventSynchronize(S.done));
+                        if (!out_pinned) HostTeam::out().copy(chars_out + S.out_b0, S.out.p, S.out_bytes);
+                    }
                     S.busy = false;
                     {
                         std::lock_guard<std::mutex> g(mu);
@@ -801,30 +848,56 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
                 }
                 if (w == 0) clk.lap("  offsets + copy in");
                 enqueue_walk_host(idx, src, off, ns, false, S.B, S.items, C.st_run, mx, C.st_up, S.copied);
-                // D2H leg: hipMemcpyAsync on the download stream.  With one stream per stage the copy
-                // engines carry both directions at once (tools/bench_host.py: 37-40 Gbp/s host->host);
-                // the alternatives measured slower and stay selectable for experiments: KBO_D2H=kernel
-                // (a small kernel stores into pinned host memory, 28 Gbp/s), KBO_D2H=direct (A5/A6
-                // store to host memory themselves, 26 Gbp/s).
-                static const char *d2h_env = std::getenv("KBO_D2H");
-                static const int d2h_mode = !d2h_env ? 1 : (std::strcmp(d2h_env, "kernel") == 0 ? 0 : (std::strcmp(d2h_env, "direct") == 0 ? 2 : 1));
-                uint8_t *dst = chars_out + sl.b0;
-                if (!out_pinned) {
-                    S.out.ensure(bytes + 32);
-                    dst = S.out.as<uint8_t>();
+                if (sink) {
+                    // characters stay on the device; run lengths are counted, scanned and (speculatively, into
+                    // the room the slot has) emitted right behind A5/A6; the completing thread downloads them
+                    S.chars.ensure(((S.B.total + 15) / 16) * 16 + 32);
+                    derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, (uint32_t)k,
+                                                  (uint32_t)threshold, nullptr, S.chars.as<uint8_t>(), nullptr, C.st_run, mx);
+                    const uint32_t gap = (uint32_t)std::min<size_t>(sink->max_gap_len, 0xFFFFFFFFu);
+                    S.rle_scratch.ensure(kbo::chunk_items_scratch_words((uint32_t)ns) * sizeof(uint32_t));
+                    S.rle_total.ensure(16);
+                    S.rle_total_pin.ensure(16);
+                    if (S.rle_capacity < 2 * ns + 16) {
+                        S.rle_capacity = 2 * ns + 16;
+                        S.rles.ensure(S.rle_capacity * sizeof(kbo_rle));
+                    }
+                    HIP_OK(kbo::launch_rle_count(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
+                                                 S.rle_scratch.as<uint32_t>(), S.rle_total.as<uint32_t>(), C.st_run));
+                    HIP_OK(hipMemcpyAsync(S.rle_total_pin.p, S.rle_total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, C.st_run));
+                    HIP_OK(kbo::launch_rle_emit(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
+                                                S.rle_scratch.as<uint32_t>(), S.rles.as<uint64_t>(), (uint32_t)S.rle_capacity,
+                                                C.st_run));
+                    HIP_OK(hipEventRecord(S.computed, C.st_run));
+                    HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
+                    S.slab_id = i;
+                    S.n_seqs = ns;
+                } else {
+                    // D2H leg: hipMemcpyAsync on the download stream.  With one stream per stage the copy
+                    // engines carry both directions at once (tools/bench_host.py: 37-40 Gbp/s host->host);
+                    // the alternatives measured slower and stay selectable for experiments: KBO_D2H=kernel
+                    // (a small kernel stores into pinned host memory, 28 Gbp/s), KBO_D2H=direct (A5/A6
+                    // store to host memory themselves, 26 Gbp/s).
+                    static const char *d2h_env = std::getenv("KBO_D2H");
+                    static const int d2h_mode = !d2h_env ? 1 : (std::strcmp(d2h_env, "kernel") == 0 ? 0 : (std::strcmp(d2h_env, "direct") == 0 ? 2 : 1));
+                    uint8_t *dst = chars_out + sl.b0;
+                    if (!out_pinned) {
+                        S.out.ensure(bytes + 32);
+                        dst = S.out.as<uint8_t>();
+                    }
+                    const bool direct = d2h_mode == 2 && mx <= kbo::kLongSeq && (((uintptr_t)dst & 3) == 0);
+                    if (!direct) S.chars.ensure(((S.B.total + 15) / 16) * 16 + 16);
+                    derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, (uint32_t)k,
+                                                  (uint32_t)threshold, format ? S.B.q.as<uint8_t>() : nullptr,
+                                                  direct ? dst : S.chars.as<uint8_t>(), nullptr, C.st_run, mx);
+                    HIP_OK(hipEventRecord(S.computed, C.st_run));
+                    HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
+                    if (!direct) {
+                        if (d2h_mode == 1) HIP_OK(hipMemcpyAsync(dst, S.chars.p, bytes, hipMemcpyDeviceToHost, C.st_down));
+                        else HIP_OK(kbo::launch_copy_to_host(S.chars.as<uint8_t>(), dst, bytes, C.st_down));
+                    }
+                    HIP_OK(hipEventRecord(S.done, C.st_down));
                 }
-                const bool direct = d2h_mode == 2 && mx <= kbo::kLongSeq && (((uintptr_t)dst & 3) == 0);
-                if (!direct) S.chars.ensure(((S.B.total + 15) / 16) * 16 + 16);
-                derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, (uint32_t)k,
-                                              (uint32_t)threshold, format ? S.B.q.as<uint8_t>() : nullptr,
-                                              direct ? dst : S.chars.as<uint8_t>(), nullptr, C.st_run, mx);
-                HIP_OK(hipEventRecord(S.computed, C.st_run));
-                HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
-                if (!direct) {
-                    if (d2h_mode == 1) HIP_OK(hipMemcpyAsync(dst, S.chars.p, bytes, hipMemcpyDeviceToHost, C.st_down));
-                    else HIP_OK(kbo::launch_copy_to_host(S.chars.as<uint8_t>(), dst, bytes, C.st_down));
-                }
-                HIP_OK(hipEventRecord(S.done, C.st_down));
                 S.busy = true;
                 S.out_b0 = sl.b0;
                 S.out_bytes = bytes;
@@ -1438,6 +1511,46 @@ int kbo_run_lengths_gapped(const uint8_t *aln, size_t len, size_t max_gap_len, k
     });
 }
 
+int kbo_run_lengths_gapped_batch(const uint8_t *aln_concat, const uint64_t *offsets, size_t n_seqs, size_t max_gap_len,
+                                 kbo_rle **rles, uint64_t *rle_offsets)
+{
+    return guarded([&] {
+        KBO_REQUIRE(aln_concat && offsets && rles && rle_offsets, KBO_E_BAD_ARG, "null argument");
+        KBO_REQUIRE(n_seqs > 0 && n_seqs < (1ull << 31), KBO_E_BAD_ARG, "1 .. 2^31-1 sequences");
+        KBO_REQUIRE(offsets[0] == 0, KBO_E_BAD_ARG, "offsets[0] must be 0");
+        const OffsetScan scan = scan_offsets(offsets, n_seqs);
+        KBO_REQUIRE(scan.monotone, KBO_E_BAD_ARG, "offsets not monotone");
+        KBO_REQUIRE(scan.longest < 0xFFFFFFFFull, KBO_E_UNSUPPORTED, "sequence longer than 2^32-1");
+        const uint64_t total = offsets[n_seqs];
+        hipStream_t st = nullptr;
+        DevBuf chars(total + 64), off((n_seqs + 1) * sizeof(uint64_t)), count(16);
+        DevBuf scratch(kbo::chunk_items_scratch_words((uint32_t)n_seqs) * sizeof(uint32_t));
+        HIP_OK(hipMemsetAsync(static_cast<uint8_t *>(chars.p) + total, 0, 64, st));
+        if (total) HIP_OK(hipMemcpyAsync(chars.p, aln_concat, total, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(off.p, offsets, (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        const uint32_t gap = (uint32_t)std::min<size_t>(max_gap_len, 0xFFFFFFFFu);
+        HIP_OK(kbo::launch_rle_count(chars.as<uint8_t>(), off.as<uint64_t>(), (uint32_t)n_seqs, gap, scratch.as<uint32_t>(),
+                                     count.as<uint32_t>(), st));
+        uint32_t n_runs = 0;
+        HIP_OK(hipMemcpy(&n_runs, count.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        DevBuf d_runs(std::max<size_t>(16, (size_t)n_runs * sizeof(kbo_rle)));
+        HIP_OK(kbo::launch_rle_emit(chars.as<uint8_t>(), off.as<uint64_t>(), (uint32_t)n_seqs, gap, scratch.as<uint32_t>(),
+                                    d_runs.as<uint64_t>(), n_runs, st));
+        kbo_rle *all = static_cast<kbo_rle *>(std::malloc(std::max<size_t>(1, n_runs) * sizeof(kbo_rle)));
+        if (!all) throw std::bad_alloc();
+        std::vector<uint32_t> words(kbo::chunk_items_scratch_words((uint32_t)n_seqs));
+        hipError_t e = n_runs ? hipMemcpy(all, d_runs.p, (size_t)n_runs * sizeof(kbo_rle), hipMemcpyDeviceToHost) : hipSuccess;
+        if (e == hipSuccess) e = hipMemcpy(words.data(), scratch.p, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            std::free(all);
+            throw KboError(KBO_E_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+        }
+        const uint32_t *local = words.data(), *sums = local + n_seqs + 1;
+        for (size_t q = 0; q <= n_seqs; q++) rle_offsets[q] = (uint64_t)sums[q / 1024] + local[q];
+        *rles = all;
+    });
+}
+
 int kbo_relative_to_ref(const uint8_t *ref_seq, const uint8_t *aln, size_t len, uint8_t *out)
 {
     return guarded([&] {
@@ -1459,16 +1572,22 @@ int kbo_find_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offs
         KBO_REQUIRE(idx && rles && rle_offsets, KBO_E_BAD_ARG, "null argument");
         kbo_find_opts o;
         if (opts) o = *opts; else kbo_find_opts_default(&o);
-        check_batch(concat, offsets, n_seqs);
-        std::vector<uint8_t> aln(offsets[n_seqs]);
-        matches_batch_impl(idx, concat, offsets, n_seqs, o.max_error_prob, false, aln.data()); // lib.rs:815
-        std::vector<kbo_rle> all;
+        // lib.rs:815-820: matches, then run_lengths_gapped per sequence; both on the device, slab by slab
+        RleSink sink;
+        sink.max_gap_len = o.max_gap_len;
+        matches_batch_impl(idx, concat, offsets, n_seqs, o.max_error_prob, false, nullptr, &sink);
+        const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
+        std::vector<uint64_t> base(slabs.size() + 1, 0);
+        for (size_t i = 0; i < slabs.size(); i++) base[i + 1] = base[i] + sink.runs[i].size();
+        kbo_rle *all = static_cast<kbo_rle *>(std::malloc(std::max<uint64_t>(1, base.back()) * sizeof(kbo_rle)));
+        if (!all) throw std::bad_alloc();
         rle_offsets[0] = 0;
-        for (size_t s = 0; s < n_seqs; s++) { // lib.rs:816-820
-            run_lengths_gapped_impl(aln.data() + offsets[s], offsets[s + 1] - offsets[s], o.max_gap_len, all);
-            rle_offsets[s + 1] = all.size();
-        }
-        *rles = copy_rles(all);
+        HostTeam::get().run(slabs.size(), [&](size_t i) {
+            if (!sink.runs[i].empty()) std::memcpy(all + base[i], sink.runs[i].data(), sink.runs[i].size() * sizeof(kbo_rle));
+            const size_t ns = slabs[i].s1 - slabs[i].s0;
+            for (size_t q = 1; q <= ns; q++) rle_offsets[slabs[i].s0 + q] = base[i] + sink.first[i][q];
+        });
+        *rles = all;
     });
 }
 

@@ -311,7 +311,8 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
             // nearest set bits of B_c around [l, r), used when the extension failed (searched only
             // inside the 32-bit word that holds the position: set bits are a few rows apart, and a
             // miss merely costs one extra extension attempt)
-            uint32_t dl, dr;
+            uint32_t dl = 0, dr = 0;
+#if !KBO_NO_TARGETS
             {
                 const uint32_t wsel = ol >> 5, pb = ol & 31u;
                 const uint32_t W = wsel == 0 ? xA.y : (wsel == 1 ? xA.z : xA.w);
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
                 const uint32_t above = W & (~0u << pb);
                 dr = above ? (uint32_t)__ffs((int)above) - pb : 0u; // (bit index - pb) + 1 rows to pass
             }
+#endif
             m = fail ? ((dl && dr) ? 1u : 0u) : m;
             tgt_l = fail ? l - dl : tgt_l; // row of the nearest set bit below l
             tgt_r = fail ? r + dr : tgt_r; // one past the nearest set bit at/after r
@@ -805,6 +807,107 @@ __global__ void translate_kernel(const int32_t *__restrict__ x, uint64_t len, ui
     out[p] = translate_char(xm, xc, xn, p, len, (int)k, (int)t);
 }
 
+// ---- format::run_lengths_gapped (format.rs:143-193) on the device -------------------------
+// One lane per sequence, left to right over its characters in 16-byte blocks.  The reference's
+// two nested loops become one step per character with the state below: outside a run a
+// character other than '-' / ' ' opens one (and is then processed as the run's first
+// character); inside a run a ' ' closes it without being consumed, anything else updates the
+// counters and may close the run (gap longer than max_gap_len, or a gap at the very end), in
+// which case the gap that closed it is taken back out of the counters.  The kernel runs twice:
+// COUNT (runs per sequence) and, after an exclusive scan of the counts, EMIT.
+struct RleState {
+    uint32_t in_run, start, end, matches, mismatches, jumps, gap_bases, gap_opens, gap_run, in_gap, prev, n_out;
+};
+
+template <bool EMIT>
+__device__ __forceinline__ void rle_close(RleState &st, uint64_t *__restrict__ out, uint32_t first, uint32_t capacity)
+{
+    if (EMIT) {
+        const uint32_t slot = first + st.n_out;
+        if (slot < capacity) {
+            uint64_t *o = out + (uint64_t)slot * 7u;
+            o[0] = st.start; o[1] = st.end; o[2] = st.matches; o[3] = st.mismatches;
+            o[4] = st.jumps; o[5] = st.gap_bases; o[6] = st.gap_opens;
+        }
+    }
+    st.n_out++;
+    st.in_run = 0;
+}
+
+template <bool EMIT>
+__device__ __forceinline__ void rle_step(RleState &st, uint32_t c, uint32_t i, uint32_t len, uint32_t max_gap_len,
+                                         uint64_t *__restrict__ out, uint32_t first, uint32_t capacity)
+{
+    if (i >= len) return; // only in the last block
+    if (st.in_run && c == ' ') rle_close<EMIT>(st, out, first, capacity); // format.rs:154: the blank is not consumed
+    if (!st.in_run && c != '-' && c != ' ') { // format.rs:148-152: a run starts here
+        st.in_run = 1;
+        st.start = i;
+        st.end = st.matches = st.mismatches = st.jumps = st.gap_bases = st.gap_opens = st.gap_run = st.in_gap = 0;
+    }
+    if (st.in_run) { // format.rs:155-188
+        const bool true_gap = c == '-';
+        if (true_gap && !st.in_gap) {
+            st.in_gap = 1;
+            st.gap_opens++;
+            st.gap_run = 0;
+        }
+        if (!true_gap) st.in_gap = 0;
+        const bool is_match = c == 'M' || c == 'R' || c == 'I';
+        const bool is_gap = true_gap || c == 'D';
+        st.matches += is_match;
+        st.gap_bases += is_gap;
+        st.mismatches += (!is_match && !is_gap);
+        st.end = (is_match || !is_gap) ? i + 1u : st.end;
+        st.jumps += (c == 'R' && i > 0 && st.prev == 'R'); // aln[i-1] is unguarded in the reference (format.rs:175)
+        st.gap_run += true_gap;
+        if (st.gap_run > max_gap_len || (is_gap && i + 1u == len && st.gap_opens > 0)) {
+            st.gap_opens -= 1;
+            st.gap_bases -= st.gap_run;
+            rle_close<EMIT>(st, out, first, capacity);
+        }
+    }
+    st.prev = c;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void rle_kernel(const uint8_t *__restrict__ chars, const uint64_t *__restrict__ off,
+                                                  uint32_t n_seqs, uint32_t max_gap_len, uint32_t *__restrict__ counts,
+                                                  const uint32_t *__restrict__ sums, uint64_t *__restrict__ out,
+                                                  uint32_t capacity)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seqs) return;
+    const uint64_t b = off[s];
+    const uint32_t len = (uint32_t)(off[s + 1] - b);
+    const uint8_t *row = chars + b;
+    const uint32_t first = EMIT ? sums[s / kScanBlock] + counts[s] : 0u; // exclusive prefix after the scan
+    RleState st;
+    st.in_run = st.start = st.end = st.matches = st.mismatches = st.jumps = st.gap_bases = st.gap_opens = 0;
+    st.gap_run = st.in_gap = st.prev = st.n_out = 0;
+    const uint32_t nblk = (len + 15u) / 16u;
+    uint4 cur = nblk ? ld16u(row, 0) : make_uint4(0, 0, 0, 0); // reads <= 15 bytes past the sequence (buffers are padded)
+    for (uint32_t bi = 0; bi < nblk; bi++) {
+        uint4 nxt = cur;
+        if (bi + 1 < nblk) nxt = ld16u(row, 16u * (bi + 1u));
+        const uint32_t p0 = 16u * bi;
+#define KBO_RLE(J) rle_step<EMIT>(st, blk_byte<J>(cur), p0 + J, len, max_gap_len, out, first, capacity);
+        KBO_RLE(0) KBO_RLE(1) KBO_RLE(2) KBO_RLE(3) KBO_RLE(4) KBO_RLE(5) KBO_RLE(6) KBO_RLE(7)
+        KBO_RLE(8) KBO_RLE(9) KBO_RLE(10) KBO_RLE(11) KBO_RLE(12) KBO_RLE(13) KBO_RLE(14) KBO_RLE(15)
+#undef KBO_RLE
+        cur = nxt;
+    }
+    if (st.in_run) rle_close<EMIT>(st, out, first, capacity); // format.rs:189 after the inner loop ran off the end
+    if (!EMIT) counts[s] = st.n_out;
+}
+
+// total number of runs (the scan's grand total) -> one word the host can read after the stream
+__global__ void rle_total_kernel(const uint32_t *__restrict__ local, const uint32_t *__restrict__ sums, uint32_t n_seqs,
+                                 uint32_t *__restrict__ total)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *total = sums[n_seqs / kScanBlock] + local[n_seqs];
+}
+
 // Copies `bytes` from device memory to pinned host memory with plain stores.  A small
 // grid-stride grid: it is PCIe-bound, leaves the copy engine to the opposite direction and
 // takes only a few wave slots per CU away from the walk kernel of the next slab.
@@ -834,6 +937,35 @@ hipError_t launch_make_items(const uint64_t *d_offsets, uint32_t n_seqs, WalkIte
     if (n_seqs == 0) return hipSuccess;
     hipLaunchKernelGGL(make_items_kernel, dim3((n_seqs + 255) / 256), dim3(256), 0, stream, d_offsets,
                        n_seqs, d_items);
+    return hipGetLastError();
+}
+
+// format::run_lengths_gapped over a batch: counts -> exclusive scan (counts[n_seqs] = total slot) -> emit.
+// d_scratch: chunk_items_scratch_words(n_seqs) u32 (per-sequence first-run index, block sums);
+// d_total: one u32.  Records beyond `capacity` are counted but not written (the caller re-emits).
+hipError_t launch_rle_count(const uint8_t *d_chars, const uint64_t *d_offsets, uint32_t n_seqs, uint32_t max_gap_len,
+                            uint32_t *d_scratch, uint32_t *d_total, hipStream_t stream)
+{
+    if (n_seqs == 0) return hipSuccess;
+    const uint32_t n = n_seqs + 1, nb = (n + kScanBlock - 1) / kScanBlock;
+    uint32_t *local = d_scratch, *sums = d_scratch + n;
+    const hipError_t e = hipMemsetAsync(local + n_seqs, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((rle_kernel<false>), dim3((n_seqs + 255) / 256), dim3(256), 0, stream, d_chars, d_offsets, n_seqs,
+                       max_gap_len, local, (const uint32_t *)nullptr, (uint64_t *)nullptr, 0u);
+    hipLaunchKernelGGL(scan_kernel, dim3(nb), dim3(256), 0, stream, local, n, kScanBlock / 256, sums);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, sums, nb, (nb + 1023) / 1024, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(rle_total_kernel, dim3(1), dim3(64), 0, stream, local, sums, n_seqs, d_total);
+    return hipGetLastError();
+}
+
+hipError_t launch_rle_emit(const uint8_t *d_chars, const uint64_t *d_offsets, uint32_t n_seqs, uint32_t max_gap_len,
+                           uint32_t *d_scratch, uint64_t *d_rles, uint32_t capacity, hipStream_t stream)
+{
+    if (n_seqs == 0) return hipSuccess;
+    uint32_t *local = d_scratch, *sums = d_scratch + n_seqs + 1;
+    hipLaunchKernelGGL((rle_kernel<true>), dim3((n_seqs + 255) / 256), dim3(256), 0, stream, d_chars, d_offsets, n_seqs,
+                       max_gap_len, local, sums, d_rles, capacity);
     return hipGetLastError();
 }
 

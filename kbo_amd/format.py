@@ -44,6 +44,21 @@ def run_lengths_gapped(aln, max_gap_len):
     return _take_rles(p, n.value)
 
 
+def run_lengths_gapped_batch(aln_concat, offsets, max_gap_len):
+    """format::run_lengths_gapped of many alignments at once on the GPU
+    -> (numpy structured-like array [n_runs, 7] uint64, rle_offsets uint64[n+1])"""
+    a = _aln_bytes(aln_concat)
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(off) - 1
+    ro = np.zeros(n + 1, dtype=np.uint64)
+    p = C.POINTER(_CRLE)()
+    check(lib().kbo_run_lengths_gapped_batch(a.ctypes.data, off.ctypes.data, n, max_gap_len, C.byref(p), ro.ctypes.data))
+    total = int(ro[-1])
+    runs = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(max(total, 1), 7))[:total].copy()
+    lib().kbo_free(p)
+    return runs, ro
+
+
 def run_lengths(aln):
     """format.rs:98-102"""
     return run_lengths_gapped(aln, 0)

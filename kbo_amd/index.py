@@ -24,7 +24,10 @@ class SbwtIndexVariant:
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            lib().kbo_index_free(h)
+            try:
+                lib().kbo_index_free(h)
+            except Exception:  # interpreter shutdown: module globals are already gone
+                pass
 
     def k(self):
         return int(lib().kbo_index_k(self._h))

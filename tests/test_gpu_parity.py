@@ -415,6 +415,62 @@ def test_batch_reads_vs_oracle(oracle):
         assert [tuple(r) for r in rles[ro[s]:ro[s + 1]]] == exp
 
 
+def test_run_lengths_on_the_device_full_alphabet(oracle):
+    """format::run_lengths_gapped on the GPU (kbo_run_lengths_gapped_batch, also the tail of
+    kbo_find_batch): random alignments over the whole alphabet the function looks at
+    ('M','R','I','D','X','-',' ' and the bases refinement writes), every max_gap_len regime,
+    empty / one-character / block-boundary lengths, against the oracle's literal loop."""
+    from kbo_amd import format as kformat
+    rng = np.random.default_rng(77)
+    alphabets = [b"MMMMMMMMMM-XR", b"M-", b"MR-X ID", b"MMMM----- ", b"ACGTMN-XRID ", b"-", b"R", b" "]
+    lens = list(range(0, 40)) + [47, 48, 49, 63, 64, 65, 150, 151, 1000, 5000]
+    alns = []
+    for t in range(6000):
+        L = int(rng.choice(lens))
+        ab = np.frombuffer(alphabets[t % len(alphabets)], dtype=np.uint8)
+        a = ab[rng.integers(0, len(ab), L)]
+        if t % 5 == 0 and L > 20:  # long gaps and long matches
+            a = a.copy()
+            p = int(rng.integers(0, L - 10))
+            a[p:p + int(rng.integers(1, 10))] = ord("-")
+        alns.append(a.tobytes())
+    concat = np.frombuffer(b"".join(alns), dtype=np.uint8)
+    offsets = np.concatenate([[0], np.cumsum([len(a) for a in alns])]).astype(np.uint64)
+    for gap in (0, 1, 3, 50, 10**9):
+        runs, ro = kformat.run_lengths_gapped_batch(concat, offsets, gap)
+        assert ro[0] == 0 and np.all(np.diff(ro.astype(np.int64)) >= 0) and ro[-1] == len(runs)
+        for s in range(len(alns)):
+            exp = oracle.run_lengths_gapped(alns[s], gap)
+            got = [tuple(int(v) for v in r) for r in runs[ro[s]:ro[s + 1]]]
+            assert got == exp, (gap, s, alns[s][:80])
+    # the single-sequence host implementation agrees too
+    for s in range(0, len(alns), 97):
+        assert [tuple(r.__dict__.values()) for r in kformat.run_lengths_gapped(alns[s], 3)] == oracle.run_lengths_gapped(alns[s], 3)
+
+
+def test_find_batch_every_read_against_oracle(oracle):
+    """kbo_find_batch end to end (walk, A5/A6, run lengths all on the device, several slabs, more
+    runs than the speculative room of a slot): every read's RLE list equals the oracle's."""
+    g = synth.genome(200_000, seed=23)
+    sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=4))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    concat, offsets = synth.reads(g, 30_000, 150, 0.04, seed=24)   # ~6 errors per read: many runs per read
+    exp_chars = ora.matches_batch(concat, offsets, 1e-7, n_threads=4)
+    try:
+        kbo_amd.lib().kbo_set_slab_bytes(1 << 20)
+        for gap in (0, 5, 40):
+            rles, ro = batch.find_batch(sbwt, concat, offsets, kbo_amd.FindOpts(max_gap_len=gap))
+            exp_runs, exp_ro = [], [0]
+            for s in range(len(offsets) - 1):
+                exp_runs += oracle.run_lengths_gapped(exp_chars[offsets[s]:offsets[s + 1]].tobytes(), gap)
+                exp_ro.append(len(exp_runs))
+            assert np.array_equal(ro, np.array(exp_ro, dtype=np.uint64)), gap
+            got = [tuple(int(v) for v in r) for r in rles]
+            assert got == exp_runs, gap
+    finally:
+        kbo_amd.lib().kbo_set_slab_bytes(32 << 20)
+
+
 def test_host_batches_in_slabs(oracle):
     """Host batches larger than the slab size go through the staged slab pipeline (more slabs than
     slots, so staging buffers and device buffers are reused within one call)."""
