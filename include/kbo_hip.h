@@ -214,7 +214,8 @@ int kbo_matches_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *o
 int kbo_map_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                   double max_error_prob, int format, uint8_t *out);
 /* find over a batch: RLEs of all sequences concatenated, rle_offsets[i]..[i+1] = sequence i
- * (rle_offsets has n_seqs+1 entries, caller-allocated; *rles library-allocated). */
+ * (rle_offsets has n_seqs+1 entries, caller-allocated; *rles library-allocated, kbo_free).  The
+ * run lengths are computed on the device (the translated characters never leave it). */
 int kbo_find_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                    const kbo_find_opts *opts, kbo_rle **rles, uint64_t *rle_offsets);
 

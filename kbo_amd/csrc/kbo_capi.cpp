@@ -684,12 +684,32 @@ void derand_translate_host_offsets(const uint8_t *d_ms, const uint64_t *d_off, c
     HIP_OK(hipStreamSynchronize(stream)); // scratch is released on return
 }
 
+// device run-length records are seven u32; the API's kbo_rle has the reference's usize fields
+constexpr size_t kRleWords = 7;
+void widen_rles(kbo_rle *dst, const uint32_t *src, size_t n, HostTeam &team)
+{
+    const size_t piece = 1u << 14;
+    team.run((n + piece - 1) / piece, [&](size_t t) {
+        const size_t a = t * piece, b = std::min(n, a + piece);
+        for (size_t q = a; q < b; q++) {
+            const uint32_t *r = src + q * kRleWords;
+            dst[q] = kbo_rle{r[0], r[1], r[2], r[3], r[4], r[5], r[6]};
+        }
+    });
+}
+
 // Where kbo_find_batch collects format::run_lengths_gapped of every slab (computed on the device
 // from the slab's characters, which then never leave it)
 struct RleSink {
     size_t max_gap_len = 0;
-    std::vector<std::vector<kbo_rle>> runs;   // per slab
-    std::vector<std::vector<uint32_t>> first; // per slab: index of the first run of each sequence, +1 entry
+    uint64_t *rle_offsets = nullptr; // caller's n_seqs + 1 entries
+    // one device: slabs complete in order, so their records go straight into the result array
+    kbo_rle *all = nullptr;
+    size_t all_cap = 0, all_used = 0;
+    // several devices: slabs complete out of order, kept per slab and put together at the end
+    std::vector<std::vector<kbo_rle>> runs;
+    std::vector<std::vector<uint32_t>> first; // index of the first run of each sequence of the slab, +1 entry
+    ~RleSink() { std::free(all); }
 };
 
 // kbo::matches over a batch (lib.rs:618-627); optional relative_to_ref (lib.rs:756-757); with a sink
@@ -720,6 +740,13 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
         sink->runs.assign(slabs.size(), {});
         sink->first.assign(slabs.size(), {});
     }
+    const bool sink_direct = sink && (g_devices.size() <= 1 || slabs.size() <= 1);
+    if (sink_direct) { // room for 2 runs per sequence to start with (untouched pages cost nothing)
+        sink->all_cap = 2 * n_seqs + 1024;
+        sink->all = static_cast<kbo_rle *>(std::malloc(sink->all_cap * sizeof(kbo_rle)));
+        if (!sink->all) throw std::bad_alloc();
+        sink->rle_offsets[0] = 0;
+    }
     clk.lap("slab list");
     // one worker per device (index replicated on each, slabs dealt round-robin, disjoint output
     // slices: no exchange between devices); a single device runs on the calling thread
@@ -743,45 +770,65 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
         std::thread drainer([&] {
             try {
                 HIP_OK(hipSetDevice(devices[w]));
-                for (;;) {
-                    size_t turn;
-                    {
-                        std::unique_lock<std::mutex> g(mu);
-                        cv.wait(g, [&] { return drained < submitted || stop; });
-                        if (drained >= submitted) return;
-                        turn = drained;
-                    }
+                const size_t none = ~size_t(0);
+                // run lengths: the number of records of a slab is known once its kernels are done, so the
+                // download is issued here; it is issued for the next slab before the previous one is
+                // copied out, so that the copy engine and the host copy work on different slabs
+                auto start = [&](size_t turn) {
+                    if (!sink) return;
                     HostSlot &S = C.slot[turn % kHostSlots];
-                    if (sink) {
-                        // the count is known once the slab's kernels are done: fetch exactly that many records
-                        HIP_OK(hipEventSynchronize(S.computed));
-                        const uint32_t total = *S.rle_total_pin.as<uint32_t>();
-                        if (total > S.rle_capacity) { // more runs than the speculative emit had room for
-                            S.rle_capacity = (size_t)total + total / 4 + 16;
-                            S.rles.ensure(S.rle_capacity * sizeof(kbo_rle));
-                            HIP_OK(kbo::launch_rle_emit(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)S.n_seqs,
-                                                        (uint32_t)std::min<size_t>(sink->max_gap_len, 0xFFFFFFFFu),
-                                                        S.rle_scratch.as<uint32_t>(), S.rles.as<uint64_t>(),
-                                                        (uint32_t)S.rle_capacity, C.st_down));
-                        }
-                        const size_t words = kbo::chunk_items_scratch_words((uint32_t)S.n_seqs);
-                        S.out.ensure(std::max<size_t>(16, (size_t)total * sizeof(kbo_rle)));
-                        S.rle_first_pin.ensure(words * sizeof(uint32_t));
-                        if (total)
-                            HIP_OK(hipMemcpyAsync(S.out.p, S.rles.p, (size_t)total * sizeof(kbo_rle), hipMemcpyDeviceToHost, C.st_down));
-                        HIP_OK(hipMemcpyAsync(S.rle_first_pin.p, S.rle_scratch.p, words * sizeof(uint32_t), hipMemcpyDeviceToHost, C.st_down));
-                        HIP_OK(hipEventRecord(S.done, C.st_down));
-                        HIP_OK(hipEventSynchronize(S.done));
-                        std::vector<kbo_rle> &runs = sink->runs[S.slab_id];
-                        runs.resize(total);
-                        if (total) HostTeam::out().copy(runs.data(), S.out.p, (size_t)total * sizeof(kbo_rle));
-                        std::vector<uint32_t> &first = sink->first[S.slab_id];
-                        first.resize(S.n_seqs + 1);
-                        const uint32_t *local = S.rle_first_pin.as<uint32_t>(), *sums = local + S.n_seqs + 1;
-                        for (size_t q = 0; q <= S.n_seqs; q++) first[q] = sums[q / 1024] + local[q];
-                    } else {
-                        HIP_OK(hipEventSynchronize(S.done));
+                    HIP_OK(hipEventSynchronize(S.computed));
+                    const uint32_t total = *S.rle_total_pin.as<uint32_t>();
+                    if (total > S.rle_capacity) { // more runs than the speculative emit had room for
+                        S.rle_capacity = (size_t)total + total / 4 + 16;
+                        S.rles.ensure(S.rle_capacity * kRleWords * sizeof(uint32_t));
+                        HIP_OK(kbo::launch_rle_emit(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)S.n_seqs,
+                                                    (uint32_t)std::min<size_t>(sink->max_gap_len, 0xFFFFFFFFu),
+                                                    S.rle_scratch.as<uint32_t>(), S.rles.as<uint32_t>(),
+                                                    (uint32_t)S.rle_capacity, C.st_down));
+                    }
+                    const size_t words = kbo::chunk_items_scratch_words((uint32_t)S.n_seqs);
+                    S.out.ensure(std::max<size_t>(16, (size_t)total * kRleWords * sizeof(uint32_t)));
+                    S.rle_first_pin.ensure(words * sizeof(uint32_t));
+                    if (total)
+                        HIP_OK(hipMemcpyAsync(S.out.p, S.rles.p, (size_t)total * kRleWords * sizeof(uint32_t),
+                                              hipMemcpyDeviceToHost, C.st_down));
+                    HIP_OK(hipMemcpyAsync(S.rle_first_pin.p, S.rle_scratch.p, words * sizeof(uint32_t), hipMemcpyDeviceToHost, C.st_down));
+                    HIP_OK(hipEventRecord(S.done, C.st_down));
+                    S.out_bytes = total; // records
+                };
+                auto finish = [&](size_t turn) {
+                    HostSlot &S = C.slot[turn % kHostSlots];
+                    HIP_OK(hipEventSynchronize(S.done));
+                    if (!sink) {
                         if (!out_pinned) HostTeam::out().copy(chars_out + S.out_b0, S.out.p, S.out_bytes);
+                    } else {
+                        const size_t total = S.out_bytes;
+                        const uint32_t *local = S.rle_first_pin.as<uint32_t>(), *sums = local + S.n_seqs + 1;
+                        if (sink_direct) {
+                            if (sink->all_used + total > sink->all_cap) {
+                                const size_t cap = (sink->all_used + total) * 2;
+                                kbo_rle *p = static_cast<kbo_rle *>(std::realloc(sink->all, cap * sizeof(kbo_rle)));
+                                if (!p) throw std::bad_alloc();
+                                sink->all = p;
+                                sink->all_cap = cap;
+                            }
+                            const size_t base = sink->all_used, s0 = slabs[S.slab_id].s0, ns_slab = S.n_seqs;
+                            widen_rles(sink->all + base, S.out.as<uint32_t>(), total, HostTeam::out());
+                            const size_t piece = 1u << 15;
+                            HostTeam::out().run((ns_slab + piece - 1) / piece, [&](size_t t) {
+                                const size_t a = t * piece + 1, b = std::min(ns_slab, a + piece - 1);
+                                for (size_t q = a; q <= b; q++) sink->rle_offsets[s0 + q] = base + sums[q / 1024] + local[q];
+                            });
+                            sink->all_used += total;
+                        } else {
+                            std::vector<kbo_rle> &runs = sink->runs[S.slab_id];
+                            runs.resize(total);
+                            widen_rles(runs.data(), S.out.as<uint32_t>(), total, HostTeam::out());
+                            std::vector<uint32_t> &first = sink->first[S.slab_id];
+                            first.resize(S.n_seqs + 1);
+                            for (size_t q = 0; q <= S.n_seqs; q++) first[q] = sums[q / 1024] + local[q];
+                        }
                     }
                     S.busy = false;
                     {
@@ -789,6 +836,23 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
                         drained++;
                     }
                     cv.notify_all();
+                };
+                size_t started = 0, pending = none;
+                for (;;) {
+                    bool can_start;
+                    {
+                        std::unique_lock<std::mutex> g(mu);
+                        cv.wait(g, [&] { return started < submitted || pending != none || stop; });
+                        can_start = started < submitted;
+                        if (!can_start && pending == none) return;
+                    }
+                    const size_t prev = pending;
+                    pending = none;
+                    if (can_start) {
+                        start(started);
+                        pending = started++;
+                    }
+                    if (prev != none) finish(prev);
                 }
             } catch (const KboError &e) {
                 std::lock_guard<std::mutex> g(mu);
@@ -860,13 +924,13 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
                     S.rle_total_pin.ensure(16);
                     if (S.rle_capacity < 2 * ns + 16) {
                         S.rle_capacity = 2 * ns + 16;
-                        S.rles.ensure(S.rle_capacity * sizeof(kbo_rle));
+                        S.rles.ensure(S.rle_capacity * kRleWords * sizeof(uint32_t));
                     }
                     HIP_OK(kbo::launch_rle_count(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
                                                  S.rle_scratch.as<uint32_t>(), S.rle_total.as<uint32_t>(), C.st_run));
                     HIP_OK(hipMemcpyAsync(S.rle_total_pin.p, S.rle_total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, C.st_run));
                     HIP_OK(kbo::launch_rle_emit(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
-                                                S.rle_scratch.as<uint32_t>(), S.rles.as<uint64_t>(), (uint32_t)S.rle_capacity,
+                                                S.rle_scratch.as<uint32_t>(), S.rles.as<uint32_t>(), (uint32_t)S.rle_capacity,
                                                 C.st_run));
                     HIP_OK(hipEventRecord(S.computed, C.st_run));
                     HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
@@ -1533,18 +1597,15 @@ int kbo_run_lengths_gapped_batch(const uint8_t *aln_concat, const uint64_t *offs
                                      count.as<uint32_t>(), st));
         uint32_t n_runs = 0;
         HIP_OK(hipMemcpy(&n_runs, count.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
-        DevBuf d_runs(std::max<size_t>(16, (size_t)n_runs * sizeof(kbo_rle)));
+        DevBuf d_runs(std::max<size_t>(16, (size_t)n_runs * kRleWords * sizeof(uint32_t)));
         HIP_OK(kbo::launch_rle_emit(chars.as<uint8_t>(), off.as<uint64_t>(), (uint32_t)n_seqs, gap, scratch.as<uint32_t>(),
-                                    d_runs.as<uint64_t>(), n_runs, st));
+                                    d_runs.as<uint32_t>(), n_runs, st));
+        std::vector<uint32_t> compact((size_t)n_runs * kRleWords + 1), words(kbo::chunk_items_scratch_words((uint32_t)n_seqs));
+        if (n_runs) HIP_OK(hipMemcpy(compact.data(), d_runs.p, (size_t)n_runs * kRleWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(words.data(), scratch.p, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         kbo_rle *all = static_cast<kbo_rle *>(std::malloc(std::max<size_t>(1, n_runs) * sizeof(kbo_rle)));
         if (!all) throw std::bad_alloc();
-        std::vector<uint32_t> words(kbo::chunk_items_scratch_words((uint32_t)n_seqs));
-        hipError_t e = n_runs ? hipMemcpy(all, d_runs.p, (size_t)n_runs * sizeof(kbo_rle), hipMemcpyDeviceToHost) : hipSuccess;
-        if (e == hipSuccess) e = hipMemcpy(words.data(), scratch.p, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            std::free(all);
-            throw KboError(KBO_E_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
-        }
+        widen_rles(all, compact.data(), n_runs, HostTeam::get());
         const uint32_t *local = words.data(), *sums = local + n_seqs + 1;
         for (size_t q = 0; q <= n_seqs; q++) rle_offsets[q] = (uint64_t)sums[q / 1024] + local[q];
         *rles = all;
@@ -1575,7 +1636,13 @@ int kbo_find_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offs
         // lib.rs:815-820: matches, then run_lengths_gapped per sequence; both on the device, slab by slab
         RleSink sink;
         sink.max_gap_len = o.max_gap_len;
+        sink.rle_offsets = rle_offsets;
         matches_batch_impl(idx, concat, offsets, n_seqs, o.max_error_prob, false, nullptr, &sink);
+        if (sink.all) { // one device: the records are already in place
+            *rles = sink.all;
+            sink.all = nullptr;
+            return;
+        }
         const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
         std::vector<uint64_t> base(slabs.size() + 1, 0);
         for (size_t i = 0; i < slabs.size(); i++) base[i + 1] = base[i] + sink.runs[i].size();

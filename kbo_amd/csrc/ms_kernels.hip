@@ -814,18 +814,19 @@ __global__ void translate_kernel(const int32_t *__restrict__ x, uint64_t len, ui
 // character); inside a run a ' ' closes it without being consumed, anything else updates the
 // counters and may close the run (gap longer than max_gap_len, or a gap at the very end), in
 // which case the gap that closed it is taken back out of the counters.  The kernel runs twice:
-// COUNT (runs per sequence) and, after an exclusive scan of the counts, EMIT.
+// COUNT (runs per sequence) and, after an exclusive scan of the counts, EMIT (records of seven
+// u32 {start, end, matches, mismatches, jumps, gap_bases, gap_opens}; the host widens them).
 struct RleState {
     uint32_t in_run, start, end, matches, mismatches, jumps, gap_bases, gap_opens, gap_run, in_gap, prev, n_out;
 };
 
 template <bool EMIT>
-__device__ __forceinline__ void rle_close(RleState &st, uint64_t *__restrict__ out, uint32_t first, uint32_t capacity)
+__device__ __forceinline__ void rle_close(RleState &st, uint32_t *__restrict__ out, uint32_t first, uint32_t capacity)
 {
     if (EMIT) {
         const uint32_t slot = first + st.n_out;
         if (slot < capacity) {
-            uint64_t *o = out + (uint64_t)slot * 7u;
+            uint32_t *o = out + (uint64_t)slot * 7u;
             o[0] = st.start; o[1] = st.end; o[2] = st.matches; o[3] = st.mismatches;
             o[4] = st.jumps; o[5] = st.gap_bases; o[6] = st.gap_opens;
         }
@@ -836,7 +837,7 @@ __device__ __forceinline__ void rle_close(RleState &st, uint64_t *__restrict__ o
 
 template <bool EMIT>
 __device__ __forceinline__ void rle_step(RleState &st, uint32_t c, uint32_t i, uint32_t len, uint32_t max_gap_len,
-                                         uint64_t *__restrict__ out, uint32_t first, uint32_t capacity)
+                                         uint32_t *__restrict__ out, uint32_t first, uint32_t capacity)
 {
     if (i >= len) return; // only in the last block
     if (st.in_run && c == ' ') rle_close<EMIT>(st, out, first, capacity); // format.rs:154: the blank is not consumed
@@ -873,7 +874,7 @@ __device__ __forceinline__ void rle_step(RleState &st, uint32_t c, uint32_t i, u
 template <bool EMIT>
 __global__ __launch_bounds__(256) void rle_kernel(const uint8_t *__restrict__ chars, const uint64_t *__restrict__ off,
                                                   uint32_t n_seqs, uint32_t max_gap_len, uint32_t *__restrict__ counts,
-                                                  const uint32_t *__restrict__ sums, uint64_t *__restrict__ out,
+                                                  const uint32_t *__restrict__ sums, uint32_t *__restrict__ out,
                                                   uint32_t capacity)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -952,7 +953,7 @@ hipError_t launch_rle_count(const uint8_t *d_chars, const uint64_t *d_offsets, u
     const hipError_t e = hipMemsetAsync(local + n_seqs, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((rle_kernel<false>), dim3((n_seqs + 255) / 256), dim3(256), 0, stream, d_chars, d_offsets, n_seqs,
-                       max_gap_len, local, (const uint32_t *)nullptr, (uint64_t *)nullptr, 0u);
+                       max_gap_len, local, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
     hipLaunchKernelGGL(scan_kernel, dim3(nb), dim3(256), 0, stream, local, n, kScanBlock / 256, sums);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, sums, nb, (nb + 1023) / 1024, (uint32_t *)nullptr);
     hipLaunchKernelGGL(rle_total_kernel, dim3(1), dim3(64), 0, stream, local, sums, n_seqs, d_total);
@@ -960,7 +961,7 @@ hipError_t launch_rle_count(const uint8_t *d_chars, const uint64_t *d_offsets, u
 }
 
 hipError_t launch_rle_emit(const uint8_t *d_chars, const uint64_t *d_offsets, uint32_t n_seqs, uint32_t max_gap_len,
-                           uint32_t *d_scratch, uint64_t *d_rles, uint32_t capacity, hipStream_t stream)
+                           uint32_t *d_scratch, uint32_t *d_rles, uint32_t capacity, hipStream_t stream)
 {
     if (n_seqs == 0) return hipSuccess;
     uint32_t *local = d_scratch, *sums = d_scratch + n_seqs + 1;

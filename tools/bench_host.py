@@ -26,3 +26,16 @@ for slab_mb in [int(x) for x in os.environ.get('SLABS', '32,64,128,256').split('
         kbo_amd.check(L.kbo_map_batch(sbwt._h, concat.ctypes.data, offsets.ctypes.data, R, 1e-7, 1, out.ctypes.data))
         best = min(best, time.perf_counter() - t0)
     print(f"slab {slab_mb:4d} MiB: {R * 150 / best / 1e9:6.2f} Gbp/s host->host ({best * 1e3:.1f} ms for {R * 150 / 1e6:.0f} Mbp)", flush=True)
+    if os.environ.get("FIND"):  # kbo::find: run lengths come back instead of characters
+        import ctypes as C
+        from kbo_amd import _capi
+        co = _capi.FindOpts(1e-7, 0)
+        ro = np.zeros(R + 1, dtype=np.uint64)
+        best = 1e9
+        for _ in range(4):
+            p = C.POINTER(_capi.RLE)()
+            t0 = time.perf_counter()
+            kbo_amd.check(L.kbo_find_batch(sbwt._h, concat.ctypes.data, offsets.ctypes.data, R, C.byref(co), C.byref(p), ro.ctypes.data))
+            best = min(best, time.perf_counter() - t0)
+            L.kbo_free(p)
+        print(f"           find: {R * 150 / best / 1e9:6.2f} Gbp/s host->host ({best * 1e3:.1f} ms, {int(ro[-1])} runs for {R} reads)", flush=True)

@@ -4,6 +4,6 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/trace_host
 rm -rf $OUT
-SLABS=${SLABS:-64} rocprofv3 --hip-runtime-trace --kernel-trace --memory-copy-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/bench_host.py > $GRAFT_REPO_ROOT/gpurun_out/trace_host.log 2>&1
+SLABS=${SLABS:-32} FIND=${FIND:-} rocprofv3 --hip-runtime-trace --kernel-trace --memory-copy-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/bench_host.py > $GRAFT_REPO_ROOT/gpurun_out/trace_host.log 2>&1
 tail -1 $GRAFT_REPO_ROOT/gpurun_out/trace_host.log
 find $OUT -name "*.csv" | head
