@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="wall-clock budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--find", action="store_true",
+                    help="time kbo::find instead of kbo::map: the step ends with format::run_lengths on the device")
     ap.add_argument("--waves-per-cu", type=int, default=0)
     return ap.parse_args()
 
@@ -107,7 +109,7 @@ def main():
     sbwt, _ = kbo_amd.build([genome], kbo_amd.BuildOpts(k=args.k, num_threads=min(16, threads)))
     concat, offsets = synth.reads(genome, args.reads, args.read_len, args.sub_rate,
                                   first_read=rank * args.reads)
-    dev = batch.DeviceBatch(sbwt, concat, offsets, device=device, format=True)
+    dev = batch.DeviceBatch(sbwt, concat, offsets, device=device, format=not args.find)
     bases = args.reads * args.read_len
     stream = torch.cuda.current_stream(device)
 
@@ -119,9 +121,11 @@ def main():
 
     for _ in range(args.warmup):
         dev.run(stream)
+        if args.find:
+            dev.run_lengths(0, stream)
     sync_all()
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     t0 = time.perf_counter()
     for s in range(args.steps):
         ev[s][0].record(stream)
@@ -129,10 +133,14 @@ def main():
         ev[s][1].record(stream)
         dev.derand_translate(stream)
         ev[s][2].record(stream)
+        if args.find:  # kbo::find (lib.rs:816-820): run lengths of the characters, still on the device
+            dev.run_lengths(0, stream)
+        ev[s][3].record(stream)
     sync_all()
     elapsed = time.perf_counter() - t0
     walk_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     dt_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    rle_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev])) if args.find else None
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -146,12 +154,13 @@ def main():
         cpu, b_alg, exact, ops = None, None, None, None
         if world == 1 and not args.no_cpu_baseline:
             # parity gate + baseline on the unformatted characters
+            fmt = dev.format
             dev.format = False
             dev.derand_translate(stream)
             torch.cuda.synchronize(device)
             cpu, b_alg, exact, ops = cpu_baseline_leg(args, genome, concat, offsets, gpu_d,
                                                       dev.chars.cpu().numpy(), sbwt)
-            dev.format = True
+            dev.format = fmt
         if b_alg is None:
             b_alg = 85.7  # SURVEY.md §8(d) figure for 1 % substitutions (used when the oracle leg is skipped)
         achieved = b_alg * bases / (walk_ms * 1e-3) / 1e9
@@ -176,7 +185,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{'C2' if (args.genome, args.reads) == (5_000_000, 1_000_000) else 'custom'}: "
-                                   f"kbo map (fill_gaps=false, call_variants=false, format=true), "
+                                   f"{'kbo find (max_gap_len=0; run lengths on the device)' if args.find else 'kbo map (fill_gaps=false, call_variants=false, format=true)'}, "
                                    f"{args.genome / 1e6:g} Mbp iid genome SBWT k={args.k}, "
                                    f"{args.reads} x {args.read_len} bp reads per GPU, "
                                    f"{args.sub_rate * 100:g}% substitutions",
@@ -191,7 +200,8 @@ def main():
                                   "are served on-die, so measured HBM traffic is far below them") if resident else
                                  ("index exceeds L2: the walk is bound by L2-miss line fills (about 56 G/s on "
                                   "this part, 128 B each of which 16 B are used), see DESIGN.md section 6")},
-            "kernels_ms": {"ms_walk": round(walk_ms, 4), "derand_translate": round(dt_ms, 4)},
+            "kernels_ms": {"ms_walk": round(walk_ms, 4), "derand_translate": round(dt_ms, 4),
+                           **({"run_lengths": round(rle_ms, 4)} if args.find else {})},
             "cpu_baseline": cpu,
             "bit_exact_vs_oracle": exact,
             "reference_ops_per_base": ops,

@@ -110,6 +110,29 @@ class DeviceBatch:
                                              self.threshold, self.q.data_ptr() if self.format else None,
                                              self.chars.data_ptr(), self.max_len, s.cuda_stream))
 
+    def run_lengths(self, max_gap_len=0, stream=None, runs_per_seq=2):
+        """format::run_lengths_gapped of the (unformatted) characters, on the device: fills self.rle_records
+        ([capacity, 7] int32) and self.rle_work (first-run indices; last word = number of runs)."""
+        torch = self.torch
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        if getattr(self, "rle_work", None) is None:
+            wb = int(lib().kbo_run_lengths_work_bytes(self.n_seqs))
+            self.rle_work = torch.zeros(wb // 4 + 1, dtype=torch.int32, device=self.device)
+            self.rle_capacity = runs_per_seq * self.n_seqs + 16
+            self.rle_records = torch.zeros((self.rle_capacity, 7), dtype=torch.int32, device=self.device)
+        check(lib().kbo_run_lengths_dev(self.chars.data_ptr(), self.off.data_ptr(), self.n_seqs, max_gap_len,
+                                        self.rle_work.data_ptr(), self.rle_records.data_ptr(), self.rle_capacity,
+                                        s.cuda_stream))
+
+    def run_lengths_host(self):
+        """-> (records [n_runs, 7] uint32, first-run index per sequence uint32 [n_seqs + 1]) on the host"""
+        w = self.rle_work.cpu().numpy().view(np.uint32)
+        n = self.n_seqs
+        words = n + 1 + (n + 1 + 1023) // 1024
+        total = int(w[words])
+        first = w[n + 1 + np.arange(n + 1) // 1024] + w[:n + 1]
+        return self.rle_records[:total].cpu().numpy().view(np.uint32), first
+
     def run(self, stream=None):
         self.walk(stream)
         self.derand_translate(stream)

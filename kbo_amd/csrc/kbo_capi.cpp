@@ -1760,6 +1760,29 @@ int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, siz
     });
 }
 
+size_t kbo_run_lengths_work_bytes(size_t n_seqs)
+{
+    return kbo::chunk_items_scratch_words((uint32_t)std::min<size_t>(n_seqs, 0xFFFFFFFEu)) * sizeof(uint32_t) + 16;
+}
+
+int kbo_run_lengths_dev(const uint8_t *d_chars, const uint64_t *d_offsets, size_t n_seqs, size_t max_gap_len,
+                        void *d_work, uint32_t *d_records, size_t capacity, void *stream)
+{
+    return guarded([&] {
+        KBO_REQUIRE(d_chars && d_offsets && d_work && (d_records || capacity == 0), KBO_E_BAD_ARG, "null argument");
+        KBO_REQUIRE(n_seqs > 0 && n_seqs < (1ull << 31), KBO_E_BAD_ARG, "1 .. 2^31-1 sequences");
+        KBO_REQUIRE(((uintptr_t)d_work & 3) == 0 && ((uintptr_t)d_records & 3) == 0, KBO_E_BAD_ARG, "4-byte alignment");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const uint32_t gap = (uint32_t)std::min<size_t>(max_gap_len, 0xFFFFFFFFu);
+        uint32_t *scratch = static_cast<uint32_t *>(d_work);
+        uint32_t *total = scratch + kbo::chunk_items_scratch_words((uint32_t)n_seqs); // last word of the work buffer
+        HIP_OK(kbo::launch_rle_count(d_chars, d_offsets, (uint32_t)n_seqs, gap, scratch, total, s));
+        if (capacity)
+            HIP_OK(kbo::launch_rle_emit(d_chars, d_offsets, (uint32_t)n_seqs, gap, scratch, d_records,
+                                        (uint32_t)std::min<size_t>(capacity, 0xFFFFFFFFu), s));
+    });
+}
+
 int kbo_walk_geometry(int *blocks, int *threads)
 {
     return guarded([&] {

@@ -626,6 +626,20 @@ def test_device_resident_path_matches_host_path(oracle):
     d, lo, hi = ora.matching_statistics(concat[:150].tobytes())
     assert np.array_equal(dev.lo.cpu().numpy()[:150], lo.astype(np.uint32).view(np.int32))
     assert np.array_equal(dev.hi.cpu().numpy()[:150], hi.astype(np.uint32).view(np.int32))
+    # find on the device: run lengths of the characters, records stay in HBM until asked for
+    for gap, room in ((0, 2), (4, 1)):  # room 1: fewer record slots than runs, the count is still exact
+        dev.rle_work = None
+        dev.run_lengths(max_gap_len=gap, runs_per_seq=room)
+        torch.cuda.synchronize()
+        w = dev.rle_work.cpu().numpy().view(np.uint32)
+        n = dev.n_seqs
+        total = int(w[n + 1 + (n + 1 + 1023) // 1024])
+        exp = [oracle.run_lengths_gapped(exp_chars[offsets[s]:offsets[s + 1]].tobytes(), gap) for s in range(n)]
+        assert total == sum(len(e) for e in exp)
+        if total <= dev.rle_capacity:
+            rec, first = dev.run_lengths_host()
+            assert np.array_equal(first, np.concatenate([[0], np.cumsum([len(e) for e in exp])]).astype(np.uint32))
+            assert [tuple(int(v) for v in r) for r in rec] == [t for e in exp for t in e]
 
 
 @pytest.mark.parametrize("k", [7, 31, 101])
