@@ -186,6 +186,8 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
     uint32_t flags = left ? F_DONE : F_FIN;
     uint32_t l = 0, r = n, d = 0, m = 0, cb = 0; // m: contraction targets known (rare block only)
     uint32_t pcb = 0; // PAIR: first two-base block of (current base, next base), 0 = no pair step here
+    uint32_t pmin = 0; // PAIR: depth from which pair steps are tried: 0 until the item's first failure (a read
+                       // is expected to match from its first base), pair_min_d afterwards (random matches)
     uint32_t tgt_l = 0, tgt_r = 0; // contraction targets (rare block only)
     // Query and output are streamed in 16-byte blocks RELATIVE TO THE ITEM (unaligned global
     // accesses): i = base index inside the item; block i>>4, word (i>>2)&3, byte i&3.
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
                     if (PAIR) {
                         const uint32_t c2 = len > 1u ? decode_base((qcur >> 8) & 0xFFu) : 4u;
                         pcb = (c < 4u && c2 < 4u) ? pair_blk0 + (c * 4u + c2) * nblk : 0u;
+                        pmin = 0;
                     }
                     l = 0;
                     r = n;
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
             const bool con = (flags & F_CON) != 0;
             const uint32_t bl = div96(l), br = div96(r);
             const uint32_t bmask = cb == null_blk ? 0u : ~0u;
-            const bool pair_try = PAIR && !con && pcb != 0u && !(flags & F_NOPAIR) && d >= a.pair_min_d;
+            const bool pair_try = PAIR && !con && pcb != 0u && !(flags & F_NOPAIR) && d >= pmin;
             const uint32_t xb = pair_try ? pcb : cb; // first block of the bit-vector this lane ranks in
             const uint32_t rkA = (xb + (bl & bmask)) << 4, rkB = (xb + (br & bmask)) << 4;
             uint4 xA, xB;
@@ -303,7 +306,10 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
             const uint32_t d_ext = pair_try ? min(d + 2, k) : d_one;
             const bool accept = !con && (l2 < r2 || (d == 0 && !pair_try));
             const bool fail = !con && !accept && !pair_try; // a failed pair step proves nothing
-            if (PAIR) flags = (pair_try && !ok) ? (flags | F_NOPAIR) : ((accept && !pair_try) ? (flags & ~F_NOPAIR) : flags);
+            if (PAIR) {
+                flags = (pair_try && !ok) ? (flags | F_NOPAIR) : ((accept && !pair_try) ? (flags & ~F_NOPAIR) : flags);
+                pmin = (fail || (pair_try && !ok)) ? a.pair_min_d : pmin;
+            }
             if (con) dbg_con++;
 #ifdef KBO_WALK_DEBUG
             dbg_ext += accept ? 1u : 0u; dbg_fail += fail ? 1u : 0u;
