@@ -938,28 +938,21 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
                     S.n_seqs = ns;
                 } else {
                     // D2H leg: hipMemcpyAsync on the download stream.  With one stream per stage the copy
-                    // engines carry both directions at once (tools/bench_host.py: 37-40 Gbp/s host->host);
-                    // the alternatives measured slower and stay selectable for experiments: KBO_D2H=kernel
-                    // (a small kernel stores into pinned host memory, 28 Gbp/s), KBO_D2H=direct (A5/A6
-                    // store to host memory themselves, 26 Gbp/s).
-                    static const char *d2h_env = std::getenv("KBO_D2H");
-                    static const int d2h_mode = !d2h_env ? 1 : (std::strcmp(d2h_env, "kernel") == 0 ? 0 : (std::strcmp(d2h_env, "direct") == 0 ? 2 : 1));
+                    // engines carry both directions at once (tools/bench_host.py: 37-40 Gbp/s host->host;
+                    // a small kernel storing into pinned memory, or A5/A6 storing there themselves, gave
+                    // 28 and 26 Gbp/s).
                     uint8_t *dst = chars_out + sl.b0;
                     if (!out_pinned) {
                         S.out.ensure(bytes + 32);
                         dst = S.out.as<uint8_t>();
                     }
-                    const bool direct = d2h_mode == 2 && mx <= kbo::kLongSeq && (((uintptr_t)dst & 3) == 0);
-                    if (!direct) S.chars.ensure(((S.B.total + 15) / 16) * 16 + 16);
+                    S.chars.ensure(((S.B.total + 15) / 16) * 16 + 16);
                     derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, (uint32_t)k,
                                                   (uint32_t)threshold, format ? S.B.q.as<uint8_t>() : nullptr,
-                                                  direct ? dst : S.chars.as<uint8_t>(), nullptr, C.st_run, mx);
+                                                  S.chars.as<uint8_t>(), nullptr, C.st_run, mx);
                     HIP_OK(hipEventRecord(S.computed, C.st_run));
                     HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
-                    if (!direct) {
-                        if (d2h_mode == 1) HIP_OK(hipMemcpyAsync(dst, S.chars.p, bytes, hipMemcpyDeviceToHost, C.st_down));
-                        else HIP_OK(kbo::launch_copy_to_host(S.chars.as<uint8_t>(), dst, bytes, C.st_down));
-                    }
+                    HIP_OK(hipMemcpyAsync(dst, S.chars.p, bytes, hipMemcpyDeviceToHost, C.st_down));
                     HIP_OK(hipEventRecord(S.done, C.st_down));
                 }
                 S.busy = true;

@@ -42,9 +42,6 @@ struct WalkArgs {
     uint32_t *hi_out;      // optional: interval end per base
 };
 
-// device -> pinned host copy done by a small kernel instead of the copy engine
-hipError_t launch_copy_to_host(const uint8_t *d_src, uint8_t *h_dst, uint64_t bytes, hipStream_t stream);
-
 // offsets (n_seqs+1) -> one item per sequence
 hipError_t launch_make_items(const uint64_t *d_offsets, uint32_t n_seqs, WalkItem *d_items,
                              hipStream_t stream);

@@ -110,26 +110,24 @@ __device__ __forceinline__ void st_partial(uint8_t *o, const uint4 &v, uint32_t 
 //                     while d > 0 && Ic empty:  I = contract_left(I, d-1); d -= 1; Ic = extend_right(I, c)
 //                     if Ic non-empty: I = Ic; d = min(d+1, k)
 //                     emit (d, I)
-// Bit-identical shortcut: contract_left(I, t) leaves I unchanged for every
-// t > m = max(LCS[l], LCS[r]), and extend_right of an unchanged interval is still empty,
-// so the loop jumps straight to depth m (one LCS look-up + one scan) instead of stepping
-// d-1, d-2, ... with a failing rank pair each time.  A non-ACGT base reads the all-zero
-// "null" rank block, so its extension is empty at every depth and the same machinery
-// contracts it down to the root (d = 0, I = [0,n)), which is what the loop above does.
+// A non-ACGT base reads the all-zero "null" rank block, so its extension is empty at every
+// depth and the contraction machinery takes it down to the root (d = 0, I = [0,n)), which is
+// what the loop above does.
 //
-// The kernel is VALU-issue bound (rocprof: SIMD issue saturated, see profiles/), so it is
-// organised around a short hot path:
-//   hot path  (every iteration, lanes not blocked): two rank-block loads, rank arithmetic,
+// The kernel is instruction-issue bound on L2-resident indexes and line-fill bound beyond
+// (DESIGN.md section 6), so it is one loop with
+//   a hot path (every iteration, lanes not blocked): two 16-byte loads per lane - rank blocks
+//             for extending lanes, contraction entries for contracting ones, two-base blocks
+//             for PAIR lanes - then the arithmetic of all three kinds written with selects,
 //             accept / emit / advance to the next base;
-//   rare block (entered when >= kRareBatch lanes are blocked, or every 4th iteration if
-//             any is): contract-left via the LCS windows, switching to the prefetched next
-//             item, requesting the prefetch after that, exit test.
+//   a rare block (entered when >= rare_batch lanes are blocked, or every rare_mask+1-th
+//             iteration if any is): switching to the prefetched next item, requesting the
+//             prefetch after that, exit test.
 // One lane per work item; lane j of wave w walks items w*64*rounds + j + 64*t.  All
 // offsets are 32-bit (one launch covers < 4 GiB of query and an index arena < 4 GiB for
 // the 32-bit build), so every access is SGPR base + 32-bit VGPR offset.
-#ifndef KBO_ABLATE
-#define KBO_ABLATE 0
-#endif
+// KBO_NO_TARGETS=1 (compile time) drops the nearest-set-bit targets of the contraction: a lane
+// then climbs one level and re-tries; measured -2 % walk time at 1 % substitutions, +4.5 % at 5 %.
 #ifndef KBO_NO_TARGETS
 #define KBO_NO_TARGETS 0
 #endif
@@ -915,28 +913,7 @@ __global__ void rle_total_kernel(const uint32_t *__restrict__ local, const uint3
     if (threadIdx.x == 0 && blockIdx.x == 0) *total = sums[n_seqs / kScanBlock] + local[n_seqs];
 }
 
-// Copies `bytes` from device memory to pinned host memory with plain stores.  A small
-// grid-stride grid: it is PCIe-bound, leaves the copy engine to the opposite direction and
-// takes only a few wave slots per CU away from the walk kernel of the next slab.
-__global__ void copy_to_host_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint64_t bytes)
-{
-    const uint64_t n16 = bytes >> 4;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint4 v;
-        __builtin_memcpy(&v, src + (i << 4), 16);
-        __builtin_memcpy(dst + (i << 4), &v, 16);
-    }
-    if (blockIdx.x == 0 && threadIdx.x < (bytes & 15u)) dst[(n16 << 4) + threadIdx.x] = src[(n16 << 4) + threadIdx.x];
-}
-
 } // namespace
-
-hipError_t launch_copy_to_host(const uint8_t *d_src, uint8_t *h_dst, uint64_t bytes, hipStream_t stream)
-{
-    if (bytes == 0) return hipSuccess;
-    hipLaunchKernelGGL(copy_to_host_kernel, dim3(256), dim3(256), 0, stream, d_src, h_dst, bytes);
-    return hipGetLastError();
-}
 
 hipError_t launch_make_items(const uint64_t *d_offsets, uint32_t n_seqs, WalkItem *d_items,
                              hipStream_t stream)
