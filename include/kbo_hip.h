@@ -254,7 +254,7 @@ int kbo_run_lengths_dev(const uint8_t *d_chars, const uint64_t *d_offsets, size_
 int kbo_walk_geometry(int *max_waves, int *threads);
 int kbo_set_walk_waves_per_cu(int waves_per_cu); /* tuning knob, 0 = default (32) */
 int kbo_set_walk_threads(int threads);           /* tuning knob: workgroup size 64/128/256 */
-int kbo_set_walk_rare(int batch, int period);    /* tuning knob: rare-block batching */
+int kbo_set_walk_rare(int period);               /* tuning knob: hot-loop iterations between item-bookkeeping visits (default 8) */
 /* Devices the host batch entry points (kbo_matches_batch / kbo_map_batch / kbo_find_batch) spread
  * their slabs over: index replicated per device, one submitting + one completing host thread and
  * three stage streams (upload, kernels, download) per device, disjoint output slices, no collective.

@@ -147,7 +147,7 @@ def lib():
     L.kbo_walk_geometry.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.kbo_set_walk_waves_per_cu.argtypes = [C.c_int]
     L.kbo_set_walk_threads.argtypes = [C.c_int]
-    L.kbo_set_walk_rare.argtypes = [C.c_int, C.c_int]
+    L.kbo_set_walk_rare.argtypes = [C.c_int]
     L.kbo_set_slab_bytes.argtypes = [sz]
     L.kbo_set_force_big_layout.argtypes = [C.c_int]
     L.kbo_set_host_threads.argtypes = [C.c_int]

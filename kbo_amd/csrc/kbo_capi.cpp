@@ -1829,9 +1829,9 @@ int kbo_set_slab_bytes(size_t bytes)
     return KBO_OK;
 }
 
-int kbo_set_walk_rare(int batch, int period)
+int kbo_set_walk_rare(int period)
 {
-    kbo::set_walk_rare(batch, period);
+    kbo::set_walk_rare(period);
     return KBO_OK;
 }
 

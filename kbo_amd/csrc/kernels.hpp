@@ -34,8 +34,7 @@ struct WalkArgs {
     const WalkItem *items; // n_items
     uint32_t n_items;
     uint32_t rounds;       // items per lane (set by launch_ms_walk)
-    uint32_t rare_batch;   // enter the rare block when this many lanes are blocked ...
-    uint32_t rare_mask;    // ... or when (iteration & rare_mask) == 0 and any lane is
+    uint32_t rare_period;  // hot-loop iterations between two visits of the rare block (set by launch_ms_walk)
     uint32_t pair_min_d;   // two-base steps only from matches at least this deep (set by launch_ms_walk)
     uint8_t *d_out;        // 1 byte per base, same indexing as q
     uint32_t *lo_out;      // optional (nullptr): interval start per base
@@ -78,7 +77,7 @@ hipError_t launch_translate(const int32_t *d_derand, uint64_t len, uint32_t k, u
 
 constexpr int kWalkThreads = 64; // default workgroup size (waves are independent: no LDS, no barriers)
 void set_walk_threads(int threads); // tuning: 64, 128 or 256
-void set_walk_rare(int batch, int period); // tuning: rare-block batching
+void set_walk_rare(int period);            // tuning: hot-loop iterations between rare-block visits
 void set_pair_min_depth(int d);            // tuning: depth from which two-base steps are tried
 constexpr uint32_t kRankRows = 96; // rows per 16-byte rank block (== kRankRowsPerBlock)
 

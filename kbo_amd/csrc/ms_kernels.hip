@@ -205,12 +205,11 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
     }
 
     uint32_t dbg_rare = 0, dbg_con = 0, dbg_iter = 0, dbg_ext = 0, dbg_fail = 0;
-    for (uint32_t iter = 0;; iter++) {
-        dbg_iter = iter;
+    for (;;) {
         // ================================ rare block ================================
-        const uint64_t blocked = __ballot((flags & F_DONE) != 0);
-        const uint64_t hot = __ballot(flags < F_BLOCK);
-        if (hot == 0 || (blocked != 0 && ((uint32_t)__popcll(blocked) >= a.rare_batch || (iter & a.rare_mask) == 0))) {
+        // entered every rare_period iterations: the hot loop below carries no item bookkeeping at
+        // all, and a lane that finishes its item waits at most rare_period - 1 iterations
+        {
             dbg_rare++;
             // ---- request the first query block of the next item once its descriptor is here
             if (flags & F_PF) {
@@ -251,6 +250,9 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
             if (__ballot(flags != F_FIN) == 0) break;
         }
 
+#pragma unroll 1
+        for (uint32_t it = 0; it < a.rare_period; it++) {
+        dbg_iter++;
         // ================================= hot path =================================
         // A lane is either extending (two rank blocks) or contracting (two contraction
         // entries {lcs, psv, nsv}); both kinds of load go through the same two load sites and
@@ -370,6 +372,7 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
                 }
             }
         }
+        } // hot loop
     }
 #ifdef KBO_WALK_DEBUG
     if (lane == 0 && a.lo_out == nullptr && a.hi_out != nullptr) { // debug: hi_out doubles as counter sink
@@ -970,16 +973,10 @@ hipError_t launch_make_chunk_items(const uint64_t *d_offsets, uint32_t n_seqs, u
 }
 
 int g_walk_threads = kWalkThreads;
-int g_rare_batch = 32, g_rare_period = 16; // tuned on C2 (tools/sweep_walk.py RARE=1)
+int g_rare_period = 8; // tuned on C2 (tools/sweep_walk.py RARE=1)
 int g_pair_min_depth = 16;                 // two-base steps only from matches at least this deep
 void set_pair_min_depth(int d) { g_pair_min_depth = d < 0 ? 0 : d; }
-void set_walk_rare(int batch, int period)
-{
-    g_rare_batch = std::max(1, std::min(64, batch));
-    int p = 1;
-    while (p < period && p < 1024) p <<= 1;
-    g_rare_period = p;
-}
+void set_walk_rare(int period) { g_rare_period = std::max(1, std::min(1024, period)); }
 void set_walk_threads(int t) { g_walk_threads = (t == 64 || t == 128 || t == 256) ? t : kWalkThreads; }
 
 hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
@@ -989,8 +986,7 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
     // items with as little slack as possible (one 64-lane wave per workgroup)
     const uint64_t lanes = (uint64_t)std::max(1, max_waves) * 64u;
     a.rounds = (uint32_t)((a.n_items + lanes - 1) / lanes);
-    a.rare_batch = (uint32_t)g_rare_batch;
-    a.rare_mask = (uint32_t)g_rare_period - 1u;
+    a.rare_period = (uint32_t)g_rare_period;
     const uint64_t per_wave = 64ull * a.rounds;
     const uint32_t waves = (uint32_t)((a.n_items + per_wave - 1) / per_wave);
     const uint32_t threads = g_walk_threads;

@@ -62,12 +62,12 @@ def time_walk(reps=8):
 
 L = kbo_amd.lib()
 if os.environ.get("RARE"):
-    for wpc in (16, 32):
-        for batch, period in ((8, 4), (16, 8), (24, 8), (32, 16), (48, 16), (32, 32), (48, 64), (64, 64)):
-            L.kbo_set_walk_threads(64); L.kbo_set_walk_waves_per_cu(wpc); L.kbo_set_walk_rare(batch, period)
+    for wpc in (32,):
+        for period in (2, 4, 6, 8, 12, 16, 32):
+            L.kbo_set_walk_threads(64); L.kbo_set_walk_waves_per_cu(wpc); L.kbo_set_walk_rare(period)
             dev.walk(stream); torch.cuda.synchronize()
             mn, med = time_walk()
-            print(f"waves/CU={wpc} batch={batch:2d} period={period:2d}  walk min {mn:.3f} ms median {med:.3f}", flush=True)
+            print(f"waves/CU={wpc} period={period:2d}  walk min {mn:.3f} ms median {med:.3f}", flush=True)
     sys.exit(0)
 if os.environ.get("ONLY"):
     L.kbo_set_walk_threads(64); L.kbo_set_walk_waves_per_cu(32)
