@@ -471,6 +471,32 @@ def test_find_batch_every_read_against_oracle(oracle):
         kbo_amd.lib().kbo_set_slab_bytes(32 << 20)
 
 
+def test_find_batch_with_contigs(oracle):
+    """find over a batch that mixes reads with contigs long enough for the chunked walk and the
+    chunked derandomize (> 64 kbp): run lengths equal the oracle's."""
+    rng = np.random.default_rng(9)
+    g = synth.genome(300_000, seed=25)
+    sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=4))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    pieces = []
+    for n in [150, 90_000, 300, 5_000, 70_001, 3, 151]:
+        s0 = int(rng.integers(0, len(g) - n))
+        p = g[s0:s0 + n].copy()
+        hit = rng.random(n) < 0.01
+        p[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+        if n > 1000:
+            p[n // 2:n // 2 + 200] = ord("N")  # a stretch that cannot match
+        pieces.append(p)
+    concat = np.concatenate(pieces)
+    offsets = np.concatenate([[0], np.cumsum([len(p) for p in pieces])]).astype(np.uint64)
+    exp_chars = ora.matches_batch(concat, offsets, 1e-7, n_threads=4)
+    for gap in (0, 100, 1000):
+        rles, ro = batch.find_batch(sbwt, concat, offsets, kbo_amd.FindOpts(max_gap_len=gap))
+        for s in range(len(pieces)):
+            exp = oracle.run_lengths_gapped(exp_chars[offsets[s]:offsets[s + 1]].tobytes(), gap)
+            assert [tuple(int(v) for v in r) for r in rles[ro[s]:ro[s + 1]]] == exp, (gap, s)
+
+
 def test_host_batches_in_slabs(oracle):
     """Host batches larger than the slab size go through the staged slab pipeline (more slabs than
     slots, so staging buffers and device buffers are reused within one call)."""
