@@ -238,10 +238,14 @@ int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *
                      uint32_t *d_lo_out, uint32_t *d_hi_out, void *d_work, size_t work_bytes, void *stream);
 /* A5+A6 fused (+ optional format::relative_to_ref when d_ref != NULL): u8 MS -> u8 chars.
  * max_seq_len = length of the longest sequence in the batch if the caller knows it (selects
- * the LDS-staged kernel for short reads), 0 = unknown. */
+ * the LDS-staged kernel for short reads), 0 = unknown.  d_work (optional, NULL = none): scratch of
+ * kbo_derand_work_bytes() bytes, 16-byte aligned; with it long reads / contigs are processed in
+ * pieces of 256 positions, one lane each, instead of one lane per sequence. */
+size_t kbo_derand_work_bytes(size_t n_seqs, uint64_t total_bases);
 int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, size_t n_seqs,
-                             size_t k, size_t threshold, const uint8_t *d_ref, uint8_t *d_chars_out,
-                             size_t max_seq_len, void *stream);
+                             uint64_t total_bases, size_t k, size_t threshold, const uint8_t *d_ref,
+                             uint8_t *d_chars_out, size_t max_seq_len, void *d_work, size_t work_bytes,
+                             void *stream);
 /* format::run_lengths_gapped over device-resident characters (the output of kbo_derand_translate_dev
  * without d_ref), enqueued on `stream`.  d_work: kbo_run_lengths_work_bytes(n_seqs) bytes; afterwards
  * word s of d_work plus word (n_seqs + 1 + s / 1024) is the index of sequence s's first run, and the

@@ -76,7 +76,7 @@ SYMBOLS = [
     "kbo_map", "kbo_find", "kbo_run_lengths_gapped", "kbo_relative_to_ref", "kbo_free",
     "kbo_ms_batch", "kbo_matches_batch", "kbo_map_batch", "kbo_find_batch", "kbo_work_bytes",
     "kbo_ms_batch_dev", "kbo_derand_translate_dev", "kbo_walk_geometry",
-    "kbo_set_walk_waves_per_cu", "kbo_set_walk_threads", "kbo_set_walk_rare", "kbo_set_slab_bytes", "kbo_set_force_big_layout", "kbo_set_devices", "kbo_set_host_threads", "kbo_release_scratch", "kbo_set_pair_steps", "kbo_run_lengths_gapped_batch", "kbo_run_lengths_work_bytes", "kbo_run_lengths_dev", "kbo_index_device_pair_bytes",
+    "kbo_set_walk_waves_per_cu", "kbo_set_walk_threads", "kbo_set_walk_rare", "kbo_set_slab_bytes", "kbo_set_force_big_layout", "kbo_set_devices", "kbo_set_host_threads", "kbo_release_scratch", "kbo_set_pair_steps", "kbo_run_lengths_gapped_batch", "kbo_derand_work_bytes", "kbo_run_lengths_work_bytes", "kbo_run_lengths_dev", "kbo_index_device_pair_bytes",
 ]
 
 _lib = None
@@ -143,7 +143,8 @@ def lib():
     L.kbo_find_batch.argtypes = [vp, vp, vp, sz, C.POINTER(FindOpts), C.POINTER(C.POINTER(RLE)), vp]
     L.kbo_work_bytes.argtypes = [sz, u64, sz, C.c_uint32]; L.kbo_work_bytes.restype = sz
     L.kbo_ms_batch_dev.argtypes = [vp, vp, vp, sz, u64, sz, vp, vp, vp, vp, sz, vp]
-    L.kbo_derand_translate_dev.argtypes = [vp, vp, sz, sz, sz, vp, vp, sz, vp]
+    L.kbo_derand_translate_dev.argtypes = [vp, vp, sz, u64, sz, sz, vp, vp, sz, vp, sz, vp]
+    L.kbo_derand_work_bytes.argtypes = [sz, u64]; L.kbo_derand_work_bytes.restype = sz
     L.kbo_walk_geometry.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.kbo_set_walk_waves_per_cu.argtypes = [C.c_int]
     L.kbo_set_walk_threads.argtypes = [C.c_int]

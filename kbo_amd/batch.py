@@ -106,9 +106,16 @@ class DeviceBatch:
 
     def derand_translate(self, stream=None):
         s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
-        check(lib().kbo_derand_translate_dev(self.ms.data_ptr(), self.off.data_ptr(), self.n_seqs, self.k,
+        if self.max_len == 0 or self.max_len > 480:  # long reads / contigs: scratch for the piece-wise kernel
+            if getattr(self, "dt_work", None) is None:
+                self.dt_work_bytes = int(lib().kbo_derand_work_bytes(self.n_seqs, self.total))
+                self.dt_work = self.torch.zeros(self.dt_work_bytes // 8 + 2, dtype=self.torch.int64, device=self.device)
+            work, work_bytes = self.dt_work.data_ptr(), self.dt_work_bytes
+        else:
+            work, work_bytes = None, 0
+        check(lib().kbo_derand_translate_dev(self.ms.data_ptr(), self.off.data_ptr(), self.n_seqs, self.total, self.k,
                                              self.threshold, self.q.data_ptr() if self.format else None,
-                                             self.chars.data_ptr(), self.max_len, s.cuda_stream))
+                                             self.chars.data_ptr(), self.max_len, work, work_bytes, s.cuda_stream))
 
     def run_lengths(self, max_gap_len=0, stream=None, runs_per_seq=2):
         """format::run_lengths_gapped of the (unformatted) characters, on the device: fills self.rle_records

@@ -402,7 +402,7 @@ struct HostSlot {
     uint64_t out_b0 = 0, out_bytes = 0;
     // run-length output (kbo_find_batch): per-sequence first-run indices + block sums, the records,
     // the number of runs (device word and its pinned copy), what the slab holds
-    DevBuf rle_scratch, rles, rle_total;
+    DevBuf rle_scratch, rles, rle_total, dt_work;
     PinBuf rle_total_pin, rle_first_pin;
     size_t rle_capacity = 0, slab_id = 0, n_seqs = 0;
 };
@@ -430,7 +430,7 @@ struct HostCtx {
                 if (e) (void)hipEventDestroy(e);
         for (HostSlot &S : slot) { // buffers belong to `dev`
             S.B.release();
-            for (DevBuf *b : {&S.chars, &S.rle_scratch, &S.rles, &S.rle_total}) b->release();
+            for (DevBuf *b : {&S.chars, &S.rle_scratch, &S.rles, &S.rle_total, &S.dt_work}) b->release();
         }
         (void)hipSetDevice(prev);
     }
@@ -481,11 +481,19 @@ void check_len_threshold(const uint64_t *offsets, size_t n_seqs, size_t k, size_
 // sequences -> one lane each, very long sequences -> chunked scan (one at a time).
 void derand_translate_host_offsets(const uint8_t *d_ms, const uint64_t *d_off, const uint64_t *offsets, size_t n_seqs,
                                    uint32_t k, uint32_t threshold, const uint8_t *d_ref, uint8_t *d_chars,
-                                   int32_t *d_derand, hipStream_t stream, uint32_t longest = 0)
+                                   int32_t *d_derand, hipStream_t stream, uint32_t longest = 0,
+                                   DevBuf *piece_work = nullptr /* lets long reads / contigs be split into pieces */)
 {
     const uint32_t mx = longest ? longest : max_len(offsets, n_seqs);
+    void *work = nullptr;
+    size_t work_bytes = 0;
+    if (piece_work && mx > 480 && !d_derand) {
+        work_bytes = kbo::derand_piece_work_bytes((uint32_t)n_seqs, offsets[n_seqs]);
+        piece_work->ensure(work_bytes);
+        work = piece_work->p;
+    }
     HIP_OK(kbo::launch_derand_translate(d_ms, d_off, (uint32_t)n_seqs, k, threshold, d_ref, d_chars, d_derand, mx,
-                                        kbo::kLongSeq, stream));
+                                        kbo::kLongSeq, stream, offsets[n_seqs], work, work_bytes));
     if (mx <= kbo::kLongSeq) return;
     size_t need = 0;
     for (size_t s = 0; s < n_seqs; s++) {
@@ -735,7 +743,7 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
                     // the room the slot has) emitted right behind A5/A6; the completing thread downloads them
                     S.chars.ensure(((S.B.total + 15) / 16) * 16 + 32);
                     derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, (uint32_t)k,
-                                                  (uint32_t)threshold, nullptr, S.chars.as<uint8_t>(), nullptr, C.st_run, mx);
+                                                  (uint32_t)threshold, nullptr, S.chars.as<uint8_t>(), nullptr, C.st_run, mx, &S.dt_work);
                     const uint32_t gap = (uint32_t)std::min<size_t>(sink->max_gap_len, 0xFFFFFFFFu);
                     S.rle_scratch.ensure(kbo::chunk_items_scratch_words((uint32_t)ns) * sizeof(uint32_t));
                     S.rle_total.ensure(16);
@@ -767,7 +775,7 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
                     S.chars.ensure(((S.B.total + 15) / 16) * 16 + 16);
                     derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, (uint32_t)k,
                                                   (uint32_t)threshold, format ? S.B.q.as<uint8_t>() : nullptr,
-                                                  S.chars.as<uint8_t>(), nullptr, C.st_run, mx);
+                                                  S.chars.as<uint8_t>(), nullptr, C.st_run, mx, &S.dt_work);
                     HIP_OK(hipEventRecord(S.computed, C.st_run));
                     HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
                     HIP_OK(hipMemcpyAsync(dst, S.chars.p, bytes, hipMemcpyDeviceToHost, C.st_down));
@@ -1232,6 +1240,7 @@ int kbo_translate_ms_vec(const int64_t *derand, size_t len, size_t k, size_t thr
         KBO_REQUIRE(k > 0, KBO_E_BAD_ARG, "k > 0 (translate.rs:268)");
         KBO_REQUIRE(threshold > 1, KBO_E_THRESHOLD_LE_1, "threshold > 1 (translate.rs:269)");
         KBO_REQUIRE(len > 2, KBO_E_LEN_LE_2, "len > 2 (translate.rs:270)");
+        KBO_REQUIRE(len < 0xFFFFFFFFull, KBO_E_UNSUPPORTED, "vector longer than 2^32-1");
         // the stencil only compares values with 0, 1, threshold and k: clamping i64 -> i32
         // preserves every comparison as long as threshold and k fit in i32
         const int64_t lim = 0x7FFFFFF0;
@@ -1553,21 +1562,27 @@ int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *
     });
 }
 
-int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, size_t n_seqs, size_t k,
-                             size_t threshold, const uint8_t *d_ref, uint8_t *d_chars_out,
-                             size_t max_seq_len, void *stream)
+size_t kbo_derand_work_bytes(size_t n_seqs, uint64_t total_bases)
+{
+    return kbo::derand_piece_work_bytes((uint32_t)std::min<size_t>(n_seqs, 0xFFFFFFFEu), total_bases);
+}
+
+int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
+                             size_t k, size_t threshold, const uint8_t *d_ref, uint8_t *d_chars_out,
+                             size_t max_seq_len, void *d_work, size_t work_bytes, void *stream)
 {
     return guarded([&] {
         KBO_REQUIRE(d_ms && d_offsets && d_chars_out, KBO_E_BAD_ARG, "null argument");
         KBO_REQUIRE(n_seqs > 0 && n_seqs < 0xFFFFFFFFull, KBO_E_EMPTY_QUERY, "empty batch");
         KBO_REQUIRE(k > 0 && k <= 255, KBO_E_BAD_ARG, "k in 1..255");
         KBO_REQUIRE(threshold > 1, KBO_E_THRESHOLD_LE_1, "threshold > 1 (derandomize.rs:275)");
-        KBO_REQUIRE(((uintptr_t)d_ms & 3) == 0 && ((uintptr_t)d_chars_out & 3) == 0 && ((uintptr_t)d_ref & 3) == 0,
-                    KBO_E_BAD_ARG, "device buffers must be 4-byte aligned");
+        KBO_REQUIRE(((uintptr_t)d_ms & 3) == 0 && ((uintptr_t)d_chars_out & 3) == 0 && ((uintptr_t)d_ref & 3) == 0 &&
+                        ((uintptr_t)d_work & 15) == 0,
+                    KBO_E_BAD_ARG, "device buffers must be 4-byte (d_work 16-byte) aligned");
         HIP_OK(kbo::launch_derand_translate(d_ms, d_offsets, (uint32_t)n_seqs, (uint32_t)k, (uint32_t)threshold,
                                             d_ref, d_chars_out, nullptr,
                                             (uint32_t)std::min<size_t>(max_seq_len, 0xFFFFFFFFu), 0xFFFFFFFFu,
-                                            static_cast<hipStream_t>(stream)));
+                                            static_cast<hipStream_t>(stream), total_bases, d_work, work_bytes));
     });
 }
 

@@ -64,7 +64,10 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream);
 hipError_t launch_derand_translate(const uint8_t *d_ms, const uint64_t *d_offsets, uint32_t n_seqs,
                                    uint32_t k, uint32_t threshold, const uint8_t *d_ref,
                                    uint8_t *d_chars_out, int32_t *d_derand_out, uint32_t max_seq_len,
-                                   uint32_t per_lane_max_len, hipStream_t stream);
+                                   uint32_t per_lane_max_len, hipStream_t stream, uint64_t total_bases = 0,
+                                   void *d_work = nullptr, size_t work_bytes = 0);
+// scratch that lets launch_derand_translate split long reads / contigs into pieces (one lane each)
+size_t derand_piece_work_bytes(uint32_t n_seqs, uint64_t total_bases);
 // A5+A6 for ONE very long sequence (pointers already offset to its first byte): chunked
 // three-level scan over per-chunk transition tables; d_scratch >= derand_long_scratch_bytes().
 size_t derand_long_scratch_bytes(uint64_t len, uint32_t k, uint32_t threshold);

@@ -485,16 +485,17 @@ __global__ void make_chunk_items_kernel(const uint64_t *__restrict__ off, const 
 //               = translate_ms_val(x[pos], next, prev).0   otherwise
 //     next = pos < len-1 ? x[pos+1] : x[pos];   prev = pos > 1 ? x[pos-1] : k   (note pos > 1)
 // so one right-to-left pass with a three-value window produces the characters.
-__device__ __forceinline__ uint8_t translate_char(int xm, int xc, int xn, uint64_t rel, uint64_t len,
-                                                  int K, int T)
+__device__ __forceinline__ uint32_t translate_char(int xm, int xc, int xn, uint32_t rel, uint32_t len, int K, int T)
 {
-    const int prev = rel > 1 ? xm : K;
-    const int next = rel < len - 1 ? xn : xc;
-    const bool r_prev = rel >= 2 && rel < len - 1 && xm > T && xc > 0 && xc < T;
-    const bool r_here = xc > T && next > 0 && next < T;
-    if (r_prev || r_here) return 'R';
-    if (xc <= 0) return (next == 1 && prev > 0) ? 'X' : '-';
-    return 'M';
+    // branch-free; 0 < v < T is written (unsigned)(v - 1) < (unsigned)(T - 1), 2 <= rel <= len-2 as
+    // (rel - 2) < (len - 3) (len >= 3)
+    const uint32_t Tm1 = (uint32_t)(T - 1);
+    const int prev = rel > 1u ? xm : K;
+    const int next = rel < len - 1u ? xn : xc;
+    const bool inherits = (rel - 2u) < (len - 3u) && xm > T && (uint32_t)(xc - 1) < Tm1;
+    const bool own = xc > T && (uint32_t)(next - 1) < Tm1;
+    const uint32_t plain = xc <= 0 ? ((next == 1 && prev > 0) ? (uint32_t)'X' : (uint32_t)'-') : (uint32_t)'M';
+    return (inherits || own) ? (uint32_t)'R' : plain;
 }
 
 // byte J (compile-time 0..15) of a 16-byte block held in registers
@@ -541,16 +542,49 @@ __device__ __forceinline__ void dt_step(DtState &st, const uint4 &cur, const uin
     st.x_cur = st.x_prev;
 }
 
+// the same for a position with 2 <= p <= len-2 whose block lies wholly inside the sequence and is
+// not its first: no position tests at all (most blocks of a long sequence)
+template <int J>
+__device__ __forceinline__ void dt_step_mid(DtState &st, const uint4 &cur, const uint4 &below, const uint4 &rcur,
+                                            uint4 &oblk, int K, int T, bool fmt)
+{
+    const int a = (int)(J > 0 ? blk_byte<(J + 15) & 15>(cur) : blk_byte<15>(below));
+    st.x_prev = (a == K) ? K : ((a > T && st.x_cur < a) ? a : st.x_cur - 1);
+    const uint32_t Tm1 = (uint32_t)(T - 1);
+    const bool is_r = (st.x_prev > T && (uint32_t)(st.x_cur - 1) < Tm1) || (st.x_cur > T && (uint32_t)(st.x_next - 1) < Tm1);
+    const uint32_t plain = st.x_cur <= 0 ? ((st.x_next == 1 && st.x_prev > 0) ? (uint32_t)'X' : (uint32_t)'-') : (uint32_t)'M';
+    uint32_t ch = is_r ? (uint32_t)'R' : plain;
+    if (fmt) ch = (ch == 'M' || ch == 'R') ? blk_byte<J>(rcur) : (uint32_t)'-';
+    blk_or_byte<J>(oblk, ch);
+    st.x_next = st.x_cur;
+    st.x_cur = st.x_prev;
+}
+
+#define KBO_DT_BLOCK_GUARDED(DOUT)                                                                                    \
+    {                                                                                                                \
+        KBO_DT(15, DOUT) KBO_DT(14, DOUT) KBO_DT(13, DOUT) KBO_DT(12, DOUT) KBO_DT(11, DOUT) KBO_DT(10, DOUT)        \
+        KBO_DT(9, DOUT) KBO_DT(8, DOUT) KBO_DT(7, DOUT) KBO_DT(6, DOUT) KBO_DT(5, DOUT) KBO_DT(4, DOUT)              \
+        KBO_DT(3, DOUT) KBO_DT(2, DOUT) KBO_DT(1, DOUT) KBO_DT(0, DOUT)                                              \
+    }
+#define KBO_DT(J, DOUT) dt_step<J>(st, cur, below, rcur, oblk, p0 + J, len, K, T, fmt, (DOUT) ? (DOUT) + p0 + J : nullptr);
+#define KBO_DT_BLOCK_MID                                                                                             \
+    {                                                                                                                \
+        KBO_DM(15) KBO_DM(14) KBO_DM(13) KBO_DM(12) KBO_DM(11) KBO_DM(10) KBO_DM(9) KBO_DM(8)                        \
+        KBO_DM(7) KBO_DM(6) KBO_DM(5) KBO_DM(4) KBO_DM(3) KBO_DM(2) KBO_DM(1) KBO_DM(0)                              \
+    }
+#define KBO_DM(J) dt_step_mid<J>(st, cur, below, rcur, oblk, K, T, fmt);
+
 // One lane per sequence, right to left, one 16-byte block (relative to the sequence start,
 // unaligned global accesses) at a time with the block below it already in flight; inside a
 // block the 16 positions are unrolled so every byte access is a constant bit-field.
 __global__ __launch_bounds__(256) void derand_translate_kernel(
     const uint8_t *__restrict__ ms, const uint64_t *__restrict__ off, uint32_t n_seqs, uint32_t k,
     uint32_t t, const uint8_t *__restrict__ ref, uint8_t *__restrict__ out, int32_t *__restrict__ derand_out,
-    uint32_t max_len)
+    uint32_t max_len, const uint32_t *__restrict__ only)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seqs) return;
+    if (only && !only[s]) return; // second pass of the piece-wise path: flagged sequences only
     const uint64_t b = off[s], e = off[s + 1];
     const uint32_t len = (uint32_t)(e - b);
     if (len < 3) return;       // the host side rejects these (derandomize.rs:276)
@@ -574,10 +608,88 @@ __global__ __launch_bounds__(256) void derand_translate_kernel(
         }
         uint4 oblk = make_uint4(0, 0, 0, 0);
         const uint32_t p0 = 16u * bi;
-#define KBO_DT(J) dt_step<J>(st, cur, below, rcur, oblk, p0 + J, len, K, T, fmt, dout ? dout + p0 + J : nullptr);
-        KBO_DT(15) KBO_DT(14) KBO_DT(13) KBO_DT(12) KBO_DT(11) KBO_DT(10) KBO_DT(9) KBO_DT(8)
-        KBO_DT(7) KBO_DT(6) KBO_DT(5) KBO_DT(4) KBO_DT(3) KBO_DT(2) KBO_DT(1) KBO_DT(0)
-#undef KBO_DT
+        if (bi >= 1u && p0 + 17u <= len && !dout) KBO_DT_BLOCK_MID
+        else KBO_DT_BLOCK_GUARDED(dout)
+        if (p0 + 16u <= len) st16u(outb, p0, oblk);
+        else st_partial(outb + p0, oblk, len - p0); // topmost, partial block of the sequence
+        cur = below;
+        rcur = rbelow;
+    }
+}
+
+// ---- piece-wise variant for batches of long reads / contigs -----------------------------
+// One lane per piece of kDtPiece positions of a sequence, so that a few thousand sequences of
+// 10 kbp still fill the device.  The recurrence runs right to left, so a piece needs x at its
+// upper end: the lane looks for the nearest position at or above the piece's end whose value is
+// known without context - a hard reset (noisy == k gives x = k whatever follows,
+// derandomize.rs:235-238) or the sequence's last position (derandomize.rs:282) - and runs the
+// recurrence from there down to the piece, then through it with the same window pass as the
+// per-lane kernel.  Exact whenever such a position lies within kDtLookahead positions (inside
+// matches every position is a reset); otherwise the sequence is flagged and redone by one lane
+// in a second launch (adversarial inputs: long stretches without a single full-length match).
+constexpr uint32_t kDtPiece = 256, kDtLookahead = 2048;
+
+__global__ __launch_bounds__(256) void derand_translate_piece_kernel(
+    const uint8_t *__restrict__ ms, const uint64_t *__restrict__ off, uint32_t n_seqs, const WalkItem *__restrict__ pieces,
+    uint32_t n_pieces, uint32_t k, uint32_t t, const uint8_t *__restrict__ ref, uint8_t *__restrict__ out,
+    uint32_t max_len, uint32_t *__restrict__ redo)
+{
+    const uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= n_pieces) return;
+    const WalkItem it = pieces[pi];
+    if (it.len == 0) return; // unused slot
+    uint32_t lo = 0, hi = n_seqs; // the sequence that holds global position it.start
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (off[mid] <= it.start) lo = mid;
+        else hi = mid;
+    }
+    const uint32_t s = lo;
+    const uint64_t b = off[s];
+    const uint32_t len = (uint32_t)(off[s + 1] - b);
+    if (len < 3 || len > max_len) return; // rejected by the host side / taken by launch_derand_long
+    const uint32_t c0 = (uint32_t)(it.start - b), c1 = c0 + it.len; // this piece: positions [c0, c1)
+    const int K = (int)k, T = (int)t;
+    const uint8_t *msb = ms + b;
+    const bool fmt = ref != nullptr;
+    const uint8_t *refb = fmt ? ref + b : msb;
+    uint8_t *outb = out + b;
+
+    DtState st{0, 0, K};
+    if (c1 < len) { // x[c1 - 1] and x[c1] from the nearest context-free position at or above c1
+        const uint32_t last = len - 1u, stop = min(last, c1 + kDtLookahead);
+        uint32_t p = c1;
+        while (p < stop && msb[p] != (uint8_t)K) p++;
+        const int a = msb[p];
+        if (p != last && a != K) { // nothing context-free in reach
+            redo[s] = 1u;
+            return;
+        }
+        int x = p == last ? (a > T ? a : 0) : K, xn = x;
+        for (uint32_t q = p; q-- > c1 - 1u;) { // down to position c1 - 1
+            const int aq = msb[q];
+            xn = x;
+            x = (aq == K) ? K : ((aq > T && x < aq) ? aq : x - 1);
+        }
+        st.x_cur = x;
+        st.x_next = xn;
+    }
+    const uint32_t b_hi = (c1 + 15u) >> 4, b_lo = c0 >> 4; // c0 is a multiple of 16 (kDtPiece is)
+    uint4 cur = ld16u(msb, 16u * (b_hi - 1u));
+    uint4 rcur = fmt ? ld16u(refb, 16u * (b_hi - 1u)) : make_uint4(0, 0, 0, 0);
+    for (uint32_t bi = b_hi; bi-- > b_lo;) {
+        uint4 below = cur, rbelow = rcur;
+        if (bi > 0) {
+            below = ld16u(msb, 16u * (bi - 1u));
+            if (fmt && bi > b_lo) rbelow = ld16u(refb, 16u * (bi - 1u));
+        }
+        uint4 oblk = make_uint4(0, 0, 0, 0);
+        const uint32_t p0 = 16u * bi;
+        if (bi >= 1u && p0 + 17u <= len) KBO_DT_BLOCK_MID
+        else {
+            int32_t *const no_out = nullptr;
+            KBO_DT_BLOCK_GUARDED(no_out)
+        }
         if (p0 + 16u <= len) st16u(outb, p0, oblk);
         else st_partial(outb + p0, oblk, len - p0); // topmost, partial block of the sequence
         cur = below;
@@ -811,7 +923,7 @@ __global__ void translate_kernel(const int32_t *__restrict__ x, uint64_t len, ui
     const int xc = x[p];
     const int xm = p > 0 ? x[p - 1] : 0;
     const int xn = p + 1 < len ? x[p + 1] : xc;
-    out[p] = translate_char(xm, xc, xn, p, len, (int)k, (int)t);
+    out[p] = (uint8_t)translate_char(xm, xc, xn, (uint32_t)p, (uint32_t)len, (int)k, (int)t); // len < 2^32 (checked by the caller)
 }
 
 // ---- format::run_lengths_gapped (format.rs:143-193) on the device -------------------------
@@ -1005,10 +1117,17 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
     return hipGetLastError();
 }
 
+size_t derand_piece_work_bytes(uint32_t n_seqs, uint64_t total_bases)
+{
+    const uint64_t slots = total_bases / kDtPiece + n_seqs;
+    return (size_t)(slots * sizeof(WalkItem) + (chunk_items_scratch_words(n_seqs) + n_seqs) * sizeof(uint32_t) + 64);
+}
+
 hipError_t launch_derand_translate(const uint8_t *d_ms, const uint64_t *d_offsets, uint32_t n_seqs,
                                    uint32_t k, uint32_t threshold, const uint8_t *d_ref,
                                    uint8_t *d_chars_out, int32_t *d_derand_out, uint32_t max_seq_len,
-                                   uint32_t per_lane_max_len, hipStream_t stream)
+                                   uint32_t per_lane_max_len, hipStream_t stream, uint64_t total_bases,
+                                   void *d_work, size_t work_bytes)
 {
     if (n_seqs == 0) return hipSuccess;
     // short sequences: LDS-staged kernel (64 sequences per wave must fit the LDS budget)
@@ -1018,8 +1137,27 @@ hipError_t launch_derand_translate(const uint8_t *d_ms, const uint64_t *d_offset
                            d_ms, d_offsets, n_seqs, k, threshold, d_ref, d_chars_out, lds_bytes);
         return hipGetLastError();
     }
+    // long reads / contigs with scratch available: one lane per piece, then the flagged sequences again
+    const uint64_t slots = total_bases / kDtPiece + n_seqs;
+    if (d_work && d_derand_out == nullptr && total_bases > 0 && slots < (1ull << 31) &&
+        work_bytes >= derand_piece_work_bytes(n_seqs, total_bases)) {
+        WalkItem *pieces = static_cast<WalkItem *>(d_work);
+        uint32_t *scratch = reinterpret_cast<uint32_t *>(pieces + slots);
+        uint32_t *redo = scratch + chunk_items_scratch_words(n_seqs);
+        hipError_t e = hipMemsetAsync(redo, 0, (size_t)n_seqs * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        e = launch_make_chunk_items(d_offsets, n_seqs, kDtPiece, 1u, (uint32_t)slots, pieces, scratch, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(derand_translate_piece_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, d_ms,
+                           d_offsets, n_seqs, pieces, (uint32_t)slots, k, threshold, d_ref, d_chars_out, per_lane_max_len, redo);
+        hipLaunchKernelGGL(derand_translate_kernel, dim3((n_seqs + 255) / 256), dim3(256), 0, stream, d_ms, d_offsets,
+                           n_seqs, k, threshold, d_ref, d_chars_out, (int32_t *)nullptr, per_lane_max_len,
+                           (const uint32_t *)redo);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(derand_translate_kernel, dim3((n_seqs + 255) / 256), dim3(256), 0, stream, d_ms,
-                       d_offsets, n_seqs, k, threshold, d_ref, d_chars_out, d_derand_out, per_lane_max_len);
+                       d_offsets, n_seqs, k, threshold, d_ref, d_chars_out, d_derand_out, per_lane_max_len,
+                       (const uint32_t *)nullptr);
     return hipGetLastError();
 }
 

@@ -471,6 +471,49 @@ def test_find_batch_every_read_against_oracle(oracle):
         kbo_amd.lib().kbo_set_slab_bytes(32 << 20)
 
 
+def test_piecewise_derandomize_long_reads_and_contigs(oracle):
+    """Batches of long reads / contigs take the piece-wise A5/A6 kernel (one lane per 256 positions,
+    started from the nearest hard reset above the piece).  Cases: long reads with errors (resets
+    everywhere), sequences foreign to the index (no reset at all: every piece gives up and the
+    sequence is redone by one lane), half-and-half, resets exactly at piece boundaries, lengths
+    around multiples of the piece size; host path and device-resident path; with relative_to_ref."""
+    import torch
+    rng = np.random.default_rng(12)
+    g = synth.genome(400_000, seed=41)
+    foreign = synth.genome(60_000, seed=42)
+    sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=4))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    pieces = []
+    for n in [10_000] * 40 + [481, 511, 512, 513, 767, 768, 769, 4096, 4097, 65_536, 30_000]:
+        s0 = int(rng.integers(0, len(g) - n))
+        p = g[s0:s0 + n].copy()
+        hit = rng.random(n) < 0.01
+        p[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+        pieces.append(p)
+    pieces.append(foreign[:20_000].copy())                                  # no match anywhere
+    pieces.append(np.concatenate([g[1000:9000], foreign[:9000], g[50_000:58_000]]))
+    pieces.append(np.concatenate([foreign[:5000], g[200_000:200_256], foreign[5000:8000]]))
+    periodic = g[300_000:330_000].copy()
+    periodic[255::256] = ord("N")                                           # a break right at every piece end
+    pieces.append(periodic)
+    concat = np.concatenate(pieces)
+    offsets = np.concatenate([[0], np.cumsum([len(p) for p in pieces])]).astype(np.uint64)
+    exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
+    assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars)
+    assert batch.map_batch(sbwt, concat, offsets, format=True).tobytes() == oracle.relative_to_ref(concat, exp_chars)
+    for known_max, fmt in ((True, False), (False, False), (True, True)):
+        dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"), format=fmt)
+        if not known_max:
+            dev.max_len = 0
+            dev.work_bytes = int(kbo_amd.lib().kbo_work_bytes(dev.n_seqs, dev.total, 0, 31))
+            dev.work = torch.zeros(dev.work_bytes // 8 + 2, dtype=torch.int64, device="cuda:0")
+        dev.run()
+        torch.cuda.synchronize()
+        got = dev.chars.cpu().numpy()[:len(concat)]
+        want = np.frombuffer(oracle.relative_to_ref(concat, exp_chars), dtype=np.uint8) if fmt else exp_chars
+        assert np.array_equal(got, want), (known_max, fmt)
+
+
 def test_find_batch_with_contigs(oracle):
     """find over a batch that mixes reads with contigs long enough for the chunked walk and the
     chunked derandomize (> 64 kbp): run lengths equal the oracle's."""
