@@ -617,86 +617,6 @@ __global__ __launch_bounds__(256) void derand_translate_kernel(
     }
 }
 
-// ---- piece-wise variant for batches of long reads / contigs -----------------------------
-// One lane per piece of kDtPiece positions of a sequence, so that a few thousand sequences of
-// 10 kbp still fill the device.  The recurrence runs right to left, so a piece needs x at its
-// upper end: the lane looks for the nearest position at or above the piece's end whose value is
-// known without context - a hard reset (noisy == k gives x = k whatever follows,
-// derandomize.rs:235-238) or the sequence's last position (derandomize.rs:282) - and runs the
-// recurrence from there down to the piece, then through it with the same window pass as the
-// per-lane kernel.  Exact whenever such a position lies within kDtLookahead positions (inside
-// matches every position is a reset); otherwise the sequence is flagged and redone by one lane
-// in a second launch (adversarial inputs: long stretches without a single full-length match).
-constexpr uint32_t kDtPiece = 256, kDtLookahead = 2048;
-
-__global__ __launch_bounds__(256) void derand_translate_piece_kernel(
-    const uint8_t *__restrict__ ms, const uint64_t *__restrict__ off, uint32_t n_seqs, const WalkItem *__restrict__ pieces,
-    uint32_t n_pieces, uint32_t k, uint32_t t, const uint8_t *__restrict__ ref, uint8_t *__restrict__ out,
-    uint32_t max_len, uint32_t *__restrict__ redo)
-{
-    const uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pi >= n_pieces) return;
-    const WalkItem it = pieces[pi];
-    if (it.len == 0) return; // unused slot
-    uint32_t lo = 0, hi = n_seqs; // the sequence that holds global position it.start
-    while (hi - lo > 1) {
-        const uint32_t mid = lo + (hi - lo) / 2;
-        if (off[mid] <= it.start) lo = mid;
-        else hi = mid;
-    }
-    const uint32_t s = lo;
-    const uint64_t b = off[s];
-    const uint32_t len = (uint32_t)(off[s + 1] - b);
-    if (len < 3 || len > max_len) return; // rejected by the host side / taken by launch_derand_long
-    const uint32_t c0 = (uint32_t)(it.start - b), c1 = c0 + it.len; // this piece: positions [c0, c1)
-    const int K = (int)k, T = (int)t;
-    const uint8_t *msb = ms + b;
-    const bool fmt = ref != nullptr;
-    const uint8_t *refb = fmt ? ref + b : msb;
-    uint8_t *outb = out + b;
-
-    DtState st{0, 0, K};
-    if (c1 < len) { // x[c1 - 1] and x[c1] from the nearest context-free position at or above c1
-        const uint32_t last = len - 1u, stop = min(last, c1 + kDtLookahead);
-        uint32_t p = c1;
-        while (p < stop && msb[p] != (uint8_t)K) p++;
-        const int a = msb[p];
-        if (p != last && a != K) { // nothing context-free in reach
-            redo[s] = 1u;
-            return;
-        }
-        int x = p == last ? (a > T ? a : 0) : K, xn = x;
-        for (uint32_t q = p; q-- > c1 - 1u;) { // down to position c1 - 1
-            const int aq = msb[q];
-            xn = x;
-            x = (aq == K) ? K : ((aq > T && x < aq) ? aq : x - 1);
-        }
-        st.x_cur = x;
-        st.x_next = xn;
-    }
-    const uint32_t b_hi = (c1 + 15u) >> 4, b_lo = c0 >> 4; // c0 is a multiple of 16 (kDtPiece is)
-    uint4 cur = ld16u(msb, 16u * (b_hi - 1u));
-    uint4 rcur = fmt ? ld16u(refb, 16u * (b_hi - 1u)) : make_uint4(0, 0, 0, 0);
-    for (uint32_t bi = b_hi; bi-- > b_lo;) {
-        uint4 below = cur, rbelow = rcur;
-        if (bi > 0) {
-            below = ld16u(msb, 16u * (bi - 1u));
-            if (fmt && bi > b_lo) rbelow = ld16u(refb, 16u * (bi - 1u));
-        }
-        uint4 oblk = make_uint4(0, 0, 0, 0);
-        const uint32_t p0 = 16u * bi;
-        if (bi >= 1u && p0 + 17u <= len) KBO_DT_BLOCK_MID
-        else {
-            int32_t *const no_out = nullptr;
-            KBO_DT_BLOCK_GUARDED(no_out)
-        }
-        if (p0 + 16u <= len) st16u(outb, p0, oblk);
-        else st_partial(outb + p0, oblk, len - p0); // topmost, partial block of the sequence
-        cur = below;
-        rcur = rbelow;
-    }
-}
-
 // ---- LDS-staged variant for batches of short sequences (reads) -------------------------
 // One wave per workgroup handles 64 consecutive sequences, whose bytes are contiguous in the
 // concatenated buffers: the wave copies that span HBM -> LDS with coalesced 16-byte accesses,
@@ -796,6 +716,149 @@ __global__ __launch_bounds__(64) void derand_translate_lds_kernel(
         }
         if (o + 16u <= span) st16u(out + base, o, c);
         else st_partial(out + base + o, c, span - o);
+    }
+}
+
+// ---- piece-wise, LDS-staged variant for batches of long reads / contigs -----------------
+// One lane per piece of kDtPiece positions of a sequence, so that a few thousand sequences of
+// 10 kbp still fill the device.  The recurrence runs right to left, so a piece needs x at its
+// upper end: the lane looks for the nearest position at or above the piece's end whose value is
+// known without context - a hard reset (noisy == k gives x = k whatever follows,
+// derandomize.rs:235-238) or the sequence's last position (derandomize.rs:282) - and runs the
+// recurrence from there down to the piece.  Exact whenever such a position lies within
+// kDtLookahead positions (inside matches every position is a reset); otherwise the sequence is
+// flagged and redone by one lane in a second launch (adversarial inputs: long stretches without a
+// single full-length match).  One wave takes 64 consecutive pieces (a contiguous span of <= 16 KB
+// of the concatenated buffers) and stages it through LDS like the read kernel above: coalesced
+// 16-byte traffic (one 16-byte request per lane and block, measured first, is bound by the
+// L2-miss request rate at 8x the bytes).  Phase 1: every lane reads what it
+// needs from OUTSIDE its piece - the look-ahead up to the nearest hard reset and the value just
+// below the piece - and derives its start state; barrier; phase 2: it overwrites its piece in
+// place (MS value in, character out); barrier; the span is copied out, relative_to_ref applied
+// on the way.  Pieces that give up (no reset in reach) leave their MS bytes in place and flag the
+// sequence, which the per-lane kernel redoes afterwards.
+// 132 = 33 words: consecutive lanes' pieces start one LDS bank apart (a 256-byte stride puts all 64
+// lanes of a step on the same bank: measured 0.67 ms against 0.44 ms for 260 on 200 Mbp); 10 KB
+// of LDS per wave keeps 4 waves per SIMD resident
+constexpr uint32_t kDtPiece = 132, kDtLookahead = 1024;
+constexpr uint32_t kDtBehind = 16; // staged bytes below the span (the value just below the first piece)
+
+__global__ __launch_bounds__(64) void derand_translate_piece_lds_kernel(
+    const uint8_t *__restrict__ ms, const uint64_t *__restrict__ off, uint32_t n_seqs, uint64_t total,
+    const WalkItem *__restrict__ pieces, uint32_t n_pieces, uint32_t k, uint32_t t, const uint8_t *__restrict__ ref,
+    uint8_t *__restrict__ out, uint32_t max_len, uint32_t *__restrict__ redo)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ uint32_t span_len_sh;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t first = blockIdx.x * 64u;
+    WalkItem it;
+    it.start = 0;
+    it.len = 0;
+    it.warm = 0;
+    if (first + lane < n_pieces) it = pieces[first + lane];
+    const uint64_t span_base = pieces[first].start; // wave-uniform; slots behind the last piece are empty
+    if (lane == 0) span_len_sh = 0;
+    __syncthreads();
+    if (it.len) atomicMax(&span_len_sh, (uint32_t)(it.start + it.len - span_base));
+    __syncthreads();
+    const uint32_t span_len = span_len_sh;
+    if (span_len == 0) return;
+    const uint64_t stage_lo = span_base >= kDtBehind ? span_base - kDtBehind : 0;
+    const uint32_t head = (uint32_t)(span_base - stage_lo); // 0 or 16
+    const uint32_t stage_len = (uint32_t)(min(span_base + span_len + kDtLookahead, total) - stage_lo);
+    for (uint32_t o = lane * 16u; o < stage_len; o += 1024u) // stage in (reads <= 15 B past the batch: buffers are padded)
+        *reinterpret_cast<uint4 *>(lds + o) = ld16u(ms + stage_lo, o);
+    __syncthreads();
+
+    const int K = (int)k, T = (int)t;
+    uint32_t len = 0, c0 = 0, c1 = 0;
+    uint8_t *row = lds; // LDS address of position 0 of the lane's sequence (may lie below lds: only [c0-1, ..) is touched)
+    int x_cur = 0, x_next = 0, a_under = 0;
+    bool active = false;
+    // the sequence that holds the span's first byte (wave-uniform search), then, per lane, the one that
+    // holds its piece: at most 63 sequences further on
+    uint32_t s_first = 0;
+    {
+        uint32_t hi = n_seqs;
+        while (hi - s_first > 1) {
+            const uint32_t mid = s_first + (hi - s_first) / 2;
+            if (off[mid] <= span_base) s_first = mid;
+            else hi = mid;
+        }
+    }
+    if (it.len) {
+        uint32_t lo = s_first, hi = min(n_seqs, s_first + 64u);
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (off[mid] <= it.start) lo = mid;
+            else hi = mid;
+        }
+        const uint64_t b = off[lo];
+        len = (uint32_t)(off[lo + 1] - b);
+        c0 = (uint32_t)(it.start - b);
+        c1 = c0 + it.len;
+        row = lds + (int64_t)(b - stage_lo);
+        active = len >= 3 && len <= max_len;
+        if (active) {
+            a_under = c0 > 0 ? row[c0 - 1u] : 0;
+            if (c1 < len) { // x[c1 - 1], x[c1] from the nearest context-free position at or above c1
+                const uint32_t last = len - 1u, stop = min(last, c1 + kDtLookahead - 1u);
+                uint32_t p = c1;
+                while (p < stop && row[p] != (uint8_t)K) p++;
+                const int a = row[p];
+                if (p != last && a != K) { // nothing context-free in reach
+                    redo[lo] = 1u;
+                    active = false;
+                } else {
+                    int x = p == last ? (a > T ? a : 0) : K, xn = x;
+                    for (uint32_t q = p; q-- > c1 - 1u;) {
+                        const int aq = row[q];
+                        xn = x;
+                        x = (aq == K) ? K : ((aq > T && x < aq) ? aq : x - 1);
+                    }
+                    x_cur = x;
+                    x_next = xn;
+                }
+            } else { // the piece holds the sequence's last position (derandomize.rs:282)
+                const int a = row[len - 1u];
+                x_cur = a > T ? a : 0;
+                x_next = x_cur;
+            }
+        }
+    }
+    __syncthreads();
+    if (active) {
+        int a = c1 - 1u > c0 ? (int)row[c1 - 2u] : a_under; // noisy[p - 1] for p = c1 - 1, fetched one step ahead
+        for (uint32_t p = c1; p-- > c0;) { // (a variant without position tests for interior pieces was slower:
+            const int a_here = a;         //  its carried flags cost more mask bookkeeping than the tests)
+            a = p > c0 + 1u ? (int)row[p - 2u] : a_under; // for the next step (unused after the last one)
+            const int x_prev = p > 0 ? ((a_here == K) ? K : ((a_here > T && x_cur < a_here) ? a_here : x_cur - 1)) : K;
+            row[p] = (uint8_t)translate_char(x_prev, x_cur, x_next, p, len, K, T);
+            x_next = x_cur;
+            x_cur = x_prev;
+        }
+    }
+    __syncthreads();
+    if ((head & 15u) == 0) {
+        for (uint32_t o = lane * 16u; o < span_len; o += 1024u) { // stage out
+            uint4 c = *reinterpret_cast<const uint4 *>(lds + head + o);
+            if (ref) {
+                const uint4 rf = ld16u(ref + span_base, o);
+                c.x = fmt_word(c.x, rf.x);
+                c.y = fmt_word(c.y, rf.y);
+                c.z = fmt_word(c.z, rf.z);
+                c.w = fmt_word(c.w, rf.w);
+            }
+            if (o + 16u <= span_len) st16u(out + span_base, o, c);
+            else st_partial(out + span_base + o, c, span_len - o);
+        }
+    } else { // a span that starts within the first 16 bytes of the batch but not at byte 0: byte by byte
+        for (uint32_t o = lane; o < span_len; o += 64u) {
+            uint32_t ch = lds[head + o];
+            if (ref) ch = (ch == 'M' || ch == 'R') ? ref[span_base + o] : (uint32_t)'-';
+            out[span_base + o] = (uint8_t)ch;
+        }
     }
 }
 
@@ -1148,8 +1211,10 @@ hipError_t launch_derand_translate(const uint8_t *d_ms, const uint64_t *d_offset
         if (e != hipSuccess) return e;
         e = launch_make_chunk_items(d_offsets, n_seqs, kDtPiece, 1u, (uint32_t)slots, pieces, scratch, stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(derand_translate_piece_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, d_ms,
-                           d_offsets, n_seqs, pieces, (uint32_t)slots, k, threshold, d_ref, d_chars_out, per_lane_max_len, redo);
+        const uint32_t lds_bytes = kDtBehind + 64u * kDtPiece + kDtLookahead + 32u;
+        hipLaunchKernelGGL(derand_translate_piece_lds_kernel, dim3((unsigned)((slots + 63) / 64)), dim3(64), lds_bytes, stream,
+                           d_ms, d_offsets, n_seqs, total_bases, pieces, (uint32_t)slots, k, threshold, d_ref, d_chars_out,
+                           per_lane_max_len, redo);
         hipLaunchKernelGGL(derand_translate_kernel, dim3((n_seqs + 255) / 256), dim3(256), 0, stream, d_ms, d_offsets,
                            n_seqs, k, threshold, d_ref, d_chars_out, (int32_t *)nullptr, per_lane_max_len,
                            (const uint32_t *)redo);

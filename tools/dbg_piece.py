@@ -7,7 +7,7 @@ sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=16))
 concat, offsets = synth.reads(g, 20000, 10000, 0.01)
 dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"))
 dev.run(); torch.cuda.synchronize()
-n = dev.n_seqs; slots = dev.total // 256 + n
+n = dev.n_seqs; slots = dev.total // 132 + n
 w = dev.dt_work.cpu().numpy().view(np.uint32)
 words = n + 1 + (n + 1 + 1023) // 1024
 redo = w[slots * 4 + words: slots * 4 + words + n]
