@@ -634,6 +634,10 @@ __device__ __forceinline__ uint32_t fmt_word(uint32_t ch, uint32_t rf)
     return (rf & mask) | (0x2D2D2D2Du & ~mask);
 }
 
+// SKEW: the LDS image gets 4 bytes of padding after every 128 bytes.  Lanes touch position p of their own
+// sequence in the same step, so with sequences whose common length is a multiple of 32 bytes the flat image
+// puts 8..64 lanes on one bank (reads of 128 or 256 bases: 3.2x slower); the padding spreads them.
+template <bool SKEW>
 __global__ __launch_bounds__(64) void derand_translate_lds_kernel(
     const uint8_t *__restrict__ ms, const uint64_t *__restrict__ off, uint32_t n_seqs, uint32_t k,
     uint32_t t, const uint8_t *__restrict__ ref, uint8_t *__restrict__ out, uint32_t lds_bytes)
@@ -647,9 +651,17 @@ __global__ __launch_bounds__(64) void derand_translate_lds_kernel(
     const uint32_t span = (uint32_t)(off[s_end] - base);
     if (span > lds_bytes) return; // cannot happen: the host sizes lds_bytes from the longest sequence
     const int K = (int)k, T = (int)t;
+    auto at = [&](uint32_t x) -> uint8_t & { return lds[SKEW ? x + ((x >> 7) << 2) : x]; };
 
-    for (uint32_t o = lane * 16u; o < span; o += 1024u) // stage in (reads <= 15 B past the span)
-        *reinterpret_cast<uint4 *>(lds + o) = ld16u(ms + base, o);
+    for (uint32_t o = lane * 16u; o < span; o += 1024u) { // stage in (reads <= 15 B past the span)
+        const uint4 v = ld16u(ms + base, o);
+        if (SKEW) { // a 16-byte chunk never straddles a 128-byte granule, but it is only 4-byte aligned
+            uint32_t *d = reinterpret_cast<uint32_t *>(&at(o));
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        } else {
+            *reinterpret_cast<uint4 *>(lds + o) = v;
+        }
+    }
     __syncthreads();
 
     if (s < n_seqs) {
@@ -661,32 +673,31 @@ __global__ __launch_bounds__(64) void derand_translate_lds_kernel(
             // the two ends (p = len-1, where next = x[p]; p = 1 and 0, where prev = K and no 'R' is
             // inherited from below) are peeled so that the middle of the sequence carries no
             // position tests.  gt_* / in_* flags move down the window with the values.
-            uint8_t *row = lds + b;
             const uint32_t Tm1 = (uint32_t)(T - 1);
             auto step = [&](int a, int x_cur) { return (a == K) ? K : ((a > T && x_cur < a) ? a : x_cur - 1); };
             auto plain = [&](int x_cur, int next, int prev) -> uint32_t { // translate.rs:180-216 without the 'R' cases
                 return x_cur <= 0 ? ((next == 1 && prev > 0) ? (uint32_t)'X' : (uint32_t)'-') : (uint32_t)'M';
             };
-            int a = row[len - 1];
+            int a = at(b + len - 1);
             int x_cur = a > T ? a : 0; // derandomize.rs:282
-            int a_below = row[len - 2];
+            int a_below = at(b + len - 2);
             int x_prev = step(a_below, x_cur);
             // p = len-1: next = x_cur itself; inherits 'R' from below (len-1 >= 2 always holds, but
             // the rule needs pos < len-1, so it does not apply here)
             bool in_cur = (uint32_t)(x_cur - 1) < Tm1, gt_cur = x_cur > T;
-            row[len - 1] = (uint8_t)((gt_cur && in_cur) ? (uint32_t)'R' : plain(x_cur, x_cur, x_prev));
+            at(b + len - 1) = (uint8_t)((gt_cur && in_cur) ? (uint32_t)'R' : plain(x_cur, x_cur, x_prev));
             int x_next = x_cur;
             bool in_next = in_cur;
             x_cur = x_prev;
             gt_cur = x_cur > T;
             in_cur = (uint32_t)(x_cur - 1) < Tm1;
-            a_below = row[len - 3];
+            a_below = at(b + len - 3);
             for (uint32_t p = len - 2; p >= 2; p--) { // middle: 2 <= p <= len-2
                 x_prev = step(a_below, x_cur);
-                a_below = row[p - 2]; // p >= 2
+                a_below = at(b + p - 2); // p >= 2
                 const bool gt_prev = x_prev > T;
                 const bool is_r = (gt_prev && in_cur) || (gt_cur && in_next);
-                row[p] = (uint8_t)(is_r ? (uint32_t)'R' : plain(x_cur, x_next, x_prev));
+                at(b + p) = (uint8_t)(is_r ? (uint32_t)'R' : plain(x_cur, x_next, x_prev));
                 x_next = x_cur;
                 in_next = in_cur;
                 x_cur = x_prev;
@@ -694,19 +705,25 @@ __global__ __launch_bounds__(64) void derand_translate_lds_kernel(
                 in_cur = (uint32_t)(x_cur - 1) < Tm1;
             }
             // p = 1: prev = K (translate.rs:277 tests pos > 1), no 'R' inherited (needs pos >= 2)
-            x_prev = step(a_below, x_cur); // a_below == row[0]
-            row[1] = (uint8_t)((gt_cur && in_next) ? (uint32_t)'R' : plain(x_cur, x_next, K));
+            x_prev = step(a_below, x_cur); // a_below == at(b + 0)
+            at(b + 1) = (uint8_t)((gt_cur && in_next) ? (uint32_t)'R' : plain(x_cur, x_next, K));
             // p = 0
             x_next = x_cur;
             in_next = in_cur;
             x_cur = x_prev;
-            row[0] = (uint8_t)((x_cur > T && in_next) ? (uint32_t)'R' : plain(x_cur, x_next, K));
+            at(b + 0) = (uint8_t)((x_cur > T && in_next) ? (uint32_t)'R' : plain(x_cur, x_next, K));
         }
     }
     __syncthreads();
 
     for (uint32_t o = lane * 16u; o < span; o += 1024u) { // stage out
-        uint4 c = *reinterpret_cast<const uint4 *>(lds + o);
+        uint4 c;
+        if (SKEW) {
+            const uint32_t *d = reinterpret_cast<const uint32_t *>(&at(o));
+            c = make_uint4(d[0], d[1], d[2], d[3]);
+        } else {
+            c = *reinterpret_cast<const uint4 *>(lds + o);
+        }
         if (ref) {
             const uint4 rf = ld16u(ref + base, o);
             c.x = fmt_word(c.x, rf.x);
@@ -1196,8 +1213,13 @@ hipError_t launch_derand_translate(const uint8_t *d_ms, const uint64_t *d_offset
     // short sequences: LDS-staged kernel (64 sequences per wave must fit the LDS budget)
     if (max_seq_len > 0 && max_seq_len <= 480 && d_derand_out == nullptr) {
         const uint32_t lds_bytes = ((64u * max_seq_len + 15u) / 16u) * 16u + 16u;
-        hipLaunchKernelGGL(derand_translate_lds_kernel, dim3((n_seqs + 63) / 64), dim3(64), lds_bytes, stream,
-                           d_ms, d_offsets, n_seqs, k, threshold, d_ref, d_chars_out, lds_bytes);
+        if (max_seq_len % 32u == 0) // e.g. reads of 128 or 256 bases: padded LDS image (see the kernel)
+            hipLaunchKernelGGL((derand_translate_lds_kernel<true>), dim3((n_seqs + 63) / 64), dim3(64),
+                               lds_bytes + lds_bytes / 32u + 16u, stream, d_ms, d_offsets, n_seqs, k, threshold, d_ref,
+                               d_chars_out, lds_bytes);
+        else
+            hipLaunchKernelGGL((derand_translate_lds_kernel<false>), dim3((n_seqs + 63) / 64), dim3(64), lds_bytes, stream,
+                               d_ms, d_offsets, n_seqs, k, threshold, d_ref, d_chars_out, lds_bytes);
         return hipGetLastError();
     }
     // long reads / contigs with scratch available: one lane per piece, then the flagged sequences again

@@ -471,6 +471,25 @@ def test_find_batch_every_read_against_oracle(oracle):
         kbo_amd.lib().kbo_set_slab_bytes(32 << 20)
 
 
+@pytest.mark.parametrize("read_len", [32, 64, 96, 128, 256, 480])
+def test_reads_whose_length_is_a_multiple_of_32(oracle, read_len):
+    """Batches whose longest read is a multiple of 32 bases use the padded LDS image in A5/A6
+    (bank-conflict avoidance); uniform and ragged batches, with and without relative_to_ref."""
+    rng = np.random.default_rng(read_len)
+    g = synth.genome(150_000, seed=43)
+    sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=4))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    concat, offsets = synth.reads(g, 5000, read_len, 0.02, seed=300 + read_len)
+    exp = ora.matches_batch(concat, offsets, 1e-7, n_threads=4)
+    assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp)
+    assert batch.map_batch(sbwt, concat, offsets, format=True).tobytes() == oracle.relative_to_ref(concat, exp)
+    lens = np.concatenate([rng.integers(3, read_len + 1, 3000), [read_len]])   # ragged, longest = read_len
+    pieces = [g[s0:s0 + n] for s0, n in zip(rng.integers(0, 100_000, len(lens)), lens)]
+    concat = np.concatenate(pieces)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), ora.matches_batch(concat, offsets, 1e-7, n_threads=4))
+
+
 def test_piecewise_derandomize_long_reads_and_contigs(oracle):
     """Batches of long reads / contigs take the piece-wise A5/A6 kernel (one lane per 256 positions,
     started from the nearest hard reset above the piece).  Cases: long reads with errors (resets
