@@ -250,10 +250,11 @@ int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, siz
  * without d_ref), enqueued on `stream`.  d_work: kbo_run_lengths_work_bytes(n_seqs) bytes; afterwards
  * word s of d_work plus word (n_seqs + 1 + s / 1024) is the index of sequence s's first run, and the
  * last word of d_work the total number of runs.  Records are seven u32 {start, end, matches,
- * mismatches, jumps, gap_bases, gap_opens}; runs beyond `capacity` are counted but not written. */
+ * mismatches, jumps, gap_bases, gap_opens}; runs beyond `capacity` are counted but not written.
+ * max_seq_len = length of the longest sequence if known (reads take LDS-staged kernels), 0 = unknown. */
 size_t kbo_run_lengths_work_bytes(size_t n_seqs);
-int kbo_run_lengths_dev(const uint8_t *d_chars, const uint64_t *d_offsets, size_t n_seqs, size_t max_gap_len,
-                        void *d_work, uint32_t *d_records, size_t capacity, void *stream);
+int kbo_run_lengths_dev(const uint8_t *d_chars, const uint64_t *d_offsets, size_t n_seqs, size_t max_seq_len,
+                        size_t max_gap_len, void *d_work, uint32_t *d_records, size_t capacity, void *stream);
 /* Walk launch geometry: upper bound on resident waves, and threads per workgroup. */
 int kbo_walk_geometry(int *max_waves, int *threads);
 int kbo_set_walk_waves_per_cu(int waves_per_cu); /* tuning knob, 0 = default (32) */

@@ -156,7 +156,7 @@ def lib():
     L.kbo_set_pair_steps.argtypes = [C.c_uint64, C.c_int]
     L.kbo_run_lengths_gapped_batch.argtypes = [vp, vp, sz, sz, vp, vp]
     L.kbo_run_lengths_work_bytes.argtypes = [sz]; L.kbo_run_lengths_work_bytes.restype = sz
-    L.kbo_run_lengths_dev.argtypes = [vp, vp, sz, sz, vp, vp, sz, vp]
+    L.kbo_run_lengths_dev.argtypes = [vp, vp, sz, sz, sz, vp, vp, sz, vp]
     L.kbo_index_device_pair_bytes.argtypes = [vp]
     L.kbo_index_device_pair_bytes.restype = C.c_uint64
     L.kbo_set_devices.argtypes = [C.POINTER(C.c_int), C.c_int]

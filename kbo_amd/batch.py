@@ -127,7 +127,7 @@ class DeviceBatch:
             self.rle_work = torch.zeros(wb // 4 + 1, dtype=torch.int32, device=self.device)
             self.rle_capacity = runs_per_seq * self.n_seqs + 16
             self.rle_records = torch.zeros((self.rle_capacity, 7), dtype=torch.int32, device=self.device)
-        check(lib().kbo_run_lengths_dev(self.chars.data_ptr(), self.off.data_ptr(), self.n_seqs, max_gap_len,
+        check(lib().kbo_run_lengths_dev(self.chars.data_ptr(), self.off.data_ptr(), self.n_seqs, self.max_len, max_gap_len,
                                         self.rle_work.data_ptr(), self.rle_records.data_ptr(), self.rle_capacity,
                                         s.cuda_stream))
 

@@ -405,6 +405,7 @@ struct HostSlot {
     DevBuf rle_scratch, rles, rle_total, dt_work;
     PinBuf rle_total_pin, rle_first_pin;
     size_t rle_capacity = 0, slab_id = 0, n_seqs = 0;
+    uint32_t longest = 0;
 };
 struct HostCtx {
     int dev = 0;
@@ -611,7 +612,7 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
                         HIP_OK(kbo::launch_rle_emit(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)S.n_seqs,
                                                     (uint32_t)std::min<size_t>(sink->max_gap_len, 0xFFFFFFFFu),
                                                     S.rle_scratch.as<uint32_t>(), S.rles.as<uint32_t>(),
-                                                    (uint32_t)S.rle_capacity, C.st_down));
+                                                    (uint32_t)S.rle_capacity, C.st_down, S.longest));
                     }
                     const size_t words = kbo::chunk_items_scratch_words((uint32_t)S.n_seqs);
                     S.out.ensure(std::max<size_t>(16, (size_t)total * kRleWords * sizeof(uint32_t)));
@@ -753,11 +754,12 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
                         S.rles.ensure(S.rle_capacity * kRleWords * sizeof(uint32_t));
                     }
                     HIP_OK(kbo::launch_rle_count(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
-                                                 S.rle_scratch.as<uint32_t>(), S.rle_total.as<uint32_t>(), C.st_run));
+                                                 S.rle_scratch.as<uint32_t>(), S.rle_total.as<uint32_t>(), C.st_run, mx));
                     HIP_OK(hipMemcpyAsync(S.rle_total_pin.p, S.rle_total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, C.st_run));
                     HIP_OK(kbo::launch_rle_emit(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
                                                 S.rle_scratch.as<uint32_t>(), S.rles.as<uint32_t>(), (uint32_t)S.rle_capacity,
-                                                C.st_run));
+                                                C.st_run, mx));
+                    S.longest = mx;
                     HIP_OK(hipEventRecord(S.computed, C.st_run));
                     HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
                     S.slab_id = i;
@@ -1413,13 +1415,14 @@ int kbo_run_lengths_gapped_batch(const uint8_t *aln_concat, const uint64_t *offs
         if (total) HIP_OK(hipMemcpyAsync(chars.p, aln_concat, total, hipMemcpyHostToDevice, st));
         HIP_OK(hipMemcpyAsync(off.p, offsets, (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         const uint32_t gap = (uint32_t)std::min<size_t>(max_gap_len, 0xFFFFFFFFu);
+        const uint32_t longest = (uint32_t)scan.longest;
         HIP_OK(kbo::launch_rle_count(chars.as<uint8_t>(), off.as<uint64_t>(), (uint32_t)n_seqs, gap, scratch.as<uint32_t>(),
-                                     count.as<uint32_t>(), st));
+                                     count.as<uint32_t>(), st, longest));
         uint32_t n_runs = 0;
         HIP_OK(hipMemcpy(&n_runs, count.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
         DevBuf d_runs(std::max<size_t>(16, (size_t)n_runs * kRleWords * sizeof(uint32_t)));
         HIP_OK(kbo::launch_rle_emit(chars.as<uint8_t>(), off.as<uint64_t>(), (uint32_t)n_seqs, gap, scratch.as<uint32_t>(),
-                                    d_runs.as<uint32_t>(), n_runs, st));
+                                    d_runs.as<uint32_t>(), n_runs, st, longest));
         std::vector<uint32_t> compact((size_t)n_runs * kRleWords + 1), words(kbo::chunk_items_scratch_words((uint32_t)n_seqs));
         if (n_runs) HIP_OK(hipMemcpy(compact.data(), d_runs.p, (size_t)n_runs * kRleWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(words.data(), scratch.p, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1591,8 +1594,8 @@ size_t kbo_run_lengths_work_bytes(size_t n_seqs)
     return kbo::chunk_items_scratch_words((uint32_t)std::min<size_t>(n_seqs, 0xFFFFFFFEu)) * sizeof(uint32_t) + 16;
 }
 
-int kbo_run_lengths_dev(const uint8_t *d_chars, const uint64_t *d_offsets, size_t n_seqs, size_t max_gap_len,
-                        void *d_work, uint32_t *d_records, size_t capacity, void *stream)
+int kbo_run_lengths_dev(const uint8_t *d_chars, const uint64_t *d_offsets, size_t n_seqs, size_t max_seq_len,
+                        size_t max_gap_len, void *d_work, uint32_t *d_records, size_t capacity, void *stream)
 {
     return guarded([&] {
         KBO_REQUIRE(d_chars && d_offsets && d_work && (d_records || capacity == 0), KBO_E_BAD_ARG, "null argument");
@@ -1602,10 +1605,11 @@ int kbo_run_lengths_dev(const uint8_t *d_chars, const uint64_t *d_offsets, size_
         const uint32_t gap = (uint32_t)std::min<size_t>(max_gap_len, 0xFFFFFFFFu);
         uint32_t *scratch = static_cast<uint32_t *>(d_work);
         uint32_t *total = scratch + kbo::chunk_items_scratch_words((uint32_t)n_seqs); // last word of the work buffer
-        HIP_OK(kbo::launch_rle_count(d_chars, d_offsets, (uint32_t)n_seqs, gap, scratch, total, s));
+        const uint32_t longest = (uint32_t)std::min<size_t>(max_seq_len, 0xFFFFFFFFu);
+        HIP_OK(kbo::launch_rle_count(d_chars, d_offsets, (uint32_t)n_seqs, gap, scratch, total, s, longest));
         if (capacity)
             HIP_OK(kbo::launch_rle_emit(d_chars, d_offsets, (uint32_t)n_seqs, gap, scratch, d_records,
-                                        (uint32_t)std::min<size_t>(capacity, 0xFFFFFFFFu), s));
+                                        (uint32_t)std::min<size_t>(capacity, 0xFFFFFFFFu), s, longest));
     });
 }
 

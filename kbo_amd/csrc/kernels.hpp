@@ -53,9 +53,10 @@ hipError_t launch_make_chunk_items(const uint64_t *d_offsets, uint32_t n_seqs, u
 // {start, end, matches, mismatches, jumps, gap_bases, gap_opens}; after launch_rle_count the first-run index of
 // sequence s is d_scratch[n_seqs + 1 + s / 1024] + d_scratch[s] and *d_total the number of runs
 hipError_t launch_rle_count(const uint8_t *d_chars, const uint64_t *d_offsets, uint32_t n_seqs, uint32_t max_gap_len,
-                            uint32_t *d_scratch, uint32_t *d_total, hipStream_t stream);
+                            uint32_t *d_scratch, uint32_t *d_total, hipStream_t stream, uint32_t max_seq_len = 0);
 hipError_t launch_rle_emit(const uint8_t *d_chars, const uint64_t *d_offsets, uint32_t n_seqs, uint32_t max_gap_len,
-                           uint32_t *d_scratch, uint32_t *d_rles, uint32_t capacity, hipStream_t stream);
+                           uint32_t *d_scratch, uint32_t *d_rles, uint32_t capacity, hipStream_t stream,
+                           uint32_t max_seq_len = 0 /* longest sequence if known: reads take the LDS-staged kernels */);
 // A1: k-bounded matching statistics over all items
 hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream);
 // A5+A6 (+ optional relative_to_ref when ref != nullptr, + optional i32 derandomised

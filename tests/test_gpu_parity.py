@@ -443,6 +443,17 @@ def test_run_lengths_on_the_device_full_alphabet(oracle):
             exp = oracle.run_lengths_gapped(alns[s], gap)
             got = [tuple(int(v) for v in r) for r in runs[ro[s]:ro[s + 1]]]
             assert got == exp, (gap, s, alns[s][:80])
+    # batches of read-sized alignments with max_gap_len 0 take the mask-based LDS kernels (padded LDS image
+    # when the longest alignment is a multiple of 32)
+    for longest in (150, 480, 256, 31):
+        short = [a[:longest] for a in alns if len(a) > 0] + [bytes(rng.choice(np.frombuffer(b"MR-X ID", dtype=np.uint8), longest))]
+        concat2 = np.frombuffer(b"".join(short), dtype=np.uint8)
+        offsets2 = np.concatenate([[0], np.cumsum([len(a) for a in short])]).astype(np.uint64)
+        runs, ro = kformat.run_lengths_gapped_batch(concat2, offsets2, 0)
+        assert ro[-1] == len(runs)
+        for s in range(len(short)):
+            got = [tuple(int(v) for v in r) for r in runs[ro[s]:ro[s + 1]]]
+            assert got == oracle.run_lengths_gapped(short[s], 0), (longest, s, short[s][:80])
     # the single-sequence host implementation agrees too
     for s in range(0, len(alns), 97):
         assert [tuple(r.__dict__.values()) for r in kformat.run_lengths_gapped(alns[s], 3)] == oracle.run_lengths_gapped(alns[s], 3)
