@@ -1,0 +1,116 @@
+// capi_internal.hpp — declarations shared by the translation units behind include/kbo_hip.h:
+//   device_index.cpp  the index handle and its per-device copies,
+//   host_batch.cpp    host batches: slabs, staging, the three-stage pipeline, run-length sink,
+//   kbo_capi.cpp      the extern "C" entry points.
+#pragma once
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "host_util.hpp"
+#include "kernels.hpp"
+#include "refine.hpp"
+#include "sbwt_index.hpp"
+
+namespace kbo_host {
+
+struct DevCopy {
+    DevBuf arena; // rank blocks of A,C,G,T | null block | contraction entries (32-bit build) | two-base blocks
+    DevBuf ent;   // contraction entries as their own allocation (big build)
+    uint64_t n_blocks = 0;
+    bool big = false;
+    uint32_t pair_off = 0; // arena index of the two-base extension blocks, 0 = none
+};
+
+} // namespace kbo_host
+
+struct kbo_index {
+    kbo::HostIndex host;
+    std::mutex mu;
+    std::map<int, kbo_host::DevCopy *> dev;
+    uint64_t rank_bytes = 0, lcs_bytes = 0;
+    ~kbo_index()
+    {
+        for (auto &kv : dev) delete kv.second;
+    }
+};
+
+namespace kbo_host {
+
+// ---- tuning state (set through the kbo_set_* entry points)
+extern int g_waves_per_cu;           // walk: resident waves per CU, 0 = default (32)
+extern std::vector<int> g_devices;   // devices the host batch entry points spread slabs over (empty = current)
+extern bool g_force_big;             // tests: use the 64-bit-offset entry layout regardless of size
+extern uint64_t g_pair_min_rows;     // indexes with at least this many rows get two-base blocks on the device
+extern size_t g_slab_bytes;          // host batches are cut into slabs of at most this many query bytes
+
+// ---- device_index.cpp
+int current_device();
+kbo::DevIndexView device_view(kbo_index *idx, int device); // uploads the index on first use
+int walk_max_waves();                                     // upper bound on resident walk waves: CUs x waves per CU
+
+// ---- A3 (kbo_capi.cpp): derandomize.rs:91-145
+double log_rm_max_cdf(size_t t, size_t alphabet_size, size_t n_kmers);
+size_t random_match_threshold(size_t k, size_t n_kmers, size_t alphabet_size, double p);
+
+// ---- host_batch.cpp
+struct BatchOnDevice {
+    DevBuf q, off, items, ms, lo, hi;
+    uint64_t total = 0;
+    void release()
+    {
+        for (DevBuf *b : {&q, &off, &items, &ms, &lo, &hi}) b->release();
+    }
+};
+struct Slab {
+    size_t s0, s1;   // sequences [s0, s1)
+    uint64_t b0, b1; // bases [b0, b1)
+};
+struct OffsetScan { // one pass over the offsets of a batch: order, shortest and longest sequence
+    bool monotone = true;
+    uint64_t shortest = ~0ull, longest = 0;
+};
+// Where kbo_find_batch collects format::run_lengths_gapped of every slab (computed on the device
+// from the slab's characters, which then never leave it)
+struct RleSink {
+    size_t max_gap_len = 0;
+    uint64_t *rle_offsets = nullptr; // caller's n_seqs + 1 entries
+    // one device: slabs complete in order, so their records go straight into the result array
+    kbo_rle *all = nullptr;
+    size_t all_cap = 0, all_used = 0;
+    // several devices: slabs complete out of order, kept per slab and put together at the end
+    std::vector<std::vector<kbo_rle>> runs;
+    std::vector<std::vector<uint32_t>> first; // index of the first run of each sequence of the slab, +1 entry
+    ~RleSink() { std::free(all); }
+};
+constexpr size_t kRleWords = 7; // device run-length records are seven u32; kbo_rle has the reference's usize fields
+
+uint32_t max_len(const uint64_t *offsets, size_t n_seqs);
+uint64_t walk_chunk(uint64_t total, size_t n_seqs, uint32_t k);
+void check_batch(const void *concat, const uint64_t *offsets, size_t n_seqs);
+void check_len_threshold(const uint64_t *offsets, size_t n_seqs, size_t k, size_t threshold);
+OffsetScan scan_offsets(const uint64_t *offsets, size_t n_seqs);
+std::vector<Slab> make_slabs(const uint64_t *offsets, size_t n_seqs, size_t max_bytes);
+// upload + A1 over a host batch (asynchronous on `stream`); leaves ms (and lo/hi) on the device.
+// `items_keep` must stay alive until the stream has been synchronised.
+void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, bool want_ival,
+                       BatchOnDevice &B, std::vector<kbo::WalkItem> &items_keep, hipStream_t stream,
+                       uint32_t longest = 0 /* longest sequence if the caller knows it */,
+                       hipStream_t copy_stream = nullptr /* uploads go here when given ... */,
+                       hipEvent_t copied = nullptr /* ... and `stream` waits for this event */);
+void run_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, bool want_ival,
+                   BatchOnDevice &B, hipStream_t stream);
+// A5+A6 over a batch whose offsets are known on the host
+void derand_translate_host_offsets(const uint8_t *d_ms, const uint64_t *d_off, const uint64_t *offsets, size_t n_seqs,
+                                   uint32_t k, uint32_t threshold, const uint8_t *d_ref, uint8_t *d_chars,
+                                   int32_t *d_derand, hipStream_t stream, uint32_t longest = 0,
+                                   DevBuf *piece_work = nullptr /* lets long reads / contigs be split into pieces */);
+void widen_rles(kbo_rle *dst, const uint32_t *src, size_t n, HostTeam &team);
+// kbo::matches over a batch (lib.rs:618-627); optional relative_to_ref (lib.rs:756-757); with a sink the
+// characters are turned into run lengths on the device instead of being downloaded (lib.rs:816-820)
+void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                        double max_error_prob, bool format, uint8_t *chars_out, RleSink *sink = nullptr);
+void release_host_scratch(); // frees the pooled per-device scratch of the host batch entry points
+
+} // namespace kbo_host

@@ -24,128 +24,11 @@
 #include <thread>
 #include <vector>
 
-#include "host_util.hpp"
-#include "kernels.hpp"
-#include "refine.hpp"
-#include "sbwt_index.hpp"
-
-namespace {
+#include "capi_internal.hpp"
 
 using namespace kbo_host;
 
-struct DevCopy {
-    DevBuf arena; // rank blocks of A,C,G,T | null block | contraction entries (32-bit build)
-    DevBuf ent;   // contraction entries as their own allocation (big build)
-    uint64_t n_blocks = 0;
-    bool big = false;
-    uint32_t pair_off = 0; // arena index of the two-base extension blocks, 0 = none
-};
-
-int g_waves_per_cu = 0;
-std::vector<int> g_devices; // devices the host batch entry points spread slabs over (empty = current)
-bool g_force_big = false;
-uint64_t g_pair_min_rows = 24ull << 20; // indexes with at least this many rows get two-base blocks on the device // tests: use the 64-bit-offset entry layout regardless of size
-
-int current_device()
-{
-    int dev = -1;
-    HIP_OK(hipGetDevice(&dev));
-    return dev;
-}
-
-} // namespace
-
-struct kbo_index {
-    kbo::HostIndex host;
-    std::mutex mu;
-    std::map<int, DevCopy *> dev;
-    uint64_t rank_bytes = 0, lcs_bytes = 0;
-    ~kbo_index()
-    {
-        for (auto &kv : dev) delete kv.second;
-    }
-};
-
-namespace {
-
-kbo::DevIndexView device_view(kbo_index *idx, int device)
-{
-    std::lock_guard<std::mutex> g(idx->mu);
-    auto it = idx->dev.find(device);
-    if (it == idx->dev.end()) {
-        KBO_REQUIRE(idx->host.n_sets < 0xFFFFFFF0ull, KBO_E_UNSUPPORTED,
-                    "n_sets >= 2^32: 64-bit device layout not built yet");
-        // two-base extension blocks: worth their 2.7 B/row once the one-base blocks stop fitting L2
-        // (the walk is then bound by line fills, and a two-base step needs one instead of two)
-        const size_t est_rank = (idx->host.n_sets / 96 + 2) * 64, est_ent = (idx->host.n_sets + 2) * 12;
-        const bool want_pairs = idx->host.n_sets >= g_pair_min_rows && !g_force_big &&
-                                est_rank * 5 + est_ent + 64 < 0xFFFFFFF0ull;
-        kbo::DeviceLayout lay;
-        kbo::make_device_layout(idx->host, lay, want_pairs);
-        int prev = current_device();
-        if (prev != device) HIP_OK(hipSetDevice(device));
-        DevCopy *dc = new DevCopy();
-        try {
-            const size_t per = lay.n_blocks * 16;
-            // arena = rank blocks of A,C,G,T | one all-zero "null" block | contraction entries.
-            // When that exceeds the 32-bit offset range (n_sets * 12 B of entries >= ~4 GiB) the
-            // entries get their own allocation and 64-bit offsets ("big" kernels).
-            const size_t ent_bytes = lay.ent.size() * sizeof(uint32_t);
-            const size_t rank_bytes = per * 4 + 16;
-            KBO_REQUIRE(rank_bytes < 0xFFFFFFF0ull, KBO_E_UNSUPPORTED, "rank blocks >= 4 GiB");
-            dc->big = g_force_big || rank_bytes + ent_bytes >= 0xFFFFFFF0ull;
-            const size_t pair_bytes = dc->big ? 0 : lay.pair.size() * sizeof(uint32_t);
-            const size_t base_bytes = ((dc->big ? rank_bytes : rank_bytes + ent_bytes) + 15) / 16 * 16;
-            const size_t arena_bytes = base_bytes + pair_bytes;
-            dc->arena.alloc(arena_bytes);
-            HIP_OK(hipMemset(dc->arena.p, 0, arena_bytes));
-            for (int c = 0; c < 4; c++)
-                HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + per * c, lay.rank[c].data(), per,
-                                 hipMemcpyHostToDevice));
-            if (dc->big) {
-                dc->ent.alloc(ent_bytes + 16);
-                HIP_OK(hipMemcpy(dc->ent.p, lay.ent.data(), ent_bytes, hipMemcpyHostToDevice));
-            } else {
-                HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + rank_bytes, lay.ent.data(), ent_bytes,
-                                 hipMemcpyHostToDevice));
-            }
-            if (pair_bytes) {
-                HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + base_bytes, lay.pair.data(), pair_bytes, hipMemcpyHostToDevice));
-                dc->pair_off = (uint32_t)(base_bytes / 16);
-            }
-            dc->n_blocks = lay.n_blocks;
-            idx->rank_bytes = per * 4;
-            idx->lcs_bytes = ent_bytes;
-        } catch (...) {
-            delete dc;
-            if (prev != device) (void)hipSetDevice(prev);
-            throw;
-        }
-        if (prev != device) HIP_OK(hipSetDevice(prev));
-        it = idx->dev.emplace(device, dc).first;
-    }
-    DevCopy *dc = it->second;
-    kbo::DevIndexView v;
-    v.arena = dc->arena.as<uint4>();
-    v.n_blocks = (uint32_t)dc->n_blocks;
-    v.lcs_off = (uint32_t)(dc->n_blocks * 4 + 1);
-    v.pair_off = dc->pair_off;
-    v.ent = dc->big ? dc->ent.as<uint8_t>() : nullptr;
-    v.big = dc->big ? 1u : 0u;
-    v.n = (uint32_t)idx->host.n_sets;
-    v.k = idx->host.k;
-    return v;
-}
-
-// upper bound on resident walk waves: CUs x waves per CU (default 32 = 8 per SIMD)
-int walk_max_waves()
-{
-    int dev = current_device();
-    int cus = 0;
-    HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    int per = g_waves_per_cu > 0 ? g_waves_per_cu : 32;
-    return std::max(1, cus) * per;
-}
+namespace kbo_host {
 
 // ---- A3: derandomize.rs:91-145, f64, identical operation order -------------------------
 double powi_f64(double a, int b) // Rust f64::powi == llvm.powi == compiler-rt __powidf2
@@ -180,652 +63,9 @@ size_t random_match_threshold(size_t k, size_t n_kmers, size_t alphabet_size, do
     return k;
 }
 
-// ---- work decomposition ------------------------------------------------------------------
-// Reads become one item each.  Longer sequences are cut into chunks that restart the walk
-// k-1 bases upstream from the empty state (MS depends only on the last k bases).
-uint32_t max_len(const uint64_t *offsets, size_t n_seqs)
-{
-    uint64_t m = 0;
-    for (size_t s = 0; s < n_seqs; s++) m = std::max(m, offsets[s + 1] - offsets[s]);
-    return (uint32_t)std::min<uint64_t>(m, 0xFFFFFFFFu);
-}
+} // namespace kbo_host
 
-// emitted bases per chunk: aim for >= ~1M items when the input allows it, 256..4096 bases
-// (every chunk after the first re-walks k-1 warm-up bases); a batch that already has enough
-// sequences to fill the device is only cut where a sequence is very long
-uint64_t walk_chunk(uint64_t total, size_t n_seqs, uint32_t k)
-{
-    uint64_t chunk = n_seqs >= (1u << 19) ? 4096 : std::min<uint64_t>(4096, std::max<uint64_t>(256, total >> 20));
-    return std::max<uint64_t>(chunk, 4ull * k);
-}
-
-void make_items_host(const uint64_t *offsets, size_t n_seqs, uint32_t k, std::vector<kbo::WalkItem> &items)
-{
-    const uint64_t total = offsets[n_seqs] - offsets[0];
-    const uint64_t chunk = walk_chunk(total, n_seqs, k);
-    items.clear();
-    for (size_t s = 0; s < n_seqs; s++) {
-        const uint64_t b = offsets[s], e = offsets[s + 1];
-        for (uint64_t c0 = b; c0 < e; c0 += chunk) {
-            const uint64_t c1 = std::min(e, c0 + chunk);
-            const uint64_t warm = std::min<uint64_t>(c0 - b, k > 0 ? k - 1 : 0);
-            kbo::WalkItem it;
-            it.start = c0 - warm;
-            it.len = (uint32_t)(c1 - c0 + warm);
-            it.warm = (uint32_t)warm;
-            items.push_back(it);
-        }
-    }
-}
-
-void check_batch(const void *concat, const uint64_t *offsets, size_t n_seqs)
-{
-    KBO_REQUIRE(concat && offsets, KBO_E_BAD_ARG, "null concat/offsets");
-    KBO_REQUIRE(n_seqs > 0, KBO_E_EMPTY_QUERY, "no sequences");
-    KBO_REQUIRE(n_seqs < 0xFFFFFFFFull, KBO_E_UNSUPPORTED, "more than 2^32-1 sequences per call");
-    for (size_t s = 0; s < n_seqs; s++) {
-        KBO_REQUIRE(offsets[s + 1] >= offsets[s], KBO_E_BAD_ARG, "offsets not monotone");
-        KBO_REQUIRE(offsets[s + 1] > offsets[s], KBO_E_EMPTY_QUERY,
-                    "empty query (index.rs:248 assert!(!query.is_empty()))");
-        KBO_REQUIRE(offsets[s + 1] - offsets[s] < 0xFFFFFFFFull, KBO_E_UNSUPPORTED,
-                    "sequence longer than 2^32-1");
-    }
-    KBO_REQUIRE(offsets[0] == 0, KBO_E_BAD_ARG, "offsets[0] must be 0");
-}
-
-// KBO_TIMING=1 in the environment prints a phase breakdown of the host batch entry points to stderr
-struct PhaseClock {
-    bool on = std::getenv("KBO_TIMING") != nullptr;
-    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-    void lap(const char *what)
-    {
-        if (!on) return;
-        const auto n = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[kbo timing] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
-        t = n;
-    }
-};
-
-struct BatchOnDevice {
-    DevBuf q, off, items, ms, lo, hi;
-    uint64_t total = 0;
-    void release()
-    {
-        for (DevBuf *b : {&q, &off, &items, &ms, &lo, &hi}) b->release();
-    }
-};
-
-// upload + A1 over a host batch (asynchronous on `stream`); leaves ms (and lo/hi) on the device.
-// `items_keep` must stay alive until the stream has been synchronised.
-void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
-                       bool want_ival, BatchOnDevice &B, std::vector<kbo::WalkItem> &items_keep, hipStream_t stream,
-                       uint32_t longest = 0 /* longest sequence if the caller knows it */,
-                       hipStream_t copy_stream = nullptr /* uploads go here when given ... */,
-                       hipEvent_t copied = nullptr /* ... and `stream` waits for this event */)
-{
-    KBO_REQUIRE(idx->host.k <= 255, KBO_E_UNSUPPORTED, "k > 255");
-    const int dev = current_device();
-    kbo::DevIndexView view = device_view(idx, dev);
-    const uint64_t total = offsets[n_seqs];
-    B.total = total;
-    // reads (nothing to chunk): the item list is derived from the offsets on the device;
-    // otherwise it is built here (chunks with k-1 warm-up bases) and uploaded
-    const uint64_t chunk = walk_chunk(total, n_seqs, idx->host.k);
-    const bool device_items = (longest ? longest : max_len(offsets, n_seqs)) <= chunk;
-    size_t n_items = n_seqs;
-    if (!device_items) {
-        make_items_host(offsets, n_seqs, idx->host.k, items_keep);
-        n_items = items_keep.size();
-    }
-    KBO_REQUIRE(n_items < (1ull << 28), KBO_E_UNSUPPORTED, "more than 2^28 work items per launch");
-    KBO_REQUIRE(total < 0xFFFFFF00ull, KBO_E_UNSUPPORTED, "4 GiB or more of query in one launch");
-
-    const size_t padded = ((total + 15) / 16) * 16 + 16;
-    B.q.ensure(padded);
-    B.off.ensure((n_seqs + 1) * sizeof(uint64_t));
-    B.items.ensure(n_items * sizeof(kbo::WalkItem));
-    B.ms.ensure(padded);
-    if (want_ival) {
-        B.lo.ensure(total * sizeof(uint32_t));
-        B.hi.ensure(total * sizeof(uint32_t));
-    }
-    hipStream_t up = copy_stream ? copy_stream : stream;
-    HIP_OK(hipMemcpyAsync(B.q.p, concat, total, hipMemcpyHostToDevice, up));
-    HIP_OK(hipMemcpyAsync(B.off.p, offsets, (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, up));
-    if (!device_items)
-        HIP_OK(hipMemcpyAsync(B.items.p, items_keep.data(), items_keep.size() * sizeof(kbo::WalkItem),
-                              hipMemcpyHostToDevice, up));
-    if (copy_stream) {
-        HIP_OK(hipEventRecord(copied, copy_stream));
-        HIP_OK(hipStreamWaitEvent(stream, copied, 0));
-    }
-    if (device_items) HIP_OK(kbo::launch_make_items(B.off.as<uint64_t>(), (uint32_t)n_seqs, B.items.as<kbo::WalkItem>(), stream));
-    kbo::WalkArgs a;
-    a.ix = view;
-    a.q = B.q.as<uint8_t>();
-    a.q_bytes = total;
-    a.items = B.items.as<kbo::WalkItem>();
-    a.n_items = (uint32_t)n_items;
-    a.rounds = 0;
-    a.d_out = B.ms.as<uint8_t>();
-    a.lo_out = want_ival ? B.lo.as<uint32_t>() : nullptr;
-    a.hi_out = want_ival ? B.hi.as<uint32_t>() : nullptr;
-    HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), stream));
-}
-
-void run_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
-                   bool want_ival, BatchOnDevice &B, hipStream_t stream)
-{
-    check_batch(concat, offsets, n_seqs);
-    std::vector<kbo::WalkItem> items;
-    enqueue_walk_host(idx, concat, offsets, n_seqs, want_ival, B, items, stream);
-    HIP_OK(hipStreamSynchronize(stream)); // the items vector must outlive the async copy
-}
-
-// ---- slabs: a host batch is processed in pieces of at most g_slab_bytes of query so that
-// (a) one launch stays below the 32-bit offset limits and (b) the H2D copy of slab i+1 and
-// the D2H copy of slab i-1 overlap the kernels of slab i (two streams, user buffers pinned
-// in place with hipHostRegister when that succeeds).
-size_t g_slab_bytes = 32ull << 20; // tools/bench_host.py: best of 8..128 MiB on the C2 reads
-
-struct Slab {
-    size_t s0, s1;   // sequences [s0, s1)
-    uint64_t b0, b1; // bases [b0, b1)
-};
-
-std::vector<Slab> make_slabs(const uint64_t *offsets, size_t n_seqs, size_t max_bytes)
-{
-    std::vector<Slab> slabs;
-    size_t s0 = 0;
-    while (s0 < n_seqs) {
-        // last s1 with offsets[s1] - offsets[s0] <= max_bytes (at least one sequence per slab)
-        size_t s1 = std::upper_bound(offsets + s0 + 1, offsets + n_seqs + 1, offsets[s0] + max_bytes) - offsets - 1;
-        s1 = std::max(s1, s0 + 1);
-        slabs.push_back(Slab{s0, s1, offsets[s0], offsets[s1]});
-        s0 = s1;
-    }
-    return slabs;
-}
-
-// one pass over the offsets of a batch: order, emptiness, shortest and longest sequence
-struct OffsetScan {
-    bool monotone = true;
-    uint64_t shortest = ~0ull, longest = 0;
-};
-OffsetScan scan_offsets(const uint64_t *offsets, size_t n_seqs)
-{
-    const size_t piece = 1u << 18;
-    const size_t n_tasks = (n_seqs + piece - 1) / piece;
-    std::vector<OffsetScan> part(n_tasks);
-    HostTeam::get().run(n_tasks, [&](size_t t) {
-        OffsetScan r;
-        const size_t a = t * piece, b = std::min(n_seqs, a + piece);
-        for (size_t s = a; s < b; s++) {
-            r.monotone &= offsets[s + 1] >= offsets[s];
-            const uint64_t len = offsets[s + 1] - offsets[s];
-            r.shortest = std::min(r.shortest, len);
-            r.longest = std::max(r.longest, len);
-        }
-        part[t] = r;
-    });
-    OffsetScan r;
-    for (const OffsetScan &x : part) {
-        r.monotone &= x.monotone;
-        r.shortest = std::min(r.shortest, x.shortest);
-        r.longest = std::max(r.longest, x.longest);
-    }
-    return r;
-}
-
-bool is_pinned_host(const void *ptr) // memory the DMA engines can reach without staging
-{
-    hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    return attr.type == hipMemoryTypeHost;
-}
-
-// ---- per-device scratch of the host batch entry points, kept between calls: slabs rotate
-// through kHostSlots slots, each with its own stream, device buffers and pinned staging, so
-// that the staging copy + H2D of slab i+1 and the D2H + copy-out of slab i-1 overlap the
-// kernels of slab i.
-constexpr int kHostSlots = 4;
-struct HostSlot {
-    BatchOnDevice B;
-    DevBuf chars;
-    PinBuf in, out, off;
-    std::vector<kbo::WalkItem> items;
-    hipEvent_t copied = nullptr, computed = nullptr, done = nullptr;
-    bool busy = false;     // a slab is in flight in this slot
-    uint64_t out_b0 = 0, out_bytes = 0;
-    // run-length output (kbo_find_batch): per-sequence first-run indices + block sums, the records,
-    // the number of runs (device word and its pinned copy), what the slab holds
-    DevBuf rle_scratch, rles, rle_total, dt_work;
-    PinBuf rle_total_pin, rle_first_pin;
-    size_t rle_capacity = 0, slab_id = 0, n_seqs = 0;
-    uint32_t longest = 0;
-};
-struct HostCtx {
-    int dev = 0;
-    HostSlot slot[kHostSlots];
-    // one stream per stage, so that every stage runs one slab at a time, in order, next to the
-    // other two stages: upload (copy engine), kernels, download (copy kernel)
-    hipStream_t st_up = nullptr, st_run = nullptr, st_down = nullptr;
-    explicit HostCtx(int d) : dev(d)
-    {
-        for (hipStream_t *st : {&st_up, &st_run, &st_down}) HIP_OK(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
-        for (HostSlot &S : slot)
-            for (hipEvent_t *e : {&S.copied, &S.computed, &S.done}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    }
-    ~HostCtx()
-    {
-        int prev = 0;
-        (void)hipGetDevice(&prev);
-        (void)hipSetDevice(dev);
-        for (hipStream_t st : {st_up, st_run, st_down})
-            if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-        for (HostSlot &S : slot)
-            for (hipEvent_t e : {S.copied, S.computed, S.done})
-                if (e) (void)hipEventDestroy(e);
-        for (HostSlot &S : slot) { // buffers belong to `dev`
-            S.B.release();
-            for (DevBuf *b : {&S.chars, &S.rle_scratch, &S.rles, &S.rle_total, &S.dt_work}) b->release();
-        }
-        (void)hipSetDevice(prev);
-    }
-};
-std::mutex g_ctx_mu;
-// leaked on purpose: destroying streams from a static destructor would run after the HIP runtime is gone
-std::vector<std::unique_ptr<HostCtx>> &g_ctx_pool = *new std::vector<std::unique_ptr<HostCtx>>();
-
-struct CtxLease { // takes a context of the device out of the pool (or makes one), puts it back
-    std::unique_ptr<HostCtx> ctx;
-    explicit CtxLease(int dev)
-    {
-        {
-            std::lock_guard<std::mutex> g(g_ctx_mu);
-            for (size_t i = 0; i < g_ctx_pool.size(); i++)
-                if (g_ctx_pool[i]->dev == dev) {
-                    ctx = std::move(g_ctx_pool[i]);
-                    g_ctx_pool.erase(g_ctx_pool.begin() + i);
-                    break;
-                }
-        }
-        if (!ctx) ctx.reset(new HostCtx(dev));
-    }
-    ~CtxLease()
-    {
-        bool busy = false; // an error may have left work in flight
-        for (HostSlot &S : ctx->slot) {
-            busy |= S.busy;
-            S.busy = false;
-        }
-        if (busy)
-            for (hipStream_t st : {ctx->st_up, ctx->st_run, ctx->st_down}) (void)hipStreamSynchronize(st);
-        std::lock_guard<std::mutex> g(g_ctx_mu);
-        g_ctx_pool.push_back(std::move(ctx));
-    }
-};
-
-void check_len_threshold(const uint64_t *offsets, size_t n_seqs, size_t k, size_t threshold)
-{
-    KBO_REQUIRE(k > 0, KBO_E_BAD_ARG, "k > 0 (derandomize.rs:274)");
-    KBO_REQUIRE(threshold > 1, KBO_E_THRESHOLD_LE_1, "threshold > 1 (derandomize.rs:275, translate.rs:269)");
-    for (size_t s = 0; s < n_seqs; s++)
-        KBO_REQUIRE(offsets[s + 1] - offsets[s] > 2, KBO_E_LEN_LE_2,
-                    "len > 2 (derandomize.rs:276, translate.rs:270)");
-}
-
-// A5+A6 over a batch whose offsets are known on the host: reads -> LDS kernel, medium
-// sequences -> one lane each, very long sequences -> chunked scan (one at a time).
-void derand_translate_host_offsets(const uint8_t *d_ms, const uint64_t *d_off, const uint64_t *offsets, size_t n_seqs,
-                                   uint32_t k, uint32_t threshold, const uint8_t *d_ref, uint8_t *d_chars,
-                                   int32_t *d_derand, hipStream_t stream, uint32_t longest = 0,
-                                   DevBuf *piece_work = nullptr /* lets long reads / contigs be split into pieces */)
-{
-    const uint32_t mx = longest ? longest : max_len(offsets, n_seqs);
-    void *work = nullptr;
-    size_t work_bytes = 0;
-    if (piece_work && mx > 480 && !d_derand) {
-        work_bytes = kbo::derand_piece_work_bytes((uint32_t)n_seqs, offsets[n_seqs]);
-        piece_work->ensure(work_bytes);
-        work = piece_work->p;
-    }
-    HIP_OK(kbo::launch_derand_translate(d_ms, d_off, (uint32_t)n_seqs, k, threshold, d_ref, d_chars, d_derand, mx,
-                                        kbo::kLongSeq, stream, offsets[n_seqs], work, work_bytes));
-    if (mx <= kbo::kLongSeq) return;
-    size_t need = 0;
-    for (size_t s = 0; s < n_seqs; s++) {
-        const uint64_t len = offsets[s + 1] - offsets[s];
-        if (len > kbo::kLongSeq) need = std::max(need, kbo::derand_long_scratch_bytes(len, k, threshold));
-    }
-    DevBuf scratch(need);
-    for (size_t s = 0; s < n_seqs; s++) {
-        const uint64_t b = offsets[s], len = offsets[s + 1] - offsets[s];
-        if (len <= kbo::kLongSeq) continue;
-        HIP_OK(kbo::launch_derand_long(d_ms + b, (uint32_t)len, k, threshold, d_ref ? d_ref + b : nullptr, d_chars + b,
-                                       d_derand ? d_derand + b : nullptr, scratch.p, stream));
-    }
-    HIP_OK(hipStreamSynchronize(stream)); // scratch is released on return
-}
-
-// device run-length records are seven u32; the API's kbo_rle has the reference's usize fields
-constexpr size_t kRleWords = 7;
-void widen_rles(kbo_rle *dst, const uint32_t *src, size_t n, HostTeam &team)
-{
-    const size_t piece = 1u << 14;
-    team.run((n + piece - 1) / piece, [&](size_t t) {
-        const size_t a = t * piece, b = std::min(n, a + piece);
-        for (size_t q = a; q < b; q++) {
-            const uint32_t *r = src + q * kRleWords;
-            dst[q] = kbo_rle{r[0], r[1], r[2], r[3], r[4], r[5], r[6]};
-        }
-    });
-}
-
-// Where kbo_find_batch collects format::run_lengths_gapped of every slab (computed on the device
-// from the slab's characters, which then never leave it)
-struct RleSink {
-    size_t max_gap_len = 0;
-    uint64_t *rle_offsets = nullptr; // caller's n_seqs + 1 entries
-    // one device: slabs complete in order, so their records go straight into the result array
-    kbo_rle *all = nullptr;
-    size_t all_cap = 0, all_used = 0;
-    // several devices: slabs complete out of order, kept per slab and put together at the end
-    std::vector<std::vector<kbo_rle>> runs;
-    std::vector<std::vector<uint32_t>> first; // index of the first run of each sequence of the slab, +1 entry
-    ~RleSink() { std::free(all); }
-};
-
-// kbo::matches over a batch (lib.rs:618-627); optional relative_to_ref (lib.rs:756-757); with a sink
-// the characters are turned into run lengths on the device instead of being downloaded (lib.rs:816-820)
-void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
-                        double max_error_prob, bool format, uint8_t *chars_out, RleSink *sink = nullptr)
-{
-    KBO_REQUIRE(idx && (chars_out || sink), KBO_E_BAD_ARG, "null argument");
-    PhaseClock clk;
-    const size_t k = idx->host.k;
-    const size_t threshold = random_match_threshold(k, idx->host.n_kmers, 4, max_error_prob); // lib.rs:620
-    KBO_REQUIRE(concat && offsets, KBO_E_BAD_ARG, "null concat/offsets");
-    KBO_REQUIRE(n_seqs > 0, KBO_E_EMPTY_QUERY, "no sequences");
-    KBO_REQUIRE(n_seqs < 0xFFFFFFFFull, KBO_E_UNSUPPORTED, "more than 2^32-1 sequences per call");
-    KBO_REQUIRE(offsets[0] == 0, KBO_E_BAD_ARG, "offsets[0] must be 0");
-    const OffsetScan scan = scan_offsets(offsets, n_seqs);
-    KBO_REQUIRE(scan.monotone, KBO_E_BAD_ARG, "offsets not monotone");
-    KBO_REQUIRE(scan.shortest > 0, KBO_E_EMPTY_QUERY, "empty query (index.rs:248 assert!(!query.is_empty()))");
-    KBO_REQUIRE(scan.longest < 0xFFFFFFFFull, KBO_E_UNSUPPORTED, "sequence longer than 2^32-1");
-    KBO_REQUIRE(k > 0, KBO_E_BAD_ARG, "k > 0 (derandomize.rs:274)");
-    KBO_REQUIRE(threshold > 1, KBO_E_THRESHOLD_LE_1, "threshold > 1 (derandomize.rs:275, translate.rs:269)");
-    KBO_REQUIRE(scan.shortest > 2, KBO_E_LEN_LE_2, "len > 2 (derandomize.rs:276, translate.rs:270)");
-    clk.lap("argument checks");
-    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
-    // user buffers the DMA engines can reach directly are used in place, pageable ones are staged
-    const bool in_pinned = is_pinned_host(concat), out_pinned = sink || is_pinned_host(chars_out);
-    if (sink) {
-        sink->runs.assign(slabs.size(), {});
-        sink->first.assign(slabs.size(), {});
-    }
-    const bool sink_direct = sink && (g_devices.size() <= 1 || slabs.size() <= 1);
-    if (sink_direct) { // room for 2 runs per sequence to start with (untouched pages cost nothing)
-        sink->all_cap = 2 * n_seqs + 1024;
-        sink->all = static_cast<kbo_rle *>(std::malloc(sink->all_cap * sizeof(kbo_rle)));
-        if (!sink->all) throw std::bad_alloc();
-        sink->rle_offsets[0] = 0;
-    }
-    clk.lap("slab list");
-    // one worker per device (index replicated on each, slabs dealt round-robin, disjoint output
-    // slices: no exchange between devices); a single device runs on the calling thread
-    std::vector<int> devices = g_devices;
-    if (devices.empty()) devices.push_back(current_device());
-    const size_t nd = std::min(devices.size(), std::max<size_t>(1, slabs.size()));
-    HostTeam &team = HostTeam::get();
-    auto worker = [&](size_t w) {
-        HIP_OK(hipSetDevice(devices[w]));
-        CtxLease lease(devices[w]);
-        HostCtx &C = *lease.ctx;
-        // The calling thread stages and submits slabs; a second thread completes them in
-        // submission order (waits for the slab's event, copies the staged output to the user
-        // buffer), so the two host copies of a slab never queue behind each other.
-        std::mutex mu;
-        std::condition_variable cv;
-        size_t submitted = 0, drained = 0;
-        bool stop = false;
-        int drain_code = KBO_OK;
-        std::string drain_error;
-        std::thread drainer([&] {
-            try {
-                HIP_OK(hipSetDevice(devices[w]));
-                const size_t none = ~size_t(0);
-                // run lengths: the number of records of a slab is known once its kernels are done, so the
-                // download is issued here; it is issued for the next slab before the previous one is
-                // copied out, so that the copy engine and the host copy work on different slabs
-                auto start = [&](size_t turn) {
-                    if (!sink) return;
-                    HostSlot &S = C.slot[turn % kHostSlots];
-                    HIP_OK(hipEventSynchronize(S.computed));
-                    const uint32_t total = *S.rle_total_pin.as<uint32_t>();
-                    if (total > S.rle_capacity) { // more runs than the speculative emit had room for
-                        S.rle_capacity = (size_t)total + total / 4 + 16;
-                        S.rles.ensure(S.rle_capacity * kRleWords * sizeof(uint32_t));
-                        HIP_OK(kbo::launch_rle_emit(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)S.n_seqs,
-                                                    (uint32_t)std::min<size_t>(sink->max_gap_len, 0xFFFFFFFFu),
-                                                    S.rle_scratch.as<uint32_t>(), S.rles.as<uint32_t>(),
-                                                    (uint32_t)S.rle_capacity, C.st_down, S.longest));
-                    }
-                    const size_t words = kbo::chunk_items_scratch_words((uint32_t)S.n_seqs);
-                    S.out.ensure(std::max<size_t>(16, (size_t)total * kRleWords * sizeof(uint32_t)));
-                    S.rle_first_pin.ensure(words * sizeof(uint32_t));
-                    if (total)
-                        HIP_OK(hipMemcpyAsync(S.out.p, S.rles.p, (size_t)total * kRleWords * sizeof(uint32_t),
-                                              hipMemcpyDeviceToHost, C.st_down));
-                    HIP_OK(hipMemcpyAsync(S.rle_first_pin.p, S.rle_scratch.p, words * sizeof(uint32_t), hipMemcpyDeviceToHost, C.st_down));
-                    HIP_OK(hipEventRecord(S.done, C.st_down));
-                    S.out_bytes = total; // records
-                };
-                auto finish = [&](size_t turn) {
-                    HostSlot &S = C.slot[turn % kHostSlots];
-                    HIP_OK(hipEventSynchronize(S.done));
-                    if (!sink) {
-                        if (!out_pinned) HostTeam::out().copy(chars_out + S.out_b0, S.out.p, S.out_bytes);
-                    } else {
-                        const size_t total = S.out_bytes;
-                        const uint32_t *local = S.rle_first_pin.as<uint32_t>(), *sums = local + S.n_seqs + 1;
-                        if (sink_direct) {
-                            if (sink->all_used + total > sink->all_cap) {
-                                const size_t cap = (sink->all_used + total) * 2;
-                                kbo_rle *p = static_cast<kbo_rle *>(std::realloc(sink->all, cap * sizeof(kbo_rle)));
-                                if (!p) throw std::bad_alloc();
-                                sink->all = p;
-                                sink->all_cap = cap;
-                            }
-                            const size_t base = sink->all_used, s0 = slabs[S.slab_id].s0, ns_slab = S.n_seqs;
-                            widen_rles(sink->all + base, S.out.as<uint32_t>(), total, HostTeam::out());
-                            const size_t piece = 1u << 15;
-                            HostTeam::out().run((ns_slab + piece - 1) / piece, [&](size_t t) {
-                                const size_t a = t * piece + 1, b = std::min(ns_slab, a + piece - 1);
-                                for (size_t q = a; q <= b; q++) sink->rle_offsets[s0 + q] = base + sums[q / 1024] + local[q];
-                            });
-                            sink->all_used += total;
-                        } else {
-                            std::vector<kbo_rle> &runs = sink->runs[S.slab_id];
-                            runs.resize(total);
-                            widen_rles(runs.data(), S.out.as<uint32_t>(), total, HostTeam::out());
-                            std::vector<uint32_t> &first = sink->first[S.slab_id];
-                            first.resize(S.n_seqs + 1);
-                            for (size_t q = 0; q <= S.n_seqs; q++) first[q] = sums[q / 1024] + local[q];
-                        }
-                    }
-                    S.busy = false;
-                    {
-                        std::lock_guard<std::mutex> g(mu);
-                        drained++;
-                    }
-                    cv.notify_all();
-                };
-                size_t started = 0, pending = none;
-                for (;;) {
-                    bool can_start;
-                    {
-                        std::unique_lock<std::mutex> g(mu);
-                        cv.wait(g, [&] { return started < submitted || pending != none || stop; });
-                        can_start = started < submitted;
-                        if (!can_start && pending == none) return;
-                    }
-                    const size_t prev = pending;
-                    pending = none;
-                    if (can_start) {
-                        start(started);
-                        pending = started++;
-                    }
-                    if (prev != none) finish(prev);
-                }
-            } catch (const KboError &e) {
-                std::lock_guard<std::mutex> g(mu);
-                drain_code = e.code;
-                drain_error = e.what();
-                drained = ~size_t(0) / 2; // releases the submitting thread
-                cv.notify_all();
-            } catch (const std::exception &e) {
-                std::lock_guard<std::mutex> g(mu);
-                drain_code = KBO_E_HIP;
-                drain_error = e.what();
-                drained = ~size_t(0) / 2;
-                cv.notify_all();
-            }
-        });
-        auto join_drainer = [&] {
-            {
-                std::lock_guard<std::mutex> g(mu);
-                stop = true;
-            }
-            cv.notify_all();
-            if (drainer.joinable()) drainer.join();
-        };
-        try {
-            size_t turn = 0;
-            for (size_t i = w; i < slabs.size(); i += nd, turn++) {
-                const Slab &sl = slabs[i];
-                HostSlot &S = C.slot[turn % kHostSlots];
-                {
-                    std::unique_lock<std::mutex> g(mu);
-                    cv.wait(g, [&] { return turn < drained + kHostSlots; }); // the slot is free again
-                    if (drain_code != KBO_OK) break;
-                }
-                if (w == 0) clk.lap("  wait for a free slot");
-                const size_t ns = sl.s1 - sl.s0;
-                const uint64_t bytes = sl.b1 - sl.b0;
-                // stage: slab-relative offsets (and the longest sequence of the slab), query bytes
-                S.off.ensure((ns + 1) * sizeof(uint64_t));
-                uint64_t *off = S.off.as<uint64_t>();
-                const size_t piece = 1u << 15, n_tasks = (ns + 1 + piece - 1) / piece;
-                std::vector<uint64_t> longest(n_tasks, 0);
-                team.run(n_tasks, [&](size_t t) {
-                    const size_t a = t * piece, b = std::min(ns + 1, a + piece);
-                    uint64_t m = 0;
-                    for (size_t j = a; j < b; j++) {
-                        off[j] = offsets[sl.s0 + j] - sl.b0;
-                        if (j < ns) m = std::max(m, offsets[sl.s0 + j + 1] - offsets[sl.s0 + j]);
-                    }
-                    longest[t] = m;
-                });
-                const uint32_t mx = (uint32_t)*std::max_element(longest.begin(), longest.end());
-                const uint8_t *src = concat + sl.b0;
-                if (!in_pinned) {
-                    S.in.ensure(bytes);
-                    team.copy(S.in.p, src, bytes);
-                    src = S.in.as<uint8_t>();
-                }
-                if (w == 0) clk.lap("  offsets + copy in");
-                enqueue_walk_host(idx, src, off, ns, false, S.B, S.items, C.st_run, mx, C.st_up, S.copied);
-                if (sink) {
-                    // characters stay on the device; run lengths are counted, scanned and (speculatively, into
-                    // the room the slot has) emitted right behind A5/A6; the completing thread downloads them
-                    S.chars.ensure(((S.B.total + 15) / 16) * 16 + 32);
-                    derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, (uint32_t)k,
-                                                  (uint32_t)threshold, nullptr, S.chars.as<uint8_t>(), nullptr, C.st_run, mx, &S.dt_work);
-                    const uint32_t gap = (uint32_t)std::min<size_t>(sink->max_gap_len, 0xFFFFFFFFu);
-                    S.rle_scratch.ensure(kbo::chunk_items_scratch_words((uint32_t)ns) * sizeof(uint32_t));
-                    S.rle_total.ensure(16);
-                    S.rle_total_pin.ensure(16);
-                    if (S.rle_capacity < 2 * ns + 16) {
-                        S.rle_capacity = 2 * ns + 16;
-                        S.rles.ensure(S.rle_capacity * kRleWords * sizeof(uint32_t));
-                    }
-                    HIP_OK(kbo::launch_rle_count(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
-                                                 S.rle_scratch.as<uint32_t>(), S.rle_total.as<uint32_t>(), C.st_run, mx));
-                    HIP_OK(hipMemcpyAsync(S.rle_total_pin.p, S.rle_total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, C.st_run));
-                    HIP_OK(kbo::launch_rle_emit(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
-                                                S.rle_scratch.as<uint32_t>(), S.rles.as<uint32_t>(), (uint32_t)S.rle_capacity,
-                                                C.st_run, mx));
-                    S.longest = mx;
-                    HIP_OK(hipEventRecord(S.computed, C.st_run));
-                    HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
-                    S.slab_id = i;
-                    S.n_seqs = ns;
-                } else {
-                    // D2H leg: hipMemcpyAsync on the download stream.  With one stream per stage the copy
-                    // engines carry both directions at once (tools/bench_host.py: 37-40 Gbp/s host->host;
-                    // a small kernel storing into pinned memory, or A5/A6 storing there themselves, gave
-                    // 28 and 26 Gbp/s).
-                    uint8_t *dst = chars_out + sl.b0;
-                    if (!out_pinned) {
-                        S.out.ensure(bytes + 32);
-                        dst = S.out.as<uint8_t>();
-                    }
-                    S.chars.ensure(((S.B.total + 15) / 16) * 16 + 16);
-                    derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, (uint32_t)k,
-                                                  (uint32_t)threshold, format ? S.B.q.as<uint8_t>() : nullptr,
-                                                  S.chars.as<uint8_t>(), nullptr, C.st_run, mx, &S.dt_work);
-                    HIP_OK(hipEventRecord(S.computed, C.st_run));
-                    HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
-                    HIP_OK(hipMemcpyAsync(dst, S.chars.p, bytes, hipMemcpyDeviceToHost, C.st_down));
-                    HIP_OK(hipEventRecord(S.done, C.st_down));
-                }
-                S.busy = true;
-                S.out_b0 = sl.b0;
-                S.out_bytes = bytes;
-                {
-                    std::lock_guard<std::mutex> g(mu);
-                    submitted++;
-                }
-                cv.notify_all();
-                if (w == 0) clk.lap("  enqueue");
-            }
-        } catch (...) {
-            join_drainer();
-            throw;
-        }
-        join_drainer();
-        if (drain_code != KBO_OK) throw KboError(drain_code, drain_error);
-        if (w == 0) clk.lap("drain");
-    };
-    if (nd == 1) {
-        const int prev = current_device();
-        worker(0);
-        if (prev != devices[0]) HIP_OK(hipSetDevice(prev));
-        return;
-    }
-    std::vector<std::thread> threads;
-    std::vector<std::string> errors(nd);
-    std::vector<int> codes(nd, KBO_OK);
-    for (size_t w = 0; w < nd; w++)
-        threads.emplace_back([&, w] {
-            try {
-                worker(w);
-            } catch (const KboError &e) {
-                codes[w] = e.code;
-                errors[w] = e.what();
-            } catch (const std::exception &e) {
-                codes[w] = KBO_E_HIP;
-                errors[w] = e.what();
-            }
-        });
-    for (auto &t : threads) t.join();
-    for (size_t w = 0; w < nd; w++)
-        if (codes[w] != KBO_OK) throw KboError(codes[w], errors[w]);
-}
+namespace {
 
 // matching statistics with intervals of a list of sequences, batched on the GPU
 kbo::MsFn make_ms_fn(kbo_index *idx)
@@ -970,6 +210,7 @@ kbo_rle *copy_rles(const std::vector<kbo_rle> &v)
 }
 
 } // namespace
+
 
 extern "C" {
 
@@ -1642,8 +883,7 @@ int kbo_set_host_threads(int n)
 int kbo_release_scratch(void)
 {
     return guarded([&] {
-        std::lock_guard<std::mutex> g(g_ctx_mu);
-        g_ctx_pool.clear();
+        release_host_scratch();
     });
 }
 
