@@ -278,9 +278,19 @@ struct CtxLease { // takes a context of the device out of the pool (or makes one
         }
         if (busy)
             for (hipStream_t st : {ctx->st_up, ctx->st_run, ctx->st_down}) (void)hipStreamSynchronize(st);
-        std::lock_guard<std::mutex> g(g_ctx_mu);
-        g_ctx_pool.push_back(std::move(ctx));
+        // keep at most kPooledPerDevice contexts per device (each holds ~0.8 GB of device and ~0.3 GB of
+        // pinned memory at the default slab size); the scratch of further concurrent callers is freed
+        std::unique_lock<std::mutex> g(g_ctx_mu);
+        size_t same = 0;
+        for (const auto &c : g_ctx_pool) same += c->dev == ctx->dev;
+        if (same < kPooledPerDevice) {
+            g_ctx_pool.push_back(std::move(ctx));
+            return;
+        }
+        g.unlock();
+        ctx.reset(); // ~HostCtx switches to its device and back
     }
+    static constexpr size_t kPooledPerDevice = 2;
 };
 
 void check_len_threshold(const uint64_t *offsets, size_t n_seqs, size_t k, size_t threshold)
