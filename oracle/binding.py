@@ -144,7 +144,10 @@ class Index:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().ora_index_free(self._h)
+            try:
+                lib().ora_index_free(self._h)
+            except Exception:  # interpreter shutdown: module globals are already gone
+                pass
             self._h = None
 
     @property

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Randomised stress run (not part of the test suite): random k, index content, batch shapes, error rates,
+slab sizes, two-base steps on/off and gap lengths; every result is compared with the oracle.
+SECONDS= wall budget, SEED= first seed."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import kbo_amd  # noqa: E402
+from kbo_amd import batch, synth  # noqa: E402
+from oracle import binding as ora  # noqa: E402
+
+budget = float(os.environ.get("SECONDS", 120))
+seed0 = int(os.environ.get("SEED", 1))
+t_end = time.time() + budget
+L = kbo_amd.lib()
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+it = 0
+while time.time() < t_end:
+    it += 1
+    rng = np.random.default_rng(seed0 * 100003 + it)
+    k = int(rng.choice([3, 5, 11, 21, 31, 32, 47, 63, 64, 101, 255]))
+    G = int(rng.choice([2_000, 30_000, 200_000]))
+    g = synth.genome(G, seed=int(rng.integers(1, 1 << 30)))
+    if rng.random() < 0.3:  # repeats and a non-ACGT byte in the index
+        g = np.concatenate([g, np.tile(g[:int(rng.integers(20, 500))], int(rng.integers(2, 20))), [ord("N")], g[::-1][:1000]]).astype(np.uint8)
+    rc = bool(rng.random() < 0.2)
+    pairs_on = bool(rng.random() < 0.5)
+    L.kbo_set_pair_steps(0 if pairs_on else (1 << 63), int(rng.choice([1, 4, 16])))
+    L.kbo_set_slab_bytes(int(rng.choice([1 << 16, 1 << 18, 32 << 20])))
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=k, num_threads=4, add_revcomp=rc))
+    oi = ora.Index.build([g.tobytes()], k=k, add_revcomp=rc)
+    # batch: reads of one length, ragged reads, a few long pieces
+    shape = rng.choice(["uniform", "ragged", "long", "mixed"])
+    lens = []
+    if shape in ("uniform", "mixed"):
+        lens += [int(rng.choice([32, 100, 128, 150, 151, 250, 256, 480]))] * int(rng.integers(100, 3000))
+    if shape in ("ragged", "mixed"):
+        lens += list(rng.integers(3, 600, int(rng.integers(100, 3000))))
+    if shape in ("long", "mixed"):
+        lens += list(rng.integers(481, 90_000, int(rng.integers(1, 12))))
+    lens = [int(min(n, len(g) - 1)) for n in lens if n >= 3]
+    rng.shuffle(lens)
+    sub = float(rng.choice([0.0, 0.01, 0.05, 0.3]))
+    pieces = []
+    for n in lens:
+        s0 = int(rng.integers(0, len(g) - n))
+        p = g[s0:s0 + n].copy()
+        hit = rng.random(n) < sub
+        p[hit] = ACGT[rng.integers(0, 4, int(hit.sum()))]
+        if rng.random() < 0.05:
+            p[rng.integers(0, n, max(1, n // 50))] = ord("N")
+        pieces.append(p)
+    concat = np.concatenate(pieces)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    p_err = float(rng.choice([1e-7, 1e-3, 0.1]))
+    try:
+        exp_chars, exp_d = oi.matches_batch(concat, offsets, p_err, n_threads=8, want_d=True)
+    except Exception as e:  # threshold <= 1 etc.: both sides must refuse
+        try:
+            batch.matches_batch(sbwt, concat, offsets, p_err)
+            raise SystemExit(f"iteration {it}: oracle refused ({e}) but the product accepted")
+        except kbo_amd.KboError:
+            continue
+    tag = f"it {it}: k={k} G={len(g)} rc={rc} pairs={pairs_on} shape={shape} n={len(lens)} sub={sub} p={p_err}"
+    d, _, _ = batch.ms_batch(sbwt, concat, offsets)
+    assert np.array_equal(d, exp_d), "MS " + tag
+    got = batch.matches_batch(sbwt, concat, offsets, p_err)
+    assert np.array_equal(got, exp_chars), "chars " + tag
+    gap = int(rng.choice([0, 0, 3, 50]))
+    rles, ro = batch.find_batch(sbwt, concat, offsets, kbo_amd.FindOpts(max_error_prob=p_err, max_gap_len=gap))
+    for s in rng.integers(0, len(lens), 40):
+        exp = ora.run_lengths_gapped(exp_chars[offsets[s]:offsets[s + 1]].tobytes(), gap)
+        assert [tuple(int(v) for v in r) for r in rles[ro[s]:ro[s + 1]]] == exp, f"rle seq {s} gap {gap} " + tag
+    dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"), max_error_prob=p_err,
+                            format=bool(rng.random() < 0.5))
+    if rng.random() < 0.3:
+        dev.max_len = 0
+        dev.work_bytes = int(L.kbo_work_bytes(dev.n_seqs, dev.total, 0, k))
+        dev.work = torch.zeros(dev.work_bytes // 8 + 2, dtype=torch.int64, device="cuda:0")
+    dev.run()
+    torch.cuda.synchronize()
+    want = np.frombuffer(ora.relative_to_ref(concat, exp_chars), dtype=np.uint8) if dev.format else exp_chars
+    assert np.array_equal(dev.ms.cpu().numpy()[:len(concat)], exp_d), "dev MS " + tag
+    assert np.array_equal(dev.chars.cpu().numpy()[:len(concat)], want), "dev chars " + tag
+    print("ok", tag, flush=True)
+print(f"{it} iterations, all equal to the oracle")
