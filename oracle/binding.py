@@ -30,8 +30,8 @@ class RLE(C.Structure):
 
 
 class OVariant(C.Structure):
-    _fields_ = [("query_pos", C.c_uint64), ("query_chars", C.c_uint8 * 8), ("query_len", C.c_uint32),
-                ("ref_chars", C.c_uint8 * 8), ("ref_len", C.c_uint32), ("overflow", C.c_uint32)]
+    _fields_ = [("query_pos", C.c_uint64), ("query_chars", C.c_uint8 * 256), ("query_len", C.c_uint32),
+                ("ref_chars", C.c_uint8 * 256), ("ref_len", C.c_uint32), ("overflow", C.c_uint32)]
 
     def as_tuple(self):
         return (int(self.query_pos), bytes(self.query_chars[:self.query_len]).decode(),

@@ -121,8 +121,8 @@ extern "C" {
 #endif
 typedef struct {
     uint64_t query_pos;
-    uint8_t query_chars[8]; uint32_t query_len; /* the reference's variants are short; longer ones set overflow */
-    uint8_t ref_chars[8]; uint32_t ref_len;
+    uint8_t query_chars[256]; uint32_t query_len; /* a variant is at most k <= 255 characters; longer would set overflow */
+    uint8_t ref_chars[256]; uint32_t ref_len;
     uint32_t overflow;
 } ora_variant;
 /* kbo::call (lib.rs:547-573) = variant_calling::call_variants (variant_calling.rs:249-294):

@@ -83,9 +83,9 @@ static int resolve_variant(const uint8_t *qk, const uint8_t *rk, size_t k, const
         if (qo > ro) { if (rpeak + 1 + vl > k) PANIC(); rs = rk + rpeak + 1; rl = vl; }
         else { if (qpeak + 1 + vl > k) PANIC(); qs = qk + qpeak + 1; ql = vl; }
     }
-    v->overflow = (ql > 8 || rl > 8);
+    v->overflow = (ql > 256 || rl > 256);
     v->query_len = (uint32_t)ql; v->ref_len = (uint32_t)rl;
-    memcpy(v->query_chars, qs, MIN(ql, 8)); memcpy(v->ref_chars, rs, MIN(rl, 8));
+    memcpy(v->query_chars, qs, MIN(ql, 256)); memcpy(v->ref_chars, rs, MIN(rl, 256));
     return 1;
 }
 
