@@ -32,6 +32,12 @@ while time.time() < t_end:
     pairs_on = bool(rng.random() < 0.5)
     L.kbo_set_pair_steps(0 if pairs_on else (1 << 63), int(rng.choice([1, 4, 16])))
     L.kbo_set_slab_bytes(int(rng.choice([1 << 16, 1 << 18, 32 << 20])))
+    big = bool(rng.random() < 0.15)          # 64-bit-offset entry layout
+    L.kbo_set_force_big_layout(int(big))
+    two_workers = bool(rng.random() < 0.15)  # the batch spread over a device list (both entries GPU 0)
+    import ctypes
+    devs = (ctypes.c_int * 2)(0, 0)
+    L.kbo_set_devices(devs if two_workers else None, 2 if two_workers else 0)
     sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=k, num_threads=4, add_revcomp=rc))
     oi = ora.Index.build([g.tobytes()], k=k, add_revcomp=rc)
     # batch: reads of one length, ragged reads, a few long pieces
@@ -66,7 +72,7 @@ while time.time() < t_end:
             raise SystemExit(f"iteration {it}: oracle refused ({e}) but the product accepted")
         except kbo_amd.KboError:
             continue
-    tag = f"it {it}: k={k} G={len(g)} rc={rc} pairs={pairs_on} shape={shape} n={len(lens)} sub={sub} p={p_err}"
+    tag = f"it {it}: k={k} G={len(g)} rc={rc} pairs={pairs_on} big={big} workers={2 if two_workers else 1} shape={shape} n={len(lens)} sub={sub} p={p_err}"
     d, _, _ = batch.ms_batch(sbwt, concat, offsets)
     assert np.array_equal(d, exp_d), "MS " + tag
     got = batch.matches_batch(sbwt, concat, offsets, p_err)
