@@ -349,6 +349,289 @@ void widen_rles(kbo_rle *dst, const uint32_t *src, size_t n, HostTeam &team)
 
 // kbo::matches over a batch (lib.rs:618-627); optional relative_to_ref (lib.rs:756-757); with a sink
 // the characters are turned into run lengths on the device instead of being downloaded (lib.rs:816-820)
+namespace {
+
+// what a batch call hands to its per-device workers
+struct BatchJob {
+    kbo_index *idx;
+    const uint8_t *concat;
+    const uint64_t *offsets;
+    uint32_t k, threshold;
+    bool format;         // apply format::relative_to_ref
+    uint8_t *chars_out;  // nullptr when a sink takes run lengths instead
+    RleSink *sink;
+    bool sink_direct;    // one worker: records go straight into sink->all
+    bool in_pinned, out_pinned; // user buffers the DMA engines reach directly are used in place
+    const std::vector<Slab> *slabs;
+    PhaseClock *clk;     // phase timing (worker 0 only)
+};
+
+// One device's share of a batch: slabs `first`, `first + stride`, ... rotate through the slots of a
+// leased HostCtx.  The calling thread stages and submits slabs; a second thread completes them in
+// submission order (downloads, copies the staged output to the user's memory), so the two host
+// copies of a slab never queue behind each other.
+class SlabWorker {
+public:
+    SlabWorker(const BatchJob &job, int device, size_t first, size_t stride, bool timed)
+        : job_(job), device_(device), first_(first), stride_(stride), timed_(timed)
+    {
+    }
+
+    void run()
+    {
+        HIP_OK(hipSetDevice(device_));
+        CtxLease lease(device_);
+        C_ = lease.ctx.get();
+        std::thread drainer([this] { drain_loop(); });
+        auto join_drainer = [&] {
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                stop_ = true;
+            }
+            cv_.notify_all();
+            if (drainer.joinable()) drainer.join();
+        };
+        try {
+            size_t turn = 0;
+            for (size_t i = first_; i < job_.slabs->size(); i += stride_, turn++) {
+                {
+                    std::unique_lock<std::mutex> g(mu_);
+                    cv_.wait(g, [&] { return turn < drained_ + kHostSlots; }); // the slot is free again
+                    if (drain_code_ != KBO_OK) break;
+                }
+                lap("  wait for a free slot");
+                submit(turn, i);
+                {
+                    std::lock_guard<std::mutex> g(mu_);
+                    submitted_++;
+                }
+                cv_.notify_all();
+                lap("  enqueue");
+            }
+        } catch (...) {
+            join_drainer();
+            throw;
+        }
+        join_drainer();
+        if (drain_code_ != KBO_OK) throw KboError(drain_code_, drain_error_);
+        lap("drain");
+    }
+
+private:
+    void lap(const char *what)
+    {
+        if (timed_) job_.clk->lap(what);
+    }
+    HostSlot &slot(size_t turn) { return C_->slot[turn % kHostSlots]; }
+
+    // ---- submitting thread: stage the slab, enqueue upload, kernels and (characters) the download
+    void submit(size_t turn, size_t slab_id)
+    {
+        const Slab &sl = (*job_.slabs)[slab_id];
+        HostSlot &S = slot(turn);
+        HostCtx &C = *C_;
+        HostTeam &team = HostTeam::get();
+        const size_t ns = sl.s1 - sl.s0;
+        const uint64_t bytes = sl.b1 - sl.b0;
+        // stage: slab-relative offsets (and the longest sequence of the slab), query bytes
+        S.off.ensure((ns + 1) * sizeof(uint64_t));
+        uint64_t *off = S.off.as<uint64_t>();
+        const uint64_t *offsets = job_.offsets;
+        const size_t piece = 1u << 15, n_tasks = (ns + 1 + piece - 1) / piece;
+        std::vector<uint64_t> longest(n_tasks, 0);
+        team.run(n_tasks, [&](size_t t) {
+            const size_t a = t * piece, b = std::min(ns + 1, a + piece);
+            uint64_t m = 0;
+            for (size_t j = a; j < b; j++) {
+                off[j] = offsets[sl.s0 + j] - sl.b0;
+                if (j < ns) m = std::max(m, offsets[sl.s0 + j + 1] - offsets[sl.s0 + j]);
+            }
+            longest[t] = m;
+        });
+        const uint32_t mx = (uint32_t)*std::max_element(longest.begin(), longest.end());
+        const uint8_t *src = job_.concat + sl.b0;
+        if (!job_.in_pinned) {
+            S.in.ensure(bytes);
+            team.copy(S.in.p, src, bytes);
+            src = S.in.as<uint8_t>();
+        }
+        lap("  offsets + copy in");
+        enqueue_walk_host(job_.idx, src, off, ns, false, S.B, S.items, C.st_run, mx, C.st_up, S.copied);
+        if (job_.sink) {
+            // characters stay on the device; run lengths are counted, scanned and (speculatively, into
+            // the room the slot has) emitted right behind A5/A6; the completing thread downloads them
+            S.chars.ensure(((S.B.total + 15) / 16) * 16 + 32);
+            derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, job_.k, job_.threshold,
+                                          nullptr, S.chars.as<uint8_t>(), nullptr, C.st_run, mx, &S.dt_work);
+            const uint32_t gap = (uint32_t)std::min<size_t>(job_.sink->max_gap_len, 0xFFFFFFFFu);
+            S.rle_scratch.ensure(kbo::chunk_items_scratch_words((uint32_t)ns) * sizeof(uint32_t));
+            S.rle_total.ensure(16);
+            S.rle_total_pin.ensure(16);
+            if (S.rle_capacity < 2 * ns + 16) {
+                S.rle_capacity = 2 * ns + 16;
+                S.rles.ensure(S.rle_capacity * kRleWords * sizeof(uint32_t));
+            }
+            HIP_OK(kbo::launch_rle_count(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
+                                         S.rle_scratch.as<uint32_t>(), S.rle_total.as<uint32_t>(), C.st_run, mx));
+            HIP_OK(hipMemcpyAsync(S.rle_total_pin.p, S.rle_total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, C.st_run));
+            HIP_OK(kbo::launch_rle_emit(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
+                                        S.rle_scratch.as<uint32_t>(), S.rles.as<uint32_t>(), (uint32_t)S.rle_capacity,
+                                        C.st_run, mx));
+            S.longest = mx;
+            HIP_OK(hipEventRecord(S.computed, C.st_run));
+            HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
+            S.slab_id = slab_id;
+            S.n_seqs = ns;
+        } else {
+            // D2H leg: hipMemcpyAsync on the download stream.  With one stream per stage the copy
+            // engines carry both directions at once (tools/bench_host.py: 37-40 Gbp/s host->host;
+            // a small kernel storing into pinned memory, or A5/A6 storing there themselves, gave
+            // 28 and 26 Gbp/s).
+            uint8_t *dst = job_.chars_out + sl.b0;
+            if (!job_.out_pinned) {
+                S.out.ensure(bytes + 32);
+                dst = S.out.as<uint8_t>();
+            }
+            S.chars.ensure(((S.B.total + 15) / 16) * 16 + 16);
+            derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, job_.k, job_.threshold,
+                                          job_.format ? S.B.q.as<uint8_t>() : nullptr, S.chars.as<uint8_t>(), nullptr,
+                                          C.st_run, mx, &S.dt_work);
+            HIP_OK(hipEventRecord(S.computed, C.st_run));
+            HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
+            HIP_OK(hipMemcpyAsync(dst, S.chars.p, bytes, hipMemcpyDeviceToHost, C.st_down));
+            HIP_OK(hipEventRecord(S.done, C.st_down));
+        }
+        S.busy = true;
+        S.out_b0 = sl.b0;
+        S.out_bytes = bytes;
+    }
+
+    // ---- completing thread
+    // run lengths: the number of records of a slab is known once its kernels are done, so the download
+    // is issued here; it is issued for the next slab before the previous one is copied out, so that the
+    // copy engine and the host copy work on different slabs
+    void start_download(size_t turn)
+    {
+        if (!job_.sink) return;
+        HostSlot &S = slot(turn);
+        HostCtx &C = *C_;
+        HIP_OK(hipEventSynchronize(S.computed));
+        const uint32_t total = *S.rle_total_pin.as<uint32_t>();
+        if (total > S.rle_capacity) { // more runs than the speculative emit had room for
+            S.rle_capacity = (size_t)total + total / 4 + 16;
+            S.rles.ensure(S.rle_capacity * kRleWords * sizeof(uint32_t));
+            HIP_OK(kbo::launch_rle_emit(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)S.n_seqs,
+                                        (uint32_t)std::min<size_t>(job_.sink->max_gap_len, 0xFFFFFFFFu),
+                                        S.rle_scratch.as<uint32_t>(), S.rles.as<uint32_t>(), (uint32_t)S.rle_capacity,
+                                        C.st_down, S.longest));
+        }
+        const size_t words = kbo::chunk_items_scratch_words((uint32_t)S.n_seqs);
+        S.out.ensure(std::max<size_t>(16, (size_t)total * kRleWords * sizeof(uint32_t)));
+        S.rle_first_pin.ensure(words * sizeof(uint32_t));
+        if (total)
+            HIP_OK(hipMemcpyAsync(S.out.p, S.rles.p, (size_t)total * kRleWords * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                  C.st_down));
+        HIP_OK(hipMemcpyAsync(S.rle_first_pin.p, S.rle_scratch.p, words * sizeof(uint32_t), hipMemcpyDeviceToHost, C.st_down));
+        HIP_OK(hipEventRecord(S.done, C.st_down));
+        S.out_bytes = total; // records
+    }
+
+    void finish(size_t turn)
+    {
+        HostSlot &S = slot(turn);
+        RleSink *sink = job_.sink;
+        HIP_OK(hipEventSynchronize(S.done));
+        if (!sink) {
+            if (!job_.out_pinned) HostTeam::out().copy(job_.chars_out + S.out_b0, S.out.p, S.out_bytes);
+        } else {
+            const size_t total = S.out_bytes;
+            const uint32_t *local = S.rle_first_pin.as<uint32_t>(), *sums = local + S.n_seqs + 1;
+            if (job_.sink_direct) {
+                if (sink->all_used + total > sink->all_cap) {
+                    const size_t cap = (sink->all_used + total) * 2;
+                    kbo_rle *p = static_cast<kbo_rle *>(std::realloc(sink->all, cap * sizeof(kbo_rle)));
+                    if (!p) throw std::bad_alloc();
+                    sink->all = p;
+                    sink->all_cap = cap;
+                }
+                const size_t base = sink->all_used, s0 = (*job_.slabs)[S.slab_id].s0, ns_slab = S.n_seqs;
+                widen_rles(sink->all + base, S.out.as<uint32_t>(), total, HostTeam::out());
+                const size_t piece = 1u << 15;
+                HostTeam::out().run((ns_slab + piece - 1) / piece, [&](size_t t) {
+                    const size_t a = t * piece + 1, b = std::min(ns_slab, a + piece - 1);
+                    for (size_t q = a; q <= b; q++) sink->rle_offsets[s0 + q] = base + sums[q / 1024] + local[q];
+                });
+                sink->all_used += total;
+            } else {
+                std::vector<kbo_rle> &runs = sink->runs[S.slab_id];
+                runs.resize(total);
+                widen_rles(runs.data(), S.out.as<uint32_t>(), total, HostTeam::out());
+                std::vector<uint32_t> &first = sink->first[S.slab_id];
+                first.resize(S.n_seqs + 1);
+                for (size_t q = 0; q <= S.n_seqs; q++) first[q] = sums[q / 1024] + local[q];
+            }
+        }
+        S.busy = false;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            drained_++;
+        }
+        cv_.notify_all();
+    }
+
+    void drain_loop()
+    {
+        auto fail = [&](int code, const char *what) {
+            std::lock_guard<std::mutex> g(mu_);
+            drain_code_ = code;
+            drain_error_ = what;
+            drained_ = ~size_t(0) / 2; // releases the submitting thread
+            cv_.notify_all();
+        };
+        try {
+            HIP_OK(hipSetDevice(device_));
+            const size_t none = ~size_t(0);
+            size_t started = 0, pending = none;
+            for (;;) {
+                bool can_start;
+                {
+                    std::unique_lock<std::mutex> g(mu_);
+                    cv_.wait(g, [&] { return started < submitted_ || pending != none || stop_; });
+                    can_start = started < submitted_;
+                    if (!can_start && pending == none) return;
+                }
+                const size_t prev = pending;
+                pending = none;
+                if (can_start) {
+                    start_download(started);
+                    pending = started++;
+                }
+                if (prev != none) finish(prev);
+            }
+        } catch (const KboError &e) {
+            fail(e.code, e.what());
+        } catch (const std::bad_alloc &) {
+            fail(KBO_E_NOMEM, "out of host memory");
+        } catch (const std::exception &e) {
+            fail(KBO_E_HIP, e.what());
+        }
+    }
+
+    const BatchJob &job_;
+    const int device_;
+    const size_t first_, stride_;
+    const bool timed_;
+    HostCtx *C_ = nullptr;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    size_t submitted_ = 0, drained_ = 0;
+    bool stop_ = false;
+    int drain_code_ = KBO_OK;
+    std::string drain_error_;
+};
+
+} // namespace
+
 void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                         double max_error_prob, bool format, uint8_t *chars_out, RleSink *sink)
 {
@@ -369,249 +652,39 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
     KBO_REQUIRE(scan.shortest > 2, KBO_E_LEN_LE_2, "len > 2 (derandomize.rs:276, translate.rs:270)");
     clk.lap("argument checks");
     const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
-    // user buffers the DMA engines can reach directly are used in place, pageable ones are staged
-    const bool in_pinned = is_pinned_host(concat), out_pinned = sink || is_pinned_host(chars_out);
+    // one worker per device (index replicated on each, slabs dealt round-robin, disjoint output
+    // slices: no exchange between devices); a single device runs on the calling thread
+    std::vector<int> devices = g_devices;
+    if (devices.empty()) devices.push_back(current_device());
+    const size_t nd = std::min(devices.size(), std::max<size_t>(1, slabs.size()));
+    BatchJob job;
+    job.idx = idx;
+    job.concat = concat;
+    job.offsets = offsets;
+    job.k = (uint32_t)k;
+    job.threshold = (uint32_t)threshold;
+    job.format = format;
+    job.chars_out = chars_out;
+    job.sink = sink;
+    job.sink_direct = sink && nd == 1;
+    job.in_pinned = is_pinned_host(concat);
+    job.out_pinned = sink || is_pinned_host(chars_out);
+    job.slabs = &slabs;
+    job.clk = &clk;
     if (sink) {
         sink->runs.assign(slabs.size(), {});
         sink->first.assign(slabs.size(), {});
     }
-    const bool sink_direct = sink && (g_devices.size() <= 1 || slabs.size() <= 1);
-    if (sink_direct) { // room for 2 runs per sequence to start with (untouched pages cost nothing)
+    if (job.sink_direct) { // room for 2 runs per sequence to start with (untouched pages cost nothing)
         sink->all_cap = 2 * n_seqs + 1024;
         sink->all = static_cast<kbo_rle *>(std::malloc(sink->all_cap * sizeof(kbo_rle)));
         if (!sink->all) throw std::bad_alloc();
         sink->rle_offsets[0] = 0;
     }
     clk.lap("slab list");
-    // one worker per device (index replicated on each, slabs dealt round-robin, disjoint output
-    // slices: no exchange between devices); a single device runs on the calling thread
-    std::vector<int> devices = g_devices;
-    if (devices.empty()) devices.push_back(current_device());
-    const size_t nd = std::min(devices.size(), std::max<size_t>(1, slabs.size()));
-    HostTeam &team = HostTeam::get();
-    auto worker = [&](size_t w) {
-        HIP_OK(hipSetDevice(devices[w]));
-        CtxLease lease(devices[w]);
-        HostCtx &C = *lease.ctx;
-        // The calling thread stages and submits slabs; a second thread completes them in
-        // submission order (waits for the slab's event, copies the staged output to the user
-        // buffer), so the two host copies of a slab never queue behind each other.
-        std::mutex mu;
-        std::condition_variable cv;
-        size_t submitted = 0, drained = 0;
-        bool stop = false;
-        int drain_code = KBO_OK;
-        std::string drain_error;
-        std::thread drainer([&] {
-            try {
-                HIP_OK(hipSetDevice(devices[w]));
-                const size_t none = ~size_t(0);
-                // run lengths: the number of records of a slab is known once its kernels are done, so the
-                // download is issued here; it is issued for the next slab before the previous one is
-                // copied out, so that the copy engine and the host copy work on different slabs
-                auto start = [&](size_t turn) {
-                    if (!sink) return;
-                    HostSlot &S = C.slot[turn % kHostSlots];
-                    HIP_OK(hipEventSynchronize(S.computed));
-                    const uint32_t total = *S.rle_total_pin.as<uint32_t>();
-                    if (total > S.rle_capacity) { // more runs than the speculative emit had room for
-                        S.rle_capacity = (size_t)total + total / 4 + 16;
-                        S.rles.ensure(S.rle_capacity * kRleWords * sizeof(uint32_t));
-                        HIP_OK(kbo::launch_rle_emit(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)S.n_seqs,
-                                                    (uint32_t)std::min<size_t>(sink->max_gap_len, 0xFFFFFFFFu),
-                                                    S.rle_scratch.as<uint32_t>(), S.rles.as<uint32_t>(),
-                                                    (uint32_t)S.rle_capacity, C.st_down, S.longest));
-                    }
-                    const size_t words = kbo::chunk_items_scratch_words((uint32_t)S.n_seqs);
-                    S.out.ensure(std::max<size_t>(16, (size_t)total * kRleWords * sizeof(uint32_t)));
-                    S.rle_first_pin.ensure(words * sizeof(uint32_t));
-                    if (total)
-                        HIP_OK(hipMemcpyAsync(S.out.p, S.rles.p, (size_t)total * kRleWords * sizeof(uint32_t),
-                                              hipMemcpyDeviceToHost, C.st_down));
-                    HIP_OK(hipMemcpyAsync(S.rle_first_pin.p, S.rle_scratch.p, words * sizeof(uint32_t), hipMemcpyDeviceToHost, C.st_down));
-                    HIP_OK(hipEventRecord(S.done, C.st_down));
-                    S.out_bytes = total; // records
-                };
-                auto finish = [&](size_t turn) {
-                    HostSlot &S = C.slot[turn % kHostSlots];
-                    HIP_OK(hipEventSynchronize(S.done));
-                    if (!sink) {
-                        if (!out_pinned) HostTeam::out().copy(chars_out + S.out_b0, S.out.p, S.out_bytes);
-                    } else {
-                        const size_t total = S.out_bytes;
-                        const uint32_t *local = S.rle_first_pin.as<uint32_t>(), *sums = local + S.n_seqs + 1;
-                        if (sink_direct) {
-                            if (sink->all_used + total > sink->all_cap) {
-                                const size_t cap = (sink->all_used + total) * 2;
-                                kbo_rle *p = static_cast<kbo_rle *>(std::realloc(sink->all, cap * sizeof(kbo_rle)));
-                                if (!p) throw std::bad_alloc();
-                                sink->all = p;
-                                sink->all_cap = cap;
-                            }
-                            const size_t base = sink->all_used, s0 = slabs[S.slab_id].s0, ns_slab = S.n_seqs;
-                            widen_rles(sink->all + base, S.out.as<uint32_t>(), total, HostTeam::out());
-                            const size_t piece = 1u << 15;
-                            HostTeam::out().run((ns_slab + piece - 1) / piece, [&](size_t t) {
-                                const size_t a = t * piece + 1, b = std::min(ns_slab, a + piece - 1);
-                                for (size_t q = a; q <= b; q++) sink->rle_offsets[s0 + q] = base + sums[q / 1024] + local[q];
-                            });
-                            sink->all_used += total;
-                        } else {
-                            std::vector<kbo_rle> &runs = sink->runs[S.slab_id];
-                            runs.resize(total);
-                            widen_rles(runs.data(), S.out.as<uint32_t>(), total, HostTeam::out());
-                            std::vector<uint32_t> &first = sink->first[S.slab_id];
-                            first.resize(S.n_seqs + 1);
-                            for (size_t q = 0; q <= S.n_seqs; q++) first[q] = sums[q / 1024] + local[q];
-                        }
-                    }
-                    S.busy = false;
-                    {
-                        std::lock_guard<std::mutex> g(mu);
-                        drained++;
-                    }
-                    cv.notify_all();
-                };
-                size_t started = 0, pending = none;
-                for (;;) {
-                    bool can_start;
-                    {
-                        std::unique_lock<std::mutex> g(mu);
-                        cv.wait(g, [&] { return started < submitted || pending != none || stop; });
-                        can_start = started < submitted;
-                        if (!can_start && pending == none) return;
-                    }
-                    const size_t prev = pending;
-                    pending = none;
-                    if (can_start) {
-                        start(started);
-                        pending = started++;
-                    }
-                    if (prev != none) finish(prev);
-                }
-            } catch (const KboError &e) {
-                std::lock_guard<std::mutex> g(mu);
-                drain_code = e.code;
-                drain_error = e.what();
-                drained = ~size_t(0) / 2; // releases the submitting thread
-                cv.notify_all();
-            } catch (const std::exception &e) {
-                std::lock_guard<std::mutex> g(mu);
-                drain_code = KBO_E_HIP;
-                drain_error = e.what();
-                drained = ~size_t(0) / 2;
-                cv.notify_all();
-            }
-        });
-        auto join_drainer = [&] {
-            {
-                std::lock_guard<std::mutex> g(mu);
-                stop = true;
-            }
-            cv.notify_all();
-            if (drainer.joinable()) drainer.join();
-        };
-        try {
-            size_t turn = 0;
-            for (size_t i = w; i < slabs.size(); i += nd, turn++) {
-                const Slab &sl = slabs[i];
-                HostSlot &S = C.slot[turn % kHostSlots];
-                {
-                    std::unique_lock<std::mutex> g(mu);
-                    cv.wait(g, [&] { return turn < drained + kHostSlots; }); // the slot is free again
-                    if (drain_code != KBO_OK) break;
-                }
-                if (w == 0) clk.lap("  wait for a free slot");
-                const size_t ns = sl.s1 - sl.s0;
-                const uint64_t bytes = sl.b1 - sl.b0;
-                // stage: slab-relative offsets (and the longest sequence of the slab), query bytes
-                S.off.ensure((ns + 1) * sizeof(uint64_t));
-                uint64_t *off = S.off.as<uint64_t>();
-                const size_t piece = 1u << 15, n_tasks = (ns + 1 + piece - 1) / piece;
-                std::vector<uint64_t> longest(n_tasks, 0);
-                team.run(n_tasks, [&](size_t t) {
-                    const size_t a = t * piece, b = std::min(ns + 1, a + piece);
-                    uint64_t m = 0;
-                    for (size_t j = a; j < b; j++) {
-                        off[j] = offsets[sl.s0 + j] - sl.b0;
-                        if (j < ns) m = std::max(m, offsets[sl.s0 + j + 1] - offsets[sl.s0 + j]);
-                    }
-                    longest[t] = m;
-                });
-                const uint32_t mx = (uint32_t)*std::max_element(longest.begin(), longest.end());
-                const uint8_t *src = concat + sl.b0;
-                if (!in_pinned) {
-                    S.in.ensure(bytes);
-                    team.copy(S.in.p, src, bytes);
-                    src = S.in.as<uint8_t>();
-                }
-                if (w == 0) clk.lap("  offsets + copy in");
-                enqueue_walk_host(idx, src, off, ns, false, S.B, S.items, C.st_run, mx, C.st_up, S.copied);
-                if (sink) {
-                    // characters stay on the device; run lengths are counted, scanned and (speculatively, into
-                    // the room the slot has) emitted right behind A5/A6; the completing thread downloads them
-                    S.chars.ensure(((S.B.total + 15) / 16) * 16 + 32);
-                    derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, (uint32_t)k,
-                                                  (uint32_t)threshold, nullptr, S.chars.as<uint8_t>(), nullptr, C.st_run, mx, &S.dt_work);
-                    const uint32_t gap = (uint32_t)std::min<size_t>(sink->max_gap_len, 0xFFFFFFFFu);
-                    S.rle_scratch.ensure(kbo::chunk_items_scratch_words((uint32_t)ns) * sizeof(uint32_t));
-                    S.rle_total.ensure(16);
-                    S.rle_total_pin.ensure(16);
-                    if (S.rle_capacity < 2 * ns + 16) {
-                        S.rle_capacity = 2 * ns + 16;
-                        S.rles.ensure(S.rle_capacity * kRleWords * sizeof(uint32_t));
-                    }
-                    HIP_OK(kbo::launch_rle_count(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
-                                                 S.rle_scratch.as<uint32_t>(), S.rle_total.as<uint32_t>(), C.st_run, mx));
-                    HIP_OK(hipMemcpyAsync(S.rle_total_pin.p, S.rle_total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, C.st_run));
-                    HIP_OK(kbo::launch_rle_emit(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
-                                                S.rle_scratch.as<uint32_t>(), S.rles.as<uint32_t>(), (uint32_t)S.rle_capacity,
-                                                C.st_run, mx));
-                    S.longest = mx;
-                    HIP_OK(hipEventRecord(S.computed, C.st_run));
-                    HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
-                    S.slab_id = i;
-                    S.n_seqs = ns;
-                } else {
-                    // D2H leg: hipMemcpyAsync on the download stream.  With one stream per stage the copy
-                    // engines carry both directions at once (tools/bench_host.py: 37-40 Gbp/s host->host;
-                    // a small kernel storing into pinned memory, or A5/A6 storing there themselves, gave
-                    // 28 and 26 Gbp/s).
-                    uint8_t *dst = chars_out + sl.b0;
-                    if (!out_pinned) {
-                        S.out.ensure(bytes + 32);
-                        dst = S.out.as<uint8_t>();
-                    }
-                    S.chars.ensure(((S.B.total + 15) / 16) * 16 + 16);
-                    derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, (uint32_t)k,
-                                                  (uint32_t)threshold, format ? S.B.q.as<uint8_t>() : nullptr,
-                                                  S.chars.as<uint8_t>(), nullptr, C.st_run, mx, &S.dt_work);
-                    HIP_OK(hipEventRecord(S.computed, C.st_run));
-                    HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
-                    HIP_OK(hipMemcpyAsync(dst, S.chars.p, bytes, hipMemcpyDeviceToHost, C.st_down));
-                    HIP_OK(hipEventRecord(S.done, C.st_down));
-                }
-                S.busy = true;
-                S.out_b0 = sl.b0;
-                S.out_bytes = bytes;
-                {
-                    std::lock_guard<std::mutex> g(mu);
-                    submitted++;
-                }
-                cv.notify_all();
-                if (w == 0) clk.lap("  enqueue");
-            }
-        } catch (...) {
-            join_drainer();
-            throw;
-        }
-        join_drainer();
-        if (drain_code != KBO_OK) throw KboError(drain_code, drain_error);
-        if (w == 0) clk.lap("drain");
-    };
     if (nd == 1) {
         const int prev = current_device();
-        worker(0);
+        SlabWorker(job, devices[0], 0, 1, true).run();
         if (prev != devices[0]) HIP_OK(hipSetDevice(prev));
         return;
     }
@@ -621,7 +694,7 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
     for (size_t w = 0; w < nd; w++)
         threads.emplace_back([&, w] {
             try {
-                worker(w);
+                SlabWorker(job, devices[w], w, nd, w == 0).run();
             } catch (const KboError &e) {
                 codes[w] = e.code;
                 errors[w] = e.what();
