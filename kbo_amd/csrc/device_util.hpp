@@ -1,0 +1,111 @@
+// device_util.hpp — device-side helpers shared by the kernel files: unaligned 16-byte accesses,
+// partial block stores, and the two-level exclusive scan used for item lists and run lengths.
+#pragma once
+#include "kernels.hpp"
+
+namespace kbo {
+namespace {
+
+__device__ __forceinline__ uint4 ld16(const uint8_t *base, uint32_t byte_off)
+{
+    return *reinterpret_cast<const uint4 *>(base + byte_off);
+}
+// unaligned 16-byte load (gfx950 global loads accept any byte address)
+__device__ __forceinline__ uint4 ld16u(const uint8_t *base, uint32_t byte_off)
+{
+    uint4 v;
+    __builtin_memcpy(&v, base + byte_off, 16);
+    return v;
+}
+// unaligned stores
+#ifndef KBO_NT_STORE
+#define KBO_NT_STORE 1 // streaming stores: -4.5 % walk time on C2 (outputs are never re-read here)
+#endif
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4), aligned(1)));
+__device__ __forceinline__ void st16u(uint8_t *base, uint32_t byte_off, const uint4 &v)
+{
+#if KBO_NT_STORE
+    u32x4_t t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t *>(base + byte_off));
+#else
+    __builtin_memcpy(base + byte_off, &v, 16);
+#endif
+}
+__device__ __forceinline__ void st4u(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
+// store the first nb (1..15) bytes of a 16-byte block: whole words, then the trailing bytes
+__device__ __forceinline__ void st_partial(uint8_t *o, const uint4 &v, uint32_t nb)
+{
+#define KBO_ST_WORD(J, W)                                                                         \
+    if (nb >= 4u * (J) + 4u) st4u(o + 4u * (J), (W));                                             \
+    else {                                                                                        \
+        if (nb > 4u * (J) + 0u) o[4u * (J) + 0u] = (uint8_t)((W));                                 \
+        if (nb > 4u * (J) + 1u) o[4u * (J) + 1u] = (uint8_t)((W) >> 8);                            \
+        if (nb > 4u * (J) + 2u) o[4u * (J) + 2u] = (uint8_t)((W) >> 16);                           \
+    }
+    KBO_ST_WORD(0u, v.x)
+    KBO_ST_WORD(1u, v.y)
+    KBO_ST_WORD(2u, v.z)
+    KBO_ST_WORD(3u, v.w)
+#undef KBO_ST_WORD
+}
+
+// byte J (compile-time 0..15) of a 16-byte block held in registers
+template <int J> __device__ __forceinline__ uint32_t blk_byte(const uint4 &v)
+{
+    const uint32_t w = (J >> 2) == 0 ? v.x : (J >> 2) == 1 ? v.y : (J >> 2) == 2 ? v.z : v.w;
+    return (w >> ((J & 3) * 8)) & 0xFFu;
+}
+template <int J> __device__ __forceinline__ void blk_or_byte(uint4 &v, uint32_t x)
+{
+    const uint32_t sh = x << ((J & 3) * 8);
+    if ((J >> 2) == 0) v.x |= sh;
+    else if ((J >> 2) == 1) v.y |= sh;
+    else if ((J >> 2) == 2) v.z |= sh;
+    else v.w |= sh;
+}
+
+constexpr uint32_t kScanBlock = 1024; // values per block of the two-level scan
+
+// exclusive scan of `per` consecutive values per thread, 256 or 1024 threads per block, in place;
+// sums[blockIdx.x] = total of the block's values (when sums != nullptr)
+__global__ void scan_kernel(uint32_t *__restrict__ data, uint32_t n, uint32_t per, uint32_t *__restrict__ sums)
+{
+    __shared__ uint32_t sh[1024];
+    const uint32_t t = threadIdx.x, nt = blockDim.x;
+    const uint64_t base = ((uint64_t)blockIdx.x * nt + t) * per;
+    uint32_t local = 0;
+    for (uint32_t j = 0; j < per; j++)
+        if (base + j < n) local += data[base + j];
+    sh[t] = local;
+    __syncthreads();
+    for (uint32_t step = 1; step < nt; step <<= 1) { // Hillis-Steele inclusive scan of the thread sums
+        const uint32_t v = t >= step ? sh[t - step] : 0u;
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = sh[t] - local; // exclusive prefix of this thread inside the block
+    for (uint32_t j = 0; j < per; j++)
+        if (base + j < n) {
+            const uint32_t v = data[base + j];
+            data[base + j] = run;
+            run += v;
+        }
+    if (sums && t == nt - 1) sums[blockIdx.x] = sh[t];
+}
+
+
+} // namespace
+
+// two-level exclusive scan of n u32 in place (n <= 2^28): data[i] becomes the prefix inside its block of
+// kScanBlock values, sums[b] the prefix of block b; value = sums[i / kScanBlock] + data[i]
+inline hipError_t launch_scan(uint32_t *data, uint32_t n, uint32_t *sums, hipStream_t stream)
+{
+    const uint32_t nb = (n + kScanBlock - 1) / kScanBlock;
+    hipLaunchKernelGGL(scan_kernel, dim3(nb), dim3(256), 0, stream, data, n, kScanBlock / 256, sums);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, sums, nb, (nb + 1023) / 1024, (uint32_t *)nullptr);
+    return hipGetLastError();
+}
+
+} // namespace kbo

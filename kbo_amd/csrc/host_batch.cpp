@@ -1,6 +1,6 @@
 // host_batch.cpp — host batches: work decomposition, slabs, pinned staging with helper threads, the
 // three-stage (upload / kernels / download) pipeline with pooled per-device scratch, and the
-// run-length sink of kbo_find_batch.  No compute here: kernels live in ms_kernels.hip.
+// run-length sink of kbo_find_batch.  No compute here: kernels live in the *_kernels.hip files.
 #include "capi_internal.hpp"
 
 #include <chrono>

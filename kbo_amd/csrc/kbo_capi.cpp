@@ -2,7 +2,7 @@
 //
 // Host logic only: argument checks mirroring the reference's asserts, index ownership,
 // device-memory plumbing and kernel launches.  All matching-statistics / derandomize /
-// translate compute happens in ms_kernels.hip; nothing here falls back to the CPU.
+// translate / run-length compute happens in the *_kernels.hip files; nothing here falls back to the CPU.
 #include "../../include/kbo_hip.h"
 
 #include <hip/hip_runtime.h>

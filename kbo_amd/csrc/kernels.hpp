@@ -1,4 +1,4 @@
-// kernels.hpp — launch interface of the gfx950 kernels (ms_kernels.hip).
+// kernels.hpp — launch interface of the gfx950 kernels (walk_kernels.hip, derand_kernels.hip, rle_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -49,7 +49,7 @@ hipError_t launch_make_items(const uint64_t *d_offsets, uint32_t n_seqs, WalkIte
 size_t chunk_items_scratch_words(uint32_t n_seqs);
 hipError_t launch_make_chunk_items(const uint64_t *d_offsets, uint32_t n_seqs, uint32_t chunk, uint32_t k,
                                    uint32_t n_slots, WalkItem *d_items, uint32_t *d_scratch, hipStream_t stream);
-// format::run_lengths_gapped over a batch of translated sequences (see ms_kernels.hip); records are 7 u32
+// format::run_lengths_gapped over a batch of translated sequences (see rle_kernels.hip); records are 7 u32
 // {start, end, matches, mismatches, jumps, gap_bases, gap_opens}; after launch_rle_count the first-run index of
 // sequence s is d_scratch[n_seqs + 1 + s / 1024] + d_scratch[s] and *d_total the number of runs
 hipError_t launch_rle_count(const uint8_t *d_chars, const uint64_t *d_offsets, uint32_t n_seqs, uint32_t max_gap_len,
