@@ -218,6 +218,13 @@ int kbo_map_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offse
  * run lengths are computed on the device (the translated characters never leave it). */
 int kbo_find_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                    const kbo_find_opts *opts, kbo_rle **rles, uint64_t *rle_offsets);
+/* The same into caller-owned memory (buffers reused from call to call cost no page faults): `rles`
+ * holds `capacity` records; *n_runs receives the number of runs of the batch.  When that exceeds
+ * `capacity` the call fails with KBO_E_NOMEM after filling rle_offsets and *n_runs (records beyond
+ * the capacity are not written), so a second call with a large enough buffer succeeds. */
+int kbo_find_batch_into(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                        const kbo_find_opts *opts, kbo_rle *rles, size_t capacity, uint64_t *rle_offsets,
+                        size_t *n_runs);
 
 /* ------------------------------------------------------------------ device-resident path
  * Everything already in the HBM of the current device; kernels are enqueued on `stream`

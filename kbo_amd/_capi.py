@@ -76,7 +76,7 @@ SYMBOLS = [
     "kbo_map", "kbo_find", "kbo_run_lengths_gapped", "kbo_relative_to_ref", "kbo_free",
     "kbo_ms_batch", "kbo_matches_batch", "kbo_map_batch", "kbo_find_batch", "kbo_work_bytes",
     "kbo_ms_batch_dev", "kbo_derand_translate_dev", "kbo_walk_geometry",
-    "kbo_set_walk_waves_per_cu", "kbo_set_walk_threads", "kbo_set_walk_rare", "kbo_set_slab_bytes", "kbo_set_force_big_layout", "kbo_set_devices", "kbo_set_host_threads", "kbo_release_scratch", "kbo_set_pair_steps", "kbo_run_lengths_gapped_batch", "kbo_derand_work_bytes", "kbo_run_lengths_work_bytes", "kbo_run_lengths_dev", "kbo_index_device_pair_bytes",
+    "kbo_set_walk_waves_per_cu", "kbo_set_walk_threads", "kbo_set_walk_rare", "kbo_set_slab_bytes", "kbo_set_force_big_layout", "kbo_set_devices", "kbo_set_host_threads", "kbo_release_scratch", "kbo_set_pair_steps", "kbo_run_lengths_gapped_batch", "kbo_find_batch_into", "kbo_derand_work_bytes", "kbo_run_lengths_work_bytes", "kbo_run_lengths_dev", "kbo_index_device_pair_bytes",
 ]
 
 _lib = None
@@ -155,6 +155,7 @@ def lib():
     L.kbo_release_scratch.argtypes = []
     L.kbo_set_pair_steps.argtypes = [C.c_uint64, C.c_int]
     L.kbo_run_lengths_gapped_batch.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.kbo_find_batch_into.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp, vp]
     L.kbo_run_lengths_work_bytes.argtypes = [sz]; L.kbo_run_lengths_work_bytes.restype = sz
     L.kbo_run_lengths_dev.argtypes = [vp, vp, sz, sz, sz, vp, vp, sz, vp]
     L.kbo_index_device_pair_bytes.argtypes = [vp]

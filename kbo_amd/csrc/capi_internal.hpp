@@ -79,10 +79,12 @@ struct RleSink {
     // one device: slabs complete in order, so their records go straight into the result array
     kbo_rle *all = nullptr;
     size_t all_cap = 0, all_used = 0;
+    bool caller_owns = false; // `all` is the caller's buffer of all_cap records: never grown; all_used keeps counting
+    bool direct = false;      // set by matches_batch_impl: one worker, records went straight into `all`
     // several devices: slabs complete out of order, kept per slab and put together at the end
     std::vector<std::vector<kbo_rle>> runs;
     std::vector<std::vector<uint32_t>> first; // index of the first run of each sequence of the slab, +1 entry
-    ~RleSink() { std::free(all); }
+    ~RleSink() { if (!caller_owns) std::free(all); }
 };
 constexpr size_t kRleWords = 7; // device run-length records are seven u32; kbo_rle has the reference's usize fields
 

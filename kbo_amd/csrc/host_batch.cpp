@@ -547,7 +547,7 @@ private:
             const size_t total = S.out_bytes;
             const uint32_t *local = S.rle_first_pin.as<uint32_t>(), *sums = local + S.n_seqs + 1;
             if (job_.sink_direct) {
-                if (sink->all_used + total > sink->all_cap) {
+                if (sink->all_used + total > sink->all_cap && !sink->caller_owns) {
                     const size_t cap = (sink->all_used + total) * 2;
                     kbo_rle *p = static_cast<kbo_rle *>(std::realloc(sink->all, cap * sizeof(kbo_rle)));
                     if (!p) throw std::bad_alloc();
@@ -555,7 +555,8 @@ private:
                     sink->all_cap = cap;
                 }
                 const size_t base = sink->all_used, s0 = (*job_.slabs)[S.slab_id].s0, ns_slab = S.n_seqs;
-                widen_rles(sink->all + base, S.out.as<uint32_t>(), total, HostTeam::out());
+                if (base + total <= sink->all_cap) // a caller's buffer that is too small only gets the count
+                    widen_rles(sink->all + base, S.out.as<uint32_t>(), total, HostTeam::out());
                 const size_t piece = 1u << 15;
                 HostTeam::out().run((ns_slab + piece - 1) / piece, [&](size_t t) {
                     const size_t a = t * piece + 1, b = std::min(ns_slab, a + piece - 1);
@@ -675,12 +676,13 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
         sink->runs.assign(slabs.size(), {});
         sink->first.assign(slabs.size(), {});
     }
-    if (job.sink_direct) { // room for 2 runs per sequence to start with (untouched pages cost nothing)
+    if (job.sink_direct && !sink->caller_owns) { // room for 2 runs per sequence to start with (untouched pages cost nothing)
         sink->all_cap = 2 * n_seqs + 1024;
         sink->all = static_cast<kbo_rle *>(std::malloc(sink->all_cap * sizeof(kbo_rle)));
         if (!sink->all) throw std::bad_alloc();
-        sink->rle_offsets[0] = 0;
     }
+    if (sink) sink->direct = job.sink_direct;
+    if (job.sink_direct) sink->rle_offsets[0] = 0;
     clk.lap("slab list");
     if (nd == 1) {
         const int prev = current_device();

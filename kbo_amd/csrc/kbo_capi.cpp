@@ -690,35 +690,70 @@ int kbo_relative_to_ref(const uint8_t *ref_seq, const uint8_t *aln, size_t len, 
     });
 }
 
+namespace {
+// kbo::find over a batch (lib.rs:815-820: matches, then run_lengths_gapped per sequence; both on the device,
+// slab by slab).  into == false: the record array is library-allocated and handed back through *rles_out;
+// into == true: records go to the caller's `buf` of `capacity` records (none are written beyond it).
+// Returns the number of runs of the batch.
+size_t find_batch_impl(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                       const kbo_find_opts *opts, bool into, kbo_rle *buf, size_t capacity, kbo_rle **rles_out,
+                       uint64_t *rle_offsets)
+{
+    kbo_find_opts o;
+    if (opts) o = *opts; else kbo_find_opts_default(&o);
+    RleSink sink;
+    sink.max_gap_len = o.max_gap_len;
+    sink.rle_offsets = rle_offsets;
+    if (into) {
+        sink.caller_owns = true;
+        sink.all = buf;
+        sink.all_cap = buf ? capacity : 0;
+    }
+    matches_batch_impl(idx, concat, offsets, n_seqs, o.max_error_prob, false, nullptr, &sink);
+    if (sink.direct) { // one device: the records are already in place
+        if (!into) {
+            *rles_out = sink.all;
+            sink.all = nullptr;
+        }
+        return sink.all_used;
+    }
+    // several devices: slabs completed out of order and were kept per slab; put them together
+    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
+    std::vector<uint64_t> base(slabs.size() + 1, 0);
+    for (size_t i = 0; i < slabs.size(); i++) base[i + 1] = base[i] + sink.runs[i].size();
+    kbo_rle *all = buf;
+    if (!into) {
+        all = static_cast<kbo_rle *>(std::malloc(std::max<uint64_t>(1, base.back()) * sizeof(kbo_rle)));
+        if (!all) throw std::bad_alloc();
+    }
+    const bool fits = !into || (buf && base.back() <= capacity);
+    rle_offsets[0] = 0;
+    HostTeam::get().run(slabs.size(), [&](size_t i) {
+        if (fits && !sink.runs[i].empty()) std::memcpy(all + base[i], sink.runs[i].data(), sink.runs[i].size() * sizeof(kbo_rle));
+        const size_t ns = slabs[i].s1 - slabs[i].s0;
+        for (size_t q = 1; q <= ns; q++) rle_offsets[slabs[i].s0 + q] = base[i] + sink.first[i][q];
+    });
+    if (!into) *rles_out = all;
+    return base.back();
+}
+} // namespace
+
 int kbo_find_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                    const kbo_find_opts *opts, kbo_rle **rles, uint64_t *rle_offsets)
 {
     return guarded([&] {
         KBO_REQUIRE(idx && rles && rle_offsets, KBO_E_BAD_ARG, "null argument");
-        kbo_find_opts o;
-        if (opts) o = *opts; else kbo_find_opts_default(&o);
-        // lib.rs:815-820: matches, then run_lengths_gapped per sequence; both on the device, slab by slab
-        RleSink sink;
-        sink.max_gap_len = o.max_gap_len;
-        sink.rle_offsets = rle_offsets;
-        matches_batch_impl(idx, concat, offsets, n_seqs, o.max_error_prob, false, nullptr, &sink);
-        if (sink.all) { // one device: the records are already in place
-            *rles = sink.all;
-            sink.all = nullptr;
-            return;
-        }
-        const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
-        std::vector<uint64_t> base(slabs.size() + 1, 0);
-        for (size_t i = 0; i < slabs.size(); i++) base[i + 1] = base[i] + sink.runs[i].size();
-        kbo_rle *all = static_cast<kbo_rle *>(std::malloc(std::max<uint64_t>(1, base.back()) * sizeof(kbo_rle)));
-        if (!all) throw std::bad_alloc();
-        rle_offsets[0] = 0;
-        HostTeam::get().run(slabs.size(), [&](size_t i) {
-            if (!sink.runs[i].empty()) std::memcpy(all + base[i], sink.runs[i].data(), sink.runs[i].size() * sizeof(kbo_rle));
-            const size_t ns = slabs[i].s1 - slabs[i].s0;
-            for (size_t q = 1; q <= ns; q++) rle_offsets[slabs[i].s0 + q] = base[i] + sink.first[i][q];
-        });
-        *rles = all;
+        find_batch_impl(idx, concat, offsets, n_seqs, opts, false, nullptr, 0, rles, rle_offsets);
+    });
+}
+
+int kbo_find_batch_into(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                        const kbo_find_opts *opts, kbo_rle *rles, size_t capacity, uint64_t *rle_offsets, size_t *n_runs)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && (rles || capacity == 0) && rle_offsets && n_runs, KBO_E_BAD_ARG, "null argument");
+        *n_runs = find_batch_impl(idx, concat, offsets, n_seqs, opts, true, rles, capacity, nullptr, rle_offsets);
+        KBO_REQUIRE(*n_runs <= capacity, KBO_E_NOMEM, "rles holds fewer records than the batch has runs (*n_runs says how many)");
     });
 }
 
