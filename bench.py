@@ -95,10 +95,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # KBO_BENCH_ONE_GPU=1: functional test of the multi-process path on a single-GPU box (all ranks share
+    # cuda:0 and rendezvous over gloo); numbers from such a run mean nothing
+    one_gpu = os.environ.get("KBO_BENCH_ONE_GPU") == "1"
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)  # RCCL; used for barrier + max only
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)  # RCCL; used for barrier + max only
 
     if args.waves_per_cu:
         kbo_amd.lib().kbo_set_walk_waves_per_cu(args.waves_per_cu)
