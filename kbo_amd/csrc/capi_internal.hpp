@@ -113,6 +113,9 @@ void widen_rles(kbo_rle *dst, const uint32_t *src, size_t n, HostTeam &team);
 // characters are turned into run lengths on the device instead of being downloaded (lib.rs:816-820)
 void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                         double max_error_prob, bool format, uint8_t *chars_out, RleSink *sink = nullptr);
+// A1 over a host batch: MS values, and intervals when lo/hi are given
+void ms_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, uint8_t *d_out,
+                   uint32_t *lo_out, uint32_t *hi_out);
 void release_host_scratch(); // frees the pooled per-device scratch of the host batch entry points
 
 } // namespace kbo_host

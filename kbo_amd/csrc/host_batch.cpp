@@ -209,7 +209,7 @@ constexpr int kHostSlots = 4;
 struct HostSlot {
     BatchOnDevice B;
     DevBuf chars;
-    PinBuf in, out, off;
+    PinBuf in, out, off, lo_pin, hi_pin;
     std::vector<kbo::WalkItem> items;
     hipEvent_t copied = nullptr, computed = nullptr, done = nullptr;
     bool busy = false;     // a slab is in flight in this slot
@@ -358,8 +358,10 @@ struct BatchJob {
     const uint64_t *offsets;
     uint32_t k, threshold;
     bool format;         // apply format::relative_to_ref
-    uint8_t *chars_out;  // nullptr when a sink takes run lengths instead
+    uint8_t *chars_out;  // nullptr when a sink takes run lengths instead, or in ms mode
     RleSink *sink;
+    uint8_t *ms_out = nullptr;             // ms mode: A1 only, the MS values come back ...
+    uint32_t *lo_out = nullptr, *hi_out = nullptr; // ... with the intervals when these are given
     bool sink_direct;    // one worker: records go straight into sink->all
     bool in_pinned, out_pinned; // user buffers the DMA engines reach directly are used in place
     const std::vector<Slab> *slabs;
@@ -456,8 +458,29 @@ private:
             src = S.in.as<uint8_t>();
         }
         lap("  offsets + copy in");
-        enqueue_walk_host(job_.idx, src, off, ns, false, S.B, S.items, C.st_run, mx, C.st_up, S.copied);
-        if (job_.sink) {
+        enqueue_walk_host(job_.idx, src, off, ns, job_.lo_out != nullptr, S.B, S.items, C.st_run, mx, C.st_up, S.copied);
+        if (job_.ms_out) { // A1 only: MS values (and intervals) straight back
+            HIP_OK(hipEventRecord(S.computed, C.st_run));
+            HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
+            uint8_t *dst = job_.ms_out + sl.b0;
+            uint32_t *dlo = job_.lo_out ? job_.lo_out + sl.b0 : nullptr, *dhi = job_.hi_out ? job_.hi_out + sl.b0 : nullptr;
+            if (!job_.out_pinned) {
+                S.out.ensure(bytes + 32);
+                dst = S.out.as<uint8_t>();
+                if (dlo) {
+                    S.lo_pin.ensure(bytes * sizeof(uint32_t));
+                    S.hi_pin.ensure(bytes * sizeof(uint32_t));
+                    dlo = S.lo_pin.as<uint32_t>();
+                    dhi = S.hi_pin.as<uint32_t>();
+                }
+            }
+            HIP_OK(hipMemcpyAsync(dst, S.B.ms.p, bytes, hipMemcpyDeviceToHost, C.st_down));
+            if (dlo) {
+                HIP_OK(hipMemcpyAsync(dlo, S.B.lo.p, bytes * sizeof(uint32_t), hipMemcpyDeviceToHost, C.st_down));
+                HIP_OK(hipMemcpyAsync(dhi, S.B.hi.p, bytes * sizeof(uint32_t), hipMemcpyDeviceToHost, C.st_down));
+            }
+            HIP_OK(hipEventRecord(S.done, C.st_down));
+        } else if (job_.sink) {
             // characters stay on the device; run lengths are counted, scanned and (speculatively, into
             // the room the slot has) emitted right behind A5/A6; the completing thread downloads them
             S.chars.ensure(((S.B.total + 15) / 16) * 16 + 32);
@@ -541,7 +564,15 @@ private:
         HostSlot &S = slot(turn);
         RleSink *sink = job_.sink;
         HIP_OK(hipEventSynchronize(S.done));
-        if (!sink) {
+        if (job_.ms_out) {
+            if (!job_.out_pinned) {
+                HostTeam::out().copy(job_.ms_out + S.out_b0, S.out.p, S.out_bytes);
+                if (job_.lo_out) {
+                    HostTeam::out().copy(job_.lo_out + S.out_b0, S.lo_pin.p, S.out_bytes * sizeof(uint32_t));
+                    HostTeam::out().copy(job_.hi_out + S.out_b0, S.hi_pin.p, S.out_bytes * sizeof(uint32_t));
+                }
+            }
+        } else if (!sink) {
             if (!job_.out_pinned) HostTeam::out().copy(job_.chars_out + S.out_b0, S.out.p, S.out_bytes);
         } else {
             const size_t total = S.out_bytes;
@@ -631,6 +662,36 @@ private:
     std::string drain_error_;
 };
 
+// one worker per device (index replicated on each, slabs dealt round-robin, disjoint output slices: no
+// exchange between devices); a single device runs on the calling thread
+void run_on_devices(const BatchJob &job, const std::vector<int> &devices, size_t nd)
+{
+    if (nd == 1) {
+        const int prev = current_device();
+        SlabWorker(job, devices[0], 0, 1, true).run();
+        if (prev != devices[0]) HIP_OK(hipSetDevice(prev));
+        return;
+    }
+    std::vector<std::thread> threads;
+    std::vector<std::string> errors(nd);
+    std::vector<int> codes(nd, KBO_OK);
+    for (size_t w = 0; w < nd; w++)
+        threads.emplace_back([&, w] {
+            try {
+                SlabWorker(job, devices[w], w, nd, w == 0).run();
+            } catch (const KboError &e) {
+                codes[w] = e.code;
+                errors[w] = e.what();
+            } catch (const std::exception &e) {
+                codes[w] = KBO_E_HIP;
+                errors[w] = e.what();
+            }
+        });
+    for (auto &t : threads) t.join();
+    for (size_t w = 0; w < nd; w++)
+        if (codes[w] != KBO_OK) throw KboError(codes[w], errors[w]);
+}
+
 } // namespace
 
 void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
@@ -653,8 +714,6 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
     KBO_REQUIRE(scan.shortest > 2, KBO_E_LEN_LE_2, "len > 2 (derandomize.rs:276, translate.rs:270)");
     clk.lap("argument checks");
     const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
-    // one worker per device (index replicated on each, slabs dealt round-robin, disjoint output
-    // slices: no exchange between devices); a single device runs on the calling thread
     std::vector<int> devices = g_devices;
     if (devices.empty()) devices.push_back(current_device());
     const size_t nd = std::min(devices.size(), std::max<size_t>(1, slabs.size()));
@@ -684,30 +743,47 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
     if (sink) sink->direct = job.sink_direct;
     if (job.sink_direct) sink->rle_offsets[0] = 0;
     clk.lap("slab list");
-    if (nd == 1) {
-        const int prev = current_device();
-        SlabWorker(job, devices[0], 0, 1, true).run();
-        if (prev != devices[0]) HIP_OK(hipSetDevice(prev));
-        return;
-    }
-    std::vector<std::thread> threads;
-    std::vector<std::string> errors(nd);
-    std::vector<int> codes(nd, KBO_OK);
-    for (size_t w = 0; w < nd; w++)
-        threads.emplace_back([&, w] {
-            try {
-                SlabWorker(job, devices[w], w, nd, w == 0).run();
-            } catch (const KboError &e) {
-                codes[w] = e.code;
-                errors[w] = e.what();
-            } catch (const std::exception &e) {
-                codes[w] = KBO_E_HIP;
-                errors[w] = e.what();
-            }
-        });
-    for (auto &t : threads) t.join();
-    for (size_t w = 0; w < nd; w++)
-        if (codes[w] != KBO_OK) throw KboError(codes[w], errors[w]);
+    run_on_devices(job, devices, nd);
+}
+
+// A1 over a host batch: MS values (and intervals) only
+void ms_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, uint8_t *d_out,
+                   uint32_t *lo_out, uint32_t *hi_out)
+{
+    KBO_REQUIRE(idx && d_out, KBO_E_BAD_ARG, "null argument");
+    KBO_REQUIRE((lo_out == nullptr) == (hi_out == nullptr), KBO_E_BAD_ARG, "lo/hi must come together");
+    KBO_REQUIRE(concat && offsets, KBO_E_BAD_ARG, "null concat/offsets");
+    KBO_REQUIRE(n_seqs > 0, KBO_E_EMPTY_QUERY, "no sequences");
+    KBO_REQUIRE(n_seqs < 0xFFFFFFFFull, KBO_E_UNSUPPORTED, "more than 2^32-1 sequences per call");
+    KBO_REQUIRE(offsets[0] == 0, KBO_E_BAD_ARG, "offsets[0] must be 0");
+    const OffsetScan scan = scan_offsets(offsets, n_seqs);
+    KBO_REQUIRE(scan.monotone, KBO_E_BAD_ARG, "offsets not monotone");
+    KBO_REQUIRE(scan.shortest > 0, KBO_E_EMPTY_QUERY, "empty query (index.rs:248 assert!(!query.is_empty()))");
+    KBO_REQUIRE(scan.longest < 0xFFFFFFFFull, KBO_E_UNSUPPORTED, "sequence longer than 2^32-1");
+    PhaseClock clk;
+    // intervals cost 8 more bytes per base on the device and on the way back: smaller slabs
+    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, lo_out ? std::max<size_t>(1u << 16, g_slab_bytes / 4) : g_slab_bytes);
+    std::vector<int> devices = g_devices;
+    if (devices.empty()) devices.push_back(current_device());
+    const size_t nd = std::min(devices.size(), std::max<size_t>(1, slabs.size()));
+    BatchJob job;
+    job.idx = idx;
+    job.concat = concat;
+    job.offsets = offsets;
+    job.k = idx->host.k;
+    job.threshold = 0;
+    job.format = false;
+    job.chars_out = nullptr;
+    job.sink = nullptr;
+    job.sink_direct = false;
+    job.ms_out = d_out;
+    job.lo_out = lo_out;
+    job.hi_out = hi_out;
+    job.in_pinned = is_pinned_host(concat);
+    job.out_pinned = is_pinned_host(d_out) && (!lo_out || (is_pinned_host(lo_out) && is_pinned_host(hi_out)));
+    job.slabs = &slabs;
+    job.clk = &clk;
+    run_on_devices(job, devices, nd);
 }
 
 void release_host_scratch()

@@ -374,29 +374,7 @@ int kbo_random_match_threshold(size_t k, size_t n_kmers, size_t alphabet_size, d
 int kbo_ms_batch(kbo_index_t *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                  uint8_t *d_out, uint32_t *lo_out, uint32_t *hi_out)
 {
-    return guarded([&] {
-        KBO_REQUIRE(idx && d_out, KBO_E_BAD_ARG, "null argument");
-        KBO_REQUIRE((lo_out == nullptr) == (hi_out == nullptr), KBO_E_BAD_ARG, "lo/hi must come together");
-        check_batch(concat, offsets, n_seqs);
-        hipStream_t stream = nullptr;
-        // intervals cost 8 more bytes per base on the device: smaller slabs
-        const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, lo_out ? g_slab_bytes / 4 : g_slab_bytes);
-        std::vector<uint64_t> off;
-        for (const Slab &sl : slabs) {
-            const size_t ns = sl.s1 - sl.s0;
-            off.resize(ns + 1);
-            for (size_t j = 0; j <= ns; j++) off[j] = offsets[sl.s0 + j] - sl.b0;
-            BatchOnDevice B;
-            std::vector<kbo::WalkItem> items;
-            enqueue_walk_host(idx, concat + sl.b0, off.data(), ns, lo_out != nullptr, B, items, stream);
-            HIP_OK(hipMemcpyAsync(d_out + sl.b0, B.ms.p, B.total, hipMemcpyDeviceToHost, stream));
-            if (lo_out) {
-                HIP_OK(hipMemcpyAsync(lo_out + sl.b0, B.lo.p, B.total * 4, hipMemcpyDeviceToHost, stream));
-                HIP_OK(hipMemcpyAsync(hi_out + sl.b0, B.hi.p, B.total * 4, hipMemcpyDeviceToHost, stream));
-            }
-            HIP_OK(hipStreamSynchronize(stream));
-        }
-    });
+    return guarded([&] { ms_batch_impl(idx, concat, offsets, n_seqs, d_out, lo_out, hi_out); });
 }
 
 int kbo_matching_statistics(kbo_index_t *idx, const uint8_t *query, size_t len, uint64_t *d, uint64_t *lo,

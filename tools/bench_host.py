@@ -26,6 +26,17 @@ for slab_mb in [int(x) for x in os.environ.get('SLABS', '32,64,128,256').split('
         kbo_amd.check(L.kbo_map_batch(sbwt._h, concat.ctypes.data, offsets.ctypes.data, R, 1e-7, 1, out.ctypes.data))
         best = min(best, time.perf_counter() - t0)
     print(f"slab {slab_mb:4d} MiB: {R * 150 / best / 1e9:6.2f} Gbp/s host->host ({best * 1e3:.1f} ms for {R * 150 / 1e6:.0f} Mbp)", flush=True)
+    if os.environ.get("MS"):  # A1 only: MS values back, then MS values + intervals
+        d = np.zeros(len(concat), dtype=np.uint8)
+        lo = np.zeros(len(concat), dtype=np.uint32)
+        hi = np.zeros(len(concat), dtype=np.uint32)
+        for what, a, b in (("ms", None, None), ("ms + intervals", lo.ctypes.data, hi.ctypes.data)):
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                kbo_amd.check(L.kbo_ms_batch(sbwt._h, concat.ctypes.data, offsets.ctypes.data, R, d.ctypes.data, a, b))
+                best = min(best, time.perf_counter() - t0)
+            print(f"{what:>15s}: {R * 150 / best / 1e9:6.2f} Gbp/s host->host ({best * 1e3:.1f} ms)", flush=True)
     if os.environ.get("FIND"):  # kbo::find: run lengths come back instead of characters
         import ctypes as C
         from kbo_amd import _capi
