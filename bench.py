@@ -74,7 +74,13 @@ def cpu_baseline_leg(args, genome, concat, offsets, gpu_d, gpu_chars, sbwt=None)
     c = ctr.as_dict()
     b_alg = (64.0 * c["rank_blocks"] + 1.0 * c["lcs_reads"]) / c["bases"] + 2.0
     exact = bool(np.array_equal(d, gpu_d[:n1 * L]) and np.array_equal(chars, gpu_chars[:n1 * L]))
+    # single-thread rate of the same restatement (SURVEY.md section 8(d) asks for both), on a ~1 s sample
+    ns = int(max(1, min(n1, 2_000_000 // L)))
+    t0 = time.perf_counter()
+    oi.matches_batch(concat[:ns * L], offsets[:ns + 1], 1e-7, n_threads=1)
+    single = ns * L / max(time.perf_counter() - t0, 1e-6) / 1e6
     base = {"value": round(n1 * L / dt / 1e6, 3), "unit": "Mbp/s", "cores": cores, "kind": "port",
+            "single_thread_value": round(single, 3),
             "sample": f"first {n1} of the {args.reads} reads ({n1 * L / 1e6:.1f} Mbp) x {passes} passes, "
                       f"oracle/kbo_oracle.c matches_batch on {cores} threads, {dt * passes:.1f} s wall "
                       f"({dt * passes * cores:.0f} core-seconds)"}
