@@ -68,7 +68,7 @@ __device__ __forceinline__ uint32_t decode_base(uint32_t ch)
 // depth and the contraction machinery takes it down to the root (d = 0, I = [0,n)), which is
 // what the loop above does.
 //
-// The kernel is instruction-issue bound on L2-resident indexes and line-fill bound beyond
+// The kernel is bound by the L2 request pipeline on L2-resident indexes and by line fills beyond
 // (DESIGN.md section 6), so it is one loop with
 //   a hot path (every iteration, lanes not blocked): two 16-byte loads per lane - rank blocks
 //             for extending lanes, contraction entries for contracting ones, two-base blocks
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
         flags |= F_PF;
     }
 
-    uint32_t dbg_rare = 0, dbg_con = 0, dbg_iter = 0, dbg_ext = 0, dbg_fail = 0;
+    uint32_t dbg_rare = 0, dbg_con = 0, dbg_iter = 0, dbg_ext = 0, dbg_fail = 0, dbg_wait = 0, dbg_fin = 0;
     for (;;) {
         // ================================ rare block ================================
         // entered every rare_period iterations: the hot loop below carries no item bookkeeping at
@@ -207,6 +207,10 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
 #pragma unroll 1
         for (uint32_t it = 0; it < a.rare_period; it++) {
         dbg_iter++;
+#ifdef KBO_WALK_DEBUG
+        dbg_wait += (flags & F_DONE) && !(flags & F_FIN) ? 1u : 0u; // finished an item, waiting for the bookkeeping visit
+        dbg_fin += (flags & F_FIN) ? 1u : 0u;                       // out of items, waiting for the wave to end
+#endif
         // ================================= hot path =================================
         // A lane is either extending (two rank blocks) or contracting (two contraction
         // entries {lcs, psv, nsv}); both kinds of load go through the same two load sites and
@@ -339,9 +343,11 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
         atomicAdd(a.hi_out + 4, dbg_ext);
         atomicAdd(a.hi_out + 5, dbg_fail);
         atomicAdd(a.hi_out + 6, dbg_con);
+        atomicAdd(a.hi_out + 7, dbg_wait);
+        atomicAdd(a.hi_out + 8, dbg_fin);
     }
 #endif
-    (void)dbg_rare; (void)dbg_con; (void)dbg_iter; (void)lane; (void)dbg_ext; (void)dbg_fail;
+    (void)dbg_wait; (void)dbg_fin; (void)dbg_rare; (void)dbg_con; (void)dbg_iter; (void)lane; (void)dbg_ext; (void)dbg_fail;
 }
 
 __global__ void make_items_kernel(const uint64_t *__restrict__ off, uint32_t n_seqs,
