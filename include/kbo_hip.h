@@ -282,6 +282,14 @@ int kbo_release_scratch(void);
  * min_rows rows (default 24 Mi; 0 = always, UINT64_MAX = never; applies to device copies made after
  * the call), used by the walk from matches at least min_depth deep (default 16; < 0 keeps it). */
 int kbo_set_pair_steps(uint64_t min_rows, int min_depth);
+/* Plan-guided walk for MS-only batches (kbo_amd/csrc/plan_kernels.hip): device copies made while it is enabled
+ * (default) carry a path cover of the index's de Bruijn graph (9 B per row) and kbo_ms_batch[_dev] / kbo_matches_batch /
+ * kbo_map_batch / kbo_find_batch skip the stretches of every read that match it; results are identical either way.
+ * enabled < 0 keeps the setting; seed_depth (default 14) / seed_cap (default 40, at most 48) tune the diagonal search,
+ * <= 0 keeps them. */
+int kbo_set_plan(int enabled, int seed_depth, int seed_cap);
+/* bytes of path cover a device copy of this index carries (0 = none) */
+uint64_t kbo_index_device_plan_bytes(const kbo_index_t *idx);
 int kbo_set_force_big_layout(int on);            /* tests: force the 64-bit-offset contraction-entry layout */
 int kbo_set_slab_bytes(size_t bytes);            /* host batches are processed in slabs of at most this many query bytes (default 32 MiB) */
 

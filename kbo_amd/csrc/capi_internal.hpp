@@ -21,6 +21,7 @@ struct DevCopy {
     uint64_t n_blocks = 0;
     bool big = false;
     uint32_t pair_off = 0; // arena index of the two-base extension blocks, 0 = none
+    DevBuf pc_text, pc_pos, pc_node; // path cover (sbwt_index.hpp PathCover), empty when the plan-guided walk is off
 };
 
 } // namespace kbo_host
@@ -29,7 +30,7 @@ struct kbo_index {
     kbo::HostIndex host;
     std::mutex mu;
     std::map<int, kbo_host::DevCopy *> dev;
-    uint64_t rank_bytes = 0, lcs_bytes = 0;
+    uint64_t rank_bytes = 0, lcs_bytes = 0, plan_bytes = 0;
     ~kbo_index()
     {
         for (auto &kv : dev) delete kv.second;
@@ -44,11 +45,15 @@ extern std::vector<int> g_devices;   // devices the host batch entry points spre
 extern bool g_force_big;             // tests: use the 64-bit-offset entry layout regardless of size
 extern uint64_t g_pair_min_rows;     // indexes with at least this many rows get two-base blocks on the device
 extern size_t g_slab_bytes;          // host batches are cut into slabs of at most this many query bytes
+extern bool g_plan_enabled;          // device copies carry a path cover and MS-only batches take the plan-guided walk
 
 // ---- device_index.cpp
 int current_device();
 kbo::DevIndexView device_view(kbo_index *idx, int device); // uploads the index on first use
 int walk_max_waves();                                     // upper bound on resident walk waves: CUs x waves per CU
+// points a.gitems / a.glist into `plan_work` (>= kbo::plan_work_bytes(n_items) bytes, 16-byte aligned) when the index
+// view carries a path cover and the launch wants MS values only; otherwise leaves them null (plain walk)
+void attach_plan(kbo::WalkArgs &a, void *plan_work);
 
 // ---- A3 (kbo_capi.cpp): derandomize.rs:91-145
 double log_rm_max_cdf(size_t t, size_t alphabet_size, size_t n_kmers);
@@ -56,11 +61,11 @@ size_t random_match_threshold(size_t k, size_t n_kmers, size_t alphabet_size, do
 
 // ---- host_batch.cpp
 struct BatchOnDevice {
-    DevBuf q, off, items, ms, lo, hi;
+    DevBuf q, off, items, ms, lo, hi, plan;
     uint64_t total = 0;
     void release()
     {
-        for (DevBuf *b : {&q, &off, &items, &ms, &lo, &hi}) b->release();
+        for (DevBuf *b : {&q, &off, &items, &ms, &lo, &hi, &plan}) b->release();
     }
 };
 struct Slab {

@@ -7,6 +7,7 @@ namespace kbo_host {
 int g_waves_per_cu = 0;
 bool g_force_big = false;
 uint64_t g_pair_min_rows = 24ull << 20;
+bool g_plan_enabled = true;
 
 int current_device()
 {
@@ -63,6 +64,18 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
             dc->n_blocks = lay.n_blocks;
             idx->rank_bytes = per * 4;
             idx->lcs_bytes = ent_bytes;
+            if (g_plan_enabled) { // path cover for the plan-guided walk: 9 bytes per row
+                kbo::PathCover pc;
+                kbo::make_path_cover(idx->host, pc);
+                static_assert(kbo::PathCover::kPad == kbo::kPlanPad, "text padding");
+                dc->pc_text.alloc(pc.text.size() + 16);
+                dc->pc_pos.alloc(pc.pos.size() * 4 + 16);
+                dc->pc_node.alloc(pc.node_at.size() * 4 + 16);
+                HIP_OK(hipMemcpy(dc->pc_text.p, pc.text.data(), pc.text.size(), hipMemcpyHostToDevice));
+                HIP_OK(hipMemcpy(dc->pc_pos.p, pc.pos.data(), pc.pos.size() * 4, hipMemcpyHostToDevice));
+                HIP_OK(hipMemcpy(dc->pc_node.p, pc.node_at.data(), pc.node_at.size() * 4, hipMemcpyHostToDevice));
+                idx->plan_bytes = pc.text.size() + pc.pos.size() * 4 + pc.node_at.size() * 4;
+            }
         } catch (...) {
             delete dc;
             if (prev != device) (void)hipSetDevice(prev);
@@ -81,7 +94,40 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
     v.big = dc->big ? 1u : 0u;
     v.n = (uint32_t)idx->host.n_sets;
     v.k = idx->host.k;
+    v.pc_text = dc->pc_text.p ? dc->pc_text.as<uint8_t>() + kbo::kPlanPad : nullptr;
+    v.pc_pos = dc->pc_pos.as<uint32_t>();
+    v.pc_node = dc->pc_node.as<uint32_t>();
+    for (int c = 0; c < 4; c++) v.C[c] = (uint32_t)idx->host.C[c];
+    v.C[4] = v.n;
     return v;
+}
+
+void attach_plan(kbo::WalkArgs &a, void *plan_work)
+{
+    a.gitems = nullptr;
+    a.glist = nullptr;
+    a.ucount = a.usums = a.qctl = nullptr;
+    a.redo = nullptr;
+    a.units = nullptr;
+    a.n_items_dev = nullptr;
+    a.unit_cap = a.plan_dmin = a.plan_cap = a.plan_gap = a.plan_chunk = 0;
+    if (!g_plan_enabled || !plan_work || !a.ix.pc_text || (a.lo_out && a.hi_out) || a.n_items == 0) return;
+    uint8_t *w = static_cast<uint8_t *>(plan_work);
+    const size_t ni = a.n_items;
+    a.gitems = reinterpret_cast<kbo::GuidedItem *>(w);
+    w += ni * sizeof(kbo::GuidedItem);
+    a.unit_cap = (uint32_t)std::min<size_t>(kbo::plan_unit_cap(ni, a.q_bytes), 0xFFFFFF00u);
+    a.units = reinterpret_cast<kbo::WalkUnit *>(w);
+    w += (size_t)a.unit_cap * sizeof(kbo::WalkUnit);
+    a.glist = reinterpret_cast<uint16_t *>(w);
+    w += (ni * kbo::kPlanList * 2 + 15) / 16 * 16;
+    a.ucount = reinterpret_cast<uint32_t *>(w);
+    w += (2 * ni + 1) * 4;
+    a.usums = reinterpret_cast<uint32_t *>(w);
+    w += (ni / 512 + 4) * 4;
+    a.qctl = reinterpret_cast<uint32_t *>(w);
+    w += 64;
+    a.redo = w;
 }
 
 // upper bound on resident walk waves: CUs x waves per CU (default 32 = 8 per SIMD)

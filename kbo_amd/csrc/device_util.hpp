@@ -65,6 +65,29 @@ template <int J> __device__ __forceinline__ void blk_or_byte(uint4 &v, uint32_t 
     else v.w |= sh;
 }
 
+// Rank inside one 16-byte block { base, w0, w1, w2 }: base + popcount of the o lowest of
+// the 96 row bits, 0 <= o < 96.  One 64-bit shift builds the "bits to drop" masks of all
+// three words: X = ~0 << (o mod 64) is the drop mask of (w0,w1) when o < 64 and of w2
+// when o >= 64.
+__device__ __forceinline__ uint32_t rank_eval(const uint4 &b, uint32_t o)
+{
+    const uint64_t X = ~0ull << (o & 63u);
+    const uint32_t xl = (uint32_t)X, xh = (uint32_t)(X >> 32);
+    const bool big = o >= 64u;
+    const uint32_t d0 = big ? 0u : xl, d1 = big ? 0u : xh, d2 = big ? xl : ~0u;
+    return b.x + __popc(b.y & ~d0) + __popc(b.z & ~d1) + __popc(b.w & ~d2);
+}
+
+__device__ __forceinline__ uint32_t div96(uint32_t i) { return __umulhi(i, 0xAAAAAAABu) >> 6; }
+
+// 'A','C','G','T' -> 0..3, anything else -> 4 (sbwt's DNA alphabet is exactly ACGT)
+__device__ __forceinline__ uint32_t decode_base(uint32_t ch)
+{
+    uint32_t c = ((ch >> 1) & 3u) ^ ((ch >> 2) & 1u);
+    uint32_t back = (0x54474341u >> (8 * c)) & 0xFFu;
+    return back == ch ? c : 4u;
+}
+
 constexpr uint32_t kScanBlock = 1024; // values per block of the two-level scan
 
 // exclusive scan of `per` consecutive values per thread, 256 or 1024 threads per block, in place;

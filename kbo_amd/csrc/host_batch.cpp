@@ -132,6 +132,8 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
     a.d_out = B.ms.as<uint8_t>();
     a.lo_out = want_ival ? B.lo.as<uint32_t>() : nullptr;
     a.hi_out = want_ival ? B.hi.as<uint32_t>() : nullptr;
+    if (view.pc_text && !want_ival) B.plan.ensure(kbo::plan_work_bytes(n_items, total));
+    attach_plan(a, view.pc_text && !want_ival ? B.plan.p : nullptr);
     HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), stream));
 }
 

@@ -751,12 +751,14 @@ int kbo_find(kbo_index_t *idx, const uint8_t *query, size_t len, const kbo_find_
 
 void kbo_free(void *p) { std::free(p); }
 
+int g_plan_dmin_shadow = 14, g_plan_cap_shadow = 40;
+
 namespace {
 // work buffer of kbo_ms_batch_dev: items, then the scan scratch of the chunked item list
 struct DevWork {
     bool chunked;
     uint32_t chunk, n_slots;
-    size_t bytes;
+    size_t bytes, plan_off;
 };
 DevWork dev_work(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k)
 {
@@ -767,6 +769,9 @@ DevWork dev_work(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32
     w.n_slots = (uint32_t)std::min<uint64_t>(slots, 0xFFFFFFFFu);
     w.bytes = std::max<uint64_t>(1, slots) * sizeof(kbo::WalkItem);
     if (w.chunked) w.bytes += kbo::chunk_items_scratch_words((uint32_t)n_seqs) * sizeof(uint32_t) + 16;
+    w.bytes = (w.bytes + 15) / 16 * 16;
+    w.plan_off = w.bytes; // work of the plan-guided walk behind it
+    w.bytes += kbo::plan_work_bytes(std::max<uint64_t>(1, slots), total_bases);
     return w;
 }
 } // namespace
@@ -815,6 +820,7 @@ int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *
         a.d_out = d_ms_out;
         a.lo_out = d_lo_out;
         a.hi_out = d_hi_out;
+        attach_plan(a, static_cast<uint8_t *>(d_work) + w.plan_off);
         HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), s));
     });
 }
@@ -906,6 +912,20 @@ int kbo_set_pair_steps(uint64_t min_rows, int min_depth)
     if (min_depth >= 0) kbo::set_pair_min_depth(min_depth);
     return KBO_OK;
 }
+
+int kbo_set_plan(int enabled, int seed_depth, int seed_cap)
+{
+    if (enabled >= 0) g_plan_enabled = enabled != 0; // launches from now on; path covers of device copies made from now on
+    extern int g_plan_dmin_shadow, g_plan_cap_shadow;
+    if (seed_depth > 0) g_plan_dmin_shadow = seed_depth;
+    if (seed_cap > 0) g_plan_cap_shadow = seed_cap;
+    kbo::set_plan_params(g_plan_dmin_shadow, g_plan_cap_shadow);
+    if (const char *e = std::getenv("KBO_PLAN_GAP")) kbo::set_plan_params(0, 0, std::atoi(e), 0);   // experiments
+    if (const char *e = std::getenv("KBO_PLAN_CHUNK")) kbo::set_plan_params(0, 0, 0, std::atoi(e));
+    return KBO_OK;
+}
+
+uint64_t kbo_index_device_plan_bytes(const kbo_index_t *idx) { return idx ? idx->plan_bytes : 0; }
 
 int kbo_set_force_big_layout(int on)
 {

@@ -16,6 +16,11 @@ struct DevIndexView {
     uint32_t big;         // 1: entries are addressed with 64-bit offsets (n_sets * 12 B >= 4 GiB)
     uint32_t n;           // n_sets
     uint32_t k;
+    // path cover of the de Bruijn graph (sbwt_index.hpp PathCover), nullptr when the device copy has none:
+    const uint8_t *pc_text;    // points at text position 0; kPlanPad zero bytes on either side
+    const uint32_t *pc_pos;    // row -> text position
+    const uint32_t *pc_node;   // text position -> row
+    uint32_t C[5];             // C[c] of the index, C[4] = n_sets: extend(root, c) = [C[c], C[c+1])
 };
 
 // One unit of walk work: `len` bases starting at absolute offset `start` of the
@@ -25,6 +30,45 @@ struct alignas(16) WalkItem {
     uint64_t start;
     uint32_t len;
     uint32_t warm;
+};
+
+// ---- plan-guided walk (plan_kernels.hip) -------------------------------------------------------------------------
+// plan_kernel finds, for every work item, a diagonal of the path-cover text (a short exact walk over the item's first
+// bases to a single row u: diagonal p0 = pos[u] - j), compares the whole item with the text on that diagonal, writes the
+// MS values this predicts - min(k, distance to the last mismatch) - and the list of mismatch positions.
+// plan_emit_kernel turns the lists into UNITS: stretches that have to be walked, one per group of mismatches closer
+// than `plan_gap`, starting on the diagonal in front of the group's first mismatch.  ms_walk_guided_kernel walks every
+// unit until the walk itself proves it is back on the diagonal (a single-row interval whose depth equals the distance
+// to the group's last mismatch); a unit that reaches the next group first flags its item, and flagged items are
+// walked again in full by the plain kernel.  Every value that is not walked is exact: see path_cover.cpp.
+constexpr uint32_t kPlanPad = 64;        // zero bytes in front of / behind the device text (== PathCover::kPad)
+constexpr uint32_t kPlanList = 12;       // u16 list entries per item after the first (13 mismatch positions in all)
+constexpr uint32_t kPlanNone = 0xFF;     // GuidedItem::n_mm: no diagonal found, walk the item plainly
+constexpr uint32_t kPlanInf = 0xFFFE;    // GuidedItem::mm0: no mismatch
+struct alignas(16) GuidedItem {
+    uint32_t start;   // absolute offset of the item's first base in the query buffer (< 4 GiB per launch)
+    uint32_t p0;      // text position of item base 0 on the diagonal (mod 2^32)
+    uint16_t len;     // bases, warm-up included
+    uint16_t j_conv;  // > 0: the item's first j_conv bases match the diagonal and were walked exactly by plan_kernel
+    uint16_t mm0;     // first mismatch position (kPlanInf: none)
+    uint8_t warm;     // leading bases without output
+    uint8_t n_mm;     // kPlanNone, or min(mismatches, 254); more than kPlanList + 1: the list is incomplete
+};
+enum : uint32_t { kUnitHead = 1u, kUnitPlain = 2u, kUnitToEnd = 4u };
+struct alignas(16) WalkUnit { // 32 bytes
+    uint32_t start;    // as GuidedItem
+    uint32_t p0;
+    uint16_t pos;      // first base the unit walks (item-relative)
+    uint16_t out_from; // first base it writes
+    int16_t last_mm;   // last mismatch of its group (-1: none, head of an item without early mismatches)
+    uint16_t bound;    // one past the last base it may walk: the next group's first mismatch, or the item's length
+    uint8_t d_start;   // depth of the walk in front of `pos` (units that start on the diagonal)
+    uint8_t flags;     // kUnitHead: starts at the root; kUnitPlain: no convergence test (chunk of an item without a
+                       // plan: k-1 warm-up bases from the root); kUnitToEnd: bound is the item's end
+    uint8_t warm;      // as GuidedItem (positions of the output words)
+    uint8_t pad0;
+    uint32_t item;     // work item it belongs to (for the redo flag)
+    uint32_t pad1[2];
 };
 
 struct WalkArgs {
@@ -39,7 +83,31 @@ struct WalkArgs {
     uint8_t *d_out;        // 1 byte per base, same indexing as q
     uint32_t *lo_out;      // optional (nullptr): interval start per base
     uint32_t *hi_out;      // optional: interval end per base
+    // plan-guided walk (all or none): work buffers sized by plan_work_bytes(), see attach_plan()
+    GuidedItem *gitems;    // nullptr: plain walk
+    uint16_t *glist;       // kPlanList entries per item
+    uint32_t *ucount;      // units per item, heavy ones then light ones (2 n_items + 1 entries), scanned in place
+    uint32_t *usums;       // block sums of that scan
+    uint8_t *redo;         // per item: 1 = a unit could not vouch for its successor, walk the item again in full
+    WalkUnit *units;       // unit_cap records (items whose units do not fit are flagged for the full walk instead)
+    uint32_t unit_cap;
+    uint32_t *qctl;        // [0] queue head of the guided walk
+    uint32_t plan_dmin;    // plan_kernel: a seed must be this deep (capped at k) before its row is trusted
+    uint32_t plan_cap;     // plan_kernel: seed iterations before an item is given up as unplanned
+    uint32_t plan_gap;     // plan_emit_kernel: mismatches closer than this share a unit (>= 2)
+    uint32_t plan_chunk;   // plan_emit_kernel: bases per unit of an item without a plan
+    const uint32_t *n_items_dev; // plain kernel: nullptr, or where the number of items is (the redo pass: qctl + 1)
 };
+// capacity of the unit array and bytes of plan work for a launch of n_items items over total_bases bases
+inline size_t plan_unit_cap(size_t n_items, uint64_t total_bases) { return 3 * n_items + total_bases / 64 + 64; }
+inline size_t plan_work_bytes(size_t n_items, uint64_t total_bases)
+{
+    return n_items * (sizeof(GuidedItem) + kPlanList * 2) + (2 * n_items + 1 + n_items / 512 + 8) * 4 +
+           (n_items + 15) / 16 * 16 + plan_unit_cap(n_items, total_bases) * sizeof(WalkUnit) + 256;
+}
+hipError_t launch_plan(const WalkArgs &a, hipStream_t stream);
+hipError_t launch_ms_walk_guided(WalkArgs a, uint32_t grid, uint32_t threads, hipStream_t stream);
+void set_plan_params(int dmin, int cap, int gap = 0, int chunk = 0); // tuning (<= 0 keeps): seed depth / seed iterations, unit gap / chunk
 
 // offsets (n_seqs+1) -> one item per sequence
 hipError_t launch_make_items(const uint64_t *d_offsets, uint32_t n_seqs, WalkItem *d_items,

@@ -1,0 +1,594 @@
+// plan_kernels.hip — gfx950 (MI355X, CDNA4): the plan-guided form of A1 (sbwt::StreamingIndex::matching_statistics,
+// called at reference index.rs:251-252) for batches that ask for the MS values only.
+//
+//   plan_kernel            per work item: a diagonal of the path-cover text, the mismatches of the item against it,
+//                          the MS values this predicts
+//   plan_emit_kernel       mismatch lists -> units (the stretches that have to be walked)
+//   ms_walk_guided_kernel  the extend / contract walk of walk_kernels.hip over the units: from the first mismatch of
+//                          a group until the walk itself proves it is back on the diagonal; everything else keeps
+//                          the predicted value
+//
+// Why the skipped values are exact (path_cover.cpp has the graph side): if the walk's interval is the single row
+// node_at[p] at depth d and the next base equals text[p+1], the reference's step gives the single row node_at[p+1]
+// at depth min(d+1, k).  A walk state (d, [l, l+1)) with d == min(k, distance to the last mismatch against the
+// diagonal) has a suffix of d bases that equals the text, so l IS the diagonal's node; from there to the next
+// mismatch nothing but such steps happens.  Whatever plan_kernel decides (which diagonal, or none) therefore only
+// changes how much is walked, never a value.
+//
+// Integer / byte work only: no MFMA.  Wavefront = 64 lanes; one lane per work item (plan, emit) or per unit (walk).
+#include "device_util.hpp"
+
+#include <algorithm>
+
+namespace kbo {
+namespace {
+
+// bit t (0..3) set where byte t of x is non-zero
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x)
+{
+    const uint32_t m = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; // bit 7 of every non-zero byte
+    return ((m >> 7) * 0x01020408u) >> 24;                                     // gathered into bits 0..3
+}
+
+__device__ __forceinline__ uint32_t sel4(const uint4 &v, uint32_t w)
+{
+    const uint32_t lo = (w & 1u) ? v.y : v.x, hi = (w & 1u) ? v.w : v.z;
+    return (w & 2u) ? hi : lo;
+}
+
+// stores bytes [lo, hi) of a 16-byte block to o + lo .. o + hi (0 <= lo <= hi <= 16)
+__device__ __forceinline__ void st_range(uint8_t *o, const uint4 &v, uint32_t lo, uint32_t hi)
+{
+    for (uint32_t t = lo; t < hi; t++) o[t] = (uint8_t)(sel4(v, t >> 2) >> ((t & 3u) * 8u));
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// plan_kernel: one lane per item, the wave in lock step.
+//  1. seed: extend from the root over the item's first bases; when an extension fails, start again from the root
+//     with the failing base (no contraction: only a diagonal is wanted, not the MS of these bases).  Done when the
+//     interval is a single row at depth >= dmin; given up after `cap` bases.
+//  2. compare the whole item with text[p0 ..], p0 = pos[row] - j; a text byte of 0 (path start, padding) matches
+//     nothing.  Predicted MS of base t = min(k, t - last mismatch at or before t) (0 at a mismatch: the guided walk
+//     always walks those itself); mismatch positions go to the item's list.
+//  3. j_conv: when the seed never restarted and nothing mismatches up to its end, the seed WAS the exact walk of
+//     those bases and ended on the diagonal's node, so the guided walk may start at the first mismatch.
+__global__ __launch_bounds__(256) void plan_kernel(WalkArgs a)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = a.ix.n, k = a.ix.k, nblk = a.ix.n_blocks, null_blk = 4u * nblk;
+    const uint8_t *arena = reinterpret_cast<const uint8_t *>(a.ix.arena);
+    const uint8_t *qb = a.q;
+    uint32_t start = 0, len = 0, warm = 0;
+    const bool have_item = idx < a.n_items;
+    if (have_item) {
+        const uint4 it = ld16(reinterpret_cast<const uint8_t *>(a.items), idx * 16u);
+        start = it.x; // launches cover < 4 GiB of query: the high word of WalkItem::start is 0
+        len = it.z;
+        warm = it.w;
+    }
+    const bool plannable = have_item && len > 0;
+    const uint32_t dmin = max(1u, min(k, a.plan_dmin & 0xFFFFu)), cap = a.plan_cap;
+
+    // ---- 1. seed
+    uint32_t l = 0, r = n, d = 0, j = 0, j0 = 0;
+    bool clean = true, seeded = false;
+    uint4 qblk = make_uint4(0, 0, 0, 0);
+    if (plannable) qblk = ld16u(qb, start);
+    for (;;) {
+        const bool act = plannable && !seeded && j < len && j < cap;
+        if (__ballot(act) == 0) break;
+        if (act) {
+            const uint32_t ch = (sel4(qblk, (j >> 2) & 3u) >> ((j & 3u) * 8u)) & 0xFFu;
+            const uint32_t c = decode_base(ch);
+            const uint32_t cbk = c < 4u ? c * nblk : null_blk, bmask = c < 4u ? ~0u : 0u;
+            const uint32_t bl = div96(l), br = div96(r);
+            const uint4 xA = ld16(arena, (cbk + (bl & bmask)) << 4), xB = ld16(arena, (cbk + (br & bmask)) << 4);
+            uint32_t l2 = rank_eval(xA, l - bl * kRankRows), r2 = rank_eval(xB, r - br * kRankRows);
+            uint32_t dbase = d;
+            if (l2 >= r2) { // start again from the root with this base: extend(root, c) = [C[c], C[c+1])
+                clean = false;
+                dbase = 0;
+                l2 = c == 0 ? a.ix.C[0] : c == 1 ? a.ix.C[1] : c == 2 ? a.ix.C[2] : c == 3 ? a.ix.C[3] : 0u;
+                r2 = c == 0 ? a.ix.C[1] : c == 1 ? a.ix.C[2] : c == 2 ? a.ix.C[3] : c == 3 ? a.ix.C[4] : 0u;
+            }
+            const bool ok = l2 < r2;
+            l = ok ? l2 : 0u;
+            r = ok ? r2 : n;
+            d = ok ? min(dbase + 1u, k) : 0u;
+            if (r == l + 1u && d >= dmin) {
+                seeded = true;
+                j0 = j;
+            }
+            j++;
+            if ((j & 15u) == 0u && !seeded) qblk = ld16u(qb, start + j); // stays within the 16-byte slack behind the queries
+        }
+    }
+    uint32_t p0 = 0;
+    if (seeded) p0 = a.ix.pc_pos[l] - j0;
+
+    // ---- 2. compare + predict
+    const uint8_t *tb = a.ix.pc_text - kPlanPad; // start of the padded text buffer
+    uint16_t *list = a.glist + (size_t)idx * kPlanList;
+    int32_t i_last = -1;
+    uint32_t cnt = 0, mm0 = kPlanInf;
+    // 64 bases per step: the four query blocks, the four text blocks and the four output blocks of a step go out
+    // back to back, so that every 128-byte line they touch is fetched (written) once, not once per 16 bytes - with
+    // thousands of waves in flight a line does not survive in L2 from one step to the next
+    for (uint32_t base0 = 0;; base0 += 64u) {
+        const bool act = seeded && base0 < len && !(a.plan_dmin & 0x20000u); // EXPERIMENT: bit 17 = no compare
+        if (__ballot(act) == 0) break;
+        if (act) {
+            uint4 qv[4], tv[4], pv[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const uint32_t base = base0 + 16u * g;
+                qv[g] = tv[g] = make_uint4(0, 0, 0, 0);
+                if (base < len) {
+                    qv[g] = ld16u(qb, start + base);
+                    const uint32_t u = p0 + base + kPlanPad; // offset into the padded buffer (mod 2^32)
+                    if (u <= n + 2u * kPlanPad - 16u) __builtin_memcpy(&tv[g], tb + u, 16);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const uint32_t base = base0 + 16u * g;
+                if (base < len) {
+                    const uint32_t nb = min(16u, len - base);
+                    uint32_t mm = (nonzero_bytes(qv[g].x ^ tv[g].x) | (nonzero_bytes(tv[g].x) ^ 0xFu)) |
+                                  ((nonzero_bytes(qv[g].y ^ tv[g].y) | (nonzero_bytes(tv[g].y) ^ 0xFu)) << 4) |
+                                  ((nonzero_bytes(qv[g].z ^ tv[g].z) | (nonzero_bytes(tv[g].z) ^ 0xFu)) << 8) |
+                                  ((nonzero_bytes(qv[g].w ^ tv[g].w) | (nonzero_bytes(tv[g].w) ^ 0xFu)) << 12);
+                    mm &= (1u << nb) - 1u;
+                    uint4 o4 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 16; t++) {
+                        i_last = ((mm >> t) & 1u) ? (int32_t)(base + t) : i_last;
+                        const uint32_t val = min((uint32_t)((int32_t)(base + t) - i_last), k);
+                        const uint32_t sh = val << ((t & 3) * 8);
+                        if ((t >> 2) == 0) o4.x |= sh;
+                        else if ((t >> 2) == 1) o4.y |= sh;
+                        else if ((t >> 2) == 2) o4.z |= sh;
+                        else o4.w |= sh;
+                    }
+                    pv[g] = o4;
+                    while (mm) { // the item's mismatch list: entry 0 in the item record, entries 1..12 in the list
+                        const uint32_t pos = base + (uint32_t)__ffs((int)mm) - 1u;
+                        if (cnt == 0) mm0 = pos;
+                        else if (cnt <= kPlanList) list[cnt - 1u] = (uint16_t)pos;
+                        cnt++;
+                        mm &= mm - 1u;
+                    }
+                }
+            }
+            if (!(a.plan_dmin & 0x10000u)) { // EXPERIMENT: bit 16 = no stores
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const uint32_t base = base0 + 16u * g;
+                    if (base < len) {
+                        const uint32_t nb = min(16u, len - base);
+                        const uint32_t lo = warm > base ? min(warm - base, 16u) : 0u;
+                        uint8_t *o = a.d_out + (start + base);
+                        if (lo == 0 && nb == 16u) __builtin_memcpy(o, &pv[g], 16); // (plain store: the four blocks of a step merge in L2)
+                        else st_range(o, pv[g], lo, nb);
+                    }
+                }
+            }
+        }
+    }
+    if (!have_item) return;
+    const uint32_t j_conv = (seeded && clean && (cnt == 0 || mm0 > j0)) ? j0 + 1u : 0u;
+    const uint32_t n_mm = seeded ? min(cnt, 254u) : kPlanNone;
+    uint4 g;
+    g.x = start;
+    g.y = p0;
+    g.z = (len & 0xFFFFu) | (j_conv << 16);
+    g.w = (mm0 & 0xFFFFu) | ((warm & 0xFFu) << 16) | (n_mm << 24);
+    *reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(a.gitems) + (size_t)idx * 16u) = g;
+    a.redo[idx] = 0;
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// Units of one item, from its record and mismatch list; EMIT = false only counts them (same code, so that the
+// counts the scan is built from are the counts the second pass writes).
+//  * item without a plan (no diagonal, or more mismatches than the list holds): chunks of `chunk` output bases, each
+//    walked from the root k-1 bases upstream (MS depends on the last k bases only), no convergence test;
+//  * otherwise one unit per group of mismatches closer than `gap` (>= 2, so that the base in front of a group's first
+//    mismatch is a match and the diagonal's node there is the walk's state once the previous group has converged);
+//    the first group of an item whose first bases were not walked exactly by plan_kernel starts at base 0 from the root.
+// Units come in two weights, heavy ones (chunks, the head of an item, groups that span more than a few bases) first
+// in the queue: the longest units then start early instead of stretching the end of the launch.
+// Returns heavy | light << 16.
+template <bool EMIT>
+__device__ __forceinline__ uint32_t make_units(const uint4 &g, const uint16_t *list, uint32_t k, uint32_t gap, uint32_t chunk,
+                                               uint32_t item, WalkUnit *out_heavy, WalkUnit *out_light)
+{
+    const uint32_t len = g.z & 0xFFFFu, j_conv = g.z >> 16, mm0 = g.w & 0xFFFFu, warm = (g.w >> 16) & 0xFFu, n_mm = g.w >> 24;
+    if (len == 0) return 0;
+    uint32_t nh = 0, nl = 0;
+    auto put = [&](uint32_t pos, uint32_t out_from, int32_t last_mm, uint32_t bound, uint32_t d_start, uint32_t flags) {
+        const bool heavy = (flags & (kUnitPlain | kUnitHead)) || last_mm - (int32_t)pos > 8;
+        WalkUnit *out = heavy ? out_heavy : out_light;
+        uint32_t &nu = heavy ? nh : nl;
+        if (EMIT) {
+            uint4 w0, w1;
+            w0.x = g.x;
+            w0.y = g.y;
+            w0.z = pos | (out_from << 16);
+            w0.w = ((uint32_t)last_mm & 0xFFFFu) | (bound << 16);
+            w1.x = d_start | (flags << 8) | (warm << 16);
+            w1.y = item;
+            w1.z = w1.w = 0;
+            uint4 *o = reinterpret_cast<uint4 *>(out + nu);
+            o[0] = w0;
+            o[1] = w1;
+        }
+        nu++;
+    };
+    if (n_mm == kPlanNone || n_mm > kPlanList + 1u) {
+        for (uint32_t c0 = warm; c0 < len; c0 += chunk) {
+            const uint32_t bound = min(len, c0 + chunk);
+            put(c0 > k - 1u ? c0 - (k - 1u) : 0u, c0, -1, bound, 0u, kUnitHead | kUnitPlain | (bound == len ? kUnitToEnd : 0u));
+        }
+        return nh | (nl << 16);
+    }
+    auto mm_at = [&](uint32_t t) -> uint32_t { return t == 0 ? mm0 : (uint32_t)list[t - 1u]; };
+    uint32_t t = 0;
+    int32_t prev = -1;
+    bool head = j_conv == 0;
+    while (head || t < n_mm) {
+        uint32_t pos = 0, d_start = 0, flags = head ? kUnitHead : 0u;
+        int32_t last = -1;
+        if (!head) {
+            pos = mm_at(t);
+            d_start = min((uint32_t)((int32_t)pos - 1 - prev), k);
+            last = prev = (int32_t)pos;
+            t++;
+        }
+        head = false;
+        while (t < n_mm && (int32_t)mm_at(t) - last < (int32_t)gap) {
+            last = prev = (int32_t)mm_at(t);
+            t++;
+        }
+        const uint32_t bound = t < n_mm ? mm_at(t) : len;
+        put(pos, max(warm, pos), last, bound, d_start, flags | (t < n_mm ? 0u : kUnitToEnd));
+    }
+    return nh | (nl << 16);
+}
+
+__global__ __launch_bounds__(256) void plan_count_kernel(WalkArgs a)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.n_items) return;
+    const uint4 g = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(a.gitems) + (size_t)idx * 16u);
+    const uint32_t c = make_units<false>(g, a.glist + (size_t)idx * kPlanList, a.ix.k, a.plan_gap, a.plan_chunk, idx, nullptr, nullptr);
+    a.ucount[idx] = c & 0xFFFFu;              // class-major: all heavy counts, then all light counts, then one 0
+    a.ucount[a.n_items + idx] = c >> 16;
+    if (idx == 0) a.ucount[2u * a.n_items] = 0; // the prefix of this extra entry is the number of units
+}
+
+__global__ __launch_bounds__(256) void plan_emit_kernel(WalkArgs a)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.n_items) return;
+    const uint4 g = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(a.gitems) + (size_t)idx * 16u);
+    auto prefix = [&](uint32_t e) -> uint32_t { return a.usums[e / kScanBlock] + a.ucount[e]; };
+    const uint32_t hs = prefix(idx), he = prefix(idx + 1u), ls = prefix(a.n_items + idx), le = prefix(a.n_items + idx + 1u);
+    if (le > a.unit_cap || he > a.unit_cap) { // no room for this item's units: it takes the full walk instead
+        if (he > hs || le > ls) a.redo[idx] = 1;
+        for (uint32_t part = 0; part < 2; part++) // (slots below the capacity are still consumed: empty units)
+            for (uint32_t sl = part ? ls : hs; sl < min(part ? le : he, a.unit_cap); sl++) {
+                uint4 *o = reinterpret_cast<uint4 *>(a.units + sl);
+                o[0] = make_uint4(0, 0, 0, 0);
+                o[1] = make_uint4((kUnitHead | kUnitPlain) << 8, idx, 0, 0);
+            }
+        return;
+    }
+    make_units<true>(g, a.glist + (size_t)idx * kPlanList, a.ix.k, a.plan_gap, a.plan_chunk, idx, a.units + hs, a.units + ls);
+}
+
+// Collects the items the guided walk flagged into a list for the plain kernel (the item records are not needed any
+// more at this point and their array becomes that list); qctl[1] counts them.
+__global__ __launch_bounds__(256) void redo_collect_kernel(WalkArgs a)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.n_items || !a.redo[idx]) return;
+    const uint32_t slot = atomicAdd(a.qctl + 1, 1u);
+    reinterpret_cast<uint4 *>(a.gitems)[slot] = reinterpret_cast<const uint4 *>(a.items)[idx];
+}
+
+// per-lane flag bits of the guided walk
+enum : uint32_t {
+    G_QF = 1u,    // fetch the query block after the current one
+    G_CON = 2u,   // contracting: loads contraction entries instead of rank blocks
+    G_HAVE = 4u,  // next unit (record, start row, first query block) is prefetched
+    G_PF = 8u,    // next unit's record is in flight, its row and query block not yet requested
+    // the bits below take the lane out of the hot path until the bookkeeping block has run
+    G_DONE = 16u, // finished its unit, wants the next one
+    G_FIN = 32u,  // no units left
+    G_BLOCKED = G_DONE | G_FIN
+};
+
+// -------------------------------------------------------------------------------------------------------------
+// ms_walk_guided_kernel.  Same walk as ms_walk_kernel (walk_kernels.hip: extend by rank blocks, contraction by
+// {lcs, psv, nsv} entries, one loop with a hot path and a bookkeeping block) over units instead of items:
+//  * a unit starts from the diagonal's row in front of its first base (prefetched with the unit's record and query
+//    block by the bookkeeping block) or from the root;
+//  * after every accepted base at the end of an output word, once the group's last mismatch is behind:
+//    converged = single-row interval && d == min(k, bases since that mismatch) -> the unit is done;
+//  * a unit that reaches its bound first (and the bound is not the item's end) flags the item for the full walk;
+//  * output in words (4 bases), bytes at the two ends of the walked stretch, so that a unit patches the predicted
+//    values without touching its neighbours;
+//  * units come off one queue in chunks of 64 per wave; a lane that finishes takes the next one.
+template <bool BIG>
+__global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
+{
+    const uint32_t n = a.ix.n, k = a.ix.k;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint8_t *arena = reinterpret_cast<const uint8_t *>(a.ix.arena);
+    const uint8_t *qb = a.q;
+    const uint8_t *utb = reinterpret_cast<const uint8_t *>(a.units);
+    const uint8_t *nodeb = reinterpret_cast<const uint8_t *>(a.ix.pc_node);
+    const uint32_t q_end = (uint32_t)a.q_bytes;
+    const uint32_t nblk = a.ix.n_blocks;
+    const uint32_t null_blk = 4u * nblk;
+    const uint32_t ent_byte0 = a.ix.lcs_off << 4;
+
+    const uint32_t q_total = min(a.usums[(2u * a.n_items) / kScanBlock] + a.ucount[2u * a.n_items], a.unit_cap);
+    uint32_t pool_next = 0, pool_end = 0;
+    bool drained = false; // (wave-uniform) the queue has nothing left
+
+    uint32_t flags = G_DONE;
+    uint32_t l = 0, r = n, d = 0, m = 0, cb = 0, tgt_l = 0, tgt_r = 0;
+    uint32_t i = 0, start = 0, warm = 0, bound = 0, out_from = 0, uflags = 0, item = 0, wlo = 0;
+    int32_t last_mm = -1;
+    uint4 qblk = make_uint4(0, 0, 0, 0), qnxt = make_uint4(0, 0, 0, 0);
+    uint32_t qcur = 0, ocur = 0;
+    uint4 nu0 = make_uint4(0, 0, 0, 0), nq0 = make_uint4(0, 0, 0, 0);
+    uint2 nu1 = make_uint2(0, 0);
+    uint32_t nrow = 0;
+    bool want = true; // wants to claim a unit
+#ifdef KBO_WALK_DEBUG
+    uint32_t dbg_iter = 0, dbg_rare = 0, dbg_acc = 0, dbg_fail = 0, dbg_con = 0, dbg_wdone = 0, dbg_wfin = 0, dbg_units = 0,
+             dbg_flagged = 0;
+#endif
+
+    for (;;) {
+        // ============================== bookkeeping block ==============================
+        {
+#ifdef KBO_WALK_DEBUG
+            dbg_rare++;
+#endif
+            // ---- the next unit's record is here: request its start row and first query block
+            if (flags & G_PF) {
+                const uint32_t pos = nu0.z & 0xFFFFu;
+                nq0 = ld16u(qb, nu0.x + (pos & ~15u));
+                if (!((nu1.x >> 8) & kUnitHead)) nrow = *reinterpret_cast<const uint32_t *>(nodeb + (uint64_t)(nu0.y + pos - 1u) * 4u);
+                flags = (flags & ~G_PF) | G_HAVE;
+            }
+            // ---- switch finished lanes to their prefetched unit
+            if (flags & G_DONE) {
+                if (flags & G_HAVE) {
+                    start = nu0.x;
+                    i = nu0.z & 0xFFFFu;
+                    out_from = nu0.z >> 16;
+                    last_mm = (int32_t)(int16_t)(nu0.w & 0xFFFFu);
+                    bound = nu0.w >> 16;
+                    uflags = (nu1.x >> 8) & 0xFFu;
+                    warm = (nu1.x >> 16) & 0xFFu;
+                    item = nu1.y;
+                    const bool head = (uflags & kUnitHead) != 0;
+                    l = head ? 0u : nrow;
+                    r = head ? n : nrow + 1u;
+                    d = head ? 0u : (nu1.x & 0xFFu);
+                    m = 0;
+                    qblk = nq0;
+                    qcur = sel4(qblk, (i >> 2) & 3u);
+                    const uint32_t c = decode_base((qcur >> ((i & 3u) * 8u)) & 0xFFu);
+                    cb = c < 4u ? c * nblk : null_blk;
+                    ocur = 0;
+                    wlo = (out_from - warm) & 3u; // first byte of the first output word that is this unit's
+                    flags = i < bound ? G_QF : G_DONE; // (empty units: see plan_emit_kernel)
+                    want = true;
+#ifdef KBO_WALK_DEBUG
+                    dbg_units++;
+#endif
+                } else {
+                    flags = ((flags & G_PF) || want) ? flags : G_FIN;
+                }
+            }
+            // ---- claim units for the lanes that have none in the pipeline
+            {
+                const uint64_t wmask = __ballot(want);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u));
+                const uint32_t n_want = (uint32_t)__popcll(wmask);
+                const uint32_t avail = pool_end - pool_next;
+                uint32_t mine = pool_next + rank, lim = pool_end;
+                if (n_want > avail && !drained) { // (wave-uniform) the chunk runs out: take the next one off the queue
+                    uint32_t nb = 0;
+                    if (lane == 0) nb = atomicAdd(a.qctl, 64u);
+                    nb = min(__shfl(nb, 0), q_total);
+                    drained = nb >= q_total;
+                    const uint32_t ne = min(nb + 64u, q_total);
+                    if (rank >= avail) {
+                        mine = nb + (rank - avail);
+                        lim = ne;
+                    }
+                    pool_next = min(nb + (n_want - avail), ne);
+                    pool_end = ne;
+                } else {
+                    pool_next = min(pool_end, pool_next + n_want);
+                }
+                if (want && mine < lim) {
+                    nu0 = ld16(utb, mine * 32u);
+                    __builtin_memcpy(&nu1, utb + (size_t)mine * 32u + 16u, 8);
+                    flags |= G_PF;
+                }
+                want = false;
+            }
+            if (__ballot(flags != G_FIN) == 0) break;
+        }
+
+#pragma unroll 1
+        for (uint32_t it = 0; it < a.rare_period; it++) {
+#ifdef KBO_WALK_DEBUG
+            dbg_iter++;
+            dbg_wdone += (flags & G_DONE) ? 1u : 0u;
+            dbg_wfin += (flags & G_FIN) ? 1u : 0u;
+#endif
+            if (!(flags & G_BLOCKED)) {
+                const bool con = (flags & G_CON) != 0;
+                const uint32_t bl = div96(l), br = div96(r);
+                const uint32_t bmask = cb == null_blk ? 0u : ~0u;
+                const uint32_t rkA = (cb + (bl & bmask)) << 4, rkB = (cb + (br & bmask)) << 4;
+                uint4 xA, xB;
+                if (BIG) { // entries live in their own region, 64-bit offsets
+                    const uint8_t *pA = con ? a.ix.ent + (uint64_t)l * 12u : arena + rkA;
+                    const uint8_t *pB = con ? a.ix.ent + (uint64_t)r * 12u : arena + rkB;
+                    __builtin_memcpy(&xA, pA, 16);
+                    __builtin_memcpy(&xB, pB, 16);
+                } else {
+                    const uint32_t enA = ent_byte0 + ((l + (l << 1)) << 2), enB = ent_byte0 + ((r + (r << 1)) << 2);
+                    xA = ld16u(arena, con ? enA : rkA);
+                    xB = ld16u(arena, con ? enB : rkB);
+                }
+                if (flags & G_QF) { // the query block after the current one (reads <= 16 bytes past the item)
+                    qnxt = ld16u(qb, min(start + (i & ~15u) + 16u, q_end));
+                    flags &= ~G_QF;
+                }
+                // ---- contracting lanes: one level up the LCS interval tree
+                const uint32_t lv = max(xA.x, xB.x);
+                const bool root = lv == 0;
+                const uint32_t cl = root ? 0u : (xA.x == lv ? xA.y : l);
+                const uint32_t cr = root ? n : (xB.x == lv ? xB.z : r);
+                const bool cstop = root || !m || cl <= tgt_l || cr >= tgt_r;
+                // ---- extending lanes
+                const uint32_t ol = l - bl * kRankRows, orr = r - br * kRankRows;
+                const uint32_t l2 = rank_eval(xA, ol), r2 = rank_eval(xB, orr);
+                const bool ok = !con && l2 < r2;
+                const bool accept = !con && (l2 < r2 || d == 0);
+                const bool fail = !con && !accept;
+#ifdef KBO_WALK_DEBUG
+                dbg_con += con ? 1u : 0u;
+                dbg_acc += accept ? 1u : 0u;
+                dbg_fail += fail ? 1u : 0u;
+#endif
+                uint32_t dl = 0, dr = 0;
+                {
+                    const uint32_t wsel = ol >> 5, pb = ol & 31u;
+                    const uint32_t W = wsel == 0 ? xA.y : (wsel == 1 ? xA.z : xA.w);
+                    const uint32_t below = W & ((1u << pb) - 1u);
+                    dl = below ? pb - (31u - (uint32_t)__clz((int)below)) : 0u;
+                }
+                {
+                    const uint32_t wsel = orr >> 5, pb = orr & 31u;
+                    const uint32_t W = wsel == 0 ? xB.y : (wsel == 1 ? xB.z : xB.w);
+                    const uint32_t above = W & (~0u << pb);
+                    dr = above ? (uint32_t)__ffs((int)above) - pb : 0u;
+                }
+                m = fail ? ((dl && dr) ? 1u : 0u) : m;
+                tgt_l = fail ? l - dl : tgt_l;
+                tgt_r = fail ? r + dr : tgt_r;
+                l = con ? cl : (ok ? l2 : l);
+                r = con ? cr : (ok ? r2 : r);
+                d = con ? lv : (ok ? min(d + 1u, k) : d);
+                flags = (con && cstop) ? (flags & ~G_CON) : (fail ? (flags | G_CON) : flags);
+                if (accept) {
+                    const bool fin = i + 1u == bound;
+                    const uint32_t e = i - warm; // output index (wraps below warm; only its low bits are used then)
+                    const bool word_done = (e & 3u) == 3u || fin;
+                    if (i >= out_from) {
+                        ocur |= d << ((e & 3u) * 8u);
+                        if (word_done) {
+                            uint8_t *o = a.d_out + (start + warm + (e & ~3u));
+                            if (wlo == 0 && (e & 3u) == 3u) st4u(o, ocur);
+                            else { // a word the unit owns only part of: bytes wlo .. e & 3
+                                if (wlo == 0) o[0] = (uint8_t)ocur;
+                                if (wlo <= 1u && (e & 3u) >= 1u) o[1] = (uint8_t)(ocur >> 8);
+                                if (wlo <= 2u && (e & 3u) >= 2u) o[2] = (uint8_t)(ocur >> 16);
+                                if ((e & 3u) == 3u) o[3] = (uint8_t)(ocur >> 24);
+                            }
+                            ocur = 0;
+                            wlo = 0;
+                        }
+                    }
+                    const bool conv = !(uflags & kUnitPlain) && word_done && (int32_t)i >= last_mm && r == l + 1u &&
+                                      d == min((uint32_t)((int32_t)i - last_mm), k);
+                    if (fin && !conv && !(uflags & (kUnitPlain | kUnitToEnd))) { // reached the next group unconverged
+                        a.redo[item] = 1;
+#ifdef KBO_WALK_DEBUG
+                        dbg_flagged++;
+#endif
+                    }
+                    i++;
+                    const bool newblk = (i & 15u) == 0;
+                    qblk.x = newblk ? qnxt.x : qblk.x;
+                    qblk.y = newblk ? qnxt.y : qblk.y;
+                    qblk.z = newblk ? qnxt.z : qblk.z;
+                    qblk.w = newblk ? qnxt.w : qblk.w;
+                    flags |= (fin || conv) ? G_DONE : (newblk ? G_QF : 0u);
+                    qcur = sel4(qblk, (i >> 2) & 3u);
+                    const uint32_t c = decode_base((qcur >> ((i & 3u) * 8u)) & 0xFFu);
+                    cb = c < 4u ? c * nblk : null_blk;
+                }
+            }
+        } // hot loop
+    }
+#ifdef KBO_WALK_DEBUG
+    if (a.lo_out == nullptr && a.hi_out != nullptr) { // debug build: hi_out doubles as the counter sink
+        if (lane == 0) {
+            atomicAdd(a.hi_out + 0, dbg_iter);
+            atomicAdd(a.hi_out + 1, dbg_rare);
+            atomicAdd(a.hi_out + 3, 1u);
+            atomicMax(a.hi_out + 13, dbg_iter);
+        }
+        atomicAdd(a.hi_out + 4, dbg_acc);
+        atomicAdd(a.hi_out + 5, dbg_fail);
+        atomicAdd(a.hi_out + 6, dbg_con);
+        atomicAdd(a.hi_out + 7, dbg_flagged);
+        atomicAdd(a.hi_out + 8, dbg_wdone);
+        atomicAdd(a.hi_out + 9, dbg_wfin);
+        atomicAdd(a.hi_out + 12, dbg_units);
+    }
+#endif
+}
+
+} // namespace
+
+int g_plan_dmin = 14, g_plan_cap = 40, g_plan_gap = 24, g_plan_chunk = 32;
+void set_plan_params(int dmin, int cap, int gap, int chunk)
+{
+    if (dmin > 0) g_plan_dmin = dmin;
+    if (cap > 0) g_plan_cap = std::min(48, cap); // the text is padded by kPlanPad >= cap bytes in front
+    if (gap > 0) g_plan_gap = std::max(2, gap);
+    if (chunk > 0) g_plan_chunk = std::max(16, chunk);
+}
+
+// plan -> unit counts -> scan -> units (the guided walk and the redo pass are launched by launch_ms_walk)
+hipError_t launch_plan(const WalkArgs &a0, hipStream_t stream)
+{
+    if (a0.n_items == 0) return hipSuccess;
+    WalkArgs a = a0;
+    a.plan_dmin = (uint32_t)g_plan_dmin;
+    a.plan_cap = (uint32_t)g_plan_cap;
+    a.plan_gap = (uint32_t)g_plan_gap;
+    a.plan_chunk = (uint32_t)g_plan_chunk;
+    const hipError_t e = hipMemsetAsync(a.qctl, 0, 64, stream);
+    if (e != hipSuccess) return e;
+    const uint32_t nb = (a.n_items + 255u) / 256u;
+    hipLaunchKernelGGL(plan_kernel, dim3(nb), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(plan_count_kernel, dim3(nb), dim3(256), 0, stream, a);
+    const hipError_t es = launch_scan(a.ucount, 2u * a.n_items + 1u, a.usums, stream);
+    if (es != hipSuccess) return es;
+    hipLaunchKernelGGL(plan_emit_kernel, dim3(nb), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_ms_walk_guided(WalkArgs a, uint32_t grid, uint32_t threads, hipStream_t stream)
+{
+    if (a.ix.big) hipLaunchKernelGGL((ms_walk_guided_kernel<true>), dim3(grid), dim3(threads), 0, stream, a);
+    else hipLaunchKernelGGL((ms_walk_guided_kernel<false>), dim3(grid), dim3(threads), 0, stream, a);
+    hipLaunchKernelGGL(redo_collect_kernel, dim3((a.n_items + 255u) / 256u), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+} // namespace kbo

@@ -58,6 +58,16 @@ struct DeviceLayout {
 };
 void make_device_layout(const HostIndex &h, DeviceLayout &out, bool with_pairs = false);
 
+// Path cover of the index's de Bruijn graph, laid out as one text (path_cover.cpp): every row sits at
+// exactly one position; text[p] is the label of the edge node_at[p-1] -> node_at[p], 0 where a path starts.
+struct PathCover {
+    static constexpr size_t kPad = 64;  // zero bytes in front of and behind the text
+    std::vector<uint8_t> text;          // kPad + n_sets + kPad bytes
+    std::vector<uint32_t> pos;          // row -> position
+    std::vector<uint32_t> node_at;      // position -> row
+};
+void make_path_cover(const HostIndex &h, PathCover &out);
+
 // flat file (own format, see kbo_capi.cpp)
 void save_host_index(const HostIndex &h, const std::string &path);
 void load_host_index(const std::string &path, HostIndex &h);

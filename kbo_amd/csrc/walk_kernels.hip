@@ -35,29 +35,6 @@ enum : uint32_t {
     F_BLOCK = 32u
 };
 
-// Rank inside one 16-byte block { base, w0, w1, w2 }: base + popcount of the o lowest of
-// the 96 row bits, 0 <= o < 96.  One 64-bit shift builds the "bits to drop" masks of all
-// three words: X = ~0 << (o mod 64) is the drop mask of (w0,w1) when o < 64 and of w2
-// when o >= 64.
-__device__ __forceinline__ uint32_t rank_eval(const uint4 &b, uint32_t o)
-{
-    const uint64_t X = ~0ull << (o & 63u);
-    const uint32_t xl = (uint32_t)X, xh = (uint32_t)(X >> 32);
-    const bool big = o >= 64u;
-    const uint32_t d0 = big ? 0u : xl, d1 = big ? 0u : xh, d2 = big ? xl : ~0u;
-    return b.x + __popc(b.y & ~d0) + __popc(b.z & ~d1) + __popc(b.w & ~d2);
-}
-
-__device__ __forceinline__ uint32_t div96(uint32_t i) { return __umulhi(i, 0xAAAAAAABu) >> 6; }
-
-// 'A','C','G','T' -> 0..3, anything else -> 4 (sbwt's DNA alphabet is exactly ACGT)
-__device__ __forceinline__ uint32_t decode_base(uint32_t ch)
-{
-    uint32_t c = ((ch >> 1) & 3u) ^ ((ch >> 2) & 1u);
-    uint32_t back = (0x54474341u >> (8 * c)) & 0xFFu;
-    return back == ch ? c : 4u;
-}
-
 // -------------------------------------------------------------------------------------
 // A1.  Semantics:
 //   for each base c:  Ic = extend_right(I, c)
@@ -130,10 +107,11 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
     const uint32_t pair_blk0 = a.ix.pair_off;     // arena index of the first two-base block (PAIR)
 
     // this lane's items: first, first + 64, ...
+    const uint32_t n_items = a.n_items_dev ? min(*a.n_items_dev, a.n_items) : a.n_items; // (redo pass: counted on the device)
     const uint64_t first64 = (uint64_t)wave * 64u * a.rounds + lane;
-    uint32_t next_item = first64 < a.n_items ? (uint32_t)first64 : a.n_items;
+    uint32_t next_item = first64 < n_items ? (uint32_t)first64 : n_items;
     uint32_t left = 0; // items whose descriptor has not been requested yet
-    if (next_item < a.n_items) left = min(a.rounds, (a.n_items - 1u - next_item) / 64u + 1u);
+    if (next_item < n_items) left = min(a.rounds, (n_items - 1u - next_item) / 64u + 1u);
 
     uint32_t flags = left ? F_DONE : F_FIN;
     uint32_t l = 0, r = n, d = 0, m = 0, cb = 0; // m: contraction targets known (rare block only)
@@ -193,7 +171,7 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
                     flags = len ? F_QF : F_DONE; // fetch block 1 right away; empty items are skipped
                     if (left) {
                         nit = ld16(itb, next_item * 16u);
-                        next_item += 64;
+                                        next_item += 64;
                         left--;
                         flags |= F_PF;
                     }
@@ -434,6 +412,7 @@ hipError_t launch_make_chunk_items(const uint64_t *d_offsets, uint32_t n_seqs, u
 
 int g_walk_threads = kWalkThreads;
 int g_rare_period = 8; // tuned on C2 (tools/sweep_walk.py RARE=1)
+int g_guided_waves_eighths = 7;            // guided walk: resident waves per SIMD (tuning, kbo_set_walk_waves_per_cu scales it)
 int g_pair_min_depth = 16;                 // two-base steps only from matches at least this deep
 void set_pair_min_depth(int d) { g_pair_min_depth = d < 0 ? 0 : d; }
 void set_walk_rare(int period) { g_rare_period = std::max(1, std::min(1024, period)); }
@@ -454,6 +433,30 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
     const dim3 grid((waves + wpb - 1) / wpb), block(threads);
     const bool ival = a.lo_out && a.hi_out;
     a.pair_min_d = (uint32_t)g_pair_min_depth;
+    if (a.gitems && a.glist && a.ix.pc_text && !ival) { // MS values only, index with a path cover: plan, then guided walk
+        hipError_t e = launch_plan(a, stream);
+        if (e != hipSuccess) return e;
+        // the guided kernel holds 7 waves per SIMD (65 VGPRs) and takes its items off a queue: one resident wave per
+        // slot, but no more waves than there are chunks of 64 items
+        const uint32_t gwaves = (uint32_t)std::min<uint64_t>((uint64_t)std::max(1, max_waves * g_guided_waves_eighths / 8),
+                                                             ((uint64_t)a.unit_cap + 63) / 64);
+        e = launch_ms_walk_guided(a, (gwaves + wpb - 1) / wpb, threads, stream);
+        if (e != hipSuccess) return e;
+        // the redo pass: items a unit flagged (its successor's start state was a wrong guess) walked plainly, in full;
+        // redo_collect_kernel has listed them where the item records were, one item per lane
+        a.items = reinterpret_cast<const WalkItem *>(a.gitems);
+        a.n_items_dev = a.qctl + 1;
+        a.gitems = nullptr;
+        a.rounds = 1;
+#ifdef KBO_WALK_DEBUG
+        a.hi_out = nullptr; // (counters build: the counter sink belongs to the guided kernel)
+#endif
+        const uint32_t rwaves = (a.n_items + 63u) / 64u;
+        const dim3 rgrid((rwaves + wpb - 1) / wpb);
+        if (a.ix.big) hipLaunchKernelGGL((ms_walk_kernel<false, true, false>), rgrid, block, 0, stream, a);
+        else hipLaunchKernelGGL((ms_walk_kernel<false, false, false>), rgrid, block, 0, stream, a);
+        return hipGetLastError();
+    }
     if (a.ix.big) {
         if (ival) hipLaunchKernelGGL((ms_walk_kernel<true, true, false>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((ms_walk_kernel<false, true, false>), grid, block, 0, stream, a);
