@@ -288,6 +288,15 @@ int kbo_set_pair_steps(uint64_t min_rows, int min_depth);
  * enabled < 0 keeps the setting; seed_depth (default 14) / seed_cap (default 40, at most 48) tune the diagonal search,
  * <= 0 keeps them. */
 int kbo_set_plan(int enabled, int seed_depth, int seed_cap);
+/* More knobs of the plan-guided walk (<= 0 keeps a value): mismatches closer than `gap` bases (default 24, >= 2) are
+ * walked by one unit; reads without a diagonal are walked in chunks of `chunk` bases (default 32); a launch with more
+ * than bail_x16 / 16 units per read (default 32 / 16) gives the plan up and takes the plain walk (and the following 16
+ * launches do not plan at all).  bail_x16 = 0 forces that path (tests). */
+int kbo_set_plan_tuning(int gap, int chunk, int bail_x16);
+/* The path cover the plan-guided walk uses (host computation, for inspection and tests): every row of the index sits at
+ * exactly one text position; text[p] ('A','C','G','T') labels the edge node_at[p-1] -> node_at[p] of the index's de
+ * Bruijn graph, 0 where a path starts.  All three arrays have n_sets entries. */
+int kbo_index_path_cover(const kbo_index_t *idx, uint8_t *text, uint32_t *pos, uint32_t *node_at);
 /* bytes of path cover a device copy of this index carries (0 = none) */
 uint64_t kbo_index_device_plan_bytes(const kbo_index_t *idx);
 int kbo_set_force_big_layout(int on);            /* tests: force the 64-bit-offset contraction-entry layout */

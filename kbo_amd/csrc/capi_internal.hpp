@@ -54,6 +54,7 @@ int walk_max_waves();                                     // upper bound on resi
 // points a.gitems / a.glist into `plan_work` (>= kbo::plan_work_bytes(n_items) bytes, 16-byte aligned) when the index
 // view carries a path cover and the launch wants MS values only; otherwise leaves them null (plain walk)
 void attach_plan(kbo::WalkArgs &a, void *plan_work);
+void plan_after_launch(const kbo::WalkArgs &a, hipStream_t stream); // after launch_ms_walk: lets the host learn whether the plan paid
 
 // ---- A3 (kbo_capi.cpp): derandomize.rs:91-145
 double log_rm_max_cdf(size_t t, size_t alphabet_size, size_t n_kmers);

@@ -2,6 +2,8 @@
 // two-base blocks) and the knobs that shape them.
 #include "capi_internal.hpp"
 
+#include <atomic>
+
 namespace kbo_host {
 
 int g_waves_per_cu = 0;
@@ -102,6 +104,37 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
     return v;
 }
 
+// Batches whose reads differ too much from the index give the plan up on the device (plan_emit_kernel), after
+// having paid for the plan kernel.  The host learns about it one launch late (an asynchronous 4-byte copy into pinned
+// memory, never waited for) and then skips planning for the next kPlanHoldoff launches.
+namespace {
+constexpr int kPlanHoldoff = 16;
+std::atomic<int> g_plan_holdoff{0};
+std::atomic<uint32_t *> g_plan_bailed{nullptr}; // pinned
+uint32_t *plan_bailed_slot()
+{
+    uint32_t *p = g_plan_bailed.load();
+    if (!p) {
+        uint32_t *fresh = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void **>(&fresh), 64, hipHostMallocDefault) != hipSuccess) return nullptr;
+        *fresh = 0;
+        uint32_t *expected = nullptr;
+        if (g_plan_bailed.compare_exchange_strong(expected, fresh)) p = fresh;
+        else {
+            (void)hipHostFree(fresh);
+            p = expected;
+        }
+    }
+    return p;
+}
+} // namespace
+
+void plan_after_launch(const kbo::WalkArgs &a, hipStream_t stream)
+{
+    if (!a.gitems || !a.qctl) return;
+    if (uint32_t *slot = plan_bailed_slot()) (void)hipMemcpyAsync(slot, a.qctl + 2, 4, hipMemcpyDeviceToHost, stream);
+}
+
 void attach_plan(kbo::WalkArgs &a, void *plan_work)
 {
     a.gitems = nullptr;
@@ -110,8 +143,19 @@ void attach_plan(kbo::WalkArgs &a, void *plan_work)
     a.redo = nullptr;
     a.units = nullptr;
     a.n_items_dev = nullptr;
+    a.unit_bail = 0;
     a.unit_cap = a.plan_dmin = a.plan_cap = a.plan_gap = a.plan_chunk = 0;
     if (!g_plan_enabled || !plan_work || !a.ix.pc_text || (a.lo_out && a.hi_out) || a.n_items == 0) return;
+    if (uint32_t *slot = plan_bailed_slot()) {
+        if (*reinterpret_cast<volatile uint32_t *>(slot)) {
+            *reinterpret_cast<volatile uint32_t *>(slot) = 0;
+            g_plan_holdoff.store(kPlanHoldoff);
+        }
+    }
+    if (g_plan_holdoff.load() > 0) {
+        g_plan_holdoff.fetch_sub(1);
+        return;
+    }
     uint8_t *w = static_cast<uint8_t *>(plan_work);
     const size_t ni = a.n_items;
     a.gitems = reinterpret_cast<kbo::GuidedItem *>(w);

@@ -135,6 +135,7 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
     if (view.pc_text && !want_ival) B.plan.ensure(kbo::plan_work_bytes(n_items, total));
     attach_plan(a, view.pc_text && !want_ival ? B.plan.p : nullptr);
     HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), stream));
+    plan_after_launch(a, stream);
 }
 
 void run_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,

@@ -822,6 +822,7 @@ int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *
         a.hi_out = d_hi_out;
         attach_plan(a, static_cast<uint8_t *>(d_work) + w.plan_off);
         HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), s));
+        plan_after_launch(a, s);
     });
 }
 
@@ -921,7 +922,27 @@ int kbo_set_plan(int enabled, int seed_depth, int seed_cap)
     if (seed_cap > 0) g_plan_cap_shadow = seed_cap;
     kbo::set_plan_params(g_plan_dmin_shadow, g_plan_cap_shadow);
     if (const char *e = std::getenv("KBO_PLAN_GAP")) kbo::set_plan_params(0, 0, std::atoi(e), 0);   // experiments
+    if (const char *e = std::getenv("KBO_PLAN_BAIL")) kbo::set_plan_bail(std::atoi(e));
     if (const char *e = std::getenv("KBO_PLAN_CHUNK")) kbo::set_plan_params(0, 0, 0, std::atoi(e));
+    return KBO_OK;
+}
+
+int kbo_index_path_cover(const kbo_index_t *idx, uint8_t *text, uint32_t *pos, uint32_t *node_at)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && text && pos && node_at, KBO_E_BAD_ARG, "null argument");
+        kbo::PathCover pc;
+        kbo::make_path_cover(idx->host, pc);
+        std::memcpy(text, pc.text.data() + kbo::PathCover::kPad, idx->host.n_sets);
+        std::memcpy(pos, pc.pos.data(), idx->host.n_sets * 4);
+        std::memcpy(node_at, pc.node_at.data(), idx->host.n_sets * 4);
+    });
+}
+
+int kbo_set_plan_tuning(int gap, int chunk, int bail_x16)
+{
+    kbo::set_plan_params(0, 0, gap, chunk);
+    if (bail_x16 >= 0) kbo::set_plan_bail(bail_x16);
     return KBO_OK;
 }
 

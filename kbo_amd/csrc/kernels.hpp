@@ -91,6 +91,7 @@ struct WalkArgs {
     uint8_t *redo;         // per item: 1 = a unit could not vouch for its successor, walk the item again in full
     WalkUnit *units;       // unit_cap records (items whose units do not fit are flagged for the full walk instead)
     uint32_t unit_cap;
+    uint32_t unit_bail;    // more units than this in a launch: the plan is given up, every item takes the plain walk
     uint32_t *qctl;        // [0] queue head of the guided walk
     uint32_t plan_dmin;    // plan_kernel: a seed must be this deep (capped at k) before its row is trusted
     uint32_t plan_cap;     // plan_kernel: seed iterations before an item is given up as unplanned
@@ -105,8 +106,9 @@ inline size_t plan_work_bytes(size_t n_items, uint64_t total_bases)
     return n_items * (sizeof(GuidedItem) + kPlanList * 2) + (2 * n_items + 1 + n_items / 512 + 8) * 4 +
            (n_items + 15) / 16 * 16 + plan_unit_cap(n_items, total_bases) * sizeof(WalkUnit) + 256;
 }
-hipError_t launch_plan(const WalkArgs &a, hipStream_t stream);
+hipError_t launch_plan(WalkArgs &a, hipStream_t stream); // fills in the plan parameters of `a` (the later launches need them)
 hipError_t launch_ms_walk_guided(WalkArgs a, uint32_t grid, uint32_t threads, hipStream_t stream);
+void set_plan_bail(int units_per_16_items); // tuning: launches with more units than this per 16 items give the plan up
 void set_plan_params(int dmin, int cap, int gap = 0, int chunk = 0); // tuning (<= 0 keeps): seed depth / seed iterations, unit gap / chunk
 
 // offsets (n_seqs+1) -> one item per sequence

@@ -272,6 +272,8 @@ __global__ __launch_bounds__(256) void plan_emit_kernel(WalkArgs a)
     if (idx >= a.n_items) return;
     const uint4 g = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(a.gitems) + (size_t)idx * 16u);
     auto prefix = [&](uint32_t e) -> uint32_t { return a.usums[e / kScanBlock] + a.ucount[e]; };
+    if (prefix(2u * a.n_items) > a.unit_bail) return; // too much to walk for the plan to pay: every item takes the
+                                                      // plain walk (redo_collect_kernel lists them all)
     const uint32_t hs = prefix(idx), he = prefix(idx + 1u), ls = prefix(a.n_items + idx), le = prefix(a.n_items + idx + 1u);
     if (le > a.unit_cap || he > a.unit_cap) { // no room for this item's units: it takes the full walk instead
         if (he > hs || le > ls) a.redo[idx] = 1;
@@ -291,7 +293,16 @@ __global__ __launch_bounds__(256) void plan_emit_kernel(WalkArgs a)
 __global__ __launch_bounds__(256) void redo_collect_kernel(WalkArgs a)
 {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.n_items || !a.redo[idx]) return;
+    if (idx >= a.n_items) return;
+    if (a.usums[(2u * a.n_items) / kScanBlock] + a.ucount[2u * a.n_items] > a.unit_bail) { // plan given up: all items, in order
+        reinterpret_cast<uint4 *>(a.gitems)[idx] = reinterpret_cast<const uint4 *>(a.items)[idx];
+        if (idx == 0) {
+            a.qctl[1] = a.n_items;
+            a.qctl[2] = 1; // tells the host (plan_after_launch) that planning did not pay for this batch
+        }
+        return;
+    }
+    if (!a.redo[idx]) return;
     const uint32_t slot = atomicAdd(a.qctl + 1, 1u);
     reinterpret_cast<uint4 *>(a.gitems)[slot] = reinterpret_cast<const uint4 *>(a.items)[idx];
 }
@@ -333,7 +344,8 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
     const uint32_t null_blk = 4u * nblk;
     const uint32_t ent_byte0 = a.ix.lcs_off << 4;
 
-    const uint32_t q_total = min(a.usums[(2u * a.n_items) / kScanBlock] + a.ucount[2u * a.n_items], a.unit_cap);
+    const uint32_t u_total = a.usums[(2u * a.n_items) / kScanBlock] + a.ucount[2u * a.n_items];
+    const uint32_t q_total = u_total > a.unit_bail ? 0u : min(u_total, a.unit_cap); // (see plan_emit_kernel)
     uint32_t pool_next = 0, pool_end = 0;
     bool drained = false; // (wave-uniform) the queue has nothing left
 
@@ -555,6 +567,8 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
 } // namespace
 
 int g_plan_dmin = 14, g_plan_cap = 40, g_plan_gap = 24, g_plan_chunk = 32;
+int g_plan_bail_x16 = 32; // give the plan up when there are more than this many units per 16 items
+void set_plan_bail(int units_per_16_items) { g_plan_bail_x16 = std::max(0, units_per_16_items); }
 void set_plan_params(int dmin, int cap, int gap, int chunk)
 {
     if (dmin > 0) g_plan_dmin = dmin;
@@ -564,14 +578,14 @@ void set_plan_params(int dmin, int cap, int gap, int chunk)
 }
 
 // plan -> unit counts -> scan -> units (the guided walk and the redo pass are launched by launch_ms_walk)
-hipError_t launch_plan(const WalkArgs &a0, hipStream_t stream)
+hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
 {
-    if (a0.n_items == 0) return hipSuccess;
-    WalkArgs a = a0;
+    if (a.n_items == 0) return hipSuccess;
     a.plan_dmin = (uint32_t)g_plan_dmin;
     a.plan_cap = (uint32_t)g_plan_cap;
     a.plan_gap = (uint32_t)g_plan_gap;
     a.plan_chunk = (uint32_t)g_plan_chunk;
+    a.unit_bail = (uint32_t)std::min<uint64_t>((uint64_t)a.n_items * (uint64_t)g_plan_bail_x16 / 16u + 64u, 0xFFFFFFFFu);
     const hipError_t e = hipMemsetAsync(a.qctl, 0, 64, stream);
     if (e != hipSuccess) return e;
     const uint32_t nb = (a.n_items + 255u) / 256u;

@@ -51,6 +51,10 @@ class SbwtIndexVariant:
         """Bytes of two-base extension blocks in the device copies of this index (0 = none)."""
         return int(lib().kbo_index_device_pair_bytes(self._h))
 
+    def device_plan_bytes(self):
+        """Bytes of path cover (plan-guided walk) in the device copies of this index (0 = none)."""
+        return int(lib().kbo_index_device_plan_bytes(self._h))
+
     def export_parts(self):
         """(rows[4] uint64 words, C[4], lcs bytes) — the abstract index content."""
         n = self.n_sets()
@@ -61,6 +65,13 @@ class SbwtIndexVariant:
         lcs = np.zeros(n, dtype=np.uint8)
         check(lib().kbo_index_export_parts(self._h, ptrs, Carr, lcs.ctypes.data))
         return rows, [int(v) for v in Carr], lcs
+
+    def path_cover(self):
+        """(text uint8[n], pos uint32[n], node_at uint32[n]) — the path cover of the plan-guided walk (kbo_hip.h)."""
+        n = self.n_sets()
+        text, pos, node = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)
+        check(lib().kbo_index_path_cover(self._h, text.ctypes.data, pos.ctypes.data, node.ctypes.data))
+        return text, pos, node
 
     @classmethod
     def from_parts(cls, k, n_sets, n_kmers, rows, Carr, lcs):

@@ -1,0 +1,123 @@
+"""The plan-guided walk (kbo_amd/csrc/plan_kernels.hip) against the plain walk and the CPU oracle: MS values must be
+identical whatever the plan kernel decides.  Every knob that changes how much is walked is forced through its corner:
+mismatch groups of one base (units that cannot vouch for their successors -> redo pass), tiny chunks, plans given up
+(bail-out + hold-off), shallow seeds that put reads on wrong diagonals."""
+import numpy as np
+import pytest
+
+import kbo_amd
+from kbo_amd import batch, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _mutate(rng, s, rate):
+    b = bytearray(s)
+    for i in range(len(b)):
+        if rng.random() < rate:
+            b[i] = b"ACGT"[rng.integers(0, 4)]
+    return bytes(b)
+
+
+@pytest.fixture
+def plan_defaults():
+    L = kbo_amd.lib()
+    yield L
+    L.kbo_set_plan(1, 14, 40)
+    L.kbo_set_plan_tuning(24, 32, 32)
+
+
+def _workload(rng, ref_seqs, n_reads):
+    """ragged reads with substitutions / indels / junk / chimeras, short reads, and two long sequences (chunked)"""
+    cat = np.frombuffer(b"".join(ref_seqs), dtype=np.uint8)
+    reads = []
+    for r in range(n_reads):
+        L = int(rng.choice([3, 7, 31, 64, 100, 150, 151, 250, 301]))
+        a = int(rng.integers(0, len(cat) - L))
+        s = bytearray(_mutate(rng, cat[a:a + L].tobytes(), [0, 0.01, 0.03, 0.2][r % 4]))
+        if r % 11 == 0 and L > 40:  # deletion, insertion
+            del s[20:23]
+            s[30:30] = b"GATTACA"
+        if r % 13 == 0:
+            s[int(rng.integers(0, len(s)))] = rng.choice(list(b"Nn$\x00"))
+        if r % 17 == 0 and L > 60:  # chimera
+            b = int(rng.integers(0, len(cat) - 40))
+            s[L // 2:] = cat[b:b + len(s) - L // 2].tobytes()
+        reads.append(bytes(s))
+    long1 = bytearray(cat[1000:31000].tobytes())
+    for p in rng.integers(0, len(long1), 150):
+        long1[p] = b"ACGT"[rng.integers(0, 4)]
+    reads.append(bytes(long1))
+    reads.append(cat[40000:47000].tobytes())
+    concat = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    offsets = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+    return concat, offsets
+
+
+@pytest.mark.parametrize("k", [3, 5, 31, 64])
+def test_plan_guided_walk_equals_plain_walk_and_oracle(oracle, plan_defaults, k):
+    L = plan_defaults
+    rng = np.random.default_rng(100 + k)
+    g = synth.genome(60_000, seed=300 + k)
+    rep = np.tile(g[:500], 8)
+    seqs = [np.concatenate([g, rep]).tobytes(), g[2000:9000].tobytes() + b"NN" + g[100:1500].tobytes(),
+            bytes(rng.choice(list(b"ACG"), 3000).astype(np.uint8))]
+    sbwt, _ = kbo_amd.build(seqs, kbo_amd.BuildOpts(k=k, num_threads=2))
+    assert sbwt.n_sets() > 0
+    ora = oracle.Index.build(seqs, k=k)
+    concat, offsets = _workload(rng, seqs, 2500)
+    _, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
+    L.kbo_set_plan(1, 14, 40)
+    sbwt.to_device(-1)  # the device copy gets its path cover while the plan is enabled
+    assert sbwt.device_plan_bytes() > 0
+    L.kbo_set_plan(0, 14, 40)
+    d_plain, _, _ = batch.ms_batch(sbwt, concat, offsets)
+    assert np.array_equal(d_plain, exp_d)
+    settings = [(14, 40, 24, 32, 1 << 20), (14, 40, 2, 16, 1 << 20), (1, 8, 5, 64, 1 << 20), (3, 48, 24, 32, 1 << 20),
+                (14, 40, 24, 32, 0), (14, 40, 24, 32, 1 << 20)]
+    for dmin, cap, gap, chunk, bail in settings:
+        L.kbo_set_plan(1, dmin, cap)
+        L.kbo_set_plan_tuning(gap, chunk, bail)
+        for _ in range(2):  # (the launch after a plan was given up is held off; the one after that plans again or not)
+            d, _, _ = batch.ms_batch(sbwt, concat, offsets)
+            assert np.array_equal(d, exp_d), (k, dmin, cap, gap, chunk, bail)
+    # intervals are only ever produced by the plain walk
+    d2, lo, hi = batch.ms_batch(sbwt, concat[:600], np.array([0, 600], dtype=np.uint64), want_intervals=True)
+    od, olo, ohi = ora.matching_statistics(concat[:600].tobytes())
+    assert np.array_equal(d2, od.astype(np.uint8)) and np.array_equal(lo, olo.astype(np.uint32)) and np.array_equal(hi, ohi.astype(np.uint32))
+
+
+def test_plan_guided_walk_device_resident_and_map(oracle, plan_defaults):
+    """The device-resident entry points and the whole map path (A1 -> A5/A6) with the plan on."""
+    import torch
+    L = plan_defaults
+    g = synth.genome(300_000, seed=77)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=4))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    for sub in (0.0, 0.01, 0.08):
+        concat, offsets = synth.reads(g, 20_000, 150, sub, seed=int(sub * 1000) + 3)
+        exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
+        for plan in (1, 0, 1):
+            L.kbo_set_plan(plan, 14, 40)
+            dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"))
+            dev.ms.fill_(0xEE)
+            dev.run()
+            torch.cuda.synchronize()
+            assert np.array_equal(dev.ms[:dev.total].cpu().numpy(), exp_d), (sub, plan)
+            assert np.array_equal(dev.chars[:dev.total].cpu().numpy(), exp_chars), (sub, plan)
+            assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars), (sub, plan)
+
+
+def test_plan_guided_walk_big_layout(oracle, plan_defaults):
+    L = plan_defaults
+    g = synth.genome(120_000, seed=78)
+    try:
+        L.kbo_set_force_big_layout(1)
+        sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=2))
+        ora = oracle.Index.build([g.tobytes()], k=31)
+        concat, offsets = synth.reads(g, 5000, 150, 0.02)
+        _, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
+        d, _, _ = batch.ms_batch(sbwt, concat, offsets)
+        assert np.array_equal(d, exp_d)
+    finally:
+        L.kbo_set_force_big_layout(0)
