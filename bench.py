@@ -27,17 +27,50 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--genome", type=int, default=5_000_000)
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
+    ap.add_argument("--config", choices=["C2", "C3"], default="C2",
+                    help="BASELINE.json workload: C2 = kbo map, 5 Mbp index, 1 M x 150 bp reads (the metric config); "
+                         "C3 = kbo find, 100 Mbp index, 10 M x 150 bp reads (SURVEY.md 8(d)'s designated roofline run)")
+    ap.add_argument("--genome", type=int, default=None)
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--sub-rate", type=float, default=0.01)
     ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="wall-clock budget of the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-clock budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--find", action="store_true",
                     help="time kbo::find instead of kbo::map: the step ends with format::run_lengths on the device")
     ap.add_argument("--waves-per-cu", type=int, default=0)
-    return ap.parse_args()
+    ap.add_argument("--no-plan", action="store_true", help="plain walk kernel only (no path cover, no plan-guided walk)")
+    args = ap.parse_args()
+    preset = {"C2": (5_000_000, 1_000_000, False), "C3": (100_000_000, 10_000_000, True)}[args.config]
+    args.custom = args.genome is not None or args.reads is not None
+    args.genome = args.genome if args.genome is not None else preset[0]
+    args.reads = args.reads if args.reads is not None else preset[1]
+    args.find = args.find or (preset[2] and not args.custom)
+    return args
+
+
+def usable_cores():
+    """Threads worth starting: the CPUs this process may run on, capped by the container's CFS quota (the GPU boxes
+    show 256 hardware threads but grant 16 CPUs' worth of time; more threads than that only get throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = f"{n} schedulable CPUs"
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                q = max(1, int(float(quota) / period + 0.5))
+                if q < n:
+                    note = f"cgroup CPU quota {q} of {n} schedulable CPUs"
+                    n = q
+            break
+        except Exception:
+            continue
+    return n, note
 
 
 def cpu_baseline_leg(args, genome, concat, offsets, gpu_d, gpu_chars, sbwt=None):
@@ -45,7 +78,7 @@ def cpu_baseline_leg(args, genome, concat, offsets, gpu_d, gpu_chars, sbwt=None)
     bounded sample of the same reads with all host cores, checks the GPU output against
     it, and returns (cpu_baseline dict, B_alg bytes/base, bit_exact)."""
     from oracle import binding as ora
-    cores = os.cpu_count() or 1
+    cores, cores_note = usable_cores()
     if len(genome) <= 20_000_000 or sbwt is None:
         oi = ora.Index.build([genome.tobytes()], k=args.k)
     else:
@@ -54,19 +87,16 @@ def cpu_baseline_leg(args, genome, concat, offsets, gpu_d, gpu_chars, sbwt=None)
         rows, Carr, lcs = sbwt.export_parts()
         oi = ora.Index.from_parts(args.k, sbwt.n_sets(), sbwt.n_kmers(), rows, Carr, lcs)
     L = args.read_len
-    # calibration slice, then a sample sized to the time budget
+    # calibration slice (also warms the index), then a sample sized to the time budget: as many of the reads as fit,
+    # walked `passes` times by a pinned thread pool after an untimed warm-up pass (oracle/kbo_oracle.c
+    # ora_matches_batch_timed: outputs allocated and touched beforehand, reads handed out dynamically)
     n0 = min(args.reads, 20_000)
-    t0 = time.perf_counter()
-    oi.matches_batch(concat[:n0 * L], offsets[:n0 + 1], 1e-7, n_threads=cores)
-    dt0 = max(time.perf_counter() - t0, 1e-4)
-    # sample = as many of the reads as fit the wall-clock budget (on a many-core host: all of
-    # them, walked several times over so the timed region is seconds, not milliseconds)
+    _, _, dt0 = oi.matches_batch_timed(concat[:n0 * L], offsets[:n0 + 1], 1e-7, n_threads=cores, passes=1)
+    dt0 = max(dt0, 1e-4)
     n1 = int(min(args.reads, max(n0, n0 * args.cpu_seconds / dt0)))
     passes = int(max(1, min(50, args.cpu_seconds / max(dt0 * n1 / n0, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(passes):
-        chars, d = oi.matches_batch(concat[:n1 * L], offsets[:n1 + 1], 1e-7, n_threads=cores, want_d=True)
-    dt = (time.perf_counter() - t0) / passes
+    chars, d, sec = oi.matches_batch_timed(concat[:n1 * L], offsets[:n1 + 1], 1e-7, n_threads=cores, passes=passes)
+    dt = sec / passes
     # operation counts of the reference algorithm (separate, untimed, counted run)
     ctr = ora.Counters()
     nc = min(n1, 50_000)
@@ -74,16 +104,17 @@ def cpu_baseline_leg(args, genome, concat, offsets, gpu_d, gpu_chars, sbwt=None)
     c = ctr.as_dict()
     b_alg = (64.0 * c["rank_blocks"] + 1.0 * c["lcs_reads"]) / c["bases"] + 2.0
     exact = bool(np.array_equal(d, gpu_d[:n1 * L]) and np.array_equal(chars, gpu_chars[:n1 * L]))
-    # single-thread rate of the same restatement (SURVEY.md section 8(d) asks for both), on a ~1 s sample
+    # single-thread rate of the same restatement (SURVEY.md section 8(d) asks for both), same driver, ~1 s sample
     ns = int(max(1, min(n1, 2_000_000 // L)))
-    t0 = time.perf_counter()
-    oi.matches_batch(concat[:ns * L], offsets[:ns + 1], 1e-7, n_threads=1)
-    single = ns * L / max(time.perf_counter() - t0, 1e-6) / 1e6
-    base = {"value": round(n1 * L / dt / 1e6, 3), "unit": "Mbp/s", "cores": cores, "kind": "port",
+    _, _, sec1 = oi.matches_batch_timed(concat[:ns * L], offsets[:ns + 1], 1e-7, n_threads=1, passes=1, want_d=False)
+    single = ns * L / max(sec1, 1e-6) / 1e6
+    allcore = n1 * L / dt / 1e6
+    base = {"value": round(allcore, 3), "unit": "Mbp/s", "cores": cores, "kind": "port",
             "single_thread_value": round(single, 3),
-            "sample": f"first {n1} of the {args.reads} reads ({n1 * L / 1e6:.1f} Mbp) x {passes} passes, "
-                      f"oracle/kbo_oracle.c matches_batch on {cores} threads, {dt * passes:.1f} s wall "
-                      f"({dt * passes * cores:.0f} core-seconds)"}
+            "scaling_efficiency": round(allcore / max(single * cores, 1e-9), 3), "cores_note": cores_note,
+            "sample": f"first {n1} of the {args.reads} reads ({n1 * L / 1e6:.1f} Mbp) x {passes} timed passes after a warm-up "
+                      f"pass, oracle/kbo_oracle.c ora_matches_batch_timed on a pool of {cores} pinned threads, "
+                      f"{sec:.1f} s wall ({sec * cores:.0f} core-seconds)"}
     ops = {k: round(v / c["bases"], 4) for k, v in c.items() if k != "bases"}
     return base, b_alg, exact, ops
 
@@ -115,6 +146,8 @@ def main():
 
     if args.waves_per_cu:
         kbo_amd.lib().kbo_set_walk_waves_per_cu(args.waves_per_cu)
+    if args.no_plan:
+        kbo_amd.lib().kbo_set_plan(0, 0, 0)
 
     # ---- inputs (deterministic); index replicated, reads sharded by rank
     genome = synth.genome(args.genome)
@@ -159,14 +192,21 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    # per-rank stage times (skew between ranks shows here)
+    per_rank = torch.tensor([walk_ms, dt_ms], dtype=torch.float64, device=device)
+    if world > 1:
+        gathered = [torch.zeros_like(per_rank) for _ in range(world)]
+        dist.all_gather(gathered, per_rank)
+        walk_all = [float(g[0].item()) for g in gathered]
+    else:
+        walk_all = [walk_ms]
 
     result = None
     if rank == 0:
         gpu_d = dev.ms.cpu().numpy()
-        gpu_chars_fmt = dev.chars.cpu().numpy()
         cpu, b_alg, exact, ops = None, None, None, None
-        if world == 1 and not args.no_cpu_baseline:
-            # parity gate + baseline on the unformatted characters
+        if not args.no_cpu_baseline:
+            # parity gate (rank 0's shard) + CPU baseline on the unformatted characters, at every world size
             fmt = dev.format
             dev.format = False
             dev.derand_translate(stream)
@@ -174,46 +214,64 @@ def main():
             cpu, b_alg, exact, ops = cpu_baseline_leg(args, genome, concat, offsets, gpu_d,
                                                       dev.chars.cpu().numpy(), sbwt)
             dev.format = fmt
-        if b_alg is None:
-            b_alg = 85.7  # SURVEY.md §8(d) figure for 1 % substitutions (used when the oracle leg is skipped)
-        achieved = b_alg * bases / (walk_ms * 1e-3) / 1e9
-        # PMC traffic of the walk kernel, from the committed rocprofv3 passes of this exact workload
-        traffic = None
+        achieved = b_alg * bases / (walk_ms * 1e-3) / 1e9 if b_alg is not None else None
+        # fabric-side traffic and L2 misses of the A1 stage, from the committed rocprofv3 passes of this exact
+        # workload and walk mode (PMC passes cannot run inside the timed region: separate runs, tools/profile_bench.sh)
+        planned = (not args.no_plan) and sbwt.device_plan_bytes() > 0
+        wl_key = f"{args.genome}x{args.reads}x{args.read_len}x{args.sub_rate:g}:{'plan' if planned else 'plain'}"
+        traffic = tsrc = misses = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                entry = json.load(open(tpath)).get("workloads", {}).get(f"{args.genome}x{args.reads}x{args.read_len}")
-                traffic = entry.get("ms_walk_hbm_bytes_per_launch") if entry else None
+                entry = json.load(open(tpath)).get("workloads", {}).get(wl_key)
+                if entry:
+                    traffic, misses, tsrc = entry.get("a1_bytes_per_launch"), entry.get("a1_tcc_miss_per_launch"), entry.get("source")
             except Exception:
-                traffic = None
+                pass
         rank_b, lcs_b = sbwt.device_bytes()
-        pair_b = sbwt.device_pair_bytes()
+        pair_b, plan_b = sbwt.device_pair_bytes(), sbwt.device_plan_bytes()
         resident = rank_b + lcs_b + pair_b < 200e6
+        std = (args.genome, args.reads, args.read_len, args.sub_rate, args.k) in ((5_000_000, 1_000_000, 150, 0.01, 31),
+                                                                                 (100_000_000, 10_000_000, 150, 0.01, 31))
+        label = (args.config if std else "custom") + ": " + \
+            ("kbo find (max_gap_len=0; run lengths on the device)" if args.find else
+             "kbo map (fill_gaps=false, call_variants=false, format=true)")
+        a1_kernels = ("plan_kernel + plan_count/scan/emit + ms_walk_guided_kernel + redo_collect + ms_walk_kernel (flagged reads)"
+                      if planned else "ms_walk_kernel")
         result = {
-            "metric": "query Mbp/sec for kbo map, k=31, 5 Mbp SBWT; bit-exact MS vs CPU",
+            "metric": f"query Mbp/sec for kbo {'find' if args.find else 'map'}, k={args.k}, {args.genome / 1e6:g} Mbp SBWT; bit-exact MS vs CPU",
             "value": round(world * bases * args.steps / elapsed / 1e6, 1),
             "unit": "Mbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{'C2' if (args.genome, args.reads) == (5_000_000, 1_000_000) else 'custom'}: "
-                                   f"{'kbo find (max_gap_len=0; run lengths on the device)' if args.find else 'kbo map (fill_gaps=false, call_variants=false, format=true)'}, "
-                                   f"{args.genome / 1e6:g} Mbp iid genome SBWT k={args.k}, "
+            "config": {"workload": f"{label}, {args.genome / 1e6:g} Mbp iid genome SBWT k={args.k}, "
                                    f"{args.reads} x {args.read_len} bp reads per GPU, "
                                    f"{args.sub_rate * 100:g}% substitutions",
                        "index_n_sets": sbwt.n_sets(), "threshold": dev.threshold,
-                       "index_device_bytes": {"rank_blocks": rank_b, "lcs": lcs_b, "two_base_blocks": pair_b},
+                       "walk": "plan-guided (path cover + guided walk)" if planned else "plain",
+                       "index_device_bytes": {"rank_blocks": rank_b, "lcs": lcs_b, "two_base_blocks": pair_b,
+                                              "path_cover": plan_b},
                        "parallelism": f"index replicated x{world}, reads sharded, no collective"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "ms_walk_kernel", "kernel_ms": round(walk_ms, 4),
-                         "algorithmic_bytes_per_base": round(b_alg, 2),
-                         "note": ("index is L2/Infinity-Cache resident at this config: algorithmic bytes "
-                                  "are served on-die, so measured HBM traffic is far below them") if resident else
-                                 ("index exceeds L2: the walk is bound by L2-miss line fills (about 56 G/s on "
-                                  "this part, 128 B each of which 16 B are used), see DESIGN.md section 6")},
-            "kernels_ms": {"ms_walk": round(walk_ms, 4), "derand_translate": round(dt_ms, 4),
+            "roofline": {
+                # SURVEY.md 8(d)'s contract figure: algorithmic bytes of the REFERENCE algorithm (64 B per 512-bit rank
+                # block it would touch + 1 B per LCS element + 2) over the time of the A1 stage.  It is not a
+                # bandwidth utilisation: this stage loads 16-byte rank blocks, and skips the stretches of a read that
+                # match the index's path cover, so frac can exceed 1.  What binds the stage is in `bound`;
+                # traffic_frac is the measured fabric traffic over the same time against the same peak.
+                "bound": ("l2-miss line fills (index is L2/Infinity-Cache resident: about 56 G fills/s on this part, "
+                          "DESIGN.md section 6)") if resident else "l2-miss line fills from HBM (about 56 G fills/s, DESIGN.md section 6)",
+                "achieved": round(achieved, 1) if achieved is not None else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved is not None else None,
+                "frac_meaning": "reference-algorithm bytes / A1 stage time / 8 TB/s (contract figure, may exceed 1)",
+                "traffic": traffic, "traffic_source": tsrc,
+                "traffic_frac": round(traffic / (walk_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
+                "l2_miss_per_base": round(misses / bases, 4) if misses else None,
+                "kernel": "A1 stage = " + a1_kernels, "kernel_ms": round(walk_ms, 4),
+                "kernel_ms_per_rank": {"min": round(min(walk_all), 4), "max": round(max(walk_all), 4)},
+                "algorithmic_bytes_per_base": round(b_alg, 2) if b_alg is not None else None},
+            "kernels_ms": {"a1_stage": round(walk_ms, 4), "derand_translate": round(dt_ms, 4),
                            **({"run_lengths": round(rle_ms, 4)} if args.find else {})},
             "cpu_baseline": cpu,
             "bit_exact_vs_oracle": exact,

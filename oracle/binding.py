@@ -79,6 +79,8 @@ def _load():
     lib.ora_relative_to_ref.restype = None
     lib.ora_matches_batch.argtypes = [vp, vp, vp, C.c_size_t, C.c_double, C.c_int, vp, vp,
                                       C.POINTER(Counters)]
+    lib.ora_matches_batch_timed.argtypes = [vp, vp, vp, C.c_size_t, C.c_double, C.c_int, C.c_int, vp, vp,
+                                            C.POINTER(C.c_double)]
     lib.ora_call.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_double, C.POINTER(OVariant), C.c_size_t]
     lib.ora_call.restype = C.c_long
     lib.ora_add_variants.argtypes = [vp, C.c_size_t, C.POINTER(OVariant), C.c_size_t]
@@ -236,6 +238,22 @@ class Index:
                                      d.ctypes.data if want_d else None,
                                      C.byref(counters) if counters is not None else None))
         return (chars, d) if want_d else chars
+
+
+def _matches_batch_timed(self, concat, offsets, max_error_prob=1e-7, n_threads=1, passes=1, want_d=True):
+    """-> (chars, d | None, seconds of the `passes` timed passes): pinned pool, warm-up pass first (kbo_oracle.h)"""
+    concat = np.ascontiguousarray(concat, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    chars = np.zeros(len(concat), dtype=np.uint8)
+    d = np.zeros(len(concat), dtype=np.uint8) if want_d else None
+    sec = C.c_double()
+    _chk(lib().ora_matches_batch_timed(self._h, concat.ctypes.data, offsets.ctypes.data, len(offsets) - 1,
+                                       max_error_prob, n_threads, passes, chars.ctypes.data,
+                                       d.ctypes.data if want_d else None, C.byref(sec)))
+    return chars, d, float(sec.value)
+
+
+Index.matches_batch_timed = _matches_batch_timed
 
 
 def log_rm_max_cdf(t, alphabet_size, n_kmers):

@@ -14,6 +14,7 @@
 #include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
+#include <unistd.h>
 #include <string.h>
 
 struct ora_index {
@@ -526,6 +527,89 @@ int ora_matches_batch(const ora_index *x, const uint8_t *concat, const uint64_t 
     }
     free(jobs); free(th);
     return rc;
+}
+
+/* ---- timed batch driver for bench.py's cpu_baseline leg: the same A1->A5->A6 chain per read, but with what a
+ * production host loop would have: a thread pool created once (pinned, one thread per core), outputs and scratch
+ * allocated and touched before the clock starts (an untimed warm-up pass), reads handed out dynamically in chunks of
+ * 256, and a barrier around every timed pass.  *seconds_out = wall time of the `passes` timed passes. */
+#include <sched.h>
+#include <stdatomic.h>
+#include <time.h>
+
+typedef struct {
+    const ora_index *x; const uint8_t *concat; const uint64_t *off; size_t n_reads, threshold, maxlen;
+    uint8_t *chars_out, *d_out; int passes, n_threads;
+    atomic_size_t next; pthread_barrier_t bar; atomic_int rc;
+} pool_job;
+typedef struct { pool_job *j; int tid; } pool_arg;
+
+static void *pool_worker(void *arg)
+{
+    pool_arg *a = (pool_arg *)arg;
+    pool_job *j = a->j;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    if (ncpu > 0) { CPU_SET((int)(a->tid % ncpu), &set); pthread_setaffinity_np(pthread_self(), sizeof set, &set); }
+    uint64_t *d = (uint64_t *)malloc((j->maxlen + 1) * sizeof(uint64_t));
+    int64_t *der = (int64_t *)malloc((j->maxlen + 1) * sizeof(int64_t));
+    uint32_t *tr = (uint32_t *)malloc((j->maxlen + 1) * sizeof(uint32_t));
+    for (int pass = 0; pass <= j->passes; pass++) { /* pass 0 is the warm-up */
+        pthread_barrier_wait(&j->bar); /* main has reset `next` */
+        for (;;) {
+            size_t b = atomic_fetch_add(&j->next, 256), e = b + 256 < j->n_reads ? b + 256 : j->n_reads;
+            if (b >= j->n_reads) break;
+            for (size_t r = b; r < e; r++) {
+                size_t o = (size_t)j->off[r], L = (size_t)(j->off[r + 1] - j->off[r]);
+                int rc = matches_one(j->x, j->concat + o, L, j->threshold, d, der, tr,
+                                     j->chars_out ? j->chars_out + o : NULL, j->d_out ? j->d_out + o : NULL, NULL);
+                if (rc) atomic_store(&j->rc, rc);
+            }
+        }
+        pthread_barrier_wait(&j->bar); /* pass done */
+    }
+    free(d); free(der); free(tr);
+    return NULL;
+}
+
+int ora_matches_batch_timed(const ora_index *x, const uint8_t *concat, const uint64_t *offsets, size_t n_reads,
+                            double max_error_prob, int n_threads, int passes, uint8_t *chars_out, uint8_t *d_out,
+                            double *seconds_out)
+{
+    if (n_threads < 1) n_threads = 1;
+    if (passes < 1) passes = 1;
+    pool_job j;
+    memset(&j, 0, sizeof j);
+    j.x = x; j.concat = concat; j.off = offsets; j.n_reads = n_reads; j.chars_out = chars_out; j.d_out = d_out;
+    j.passes = passes; j.n_threads = n_threads;
+    j.threshold = ora_random_match_threshold(x->k, x->n_kmers, 4, max_error_prob);
+    for (size_t r = 0; r < n_reads; r++) {
+        size_t L = (size_t)(offsets[r + 1] - offsets[r]);
+        if (L > j.maxlen) j.maxlen = L;
+    }
+    atomic_init(&j.next, 0);
+    atomic_init(&j.rc, 0);
+    pthread_barrier_init(&j.bar, NULL, (unsigned)n_threads + 1);
+    pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    pool_arg *args = (pool_arg *)calloc((size_t)n_threads, sizeof(pool_arg));
+    for (int t = 0; t < n_threads; t++) {
+        args[t].j = &j; args[t].tid = t;
+        pthread_create(&th[t], NULL, pool_worker, &args[t]);
+    }
+    struct timespec t0, t1;
+    for (int pass = 0; pass <= passes; pass++) {
+        atomic_store(&j.next, 0);
+        if (pass == 1) clock_gettime(CLOCK_MONOTONIC, &t0);
+        pthread_barrier_wait(&j.bar); /* start */
+        pthread_barrier_wait(&j.bar); /* done */
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    pthread_barrier_destroy(&j.bar);
+    free(th); free(args);
+    if (seconds_out) *seconds_out = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    return atomic_load(&j.rc);
 }
 
 /* --------------------------------------------------- format.rs:98-193 */

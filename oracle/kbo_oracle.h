@@ -103,6 +103,12 @@ int ora_matches_batch(const ora_index *idx, const uint8_t *concat,
                       int n_threads, uint8_t *chars_out, uint8_t *d_out,
                       ora_counters *ctr);
 
+/* the same with a pinned thread pool, pre-touched outputs, dynamic hand-out of reads and `passes` timed passes after an
+ * untimed warm-up pass; *seconds_out = wall time of the timed passes */
+int ora_matches_batch_timed(const ora_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_reads,
+                            double max_error_prob, int n_threads, int passes, uint8_t *chars_out, uint8_t *d_out,
+                            double *seconds_out);
+
 /* error codes (mirror the reference's asserts) */
 #define ORA_OK 0
 #define ORA_E_EMPTY_QUERY (-1) /* index.rs:248 */

@@ -1,0 +1,117 @@
+"""BASELINE.json's configurations as parity tests (every read against the CPU oracle, bit-exact):
+   C1  10 kbp query vs 1 Mbp reference, kbo map with all defaults (fill_gaps + call_variants), product vs oracle.map
+   C2  5 Mbp index, the full 1 M x 150 bp batch bench.py times (plan-guided and plain walk)
+   C3/C4 shape  an index above the two-base-step threshold (>= 24 Mi rows: the real PAIR kernel, not forced on),
+       >= 1 M reads through kbo_map_batch / kbo_find_batch; the plan-guided walk on the same index
+   BIG  the 64-bit-offset entry layout at 50 Mbp
+The oracle adopts the product-built index for the large ones (its own row-sorting builder needs minutes there; builder
+equality is tests/test_builder_vs_oracle.py).  C5 (3 Gbp) is not run: see DESIGN.md section 8."""
+import numpy as np
+import pytest
+
+import kbo_amd
+from kbo_amd import batch, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _adopt(oracle, sbwt):
+    rows, Carr, lcs = sbwt.export_parts()
+    return oracle.Index.from_parts(sbwt.k(), sbwt.n_sets(), sbwt.n_kmers(), rows, Carr, lcs)
+
+
+def _threads():
+    import os
+    return max(1, min(16, len(os.sched_getaffinity(0))))
+
+
+@pytest.fixture
+def plan_restore():
+    L = kbo_amd.lib()
+    yield L
+    L.kbo_set_plan(1, 14, 40)
+    L.kbo_set_force_big_layout(0)
+
+
+def test_c1_map_full_defaults_10kbp_vs_1mbp(oracle):
+    """lib.rs:720-761 with MapOpts::default(): the reference genome is the query of kbo::map's argument order
+    (map(ref_seq, query_sbwt)); here a 10 kbp 'reference' stretch with variants against a 1 Mbp index."""
+    rng = np.random.default_rng(11)
+    g = synth.genome(1_000_000, seed=1234)
+    sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    ref = bytearray(g[400_000:410_000].tobytes())
+    for p in sorted(rng.integers(100, 9900, 25)):   # substitutions
+        ref[p] = b"ACGT"[(b"ACGT".index(ref[p]) + 1 + int(rng.integers(0, 3))) % 4]
+    del ref[5000:5007]                              # a deletion and an insertion
+    ref[7000:7000] = b"GATTACAGATTACA"
+    ref = bytes(ref)
+    got = kbo_amd.map(ref, sbwt, lcs, kbo_amd.MapOpts())
+    exp = ora.map(ref, 31, 1e-7, True, True, True)
+    assert got == exp
+    assert sum(1 for a, b in zip(got, ref) if a == b) > 9000  # (it is an alignment, not a row of gaps)
+
+
+def test_c2_full_batch_every_read(oracle, plan_restore):
+    import torch
+    L = plan_restore
+    g = synth.genome(5_000_000)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    concat, offsets = synth.reads(g, 1_000_000, 150, 0.01)
+    exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=_threads(), want_d=True)
+    for plan in (1, 0):
+        L.kbo_set_plan(plan, 14, 40)
+        dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"))
+        dev.ms.fill_(0xEE)
+        dev.run()
+        torch.cuda.synchronize()
+        assert np.array_equal(dev.ms[:dev.total].cpu().numpy(), exp_d), plan
+        assert np.array_equal(dev.chars[:dev.total].cpu().numpy(), exp_chars), plan
+        del dev
+    assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars)  # host entry point, slabs
+
+
+def test_c3_c4_shape_pair_kernel_and_plan(oracle, plan_restore):
+    """26 Mbp index (> 24 Mi rows: device copies carry two-base blocks and the plain walk is the PAIR kernel),
+    1.2 M reads: map with formatting and find, every read, plain and plan-guided."""
+    L = plan_restore
+    g = synth.genome(26_000_000, seed=4321)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
+    assert sbwt.n_sets() >= 24 << 20
+    ora = _adopt(oracle, sbwt)
+    concat, offsets = synth.reads(g, 1_200_000, 150, 0.01, seed=99)
+    exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=_threads(), want_d=True)
+    exp_map = np.frombuffer(oracle.relative_to_ref(concat, exp_chars), dtype=np.uint8)
+    L.kbo_set_plan(1, 14, 40)
+    sbwt.to_device(-1)
+    assert sbwt.device_pair_bytes() > 0 and sbwt.device_plan_bytes() > 0
+    for plan in (0, 1):
+        L.kbo_set_plan(plan, 14, 40)
+        d, _, _ = batch.ms_batch(sbwt, concat, offsets)
+        assert np.array_equal(d, exp_d), plan
+        assert np.array_equal(batch.map_batch(sbwt, concat, offsets, format=True), exp_map), plan
+    rles, ro = batch.find_batch(sbwt, concat, offsets, kbo_amd.FindOpts(max_gap_len=0))
+    rng = np.random.default_rng(3)
+    for s in rng.integers(0, 1_200_000, 400):
+        exp = oracle.run_lengths_gapped(exp_chars[offsets[s]:offsets[s + 1]].tobytes(), 0)
+        assert [tuple(int(v) for v in r) for r in rles[ro[s]:ro[s + 1]]] == exp
+
+
+def test_big_layout_at_50mbp(oracle, plan_restore):
+    L = plan_restore
+    L.kbo_set_force_big_layout(1)
+    g = synth.genome(50_000_000, seed=777)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
+    ora = _adopt(oracle, sbwt)
+    concat, offsets = synth.reads(g, 300_000, 150, 0.02, seed=5)
+    exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=_threads(), want_d=True)
+    for plan in (0, 1):
+        L.kbo_set_plan(plan, 14, 40)
+        d, _, _ = batch.ms_batch(sbwt, concat, offsets)
+        assert np.array_equal(d, exp_d), plan
+    assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars)
+    d2, lo, hi = batch.ms_batch(sbwt, concat[:3000], offsets[:21], want_intervals=True)
+    for s in range(20):
+        od, olo, ohi = ora.matching_statistics(concat[150 * s:150 * s + 150].tobytes())
+        assert np.array_equal(lo[150 * s:150 * s + 150], olo.astype(np.uint32)) and np.array_equal(hi[150 * s:150 * s + 150], ohi.astype(np.uint32))
