@@ -40,8 +40,17 @@ def parse():
     ap.add_argument("--find", action="store_true",
                     help="time kbo::find instead of kbo::map: the step ends with format::run_lengths on the device")
     ap.add_argument("--waves-per-cu", type=int, default=0)
+    ap.add_argument("--call", action="store_true",
+                    help="time the first pass of kbo call (C5 shape, scaled): MS walk with intervals + the breakpoint scan "
+                         "on the device over 10 kbp reads (defaults: --genome 100000000 --reads 10000 --read-len 10000)")
     ap.add_argument("--no-plan", action="store_true", help="plain walk kernel only (no path cover, no plan-guided walk)")
     args = ap.parse_args()
+    if args.call:
+        args.genome = args.genome if args.genome is not None else 100_000_000
+        args.reads = args.reads if args.reads is not None else 10_000
+        args.read_len = args.read_len if args.read_len != 150 else 10_000
+        args.custom = True
+        return args
     preset = {"C2": (5_000_000, 1_000_000, False), "C3": (100_000_000, 10_000_000, True)}[args.config]
     args.custom = args.genome is not None or args.reads is not None
     args.genome = args.genome if args.genome is not None else preset[0]
@@ -119,8 +128,88 @@ def cpu_baseline_leg(args, genome, concat, offsets, gpu_d, gpu_chars, sbwt=None)
     return base, b_alg, exact, ops
 
 
+def main_call(args):
+    """kbo call, first pass (variant_calling.rs:266-273) over a batch of long reads resident in HBM: A1 with intervals,
+    then the breakpoint scan; what leaves the device is one 16-byte record per site.  Parity: the sites of the first
+    reads against a host scan of the oracle's MS."""
+    import torch
+    import kbo_amd
+    from kbo_amd import batch, derandomize, synth
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    genome = synth.genome(args.genome)
+    cores, _ = usable_cores()
+    sbwt, _ = kbo_amd.build([genome], kbo_amd.BuildOpts(k=args.k, num_threads=min(16, cores)))
+    concat, offsets = synth.reads(genome, args.reads, args.read_len, args.sub_rate)
+    dev = batch.DeviceBatch(sbwt, concat, offsets, device=device, want_intervals=True)
+    thr = derandomize.random_match_threshold(args.k, sbwt.n_kmers(), 4, 1e-7)
+    cap = dev.total // 16 + 1024
+    sites = torch.zeros((cap, 4), dtype=torch.int32, device=device)
+    count = torch.zeros(4, dtype=torch.int32, device=device)
+    stream = torch.cuda.current_stream(device)
+    L = kbo_amd.lib()
+
+    def step():
+        dev.walk(stream)
+        kbo_amd.check(L.kbo_call_sites_dev(dev.ms.data_ptr(), dev.lo.data_ptr(), dev.hi.data_ptr(), dev.off.data_ptr(),
+                                           dev.n_seqs, dev.total, args.k, thr, sites.data_ptr(), cap, count.data_ptr(),
+                                           stream.cuda_stream))
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(device)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        ev[s][0].record(stream)
+        dev.walk(stream)
+        ev[s][1].record(stream)
+        kbo_amd.check(L.kbo_call_sites_dev(dev.ms.data_ptr(), dev.lo.data_ptr(), dev.hi.data_ptr(), dev.off.data_ptr(),
+                                           dev.n_seqs, dev.total, args.k, thr, sites.data_ptr(), cap, count.data_ptr(),
+                                           stream.cuda_stream))
+        ev[s][2].record(stream)
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    walk_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    scan_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    n_sites = int(count[0].item())
+    recs = sites[:min(n_sites, cap)].cpu().numpy().view(np.uint32)
+    # parity: sites of the first reads vs a host scan (variant_calling.rs:268-273) of the oracle's MS
+    exact = None
+    if not args.no_cpu_baseline:
+        from oracle import binding as ora
+        rows, Carr, lcs = sbwt.export_parts()
+        oi = ora.Index.from_parts(args.k, sbwt.n_sets(), sbwt.n_kmers(), rows, Carr, lcs)
+        n_chk = min(args.reads, 40)
+        want = set()
+        for r in range(n_chk):
+            q = concat[r * args.read_len:(r + 1) * args.read_len].tobytes()
+            d, lo, hi = oi.matching_statistics(q)
+            for i in range(1, len(q)):
+                if d[i] < d[i - 1] and d[i - 1] >= thr and d[i] < thr:
+                    for j in range(i + 1, min(i + args.k + 1, len(q))):
+                        if d[j] >= thr and hi[j] - lo[j] == 1:
+                            want.add((r, i, j, int(lo[j])))
+                            break
+        got = {tuple(int(v) for v in x) for x in recs if x[0] < n_chk}
+        exact = got == want and n_sites <= cap
+    bases = dev.total
+    print(json.dumps({
+        "metric": f"query Mbp/sec for kbo call first pass (MS with intervals + breakpoint scan on the device), k={args.k}, "
+                  f"{args.genome / 1e6:g} Mbp SBWT",
+        "value": round(bases * args.steps / elapsed / 1e6, 1), "unit": "Mbp/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"C5 shape, scaled: kbo call first pass, {args.genome / 1e6:g} Mbp iid genome SBWT k={args.k}, "
+                               f"{args.reads} x {args.read_len} bp reads, {args.sub_rate * 100:g}% substitutions",
+                   "threshold": thr, "sites_per_step": n_sites, "bytes_leaving_the_device_per_base": round(16 * n_sites / bases, 4)},
+        "kernels_ms": {"ms_walk_with_intervals": round(walk_ms, 4), "call_sites": round(scan_ms, 4)},
+        "bit_exact_vs_oracle": exact}), flush=True)
+
+
 def main():
     args = parse()
+    if args.call:
+        return main_call(args)
     import torch
     import torch.distributed as dist
 

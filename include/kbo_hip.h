@@ -175,6 +175,20 @@ int kbo_map(kbo_index_t *query_idx, const uint8_t *ref_seq, size_t len, const kb
  * (variant_calling.rs:249-294; all MS passes on the GPU, k-mer walks of the sites batched). */
 int kbo_call(kbo_index_t *query_idx, const uint8_t *ref_seq, size_t len, const kbo_call_opts *opts,
              kbo_variant **out, size_t *n_out);
+/* kbo::call over a batch: every sequence of (concat, offsets) plays ref_seq against the same query index.  The first
+ * pass of call_variants (MS walk + the breakpoint scan, variant_calling.rs:266-273) runs on the device for the whole
+ * batch and only the sites come back; the second pass walks all query-side k-mers in one batch and, per sequence, the
+ * reference-side k-mers against that sequence's own index (lib.rs:553).  *out holds var_offsets[n_seqs] variants, those
+ * of sequence s at [var_offsets[s], var_offsets[s+1]); one allocation, kbo_free(*out).  opts->sbwt_build_opts.k must
+ * equal the index's k (lib.rs:559). */
+int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                   const kbo_call_opts *opts, kbo_variant **out, uint64_t *var_offsets /* n_seqs + 1 */);
+/* The breakpoint scan alone, device-resident: d_ms / d_lo / d_hi as kbo_ms_batch_dev wrote them (intervals requested),
+ * d_sites receives up to `capacity` 16-byte records {sequence, i, j, row of ms[j]} in arrival order, *d_count the number
+ * found (it can exceed capacity: repeat with more room).  Asynchronous on `stream`. */
+int kbo_call_sites_dev(const uint8_t *d_ms, const uint32_t *d_lo, const uint32_t *d_hi, const uint64_t *d_offsets,
+                       size_t n_seqs, uint64_t total_bases, size_t k, size_t threshold, void *d_sites, size_t capacity,
+                       uint32_t *d_count, void *stream);
 /* translate::add_variants (translate.rs:350-386) on Rust-char (u32) alignment strings, in place. */
 int kbo_add_variants(uint32_t *translation, size_t len, const kbo_variant *variants, size_t n_variants);
 /* gap_filling::fill_gaps (gap_filling.rs:444-526) preceded by the steps its callers run

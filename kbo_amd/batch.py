@@ -66,6 +66,19 @@ def find_batch(sbwt, concat, offsets, find_opts=None):
     return rles, ro
 
 
+def call_batch(sbwt, concat, offsets, call_opts=None):
+    """kbo::call with every sequence of the batch as ref_seq -> list (per sequence) of lists of Variant"""
+    from . import CallOpts, variant_calling
+    o = call_opts if call_opts is not None else CallOpts()
+    co = _capi.CallOpts(o.max_error_prob, o.sbwt_build_opts._to_c())
+    concat, offsets, n = _prep(concat, offsets)
+    vo = np.zeros(n + 1, dtype=np.uint64)
+    p = C.POINTER(_capi.Variant)()
+    check(lib().kbo_call_batch(sbwt._h, concat.ctypes.data, offsets.ctypes.data, n, C.byref(co), C.byref(p), vo.ctypes.data))
+    allv = variant_calling._from_c(p, int(vo[-1]))  # (frees the allocation)
+    return [allv[int(vo[s]):int(vo[s + 1])] for s in range(n)]
+
+
 class DeviceBatch:
     """A batch of reads resident in HBM (torch owns the memory, the C ABI gets raw
     pointers and the torch stream).  run() = A1 walk kernel, then fused A5+A6 kernel."""

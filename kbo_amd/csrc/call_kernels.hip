@@ -1,0 +1,72 @@
+// call_kernels.hip — gfx950 (MI355X, CDNA4): the breakpoint scan of variant_calling::call_variants
+// (reference variant_calling.rs:268-273) over a whole batch, on the device, so that only the sites leave it.
+//
+//   for i in 1..len:  if ms[i].d < ms[i-1].d && ms[i-1].d >= t && ms[i].d < t:
+//       first j in i+1 .. min(i+k+1, len) with ms[j].d >= t && interval of ms[j] is one row  ->  site (i, j, row)
+//
+// One lane per base of the concatenated batch: the d test is three byte compares on coalesced loads and is false
+// for all but about one base per mismatch; a lane that passes finds its sequence by binary search over the offsets
+// (needed for i >= 1 and for len) and scans at most k positions to the right.  Sites are appended to one list, one
+// atomic per wave; the host sorts them by (sequence, i).  Integer work only.
+#include "device_util.hpp"
+
+namespace kbo {
+namespace {
+
+__global__ __launch_bounds__(256) void call_sites_kernel(const uint8_t *__restrict__ d, const uint32_t *__restrict__ lo,
+                                                         const uint32_t *__restrict__ hi, const uint64_t *__restrict__ off,
+                                                         uint32_t n_seqs, uint64_t total, uint32_t k, uint32_t t,
+                                                         uint4 *__restrict__ sites, uint32_t cap, uint32_t *__restrict__ count)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool hit = false;
+    uint4 rec = make_uint4(0, 0, 0, 0);
+    if (p >= 1 && p < total) {
+        const uint32_t a = d[p - 1], b = d[p];
+        if (b < a && a >= t && b < t) {
+            uint32_t s0 = 0, s1 = n_seqs; // the sequence that holds p: largest s with off[s] <= p
+            while (s1 - s0 > 1) {
+                const uint32_t m = s0 + (s1 - s0) / 2;
+                if (off[m] <= p) s0 = m;
+                else s1 = m;
+            }
+            const uint64_t b0 = off[s0], e0 = off[s0 + 1];
+            if (p > b0) { // i >= 1: p - 1 belongs to the same sequence
+                const uint64_t j_end = min(p + k + 1u, e0);
+                for (uint64_t j = p + 1; j < j_end; j++) {
+                    if (d[j] >= t && hi[j] - lo[j] == 1u) {
+                        hit = true;
+                        rec = make_uint4(s0, (uint32_t)(p - b0), (uint32_t)(j - b0), lo[j]);
+                        break;
+                    }
+                }
+            }
+        }
+    }
+    const uint64_t mk = __ballot(hit);
+    if (mk) {
+        const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__builtin_ctzll(mk);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mk));
+        base = __shfl(base, leader);
+        const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+        if (hit && slot < cap) sites[slot] = rec;
+    }
+}
+
+} // namespace
+
+// *d_count must be 0 before the launch; afterwards it holds the number of sites found (which may exceed `cap`:
+// only the first `cap` arrivals were stored, the caller repeats with more room)
+hipError_t launch_call_sites(const uint8_t *d_ms, const uint32_t *d_lo, const uint32_t *d_hi, const uint64_t *d_off,
+                             uint32_t n_seqs, uint64_t total, uint32_t k, uint32_t threshold, void *d_sites, uint32_t cap,
+                             uint32_t *d_count, hipStream_t stream)
+{
+    if (total == 0 || n_seqs == 0) return hipSuccess;
+    const uint64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(call_sites_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_ms, d_lo, d_hi, d_off, n_seqs, total,
+                       k, threshold, static_cast<uint4 *>(d_sites), cap, d_count);
+    return hipGetLastError();
+}
+
+} // namespace kbo

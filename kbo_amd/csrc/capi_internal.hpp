@@ -31,6 +31,7 @@ struct kbo_index {
     std::mutex mu;
     std::map<int, kbo_host::DevCopy *> dev;
     uint64_t rank_bytes = 0, lcs_bytes = 0, plan_bytes = 0;
+    bool transient = false; // an index that serves one small batch (kbo::call builds one per sequence): no path cover
     ~kbo_index()
     {
         for (auto &kv : dev) delete kv.second;

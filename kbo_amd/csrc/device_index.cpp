@@ -66,7 +66,7 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
             dc->n_blocks = lay.n_blocks;
             idx->rank_bytes = per * 4;
             idx->lcs_bytes = ent_bytes;
-            if (g_plan_enabled) { // path cover for the plan-guided walk: 9 bytes per row
+            if (g_plan_enabled && !idx->transient) { // path cover for the plan-guided walk: 9 bytes per row
                 kbo::PathCover pc;
                 kbo::make_path_cover(idx->host, pc);
                 static_assert(kbo::PathCover::kPad == kbo::kPlanPad, "text padding");

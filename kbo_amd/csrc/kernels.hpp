@@ -149,6 +149,11 @@ constexpr uint32_t kLongSeq = 1u << 16; // sequences longer than this take the c
 hipError_t launch_translate(const int32_t *d_derand, uint64_t len, uint32_t k, uint32_t threshold,
                             uint8_t *d_chars_out, hipStream_t stream);
 
+// the breakpoint scan of call_variants over a batch (call_kernels.hip): 16-byte records {sequence, i, j, row of ms[j]}
+hipError_t launch_call_sites(const uint8_t *d_ms, const uint32_t *d_lo, const uint32_t *d_hi, const uint64_t *d_off,
+                             uint32_t n_seqs, uint64_t total, uint32_t k, uint32_t threshold, void *d_sites, uint32_t cap,
+                             uint32_t *d_count, hipStream_t stream);
+
 constexpr int kWalkThreads = 64; // default workgroup size (waves are independent: no LDS, no barriers)
 void set_walk_threads(int threads); // tuning: 64, 128 or 256
 void set_walk_rare(int period);            // tuning: hot-loop iterations between rare-block visits

@@ -190,39 +190,23 @@ bool resolve_variant(const std::vector<uint8_t> &query_kmer, const std::vector<u
 
 } // namespace
 
-std::vector<Variant> call_variants(const HostNav &nav_ref, const MsFn &ms_ref, const MsFn &ms_query, uint32_t k,
-                                   const uint8_t *query, size_t len, size_t d)
+void call_site_kmers(const HostNav &nav_ref, const uint8_t *query, uint32_t k, const std::vector<CallSite> &sites,
+                     std::vector<std::vector<uint8_t>> &query_kmers, std::vector<std::vector<uint8_t>> &ref_kmers)
+{
+    for (const CallSite &st : sites) {
+        query_kmers.push_back(get_kmer_ending_at(query, st.j, k)); // variant_calling.rs:275
+        std::vector<uint8_t> rk;
+        nav_ref.access_kmer(st.lo, rk);                            // :276
+        ref_kmers.push_back(std::move(rk));
+    }
+}
+
+std::vector<Variant> resolve_call_sites(const std::vector<CallSite> &sites, const std::vector<uint8_t> *query_kmers,
+                                        const std::vector<uint8_t> *ref_kmers, const std::vector<MsVal> *ms_vs_ref,
+                                        const std::vector<MsVal> *ms_vs_query, size_t d)
 {
     std::vector<Variant> calls;
-    // first pass: whole-sequence MS on the GPU (variant_calling.rs:266)
-    std::vector<std::vector<uint8_t>> one(1, std::vector<uint8_t>(query, query + len));
-    std::vector<std::vector<MsVal>> msv;
-    ms_ref(one, msv);
-    const std::vector<MsVal> &ms = msv[0];
-    // breakpoint scan (variant_calling.rs:268-273): collect the sites, their k-mers
-    struct Site { size_t i, j; };
-    std::vector<Site> sites;
-    std::vector<std::vector<uint8_t>> query_kmers, ref_kmers;
-    for (size_t i = 1; i < len; i++) {
-        if (ms[i].d < ms[i - 1].d && ms[i - 1].d >= d && ms[i].d < d) {
-            for (size_t j = i + 1; j < std::min(i + k + 1, len); j++) {
-                if (ms[j].d >= d && ms[j].hi - ms[j].lo == 1) {
-                    sites.push_back({i, j});
-                    query_kmers.push_back(get_kmer_ending_at(query, j, k));                 // :275
-                    std::vector<uint8_t> rk;
-                    nav_ref.access_kmer(ms[j].lo, rk);                                      // :276
-                    ref_kmers.push_back(std::move(rk));
-                    break;
-                }
-            }
-        }
-    }
-    if (sites.empty()) return calls;
-    // second pass: the two k-length walks of every site, batched on the GPU (:279-280)
-    std::vector<std::vector<MsVal>> ms_vs_ref, ms_vs_query;
-    ms_ref(query_kmers, ms_vs_ref);
-    ms_query(ref_kmers, ms_vs_query);
-    for (size_t s = 0; s < sites.size(); s++) {
+    for (size_t s = 0; s < sites.size(); s++) { // variant_calling.rs:282-284
         Variant v;
         if (resolve_variant(query_kmers[s], ref_kmers[s], ms_vs_query[s], ms_vs_ref[s], d, v.query_chars, v.ref_chars)) {
             v.query_pos = sites[s].i;
@@ -230,6 +214,37 @@ std::vector<Variant> call_variants(const HostNav &nav_ref, const MsFn &ms_ref, c
         }
     }
     return calls;
+}
+
+std::vector<Variant> call_variants(const HostNav &nav_ref, const MsFn &ms_ref, const MsFn &ms_query, uint32_t k,
+                                   const uint8_t *query, size_t len, size_t d)
+{
+    // first pass: whole-sequence MS on the GPU (variant_calling.rs:266)
+    std::vector<std::vector<uint8_t>> one(1, std::vector<uint8_t>(query, query + len));
+    std::vector<std::vector<MsVal>> msv;
+    ms_ref(one, msv);
+    const std::vector<MsVal> &ms = msv[0];
+    // breakpoint scan (variant_calling.rs:268-273) - the batched entry point runs this scan on the device
+    // (call_kernels.hip) and arrives at the same site list
+    std::vector<CallSite> sites;
+    for (size_t i = 1; i < len; i++) {
+        if (ms[i].d < ms[i - 1].d && ms[i - 1].d >= d && ms[i].d < d) {
+            for (size_t j = i + 1; j < std::min(i + k + 1, len); j++) {
+                if (ms[j].d >= d && ms[j].hi - ms[j].lo == 1) {
+                    sites.push_back({i, j, ms[j].lo});
+                    break;
+                }
+            }
+        }
+    }
+    if (sites.empty()) return {};
+    std::vector<std::vector<uint8_t>> query_kmers, ref_kmers;
+    call_site_kmers(nav_ref, query, k, sites, query_kmers, ref_kmers);
+    // second pass: the two k-length walks of every site, batched on the GPU (:279-280)
+    std::vector<std::vector<MsVal>> ms_vs_ref, ms_vs_query;
+    ms_ref(query_kmers, ms_vs_ref);
+    ms_query(ref_kmers, ms_vs_query);
+    return resolve_call_sites(sites, query_kmers.data(), ref_kmers.data(), ms_vs_ref.data(), ms_vs_query.data(), d);
 }
 
 void add_variants(std::vector<uint8_t> &refined, const std::vector<Variant> &variants)

@@ -50,6 +50,19 @@ using MsFn = std::function<void(const std::vector<std::vector<uint8_t>> &seqs, s
 std::vector<Variant> call_variants(const HostNav &nav_ref, const MsFn &ms_ref, const MsFn &ms_query, uint32_t k,
                                    const uint8_t *query, size_t len, size_t threshold_d);
 
+// the two halves of call_variants behind the breakpoint scan, shared with the batched entry point (call_batch.cpp):
+// a site = breakpoint i, the unique match j to its right and that match's row (variant_calling.rs:268-276)
+struct CallSite {
+    size_t i, j;
+    uint32_t lo;
+};
+void call_site_kmers(const HostNav &nav_ref, const uint8_t *query, uint32_t k, const std::vector<CallSite> &sites,
+                     std::vector<std::vector<uint8_t>> &query_kmers, std::vector<std::vector<uint8_t>> &ref_kmers);
+// arrays of sites.size() entries each
+std::vector<Variant> resolve_call_sites(const std::vector<CallSite> &sites, const std::vector<uint8_t> *query_kmers,
+                                        const std::vector<uint8_t> *ref_kmers, const std::vector<MsVal> *ms_vs_ref,
+                                        const std::vector<MsVal> *ms_vs_query, size_t threshold_d);
+
 // translate::add_variants (translate.rs:350-386)
 void add_variants(std::vector<uint8_t> &translation, const std::vector<Variant> &variants);
 

@@ -115,3 +115,45 @@ def test_big_layout_at_50mbp(oracle, plan_restore):
     for s in range(20):
         od, olo, ohi = ora.matching_statistics(concat[150 * s:150 * s + 150].tobytes())
         assert np.array_equal(lo[150 * s:150 * s + 150], olo.astype(np.uint32)) and np.array_equal(hi[150 * s:150 * s + 150], ohi.astype(np.uint32))
+
+
+def test_call_batch_equals_per_sequence_call(oracle):
+    """kbo_call_batch (first pass + breakpoint scan on the device for the whole batch) against kbo::call per sequence:
+    the oracle's literal restatement, and the single-sequence entry point.  Reads with substitutions, insertions and
+    deletions against a 300 kbp index; ragged lengths incl. sequences without a single variant."""
+    rng = np.random.default_rng(2024)
+    g = synth.genome(300_000, seed=606)
+    k = 31
+    sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=k, num_threads=_threads()))
+    ora = oracle.Index.build([g.tobytes()], k=k)
+    reads = []
+    for r in range(120):
+        L = int(rng.choice([200, 1000, 2500, 6000]))
+        a = int(rng.integers(0, len(g) - L - 50))
+        s = bytearray(g[a:a + L].tobytes())
+        if r % 7:  # (every 7th read is an exact copy: no variants)
+            for p in sorted(rng.integers(40, L - 40, max(1, L // 300)), reverse=True):
+                kind = int(rng.integers(0, 3))
+                if kind == 0:
+                    s[p] = b"ACGT"[(b"ACGT".index(s[p]) + 1 + int(rng.integers(0, 3))) % 4]
+                elif kind == 1:
+                    del s[p:p + int(rng.integers(1, 6))]
+                else:
+                    s[p:p] = bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, 6))).astype(np.uint8))
+        reads.append(bytes(s))
+    concat = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    offsets = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+    opts = kbo_amd.CallOpts(sbwt_build_opts=kbo_amd.BuildOpts(k=k, build_select=True))
+    got = batch.call_batch(sbwt, concat, offsets, opts)
+    assert len(got) == len(reads)
+    n_var = 0
+    for s, rd in enumerate(reads):
+        exp, _, _ = ora.call(rd, k, 1e-7)
+        mine = [(v.query_pos, bytes(v.query_chars).decode(), bytes(v.ref_chars).decode()) for v in got[s]]
+        assert mine == exp, s
+        if s % 10 == 0:
+            one = kbo_amd.call(sbwt, lcs, rd, opts)
+            assert mine == [(v.query_pos, bytes(v.query_chars).decode(), bytes(v.ref_chars).decode()) for v in one], s
+        n_var += len(mine)
+    assert n_var > 100
+    assert all(len(got[s]) == 0 for s in range(0, len(reads), 7))
