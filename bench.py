@@ -143,9 +143,10 @@ def main_call(args):
     concat, offsets = synth.reads(genome, args.reads, args.read_len, args.sub_rate)
     dev = batch.DeviceBatch(sbwt, concat, offsets, device=device, want_intervals=True)
     thr = derandomize.random_match_threshold(args.k, sbwt.n_kmers(), 4, 1e-7)
-    cap = dev.total // 16 + 1024
+    LISTS = 256  # KBO_CALL_LISTS
+    cap = (dev.total // 8 + 4096) // LISTS * LISTS
     sites = torch.zeros((cap, 4), dtype=torch.int32, device=device)
-    count = torch.zeros(4, dtype=torch.int32, device=device)
+    count = torch.zeros(LISTS * 16, dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream(device)
     L = kbo_amd.lib()
 
@@ -171,8 +172,11 @@ def main_call(args):
     elapsed = time.perf_counter() - t0
     walk_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     scan_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-    n_sites = int(count[0].item())
-    recs = sites[:min(n_sites, cap)].cpu().numpy().view(np.uint32)
+    counts = count.cpu().numpy()[::16]
+    n_sites, seg = int(counts.sum()), cap // LISTS
+    fits = bool((counts <= seg).all())
+    sites_h = sites.cpu().numpy().view(np.uint32)
+    recs = np.concatenate([sites_h[g * seg:g * seg + min(int(counts[g]), seg)] for g in range(LISTS)]) if n_sites else sites_h[:0]
     # parity: sites of the first reads vs a host scan (variant_calling.rs:268-273) of the oracle's MS
     exact = None
     if not args.no_cpu_baseline:
@@ -191,7 +195,7 @@ def main_call(args):
                             want.add((r, i, j, int(lo[j])))
                             break
         got = {tuple(int(v) for v in x) for x in recs if x[0] < n_chk}
-        exact = got == want and n_sites <= cap
+        exact = got == want and fits
     bases = dev.total
     print(json.dumps({
         "metric": f"query Mbp/sec for kbo call first pass (MS with intervals + breakpoint scan on the device), k={args.k}, "

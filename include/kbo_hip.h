@@ -183,9 +183,12 @@ int kbo_call(kbo_index_t *query_idx, const uint8_t *ref_seq, size_t len, const k
  * equal the index's k (lib.rs:559). */
 int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                    const kbo_call_opts *opts, kbo_variant **out, uint64_t *var_offsets /* n_seqs + 1 */);
-/* The breakpoint scan alone, device-resident: d_ms / d_lo / d_hi as kbo_ms_batch_dev wrote them (intervals requested),
- * d_sites receives up to `capacity` 16-byte records {sequence, i, j, row of ms[j]} in arrival order, *d_count the number
- * found (it can exceed capacity: repeat with more room).  Asynchronous on `stream`. */
+/* The breakpoint scan alone, device-resident: d_ms / d_lo / d_hi as kbo_ms_batch_dev wrote them (intervals requested).
+ * Sites are 16-byte records {sequence, i, j, row of ms[j]} in KBO_CALL_LISTS lists (one counter would serialise the
+ * appends): list g occupies d_sites[g * (capacity / KBO_CALL_LISTS) ...] and has d_count[16 g] records, in arrival
+ * order; d_count is KBO_CALL_LISTS counters 64 bytes apart (16 KiB).  A counter above capacity / KBO_CALL_LISTS means
+ * that list overflowed: repeat with more room.  Asynchronous on `stream`. */
+#define KBO_CALL_LISTS 256
 int kbo_call_sites_dev(const uint8_t *d_ms, const uint32_t *d_lo, const uint32_t *d_hi, const uint64_t *d_offsets,
                        size_t n_seqs, uint64_t total_bases, size_t k, size_t threshold, void *d_sites, size_t capacity,
                        uint32_t *d_count, void *stream);

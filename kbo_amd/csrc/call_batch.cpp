@@ -43,31 +43,38 @@ std::vector<SiteRec> find_sites(kbo_index *idx, const uint8_t *concat, const uin
     hipStream_t stream = nullptr;
     const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
     DevBuf d_sites, d_count;
-    d_count.alloc(16);
+    d_count.alloc(kbo::kCallSegs * 64);
+    std::vector<uint32_t> counts(kbo::kCallSegs * 16);
     for (const Slab &sl : slabs) {
         const size_t ns = sl.s1 - sl.s0;
         std::vector<uint64_t> off(ns + 1);
         for (size_t s = 0; s <= ns; s++) off[s] = offsets[sl.s0 + s] - sl.b0;
         BatchOnDevice B;
         run_walk_host(idx, concat + sl.b0, off.data(), ns, true, B, stream);
-        uint32_t cap = (uint32_t)std::min<uint64_t>((sl.b1 - sl.b0) / 16 + 1024, 0x7FFFFFFFu);
+        uint32_t cap = (uint32_t)std::min<uint64_t>(((sl.b1 - sl.b0) / 16 + 1024) / kbo::kCallSegs * kbo::kCallSegs + kbo::kCallSegs * 16, 0x7FFFFF00u);
         for (;;) {
             d_sites.ensure((size_t)cap * 16);
-            HIP_OK(hipMemsetAsync(d_count.p, 0, 4, stream));
+            HIP_OK(hipMemsetAsync(d_count.p, 0, kbo::kCallSegs * 64, stream));
             HIP_OK(kbo::launch_call_sites(B.ms.as<uint8_t>(), B.lo.as<uint32_t>(), B.hi.as<uint32_t>(), B.off.as<uint64_t>(),
                                           (uint32_t)ns, sl.b1 - sl.b0, idx->host.k, threshold, d_sites.p, cap,
                                           d_count.as<uint32_t>(), stream));
-            uint32_t n = 0;
-            HIP_OK(hipMemcpyAsync(&n, d_count.p, 4, hipMemcpyDeviceToHost, stream));
+            HIP_OK(hipMemcpyAsync(counts.data(), d_count.p, kbo::kCallSegs * 64, hipMemcpyDeviceToHost, stream));
             HIP_OK(hipStreamSynchronize(stream));
-            if (n > cap) { // more sites than room (dense mismatches): once more with exactly enough
-                cap = n;
+            const uint32_t seg_cap = cap / kbo::kCallSegs;
+            uint32_t worst = 0;
+            for (uint32_t g = 0; g < kbo::kCallSegs; g++) worst = std::max(worst, counts[g * 16]);
+            if (worst > seg_cap) { // a list overflowed (dense mismatches): once more with room for the fullest
+                cap = (uint32_t)std::min<uint64_t>((uint64_t)(worst + 16) * kbo::kCallSegs, 0x7FFFFF00u);
                 continue;
             }
-            const size_t at = all.size();
-            all.resize(at + n);
-            if (n) HIP_OK(hipMemcpy(all.data() + at, d_sites.p, (size_t)n * 16, hipMemcpyDeviceToHost));
-            for (size_t x = at; x < all.size(); x++) all[x].seq += (uint32_t)sl.s0;
+            for (uint32_t g = 0; g < kbo::kCallSegs; g++) {
+                const uint32_t n = counts[g * 16];
+                if (!n) continue;
+                const size_t at = all.size();
+                all.resize(at + n);
+                HIP_OK(hipMemcpy(all.data() + at, d_sites.as<uint8_t>() + (size_t)g * seg_cap * 16, (size_t)n * 16, hipMemcpyDeviceToHost));
+                for (size_t x = at; x < all.size(); x++) all[x].seq += (uint32_t)sl.s0;
+            }
             break;
         }
     }
@@ -191,7 +198,8 @@ extern "C" int kbo_call_sites_dev(const uint8_t *d_ms, const uint32_t *d_lo, con
         KBO_REQUIRE(d_ms && d_lo && d_hi && d_offsets && d_sites && d_count, KBO_E_BAD_ARG, "null argument");
         KBO_REQUIRE(n_seqs < 0xFFFFFFFFull && capacity <= 0x7FFFFFFFull && k > 0 && k <= 255, KBO_E_BAD_ARG, "argument out of range");
         hipStream_t s = static_cast<hipStream_t>(stream);
-        HIP_OK(hipMemsetAsync(d_count, 0, 4, s));
+        KBO_REQUIRE(capacity >= kbo::kCallSegs, KBO_E_BAD_ARG, "capacity below the number of lists");
+        HIP_OK(hipMemsetAsync(d_count, 0, kbo::kCallSegs * 64, s));
         HIP_OK(kbo::launch_call_sites(d_ms, d_lo, d_hi, d_offsets, (uint32_t)n_seqs, total_bases, (uint32_t)k, (uint32_t)threshold,
                                       d_sites, (uint32_t)capacity, d_count, s));
     });

@@ -6,7 +6,8 @@
 //
 // One lane per base of the concatenated batch: the d test is three byte compares on coalesced loads and is false
 // for all but about one base per mismatch; a lane that passes finds its sequence by binary search over the offsets
-// (needed for i >= 1 and for len) and scans at most k positions to the right.  Sites are appended to one list, one
+// (needed for i >= 1 and for len); the scan of the at most k positions to its right is done by the whole wave, 64
+// positions per step (one lane scanning alone spends a memory round trip per position).  Sites are appended to one list, one
 // atomic per wave; the host sorts them by (sequence, i).  Integer work only.
 #include "device_util.hpp"
 
@@ -19,45 +20,64 @@ __global__ __launch_bounds__(256) void call_sites_kernel(const uint8_t *__restri
                                                          uint4 *__restrict__ sites, uint32_t cap, uint32_t *__restrict__ count)
 {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool hit = false;
+    const uint32_t lane = threadIdx.x & 63u;
+    bool cand = false, hit = false;
     uint4 rec = make_uint4(0, 0, 0, 0);
+    uint64_t b0 = 0, e0 = 0;
+    uint32_t s0 = 0;
     if (p >= 1 && p < total) {
         const uint32_t a = d[p - 1], b = d[p];
         if (b < a && a >= t && b < t) {
-            uint32_t s0 = 0, s1 = n_seqs; // the sequence that holds p: largest s with off[s] <= p
+            uint32_t s1 = n_seqs; // the sequence that holds p: largest s with off[s] <= p
             while (s1 - s0 > 1) {
                 const uint32_t m = s0 + (s1 - s0) / 2;
                 if (off[m] <= p) s0 = m;
                 else s1 = m;
             }
-            const uint64_t b0 = off[s0], e0 = off[s0 + 1];
-            if (p > b0) { // i >= 1: p - 1 belongs to the same sequence
-                const uint64_t j_end = min(p + k + 1u, e0);
-                for (uint64_t j = p + 1; j < j_end; j++) {
-                    if (d[j] >= t && hi[j] - lo[j] == 1u) {
-                        hit = true;
-                        rec = make_uint4(s0, (uint32_t)(p - b0), (uint32_t)(j - b0), lo[j]);
-                        break;
-                    }
+            b0 = off[s0];
+            e0 = off[s0 + 1];
+            cand = p > b0; // i >= 1: p - 1 belongs to the same sequence
+        }
+    }
+    // the search to the right, one breakpoint at a time with the whole wave: lane x looks at position p + 1 + x (+ 64, ...)
+    for (uint64_t todo = __ballot(cand); todo; todo &= todo - 1) {
+        const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+        const uint64_t pp = ((uint64_t)__shfl((uint32_t)(p >> 32), src) << 32) | __shfl((uint32_t)p, src);
+        const uint64_t ee = ((uint64_t)__shfl((uint32_t)(e0 >> 32), src) << 32) | __shfl((uint32_t)e0, src);
+        const uint64_t j_end = min(pp + k + 1u, ee);
+        for (uint64_t j0 = pp + 1; j0 < j_end; j0 += 64) {
+            const uint64_t j = j0 + lane;
+            const bool ok = j < j_end && d[j] >= t && hi[j] - lo[j] == 1u;
+            const uint64_t okm = __ballot(ok);
+            if (okm) {
+                const uint32_t first = (uint32_t)__builtin_ctzll(okm);
+                const uint64_t jf = j0 + first;
+                const uint32_t row = __shfl(ok ? lo[j] : 0u, first);
+                if (lane == src) {
+                    hit = true;
+                    rec = make_uint4(s0, (uint32_t)(p - b0), (uint32_t)(jf - b0), row);
                 }
+                break;
             }
         }
     }
     const uint64_t mk = __ballot(hit);
     if (mk) {
-        const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__builtin_ctzll(mk);
+        const uint32_t leader = (uint32_t)__builtin_ctzll(mk);
+        // kCallSegs lists instead of one: a single counter would serialise one returning atomic per wave with a site
+        const uint32_t seg = blockIdx.x % kCallSegs, seg_cap = cap / kCallSegs;
         uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mk));
+        if (lane == leader) base = atomicAdd(count + seg * 16u, (uint32_t)__popcll(mk));
         base = __shfl(base, leader);
         const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-        if (hit && slot < cap) sites[slot] = rec;
+        if (hit && slot < seg_cap) sites[(size_t)seg * seg_cap + slot] = rec;
     }
 }
 
 } // namespace
 
-// *d_count must be 0 before the launch; afterwards it holds the number of sites found (which may exceed `cap`:
-// only the first `cap` arrivals were stored, the caller repeats with more room)
+// d_count: kCallSegs counters 64 bytes apart, 0 before the launch; list g holds records [g * (cap / kCallSegs), ... +
+// d_count[16 g]) of d_sites; a counter above cap / kCallSegs means that list overflowed (repeat with more room)
 hipError_t launch_call_sites(const uint8_t *d_ms, const uint32_t *d_lo, const uint32_t *d_hi, const uint64_t *d_off,
                              uint32_t n_seqs, uint64_t total, uint32_t k, uint32_t threshold, void *d_sites, uint32_t cap,
                              uint32_t *d_count, hipStream_t stream)

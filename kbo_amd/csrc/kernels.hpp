@@ -149,7 +149,9 @@ constexpr uint32_t kLongSeq = 1u << 16; // sequences longer than this take the c
 hipError_t launch_translate(const int32_t *d_derand, uint64_t len, uint32_t k, uint32_t threshold,
                             uint8_t *d_chars_out, hipStream_t stream);
 
-// the breakpoint scan of call_variants over a batch (call_kernels.hip): 16-byte records {sequence, i, j, row of ms[j]}
+// the breakpoint scan of call_variants over a batch (call_kernels.hip): 16-byte records {sequence, i, j, row of ms[j]} in
+// kCallSegs lists (see launch_call_sites)
+constexpr uint32_t kCallSegs = 256;
 hipError_t launch_call_sites(const uint8_t *d_ms, const uint32_t *d_lo, const uint32_t *d_hi, const uint64_t *d_off,
                              uint32_t n_seqs, uint64_t total, uint32_t k, uint32_t threshold, void *d_sites, uint32_t cap,
                              uint32_t *d_count, hipStream_t stream);
