@@ -245,9 +245,13 @@ int kbo_find_batch_into(kbo_index_t *idx, const uint8_t *concat, const uint64_t 
 
 /* ------------------------------------------------------------------ device-resident path
  * Everything already in the HBM of the current device; kernels are enqueued on `stream`
- * (a hipStream_t) and the call returns immediately.  d_concat must be 16-byte aligned
- * and have at least 16 readable bytes after its last base,
- * the other buffers 4-byte aligned; sequences shorter than 3 are skipped by the fused
+ * (a hipStream_t) and the call returns immediately.  d_concat must be 16-byte aligned,
+ * the other buffers 4-byte aligned.
+ * SLACK: the kernels move bytes in 16-byte blocks relative to each sequence, so every per-base
+ * buffer handed to these entry points - d_concat, d_ms_out / d_ms, d_ref, d_chars_out / d_chars -
+ * must have at least 16 readable (for outputs: writable) bytes behind its last base, i.e. be
+ * allocated with total_bases + 16 bytes or more (the in-repo callers round up to 16 and add 64).
+ * The calls check what they can: they refuse total_bases + 16 > 2^32.  Sequences shorter than 3 are skipped by the fused
  * derandomize/translate kernel (the host entry points reject them like the reference).
  * d_work is device scratch of at least kbo_work_bytes(...) bytes for the batch (16-byte aligned). */
 size_t kbo_work_bytes(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k);

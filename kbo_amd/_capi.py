@@ -64,7 +64,7 @@ class RLE(C.Structure):
         return tuple(int(getattr(self, n)) for n, _ in self._fields_)
 
 
-# every symbol include/kbo_hip.h declares (checked by tests/test_capi_symbols.py)
+# every symbol include/kbo_hip.h declares (checked by tests/test_capi_host.py)
 SYMBOLS = [
     "kbo_last_error", "kbo_version", "kbo_build_opts_default", "kbo_find_opts_default",
     "kbo_map_opts_default", "kbo_call_opts_default", "kbo_call", "kbo_add_variants", "kbo_fill_gaps",

@@ -438,6 +438,8 @@ private:
         HostTeam &team = HostTeam::get();
         const size_t ns = sl.s1 - sl.s0;
         const uint64_t bytes = sl.b1 - sl.b0;
+        S.busy = true; // from the first enqueue on: if anything below throws, ~CtxLease drains the streams before the
+                       // context (and the caller's pinned buffers the copies read) can be reused
         // stage: slab-relative offsets (and the longest sequence of the slab), query bytes
         S.off.ensure((ns + 1) * sizeof(uint64_t));
         uint64_t *off = S.off.as<uint64_t>();
@@ -671,8 +673,11 @@ void run_on_devices(const BatchJob &job, const std::vector<int> &devices, size_t
 {
     if (nd == 1) {
         const int prev = current_device();
+        struct Restore { // also when run() throws
+            int prev, used;
+            ~Restore() { if (prev != used) (void)hipSetDevice(prev); }
+        } restore{prev, devices[0]};
         SlabWorker(job, devices[0], 0, 1, true).run();
-        if (prev != devices[0]) HIP_OK(hipSetDevice(prev));
         return;
     }
     std::vector<std::thread> threads;

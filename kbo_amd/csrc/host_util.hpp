@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <new>
@@ -141,7 +142,7 @@ public:
     void run(size_t n_tasks, const std::function<void(size_t)> &fn)
     {
         if (n_tasks == 0) return;
-        if (n_tasks == 1 || want_ <= 1) {
+        if (n_tasks == 1 || want_ <= 1) { // (exceptions propagate as they are)
             for (size_t i = 0; i < n_tasks; i++) fn(i);
             return;
         }
@@ -157,9 +158,14 @@ public:
         }
         cv_.notify_all();
         work();
-        std::unique_lock<std::mutex> g(mu_);
-        done_cv_.wait(g, [&] { return remaining_ == 0; });
-        fn_ = nullptr;
+        std::exception_ptr err;
+        {
+            std::unique_lock<std::mutex> g(mu_);
+            done_cv_.wait(g, [&] { return remaining_ == 0; });
+            fn_ = nullptr;
+            std::swap(err, err_);
+        }
+        if (err) std::rethrow_exception(err); // the first exception a task threw, once every task has drained
     }
     void copy(void *dst, const void *src, size_t bytes)
     {
@@ -182,9 +188,15 @@ private:
                 i = next_++;
                 fn = fn_;
             }
-            (*fn)(i);
+            std::exception_ptr err;
+            try {
+                (*fn)(i);
+            } catch (...) { // (on a helper thread an escaping exception would terminate the process)
+                err = std::current_exception();
+            }
             {
                 std::lock_guard<std::mutex> g(mu_);
+                if (err && !err_) err_ = err;
                 if (--remaining_ == 0) done_cv_.notify_all();
             }
         }
@@ -205,6 +217,7 @@ private:
     std::condition_variable cv_, done_cv_;
     std::vector<std::thread> threads_;
     const std::function<void(size_t)> *fn_ = nullptr;
+    std::exception_ptr err_;
     size_t next_ = 0, total_ = 0, remaining_ = 0;
     uint64_t gen_ = 0;
     unsigned want_ = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));

@@ -282,6 +282,12 @@ int kbo_index_from_parts(uint32_t k, uint64_t n_sets, uint64_t n_kmers, const ui
         }
         idx->host.lcs.assign(lcs, lcs + n_sets);
         idx->host.lcs[0] = 0;
+        try {
+            kbo::validate_host_index(idx->host); // C[] vs edge bits, LCS < k: the kernels trust them
+        } catch (...) {
+            delete idx;
+            throw;
+        }
         *out = idx;
     });
 }

@@ -458,6 +458,30 @@ void save_host_index(const HostIndex &h, const std::string &path)
     if (!ok) throw std::runtime_error("short write to " + path);
 }
 
+// Consistency of an index that did not come out of build_host_index (a file, kbo_index_from_parts): the walk kernels
+// trust C[] and the rank data to keep every interval inside [0, n_sets].
+void validate_host_index(const HostIndex &h)
+{
+    auto bad = [](const char *what) { throw std::runtime_error(std::string("inconsistent index: ") + what); };
+    if (h.k < 1 || h.k > 255) bad("k outside 1..255");
+    if (h.n_sets < 1) bad("n_sets == 0");
+    const size_t nw = (h.n_sets + 63) / 64;
+    uint64_t acc = 1;
+    for (int c = 0; c < 4; c++) {
+        if (h.rows[c].size() != nw) bad("subset-matrix row of the wrong length");
+        if (h.n_sets & 63)
+            if (h.rows[c][nw - 1] >> (h.n_sets & 63)) bad("bits set beyond n_sets");
+        if (h.C[c] != acc) bad("C[c] != 1 + number of edge bits of smaller characters");
+        for (size_t w = 0; w < nw; w++) acc += (uint64_t)__builtin_popcountll(h.rows[c][w]);
+    }
+    if (acc != h.n_sets) bad("edge bits != n_sets - 1");
+    if (h.lcs.size() != h.n_sets) bad("LCS array of the wrong length");
+    if (h.lcs[0] != 0) bad("LCS[0] != 0");
+    for (uint64_t i = 0; i < h.n_sets; i++)
+        if (h.lcs[i] >= h.k) bad("LCS value >= k");
+    if (h.n_kmers > h.n_sets) bad("n_kmers > n_sets");
+}
+
 void load_host_index(const std::string &path, HostIndex &h)
 {
     FILE *f = std::fopen(path.c_str(), "rb");
@@ -469,6 +493,10 @@ void load_host_index(const std::string &path, HostIndex &h)
     if (ok) {
         h.k = (uint32_t)hdr[0]; h.n_sets = hdr[1]; h.n_kmers = hdr[2];
         for (int c = 0; c < 4; c++) h.C[c] = hdr[3 + c];
+        if (hdr[0] < 1 || hdr[0] > 255 || h.n_sets < 1 || h.n_sets >= (1ull << 40)) { // (sizes come from the file)
+            std::fclose(f);
+            throw std::runtime_error("bad index file " + path + ": header out of range");
+        }
         size_t nw = (h.n_sets + 63) / 64;
         for (int c = 0; c < 4 && ok; c++) {
             h.rows[c].resize(nw);
@@ -477,8 +505,10 @@ void load_host_index(const std::string &path, HostIndex &h)
         h.lcs.resize(h.n_sets);
         ok = ok && std::fread(h.lcs.data(), 1, h.n_sets, f) == h.n_sets;
     }
+    if (ok) ok = std::fgetc(f) == EOF; // nothing may follow the LCS array
     std::fclose(f);
     if (!ok) throw std::runtime_error("bad or truncated index file " + path);
+    validate_host_index(h);
 }
 
 } // namespace kbo

@@ -71,5 +71,6 @@ void make_path_cover(const HostIndex &h, PathCover &out);
 // flat file (own format, see kbo_capi.cpp)
 void save_host_index(const HostIndex &h, const std::string &path);
 void load_host_index(const std::string &path, HostIndex &h);
+void validate_host_index(const HostIndex &h); // throws std::runtime_error on inconsistent k / C / edge bits / LCS
 
 } // namespace kbo

@@ -148,3 +148,37 @@ def test_compute_fails_loudly_without_gpu():
         with pytest.raises(kbo_amd.KboError) as e:
             call()
         assert e.value.code == -7
+
+
+def test_from_parts_rejects_inconsistent_indexes(tmp_path):
+    """kbo_index_from_parts / kbo_index_load validate what the kernels trust: C[] against the edge bits, LCS < k,
+    file length (an index that came from elsewhere must not be able to send the walk out of bounds)."""
+    import numpy as np
+    from kbo_amd import index as kindex
+    sbwt, _ = kbo_amd.build([b"AAAGAACCA-TCAGGGCG"], kbo_amd.BuildOpts(k=3))
+    rows, Carr, lcs = sbwt.export_parts()
+    ok = kindex.SbwtIndexVariant.from_parts(3, sbwt.n_sets(), sbwt.n_kmers(), rows, Carr, lcs)
+    assert ok.n_sets() == 16
+    for breakage in ("C", "lcs", "bits", "k"):
+        r2, C2, l2, k2 = [r.copy() for r in rows], list(Carr), lcs.copy(), 3
+        if breakage == "C":
+            C2[2] += 1
+        elif breakage == "lcs":
+            l2[5] = 3
+        elif breakage == "bits":
+            r2[0][0] |= np.uint64(1 << 2)
+        else:
+            k2 = 0
+        with pytest.raises(AssertionError):
+            kindex.SbwtIndexVariant.from_parts(k2, sbwt.n_sets(), sbwt.n_kmers(), r2, C2, l2)
+    prefix = str(tmp_path / "idx")
+    kindex.serialize_sbwt(prefix, sbwt)
+    raw = open(prefix + ".kbohip", "rb").read()
+    open(prefix + ".kbohip", "wb").write(raw + b"x")          # trailing bytes
+    with pytest.raises(AssertionError):
+        kindex.load_sbwt(prefix)
+    open(prefix + ".kbohip", "wb").write(raw[:-3])             # truncated
+    with pytest.raises(AssertionError):
+        kindex.load_sbwt(prefix)
+    open(prefix + ".kbohip", "wb").write(raw)
+    assert kindex.load_sbwt(prefix)[0].n_sets() == 16
