@@ -21,6 +21,8 @@ struct DevCopy {
     uint64_t n_blocks = 0;
     bool big = false;
     uint32_t pair_off = 0; // arena index of the two-base extension blocks, 0 = none
+    DevBuf seed_tab;                 // intervals of all strings of seed_d bases (plan_kernel's seeds)
+    uint32_t seed_d = 0;
     DevBuf pc_text, pc_pos, pc_node; // path cover (sbwt_index.hpp PathCover), empty when the plan-guided walk is off
 };
 

@@ -77,6 +77,33 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
                 HIP_OK(hipMemcpy(dc->pc_pos.p, pc.pos.data(), pc.pos.size() * 4, hipMemcpyHostToDevice));
                 HIP_OK(hipMemcpy(dc->pc_node.p, pc.node_at.data(), pc.node_at.size() * 4, hipMemcpyHostToDevice));
                 idx->plan_bytes = pc.text.size() + pc.pos.size() * 4 + pc.node_at.size() * 4;
+                // seed table: the interval of every string of D bases, so that a seed starts D bases deep.  D = 10 for
+                // indexes that can use it (8 MiB), 8 for small ones, none below k = 8.
+                const uint32_t D = idx->host.k >= 10 && idx->host.n_sets >= (1u << 20) ? 10u : (idx->host.k >= 8 ? 8u : 0u);
+                if (D) {
+                    const kbo::HostNav nav(idx->host);
+                    std::vector<uint32_t> cur{0u, (uint32_t)idx->host.n_sets}, nxt; // {l, r} pairs, level by level
+                    for (uint32_t t = 0; t < D; t++) {
+                        nxt.resize(cur.size() * 4);
+                        for (size_t p = 0; p < cur.size() / 2; p++) {
+                            const uint32_t l = cur[2 * p], r = cur[2 * p + 1];
+                            for (int c = 0; c < 4; c++) {
+                                uint32_t l2 = 0, r2 = 0;
+                                if (l < r) {
+                                    l2 = (uint32_t)(idx->host.C[c] + nav.rank(c, l));
+                                    r2 = (uint32_t)(idx->host.C[c] + nav.rank(c, r));
+                                }
+                                nxt[2 * (4 * p + c)] = l2;
+                                nxt[2 * (4 * p + c) + 1] = r2;
+                            }
+                        }
+                        cur.swap(nxt);
+                    }
+                    dc->seed_tab.alloc(cur.size() * 4);
+                    HIP_OK(hipMemcpy(dc->seed_tab.p, cur.data(), cur.size() * 4, hipMemcpyHostToDevice));
+                    dc->seed_d = D;
+                    idx->plan_bytes += cur.size() * 4;
+                }
             }
         } catch (...) {
             delete dc;
@@ -98,6 +125,8 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
     v.k = idx->host.k;
     v.pc_text = dc->pc_text.p ? dc->pc_text.as<uint8_t>() + kbo::kPlanPad : nullptr;
     v.pc_pos = dc->pc_pos.as<uint32_t>();
+    v.seed_tab = dc->seed_d ? dc->seed_tab.as<uint2>() : nullptr;
+    v.seed_d = dc->seed_d;
     v.pc_node = dc->pc_node.as<uint32_t>();
     for (int c = 0; c < 4; c++) v.C[c] = (uint32_t)idx->host.C[c];
     v.C[4] = v.n;

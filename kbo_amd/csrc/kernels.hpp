@@ -21,6 +21,10 @@ struct DevIndexView {
     const uint32_t *pc_pos;    // row -> text position
     const uint32_t *pc_node;   // text position -> row
     uint32_t C[5];             // C[c] of the index, C[4] = n_sets: extend(root, c) = [C[c], C[c+1])
+    // plan_kernel's seed table: interval {l, r} of every string of seed_d bases (code = bases as 2-bit digits, first
+    // base most significant), l >= r when it is no suffix of a row; nullptr / 0 when the index has none
+    const uint2 *seed_tab;
+    uint32_t seed_d;
 };
 
 // One unit of walk work: `len` bases starting at absolute offset `start` of the

@@ -70,37 +70,83 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a)
     const uint32_t dmin = max(1u, min(k, a.plan_dmin & 0xFFFFu)), cap = a.plan_cap;
 
     // ---- 1. seed
+    // state: the interval [l, r) at depth d of the bases [.., j); tab = the next step is a look-up of the seed_d bases
+    // from j on in the seed table (the start of a seed: the item's first bases, or the bases behind a failure)
     uint32_t l = 0, r = n, d = 0, j = 0, j0 = 0;
     bool clean = true, seeded = false;
+    const uint32_t D = a.ix.seed_tab ? a.ix.seed_d : 0u;
+    bool tab = D != 0;
     uint4 qblk = make_uint4(0, 0, 0, 0);
     if (plannable) qblk = ld16u(qb, start);
+    uint32_t qbase = 0; // item position of qblk's first byte
     for (;;) {
         const bool act = plannable && !seeded && j < len && j < cap;
         if (__ballot(act) == 0) break;
         if (act) {
-            const uint32_t ch = (sel4(qblk, (j >> 2) & 3u) >> ((j & 3u) * 8u)) & 0xFFu;
-            const uint32_t c = decode_base(ch);
-            const uint32_t cbk = c < 4u ? c * nblk : null_blk, bmask = c < 4u ? ~0u : 0u;
-            const uint32_t bl = div96(l), br = div96(r);
-            const uint4 xA = ld16(arena, (cbk + (bl & bmask)) << 4), xB = ld16(arena, (cbk + (br & bmask)) << 4);
-            uint32_t l2 = rank_eval(xA, l - bl * kRankRows), r2 = rank_eval(xB, r - br * kRankRows);
-            uint32_t dbase = d;
-            if (l2 >= r2) { // start again from the root with this base: extend(root, c) = [C[c], C[c+1])
-                clean = false;
-                dbase = 0;
-                l2 = c == 0 ? a.ix.C[0] : c == 1 ? a.ix.C[1] : c == 2 ? a.ix.C[2] : c == 3 ? a.ix.C[3] : 0u;
-                r2 = c == 0 ? a.ix.C[1] : c == 1 ? a.ix.C[2] : c == 2 ? a.ix.C[3] : c == 3 ? a.ix.C[4] : 0u;
+            if (tab && j + D <= len) {
+                // ---- D bases at once (they may straddle two query blocks: bytes are fetched one by one from the
+                // current block and the one after it)
+                const uint4 qn = (j + D > qbase + 16u) ? ld16u(qb, start + qbase + 16u) : qblk;
+                uint32_t w = 0, okc = 1;
+                for (uint32_t t = 0; t < D; t++) {
+                    const uint32_t o = j + t - qbase; // 0 .. 31
+                    const uint32_t word = o < 16u ? sel4(qblk, (o >> 2) & 3u) : sel4(qn, (o >> 2) & 3u);
+                    const uint32_t c = decode_base((word >> ((o & 3u) * 8u)) & 0xFFu);
+                    okc &= c < 4u ? 1u : 0u;
+                    w = (w << 2) | (c & 3u);
+                }
+                uint2 iv = make_uint2(0, 0);
+                if (okc) iv = a.ix.seed_tab[w];
+                if (iv.x < iv.y) {
+                    l = iv.x;
+                    r = iv.y;
+                    d = D;
+                    j += D;
+                    tab = false;
+                    if (r == l + 1u && d >= dmin) {
+                        seeded = true;
+                        j0 = j - 1u;
+                    }
+                } else { // no such string in the index: a seed that starts a few bases further on
+                    clean = false;
+                    j += (D + 1u) / 2u;
+                }
+                if (j >= qbase + 16u && !seeded) {
+                    qbase = j & ~15u;
+                    qblk = ld16u(qb, start + qbase);
+                }
+            } else {
+                const uint32_t o = j - qbase;
+                const uint32_t ch = (sel4(qblk, (o >> 2) & 3u) >> ((o & 3u) * 8u)) & 0xFFu;
+                const uint32_t c = decode_base(ch);
+                const uint32_t cbk = c < 4u ? c * nblk : null_blk, bmask = c < 4u ? ~0u : 0u;
+                const uint32_t bl = div96(l), br = div96(r);
+                const uint4 xA = ld16(arena, (cbk + (bl & bmask)) << 4), xB = ld16(arena, (cbk + (br & bmask)) << 4);
+                uint32_t l2 = rank_eval(xA, l - bl * kRankRows), r2 = rank_eval(xB, r - br * kRankRows);
+                uint32_t dbase = d;
+                bool again = false;
+                if (l2 >= r2) { // the seed ends here: start again behind this base (table) or with it (no table)
+                    clean = false;
+                    dbase = 0;
+                    again = D != 0;
+                    l2 = c == 0 ? a.ix.C[0] : c == 1 ? a.ix.C[1] : c == 2 ? a.ix.C[2] : c == 3 ? a.ix.C[3] : 0u;
+                    r2 = c == 0 ? a.ix.C[1] : c == 1 ? a.ix.C[2] : c == 2 ? a.ix.C[3] : c == 3 ? a.ix.C[4] : 0u;
+                }
+                const bool ok = l2 < r2 && !again;
+                l = ok ? l2 : 0u;
+                r = ok ? r2 : n;
+                d = ok ? min(dbase + 1u, k) : 0u;
+                tab = again;
+                if (r == l + 1u && d >= dmin) {
+                    seeded = true;
+                    j0 = j;
+                }
+                j++;
+                if (j >= qbase + 16u && !seeded) {
+                    qbase = j & ~15u;
+                    qblk = ld16u(qb, start + qbase); // stays within the 16-byte slack behind the queries
+                }
             }
-            const bool ok = l2 < r2;
-            l = ok ? l2 : 0u;
-            r = ok ? r2 : n;
-            d = ok ? min(dbase + 1u, k) : 0u;
-            if (r == l + 1u && d >= dmin) {
-                seeded = true;
-                j0 = j;
-            }
-            j++;
-            if ((j & 15u) == 0u && !seeded) qblk = ld16u(qb, start + j); // stays within the 16-byte slack behind the queries
         }
     }
     uint32_t p0 = 0;
