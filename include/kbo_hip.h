@@ -131,6 +131,14 @@ uint64_t kbo_index_n_sets(const kbo_index_t *idx);  /* SbwtIndex::n_sets()      
  * device-ready file format "<prefix>.kbohip" (NOT the sbwt crate's .sbwt/.lcs). */
 int kbo_index_save(const kbo_index_t *idx, const char *path);
 int kbo_index_load(const char *path, kbo_index_t **out);
+/* index::serialize_sbwt / load_sbwt (index.rs:128-151, 195-212): the file pair <prefix>.sbwt + <prefix>.lcs.  The part of
+ * the format the reference itself writes - the u64-LE length and the tag "SubsetMatrix" (index.rs:139-140) - is
+ * reproduced; the payload behind it belongs to the sbwt crate's own serialize() and is NOT pinned by anything in the
+ * reference tree, so these functions write and read their own payload (second tag
+ * "KBOSBWT1") and kbo_index_load_sbwt returns KBO_E_UNSUPPORTED for a file kbo-cli wrote: such an index comes in
+ * through kbo_index_from_parts.  KBO_E_IO when a file is missing, truncated or inconsistent. */
+int kbo_index_save_sbwt(const kbo_index_t *idx, const char *prefix);
+int kbo_index_load_sbwt(const char *prefix, kbo_index_t **out);
 
 /* Upload (idempotent) the device layout to HIP device `device` (-1 = current). */
 int kbo_index_to_device(kbo_index_t *idx, int device);
@@ -320,6 +328,10 @@ int kbo_set_plan_tuning(int gap, int chunk, int bail_x16);
 int kbo_index_path_cover(const kbo_index_t *idx, uint8_t *text, uint32_t *pos, uint32_t *node_at);
 /* bytes of path cover a device copy of this index carries (0 = none) */
 uint64_t kbo_index_device_plan_bytes(const kbo_index_t *idx);
+/* Experiments on the plain walk kernel: only the first lane_limit lanes of every wave take reads
+ * (64 = all; what a sub-wave tiling would have to beat), and every workgroup reserves dummy_lds_bytes of LDS it never
+ * touches (what staging a wave's MS values in LDS for a fused A5/A6 would cost in occupancy). */
+int kbo_set_walk_experiment(int lane_limit, int dummy_lds_bytes);
 int kbo_set_force_big_layout(int on);            /* tests: force the 64-bit-offset contraction-entry layout */
 int kbo_set_slab_bytes(size_t bytes);            /* host batches are processed in slabs of at most this many query bytes (default 32 MiB) */
 

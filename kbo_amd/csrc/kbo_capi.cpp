@@ -336,6 +336,39 @@ int kbo_index_load(const char *path, kbo_index_t **out)
     return rc == KBO_E_BAD_ARG && path && out ? KBO_E_IO : rc;
 }
 
+int kbo_index_save_sbwt(const kbo_index_t *idx, const char *prefix)
+{
+    int rc = guarded([&] {
+        KBO_REQUIRE(idx && prefix, KBO_E_BAD_ARG, "null argument");
+        kbo::save_sbwt_pair(idx->host, prefix);
+    });
+    return rc == KBO_E_BAD_ARG && idx && prefix ? KBO_E_IO : rc;
+}
+
+int kbo_index_load_sbwt(const char *prefix, kbo_index_t **out)
+{
+    int rc = guarded([&] {
+        KBO_REQUIRE(prefix && out, KBO_E_BAD_ARG, "null argument");
+        *out = nullptr;
+        kbo_index *idx = new kbo_index();
+        bool own = false;
+        try {
+            own = kbo::load_sbwt_pair(prefix, idx->host);
+        } catch (...) {
+            delete idx;
+            throw;
+        }
+        if (!own) {
+            delete idx;
+            throw KboError(KBO_E_UNSUPPORTED,
+                           std::string(prefix) + ".sbwt was written by the sbwt crate: its field layout behind the SubsetMatrix tag is not "
+                           "pinned by the reference (index.rs:143); hand the index over with kbo_index_from_parts");
+        }
+        *out = idx;
+    });
+    return rc == KBO_E_BAD_ARG && prefix && out ? KBO_E_IO : rc;
+}
+
 int kbo_index_to_device(kbo_index_t *idx, int device)
 {
     return guarded([&] {
@@ -943,6 +976,12 @@ int kbo_index_path_cover(const kbo_index_t *idx, uint8_t *text, uint32_t *pos, u
         std::memcpy(pos, pc.pos.data(), idx->host.n_sets * 4);
         std::memcpy(node_at, pc.node_at.data(), idx->host.n_sets * 4);
     });
+}
+
+int kbo_set_walk_experiment(int lane_limit, int dummy_lds_bytes)
+{
+    kbo::set_walk_experiment(lane_limit, dummy_lds_bytes);
+    return KBO_OK;
 }
 
 int kbo_set_plan_tuning(int gap, int chunk, int bail_x16)

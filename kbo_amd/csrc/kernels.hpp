@@ -84,6 +84,7 @@ struct WalkArgs {
     uint32_t rounds;       // items per lane (set by launch_ms_walk)
     uint32_t rare_period;  // hot-loop iterations between two visits of the rare block (set by launch_ms_walk)
     uint32_t pair_min_d;   // two-base steps only from matches at least this deep (set by launch_ms_walk)
+    uint32_t lane_limit;   // plain kernel: lanes from this one on get no items (64 = all work; experiments)
     uint8_t *d_out;        // 1 byte per base, same indexing as q
     uint32_t *lo_out;      // optional (nullptr): interval start per base
     uint32_t *hi_out;      // optional: interval end per base
@@ -162,6 +163,7 @@ hipError_t launch_call_sites(const uint8_t *d_ms, const uint32_t *d_lo, const ui
 
 constexpr int kWalkThreads = 64; // default workgroup size (waves are independent: no LDS, no barriers)
 void set_walk_threads(int threads); // tuning: 64, 128 or 256
+void set_walk_experiment(int lane_limit, int dummy_lds_bytes); // experiments behind DESIGN.md section 6
 void set_walk_rare(int period);            // tuning: hot-loop iterations between rare-block visits
 void set_pair_min_depth(int d);            // tuning: depth from which two-base steps are tried
 constexpr uint32_t kRankRows = 96; // rows per 16-byte rank block (== kRankRowsPerBlock)

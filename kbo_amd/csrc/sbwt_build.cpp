@@ -511,4 +511,82 @@ void load_host_index(const std::string &path, HostIndex &h)
     validate_host_index(h);
 }
 
+// ---- <prefix>.sbwt / <prefix>.lcs, the file pair of index::serialize_sbwt / load_sbwt (reference index.rs:128-151,
+// 195-212).  What the reference itself writes is pinned: the u64-LE length 12 and the tag "SubsetMatrix" in front of the
+// .sbwt file (index.rs:139-140).  What follows is written by the sbwt crate's own `serialize` (index.rs:143, 150), whose
+// field layout is not in the reference tree and could not be checked here (no crate source, no sample file): PARITY
+// UNPINNED.  This implementation therefore writes its own payload behind the pinned header, marked by a second tag, and
+// refuses - loudly, with KBO_E_UNSUPPORTED - a payload it did not write instead of guessing at the crate's fields; an
+// index built by kbo-cli comes in through kbo_index_from_parts.
+static const char kSbwtTag[12] = {'S', 'u', 'b', 's', 'e', 't', 'M', 'a', 't', 'r', 'i', 'x'};
+static const char kOwnSbwt[8] = {'K', 'B', 'O', 'S', 'B', 'W', 'T', '1'};
+static const char kOwnLcs[8] = {'K', 'B', 'O', 'L', 'C', 'S', '0', '1'};
+
+void save_sbwt_pair(const HostIndex &h, const std::string &prefix)
+{
+    const std::string sp = prefix + ".sbwt", lp = prefix + ".lcs";
+    FILE *f = std::fopen(sp.c_str(), "wb");
+    if (!f) throw std::runtime_error("Expected write access to " + sp);
+    const uint64_t taglen = 12, hdr[7] = {h.k, h.n_sets, h.n_kmers, h.C[0], h.C[1], h.C[2], h.C[3]};
+    const size_t nw = (h.n_sets + 63) / 64;
+    bool ok = std::fwrite(&taglen, 8, 1, f) == 1 && std::fwrite(kSbwtTag, 1, 12, f) == 12 &&
+              std::fwrite(kOwnSbwt, 1, 8, f) == 8 && std::fwrite(hdr, 8, 7, f) == 7;
+    for (int c = 0; c < 4 && ok; c++) ok = std::fwrite(h.rows[c].data(), 8, nw, f) == nw;
+    std::fclose(f);
+    if (!ok) throw std::runtime_error("short write to " + sp);
+    f = std::fopen(lp.c_str(), "wb");
+    if (!f) throw std::runtime_error("Expected write access to " + lp);
+    const uint64_t n = h.n_sets;
+    ok = std::fwrite(kOwnLcs, 1, 8, f) == 8 && std::fwrite(&n, 8, 1, f) == 1 && std::fwrite(h.lcs.data(), 1, n, f) == n;
+    std::fclose(f);
+    if (!ok) throw std::runtime_error("short write to " + lp);
+}
+
+// returns false (h untouched) when the .sbwt payload was not written by save_sbwt_pair
+bool load_sbwt_pair(const std::string &prefix, HostIndex &h)
+{
+    const std::string sp = prefix + ".sbwt", lp = prefix + ".lcs";
+    FILE *f = std::fopen(sp.c_str(), "rb");
+    if (!f) throw std::runtime_error("Expected SBWT at " + sp);
+    uint64_t taglen = 0, hdr[7];
+    char tag[12], own[8];
+    bool ok = std::fread(&taglen, 8, 1, f) == 1 && taglen == 12 && std::fread(tag, 1, 12, f) == 12 &&
+              std::memcmp(tag, kSbwtTag, 12) == 0;
+    if (!ok) {
+        std::fclose(f);
+        throw std::runtime_error(sp + ": not an .sbwt file (header is not the SubsetMatrix tag, index.rs:139-140)");
+    }
+    if (std::fread(own, 1, 8, f) != 8 || std::memcmp(own, kOwnSbwt, 8) != 0) {
+        std::fclose(f);
+        return false;
+    }
+    HostIndex t;
+    ok = std::fread(hdr, 8, 7, f) == 7 && hdr[0] >= 1 && hdr[0] <= 255 && hdr[1] >= 1 && hdr[1] < (1ull << 40);
+    if (ok) {
+        t.k = (uint32_t)hdr[0]; t.n_sets = hdr[1]; t.n_kmers = hdr[2];
+        for (int c = 0; c < 4; c++) t.C[c] = hdr[3 + c];
+        const size_t nw = (t.n_sets + 63) / 64;
+        for (int c = 0; c < 4 && ok; c++) {
+            t.rows[c].resize(nw);
+            ok = std::fread(t.rows[c].data(), 8, nw, f) == nw;
+        }
+        ok = ok && std::fgetc(f) == EOF;
+    }
+    std::fclose(f);
+    if (!ok) throw std::runtime_error("bad or truncated index file " + sp);
+    f = std::fopen(lp.c_str(), "rb");
+    if (!f) throw std::runtime_error("Expected LCS array at " + lp);
+    uint64_t n = 0;
+    ok = std::fread(own, 1, 8, f) == 8 && std::memcmp(own, kOwnLcs, 8) == 0 && std::fread(&n, 8, 1, f) == 1 && n == t.n_sets;
+    if (ok) {
+        t.lcs.resize(n);
+        ok = std::fread(t.lcs.data(), 1, n, f) == n && std::fgetc(f) == EOF;
+    }
+    std::fclose(f);
+    if (!ok) throw std::runtime_error("bad, truncated or mismatched LCS file " + lp);
+    validate_host_index(t);
+    h = std::move(t);
+    return true;
+}
+
 } // namespace kbo

@@ -71,6 +71,8 @@ void make_path_cover(const HostIndex &h, PathCover &out);
 // flat file (own format, see kbo_capi.cpp)
 void save_host_index(const HostIndex &h, const std::string &path);
 void load_host_index(const std::string &path, HostIndex &h);
+void save_sbwt_pair(const HostIndex &h, const std::string &prefix); // <prefix>.sbwt + <prefix>.lcs (sbwt_build.cpp)
+bool load_sbwt_pair(const std::string &prefix, HostIndex &h);       // false: payload written by the sbwt crate itself
 void validate_host_index(const HostIndex &h); // throws std::runtime_error on inconsistent k / C / edge bits / LCS
 
 } // namespace kbo

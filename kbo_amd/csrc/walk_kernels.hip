@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
     // this lane's items: first, first + 64, ...
     const uint32_t n_items = a.n_items_dev ? min(*a.n_items_dev, a.n_items) : a.n_items; // (redo pass: counted on the device)
     const uint64_t first64 = (uint64_t)wave * 64u * a.rounds + lane;
-    uint32_t next_item = first64 < n_items ? (uint32_t)first64 : n_items;
+    uint32_t next_item = (first64 < n_items && lane < a.lane_limit) ? (uint32_t)first64 : n_items;
     uint32_t left = 0; // items whose descriptor has not been requested yet
     if (next_item < n_items) left = min(a.rounds, (n_items - 1u - next_item) / 64u + 1u);
 
@@ -412,6 +412,12 @@ hipError_t launch_make_chunk_items(const uint64_t *d_offsets, uint32_t n_seqs, u
 
 int g_walk_threads = kWalkThreads;
 int g_rare_period = 8; // tuned on C2 (tools/sweep_walk.py RARE=1)
+int g_walk_lane_limit = 64, g_walk_dummy_lds = 0; // experiments (kbo_set_walk_experiment): see DESIGN.md section 6
+void set_walk_experiment(int lane_limit, int dummy_lds_bytes)
+{
+    g_walk_lane_limit = std::max(1, std::min(64, lane_limit));
+    g_walk_dummy_lds = std::max(0, std::min(64 << 10, dummy_lds_bytes));
+}
 int g_guided_waves_eighths = 7;            // guided walk: resident waves per SIMD (tuning, kbo_set_walk_waves_per_cu scales it)
 int g_pair_min_depth = 16;                 // two-base steps only from matches at least this deep
 void set_pair_min_depth(int d) { g_pair_min_depth = d < 0 ? 0 : d; }
@@ -426,6 +432,8 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
     const uint64_t lanes = (uint64_t)std::max(1, max_waves) * 64u;
     a.rounds = (uint32_t)((a.n_items + lanes - 1) / lanes);
     a.rare_period = (uint32_t)g_rare_period;
+    a.lane_limit = (uint32_t)g_walk_lane_limit;
+    const uint32_t lds = (uint32_t)g_walk_dummy_lds; // (experiment: LDS the kernel does not touch, to cap the occupancy)
     const uint64_t per_wave = 64ull * a.rounds;
     const uint32_t waves = (uint32_t)((a.n_items + per_wave - 1) / per_wave);
     const uint32_t threads = g_walk_threads;
@@ -458,12 +466,12 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
         return hipGetLastError();
     }
     if (a.ix.big) {
-        if (ival) hipLaunchKernelGGL((ms_walk_kernel<true, true, false>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((ms_walk_kernel<false, true, false>), grid, block, 0, stream, a);
+        if (ival) hipLaunchKernelGGL((ms_walk_kernel<true, true, false>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((ms_walk_kernel<false, true, false>), grid, block, lds, stream, a);
     } else {
-        if (ival) hipLaunchKernelGGL((ms_walk_kernel<true, false, false>), grid, block, 0, stream, a);
-        else if (a.ix.pair_off) hipLaunchKernelGGL((ms_walk_kernel<false, false, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((ms_walk_kernel<false, false, false>), grid, block, 0, stream, a);
+        if (ival) hipLaunchKernelGGL((ms_walk_kernel<true, false, false>), grid, block, lds, stream, a);
+        else if (a.ix.pair_off) hipLaunchKernelGGL((ms_walk_kernel<false, false, true>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((ms_walk_kernel<false, false, false>), grid, block, lds, stream, a);
     }
     return hipGetLastError();
 }

@@ -108,14 +108,27 @@ def build_sbwt_from_vecs(slices, build_options=None):
 
 
 def serialize_sbwt(outfile_prefix, sbwt, lcs=None):
-    """index::serialize_sbwt (index.rs:128-151); own flat format `<prefix>.kbohip`."""
-    check(lib().kbo_index_save(sbwt._h, (outfile_prefix + ".kbohip").encode()))
+    """index::serialize_sbwt (index.rs:128-151): `<prefix>.sbwt` + `<prefix>.lcs` (pinned header, own payload: see
+    kbo_hip.h kbo_index_save_sbwt)."""
+    check(lib().kbo_index_save_sbwt(sbwt._h, outfile_prefix.encode()))
 
 
 def load_sbwt(index_prefix):
     """index::load_sbwt (index.rs:195-212)."""
     h = C.c_void_p()
-    check(lib().kbo_index_load((index_prefix + ".kbohip").encode(), C.byref(h)))
+    check(lib().kbo_index_load_sbwt(index_prefix.encode(), C.byref(h)))
+    sbwt = SbwtIndexVariant(h)
+    return sbwt, LcsArray(sbwt)
+
+
+def save_flat(path, sbwt):
+    """the single-file cache format (`kbo_index_save`)"""
+    check(lib().kbo_index_save(sbwt._h, path.encode()))
+
+
+def load_flat(path):
+    h = C.c_void_p()
+    check(lib().kbo_index_load(path.encode(), C.byref(h)))
     sbwt = SbwtIndexVariant(h)
     return sbwt, LcsArray(sbwt)
 

@@ -171,14 +171,44 @@ def test_from_parts_rejects_inconsistent_indexes(tmp_path):
             k2 = 0
         with pytest.raises(AssertionError):
             kindex.SbwtIndexVariant.from_parts(k2, sbwt.n_sets(), sbwt.n_kmers(), r2, C2, l2)
-    prefix = str(tmp_path / "idx")
-    kindex.serialize_sbwt(prefix, sbwt)
-    raw = open(prefix + ".kbohip", "rb").read()
-    open(prefix + ".kbohip", "wb").write(raw + b"x")          # trailing bytes
+    # the single-file cache format
+    path = str(tmp_path / "idx.kbohip")
+    kindex.save_flat(path, sbwt)
+    raw = open(path, "rb").read()
+    open(path, "wb").write(raw + b"x")          # trailing bytes
+    with pytest.raises(AssertionError):
+        kindex.load_flat(path)
+    open(path, "wb").write(raw[:-3])             # truncated
+    with pytest.raises(AssertionError):
+        kindex.load_flat(path)
+    open(path, "wb").write(raw)
+    assert kindex.load_flat(path)[0].n_sets() == 16
+
+
+def test_sbwt_lcs_file_pair_round_trip_and_foreign_payload(tmp_path):
+    """index::serialize_sbwt / load_sbwt (index.rs:128-151, 195-212; the reference's own test is a round trip,
+    index.rs:277-296).  The header the reference writes is reproduced byte for byte; a payload this library did not
+    write (one from the sbwt crate) is refused as unsupported, not guessed at."""
+    import struct
+    from kbo_amd import index as kindex
+    sbwt, lcs = kbo_amd.build([b"AAAGAACCA-TCAGGGCG"], kbo_amd.BuildOpts(k=3))
+    prefix = str(tmp_path / "serialized_index_1")
+    kindex.serialize_sbwt(prefix, sbwt, lcs)
+    raw = open(prefix + ".sbwt", "rb").read()
+    assert raw[:20] == struct.pack("<Q", 12) + b"SubsetMatrix"          # index.rs:139-140
+    loaded, _ = kindex.load_sbwt(prefix)
+    a, b = sbwt.export_parts(), loaded.export_parts()
+    assert (loaded.k(), loaded.n_sets(), loaded.n_kmers()) == (3, 16, 13)
+    assert all((x == y).all() for x, y in zip(a[0], b[0])) and a[1] == b[1] and (a[2] == b[2]).all()
+    # a payload from elsewhere behind the same header
+    open(prefix + ".sbwt", "wb").write(raw[:20] + b"\x10" + bytes(200))
+    with pytest.raises(kbo_amd.KboError) as e:
+        kindex.load_sbwt(prefix)
+    assert e.value.code == -8  # KBO_E_UNSUPPORTED
+    open(prefix + ".sbwt", "wb").write(b"garbage")
     with pytest.raises(AssertionError):
         kindex.load_sbwt(prefix)
-    open(prefix + ".kbohip", "wb").write(raw[:-3])             # truncated
+    open(prefix + ".sbwt", "wb").write(raw)
+    open(prefix + ".lcs", "wb").write(open(prefix + ".lcs", "rb").read()[:-1])  # LCS file shorter than the index
     with pytest.raises(AssertionError):
         kindex.load_sbwt(prefix)
-    open(prefix + ".kbohip", "wb").write(raw)
-    assert kindex.load_sbwt(prefix)[0].n_sets() == 16

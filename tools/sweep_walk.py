@@ -20,12 +20,12 @@ if os.environ.get("PAIRS"):
     sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=32))
     from kbo_amd import index as kindex
     path = "/tmp/sweep_index"
-    kindex.serialize_sbwt(path, sbwt)
+    kindex.save_flat(path, sbwt)
     base = None
     for setting in os.environ["PAIRS"].split(","):
         min_depth = int(setting)
         kbo_amd.lib().kbo_set_pair_steps((1 << 63) if min_depth < 0 else 0, max(min_depth, 0))
-        sbwt, _ = kindex.load_sbwt(path)
+        sbwt, _ = kindex.load_flat(path)
         dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"))
         stream = torch.cuda.current_stream()
         ts = []
