@@ -20,6 +20,10 @@
 
 #include <algorithm>
 
+#ifndef KBO_K2_NT
+#define KBO_K2_NT 0
+#endif
+
 namespace kbo {
 namespace {
 
@@ -506,8 +510,21 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
                     __builtin_memcpy(&xB, pB, 16);
                 } else {
                     const uint32_t enA = ent_byte0 + ((l + (l << 1)) << 2), enB = ent_byte0 + ((r + (r << 1)) << 2);
+#if KBO_K2_NT // experiment: contraction entries (no reuse) as non-temporal loads, so that they do not push rank blocks out of L2
+                    if (con) {
+                        typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+                        const u32x4a4 va = __builtin_nontemporal_load(reinterpret_cast<const u32x4a4 *>(arena + enA));
+                        const u32x4a4 vb = __builtin_nontemporal_load(reinterpret_cast<const u32x4a4 *>(arena + enB));
+                        xA = make_uint4(va.x, va.y, va.z, va.w);
+                        xB = make_uint4(vb.x, vb.y, vb.z, vb.w);
+                    } else {
+                        xA = ld16u(arena, rkA);
+                        xB = ld16u(arena, rkB);
+                    }
+#else
                     xA = ld16u(arena, con ? enA : rkA);
                     xB = ld16u(arena, con ? enB : rkB);
+#endif
                 }
                 if (flags & G_QF) { // the query block after the current one (reads <= 16 bytes past the item)
                     qnxt = ld16u(qb, min(start + (i & ~15u) + 16u, q_end));
