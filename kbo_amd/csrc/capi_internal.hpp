@@ -48,6 +48,7 @@ extern std::vector<int> g_devices;   // devices the host batch entry points spre
 extern bool g_force_big;             // tests: use the 64-bit-offset entry layout regardless of size
 extern uint64_t g_pair_min_rows;     // indexes with at least this many rows get two-base blocks on the device
 extern size_t g_slab_bytes;          // host batches are cut into slabs of at most this many query bytes
+extern int g_plan_cap_div;           // tests: the unit array gets 1/this of its normal capacity
 extern bool g_plan_enabled;          // device copies carry a path cover and MS-only batches take the plan-guided walk
 
 // ---- device_index.cpp
@@ -57,6 +58,7 @@ int walk_max_waves();                                     // upper bound on resi
 // points a.gitems / a.glist into `plan_work` (>= kbo::plan_work_bytes(n_items) bytes, 16-byte aligned) when the index
 // view carries a path cover and the launch wants MS values only; otherwise leaves them null (plain walk)
 void attach_plan(kbo::WalkArgs &a, void *plan_work);
+void plan_reset_holdoff();
 void plan_after_launch(const kbo::WalkArgs &a, hipStream_t stream); // after launch_ms_walk: lets the host learn whether the plan paid
 
 // ---- A3 (kbo_capi.cpp): derandomize.rs:91-145

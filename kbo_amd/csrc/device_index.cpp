@@ -10,6 +10,7 @@ int g_waves_per_cu = 0;
 bool g_force_big = false;
 uint64_t g_pair_min_rows = 24ull << 20;
 bool g_plan_enabled = true;
+int g_plan_cap_div = 1;
 
 int current_device()
 {
@@ -158,6 +159,12 @@ uint32_t *plan_bailed_slot()
 }
 } // namespace
 
+void plan_reset_holdoff() // an explicit kbo_set_plan(1, ..) plans the next launch, whatever earlier batches looked like
+{
+    g_plan_holdoff.store(0);
+    if (uint32_t *slot = g_plan_bailed.load()) *reinterpret_cast<volatile uint32_t *>(slot) = 0;
+}
+
 void plan_after_launch(const kbo::WalkArgs &a, hipStream_t stream)
 {
     if (!a.gitems || !a.qctl) return;
@@ -190,6 +197,7 @@ void attach_plan(kbo::WalkArgs &a, void *plan_work)
     a.gitems = reinterpret_cast<kbo::GuidedItem *>(w);
     w += ni * sizeof(kbo::GuidedItem);
     a.unit_cap = (uint32_t)std::min<size_t>(kbo::plan_unit_cap(ni, a.q_bytes), 0xFFFFFF00u);
+    if (g_plan_cap_div > 1) a.unit_cap = std::max<uint32_t>(1u, a.unit_cap / (uint32_t)g_plan_cap_div); // (tests: force the overflow path)
     a.units = reinterpret_cast<kbo::WalkUnit *>(w);
     w += (size_t)a.unit_cap * sizeof(kbo::WalkUnit);
     a.glist = reinterpret_cast<uint16_t *>(w);

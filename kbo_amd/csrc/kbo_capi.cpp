@@ -956,6 +956,7 @@ int kbo_set_pair_steps(uint64_t min_rows, int min_depth)
 int kbo_set_plan(int enabled, int seed_depth, int seed_cap)
 {
     if (enabled >= 0) g_plan_enabled = enabled != 0; // launches from now on; path covers of device copies made from now on
+    if (enabled > 0) plan_reset_holdoff();
     extern int g_plan_dmin_shadow, g_plan_cap_shadow;
     if (seed_depth > 0) g_plan_dmin_shadow = seed_depth;
     if (seed_cap > 0) g_plan_cap_shadow = seed_cap;
@@ -987,7 +988,10 @@ int kbo_set_walk_experiment(int lane_limit, int dummy_lds_bytes)
 int kbo_set_plan_tuning(int gap, int chunk, int bail_x16)
 {
     kbo::set_plan_params(0, 0, gap, chunk);
-    if (bail_x16 >= 0) kbo::set_plan_bail(bail_x16);
+    if (bail_x16 >= 0) {
+        kbo::set_plan_bail(bail_x16 & 0xFFFF);
+        g_plan_cap_div = std::max(1, bail_x16 >> 16); // tests: bits 16.. = divisor of the unit array's capacity
+    }
     return KBO_OK;
 }
 

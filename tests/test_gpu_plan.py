@@ -24,7 +24,7 @@ def plan_defaults():
     L = kbo_amd.lib()
     yield L
     L.kbo_set_plan(1, 14, 40)
-    L.kbo_set_plan_tuning(24, 32, 32)
+    L.kbo_set_plan_tuning(24, 32, (1 << 16) | 32)
 
 
 def _workload(rng, ref_seqs, n_reads):
@@ -73,8 +73,9 @@ def test_plan_guided_walk_equals_plain_walk_and_oracle(oracle, plan_defaults, k)
     L.kbo_set_plan(0, 14, 40)
     d_plain, _, _ = batch.ms_batch(sbwt, concat, offsets)
     assert np.array_equal(d_plain, exp_d)
-    settings = [(14, 40, 24, 32, 1 << 20), (14, 40, 2, 16, 1 << 20), (1, 8, 5, 64, 1 << 20), (3, 48, 24, 32, 1 << 20),
-                (14, 40, 24, 32, 0), (14, 40, 24, 32, 1 << 20)]
+    settings = [(14, 40, 24, 32, 0xFFFF), (14, 40, 2, 16, 0xFFFF), (1, 8, 5, 64, 0xFFFF), (3, 48, 24, 32, 0xFFFF),
+                (14, 40, 24, 32, 0), (14, 40, 24, 32, (40 << 16) | 0xFFFF),  # unit array 1/40 of its size: overflow path
+                (14, 40, 24, 32, 0xFFFF)]
     for dmin, cap, gap, chunk, bail in settings:
         L.kbo_set_plan(1, dmin, cap)
         L.kbo_set_plan_tuning(gap, chunk, bail)
