@@ -389,8 +389,12 @@ int kbo_index_device_bytes(const kbo_index_t *idx, uint64_t *rank_bytes, uint64_
 
 uint64_t kbo_index_device_pair_bytes(const kbo_index_t *idx)
 {
-    if (!idx || idx->host.n_sets < g_pair_min_rows || g_force_big) return 0;
-    return (idx->host.n_sets / kbo::kRankRowsPerBlock + 2) * 16 * 16;
+    if (!idx) return 0;
+    uint64_t bytes = 0; // what the device copies actually carry (none for the 64-bit entry layout)
+    std::lock_guard<std::mutex> g(const_cast<kbo_index *>(idx)->mu);
+    for (const auto &kv : idx->dev)
+        if (kv.second->pair_off) bytes = std::max<uint64_t>(bytes, (kv.second->n_blocks) * 16ull * 16ull);
+    return bytes;
 }
 
 int kbo_log_rm_max_cdf(size_t t, size_t alphabet_size, size_t n_kmers, double *out)

@@ -20,10 +20,6 @@
 
 #include <algorithm>
 
-#ifndef KBO_K2_NT
-#define KBO_K2_NT 0
-#endif
-
 namespace kbo {
 namespace {
 
@@ -71,7 +67,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a)
         warm = it.w;
     }
     const bool plannable = have_item && len > 0;
-    const uint32_t dmin = max(1u, min(k, a.plan_dmin & 0xFFFFu)), cap = a.plan_cap;
+    const uint32_t dmin = max(1u, min(k, a.plan_dmin)), cap = a.plan_cap;
 
     // ---- 1. seed
     // state: the interval [l, r) at depth d of the bases [.., j); tab = the next step is a look-up of the seed_d bases
@@ -165,7 +161,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a)
     // back to back, so that every 128-byte line they touch is fetched (written) once, not once per 16 bytes - with
     // thousands of waves in flight a line does not survive in L2 from one step to the next
     for (uint32_t base0 = 0;; base0 += 64u) {
-        const bool act = seeded && base0 < len && !(a.plan_dmin & 0x20000u); // EXPERIMENT: bit 17 = no compare
+        const bool act = seeded && base0 < len;
         if (__ballot(act) == 0) break;
         if (act) {
             uint4 qv[4], tv[4], pv[4];
@@ -210,17 +206,15 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a)
                     }
                 }
             }
-            if (!(a.plan_dmin & 0x10000u)) { // EXPERIMENT: bit 16 = no stores
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const uint32_t base = base0 + 16u * g;
-                    if (base < len) {
-                        const uint32_t nb = min(16u, len - base);
-                        const uint32_t lo = warm > base ? min(warm - base, 16u) : 0u;
-                        uint8_t *o = a.d_out + (start + base);
-                        if (lo == 0 && nb == 16u) __builtin_memcpy(o, &pv[g], 16); // (plain store: the four blocks of a step merge in L2)
-                        else st_range(o, pv[g], lo, nb);
-                    }
+            for (int g = 0; g < 4; g++) {
+                const uint32_t base = base0 + 16u * g;
+                if (base < len) {
+                    const uint32_t nb = min(16u, len - base);
+                    const uint32_t lo = warm > base ? min(warm - base, 16u) : 0u;
+                    uint8_t *o = a.d_out + (start + base);
+                    if (lo == 0 && nb == 16u) __builtin_memcpy(o, &pv[g], 16); // (plain store: the four blocks of a step merge in L2)
+                    else st_range(o, pv[g], lo, nb);
                 }
             }
         }
@@ -374,7 +368,7 @@ enum : uint32_t {
 // {lcs, psv, nsv} entries, one loop with a hot path and a bookkeeping block) over units instead of items:
 //  * a unit starts from the diagonal's row in front of its first base (prefetched with the unit's record and query
 //    block by the bookkeeping block) or from the root;
-//  * after every accepted base at the end of an output word, once the group's last mismatch is behind:
+//  * after every accepted base, once the group's last mismatch is behind:
 //    converged = single-row interval && d == min(k, bases since that mismatch) -> the unit is done;
 //  * a unit that reaches its bound first (and the bound is not the item's end) flags the item for the full walk;
 //  * output in words (4 bases), bytes at the two ends of the walked stretch, so that a unit patches the predicted
@@ -510,21 +504,8 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
                     __builtin_memcpy(&xB, pB, 16);
                 } else {
                     const uint32_t enA = ent_byte0 + ((l + (l << 1)) << 2), enB = ent_byte0 + ((r + (r << 1)) << 2);
-#if KBO_K2_NT // experiment: contraction entries (no reuse) as non-temporal loads, so that they do not push rank blocks out of L2
-                    if (con) {
-                        typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
-                        const u32x4a4 va = __builtin_nontemporal_load(reinterpret_cast<const u32x4a4 *>(arena + enA));
-                        const u32x4a4 vb = __builtin_nontemporal_load(reinterpret_cast<const u32x4a4 *>(arena + enB));
-                        xA = make_uint4(va.x, va.y, va.z, va.w);
-                        xB = make_uint4(vb.x, vb.y, vb.z, vb.w);
-                    } else {
-                        xA = ld16u(arena, rkA);
-                        xB = ld16u(arena, rkB);
-                    }
-#else
                     xA = ld16u(arena, con ? enA : rkA);
                     xB = ld16u(arena, con ? enB : rkB);
-#endif
                 }
                 if (flags & G_QF) { // the query block after the current one (reads <= 16 bytes past the item)
                     qnxt = ld16u(qb, min(start + (i & ~15u) + 16u, q_end));
@@ -570,7 +551,10 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
                 if (accept) {
                     const bool fin = i + 1u == bound;
                     const uint32_t e = i - warm; // output index (wraps below warm; only its low bits are used then)
-                    const bool word_done = (e & 3u) == 3u || fin;
+                    // converged: the walk is provably back on the diagonal (see the header); the unit ends here
+                    const bool conv = !(uflags & kUnitPlain) && (int32_t)i >= last_mm && r == l + 1u &&
+                                      d == min((uint32_t)((int32_t)i - last_mm), k);
+                    const bool word_done = (e & 3u) == 3u || fin || conv;
                     if (i >= out_from) {
                         ocur |= d << ((e & 3u) * 8u);
                         if (word_done) {
@@ -586,8 +570,6 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
                             wlo = 0;
                         }
                     }
-                    const bool conv = !(uflags & kUnitPlain) && word_done && (int32_t)i >= last_mm && r == l + 1u &&
-                                      d == min((uint32_t)((int32_t)i - last_mm), k);
                     if (fin && !conv && !(uflags & (kUnitPlain | kUnitToEnd))) { // reached the next group unconverged
                         a.redo[item] = 1;
 #ifdef KBO_WALK_DEBUG

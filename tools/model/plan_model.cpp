@@ -221,9 +221,10 @@ static void k2_unit(const Model &M, const uint8_t *q, const Item &it, const Plan
         M.step(s, q[it.start + i], f, cl);
         C.k2_accept++; C.k2_fail += f; C.k2_climb += cl;
         const bool fin = i + 1 == u.bound;
-        bool word_done;
         const uint32_t e = i - it.warm;
-        word_done = (e & 3u) == 3u || fin;
+        const int64_t dp = (int64_t)i - u.last_mm;
+        conv = !u.plain && (int32_t)i >= u.last_mm && s.r == s.l + 1 && s.d == (uint32_t)(dp < (int64_t)k ? dp : k);
+        const bool word_done = (e & 3u) == 3u || fin || conv;
         if (i >= u.out_from) {
             ocur |= s.d << (8 * (e & 3u));
             if (word_done) {
@@ -232,8 +233,6 @@ static void k2_unit(const Model &M, const uint8_t *q, const Item &it, const Plan
                 ocur = 0; wlo = 0;
             }
         }
-        const int64_t dp = (int64_t)i - u.last_mm;
-        conv = !u.plain && (int32_t)i >= u.last_mm && word_done && s.r == s.l + 1 && s.d == (uint32_t)(dp < (int64_t)k ? dp : k);
         i++;
         if (conv) break;
     }
