@@ -3,6 +3,7 @@
 //   host_batch.cpp    host batches: slabs, staging, the three-stage pipeline, run-length sink,
 //   kbo_capi.cpp      the extern "C" entry points.
 #pragma once
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -43,13 +44,16 @@ struct kbo_index {
 namespace kbo_host {
 
 // ---- tuning state (set through the kbo_set_* entry points)
-extern int g_waves_per_cu;           // walk: resident waves per CU, 0 = default (32)
-extern std::vector<int> g_devices;   // devices the host batch entry points spread slabs over (empty = current)
-extern bool g_force_big;             // tests: use the 64-bit-offset entry layout regardless of size
-extern uint64_t g_pair_min_rows;     // indexes with at least this many rows get two-base blocks on the device
-extern size_t g_slab_bytes;          // host batches are cut into slabs of at most this many query bytes
-extern int g_plan_cap_div;           // tests: the unit array gets 1/this of its normal capacity
-extern bool g_plan_enabled;          // device copies carry a path cover and MS-only batches take the plan-guided walk
+extern std::atomic<int> g_waves_per_cu;           // walk: resident waves per CU, 0 = default (32)
+extern std::vector<int> g_devices;   // guarded by g_devices_mu: read it through devices_snapshot()
+extern std::mutex g_devices_mu;
+std::vector<int> devices_snapshot();
+//   // devices the host batch entry points spread slabs over (empty = current)
+extern std::atomic<bool> g_force_big;             // tests: use the 64-bit-offset entry layout regardless of size
+extern std::atomic<uint64_t> g_pair_min_rows;     // indexes with at least this many rows get two-base blocks on the device
+extern std::atomic<size_t> g_slab_bytes;          // host batches are cut into slabs of at most this many query bytes
+extern std::atomic<int> g_plan_cap_div;           // tests: the unit array gets 1/this of its normal capacity
+extern std::atomic<bool> g_plan_enabled;          // device copies carry a path cover and MS-only batches take the plan-guided walk
 
 // ---- device_index.cpp
 int current_device();

@@ -6,11 +6,12 @@
 
 namespace kbo_host {
 
-int g_waves_per_cu = 0;
-bool g_force_big = false;
-uint64_t g_pair_min_rows = 24ull << 20;
-bool g_plan_enabled = true;
-int g_plan_cap_div = 1;
+// tuning state: set through the kbo_set_* entry points, possibly while other threads are inside calls
+std::atomic<int> g_waves_per_cu{0};
+std::atomic<bool> g_force_big{false};
+std::atomic<uint64_t> g_pair_min_rows{24ull << 20};
+std::atomic<bool> g_plan_enabled{true};
+std::atomic<int> g_plan_cap_div{1};
 
 int current_device()
 {
@@ -197,7 +198,8 @@ void attach_plan(kbo::WalkArgs &a, void *plan_work)
     a.gitems = reinterpret_cast<kbo::GuidedItem *>(w);
     w += ni * sizeof(kbo::GuidedItem);
     a.unit_cap = (uint32_t)std::min<size_t>(kbo::plan_unit_cap(ni, a.q_bytes), 0xFFFFFF00u);
-    if (g_plan_cap_div > 1) a.unit_cap = std::max<uint32_t>(1u, a.unit_cap / (uint32_t)g_plan_cap_div); // (tests: force the overflow path)
+    const int cap_div = g_plan_cap_div.load();
+    if (cap_div > 1) a.unit_cap = std::max<uint32_t>(1u, a.unit_cap / (uint32_t)cap_div); // (tests: force the overflow path)
     a.units = reinterpret_cast<kbo::WalkUnit *>(w);
     w += (size_t)a.unit_cap * sizeof(kbo::WalkUnit);
     a.glist = reinterpret_cast<uint16_t *>(w);
@@ -217,7 +219,8 @@ int walk_max_waves()
     int dev = current_device();
     int cus = 0;
     HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    int per = g_waves_per_cu > 0 ? g_waves_per_cu : 32;
+    const int wpc = g_waves_per_cu.load();
+    int per = wpc > 0 ? wpc : 32;
     return std::max(1, cus) * per;
 }
 

@@ -11,6 +11,12 @@
 namespace kbo_host {
 
 std::vector<int> g_devices;
+std::mutex g_devices_mu;
+std::vector<int> devices_snapshot()
+{
+    std::lock_guard<std::mutex> g(g_devices_mu);
+    return g_devices;
+}
 
 // ---- work decomposition ------------------------------------------------------------------
 // Reads become one item each.  Longer sequences are cut into chunks that restart the walk
@@ -151,7 +157,7 @@ void run_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offset
 // (a) one launch stays below the 32-bit offset limits and (b) the H2D copy of slab i+1 and
 // the D2H copy of slab i-1 overlap the kernels of slab i (two streams, user buffers pinned
 // in place with hipHostRegister when that succeeds).
-size_t g_slab_bytes = 32ull << 20; // tools/bench_host.py: best of 8..128 MiB on the C2 reads
+std::atomic<size_t> g_slab_bytes{32ull << 20}; // tools/bench_host.py: best of 8..128 MiB on the C2 reads
 
 
 std::vector<Slab> make_slabs(const uint64_t *offsets, size_t n_seqs, size_t max_bytes)
@@ -722,7 +728,7 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
     KBO_REQUIRE(scan.shortest > 2, KBO_E_LEN_LE_2, "len > 2 (derandomize.rs:276, translate.rs:270)");
     clk.lap("argument checks");
     const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
-    std::vector<int> devices = g_devices;
+    std::vector<int> devices = devices_snapshot();
     if (devices.empty()) devices.push_back(current_device());
     const size_t nd = std::min(devices.size(), std::max<size_t>(1, slabs.size()));
     BatchJob job;
@@ -770,8 +776,8 @@ void ms_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *offset
     KBO_REQUIRE(scan.longest < 0xFFFFFFFFull, KBO_E_UNSUPPORTED, "sequence longer than 2^32-1");
     PhaseClock clk;
     // intervals cost 8 more bytes per base on the device and on the way back: smaller slabs
-    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, lo_out ? std::max<size_t>(1u << 16, g_slab_bytes / 4) : g_slab_bytes);
-    std::vector<int> devices = g_devices;
+    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, lo_out ? std::max<size_t>(1u << 16, g_slab_bytes.load() / 4) : g_slab_bytes.load());
+    std::vector<int> devices = devices_snapshot();
     if (devices.empty()) devices.push_back(current_device());
     const size_t nd = std::min(devices.size(), std::max<size_t>(1, slabs.size()));
     BatchJob job;

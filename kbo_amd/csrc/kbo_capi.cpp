@@ -794,8 +794,6 @@ int kbo_find(kbo_index_t *idx, const uint8_t *query, size_t len, const kbo_find_
 
 void kbo_free(void *p) { std::free(p); }
 
-int g_plan_dmin_shadow = 14, g_plan_cap_shadow = 40;
-
 namespace {
 // work buffer of kbo_ms_batch_dev: items, then the scan scratch of the chunked item list
 struct DevWork {
@@ -932,6 +930,7 @@ int kbo_set_devices(const int *devices, int n)
         int count = 0;
         HIP_OK(hipGetDeviceCount(&count));
         for (int i = 0; i < n; i++) KBO_REQUIRE(devices[i] >= 0 && devices[i] < count, KBO_E_BAD_ARG, "no such device");
+        std::lock_guard<std::mutex> g(g_devices_mu);
         g_devices.assign(devices, devices + n);
     });
 }
@@ -961,10 +960,7 @@ int kbo_set_plan(int enabled, int seed_depth, int seed_cap)
 {
     if (enabled >= 0) g_plan_enabled = enabled != 0; // launches from now on; path covers of device copies made from now on
     if (enabled > 0) plan_reset_holdoff();
-    extern int g_plan_dmin_shadow, g_plan_cap_shadow;
-    if (seed_depth > 0) g_plan_dmin_shadow = seed_depth;
-    if (seed_cap > 0) g_plan_cap_shadow = seed_cap;
-    kbo::set_plan_params(g_plan_dmin_shadow, g_plan_cap_shadow);
+    kbo::set_plan_params(seed_depth, seed_cap); // (<= 0 keeps a value)
     if (const char *e = std::getenv("KBO_PLAN_GAP")) kbo::set_plan_params(0, 0, std::atoi(e), 0);   // experiments
     if (const char *e = std::getenv("KBO_PLAN_BAIL")) kbo::set_plan_bail(std::atoi(e));
     if (const char *e = std::getenv("KBO_PLAN_CHUNK")) kbo::set_plan_params(0, 0, 0, std::atoi(e));

@@ -19,6 +19,7 @@
 #include "device_util.hpp"
 
 #include <algorithm>
+#include <atomic>
 
 namespace kbo {
 namespace {
@@ -611,8 +612,8 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
 
 } // namespace
 
-int g_plan_dmin = 14, g_plan_cap = 40, g_plan_gap = 24, g_plan_chunk = 32;
-int g_plan_bail_x16 = 32; // give the plan up when there are more than this many units per 16 items
+std::atomic<int> g_plan_dmin{14}, g_plan_cap{40}, g_plan_gap{24}, g_plan_chunk{32};
+std::atomic<int> g_plan_bail_x16{32}; // give the plan up when there are more than this many units per 16 items
 void set_plan_bail(int units_per_16_items) { g_plan_bail_x16 = std::max(0, units_per_16_items); }
 void set_plan_params(int dmin, int cap, int gap, int chunk)
 {
@@ -626,11 +627,11 @@ void set_plan_params(int dmin, int cap, int gap, int chunk)
 hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
 {
     if (a.n_items == 0) return hipSuccess;
-    a.plan_dmin = (uint32_t)g_plan_dmin;
-    a.plan_cap = (uint32_t)g_plan_cap;
-    a.plan_gap = (uint32_t)g_plan_gap;
-    a.plan_chunk = (uint32_t)g_plan_chunk;
-    a.unit_bail = (uint32_t)std::min<uint64_t>((uint64_t)a.n_items * (uint64_t)g_plan_bail_x16 / 16u + 64u, 0xFFFFFFFFu);
+    a.plan_dmin = (uint32_t)g_plan_dmin.load();
+    a.plan_cap = (uint32_t)g_plan_cap.load();
+    a.plan_gap = (uint32_t)g_plan_gap.load();
+    a.plan_chunk = (uint32_t)g_plan_chunk.load();
+    a.unit_bail = (uint32_t)std::min<uint64_t>((uint64_t)a.n_items * (uint64_t)g_plan_bail_x16.load() / 16u + 64u, 0xFFFFFFFFu);
     const hipError_t e = hipMemsetAsync(a.qctl, 0, 64, stream);
     if (e != hipSuccess) return e;
     const uint32_t nb = (a.n_items + 255u) / 256u;

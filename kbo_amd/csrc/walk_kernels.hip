@@ -18,6 +18,7 @@
 #include "device_util.hpp"
 
 #include <algorithm>
+#include <atomic>
 
 namespace kbo {
 namespace {
@@ -410,16 +411,17 @@ hipError_t launch_make_chunk_items(const uint64_t *d_offsets, uint32_t n_seqs, u
     return hipGetLastError();
 }
 
-int g_walk_threads = kWalkThreads;
-int g_rare_period = 8; // tuned on C2 (tools/sweep_walk.py RARE=1)
-int g_walk_lane_limit = 64, g_walk_dummy_lds = 0; // experiments (kbo_set_walk_experiment): see DESIGN.md section 6
+// tuning state (kbo_set_* entry points; may change while other threads launch: atomics, read once per launch)
+std::atomic<int> g_walk_threads{kWalkThreads};
+std::atomic<int> g_rare_period{8}; // tuned on C2 (tools/sweep_walk.py RARE=1)
+std::atomic<int> g_walk_lane_limit{64}, g_walk_dummy_lds{0}; // experiments (kbo_set_walk_experiment): see DESIGN.md section 6
 void set_walk_experiment(int lane_limit, int dummy_lds_bytes)
 {
     g_walk_lane_limit = std::max(1, std::min(64, lane_limit));
     g_walk_dummy_lds = std::max(0, std::min(64 << 10, dummy_lds_bytes));
 }
-int g_guided_waves_eighths = 7;            // guided walk: resident waves per SIMD (tuning, kbo_set_walk_waves_per_cu scales it)
-int g_pair_min_depth = 16;                 // two-base steps only from matches at least this deep
+std::atomic<int> g_guided_waves_eighths{7};            // guided walk: resident waves per SIMD (tuning, kbo_set_walk_waves_per_cu scales it)
+std::atomic<int> g_pair_min_depth{16};                 // two-base steps only from matches at least this deep
 void set_pair_min_depth(int d) { g_pair_min_depth = d < 0 ? 0 : d; }
 void set_walk_rare(int period) { g_rare_period = std::max(1, std::min(1024, period)); }
 void set_walk_threads(int t) { g_walk_threads = (t == 64 || t == 128 || t == 256) ? t : kWalkThreads; }
@@ -431,22 +433,22 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
     // items with as little slack as possible (one 64-lane wave per workgroup)
     const uint64_t lanes = (uint64_t)std::max(1, max_waves) * 64u;
     a.rounds = (uint32_t)((a.n_items + lanes - 1) / lanes);
-    a.rare_period = (uint32_t)g_rare_period;
-    a.lane_limit = (uint32_t)g_walk_lane_limit;
-    const uint32_t lds = (uint32_t)g_walk_dummy_lds; // (experiment: LDS the kernel does not touch, to cap the occupancy)
+    a.rare_period = (uint32_t)g_rare_period.load();
+    a.lane_limit = (uint32_t)g_walk_lane_limit.load();
+    const uint32_t lds = (uint32_t)g_walk_dummy_lds.load(); // (experiment: LDS the kernel does not touch, to cap the occupancy)
     const uint64_t per_wave = 64ull * a.rounds;
     const uint32_t waves = (uint32_t)((a.n_items + per_wave - 1) / per_wave);
-    const uint32_t threads = g_walk_threads;
+    const uint32_t threads = (uint32_t)g_walk_threads.load();
     const uint32_t wpb = threads / 64;
     const dim3 grid((waves + wpb - 1) / wpb), block(threads);
     const bool ival = a.lo_out && a.hi_out;
-    a.pair_min_d = (uint32_t)g_pair_min_depth;
+    a.pair_min_d = (uint32_t)g_pair_min_depth.load();
     if (a.gitems && a.glist && a.ix.pc_text && !ival) { // MS values only, index with a path cover: plan, then guided walk
         hipError_t e = launch_plan(a, stream);
         if (e != hipSuccess) return e;
         // the guided kernel holds 7 waves per SIMD (65 VGPRs) and takes its items off a queue: one resident wave per
         // slot, but no more waves than there are chunks of 64 items
-        const uint32_t gwaves = (uint32_t)std::min<uint64_t>((uint64_t)std::max(1, max_waves * g_guided_waves_eighths / 8),
+        const uint32_t gwaves = (uint32_t)std::min<uint64_t>((uint64_t)std::max(1, max_waves * g_guided_waves_eighths.load() / 8),
                                                              ((uint64_t)a.unit_cap + 63) / 64);
         e = launch_ms_walk_guided(a, (gwaves + wpb - 1) / wpb, threads, stream);
         if (e != hipSuccess) return e;

@@ -157,3 +157,33 @@ def test_call_batch_equals_per_sequence_call(oracle):
         n_var += len(mine)
     assert n_var > 100
     assert all(len(got[s]) == 0 for s in range(0, len(reads), 7))
+
+
+def test_host_batches_over_two_distinct_devices(oracle):
+    """kbo_set_devices with two different GPUs: index replicated on both, slabs dealt round-robin, disjoint output
+    slices, no exchange.  Skipped on boxes with one GPU (the round-end GPU box has one; the
+    same path with the device list (0, 0) runs in test_host_batches_in_slabs)."""
+    import ctypes
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    g = synth.genome(400_000, seed=52)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    concat, offsets = synth.reads(g, 60_000, 150, 0.01)
+    exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=_threads(), want_d=True)
+    L = kbo_amd.lib()
+    try:
+        L.kbo_set_slab_bytes(1 << 20)
+        devs = (ctypes.c_int * 2)(0, 1)
+        kbo_amd.check(L.kbo_set_devices(devs, 2))
+        assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars)
+        d, _, _ = batch.ms_batch(sbwt, concat, offsets)
+        assert np.array_equal(d, exp_d)
+        rles, ro = batch.find_batch(sbwt, concat, offsets, kbo_amd.FindOpts(max_gap_len=0))
+        for s in (0, 1, 30_000, 59_999):
+            assert [tuple(int(v) for v in r) for r in rles[ro[s]:ro[s + 1]]] == \
+                oracle.run_lengths_gapped(exp_chars[offsets[s]:offsets[s + 1]].tobytes(), 0)
+    finally:
+        L.kbo_set_devices(None, 0)
+        L.kbo_set_slab_bytes(32 << 20)
