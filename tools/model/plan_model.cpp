@@ -48,6 +48,30 @@ struct Model {
         }
         make_path_cover(h, pc);
     }
+    // ---- shallow tables: presence of every string of 1..D bases (as suffix of a row) and the interval of every D-mer
+    uint32_t D = 0;
+    std::vector<std::vector<uint8_t>> present; // present[t][code]
+    std::vector<uint32_t> tabD;                // {l, r} per D-mer
+    void build_shallow(uint32_t d_max)
+    {
+        D = std::min(d_max, k);
+        present.assign(D + 1, {});
+        std::vector<uint32_t> cur{0u, n}, nxt;
+        for (uint32_t t = 1; t <= D; t++) {
+            nxt.assign(cur.size() * 4, 0);
+            present[t].assign(cur.size() / 2 * 4, 0);
+            for (size_t p = 0; p < cur.size() / 2; p++)
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t l = cur[2 * p], r = cur[2 * p + 1];
+                    uint32_t l2 = 0, r2 = 0;
+                    if (l < r) { l2 = (uint32_t)h.C[c] + rank(c, l); r2 = (uint32_t)h.C[c] + rank(c, r); }
+                    nxt[2 * (4 * p + c)] = l2; nxt[2 * (4 * p + c) + 1] = r2;
+                    present[t][4 * p + c] = l2 < r2;
+                }
+            cur.swap(nxt);
+        }
+        tabD = cur;
+    }
     uint32_t rank(int c, uint32_t i) const
     {
         uint32_t w = i >> 6, o = i & 63;
@@ -240,6 +264,106 @@ static void k2_unit(const Model &M, const uint8_t *q, const Item &it, const Plan
     if (conv && i < u.bound) C.k2_done_early++;
 }
 
+// ---- the hybrid walk of a unit: while the depth is at most D the state is just (d, the last d bases): the next depth
+// is the longest suffix of at most d+1 bases that is present (presence is closed under taking substrings, so the
+// reference's extend / contract loop ends exactly there); the interval is fetched from the D-mer table when the depth
+// reaches D, and from then on the walk is the ordinary one until a contraction takes it below D again.
+struct HybridCounters { uint64_t tests = 0, tab = 0, ext = 0, fail = 0, climb = 0, iters = 0; };
+static HybridCounters g_hy;
+static void k2_unit_hybrid(const Model &M, const uint8_t *q, const Item &it, const Plan &pl, const Unit &u, uint8_t *ms,
+                           uint8_t *redo)
+{
+    const uint32_t k = M.k, D = M.D;
+    Model::St s{0, M.n, 0};
+    bool shallow = true; // root = shallow with d = 0
+    uint64_t hist = 0; // the last bases as 2-bit digits, newest in the low bits (at least D + 1 of them are kept)
+    uint32_t vlen = 0; // how many of them are valid (ACGT, inside the item), capped at D + 1
+    if (!u.head) {
+        s.l = M.pc.node_at[(uint32_t)(pl.p0 + u.pos - 1)];
+        s.r = s.l + 1;
+        s.d = u.d_start;
+        shallow = false;
+    }
+    // (the last bases before pos are needed when the walk drops into shallow mode: take them from the query)
+    auto reload_hist = [&](uint32_t i) { // history = bases [i - D, i) as far as they are ACGT and inside the item
+        hist = 0; vlen = 0;
+        for (uint32_t t = (i > D + 1 ? i - (D + 1) : 0); t < i; t++) {
+            const int c = Model::code(q[it.start + t]);
+            if (c < 0) { hist = 0; vlen = 0; } else { hist = (hist << 2) | (uint64_t)c; vlen = std::min(vlen + 1, D + 1); }
+        }
+    };
+    if (!u.head) reload_hist(u.pos); // (a unit that starts at the root must not see the bases in front of it)
+    uint32_t i = u.pos;
+    bool conv = false;
+    while (i < u.bound) {
+        const int c = Model::code(q[it.start + i]);
+        if (c < 0) { hist = 0; vlen = 0; } else { hist = (hist << 2) | (uint64_t)c; vlen = std::min(vlen + 1, D + 1); }
+        if (shallow && s.d == D && D < k && c >= 0) { // the depth has reached the table: fetch the interval of the last D bases (before c)
+            const uint32_t key = (uint32_t)((hist >> 2) & ((1ull << (2 * D)) - 1ull)); // (d == D: the D bases before c are valid)
+            s.l = M.tabD[2 * key]; s.r = M.tabD[2 * key + 1];
+            shallow = false;
+            g_hy.tab++; g_hy.iters++;
+        }
+        if (!shallow) {
+            // ordinary step, but a contraction that lands below D switches to shallow mode
+            uint32_t l2 = 0, r2 = 0;
+            auto ext = [&](uint32_t l, uint32_t r) {
+                if (c < 0) { l2 = r2 = 0; return; }
+                l2 = (uint32_t)M.h.C[c] + M.rank(c, l); r2 = (uint32_t)M.h.C[c] + M.rank(c, r);
+            };
+            ext(s.l, s.r); g_hy.ext++; g_hy.iters++;
+            bool failed = false;
+            while (s.d > 0 && l2 >= r2) {
+                failed = true;
+                // one level up: m = max(lcs[l], lcs[r]) is where the interval changes next
+                const uint32_t lm = s.l < M.n ? M.h.lcs[s.l] : 0, rm = s.r < M.n ? M.h.lcs[s.r] : 0;
+                const uint32_t m = std::max(lm, rm);
+                g_hy.climb++; g_hy.iters++;
+                if (m < D || m == 0) { // lengths m+1 and below are decided by the presence tables
+                    shallow = true;
+                    s.d = m; // depth before this base, as far as the candidates go
+                    break;
+                }
+                s.d = m;
+                while (s.l > 0 && M.h.lcs[s.l] >= s.d) s.l--;
+                while (s.r < M.n && M.h.lcs[s.r] >= s.d) s.r++;
+                ext(s.l, s.r); g_hy.ext++; g_hy.iters++;
+            }
+            if (failed) g_hy.fail++;
+            if (!shallow) {
+                if (l2 < r2) { s.l = l2; s.r = r2; s.d = s.d + 1 < k ? s.d + 1 : k; }
+            }
+        }
+        if (shallow) {
+            uint32_t t = std::min(std::min(s.d + 1, std::min(vlen, D)), std::min(D, k));
+            g_hy.iters++;
+            while (t > 0) {
+                g_hy.tests++;
+                const uint32_t key = (uint32_t)(hist & ((1ull << (2 * t)) - 1ull));
+                if (M.present[t][key]) break;
+                t--;
+            }
+            s.d = t; s.l = 0; s.r = M.n; // (no interval in shallow mode)
+        }
+        const bool fin = i + 1 == u.bound;
+        const uint32_t e = i - it.warm;
+        const int64_t dp = (int64_t)i - u.last_mm;
+        // convergence needs an interval: in shallow mode at depth D look it up now (it is needed for the next base anyway)
+        if (shallow && s.d == D && D < k && !u.plain && (int32_t)i >= u.last_mm && s.d == (uint32_t)(dp < (int64_t)k ? dp : k)) {
+            const uint32_t key = (uint32_t)(hist & ((1ull << (2 * D)) - 1ull));
+            s.l = M.tabD[2 * key]; s.r = M.tabD[2 * key + 1];
+            shallow = false;
+            g_hy.tab++; g_hy.iters++;
+        }
+        conv = !shallow && !u.plain && (int32_t)i >= u.last_mm && s.r == s.l + 1 && s.d == (uint32_t)(dp < (int64_t)k ? dp : k);
+        if (i >= u.out_from) ms[it.start + i] = (uint8_t)s.d;
+        (void)e; (void)fin;
+        i++;
+        if (conv) break;
+    }
+    if (!conv && !u.plain && !u.to_end) redo[u.item] = 1;
+}
+
 struct Workload {
     std::vector<uint8_t> q;
     std::vector<Item> items;
@@ -281,6 +405,7 @@ static int run(const Model &M, const Workload &W, const char *name, bool verbose
     uint64_t max_unit = 0, redone = 0;
     for (const Unit &u : units) {
         const uint64_t before = C.k2_accept + C.k2_fail + C.k2_climb;
+        if (M.D) { k2_unit_hybrid(M, W.q.data(), W.items[u.item], plans[u.item], u, ms.data(), redo.data()); continue; }
         k2_unit(M, W.q.data(), W.items[u.item], plans[u.item], u, ms.data(), redo.data(), C);
         const uint64_t iters = C.k2_accept + C.k2_fail + C.k2_climb - before;
         max_unit = std::max(max_unit, iters);
@@ -302,6 +427,12 @@ static int run(const Model &M, const Workload &W, const char *name, bool verbose
             for (uint32_t i = 0; i < it.len; i++) { M.step(st, W.q[it.start + i], f, cl); if (i >= it.warm) ms[it.start + i] = (uint8_t)st.d; }
         }
     g_units += units.size(); g_redone += redone;
+    if (verbose && M.D) {
+        const double nu = (double)units.size();
+        printf("   hybrid (D=%u) per unit: iterations %.1f = presence rounds + table look-ups %.2f + extends %.1f + climbs %.2f; presence tests %.1f, failed extends %.2f\n",
+               M.D, g_hy.iters / nu, g_hy.tab / nu, g_hy.ext / nu, g_hy.climb / nu, g_hy.tests / nu, g_hy.fail / nu);
+        g_hy = HybridCounters();
+    }
     if (verbose) printf("   units %.2f per item, longest unit %llu iterations, items flagged for a full walk %.3f%%\n",
                         units.size() / (double)W.items.size(), (unsigned long long)max_unit, 100.0 * redone / W.items.size());
     uint64_t bad = 0, first_bad = ~0ull;
@@ -362,6 +493,7 @@ int main(int argc, char **argv)
             HostIndex h;
             try { build(seqs, k, h); } catch (const std::exception &e) { printf("build failed: %s\n", e.what()); continue; }
             Model M(h);
+            if (rnd() % 3) M.build_shallow(1 + rnd() % 8);
             Workload W;
             const int nreads = 100;
             for (int r = 0; r < nreads; r++) {
@@ -420,6 +552,7 @@ int main(int argc, char **argv)
     for (uint64_t r = 0; r < R; r++) W.items.push_back({r * L, L, 0});
     if (getenv("GAP")) g_gap = atoi(getenv("GAP"));
     if (getenv("CHUNK")) g_chunk = atoi(getenv("CHUNK"));
+    if (getenv("HYB")) const_cast<Model &>(M).build_shallow((uint32_t)atoi(getenv("HYB")));
     for (uint32_t dm : {14u}) {
         g_dmin = dm;
         char name[64];
