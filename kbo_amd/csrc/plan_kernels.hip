@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
 
 } // namespace
 
-std::atomic<int> g_plan_dmin{14}, g_plan_cap{40}, g_plan_gap{24}, g_plan_chunk{32};
+std::atomic<int> g_plan_dmin{14}, g_plan_cap{40}, g_plan_gap{20}, g_plan_chunk{32};
 std::atomic<int> g_plan_bail_x16{32}; // give the plan up when there are more than this many units per 16 items
 void set_plan_bail(int units_per_16_items) { g_plan_bail_x16 = std::max(0, units_per_16_items); }
 void set_plan_params(int dmin, int cap, int gap, int chunk)
