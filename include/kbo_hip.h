@@ -191,6 +191,14 @@ int kbo_call(kbo_index_t *query_idx, const uint8_t *ref_seq, size_t len, const k
  * equal the index's k (lib.rs:559). */
 int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                    const kbo_call_opts *opts, kbo_variant **out, uint64_t *var_offsets /* n_seqs + 1 */);
+/* The first pass of call_variants in one go, device-resident: the walk of kbo_ms_batch_dev (MS values to d_ms_out, no
+ * intervals) whose lanes run the breakpoint scan on the values they produce.  Sites are 16-byte records {offset of i in
+ * d_concat, offset of j, row of ms[j], 0} in KBO_CALL_LISTS lists as below; d_count needs KBO_CALL_LISTS * 64 + 64 bytes:
+ * the last counter is non-zero when some read had more than four breakpoints waiting within k bases - then (and when a
+ * list overflowed) use kbo_ms_batch_dev with intervals + kbo_call_sites_dev instead.  Asynchronous on `stream`. */
+int kbo_call_walk_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs,
+                      uint64_t total_bases, size_t max_seq_len, size_t threshold, uint8_t *d_ms_out, void *d_sites,
+                      size_t capacity, uint32_t *d_count, void *d_work, size_t work_bytes, void *stream);
 /* The breakpoint scan alone, device-resident: d_ms / d_lo / d_hi as kbo_ms_batch_dev wrote them (intervals requested).
  * Sites are 16-byte records {sequence, i, j, row of ms[j]} in KBO_CALL_LISTS lists (one counter would serialise the
  * appends): list g occupies d_sites[g * (capacity / KBO_CALL_LISTS) ...] and has d_count[16 g] records, in arrival

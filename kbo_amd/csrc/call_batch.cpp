@@ -36,33 +36,49 @@ void ms_only(kbo_index *idx, const std::vector<std::vector<uint8_t>> &seqs, std:
     }
 }
 
-// first pass on the device: sites of sequences [0, n_seqs), sorted by (sequence, i)
+// first pass on the device: sites of sequences [0, n_seqs), sorted by (sequence, i).  Normally the walk itself finds them
+// (call mode of ms_walk_kernel: no intervals are written at all); a slab in which a lane had more than four breakpoints
+// waiting at once, or whose site lists overflowed, is done again the long way (walk with intervals + call_sites_kernel).
 std::vector<SiteRec> find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, uint32_t threshold)
 {
     std::vector<SiteRec> all;
     hipStream_t stream = nullptr;
     const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
     DevBuf d_sites, d_count;
-    d_count.alloc(kbo::kCallSegs * 64);
-    std::vector<uint32_t> counts(kbo::kCallSegs * 16);
+    const size_t count_bytes = kbo::kCallSegs * 64 + 64;
+    d_count.alloc(count_bytes);
+    std::vector<uint32_t> counts(count_bytes / 4);
+    struct Raw { uint32_t a, b, c, d; };
+    std::vector<Raw> raw;
     for (const Slab &sl : slabs) {
         const size_t ns = sl.s1 - sl.s0;
         std::vector<uint64_t> off(ns + 1);
         for (size_t s = 0; s <= ns; s++) off[s] = offsets[sl.s0 + s] - sl.b0;
-        BatchOnDevice B;
-        run_walk_host(idx, concat + sl.b0, off.data(), ns, true, B, stream);
         uint32_t cap = (uint32_t)std::min<uint64_t>(((sl.b1 - sl.b0) / 16 + 1024) / kbo::kCallSegs * kbo::kCallSegs + kbo::kCallSegs * 16, 0x7FFFFF00u);
+        bool by_walk = true; // first the call mode of the walk, then (if it gave up) the stand-alone scan
         for (;;) {
             d_sites.ensure((size_t)cap * 16);
-            HIP_OK(hipMemsetAsync(d_count.p, 0, kbo::kCallSegs * 64, stream));
-            HIP_OK(kbo::launch_call_sites(B.ms.as<uint8_t>(), B.lo.as<uint32_t>(), B.hi.as<uint32_t>(), B.off.as<uint64_t>(),
-                                          (uint32_t)ns, sl.b1 - sl.b0, idx->host.k, threshold, d_sites.p, cap,
-                                          d_count.as<uint32_t>(), stream));
-            HIP_OK(hipMemcpyAsync(counts.data(), d_count.p, kbo::kCallSegs * 64, hipMemcpyDeviceToHost, stream));
+            HIP_OK(hipMemsetAsync(d_count.p, 0, count_bytes, stream));
+            BatchOnDevice B;
+            std::vector<kbo::WalkItem> items;
+            if (by_walk) {
+                const CallSink sink{d_sites.p, d_count.as<uint32_t>(), cap / kbo::kCallSegs, threshold};
+                enqueue_walk_host(idx, concat + sl.b0, off.data(), ns, false, B, items, stream, 0, nullptr, nullptr, &sink);
+            } else {
+                run_walk_host(idx, concat + sl.b0, off.data(), ns, true, B, stream);
+                HIP_OK(kbo::launch_call_sites(B.ms.as<uint8_t>(), B.lo.as<uint32_t>(), B.hi.as<uint32_t>(), B.off.as<uint64_t>(),
+                                              (uint32_t)ns, sl.b1 - sl.b0, idx->host.k, threshold, d_sites.p, cap,
+                                              d_count.as<uint32_t>(), stream));
+            }
+            HIP_OK(hipMemcpyAsync(counts.data(), d_count.p, count_bytes, hipMemcpyDeviceToHost, stream));
             HIP_OK(hipStreamSynchronize(stream));
             const uint32_t seg_cap = cap / kbo::kCallSegs;
             uint32_t worst = 0;
             for (uint32_t g = 0; g < kbo::kCallSegs; g++) worst = std::max(worst, counts[g * 16]);
+            if (by_walk && counts[kbo::kCallSegs * 16]) { // a lane ran out of room for waiting breakpoints
+                by_walk = false;
+                continue;
+            }
             if (worst > seg_cap) { // a list overflowed (dense mismatches): once more with room for the fullest
                 cap = (uint32_t)std::min<uint64_t>((uint64_t)(worst + 16) * kbo::kCallSegs, 0x7FFFFF00u);
                 continue;
@@ -70,10 +86,16 @@ std::vector<SiteRec> find_sites(kbo_index *idx, const uint8_t *concat, const uin
             for (uint32_t g = 0; g < kbo::kCallSegs; g++) {
                 const uint32_t n = counts[g * 16];
                 if (!n) continue;
-                const size_t at = all.size();
-                all.resize(at + n);
-                HIP_OK(hipMemcpy(all.data() + at, d_sites.as<uint8_t>() + (size_t)g * seg_cap * 16, (size_t)n * 16, hipMemcpyDeviceToHost));
-                for (size_t x = at; x < all.size(); x++) all[x].seq += (uint32_t)sl.s0;
+                raw.resize(n);
+                HIP_OK(hipMemcpy(raw.data(), d_sites.as<uint8_t>() + (size_t)g * seg_cap * 16, (size_t)n * 16, hipMemcpyDeviceToHost));
+                for (const Raw &x : raw) {
+                    if (by_walk) { // {slab offset of i, of j, row}: find the sequence
+                        const size_t s = (size_t)(std::upper_bound(off.begin(), off.end(), (uint64_t)x.a) - off.begin()) - 1;
+                        all.push_back(SiteRec{(uint32_t)(sl.s0 + s), (uint32_t)(x.a - off[s]), (uint32_t)(x.b - off[s]), x.c});
+                    } else {
+                        all.push_back(SiteRec{(uint32_t)(sl.s0 + x.a), x.b, x.c, x.d});
+                    }
+                }
             }
             break;
         }

@@ -111,11 +111,19 @@ OffsetScan scan_offsets(const uint64_t *offsets, size_t n_seqs);
 std::vector<Slab> make_slabs(const uint64_t *offsets, size_t n_seqs, size_t max_bytes);
 // upload + A1 over a host batch (asynchronous on `stream`); leaves ms (and lo/hi) on the device.
 // `items_keep` must stay alive until the stream has been synchronised.
+// call mode of the walk (kernels.hpp WalkArgs::call_*): where the sites go
+struct CallSink {
+    void *d_sites;        // kCallSegs lists of cap_per_list 16-byte records
+    uint32_t *d_counts;   // kCallSegs counters 64 bytes apart + the overflow counter behind them, zeroed by the caller
+    uint32_t cap_per_list;
+    uint32_t threshold;
+};
 void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, bool want_ival,
                        BatchOnDevice &B, std::vector<kbo::WalkItem> &items_keep, hipStream_t stream,
                        uint32_t longest = 0 /* longest sequence if the caller knows it */,
                        hipStream_t copy_stream = nullptr /* uploads go here when given ... */,
-                       hipEvent_t copied = nullptr /* ... and `stream` waits for this event */);
+                       hipEvent_t copied = nullptr /* ... and `stream` waits for this event */,
+                       const CallSink *call = nullptr /* call mode: MS values + sites, no intervals */);
 void run_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, bool want_ival,
                    BatchOnDevice &B, hipStream_t stream);
 // A5+A6 over a batch whose offsets are known on the host

@@ -180,6 +180,8 @@ void attach_plan(kbo::WalkArgs &a, void *plan_work)
     a.redo = nullptr;
     a.units = nullptr;
     a.n_items_dev = nullptr;
+    // (a.call_* are set by the caller before attach_plan; call mode never plans)
+    if (a.call_sites) return;
     a.unit_bail = 0;
     a.unit_cap = a.plan_dmin = a.plan_cap = a.plan_gap = a.plan_chunk = 0;
     if (!g_plan_enabled || !plan_work || !a.ix.pc_text || (a.lo_out && a.hi_out) || a.n_items == 0) return;

@@ -37,7 +37,9 @@ uint64_t walk_chunk(uint64_t total, size_t n_seqs, uint32_t k)
     return std::max<uint64_t>(chunk, 4ull * k);
 }
 
-void make_items_host(const uint64_t *offsets, size_t n_seqs, uint32_t k, std::vector<kbo::WalkItem> &items)
+// call = true: items for the call mode of the walk (k warm-up bases so that the MS value in front of the first owned
+// base is exact up to min(., k); up to k more bases behind the chunk, walked only to finish the search to the right)
+void make_items_host(const uint64_t *offsets, size_t n_seqs, uint32_t k, std::vector<kbo::WalkItem> &items, bool call = false)
 {
     const uint64_t total = offsets[n_seqs] - offsets[0];
     const uint64_t chunk = walk_chunk(total, n_seqs, k);
@@ -46,11 +48,12 @@ void make_items_host(const uint64_t *offsets, size_t n_seqs, uint32_t k, std::ve
         const uint64_t b = offsets[s], e = offsets[s + 1];
         for (uint64_t c0 = b; c0 < e; c0 += chunk) {
             const uint64_t c1 = std::min(e, c0 + chunk);
-            const uint64_t warm = std::min<uint64_t>(c0 - b, k > 0 ? k - 1 : 0);
+            const uint64_t warm = std::min<uint64_t>(c0 - b, call ? k : (k > 0 ? k - 1 : 0));
+            const uint64_t tail = call ? std::min<uint64_t>(e - c1, k) : 0;
             kbo::WalkItem it;
             it.start = c0 - warm;
-            it.len = (uint32_t)(c1 - c0 + warm);
-            it.warm = (uint32_t)warm;
+            it.len = (uint32_t)(c1 - c0 + warm + tail);
+            it.warm = (uint32_t)warm | ((uint32_t)tail << 16);
             items.push_back(it);
         }
     }
@@ -89,7 +92,7 @@ struct PhaseClock {
 // `items_keep` must stay alive until the stream has been synchronised.
 void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                        bool want_ival, BatchOnDevice &B, std::vector<kbo::WalkItem> &items_keep, hipStream_t stream,
-                       uint32_t longest, hipStream_t copy_stream, hipEvent_t copied)
+                       uint32_t longest, hipStream_t copy_stream, hipEvent_t copied, const CallSink *call)
 {
     KBO_REQUIRE(idx->host.k <= 255, KBO_E_UNSUPPORTED, "k > 255");
     const int dev = current_device();
@@ -102,7 +105,7 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
     const bool device_items = (longest ? longest : max_len(offsets, n_seqs)) <= chunk;
     size_t n_items = n_seqs;
     if (!device_items) {
-        make_items_host(offsets, n_seqs, idx->host.k, items_keep);
+        make_items_host(offsets, n_seqs, idx->host.k, items_keep, call != nullptr);
         n_items = items_keep.size();
     }
     KBO_REQUIRE(n_items < (1ull << 28), KBO_E_UNSUPPORTED, "more than 2^28 work items per launch");
@@ -128,7 +131,7 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
         HIP_OK(hipStreamWaitEvent(stream, copied, 0));
     }
     if (device_items) HIP_OK(kbo::launch_make_items(B.off.as<uint64_t>(), (uint32_t)n_seqs, B.items.as<kbo::WalkItem>(), stream));
-    kbo::WalkArgs a;
+    kbo::WalkArgs a{};
     a.ix = view;
     a.q = B.q.as<uint8_t>();
     a.q_bytes = total;
@@ -138,8 +141,12 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
     a.d_out = B.ms.as<uint8_t>();
     a.lo_out = want_ival ? B.lo.as<uint32_t>() : nullptr;
     a.hi_out = want_ival ? B.hi.as<uint32_t>() : nullptr;
-    if (view.pc_text && !want_ival) B.plan.ensure(kbo::plan_work_bytes(n_items, total));
-    attach_plan(a, view.pc_text && !want_ival ? B.plan.p : nullptr);
+    a.call_sites = call ? static_cast<uint4 *>(call->d_sites) : nullptr;
+    a.call_counts = call ? call->d_counts : nullptr;
+    a.call_cap = call ? call->cap_per_list : 0;
+    a.call_thr = call ? call->threshold : 0;
+    if (view.pc_text && !want_ival && !call) B.plan.ensure(kbo::plan_work_bytes(n_items, total));
+    attach_plan(a, view.pc_text && !want_ival && !call ? B.plan.p : nullptr);
     HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), stream));
     plan_after_launch(a, stream);
 }

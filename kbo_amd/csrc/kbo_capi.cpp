@@ -822,9 +822,10 @@ size_t kbo_work_bytes(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, u
     return dev_work(n_seqs, total_bases, max_seq_len, k).bytes;
 }
 
-int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs,
-                     uint64_t total_bases, size_t max_seq_len, uint8_t *d_ms_out, uint32_t *d_lo_out,
-                     uint32_t *d_hi_out, void *d_work, size_t work_bytes, void *stream)
+namespace {
+int ms_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs,
+                      uint64_t total_bases, size_t max_seq_len, uint8_t *d_ms_out, uint32_t *d_lo_out,
+                      uint32_t *d_hi_out, void *d_work, size_t work_bytes, void *stream, const CallSink *call)
 {
     return guarded([&] {
         KBO_REQUIRE(idx && d_concat && d_offsets && d_ms_out && d_work, KBO_E_BAD_ARG, "null argument");
@@ -847,11 +848,11 @@ int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *
         if (w.chunked) {
             uint32_t *scratch = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(d_work) +
                                                             ((size_t)w.n_slots * sizeof(kbo::WalkItem) + 15) / 16 * 16);
-            HIP_OK(kbo::launch_make_chunk_items(d_offsets, (uint32_t)n_seqs, w.chunk, idx->host.k, w.n_slots, items, scratch, s));
+            HIP_OK(kbo::launch_make_chunk_items(d_offsets, (uint32_t)n_seqs, w.chunk, idx->host.k, w.n_slots, items, scratch, s, call != nullptr));
         } else {
             HIP_OK(kbo::launch_make_items(d_offsets, (uint32_t)n_seqs, items, s));
         }
-        kbo::WalkArgs a;
+        kbo::WalkArgs a{};
         a.ix = view;
         a.q = d_concat;
         a.q_bytes = total_bases;
@@ -861,10 +862,37 @@ int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *
         a.d_out = d_ms_out;
         a.lo_out = d_lo_out;
         a.hi_out = d_hi_out;
+        a.call_sites = call ? static_cast<uint4 *>(call->d_sites) : nullptr;
+        a.call_counts = call ? call->d_counts : nullptr;
+        a.call_cap = call ? call->cap_per_list : 0;
+        a.call_thr = call ? call->threshold : 0;
         attach_plan(a, static_cast<uint8_t *>(d_work) + w.plan_off);
         HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), s));
         plan_after_launch(a, s);
     });
+}
+} // namespace
+
+int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs,
+                     uint64_t total_bases, size_t max_seq_len, uint8_t *d_ms_out, uint32_t *d_lo_out,
+                     uint32_t *d_hi_out, void *d_work, size_t work_bytes, void *stream)
+{
+    return ms_batch_dev_impl(idx, d_concat, d_offsets, n_seqs, total_bases, max_seq_len, d_ms_out, d_lo_out, d_hi_out, d_work,
+                             work_bytes, stream, nullptr);
+}
+
+int kbo_call_walk_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs,
+                      uint64_t total_bases, size_t max_seq_len, size_t threshold, uint8_t *d_ms_out, void *d_sites,
+                      size_t capacity, uint32_t *d_count, void *d_work, size_t work_bytes, void *stream)
+{
+    if (!d_sites || !d_count || capacity < kbo::kCallSegs || capacity > 0x7FFFFF00ull) {
+        last_error() = "kbo_call_walk_dev: bad site buffer";
+        return KBO_E_BAD_ARG;
+    }
+    if (hipMemsetAsync(d_count, 0, kbo::kCallSegs * 64 + 64, static_cast<hipStream_t>(stream)) != hipSuccess) return KBO_E_HIP;
+    const CallSink sink{d_sites, d_count, (uint32_t)(capacity / kbo::kCallSegs), (uint32_t)threshold};
+    return ms_batch_dev_impl(idx, d_concat, d_offsets, n_seqs, total_bases, max_seq_len, d_ms_out, nullptr, nullptr, d_work,
+                             work_bytes, stream, &sink);
 }
 
 size_t kbo_derand_work_bytes(size_t n_seqs, uint64_t total_bases)

@@ -33,7 +33,8 @@ struct DevIndexView {
 struct alignas(16) WalkItem {
     uint64_t start;
     uint32_t len;
-    uint32_t warm;
+    uint32_t warm; // low 16 bits: warm-up bases; high 16 bits (call mode): bases at the end that are walked only to finish
+                   // the search to the right of the breakpoints in front of them (they belong to the next chunk)
 };
 
 // ---- plan-guided walk (plan_kernels.hip) -------------------------------------------------------------------------
@@ -102,6 +103,13 @@ struct WalkArgs {
     uint32_t plan_cap;     // plan_kernel: seed iterations before an item is given up as unplanned
     uint32_t plan_gap;     // plan_emit_kernel: mismatches closer than this share a unit (>= 2)
     uint32_t plan_chunk;   // plan_emit_kernel: bases per unit of an item without a plan
+    // call mode of the plain kernel (all or none; call_kernels.hip has the stand-alone scan): the breakpoint scan of
+    // call_variants (variant_calling.rs:268-273) done by the walking lane itself, sites {first base of the item + i, .. + j,
+    // row, 0} appended to kCallSegs lists of call_cap records each (counters 64 bytes apart)
+    uint4 *call_sites;
+    uint32_t *call_counts;
+    uint32_t call_cap;     // records per list
+    uint32_t call_thr;     // derandomisation threshold t of the predicate
     const uint32_t *n_items_dev; // plain kernel: nullptr, or where the number of items is (the redo pass: qctl + 1)
 };
 // capacity of the unit array and bytes of plan work for a launch of n_items items over total_bases bases
@@ -123,7 +131,8 @@ hipError_t launch_make_items(const uint64_t *d_offsets, uint32_t n_seqs, WalkIte
 // slots are written (unused ones as empty items); d_scratch: chunk_items_scratch_words(n_seqs) u32
 size_t chunk_items_scratch_words(uint32_t n_seqs);
 hipError_t launch_make_chunk_items(const uint64_t *d_offsets, uint32_t n_seqs, uint32_t chunk, uint32_t k,
-                                   uint32_t n_slots, WalkItem *d_items, uint32_t *d_scratch, hipStream_t stream);
+                                   uint32_t n_slots, WalkItem *d_items, uint32_t *d_scratch, hipStream_t stream,
+                                   bool call = false /* items for the call mode of the walk */);
 // format::run_lengths_gapped over a batch of translated sequences (see rle_kernels.hip); records are 7 u32
 // {start, end, matches, mismatches, jumps, gap_bases, gap_opens}; after launch_rle_count the first-run index of
 // sequence s is d_scratch[n_seqs + 1 + s / 1024] + d_scratch[s] and *d_total the number of runs

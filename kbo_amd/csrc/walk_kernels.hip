@@ -92,7 +92,11 @@ __device__ __forceinline__ void emit_ms(uint8_t *d_out, uint32_t start, uint32_t
 // non-empty result means neither step needed a contraction, so the two emitted values are
 // min(d+1, k) and min(d+2, k).  An empty result says nothing: the lane falls back to single steps
 // for that base.  Halves the line fills per base where the index does not fit L2.
-template <bool IVAL, bool BIG, bool PAIR>
+// CALL: the lane also runs the breakpoint scan of call_variants on the values it produces: a base whose MS value drops
+// from >= t to < t is a breakpoint; the first base within k to its right with MS >= t and a single-row interval resolves
+// it (and every other breakpoint still waiting).  Up to four breakpoints wait per lane; a fifth within k bases sets the
+// overflow counter (call_counts[16 * kCallSegs]) and the host falls back to the stand-alone scan for the batch.
+template <bool IVAL, bool BIG, bool PAIR, bool CALL = false>
 __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
 {
     const uint32_t n = a.ix.n, k = a.ix.k;
@@ -123,6 +127,7 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
     // Query and output are streamed in 16-byte blocks RELATIVE TO THE ITEM (unaligned global
     // accesses): i = base index inside the item; block i>>4, word (i>>2)&3, byte i&3.
     uint32_t i = 0, len = 0, warm = 0, start = 0;
+    uint32_t tail = 0, dprev = 0, np = 0, pend0 = 0, pend1 = 0, pend2 = 0, pend3 = 0; // CALL: see above
     uint4 qblk = make_uint4(0, 0, 0, 0), qnxt = make_uint4(0, 0, 0, 0); // current / next query block
     uint32_t qcur = 0;                                                  // current query word
     uint4 oblk = make_uint4(0, 0, 0, 0);                                // output block being filled
@@ -154,7 +159,12 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
                 if (flags & F_HAVE) {
                     start = nit.x;
                     len = nit.z;
-                    warm = nit.w;
+                    warm = nit.w & 0xFFFFu;
+                    if (CALL) {
+                        tail = nit.w >> 16;
+                        np = 0;
+                        dprev = 0;
+                    }
                     i = 0;
                     qblk = nq0;
                     qcur = qblk.x;
@@ -211,7 +221,9 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
             const bool con = (flags & F_CON) != 0;
             const uint32_t bl = div96(l), br = div96(r);
             const uint32_t bmask = cb == null_blk ? 0u : ~0u;
-            const bool pair_try = PAIR && !con && pcb != 0u && !(flags & F_NOPAIR) && d >= pmin;
+            // (call mode: two-base steps only while no breakpoint is waiting for its match - the interval after the first
+            // base of a pair is never computed)
+            const bool pair_try = PAIR && !con && pcb != 0u && !(flags & F_NOPAIR) && d >= pmin && (!CALL || np == 0u);
             const uint32_t xb = pair_try ? pcb : cb; // first block of the bit-vector this lane ranks in
             const uint32_t rkA = (xb + (bl & bmask)) << 4, rkB = (xb + (br & bmask)) << 4;
             uint4 xA, xB;
@@ -277,6 +289,31 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
             r = con ? cr : (ok ? r2 : r);
             d = con ? lv : (ok ? d_ext : d);
             flags = (con && cstop) ? (flags & ~F_CON) : (fail ? (flags | F_CON) : flags);
+            if (CALL && accept) { // (a two-base step arrives here with no breakpoint waiting and d rising: nothing to do)
+                const uint32_t k1 = k;
+                // breakpoint at a base this item owns (not the first base of a sequence: the reference's loop starts at 1)
+                if (i >= warm && i > 0 && i < len - tail && d < dprev && dprev >= a.call_thr && d < a.call_thr) {
+                    // drop the ones whose window has passed, then queue this one
+                    while (np && pend0 + k1 < i) { pend0 = pend1; pend1 = pend2; pend2 = pend3; np--; }
+                    if (np == 4u) atomicAdd(a.call_counts + 16u * kCallSegs, 1u);
+                    else {
+                        if (np == 0) pend0 = i; else if (np == 1) pend1 = i; else if (np == 2) pend2 = i; else pend3 = i;
+                        np++;
+                    }
+                } else if (np && d >= a.call_thr && r == l + 1u) {
+                    // the first unique match to the right of every waiting breakpoint: a site for those within k of it
+                    const uint32_t seg = wave % kCallSegs;
+                    for (uint32_t x = 0; x < np; x++) {
+                        const uint32_t bp = x == 0 ? pend0 : x == 1 ? pend1 : x == 2 ? pend2 : pend3;
+                        if (i <= bp + k1) {
+                            const uint32_t slot = atomicAdd(a.call_counts + seg * 16u, 1u);
+                            if (slot < a.call_cap) a.call_sites[(size_t)seg * a.call_cap + slot] = make_uint4(start + bp, start + i, l, 0u);
+                        }
+                    }
+                    np = 0;
+                }
+                dprev = d;
+            }
             if (accept) {
                 if (i >= warm) { // emit: output byte e = i - warm of this item
                     if (IVAL) {
@@ -358,7 +395,7 @@ __global__ void chunk_count_kernel(const uint64_t *__restrict__ off, uint32_t n_
 
 __global__ void make_chunk_items_kernel(const uint64_t *__restrict__ off, const uint32_t *__restrict__ local,
                                         const uint32_t *__restrict__ sums, uint32_t n_seqs, uint32_t chunk,
-                                        uint32_t k, uint32_t n_slots, WalkItem *__restrict__ items)
+                                        uint32_t k, uint32_t n_slots, WalkItem *__restrict__ items, uint32_t call)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_slots) return;
@@ -376,10 +413,13 @@ __global__ void make_chunk_items_kernel(const uint64_t *__restrict__ off, const 
         }
         const uint64_t b = off[lo], len = off[lo + 1] - b;
         const uint64_t c0 = (uint64_t)(t - first_item(lo)) * chunk;
-        const uint64_t warm = min(c0, (uint64_t)(k > 0 ? k - 1 : 0));
+        // (call mode: k warm-up bases and up to k bases of the next chunk, see WalkItem)
+        const uint64_t warm = min(c0, (uint64_t)(call ? k : (k > 0 ? k - 1 : 0)));
+        const uint64_t body = min((uint64_t)chunk, len - c0);
+        const uint64_t tail = call ? min((uint64_t)k, len - c0 - body) : 0;
         it.start = b + c0 - warm;
-        it.len = (uint32_t)(min((uint64_t)chunk, len - c0) + warm);
-        it.warm = (uint32_t)warm;
+        it.len = (uint32_t)(body + warm + tail);
+        it.warm = (uint32_t)warm | ((uint32_t)tail << 16);
     }
     items[t] = it;
 }
@@ -398,7 +438,7 @@ hipError_t launch_make_items(const uint64_t *d_offsets, uint32_t n_seqs, WalkIte
 size_t chunk_items_scratch_words(uint32_t n_seqs) { return (size_t)n_seqs + 1 + ((size_t)n_seqs + 1 + kScanBlock - 1) / kScanBlock; }
 
 hipError_t launch_make_chunk_items(const uint64_t *d_offsets, uint32_t n_seqs, uint32_t chunk, uint32_t k,
-                                   uint32_t n_slots, WalkItem *d_items, uint32_t *d_scratch, hipStream_t stream)
+                                   uint32_t n_slots, WalkItem *d_items, uint32_t *d_scratch, hipStream_t stream, bool call)
 {
     if (n_seqs == 0 || n_slots == 0) return hipSuccess;
     const uint32_t n = n_seqs + 1;
@@ -407,7 +447,7 @@ hipError_t launch_make_chunk_items(const uint64_t *d_offsets, uint32_t n_seqs, u
     const hipError_t es = launch_scan(local, n, sums, stream);
     if (es != hipSuccess) return es;
     hipLaunchKernelGGL(make_chunk_items_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, stream, d_offsets, local, sums,
-                       n_seqs, chunk, k, n_slots, d_items);
+                       n_seqs, chunk, k, n_slots, d_items, call ? 1u : 0u);
     return hipGetLastError();
 }
 
@@ -443,7 +483,7 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
     const dim3 grid((waves + wpb - 1) / wpb), block(threads);
     const bool ival = a.lo_out && a.hi_out;
     a.pair_min_d = (uint32_t)g_pair_min_depth.load();
-    if (a.gitems && a.glist && a.ix.pc_text && !ival) { // MS values only, index with a path cover: plan, then guided walk
+    if (a.gitems && a.glist && a.ix.pc_text && !ival && !a.call_sites) { // MS values only, index with a path cover: plan, then guided walk
         hipError_t e = launch_plan(a, stream);
         if (e != hipSuccess) return e;
         // the guided kernel holds 7 waves per SIMD (65 VGPRs) and takes its items off a queue: one resident wave per
@@ -465,6 +505,12 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
         const dim3 rgrid((rwaves + wpb - 1) / wpb);
         if (a.ix.big) hipLaunchKernelGGL((ms_walk_kernel<false, true, false>), rgrid, block, 0, stream, a);
         else hipLaunchKernelGGL((ms_walk_kernel<false, false, false>), rgrid, block, 0, stream, a);
+        return hipGetLastError();
+    }
+    if (a.call_sites) { // call mode: MS values + the breakpoint scan, no intervals written
+        if (a.ix.big) hipLaunchKernelGGL((ms_walk_kernel<false, true, false, true>), grid, block, lds, stream, a);
+        else if (a.ix.pair_off) hipLaunchKernelGGL((ms_walk_kernel<false, false, true, true>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((ms_walk_kernel<false, false, false, true>), grid, block, lds, stream, a);
         return hipGetLastError();
     }
     if (a.ix.big) {
