@@ -242,7 +242,7 @@ def main():
 
     # ---- inputs (deterministic); index replicated, reads sharded by rank
     genome = synth.genome(args.genome)
-    threads = max(1, (os.cpu_count() or 1) // max(1, world))
+    threads = max(1, usable_cores()[0] // max(1, world))  # (the ranks of a node share the container's CPU quota)
     sbwt, _ = kbo_amd.build([genome], kbo_amd.BuildOpts(k=args.k, num_threads=min(16, threads)))
     concat, offsets = synth.reads(genome, args.reads, args.read_len, args.sub_rate,
                                   first_read=rank * args.reads)
