@@ -223,7 +223,8 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
             const uint32_t bmask = cb == null_blk ? 0u : ~0u;
             // (call mode: two-base steps only while no breakpoint is waiting for its match - the interval after the first
             // base of a pair is never computed)
-            const bool pair_try = PAIR && !con && pcb != 0u && !(flags & F_NOPAIR) && d >= pmin && (!CALL || np == 0u);
+            const bool pair_try = PAIR && !con && pcb != 0u && !(flags & F_NOPAIR) && d >= pmin &&
+                                  (!CALL || np == 0u || d + 2u < a.call_thr); // (neither base of the pair can be the match then)
             const uint32_t xb = pair_try ? pcb : cb; // first block of the bit-vector this lane ranks in
             const uint32_t rkA = (xb + (bl & bmask)) << 4, rkB = (xb + (br & bmask)) << 4;
             uint4 xA, xB;
@@ -314,20 +315,22 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
                 }
                 dprev = d;
             }
+            // call mode: an item whose breakpoints are all resolved need not walk the bases it borrowed from the next chunk
+            const uint32_t end_at = (CALL && np == 0u) ? len - tail : len;
             if (accept) {
                 if (i >= warm) { // emit: output byte e = i - warm of this item
                     if (IVAL) {
                         a.lo_out[start + i] = l;
                         a.hi_out[start + i] = r;
                     }
-                    emit_ms(a.d_out, start, warm, i, i + 1 == len, pair_try ? d_one : d, ocur, oblk);
+                    emit_ms(a.d_out, start, warm, i, i + 1 >= end_at && !(PAIR && pair_try), pair_try ? d_one : d, ocur, oblk);
                 }
                 if (PAIR && pair_try) { // second base of the pair (same query word, never the item's first)
                     i++;
-                    if (i >= warm) emit_ms(a.d_out, start, warm, i, i + 1 == len, d, ocur, oblk);
+                    if (i >= warm) emit_ms(a.d_out, start, warm, i, i + 1 >= end_at, d, ocur, oblk);
                 }
                 i++;
-                const bool fin = i == len;
+                const bool fin = i >= end_at;
                 const bool newblk = (i & 15u) == 0;
                 qblk.x = newblk ? qnxt.x : qblk.x;
                 qblk.y = newblk ? qnxt.y : qblk.y;
