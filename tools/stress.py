@@ -34,6 +34,12 @@ while time.time() < t_end:
     L.kbo_set_slab_bytes(int(rng.choice([1 << 16, 1 << 18, 32 << 20])))
     big = bool(rng.random() < 0.15)          # 64-bit-offset entry layout
     L.kbo_set_force_big_layout(int(big))
+    # plan-guided walk: on for most runs, with its knobs thrown around (seed depth / cap, gap, chunk, bail-out, tiny
+    # unit array); device copies made while it is off carry no path cover at all
+    plan_on = bool(rng.random() < 0.8)
+    L.kbo_set_plan(int(plan_on), int(rng.choice([1, 4, 10, 14, 20])), int(rng.choice([4, 16, 40, 48])))
+    L.kbo_set_plan_tuning(int(rng.choice([2, 3, 8, 20, 40])), int(rng.choice([16, 32, 100])),
+                          int(rng.choice([0, 8, 32, 0xFFFF, (30 << 16) | 0xFFFF, (4 << 16) | 64])))
     two_workers = bool(rng.random() < 0.15)  # the batch spread over a device list (both entries GPU 0)
     import ctypes
     devs = (ctypes.c_int * 2)(0, 0)
@@ -72,7 +78,7 @@ while time.time() < t_end:
             raise SystemExit(f"iteration {it}: oracle refused ({e}) but the product accepted")
         except kbo_amd.KboError:
             continue
-    tag = f"it {it}: k={k} G={len(g)} rc={rc} pairs={pairs_on} big={big} workers={2 if two_workers else 1} shape={shape} n={len(lens)} sub={sub} p={p_err}"
+    tag = f"it {it}: plan={plan_on} k={k} G={len(g)} rc={rc} pairs={pairs_on} big={big} workers={2 if two_workers else 1} shape={shape} n={len(lens)} sub={sub} p={p_err}"
     d, _, _ = batch.ms_batch(sbwt, concat, offsets)
     assert np.array_equal(d, exp_d), "MS " + tag
     got = batch.matches_batch(sbwt, concat, offsets, p_err)
@@ -93,5 +99,18 @@ while time.time() < t_end:
     want = np.frombuffer(ora.relative_to_ref(concat, exp_chars), dtype=np.uint8) if dev.format else exp_chars
     assert np.array_equal(dev.ms.cpu().numpy()[:len(concat)], exp_d), "dev MS " + tag
     assert np.array_equal(dev.chars.cpu().numpy()[:len(concat)], want), "dev chars " + tag
+    if rng.random() < 0.15 and not rc:  # kbo::call over a few of the sequences as a batch vs the oracle, one by one
+        pick = [int(x) for x in rng.integers(0, len(lens), 6) if lens[int(x)] >= 3]
+        if pick:
+            cc = np.concatenate([pieces[x] for x in pick])
+            co = np.concatenate([[0], np.cumsum([lens[x] for x in pick])]).astype(np.uint64)
+            opts = kbo_amd.CallOpts(max_error_prob=p_err, sbwt_build_opts=kbo_amd.BuildOpts(k=k, build_select=True))
+            try:
+                got_calls = batch.call_batch(sbwt, cc, co, opts)
+                for x, vs in zip(pick, got_calls):
+                    exp_calls, _, _ = oi.call(pieces[x].tobytes(), k, p_err)
+                    assert [(v.query_pos, bytes(v.query_chars).decode(), bytes(v.ref_chars).decode()) for v in vs] == exp_calls, "call " + tag
+            except (kbo_amd.KboError, ora.OracleError):
+                pass  # (reference panics: covered by stress_refine.py)
     print("ok", tag, flush=True)
 print(f"{it} iterations, all equal to the oracle")
