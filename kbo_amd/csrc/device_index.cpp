@@ -3,6 +3,7 @@
 #include "capi_internal.hpp"
 
 #include <atomic>
+#include <cstdlib>
 
 namespace kbo_host {
 
@@ -81,7 +82,9 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
                 idx->plan_bytes = pc.text.size() + pc.pos.size() * 4 + pc.node_at.size() * 4;
                 // seed table: the interval of every string of D bases, so that a seed starts D bases deep.  D = 10 for
                 // indexes that can use it (8 MiB), 8 for small ones, none below k = 8.
-                const uint32_t D = idx->host.k >= 10 && idx->host.n_sets >= (1u << 20) ? 10u : (idx->host.k >= 8 ? 8u : 0u);
+                uint32_t D = idx->host.k >= 10 && idx->host.n_sets >= (1u << 20) ? 10u : (idx->host.k >= 8 ? 8u : 0u);
+                if (const char *e = std::getenv("KBO_PLAN_SEED_D")) // experiments
+                    D = std::min<uint32_t>({(uint32_t)std::max(0, std::atoi(e)), 13u, idx->host.k});
                 if (D) {
                     const kbo::HostNav nav(idx->host);
                     std::vector<uint32_t> cur{0u, (uint32_t)idx->host.n_sets}, nxt; // {l, r} pairs, level by level

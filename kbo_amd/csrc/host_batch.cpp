@@ -105,7 +105,8 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
     // reads (nothing to chunk): the item list is derived from the offsets on the device;
     // otherwise it is built here (chunks with k-1 warm-up bases) and uploaded
     const uint64_t chunk = walk_chunk(total, n_seqs, idx->host.k);
-    const bool device_items = (longest ? longest : max_len(offsets, n_seqs)) <= chunk;
+    const uint32_t longest_seq = longest ? longest : max_len(offsets, n_seqs);
+    const bool device_items = longest_seq <= chunk;
     size_t n_items = n_seqs;
     if (!device_items) {
         make_items_host(offsets, n_seqs, idx->host.k, items_keep, call != nullptr);
@@ -148,6 +149,7 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
     a.call_counts = call ? call->d_counts : nullptr;
     a.call_cap = call ? call->cap_per_list : 0;
     a.call_thr = call ? call->threshold : 0;
+    a.max_item_len = device_items ? longest_seq : (uint32_t)std::min<uint64_t>(chunk + idx->host.k, 0xFFFFFFFFu);
     if (view.pc_text && !want_ival && !call) B.plan.ensure(kbo::plan_work_bytes(n_items, total));
     attach_plan(a, view.pc_text && !want_ival && !call ? B.plan.p : nullptr);
     HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), stream));

@@ -866,6 +866,7 @@ int ms_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
         a.call_counts = call ? call->d_counts : nullptr;
         a.call_cap = call ? call->cap_per_list : 0;
         a.call_thr = call ? call->threshold : 0;
+        a.max_item_len = w.chunked ? w.chunk + idx->host.k : (uint32_t)std::min<size_t>(max_seq_len, 0xFFFFFFFFu);
         attach_plan(a, static_cast<uint8_t *>(d_work) + w.plan_off);
         HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), s));
         plan_after_launch(a, s);

@@ -110,6 +110,7 @@ struct WalkArgs {
     uint32_t *call_counts;
     uint32_t call_cap;     // records per list
     uint32_t call_thr;     // derandomisation threshold t of the predicate
+    uint32_t max_item_len; // 0 = not known, else no item is longer than this (plan_kernel sizes its LDS staging from it)
     const uint32_t *n_items_dev; // plain kernel: nullptr, or where the number of items is (the redo pass: qctl + 1)
 };
 // capacity of the unit array and bytes of plan work for a launch of n_items items over total_bases bases
@@ -121,6 +122,7 @@ inline size_t plan_work_bytes(size_t n_items, uint64_t total_bases)
 }
 hipError_t launch_plan(WalkArgs &a, hipStream_t stream); // fills in the plan parameters of `a` (the later launches need them)
 hipError_t launch_ms_walk_guided(WalkArgs a, uint32_t grid, uint32_t threads, hipStream_t stream);
+void set_plan_stage(int on); // experiments: plan_kernel with (default) / without its LDS staging
 void set_plan_bail(int units_per_16_items); // tuning: launches with more units than this per 16 items give the plan up
 void set_plan_params(int dmin, int cap, int gap = 0, int chunk = 0); // tuning (<= 0 keeps): seed depth / seed iterations, unit gap / chunk
 

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 
 namespace kbo {
 namespace {
@@ -40,22 +41,39 @@ __device__ __forceinline__ uint32_t sel4(const uint4 &v, uint32_t w)
 // stores bytes [lo, hi) of a 16-byte block to o + lo .. o + hi (0 <= lo <= hi <= 16)
 __device__ __forceinline__ void st_range(uint8_t *o, const uint4 &v, uint32_t lo, uint32_t hi)
 {
-    for (uint32_t t = lo; t < hi; t++) o[t] = (uint8_t)(sel4(v, t >> 2) >> ((t & 3u) * 8u));
+#pragma unroll
+    for (uint32_t t = 0; t < 16; t++) { // (compile-time byte positions: no indexed copy of v in scratch)
+        const uint32_t w = (t >> 2) == 0 ? v.x : (t >> 2) == 1 ? v.y : (t >> 2) == 2 ? v.z : v.w;
+        if (t >= lo && t < hi) o[t] = (uint8_t)(w >> ((t & 3u) * 8u));
+    }
 }
 
 // -------------------------------------------------------------------------------------------------------------
 // plan_kernel: one lane per item, the wave in lock step.
+//  0. staging: the items of a wave are neighbours in the query buffer (reads back to back; chunks of a long sequence
+//     overlap by their warm-up bases only), so the wave copies its stretch of the buffer into LDS with full-line loads,
+//     every lane reads its item from there, writes the predicted values over it (in place: a lane only writes its own
+//     output bytes, and within a step all reads come before all writes), and the wave writes the stretch out with
+//     full-line stores.  Per-lane bursts would fetch every query / output line once per step instead (a line does not
+//     survive in L2 between two steps of a lane: thousands of waves are in flight).  Waves whose items are not
+//     neighbours, or do not fit the wave's LDS, go to the buffers directly.
 //  1. seed: extend from the root over the item's first bases; when an extension fails, start again from the root
 //     with the failing base (no contraction: only a diagonal is wanted, not the MS of these bases).  Done when the
 //     interval is a single row at depth >= dmin; given up after `cap` bases.
-//  2. compare the whole item with text[p0 ..], p0 = pos[row] - j; a text byte of 0 (path start, padding) matches
+//  2. compare the whole item with text[p0 ..], p0 = pos[row] - j, kPlanStep blocks of text at a time (all loads of a
+//     step go out together: the lines they touch are fetched once); a text byte of 0 (path start, padding) matches
 //     nothing.  Predicted MS of base t = min(k, t - last mismatch at or before t) (0 at a mismatch: the guided walk
 //     always walks those itself); mismatch positions go to the item's list.
 //  3. j_conv: when the seed never restarted and nothing mismatches up to its end, the seed WAS the exact walk of
 //     those bases and ended on the diagonal's node, so the guided walk may start at the first mismatch.
-__global__ __launch_bounds__(256) void plan_kernel(WalkArgs a)
+constexpr int kPlanStep = 10;           // 16-byte blocks per compare step (reads of up to 160 bases: one step)
+constexpr uint32_t kPlanLdsSlack = 48;  // bytes of a wave's LDS behind the staged stretch (block reads run past an item)
+__global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds)
 {
+    extern __shared__ __attribute__((aligned(16))) uint8_t plan_lds[];
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint8_t *sm = plan_lds + (threadIdx.x >> 6) * wave_lds;
     const uint32_t n = a.ix.n, k = a.ix.k, nblk = a.ix.n_blocks, null_blk = 4u * nblk;
     const uint8_t *arena = reinterpret_cast<const uint8_t *>(a.ix.arena);
     const uint8_t *qb = a.q;
@@ -70,6 +88,36 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a)
     const bool plannable = have_item && len > 0;
     const uint32_t dmin = max(1u, min(k, a.plan_dmin)), cap = a.plan_cap;
 
+    // ---- 0. staging (everything here is wave-uniform)
+    bool staged = false;
+    uint32_t base16 = 0, wave_hi = 0, out_lo = 0, soff = 0;
+    {
+        const uint64_t have = __ballot(have_item); // (item lanes are the wave's first lanes)
+        if (wave_lds != 0 && have != 0) {
+            const uint32_t last = (uint32_t)__popcll(have) - 1u;
+            const uint32_t nxt_start = __shfl_down(start, 1), nxt_warm = __shfl_down(warm, 1);
+            const bool bad = lane < last && (nxt_start < start || nxt_start + nxt_warm != start + len);
+            const uint32_t lo = __shfl(start, 0);
+            wave_hi = __shfl(start + len, (int)last);
+            out_lo = lo + __shfl(warm, 0);
+            base16 = lo & ~15u;
+            staged = __ballot(bad) == 0 && wave_hi > lo && (uint64_t)(wave_hi - base16) + kPlanLdsSlack <= wave_lds;
+            soff = start - base16;
+        }
+    }
+    if (staged) {
+        for (uint32_t c = lane * 16u; c < wave_hi - base16; c += 1024u) // (reads <= 15 bytes past the last item)
+            *reinterpret_cast<uint4 *>(sm + c) = ld16u(qb, base16 + c);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    auto qld = [&](uint32_t x) -> uint4 { // 16 bytes of the item from base x on
+        uint4 v;
+        if (staged) __builtin_memcpy(&v, sm + soff + x, 16);
+        else __builtin_memcpy(&v, qb + start + x, 16);
+        return v;
+    };
+
     // ---- 1. seed
     // state: the interval [l, r) at depth d of the bases [.., j); tab = the next step is a look-up of the seed_d bases
     // from j on in the seed table (the start of a seed: the item's first bases, or the bases behind a failure)
@@ -78,7 +126,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a)
     const uint32_t D = a.ix.seed_tab ? a.ix.seed_d : 0u;
     bool tab = D != 0;
     uint4 qblk = make_uint4(0, 0, 0, 0);
-    if (plannable) qblk = ld16u(qb, start);
+    if (plannable) qblk = qld(0);
     uint32_t qbase = 0; // item position of qblk's first byte
     for (;;) {
         const bool act = plannable && !seeded && j < len && j < cap;
@@ -87,7 +135,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a)
             if (tab && j + D <= len) {
                 // ---- D bases at once (they may straddle two query blocks: bytes are fetched one by one from the
                 // current block and the one after it)
-                const uint4 qn = (j + D > qbase + 16u) ? ld16u(qb, start + qbase + 16u) : qblk;
+                const uint4 qn = (j + D > qbase + 16u) ? qld(qbase + 16u) : qblk;
                 uint32_t w = 0, okc = 1;
                 for (uint32_t t = 0; t < D; t++) {
                     const uint32_t o = j + t - qbase; // 0 .. 31
@@ -114,7 +162,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a)
                 }
                 if (j >= qbase + 16u && !seeded) {
                     qbase = j & ~15u;
-                    qblk = ld16u(qb, start + qbase);
+                    qblk = qld(qbase);
                 }
             } else {
                 const uint32_t o = j - qbase;
@@ -145,7 +193,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a)
                 j++;
                 if (j >= qbase + 16u && !seeded) {
                     qbase = j & ~15u;
-                    qblk = ld16u(qb, start + qbase); // stays within the 16-byte slack behind the queries
+                    qblk = qld(qbase); // (direct: stays within the 16-byte slack behind the queries)
                 }
             }
         }
@@ -158,34 +206,45 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a)
     uint16_t *list = a.glist + (size_t)idx * kPlanList;
     int32_t i_last = -1;
     uint32_t cnt = 0, mm0 = kPlanInf;
-    // 64 bases per step: the four query blocks, the four text blocks and the four output blocks of a step go out
-    // back to back, so that every 128-byte line they touch is fetched (written) once, not once per 16 bytes - with
-    // thousands of waves in flight a line does not survive in L2 from one step to the next
-    for (uint32_t base0 = 0;; base0 += 64u) {
+    for (uint32_t base0 = 0;; base0 += 16u * kPlanStep) {
         const bool act = seeded && base0 < len;
         if (__ballot(act) == 0) break;
-        if (act) {
-            uint4 qv[4], tv[4], pv[4];
+        uint32_t mmw[kPlanStep / 2]; // mismatch masks of the step's blocks, two per word
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
+        for (int g = 0; g < kPlanStep / 2; g++) mmw[g] = 0;
+        if (act) {
+            uint4 tv[kPlanStep];
+#pragma unroll
+            for (int g = 0; g < kPlanStep; g++) {
                 const uint32_t base = base0 + 16u * g;
-                qv[g] = tv[g] = make_uint4(0, 0, 0, 0);
-                if (base < len) {
-                    qv[g] = ld16u(qb, start + base);
-                    const uint32_t u = p0 + base + kPlanPad; // offset into the padded buffer (mod 2^32)
-                    if (u <= n + 2u * kPlanPad - 16u) __builtin_memcpy(&tv[g], tb + u, 16);
-                }
+                tv[g] = make_uint4(0, 0, 0, 0);
+                const uint32_t u = p0 + base + kPlanPad; // offset into the padded buffer (mod 2^32)
+                if (base < len && u <= n + 2u * kPlanPad - 16u) __builtin_memcpy(&tv[g], tb + u, 16);
             }
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
+            for (int g = 0; g < kPlanStep; g++) {
                 const uint32_t base = base0 + 16u * g;
                 if (base < len) {
+                    const uint4 qv = qld(base);
                     const uint32_t nb = min(16u, len - base);
-                    uint32_t mm = (nonzero_bytes(qv[g].x ^ tv[g].x) | (nonzero_bytes(tv[g].x) ^ 0xFu)) |
-                                  ((nonzero_bytes(qv[g].y ^ tv[g].y) | (nonzero_bytes(tv[g].y) ^ 0xFu)) << 4) |
-                                  ((nonzero_bytes(qv[g].z ^ tv[g].z) | (nonzero_bytes(tv[g].z) ^ 0xFu)) << 8) |
-                                  ((nonzero_bytes(qv[g].w ^ tv[g].w) | (nonzero_bytes(tv[g].w) ^ 0xFu)) << 12);
+                    uint32_t mm = (nonzero_bytes(qv.x ^ tv[g].x) | (nonzero_bytes(tv[g].x) ^ 0xFu)) |
+                                  ((nonzero_bytes(qv.y ^ tv[g].y) | (nonzero_bytes(tv[g].y) ^ 0xFu)) << 4) |
+                                  ((nonzero_bytes(qv.z ^ tv[g].z) | (nonzero_bytes(tv[g].z) ^ 0xFu)) << 8) |
+                                  ((nonzero_bytes(qv.w ^ tv[g].w) | (nonzero_bytes(tv[g].w) ^ 0xFu)) << 12);
                     mm &= (1u << nb) - 1u;
+                    mmw[g >> 1] |= mm << (16 * (g & 1));
+                }
+            }
+        }
+        // (staged: every lane has read its query bytes of this step before any lane overwrites them)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (act) {
+#pragma unroll
+            for (int g = 0; g < kPlanStep; g++) {
+                const uint32_t base = base0 + 16u * g;
+                if (base < len) {
+                    uint32_t mm = (mmw[g >> 1] >> (16 * (g & 1))) & 0xFFFFu;
                     uint4 o4 = make_uint4(0, 0, 0, 0);
 #pragma unroll
                     for (int t = 0; t < 16; t++) {
@@ -197,7 +256,6 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a)
                         else if ((t >> 2) == 2) o4.z |= sh;
                         else o4.w |= sh;
                     }
-                    pv[g] = o4;
                     while (mm) { // the item's mismatch list: entry 0 in the item record, entries 1..12 in the list
                         const uint32_t pos = base + (uint32_t)__ffs((int)mm) - 1u;
                         if (cnt == 0) mm0 = pos;
@@ -205,19 +263,29 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a)
                         cnt++;
                         mm &= mm - 1u;
                     }
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const uint32_t base = base0 + 16u * g;
-                if (base < len) {
                     const uint32_t nb = min(16u, len - base);
                     const uint32_t lo = warm > base ? min(warm - base, 16u) : 0u;
-                    uint8_t *o = a.d_out + (start + base);
-                    if (lo == 0 && nb == 16u) __builtin_memcpy(o, &pv[g], 16); // (plain store: the four blocks of a step merge in L2)
-                    else st_range(o, pv[g], lo, nb);
+                    if (staged) {
+                        uint8_t *o = sm + soff + base;
+                        if (lo == 0 && nb == 16u) __builtin_memcpy(o, &o4, 16);
+                        else st_range(o, o4, lo, nb);
+                    } else {
+                        uint8_t *o = a.d_out + (start + base);
+                        if (lo == 0 && nb == 16u) __builtin_memcpy(o, &o4, 16); // (plain store: the blocks of a step merge in L2)
+                        else st_range(o, o4, lo, nb);
+                    }
                 }
             }
+        }
+    }
+    if (staged) { // the wave's output bytes [out_lo, wave_hi), in blocks aligned like the staged copy
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t c = lane * 16u; c < wave_hi - base16; c += 1024u) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(sm + c);
+            const uint32_t g0 = base16 + c;
+            if (g0 >= out_lo && g0 + 16u <= wave_hi) __builtin_memcpy(a.d_out + g0, &v, 16);
+            else st_range(a.d_out + g0, v, out_lo > g0 ? min(out_lo - g0, 16u) : 0u, min(wave_hi - g0, 16u));
         }
     }
     if (!have_item) return;
@@ -613,7 +681,9 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
 } // namespace
 
 std::atomic<int> g_plan_dmin{14}, g_plan_cap{40}, g_plan_gap{20}, g_plan_chunk{32};
+std::atomic<int> g_plan_stage{1};     // plan_kernel stages queries and predictions through LDS (0: experiments)
 std::atomic<int> g_plan_bail_x16{32}; // give the plan up when there are more than this many units per 16 items
+void set_plan_stage(int on) { g_plan_stage = on != 0; }
 void set_plan_bail(int units_per_16_items) { g_plan_bail_x16 = std::max(0, units_per_16_items); }
 void set_plan_params(int dmin, int cap, int gap, int chunk)
 {
@@ -635,7 +705,15 @@ hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
     const hipError_t e = hipMemsetAsync(a.qctl, 0, 64, stream);
     if (e != hipSuccess) return e;
     const uint32_t nb = (a.n_items + 255u) / 256u;
-    hipLaunchKernelGGL(plan_kernel, dim3(nb), dim3(256), 0, stream, a);
+    // LDS for the staged stretch of every wave: 64 items of at most max_item_len bases (not known, or too long for
+    // four waves to share 64 KiB: no staging)
+    uint32_t wave_lds = 0;
+    static const int env_stage = std::getenv("KBO_PLAN_STAGE") ? std::atoi(std::getenv("KBO_PLAN_STAGE")) : -1; // experiments
+    if (a.max_item_len != 0 && (env_stage >= 0 ? env_stage != 0 : g_plan_stage.load() != 0)) {
+        const uint64_t need = (64ull * a.max_item_len + 16u + kPlanLdsSlack + 15u) / 16u * 16u;
+        if (need <= 16384u) wave_lds = (uint32_t)need;
+    }
+    hipLaunchKernelGGL(plan_kernel, dim3(nb), dim3(256), 4u * wave_lds, stream, a, wave_lds);
     hipLaunchKernelGGL(plan_count_kernel, dim3(nb), dim3(256), 0, stream, a);
     const hipError_t es = launch_scan(a.ucount, 2u * a.n_items + 1u, a.usums, stream);
     if (es != hipSuccess) return es;
