@@ -24,6 +24,8 @@ struct DevCopy {
     uint32_t pair_off = 0; // arena index of the two-base extension blocks, 0 = none
     DevBuf seed_tab;                 // intervals of all strings of seed_d bases (plan_kernel's seeds)
     uint32_t seed_d = 0;
+    DevBuf fat;                      // recovery lines of the guided walk (sbwt_index.hpp)
+    uint32_t fat_null = 0;
     DevBuf pc_text, pc_pos, pc_node; // path cover (sbwt_index.hpp PathCover), empty when the plan-guided walk is off
 };
 

@@ -80,6 +80,14 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
                 HIP_OK(hipMemcpy(dc->pc_pos.p, pc.pos.data(), pc.pos.size() * 4, hipMemcpyHostToDevice));
                 HIP_OK(hipMemcpy(dc->pc_node.p, pc.node_at.data(), pc.node_at.size() * 4, hipMemcpyHostToDevice));
                 idx->plan_bytes = pc.text.size() + pc.pos.size() * 4 + pc.node_at.size() * 4;
+                {
+                    std::vector<uint8_t> lines;
+                    kbo::make_recovery_lines(idx->host, lines);
+                    dc->fat.alloc(lines.size() + 16);
+                    HIP_OK(hipMemcpy(dc->fat.p, lines.data(), lines.size(), hipMemcpyHostToDevice));
+                    dc->fat_null = (uint32_t)(lines.size() / 128 - 1);
+                    idx->plan_bytes += lines.size();
+                }
                 // seed table: the interval of every string of D bases, so that a seed starts D bases deep.  D = 10 for
                 // indexes that can use it (8 MiB), 8 for small ones, none below k = 8.
                 uint32_t D = idx->host.k >= 10 && idx->host.n_sets >= (1u << 20) ? 10u : (idx->host.k >= 8 ? 8u : 0u);
@@ -132,6 +140,8 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
     v.pc_pos = dc->pc_pos.as<uint32_t>();
     v.seed_tab = dc->seed_d ? dc->seed_tab.as<uint2>() : nullptr;
     v.seed_d = dc->seed_d;
+    v.fat = dc->fat.p ? dc->fat.as<uint8_t>() : nullptr;
+    v.fat_null = dc->fat_null;
     v.pc_node = dc->pc_node.as<uint32_t>();
     for (int c = 0; c < 4; c++) v.C[c] = (uint32_t)idx->host.C[c];
     v.C[4] = v.n;

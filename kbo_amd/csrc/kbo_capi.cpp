@@ -1050,6 +1050,12 @@ int kbo_set_walk_threads(int threads)
     return KBO_OK;
 }
 
+int kbo_set_guided_walk(int waves_per_cu, int recovery_lines)
+{
+    kbo::set_guided_walk(waves_per_cu, recovery_lines);
+    return KBO_OK;
+}
+
 int kbo_set_walk_waves_per_cu(int waves_per_cu)
 {
     g_waves_per_cu = waves_per_cu > 0 ? waves_per_cu : 0;

@@ -25,6 +25,9 @@ struct DevIndexView {
     // base most significant), l >= r when it is no suffix of a row; nullptr / 0 when the index has none
     const uint2 *seed_tab;
     uint32_t seed_d;
+    // recovery lines of the guided walk (sbwt_index.hpp make_recovery_lines), nullptr when the device copy has none
+    const uint8_t *fat;
+    uint32_t fat_null; // line index of an all-zero line (extensions by a non-ACGT byte)
 };
 
 // One unit of walk work: `len` bases starting at absolute offset `start` of the
@@ -122,6 +125,8 @@ inline size_t plan_work_bytes(size_t n_items, uint64_t total_bases)
 }
 hipError_t launch_plan(WalkArgs &a, hipStream_t stream); // fills in the plan parameters of `a` (the later launches need them)
 hipError_t launch_ms_walk_guided(WalkArgs a, uint32_t grid, uint32_t threads, hipStream_t stream);
+void set_guided_walk(int waves_per_cu, int recovery_lines); // tuning: see kbo_set_guided_walk
+bool guided_uses_recovery_lines(const WalkArgs &a);
 void set_plan_stage(int on); // experiments: plan_kernel with (default) / without its LDS staging
 void set_plan_bail(int units_per_16_items); // tuning: launches with more units than this per 16 items give the plan up
 void set_plan_params(int dmin, int cap, int gap = 0, int chunk = 0); // tuning (<= 0 keeps): seed depth / seed iterations, unit gap / chunk

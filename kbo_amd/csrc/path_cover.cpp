@@ -14,6 +14,8 @@
 // pass over the resulting chains numbers them.
 #include "sbwt_index.hpp"
 
+#include <cstring>
+
 #include <stdexcept>
 
 namespace kbo {
@@ -78,6 +80,25 @@ void make_path_cover(const HostIndex &h, PathCover &out)
     for (uint64_t i = 0; i < n; i++)
         if (out.pos[i] == NONE) lay((uint32_t)i);
     if (p != n) throw std::runtime_error("path cover: rows left without a position");
+}
+
+// Recovery lines: sbwt_index.hpp.
+void make_recovery_lines(const HostIndex &h, std::vector<uint8_t> &out)
+{
+    const uint64_t n = h.n_sets, n_lines = n / kFatRows + 2, n_words = (n + 63) / 64;
+    out.assign((n_lines + 1) * 128, 0);
+    uint64_t cum[4] = {h.C[0], h.C[1], h.C[2], h.C[3]};
+    for (uint64_t b = 0; b < n_lines; b++) {
+        uint8_t *line = out.data() + b * 128;
+        for (int c = 0; c < 4; c++) {
+            uint64_t w = b < n_words ? h.rows[c][b] : 0;
+            if (b * 64 + 64 > n) w &= b * 64 >= n ? 0 : (~0ull >> (64 - (n - b * 64))); // (rows beyond the last one: no bits)
+            const uint32_t blk[4] = {(uint32_t)cum[c], (uint32_t)w, (uint32_t)(w >> 32), 0u};
+            std::memcpy(line + 16 * c, blk, 16);
+            cum[c] += (uint64_t)__builtin_popcountll(w);
+        }
+        if (b * 64 < n) std::memcpy(line + 64, h.lcs.data() + b * 64, (size_t)std::min<uint64_t>(64, n - b * 64));
+    }
 }
 
 } // namespace kbo

@@ -426,6 +426,7 @@ enum : uint32_t {
     G_CON = 2u,   // contracting: loads contraction entries instead of rank blocks
     G_HAVE = 4u,  // next unit (record, start row, first query block) is prefetched
     G_PF = 8u,    // next unit's record is in flight, its row and query block not yet requested
+    G_ENT = 64u,  // (recovery lines) the next contraction level is read from the entries
     // the bits below take the lane out of the hot path until the bookkeeping block has run
     G_DONE = 16u, // finished its unit, wants the next one
     G_FIN = 32u,  // no units left
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
     int32_t last_mm = -1;
     uint4 qblk = make_uint4(0, 0, 0, 0), qnxt = make_uint4(0, 0, 0, 0);
     uint32_t qcur = 0, ocur = 0;
-    uint4 nu0 = make_uint4(0, 0, 0, 0), nq0 = make_uint4(0, 0, 0, 0);
+    uint4 nu0 = make_uint4(0, 0, 0, 0), nq0 = make_uint4(0, 0, 0, 0), nq1 = make_uint4(0, 0, 0, 0);
     uint2 nu1 = make_uint2(0, 0);
     uint32_t nrow = 0;
     bool want = true; // wants to claim a unit
@@ -487,6 +488,7 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
             if (flags & G_PF) {
                 const uint32_t pos = nu0.z & 0xFFFFu;
                 nq0 = ld16u(qb, nu0.x + (pos & ~15u));
+                nq1 = ld16u(qb, min(nu0.x + (pos & ~15u) + 16u, q_end)); // (with the first: one fill for the line they share)
                 if (!((nu1.x >> 8) & kUnitHead)) nrow = *reinterpret_cast<const uint32_t *>(nodeb + (uint64_t)(nu0.y + pos - 1u) * 4u);
                 flags = (flags & ~G_PF) | G_HAVE;
             }
@@ -507,12 +509,13 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
                     d = head ? 0u : (nu1.x & 0xFFu);
                     m = 0;
                     qblk = nq0;
+                    qnxt = nq1;
                     qcur = sel4(qblk, (i >> 2) & 3u);
                     const uint32_t c = decode_base((qcur >> ((i & 3u) * 8u)) & 0xFFu);
                     cb = c < 4u ? c * nblk : null_blk;
                     ocur = 0;
                     wlo = (out_from - warm) & 3u; // first byte of the first output word that is this unit's
-                    flags = i < bound ? G_QF : G_DONE; // (empty units: see plan_emit_kernel)
+                    flags = i < bound ? 0u : G_DONE; // (empty units: see plan_emit_kernel)
                     want = true;
 #ifdef KBO_WALK_DEBUG
                     dbg_units++;
@@ -678,6 +681,310 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
 #endif
 }
 
+// x < y in every byte (yb = y in all four bytes), as bits 0..3
+__device__ __forceinline__ uint32_t lt4(uint32_t x, uint32_t yb)
+{
+    const uint32_t H = 0x80808080u;
+    const uint32_t t = (x | H) - (yb & ~H);               // bit 7 of a byte: its low seven bits are >= y's
+    const uint32_t lt = ((~x & yb) | (~(x ^ yb) & ~t)) & H; // top bit decides, else the low bits
+    return ((lt >> 7) * 0x01020408u) >> 24;
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// ms_walk_recovery_kernel: ms_walk_guided_kernel over the recovery lines (sbwt_index.hpp) instead of the rank blocks
+// and contraction entries.  A unit is the stretch behind a mismatch: nearly every base lands on a row that is random
+// with respect to the last one, fails to extend about every other time and then needs the LCS values around its
+// rows - with rank blocks and entries two line fills per failing base, here the line of the failed extension holds
+// them.  Contraction: lv = max(LCS[l], LCS[r]); the level's ends are the previous value < lv to the left of l and
+// the next one to the right of r, searched in the 16 values [.., l] and [r, ..] of the line(s); when a window ends
+// first (end of the line, long run of equal suffixes) the level is taken from the {lcs, psv, nsv} entries in the
+// next iteration instead.  Everything else is ms_walk_guided_kernel.
+template <bool BIG>
+__global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
+{
+    const uint32_t n = a.ix.n, k = a.ix.k;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint8_t *arena = reinterpret_cast<const uint8_t *>(a.ix.arena);
+    const uint8_t *qb = a.q;
+    const uint8_t *utb = reinterpret_cast<const uint8_t *>(a.units);
+    const uint8_t *nodeb = reinterpret_cast<const uint8_t *>(a.ix.pc_node);
+    const uint32_t q_end = (uint32_t)a.q_bytes;
+    const uint8_t *fat = a.ix.fat;
+    const uint32_t null_line = a.ix.fat_null;
+    const uint32_t ent_byte0 = a.ix.lcs_off << 4;
+
+    const uint32_t u_total = a.usums[(2u * a.n_items) / kScanBlock] + a.ucount[2u * a.n_items];
+    const uint32_t q_total = u_total > a.unit_bail ? 0u : min(u_total, a.unit_cap); // (see plan_emit_kernel)
+    uint32_t pool_next = 0, pool_end = 0;
+    bool drained = false; // (wave-uniform) the queue has nothing left
+
+    uint32_t flags = G_DONE;
+    uint32_t l = 0, r = n, d = 0, cb = 0;
+    uint32_t i = 0, start = 0, warm = 0, bound = 0, out_from = 0, uflags = 0, item = 0, wlo = 0;
+    int32_t last_mm = -1;
+    uint4 qblk = make_uint4(0, 0, 0, 0), qnxt = make_uint4(0, 0, 0, 0);
+    uint32_t qcur = 0, ocur = 0;
+    uint4 nu0 = make_uint4(0, 0, 0, 0), nq0 = make_uint4(0, 0, 0, 0), nq1 = make_uint4(0, 0, 0, 0);
+    uint2 nu1 = make_uint2(0, 0);
+    uint32_t nrow = 0;
+    bool want = true; // wants to claim a unit
+    uint32_t visits = 0;
+#ifdef KBO_WALK_DEBUG
+    uint32_t dbg_iter = 0, dbg_rare = 0, dbg_acc = 0, dbg_fail = 0, dbg_con = 0, dbg_wdone = 0, dbg_wfin = 0, dbg_units = 0,
+             dbg_flagged = 0, dbg_short = 0;
+#endif
+
+    for (;;) {
+        // ============================== bookkeeping block ==============================
+        {
+#ifdef KBO_WALK_DEBUG
+            dbg_rare++;
+#endif
+            // ---- the next unit's record is here: request its start row and first query block
+            if (flags & G_PF) {
+                const uint32_t pos = nu0.z & 0xFFFFu;
+                nq0 = ld16u(qb, nu0.x + (pos & ~15u));
+                nq1 = ld16u(qb, min(nu0.x + (pos & ~15u) + 16u, q_end)); // (with the first: one fill for the line they share)
+                if (!((nu1.x >> 8) & kUnitHead)) nrow = *reinterpret_cast<const uint32_t *>(nodeb + (uint64_t)(nu0.y + pos - 1u) * 4u);
+                flags = (flags & ~G_PF) | G_HAVE;
+            }
+            // ---- switch finished lanes to their prefetched unit
+            if (flags & G_DONE) {
+                if (flags & G_HAVE) {
+                    start = nu0.x;
+                    i = nu0.z & 0xFFFFu;
+                    out_from = nu0.z >> 16;
+                    last_mm = (int32_t)(int16_t)(nu0.w & 0xFFFFu);
+                    bound = nu0.w >> 16;
+                    uflags = (nu1.x >> 8) & 0xFFu;
+                    warm = (nu1.x >> 16) & 0xFFu;
+                    item = nu1.y;
+                    const bool head = (uflags & kUnitHead) != 0;
+                    l = head ? 0u : nrow;
+                    r = head ? n : nrow + 1u;
+                    d = head ? 0u : (nu1.x & 0xFFu);
+                    qblk = nq0;
+                    qnxt = nq1;
+                    qcur = sel4(qblk, (i >> 2) & 3u);
+                    const uint32_t c = decode_base((qcur >> ((i & 3u) * 8u)) & 0xFFu);
+                    cb = c < 4u ? c << 4 : ~0u; // offset of the base's rank block inside a line (~0: no such base)
+                    ocur = 0;
+                    wlo = (out_from - warm) & 3u; // first byte of the first output word that is this unit's
+                    flags = i < bound ? 0u : G_DONE; // (empty units: see plan_emit_kernel)
+                    want = true;
+#ifdef KBO_WALK_DEBUG
+                    dbg_units++;
+#endif
+                } else {
+                    flags = ((flags & G_PF) || want) ? flags : G_FIN;
+                }
+            }
+            // ---- claim units for the lanes that have none in the pipeline
+            {
+                const uint64_t wmask = __ballot(want);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u));
+                const uint32_t n_want = (uint32_t)__popcll(wmask);
+                const uint32_t avail = pool_end - pool_next;
+                uint32_t mine = pool_next + rank, lim = pool_end;
+                if (n_want > avail && !drained) { // (wave-uniform) the chunk runs out: take the next one off the queue
+                    uint32_t nb = 0;
+                    if (lane == 0) nb = atomicAdd(a.qctl, 64u);
+                    nb = min(__shfl(nb, 0), q_total);
+                    drained = nb >= q_total;
+                    const uint32_t ne = min(nb + 64u, q_total);
+                    if (rank >= avail) {
+                        mine = nb + (rank - avail);
+                        lim = ne;
+                    }
+                    pool_next = min(nb + (n_want - avail), ne);
+                    pool_end = ne;
+                } else {
+                    pool_next = min(pool_end, pool_next + n_want);
+                }
+                if (want && mine < lim) {
+                    nu0 = ld16(utb, mine * 32u);
+                    __builtin_memcpy(&nu1, utb + (size_t)mine * 32u + 16u, 8);
+                    flags |= G_PF;
+                }
+                want = false;
+            }
+            if (__ballot(flags != G_FIN) == 0) break;
+            if (++visits > (1u << 21)) { // (cannot happen: a wave sees a few thousand visits in the largest launch; ends a
+                if (lane == 0) a.qctl[3] = 1; // walk that does not make progress instead of hanging the device)
+                break;
+            }
+        }
+
+#pragma unroll 1
+        for (uint32_t it = 0; it < a.rare_period; it++) {
+#ifdef KBO_WALK_DEBUG
+            dbg_iter++;
+            dbg_wdone += (flags & G_DONE) ? 1u : 0u;
+            dbg_wfin += (flags & G_FIN) ? 1u : 0u;
+#endif
+            if (!(flags & G_BLOCKED)) {
+                const bool ent = (flags & G_ENT) != 0; // this iteration takes one contraction level from the entries
+                const uint32_t bl = l >> 6, br = r >> 6, ol = l & 63u, orr = r & 63u;
+                // 16-row windows of LCS values, [.., l] and [r, ..], cut at the line's ends
+                const uint32_t wl = ol > 15u ? ol - 15u : 0u, wr = min(orr, 48u);
+                const bool cnull = cb == ~0u;
+                uint4 xA, xB, wA, wB;
+                if (BIG) {
+                    const uint64_t oA = (uint64_t)bl << 7, oB = (uint64_t)br << 7, oN = (uint64_t)null_line << 7;
+                    __builtin_memcpy(&xA, fat + (cnull ? oN : oA + cb), 16);
+                    __builtin_memcpy(&xB, fat + (cnull ? oN : oB + cb), 16);
+                    __builtin_memcpy(&wA, fat + oA + 64u + wl, 16);
+                    __builtin_memcpy(&wB, fat + oB + 64u + wr, 16);
+                } else {
+                    const uint32_t oA = bl << 7, oB = br << 7, oN = null_line << 7;
+                    xA = ld16(fat, cnull ? oN : oA + cb);
+                    xB = ld16(fat, cnull ? oN : oB + cb);
+                    wA = ld16u(fat, oA + 64u + wl);
+                    wB = ld16u(fat, oB + 64u + wr);
+                }
+                if (__ballot(ent)) { // (rare: the windows did not hold a level's ends)
+                    if (ent) {
+                        if (BIG) {
+                            __builtin_memcpy(&wA, a.ix.ent + (uint64_t)l * 12u, 16);
+                            __builtin_memcpy(&wB, a.ix.ent + (uint64_t)r * 12u, 16);
+                        } else {
+                            wA = ld16u(arena, ent_byte0 + ((l + (l << 1)) << 2));
+                            wB = ld16u(arena, ent_byte0 + ((r + (r << 1)) << 2));
+                        }
+                    }
+                }
+                if (flags & G_QF) { // the query block after the current one (reads <= 16 bytes past the item)
+                    qnxt = ld16u(qb, min(start + (i & ~15u) + 16u, q_end));
+                    flags &= ~G_QF;
+                }
+                // ---- the base's extension from [l, r); when it is empty: contraction levels out of the windows, the
+                // extension tried again after each from the two rank blocks that are already here (a level found in
+                // the windows ends inside the two lines)
+                const uint64_t WA = ((uint64_t)xA.z << 32) | xA.y, WB = ((uint64_t)xB.z << 32) | xB.y;
+                uint32_t l2 = xA.x + (uint32_t)__popcll(WA & ((1ull << ol) - 1ull));
+                uint32_t r2 = xB.x + (uint32_t)__popcll(WB & ((1ull << orr) - 1ull));
+                bool ok = !ent && l2 < r2;
+                bool short_win = false; // the windows end before the level does
+#ifdef KBO_WALK_DEBUG
+                dbg_fail += (!ent && !ok && d != 0) ? 1u : 0u;
+#endif
+                if (ent) { // one level from the entries; the extension comes with the next iteration (other lines)
+                    const uint32_t lve = max(wA.x, wB.x);
+                    const bool roote = lve == 0;
+                    const uint32_t cle = roote ? 0u : (wA.x == lve ? wA.y : l), cre = roote ? n : (wB.x == lve ? wB.z : r);
+                    l = cle;
+                    r = cre;
+                    d = lve;
+                    flags &= ~G_ENT;
+                }
+#pragma unroll 1
+                for (uint32_t lev = 0; lev < 4u; lev++) {
+                    const bool need = !ent && !ok && d != 0 && !short_win;
+                    if (__ballot(need) == 0) break;
+                    if (need) {
+                        const uint32_t pl = l - (bl << 6) - wl, pr = r - (br << 6) - wr; // 0..15: l and r stay in the windows
+                        const uint32_t lcs_l = (sel4(wA, pl >> 2) >> ((pl & 3u) * 8u)) & 0xFFu;
+                        const uint32_t lcs_r = (sel4(wB, pr >> 2) >> ((pr & 3u) * 8u)) & 0xFFu;
+                        const uint32_t lvw = max(lcs_l, lcs_r), yb = lvw * 0x01010101u;
+                        const uint32_t mA = lt4(wA.x, yb) | (lt4(wA.y, yb) << 4) | (lt4(wA.z, yb) << 8) | (lt4(wA.w, yb) << 12);
+                        const uint32_t mB = lt4(wB.x, yb) | (lt4(wB.y, yb) << 4) | (lt4(wB.z, yb) << 8) | (lt4(wB.w, yb) << 12);
+                        const uint32_t below = mA & ((1u << pl) - 1u), above = mB & ~((2u << pr) - 1u);
+                        const bool need_l = lcs_l == lvw, need_r = lcs_r == lvw;
+                        if (lvw == 0) { // the root: its extension is [C[c], C[c+1])
+                            const uint32_t c = cb >> 4;
+                            l = 0;
+                            r = n;
+                            d = 0;
+                            l2 = c == 0 ? a.ix.C[0] : c == 1 ? a.ix.C[1] : c == 2 ? a.ix.C[2] : c == 3 ? a.ix.C[3] : 0u;
+                            r2 = c == 0 ? a.ix.C[1] : c == 1 ? a.ix.C[2] : c == 2 ? a.ix.C[3] : c == 3 ? a.ix.C[4] : 0u;
+                            ok = l2 < r2;
+                        } else if ((need_l && !below) || (need_r && !above)) {
+                            short_win = true;
+                        } else {
+                            l = need_l ? (bl << 6) + wl + (31u - (uint32_t)__clz((int)below)) : l;
+                            r = need_r ? (br << 6) + wr + (uint32_t)__ffs((int)above) - 1u : r;
+                            d = lvw;
+                            l2 = xA.x + (uint32_t)__popcll(WA & ((1ull << (l - (bl << 6))) - 1ull));
+                            r2 = xB.x + (uint32_t)__popcll(WB & ((1ull << (r - (br << 6))) - 1ull));
+                            ok = l2 < r2;
+                        }
+#ifdef KBO_WALK_DEBUG
+                        dbg_con++;
+                        dbg_short += short_win ? 1u : 0u;
+#endif
+                    }
+                }
+                // accepted: the extension exists, or the walk is at the root (a base without an edge there keeps d = 0)
+                const bool accept = !ent && (ok || d == 0);
+                flags |= short_win ? G_ENT : 0u;
+                l = ok ? l2 : l;
+                r = ok ? r2 : r;
+                d = ok ? min(d + 1u, k) : d;
+#ifdef KBO_WALK_DEBUG
+                dbg_acc += accept ? 1u : 0u;
+#endif
+                if (accept) {
+                    const bool fin = i + 1u == bound;
+                    const uint32_t e = i - warm; // output index (wraps below warm; only its low bits are used then)
+                    // converged: the walk is provably back on the diagonal (see the header); the unit ends here
+                    const bool conv = !(uflags & kUnitPlain) && (int32_t)i >= last_mm && r == l + 1u &&
+                                      d == min((uint32_t)((int32_t)i - last_mm), k);
+                    const bool word_done = (e & 3u) == 3u || fin || conv;
+                    if (i >= out_from) {
+                        ocur |= d << ((e & 3u) * 8u);
+                        if (word_done) {
+                            uint8_t *o = a.d_out + (start + warm + (e & ~3u));
+                            if (wlo == 0 && (e & 3u) == 3u) st4u(o, ocur);
+                            else { // a word the unit owns only part of: bytes wlo .. e & 3
+                                if (wlo == 0) o[0] = (uint8_t)ocur;
+                                if (wlo <= 1u && (e & 3u) >= 1u) o[1] = (uint8_t)(ocur >> 8);
+                                if (wlo <= 2u && (e & 3u) >= 2u) o[2] = (uint8_t)(ocur >> 16);
+                                if ((e & 3u) == 3u) o[3] = (uint8_t)(ocur >> 24);
+                            }
+                            ocur = 0;
+                            wlo = 0;
+                        }
+                    }
+                    if (fin && !conv && !(uflags & (kUnitPlain | kUnitToEnd))) { // reached the next group unconverged
+                        a.redo[item] = 1;
+#ifdef KBO_WALK_DEBUG
+                        dbg_flagged++;
+#endif
+                    }
+                    i++;
+                    const bool newblk = (i & 15u) == 0;
+                    qblk.x = newblk ? qnxt.x : qblk.x;
+                    qblk.y = newblk ? qnxt.y : qblk.y;
+                    qblk.z = newblk ? qnxt.z : qblk.z;
+                    qblk.w = newblk ? qnxt.w : qblk.w;
+                    flags |= (fin || conv) ? G_DONE : (newblk ? G_QF : 0u);
+                    qcur = sel4(qblk, (i >> 2) & 3u);
+                    const uint32_t c = decode_base((qcur >> ((i & 3u) * 8u)) & 0xFFu);
+                    cb = c < 4u ? c << 4 : ~0u;
+                }
+            }
+        } // hot loop
+    }
+#ifdef KBO_WALK_DEBUG
+    if (a.lo_out == nullptr && a.hi_out != nullptr) { // debug build: hi_out doubles as the counter sink
+        if (lane == 0) {
+            atomicAdd(a.hi_out + 0, dbg_iter);
+            atomicAdd(a.hi_out + 1, dbg_rare);
+            atomicAdd(a.hi_out + 3, 1u);
+            atomicMax(a.hi_out + 13, dbg_iter);
+        }
+        atomicAdd(a.hi_out + 4, dbg_acc);
+        atomicAdd(a.hi_out + 5, dbg_fail);
+        atomicAdd(a.hi_out + 6, dbg_con);
+        atomicAdd(a.hi_out + 7, dbg_flagged);
+        atomicAdd(a.hi_out + 8, dbg_wdone);
+        atomicAdd(a.hi_out + 9, dbg_wfin);
+        atomicAdd(a.hi_out + 12, dbg_units);
+        atomicAdd(a.hi_out + 14, dbg_short);
+    }
+#endif
+}
+
 } // namespace
 
 std::atomic<int> g_plan_dmin{14}, g_plan_cap{40}, g_plan_gap{20}, g_plan_chunk{32};
@@ -723,7 +1030,10 @@ hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
 
 hipError_t launch_ms_walk_guided(WalkArgs a, uint32_t grid, uint32_t threads, hipStream_t stream)
 {
-    if (a.ix.big) hipLaunchKernelGGL((ms_walk_guided_kernel<true>), dim3(grid), dim3(threads), 0, stream, a);
+    if (guided_uses_recovery_lines(a)) {
+        if (a.ix.big) hipLaunchKernelGGL((ms_walk_recovery_kernel<true>), dim3(grid), dim3(threads), 0, stream, a);
+        else hipLaunchKernelGGL((ms_walk_recovery_kernel<false>), dim3(grid), dim3(threads), 0, stream, a);
+    } else if (a.ix.big) hipLaunchKernelGGL((ms_walk_guided_kernel<true>), dim3(grid), dim3(threads), 0, stream, a);
     else hipLaunchKernelGGL((ms_walk_guided_kernel<false>), dim3(grid), dim3(threads), 0, stream, a);
     hipLaunchKernelGGL(redo_collect_kernel, dim3((a.n_items + 255u) / 256u), dim3(256), 0, stream, a);
     return hipGetLastError();

@@ -58,6 +58,17 @@ struct DeviceLayout {
 };
 void make_device_layout(const HostIndex &h, DeviceLayout &out, bool with_pairs = false);
 
+// Recovery lines (the guided walk's view of the index: plan_kernels.hip).  Where a read leaves the reference the walk
+// alternates failed extensions, contractions and extensions on rows that are random from one base to the next, so what
+// a base needs should come with ONE 128-byte line: line b covers rows [64 b, 64 b + 64) and holds
+//     bytes  0 ..  63   four 16-byte rank blocks { C[c] + rank_c(64 b), row bits 0..31, row bits 32..63, 0 }, c = A,C,G,T
+//     bytes 64 .. 127   LCS[64 b .. 64 b + 64)  (0 beyond row n_sets - 1: the sentinel of the contraction searches)
+// A failed extension has fetched the line that also holds the LCS values around its rows; the contraction scans them
+// (previous / next smaller value inside a 16-row window) and falls back to the {lcs, psv, nsv} entries when the
+// window does not hold the answer.  n_sets / 64 + 2 lines and one all-zero line behind them; 2 bytes per row.
+constexpr uint32_t kFatRows = 64;
+void make_recovery_lines(const HostIndex &h, std::vector<uint8_t> &out);
+
 // Path cover of the index's de Bruijn graph, laid out as one text (path_cover.cpp): every row sits at
 // exactly one position; text[p] is the label of the edge node_at[p-1] -> node_at[p], 0 where a path starts.
 struct PathCover {

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 
 namespace kbo {
 namespace {
@@ -463,7 +464,26 @@ void set_walk_experiment(int lane_limit, int dummy_lds_bytes)
     g_walk_lane_limit = std::max(1, std::min(64, lane_limit));
     g_walk_dummy_lds = std::max(0, std::min(64 << 10, dummy_lds_bytes));
 }
-std::atomic<int> g_guided_waves_eighths{7};            // guided walk: resident waves per SIMD (tuning, kbo_set_walk_waves_per_cu scales it)
+// guided walk: resident waves per CU, in 32nds of the plain walk's (so that kbo_set_walk_waves_per_cu scales both); 0 = by
+// the kernel: 8 (rank blocks + entries) or 10 (recovery lines).  Few: a lane comes back to the line of its last iteration
+// (failed extension -> contraction -> retry) and finds it in L2 only while the lines of all lanes in flight fit there -
+// 8 waves x 64 lanes x 32 CUs x 128 B = 2 of an XCD's 4 MiB - and even lanes that never come back run into each other's
+// fills beyond that
+std::atomic<int> g_guided_waves_32nds{0};
+// guided walk over the recovery lines (plan_kernels.hip): -1 = where the rank blocks are far beyond L2 (the two-base
+// steps' threshold), 0 / 1 = never / always
+std::atomic<int> g_guided_fat{-1};
+void set_guided_walk(int waves_per_cu, int recovery_lines)
+{
+    if (waves_per_cu >= 0) g_guided_waves_32nds = std::min(32, waves_per_cu);
+    if (recovery_lines >= -1) g_guided_fat = recovery_lines < 0 ? -1 : (recovery_lines != 0 ? 1 : 0);
+}
+bool guided_uses_recovery_lines(const WalkArgs &a)
+{
+    static const int env_fat = std::getenv("KBO_PLAN_FAT") ? std::atoi(std::getenv("KBO_PLAN_FAT")) : -1; // experiments
+    const int f = env_fat >= 0 ? env_fat : g_guided_fat.load();
+    return a.ix.fat != nullptr && (f < 0 ? a.ix.n >= (24u << 20) : f != 0);
+}
 std::atomic<int> g_pair_min_depth{16};                 // two-base steps only from matches at least this deep
 void set_pair_min_depth(int d) { g_pair_min_depth = d < 0 ? 0 : d; }
 void set_walk_rare(int period) { g_rare_period = std::max(1, std::min(1024, period)); }
@@ -489,9 +509,12 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
     if (a.gitems && a.glist && a.ix.pc_text && !ival && !a.call_sites) { // MS values only, index with a path cover: plan, then guided walk
         hipError_t e = launch_plan(a, stream);
         if (e != hipSuccess) return e;
-        // the guided kernel holds 7 waves per SIMD (65 VGPRs) and takes its items off a queue: one resident wave per
-        // slot, but no more waves than there are chunks of 64 items
-        const uint32_t gwaves = (uint32_t)std::min<uint64_t>((uint64_t)std::max(1, max_waves * g_guided_waves_eighths.load() / 8),
+        // the guided kernel takes its units off a queue: a fixed number of resident waves, but no more than there are
+        // chunks of 64 units
+        static const int env_gw = std::getenv("KBO_GUIDED_WAVES") ? std::atoi(std::getenv("KBO_GUIDED_WAVES")) : 0; // experiments: 32nds
+        const int gw_set = env_gw > 0 ? env_gw : g_guided_waves_32nds.load();
+        const int gw = gw_set > 0 ? gw_set : (guided_uses_recovery_lines(a) ? 10 : 8);
+        const uint32_t gwaves = (uint32_t)std::min<uint64_t>((uint64_t)std::max(1, max_waves * gw / 32),
                                                              ((uint64_t)a.unit_cap + 63) / 64);
         e = launch_ms_walk_guided(a, (gwaves + wpb - 1) / wpb, threads, stream);
         if (e != hipSuccess) return e;

@@ -25,6 +25,7 @@ def plan_defaults():
     yield L
     L.kbo_set_plan(1, 14, 40)
     L.kbo_set_plan_tuning(20, 32, (1 << 16) | 32)
+    L.kbo_set_guided_walk(0, -1)
 
 
 def _workload(rng, ref_seqs, n_reads):
@@ -76,12 +77,14 @@ def test_plan_guided_walk_equals_plain_walk_and_oracle(oracle, plan_defaults, k)
     settings = [(14, 40, 24, 32, 0xFFFF), (14, 40, 2, 16, 0xFFFF), (1, 8, 5, 64, 0xFFFF), (3, 48, 24, 32, 0xFFFF),
                 (14, 40, 24, 32, 0), (14, 40, 24, 32, (40 << 16) | 0xFFFF),  # unit array 1/40 of its size: overflow path
                 (14, 40, 24, 32, 0xFFFF)]
-    for dmin, cap, gap, chunk, bail in settings:
-        L.kbo_set_plan(1, dmin, cap)
-        L.kbo_set_plan_tuning(gap, chunk, bail)
-        for _ in range(2):  # (the launch after a plan was given up is held off; the one after that plans again or not)
-            d, _, _ = batch.ms_batch(sbwt, concat, offsets)
-            assert np.array_equal(d, exp_d), (k, dmin, cap, gap, chunk, bail)
+    for fat in (0, 1):  # the guided walk over rank blocks + entries / over the recovery lines (a size-based choice otherwise)
+        L.kbo_set_guided_walk(0, fat)
+        for dmin, cap, gap, chunk, bail in settings:
+            L.kbo_set_plan(1, dmin, cap)
+            L.kbo_set_plan_tuning(gap, chunk, bail)
+            for _ in range(2):  # (the launch after a plan was given up is held off; the one after that plans again or not)
+                d, _, _ = batch.ms_batch(sbwt, concat, offsets)
+                assert np.array_equal(d, exp_d), (k, fat, dmin, cap, gap, chunk, bail)
     # intervals are only ever produced by the plain walk
     d2, lo, hi = batch.ms_batch(sbwt, concat[:600], np.array([0, 600], dtype=np.uint64), want_intervals=True)
     od, olo, ohi = ora.matching_statistics(concat[:600].tobytes())
@@ -98,7 +101,8 @@ def test_plan_guided_walk_device_resident_and_map(oracle, plan_defaults):
     for sub in (0.0, 0.01, 0.08):
         concat, offsets = synth.reads(g, 20_000, 150, sub, seed=int(sub * 1000) + 3)
         exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
-        for plan in (1, 0, 1):
+        for plan in (1, 0, 2):
+            L.kbo_set_guided_walk(0, 1 if plan == 2 else 0)
             L.kbo_set_plan(plan, 14, 40)
             dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"))
             dev.ms.fill_(0xEE)
@@ -118,7 +122,9 @@ def test_plan_guided_walk_big_layout(oracle, plan_defaults):
         ora = oracle.Index.build([g.tobytes()], k=31)
         concat, offsets = synth.reads(g, 5000, 150, 0.02)
         _, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
-        d, _, _ = batch.ms_batch(sbwt, concat, offsets)
-        assert np.array_equal(d, exp_d)
+        for fat in (0, 1):
+            L.kbo_set_guided_walk(0, fat)
+            d, _, _ = batch.ms_batch(sbwt, concat, offsets)
+            assert np.array_equal(d, exp_d), fat
     finally:
         L.kbo_set_force_big_layout(0)

@@ -25,4 +25,4 @@ for sub in [float(x) for x in os.environ.get("SUB", "0.01").split(",")]:
         print(f"sub={sub} rare={rare}: waves {waves}, hot iterations per wave avg {it:.1f} max {c[13]}, bookkeeping visits {c[1]/waves:.1f}, units {c[12]} ({c[12]/R:.2f} per read), items flagged {c[7]}")
         print("   per lane-slot: accept %.1f fail %.1f contract %.1f | waiting for switch %.1f, out of units %.1f | of %.1f" %
               (c[4]/lanes, c[5]/lanes, c[6]/lanes, c[8]/lanes, c[9]/lanes, it))
-        print("   per unit: accept %.1f fail %.1f contract %.1f" % (c[4]/max(c[12],1), c[5]/max(c[12],1), c[6]/max(c[12],1)))
+        print("   per unit: accept %.1f fail %.1f contract %.1f (of which windows too short: %.2f)" % (c[4]/max(c[12],1), c[5]/max(c[12],1), c[6]/max(c[12],1), c[14]/max(c[12],1)))

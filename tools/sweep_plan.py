@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Plan-guided walk vs plain walk on synthetic reads: walk time (plan kernel + guided kernel) and MS equality.
-G=genome bases, R=reads, SUB=substitution rates (comma separated), DMIN / CAP lists to sweep."""
+G=genome bases, R=reads, SUB=substitution rates (comma separated), DMIN / CAP lists to sweep, GW = list of
+<guided waves per CU>:<recovery lines 0/1>."""
 import os
 import sys
 
@@ -40,6 +41,8 @@ for sub in [float(x) for x in os.environ.get("SUB", "0.01").split(",")]:
     print(f"sub={sub}: plain walk min {mn:.3f} ms median {med:.3f}  ({R*150/mn/1e6:.1f} Gbp/s)", flush=True)
     for dmin in [int(x) for x in os.environ.get("DMIN", "14").split(",")]:
         for cap in [int(x) for x in os.environ.get("CAP", "40").split(",")]:
+         for gw, fatl in [(int(x.split(":")[0]), int(x.split(":")[1])) for x in os.environ.get("GW", "8:0").split(",")]:
+          L.kbo_set_guided_walk(gw, fatl)
           for wpc in [int(x) for x in os.environ.get("WPC", "32").split(",")]:
             for rare in [int(x) for x in os.environ.get("RARE", "8").split(",")]:
                 L.kbo_set_plan(1, dmin, cap); L.kbo_set_walk_rare(rare); L.kbo_set_walk_waves_per_cu(wpc)
@@ -50,7 +53,7 @@ for sub in [float(x) for x in os.environ.get("SUB", "0.01").split(",")]:
                     print("   MISMATCH at", bad[:10].tolist(), "of", int(bad.numel()),
                           "got", dev.ms[bad[:10]].tolist(), "want", base[bad[:10]].tolist(), flush=True)
                 mn, med = time_walk(dev)
-                print(f"   plan dmin={dmin} cap={cap} rare={rare} wpc={wpc}: walk min {mn:.3f} ms median {med:.3f}  "
+                print(f"   plan dmin={dmin} cap={cap} rare={rare} wpc={wpc} guided waves/CU={gw} recovery lines={fatl}: walk min {mn:.3f} ms median {med:.3f}  "
                       f"({R*150/mn/1e6:.1f} Gbp/s)  same MS: {same}", flush=True)
     L.kbo_set_walk_rare(8); L.kbo_set_walk_waves_per_cu(32)
     del dev
