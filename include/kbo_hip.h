@@ -304,7 +304,7 @@ int kbo_walk_geometry(int *max_waves, int *threads);
 int kbo_set_walk_waves_per_cu(int waves_per_cu); /* tuning knob, 0 = default (32) */
 int kbo_set_walk_threads(int threads);           /* tuning knob: workgroup size 64/128/256 */
 /* tuning knobs of the guided walk (the plan-guided form of A1).  waves_per_cu: resident waves per CU, 0 = default (8 or
- * 10, scaled with kbo_set_walk_waves_per_cu; few, so that the lines of the lanes in flight stay in L2: DESIGN.md 4.2),
+ * 12, scaled with kbo_set_walk_waves_per_cu; few, so that the lines of the lanes in flight stay in L2: DESIGN.md 4.2),
  * < 0 keeps.  recovery_lines: 1 / 0 = the walk reads the index through the recovery lines (one 128-byte line per 64 rows
  * with rank blocks and LCS values) / through the rank blocks and contraction entries, -1 = by index size (default),
  * < -1 keeps. */

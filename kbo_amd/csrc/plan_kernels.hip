@@ -415,9 +415,15 @@ __global__ __launch_bounds__(256) void redo_collect_kernel(WalkArgs a)
         }
         return;
     }
-    if (!a.redo[idx]) return;
-    const uint32_t slot = atomicAdd(a.qctl + 1, 1u);
-    reinterpret_cast<uint4 *>(a.gitems)[slot] = reinterpret_cast<const uint4 *>(a.items)[idx];
+    // one counter update per wave (returning atomics on one address take about 10 ns each)
+    const bool f = a.redo[idx] != 0;
+    const uint64_t fm = __ballot(f);
+    if (fm == 0) return;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+    uint32_t base = 0;
+    if (f && rank == 0) base = atomicAdd(a.qctl + 1, (uint32_t)__popcll(fm));
+    base = __shfl(base, (int)__builtin_ctzll(fm));
+    if (f) reinterpret_cast<uint4 *>(a.gitems)[base + rank] = reinterpret_cast<const uint4 *>(a.items)[idx];
 }
 
 // per-lane flag bits of the guided walk
@@ -430,7 +436,8 @@ enum : uint32_t {
     // the bits below take the lane out of the hot path until the bookkeeping block has run
     G_DONE = 16u, // finished its unit, wants the next one
     G_FIN = 32u,  // no units left
-    G_BLOCKED = G_DONE | G_FIN
+    G_FLUSH = 128u, // its window of output bytes is full: written out by the bookkeeping block
+    G_BLOCKED = G_DONE | G_FIN | G_FLUSH
 };
 
 // -------------------------------------------------------------------------------------------------------------
@@ -465,10 +472,14 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
 
     uint32_t flags = G_DONE;
     uint32_t l = 0, r = n, d = 0, m = 0, cb = 0, tgt_l = 0, tgt_r = 0;
-    uint32_t i = 0, start = 0, warm = 0, bound = 0, out_from = 0, uflags = 0, item = 0, wlo = 0;
+    uint32_t i = 0, start = 0, warm = 0, bound = 0, out_from = 0, uflags = 0, item = 0;
     int32_t last_mm = -1;
     uint4 qblk = make_uint4(0, 0, 0, 0), qnxt = make_uint4(0, 0, 0, 0);
     uint32_t qcur = 0, ocur = 0;
+    // output window: the unit's MS bytes wait in registers (32 bytes from output index wbase on, wfirst .. wend - 1 of them
+    // the unit's) and go out together when the unit ends: a word stored on its own every fourth base is a line fill of its own
+    uint32_t ow[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t wbase = 0, wfirst = 0, wend = 0;
     uint4 nu0 = make_uint4(0, 0, 0, 0), nq0 = make_uint4(0, 0, 0, 0), nq1 = make_uint4(0, 0, 0, 0);
     uint2 nu1 = make_uint2(0, 0);
     uint32_t nrow = 0;
@@ -492,6 +503,30 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
                 if (!((nu1.x >> 8) & kUnitHead)) nrow = *reinterpret_cast<const uint32_t *>(nodeb + (uint64_t)(nu0.y + pos - 1u) * 4u);
                 flags = (flags & ~G_PF) | G_HAVE;
             }
+            // ---- finished units (and full windows): the output bytes, whole words where the unit owns them
+            {
+                const bool fl = (flags & (G_DONE | G_FLUSH)) && wend != 0;
+                if (__ballot(fl)) {
+                    if (fl) {
+                        uint8_t *o = a.d_out + (start + warm + wbase);
+#pragma unroll
+                        for (uint32_t w = 0; w < 8; w++) {
+                            const uint32_t lo = max(wfirst, 4u * w), hi = min(wend, 4u * w + 4u); // bytes [lo, hi) of word w
+                            if (lo == 4u * w && hi == 4u * w + 4u) st4u(o + 4u * w, ow[w]);
+                            else {
+#pragma unroll
+                                for (uint32_t t = 0; t < 4; t++)
+                                    if (4u * w + t >= lo && 4u * w + t < hi) o[4u * w + t] = (uint8_t)(ow[w] >> (8u * t));
+                            }
+                            ow[w] = 0;
+                        }
+                        wbase += 32u;
+                        wfirst = 0;
+                        wend = 0;
+                        flags &= ~G_FLUSH;
+                    }
+                }
+            }
             // ---- switch finished lanes to their prefetched unit
             if (flags & G_DONE) {
                 if (flags & G_HAVE) {
@@ -514,7 +549,8 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
                     const uint32_t c = decode_base((qcur >> ((i & 3u) * 8u)) & 0xFFu);
                     cb = c < 4u ? c * nblk : null_blk;
                     ocur = 0;
-                    wlo = (out_from - warm) & 3u; // first byte of the first output word that is this unit's
+                    wbase = (out_from - warm) & ~3u;
+                    wfirst = (out_from - warm) & 3u; // first byte of the first output word that is this unit's
                     flags = i < bound ? 0u : G_DONE; // (empty units: see plan_emit_kernel)
                     want = true;
 #ifdef KBO_WALK_DEBUG
@@ -628,19 +664,16 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
                                       d == min((uint32_t)((int32_t)i - last_mm), k);
                     const bool word_done = (e & 3u) == 3u || fin || conv;
                     if (i >= out_from) {
+                        const uint32_t wi = e - wbase; // 0 .. 31
                         ocur |= d << ((e & 3u) * 8u);
+                        wend = wi + 1u;
                         if (word_done) {
-                            uint8_t *o = a.d_out + (start + warm + (e & ~3u));
-                            if (wlo == 0 && (e & 3u) == 3u) st4u(o, ocur);
-                            else { // a word the unit owns only part of: bytes wlo .. e & 3
-                                if (wlo == 0) o[0] = (uint8_t)ocur;
-                                if (wlo <= 1u && (e & 3u) >= 1u) o[1] = (uint8_t)(ocur >> 8);
-                                if (wlo <= 2u && (e & 3u) >= 2u) o[2] = (uint8_t)(ocur >> 16);
-                                if ((e & 3u) == 3u) o[3] = (uint8_t)(ocur >> 24);
-                            }
+                            const uint32_t ws = wi >> 2;
+#pragma unroll
+                            for (uint32_t w = 0; w < 8; w++) ow[w] = ws == w ? ocur : ow[w];
                             ocur = 0;
-                            wlo = 0;
                         }
+                        flags |= (wi == 31u && !(fin || conv)) ? G_FLUSH : 0u; // (long units: the window goes out in between)
                     }
                     if (fin && !conv && !(uflags & (kUnitPlain | kUnitToEnd))) { // reached the next group unconverged
                         a.redo[item] = 1;
@@ -720,10 +753,14 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
 
     uint32_t flags = G_DONE;
     uint32_t l = 0, r = n, d = 0, cb = 0;
-    uint32_t i = 0, start = 0, warm = 0, bound = 0, out_from = 0, uflags = 0, item = 0, wlo = 0;
+    uint32_t i = 0, start = 0, warm = 0, bound = 0, out_from = 0, uflags = 0, item = 0;
     int32_t last_mm = -1;
     uint4 qblk = make_uint4(0, 0, 0, 0), qnxt = make_uint4(0, 0, 0, 0);
     uint32_t qcur = 0, ocur = 0;
+    // output window: the unit's MS bytes wait in registers (32 bytes from output index wbase on, wfirst .. wend - 1 of them
+    // the unit's) and go out together when the unit ends: a word stored on its own every fourth base is a line fill of its own
+    uint32_t ow[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t wbase = 0, wfirst = 0, wend = 0;
     uint4 nu0 = make_uint4(0, 0, 0, 0), nq0 = make_uint4(0, 0, 0, 0), nq1 = make_uint4(0, 0, 0, 0);
     uint2 nu1 = make_uint2(0, 0);
     uint32_t nrow = 0;
@@ -748,6 +785,30 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                 if (!((nu1.x >> 8) & kUnitHead)) nrow = *reinterpret_cast<const uint32_t *>(nodeb + (uint64_t)(nu0.y + pos - 1u) * 4u);
                 flags = (flags & ~G_PF) | G_HAVE;
             }
+            // ---- finished units (and full windows): the output bytes, whole words where the unit owns them
+            {
+                const bool fl = (flags & (G_DONE | G_FLUSH)) && wend != 0;
+                if (__ballot(fl)) {
+                    if (fl) {
+                        uint8_t *o = a.d_out + (start + warm + wbase);
+#pragma unroll
+                        for (uint32_t w = 0; w < 8; w++) {
+                            const uint32_t lo = max(wfirst, 4u * w), hi = min(wend, 4u * w + 4u); // bytes [lo, hi) of word w
+                            if (lo == 4u * w && hi == 4u * w + 4u) st4u(o + 4u * w, ow[w]);
+                            else {
+#pragma unroll
+                                for (uint32_t t = 0; t < 4; t++)
+                                    if (4u * w + t >= lo && 4u * w + t < hi) o[4u * w + t] = (uint8_t)(ow[w] >> (8u * t));
+                            }
+                            ow[w] = 0;
+                        }
+                        wbase += 32u;
+                        wfirst = 0;
+                        wend = 0;
+                        flags &= ~G_FLUSH;
+                    }
+                }
+            }
             // ---- switch finished lanes to their prefetched unit
             if (flags & G_DONE) {
                 if (flags & G_HAVE) {
@@ -769,7 +830,8 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                     const uint32_t c = decode_base((qcur >> ((i & 3u) * 8u)) & 0xFFu);
                     cb = c < 4u ? c << 4 : ~0u; // offset of the base's rank block inside a line (~0: no such base)
                     ocur = 0;
-                    wlo = (out_from - warm) & 3u; // first byte of the first output word that is this unit's
+                    wbase = (out_from - warm) & ~3u;
+                    wfirst = (out_from - warm) & 3u; // first byte of the first output word that is this unit's
                     flags = i < bound ? 0u : G_DONE; // (empty units: see plan_emit_kernel)
                     want = true;
 #ifdef KBO_WALK_DEBUG
@@ -931,19 +993,16 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                                       d == min((uint32_t)((int32_t)i - last_mm), k);
                     const bool word_done = (e & 3u) == 3u || fin || conv;
                     if (i >= out_from) {
+                        const uint32_t wi = e - wbase; // 0 .. 31
                         ocur |= d << ((e & 3u) * 8u);
+                        wend = wi + 1u;
                         if (word_done) {
-                            uint8_t *o = a.d_out + (start + warm + (e & ~3u));
-                            if (wlo == 0 && (e & 3u) == 3u) st4u(o, ocur);
-                            else { // a word the unit owns only part of: bytes wlo .. e & 3
-                                if (wlo == 0) o[0] = (uint8_t)ocur;
-                                if (wlo <= 1u && (e & 3u) >= 1u) o[1] = (uint8_t)(ocur >> 8);
-                                if (wlo <= 2u && (e & 3u) >= 2u) o[2] = (uint8_t)(ocur >> 16);
-                                if ((e & 3u) == 3u) o[3] = (uint8_t)(ocur >> 24);
-                            }
+                            const uint32_t ws = wi >> 2;
+#pragma unroll
+                            for (uint32_t w = 0; w < 8; w++) ow[w] = ws == w ? ocur : ow[w];
                             ocur = 0;
-                            wlo = 0;
                         }
+                        flags |= (wi == 31u && !(fin || conv)) ? G_FLUSH : 0u; // (long units: the window goes out in between)
                     }
                     if (fin && !conv && !(uflags & (kUnitPlain | kUnitToEnd))) { // reached the next group unconverged
                         a.redo[item] = 1;

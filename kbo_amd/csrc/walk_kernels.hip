@@ -465,7 +465,7 @@ void set_walk_experiment(int lane_limit, int dummy_lds_bytes)
     g_walk_dummy_lds = std::max(0, std::min(64 << 10, dummy_lds_bytes));
 }
 // guided walk: resident waves per CU, in 32nds of the plain walk's (so that kbo_set_walk_waves_per_cu scales both); 0 = by
-// the kernel: 8 (rank blocks + entries) or 10 (recovery lines).  Few: a lane comes back to the line of its last iteration
+// the kernel: 8 (rank blocks + entries) or 12 (recovery lines).  Few: a lane comes back to the line of its last iteration
 // (failed extension -> contraction -> retry) and finds it in L2 only while the lines of all lanes in flight fit there -
 // 8 waves x 64 lanes x 32 CUs x 128 B = 2 of an XCD's 4 MiB - and even lanes that never come back run into each other's
 // fills beyond that
@@ -513,7 +513,7 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
         // chunks of 64 units
         static const int env_gw = std::getenv("KBO_GUIDED_WAVES") ? std::atoi(std::getenv("KBO_GUIDED_WAVES")) : 0; // experiments: 32nds
         const int gw_set = env_gw > 0 ? env_gw : g_guided_waves_32nds.load();
-        const int gw = gw_set > 0 ? gw_set : (guided_uses_recovery_lines(a) ? 10 : 8);
+        const int gw = gw_set > 0 ? gw_set : (guided_uses_recovery_lines(a) ? 12 : 8);
         const uint32_t gwaves = (uint32_t)std::min<uint64_t>((uint64_t)std::max(1, max_waves * gw / 32),
                                                              ((uint64_t)a.unit_cap + 63) / 64);
         e = launch_ms_walk_guided(a, (gwaves + wpb - 1) / wpb, threads, stream);

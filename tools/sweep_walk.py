@@ -61,6 +61,8 @@ def time_walk(reps=8):
 
 
 L = kbo_amd.lib()
+if os.environ.get("NOPLAN"):  # the plain walk (default: whatever kbo_ms_batch_dev takes, i.e. the plan-guided walk)
+    L.kbo_set_plan(0, 0, 0)
 if os.environ.get("RARE"):
     for wpc in (32,):
         for period in (2, 4, 6, 8, 12, 16, 32):
