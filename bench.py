@@ -327,7 +327,7 @@ def main():
         label = (args.config if std else "custom") + ": " + \
             ("kbo find (max_gap_len=0; run lengths on the device)" if args.find else
              "kbo map (fill_gaps=false, call_variants=false, format=true)")
-        a1_kernels = ("plan_kernel + plan_count/scan/emit + ms_walk_guided_kernel + redo_collect + ms_walk_kernel (flagged reads)"
+        a1_kernels = ("plan_kernel + plan_count/scan/emit + ms_walk_guided_kernel (ms_walk_recovery_kernel from 24 Mi rows on) + redo_collect + ms_walk_kernel (flagged reads)"
                       if planned else "ms_walk_kernel")
         result = {
             "metric": f"query Mbp/sec for kbo {'find' if args.find else 'map'}, k={args.k}, {args.genome / 1e6:g} Mbp SBWT; bit-exact MS vs CPU",

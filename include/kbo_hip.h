@@ -333,7 +333,7 @@ int kbo_set_pair_steps(uint64_t min_rows, int min_depth);
 int kbo_set_plan(int enabled, int seed_depth, int seed_cap);
 /* More knobs of the plan-guided walk (<= 0 keeps a value): mismatches closer than `gap` bases (default 20, >= 2) are
  * walked by one unit; reads without a diagonal are walked in chunks of `chunk` bases (default 32); a launch with more
- * than bail_x16 / 16 units per read (default 32 / 16) gives the plan up and takes the plain walk (and the following 16
+ * than bail_x16 / 16 units per read (default 50 / 16: the break-even is near 4 % substitutions) gives the plan up and takes the plain walk (and the following 16
  * launches do not plan at all).  bail_x16 = 0 forces that path (tests); bits 16 and up of bail_x16, when set, divide the
  * capacity of the unit array (tests: reads whose units do not fit take the plain walk). */
 int kbo_set_plan_tuning(int gap, int chunk, int bail_x16);

@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
 
 std::atomic<int> g_plan_dmin{14}, g_plan_cap{40}, g_plan_gap{20}, g_plan_chunk{32};
 std::atomic<int> g_plan_stage{1};     // plan_kernel stages queries and predictions through LDS (0: experiments)
-std::atomic<int> g_plan_bail_x16{32}; // give the plan up when there are more than this many units per 16 items
+std::atomic<int> g_plan_bail_x16{50}; // give the plan up when there are more than this many units per 16 items
 void set_plan_stage(int on) { g_plan_stage = on != 0; }
 void set_plan_bail(int units_per_16_items) { g_plan_bail_x16 = std::max(0, units_per_16_items); }
 void set_plan_params(int dmin, int cap, int gap, int chunk)
@@ -1079,7 +1079,9 @@ hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
         const uint64_t need = (64ull * a.max_item_len + 16u + kPlanLdsSlack + 15u) / 16u * 16u;
         if (need <= 16384u) wave_lds = (uint32_t)need;
     }
-    hipLaunchKernelGGL(plan_kernel, dim3(nb), dim3(256), 4u * wave_lds, stream, a, wave_lds);
+    static const int env_blk = std::getenv("KBO_PLAN_BLOCK") ? std::atoi(std::getenv("KBO_PLAN_BLOCK")) : 0; // experiments
+    const uint32_t bt = env_blk == 64 || env_blk == 128 ? (uint32_t)env_blk : 256u;
+    hipLaunchKernelGGL(plan_kernel, dim3((a.n_items + bt - 1u) / bt), dim3(bt), (bt / 64u) * wave_lds, stream, a, wave_lds);
     hipLaunchKernelGGL(plan_count_kernel, dim3(nb), dim3(256), 0, stream, a);
     const hipError_t es = launch_scan(a.ucount, 2u * a.n_items + 1u, a.usums, stream);
     if (es != hipSuccess) return es;

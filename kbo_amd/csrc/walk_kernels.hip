@@ -527,10 +527,12 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
 #ifdef KBO_WALK_DEBUG
         a.hi_out = nullptr; // (counters build: the counter sink belongs to the guided kernel)
 #endif
+        // (one item per lane, so that a few hundred flagged items spread over waves; nearly all of these waves find no
+        // item and leave at once - workgroups of four waves: a quarter of the dispatches)
         const uint32_t rwaves = (a.n_items + 63u) / 64u;
-        const dim3 rgrid((rwaves + wpb - 1) / wpb);
-        if (a.ix.big) hipLaunchKernelGGL((ms_walk_kernel<false, true, false>), rgrid, block, 0, stream, a);
-        else hipLaunchKernelGGL((ms_walk_kernel<false, false, false>), rgrid, block, 0, stream, a);
+        const dim3 rgrid((rwaves + 3u) / 4u), rblock(256);
+        if (a.ix.big) hipLaunchKernelGGL((ms_walk_kernel<false, true, false>), rgrid, rblock, 0, stream, a);
+        else hipLaunchKernelGGL((ms_walk_kernel<false, false, false>), rgrid, rblock, 0, stream, a);
         return hipGetLastError();
     }
     if (a.call_sites) { // call mode: MS values + the breakpoint scan, no intervals written

@@ -24,7 +24,7 @@ def plan_defaults():
     L = kbo_amd.lib()
     yield L
     L.kbo_set_plan(1, 14, 40)
-    L.kbo_set_plan_tuning(20, 32, (1 << 16) | 32)
+    L.kbo_set_plan_tuning(20, 32, (1 << 16) | 50)
     L.kbo_set_guided_walk(0, -1)
 
 

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Folds a tools/summarize_prof.py summary into profiles/traffic_latest.json (what bench.py quotes as roofline.traffic):
+A1-stage bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 and TCC misses, summed over the stage's kernels, per launch.
+Usage: tools/traffic_from_summary.py <summary.json> <workload key, e.g. 5000000x1000000x150x0.01:plan> <source label>"""
+import json
+import os
+import sys
+
+A1 = ("plan_kernel", "plan_count_kernel", "scan_kernel", "plan_emit_kernel", "ms_walk_guided_kernel",
+      "ms_walk_recovery_kernel", "redo_collect_kernel", "ms_walk_kernel")
+summ, key, source = json.load(open(sys.argv[1])), sys.argv[2], sys.argv[3]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+path = os.path.join(root, "profiles", "traffic_latest.json")
+doc = json.load(open(path))
+calls = {k["kernel"]: k["calls"] for k in summ["kernel_stats"]}
+per_step = min(c for k, c in calls.items() if k in ("plan_kernel", "ms_walk_kernel"))  # launches of the stage in the run
+kern, tot_b, tot_m = {}, 0, 0
+for k in A1:
+    d = summ["pmc_avg_per_launch"].get(k)
+    if not d or "FETCH_SIZE" not in d:
+        continue
+    mult = calls.get(k, per_step) / per_step if k == "scan_kernel" else 1  # (several scan launches per stage)
+    b = int((2 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0)) * 1024 * mult)
+    m = int(d.get("TCC_MISS_sum", 0) * mult)
+    kern[k] = {"bytes": b, "tcc_miss": m, "tcc_hit": int(d.get("TCC_HIT_sum", 0) * mult)}
+    tot_b += b
+    tot_m += m
+doc["workloads"][key] = {"source": source, "a1_bytes_per_launch": tot_b, "a1_tcc_miss_per_launch": tot_m, "kernels": kern}
+json.dump(doc, open(path, "w"), indent=1)
+print(key, "bytes", tot_b, "misses", tot_m)
