@@ -351,8 +351,10 @@ def main():
                 # bandwidth utilisation: this stage loads 16-byte rank blocks, and skips the stretches of a read that
                 # match the index's path cover, so frac can exceed 1.  What binds the stage is in `bound`;
                 # traffic_frac is the measured fabric traffic over the same time against the same peak.
-                "bound": ("l2-miss line fills (index is L2/Infinity-Cache resident: about 56 G fills/s on this part, "
-                          "DESIGN.md section 6)") if resident else "l2-miss line fills from HBM (about 56 G fills/s, DESIGN.md section 6)",
+                "bound": ("l2-miss line fills, by their latency: the guided walk keeps 8-12 waves per CU so that the lines of the "
+                          "lanes in flight stay in L2 (DESIGN.md sections 4.2, 6)") if planned else
+                         (("l2-miss line fills (index is L2/Infinity-Cache resident: about 56 G fills/s on this part, "
+                           "DESIGN.md section 6)") if resident else "l2-miss line fills from HBM (about 56 G fills/s, DESIGN.md section 6)"),
                 "achieved": round(achieved, 1) if achieved is not None else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved is not None else None,
                 "frac_meaning": "reference-algorithm bytes / A1 stage time / 8 TB/s (contract figure, may exceed 1)",
