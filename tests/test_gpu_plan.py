@@ -55,7 +55,7 @@ def _workload(rng, ref_seqs, n_reads):
     return concat, offsets
 
 
-@pytest.mark.parametrize("k", [3, 5, 31, 64])
+@pytest.mark.parametrize("k", [3, 5, 31, 64, 160])  # (160: LCS bytes with the top bit set in the recovery lines)
 def test_plan_guided_walk_equals_plain_walk_and_oracle(oracle, plan_defaults, k):
     L = plan_defaults
     rng = np.random.default_rng(100 + k)
