@@ -173,6 +173,8 @@ def main_call(args):
     fits = bool((counts <= seg).all()) and int(counts_all[LISTS * 16]) == 0
     sites_h = sites.cpu().numpy().view(np.uint32)
     raw = np.concatenate([sites_h[g * seg:g * seg + min(int(counts[g]), seg)] for g in range(LISTS)]) if n_sites else sites_h[:0]
+    raw = raw[raw[:, 0] != 0xFFFFFFFF]  # (void records: kbo_hip.h, kbo_call_walk_dev)
+    n_sites = len(raw)
     # {offset of i, offset of j, row, 0} -> {read, i, j, row}
     recs = np.stack([raw[:, 0] // args.read_len, raw[:, 0] % args.read_len, raw[:, 1] % args.read_len, raw[:, 2]], axis=1) if n_sites else raw
     # parity: sites of the first reads vs a host scan (variant_calling.rs:268-273) of the oracle's MS

@@ -195,7 +195,9 @@ int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, const uint64_t
  * intervals) whose lanes run the breakpoint scan on the values they produce.  Sites are 16-byte records {offset of i in
  * d_concat, offset of j, row of ms[j], 0} in KBO_CALL_LISTS lists as below; d_count needs KBO_CALL_LISTS * 64 + 64 bytes:
  * the last counter is non-zero when some read had more than four breakpoints waiting within k bases - then (and when a
- * list overflowed) use kbo_ms_batch_dev with intervals + kbo_call_sites_dev instead.  Asynchronous on `stream`. */
+ * list overflowed) use kbo_ms_batch_dev with intervals + kbo_call_sites_dev instead.  A record whose first word is
+ * 0xFFFFFFFF is void and to be skipped (plan-guided walk: a site of a read that was afterwards scanned again in full,
+ * where the same site appears once more).  Asynchronous on `stream`. */
 int kbo_call_walk_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs,
                       uint64_t total_bases, size_t max_seq_len, size_t threshold, uint8_t *d_ms_out, void *d_sites,
                       size_t capacity, uint32_t *d_count, void *d_work, size_t work_bytes, void *stream);

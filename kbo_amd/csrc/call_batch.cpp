@@ -89,6 +89,7 @@ std::vector<SiteRec> find_sites(kbo_index *idx, const uint8_t *concat, const uin
                 raw.resize(n);
                 HIP_OK(hipMemcpy(raw.data(), d_sites.as<uint8_t>() + (size_t)g * seg_cap * 16, (size_t)n * 16, hipMemcpyDeviceToHost));
                 for (const Raw &x : raw) {
+                    if (by_walk && x.a == 0xFFFFFFFFu) continue; // (a site of an item that the redo pass scanned again)
                     if (by_walk) { // {slab offset of i, of j, row}: find the sequence
                         const size_t s = (size_t)(std::upper_bound(off.begin(), off.end(), (uint64_t)x.a) - off.begin()) - 1;
                         all.push_back(SiteRec{(uint32_t)(sl.s0 + s), (uint32_t)(x.a - off[s]), (uint32_t)(x.b - off[s]), x.c});

@@ -193,8 +193,9 @@ void attach_plan(kbo::WalkArgs &a, void *plan_work)
     a.redo = nullptr;
     a.units = nullptr;
     a.n_items_dev = nullptr;
-    // (a.call_* are set by the caller before attach_plan; call mode never plans)
-    if (a.call_sites) return;
+    // (a.call_* are set by the caller before attach_plan)
+    static const int env_pc = std::getenv("KBO_PLAN_CALL") ? std::atoi(std::getenv("KBO_PLAN_CALL")) : 1; // experiments: 0 = call mode never plans
+    if (a.call_sites && !env_pc) return;
     a.unit_bail = 0;
     a.unit_cap = a.plan_dmin = a.plan_cap = a.plan_gap = a.plan_chunk = 0;
     if (!g_plan_enabled || !plan_work || !a.ix.pc_text || (a.lo_out && a.hi_out) || a.n_items == 0) return;
@@ -212,13 +213,14 @@ void attach_plan(kbo::WalkArgs &a, void *plan_work)
     const size_t ni = a.n_items;
     a.gitems = reinterpret_cast<kbo::GuidedItem *>(w);
     w += ni * sizeof(kbo::GuidedItem);
-    a.unit_cap = (uint32_t)std::min<size_t>(kbo::plan_unit_cap(ni, a.q_bytes), 0xFFFFFF00u);
-    const int cap_div = g_plan_cap_div.load();
-    if (cap_div > 1) a.unit_cap = std::max<uint32_t>(1u, a.unit_cap / (uint32_t)cap_div); // (tests: force the overflow path)
+    a.unit_cap = (uint32_t)std::min<size_t>(kbo::plan_unit_cap(ni, a.q_bytes), 0x7FFFFF00u);
+    a.redo_cap = 2u * a.unit_cap; // (>= every item cut into pieces of 64 bases: redo_collect_kernel)
     a.units = reinterpret_cast<kbo::WalkUnit *>(w);
     w += (size_t)a.unit_cap * sizeof(kbo::WalkUnit);
+    const int cap_div = g_plan_cap_div.load();
+    if (cap_div > 1) a.unit_cap = std::max<uint32_t>(1u, a.unit_cap / (uint32_t)cap_div); // (tests: force the overflow path)
     a.glist = reinterpret_cast<uint16_t *>(w);
-    w += (ni * kbo::kPlanList * 2 + 15) / 16 * 16;
+    w += (ni * kbo::kPlanListMax * 2 + 15) / 16 * 16;
     a.ucount = reinterpret_cast<uint32_t *>(w);
     w += (2 * ni + 1) * 4;
     a.usums = reinterpret_cast<uint32_t *>(w);

@@ -37,6 +37,8 @@ uint64_t walk_chunk(uint64_t total, size_t n_seqs, uint32_t k)
     // 39.9 / 41.9 / 42.9 / 43.6 / 46.0 / 42.5 / 32.1 / 26.0 Gbp/s: about 130 k items, a quarter of the lanes, is the best
     // trade between the k warm-up bases every chunk re-walks and the number of chains in flight)
     uint64_t chunk = n_seqs >= (1u << 19) ? 4096 : std::min<uint64_t>(4096, std::max<uint64_t>(256, total >> 17));
+    static const int env_chunk = std::getenv("KBO_WALK_CHUNK") ? std::atoi(std::getenv("KBO_WALK_CHUNK")) : 0; // experiments
+    if (env_chunk > 0) chunk = (uint64_t)env_chunk;
     return std::max<uint64_t>(chunk, 4ull * k);
 }
 
@@ -150,8 +152,8 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
     a.call_cap = call ? call->cap_per_list : 0;
     a.call_thr = call ? call->threshold : 0;
     a.max_item_len = device_items ? longest_seq : (uint32_t)std::min<uint64_t>(chunk + idx->host.k, 0xFFFFFFFFu);
-    if (view.pc_text && !want_ival && !call) B.plan.ensure(kbo::plan_work_bytes(n_items, total));
-    attach_plan(a, view.pc_text && !want_ival && !call ? B.plan.p : nullptr);
+    if (view.pc_text && !want_ival) B.plan.ensure(kbo::plan_work_bytes(n_items, total));
+    attach_plan(a, view.pc_text && !want_ival ? B.plan.p : nullptr);
     HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), stream));
     plan_after_launch(a, stream);
 }

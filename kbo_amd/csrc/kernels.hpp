@@ -50,7 +50,8 @@ struct alignas(16) WalkItem {
 // to the group's last mismatch); a unit that reaches the next group first flags its item, and flagged items are
 // walked again in full by the plain kernel.  Every value that is not walked is exact: see path_cover.cpp.
 constexpr uint32_t kPlanPad = 64;        // zero bytes in front of / behind the device text (== PathCover::kPad)
-constexpr uint32_t kPlanList = 12;       // u16 list entries per item after the first (13 mismatch positions in all)
+constexpr uint32_t kPlanList = 12;       // u16 list entries per item after the first (13 mismatch positions in all): reads
+constexpr uint32_t kPlanListMax = 28;    // the same for long items (WalkArgs::plan_list); the list array is sized for it
 constexpr uint32_t kPlanNone = 0xFF;     // GuidedItem::n_mm: no diagonal found, walk the item plainly
 constexpr uint32_t kPlanInf = 0xFFFE;    // GuidedItem::mm0: no mismatch
 struct alignas(16) GuidedItem {
@@ -60,7 +61,7 @@ struct alignas(16) GuidedItem {
     uint16_t j_conv;  // > 0: the item's first j_conv bases match the diagonal and were walked exactly by plan_kernel
     uint16_t mm0;     // first mismatch position (kPlanInf: none)
     uint8_t warm;     // leading bases without output
-    uint8_t n_mm;     // kPlanNone, or min(mismatches, 254); more than kPlanList + 1: the list is incomplete
+    uint8_t n_mm;     // kPlanNone, or min(mismatches, 254); more than plan_list + 1: the list is incomplete
 };
 enum : uint32_t { kUnitHead = 1u, kUnitPlain = 2u, kUnitToEnd = 4u };
 struct alignas(16) WalkUnit { // 32 bytes
@@ -76,7 +77,8 @@ struct alignas(16) WalkUnit { // 32 bytes
     uint8_t warm;      // as GuidedItem (positions of the output words)
     uint8_t pad0;
     uint32_t item;     // work item it belongs to (for the redo flag)
-    uint32_t pad1[2];
+    uint32_t lim_len;  // (call mode) bases of the item that are its own (the rest belong to the next chunk) | length << 16
+    uint32_t pad1;
 };
 
 struct WalkArgs {
@@ -94,18 +96,20 @@ struct WalkArgs {
     uint32_t *hi_out;      // optional: interval end per base
     // plan-guided walk (all or none): work buffers sized by plan_work_bytes(), see attach_plan()
     GuidedItem *gitems;    // nullptr: plain walk
-    uint16_t *glist;       // kPlanList entries per item
+    uint16_t *glist;       // plan_list entries per item
     uint32_t *ucount;      // units per item, heavy ones then light ones (2 n_items + 1 entries), scanned in place
     uint32_t *usums;       // block sums of that scan
     uint8_t *redo;         // per item: 1 = a unit could not vouch for its successor, walk the item again in full
     WalkUnit *units;       // unit_cap records (items whose units do not fit are flagged for the full walk instead)
     uint32_t unit_cap;
+    uint32_t redo_cap;     // WalkItem records the unit array holds (the redo pass's list is built there)
     uint32_t unit_bail;    // more units than this in a launch: the plan is given up, every item takes the plain walk
     uint32_t *qctl;        // [0] queue head of the guided walk
     uint32_t plan_dmin;    // plan_kernel: a seed must be this deep (capped at k) before its row is trusted
     uint32_t plan_cap;     // plan_kernel: seed iterations before an item is given up as unplanned
     uint32_t plan_gap;     // plan_emit_kernel: mismatches closer than this share a unit (>= 2)
     uint32_t plan_chunk;   // plan_emit_kernel: bases per unit of an item without a plan
+    uint32_t plan_list;    // mismatch-list entries per item (kPlanList or kPlanListMax, set by launch_plan)
     // call mode of the plain kernel (all or none; call_kernels.hip has the stand-alone scan): the breakpoint scan of
     // call_variants (variant_calling.rs:268-273) done by the walking lane itself, sites {first base of the item + i, .. + j,
     // row, 0} appended to kCallSegs lists of call_cap records each (counters 64 bytes apart)
@@ -120,7 +124,7 @@ struct WalkArgs {
 inline size_t plan_unit_cap(size_t n_items, uint64_t total_bases) { return 3 * n_items + total_bases / 64 + 64; }
 inline size_t plan_work_bytes(size_t n_items, uint64_t total_bases)
 {
-    return n_items * (sizeof(GuidedItem) + kPlanList * 2) + (2 * n_items + 1 + n_items / 512 + 8) * 4 +
+    return n_items * (sizeof(GuidedItem) + kPlanListMax * 2) + (2 * n_items + 1 + n_items / 512 + 8) * 4 +
            (n_items + 15) / 16 * 16 + plan_unit_cap(n_items, total_bases) * sizeof(WalkUnit) + 256;
 }
 hipError_t launch_plan(WalkArgs &a, hipStream_t stream); // fills in the plan parameters of `a` (the later launches need them)

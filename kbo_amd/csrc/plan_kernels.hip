@@ -77,13 +77,14 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
     const uint32_t n = a.ix.n, k = a.ix.k, nblk = a.ix.n_blocks, null_blk = 4u * nblk;
     const uint8_t *arena = reinterpret_cast<const uint8_t *>(a.ix.arena);
     const uint8_t *qb = a.q;
-    uint32_t start = 0, len = 0, warm = 0;
+    uint32_t start = 0, len = 0, warm = 0, olen = 0;
     const bool have_item = idx < a.n_items;
     if (have_item) {
         const uint4 it = ld16(reinterpret_cast<const uint8_t *>(a.items), idx * 16u);
         start = it.x; // launches cover < 4 GiB of query: the high word of WalkItem::start is 0
         len = it.z;
-        warm = it.w;
+        warm = it.w & 0xFFFFu; // (call mode keeps the bases borrowed from the next chunk in the high half: WalkItem)
+        olen = len - min(len, it.w >> 16);
     }
     const bool plannable = have_item && len > 0;
     const uint32_t dmin = max(1u, min(k, a.plan_dmin)), cap = a.plan_cap;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
         if (wave_lds != 0 && have != 0) {
             const uint32_t last = (uint32_t)__popcll(have) - 1u;
             const uint32_t nxt_start = __shfl_down(start, 1), nxt_warm = __shfl_down(warm, 1);
-            const bool bad = lane < last && (nxt_start < start || nxt_start + nxt_warm != start + len);
+            const bool bad = (lane < last && (nxt_start < start || nxt_start + nxt_warm != start + len)) || olen != len;
             const uint32_t lo = __shfl(start, 0);
             wave_hi = __shfl(start + len, (int)last);
             out_lo = lo + __shfl(warm, 0);
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
 
     // ---- 2. compare + predict
     const uint8_t *tb = a.ix.pc_text - kPlanPad; // start of the padded text buffer
-    uint16_t *list = a.glist + (size_t)idx * kPlanList;
+    uint16_t *list = a.glist + (size_t)idx * a.plan_list;
     int32_t i_last = -1;
     uint32_t cnt = 0, mm0 = kPlanInf;
     for (uint32_t base0 = 0;; base0 += 16u * kPlanStep) {
@@ -259,12 +260,13 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                     while (mm) { // the item's mismatch list: entry 0 in the item record, entries 1..12 in the list
                         const uint32_t pos = base + (uint32_t)__ffs((int)mm) - 1u;
                         if (cnt == 0) mm0 = pos;
-                        else if (cnt <= kPlanList) list[cnt - 1u] = (uint16_t)pos;
+                        else if (cnt <= a.plan_list) list[cnt - 1u] = (uint16_t)pos;
                         cnt++;
                         mm &= mm - 1u;
                     }
-                    const uint32_t nb = min(16u, len - base);
-                    const uint32_t lo = warm > base ? min(warm - base, 16u) : 0u;
+                    // (olen: call mode's items end with bases of the next chunk, whose MS bytes are that chunk's to write)
+                    const uint32_t nb = olen > base ? min(16u, olen - base) : 0u;
+                    const uint32_t lo = min(warm > base ? min(warm - base, 16u) : 0u, nb);
                     if (staged) {
                         uint8_t *o = sm + soff + base;
                         if (lo == 0 && nb == 16u) __builtin_memcpy(o, &o4, 16);
@@ -311,14 +313,18 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
 // Units come in two weights, heavy ones (chunks, the head of an item, groups that span more than a few bases) first
 // in the queue: the longest units then start early instead of stretching the end of the launch.
 // Returns heavy | light << 16.
+// lim_len != 0: call mode - bases of the item that are its own | the item's length << 16, copied into every unit (the walk's
+// breakpoint scan needs them); the chunks of an item without a plan then own `chunk` bases each (their breakpoints and
+// MS bytes), start k bases upstream and may walk up to k bases past their end to resolve the breakpoints still waiting.
 template <bool EMIT>
 __device__ __forceinline__ uint32_t make_units(const uint4 &g, const uint16_t *list, uint32_t k, uint32_t gap, uint32_t chunk,
-                                               uint32_t item, WalkUnit *out_heavy, WalkUnit *out_light)
+                                               uint32_t item, WalkUnit *out_heavy, WalkUnit *out_light, uint32_t lim_len = 0,
+                                               uint32_t plist = kPlanList /* list entries per item */)
 {
     const uint32_t len = g.z & 0xFFFFu, j_conv = g.z >> 16, mm0 = g.w & 0xFFFFu, warm = (g.w >> 16) & 0xFFu, n_mm = g.w >> 24;
     if (len == 0) return 0;
     uint32_t nh = 0, nl = 0;
-    auto put = [&](uint32_t pos, uint32_t out_from, int32_t last_mm, uint32_t bound, uint32_t d_start, uint32_t flags) {
+    auto put = [&](uint32_t pos, uint32_t out_from, int32_t last_mm, uint32_t bound, uint32_t d_start, uint32_t flags, uint32_t ll) {
         const bool heavy = (flags & (kUnitPlain | kUnitHead)) || last_mm - (int32_t)pos > 8;
         WalkUnit *out = heavy ? out_heavy : out_light;
         uint32_t &nu = heavy ? nh : nl;
@@ -330,17 +336,21 @@ __device__ __forceinline__ uint32_t make_units(const uint4 &g, const uint16_t *l
             w0.w = ((uint32_t)last_mm & 0xFFFFu) | (bound << 16);
             w1.x = d_start | (flags << 8) | (warm << 16);
             w1.y = item;
-            w1.z = w1.w = 0;
+            w1.z = ll;
+            w1.w = 0;
             uint4 *o = reinterpret_cast<uint4 *>(out + nu);
             o[0] = w0;
             o[1] = w1;
         }
         nu++;
     };
-    if (n_mm == kPlanNone || n_mm > kPlanList + 1u) {
-        for (uint32_t c0 = warm; c0 < len; c0 += chunk) {
-            const uint32_t bound = min(len, c0 + chunk);
-            put(c0 > k - 1u ? c0 - (k - 1u) : 0u, c0, -1, bound, 0u, kUnitHead | kUnitPlain | (bound == len ? kUnitToEnd : 0u));
+    if (n_mm == kPlanNone || n_mm > plist + 1u) {
+        const bool call = lim_len != 0;
+        const uint32_t own = call ? (lim_len & 0xFFFFu) : len, wk = call ? k : k - 1u;
+        for (uint32_t c0 = warm; c0 < own; c0 += chunk) {
+            const uint32_t own_end = min(own, c0 + chunk), bound = call ? min(len, own_end + k) : own_end;
+            put(c0 > wk ? c0 - wk : 0u, c0, -1, bound, 0u, kUnitHead | kUnitPlain | (bound == len ? kUnitToEnd : 0u),
+                call ? (own_end | (len << 16)) : 0u);
         }
         return nh | (nl << 16);
     }
@@ -363,7 +373,7 @@ __device__ __forceinline__ uint32_t make_units(const uint4 &g, const uint16_t *l
             t++;
         }
         const uint32_t bound = t < n_mm ? mm_at(t) : len;
-        put(pos, max(warm, pos), last, bound, d_start, flags | (t < n_mm ? 0u : kUnitToEnd));
+        put(pos, max(warm, pos), last, bound, d_start, flags | (t < n_mm ? 0u : kUnitToEnd), lim_len);
     }
     return nh | (nl << 16);
 }
@@ -373,7 +383,12 @@ __global__ __launch_bounds__(256) void plan_count_kernel(WalkArgs a)
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.n_items) return;
     const uint4 g = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(a.gitems) + (size_t)idx * 16u);
-    const uint32_t c = make_units<false>(g, a.glist + (size_t)idx * kPlanList, a.ix.k, a.plan_gap, a.plan_chunk, idx, nullptr, nullptr);
+    uint32_t lim_len = 0;
+    if (a.call_sites) { // (call mode: see plan_emit_kernel)
+        const uint4 it = ld16(reinterpret_cast<const uint8_t *>(a.items), idx * 16u);
+        lim_len = (it.z - (it.w >> 16)) | (it.z << 16);
+    }
+    const uint32_t c = make_units<false>(g, a.glist + (size_t)idx * a.plan_list, a.ix.k, a.plan_gap, a.plan_chunk, idx, nullptr, nullptr, lim_len, a.plan_list);
     a.ucount[idx] = c & 0xFFFFu;              // class-major: all heavy counts, then all light counts, then one 0
     a.ucount[a.n_items + idx] = c >> 16;
     if (idx == 0) a.ucount[2u * a.n_items] = 0; // the prefix of this extra entry is the number of units
@@ -387,6 +402,11 @@ __global__ __launch_bounds__(256) void plan_emit_kernel(WalkArgs a)
     auto prefix = [&](uint32_t e) -> uint32_t { return a.usums[e / kScanBlock] + a.ucount[e]; };
     if (prefix(2u * a.n_items) > a.unit_bail) return; // too much to walk for the plan to pay: every item takes the
                                                       // plain walk (redo_collect_kernel lists them all)
+    uint32_t lim_len = 0;
+    if (a.call_sites) { // call mode: the walk of a unit needs the item's own length and whole length for its breakpoint scan
+        const uint4 it = ld16(reinterpret_cast<const uint8_t *>(a.items), idx * 16u);
+        lim_len = (it.z - (it.w >> 16)) | (it.z << 16);
+    }
     const uint32_t hs = prefix(idx), he = prefix(idx + 1u), ls = prefix(a.n_items + idx), le = prefix(a.n_items + idx + 1u);
     if (le > a.unit_cap || he > a.unit_cap) { // no room for this item's units: it takes the full walk instead
         if (he > hs || le > ls) a.redo[idx] = 1;
@@ -398,17 +418,24 @@ __global__ __launch_bounds__(256) void plan_emit_kernel(WalkArgs a)
             }
         return;
     }
-    make_units<true>(g, a.glist + (size_t)idx * kPlanList, a.ix.k, a.plan_gap, a.plan_chunk, idx, a.units + hs, a.units + ls);
+    make_units<true>(g, a.glist + (size_t)idx * a.plan_list, a.ix.k, a.plan_gap, a.plan_chunk, idx, a.units + hs, a.units + ls, lim_len,
+                     a.plan_list);
 }
 
-// Collects the items the guided walk flagged into a list for the plain kernel (the item records are not needed any
-// more at this point and their array becomes that list); qctl[1] counts them.
+// Collects the items the guided walk flagged into a list for the plain kernel; qctl[1] counts its entries.  The list is
+// built in the unit array (all units are walked by now; 2 * unit_cap item records fit: more than every item cut into
+// pieces).  A flagged item longer than 96 output bases is cut into pieces of 64 with their own warm-up (and, in call mode,
+// borrowed) bases, like the chunks of a long sequence: the redo pass is a handful of items, and one lane walking 800 bases
+// on its own would be most of the stage's time.  A plan that was given up: all items as they are, in order.
+constexpr uint32_t kRedoPiece = 64;
 __global__ __launch_bounds__(256) void redo_collect_kernel(WalkArgs a)
 {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.n_items) return;
+    WalkItem *list = reinterpret_cast<WalkItem *>(a.units);
+    const uint4 it = ld16(reinterpret_cast<const uint8_t *>(a.items), idx * 16u);
     if (a.usums[(2u * a.n_items) / kScanBlock] + a.ucount[2u * a.n_items] > a.unit_bail) { // plan given up: all items, in order
-        reinterpret_cast<uint4 *>(a.gitems)[idx] = reinterpret_cast<const uint4 *>(a.items)[idx];
+        reinterpret_cast<uint4 *>(list)[idx] = it;
         if (idx == 0) {
             a.qctl[1] = a.n_items;
             a.qctl[2] = 1; // tells the host (plan_after_launch) that planning did not pay for this batch
@@ -419,11 +446,51 @@ __global__ __launch_bounds__(256) void redo_collect_kernel(WalkArgs a)
     const bool f = a.redo[idx] != 0;
     const uint64_t fm = __ballot(f);
     if (fm == 0) return;
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+    const uint32_t len = it.z, warm = it.w & 0xFFFFu, tail = it.w >> 16, body = len - warm - tail;
+    const uint32_t marg = a.call_sites ? a.ix.k : (a.ix.k > 0 ? a.ix.k - 1u : 0u); // warm-up of a chunk (make_chunk_items_kernel)
+    const uint32_t np = !f ? 0u : (body > kRedoPiece + kRedoPiece / 2u ? (body + kRedoPiece - 1u) / kRedoPiece : 1u);
+    uint32_t incl = np; // inclusive scan over the wave
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off);
+        if ((int)lane >= off) incl += t;
+    }
+    const int last = 63 - (int)__builtin_clzll(__ballot(true));
+    const uint32_t total = __shfl(incl, last);
     uint32_t base = 0;
-    if (f && rank == 0) base = atomicAdd(a.qctl + 1, (uint32_t)__popcll(fm));
-    base = __shfl(base, (int)__builtin_ctzll(fm));
-    if (f) reinterpret_cast<uint4 *>(a.gitems)[base + rank] = reinterpret_cast<const uint4 *>(a.items)[idx];
+    if ((int)lane == last) base = atomicAdd(a.qctl + 1, total);
+    base = __shfl(base, last) + incl - np;
+    if (np == 1) {
+        if (base < a.redo_cap) reinterpret_cast<uint4 *>(list)[base] = it;
+    } else {
+        for (uint32_t p = 0; p < np; p++) {
+            const uint32_t out_lo = warm + p * kRedoPiece, out_hi = min(out_lo + kRedoPiece, warm + body);
+            const uint32_t w2 = p == 0 ? warm : min(marg, out_lo);
+            const uint32_t t2 = a.call_sites ? min(a.ix.k, len - out_hi) : 0u;
+            if (base + p < a.redo_cap)
+                reinterpret_cast<uint4 *>(list)[base + p] = make_uint4(it.x + out_lo - w2, it.y, (out_hi - out_lo) + w2 + t2, w2 | (t2 << 16));
+        }
+    }
+}
+
+// Call mode, after the guided walk: a site written by a unit carries its item (w = item + 1); the sites of items that are
+// flagged for the redo pass are made void (x = ~0: that pass scans the item again), the others get the row of a match
+// that was placed on the diagonal (w's top bit: z holds the text position) and w = 0.
+__global__ __launch_bounds__(256) void call_fix_sites_kernel(WalkArgs a)
+{
+    const uint32_t seg = blockIdx.x;
+    const uint32_t n = min(a.call_counts[seg * 16u], a.call_cap);
+    uint4 *list = a.call_sites + (size_t)seg * a.call_cap;
+    for (uint32_t sl = threadIdx.x; sl < n; sl += blockDim.x) {
+        uint4 v = list[sl];
+        if (v.w == 0) continue;
+        const uint32_t item = (v.w & 0x7FFFFFFFu) - 1u;
+        if (a.redo[item]) v.x = ~0u;
+        else if (v.w >> 31) v.z = a.ix.pc_node[v.z];
+        v.w = 0;
+        list[sl] = v;
+    }
 }
 
 // per-lane flag bits of the guided walk
@@ -451,7 +518,7 @@ enum : uint32_t {
 //  * output in words (4 bases), bytes at the two ends of the walked stretch, so that a unit patches the predicted
 //    values without touching its neighbours;
 //  * units come off one queue in chunks of 64 per wave; a lane that finishes takes the next one.
-template <bool BIG>
+template <bool BIG, bool CALL>
 __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
 {
     const uint32_t n = a.ix.n, k = a.ix.k;
@@ -481,7 +548,11 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
     uint32_t ow[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t wbase = 0, wfirst = 0, wend = 0;
     uint4 nu0 = make_uint4(0, 0, 0, 0), nq0 = make_uint4(0, 0, 0, 0), nq1 = make_uint4(0, 0, 0, 0);
-    uint2 nu1 = make_uint2(0, 0);
+    uint4 nu1 = make_uint4(0, 0, 0, 0);
+    // CALL: the breakpoint scan of call_variants over what the unit walks (ms_walk_kernel's, walk_kernels.hip); when the
+    // unit converges with breakpoints still waiting, the match that resolves them is the base where the depth on the
+    // diagonal reaches the threshold - known without walking there (units are at least threshold + 1 bases apart)
+    uint32_t lim = 0, ilen = 0, up0 = 0, dprev = 0, np = 0, pend0 = 0, pend1 = 0, pend2 = 0, pend3 = 0;
     uint32_t nrow = 0;
     bool want = true; // wants to claim a unit
 #ifdef KBO_WALK_DEBUG
@@ -548,6 +619,13 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
                     qcur = sel4(qblk, (i >> 2) & 3u);
                     const uint32_t c = decode_base((qcur >> ((i & 3u) * 8u)) & 0xFFu);
                     cb = c < 4u ? c * nblk : null_blk;
+                    if (CALL) {
+                        lim = nu1.z & 0xFFFFu;
+                        ilen = nu1.z >> 16;
+                        up0 = nu0.y;
+                        dprev = d;
+                        np = 0;
+                    }
                     ocur = 0;
                     wbase = (out_from - warm) & ~3u;
                     wfirst = (out_from - warm) & 3u; // first byte of the first output word that is this unit's
@@ -584,7 +662,7 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
                 }
                 if (want && mine < lim) {
                     nu0 = ld16(utb, mine * 32u);
-                    __builtin_memcpy(&nu1, utb + (size_t)mine * 32u + 16u, 8);
+                    __builtin_memcpy(&nu1, utb + (size_t)mine * 32u + 16u, 16);
                     flags |= G_PF;
                 }
                 want = false;
@@ -657,13 +735,48 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
                 d = con ? lv : (ok ? min(d + 1u, k) : d);
                 flags = (con && cstop) ? (flags & ~G_CON) : (fail ? (flags | G_CON) : flags);
                 if (accept) {
-                    const bool fin = i + 1u == bound;
+                    bool fin = i + 1u == bound;
                     const uint32_t e = i - warm; // output index (wraps below warm; only its low bits are used then)
                     // converged: the walk is provably back on the diagonal (see the header); the unit ends here
                     const bool conv = !(uflags & kUnitPlain) && (int32_t)i >= last_mm && r == l + 1u &&
                                       d == min((uint32_t)((int32_t)i - last_mm), k);
+                    if (CALL) {
+                        const uint32_t thr = a.call_thr, seg = (((blockIdx.x * blockDim.x + threadIdx.x) >> 6)) % kCallSegs;
+                        if (i >= out_from && i > 0 && i < lim && d < dprev && dprev >= thr && d < thr) { // a breakpoint this unit owns
+                            while (np && pend0 + k < i) { pend0 = pend1; pend1 = pend2; pend2 = pend3; np--; }
+                            if (np == 4u) atomicAdd(a.call_counts + 16u * kCallSegs, 1u);
+                            else {
+                                if (np == 0) pend0 = i; else if (np == 1) pend1 = i; else if (np == 2) pend2 = i; else pend3 = i;
+                                np++;
+                            }
+                        } else if (np && d >= thr && r == l + 1u) { // the first unique match to the right of the waiting ones
+                            for (uint32_t x = 0; x < np; x++) {
+                                const uint32_t bp = x == 0 ? pend0 : x == 1 ? pend1 : x == 2 ? pend2 : pend3;
+                                if (i <= bp + k) {
+                                    const uint32_t slot = atomicAdd(a.call_counts + seg * 16u, 1u);
+                                    if (slot < a.call_cap) a.call_sites[(size_t)seg * a.call_cap + slot] = make_uint4(start + bp, start + i, l, item + 1u);
+                                }
+                            }
+                            np = 0;
+                        }
+                        dprev = d;
+                        if (conv && np) { // back on the diagonal: the depth reaches thr at js, on the diagonal's node there
+                            const uint32_t js = (uint32_t)(last_mm + (int32_t)thr);
+                            for (uint32_t x = 0; x < np; x++) {
+                                const uint32_t bp = x == 0 ? pend0 : x == 1 ? pend1 : x == 2 ? pend2 : pend3;
+                                if (js < ilen && js <= bp + k) {
+                                    const uint32_t slot = atomicAdd(a.call_counts + seg * 16u, 1u);
+                                    if (slot < a.call_cap) // (row = node_at[text position]: filled in by call_fix_sites_kernel)
+                                        a.call_sites[(size_t)seg * a.call_cap + slot] = make_uint4(start + bp, start + js, up0 + js, (item + 1u) | 0x80000000u);
+                                }
+                            }
+                            np = 0;
+                        }
+                        // a chunk of an item without a plan: done with its own bases once no breakpoint waits any more
+                        fin = fin || ((uflags & kUnitPlain) && i + 1u >= lim && np == 0u);
+                    }
                     const bool word_done = (e & 3u) == 3u || fin || conv;
-                    if (i >= out_from) {
+                    if (i >= out_from && (!CALL || i < lim)) { // (call mode: the bases borrowed from the next chunk are that chunk's to write)
                         const uint32_t wi = e - wbase; // 0 .. 31
                         ocur |= d << ((e & 3u) * 8u);
                         wend = wi + 1u;
@@ -732,7 +845,7 @@ __device__ __forceinline__ uint32_t lt4(uint32_t x, uint32_t yb)
 // the next one to the right of r, searched in the 16 values [.., l] and [r, ..] of the line(s); when a window ends
 // first (end of the line, long run of equal suffixes) the level is taken from the {lcs, psv, nsv} entries in the
 // next iteration instead.  Everything else is ms_walk_guided_kernel.
-template <bool BIG>
+template <bool BIG, bool CALL>
 __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
 {
     const uint32_t n = a.ix.n, k = a.ix.k;
@@ -762,7 +875,11 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
     uint32_t ow[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t wbase = 0, wfirst = 0, wend = 0;
     uint4 nu0 = make_uint4(0, 0, 0, 0), nq0 = make_uint4(0, 0, 0, 0), nq1 = make_uint4(0, 0, 0, 0);
-    uint2 nu1 = make_uint2(0, 0);
+    uint4 nu1 = make_uint4(0, 0, 0, 0);
+    // CALL: the breakpoint scan of call_variants over what the unit walks (ms_walk_kernel's, walk_kernels.hip); when the
+    // unit converges with breakpoints still waiting, the match that resolves them is the base where the depth on the
+    // diagonal reaches the threshold - known without walking there (units are at least threshold + 1 bases apart)
+    uint32_t lim = 0, ilen = 0, up0 = 0, dprev = 0, np = 0, pend0 = 0, pend1 = 0, pend2 = 0, pend3 = 0;
     uint32_t nrow = 0;
     bool want = true; // wants to claim a unit
     uint32_t visits = 0;
@@ -829,6 +946,13 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                     qcur = sel4(qblk, (i >> 2) & 3u);
                     const uint32_t c = decode_base((qcur >> ((i & 3u) * 8u)) & 0xFFu);
                     cb = c < 4u ? c << 4 : ~0u; // offset of the base's rank block inside a line (~0: no such base)
+                    if (CALL) {
+                        lim = nu1.z & 0xFFFFu;
+                        ilen = nu1.z >> 16;
+                        up0 = nu0.y;
+                        dprev = d;
+                        np = 0;
+                    }
                     ocur = 0;
                     wbase = (out_from - warm) & ~3u;
                     wfirst = (out_from - warm) & 3u; // first byte of the first output word that is this unit's
@@ -865,7 +989,7 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                 }
                 if (want && mine < lim) {
                     nu0 = ld16(utb, mine * 32u);
-                    __builtin_memcpy(&nu1, utb + (size_t)mine * 32u + 16u, 8);
+                    __builtin_memcpy(&nu1, utb + (size_t)mine * 32u + 16u, 16);
                     flags |= G_PF;
                 }
                 want = false;
@@ -986,13 +1110,48 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                 dbg_acc += accept ? 1u : 0u;
 #endif
                 if (accept) {
-                    const bool fin = i + 1u == bound;
+                    bool fin = i + 1u == bound;
                     const uint32_t e = i - warm; // output index (wraps below warm; only its low bits are used then)
                     // converged: the walk is provably back on the diagonal (see the header); the unit ends here
                     const bool conv = !(uflags & kUnitPlain) && (int32_t)i >= last_mm && r == l + 1u &&
                                       d == min((uint32_t)((int32_t)i - last_mm), k);
+                    if (CALL) {
+                        const uint32_t thr = a.call_thr, seg = (((blockIdx.x * blockDim.x + threadIdx.x) >> 6)) % kCallSegs;
+                        if (i >= out_from && i > 0 && i < lim && d < dprev && dprev >= thr && d < thr) { // a breakpoint this unit owns
+                            while (np && pend0 + k < i) { pend0 = pend1; pend1 = pend2; pend2 = pend3; np--; }
+                            if (np == 4u) atomicAdd(a.call_counts + 16u * kCallSegs, 1u);
+                            else {
+                                if (np == 0) pend0 = i; else if (np == 1) pend1 = i; else if (np == 2) pend2 = i; else pend3 = i;
+                                np++;
+                            }
+                        } else if (np && d >= thr && r == l + 1u) { // the first unique match to the right of the waiting ones
+                            for (uint32_t x = 0; x < np; x++) {
+                                const uint32_t bp = x == 0 ? pend0 : x == 1 ? pend1 : x == 2 ? pend2 : pend3;
+                                if (i <= bp + k) {
+                                    const uint32_t slot = atomicAdd(a.call_counts + seg * 16u, 1u);
+                                    if (slot < a.call_cap) a.call_sites[(size_t)seg * a.call_cap + slot] = make_uint4(start + bp, start + i, l, item + 1u);
+                                }
+                            }
+                            np = 0;
+                        }
+                        dprev = d;
+                        if (conv && np) { // back on the diagonal: the depth reaches thr at js, on the diagonal's node there
+                            const uint32_t js = (uint32_t)(last_mm + (int32_t)thr);
+                            for (uint32_t x = 0; x < np; x++) {
+                                const uint32_t bp = x == 0 ? pend0 : x == 1 ? pend1 : x == 2 ? pend2 : pend3;
+                                if (js < ilen && js <= bp + k) {
+                                    const uint32_t slot = atomicAdd(a.call_counts + seg * 16u, 1u);
+                                    if (slot < a.call_cap) // (row = node_at[text position]: filled in by call_fix_sites_kernel)
+                                        a.call_sites[(size_t)seg * a.call_cap + slot] = make_uint4(start + bp, start + js, up0 + js, (item + 1u) | 0x80000000u);
+                                }
+                            }
+                            np = 0;
+                        }
+                        // a chunk of an item without a plan: done with its own bases once no breakpoint waits any more
+                        fin = fin || ((uflags & kUnitPlain) && i + 1u >= lim && np == 0u);
+                    }
                     const bool word_done = (e & 3u) == 3u || fin || conv;
-                    if (i >= out_from) {
+                    if (i >= out_from && (!CALL || i < lim)) { // (call mode: the bases borrowed from the next chunk are that chunk's to write)
                         const uint32_t wi = e - wbase; // 0 .. 31
                         ocur |= d << ((e & 3u) * 8u);
                         wend = wi + 1u;
@@ -1066,8 +1225,13 @@ hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
     a.plan_dmin = (uint32_t)g_plan_dmin.load();
     a.plan_cap = (uint32_t)g_plan_cap.load();
     a.plan_gap = (uint32_t)g_plan_gap.load();
+    if (a.call_sites) a.plan_gap = std::max(a.plan_gap, a.call_thr + 1u); // (a unit resolves its breakpoints before the next one starts)
     a.plan_chunk = (uint32_t)g_plan_chunk.load();
-    a.unit_bail = (uint32_t)std::min<uint64_t>((uint64_t)a.n_items * (uint64_t)g_plan_bail_x16.load() / 16u + 64u, 0xFFFFFFFFu);
+    // mismatches an item's list holds: 13 for reads (more than that on 150 bases is a wrong diagonal), 29 for the chunks of
+    // long sequences (800 bases at 1 % substitutions exceed 13 every twentieth time)
+    a.plan_list = (a.max_item_len != 0 && a.max_item_len <= 255u) ? kPlanList : kPlanListMax;
+    // (per read of 150 bases: chunks of long sequences hold several reads' worth of units)
+    a.unit_bail = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(a.n_items, a.q_bytes / 150u) * (uint64_t)g_plan_bail_x16.load() / 16u + 64u, 0xFFFFFFFFu);
     const hipError_t e = hipMemsetAsync(a.qctl, 0, 64, stream);
     if (e != hipSuccess) return e;
     const uint32_t nb = (a.n_items + 255u) / 256u;
@@ -1089,14 +1253,22 @@ hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_ms_walk_guided(WalkArgs a, uint32_t grid, uint32_t threads, hipStream_t stream)
+template <bool CALL> static void launch_guided_variant(const WalkArgs &a, uint32_t grid, uint32_t threads, hipStream_t stream)
 {
     if (guided_uses_recovery_lines(a)) {
-        if (a.ix.big) hipLaunchKernelGGL((ms_walk_recovery_kernel<true>), dim3(grid), dim3(threads), 0, stream, a);
-        else hipLaunchKernelGGL((ms_walk_recovery_kernel<false>), dim3(grid), dim3(threads), 0, stream, a);
-    } else if (a.ix.big) hipLaunchKernelGGL((ms_walk_guided_kernel<true>), dim3(grid), dim3(threads), 0, stream, a);
-    else hipLaunchKernelGGL((ms_walk_guided_kernel<false>), dim3(grid), dim3(threads), 0, stream, a);
+        if (a.ix.big) hipLaunchKernelGGL((ms_walk_recovery_kernel<true, CALL>), dim3(grid), dim3(threads), 0, stream, a);
+        else hipLaunchKernelGGL((ms_walk_recovery_kernel<false, CALL>), dim3(grid), dim3(threads), 0, stream, a);
+    } else if (a.ix.big) hipLaunchKernelGGL((ms_walk_guided_kernel<true, CALL>), dim3(grid), dim3(threads), 0, stream, a);
+    else hipLaunchKernelGGL((ms_walk_guided_kernel<false, CALL>), dim3(grid), dim3(threads), 0, stream, a);
+}
+
+hipError_t launch_ms_walk_guided(WalkArgs a, uint32_t grid, uint32_t threads, hipStream_t stream)
+{
+    if (a.call_sites) launch_guided_variant<true>(a, grid, threads, stream);
+    else launch_guided_variant<false>(a, grid, threads, stream);
     hipLaunchKernelGGL(redo_collect_kernel, dim3((a.n_items + 255u) / 256u), dim3(256), 0, stream, a);
+    // call mode: sites of items that go to the redo pass are void (that pass finds them again), the others get their rows
+    if (a.call_sites) hipLaunchKernelGGL(call_fix_sites_kernel, dim3(kCallSegs), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

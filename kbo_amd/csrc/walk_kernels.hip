@@ -114,10 +114,13 @@ __global__ __launch_bounds__(256) void ms_walk_kernel(WalkArgs a)
 
     // this lane's items: first, first + 64, ...
     const uint32_t n_items = a.n_items_dev ? min(*a.n_items_dev, a.n_items) : a.n_items; // (redo pass: counted on the device)
-    const uint64_t first64 = (uint64_t)wave * 64u * a.rounds + lane;
+    // (redo pass: as many items per lane as the launch needs to cover the list - one, unless the list is long)
+    const uint32_t lanes_all = gridDim.x * blockDim.x;
+    const uint32_t rounds = a.n_items_dev ? max(1u, (n_items + lanes_all - 1u) / lanes_all) : a.rounds;
+    const uint64_t first64 = (uint64_t)wave * 64u * rounds + lane;
     uint32_t next_item = (first64 < n_items && lane < a.lane_limit) ? (uint32_t)first64 : n_items;
     uint32_t left = 0; // items whose descriptor has not been requested yet
-    if (next_item < n_items) left = min(a.rounds, (n_items - 1u - next_item) / 64u + 1u);
+    if (next_item < n_items) left = min(rounds, (n_items - 1u - next_item) / 64u + 1u);
 
     uint32_t flags = left ? F_DONE : F_FIN;
     uint32_t l = 0, r = n, d = 0, m = 0, cb = 0; // m: contraction targets known (rare block only)
@@ -506,7 +509,7 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
     const dim3 grid((waves + wpb - 1) / wpb), block(threads);
     const bool ival = a.lo_out && a.hi_out;
     a.pair_min_d = (uint32_t)g_pair_min_depth.load();
-    if (a.gitems && a.glist && a.ix.pc_text && !ival && !a.call_sites) { // MS values only, index with a path cover: plan, then guided walk
+    if (a.gitems && a.glist && a.ix.pc_text && !ival) { // MS values only, index with a path cover: plan, then guided walk
         hipError_t e = launch_plan(a, stream);
         if (e != hipSuccess) return e;
         // the guided kernel takes its units off a queue: a fixed number of resident waves, but no more than there are
@@ -520,7 +523,9 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
         if (e != hipSuccess) return e;
         // the redo pass: items a unit flagged (its successor's start state was a wrong guess) walked plainly, in full;
         // redo_collect_kernel has listed them where the item records were, one item per lane
-        a.items = reinterpret_cast<const WalkItem *>(a.gitems);
+        const uint32_t n_orig = a.n_items;
+        a.items = reinterpret_cast<const WalkItem *>(a.units); // (the unit array is free by now: see redo_collect_kernel)
+        a.n_items = a.redo_cap;
         a.n_items_dev = a.qctl + 1;
         a.gitems = nullptr;
         a.rounds = 1;
@@ -529,9 +534,12 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
 #endif
         // (one item per lane, so that a few hundred flagged items spread over waves; nearly all of these waves find no
         // item and leave at once - workgroups of four waves: a quarter of the dispatches)
-        const uint32_t rwaves = (a.n_items + 63u) / 64u;
+        const uint32_t rwaves = (n_orig + 63u) / 64u;
         const dim3 rgrid((rwaves + 3u) / 4u), rblock(256);
-        if (a.ix.big) hipLaunchKernelGGL((ms_walk_kernel<false, true, false>), rgrid, rblock, 0, stream, a);
+        if (a.call_sites) { // (call mode: the flagged items' scan with their walk)
+            if (a.ix.big) hipLaunchKernelGGL((ms_walk_kernel<false, true, false, true>), rgrid, rblock, 0, stream, a);
+            else hipLaunchKernelGGL((ms_walk_kernel<false, false, false, true>), rgrid, rblock, 0, stream, a);
+        } else if (a.ix.big) hipLaunchKernelGGL((ms_walk_kernel<false, true, false>), rgrid, rblock, 0, stream, a);
         else hipLaunchKernelGGL((ms_walk_kernel<false, false, false>), rgrid, rblock, 0, stream, a);
         return hipGetLastError();
     }

@@ -128,3 +128,79 @@ def test_plan_guided_walk_big_layout(oracle, plan_defaults):
             assert np.array_equal(d, exp_d), fat
     finally:
         L.kbo_set_force_big_layout(0)
+
+
+def _call_walk_sites(L, sbwt, dev, thr):
+    """kbo_call_walk_dev over a DeviceBatch -> (set of (i_abs, j_abs, row), MS bytes, usable)"""
+    import torch
+    lists = 256  # KBO_CALL_LISTS
+    cap = (dev.total // 4 + 8192) // lists * lists
+    sites = torch.zeros((cap, 4), dtype=torch.int32, device=dev.device)
+    count = torch.zeros(lists * 16 + 16, dtype=torch.int32, device=dev.device)
+    s = torch.cuda.current_stream(dev.device)
+    dev.ms.fill_(0xEE)
+    kbo_amd.check(L.kbo_call_walk_dev(sbwt._h, dev.q.data_ptr(), dev.off.data_ptr(), dev.n_seqs, dev.total, dev.max_len, thr,
+                                      dev.ms.data_ptr(), sites.data_ptr(), cap, count.data_ptr(), dev.work.data_ptr(),
+                                      dev.work_bytes, s.cuda_stream))
+    torch.cuda.synchronize()
+    c = count.cpu().numpy()
+    seg = cap // lists
+    ok = bool((c[:lists * 16:16] <= seg).all()) and int(c[lists * 16]) == 0
+    h = sites.cpu().numpy().view(np.uint32)
+    raw = np.concatenate([h[g * seg:g * seg + min(int(c[g * 16]), seg)] for g in range(lists)])
+    raw = raw[raw[:, 0] != 0xFFFFFFFF]
+    return {(int(a), int(b), int(r)) for a, b, r, _ in raw}, dev.ms[:dev.total].cpu().numpy(), ok
+
+
+@pytest.mark.parametrize("k", [31, 51])
+def test_call_mode_of_the_plan_guided_walk(oracle, plan_defaults, k):
+    """The breakpoint scan of call_variants (variant_calling.rs:268-273) carried by the guided walk's units: same sites as
+    the plain walk in call mode and as a host scan of the oracle's MS, on reads and on chunked long sequences."""
+    import torch
+    from kbo_amd import derandomize
+    L = plan_defaults
+    rng = np.random.default_rng(700 + k)
+    g = synth.genome(400_000, seed=900 + k)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=k, num_threads=4))
+    ora = oracle.Index.build([g.tobytes()], k=k)
+    thr = derandomize.random_match_threshold(k, sbwt.n_kmers(), 4, 1e-7)
+    cat = g
+    seqs = []
+    for r in range(600):  # reads of 150 .. 2000 bases with substitutions, some indels, a few junk stretches
+        n = int(rng.choice([150, 300, 1000, 2000]))
+        a = int(rng.integers(0, len(cat) - n))
+        s = bytearray(_mutate(rng, cat[a:a + n].tobytes(), [0.003, 0.01, 0.03][r % 3]))
+        if r % 7 == 0:
+            del s[60:62]
+        if r % 9 == 0:
+            s[100:100] = b"ACGTTGCA"
+        if r % 31 == 0:
+            s[40:70] = bytes(rng.choice(list(b"ACGT"), 30).astype(np.uint8))
+        seqs.append(bytes(s))
+    seqs.append(_mutate(rng, cat[5000:65000].tobytes(), 0.01))  # chunked
+    concat = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+    offsets = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
+    dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"))
+    want = set()
+    for si, s in enumerate(seqs[:200] + seqs[-1:]):
+        base = int(offsets[si if si < 200 else len(seqs) - 1])
+        d, lo, hi = ora.matching_statistics(s)
+        for i in range(1, len(s)):
+            if d[i] < d[i - 1] and d[i - 1] >= thr and d[i] < thr:
+                for j in range(i + 1, min(i + k + 1, len(s))):
+                    if d[j] >= thr and hi[j] - lo[j] == 1:
+                        want.add((base + i, base + j, int(lo[j])))
+                        break
+    exp_d = np.concatenate([ora.matching_statistics(s)[0] for s in seqs]).astype(np.uint8)
+    got = {}
+    for plan in (0, 1, 2):  # plain walk in call mode; guided walk over rank blocks + entries; over the recovery lines
+        L.kbo_set_plan(1 if plan else 0, 14, 40)
+        L.kbo_set_guided_walk(0, 1 if plan == 2 else 0)
+        sites, ms, ok = _call_walk_sites(L, sbwt, dev, thr)
+        assert ok
+        assert np.array_equal(ms, exp_d), plan
+        got[plan] = sites
+        lo_b, hi_b = int(offsets[200]), int(offsets[len(seqs) - 1])
+        assert {x for x in sites if x[0] < lo_b or x[0] >= hi_b} == want, plan
+    assert got[0] == got[1] == got[2]
+    assert len(got[0]) > 500

@@ -10,7 +10,7 @@ sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=16))
 R = int(os.environ.get("R", 1_000_000))
 L = kbo_amd.lib()
 for sub in [float(x) for x in os.environ.get("SUB", "0.01").split(",")]:
-    concat, offsets = synth.reads(g, R, 150, sub)
+    concat, offsets = synth.reads(g, R, int(os.environ.get("LEN", 150)), sub)
     dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"))
     for rare in [int(x) for x in os.environ.get("RARE", "8").split(",")]:
         L.kbo_set_walk_rare(rare)
