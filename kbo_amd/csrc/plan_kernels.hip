@@ -836,6 +836,14 @@ __device__ __forceinline__ uint32_t lt4(uint32_t x, uint32_t yb)
     return ((lt >> 7) * 0x01020408u) >> 24;
 }
 
+// the same for values below 128 on both sides (k <= 127: every LCS value and level)
+__device__ __forceinline__ uint32_t lt4_7(uint32_t x, uint32_t yb)
+{
+    const uint32_t H = 0x80808080u;
+    const uint32_t lt = ~((x | H) - yb) & H;
+    return ((lt >> 7) * 0x01020408u) >> 24;
+}
+
 // -------------------------------------------------------------------------------------------------------------
 // ms_walk_recovery_kernel: ms_walk_guided_kernel over the recovery lines (sbwt_index.hpp) instead of the rank blocks
 // and contraction entries.  A unit is the stretch behind a mismatch: nearly every base lands on a row that is random
@@ -845,7 +853,7 @@ __device__ __forceinline__ uint32_t lt4(uint32_t x, uint32_t yb)
 // the next one to the right of r, searched in the 16 values [.., l] and [r, ..] of the line(s); when a window ends
 // first (end of the line, long run of equal suffixes) the level is taken from the {lcs, psv, nsv} entries in the
 // next iteration instead.  Everything else is ms_walk_guided_kernel.
-template <bool BIG, bool CALL>
+template <bool BIG, bool CALL, bool K7>
 __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
 {
     const uint32_t n = a.ix.n, k = a.ix.k;
@@ -1072,8 +1080,10 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                         const uint32_t lcs_l = (sel4(wA, pl >> 2) >> ((pl & 3u) * 8u)) & 0xFFu;
                         const uint32_t lcs_r = (sel4(wB, pr >> 2) >> ((pr & 3u) * 8u)) & 0xFFu;
                         const uint32_t lvw = max(lcs_l, lcs_r), yb = lvw * 0x01010101u;
-                        const uint32_t mA = lt4(wA.x, yb) | (lt4(wA.y, yb) << 4) | (lt4(wA.z, yb) << 8) | (lt4(wA.w, yb) << 12);
-                        const uint32_t mB = lt4(wB.x, yb) | (lt4(wB.y, yb) << 4) | (lt4(wB.z, yb) << 8) | (lt4(wB.w, yb) << 12);
+                        const uint32_t mA = K7 ? lt4_7(wA.x, yb) | (lt4_7(wA.y, yb) << 4) | (lt4_7(wA.z, yb) << 8) | (lt4_7(wA.w, yb) << 12)
+                                               : lt4(wA.x, yb) | (lt4(wA.y, yb) << 4) | (lt4(wA.z, yb) << 8) | (lt4(wA.w, yb) << 12);
+                        const uint32_t mB = K7 ? lt4_7(wB.x, yb) | (lt4_7(wB.y, yb) << 4) | (lt4_7(wB.z, yb) << 8) | (lt4_7(wB.w, yb) << 12)
+                                               : lt4(wB.x, yb) | (lt4(wB.y, yb) << 4) | (lt4(wB.z, yb) << 8) | (lt4(wB.w, yb) << 12);
                         const uint32_t below = mA & ((1u << pl) - 1u), above = mB & ~((2u << pr) - 1u);
                         const bool need_l = lcs_l == lvw, need_r = lcs_r == lvw;
                         if (lvw == 0) { // the root: its extension is [C[c], C[c+1])
@@ -1256,8 +1266,11 @@ hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
 template <bool CALL> static void launch_guided_variant(const WalkArgs &a, uint32_t grid, uint32_t threads, hipStream_t stream)
 {
     if (guided_uses_recovery_lines(a)) {
-        if (a.ix.big) hipLaunchKernelGGL((ms_walk_recovery_kernel<true, CALL>), dim3(grid), dim3(threads), 0, stream, a);
-        else hipLaunchKernelGGL((ms_walk_recovery_kernel<false, CALL>), dim3(grid), dim3(threads), 0, stream, a);
+        if (a.ix.k <= 127u) {
+            if (a.ix.big) hipLaunchKernelGGL((ms_walk_recovery_kernel<true, CALL, true>), dim3(grid), dim3(threads), 0, stream, a);
+            else hipLaunchKernelGGL((ms_walk_recovery_kernel<false, CALL, true>), dim3(grid), dim3(threads), 0, stream, a);
+        } else if (a.ix.big) hipLaunchKernelGGL((ms_walk_recovery_kernel<true, CALL, false>), dim3(grid), dim3(threads), 0, stream, a);
+        else hipLaunchKernelGGL((ms_walk_recovery_kernel<false, CALL, false>), dim3(grid), dim3(threads), 0, stream, a);
     } else if (a.ix.big) hipLaunchKernelGGL((ms_walk_guided_kernel<true, CALL>), dim3(grid), dim3(threads), 0, stream, a);
     else hipLaunchKernelGGL((ms_walk_guided_kernel<false, CALL>), dim3(grid), dim3(threads), 0, stream, a);
 }
