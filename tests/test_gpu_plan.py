@@ -193,14 +193,17 @@ def test_call_mode_of_the_plan_guided_walk(oracle, plan_defaults, k):
                         break
     exp_d = np.concatenate([ora.matching_statistics(s)[0] for s in seqs]).astype(np.uint8)
     got = {}
-    for plan in (0, 1, 2):  # plain walk in call mode; guided walk over rank blocks + entries; over the recovery lines
+    # plain walk in call mode; guided walk over rank blocks + entries; over the recovery lines; with a unit array of 1/40 of
+    # its size (most items overflow it and go to the redo pass in pieces, the sites their units wrote are void)
+    for plan in (0, 1, 2, 3):
         L.kbo_set_plan(1 if plan else 0, 14, 40)
         L.kbo_set_guided_walk(0, 1 if plan == 2 else 0)
+        L.kbo_set_plan_tuning(20, 32, ((40 << 16) | 0xFFFF) if plan == 3 else ((1 << 16) | 0xFFFF))
         sites, ms, ok = _call_walk_sites(L, sbwt, dev, thr)
         assert ok
         assert np.array_equal(ms, exp_d), plan
         got[plan] = sites
         lo_b, hi_b = int(offsets[200]), int(offsets[len(seqs) - 1])
         assert {x for x in sites if x[0] < lo_b or x[0] >= hi_b} == want, plan
-    assert got[0] == got[1] == got[2]
+    assert got[0] == got[1] == got[2] == got[3]
     assert len(got[0]) > 500
