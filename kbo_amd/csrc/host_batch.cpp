@@ -36,7 +36,12 @@ uint64_t walk_chunk(uint64_t total, size_t n_seqs, uint32_t k)
     // (measured on 100 Mbp of 10 kbp reads, call mode: 192 / 256 / 384 / 512 / 768 / 1024 / 1536 / 2048 bases per chunk ->
     // 39.9 / 41.9 / 42.9 / 43.6 / 46.0 / 42.5 / 32.1 / 26.0 Gbp/s: about 130 k items, a quarter of the lanes, is the best
     // trade between the k warm-up bases every chunk re-walks and the number of chains in flight)
-    uint64_t chunk = n_seqs >= (1u << 19) ? 4096 : std::min<uint64_t>(4096, std::max<uint64_t>(256, total >> 17));
+    // Not above 768: the plan-guided walk keeps at most 29 mismatches of an item (13 for reads), which chunks of 800 bases
+    // at 1 % substitutions rarely exceed and chunks of 4000 always do (500 Mbp of 10 kbp reads, call mode: 46.5 Gbp/s with
+    // chunks of 3814 bases, every one of them walked as an item without a plan); 30 warm-up bases per 768 cost the plain
+    // walk 4 %.
+    (void)n_seqs;
+    uint64_t chunk = std::min<uint64_t>(768, std::max<uint64_t>(256, total >> 17));
     static const int env_chunk = std::getenv("KBO_WALK_CHUNK") ? std::atoi(std::getenv("KBO_WALK_CHUNK")) : 0; // experiments
     if (env_chunk > 0) chunk = (uint64_t)env_chunk;
     return std::max<uint64_t>(chunk, 4ull * k);
