@@ -278,7 +278,8 @@ size_t kbo_work_bytes(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, u
  * get one work item per sequence; when max_seq_len is unknown or long, the item list is built on the
  * device from the offsets: sequences are cut into chunks that restart the walk k-1 bases upstream
  * (the MS of a base depends only on the k bases ending at it), so a few long sequences still fill the
- * device.  Same results either way. */
+ * device.  Same results either way - provided max_seq_len, when given, is not SMALLER than the longest sequence: the
+ * kernels size their work items (16-bit lengths) and LDS stretches from it; pass 0 when in doubt. */
 int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets,
                      size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint8_t *d_ms_out,
                      uint32_t *d_lo_out, uint32_t *d_hi_out, void *d_work, size_t work_bytes, void *stream);
