@@ -545,7 +545,10 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
     uint32_t qcur = 0, ocur = 0;
     // output window: the unit's MS bytes wait in registers (32 bytes from output index wbase on, wfirst .. wend - 1 of them
     // the unit's) and go out together when the unit ends: a word stored on its own every fourth base is a line fill of its own
-    uint32_t ow[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // (the window's words live in LDS, word w of lane L at [w * 64 + L] of the wave's 2 KB: one ds_write when a word is
+    // complete instead of a compare-and-select per window register)
+    __shared__ uint32_t ow_lds[4 * 512];
+    uint32_t *ow = ow_lds + (threadIdx.x >> 6) * 512u + lane;
     uint32_t wbase = 0, wfirst = 0, wend = 0;
     uint4 nu0 = make_uint4(0, 0, 0, 0), nq0 = make_uint4(0, 0, 0, 0), nq1 = make_uint4(0, 0, 0, 0);
     uint4 nu1 = make_uint4(0, 0, 0, 0);
@@ -583,13 +586,15 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
 #pragma unroll
                         for (uint32_t w = 0; w < 8; w++) {
                             const uint32_t lo = max(wfirst, 4u * w), hi = min(wend, 4u * w + 4u); // bytes [lo, hi) of word w
-                            if (lo == 4u * w && hi == 4u * w + 4u) st4u(o + 4u * w, ow[w]);
-                            else {
+                            if (lo < hi) {
+                                const uint32_t v = ow[w * 64u];
+                                if (lo == 4u * w && hi == 4u * w + 4u) st4u(o + 4u * w, v);
+                                else {
 #pragma unroll
-                                for (uint32_t t = 0; t < 4; t++)
-                                    if (4u * w + t >= lo && 4u * w + t < hi) o[4u * w + t] = (uint8_t)(ow[w] >> (8u * t));
+                                    for (uint32_t t = 0; t < 4; t++)
+                                        if (4u * w + t >= lo && 4u * w + t < hi) o[4u * w + t] = (uint8_t)(v >> (8u * t));
+                                }
                             }
-                            ow[w] = 0;
                         }
                         wbase += 32u;
                         wfirst = 0;
@@ -781,9 +786,7 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
                         ocur |= d << ((e & 3u) * 8u);
                         wend = wi + 1u;
                         if (word_done) {
-                            const uint32_t ws = wi >> 2;
-#pragma unroll
-                            for (uint32_t w = 0; w < 8; w++) ow[w] = ws == w ? ocur : ow[w];
+                            ow[(wi >> 2) * 64u] = ocur;
                             ocur = 0;
                         }
                         flags |= (wi == 31u && !(fin || conv)) ? G_FLUSH : 0u; // (long units: the window goes out in between)
@@ -880,7 +883,10 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
     uint32_t qcur = 0, ocur = 0;
     // output window: the unit's MS bytes wait in registers (32 bytes from output index wbase on, wfirst .. wend - 1 of them
     // the unit's) and go out together when the unit ends: a word stored on its own every fourth base is a line fill of its own
-    uint32_t ow[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // (the window's words live in LDS, word w of lane L at [w * 64 + L] of the wave's 2 KB: one ds_write when a word is
+    // complete instead of a compare-and-select per window register)
+    __shared__ uint32_t ow_lds[4 * 512];
+    uint32_t *ow = ow_lds + (threadIdx.x >> 6) * 512u + lane;
     uint32_t wbase = 0, wfirst = 0, wend = 0;
     uint4 nu0 = make_uint4(0, 0, 0, 0), nq0 = make_uint4(0, 0, 0, 0), nq1 = make_uint4(0, 0, 0, 0);
     uint4 nu1 = make_uint4(0, 0, 0, 0);
@@ -919,13 +925,15 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
 #pragma unroll
                         for (uint32_t w = 0; w < 8; w++) {
                             const uint32_t lo = max(wfirst, 4u * w), hi = min(wend, 4u * w + 4u); // bytes [lo, hi) of word w
-                            if (lo == 4u * w && hi == 4u * w + 4u) st4u(o + 4u * w, ow[w]);
-                            else {
+                            if (lo < hi) {
+                                const uint32_t v = ow[w * 64u];
+                                if (lo == 4u * w && hi == 4u * w + 4u) st4u(o + 4u * w, v);
+                                else {
 #pragma unroll
-                                for (uint32_t t = 0; t < 4; t++)
-                                    if (4u * w + t >= lo && 4u * w + t < hi) o[4u * w + t] = (uint8_t)(ow[w] >> (8u * t));
+                                    for (uint32_t t = 0; t < 4; t++)
+                                        if (4u * w + t >= lo && 4u * w + t < hi) o[4u * w + t] = (uint8_t)(v >> (8u * t));
+                                }
                             }
-                            ow[w] = 0;
                         }
                         wbase += 32u;
                         wfirst = 0;
@@ -1166,9 +1174,7 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                         ocur |= d << ((e & 3u) * 8u);
                         wend = wi + 1u;
                         if (word_done) {
-                            const uint32_t ws = wi >> 2;
-#pragma unroll
-                            for (uint32_t w = 0; w < 8; w++) ow[w] = ws == w ? ocur : ow[w];
+                            ow[(wi >> 2) * 64u] = ocur;
                             ocur = 0;
                         }
                         flags |= (wi == 31u && !(fin || conv)) ? G_FLUSH : 0u; // (long units: the window goes out in between)
