@@ -9,11 +9,29 @@
 #include "capi_internal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstdio>
+#include <chrono>
+#include <atomic>
+#include <mutex>
 #include <thread>
 
 using namespace kbo_host;
 
 namespace {
+
+// KBO_TIMING=1 in the environment: phases of kbo_call_batch on stderr
+struct CallClock {
+    bool on = std::getenv("KBO_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[kbo timing] call: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 
 struct SiteRec {
     uint32_t seq, i, j, lo;
@@ -30,6 +48,30 @@ void ms_only(kbo_index *idx, const std::vector<std::vector<uint8_t>> &seqs, std:
     for (size_t s = 0; s < seqs.size(); s++) std::memcpy(concat.data() + off[s], seqs[s].data(), seqs[s].size());
     std::vector<uint8_t> d(off.back() + 16);
     ms_batch_impl(idx, concat.data(), off.data(), seqs.size(), d.data(), nullptr, nullptr);
+    for (size_t s = 0; s < seqs.size(); s++) {
+        out[s].resize(seqs[s].size());
+        for (size_t i = 0; i < seqs[s].size(); i++) out[s][i] = kbo::MsVal{d[off[s] + i], 0u, 0u};
+    }
+}
+
+// the same for the few k-mers of one sequence against that sequence's own index, from a pool thread of kbo_call_batch: the
+// calling thread's own buffers and stream, no slabs, no pinned staging, no shared worker team (a millisecond of fixed
+// costs per call that all threads would queue for)
+void ms_only_small(kbo_index *idx, const std::vector<std::vector<uint8_t>> &seqs, std::vector<std::vector<kbo::MsVal>> &out)
+{
+    out.assign(seqs.size(), {});
+    if (seqs.empty()) return;
+    static thread_local BatchOnDevice B;
+    static thread_local std::vector<uint64_t> off;
+    static thread_local std::vector<uint8_t> concat, d;
+    off.assign(seqs.size() + 1, 0);
+    for (size_t s = 0; s < seqs.size(); s++) off[s + 1] = off[s] + seqs[s].size();
+    concat.resize(off.back());
+    for (size_t s = 0; s < seqs.size(); s++) std::memcpy(concat.data() + off[s], seqs[s].data(), seqs[s].size());
+    d.resize(off.back() + 16);
+    hipStream_t stream = nullptr; // (the thread's default stream: every call below is synchronous for this thread anyway)
+    run_walk_host(idx, concat.data(), off.data(), seqs.size(), false, B, stream);
+    HIP_OK(hipMemcpy(d.data(), B.ms.p, off.back(), hipMemcpyDeviceToHost));
     for (size_t s = 0; s < seqs.size(); s++) {
         out[s].resize(seqs[s].size());
         for (size_t i = 0; i < seqs[s].size(); i++) out[s][i] = kbo::MsVal{d[off[s] + i], 0u, 0u};
@@ -120,8 +162,10 @@ extern "C" int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, con
                     "assert!(sbwt_ref.k() == sbwt_query.k()) (lib.rs:559)");
         const uint32_t k = query_idx->host.k;
         const size_t d = random_match_threshold(k, query_idx->host.n_kmers, 4, o.max_error_prob); // variant_calling.rs:260
+        CallClock clk;
         // ---- first pass, on the device
         const std::vector<SiteRec> recs = find_sites(query_idx, concat, offsets, n_seqs, (uint32_t)d);
+        clk.lap("first pass (sites)");
         // ---- k-mers of every site (host: access_kmer walks the index backwards, k steps per site)
         const size_t n_sites = recs.size();
         std::vector<kbo::CallSite> sites(n_sites);
@@ -157,32 +201,60 @@ extern "C" int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, con
             for (auto &x : th) x.join();
             if (err) std::rethrow_exception(err);
         }
+        clk.lap("k-mers of the sites");
         // ---- second pass: all query-side k-mers against the index, one batch (variant_calling.rs:279)
         std::vector<std::vector<kbo::MsVal>> ms_vs_ref;
         ms_only(query_idx, query_kmers, ms_vs_ref);
+        clk.lap("query k-mers vs the index");
         // ---- ... and per sequence its reference-side k-mers against its own index (lib.rs:553, variant_calling.rs:280)
+        // (host threads: every sequence builds its own small index, uploads it, walks a handful of k-mers and frees it
+        // again - a millisecond of mostly waiting per sequence, so the sequences are spread over a pool)
         std::vector<std::vector<kbo::Variant>> calls(n_seqs);
-        size_t n_var = 0;
-        for (size_t s = 0; s < n_seqs; s++) {
-            const size_t a = first[s], b = first[s + 1];
-            if (a == b) continue;
-            kbo_index ref_idx;
-            ref_idx.transient = true; // no path cover for an index that serves one small batch
-            kbo::BuildParams p;
-            p.k = o.sbwt_build_opts.k;
-            p.add_revcomp = o.sbwt_build_opts.add_revcomp != 0;
-            p.num_threads = 1;
-            const uint8_t *seqs1[1] = {concat + offsets[s]};
-            const size_t lens1[1] = {(size_t)(offsets[s + 1] - offsets[s])};
-            kbo::build_host_index(seqs1, lens1, 1, p, ref_idx.host);
-            std::vector<std::vector<uint8_t>> rk(ref_kmers.begin() + a, ref_kmers.begin() + b);
-            std::vector<std::vector<kbo::MsVal>> ms_vs_query;
-            ms_only(&ref_idx, rk, ms_vs_query);
-            std::vector<kbo::CallSite> mine(sites.begin() + a, sites.begin() + b);
-            calls[s] = kbo::resolve_call_sites(mine, query_kmers.data() + a, ref_kmers.data() + a, ms_vs_ref.data() + a,
-                                               ms_vs_query.data(), d);
-            n_var += calls[s].size();
+        {
+            std::atomic<size_t> next{0};
+            std::exception_ptr err;
+            std::mutex mu;
+            const int dev = current_device();
+            auto work = [&] {
+                try {
+                    HIP_OK(hipSetDevice(dev));
+                    for (;;) {
+                        const size_t s = next.fetch_add(1);
+                        if (s >= n_seqs) break;
+                        const size_t a = first[s], b = first[s + 1];
+                        if (a == b) continue;
+                        kbo_index ref_idx;
+                        ref_idx.transient = true; // no path cover for an index that serves one small batch
+                        kbo::BuildParams p;
+                        p.k = o.sbwt_build_opts.k;
+                        p.add_revcomp = o.sbwt_build_opts.add_revcomp != 0;
+                        p.num_threads = 1;
+                        const uint8_t *seqs1[1] = {concat + offsets[s]};
+                        const size_t lens1[1] = {(size_t)(offsets[s + 1] - offsets[s])};
+                        kbo::build_host_index(seqs1, lens1, 1, p, ref_idx.host);
+                        std::vector<std::vector<uint8_t>> rk(ref_kmers.begin() + a, ref_kmers.begin() + b);
+                        std::vector<std::vector<kbo::MsVal>> ms_vs_query;
+                        ms_only_small(&ref_idx, rk, ms_vs_query);
+                        std::vector<kbo::CallSite> mine(sites.begin() + a, sites.begin() + b);
+                        calls[s] = kbo::resolve_call_sites(mine, query_kmers.data() + a, ref_kmers.data() + a, ms_vs_ref.data() + a,
+                                                           ms_vs_query.data(), d);
+                    }
+                } catch (...) {
+                    std::lock_guard<std::mutex> g(mu);
+                    if (!err) err = std::current_exception();
+                    next.store(n_seqs); // (the others stop at their next sequence)
+                }
+            };
+            const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)std::thread::hardware_concurrency(), n_seqs}));
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+            work();
+            for (auto &x : th) x.join();
+            if (err) std::rethrow_exception(err);
         }
+        clk.lap("per-sequence indexes + walks");
+        size_t n_var = 0;
+        for (const auto &c : calls) n_var += c.size();
         // ---- one allocation: records, then the characters
         size_t chars = 0;
         for (const auto &c : calls)

@@ -17,6 +17,22 @@
 namespace kbo_host {
 
 struct DevCopy {
+    // (an index that serves one small batch borrows its arena from a buffer the calling thread keeps: kbo::call builds
+    // one such index per sequence, and a hipMalloc / hipFree pair per sequence serialises every thread of the process)
+    bool arena_borrowed = false;
+    ~DevCopy()
+    {
+        if (arena_borrowed) {
+            arena.p = nullptr;
+            arena.cap = 0;
+            transient_arena_in_use() = false;
+        }
+    }
+    static bool &transient_arena_in_use()
+    {
+        static thread_local bool in_use = false;
+        return in_use;
+    }
     DevBuf arena; // rank blocks of A,C,G,T | null block | contraction entries (32-bit build) | two-base blocks
     DevBuf ent;   // contraction entries as their own allocation (big build)
     uint64_t n_blocks = 0;

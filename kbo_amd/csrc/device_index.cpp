@@ -50,7 +50,15 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
             const size_t pair_bytes = dc->big ? 0 : lay.pair.size() * sizeof(uint32_t);
             const size_t base_bytes = ((dc->big ? rank_bytes : rank_bytes + ent_bytes) + 15) / 16 * 16;
             const size_t arena_bytes = base_bytes + pair_bytes;
-            dc->arena.alloc(arena_bytes);
+            static thread_local DevBuf t_arena; // (see DevCopy::arena_borrowed)
+            if (idx->transient && !dc->big && !DevCopy::transient_arena_in_use()) {
+                t_arena.ensure(arena_bytes);
+                dc->arena.p = t_arena.p;
+                dc->arena_borrowed = true;
+                DevCopy::transient_arena_in_use() = true;
+            } else {
+                dc->arena.alloc(arena_bytes);
+            }
             HIP_OK(hipMemset(dc->arena.p, 0, arena_bytes));
             for (int c = 0; c < 4; c++)
                 HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + per * c, lay.rank[c].data(), per,
