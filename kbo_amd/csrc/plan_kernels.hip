@@ -68,7 +68,7 @@ __device__ __forceinline__ void st_range(uint8_t *o, const uint4 &v, uint32_t lo
 //     those bases and ended on the diagonal's node, so the guided walk may start at the first mismatch.
 constexpr int kPlanStep = 10;           // 16-byte blocks per compare step (reads of up to 160 bases: one step)
 constexpr uint32_t kPlanLdsSlack = 48;  // bytes of a wave's LDS behind the staged stretch (block reads run past an item)
-__global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds)
+__global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds, uint32_t stage_ok)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t plan_lds[];
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
     uint32_t base16 = 0, wave_hi = 0, out_lo = 0, soff = 0;
     {
         const uint64_t have = __ballot(have_item); // (item lanes are the wave's first lanes)
-        if (wave_lds != 0 && have != 0) {
+        if (stage_ok != 0 && have != 0) {
             const uint32_t last = (uint32_t)__popcll(have) - 1u;
             const uint32_t nxt_start = __shfl_down(start, 1), nxt_warm = __shfl_down(warm, 1);
             const bool bad = (lane < last && (nxt_start < start || nxt_start + nxt_warm != start + len)) || olen != len;
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
             soff = start - base16;
         }
     }
+    const bool xpose = !staged && wave_lds >= 64u * 16u * (uint32_t)kPlanStep; // unstaged: outputs transposed through LDS
     if (staged) {
         for (uint32_t c = lane * 16u; c < wave_hi - base16; c += 1024u) // (reads <= 15 bytes past the last item)
             *reinterpret_cast<uint4 *>(sm + c) = ld16u(qb, base16 + c);
@@ -271,6 +272,8 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                         uint8_t *o = sm + soff + base;
                         if (lo == 0 && nb == 16u) __builtin_memcpy(o, &o4, 16);
                         else st_range(o, o4, lo, nb);
+                    } else if (xpose) { // (goes out below, with the other lanes' blocks)
+                        *reinterpret_cast<uint4 *>(sm + (lane * (uint32_t)kPlanStep + (uint32_t)g) * 16u) = o4;
                     } else {
                         uint8_t *o = a.d_out + (start + base);
                         if (lo == 0 && nb == 16u) __builtin_memcpy(o, &o4, 16); // (plain store: the blocks of a step merge in L2)
@@ -278,6 +281,31 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                     }
                 }
             }
+        }
+        if (xpose) {
+            // the step's blocks of all lanes, lane-major in LDS, go out in that order: ten consecutive lanes write one
+            // item's 160 bytes (whole lines) - a lane storing its own ten blocks one by one puts 64 partial lines into
+            // every store instruction (unstaged plan kernel on 830-base chunks: 0.35 ms, 0.14 of it these stores)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t actw = act ? 1u : 0u;
+#pragma unroll 1
+            for (uint32_t i = 0; i < (uint32_t)kPlanStep; i++) {
+                const uint32_t t = i * 64u + lane, c = t / (uint32_t)kPlanStep, g = t - c * (uint32_t)kPlanStep;
+                const uint32_t c_start = __shfl(start, (int)c), c_len = __shfl(len, (int)c), c_olen = __shfl(olen, (int)c),
+                               c_warm = __shfl(warm, (int)c), c_act = __shfl(actw, (int)c);
+                const uint32_t base = base0 + 16u * g;
+                if (c_act && base < c_len) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(sm + t * 16u);
+                    const uint32_t nb = c_olen > base ? min(16u, c_olen - base) : 0u;
+                    const uint32_t lo = min(c_warm > base ? min(c_warm - base, 16u) : 0u, nb);
+                    uint8_t *o = a.d_out + (c_start + base);
+                    if (lo == 0 && nb == 16u) __builtin_memcpy(o, &v, 16);
+                    else st_range(o, v, lo, nb);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
     if (staged) { // the wave's output bytes [out_lo, wave_hi), in blocks aligned like the staged copy
@@ -1253,15 +1281,20 @@ hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
     const uint32_t nb = (a.n_items + 255u) / 256u;
     // LDS for the staged stretch of every wave: 64 items of at most max_item_len bases (not known, or too long for
     // four waves to share 64 KiB: no staging)
-    uint32_t wave_lds = 0;
+    // items that cannot be staged: 10 KB per wave for the transposed write-out of a step's predicted values
+    uint32_t wave_lds = 64u * 16u * (uint32_t)kPlanStep, stage_ok = 0;
     static const int env_stage = std::getenv("KBO_PLAN_STAGE") ? std::atoi(std::getenv("KBO_PLAN_STAGE")) : -1; // experiments
     if (a.max_item_len != 0 && (env_stage >= 0 ? env_stage != 0 : g_plan_stage.load() != 0)) {
         const uint64_t need = (64ull * a.max_item_len + 16u + kPlanLdsSlack + 15u) / 16u * 16u;
-        if (need <= 16384u) wave_lds = (uint32_t)need;
+        if (need <= 16384u) {
+            wave_lds = std::max<uint32_t>(wave_lds, (uint32_t)need);
+            stage_ok = 1;
+        }
     }
+    if (env_stage == 0) wave_lds = 0; // (experiments: neither staging nor the transposed write-out)
     static const int env_blk = std::getenv("KBO_PLAN_BLOCK") ? std::atoi(std::getenv("KBO_PLAN_BLOCK")) : 0; // experiments
     const uint32_t bt = env_blk == 64 || env_blk == 128 ? (uint32_t)env_blk : 256u;
-    hipLaunchKernelGGL(plan_kernel, dim3((a.n_items + bt - 1u) / bt), dim3(bt), (bt / 64u) * wave_lds, stream, a, wave_lds);
+    hipLaunchKernelGGL(plan_kernel, dim3((a.n_items + bt - 1u) / bt), dim3(bt), (bt / 64u) * wave_lds, stream, a, wave_lds, stage_ok);
     hipLaunchKernelGGL(plan_count_kernel, dim3(nb), dim3(256), 0, stream, a);
     const hipError_t es = launch_scan(a.ucount, 2u * a.n_items + 1u, a.usums, stream);
     if (es != hipSuccess) return es;
