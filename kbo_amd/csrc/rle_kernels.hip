@@ -26,9 +26,8 @@ __device__ __forceinline__ void rle_close(RleState &st, uint32_t *__restrict__ o
     if (EMIT) {
         const uint32_t slot = first + st.n_out;
         if (slot < capacity) {
-            uint32_t *o = out + (uint64_t)slot * 7u;
-            o[0] = st.start; o[1] = st.end; o[2] = st.matches; o[3] = st.mismatches;
-            o[4] = st.jumps; o[5] = st.gap_bases; o[6] = st.gap_opens;
+            const uint32_t rec[7] = {st.start, st.end, st.matches, st.mismatches, st.jumps, st.gap_bases, st.gap_opens};
+            __builtin_memcpy(out + (uint64_t)slot * 7u, rec, 28); // (16 + 12 bytes: two stores instead of seven)
         }
     }
     st.n_out++;
@@ -142,8 +141,9 @@ __global__ __launch_bounds__(64) void rle0_lds_kernel(const uint8_t *__restrict_
         if (EMIT) {
             const uint32_t slot = first + n_out;
             if (slot < capacity) {
-                uint32_t *o = out + (uint64_t)slot * 7u;
-                o[0] = start; o[1] = end; o[2] = matches; o[3] = mismatches; o[4] = jumps; o[5] = gap_bases; o[6] = 0u;
+                // (two stores, 16 + 12 bytes: seven dword stores are seven partial-line requests per record)
+                const uint32_t rec[7] = {start, end, matches, mismatches, jumps, gap_bases, 0u};
+                __builtin_memcpy(out + (uint64_t)slot * 7u, rec, 28);
             }
         }
         n_out++;
