@@ -216,6 +216,7 @@ __global__ __launch_bounds__(64) void derand_translate_lds_kernel(
             gt_cur = x_cur > T;
             in_cur = (uint32_t)(x_cur - 1) < Tm1;
             a_below = at(b + len - 3);
+#pragma unroll 4
             for (uint32_t p = len - 2; p >= 2; p--) { // middle: 2 <= p <= len-2
                 x_prev = step(a_below, x_cur);
                 a_below = at(b + p - 2); // p >= 2
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(64) void derand_translate_piece_lds_kernel(
     __syncthreads();
     if (active) {
         int a = c1 - 1u > c0 ? (int)row[c1 - 2u] : a_under; // noisy[p - 1] for p = c1 - 1, fetched one step ahead
+#pragma unroll 4
         for (uint32_t p = c1; p-- > c0;) { // (a variant without position tests for interior pieces was slower:
             const int a_here = a;         //  its carried flags cost more mask bookkeeping than the tests)
             a = p > c0 + 1u ? (int)row[p - 2u] : a_under; // for the next step (unused after the last one)
