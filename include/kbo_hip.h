@@ -344,6 +344,11 @@ int kbo_set_plan_tuning(int gap, int chunk, int bail_x16);
  * exactly one text position; text[p] ('A','C','G','T') labels the edge node_at[p-1] -> node_at[p] of the index's de
  * Bruijn graph, 0 where a path starts.  All three arrays have n_sets entries. */
 int kbo_index_path_cover(const kbo_index_t *idx, uint8_t *text, uint32_t *pos, uint32_t *node_at);
+/* The recovery lines the guided walk reads large indexes through (host computation, for inspection and tests): line b
+ * (128 bytes) covers rows [64 b, 64 b + 64): four 16-byte rank blocks { C[c] + rank_c(64 b), row bits 0..31, row bits
+ * 32..63, 0 } for c = A, C, G, T, then the 64 LCS bytes of those rows (0 beyond the last row).  n_sets / 64 + 2 lines and
+ * one all-zero line; *n_bytes receives the size, lines == NULL only asks for it. */
+int kbo_index_recovery_lines(const kbo_index_t *idx, uint8_t *lines, size_t *n_bytes);
 /* bytes of path cover a device copy of this index carries (0 = none) */
 uint64_t kbo_index_device_plan_bytes(const kbo_index_t *idx);
 /* Experiments on the plain walk kernel: only the first lane_limit lanes of every wave take reads

@@ -77,7 +77,7 @@ SYMBOLS = [
     "kbo_ms_batch", "kbo_matches_batch", "kbo_map_batch", "kbo_find_batch", "kbo_work_bytes",
     "kbo_ms_batch_dev", "kbo_derand_translate_dev", "kbo_walk_geometry",
     "kbo_set_walk_waves_per_cu", "kbo_set_walk_threads", "kbo_set_walk_rare", "kbo_set_slab_bytes", "kbo_set_force_big_layout", "kbo_set_devices", "kbo_set_host_threads", "kbo_release_scratch", "kbo_set_pair_steps", "kbo_run_lengths_gapped_batch", "kbo_find_batch_into", "kbo_derand_work_bytes", "kbo_run_lengths_work_bytes", "kbo_run_lengths_dev", "kbo_index_device_pair_bytes",
-    "kbo_set_plan", "kbo_index_device_plan_bytes", "kbo_set_plan_tuning", "kbo_index_path_cover", "kbo_call_batch", "kbo_call_sites_dev", "kbo_call_walk_dev", "kbo_set_walk_experiment", "kbo_set_guided_walk", "kbo_index_save_sbwt", "kbo_index_load_sbwt",
+    "kbo_set_plan", "kbo_index_device_plan_bytes", "kbo_set_plan_tuning", "kbo_index_path_cover", "kbo_index_recovery_lines", "kbo_call_batch", "kbo_call_sites_dev", "kbo_call_walk_dev", "kbo_set_walk_experiment", "kbo_set_guided_walk", "kbo_index_save_sbwt", "kbo_index_load_sbwt",
 ]
 
 _lib = None
@@ -169,6 +169,7 @@ def lib():
     L.kbo_set_plan_tuning.argtypes = [C.c_int, C.c_int, C.c_int]
     L.kbo_set_walk_experiment.argtypes = [C.c_int, C.c_int]
     L.kbo_index_path_cover.argtypes = [vp, vp, vp, vp]
+    L.kbo_index_recovery_lines.argtypes = [vp, vp, C.POINTER(C.c_size_t)]
     L.kbo_call_batch.argtypes = [vp, vp, vp, sz, C.POINTER(CallOpts), C.POINTER(C.POINTER(Variant)), vp]
     L.kbo_call_sites_dev.argtypes = [vp, vp, vp, vp, sz, u64, sz, sz, vp, sz, vp, vp]
     L.kbo_call_walk_dev.argtypes = [vp, vp, vp, sz, u64, sz, sz, vp, vp, sz, vp, vp, sz, vp]

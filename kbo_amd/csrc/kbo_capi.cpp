@@ -996,6 +996,21 @@ int kbo_set_plan(int enabled, int seed_depth, int seed_cap)
     return KBO_OK;
 }
 
+int kbo_index_recovery_lines(const kbo_index_t *idx, uint8_t *lines, size_t *n_bytes)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && n_bytes, KBO_E_BAD_ARG, "null argument");
+        const size_t need = (idx->host.n_sets / kbo::kFatRows + 3) * 128;
+        if (lines) {
+            KBO_REQUIRE(*n_bytes >= need, KBO_E_BAD_ARG, "buffer smaller than the lines");
+            std::vector<uint8_t> v;
+            kbo::make_recovery_lines(idx->host, v);
+            std::memcpy(lines, v.data(), v.size());
+        }
+        *n_bytes = need;
+    });
+}
+
 int kbo_index_path_cover(const kbo_index_t *idx, uint8_t *text, uint32_t *pos, uint32_t *node_at)
 {
     return guarded([&] {

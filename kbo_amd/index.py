@@ -73,6 +73,14 @@ class SbwtIndexVariant:
         check(lib().kbo_index_path_cover(self._h, text.ctypes.data, pos.ctypes.data, node.ctypes.data))
         return text, pos, node
 
+    def recovery_lines(self):
+        """uint8[n_lines, 128] - the recovery lines of the guided walk (kbo_hip.h: kbo_index_recovery_lines)."""
+        nb = C.c_size_t(0)
+        check(lib().kbo_index_recovery_lines(self._h, None, C.byref(nb)))
+        out = np.zeros(nb.value, dtype=np.uint8)
+        check(lib().kbo_index_recovery_lines(self._h, out.ctypes.data, C.byref(nb)))
+        return out.reshape(-1, 128)
+
     @classmethod
     def from_parts(cls, k, n_sets, n_kmers, rows, Carr, lcs):
         rows = [np.ascontiguousarray(r, dtype=np.uint64) for r in rows]

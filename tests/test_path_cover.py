@@ -51,3 +51,33 @@ def test_path_cover_single_contig_is_one_path():
     text, pos, node = sbwt.path_cover()
     assert int((text == 0).sum()) <= 3  # root + dummy chain + genome: one path, give or take a repeated k-mer
     assert _check_cover(sbwt) >= sbwt.n_sets() - 3
+
+
+@pytest.mark.parametrize("k,add_revcomp", [(5, False), (31, False), (31, True), (200, False)])
+def test_recovery_lines_hold_rank_blocks_and_lcs(k, add_revcomp):
+    """kbo_index_recovery_lines: every 128-byte line = four rank blocks {C[c] + rank_c(64 b), 64 row bits} + 64 LCS bytes,
+    checked against the index's own parts; rows beyond the last one carry no bits and LCS 0; the last line is all zero."""
+    rng = np.random.default_rng(11 + k)
+    seqs = [bytes(rng.choice(list(b"ACGT"), 5000).astype(np.uint8)), b"ACGT" * 300 + b"N" + bytes(rng.choice(list(b"ACGT"), 700).astype(np.uint8))]
+    sbwt, _ = kbo_amd.build(seqs, kbo_amd.BuildOpts(k=k, add_revcomp=add_revcomp, num_threads=2))
+    n = sbwt.n_sets()
+    rows, Carr, lcs = sbwt.export_parts()
+    lines = sbwt.recovery_lines()
+    assert lines.shape == (n // 64 + 3, 128)
+    assert not lines[-1].any()
+    bits = [np.unpackbits(np.asarray(r, dtype=np.uint64).view(np.uint8), bitorder="little")[:n] for r in rows]
+    cum = [np.concatenate([[0], np.cumsum(b)]) for b in bits]
+    for b in range(n // 64 + 2):
+        lo, hi = 64 * b, min(n, 64 * b + 64)
+        for c in range(4):
+            blk = lines[b, 16 * c:16 * c + 16].view(np.uint32)
+            assert blk[0] == int(Carr[c]) + int(cum[c][min(lo, n)])
+            want = np.zeros(64, dtype=np.uint8)
+            if lo < n:
+                want[:hi - lo] = bits[c][lo:hi]
+            assert np.array_equal(np.unpackbits(blk[1:3].view(np.uint8), bitorder="little"), want)
+            assert blk[3] == 0
+        want_lcs = np.zeros(64, dtype=np.uint8)
+        if lo < n:
+            want_lcs[:hi - lo] = lcs[lo:hi]
+        assert np.array_equal(lines[b, 64:], want_lcs)
