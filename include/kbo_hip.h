@@ -331,8 +331,8 @@ int kbo_set_pair_steps(uint64_t min_rows, int min_depth);
 /* Plan-guided walk for MS-only batches (kbo_amd/csrc/plan_kernels.hip): device copies made while it is enabled
  * (default) carry a path cover of the index's de Bruijn graph (9 B per row) and kbo_ms_batch[_dev] / kbo_matches_batch /
  * kbo_map_batch / kbo_find_batch skip the stretches of every read that match it; results are identical either way.
- * enabled < 0 keeps the setting; seed_depth (default 14) / seed_cap (default 40, at most 48) tune the diagonal search,
- * <= 0 keeps them. */
+ * enabled < 0 keeps the setting; seed_depth (> 0: fixed; < 0: automatic = log4(rows) + 3, the default; 0 keeps) and
+ * seed_cap (default 40, at most 48; <= 0 keeps) tune the diagonal search. */
 int kbo_set_plan(int enabled, int seed_depth, int seed_cap);
 /* More knobs of the plan-guided walk (<= 0 keeps a value): mismatches closer than `gap` bases (default 20, >= 2) are
  * walked by one unit; reads without a diagonal are walked in chunks of `chunk` bases (default 32); a launch with more

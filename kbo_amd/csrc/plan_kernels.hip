@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdlib>
 
 namespace kbo {
@@ -1249,14 +1250,14 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
 
 } // namespace
 
-std::atomic<int> g_plan_dmin{14}, g_plan_cap{40}, g_plan_gap{20}, g_plan_chunk{32};
+std::atomic<int> g_plan_dmin{0} /* 0: by index size */, g_plan_cap{40}, g_plan_gap{20}, g_plan_chunk{32};
 std::atomic<int> g_plan_stage{1};     // plan_kernel stages queries and predictions through LDS (0: experiments)
 std::atomic<int> g_plan_bail_x16{50}; // give the plan up when there are more than this many units per 16 items
 void set_plan_stage(int on) { g_plan_stage = on != 0; }
 void set_plan_bail(int units_per_16_items) { g_plan_bail_x16 = std::max(0, units_per_16_items); }
 void set_plan_params(int dmin, int cap, int gap, int chunk)
 {
-    if (dmin > 0) g_plan_dmin = dmin;
+    if (dmin != 0) g_plan_dmin = std::max(0, dmin); // (< 0: back to the automatic choice)
     if (cap > 0) g_plan_cap = std::min(48, cap); // the text is padded by kPlanPad >= cap bytes in front
     if (gap > 0) g_plan_gap = std::max(2, gap);
     if (chunk > 0) g_plan_chunk = std::max(16, chunk);
@@ -1266,7 +1267,11 @@ void set_plan_params(int dmin, int cap, int gap, int chunk)
 hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
 {
     if (a.n_items == 0) return hipSuccess;
-    a.plan_dmin = (uint32_t)g_plan_dmin.load();
+    // seed depth: a single-row interval is trusted as the item's diagonal from log4(rows) + 3 bases on (measured: 14 on the
+    // 5 Mbp index, 16 on the 100 Mbp one - 12 / 13 / 14 / 16 bases: 1.19 / 1.16 / 1.14 / 1.18 ms, 13 / 14 / 15 / 16 / 18:
+    // 4.10 / 3.80 / 3.58 / 3.56 / 3.69 ms; shallower seeds put items on wrong diagonals, deeper ones cost extensions)
+    const int dmin_set = g_plan_dmin.load();
+    a.plan_dmin = dmin_set > 0 ? (uint32_t)dmin_set : (uint32_t)(std::lround(std::log2((double)std::max<uint32_t>(a.ix.n, 4u)) / 2.0) + 3);
     a.plan_cap = (uint32_t)g_plan_cap.load();
     a.plan_gap = (uint32_t)g_plan_gap.load();
     if (a.call_sites) a.plan_gap = std::max(a.plan_gap, a.call_thr + 1u); // (a unit resolves its breakpoints before the next one starts)
