@@ -98,7 +98,12 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
                 }
                 // seed table: the interval of every string of D bases, so that a seed starts D bases deep.  D = 10 for
                 // indexes that can use it (8 MiB), 8 for small ones, none below k = 8.
+                // (deeper tables for large indexes - 12 bases / 128 MiB from 32 Mi rows, 13 / 512 MiB from 512 Mi rows: the
+                // extensions they save are line fills there; 100 Mbp index, A1 per 3 M reads: 3.60 / 3.52 / 3.46 ms with 10 /
+                // 12 / 13 bases.  On a 5 Mbp index 11 - 13 bases change nothing.)
                 uint32_t D = idx->host.k >= 10 && idx->host.n_sets >= (1u << 20) ? 10u : (idx->host.k >= 8 ? 8u : 0u);
+                if (D == 10 && idx->host.k >= 13 && idx->host.n_sets >= (512u << 20)) D = 13;
+                else if (D == 10 && idx->host.k >= 12 && idx->host.n_sets >= (32u << 20)) D = 12;
                 if (const char *e = std::getenv("KBO_PLAN_SEED_D")) // experiments
                     D = std::min<uint32_t>({(uint32_t)std::max(0, std::atoi(e)), 13u, idx->host.k});
                 if (D) {
