@@ -332,10 +332,10 @@ int kbo_set_pair_steps(uint64_t min_rows, int min_depth);
  * (default) carry a path cover of the index's de Bruijn graph (9 B per row) and kbo_ms_batch[_dev] / kbo_matches_batch /
  * kbo_map_batch / kbo_find_batch skip the stretches of every read that match it; results are identical either way.
  * enabled < 0 keeps the setting; seed_depth (> 0: fixed; < 0: automatic = log4(rows) + 3, the default; 0 keeps) and
- * seed_cap (default 40, at most 48; <= 0 keeps) tune the diagonal search. */
+ * seed_cap (default 64 = the most; <= 0 keeps) tune the diagonal search. */
 int kbo_set_plan(int enabled, int seed_depth, int seed_cap);
-/* More knobs of the plan-guided walk (<= 0 keeps a value): mismatches closer than `gap` bases (default 20, >= 2) are
- * walked by one unit; reads without a diagonal are walked in chunks of `chunk` bases (default 32); a launch with more
+/* More knobs of the plan-guided walk (0 keeps a value): mismatches closer than `gap` bases (>= 2; < 0: automatic =
+ * log4(rows) + 9, the default: 20 on a 5 Mbp index, 22 on 100 Mbp) are walked by one unit; reads without a diagonal are walked in chunks of `chunk` bases (default 32); a launch with more
  * than bail_x16 / 16 units per read (default 50 / 16: the break-even is near 4 % substitutions) gives the plan up and takes the plain walk (and the following 16
  * launches do not plan at all).  bail_x16 = 0 forces that path (tests); bits 16 and up of bail_x16, when set, divide the
  * capacity of the unit array (tests: reads whose units do not fit take the plain walk). */

@@ -1250,7 +1250,7 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
 
 } // namespace
 
-std::atomic<int> g_plan_dmin{0} /* 0: by index size */, g_plan_cap{40}, g_plan_gap{20}, g_plan_chunk{32};
+std::atomic<int> g_plan_dmin{0} /* 0: by index size */, g_plan_cap{64}, g_plan_gap{0} /* 0: by index size */, g_plan_chunk{32};
 std::atomic<int> g_plan_stage{1};     // plan_kernel stages queries and predictions through LDS (0: experiments)
 std::atomic<int> g_plan_bail_x16{50}; // give the plan up when there are more than this many units per 16 items
 void set_plan_stage(int on) { g_plan_stage = on != 0; }
@@ -1258,8 +1258,8 @@ void set_plan_bail(int units_per_16_items) { g_plan_bail_x16 = std::max(0, units
 void set_plan_params(int dmin, int cap, int gap, int chunk)
 {
     if (dmin != 0) g_plan_dmin = std::max(0, dmin); // (< 0: back to the automatic choice)
-    if (cap > 0) g_plan_cap = std::min(48, cap); // the text is padded by kPlanPad >= cap bytes in front
-    if (gap > 0) g_plan_gap = std::max(2, gap);
+    if (cap > 0) g_plan_cap = std::min((int)kPlanPad, cap); // the text is padded by kPlanPad >= cap bytes in front
+    if (gap != 0) g_plan_gap = gap < 0 ? 0 : std::max(2, gap); // (< 0: back to the automatic choice)
     if (chunk > 0) g_plan_chunk = std::max(16, chunk);
 }
 
@@ -1273,7 +1273,11 @@ hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
     const int dmin_set = g_plan_dmin.load();
     a.plan_dmin = dmin_set > 0 ? (uint32_t)dmin_set : (uint32_t)(std::lround(std::log2((double)std::max<uint32_t>(a.ix.n, 4u)) / 2.0) + 3);
     a.plan_cap = (uint32_t)g_plan_cap.load();
-    a.plan_gap = (uint32_t)g_plan_gap.load();
+    // mismatches closer than this share a unit: a unit needs about log4(rows) + 2 bases behind its last mismatch to converge,
+    // and one that has not when the next begins sends its read to the redo pass (5 Mbp index: 20; 100 Mbp, A1 per 3 M reads:
+    // 18 / 20 / 22 / 24 -> 3.54 / 3.51 / 3.36 / 3.36 ms)
+    const int gap_set = g_plan_gap.load();
+    a.plan_gap = gap_set > 0 ? (uint32_t)gap_set : (uint32_t)(std::lround(std::log2((double)std::max<uint32_t>(a.ix.n, 4u)) / 2.0) + 9);
     if (a.call_sites) a.plan_gap = std::max(a.plan_gap, a.call_thr + 1u); // (a unit resolves its breakpoints before the next one starts)
     a.plan_chunk = (uint32_t)g_plan_chunk.load();
     // mismatches an item's list holds: 13 for reads (more than that on 150 bases is a wrong diagonal), 29 for the chunks of

@@ -23,8 +23,8 @@ def _mutate(rng, s, rate):
 def plan_defaults():
     L = kbo_amd.lib()
     yield L
-    L.kbo_set_plan(1, -1, 40)  # (seed depth back to the automatic choice)
-    L.kbo_set_plan_tuning(20, 32, (1 << 16) | 50)
+    L.kbo_set_plan(1, -1, 64)  # (seed depth back to the automatic choice)
+    L.kbo_set_plan_tuning(-1, 32, (1 << 16) | 50)
     L.kbo_set_guided_walk(0, -1)
 
 

@@ -37,8 +37,8 @@ while time.time() < t_end:
     # plan-guided walk: on for most runs, with its knobs thrown around (seed depth / cap, gap, chunk, bail-out, tiny
     # unit array); device copies made while it is off carry no path cover at all
     plan_on = bool(rng.random() < 0.8)
-    L.kbo_set_plan(int(plan_on), int(rng.choice([-1, 1, 4, 10, 14, 20])), int(rng.choice([4, 16, 40, 48])))
-    L.kbo_set_plan_tuning(int(rng.choice([2, 3, 8, 20, 40])), int(rng.choice([16, 32, 100])),
+    L.kbo_set_plan(int(plan_on), int(rng.choice([-1, 1, 4, 10, 14, 20])), int(rng.choice([4, 16, 40, 64])))
+    L.kbo_set_plan_tuning(int(rng.choice([-1, 2, 3, 8, 20, 40])), int(rng.choice([16, 32, 100])),
                           int(rng.choice([0, 8, 32, 0xFFFF, (30 << 16) | 0xFFFF, (4 << 16) | 64])))
     L.kbo_set_guided_walk(int(rng.choice([0, 1, 8, 32])), int(rng.choice([-1, 0, 1])))
     two_workers = bool(rng.random() < 0.15)  # the batch spread over a device list (both entries GPU 0)

@@ -40,7 +40,7 @@ for sub in [float(x) for x in os.environ.get("SUB", "0.01").split(",")]:
     mn, med = time_walk(dev)
     print(f"sub={sub}: plain walk min {mn:.3f} ms median {med:.3f}  ({R*150/mn/1e6:.1f} Gbp/s)", flush=True)
     for dmin in [int(x) for x in os.environ.get("DMIN", "-1").split(",")]:
-        for cap in [int(x) for x in os.environ.get("CAP", "40").split(",")]:
+        for cap in [int(x) for x in os.environ.get("CAP", "64").split(",")]:
          for gw, fatl in [(int(x.split(":")[0]), int(x.split(":")[1])) for x in os.environ.get("GW", "8:0").split(",")]:
           L.kbo_set_guided_walk(gw, fatl)
           for wpc in [int(x) for x in os.environ.get("WPC", "32").split(",")]:
