@@ -1,12 +1,17 @@
 // plan_kernels.hip — gfx950 (MI355X, CDNA4): the plan-guided form of A1 (sbwt::StreamingIndex::matching_statistics,
 // called at reference index.rs:251-252) for batches that ask for the MS values only.
 //
-//   plan_kernel            per work item: a diagonal of the path-cover text, the mismatches of the item against it,
-//                          the MS values this predicts
-//   plan_emit_kernel       mismatch lists -> units (the stretches that have to be walked)
-//   ms_walk_guided_kernel  the extend / contract walk of walk_kernels.hip over the units: from the first mismatch of
-//                          a group until the walk itself proves it is back on the diagonal; everything else keeps
-//                          the predicted value
+//   plan_kernel              per work item: a diagonal of the path-cover text, the mismatches of the item against it,
+//                            the MS values this predicts (queries and predictions staged through LDS in whole lines)
+//   plan_count / plan_emit   mismatch lists -> units (the stretches that have to be walked), two-level scan between them
+//   ms_walk_guided_kernel    the extend / contract walk of walk_kernels.hip over the units: from the first mismatch of
+//                            a group until the walk itself proves it is back on the diagonal; everything else keeps
+//                            the predicted value.  8 resident waves per CU: the lines of the lanes in flight stay in L2
+//   ms_walk_recovery_kernel  the same over the recovery lines (sbwt_index.hpp; indexes far beyond L2): extension,
+//                            contraction levels and the retry of a failing base from ONE 128-byte line
+//   (CALL instantiations)    the breakpoint scan of call_variants carried by the units (kbo_call_walk_dev)
+//   redo_collect_kernel      items a unit could not vouch for -> list for the plain kernel, long ones in pieces
+//   call_fix_sites_kernel    call mode: rows of matches placed on the diagonal, sites of redone items voided
 //
 // Why the skipped values are exact (path_cover.cpp has the graph side): if the walk's interval is the single row
 // node_at[p] at depth d and the next base equals text[p+1], the reference's step gives the single row node_at[p+1]
