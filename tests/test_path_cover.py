@@ -81,3 +81,71 @@ def test_recovery_lines_hold_rank_blocks_and_lcs(k, add_revcomp):
         if lo < n:
             want_lcs[:hi - lo] = lcs[lo:hi]
         assert np.array_equal(lines[b, 64:], want_lcs)
+
+
+def test_contraction_from_the_lines_windows_equals_the_entries():
+    """The recovery kernel takes a contraction level out of two 16-row LCS windows of the lines ([.., l] and [r, ..], cut at
+    the line's ends) instead of the {lcs, psv, nsv} entries.  Model of both in numpy on a real index: wherever the windows
+    hold the level's ends the two agree, and they fall short exactly when an end lies outside them."""
+    rng = np.random.default_rng(5)
+    g = synth.genome(30_000, seed=9)
+    rep = np.tile(g[:300], 6)
+    sbwt, _ = kbo_amd.build([np.concatenate([g, rep]).tobytes()], kbo_amd.BuildOpts(k=31, num_threads=2))
+    n = sbwt.n_sets()
+    _, _, lcs = sbwt.export_parts()
+    lines = sbwt.recovery_lines()
+    lcs_at = lambda i: int(lcs[i]) if i < n else 0  # noqa: E731  (sentinel behind the last row)
+
+    def entries(l, r):  # device_index.cpp / sbwt_index.hpp: one level up with psv / nsv
+        lv = max(lcs_at(l), lcs_at(r))
+        if lv == 0:
+            return 0, 0, n
+        nl, nr = l, r
+        if lcs_at(l) == lv:
+            nl = l - 1
+            while lcs_at(nl) >= lv:
+                nl -= 1
+        if lcs_at(r) == lv:
+            nr = r + 1
+            while lcs_at(nr) >= lv:
+                nr += 1
+        return lv, nl, nr
+
+    def windows(l, r):  # plan_kernels.hip, ms_walk_recovery_kernel
+        bl, br, ol, orr = l >> 6, r >> 6, l & 63, r & 63
+        wl, wr = (ol - 15 if ol > 15 else 0), min(orr, 48)
+        wa = lines[bl, 64 + wl:64 + wl + 16].astype(int)
+        wb = lines[br, 64 + wr:64 + wr + 16].astype(int)
+        pl, pr = ol - wl, orr - wr
+        lv = max(wa[pl], wb[pr])
+        if lv == 0:
+            return 0, 0, n
+        nl, nr = l, r
+        if wa[pl] == lv:
+            below = [q for q in range(pl) if wa[q] < lv]
+            if not below:
+                return None
+            nl = (bl << 6) + wl + below[-1]
+        if wb[pr] == lv:
+            above = [q for q in range(pr + 1, 16) if wb[q] < lv]
+            if not above:
+                return None
+            nr = (br << 6) + wr + above[0]
+        return lv, nl, nr
+
+    short = 0
+    for _ in range(20_000):
+        l = int(rng.integers(0, n))
+        r = min(n, l + int(rng.choice([1, 1, 1, 2, 3, 8, 40])))
+        want = entries(l, r)
+        got = windows(l, r)
+        if got is None:
+            short += 1
+            lv, nl, nr = want
+            bl, br = l >> 6, r >> 6
+            wl_abs = (bl << 6) + ((l & 63) - 15 if (l & 63) > 15 else 0)
+            wr_abs = (br << 6) + min(r & 63, 48) + 15
+            assert nl < wl_abs or nr > wr_abs
+        else:
+            assert got == want
+    assert 0 < short < 6_000
