@@ -131,12 +131,14 @@ uint64_t kbo_index_n_sets(const kbo_index_t *idx);  /* SbwtIndex::n_sets()      
  * device-ready file format "<prefix>.kbohip" (NOT the sbwt crate's .sbwt/.lcs). */
 int kbo_index_save(const kbo_index_t *idx, const char *path);
 int kbo_index_load(const char *path, kbo_index_t **out);
-/* index::serialize_sbwt / load_sbwt (index.rs:128-151, 195-212): the file pair <prefix>.sbwt + <prefix>.lcs.  The part of
- * the format the reference itself writes - the u64-LE length and the tag "SubsetMatrix" (index.rs:139-140) - is
- * reproduced; the payload behind it belongs to the sbwt crate's own serialize() and is NOT pinned by anything in the
- * reference tree, so these functions write and read their own payload (second tag
- * "KBOSBWT1") and kbo_index_load_sbwt returns KBO_E_UNSUPPORTED for a file kbo-cli wrote: such an index comes in
- * through kbo_index_from_parts.  KBO_E_IO when a file is missing, truncated or inconsistent. */
+/* index::serialize_sbwt / load_sbwt (index.rs:128-151, 195-212).  The reference writes <prefix>.sbwt + <prefix>.lcs: a
+ * u64-LE length and the tag "SubsetMatrix" (index.rs:139-140), then the sbwt crate's own serialize() payload, which
+ * nothing in the reference tree pins: PARITY UNPINNED.  These functions therefore keep their
+ * own payload (pinned header + second tag "KBOSBWT1") under their OWN names, <prefix>.sbwt.kbohip + <prefix>.lcs.kbohip,
+ * so that kbo-cli never mistakes the pair for a crate-written index; kbo_index_load_sbwt reads that pair and returns
+ * KBO_E_UNSUPPORTED (not a guess at the crate's fields) when all it finds is a crate-written <prefix>.sbwt: such an index
+ * comes in through kbo_index_from_parts (INTEGRATION.md has the Rust side).  KBO_E_IO when a file is missing, truncated
+ * or inconsistent. */
 int kbo_index_save_sbwt(const kbo_index_t *idx, const char *prefix);
 int kbo_index_load_sbwt(const char *prefix, kbo_index_t **out);
 
@@ -302,17 +304,6 @@ int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, siz
 size_t kbo_run_lengths_work_bytes(size_t n_seqs);
 int kbo_run_lengths_dev(const uint8_t *d_chars, const uint64_t *d_offsets, size_t n_seqs, size_t max_seq_len,
                         size_t max_gap_len, void *d_work, uint32_t *d_records, size_t capacity, void *stream);
-/* Walk launch geometry: upper bound on resident waves, and threads per workgroup. */
-int kbo_walk_geometry(int *max_waves, int *threads);
-int kbo_set_walk_waves_per_cu(int waves_per_cu); /* tuning knob, 0 = default (32) */
-int kbo_set_walk_threads(int threads);           /* tuning knob: workgroup size 64/128/256 */
-/* tuning knobs of the guided walk (the plan-guided form of A1).  waves_per_cu: resident waves per CU, 0 = default (8 or
- * 12, scaled with kbo_set_walk_waves_per_cu; few, so that the lines of the lanes in flight stay in L2: DESIGN.md 4.2),
- * < 0 keeps.  recovery_lines: 1 / 0 = the walk reads the index through the recovery lines (one 128-byte line per 64 rows
- * with rank blocks and LCS values) / through the rank blocks and contraction entries, -1 = by index size (default),
- * < -1 keeps. */
-int kbo_set_guided_walk(int waves_per_cu, int recovery_lines);
-int kbo_set_walk_rare(int period);               /* tuning knob: hot-loop iterations between item-bookkeeping visits (default 8) */
 /* Devices the host batch entry points (kbo_matches_batch / kbo_map_batch / kbo_find_batch) spread
  * their slabs over: index replicated per device, one submitting + one completing host thread and
  * three stage streams (upload, kernels, download) per device, disjoint output slices, no collective.
@@ -321,25 +312,12 @@ int kbo_set_devices(const int *devices, int n);
 /* Host helper threads used by the host batch entry points for the staging copies between pageable
  * user buffers and pinned memory (two teams of this size; default min(8, cores)). */
 int kbo_set_host_threads(int n);
+/* host batches are processed in slabs of at most this many query bytes (default 32 MiB) */
+int kbo_set_slab_bytes(size_t bytes);
 /* Frees the per-device scratch (streams, device buffers, pinned staging) the host batch entry
- * points keep between calls. */
+ * points keep between calls, and the calling thread's own caches (kbo_call / kbo_call_batch keep a
+ * device arena for their per-sequence indexes per host thread). */
 int kbo_release_scratch(void);
-/* Two-base extension blocks (2.7 B per index row on the device): built for indexes with at least
- * min_rows rows (default 24 Mi; 0 = always, UINT64_MAX = never; applies to device copies made after
- * the call), used by the walk from matches at least min_depth deep (default 16; < 0 keeps it). */
-int kbo_set_pair_steps(uint64_t min_rows, int min_depth);
-/* Plan-guided walk for MS-only batches (kbo_amd/csrc/plan_kernels.hip): device copies made while it is enabled
- * (default) carry a path cover of the index's de Bruijn graph (9 B per row) and kbo_ms_batch[_dev] / kbo_matches_batch /
- * kbo_map_batch / kbo_find_batch skip the stretches of every read that match it; results are identical either way.
- * enabled < 0 keeps the setting; seed_depth (> 0: fixed; < 0: automatic = log4(rows) + 3, the default; 0 keeps) and
- * seed_cap (default 64 = the most; <= 0 keeps) tune the diagonal search. */
-int kbo_set_plan(int enabled, int seed_depth, int seed_cap);
-/* More knobs of the plan-guided walk (0 keeps a value): mismatches closer than `gap` bases (>= 2; < 0: automatic =
- * log4(rows) + 9, the default: 20 on a 5 Mbp index, 22 on 100 Mbp) are walked by one unit; reads without a diagonal are walked in chunks of `chunk` bases (default 32); a launch with more
- * than bail_x16 / 16 units per read (default 50 / 16: the break-even is near 4 % substitutions) gives the plan up and takes the plain walk (and the following 16
- * launches do not plan at all).  bail_x16 = 0 forces that path (tests); bits 16 and up of bail_x16, when set, divide the
- * capacity of the unit array (tests: reads whose units do not fit take the plain walk). */
-int kbo_set_plan_tuning(int gap, int chunk, int bail_x16);
 /* The path cover the plan-guided walk uses (host computation, for inspection and tests): every row of the index sits at
  * exactly one text position; text[p] ('A','C','G','T') labels the edge node_at[p-1] -> node_at[p] of the index's de
  * Bruijn graph, 0 where a path starts.  All three arrays have n_sets entries. */
@@ -349,14 +327,10 @@ int kbo_index_path_cover(const kbo_index_t *idx, uint8_t *text, uint32_t *pos, u
  * 32..63, 0 } for c = A, C, G, T, then the 64 LCS bytes of those rows (0 beyond the last row).  n_sets / 64 + 2 lines and
  * one all-zero line; *n_bytes receives the size, lines == NULL only asks for it. */
 int kbo_index_recovery_lines(const kbo_index_t *idx, uint8_t *lines, size_t *n_bytes);
-/* bytes of path cover a device copy of this index carries (0 = none) */
+/* bytes of path cover + recovery lines + seed table a device copy of this index carries (0 = none) */
 uint64_t kbo_index_device_plan_bytes(const kbo_index_t *idx);
-/* Experiments on the plain walk kernel: only the first lane_limit lanes of every wave take reads
- * (64 = all; what a sub-wave tiling would have to beat), and every workgroup reserves dummy_lds_bytes of LDS it never
- * touches (what staging a wave's MS values in LDS for a fused A5/A6 would cost in occupancy). */
-int kbo_set_walk_experiment(int lane_limit, int dummy_lds_bytes);
-int kbo_set_force_big_layout(int on);            /* tests: force the 64-bit-offset contraction-entry layout */
-int kbo_set_slab_bytes(size_t bytes);            /* host batches are processed in slabs of at most this many query bytes (default 32 MiB) */
+
+/* Tuning knobs, experiment switches and test hooks (none of them changes a result) are declared in kbo_hip_tuning.h. */
 
 #ifdef __cplusplus
 }

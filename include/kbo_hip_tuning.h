@@ -1,0 +1,71 @@
+/*
+ * kbo_hip_tuning.h — tuning knobs, experiment switches and test hooks of libkbo_hip.so.
+ *
+ * NOT part of the drop-in boundary (include/kbo_hip.h): nothing here has a counterpart in the reference crate, no
+ * setting changes a result (every combination is parity-tested against the oracle), and a binding of the reference
+ * never needs this file.  The in-repo tests, tools/ and bench.py use it to force code paths through their corners at
+ * small sizes and to record the measurements behind DESIGN.md section 6.  All settings are process-wide and apply to
+ * launches (or, where stated, to device copies of an index) made after the call.
+ */
+#ifndef KBO_HIP_TUNING_H
+#define KBO_HIP_TUNING_H
+
+#include "kbo_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ launch geometry of the walk kernels */
+/* upper bound on resident waves of the plain walk, and threads per workgroup */
+int kbo_walk_geometry(int *max_waves, int *threads);
+int kbo_set_walk_waves_per_cu(int waves_per_cu); /* 0 = default (32) */
+int kbo_set_walk_threads(int threads);           /* workgroup size 64 / 128 / 256 */
+int kbo_set_walk_rare(int period);               /* hot-loop iterations between item-bookkeeping visits (default 8) */
+/* The guided walk (the plan-guided form of A1).  waves_per_cu: resident waves per CU, 0 = default (8 or 12, scaled with
+ * kbo_set_walk_waves_per_cu; few, so that the lines of the lanes in flight stay in L2: DESIGN.md 4.2), < 0 keeps.
+ * recovery_lines: 1 / 0 = the walk reads the index through the recovery lines (one 128-byte line per 64 rows with rank
+ * blocks and LCS values) / through the rank blocks and contraction entries, -1 = by index size (default), < -1 keeps. */
+int kbo_set_guided_walk(int waves_per_cu, int recovery_lines);
+
+/* ------------------------------------------------------------------ index layout on the device */
+/* Two-base extension blocks (2.7 B per index row on the device): built for indexes with at least min_rows rows
+ * (default 24 Mi; 0 = always, UINT64_MAX = never; applies to device copies made after the call), used by the walk from
+ * matches at least min_depth deep (default 16; < 0 keeps it). */
+int kbo_set_pair_steps(uint64_t min_rows, int min_depth);
+/* tests: force the 64-bit-offset contraction-entry layout (device copies made after the call) */
+int kbo_set_force_big_layout(int on);
+/* tests: depth of the seed table of device copies made after the call (0 = by index size: 8 / 10 / 12 / 13 bases;
+ * 1 .. 13 = that many, capped at k).  Large tables are what large indexes get: 12 bases = 128 MiB, 13 = 512 MiB. */
+int kbo_set_seed_table_depth(int bases);
+
+/* ------------------------------------------------------------------ the plan-guided walk */
+/* Device copies made while it is enabled (default) carry a path cover of the index's de Bruijn graph (9 B per row) and
+ * kbo_ms_batch[_dev] / kbo_matches_batch / kbo_map_batch / kbo_find_batch skip the stretches of every read that match it;
+ * results are identical either way.  enabled < 0 keeps the setting, > 0 also clears every copy's hold-off; seed_depth
+ * (> 0: fixed; < 0: automatic = log4(rows) + 3, the default; 0 keeps) and seed_cap (default 64 = the most; <= 0 keeps)
+ * tune the diagonal search. */
+int kbo_set_plan(int enabled, int seed_depth, int seed_cap);
+/* (0 keeps a value) mismatches closer than `gap` bases (>= 2; < 0: automatic = log4(rows) + 9, the default: 20 on a
+ * 5 Mbp index, 22 on 100 Mbp) are walked by one unit; reads without a diagonal are walked in chunks of `chunk` bases
+ * (default 32); a launch with more than bail_x16 / 16 units per read (default 50 / 16: the break-even is near 4 %
+ * substitutions) gives the plan up and takes the plain walk, and the following 16 launches over that device copy of that
+ * index do not plan at all.  bail_x16 = 0 forces that path (tests), < 0 keeps. */
+int kbo_set_plan_tuning(int gap, int chunk, int bail_x16);
+/* tests: the unit array of a launch gets 1 / divisor of its normal capacity (reads whose units do not fit take the plain
+ * walk); 1 = normal */
+int kbo_set_plan_unit_cap_divisor(int divisor);
+/* inspection / tests: launches over the copy of `idx` on `device` (-1 = current) that gave the plan up so far, and the
+ * launches the copy will still skip planning for; either pointer may be NULL.  KBO_E_BAD_ARG when no such copy exists. */
+int kbo_index_plan_holdoff(kbo_index_t *idx, int device, uint32_t *bails, int *holdoff);
+
+/* ------------------------------------------------------------------ experiments recorded in DESIGN.md section 6 */
+/* plain walk kernel: only the first lane_limit lanes of every wave take reads (64 = all; what a sub-wave tiling would
+ * have to beat), and every workgroup reserves dummy_lds_bytes of LDS it never touches (what staging a wave's MS values
+ * in LDS for a fused A5/A6 would cost in occupancy) */
+int kbo_set_walk_experiment(int lane_limit, int dummy_lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KBO_HIP_TUNING_H */

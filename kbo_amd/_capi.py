@@ -64,7 +64,7 @@ class RLE(C.Structure):
         return tuple(int(getattr(self, n)) for n, _ in self._fields_)
 
 
-# every symbol include/kbo_hip.h declares (checked by tests/test_capi_host.py)
+# every symbol include/kbo_hip.h declares (checked by tests/test_capi_host.py) ...
 SYMBOLS = [
     "kbo_last_error", "kbo_version", "kbo_build_opts_default", "kbo_find_opts_default",
     "kbo_map_opts_default", "kbo_call_opts_default", "kbo_call", "kbo_add_variants", "kbo_fill_gaps",
@@ -75,9 +75,17 @@ SYMBOLS = [
     "kbo_derandomize_ms_val", "kbo_translate_ms_vec", "kbo_translate_ms_val", "kbo_matches",
     "kbo_map", "kbo_find", "kbo_run_lengths_gapped", "kbo_relative_to_ref", "kbo_free",
     "kbo_ms_batch", "kbo_matches_batch", "kbo_map_batch", "kbo_find_batch", "kbo_work_bytes",
-    "kbo_ms_batch_dev", "kbo_derand_translate_dev", "kbo_walk_geometry",
-    "kbo_set_walk_waves_per_cu", "kbo_set_walk_threads", "kbo_set_walk_rare", "kbo_set_slab_bytes", "kbo_set_force_big_layout", "kbo_set_devices", "kbo_set_host_threads", "kbo_release_scratch", "kbo_set_pair_steps", "kbo_run_lengths_gapped_batch", "kbo_find_batch_into", "kbo_derand_work_bytes", "kbo_run_lengths_work_bytes", "kbo_run_lengths_dev", "kbo_index_device_pair_bytes",
-    "kbo_set_plan", "kbo_index_device_plan_bytes", "kbo_set_plan_tuning", "kbo_index_path_cover", "kbo_index_recovery_lines", "kbo_call_batch", "kbo_call_sites_dev", "kbo_call_walk_dev", "kbo_set_walk_experiment", "kbo_set_guided_walk", "kbo_index_save_sbwt", "kbo_index_load_sbwt",
+    "kbo_ms_batch_dev", "kbo_derand_translate_dev", "kbo_set_slab_bytes", "kbo_set_devices", "kbo_set_host_threads",
+    "kbo_release_scratch", "kbo_run_lengths_gapped_batch", "kbo_find_batch_into", "kbo_derand_work_bytes",
+    "kbo_run_lengths_work_bytes", "kbo_run_lengths_dev", "kbo_index_device_pair_bytes", "kbo_index_device_plan_bytes",
+    "kbo_index_path_cover", "kbo_index_recovery_lines", "kbo_call_batch", "kbo_call_sites_dev", "kbo_call_walk_dev",
+    "kbo_index_save_sbwt", "kbo_index_load_sbwt",
+]
+# ... and include/kbo_hip_tuning.h (knobs, experiment switches, test hooks: not part of the drop-in boundary)
+TUNING_SYMBOLS = [
+    "kbo_walk_geometry", "kbo_set_walk_waves_per_cu", "kbo_set_walk_threads", "kbo_set_walk_rare", "kbo_set_guided_walk",
+    "kbo_set_pair_steps", "kbo_set_force_big_layout", "kbo_set_seed_table_depth", "kbo_set_plan", "kbo_set_plan_tuning",
+    "kbo_set_plan_unit_cap_divisor", "kbo_index_plan_holdoff", "kbo_set_walk_experiment",
 ]
 
 _lib = None
@@ -168,6 +176,9 @@ def lib():
     L.kbo_set_plan.argtypes = [C.c_int, C.c_int, C.c_int]
     L.kbo_set_plan_tuning.argtypes = [C.c_int, C.c_int, C.c_int]
     L.kbo_set_walk_experiment.argtypes = [C.c_int, C.c_int]
+    L.kbo_set_plan_unit_cap_divisor.argtypes = [C.c_int]
+    L.kbo_set_seed_table_depth.argtypes = [C.c_int]
+    L.kbo_index_plan_holdoff.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
     L.kbo_index_path_cover.argtypes = [vp, vp, vp, vp]
     L.kbo_index_recovery_lines.argtypes = [vp, vp, C.POINTER(C.c_size_t)]
     L.kbo_call_batch.argtypes = [vp, vp, vp, sz, C.POINTER(CallOpts), C.POINTER(C.POINTER(Variant)), vp]

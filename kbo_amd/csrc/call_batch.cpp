@@ -57,11 +57,17 @@ void ms_only(kbo_index *idx, const std::vector<std::vector<uint8_t>> &seqs, std:
 // the same for the few k-mers of one sequence against that sequence's own index, from a pool thread of kbo_call_batch: the
 // calling thread's own buffers and stream, no slabs, no pinned staging, no shared worker team (a millisecond of fixed
 // costs per call that all threads would queue for)
+// (device buffers kept per host thread; DevBuf::ensure gives a thread that has moved to another device fresh memory)
+BatchOnDevice &small_batch_buffers()
+{
+    static thread_local BatchOnDevice B;
+    return B;
+}
 void ms_only_small(kbo_index *idx, const std::vector<std::vector<uint8_t>> &seqs, std::vector<std::vector<kbo::MsVal>> &out)
 {
     out.assign(seqs.size(), {});
     if (seqs.empty()) return;
-    static thread_local BatchOnDevice B;
+    BatchOnDevice &B = small_batch_buffers();
     static thread_local std::vector<uint64_t> off;
     static thread_local std::vector<uint8_t> concat, d;
     off.assign(seqs.size() + 1, 0);
@@ -148,6 +154,8 @@ std::vector<SiteRec> find_sites(kbo_index *idx, const uint8_t *concat, const uin
 }
 
 } // namespace
+
+void kbo_host::release_call_thread_caches() { small_batch_buffers().release(); }
 
 extern "C" int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                               const kbo_call_opts *opts, kbo_variant **out, uint64_t *var_offsets)

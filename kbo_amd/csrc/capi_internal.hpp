@@ -20,14 +20,6 @@ struct DevCopy {
     // (an index that serves one small batch borrows its arena from a buffer the calling thread keeps: kbo::call builds
     // one such index per sequence, and a hipMalloc / hipFree pair per sequence serialises every thread of the process)
     bool arena_borrowed = false;
-    ~DevCopy()
-    {
-        if (arena_borrowed) {
-            arena.p = nullptr;
-            arena.cap = 0;
-            transient_arena_in_use() = false;
-        }
-    }
     static bool &transient_arena_in_use()
     {
         static thread_local bool in_use = false;
@@ -43,6 +35,24 @@ struct DevCopy {
     DevBuf fat;                      // recovery lines of the guided walk (sbwt_index.hpp)
     uint32_t fat_null = 0;
     DevBuf pc_text, pc_pos, pc_node; // path cover (sbwt_index.hpp PathCover), empty when the plan-guided walk is off
+    // Plan hold-off of THIS copy (one index on one device): a batch whose reads differ too much from the index gives the
+    // plan up on the device; the host learns of it one launch late (asynchronous 8-byte copy into `bailed`, pinned, never
+    // waited for) and then skips planning for the next kPlanHoldoff launches over this copy - and over no other.
+    struct PlanState {
+        std::atomic<int> holdoff{0};
+        std::atomic<uint32_t> epoch{0};  // kbo_set_plan(1, ..) generation this state was last reset for
+        uint32_t *bailed = nullptr;      // pinned: [0] plan given up, [1] a walk ended by its no-progress guard
+        std::atomic<uint32_t> bails{0};  // launches that gave the plan up (inspection / tests)
+    } plan;
+    ~DevCopy()
+    {
+        if (plan.bailed) (void)hipHostFree(plan.bailed);
+        if (arena_borrowed) {
+            arena.p = nullptr;
+            arena.cap = 0;
+            transient_arena_in_use() = false;
+        }
+    }
 };
 
 } // namespace kbo_host
@@ -71,17 +81,20 @@ extern std::atomic<bool> g_force_big;             // tests: use the 64-bit-offse
 extern std::atomic<uint64_t> g_pair_min_rows;     // indexes with at least this many rows get two-base blocks on the device
 extern std::atomic<size_t> g_slab_bytes;          // host batches are cut into slabs of at most this many query bytes
 extern std::atomic<int> g_plan_cap_div;           // tests: the unit array gets 1/this of its normal capacity
+extern std::atomic<int> g_seed_table_depth;       // tests: bases per seed-table entry of new device copies (0 = by index size)
 extern std::atomic<bool> g_plan_enabled;          // device copies carry a path cover and MS-only batches take the plan-guided walk
 
 // ---- device_index.cpp
 int current_device();
-kbo::DevIndexView device_view(kbo_index *idx, int device); // uploads the index on first use
+// uploads the index on first use; *plan (optional) receives the copy's plan hold-off state
+kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **plan = nullptr);
 int walk_max_waves();                                     // upper bound on resident walk waves: CUs x waves per CU
 // points a.gitems / a.glist into `plan_work` (>= kbo::plan_work_bytes(n_items) bytes, 16-byte aligned) when the index
 // view carries a path cover and the launch wants MS values only; otherwise leaves them null (plain walk)
-void attach_plan(kbo::WalkArgs &a, void *plan_work);
-void plan_reset_holdoff();
-void plan_after_launch(const kbo::WalkArgs &a, hipStream_t stream); // after launch_ms_walk: lets the host learn whether the plan paid
+void attach_plan(kbo::WalkArgs &a, void *plan_work, DevCopy::PlanState *ps);
+void plan_reset_holdoff(); // every copy plans its next launch again
+// after launch_ms_walk: lets the host learn whether the plan paid (and whether a walk was cut short by its guard)
+void plan_after_launch(const kbo::WalkArgs &a, hipStream_t stream, DevCopy::PlanState *ps);
 
 // ---- A3 (kbo_capi.cpp): derandomize.rs:91-145
 double log_rm_max_cdf(size_t t, size_t alphabet_size, size_t n_kmers);
@@ -157,6 +170,8 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
 // A1 over a host batch: MS values, and intervals when lo/hi are given
 void ms_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, uint8_t *d_out,
                    uint32_t *lo_out, uint32_t *hi_out);
-void release_host_scratch(); // frees the pooled per-device scratch of the host batch entry points
+void release_host_scratch(); // frees the pooled per-device scratch of the host batch entry points + the calling thread's caches
+void release_transient_arena();     // device_index.cpp: the calling thread's arena for transient indexes (when not in use)
+void release_call_thread_caches();  // call_batch.cpp: the calling thread's small-batch device buffers
 
 } // namespace kbo_host

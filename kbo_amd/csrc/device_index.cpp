@@ -13,6 +13,7 @@ std::atomic<bool> g_force_big{false};
 std::atomic<uint64_t> g_pair_min_rows{24ull << 20};
 std::atomic<bool> g_plan_enabled{true};
 std::atomic<int> g_plan_cap_div{1};
+std::atomic<int> g_seed_table_depth{0};
 
 int current_device()
 {
@@ -21,7 +22,19 @@ int current_device()
     return dev;
 }
 
-kbo::DevIndexView device_view(kbo_index *idx, int device)
+// the arena transient indexes borrow (DevCopy::arena_borrowed): one per host thread, reallocated when the thread has
+// moved to another device (DevBuf::ensure), freed by kbo_release_scratch() for the calling thread and at thread exit
+static DevBuf &transient_arena()
+{
+    static thread_local DevBuf t_arena;
+    return t_arena;
+}
+void release_transient_arena()
+{
+    if (!DevCopy::transient_arena_in_use()) transient_arena().release();
+}
+
+kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **plan)
 {
     std::lock_guard<std::mutex> g(idx->mu);
     auto it = idx->dev.find(device);
@@ -50,8 +63,8 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
             const size_t pair_bytes = dc->big ? 0 : lay.pair.size() * sizeof(uint32_t);
             const size_t base_bytes = ((dc->big ? rank_bytes : rank_bytes + ent_bytes) + 15) / 16 * 16;
             const size_t arena_bytes = base_bytes + pair_bytes;
-            static thread_local DevBuf t_arena; // (see DevCopy::arena_borrowed)
             if (idx->transient && !dc->big && !DevCopy::transient_arena_in_use()) {
+                DevBuf &t_arena = transient_arena(); // (the current device is `device` here)
                 t_arena.ensure(arena_bytes);
                 dc->arena.p = t_arena.p;
                 dc->arena_borrowed = true;
@@ -78,6 +91,8 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
             idx->rank_bytes = per * 4;
             idx->lcs_bytes = ent_bytes;
             if (g_plan_enabled && !idx->transient) { // path cover for the plan-guided walk: 9 bytes per row
+                HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&dc->plan.bailed), 64, hipHostMallocDefault));
+                dc->plan.bailed[0] = dc->plan.bailed[1] = 0;
                 kbo::PathCover pc;
                 kbo::make_path_cover(idx->host, pc);
                 static_assert(kbo::PathCover::kPad == kbo::kPlanPad, "text padding");
@@ -104,6 +119,7 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
                 uint32_t D = idx->host.k >= 10 && idx->host.n_sets >= (1u << 20) ? 10u : (idx->host.k >= 8 ? 8u : 0u);
                 if (D == 10 && idx->host.k >= 13 && idx->host.n_sets >= (512u << 20)) D = 13;
                 else if (D == 10 && idx->host.k >= 12 && idx->host.n_sets >= (32u << 20)) D = 12;
+                if (const int forced = g_seed_table_depth.load()) D = std::min<uint32_t>({(uint32_t)forced, 13u, idx->host.k}); // tests
                 if (const char *e = std::getenv("KBO_PLAN_SEED_D")) // experiments
                     D = std::min<uint32_t>({(uint32_t)std::max(0, std::atoi(e)), 13u, idx->host.k});
                 if (D) {
@@ -140,6 +156,7 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
         it = idx->dev.emplace(device, dc).first;
     }
     DevCopy *dc = it->second;
+    if (plan) *plan = &dc->plan;
     kbo::DevIndexView v;
     v.arena = dc->arena.as<uint4>();
     v.n_blocks = (uint32_t)dc->n_blocks;
@@ -162,43 +179,23 @@ kbo::DevIndexView device_view(kbo_index *idx, int device)
 }
 
 // Batches whose reads differ too much from the index give the plan up on the device (plan_emit_kernel), after
-// having paid for the plan kernel.  The host learns about it one launch late (an asynchronous 4-byte copy into pinned
-// memory, never waited for) and then skips planning for the next kPlanHoldoff launches.
+// having paid for the plan kernel.  The host learns about it one launch late (an asynchronous 8-byte copy into pinned
+// memory, never waited for) and then skips planning for the next kPlanHoldoff launches OVER THAT COPY of that index
+// (DevCopy::PlanState): other indexes, and the same index on other devices, keep planning.
 namespace {
 constexpr int kPlanHoldoff = 16;
-std::atomic<int> g_plan_holdoff{0};
-std::atomic<uint32_t *> g_plan_bailed{nullptr}; // pinned
-uint32_t *plan_bailed_slot()
-{
-    uint32_t *p = g_plan_bailed.load();
-    if (!p) {
-        uint32_t *fresh = nullptr;
-        if (hipHostMalloc(reinterpret_cast<void **>(&fresh), 64, hipHostMallocDefault) != hipSuccess) return nullptr;
-        *fresh = 0;
-        uint32_t *expected = nullptr;
-        if (g_plan_bailed.compare_exchange_strong(expected, fresh)) p = fresh;
-        else {
-            (void)hipHostFree(fresh);
-            p = expected;
-        }
-    }
-    return p;
-}
+std::atomic<uint32_t> g_plan_epoch{1}; // bumped by kbo_set_plan(1, ..): every copy forgets its hold-off
 } // namespace
 
-void plan_reset_holdoff() // an explicit kbo_set_plan(1, ..) plans the next launch, whatever earlier batches looked like
+void plan_reset_holdoff() { g_plan_epoch.fetch_add(1); }
+
+void plan_after_launch(const kbo::WalkArgs &a, hipStream_t stream, DevCopy::PlanState *ps)
 {
-    g_plan_holdoff.store(0);
-    if (uint32_t *slot = g_plan_bailed.load()) *reinterpret_cast<volatile uint32_t *>(slot) = 0;
+    if (!a.gitems || !a.qctl || !ps || !ps->bailed) return;
+    (void)hipMemcpyAsync(ps->bailed, a.qctl + 2, 8, hipMemcpyDeviceToHost, stream);
 }
 
-void plan_after_launch(const kbo::WalkArgs &a, hipStream_t stream)
-{
-    if (!a.gitems || !a.qctl) return;
-    if (uint32_t *slot = plan_bailed_slot()) (void)hipMemcpyAsync(slot, a.qctl + 2, 4, hipMemcpyDeviceToHost, stream);
-}
-
-void attach_plan(kbo::WalkArgs &a, void *plan_work)
+void attach_plan(kbo::WalkArgs &a, void *plan_work, DevCopy::PlanState *ps)
 {
     a.gitems = nullptr;
     a.glist = nullptr;
@@ -212,15 +209,21 @@ void attach_plan(kbo::WalkArgs &a, void *plan_work)
     a.unit_bail = 0;
     a.unit_cap = a.plan_dmin = a.plan_cap = a.plan_gap = a.plan_chunk = 0;
     if (!g_plan_enabled || !plan_work || !a.ix.pc_text || (a.lo_out && a.hi_out) || a.n_items == 0) return;
-    if (uint32_t *slot = plan_bailed_slot()) {
-        if (*reinterpret_cast<volatile uint32_t *>(slot)) {
-            *reinterpret_cast<volatile uint32_t *>(slot) = 0;
-            g_plan_holdoff.store(kPlanHoldoff);
+    if (ps) {
+        const uint32_t epoch = g_plan_epoch.load();
+        if (ps->epoch.exchange(epoch) != epoch) { // an explicit kbo_set_plan(1, ..) since: plan the next launch
+            ps->holdoff.store(0);
+            if (ps->bailed) *reinterpret_cast<volatile uint32_t *>(ps->bailed) = 0;
         }
-    }
-    if (g_plan_holdoff.load() > 0) {
-        g_plan_holdoff.fetch_sub(1);
-        return;
+        if (ps->bailed && *reinterpret_cast<volatile uint32_t *>(ps->bailed)) {
+            *reinterpret_cast<volatile uint32_t *>(ps->bailed) = 0;
+            ps->holdoff.store(kPlanHoldoff);
+            ps->bails.fetch_add(1);
+        }
+        if (ps->holdoff.load() > 0) {
+            ps->holdoff.fetch_sub(1);
+            return;
+        }
     }
     uint8_t *w = static_cast<uint8_t *>(plan_work);
     const size_t ni = a.n_items;

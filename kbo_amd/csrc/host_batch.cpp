@@ -106,7 +106,8 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
 {
     KBO_REQUIRE(idx->host.k <= 255, KBO_E_UNSUPPORTED, "k > 255");
     const int dev = current_device();
-    kbo::DevIndexView view = device_view(idx, dev);
+    DevCopy::PlanState *plan_state = nullptr;
+    kbo::DevIndexView view = device_view(idx, dev, &plan_state);
     const uint64_t total = offsets[n_seqs];
     B.total = total;
     // reads (nothing to chunk): the item list is derived from the offsets on the device;
@@ -156,11 +157,12 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
     a.call_counts = call ? call->d_counts : nullptr;
     a.call_cap = call ? call->cap_per_list : 0;
     a.call_thr = call ? call->threshold : 0;
-    a.max_item_len = device_items ? longest_seq : (uint32_t)std::min<uint64_t>(chunk + idx->host.k, 0xFFFFFFFFu);
+    // (no item is longer than this: chunk + k - 1 warm-up bases; call mode: k warm-up + up to k borrowed bases)
+    a.max_item_len = device_items ? longest_seq : (uint32_t)std::min<uint64_t>(chunk + (call ? 2ull * idx->host.k : idx->host.k), 0xFFFFFFFFu);
     if (view.pc_text && !want_ival) B.plan.ensure(kbo::plan_work_bytes(n_items, total));
-    attach_plan(a, view.pc_text && !want_ival ? B.plan.p : nullptr);
+    attach_plan(a, view.pc_text && !want_ival ? B.plan.p : nullptr, plan_state);
     HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), stream));
-    plan_after_launch(a, stream);
+    plan_after_launch(a, stream, plan_state);
 }
 
 void run_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
@@ -821,8 +823,14 @@ void ms_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *offset
 
 void release_host_scratch()
 {
-    std::lock_guard<std::mutex> g(g_ctx_mu);
-    g_ctx_pool.clear();
+    {
+        std::lock_guard<std::mutex> g(g_ctx_mu);
+        g_ctx_pool.clear();
+    }
+    // the calling thread's own caches (kbo_call / kbo_call_batch keep a transient-index arena and a small batch's device
+    // buffers per host thread; pool threads free theirs when they exit)
+    release_transient_arena();
+    release_call_thread_caches();
 }
 
 } // namespace kbo_host

@@ -72,9 +72,11 @@ struct DevBuf {
     explicit DevBuf(size_t bytes) { alloc(bytes); }
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
+    int dev = -1; // HIP device the memory lives on (the current one at allocation)
     void alloc(size_t bytes)
     {
         release();
+        (void)hipGetDevice(&dev);
         hipError_t e = hipMalloc(&p, std::max<size_t>(bytes, 16));
         if (e != hipSuccess) {
             p = nullptr;
@@ -89,9 +91,14 @@ struct DevBuf {
         cap = 0;
     }
     size_t cap = 0;
-    void ensure(size_t bytes) // grow-only: slot buffers are reused from slab to slab
+    // grow-only: slot buffers are reused from slab to slab.  A buffer kept by a host thread across calls (thread_local
+    // caches) is only reused on the device it was allocated on: a thread that has moved to another device gets fresh memory.
+    void ensure(size_t bytes)
     {
-        if (bytes <= cap && p) return;
+        if (bytes <= cap && p) {
+            int cur = -1;
+            if (hipGetDevice(&cur) == hipSuccess && cur == dev) return;
+        }
         alloc(bytes);
         cap = std::max<size_t>(bytes, 16);
     }

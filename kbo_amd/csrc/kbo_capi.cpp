@@ -4,6 +4,7 @@
 // device-memory plumbing and kernel launches.  All matching-statistics / derandomize /
 // translate / run-length compute happens in the *_kernels.hip files; nothing here falls back to the CPU.
 #include "../../include/kbo_hip.h"
+#include "../../include/kbo_hip_tuning.h"
 
 #include <hip/hip_runtime.h>
 
@@ -25,6 +26,7 @@
 #include <vector>
 
 #include "capi_internal.hpp"
+#include "../../include/kbo_hip_tuning.h"
 
 using namespace kbo_host;
 
@@ -839,7 +841,8 @@ int ms_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
         KBO_REQUIRE((d_lo_out == nullptr) == (d_hi_out == nullptr), KBO_E_BAD_ARG, "lo/hi must come together");
 #endif
         hipStream_t s = static_cast<hipStream_t>(stream);
-        kbo::DevIndexView view = device_view(idx, current_device());
+        DevCopy::PlanState *plan_state = nullptr;
+        kbo::DevIndexView view = device_view(idx, current_device(), &plan_state);
         kbo::WalkItem *items = static_cast<kbo::WalkItem *>(d_work);
         // reads: one item per sequence; batches that hold (or may hold) long sequences: chunks
         const DevWork w = dev_work(n_seqs, total_bases, max_seq_len, idx->host.k);
@@ -866,10 +869,10 @@ int ms_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
         a.call_counts = call ? call->d_counts : nullptr;
         a.call_cap = call ? call->cap_per_list : 0;
         a.call_thr = call ? call->threshold : 0;
-        a.max_item_len = w.chunked ? w.chunk + idx->host.k : (uint32_t)std::min<size_t>(max_seq_len, 0xFFFFFFFFu);
-        attach_plan(a, static_cast<uint8_t *>(d_work) + w.plan_off);
+        a.max_item_len = w.chunked ? w.chunk + (call ? 2u : 1u) * idx->host.k : (uint32_t)std::min<size_t>(max_seq_len, 0xFFFFFFFFu);
+        attach_plan(a, static_cast<uint8_t *>(d_work) + w.plan_off, plan_state);
         HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), s));
-        plan_after_launch(a, s);
+        plan_after_launch(a, s, plan_state);
     });
 }
 } // namespace
@@ -1032,11 +1035,33 @@ int kbo_set_walk_experiment(int lane_limit, int dummy_lds_bytes)
 int kbo_set_plan_tuning(int gap, int chunk, int bail_x16)
 {
     kbo::set_plan_params(0, 0, gap, chunk);
-    if (bail_x16 >= 0) {
-        kbo::set_plan_bail(bail_x16 & 0xFFFF);
-        g_plan_cap_div = std::max(1, bail_x16 >> 16); // tests: bits 16.. = divisor of the unit array's capacity
-    }
+    if (bail_x16 >= 0) kbo::set_plan_bail(bail_x16);
     return KBO_OK;
+}
+
+int kbo_set_plan_unit_cap_divisor(int divisor)
+{
+    g_plan_cap_div = std::max(1, divisor);
+    return KBO_OK;
+}
+
+int kbo_set_seed_table_depth(int bases)
+{
+    g_seed_table_depth = std::max(0, std::min(bases, 13));
+    return KBO_OK;
+}
+
+int kbo_index_plan_holdoff(kbo_index_t *idx, int device, uint32_t *bails, int *holdoff)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx, KBO_E_BAD_ARG, "null index");
+        const int dev = device < 0 ? current_device() : device;
+        std::lock_guard<std::mutex> g(idx->mu);
+        auto it = idx->dev.find(dev);
+        KBO_REQUIRE(it != idx->dev.end(), KBO_E_BAD_ARG, "the index has no copy on that device");
+        if (bails) *bails = it->second->plan.bails.load();
+        if (holdoff) *holdoff = it->second->plan.holdoff.load();
+    });
 }
 
 uint64_t kbo_index_device_plan_bytes(const kbo_index_t *idx) { return idx ? idx->plan_bytes : 0; }

@@ -468,11 +468,14 @@ __global__ __launch_bounds__(256) void redo_collect_kernel(WalkArgs a)
     if (idx >= a.n_items) return;
     WalkItem *list = reinterpret_cast<WalkItem *>(a.units);
     const uint4 it = ld16(reinterpret_cast<const uint8_t *>(a.items), idx * 16u);
-    if (a.usums[(2u * a.n_items) / kScanBlock] + a.ucount[2u * a.n_items] > a.unit_bail) { // plan given up: all items, in order
+    // plan given up: all items, in order.  The same when a wave of the guided walk left through its no-progress guard
+    // (qctl[3]; it cannot, but then units are unwalked): every item is walked again in full, so the batch stays exact.
+    const bool gave_up = a.usums[(2u * a.n_items) / kScanBlock] + a.ucount[2u * a.n_items] > a.unit_bail;
+    if (gave_up || a.qctl[3]) {
         reinterpret_cast<uint4 *>(list)[idx] = it;
         if (idx == 0) {
             a.qctl[1] = a.n_items;
-            a.qctl[2] = 1; // tells the host (plan_after_launch) that planning did not pay for this batch
+            if (gave_up) a.qctl[2] = 1; // tells the host (plan_after_launch) that planning did not pay for this batch
         }
         return;
     }
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(256) void call_fix_sites_kernel(WalkArgs a)
         uint4 v = list[sl];
         if (v.w == 0) continue;
         const uint32_t item = (v.w & 0x7FFFFFFFu) - 1u;
-        if (a.redo[item]) v.x = ~0u;
+        if (a.redo[item] || a.qctl[3]) v.x = ~0u; // (qctl[3]: every item is scanned again, see redo_collect_kernel)
         else if (v.w >> 31) v.z = a.ix.pc_node[v.z];
         v.w = 0;
         list[sl] = v;

@@ -522,9 +522,12 @@ static const char kSbwtTag[12] = {'S', 'u', 'b', 's', 'e', 't', 'M', 'a', 't', '
 static const char kOwnSbwt[8] = {'K', 'B', 'O', 'S', 'B', 'W', 'T', '1'};
 static const char kOwnLcs[8] = {'K', 'B', 'O', 'L', 'C', 'S', '0', '1'};
 
+// The pair goes to <prefix>.sbwt.kbohip + <prefix>.lcs.kbohip, NOT to the reference's <prefix>.sbwt / <prefix>.lcs: a file
+// with the SubsetMatrix tag under the upstream name looks like a crate-written index to kbo-cli, whose loader would read
+// this payload as the crate's fields (garbage-sized allocations, a panic) instead of refusing it.
 void save_sbwt_pair(const HostIndex &h, const std::string &prefix)
 {
-    const std::string sp = prefix + ".sbwt", lp = prefix + ".lcs";
+    const std::string sp = prefix + ".sbwt.kbohip", lp = prefix + ".lcs.kbohip";
     FILE *f = std::fopen(sp.c_str(), "wb");
     if (!f) throw std::runtime_error("Expected write access to " + sp);
     const uint64_t taglen = 12, hdr[7] = {h.k, h.n_sets, h.n_kmers, h.C[0], h.C[1], h.C[2], h.C[3]};
@@ -543,11 +546,18 @@ void save_sbwt_pair(const HostIndex &h, const std::string &prefix)
 }
 
 // returns false (h untouched) when the .sbwt payload was not written by save_sbwt_pair
+// (looks for <prefix>.sbwt.kbohip first, then for <prefix>.sbwt: a pair this library wrote under the upstream names
+// before they were moved aside is still read; a crate-written <prefix>.sbwt is reported as such)
 bool load_sbwt_pair(const std::string &prefix, HostIndex &h)
 {
-    const std::string sp = prefix + ".sbwt", lp = prefix + ".lcs";
+    std::string sp = prefix + ".sbwt.kbohip", lp = prefix + ".lcs.kbohip";
     FILE *f = std::fopen(sp.c_str(), "rb");
-    if (!f) throw std::runtime_error("Expected SBWT at " + sp);
+    if (!f) {
+        sp = prefix + ".sbwt";
+        lp = prefix + ".lcs";
+        f = std::fopen(sp.c_str(), "rb");
+    }
+    if (!f) throw std::runtime_error("Expected SBWT at " + prefix + ".sbwt.kbohip (or a crate-written " + sp + ")");
     uint64_t taglen = 0, hdr[7];
     char tag[12], own[8];
     bool ok = std::fread(&taglen, 8, 1, f) == 1 && taglen == 12 && std::fread(tag, 1, 12, f) == 12 &&

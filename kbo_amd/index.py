@@ -116,13 +116,15 @@ def build_sbwt_from_vecs(slices, build_options=None):
 
 
 def serialize_sbwt(outfile_prefix, sbwt, lcs=None):
-    """index::serialize_sbwt (index.rs:128-151): `<prefix>.sbwt` + `<prefix>.lcs` (pinned header, own payload: see
-    kbo_hip.h kbo_index_save_sbwt)."""
+    """index::serialize_sbwt (index.rs:128-151).  NOT interchangeable with the reference's files: the sbwt crate's payload
+    is unpinned here, so the pair is written as `<prefix>.sbwt.kbohip` + `<prefix>.lcs.kbohip` (pinned header, own payload:
+    kbo_hip.h kbo_index_save_sbwt) and kbo-cli cannot read it; indexes cross the boundary through from_parts."""
     check(lib().kbo_index_save_sbwt(sbwt._h, outfile_prefix.encode()))
 
 
 def load_sbwt(index_prefix):
-    """index::load_sbwt (index.rs:195-212)."""
+    """index::load_sbwt (index.rs:195-212) for a pair serialize_sbwt wrote; a crate-written `<prefix>.sbwt` raises
+    KboError(KBO_E_UNSUPPORTED) instead of being guessed at."""
     h = C.c_void_p()
     check(lib().kbo_index_load_sbwt(index_prefix.encode(), C.byref(h)))
     sbwt = SbwtIndexVariant(h)

@@ -75,12 +75,16 @@ def _load():
     lib.ora_matches.argtypes = [vp, vp, C.c_size_t, C.c_double, vp]
     lib.ora_run_lengths_gapped.argtypes = [vp, C.c_size_t, C.c_size_t, C.POINTER(RLE), C.c_size_t]
     lib.ora_run_lengths_gapped.restype = C.c_size_t
+    lib.ora_run_lengths_batch.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, vp]
+    lib.ora_run_lengths_batch.restype = C.c_size_t
     lib.ora_relative_to_ref.argtypes = [vp, vp, C.c_size_t, vp]
     lib.ora_relative_to_ref.restype = None
     lib.ora_matches_batch.argtypes = [vp, vp, vp, C.c_size_t, C.c_double, C.c_int, vp, vp,
                                       C.POINTER(Counters)]
     lib.ora_matches_batch_timed.argtypes = [vp, vp, vp, C.c_size_t, C.c_double, C.c_int, C.c_int, vp, vp,
                                             C.POINTER(C.c_double)]
+    lib.ora_call_sites_batch.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_int, vp, C.c_size_t]
+    lib.ora_call_sites_batch.restype = C.c_long
     lib.ora_call.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_double, C.POINTER(OVariant), C.c_size_t]
     lib.ora_call.restype = C.c_long
     lib.ora_add_variants.argtypes = [vp, C.c_size_t, C.POINTER(OVariant), C.c_size_t]
@@ -256,6 +260,26 @@ def _matches_batch_timed(self, concat, offsets, max_error_prob=1e-7, n_threads=1
 Index.matches_batch_timed = _matches_batch_timed
 
 
+def _call_sites_batch(self, concat, offsets, threshold, n_threads=1):
+    """First pass of call_variants (variant_calling.rs:266-273) for every read of a batch -> u64 array (n_sites, 4) of
+    {read, i, j, ref_colex}, in read order."""
+    concat = np.ascontiguousarray(concat, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    cap = max(1024, len(concat) // 16)
+    while True:
+        recs = np.zeros((cap, 4), dtype=np.uint64)
+        n = int(lib().ora_call_sites_batch(self._h, concat.ctypes.data, offsets.ctypes.data, len(offsets) - 1, threshold,
+                                           n_threads, recs.ctypes.data, cap))
+        if n < 0:
+            raise OracleError(n)
+        if n <= cap:
+            return recs[:n]
+        cap = n
+
+
+Index.call_sites_batch = _call_sites_batch
+
+
 def log_rm_max_cdf(t, alphabet_size, n_kmers):
     return float(lib().ora_log_rm_max_cdf(t, alphabet_size, n_kmers))
 
@@ -294,6 +318,22 @@ def run_lengths_gapped(aln, max_gap_len=0):
     buf = (RLE * max(n, 1))()
     lib().ora_run_lengths_gapped(a.ctypes.data, len(a), max_gap_len, buf, n)
     return [buf[i].as_tuple() for i in range(n)]
+
+
+def run_lengths_batch(aln_concat, offsets, max_gap_len=0):
+    """format::run_lengths_gapped of every alignment of a batch -> (u64 array (n_runs, 7), u64 offsets (n_seqs + 1))."""
+    aln = np.ascontiguousarray(aln_concat, dtype=np.uint8)
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(off) - 1
+    ro = np.zeros(n + 1, dtype=np.uint64)
+    cap = max(1024, 2 * n)
+    while True:
+        recs = np.zeros((cap, 7), dtype=np.uint64)
+        tot = int(lib().ora_run_lengths_batch(aln.ctypes.data, off.ctypes.data, n, max_gap_len, recs.ctypes.data, cap,
+                                              ro.ctypes.data))
+        if tot <= cap:
+            return recs[:tot], ro
+        cap = tot
 
 
 def relative_to_ref(ref_seq, aln):

@@ -548,10 +548,24 @@ static void *pool_worker(void *arg)
 {
     pool_arg *a = (pool_arg *)arg;
     pool_job *j = a->j;
-    cpu_set_t set;
-    CPU_ZERO(&set);
-    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-    if (ncpu > 0) { CPU_SET((int)(a->tid % ncpu), &set); pthread_setaffinity_np(pthread_self(), sizeof set, &set); }
+    /* pinned to the tid-th CPU of the PROCESS's affinity mask (inside a cpuset CPU number tid may not be ours) */
+    cpu_set_t allowed, set;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) == 0) {
+        int n_allowed = CPU_COUNT(&allowed);
+        if (n_allowed > 0) {
+            int want = a->tid % n_allowed, seen = 0;
+            for (int c = 0; c < CPU_SETSIZE; c++) {
+                if (!CPU_ISSET(c, &allowed)) continue;
+                if (seen++ == want) {
+                    CPU_ZERO(&set);
+                    CPU_SET(c, &set);
+                    pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+                    break;
+                }
+            }
+        }
+    }
     uint64_t *d = (uint64_t *)malloc((j->maxlen + 1) * sizeof(uint64_t));
     int64_t *der = (int64_t *)malloc((j->maxlen + 1) * sizeof(int64_t));
     uint32_t *tr = (uint32_t *)malloc((j->maxlen + 1) * sizeof(uint32_t));
@@ -612,6 +626,78 @@ int ora_matches_batch_timed(const ora_index *x, const uint8_t *concat, const uin
     return atomic_load(&j.rc);
 }
 
+/* ---- the first pass of call_variants over a batch of reads (variant_calling.rs:266-273, statement for statement per
+ * read): the breakpoint predicate on the MS values and the search for the closest unique match to its right.  Records
+ * {read, i, j, ref_colex} in read order (threads own contiguous ranges of reads, put together afterwards).  Returns the
+ * number of sites (records beyond `cap` are counted, not written) or a negative ORA_E_* code. */
+typedef struct {
+    const ora_index *x; const uint8_t *concat; const uint64_t *off; size_t begin, end, threshold;
+    uint64_t *recs; size_t n, cap; int rc;
+} sites_job;
+
+static void *sites_worker(void *arg)
+{
+    sites_job *j = (sites_job *)arg;
+    size_t maxlen = 0;
+    for (size_t r = j->begin; r < j->end; r++) {
+        size_t L = (size_t)(j->off[r + 1] - j->off[r]);
+        if (L > maxlen) maxlen = L;
+    }
+    uint64_t *d = (uint64_t *)malloc((maxlen + 1) * sizeof(uint64_t));
+    uint64_t *lo = (uint64_t *)malloc((maxlen + 1) * sizeof(uint64_t));
+    uint64_t *hi = (uint64_t *)malloc((maxlen + 1) * sizeof(uint64_t));
+    const size_t k = j->x->k, t = j->threshold;
+    for (size_t r = j->begin; r < j->end; r++) {
+        const size_t o = (size_t)j->off[r], len = (size_t)(j->off[r + 1] - j->off[r]);
+        int rc = ora_matching_statistics(j->x, j->concat + o, len, d, lo, hi, NULL); /* variant_calling.rs:266 */
+        if (rc) { j->rc = rc; break; }
+        for (size_t i = 1; i < len; i++) {                                       /* :268 */
+            if (d[i] < d[i - 1] && d[i - 1] >= t && d[i] < t) {                    /* :269 */
+                const size_t jend = i + k + 1 < len ? i + k + 1 : len;           /* :271 */
+                for (size_t q = i + 1; q < jend; q++) {
+                    if (d[q] >= t && hi[q] - lo[q] == 1) {                        /* :272 */
+                        if (j->n == j->cap) {
+                            j->cap = j->cap ? 2 * j->cap : 1024;
+                            j->recs = (uint64_t *)realloc(j->recs, j->cap * 4 * sizeof(uint64_t));
+                        }
+                        uint64_t *w = j->recs + 4 * j->n++;
+                        w[0] = r; w[1] = i; w[2] = q; w[3] = lo[q];              /* :273 ref_colex */
+                        break;                                                   /* :289 */
+                    }
+                }
+            }
+        }
+    }
+    free(d); free(lo); free(hi);
+    return NULL;
+}
+
+long ora_call_sites_batch(const ora_index *x, const uint8_t *concat, const uint64_t *offsets, size_t n_reads,
+                          size_t threshold, int n_threads, uint64_t *recs_out, size_t cap)
+{
+    if (n_threads < 1) n_threads = 1;
+    if ((size_t)n_threads > n_reads) n_threads = n_reads ? (int)n_reads : 1;
+    sites_job *jobs = (sites_job *)calloc((size_t)n_threads, sizeof(sites_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    for (int t = 0; t < n_threads; t++) {
+        jobs[t].x = x; jobs[t].concat = concat; jobs[t].off = offsets; jobs[t].threshold = threshold;
+        jobs[t].begin = n_reads * (size_t)t / (size_t)n_threads;
+        jobs[t].end = n_reads * (size_t)(t + 1) / (size_t)n_threads;
+        pthread_create(&th[t], NULL, sites_worker, &jobs[t]);
+    }
+    long total = 0;
+    int rc = ORA_OK;
+    for (int t = 0; t < n_threads; t++) {
+        pthread_join(th[t], NULL);
+        if (jobs[t].rc && !rc) rc = jobs[t].rc;
+        for (size_t s = 0; s < jobs[t].n; s++, total++)
+            if ((size_t)total < cap && recs_out) memcpy(recs_out + 4 * total, jobs[t].recs + 4 * s, 4 * sizeof(uint64_t));
+        free(jobs[t].recs);
+    }
+    free(jobs); free(th);
+    return rc ? (long)rc : total;
+}
+
 /* --------------------------------------------------- format.rs:98-193 */
 
 size_t ora_run_lengths_gapped(const uint8_t *aln, size_t len, size_t max_gap_len,
@@ -657,6 +743,22 @@ size_t ora_run_lengths_gapped(const uint8_t *aln, size_t len, size_t max_gap_len
         }
     }
     return n_out;
+}
+
+/* format::run_lengths_gapped (format.rs:143-193) of every alignment of a batch, the literal loop above per alignment:
+ * rle_offsets[s] .. [s+1] = the runs of alignment s in recs_out (seven u64 each, capacity cap records).  Returns the
+ * number of runs (those beyond cap are counted, not written). */
+size_t ora_run_lengths_batch(const uint8_t *aln_concat, const uint64_t *offsets, size_t n_seqs, size_t max_gap_len,
+                             ora_rle *recs_out, size_t cap, uint64_t *rle_offsets)
+{
+    size_t total = 0;
+    for (size_t s = 0; s < n_seqs; s++) {
+        rle_offsets[s] = total;
+        total += ora_run_lengths_gapped(aln_concat + offsets[s], (size_t)(offsets[s + 1] - offsets[s]), max_gap_len,
+                                        total < cap ? recs_out + total : NULL, total < cap ? cap - total : 0);
+    }
+    rle_offsets[n_seqs] = total;
+    return total;
 }
 
 void ora_relative_to_ref(const uint8_t *ref_seq, const uint8_t *aln, size_t len, uint8_t *out)

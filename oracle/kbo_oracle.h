@@ -91,6 +91,8 @@ typedef struct {
 /* returns number of RLEs (writes at most cap) */
 size_t ora_run_lengths_gapped(const uint8_t *aln, size_t len, size_t max_gap_len,
                               ora_rle *out, size_t cap);
+size_t ora_run_lengths_batch(const uint8_t *aln_concat, const uint64_t *offsets, size_t n_seqs, size_t max_gap_len,
+                             ora_rle *recs_out, size_t cap, uint64_t *rle_offsets);
 void ora_relative_to_ref(const uint8_t *ref_seq, const uint8_t *aln, size_t len,
                          uint8_t *out);
 
@@ -133,6 +135,10 @@ typedef struct {
 } ora_variant;
 /* kbo::call (lib.rs:547-573) = variant_calling::call_variants (variant_calling.rs:249-294):
  * returns the number of variants (writes at most cap), or a negative ORA_E_* code. */
+/* first pass of call_variants over a batch (variant_calling.rs:266-273 per read): records {read, i, j, ref_colex} as
+ * four u64, in read order; returns the number of sites (those beyond cap are not written) or a negative code */
+long ora_call_sites_batch(const ora_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_reads,
+                          size_t threshold, int n_threads, uint64_t *recs_out, size_t cap);
 long ora_call(const ora_index *query_idx, const uint8_t *ref_seq, size_t len, uint32_t k, double max_error_prob,
               ora_variant *out, size_t cap);
 /* translate::add_variants (translate.rs:350-386), in place on byte chars */

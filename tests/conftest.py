@@ -24,3 +24,32 @@ def oracle():
     from oracle import binding
     binding.lib()
     return binding
+
+
+def shipped_defaults(L):
+    """Every process-wide knob of include/kbo_hip_tuning.h back to what the library ships with."""
+    L.kbo_set_plan(1, -1, 64)            # plan on, seed depth automatic (log4(rows) + 3), seed search over 64 bases
+    L.kbo_set_plan_tuning(-1, 32, 50)    # unit gap automatic (log4(rows) + 9), chunks of 32, bail-out at 50 / 16 units per read
+    L.kbo_set_plan_unit_cap_divisor(1)
+    L.kbo_set_guided_walk(0, -1)         # resident waves and rank blocks / recovery lines by index size
+    L.kbo_set_force_big_layout(0)
+    L.kbo_set_seed_table_depth(0)
+    L.kbo_set_pair_steps(24 << 20, 16)
+    L.kbo_set_walk_waves_per_cu(0)
+    L.kbo_set_slab_bytes(32 << 20)
+    L.kbo_set_devices(None, 0)
+
+
+@pytest.fixture(autouse=True)
+def _shipped_defaults_around_every_test():
+    """Tests that force a knob through its corner must not leak the setting into the tests that run after them (round 2
+    left seed depth 14 / cap 40 behind for most of the suite): every test starts from, and leaves, the shipped defaults."""
+    import kbo_amd
+    try:
+        L = kbo_amd.lib()
+    except Exception:
+        yield
+        return
+    shipped_defaults(L)
+    yield
+    shipped_defaults(L)

@@ -16,12 +16,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_every_declared_symbol_is_exported():
-    hdr = open(os.path.join(ROOT, "include", "kbo_hip.h")).read()
-    declared = set(re.findall(r"\b(kbo_[a-z0-9_]+)\s*\(", hdr))
-    assert declared == set(_capi.SYMBOLS)
     L = C.CDLL(_capi.LIB_PATH)
-    for name in declared:
-        assert hasattr(L, name), name
+    for header, symbols in (("kbo_hip.h", _capi.SYMBOLS), ("kbo_hip_tuning.h", _capi.TUNING_SYMBOLS)):
+        hdr = open(os.path.join(ROOT, "include", header)).read()
+        declared = set(re.findall(r"\b(kbo_[a-z0-9_]+)\s*\(", hdr))
+        assert declared == set(symbols), (header, declared ^ set(symbols))
+        for name in declared:
+            assert hasattr(L, name), name
+    # the drop-in boundary carries no tuning knob or test hook
+    assert not (set(_capi.SYMBOLS) & set(_capi.TUNING_SYMBOLS))
+    assert not [n for n in _capi.SYMBOLS if "experiment" in n or "force" in n or "tuning" in n]
 
 
 def test_no_oracle_in_product():
@@ -187,28 +191,39 @@ def test_from_parts_rejects_inconsistent_indexes(tmp_path):
 
 def test_sbwt_lcs_file_pair_round_trip_and_foreign_payload(tmp_path):
     """index::serialize_sbwt / load_sbwt (index.rs:128-151, 195-212; the reference's own test is a round trip,
-    index.rs:277-296).  The header the reference writes is reproduced byte for byte; a payload this library did not
-    write (one from the sbwt crate) is refused as unsupported, not guessed at."""
+    index.rs:277-296).  The pair is written under its own names (<prefix>.sbwt.kbohip / .lcs.kbohip) so that kbo-cli
+    never takes it for a crate-written index; the header the reference writes is reproduced byte for byte; a
+    crate-written <prefix>.sbwt is refused as unsupported, not guessed at."""
     import struct
     from kbo_amd import index as kindex
     sbwt, lcs = kbo_amd.build([b"AAAGAACCA-TCAGGGCG"], kbo_amd.BuildOpts(k=3))
     prefix = str(tmp_path / "serialized_index_1")
     kindex.serialize_sbwt(prefix, sbwt, lcs)
-    raw = open(prefix + ".sbwt", "rb").read()
+    assert not os.path.exists(prefix + ".sbwt") and not os.path.exists(prefix + ".lcs")  # the upstream names stay free
+    raw = open(prefix + ".sbwt.kbohip", "rb").read()
     assert raw[:20] == struct.pack("<Q", 12) + b"SubsetMatrix"          # index.rs:139-140
     loaded, _ = kindex.load_sbwt(prefix)
     a, b = sbwt.export_parts(), loaded.export_parts()
     assert (loaded.k(), loaded.n_sets(), loaded.n_kmers()) == (3, 16, 13)
     assert all((x == y).all() for x, y in zip(a[0], b[0])) and a[1] == b[1] and (a[2] == b[2]).all()
-    # a payload from elsewhere behind the same header
-    open(prefix + ".sbwt", "wb").write(raw[:20] + b"\x10" + bytes(200))
+    # a crate-written pair under the upstream names (same header, the sbwt crate's payload behind it) and no pair of ours
+    other = str(tmp_path / "from_kbo_cli")
+    open(other + ".sbwt", "wb").write(raw[:20] + b"\x10" + bytes(200))
+    open(other + ".lcs", "wb").write(bytes(64))
     with pytest.raises(kbo_amd.KboError) as e:
-        kindex.load_sbwt(prefix)
+        kindex.load_sbwt(other)
     assert e.value.code == -8  # KBO_E_UNSUPPORTED
-    open(prefix + ".sbwt", "wb").write(b"garbage")
+    # a pair this library wrote under the upstream names before they were moved aside is still read
+    legacy = str(tmp_path / "legacy")
+    open(legacy + ".sbwt", "wb").write(raw)
+    open(legacy + ".lcs", "wb").write(open(prefix + ".lcs.kbohip", "rb").read())
+    assert kindex.load_sbwt(legacy)[0].n_sets() == 16
+    open(prefix + ".sbwt.kbohip", "wb").write(b"garbage")
     with pytest.raises(AssertionError):
         kindex.load_sbwt(prefix)
-    open(prefix + ".sbwt", "wb").write(raw)
-    open(prefix + ".lcs", "wb").write(open(prefix + ".lcs", "rb").read()[:-1])  # LCS file shorter than the index
+    open(prefix + ".sbwt.kbohip", "wb").write(raw)
+    open(prefix + ".lcs.kbohip", "wb").write(open(prefix + ".lcs.kbohip", "rb").read()[:-1])  # LCS file shorter than the index
     with pytest.raises(AssertionError):
         kindex.load_sbwt(prefix)
+    with pytest.raises(AssertionError):
+        kindex.load_sbwt(str(tmp_path / "no_such_prefix"))

@@ -1,36 +1,37 @@
-"""BASELINE.json's configurations as parity tests (every read against the CPU oracle, bit-exact):
+"""BASELINE.json's configurations as parity tests (every read against the CPU oracle, bit-exact), run with the SHIPPED
+defaults of every knob unless a test says otherwise (tests/conftest.py resets them around every test):
    C1  10 kbp query vs 1 Mbp reference, kbo map with all defaults (fill_gaps + call_variants), product vs oracle.map
    C2  5 Mbp index, the full 1 M x 150 bp batch bench.py times (plan-guided and plain walk)
-   C3/C4 shape  an index above the two-base-step threshold (>= 24 Mi rows: the real PAIR kernel, not forced on),
-       >= 1 M reads through kbo_map_batch / kbo_find_batch; the plan-guided walk on the same index
-   BIG  the 64-bit-offset entry layout at 50 Mbp
+   C3  kbo find at its real size: 100 Mbp index (12-base seed table, seed depth 16, unit gap 22, recovery lines beyond the
+       Infinity Cache, two-base blocks), 4 M reads through kbo_find_batch / kbo_map_batch / kbo_ms_batch, every read
+   C3/C4 shape  26 Mbp index (>= 24 Mi rows: the real PAIR kernel and the recovery lines, not forced on), 1.2 M reads,
+       MS / map / find, plain and plan-guided; call mode (kbo_call_walk_dev, every read; kbo_call_batch) on the same index
+   BIG  the 64-bit-offset entry layout at 50 Mbp, MS / matches / intervals and call mode, every read
+   seed tables of 9 .. 13 bases forced onto a small index (what 32 Mi / 512 Mi-row indexes get by size)
 The oracle adopts the product-built index for the large ones (its own row-sorting builder needs minutes there; builder
-equality is tests/test_builder_vs_oracle.py).  C5 (3 Gbp) is not run: see DESIGN.md section 8."""
+equality is tests/test_builder_vs_oracle.py).  C4 at 250 Mbp x 100 M reads and C5 (3 Gbp) are not run here: DESIGN.md 8."""
 import numpy as np
 import pytest
 
 import kbo_amd
-from kbo_amd import batch, synth
+from kbo_amd import batch, derandomize, synth
+from gpu_helpers import adopt as _adopt, call_walk_sites, long_reads, oracle_sites, threads as _threads
 
 pytestmark = pytest.mark.gpu
 
 
-def _adopt(oracle, sbwt):
-    rows, Carr, lcs = sbwt.export_parts()
-    return oracle.Index.from_parts(sbwt.k(), sbwt.n_sets(), sbwt.n_kmers(), rows, Carr, lcs)
-
-
-def _threads():
-    import os
-    return max(1, min(16, len(os.sched_getaffinity(0))))
-
-
 @pytest.fixture
 def plan_restore():
-    L = kbo_amd.lib()
-    yield L
-    L.kbo_set_plan(1, 14, 40)
-    L.kbo_set_force_big_layout(0)
+    """(tests/conftest.py puts every knob back to the shipped defaults around every test)"""
+    return kbo_amd.lib()
+
+
+def _check_find_every_read(oracle, sbwt, concat, offsets, exp_chars, gap=0):
+    """kbo_find_batch against format::run_lengths_gapped (oracle, literal) of the expected characters, every read"""
+    rles, ro = batch.find_batch(sbwt, concat, offsets, kbo_amd.FindOpts(max_gap_len=gap))
+    exp_r, exp_o = oracle.run_lengths_batch(exp_chars, offsets, gap)
+    assert np.array_equal(np.asarray(ro, dtype=np.uint64), exp_o)
+    assert np.array_equal(np.asarray(rles, dtype=np.uint64).reshape(-1, 7), exp_r)
 
 
 def test_c1_map_full_defaults_10kbp_vs_1mbp(oracle):
@@ -60,8 +61,8 @@ def test_c2_full_batch_every_read(oracle, plan_restore):
     ora = oracle.Index.build([g.tobytes()], k=31)
     concat, offsets = synth.reads(g, 1_000_000, 150, 0.01)
     exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=_threads(), want_d=True)
-    for plan in (1, 0):
-        L.kbo_set_plan(plan, 14, 40)
+    for plan in (1, 0):  # shipped defaults (seed depth log4(rows) + 3, 64-base seed search, automatic gap); then the plain walk
+        L.kbo_set_plan(plan, 0, 0)
         dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"))
         dev.ms.fill_(0xEE)
         dev.run()
@@ -72,9 +73,70 @@ def test_c2_full_batch_every_read(oracle, plan_restore):
     assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars)  # host entry point, slabs
 
 
+def test_c3_find_at_its_real_size(oracle, plan_restore):
+    """BASELINE C3: kbo find, 100 Mbp index, 150 bp reads, 1 % substitutions, shipped defaults.  What only this size
+    reaches: the 12-base seed table (>= 32 Mi rows), seed depth 16 / unit gap 22 (log4 of 10^8 rows), recovery lines of
+    200 MB (beyond L2, around the Infinity Cache), two-base blocks of 267 MB.  4 M of C3's 10 M reads (same generator,
+    same seed: the first 4 M), every read compared."""
+    g = synth.genome(100_000_000)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
+    n = sbwt.n_sets()
+    assert n == 100_000_001
+    ora = _adopt(oracle, sbwt)
+    concat, offsets = synth.reads(g, 4_000_000, 150, 0.01)
+    exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=_threads(), want_d=True)
+    sbwt.to_device(-1)
+    assert sbwt.device_pair_bytes() > 0
+    assert sbwt.device_plan_bytes() - 11 * n >= (128 << 20)  # path cover 9 B/row + lines 2 B/row + the 12-base table
+    _check_find_every_read(oracle, sbwt, concat, offsets, exp_chars)          # kbo_find_batch (slabs of 32 MiB)
+    exp_map = np.frombuffer(oracle.relative_to_ref(concat, exp_chars), dtype=np.uint8)
+    assert np.array_equal(batch.map_batch(sbwt, concat, offsets, format=True), exp_map)
+    d, _, _ = batch.ms_batch(sbwt, concat, offsets)
+    assert np.array_equal(d, exp_d)
+    bails = __import__("ctypes").c_uint32(0)
+    kbo_amd.check(plan_restore.kbo_index_plan_holdoff(sbwt._h, -1, bails, None))
+    assert bails.value == 0  # the plan-guided walk really ran (no launch gave the plan up)
+    plan_restore.kbo_set_plan(0, 0, 0)  # and the plain walk (PAIR kernel) on a part
+    d, _, _ = batch.ms_batch(sbwt, concat[:150 * 500_000], offsets[:500_001])
+    assert np.array_equal(d, exp_d[:150 * 500_000])
+
+
+def _call_mode_every_read(L, oracle, ora, sbwt, g, seed):
+    """kbo_call_walk_dev (plan-guided and plain call mode) against the oracle's first pass of call_variants on every read:
+    150 bp reads and 10 kbp reads (chunked, with k warm-up and borrowed bases); then kbo_call_batch vs oracle.call."""
+    import torch
+    rng = np.random.default_rng(seed)
+    k = sbwt.k()
+    thr = derandomize.random_match_threshold(k, sbwt.n_kmers(), 4, 1e-7)
+    c1, o1 = synth.reads(g, 300_000, 150, 0.01, seed=seed)
+    c2, o2 = long_reads(rng, g, 1500, 10_000, 0.01)
+    for concat, offsets in ((c1, o1), (c2, o2)):
+        want = oracle_sites(ora, concat, offsets, thr)
+        assert len(want) > 1000
+        _, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=_threads(), want_d=True)
+        dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"))
+        for plan in (1, 0):
+            L.kbo_set_plan(plan, 0, 0)
+            sites, ms, ok = call_walk_sites(L, sbwt, dev, thr)
+            assert ok
+            assert np.array_equal(ms, exp_d), plan
+            assert sites == want, plan
+        del dev
+    L.kbo_set_plan(1, 0, 0)
+    opts = kbo_amd.CallOpts(sbwt_build_opts=kbo_amd.BuildOpts(k=k, build_select=True))
+    got = batch.call_batch(sbwt, c2[:10_000 * 60], o2[:61], opts)
+    n_var = 0
+    for s in range(60):
+        exp, _, _ = ora.call(c2[10_000 * s:10_000 * (s + 1)].tobytes(), k, 1e-7)
+        assert [(v.query_pos, bytes(v.query_chars).decode(), bytes(v.ref_chars).decode()) for v in got[s]] == exp, s
+        n_var += len(exp)
+    return n_var
+
+
 def test_c3_c4_shape_pair_kernel_and_plan(oracle, plan_restore):
-    """26 Mbp index (> 24 Mi rows: device copies carry two-base blocks and the plain walk is the PAIR kernel),
-    1.2 M reads: map with formatting and find, every read, plain and plan-guided."""
+    """26 Mbp index (> 24 Mi rows: device copies carry two-base blocks, the plain walk is the PAIR kernel and the guided
+    walk reads the recovery lines), 1.2 M reads: map with formatting and find, every read, plain and plan-guided, shipped
+    defaults; then call mode on the same index."""
     L = plan_restore
     g = synth.genome(26_000_000, seed=4321)
     sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
@@ -83,22 +145,23 @@ def test_c3_c4_shape_pair_kernel_and_plan(oracle, plan_restore):
     concat, offsets = synth.reads(g, 1_200_000, 150, 0.01, seed=99)
     exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=_threads(), want_d=True)
     exp_map = np.frombuffer(oracle.relative_to_ref(concat, exp_chars), dtype=np.uint8)
-    L.kbo_set_plan(1, 14, 40)
     sbwt.to_device(-1)
     assert sbwt.device_pair_bytes() > 0 and sbwt.device_plan_bytes() > 0
     for plan in (0, 1):
-        L.kbo_set_plan(plan, 14, 40)
+        L.kbo_set_plan(plan, 0, 0)
         d, _, _ = batch.ms_batch(sbwt, concat, offsets)
         assert np.array_equal(d, exp_d), plan
         assert np.array_equal(batch.map_batch(sbwt, concat, offsets, format=True), exp_map), plan
-    rles, ro = batch.find_batch(sbwt, concat, offsets, kbo_amd.FindOpts(max_gap_len=0))
-    rng = np.random.default_rng(3)
-    for s in rng.integers(0, 1_200_000, 400):
-        exp = oracle.run_lengths_gapped(exp_chars[offsets[s]:offsets[s + 1]].tobytes(), 0)
-        assert [tuple(int(v) for v in r) for r in rles[ro[s]:ro[s + 1]]] == exp
+    _check_find_every_read(oracle, sbwt, concat, offsets, exp_chars)
+    _check_find_every_read(oracle, sbwt, concat[:150 * 100_000], offsets[:100_001], exp_chars[:150 * 100_000], gap=5)
+    # k = 31 with this many k-mers leaves little room between the threshold (24) and k: few sites resolve into variants,
+    # the comparison is what counts
+    _call_mode_every_read(L, oracle, ora, sbwt, g, seed=31)
 
 
 def test_big_layout_at_50mbp(oracle, plan_restore):
+    """The 64-bit-offset contraction-entry layout (what indexes beyond ~3 * 10^8 rows get by size) forced on at 50 Mbp:
+    MS / matches / intervals, plain and plan-guided (shipped defaults), and call mode, every read."""
     L = plan_restore
     L.kbo_set_force_big_layout(1)
     g = synth.genome(50_000_000, seed=777)
@@ -107,7 +170,7 @@ def test_big_layout_at_50mbp(oracle, plan_restore):
     concat, offsets = synth.reads(g, 300_000, 150, 0.02, seed=5)
     exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=_threads(), want_d=True)
     for plan in (0, 1):
-        L.kbo_set_plan(plan, 14, 40)
+        L.kbo_set_plan(plan, 0, 0)
         d, _, _ = batch.ms_batch(sbwt, concat, offsets)
         assert np.array_equal(d, exp_d), plan
     assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars)
@@ -115,6 +178,65 @@ def test_big_layout_at_50mbp(oracle, plan_restore):
     for s in range(20):
         od, olo, ohi = ora.matching_statistics(concat[150 * s:150 * s + 150].tobytes())
         assert np.array_equal(lo[150 * s:150 * s + 150], olo.astype(np.uint32)) and np.array_equal(hi[150 * s:150 * s + 150], ohi.astype(np.uint32))
+    _call_mode_every_read(L, oracle, ora, sbwt, g, seed=32)
+
+
+@pytest.mark.parametrize("depth", [9, 11, 12, 13])
+def test_forced_seed_tables(oracle, plan_restore, depth):
+    """plan_kernel's seed table at the depths that otherwise only indexes of >= 32 Mi (12 bases, 128 MiB) and >= 512 Mi rows
+    (13 bases, 512 MiB) get, forced onto a 400 kbp index: seeds of D bases straddle two 16-byte query blocks whenever they
+    start behind base 16 - D (every restart after a failed seed), reads with junk heads make them restart."""
+    L = plan_restore
+    L.kbo_set_seed_table_depth(depth)
+    rng = np.random.default_rng(depth)
+    g = synth.genome(400_000, seed=1300 + depth)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    sbwt.to_device(-1)
+    assert sbwt.device_plan_bytes() - 11 * sbwt.n_sets() >= 8 * 4 ** depth  # the table is there, at that depth
+    for sub, junk in ((0.01, 0), (0.04, 0), (0.01, 12), (0.0, 5)):
+        concat, offsets = synth.reads(g, 30_000, 150, sub, seed=depth * 10 + junk)
+        concat = concat.copy()
+        if junk:  # the first bases of every third read replaced: the first seed fails, the next starts mid-block
+            r = concat.reshape(-1, 150)
+            r[::3, :junk] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (len(r[::3]), junk))]
+        exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=_threads(), want_d=True)
+        d, _, _ = batch.ms_batch(sbwt, concat, offsets)
+        assert np.array_equal(d, exp_d), (depth, sub, junk)
+        assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars), (depth, sub, junk)
+
+
+def test_hold_off_is_per_index(oracle, plan_restore):
+    """A batch that gives the plan up holds planning off for the next launches over THAT copy of THAT index only: an
+    unrelated index on the same device keeps planning (round 2 kept one process-wide counter)."""
+    import ctypes
+    L = plan_restore
+    g1, g2 = synth.genome(300_000, seed=41), synth.genome(300_000, seed=42)
+    a, _ = kbo_amd.build([g1], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
+    b, _ = kbo_amd.build([g2], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
+    oa, ob = oracle.Index.build([g1.tobytes()], k=31), oracle.Index.build([g2.tobytes()], k=31)
+    bad, bad_off = synth.reads(g1, 20_000, 150, 0.12, seed=1)    # 12 % substitutions: far above the bail-out
+    good, good_off = synth.reads(g2, 20_000, 150, 0.01, seed=2)
+    _, exp_bad = oa.matches_batch(bad, bad_off, 1e-7, n_threads=_threads(), want_d=True)
+    _, exp_good = ob.matches_batch(good, good_off, 1e-7, n_threads=_threads(), want_d=True)
+
+    def state(ix):
+        bails, hold = ctypes.c_uint32(0), ctypes.c_int(0)
+        kbo_amd.check(L.kbo_index_plan_holdoff(ix._h, -1, bails, hold))
+        return bails.value, hold.value
+
+    for _ in range(3):
+        d, _, _ = batch.ms_batch(a, bad, bad_off)
+        assert np.array_equal(d, exp_bad)
+        d, _, _ = batch.ms_batch(b, good, good_off)
+        assert np.array_equal(d, exp_good)
+    bails_a, hold_a = state(a)
+    bails_b, hold_b = state(b)
+    assert bails_a >= 1 and hold_a > 0  # index a bailed and is held off ...
+    assert bails_b == 0 and hold_b == 0  # ... index b never noticed
+    L.kbo_set_plan(1, 0, 0)              # an explicit enable clears every hold-off
+    d, _, _ = batch.ms_batch(a, good[:150 * 100], good_off[:101])
+    assert state(a)[1] == 0
 
 
 def test_call_batch_equals_per_sequence_call(oracle):
@@ -187,3 +309,17 @@ def test_host_batches_over_two_distinct_devices(oracle):
     finally:
         L.kbo_set_devices(None, 0)
         L.kbo_set_slab_bytes(32 << 20)
+    # kbo_call_batch from ONE host thread on device 0, then on device 1: the thread's cached device buffers (the arena its
+    # per-sequence indexes borrow, the small batch's buffers) must not be reused across devices
+    opts = kbo_amd.CallOpts(sbwt_build_opts=kbo_amd.BuildOpts(k=31, build_select=True))
+    rng = np.random.default_rng(8)
+    c2, o2 = long_reads(rng, g, 40, 5000, 0.004)
+    per_dev = []
+    for dv in (0, 1, 0):
+        with torch.cuda.device(dv):
+            got = batch.call_batch(sbwt, c2, o2, opts)
+            per_dev.append([[(v.query_pos, bytes(v.query_chars), bytes(v.ref_chars)) for v in vs] for vs in got])
+    assert per_dev[0] == per_dev[1] == per_dev[2]
+    for s in range(40):
+        exp, _, _ = ora.call(c2[5000 * s:5000 * (s + 1)].tobytes(), 31, 1e-7)
+        assert [(q, a.decode(), b.decode()) for q, a, b in per_dev[1][s]] == exp

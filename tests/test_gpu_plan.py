@@ -21,11 +21,8 @@ def _mutate(rng, s, rate):
 
 @pytest.fixture
 def plan_defaults():
-    L = kbo_amd.lib()
-    yield L
-    L.kbo_set_plan(1, -1, 64)  # (seed depth back to the automatic choice)
-    L.kbo_set_plan_tuning(-1, 32, (1 << 16) | 50)
-    L.kbo_set_guided_walk(0, -1)
+    """(tests/conftest.py puts every knob back to the shipped defaults around every test)"""
+    return kbo_amd.lib()
 
 
 def _workload(rng, ref_seqs, n_reads):
@@ -74,17 +71,20 @@ def test_plan_guided_walk_equals_plain_walk_and_oracle(oracle, plan_defaults, k)
     L.kbo_set_plan(0, 14, 40)
     d_plain, _, _ = batch.ms_batch(sbwt, concat, offsets)
     assert np.array_equal(d_plain, exp_d)
-    settings = [(14, 40, 24, 32, 0xFFFF), (14, 40, 2, 16, 0xFFFF), (1, 8, 5, 64, 0xFFFF), (3, 48, 24, 32, 0xFFFF),
-                (14, 40, 24, 32, 0), (14, 40, 24, 32, (40 << 16) | 0xFFFF),  # unit array 1/40 of its size: overflow path
-                (14, 40, 24, 32, 0xFFFF)]
+    # (seed depth, seed cap, unit gap, chunk, bail-out, divisor of the unit array); -1 = the shipped automatic choice
+    settings = [(-1, 64, -1, 32, 50, 1),  # the shipped defaults
+                (14, 40, 24, 32, 0xFFFF, 1), (14, 40, 2, 16, 0xFFFF, 1), (1, 8, 5, 64, 0xFFFF, 1), (3, 48, 24, 32, 0xFFFF, 1),
+                (14, 40, 24, 32, 0, 1), (14, 40, 24, 32, 0xFFFF, 40),  # plan given up; unit array 1/40 of its size: overflow path
+                (14, 40, 24, 32, 0xFFFF, 1)]
     for fat in (0, 1):  # the guided walk over rank blocks + entries / over the recovery lines (a size-based choice otherwise)
         L.kbo_set_guided_walk(0, fat)
-        for dmin, cap, gap, chunk, bail in settings:
+        for dmin, cap, gap, chunk, bail, div in settings:
             L.kbo_set_plan(1, dmin, cap)
             L.kbo_set_plan_tuning(gap, chunk, bail)
+            L.kbo_set_plan_unit_cap_divisor(div)
             for _ in range(2):  # (the launch after a plan was given up is held off; the one after that plans again or not)
                 d, _, _ = batch.ms_batch(sbwt, concat, offsets)
-                assert np.array_equal(d, exp_d), (k, fat, dmin, cap, gap, chunk, bail)
+                assert np.array_equal(d, exp_d), (k, fat, dmin, cap, gap, chunk, bail, div)
     # intervals are only ever produced by the plain walk
     d2, lo, hi = batch.ms_batch(sbwt, concat[:600], np.array([0, 600], dtype=np.uint64), want_intervals=True)
     od, olo, ohi = ora.matching_statistics(concat[:600].tobytes())
@@ -130,26 +130,7 @@ def test_plan_guided_walk_big_layout(oracle, plan_defaults):
         L.kbo_set_force_big_layout(0)
 
 
-def _call_walk_sites(L, sbwt, dev, thr):
-    """kbo_call_walk_dev over a DeviceBatch -> (set of (i_abs, j_abs, row), MS bytes, usable)"""
-    import torch
-    lists = 256  # KBO_CALL_LISTS
-    cap = (dev.total // 4 + 8192) // lists * lists
-    sites = torch.zeros((cap, 4), dtype=torch.int32, device=dev.device)
-    count = torch.zeros(lists * 16 + 16, dtype=torch.int32, device=dev.device)
-    s = torch.cuda.current_stream(dev.device)
-    dev.ms.fill_(0xEE)
-    kbo_amd.check(L.kbo_call_walk_dev(sbwt._h, dev.q.data_ptr(), dev.off.data_ptr(), dev.n_seqs, dev.total, dev.max_len, thr,
-                                      dev.ms.data_ptr(), sites.data_ptr(), cap, count.data_ptr(), dev.work.data_ptr(),
-                                      dev.work_bytes, s.cuda_stream))
-    torch.cuda.synchronize()
-    c = count.cpu().numpy()
-    seg = cap // lists
-    ok = bool((c[:lists * 16:16] <= seg).all()) and int(c[lists * 16]) == 0
-    h = sites.cpu().numpy().view(np.uint32)
-    raw = np.concatenate([h[g * seg:g * seg + min(int(c[g * 16]), seg)] for g in range(lists)])
-    raw = raw[raw[:, 0] != 0xFFFFFFFF]
-    return {(int(a), int(b), int(r)) for a, b, r, _ in raw}, dev.ms[:dev.total].cpu().numpy(), ok
+from gpu_helpers import call_walk_sites as _call_walk_sites  # noqa: E402
 
 
 @pytest.mark.parametrize("k", [31, 51])
@@ -198,7 +179,8 @@ def test_call_mode_of_the_plan_guided_walk(oracle, plan_defaults, k):
     for plan in (0, 1, 2, 3):
         L.kbo_set_plan(1 if plan else 0, 14, 40)
         L.kbo_set_guided_walk(0, 1 if plan == 2 else 0)
-        L.kbo_set_plan_tuning(20, 32, ((40 << 16) | 0xFFFF) if plan == 3 else ((1 << 16) | 0xFFFF))
+        L.kbo_set_plan_tuning(20, 32, 0xFFFF)
+        L.kbo_set_plan_unit_cap_divisor(40 if plan == 3 else 1)
         sites, ms, ok = _call_walk_sites(L, sbwt, dev, thr)
         assert ok
         assert np.array_equal(ms, exp_d), plan

@@ -39,7 +39,8 @@ while time.time() < t_end:
     plan_on = bool(rng.random() < 0.8)
     L.kbo_set_plan(int(plan_on), int(rng.choice([-1, 1, 4, 10, 14, 20])), int(rng.choice([4, 16, 40, 64])))
     L.kbo_set_plan_tuning(int(rng.choice([-1, 2, 3, 8, 20, 40])), int(rng.choice([16, 32, 100])),
-                          int(rng.choice([0, 8, 32, 0xFFFF, (30 << 16) | 0xFFFF, (4 << 16) | 64])))
+                          int(rng.choice([0, 8, 32, 50, 64, 0xFFFF])))
+    L.kbo_set_plan_unit_cap_divisor(int(rng.choice([1, 1, 1, 4, 30])))
     L.kbo_set_guided_walk(int(rng.choice([0, 1, 8, 32])), int(rng.choice([-1, 0, 1])))
     two_workers = bool(rng.random() < 0.15)  # the batch spread over a device list (both entries GPU 0)
     import ctypes
@@ -106,12 +107,21 @@ while time.time() < t_end:
             cc = np.concatenate([pieces[x] for x in pick])
             co = np.concatenate([[0], np.cumsum([lens[x] for x in pick])]).astype(np.uint64)
             opts = kbo_amd.CallOpts(max_error_prob=p_err, sbwt_build_opts=kbo_amd.BuildOpts(k=k, build_select=True))
+            # product and oracle must agree on WHETHER the call fails (reference panics), not only on its result
+            exp_all, ora_err = [], None
+            try:
+                for x in pick:
+                    exp_all.append(oi.call(pieces[x].tobytes(), k, p_err)[0])
+            except ora.OracleError as e:
+                ora_err = e
             try:
                 got_calls = batch.call_batch(sbwt, cc, co, opts)
-                for x, vs in zip(pick, got_calls):
-                    exp_calls, _, _ = oi.call(pieces[x].tobytes(), k, p_err)
+            except kbo_amd.KboError as e:
+                assert ora_err is not None, f"call: the product refused ({e}) what the oracle accepted " + tag
+                got_calls = None
+            if got_calls is not None:
+                assert ora_err is None, f"call: the oracle refused ({ora_err}) what the product accepted " + tag
+                for exp_calls, vs in zip(exp_all, got_calls):
                     assert [(v.query_pos, bytes(v.query_chars).decode(), bytes(v.ref_chars).decode()) for v in vs] == exp_calls, "call " + tag
-            except (kbo_amd.KboError, ora.OracleError):
-                pass  # (reference panics: covered by stress_refine.py)
     print("ok", tag, flush=True)
 print(f"{it} iterations, all equal to the oracle")
