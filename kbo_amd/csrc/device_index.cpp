@@ -199,7 +199,7 @@ void attach_plan(kbo::WalkArgs &a, void *plan_work, DevCopy::PlanState *ps)
 {
     a.gitems = nullptr;
     a.glist = nullptr;
-    a.ucount = a.usums = a.qctl = nullptr;
+    a.ucount = a.usums = a.qctl = a.pstats = nullptr;
     a.redo = nullptr;
     a.units = nullptr;
     a.n_items_dev = nullptr;
@@ -226,24 +226,19 @@ void attach_plan(kbo::WalkArgs &a, void *plan_work, DevCopy::PlanState *ps)
         }
     }
     uint8_t *w = static_cast<uint8_t *>(plan_work);
-    const size_t ni = a.n_items;
-    a.gitems = reinterpret_cast<kbo::GuidedItem *>(w);
-    w += ni * sizeof(kbo::GuidedItem);
-    a.unit_cap = (uint32_t)std::min<size_t>(kbo::plan_unit_cap(ni, a.q_bytes), 0x7FFFFF00u);
+    const kbo::PlanLayout L = kbo::plan_layout(a.n_items, a.q_bytes);
+    a.gitems = reinterpret_cast<kbo::GuidedItem *>(w + L.gitems);
+    a.unit_cap = L.unit_cap;
     a.redo_cap = 2u * a.unit_cap; // (>= every item cut into pieces of 64 bases: redo_collect_kernel)
-    a.units = reinterpret_cast<kbo::WalkUnit *>(w);
-    w += (size_t)a.unit_cap * sizeof(kbo::WalkUnit);
+    a.units = reinterpret_cast<kbo::WalkUnit *>(w + L.units);
     const int cap_div = g_plan_cap_div.load();
     if (cap_div > 1) a.unit_cap = std::max<uint32_t>(1u, a.unit_cap / (uint32_t)cap_div); // (tests: force the overflow path)
-    a.glist = reinterpret_cast<uint16_t *>(w);
-    w += (ni * kbo::kPlanListMax * 2 + 15) / 16 * 16;
-    a.ucount = reinterpret_cast<uint32_t *>(w);
-    w += (2 * ni + 1) * 4;
-    a.usums = reinterpret_cast<uint32_t *>(w);
-    w += (ni / 512 + 4) * 4;
-    a.qctl = reinterpret_cast<uint32_t *>(w);
-    w += 64;
-    a.redo = w;
+    a.glist = reinterpret_cast<uint16_t *>(w + L.glist);
+    a.ucount = reinterpret_cast<uint32_t *>(w + L.ucount);
+    a.usums = reinterpret_cast<uint32_t *>(w + L.usums);
+    a.qctl = reinterpret_cast<uint32_t *>(w + L.qctl);
+    a.pstats = reinterpret_cast<uint32_t *>(w + L.pstats);
+    a.redo = w + L.redo;
 }
 
 // upper bound on resident walk waves: CUs x waves per CU (default 32 = 8 per SIMD)

@@ -88,6 +88,31 @@ __device__ __forceinline__ uint32_t decode_base(uint32_t ch)
     return back == ch ? c : 4u;
 }
 
+// sum of v over the 64 lanes of the wave (all lanes must call it)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// adds the wave's totals of up to four work counters to the launch's statistics (kernels.hpp kPlanStat*): one atomic
+// per counter and wave, on the slot the wave's number selects
+__device__ __forceinline__ void plan_stats_add(uint32_t *pstats, uint32_t i0, uint32_t v0, uint32_t i1, uint32_t v1, uint32_t i2, uint32_t v2,
+                                               uint32_t i3, uint32_t v3)
+{
+    v0 = wave_sum(v0);
+    v1 = wave_sum(v1);
+    v2 = wave_sum(v2);
+    v3 = wave_sum(v3);
+    if ((threadIdx.x & 63u) == 0 && pstats) {
+        uint32_t *s = pstats + (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) % kPlanStatSlots) * kPlanStatWords;
+        if (v0) atomicAdd(s + i0, v0);
+        if (v1) atomicAdd(s + i1, v1);
+        if (v2) atomicAdd(s + i2, v2);
+        if (v3) atomicAdd(s + i3, v3);
+    }
+}
+
 constexpr uint32_t kScanBlock = 1024; // values per block of the two-level scan
 
 // exclusive scan of `per` consecutive values per thread, 256 or 1024 threads per block, in place;

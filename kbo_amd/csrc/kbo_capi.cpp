@@ -899,6 +899,32 @@ int kbo_call_walk_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
                              work_bytes, stream, &sink);
 }
 
+int kbo_plan_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k, const void *d_work,
+                       uint64_t out[KBO_PLAN_STATS], void *stream)
+{
+    return guarded([&] {
+        KBO_REQUIRE(d_work && out && n_seqs > 0 && total_bases > 0, KBO_E_BAD_ARG, "null / empty argument");
+        const DevWork w = dev_work(n_seqs, total_bases, max_seq_len, k);
+        const kbo::PlanLayout L = kbo::plan_layout(w.n_slots, total_bases);
+        const uint8_t *plan = static_cast<const uint8_t *>(d_work) + w.plan_off;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        uint32_t ctl[16], st[kbo::kPlanStatSlots * kbo::kPlanStatWords], tot[2];
+        const uint32_t last = 2u * w.n_slots; // the scan's extra entry: its prefix is the number of units
+        HIP_OK(hipMemcpyAsync(ctl, plan + L.qctl, sizeof ctl, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(st, plan + L.pstats, sizeof st, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(&tot[0], plan + L.ucount + (size_t)last * 4, 4, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(&tot[1], plan + L.usums + (size_t)(last / 1024u) * 4, 4, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        for (uint32_t i = 0; i < KBO_PLAN_STATS; i++) out[i] = 0;
+        for (uint32_t sl = 0; sl < kbo::kPlanStatSlots; sl++)
+            for (uint32_t i = 0; i < kbo::kPlanStatWords; i++) out[i] += st[sl * kbo::kPlanStatWords + i];
+        out[8] = (uint64_t)tot[0] + tot[1];
+        out[9] = ctl[1];
+        out[10] = ctl[2];
+        out[11] = ctl[3];
+    });
+}
+
 size_t kbo_derand_work_bytes(size_t n_seqs, uint64_t total_bases)
 {
     return kbo::derand_piece_work_bytes((uint32_t)std::min<size_t>(n_seqs, 0xFFFFFFFEu), total_bases);

@@ -104,7 +104,8 @@ struct WalkArgs {
     uint32_t unit_cap;
     uint32_t redo_cap;     // WalkItem records the unit array holds (the redo pass's list is built there)
     uint32_t unit_bail;    // more units than this in a launch: the plan is given up, every item takes the plain walk
-    uint32_t *qctl;        // [0] queue head of the guided walk
+    uint32_t *qctl;        // [0] queue head of the guided walk, [1] entries of the redo list, [2] plan given up, [3] a walk left through its guard
+    uint32_t *pstats;      // work counters of the launch (kPlanStat*): kPlanStatSlots slots of 8 u32, summed by the host
     uint32_t plan_dmin;    // plan_kernel: a seed must be this deep (capped at k) before its row is trusted
     uint32_t plan_cap;     // plan_kernel: seed iterations before an item is given up as unplanned
     uint32_t plan_gap;     // plan_emit_kernel: mismatches closer than this share a unit (>= 2)
@@ -120,13 +121,44 @@ struct WalkArgs {
     uint32_t max_item_len; // 0 = not known, else no item is longer than this (plan_kernel sizes its LDS staging from it)
     const uint32_t *n_items_dev; // plain kernel: nullptr, or where the number of items is (the redo pass: qctl + 1)
 };
+// Work counters the plan-guided stage keeps about itself (one wave-level atomic per counter and wave, spread over slots):
+// what the CPU model of the stage (oracle/plan_model.c) is pinned to, tests/test_gpu_model.py
+enum : uint32_t { kPlanStatUnits = 0, kPlanStatAccepted, kPlanStatFailed, kPlanStatLevels, kPlanStatEntryLevels,
+                  kPlanStatSeedLookups, kPlanStatSeedExtensions, kPlanStatMismatches, kPlanStatWords };
+constexpr uint32_t kPlanStatSlots = 8;
+// where the pieces of a launch's plan work live inside its work buffer (attach_plan)
+struct PlanLayout {
+    size_t gitems, units, glist, ucount, usums, qctl, pstats, redo, end;
+    uint32_t unit_cap;
+};
 // capacity of the unit array and bytes of plan work for a launch of n_items items over total_bases bases
 inline size_t plan_unit_cap(size_t n_items, uint64_t total_bases) { return 3 * n_items + total_bases / 64 + 64; }
-inline size_t plan_work_bytes(size_t n_items, uint64_t total_bases)
+inline PlanLayout plan_layout(size_t n_items, uint64_t total_bases)
 {
-    return n_items * (sizeof(GuidedItem) + kPlanListMax * 2) + (2 * n_items + 1 + n_items / 512 + 8) * 4 +
-           (n_items + 15) / 16 * 16 + plan_unit_cap(n_items, total_bases) * sizeof(WalkUnit) + 256;
+    PlanLayout L;
+    size_t w = 0;
+    L.gitems = w;
+    w += n_items * sizeof(GuidedItem);
+    L.unit_cap = (uint32_t)(plan_unit_cap(n_items, total_bases) < 0x7FFFFF00ull ? plan_unit_cap(n_items, total_bases) : 0x7FFFFF00ull);
+    L.units = w;
+    w += (size_t)L.unit_cap * sizeof(WalkUnit);
+    L.glist = w;
+    w += (n_items * kPlanListMax * 2 + 15) / 16 * 16;
+    L.ucount = w;
+    w += (2 * n_items + 1) * 4;
+    L.usums = w;
+    w += (n_items / 512 + 4) * 4;
+    w = (w + 15) / 16 * 16;
+    L.qctl = w;
+    w += 64;
+    L.pstats = w;
+    w += kPlanStatSlots * kPlanStatWords * 4;
+    L.redo = w;
+    w += (n_items + 15) / 16 * 16;
+    L.end = w;
+    return L;
 }
+inline size_t plan_work_bytes(size_t n_items, uint64_t total_bases) { return plan_layout(n_items, total_bases).end + 64; }
 hipError_t launch_plan(WalkArgs &a, hipStream_t stream); // fills in the plan parameters of `a` (the later launches need them)
 hipError_t launch_ms_walk_guided(WalkArgs a, uint32_t grid, uint32_t threads, hipStream_t stream);
 void set_guided_walk(int waves_per_cu, int recovery_lines); // tuning: see kbo_set_guided_walk

@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
     uint4 qblk = make_uint4(0, 0, 0, 0);
     if (plannable) qblk = qld(0);
     uint32_t qbase = 0; // item position of qblk's first byte
+    uint32_t st_lookups = 0, st_ext = 0; // work counters (kPlanStat*)
     for (;;) {
         const bool act = plannable && !seeded && j < len && j < cap;
         if (__ballot(act) == 0) break;
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                 }
                 uint2 iv = make_uint2(0, 0);
                 if (okc) iv = a.ix.seed_tab[w];
+                st_lookups += okc;
                 if (iv.x < iv.y) {
                     l = iv.x;
                     r = iv.y;
@@ -182,6 +184,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                 uint32_t l2 = rank_eval(xA, l - bl * kRankRows), r2 = rank_eval(xB, r - br * kRankRows);
                 uint32_t dbase = d;
                 bool again = false;
+                st_ext++;
                 if (l2 >= r2) { // the seed ends here: start again behind this base (table) or with it (no table)
                     clean = false;
                     dbase = 0;
@@ -324,6 +327,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
             else st_range(a.d_out + g0, v, out_lo > g0 ? min(out_lo - g0, 16u) : 0u, min(wave_hi - g0, 16u));
         }
     }
+    plan_stats_add(a.pstats, kPlanStatSeedLookups, st_lookups, kPlanStatSeedExtensions, st_ext, kPlanStatMismatches, cnt, 0, 0);
     if (!have_item) return;
     const uint32_t j_conv = (seeded && clean && (cnt == 0 || mm0 > j0)) ? j0 + 1u : 0u;
     const uint32_t n_mm = seeded ? min(cnt, 254u) : kPlanNone;
@@ -595,6 +599,7 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
     uint32_t lim = 0, ilen = 0, up0 = 0, dprev = 0, np = 0, pend0 = 0, pend1 = 0, pend2 = 0, pend3 = 0;
     uint32_t nrow = 0;
     bool want = true; // wants to claim a unit
+    uint32_t st_units = 0, st_acc = 0, st_fail = 0, st_con = 0; // work counters (kPlanStat*)
 #ifdef KBO_WALK_DEBUG
     uint32_t dbg_iter = 0, dbg_rare = 0, dbg_acc = 0, dbg_fail = 0, dbg_con = 0, dbg_wdone = 0, dbg_wfin = 0, dbg_units = 0,
              dbg_flagged = 0;
@@ -672,6 +677,7 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
                     wbase = (out_from - warm) & ~3u;
                     wfirst = (out_from - warm) & 3u; // first byte of the first output word that is this unit's
                     flags = i < bound ? 0u : G_DONE; // (empty units: see plan_emit_kernel)
+                    st_units += i < bound ? 1u : 0u;
                     want = true;
 #ifdef KBO_WALK_DEBUG
                     dbg_units++;
@@ -751,6 +757,9 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
                 const bool ok = !con && l2 < r2;
                 const bool accept = !con && (l2 < r2 || d == 0);
                 const bool fail = !con && !accept;
+                st_con += con ? 1u : 0u;
+                st_acc += accept ? 1u : 0u;
+                st_fail += fail ? 1u : 0u;
 #ifdef KBO_WALK_DEBUG
                 dbg_con += con ? 1u : 0u;
                 dbg_acc += accept ? 1u : 0u;
@@ -848,6 +857,7 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
             }
         } // hot loop
     }
+    plan_stats_add(a.pstats, kPlanStatUnits, st_units, kPlanStatAccepted, st_acc, kPlanStatFailed, st_fail, kPlanStatLevels, st_con);
 #ifdef KBO_WALK_DEBUG
     if (a.lo_out == nullptr && a.hi_out != nullptr) { // debug build: hi_out doubles as the counter sink
         if (lane == 0) {
@@ -934,6 +944,7 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
     uint32_t nrow = 0;
     bool want = true; // wants to claim a unit
     uint32_t visits = 0;
+    uint32_t st_units = 0, st_acc = 0, st_fail = 0, st_con = 0, st_ent = 0; // work counters (kPlanStat*)
 #ifdef KBO_WALK_DEBUG
     uint32_t dbg_iter = 0, dbg_rare = 0, dbg_acc = 0, dbg_fail = 0, dbg_con = 0, dbg_wdone = 0, dbg_wfin = 0, dbg_units = 0,
              dbg_flagged = 0, dbg_short = 0;
@@ -1010,6 +1021,7 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                     wbase = (out_from - warm) & ~3u;
                     wfirst = (out_from - warm) & 3u; // first byte of the first output word that is this unit's
                     flags = i < bound ? 0u : G_DONE; // (empty units: see plan_emit_kernel)
+                    st_units += i < bound ? 1u : 0u;
                     want = true;
 #ifdef KBO_WALK_DEBUG
                     dbg_units++;
@@ -1104,6 +1116,8 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                 uint32_t r2 = xB.x + (uint32_t)__popcll(WB & ((1ull << orr) - 1ull));
                 bool ok = !ent && l2 < r2;
                 bool short_win = false; // the windows end before the level does
+                st_fail += (!ent && !ok && d != 0) ? 1u : 0u;
+                st_ent += ent ? 1u : 0u;
 #ifdef KBO_WALK_DEBUG
                 dbg_fail += (!ent && !ok && d != 0) ? 1u : 0u;
 #endif
@@ -1149,6 +1163,7 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                             r2 = xB.x + (uint32_t)__popcll(WB & ((1ull << (r - (br << 6))) - 1ull));
                             ok = l2 < r2;
                         }
+                        st_con++;
 #ifdef KBO_WALK_DEBUG
                         dbg_con++;
                         dbg_short += short_win ? 1u : 0u;
@@ -1161,6 +1176,7 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                 l = ok ? l2 : l;
                 r = ok ? r2 : r;
                 d = ok ? min(d + 1u, k) : d;
+                st_acc += accept ? 1u : 0u;
 #ifdef KBO_WALK_DEBUG
                 dbg_acc += accept ? 1u : 0u;
 #endif
@@ -1236,6 +1252,8 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
             }
         } // hot loop
     }
+    plan_stats_add(a.pstats, kPlanStatUnits, st_units, kPlanStatAccepted, st_acc, kPlanStatFailed, st_fail, kPlanStatLevels, st_con);
+    plan_stats_add(a.pstats, kPlanStatEntryLevels, st_ent, 0, 0, 0, 0, 0, 0);
 #ifdef KBO_WALK_DEBUG
     if (a.lo_out == nullptr && a.hi_out != nullptr) { // debug build: hi_out doubles as the counter sink
         if (lane == 0) {
@@ -1293,7 +1311,8 @@ hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
     a.plan_list = (a.max_item_len != 0 && a.max_item_len <= 255u) ? kPlanList : kPlanListMax;
     // (per read of 150 bases: chunks of long sequences hold several reads' worth of units)
     a.unit_bail = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(a.n_items, a.q_bytes / 150u) * (uint64_t)g_plan_bail_x16.load() / 16u + 64u, 0xFFFFFFFFu);
-    const hipError_t e = hipMemsetAsync(a.qctl, 0, 64, stream);
+    // (queue head, redo count, flags and - behind them - the launch's work counters)
+    const hipError_t e = hipMemsetAsync(a.qctl, 0, 64 + kPlanStatSlots * kPlanStatWords * 4, stream);
     if (e != hipSuccess) return e;
     const uint32_t nb = (a.n_items + 255u) / 256u;
     // LDS for the staged stretch of every wave: 64 items of at most max_item_len bases (not known, or too long for

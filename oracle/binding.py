@@ -21,6 +21,23 @@ class Counters(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class PlanParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("seed_table_depth", "seed_depth", "seed_cap", "gap", "chunk", "list_cap", "bail_x16",
+                                          "recovery_lines")]
+
+
+class PlanCounts(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "bases", "items", "items_unseeded", "items_clean", "items_list_overflow", "items_flagged", "gave_up",
+        "seed_lookups", "seed_extensions", "pos_lookups", "compare_bases", "mismatches",
+        "units_counted", "units", "units_head", "units_plain", "node_lookups",
+        "walk_accepted", "walk_failed", "walk_contractions", "walk_entry_levels", "walk_short_windows", "walk_iterations_lines",
+        "walk_out_bytes", "unit_distinct_lines", "redo_bases", "redo_iterations")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
 class RLE(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("start", "end", "matches", "mismatches", "jumps", "gap_bases", "gap_opens")]
@@ -83,6 +100,7 @@ def _load():
                                       C.POINTER(Counters)]
     lib.ora_matches_batch_timed.argtypes = [vp, vp, vp, C.c_size_t, C.c_double, C.c_int, C.c_int, vp, vp,
                                             C.POINTER(C.c_double)]
+    lib.ora_plan_model.argtypes = [vp, vp, vp, vp, C.POINTER(PlanParams), vp, vp, C.c_size_t, C.c_int, vp, C.POINTER(PlanCounts)]
     lib.ora_call_sites_batch.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_int, vp, C.c_size_t]
     lib.ora_call_sites_batch.restype = C.c_long
     lib.ora_call.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_double, C.POINTER(OVariant), C.c_size_t]
@@ -278,6 +296,36 @@ def _call_sites_batch(self, concat, offsets, threshold, n_threads=1):
 
 
 Index.call_sites_batch = _call_sites_batch
+
+
+def shipped_plan_params(k, n_sets, recovery_lines=None):
+    """The parameters the product's plan-guided stage runs with by default on an index of n_sets rows (device_index.cpp:
+    seed table depth; plan_kernels.hip launch_plan: seed depth, gap; walk_kernels.hip: recovery lines from 24 Mi rows)."""
+    import math
+    half_log = int(math.floor(math.log2(max(n_sets, 4)) / 2.0 + 0.5))  # std::lround(log2(n) / 2)
+    d = 10 if (k >= 10 and n_sets >= (1 << 20)) else (8 if k >= 8 else 0)
+    if d == 10 and k >= 13 and n_sets >= (512 << 20):
+        d = 13
+    elif d == 10 and k >= 12 and n_sets >= (32 << 20):
+        d = 12
+    return PlanParams(seed_table_depth=d, seed_depth=half_log + 3, seed_cap=64, gap=half_log + 9, chunk=32, list_cap=13,
+                      bail_x16=50, recovery_lines=int(n_sets >= (24 << 20)) if recovery_lines is None else int(recovery_lines))
+
+
+def _plan_model(self, cover, params, concat, offsets, n_threads=1):
+    """ora_plan_model -> (MS bytes the modelled stage produces, counts dict).  cover = (text u8[n], pos u32[n], node_at u32[n])."""
+    text, pos, node_at = (np.ascontiguousarray(cover[0], dtype=np.uint8), np.ascontiguousarray(cover[1], dtype=np.uint32),
+                          np.ascontiguousarray(cover[2], dtype=np.uint32))
+    concat = np.ascontiguousarray(concat, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    ms = np.zeros(len(concat), dtype=np.uint8)
+    cn = PlanCounts()
+    _chk(lib().ora_plan_model(self._h, text.ctypes.data, pos.ctypes.data, node_at.ctypes.data, C.byref(params),
+                              concat.ctypes.data, offsets.ctypes.data, len(offsets) - 1, n_threads, ms.ctypes.data, C.byref(cn)))
+    return ms, cn.as_dict()
+
+
+Index.plan_model = _plan_model
 
 
 def log_rm_max_cdf(t, alphabet_size, n_kmers):

@@ -279,11 +279,44 @@ int ora_index_find_kmer(const ora_index *x, const uint8_t *kmer, uint64_t *row)
     return 0;
 }
 
+/* position of the (j+1)-th set bit of B_c (j < popcount(B_c)) */
+static uint64_t select_c(const ora_index *x, int c, uint64_t j)
+{
+    uint64_t lo = 0, hi = ((x->n + 63) / 64 - 1) >> 3; /* last 512-bit block (of those that hold words) whose sample is <= j */
+    while (lo < hi) {
+        uint64_t mid = lo + (hi - lo + 1) / 2;
+        if (x->rank512[c][mid] <= j) lo = mid; else hi = mid - 1;
+    }
+    uint64_t r = x->rank512[c][lo], w = lo << 3;
+    for (;; w++) {
+        uint64_t pc = (uint64_t)__builtin_popcountll(x->bits[c][w]);
+        if (r + pc > j) break;
+        r += pc;
+    }
+    uint64_t word = x->bits[c][w];
+    for (uint64_t t = r; t < j; t++) word &= word - 1; /* drop the set bits in front of the wanted one */
+    return (w << 6) + (uint64_t)__builtin_ctzll(word);
+}
+
 int ora_index_access_kmer(const ora_index *x, uint64_t colex, uint8_t *out_k)
 {
-    if (!x->rows || colex >= x->n) return ORA_E_BAD_ARG;
-    const uint8_t *r = x->rows + colex * x->k;
-    for (uint32_t t = 0; t < x->k; t++) out_k[t] = (uint8_t)"$ACGT"[r[x->k - 1 - t]];
+    if (colex >= x->n) return ORA_E_BAD_ARG;
+    if (x->rows) {
+        const uint8_t *r = x->rows + colex * x->k;
+        for (uint32_t t = 0; t < x->k; t++) out_k[t] = (uint8_t)"$ACGT"[r[x->k - 1 - t]];
+        return ORA_OK;
+    }
+    /* an index adopted from its parts has no row table: spell the row from the subset matrix alone.  Row i >= 1 with
+     * C[c] <= i < C[c+1] ends in c and is (row p)[1..] + c for the row p that holds the (i - C[c])-th edge bit of B_c
+     * (the extend-right bijection read backwards); row 0 is $^k.  k steps give the k characters, last one first. */
+    uint64_t i = colex;
+    for (uint32_t t = x->k; t-- > 0;) {
+        if (i == 0) { out_k[t] = '$'; continue; }
+        int c = 3;
+        while (c > 0 && i < x->C[c]) c--;
+        out_k[t] = (uint8_t)"ACGT"[c];
+        i = select_c(x, c, i - x->C[c]);
+    }
     return ORA_OK;
 }
 

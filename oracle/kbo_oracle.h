@@ -151,6 +151,35 @@ int ora_fill_gaps(const ora_index *idx, const uint8_t *translation, const uint64
 int ora_map(const ora_index *query_idx, const uint8_t *ref_seq, size_t len, uint32_t k, double max_error_prob,
             int fill_gaps, int call_variants, int format, uint8_t *out);
 #define ORA_E_PANIC (-6) /* the reference would panic (index out of bounds / usize underflow / assert!) */
+/* ---- plan_model.c: CPU model of the PRODUCT's plan-guided A1 stage (kbo_amd/csrc/plan_kernels.hip).  It repeats the
+ * stage's decisions read by read, produces the stage's MS values by the stage's own means (the caller checks them against
+ * ora_matching_statistics) and counts its work; bench.py's roofline prices the stage by these counts. ---- */
+typedef struct {
+    uint32_t seed_table_depth; /* bases per seed-table entry (0 = no table): what the device copy carries            */
+    uint32_t seed_depth;       /* a single-row seed must be this deep (capped at k): log4(rows) + 3 by default        */
+    uint32_t seed_cap;         /* bases of an item in which a seed may start (64)                                     */
+    uint32_t gap;              /* mismatches closer than this share a unit: log4(rows) + 9 by default                 */
+    uint32_t chunk;            /* bases per unit of an item without a plan (32)                                       */
+    uint32_t list_cap;         /* mismatches an item's record + list hold (13 for reads)                              */
+    uint32_t bail_x16;         /* more units than this / 16 per read of 150 bases: the plan is given up (50)          */
+    uint32_t recovery_lines;   /* 0: rank blocks + entries (ms_walk_guided_kernel); 1: recovery lines (>= 24 Mi rows) */
+} ora_plan_params;
+
+typedef struct { /* all u64; per launch (the batch handed in) */
+    uint64_t bases, items, items_unseeded, items_clean, items_list_overflow, items_flagged, gave_up;
+    uint64_t seed_lookups, seed_extensions, pos_lookups, compare_bases, mismatches;
+    uint64_t units_counted, units, units_head, units_plain, node_lookups;
+    uint64_t walk_accepted, walk_failed, walk_contractions, walk_entry_levels, walk_short_windows, walk_iterations_lines;
+    uint64_t walk_out_bytes, unit_distinct_lines;
+    uint64_t redo_bases, redo_iterations;
+} ora_plan_counts;
+
+/* text / pos / node_at: the path cover of the index (n_sets entries each: kbo_index_path_cover of the product, whose
+ * claims tests/test_path_cover.py checks against the subset matrix).  ms_out: offsets[n_reads] bytes. */
+int ora_plan_model(const ora_index *idx, const uint8_t *text, const uint32_t *pos, const uint32_t *node_at,
+                   const ora_plan_params *params, const uint8_t *concat, const uint64_t *offsets, size_t n_reads,
+                   int n_threads, uint8_t *ms_out, ora_plan_counts *counts);
+
 #ifdef __cplusplus
 }
 #endif

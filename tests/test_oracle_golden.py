@@ -243,3 +243,25 @@ def test_oracle_map_goldens(golden, oracle):  # lib.rs:647-717
         idx = oracle.Index.build(g["query_seqs"], k=g["k"])
         got = idx.map(g["ref_seq"], g["k"], g["max_error_prob"], g["fill_gaps"], g["call_variants"], g["format"])
         assert got.decode() == g["expected"], g["src"]
+
+
+def test_access_kmer_of_an_adopted_index(oracle):
+    """An index adopted from its parts (ora_index_from_parts) has no row table: access_kmer spells the row from the subset
+    matrix alone (the extend-right bijection read backwards).  Same k-mers as the built index, hence the same kbo::call."""
+    rng = np.random.default_rng(5)
+    for k in (3, 5, 31, 64):
+        seqs = [bytes(rng.choice(list(b"ACGT"), int(rng.integers(300, 4000))).astype(np.uint8)) for _ in range(3)]
+        seqs[1] = seqs[1][:40] + b"N" + seqs[1][40:] + seqs[0][:100]
+        a = oracle.Index.build(seqs, k=k)
+        b = oracle.Index.from_parts(k, a.n_sets, a.n_kmers, [a.bits(c) for c in range(4)], a.C, a.lcs())
+        for i in range(a.n_sets):
+            assert a.access_kmer(i) == b.access_kmer(i), (k, i)
+        rd = bytearray(seqs[2][:1500])
+        for p in (300, 700, 1200):
+            if p < len(rd):
+                rd[p] = ord("A") if rd[p] != ord("A") else ord("C")
+        assert a.call(bytes(rd), k, 1e-3)[0] == b.call(bytes(rd), k, 1e-3)[0]
+    a = oracle.Index.build([b"AAAGAACCA-TCAGGGCG"], k=3)  # the reference's index (index.rs:265): rows as in SURVEY appendix A
+    b = oracle.Index.from_parts(3, a.n_sets, a.n_kmers, [a.bits(c) for c in range(4)], a.C, a.lcs())
+    assert [b.access_kmer(i) for i in range(16)] == [a.access_kmer(i) for i in range(16)]
+    assert b.access_kmer(9) == b"$TC" and b.access_kmer(15) == b"$$T"
