@@ -128,7 +128,10 @@ uint64_t kbo_index_n_kmers(const kbo_index_t *idx); /* SbwtIndex::n_kmers() lib.
 uint64_t kbo_index_n_sets(const kbo_index_t *idx);  /* SbwtIndex::n_sets()             */
 
 /* index::serialize_sbwt / load_sbwt (index.rs:128-151, 195-212) — own flat,
- * device-ready file format "<prefix>.kbohip" (NOT the sbwt crate's .sbwt/.lcs). */
+ * device-ready file format "<prefix>.kbohip" (NOT the sbwt crate's .sbwt/.lcs).  While the plan-guided walk is enabled
+ * (default) the file also carries the index's path cover (9 bytes per row; computed by the save if the handle has none
+ * yet): laying it out is the one slow, serial part of making a device copy (26 s per 10^8 rows), so a loaded index uploads
+ * in the time of a few streaming passes.  A cover read from a file is validated against the subset matrix (KBO_E_IO). */
 int kbo_index_save(const kbo_index_t *idx, const char *path);
 int kbo_index_load(const char *path, kbo_index_t **out);
 /* index::serialize_sbwt / load_sbwt (index.rs:128-151, 195-212).  The reference writes <prefix>.sbwt + <prefix>.lcs: a

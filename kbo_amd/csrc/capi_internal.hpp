@@ -5,6 +5,7 @@
 #pragma once
 #include <atomic>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -63,6 +64,9 @@ struct kbo_index {
     std::map<int, kbo_host::DevCopy *> dev;
     uint64_t rank_bytes = 0, lcs_bytes = 0, plan_bytes = 0;
     bool transient = false; // an index that serves one small batch (kbo::call builds one per sequence): no path cover
+    // the path cover of the plan-guided walk once it has been computed (or read from an index file), guarded by `mu`:
+    // every device copy uploads it from here, kbo_index_save writes it (laying it out is a 26 s pointer chase per 10^8 rows)
+    std::unique_ptr<kbo::PathCover> cover;
     ~kbo_index()
     {
         for (auto &kv : dev) delete kv.second;

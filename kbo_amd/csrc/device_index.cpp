@@ -93,8 +93,11 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
             if (g_plan_enabled && !idx->transient) { // path cover for the plan-guided walk: 9 bytes per row
                 HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&dc->plan.bailed), 64, hipHostMallocDefault));
                 dc->plan.bailed[0] = dc->plan.bailed[1] = 0;
-                kbo::PathCover pc;
-                kbo::make_path_cover(idx->host, pc);
+                if (!idx->cover) { // (idx->mu is held)
+                    idx->cover.reset(new kbo::PathCover());
+                    kbo::make_path_cover(idx->host, *idx->cover);
+                }
+                const kbo::PathCover &pc = *idx->cover;
                 static_assert(kbo::PathCover::kPad == kbo::kPlanPad, "text padding");
                 dc->pc_text.alloc(pc.text.size() + 16);
                 dc->pc_pos.alloc(pc.pos.size() * 4 + 16);

@@ -312,11 +312,17 @@ size_t kbo_index_k(const kbo_index_t *idx) { return idx ? idx->host.k : 0; }
 uint64_t kbo_index_n_kmers(const kbo_index_t *idx) { return idx ? idx->host.n_kmers : 0; }
 uint64_t kbo_index_n_sets(const kbo_index_t *idx) { return idx ? idx->host.n_sets : 0; }
 
-int kbo_index_save(const kbo_index_t *idx, const char *path)
+int kbo_index_save(const kbo_index_t *idx_c, const char *path)
 {
+    kbo_index_t *idx = const_cast<kbo_index_t *>(idx_c); // (the handle's cache of its path cover is filled in under its mutex)
     int rc = guarded([&] {
         KBO_REQUIRE(idx && path, KBO_E_BAD_ARG, "null argument");
-        kbo::save_host_index(idx->host, path);
+        std::lock_guard<std::mutex> g(idx->mu);
+        if (g_plan_enabled && !idx->cover && !idx->transient && idx->host.n_sets < 0xFFFFFFF0ull) {
+            idx->cover.reset(new kbo::PathCover());
+            kbo::make_path_cover(idx->host, *idx->cover);
+        }
+        kbo::save_host_index(idx->host, path, g_plan_enabled ? idx->cover.get() : nullptr);
     });
     return rc == KBO_E_BAD_ARG && idx && path ? KBO_E_IO : rc;
 }
@@ -328,7 +334,10 @@ int kbo_index_load(const char *path, kbo_index_t **out)
         *out = nullptr;
         kbo_index *idx = new kbo_index();
         try {
-            kbo::load_host_index(path, idx->host);
+            std::unique_ptr<kbo::PathCover> pc(new kbo::PathCover());
+            bool have = false;
+            kbo::load_host_index(path, idx->host, pc.get(), &have);
+            if (have) idx->cover = std::move(pc);
         } catch (...) {
             delete idx;
             throw;
@@ -1044,8 +1053,13 @@ int kbo_index_path_cover(const kbo_index_t *idx, uint8_t *text, uint32_t *pos, u
 {
     return guarded([&] {
         KBO_REQUIRE(idx && text && pos && node_at, KBO_E_BAD_ARG, "null argument");
-        kbo::PathCover pc;
-        kbo::make_path_cover(idx->host, pc);
+        kbo_index_t *ix = const_cast<kbo_index_t *>(idx); // (fills the handle's cache of its cover, under its mutex)
+        std::lock_guard<std::mutex> g(ix->mu);
+        if (!ix->cover) {
+            ix->cover.reset(new kbo::PathCover());
+            kbo::make_path_cover(ix->host, *ix->cover);
+        }
+        const kbo::PathCover &pc = *ix->cover;
         std::memcpy(text, pc.text.data() + kbo::PathCover::kPad, idx->host.n_sets);
         std::memcpy(pos, pc.pos.data(), idx->host.n_sets * 4);
         std::memcpy(node_at, pc.node_at.data(), idx->host.n_sets * 4);

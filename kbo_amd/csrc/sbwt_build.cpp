@@ -442,10 +442,14 @@ void make_device_layout(const HostIndex &h, DeviceLayout &out, bool with_pairs)
     for (auto &t : th) t.join();
 }
 
-// ---- flat index file: magic, k, n_sets, n_kmers, C[4], rows[4], lcs --------------
+// ---- flat index file: magic, k, n_sets, n_kmers, C[4], rows[4], lcs [, "KBOPCOV1", text, pos, node_at] -------------
+// The optional tail is the path cover of the plan-guided walk (9 bytes per row): laying the chains out is one long
+// pointer chase (26 s per 10^8 rows, 13 minutes for a human genome), the one part of a device copy worth keeping on disk;
+// rank blocks, contraction entries, two-base blocks, recovery lines and the seed table are streaming passes.
 static const char kMagic[8] = {'K', 'B', 'O', 'H', 'I', 'P', '0', '1'};
+static const char kCoverTag[8] = {'K', 'B', 'O', 'P', 'C', 'O', 'V', '1'};
 
-void save_host_index(const HostIndex &h, const std::string &path)
+void save_host_index(const HostIndex &h, const std::string &path, const PathCover *cover)
 {
     FILE *f = std::fopen(path.c_str(), "wb");
     if (!f) throw std::runtime_error("cannot open " + path + " for writing");
@@ -454,8 +458,61 @@ void save_host_index(const HostIndex &h, const std::string &path)
     size_t nw = (h.n_sets + 63) / 64;
     for (int c = 0; c < 4 && ok; c++) ok = std::fwrite(h.rows[c].data(), 8, nw, f) == nw;
     ok = ok && std::fwrite(h.lcs.data(), 1, h.n_sets, f) == h.n_sets;
+    if (ok && cover) {
+        const size_t n = h.n_sets;
+        ok = cover->text.size() == n + 2 * PathCover::kPad && cover->pos.size() == n && cover->node_at.size() == n &&
+             std::fwrite(kCoverTag, 1, 8, f) == 8 && std::fwrite(cover->text.data() + PathCover::kPad, 1, n, f) == n &&
+             std::fwrite(cover->pos.data(), 4, n, f) == n && std::fwrite(cover->node_at.data(), 4, n, f) == n;
+    }
     std::fclose(f);
     if (!ok) throw std::runtime_error("short write to " + path);
+}
+
+// A cover read from a file is trusted no further than the walk can check for itself: positions and rows must be inverse
+// permutations of each other and every claimed edge node_at[p-1] -> node_at[p] labelled text[p] must be in the subset
+// matrix (the same test tests/test_path_cover.py runs); anything else is an inconsistent file.
+void validate_path_cover(const HostIndex &h, const PathCover &pc)
+{
+    auto bad = [](const char *what) { throw std::runtime_error(std::string("inconsistent path cover: ") + what); };
+    const uint64_t n = h.n_sets;
+    if (pc.text.size() != n + 2 * PathCover::kPad || pc.pos.size() != n || pc.node_at.size() != n) bad("array sizes");
+    const uint8_t *text = pc.text.data() + PathCover::kPad;
+    for (uint64_t p = 0; p < n; p++) {
+        const uint32_t u = pc.node_at[p];
+        if (u >= n || pc.pos[u] != p) bad("pos / node_at are not inverse permutations");
+    }
+    // edge check: the successor of row u by c is C[c] + rank_c(first row of u's (k-1)-suffix group); one streaming pass over
+    // the rows gives every row its group's first row, a second one checks the claimed edges through a rank directory
+    std::vector<uint32_t> cum[4];
+    for (int c = 0; c < 4; c++) {
+        cum[c].resize(h.rows[c].size() + 1);
+        uint32_t a = 0;
+        for (size_t w = 0; w < h.rows[c].size(); w++) {
+            cum[c][w] = a;
+            a += (uint32_t)__builtin_popcountll(h.rows[c][w]);
+        }
+        cum[c][h.rows[c].size()] = a;
+    }
+    auto rank = [&](int c, uint64_t i) -> uint64_t {
+        const uint64_t w = i >> 6, o = i & 63;
+        return cum[c][w] + (o ? (uint64_t)__builtin_popcountll(h.rows[c][w] & ((1ull << o) - 1)) : 0);
+    };
+    std::vector<uint32_t> first(n);
+    for (uint64_t i = 0, f0 = 0; i < n; i++) {
+        if (i == 0 || h.lcs[i] + 1u < h.k) f0 = i;
+        first[i] = (uint32_t)f0;
+    }
+    for (uint64_t p = 0; p < n; p++) {
+        const uint8_t t = text[p];
+        if (t == 0) continue;
+        const int c = t == 'A' ? 0 : t == 'C' ? 1 : t == 'G' ? 2 : t == 'T' ? 3 : -1;
+        if (c < 0 || p == 0) bad("text byte");
+        const uint64_t f0 = first[pc.node_at[p - 1]];
+        if (!((h.rows[c][f0 >> 6] >> (f0 & 63)) & 1)) bad("claimed edge is not in the subset matrix");
+        // the rows of a group share its successors: the one claimed must be among the group's successors by c
+        // (exactly one successor per (group, c): C[c] + rank_c(f0))
+        if (pc.node_at[p] != h.C[c] + rank(c, f0)) bad("claimed edge leads elsewhere");
+    }
 }
 
 // Consistency of an index that did not come out of build_host_index (a file, kbo_index_from_parts): the walk kernels
@@ -482,8 +539,9 @@ void validate_host_index(const HostIndex &h)
     if (h.n_kmers > h.n_sets) bad("n_kmers > n_sets");
 }
 
-void load_host_index(const std::string &path, HostIndex &h)
+void load_host_index(const std::string &path, HostIndex &h, PathCover *cover, bool *have_cover)
 {
+    if (have_cover) *have_cover = false;
     FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) throw std::runtime_error("cannot open " + path);
     char magic[8];
@@ -505,10 +563,30 @@ void load_host_index(const std::string &path, HostIndex &h)
         h.lcs.resize(h.n_sets);
         ok = ok && std::fread(h.lcs.data(), 1, h.n_sets, f) == h.n_sets;
     }
-    if (ok) ok = std::fgetc(f) == EOF; // nothing may follow the LCS array
+    bool with_cover = false;
+    if (ok) { // nothing may follow the LCS array but a path cover
+        char tag[8];
+        const size_t got = std::fread(tag, 1, 8, f);
+        if (got == 8 && std::memcmp(tag, kCoverTag, 8) == 0) {
+            const size_t n = h.n_sets;
+            PathCover tmp, &pc = cover ? *cover : tmp;
+            pc.text.assign(n + 2 * PathCover::kPad, 0);
+            pc.pos.resize(n);
+            pc.node_at.resize(n);
+            ok = std::fread(pc.text.data() + PathCover::kPad, 1, n, f) == n && std::fread(pc.pos.data(), 4, n, f) == n &&
+                 std::fread(pc.node_at.data(), 4, n, f) == n && std::fgetc(f) == EOF;
+            with_cover = ok && cover != nullptr;
+        } else {
+            ok = got == 0;
+        }
+    }
     std::fclose(f);
     if (!ok) throw std::runtime_error("bad or truncated index file " + path);
     validate_host_index(h);
+    if (with_cover) {
+        validate_path_cover(h, *cover);
+        if (have_cover) *have_cover = true;
+    }
 }
 
 // ---- <prefix>.sbwt / <prefix>.lcs, the file pair of index::serialize_sbwt / load_sbwt (reference index.rs:128-151,

@@ -80,8 +80,11 @@ struct PathCover {
 void make_path_cover(const HostIndex &h, PathCover &out);
 
 // flat file (own format, see kbo_capi.cpp)
-void save_host_index(const HostIndex &h, const std::string &path);
-void load_host_index(const std::string &path, HostIndex &h);
+// (cover: optional path cover written behind / read from behind the index; a cover from a file is validated against the
+// subset matrix before it is used)
+void save_host_index(const HostIndex &h, const std::string &path, const PathCover *cover = nullptr);
+void load_host_index(const std::string &path, HostIndex &h, PathCover *cover = nullptr, bool *have_cover = nullptr);
+void validate_path_cover(const HostIndex &h, const PathCover &pc); // throws std::runtime_error
 void save_sbwt_pair(const HostIndex &h, const std::string &prefix); // <prefix>.sbwt + <prefix>.lcs (sbwt_build.cpp)
 bool load_sbwt_pair(const std::string &prefix, HostIndex &h);       // false: payload written by the sbwt crate itself
 void validate_host_index(const HostIndex &h); // throws std::runtime_error on inconsistent k / C / edge bits / LCS

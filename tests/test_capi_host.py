@@ -187,6 +187,29 @@ def test_from_parts_rejects_inconsistent_indexes(tmp_path):
         kindex.load_flat(path)
     open(path, "wb").write(raw)
     assert kindex.load_flat(path)[0].n_sets() == 16
+    # the file carries the path cover of the plan-guided walk (text n + pos 4 n + node_at 4 n bytes behind a tag); a loaded
+    # index hands out the same cover without computing it again, a cover that claims an edge the subset matrix does not
+    # have is refused
+    n = 16
+    assert raw[-(9 * n + 8):-(9 * n)] == b"KBOPCOV1"
+    loaded, _ = kindex.load_flat(path)
+    assert all((a == b).all() for a, b in zip(sbwt.path_cover(), loaded.path_cover()))
+    text_off = len(raw) - 9 * n
+    for p in range(n):
+        if raw[text_off + p] not in (0, ord("T")):
+            broken = bytearray(raw)
+            broken[text_off + p] = ord("T")  # a label the edge does not carry
+            open(path, "wb").write(bytes(broken))
+            with pytest.raises(AssertionError):
+                kindex.load_flat(path)
+            break
+    broken = bytearray(raw)
+    broken[len(raw) - 4 * n:len(raw) - 4 * n + 4] = broken[len(raw) - 4 * n + 4:len(raw) - 4 * n + 8]  # node_at no permutation
+    open(path, "wb").write(bytes(broken))
+    with pytest.raises(AssertionError):
+        kindex.load_flat(path)
+    open(path, "wb").write(raw[:8 + 56 + 4 * 8 + n])  # an index file without a cover (what earlier versions wrote) still loads
+    assert kindex.load_flat(path)[0].n_sets() == 16
 
 
 def test_sbwt_lcs_file_pair_round_trip_and_foreign_payload(tmp_path):
