@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
 """bench.py — kbo map query throughput on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path (A1 walk kernel + fused A5/A6 derandomize/translate
-kernel, i.e. kbo::map with fill_gaps=false, call_variants=false, lib.rs:735-738) over one
-batch of synthetic reads already resident in HBM.  Workload = BASELINE config C2:
-5 Mbp iid genome, k=31 SBWT, 1 M x 150 bp forward reads with 1 % substitutions per GPU
-(weak scaling: every rank holds the replicated index and its own reads; no collective on
-the data path).  Prints ONE JSON line on rank 0.
+One "step" = one pass of the hot path (A1: the plan-guided MS walk; A5/A6: the fused derandomize / translate kernel,
+i.e. kbo::map with fill_gaps=false, call_variants=false, lib.rs:735-738) over one batch of synthetic reads already
+resident in HBM.  Default workload = BASELINE config C2: 5 Mbp iid genome, k=31 SBWT, 1 M x 150 bp forward reads with
+1 % substitutions per GPU (weak scaling: every rank holds the replicated index and its own reads; no collective on the data
+path).  Prints ONE JSON line on rank 0.
+
+  python bench.py --gpus N --steps K --warmup W        N > 1 without RANK in the environment: this process builds the
+                                                       index cache on the host (it never touches a GPU) and starts N
+                                                       ranks through torch.distributed.run, relays rank 0's line
+  --config C2 | C3 | C4                                C3 = kbo find, 100 Mbp, 10 M reads per GPU; C4 = kbo map, 250 Mbp,
+                                                       100 M reads in all, sharded over the ranks (strong scaling)
+The oracle (oracle/) is used after the timed region only: parity gate, CPU baseline, and the CPU model of the plan-guided
+stage whose work counts price the roofline.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,24 +28,34 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+FILL_CEILING_PER_S = 56e9   # L2-miss line fills/s this part delivers to dependent 16-byte gathers from tables beyond L2:
+FILL_CEILING_SOURCE = "profiles/r01_ubench_gather4.txt (tools/ubench/gather4.hip: 55-59 G loads/s for 67 MB .. 4.3 GB tables)"
+PRESETS = {"C2": (5_000_000, 1_000_000, False, "weak"), "C3": (100_000_000, 10_000_000, True, "weak"),
+           "C4": (250_000_000, 100_000_000, False, "strong")}
+SLAB_READS = 8_000_000      # reads per device-resident slab (one launch covers < 4 GiB of query)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["C2", "C3"], default="C2",
-                    help="BASELINE.json workload: C2 = kbo map, 5 Mbp index, 1 M x 150 bp reads (the metric config); "
-                         "C3 = kbo find, 100 Mbp index, 10 M x 150 bp reads (SURVEY.md 8(d)'s designated roofline run)")
+    ap.add_argument("--config", choices=sorted(PRESETS), default="C2",
+                    help="BASELINE.json workload: C2 = kbo map, 5 Mbp index, 1 M x 150 bp reads per GPU (the metric config); "
+                         "C3 = kbo find, 100 Mbp index, 10 M reads per GPU (SURVEY.md 8(d)'s designated roofline run); "
+                         "C4 = kbo map, 250 Mbp index, 100 M reads sharded over the GPUs")
     ap.add_argument("--genome", type=int, default=None)
-    ap.add_argument("--reads", type=int, default=None, help="reads per GPU")
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU (C4: reads in all)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--sub-rate", type=float, default=0.01)
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-clock budget of the CPU baseline leg")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip everything that runs the oracle (parity gate, CPU "
+                    "baseline, stage model) and the sensitivity / host-to-host legs: profiling runs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sensitivity and host-to-host legs only")
+    ap.add_argument("--extras", action="store_true", help="run the sensitivity and host-to-host legs on a custom workload too "
+                    "(they run by default on the preset configurations, on rank 0 at N = 1)")
     ap.add_argument("--find", action="store_true",
                     help="time kbo::find instead of kbo::map: the step ends with format::run_lengths on the device")
     ap.add_argument("--waves-per-cu", type=int, default=0)
@@ -44,18 +63,22 @@ def parse():
                     help="time the first pass of kbo call (C5 shape, scaled): MS walk with intervals + the breakpoint scan "
                          "on the device over 10 kbp reads (defaults: --genome 100000000 --reads 10000 --read-len 10000)")
     ap.add_argument("--no-plan", action="store_true", help="plain walk kernel only (no path cover, no plan-guided walk)")
-    args = ap.parse_args()
+    ap.add_argument("--index-cache", default=None, help="index file (.kbohip, with its path cover) to load instead of building; "
+                    "written first if it does not exist")
+    args = ap.parse_args(argv)
     if args.call:
         args.genome = args.genome if args.genome is not None else 100_000_000
         args.reads = args.reads if args.reads is not None else 10_000
         args.read_len = args.read_len if args.read_len != 150 else 10_000
         args.custom = True
+        args.scaling = "weak"
         return args
-    preset = {"C2": (5_000_000, 1_000_000, False), "C3": (100_000_000, 10_000_000, True)}[args.config]
+    preset = PRESETS[args.config]
     args.custom = args.genome is not None or args.reads is not None
     args.genome = args.genome if args.genome is not None else preset[0]
     args.reads = args.reads if args.reads is not None else preset[1]
     args.find = args.find or (preset[2] and not args.custom)
+    args.scaling = preset[3]
     return args
 
 
@@ -82,64 +105,304 @@ def usable_cores():
     return n, note
 
 
-def cpu_baseline_leg(args, genome, concat, offsets, gpu_d, gpu_chars, sbwt=None):
-    """Times the oracle (C restatement of the reference algorithm, sbwt-like layout) on a
-    bounded sample of the same reads with all host cores, checks the GPU output against
-    it, and returns (cpu_baseline dict, B_alg bytes/base, bit_exact)."""
+# ---------------------------------------------------------------------------------------------- index: build once, cache
+
+def cache_path(args):
+    if args.index_cache:
+        return args.index_cache
+    d = os.environ.get("KBO_BENCH_CACHE_DIR", "/tmp")
+    return os.path.join(d, f"kbo_bench_iid_{args.genome}_k{args.k}{'_noplan' if args.no_plan else ''}.kbohip")
+
+
+def build_or_load_index(args, threads, may_build=True):
+    """-> (genome, sbwt).  The index file carries the path cover (kbo_index_save), so a rank that loads it uploads after a
+    few streaming passes instead of repeating the build and the cover's pointer chase."""
+    import kbo_amd
+    from kbo_amd import index as kindex, synth
+    genome = synth.genome(args.genome)
+    path = cache_path(args)
+    if os.path.exists(path):
+        try:
+            sbwt, _ = kindex.load_flat(path)
+            if sbwt.k() == args.k and sbwt.n_kmers() > 0:
+                return genome, sbwt
+        except Exception as e:  # (a stale or torn file: build again)
+            print(f"[bench] index cache {path} unusable ({e}); rebuilding", file=sys.stderr)
+    if not may_build:
+        raise SystemExit(f"bench.py: index cache {path} missing")
+    sbwt, _ = kbo_amd.build([genome], kbo_amd.BuildOpts(k=args.k, num_threads=min(16, max(1, threads))))
+    try:
+        tmp = f"{path}.{os.getpid()}.tmp"
+        kindex.save_flat(tmp, sbwt)  # (computes the cover while the plan is enabled)
+        os.replace(tmp, path)
+    except Exception as e:
+        print(f"[bench] could not write the index cache {path}: {e}", file=sys.stderr)
+    return genome, sbwt
+
+
+def shard(args, rank, world):
+    """-> (reads of this rank, index of its first read).  weak scaling (C2, C3): args.reads per rank; strong (C4):
+    args.reads in all, contiguous ranges; the shards tile the read set exactly (tests/test_dist_gloo.py)."""
+    if args.scaling == "strong":
+        per_rank = (args.reads + world - 1) // world
+        first = rank * per_rank
+        return max(0, min(per_rank, args.reads - first)), first
+    return args.reads, rank * args.reads
+
+
+def spawn_command(args, argv, port):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    if not args.index_cache:
+        cmd += ["--index-cache", cache_path(args)]
+    return cmd
+
+
+def spawn_ranks(args, argv):
+    """--gpus N > 1 from a plain `python bench.py`: build the cache here (host only), start N ranks, relay their output."""
+    import kbo_amd
+    if args.no_plan:
+        kbo_amd.lib().kbo_set_plan(0, 0, 0)
+    cores, _ = usable_cores()
+    build_or_load_index(args, cores)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = spawn_command(args, argv, port)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------- oracle-side legs (rank 0)
+
+def cpu_baseline_leg(args, oi, concat, offsets, gpu_d, gpu_chars):
+    """Times the oracle (C restatement of the reference algorithm, sbwt-like layout) on a bounded sample of the same reads
+    with all host cores, checks the GPU output against it, and returns (cpu_baseline dict, B_ref bytes/base, bit_exact, ops)."""
     from oracle import binding as ora
     cores, cores_note = usable_cores()
-    if len(genome) <= 20_000_000 or sbwt is None:
-        oi = ora.Index.build([genome.tobytes()], k=args.k)
-    else:
-        # the oracle's own row-sorting builder needs minutes and > 30 B/base beyond ~20 Mbp; for the
-        # large configs it adopts the product-built index (builder equality is a separate CPU test)
-        rows, Carr, lcs = sbwt.export_parts()
-        oi = ora.Index.from_parts(args.k, sbwt.n_sets(), sbwt.n_kmers(), rows, Carr, lcs)
     L = args.read_len
-    # calibration slice (also warms the index), then a sample sized to the time budget: as many of the reads as fit,
-    # walked `passes` times by a pinned thread pool after an untimed warm-up pass (oracle/kbo_oracle.c
-    # ora_matches_batch_timed: outputs allocated and touched beforehand, reads handed out dynamically)
-    n0 = min(args.reads, 20_000)
+    n_all = len(offsets) - 1
+    # calibration slice (also warms the index), then a sample sized to the time budget, walked by a pinned thread pool after
+    # an untimed warm-up pass (oracle/kbo_oracle.c ora_matches_batch_timed: outputs allocated and touched beforehand, reads
+    # handed out dynamically).  Three timed runs of `passes` passes each: the MEDIAN is quoted (one run is noisy on a
+    # shared box: round 2's driver saw 696 Mbp/s where the builder saw 453 - 688).
+    n0 = min(n_all, 20_000)
     _, _, dt0 = oi.matches_batch_timed(concat[:n0 * L], offsets[:n0 + 1], 1e-7, n_threads=cores, passes=1)
     dt0 = max(dt0, 1e-4)
-    n1 = int(min(args.reads, max(n0, n0 * args.cpu_seconds / dt0)))
-    passes = int(max(1, min(50, args.cpu_seconds / max(dt0 * n1 / n0, 1e-3))))
-    chars, d, sec = oi.matches_batch_timed(concat[:n1 * L], offsets[:n1 + 1], 1e-7, n_threads=cores, passes=passes)
-    dt = sec / passes
+    budget = 0.6 * args.cpu_seconds / 3.0
+    n1 = int(min(n_all, max(n0, n0 * budget / dt0)))
+    passes = int(max(1, min(50, budget / max(dt0 * n1 / n0, 1e-3))))
+    rates, sec_all = [], 0.0
+    chars = d = None
+    for _ in range(3):
+        chars, d, sec = oi.matches_batch_timed(concat[:n1 * L], offsets[:n1 + 1], 1e-7, n_threads=cores, passes=passes)
+        rates.append(n1 * L * passes / sec / 1e6)
+        sec_all += sec
+    allcore = float(np.median(rates))
     # operation counts of the reference algorithm (separate, untimed, counted run)
     ctr = ora.Counters()
     nc = min(n1, 50_000)
     oi.matches_batch(concat[:nc * L], offsets[:nc + 1], 1e-7, n_threads=cores, counters=ctr)
     c = ctr.as_dict()
-    b_alg = (64.0 * c["rank_blocks"] + 1.0 * c["lcs_reads"]) / c["bases"] + 2.0
+    b_ref = (64.0 * c["rank_blocks"] + 1.0 * c["lcs_reads"]) / c["bases"] + 2.0
     exact = bool(np.array_equal(d, gpu_d[:n1 * L]) and np.array_equal(chars, gpu_chars[:n1 * L]))
-    # single-thread rate of the same restatement (SURVEY.md section 8(d) asks for both), same driver, ~1 s sample
-    ns = int(max(1, min(n1, 2_000_000 // L)))
-    _, _, sec1 = oi.matches_batch_timed(concat[:ns * L], offsets[:ns + 1], 1e-7, n_threads=1, passes=1, want_d=False)
-    single = ns * L / max(sec1, 1e-6) / 1e6
-    allcore = n1 * L / dt / 1e6
+    # single-thread rate of the same restatement (SURVEY.md section 8(d) asks for both): same driver, ~ a quarter of the budget,
+    # median of three runs as well
+    t1 = 0.3 * args.cpu_seconds / 3.0
+    ns = int(max(2_000, min(n1, n0 * t1 / (dt0 * cores))))
+    singles = []
+    for _ in range(3):
+        _, _, sec1 = oi.matches_batch_timed(concat[:ns * L], offsets[:ns + 1], 1e-7, n_threads=1, passes=1, want_d=False)
+        singles.append(ns * L / max(sec1, 1e-6) / 1e6)
+    single = float(np.median(singles))
     base = {"value": round(allcore, 3), "unit": "Mbp/s", "cores": cores, "kind": "port",
-            "single_thread_value": round(single, 3),
+            "runs_mbps": [round(r, 1) for r in rates],
+            "single_thread_value": round(single, 3), "single_thread_runs_mbps": [round(r, 1) for r in singles],
             "scaling_efficiency": round(allcore / max(single * cores, 1e-9), 3), "cores_note": cores_note,
-            "sample": f"first {n1} of the {args.reads} reads ({n1 * L / 1e6:.1f} Mbp) x {passes} timed passes after a warm-up "
-                      f"pass, oracle/kbo_oracle.c ora_matches_batch_timed on a pool of {cores} pinned threads, "
-                      f"{sec:.1f} s wall ({sec * cores:.0f} core-seconds)"}
+            "sample": f"first {n1} of the {n_all} reads ({n1 * L / 1e6:.1f} Mbp), median of 3 runs of {passes} timed passes each after a "
+                      f"warm-up pass, oracle/kbo_oracle.c ora_matches_batch_timed on a pool of {cores} pinned threads, "
+                      f"{sec_all:.1f} s wall ({sec_all * cores:.0f} core-seconds); single thread: {ns} reads, median of 3"}
     ops = {k: round(v / c["bases"], 4) for k, v in c.items() if k != "bases"}
-    return base, b_alg, exact, ops
+    return base, b_ref, exact, ops
+
+
+def stage_model_leg(args, sbwt, oi, concat, offsets, gpu_d, n_sample=2_000_000):
+    """The CPU model of the plan-guided stage (oracle/plan_model.c, pinned to the kernels' own counters by
+    tests/test_gpu_model.py) over the timed reads: its MS values are checked against the GPU's, its work counts give the
+    stage's compulsory bytes per base (B_plan) and the distinct 128-byte lines a unit touches."""
+    from oracle import binding as ora
+    cores, _ = usable_cores()
+    n = min(len(offsets) - 1, n_sample)
+    L = args.read_len
+    P = ora.shipped_plan_params(args.k, sbwt.n_sets())
+    ms, cn = oi.plan_model(sbwt.path_cover(), P, concat[:n * L], offsets[:n + 1], n_threads=cores)
+    same = bool(np.array_equal(ms, gpu_d[:n * L]))
+    iters = cn["walk_accepted"] + cn["walk_failed"] + cn["walk_contractions"]
+    by = {
+        # plan_kernel's streams: the queries, the text of their diagonals, the predicted MS values
+        "streams": cn["bases"] + 2 * cn["compare_bases"],
+        # item records: WalkItem read, GuidedItem written and read by count + emit, redo flag, unit counts through the scan,
+        # mismatch lists written once and read twice
+        "item_records": cn["items"] * (16 + 16 + 32 + 1 + 8 + 16) + 6 * max(0, cn["mismatches"] - cn["items"] + cn["items_unseeded"]),
+        "seeds": 8 * cn["seed_lookups"] + 32 * cn["seed_extensions"] + 4 * cn["pos_lookups"],
+        # a unit: record written and read, start row, two query blocks, its output bytes
+        "unit_records": cn["units"] * (32 + 32 + 32) + 4 * cn["node_lookups"] + cn["walk_out_bytes"],
+        # the walk: two 16-byte loads per iteration (rank blocks or entries); over recovery lines two rank blocks + two LCS
+        # windows per iteration, two entries per level taken from the entries
+        "walk": (64 * cn["walk_iterations_lines"] + 32 * cn["walk_entry_levels"]) if P.recovery_lines else 32 * iters,
+        "redo": 16 * cn["items_flagged"] + 32 * cn["redo_iterations"] + 2 * cn["redo_bases"],
+    }
+    total = float(sum(by.values()))
+    per_base = {k: round(v / cn["bases"], 4) for k, v in by.items()}
+    units = max(1, cn["units"])
+    summary = {
+        "sample_reads": n, "ms_equal_to_gpu": same, "gave_up": bool(cn["gave_up"]), "form": "recovery lines" if P.recovery_lines else "rank blocks + entries",
+        "parameters": {"seed_table_depth": P.seed_table_depth, "seed_depth": P.seed_depth, "gap": P.gap, "chunk": P.chunk,
+                       "list_cap": P.list_cap, "bail_x16": P.bail_x16},
+        "units_per_read": round(cn["units"] / cn["items"], 4), "unseeded_reads": cn["items_unseeded"], "flagged_reads": cn["items_flagged"],
+        "seed_extensions_per_read": round(cn["seed_extensions"] / cn["items"], 3),
+        "per_unit": {"accepted": round(cn["walk_accepted"] / units, 3), "failed": round(cn["walk_failed"] / units, 3),
+                     "contraction_levels": round(cn["walk_contractions"] / units, 3),
+                     "entry_levels": round(cn["walk_entry_levels"] / units, 3),
+                     "iterations": round((cn["walk_iterations_lines"] if P.recovery_lines else iters) / units, 3),
+                     "distinct_lines": round(cn["unit_distinct_lines"] / units, 3)},
+        "bytes_per_base": per_base,
+    }
+    return total / cn["bases"], summary, cn
+
+
+def run_batch(dev, stream, find, steps, warmup, torch, device):
+    """warm-up + timed steps of one resident batch -> (elapsed s, a1 ms, a5/a6 ms, rle ms | None)"""
+    for _ in range(warmup):
+        dev.run(stream)
+        if find:
+            dev.run_lengths(0, stream)
+    torch.cuda.synchronize(device)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+    t0 = time.perf_counter()
+    for s in range(steps):
+        ev[s][0].record(stream)
+        dev.walk(stream)
+        ev[s][1].record(stream)
+        dev.derand_translate(stream)
+        ev[s][2].record(stream)
+        if find:
+            dev.run_lengths(0, stream)
+        ev[s][3].record(stream)
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    return (elapsed, float(np.mean([e[0].elapsed_time(e[1]) for e in ev])), float(np.mean([e[1].elapsed_time(e[2]) for e in ev])),
+            float(np.mean([e[2].elapsed_time(e[3]) for e in ev])) if find else None)
+
+
+def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream):
+    """SURVEY.md 8(d) asks for 0 % and 5 % variants of C2; VERDICT adds what the iid forward reads hide: reads from the
+    other strand (the index has no reverse complements), reads from elsewhere, a repeat-rich genome of many contigs.  Each:
+    a resident batch of the C2 shape, 2 warm-up + 5 timed steps, every one of its first 20 000 reads against the oracle."""
+    import kbo_amd
+    from kbo_amd import batch, synth
+    from oracle import binding as ora
+    cores, _ = usable_cores()
+    n_reads, L = min(args.reads, 1_000_000), args.read_len
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+
+    def measure(name, ix, o, concat, offsets, note):
+        dev = batch.DeviceBatch(ix, concat, offsets, device=device, format=True)
+        elapsed, a1, dt, _ = run_batch(dev, stream, False, 5, 2, torch, device)
+        st = dev.plan_stats(stream)
+        dev.format = False
+        dev.derand_translate(stream)
+        torch.cuda.synchronize(device)
+        n_chk = min(n_reads, 20_000)
+        exp_chars, exp_d = o.matches_batch(concat[:n_chk * L], offsets[:n_chk + 1], 1e-7, n_threads=cores, want_d=True)
+        ok = bool(np.array_equal(dev.ms[:n_chk * L].cpu().numpy(), exp_d) and np.array_equal(dev.chars[:n_chk * L].cpu().numpy(), exp_chars))
+        del dev
+        return {"variant": name, "value": round(n_reads * L * 5 / elapsed / 1e6, 1), "unit": "Mbp/s", "a1_stage_ms": round(a1, 4),
+                "derand_translate_ms": round(dt, 4), "bit_exact_vs_oracle": ok, "note": note}
+
+    out = []
+    L_ = kbo_amd.lib()
+    for sub in (0.0, 0.05):
+        L_.kbo_set_plan(1, 0, 0)  # (every variant starts with a clean hold-off)
+        concat, offsets = synth.reads(genome, n_reads, L, sub, seed=0x5E115 + int(sub * 1000))
+        out.append(measure(f"{sub * 100:g}% substitutions", sbwt, oi, concat, offsets,
+                           "above ~4 % the stage gives the plan up on the device and walks plainly (and holds planning off)" if sub > 0.04 else
+                           "error-free: plan_kernel alone, nothing to walk"))
+    L_.kbo_set_plan(1, 0, 0)
+    concat, offsets = synth.reads(genome, n_reads, L, 0.01, seed=0x5E117)
+    rc = comp[concat.reshape(-1, L)[:, ::-1]].reshape(-1).copy()
+    out.append(measure("reverse-strand reads, 1% substitutions", sbwt, oi, rc, offsets,
+                       "the index holds one strand (BuildOpts::add_revcomp=false, the crate default): nothing seeds, plain walk"))
+    L_.kbo_set_plan(1, 0, 0)
+    other = synth.genome(args.genome, seed=0xBADC0DE)
+    concat, offsets = synth.reads(other, n_reads, L, 0.0, seed=0x5E118)
+    out.append(measure("unrelated reads", sbwt, oi, concat, offsets, "reads of another random genome: MS values of 10 - 13 everywhere"))
+    del other
+    # a repeat-rich genome of many contigs: 40 contigs, a fifth of every contig copied from elsewhere, short tandem arrays
+    L_.kbo_set_plan(1, 0, 0)
+    rng = np.random.default_rng(0x5E119)
+    base = synth.genome(args.genome, seed=0x5E11A)
+    contigs = []
+    clen = max(2 * L, args.genome // 40)
+    for c in range(40):
+        piece = base[c * clen:(c + 1) * clen].copy()
+        if len(piece) < 2 * L:
+            break
+        for _ in range(8):  # copies of 2.5 % of the contig from anywhere in the genome
+            n = max(L, clen // 40)
+            src = int(rng.integers(0, len(base) - n))
+            dst = int(rng.integers(0, len(piece) - n))
+            piece[dst:dst + n] = base[src:src + n]
+        t0 = int(rng.integers(0, len(piece) - 2000))
+        piece[t0:t0 + 2000] = np.tile(piece[t0:t0 + 50], 40)  # a tandem array
+        contigs.append(piece)
+    rix, _ = kbo_amd.build(contigs, kbo_amd.BuildOpts(k=args.k, num_threads=min(16, cores)))
+    rows, Carr, lcs = rix.export_parts()
+    roi = ora.Index.from_parts(args.k, rix.n_sets(), rix.n_kmers(), rows, Carr, lcs)
+    cat = np.concatenate(contigs)
+    concat, offsets = synth.reads(cat, n_reads, L, 0.01, seed=0x5E11B)
+    e = measure("repeat-rich genome, 40 contigs", rix, roi, concat, offsets,
+                "a fifth of every contig duplicated from elsewhere + tandem arrays: path cover of many paths, units that do not converge "
+                "before the next group go to the redo pass")
+    e["index_n_sets"] = rix.n_sets()
+    out.append(e)
+    L_.kbo_set_plan(1, 0, 0)
+    return out
+
+
+def host_to_host_leg(args, sbwt, genome):
+    """The product entry point a binding calls: kbo_map_batch over pageable host buffers (H2D, kernels, D2H in a three-stage
+    slab pipeline); PCIe-inclusive, never the reported value.  4 x the batch, best of 3."""
+    import kbo_amd
+    from kbo_amd import synth
+    R = min(4 * args.reads, 4_000_000)
+    concat, offsets = synth.reads(genome, R, args.read_len, args.sub_rate)
+    out = np.zeros(len(concat), dtype=np.uint8)
+    L = kbo_amd.lib()
+    best = 1e9
+    for _ in range(4):
+        t0 = time.perf_counter()
+        kbo_amd.check(L.kbo_map_batch(sbwt._h, concat.ctypes.data, offsets.ctypes.data, R, 1e-7, 1, out.ctypes.data))
+        best = min(best, time.perf_counter() - t0)
+    return {"value": round(R * args.read_len / best / 1e6, 1), "unit": "Mbp/s", "entry_point": "kbo_map_batch (format=true)",
+            "reads": R, "ms": round(best * 1e3, 2), "bytes_per_base_over_pcie": 2.0,
+            "note": "pageable numpy buffers in and out, 1 B/base each way; best of 4 calls (the first pays the pinned staging)"}
 
 
 def main_call(args):
-    """kbo call, first pass (variant_calling.rs:266-273) over a batch of long reads resident in HBM: A1 with intervals,
-    then the breakpoint scan; what leaves the device is one 16-byte record per site.  Parity: the sites of the first
-    reads against a host scan of the oracle's MS."""
+    """kbo call, first pass (variant_calling.rs:266-273) over a batch of long reads resident in HBM: the walk in call mode
+    (its lanes run the breakpoint scan); what leaves the device is one 16-byte record per site.  Parity: the sites of
+    every read against the oracle's first pass."""
     import torch
     import kbo_amd
     from kbo_amd import batch, derandomize, synth
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    genome = synth.genome(args.genome)
     cores, _ = usable_cores()
-    sbwt, _ = kbo_amd.build([genome], kbo_amd.BuildOpts(k=args.k, num_threads=min(16, cores)))
+    genome, sbwt = build_or_load_index(args, cores)
     concat, offsets = synth.reads(genome, args.reads, args.read_len, args.sub_rate)
     dev = batch.DeviceBatch(sbwt, concat, offsets, device=device)
     thr = derandomize.random_match_threshold(args.k, sbwt.n_kmers(), 4, 1e-7)
@@ -175,27 +438,18 @@ def main_call(args):
     raw = np.concatenate([sites_h[g * seg:g * seg + min(int(counts[g]), seg)] for g in range(LISTS)]) if n_sites else sites_h[:0]
     raw = raw[raw[:, 0] != 0xFFFFFFFF]  # (void records: kbo_hip.h, kbo_call_walk_dev)
     n_sites = len(raw)
-    # {offset of i, offset of j, row, 0} -> {read, i, j, row}
-    recs = np.stack([raw[:, 0] // args.read_len, raw[:, 0] % args.read_len, raw[:, 1] % args.read_len, raw[:, 2]], axis=1) if n_sites else raw
-    # parity: sites of the first reads vs a host scan (variant_calling.rs:268-273) of the oracle's MS
     exact = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:  # every read: the oracle's first pass of call_variants (ora_call_sites_batch)
         from oracle import binding as ora
         rows, Carr, lcs = sbwt.export_parts()
         oi = ora.Index.from_parts(args.k, sbwt.n_sets(), sbwt.n_kmers(), rows, Carr, lcs)
-        n_chk = min(args.reads, 40)
-        want = set()
-        for r in range(n_chk):
-            q = concat[r * args.read_len:(r + 1) * args.read_len].tobytes()
-            d, lo, hi = oi.matching_statistics(q)
-            for i in range(1, len(q)):
-                if d[i] < d[i - 1] and d[i - 1] >= thr and d[i] < thr:
-                    for j in range(i + 1, min(i + args.k + 1, len(q))):
-                        if d[j] >= thr and hi[j] - lo[j] == 1:
-                            want.add((r, i, j, int(lo[j])))
-                            break
-        got = {tuple(int(v) for v in x) for x in recs if x[0] < n_chk}
-        exact = got == want and fits
+        recs = oi.call_sites_batch(concat, offsets, thr, n_threads=cores)
+        base = offsets[recs[:, 0].astype(np.int64)]
+        want = np.stack([base + recs[:, 1], base + recs[:, 2], recs[:, 3]], axis=1).astype(np.uint64)
+        got = raw[:, :3].astype(np.uint64)
+        want = want[np.lexsort(want.T[::-1])]
+        got = got[np.lexsort(got.T[::-1])]
+        exact = bool(fits and want.shape == got.shape and np.array_equal(want, got))
     bases = dev.total
     print(json.dumps({
         "metric": f"query Mbp/sec for kbo call first pass (MS walk whose lanes run the breakpoint scan; sites only leave the device), k={args.k}, "
@@ -207,11 +461,15 @@ def main_call(args):
                                f"{args.reads} x {args.read_len} bp reads, {args.sub_rate * 100:g}% substitutions",
                    "threshold": thr, "sites_per_step": n_sites, "bytes_leaving_the_device_per_base": round(16 * n_sites / bases, 4)},
         "kernels_ms": {"ms_walk_call_mode": round(walk_ms, 4)},
-        "bit_exact_vs_oracle": exact}), flush=True)
+        "bit_exact_vs_oracle": exact, "parity_scope": "sites of every read vs the oracle's first pass of call_variants"}), flush=True)
 
 
-def main():
-    args = parse()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "RANK" not in os.environ and not args.call:
+        # (this process never initialises a GPU: it builds the index cache and waits for its children)
+        raise SystemExit(spawn_ranks(args, argv))
     if args.call:
         return main_call(args)
     import torch
@@ -237,20 +495,37 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)  # RCCL; used for barrier + max only
 
+    L = kbo_amd.lib()
     if args.waves_per_cu:
-        kbo_amd.lib().kbo_set_walk_waves_per_cu(args.waves_per_cu)
+        L.kbo_set_walk_waves_per_cu(args.waves_per_cu)
     if args.no_plan:
-        kbo_amd.lib().kbo_set_plan(0, 0, 0)
+        L.kbo_set_plan(0, 0, 0)
 
-    # ---- inputs (deterministic); index replicated, reads sharded by rank
-    genome = synth.genome(args.genome)
+    # ---- index: replicated.  Rank 0 builds it once (or finds the cache a parent / an earlier run left) and writes the
+    # cache, path cover included; the other ranks load it
     threads = max(1, usable_cores()[0] // max(1, world))  # (the ranks of a node share the container's CPU quota)
-    sbwt, _ = kbo_amd.build([genome], kbo_amd.BuildOpts(k=args.k, num_threads=min(16, threads)))
-    concat, offsets = synth.reads(genome, args.reads, args.read_len, args.sub_rate,
-                                  first_read=rank * args.reads)
-    dev = batch.DeviceBatch(sbwt, concat, offsets, device=device, format=not args.find)
-    bases = args.reads * args.read_len
+    t_index = time.perf_counter()
+    if world > 1:
+        if rank == 0:
+            genome, sbwt = build_or_load_index(args, usable_cores()[0])
+        dist.barrier()
+        if rank != 0:
+            genome, sbwt = build_or_load_index(args, threads, may_build=not os.path.exists(cache_path(args)))
+    else:
+        genome, sbwt = build_or_load_index(args, threads)
+    t_index = time.perf_counter() - t_index
+
+    # ---- reads: sharded by rank.  weak scaling (C2, C3): args.reads per rank; strong (C4): args.reads in all
+    n_mine, first = shard(args, rank, world)
     stream = torch.cuda.current_stream(device)
+    slabs = []
+    for s0 in range(0, n_mine, SLAB_READS):
+        ns = min(SLAB_READS, n_mine - s0)
+        concat, offsets = synth.reads(genome, ns, args.read_len, args.sub_rate, first_read=first + s0)
+        slabs.append(batch.DeviceBatch(sbwt, concat, offsets, device=device, format=not args.find))
+        if s0 == 0:
+            concat0, offsets0 = concat, offsets  # (rank 0's parity gate and CPU baseline use the first slab)
+    bases = n_mine * args.read_len
 
     def sync_all():
         torch.cuda.synchronize(device)
@@ -258,60 +533,78 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        dev.run(stream)
-        if args.find:
-            dev.run_lengths(0, stream)
-    sync_all()
+    def one_step(events=None):
+        for i, dev in enumerate(slabs):
+            if events is not None:
+                events[i][0].record(stream)
+            dev.walk(stream)
+            if events is not None:
+                events[i][1].record(stream)
+            dev.derand_translate(stream)
+            if events is not None:
+                events[i][2].record(stream)
+            if args.find:  # kbo::find (lib.rs:816-820): run lengths of the characters, still on the device
+                dev.run_lengths(0, stream)
+            if events is not None:
+                events[i][3].record(stream)
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    for _ in range(args.warmup):
+        one_step()
+    sync_all()
+    ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in slabs] for _ in range(args.steps)]
     t0 = time.perf_counter()
     for s in range(args.steps):
-        ev[s][0].record(stream)
-        dev.walk(stream)
-        ev[s][1].record(stream)
-        dev.derand_translate(stream)
-        ev[s][2].record(stream)
-        if args.find:  # kbo::find (lib.rs:816-820): run lengths of the characters, still on the device
-            dev.run_lengths(0, stream)
-        ev[s][3].record(stream)
+        one_step(ev[s])
     sync_all()
     elapsed = time.perf_counter() - t0
-    walk_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    dt_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-    rle_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev])) if args.find else None
+    walk_ms = float(np.mean([sum(e[0].elapsed_time(e[1]) for e in step) for step in ev]))
+    dt_ms = float(np.mean([sum(e[1].elapsed_time(e[2]) for e in step) for step in ev]))
+    rle_ms = float(np.mean([sum(e[2].elapsed_time(e[3]) for e in step) for step in ev])) if args.find else None
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if not one_gpu or world == 1 else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     # per-rank stage times (skew between ranks shows here)
-    per_rank = torch.tensor([walk_ms, dt_ms], dtype=torch.float64, device=device)
+    per_rank_t = torch.tensor([walk_ms, dt_ms], dtype=torch.float64, device=t.device)
     if world > 1:
-        gathered = [torch.zeros_like(per_rank) for _ in range(world)]
-        dist.all_gather(gathered, per_rank)
+        gathered = [torch.zeros_like(per_rank_t) for _ in range(world)]
+        dist.all_gather(gathered, per_rank_t)
         walk_all = [float(g[0].item()) for g in gathered]
     else:
         walk_all = [walk_ms]
+    total_bases = args.reads * args.read_len if args.scaling == "strong" else world * bases
 
     result = None
     if rank == 0:
+        dev = slabs[0]
+        stats = dev.plan_stats(stream)
         gpu_d = dev.ms.cpu().numpy()
-        cpu, b_alg, exact, ops = None, None, None, None
+        cpu = b_ref = exact = ops = b_plan = model = None
+        sens = h2h = None
+        planned = (not args.no_plan) and sbwt.device_plan_bytes() > 0
         if not args.no_cpu_baseline:
-            # parity gate (rank 0's shard) + CPU baseline on the unformatted characters, at every world size
+            from oracle import binding as ora
+            rows, Carr, lcs = sbwt.export_parts()
+            # (the oracle adopts the product-built index: its own row-sorting builder needs minutes and > 30 B/base beyond
+            # ~20 Mbp; builder equality is tests/test_builder_vs_oracle.py)
+            oi = ora.Index.from_parts(args.k, sbwt.n_sets(), sbwt.n_kmers(), rows, Carr, lcs)
+            # parity gate (rank 0's first slab) + CPU baseline on the unformatted characters, at every world size
             fmt = dev.format
             dev.format = False
             dev.derand_translate(stream)
             torch.cuda.synchronize(device)
-            cpu, b_alg, exact, ops = cpu_baseline_leg(args, genome, concat, offsets, gpu_d,
-                                                      dev.chars.cpu().numpy(), sbwt)
+            cpu, b_ref, exact, ops = cpu_baseline_leg(args, oi, concat0, offsets0, gpu_d, dev.chars.cpu().numpy())
             dev.format = fmt
-        achieved = b_alg * bases / (walk_ms * 1e-3) / 1e9 if b_alg is not None else None
+            if planned and not stats["gave_up"]:
+                b_plan, model, _ = stage_model_leg(args, sbwt, oi, concat0, offsets0, gpu_d)
+                exact = bool(exact and model["ms_equal_to_gpu"])
+            if world == 1 and not args.no_extras and (args.extras or not args.custom):
+                sens = sensitivity_leg(args, genome, sbwt, oi, torch, device, stream)
+                h2h = host_to_host_leg(args, sbwt, genome)
         # fabric-side traffic and L2 misses of the A1 stage, from the committed rocprofv3 passes of this exact
         # workload and walk mode (PMC passes cannot run inside the timed region: separate runs, tools/profile_bench.sh)
-        planned = (not args.no_plan) and sbwt.device_plan_bytes() > 0
-        wl_key = f"{args.genome}x{args.reads}x{args.read_len}x{args.sub_rate:g}:{'plan' if planned else 'plain'}"
+        wl_key = f"{args.genome}x{n_mine}x{args.read_len}x{args.sub_rate:g}:{'plan' if planned else 'plain'}"
         traffic = tsrc = misses = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
@@ -323,54 +616,70 @@ def main():
                 pass
         rank_b, lcs_b = sbwt.device_bytes()
         pair_b, plan_b = sbwt.device_pair_bytes(), sbwt.device_plan_bytes()
-        resident = rank_b + lcs_b + pair_b < 200e6
-        std = (args.genome, args.reads, args.read_len, args.sub_rate, args.k) in ((5_000_000, 1_000_000, 150, 0.01, 31),
-                                                                                 (100_000_000, 10_000_000, 150, 0.01, 31))
+        std = (args.genome, args.reads, args.read_len, args.sub_rate, args.k) in tuple((g, r, 150, 0.01, 31) for g, r, _, _ in PRESETS.values())
         label = (args.config if std else "custom") + ": " + \
             ("kbo find (max_gap_len=0; run lengths on the device)" if args.find else
              "kbo map (fill_gaps=false, call_variants=false, format=true)")
         a1_kernels = ("plan_kernel + plan_count/scan/emit + ms_walk_guided_kernel (ms_walk_recovery_kernel from 24 Mi rows on) + redo_collect + ms_walk_kernel (flagged reads)"
                       if planned else "ms_walk_kernel")
+        walk_s = walk_ms * 1e-3
+        # what the stage is priced by: its OWN compulsory bytes (B_plan, counted by the model on the timed reads) when it
+        # planned, the reference algorithm's bytes when it walked plainly
+        b_alg = b_plan if b_plan is not None else b_ref
+        achieved = b_alg * bases / walk_s / 1e9 if b_alg is not None else None
+        ref_achieved = b_ref * bases / walk_s / 1e9 if b_ref is not None else None
+        roofline = {
+            "bound": "hbm",
+            "bound_detail": ("L2-miss line fills by their rate and latency: integer gather work, 16 bytes used per 128-byte fill; the guided walk "
+                             "keeps 8-12 waves per CU so that the lines of the lanes in flight stay in L2 (DESIGN.md sections 4.2, 6)"),
+            "achieved": round(achieved, 1) if achieved is not None else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved is not None else None,
+            "frac_meaning": ("compulsory bytes of the plan-guided stage (B_plan: streams, records, two 16-byte loads per walk iteration; counted on "
+                             "the timed reads by oracle/plan_model.c, whose counts equal the kernels' own counters) / A1 stage time / 8 TB/s"
+                             if b_plan is not None else "reference-algorithm bytes (SURVEY.md 8(d)) / A1 stage time / 8 TB/s"),
+            "algorithmic_bytes_per_base": round(b_alg, 3) if b_alg is not None else None,
+            "units_per_launch": bases, "kernel": "A1 stage = " + a1_kernels, "kernel_ms": round(walk_ms, 4),
+            "kernel_ms_per_rank": {"min": round(min(walk_all), 4), "max": round(max(walk_all), 4)},
+            "traffic": int(traffic) if traffic else None, "traffic_source": tsrc,
+            "traffic_frac": round(traffic / walk_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
+            "wasted_traffic": round(traffic / (b_alg * bases), 3) if traffic and b_alg else None,
+            "l2_miss_per_launch": int(misses) if misses else None,
+            "fill_rate_frac": round(misses / walk_s / FILL_CEILING_PER_S, 4) if misses else None,
+            "fill_rate_ceiling": {"fills_per_s": FILL_CEILING_PER_S, "source": FILL_CEILING_SOURCE},
+            "fills_min_per_unit": model["per_unit"]["distinct_lines"] if model else None,
+            "frac_reference_algorithm": round(ref_achieved / HBM_PEAK_GBPS, 4) if ref_achieved is not None else None,
+            "reference_algorithm_bytes_per_base": round(b_ref, 2) if b_ref is not None else None,
+            "cross_check_whole_step_gbps": round(b_alg * bases / (elapsed / args.steps) / 1e9, 1) if b_alg is not None else None,
+            "stage_model": model,
+            "stage_counters_gpu_first_slab": stats if planned else None,
+        }
         result = {
             "metric": f"query Mbp/sec for kbo {'find' if args.find else 'map'}, k={args.k}, {args.genome / 1e6:g} Mbp SBWT; bit-exact MS vs CPU",
-            "value": round(world * bases * args.steps / elapsed / 1e6, 1),
+            "value": round(total_bases * args.steps / elapsed / 1e6, 1),
             "unit": "Mbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{label}, {args.genome / 1e6:g} Mbp iid genome SBWT k={args.k}, "
-                                   f"{args.reads} x {args.read_len} bp reads per GPU, "
-                                   f"{args.sub_rate * 100:g}% substitutions",
+                                   + (f"{args.reads} x {args.read_len} bp reads in all, {n_mine} per GPU, " if args.scaling == "strong"
+                                      else f"{args.reads} x {args.read_len} bp reads per GPU, ")
+                                   + f"{args.sub_rate * 100:g}% substitutions",
                        "index_n_sets": sbwt.n_sets(), "threshold": dev.threshold,
                        "walk": "plan-guided (path cover + guided walk)" if planned else "plain",
                        "index_device_bytes": {"rank_blocks": rank_b, "lcs": lcs_b, "two_base_blocks": pair_b,
-                                              "path_cover": plan_b},
+                                              "path_cover_lines_seed_table": plan_b,
+                                              "per_row": round((rank_b + lcs_b + pair_b + plan_b) / sbwt.n_sets(), 2)},
+                       "resident_slabs_per_gpu": len(slabs), "index_seconds_rank0": round(t_index, 2),
                        "parallelism": f"index replicated x{world}, reads sharded, no collective"},
-            "roofline": {
-                # SURVEY.md 8(d)'s contract figure: algorithmic bytes of the REFERENCE algorithm (64 B per 512-bit rank
-                # block it would touch + 1 B per LCS element + 2) over the time of the A1 stage.  It is not a
-                # bandwidth utilisation: this stage loads 16-byte rank blocks, and skips the stretches of a read that
-                # match the index's path cover, so frac can exceed 1.  What binds the stage is in `bound`;
-                # traffic_frac is the measured fabric traffic over the same time against the same peak.
-                "bound": ("l2-miss line fills, by their latency: the guided walk keeps 8-12 waves per CU so that the lines of the "
-                          "lanes in flight stay in L2 (DESIGN.md sections 4.2, 6)") if planned else
-                         (("l2-miss line fills (index is L2/Infinity-Cache resident: about 56 G fills/s on this part, "
-                           "DESIGN.md section 6)") if resident else "l2-miss line fills from HBM (about 56 G fills/s, DESIGN.md section 6)"),
-                "achieved": round(achieved, 1) if achieved is not None else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved is not None else None,
-                "frac_meaning": "reference-algorithm bytes / A1 stage time / 8 TB/s (contract figure, may exceed 1)",
-                "traffic": traffic, "traffic_source": tsrc,
-                "traffic_frac": round(traffic / (walk_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
-                "l2_miss_per_base": round(misses / bases, 4) if misses else None,
-                "kernel": "A1 stage = " + a1_kernels, "kernel_ms": round(walk_ms, 4),
-                "kernel_ms_per_rank": {"min": round(min(walk_all), 4), "max": round(max(walk_all), 4)},
-                "algorithmic_bytes_per_base": round(b_alg, 2) if b_alg is not None else None},
+            "roofline": roofline,
             "kernels_ms": {"a1_stage": round(walk_ms, 4), "derand_translate": round(dt_ms, 4),
                            **({"run_lengths": round(rle_ms, 4)} if args.find else {})},
             "cpu_baseline": cpu,
             "bit_exact_vs_oracle": exact,
             "reference_ops_per_base": ops,
+            "sensitivity": sens,
+            "host_to_host": h2h,
         }
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -1,0 +1,56 @@
+"""bench.py end to end on the GPU box, at reduced size: the single-process line (roofline priced by the stage model, CPU
+baseline, sensitivity variants, host-to-host rate) and `--gpus 2` started from a plain `python bench.py` (the parent builds
+the index cache on the host and spawns the ranks; with KBO_BENCH_ONE_GPU=1 both ranks share cuda:0 over gloo - a functional
+test of the multi-process path, its numbers mean nothing)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(args, tmp_path, extra_env=None):
+    env = dict(os.environ, KBO_BENCH_CACHE_DIR=str(tmp_path), **(extra_env or {}))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _check_line(r, n_gpus):
+    assert r["n_gpus"] == n_gpus and r["unit"] == "Mbp/s" and r["higher_is_better"] is True and r["vs_baseline"] is None
+    assert r["bit_exact_vs_oracle"] is True
+    ro = r["roofline"]
+    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0
+    assert 0 < ro["frac"] <= 1.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
+    assert ro["stage_model"]["ms_equal_to_gpu"] is True
+    # the model's counts are the kernels' own (first slab)
+    st, m = ro["stage_counters_gpu_first_slab"], ro["stage_model"]
+    assert abs(st["units"] / st["units_walked"] - 1) < 1e-9 and m["units_per_read"] > 1.0
+    assert ro["cross_check_whole_step_gbps"] <= ro["peak"]
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and len(cb["runs_mbps"]) == 3
+
+
+def test_bench_line_single_process_with_extras(tmp_path):
+    r = _run(["--genome", "400000", "--reads", "30000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1.5", "--extras"], tmp_path)
+    _check_line(r, 1)
+    names = [v["variant"] for v in r["sensitivity"]]
+    assert len(names) == 5 and any("reverse" in n for n in names) and any("repeat" in n for n in names)
+    assert all(v["bit_exact_vs_oracle"] is True and v["value"] > 0 for v in r["sensitivity"])
+    assert r["host_to_host"]["value"] > 0
+
+
+def test_bench_gpus_2_spawns_two_ranks(tmp_path):
+    r = _run(["--gpus", "2", "--genome", "400000", "--reads", "30000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1.5"],
+             tmp_path, {"KBO_BENCH_ONE_GPU": "1"})
+    _check_line(r, 2)
+    assert r["scaling"] == "weak" and "x2" in r["config"]["parallelism"]
+    assert os.path.exists(os.path.join(str(tmp_path), "kbo_bench_iid_400000_k31.kbohip"))  # built once by the parent, loaded by the ranks
+    lo, hi = r["roofline"]["kernel_ms_per_rank"]["min"], r["roofline"]["kernel_ms_per_rank"]["max"]
+    assert 0 < lo <= hi
