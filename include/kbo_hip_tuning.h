@@ -70,6 +70,14 @@ int kbo_index_plan_holdoff(kbo_index_t *idx, int device, uint32_t *bails, int *h
 int kbo_plan_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k, const void *d_work,
                        uint64_t out[KBO_PLAN_STATS], void *stream);
 
+/* test hook: what kbo_call_batch answers the reference-side walks of its sites with (variant_calling.rs:280: the matched
+ * row's k-mer against the index the reference builds of the sequence itself, lib.rs:553) - the depths of the walk of each
+ * of n_kmers k-mers (k bytes each, back to back) against the SBWT of `seq` built with (k, add_revcomp), computed from a
+ * suffix automaton of the sequence's ACGT-runs of at least k characters instead of that index.  Host only (no GPU).
+ * depths_out: n_kmers * k values.  tests/test_capi_host.py compares them with the oracle's walk of a real one-sequence index. */
+int kbo_run_automaton_depths(const uint8_t *seq, size_t len, uint32_t k, int add_revcomp, const uint8_t *kmers,
+                             size_t n_kmers, uint32_t *depths_out);
+
 /* ------------------------------------------------------------------ experiments recorded in DESIGN.md section 6 */
 /* plain walk kernel: only the first lane_limit lanes of every wave take reads (64 = all; what a sub-wave tiling would
  * have to beat), and every workgroup reserves dummy_lds_bytes of LDS it never touches (what staging a wave's MS values

@@ -85,7 +85,7 @@ SYMBOLS = [
 TUNING_SYMBOLS = [
     "kbo_walk_geometry", "kbo_set_walk_waves_per_cu", "kbo_set_walk_threads", "kbo_set_walk_rare", "kbo_set_guided_walk",
     "kbo_set_pair_steps", "kbo_set_force_big_layout", "kbo_set_seed_table_depth", "kbo_set_plan", "kbo_set_plan_tuning",
-    "kbo_set_plan_unit_cap_divisor", "kbo_index_plan_holdoff", "kbo_set_walk_experiment", "kbo_plan_stats_dev",
+    "kbo_set_plan_unit_cap_divisor", "kbo_index_plan_holdoff", "kbo_set_walk_experiment", "kbo_plan_stats_dev", "kbo_run_automaton_depths",
 ]
 
 _lib = None
@@ -177,6 +177,7 @@ def lib():
     L.kbo_set_plan_tuning.argtypes = [C.c_int, C.c_int, C.c_int]
     L.kbo_set_walk_experiment.argtypes = [C.c_int, C.c_int]
     L.kbo_plan_stats_dev.argtypes = [sz, u64, sz, C.c_uint32, vp, vp, vp]
+    L.kbo_run_automaton_depths.argtypes = [vp, sz, C.c_uint32, C.c_int, vp, sz, vp]
     L.kbo_set_plan_unit_cap_divisor.argtypes = [C.c_int]
     L.kbo_set_seed_table_depth.argtypes = [C.c_int]
     L.kbo_index_plan_holdoff.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]

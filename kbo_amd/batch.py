@@ -79,6 +79,38 @@ def call_batch(sbwt, concat, offsets, call_opts=None):
     return [allv[int(vo[s]):int(vo[s + 1])] for s in range(n)]
 
 
+def call_batch_arrays(sbwt, concat, offsets, call_opts=None):
+    """kbo_call_batch without a Python object per variant -> dict of numpy arrays: var_offsets (n_seqs + 1), query_pos,
+    query_len, ref_len (one entry per variant) and chars (per variant its query characters, then its reference
+    characters, back to back in variant order).  variants_of(result, s) turns one sequence's slice into Variant objects."""
+    from . import CallOpts
+    o = call_opts if call_opts is not None else CallOpts()
+    co = _capi.CallOpts(o.max_error_prob, o.sbwt_build_opts._to_c())
+    concat, offsets, n = _prep(concat, offsets)
+    vo = np.zeros(n + 1, dtype=np.uint64)
+    p = C.POINTER(_capi.Variant)()
+    check(lib().kbo_call_batch(sbwt._h, concat.ctypes.data, offsets.ctypes.data, n, C.byref(co), C.byref(p), vo.ctypes.data))
+    nv = int(vo[-1])
+    rec = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(max(1, nv), C.sizeof(_capi.Variant) // 8))[:nv].copy()
+    total = int(rec[:, 2].sum() + rec[:, 4].sum()) if nv else 0
+    base = C.addressof(p.contents) + max(1, nv) * C.sizeof(_capi.Variant)  # (one allocation: records, then the characters)
+    chars = np.ctypeslib.as_array(C.cast(base, C.POINTER(C.c_uint8)), shape=(max(1, total),))[:total].copy()
+    lib().kbo_free(p)
+    return {"var_offsets": vo, "query_pos": rec[:, 0], "query_len": rec[:, 2], "ref_len": rec[:, 4], "chars": chars}
+
+
+def variants_of(res, s):
+    """the variants of sequence s of a call_batch_arrays result as (query_pos, query_chars bytes, ref_chars bytes) tuples"""
+    a, b = int(res["var_offsets"][s]), int(res["var_offsets"][s + 1])
+    start = np.concatenate([[0], np.cumsum(res["query_len"] + res["ref_len"])]).astype(np.int64) if "_starts" not in res else res["_starts"]
+    res["_starts"] = start
+    out = []
+    for v in range(a, b):
+        q0, ql, rl = int(start[v]), int(res["query_len"][v]), int(res["ref_len"][v])
+        out.append((int(res["query_pos"][v]), res["chars"][q0:q0 + ql].tobytes(), res["chars"][q0 + ql:q0 + ql + rl].tobytes()))
+    return out
+
+
 class DeviceBatch:
     """A batch of reads resident in HBM (torch owns the memory, the C ABI gets raw
     pointers and the torch stream).  run() = A1 walk kernel, then fused A5+A6 kernel."""

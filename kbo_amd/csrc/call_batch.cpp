@@ -1,11 +1,13 @@
 // call_batch.cpp — kbo::call (reference lib.rs:547-573, variant_calling.rs:249-294) over a batch of sequences.
 //
 // The first pass of call_variants - the MS walk of every sequence against the index and the breakpoint scan over it -
-// runs on the device for the whole batch (ms_walk_kernel with intervals, call_sites_kernel); only the sites
-// {sequence, i, j, row} come back, about one record per mismatch instead of 9 bytes per base.  The second pass keeps
-// the reference's shape: the k-mers of every site (refine.cpp), the walk of all query-side k-mers against the index
-// in ONE batch, and per sequence (the reference builds an index of every sequence it is called with, lib.rs:553) the
-// walk of its reference-side k-mers against that sequence's own index.
+// runs on the device for the whole batch (the call mode of the walk kernels); only the sites {sequence, i, j, row} come
+// back, about one record per mismatch instead of 9 bytes per base - and with them, gathered by one more kernel while the
+// MS values are still resident, what the second pass needs of the device: the k MS values in front of every match (the
+// walk of the query-side k-mer, variant_calling.rs:279, is a function of them) and the k characters of the matched row
+// (access_kmer, :276, read off the path cover).  What is left for the host is the walk of that row's k-mer against the
+// index of the sequence itself (:280; the reference builds one per call, lib.rs:553) - answered by a suffix automaton of
+// the sequence instead of an SBWT of it, see RunAutomaton - and resolve_variant.
 #include "capi_internal.hpp"
 
 #include <algorithm>
@@ -37,67 +39,33 @@ struct SiteRec {
     uint32_t seq, i, j, lo;
 };
 
-// MS values (no intervals) of a list of equally long k-mers against `idx`, one GPU batch
-void ms_only(kbo_index *idx, const std::vector<std::vector<uint8_t>> &seqs, std::vector<std::vector<kbo::MsVal>> &out)
-{
-    out.assign(seqs.size(), {});
-    if (seqs.empty()) return;
-    std::vector<uint64_t> off(seqs.size() + 1, 0);
-    for (size_t s = 0; s < seqs.size(); s++) off[s + 1] = off[s] + seqs[s].size();
-    std::vector<uint8_t> concat(off.back());
-    for (size_t s = 0; s < seqs.size(); s++) std::memcpy(concat.data() + off[s], seqs[s].data(), seqs[s].size());
-    std::vector<uint8_t> d(off.back() + 16);
-    ms_batch_impl(idx, concat.data(), off.data(), seqs.size(), d.data(), nullptr, nullptr);
-    for (size_t s = 0; s < seqs.size(); s++) {
-        out[s].resize(seqs[s].size());
-        for (size_t i = 0; i < seqs[s].size(); i++) out[s][i] = kbo::MsVal{d[off[s] + i], 0u, 0u};
-    }
-}
+// What the second pass of a batch needs per site, gathered on the device right behind the first pass (call_kernels.hip
+// call_gather_kernel): the k MS values ending at the match and the k characters of the matched row.
+struct SiteWindows {
+    std::vector<SiteRec> recs;   // in arrival order
+    std::vector<uint8_t> win;    // recs.size() records of `stride` bytes
+    uint32_t stride = 0, kpad = 0;
+};
 
-// the same for the few k-mers of one sequence against that sequence's own index, from a pool thread of kbo_call_batch: the
-// calling thread's own buffers and stream, no slabs, no pinned staging, no shared worker team (a millisecond of fixed
-// costs per call that all threads would queue for)
-// (device buffers kept per host thread; DevBuf::ensure gives a thread that has moved to another device fresh memory)
-BatchOnDevice &small_batch_buffers()
-{
-    static thread_local BatchOnDevice B;
-    return B;
-}
-void ms_only_small(kbo_index *idx, const std::vector<std::vector<uint8_t>> &seqs, std::vector<std::vector<kbo::MsVal>> &out)
-{
-    out.assign(seqs.size(), {});
-    if (seqs.empty()) return;
-    BatchOnDevice &B = small_batch_buffers();
-    static thread_local std::vector<uint64_t> off;
-    static thread_local std::vector<uint8_t> concat, d;
-    off.assign(seqs.size() + 1, 0);
-    for (size_t s = 0; s < seqs.size(); s++) off[s + 1] = off[s] + seqs[s].size();
-    concat.resize(off.back());
-    for (size_t s = 0; s < seqs.size(); s++) std::memcpy(concat.data() + off[s], seqs[s].data(), seqs[s].size());
-    d.resize(off.back() + 16);
-    hipStream_t stream = nullptr; // (the thread's default stream: every call below is synchronous for this thread anyway)
-    run_walk_host(idx, concat.data(), off.data(), seqs.size(), false, B, stream);
-    HIP_OK(hipMemcpy(d.data(), B.ms.p, off.back(), hipMemcpyDeviceToHost));
-    for (size_t s = 0; s < seqs.size(); s++) {
-        out[s].resize(seqs[s].size());
-        for (size_t i = 0; i < seqs[s].size(); i++) out[s][i] = kbo::MsVal{d[off[s] + i], 0u, 0u};
-    }
-}
-
-// first pass on the device: sites of sequences [0, n_seqs), sorted by (sequence, i).  Normally the walk itself finds them
+// first pass on the device: sites of sequences [0, n_seqs) with their windows.  Normally the walk itself finds them
 // (call mode of ms_walk_kernel: no intervals are written at all); a slab in which a lane had more than four breakpoints
 // waiting at once, or whose site lists overflowed, is done again the long way (walk with intervals + call_sites_kernel).
-std::vector<SiteRec> find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, uint32_t threshold)
+SiteWindows find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, uint32_t threshold)
 {
-    std::vector<SiteRec> all;
+    SiteWindows all;
+    const uint32_t k = idx->host.k;
+    all.stride = kbo::call_gather_stride(k);
+    all.kpad = (k + 15u) / 16u * 16u;
     hipStream_t stream = nullptr;
     const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
-    DevBuf d_sites, d_count;
+    DevBuf d_sites, d_count, d_compact, d_win;
     const size_t count_bytes = kbo::kCallSegs * 64 + 64;
     d_count.alloc(count_bytes);
     std::vector<uint32_t> counts(count_bytes / 4);
     struct Raw { uint32_t a, b, c, d; };
     std::vector<Raw> raw;
+    std::vector<uint32_t> compact;
+    const kbo::DevIndexView view = device_view(idx, current_device());
     for (const Slab &sl : slabs) {
         const size_t ns = sl.s1 - sl.s0;
         std::vector<uint64_t> off(ns + 1);
@@ -131,6 +99,8 @@ std::vector<SiteRec> find_sites(kbo_index *idx, const uint8_t *concat, const uin
                 cap = (uint32_t)std::min<uint64_t>((uint64_t)(worst + 16) * kbo::kCallSegs, 0x7FFFFF00u);
                 continue;
             }
+            const size_t first_new = all.recs.size();
+            compact.clear();
             for (uint32_t g = 0; g < kbo::kCallSegs; g++) {
                 const uint32_t n = counts[g * 16];
                 if (!n) continue;
@@ -140,22 +110,129 @@ std::vector<SiteRec> find_sites(kbo_index *idx, const uint8_t *concat, const uin
                     if (by_walk && x.a == 0xFFFFFFFFu) continue; // (a site of an item that the redo pass scanned again)
                     if (by_walk) { // {slab offset of i, of j, row}: find the sequence
                         const size_t s = (size_t)(std::upper_bound(off.begin(), off.end(), (uint64_t)x.a) - off.begin()) - 1;
-                        all.push_back(SiteRec{(uint32_t)(sl.s0 + s), (uint32_t)(x.a - off[s]), (uint32_t)(x.b - off[s]), x.c});
+                        all.recs.push_back(SiteRec{(uint32_t)(sl.s0 + s), (uint32_t)(x.a - off[s]), (uint32_t)(x.b - off[s]), x.c});
+                        compact.push_back(x.b);
+                        compact.push_back(x.c);
                     } else {
-                        all.push_back(SiteRec{(uint32_t)(sl.s0 + x.a), x.b, x.c, x.d});
+                        all.recs.push_back(SiteRec{(uint32_t)(sl.s0 + x.a), x.b, x.c, x.d});
+                        compact.push_back((uint32_t)(off[x.a] + x.c));
+                        compact.push_back(x.d);
                     }
                 }
+            }
+            // the windows of this slab's sites, while its MS values are still on the device
+            const size_t n_new = all.recs.size() - first_new;
+            if (n_new) {
+                d_compact.ensure(n_new * 8);
+                d_win.ensure(n_new * (size_t)all.stride);
+                HIP_OK(hipMemcpyAsync(d_compact.p, compact.data(), n_new * 8, hipMemcpyHostToDevice, stream));
+                HIP_OK(kbo::launch_call_gather(d_compact.p, (uint32_t)n_new, k, B.ms.as<uint8_t>(), view, d_win.as<uint8_t>(), all.stride, stream));
+                all.win.resize(all.recs.size() * (size_t)all.stride);
+                HIP_OK(hipMemcpyAsync(all.win.data() + first_new * (size_t)all.stride, d_win.p, n_new * (size_t)all.stride,
+                                      hipMemcpyDeviceToHost, stream));
+                HIP_OK(hipStreamSynchronize(stream));
             }
             break;
         }
     }
-    std::sort(all.begin(), all.end(), [](const SiteRec &a, const SiteRec &b) { return a.seq != b.seq ? a.seq < b.seq : a.i < b.i; });
     return all;
 }
 
-} // namespace
+// ---- the reference-side walk of a site (variant_calling.rs:280: the matched row's k-mer against the index of the sequence
+// itself, which the reference builds per call, lib.rs:553) without building that index.
+// What resolve_variant reads of that walk are the depths only, and the depth at position t is the length of the longest
+// suffix of kmer[0 ..= t] (at most k) that is a suffix of some row of the sequence's SBWT.  The ACGT suffixes of that index's
+// rows are exactly the substrings (of at most k characters) of the sequence's ACGT-runs of at least k characters: a row is
+// a k-mer of such a run or a $-padded prefix of one, and every substring of a run ends some k-mer or padded prefix of it
+// (shorter runs contribute no rows; index.rs:73-94 / SURVEY.md section 8(a) A0).  With add_revcomp the reverse complements
+// of those runs count as well.  So the depths are plain matching statistics of the k-mer against those runs: a suffix
+// automaton of the runs (linear in the sequence, a few hundred KB for a 10 kbp read) answers them in k steps per site,
+// where building, uploading and walking a one-sequence SBWT cost 2.8 ms of host time per sequence.
+// tests: kbo_call_batch == the oracle's literal kbo::call (which builds that index) per sequence, and the reference's goldens.
+class RunAutomaton {
+public:
+    void build(const uint8_t *seq, size_t len, uint32_t k, bool add_revcomp)
+    {
+        next_.clear();
+        link_.clear();
+        len_.clear();
+        new_state(0, -1);
+        size_t run = 0;
+        for (size_t i = 0; i <= len; i++) {
+            const int c = i < len ? code(seq[i]) : -1;
+            if (c >= 0) { run++; continue; }
+            if (run >= k) {
+                last_ = 0;
+                for (size_t t = i - run; t < i; t++) extend(code(seq[t]));
+                if (add_revcomp) {
+                    last_ = 0;
+                    for (size_t t = i; t-- > i - run;) extend(3 - code(seq[t]));
+                }
+            }
+            run = 0;
+        }
+    }
+    // depths of the walk of `kmer` (k characters, '$' and other non-ACGT bytes reset it) -> out[0 .. k)
+    void depths(const uint8_t *kmer, uint32_t k, uint32_t *out) const
+    {
+        int32_t v = 0;
+        uint32_t l = 0;
+        for (uint32_t t = 0; t < k; t++) {
+            const int c = code(kmer[t]);
+            if (c < 0) { v = 0; l = 0; out[t] = 0; continue; }
+            while (v != 0 && next_[(size_t)v * 4 + c] < 0) { v = link_[v]; l = (uint32_t)len_[v]; }
+            if (next_[(size_t)v * 4 + c] >= 0) { v = next_[(size_t)v * 4 + c]; l++; }
+            else { v = 0; l = 0; }
+            out[t] = l < k ? l : k;
+        }
+    }
 
-void kbo_host::release_call_thread_caches() { small_batch_buffers().release(); }
+private:
+    static int code(uint8_t ch) { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1; }
+    int32_t new_state(int32_t length, int32_t link)
+    {
+        len_.push_back(length);
+        link_.push_back(link);
+        next_.insert(next_.end(), 4, -1);
+        return (int32_t)len_.size() - 1;
+    }
+    int32_t clone_of(int32_t q, int32_t length)
+    {
+        const int32_t cl = new_state(length, link_[q]);
+        for (int c = 0; c < 4; c++) next_[(size_t)cl * 4 + c] = next_[(size_t)q * 4 + c];
+        return cl;
+    }
+    void extend(int c) // (generalised: `last_` may be the root again at the start of every run)
+    {
+        int32_t p = last_;
+        if (next_[(size_t)p * 4 + c] >= 0) {
+            const int32_t q = next_[(size_t)p * 4 + c];
+            if (len_[p] + 1 == len_[q]) { last_ = q; return; }
+            const int32_t cl = clone_of(q, len_[p] + 1);
+            while (p >= 0 && next_[(size_t)p * 4 + c] == q) { next_[(size_t)p * 4 + c] = cl; p = link_[p]; }
+            link_[q] = cl;
+            last_ = cl;
+            return;
+        }
+        const int32_t cur = new_state(len_[p] + 1, 0);
+        while (p >= 0 && next_[(size_t)p * 4 + c] < 0) { next_[(size_t)p * 4 + c] = cur; p = link_[p]; }
+        if (p >= 0) {
+            const int32_t q = next_[(size_t)p * 4 + c];
+            if (len_[p] + 1 == len_[q]) link_[cur] = q;
+            else {
+                const int32_t cl = clone_of(q, len_[p] + 1);
+                while (p >= 0 && next_[(size_t)p * 4 + c] == q) { next_[(size_t)p * 4 + c] = cl; p = link_[p]; }
+                link_[q] = cl;
+                link_[cur] = cl;
+            }
+        }
+        last_ = cur;
+    }
+    std::vector<int32_t> next_, link_, len_;
+    int32_t last_ = 0;
+};
+
+} // namespace
 
 extern "C" int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                               const kbo_call_opts *opts, kbo_variant **out, uint64_t *var_offsets)
@@ -171,96 +248,92 @@ extern "C" int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, con
         const uint32_t k = query_idx->host.k;
         const size_t d = random_match_threshold(k, query_idx->host.n_kmers, 4, o.max_error_prob); // variant_calling.rs:260
         CallClock clk;
-        // ---- first pass, on the device
-        const std::vector<SiteRec> recs = find_sites(query_idx, concat, offsets, n_seqs, (uint32_t)d);
-        clk.lap("first pass (sites)");
-        // ---- k-mers of every site (host: access_kmer walks the index backwards, k steps per site)
-        const size_t n_sites = recs.size();
-        std::vector<kbo::CallSite> sites(n_sites);
-        for (size_t x = 0; x < n_sites; x++) sites[x] = kbo::CallSite{recs[x].i, recs[x].j, recs[x].lo};
-        std::vector<size_t> first(n_seqs + 1, 0); // sites of sequence s: [first[s], first[s+1])
-        for (const SiteRec &r : recs) first[r.seq + 1]++;
+        // ---- first pass on the device (MS walk + breakpoint scan), then the windows of every site
+        const SiteWindows sw = find_sites(query_idx, concat, offsets, n_seqs, (uint32_t)d);
+        clk.lap("first pass (sites + windows)");
+        // ---- sites by sequence (counting sort; a sequence's few sites are put in order of i by its worker)
+        const size_t n_sites = sw.recs.size();
+        std::vector<size_t> first(n_seqs + 1, 0);
+        for (const SiteRec &r : sw.recs) first[r.seq + 1]++;
         for (size_t s = 0; s < n_seqs; s++) first[s + 1] += first[s];
-        std::vector<std::vector<uint8_t>> query_kmers(n_sites), ref_kmers(n_sites);
+        std::vector<uint32_t> order(n_sites);
         {
-            kbo::HostNav nav(query_idx->host);
-            const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({16, std::thread::hardware_concurrency(), n_seqs}));
-            std::vector<std::thread> th;
-            std::exception_ptr err;
-            std::mutex mu;
-            for (unsigned t = 0; t < nt; t++)
-                th.emplace_back([&, t] {
-                    try {
-                        for (size_t s = t; s < n_seqs; s += nt) {
-                            if (first[s] == first[s + 1]) continue;
-                            std::vector<kbo::CallSite> mine(sites.begin() + first[s], sites.begin() + first[s + 1]);
-                            std::vector<std::vector<uint8_t>> qk, rk;
-                            kbo::call_site_kmers(nav, concat + offsets[s], k, mine, qk, rk);
-                            for (size_t x = 0; x < mine.size(); x++) {
-                                query_kmers[first[s] + x] = std::move(qk[x]);
-                                ref_kmers[first[s] + x] = std::move(rk[x]);
-                            }
-                        }
-                    } catch (...) {
-                        std::lock_guard<std::mutex> g(mu);
-                        if (!err) err = std::current_exception();
-                    }
-                });
-            for (auto &x : th) x.join();
-            if (err) std::rethrow_exception(err);
+            std::vector<size_t> fill(first.begin(), first.end() - 1);
+            for (size_t x = 0; x < n_sites; x++) order[fill[sw.recs[x].seq]++] = (uint32_t)x;
         }
-        clk.lap("k-mers of the sites");
-        // ---- second pass: all query-side k-mers against the index, one batch (variant_calling.rs:279)
-        std::vector<std::vector<kbo::MsVal>> ms_vs_ref;
-        ms_only(query_idx, query_kmers, ms_vs_ref);
-        clk.lap("query k-mers vs the index");
-        // ---- ... and per sequence its reference-side k-mers against its own index (lib.rs:553, variant_calling.rs:280)
-        // (host threads: every sequence builds its own small index, uploads it, walks a handful of k-mers and frees it
-        // again - a millisecond of mostly waiting per sequence, so the sequences are spread over a pool)
+        clk.lap("sites by sequence");
+        // ---- second pass, per sequence on host threads.  (The per-sequence index of lib.rs:553 is never built: its build
+        // depends on k and add_revcomp only, both checked above, so it cannot fail for one sequence and not for another;
+        // a sequence without sites yields no variants either way.)
         std::vector<std::vector<kbo::Variant>> calls(n_seqs);
         {
             std::atomic<size_t> next{0};
             std::exception_ptr err;
             std::mutex mu;
-            const int dev = current_device();
+            const kbo::HostNav nav(query_idx->host);
+            const bool revcomp = o.sbwt_build_opts.add_revcomp != 0;
             auto work = [&] {
                 try {
-                    HIP_OK(hipSetDevice(dev));
+                    RunAutomaton sam;
+                    std::vector<uint32_t> dep(k);
+                    std::vector<uint32_t> mine;
                     for (;;) {
-                        const size_t s = next.fetch_add(1);
-                        if (s >= n_seqs) break;
-                        const size_t a = first[s], b = first[s + 1];
-                        if (a == b) continue;
-                        kbo_index ref_idx;
-                        ref_idx.transient = true; // no path cover for an index that serves one small batch
-                        kbo::BuildParams p;
-                        p.k = o.sbwt_build_opts.k;
-                        p.add_revcomp = o.sbwt_build_opts.add_revcomp != 0;
-                        p.num_threads = 1;
-                        const uint8_t *seqs1[1] = {concat + offsets[s]};
-                        const size_t lens1[1] = {(size_t)(offsets[s + 1] - offsets[s])};
-                        kbo::build_host_index(seqs1, lens1, 1, p, ref_idx.host);
-                        std::vector<std::vector<uint8_t>> rk(ref_kmers.begin() + a, ref_kmers.begin() + b);
-                        std::vector<std::vector<kbo::MsVal>> ms_vs_query;
-                        ms_only_small(&ref_idx, rk, ms_vs_query);
-                        std::vector<kbo::CallSite> mine(sites.begin() + a, sites.begin() + b);
-                        calls[s] = kbo::resolve_call_sites(mine, query_kmers.data() + a, ref_kmers.data() + a, ms_vs_ref.data() + a,
-                                                           ms_vs_query.data(), d);
+                        const size_t s0 = next.fetch_add(16);
+                        if (s0 >= n_seqs) break;
+                        for (size_t s = s0; s < std::min(n_seqs, s0 + 16); s++) {
+                            const size_t a = first[s], b = first[s + 1];
+                            if (a == b) continue;
+                            const uint8_t *seq = concat + offsets[s];
+                            const size_t len = (size_t)(offsets[s + 1] - offsets[s]);
+                            mine.assign(order.begin() + a, order.begin() + b);
+                            std::sort(mine.begin(), mine.end(), [&](uint32_t x, uint32_t y) { return sw.recs[x].i < sw.recs[y].i; });
+                            sam.build(seq, len, k, revcomp);
+                            const size_t m = mine.size();
+                            std::vector<kbo::CallSite> sites(m);
+                            std::vector<std::vector<uint8_t>> qk(m), rk(m);
+                            std::vector<std::vector<kbo::MsVal>> ms_vs_ref(m), ms_vs_query(m);
+                            for (size_t x = 0; x < m; x++) {
+                                const SiteRec &r = sw.recs[mine[x]];
+                                const uint8_t *w = sw.win.data() + (size_t)mine[x] * sw.stride;
+                                sites[x] = kbo::CallSite{r.i, r.j, r.lo};
+                                // query-side k-mer (variant_calling.rs:46-58, 275) and its walk against the index (:279): the MS
+                                // values of the first pass, capped by the distance from the k-mer's (or the sequence's) first base
+                                qk[x].assign(k, '$');
+                                ms_vs_ref[x].assign(k, kbo::MsVal{0u, 0u, 0u});
+                                for (uint32_t t = 0; t < k; t++) {
+                                    const int64_t pos = (int64_t)r.j - (int64_t)(k - 1u) + t;
+                                    if (pos < 0) continue; // '$': the walk restarts behind it
+                                    qk[x][t] = seq[pos];
+                                    const uint32_t since = (uint32_t)std::min<int64_t>(t + 1u, pos + 1);
+                                    ms_vs_ref[x][t].d = std::min<uint32_t>(w[t], since);
+                                }
+                                // matched row's k-mer (:276): from the device's path cover, or spelled here when its window crosses a
+                                // path start
+                                if (w[2u * sw.kpad]) nav.access_kmer(r.lo, rk[x]);
+                                else rk[x].assign(w + sw.kpad, w + sw.kpad + k);
+                                // its walk against the sequence's own index (:280)
+                                sam.depths(rk[x].data(), k, dep.data());
+                                ms_vs_query[x].resize(k);
+                                for (uint32_t t = 0; t < k; t++) ms_vs_query[x][t] = kbo::MsVal{dep[t], 0u, 0u};
+                            }
+                            calls[s] = kbo::resolve_call_sites(sites, qk.data(), rk.data(), ms_vs_ref.data(), ms_vs_query.data(), d);
+                        }
                     }
                 } catch (...) {
                     std::lock_guard<std::mutex> g(mu);
                     if (!err) err = std::current_exception();
-                    next.store(n_seqs); // (the others stop at their next sequence)
+                    next.store(n_seqs); // (the others stop at their next sequences)
                 }
             };
-            const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)std::thread::hardware_concurrency(), n_seqs}));
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)hw, (n_seqs + 15) / 16}));
             std::vector<std::thread> th;
             for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
             work();
             for (auto &x : th) x.join();
             if (err) std::rethrow_exception(err);
         }
-        clk.lap("per-sequence indexes + walks");
+        clk.lap("second pass (host threads)");
         size_t n_var = 0;
         for (const auto &c : calls) n_var += c.size();
         // ---- one allocation: records, then the characters
@@ -290,6 +363,19 @@ extern "C" int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, con
             var_offsets[s + 1] = w;
         }
         *out = rec;
+        clk.lap("packing");
+    });
+}
+
+// test hook (kbo_hip_tuning.h): the depths RunAutomaton answers, for checking against a real one-sequence index on the CPU
+extern "C" int kbo_run_automaton_depths(const uint8_t *seq, size_t len, uint32_t k, int add_revcomp, const uint8_t *kmers,
+                                        size_t n_kmers, uint32_t *depths_out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(seq && kmers && depths_out && k > 0 && k <= 255, KBO_E_BAD_ARG, "null argument or k outside 1..255");
+        RunAutomaton sam;
+        sam.build(seq, len, k, add_revcomp != 0);
+        for (size_t x = 0; x < n_kmers; x++) sam.depths(kmers + x * k, k, depths_out + x * k);
     });
 }
 

@@ -74,7 +74,56 @@ __global__ __launch_bounds__(256) void call_sites_kernel(const uint8_t *__restri
     }
 }
 
+// The inputs of resolve_variant that the device already holds, per site (one wave each): the k MS values in front of and at
+// the match j - the walk of the query-side k-mer (variant_calling.rs:275, 279) is a fresh walk over a substring of the
+// sequence, and the set of strings that are suffixes of index rows is closed under taking suffixes, so its value at position
+// t is min(MS of the whole sequence there, t + 1): no second walk - and the k characters of the matched row
+// (variant_calling.rs:276 access_kmer), read off the path cover: text[p - k + 1 .. p] for p = pos[row] spells the row as long as
+// no path starts inside (p - k + 1, p]; the first character is the label of the node at p - k + 1.  A window that crosses a
+// path start is flagged and spelled by the host (rank / select on its copy of the index).
+// Record: [0, k) MS bytes (0xFF in front of the slab's first base: the host cuts at the sequence's start anyway),
+// [kpad, kpad + k) row characters, [2 kpad] flag (1 = spell the row on the host).
+__global__ __launch_bounds__(256) void call_gather_kernel(const uint2 *__restrict__ sites, uint32_t n_sites, uint32_t k, uint32_t kpad,
+                                                          const uint8_t *__restrict__ ms, DevIndexView ix, uint8_t *__restrict__ out,
+                                                          uint32_t stride)
+{
+    const uint32_t site = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (site >= n_sites) return;
+    const uint2 sj = sites[site];
+    uint8_t *rec = out + (size_t)site * stride;
+    const bool cover = ix.pc_text != nullptr;
+    const int64_t p = cover ? (int64_t)ix.pc_pos[sj.y] : 0;
+    bool broken = !cover;
+    for (uint32_t t = lane; t < k; t += 64u) {
+        const int64_t a = (int64_t)sj.x - (int64_t)(k - 1u) + t;
+        rec[t] = a >= 0 ? ms[a] : (uint8_t)0xFF;
+        uint32_t ch = 0;
+        if (cover) {
+            const int64_t q = p - (int64_t)(k - 1u) + t;
+            if (q >= -(int64_t)kPlanPad) ch = ix.pc_text[q];
+            if (t == 0 && q >= 0) { // the node where the window begins: its own last character (the text holds edge labels)
+                const uint32_t row = ix.pc_node[q];
+                ch = row >= ix.C[3] ? 'T' : row >= ix.C[2] ? 'G' : row >= ix.C[1] ? 'C' : row >= ix.C[0] ? 'A' : '$';
+            }
+            broken = broken || ch == 0;
+        }
+        rec[kpad + t] = (uint8_t)ch;
+    }
+    if (__ballot(broken) != 0 && lane == 0) rec[2u * kpad] = 1;
+    else if (lane == 0) rec[2u * kpad] = 0;
+}
+
 } // namespace
+
+hipError_t launch_call_gather(const void *d_sites, uint32_t n_sites, uint32_t k, const uint8_t *d_ms, const DevIndexView &ix,
+                              uint8_t *d_out, uint32_t stride, hipStream_t stream)
+{
+    if (n_sites == 0) return hipSuccess;
+    const uint32_t kpad = (k + 15u) / 16u * 16u;
+    hipLaunchKernelGGL(call_gather_kernel, dim3((n_sites + 3u) / 4u), dim3(256), 0, stream, static_cast<const uint2 *>(d_sites), n_sites, k,
+                       kpad, d_ms, ix, d_out, stride);
+    return hipGetLastError();
+}
 
 // d_count: kCallSegs counters 64 bytes apart, 0 before the launch; list g holds records [g * (cap / kCallSegs), ... +
 // d_count[16 g]) of d_sites; a counter above cap / kCallSegs means that list overflowed (repeat with more room)

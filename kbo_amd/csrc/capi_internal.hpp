@@ -176,6 +176,5 @@ void ms_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *offset
                    uint32_t *lo_out, uint32_t *hi_out);
 void release_host_scratch(); // frees the pooled per-device scratch of the host batch entry points + the calling thread's caches
 void release_transient_arena();     // device_index.cpp: the calling thread's arena for transient indexes (when not in use)
-void release_call_thread_caches();  // call_batch.cpp: the calling thread's small-batch device buffers
 
 } // namespace kbo_host

@@ -830,7 +830,6 @@ void release_host_scratch()
     // the calling thread's own caches (kbo_call / kbo_call_batch keep a transient-index arena and a small batch's device
     // buffers per host thread; pool threads free theirs when they exit)
     release_transient_arena();
-    release_call_thread_caches();
 }
 
 } // namespace kbo_host

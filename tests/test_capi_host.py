@@ -250,3 +250,45 @@ def test_sbwt_lcs_file_pair_round_trip_and_foreign_payload(tmp_path):
         kindex.load_sbwt(prefix)
     with pytest.raises(AssertionError):
         kindex.load_sbwt(str(tmp_path / "no_such_prefix"))
+
+
+@pytest.mark.parametrize("k,revcomp", [(3, False), (5, True), (31, False), (31, True), (64, False)])
+def test_run_automaton_equals_the_walk_of_a_one_sequence_index(oracle, k, revcomp):
+    """kbo_call_batch never builds the per-sequence index of lib.rs:553: the depths of the reference-side walk
+    (variant_calling.rs:280) come from a suffix automaton of the sequence's ACGT-runs of >= k characters.  Here those depths
+    against the oracle's literal walk of a really built one-sequence index: sequences with N's (runs shorter than k have no
+    rows), repeats, reverse complements; k-mers cut from the sequence, mutated, '$'-padded, with junk."""
+    rng = np.random.default_rng(1000 + k + int(revcomp))
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for trial in range(6):
+        n = int(rng.integers(2 * k + 5, 3000))
+        seq = acgt[rng.integers(0, 4, n)].copy()
+        if trial % 2:
+            seq[rng.integers(0, n, max(1, n // 60))] = ord("N")        # runs, some shorter than k
+        if trial % 3 == 0 and n > 400:
+            seq[300:400] = seq[50:150]                                   # a repeat
+        if trial == 5:
+            seq[:] = acgt[rng.integers(0, 2, n)]                         # low complexity
+        ora = oracle.Index.build([seq.tobytes()], k=k, add_revcomp=revcomp)
+        kmers = []
+        for _ in range(300):
+            a = int(rng.integers(0, n - k))
+            km = seq[a:a + k].copy()
+            kind = int(rng.integers(0, 5))
+            if kind == 1:
+                km[int(rng.integers(0, k))] = acgt[int(rng.integers(0, 4))]
+            elif kind == 2:
+                km[:int(rng.integers(1, k))] = ord("$")
+            elif kind == 3:
+                km = acgt[rng.integers(0, 4, k)]
+            elif kind == 4 and revcomp:
+                km = (np.frombuffer(bytes(km), dtype=np.uint8)[::-1]).copy()
+                km = np.array([{65: 84, 67: 71, 71: 67, 84: 65}.get(int(c), int(c)) for c in km], dtype=np.uint8)
+            kmers.append(np.asarray(km, dtype=np.uint8))
+        flat = np.concatenate(kmers)
+        got = np.zeros(len(kmers) * k, dtype=np.uint32)
+        kbo_amd.check(kbo_amd.lib().kbo_run_automaton_depths(seq.ctypes.data, n, k, int(revcomp), flat.ctypes.data, len(kmers),
+                                                              got.ctypes.data))
+        for x, km in enumerate(kmers):
+            d, _, _ = ora.matching_statistics(km.tobytes())
+            assert np.array_equal(got[x * k:(x + 1) * k], d.astype(np.uint32)), (k, revcomp, trial, x)

@@ -262,6 +262,14 @@ def test_call_batch_equals_per_sequence_call(oracle):
                     del s[p:p + int(rng.integers(1, 6))]
                 else:
                     s[p:p] = bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, 6))).astype(np.uint8))
+        if r % 5 == 0:  # non-ACGT bytes: they split the sequence's own index into runs (runs shorter than k have no rows)
+            for p in rng.integers(0, len(s), 3):
+                s[p] = ord("N")
+        if r % 11 == 0 and len(s) > 400:
+            for p in range(100, 400, 37):  # a stretch of runs shorter than k
+                s[p] = ord("N")
+        if r % 13 == 0 and len(s) > 900:   # a copy of an earlier stretch of the same read (the automaton sees it twice)
+            s[700:800] = s[100:200]
         reads.append(bytes(s))
     concat = np.frombuffer(b"".join(reads), dtype=np.uint8)
     offsets = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)

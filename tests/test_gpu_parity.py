@@ -69,6 +69,14 @@ def test_find_golden(golden):  # lib.rs:786-805
 
 # ------------------------------------------------------------------ refinement stages ("next" rows)
 
+def _call_as_batch(sbwt, seq, opts):
+    """the same call through kbo_call_batch (a batch of one sequence): first pass in call mode on the device, the site
+    windows gathered there, the reference-side walk answered by the run automaton instead of a per-sequence SBWT"""
+    seq = seq.encode() if isinstance(seq, str) else bytes(seq)
+    concat = np.frombuffer(seq, dtype=np.uint8)
+    return batch.call_batch(sbwt, concat, np.array([0, len(seq)], dtype=np.uint64), opts)[0]
+
+
 def test_call_goldens(golden):
     """variant_calling.rs:312-454 (index built from reference, query streamed) and the call()
     doctest lib.rs:526-544."""
@@ -80,12 +88,14 @@ def test_call_goldens(golden):
         got = kbo_amd.call(sbwt_ref, lcs_ref, g["query"], kbo_amd.CallOpts(g["max_error_prob"], opts))
         exp = [Variant(p, list(q.encode()), list(r.encode())) for p, q, r in g["expected"]]
         assert got == exp, g["src"]
+        assert _call_as_batch(sbwt_ref, g["query"], kbo_amd.CallOpts(g["max_error_prob"], opts)) == exp, g["src"]
     for g in golden["call"]:
         opts = kbo_amd.BuildOpts(k=g["k"], build_select=True)
         sbwt_query, lcs_query = kbo_amd.build([g["query"]], opts)
         got = kbo_amd.call(sbwt_query, lcs_query, g["reference"], kbo_amd.CallOpts(g["max_error_prob"], opts))
         exp = [Variant(p, list(q.encode()), list(r.encode())) for p, q, r in g["expected"]]
         assert got == exp, g["src"]
+        assert _call_as_batch(sbwt_query, g["reference"], kbo_amd.CallOpts(g["max_error_prob"], opts)) == exp, g["src"]
 
 
 def test_long_generated_variant_calling():
@@ -123,6 +133,7 @@ def test_long_generated_variant_calling():
     opts = kbo_amd.BuildOpts(k=k, build_select=True)
     sbwt_ref, lcs_ref = kbo_amd.build([bytes(reference)], opts)
     calls = kbo_amd.call(sbwt_ref, lcs_ref, bytes(query), kbo_amd.CallOpts(p, opts))
+    assert _call_as_batch(sbwt_ref, bytes(query), kbo_amd.CallOpts(p, opts)) == calls
     assert len(calls) >= 0.99 * len(truth)
     wrong = [c for c in calls if truth.get(c.query_pos) != c]
     assert len(wrong) <= 0.002 * len(calls), wrong[:5]
