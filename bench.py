@@ -266,7 +266,11 @@ def stage_model_leg(args, sbwt, oi, concat, offsets, gpu_d, n_sample=2_000_000):
                      "contraction_levels": round(cn["walk_contractions"] / units, 3),
                      "entry_levels": round(cn["walk_entry_levels"] / units, 3),
                      "iterations": round((cn["walk_iterations_lines"] if P.recovery_lines else iters) / units, 3),
-                     "distinct_lines": round(cn["unit_distinct_lines"] / units, 3)},
+                     # 128-byte lines one unit touches (record, start row, query, output, index); "beyond_l2" leaves out the
+                     # rank blocks when all of them fit one XCD's 4 MiB L2 (C2: 3.3 MB - they stay resident, shared by all units)
+                     "distinct_lines": round(cn["unit_distinct_lines"] / units, 3),
+                     "distinct_lines_beyond_l2": round((cn["unit_distinct_lines"] - (cn["unit_distinct_rank_lines"]
+                                                        if sbwt.device_bytes()[0] < (4 << 20) else 0)) / units, 3)},
         "bytes_per_base": per_base,
     }
     return total / cn["bases"], summary, cn
@@ -646,7 +650,8 @@ def main(argv=None):
             "l2_miss_per_launch": int(misses) if misses else None,
             "fill_rate_frac": round(misses / walk_s / FILL_CEILING_PER_S, 4) if misses else None,
             "fill_rate_ceiling": {"fills_per_s": FILL_CEILING_PER_S, "source": FILL_CEILING_SOURCE},
-            "fills_min_per_unit": model["per_unit"]["distinct_lines"] if model else None,
+            "fills_min_per_unit": model["per_unit"]["distinct_lines_beyond_l2"] if model else None,
+            "l2_miss_per_unit": round(misses / max(1, stats["units"]), 2) if misses and planned else None,
             "frac_reference_algorithm": round(ref_achieved / HBM_PEAK_GBPS, 4) if ref_achieved is not None else None,
             "reference_algorithm_bytes_per_base": round(b_ref, 2) if b_ref is not None else None,
             "cross_check_whole_step_gbps": round(b_alg * bases / (elapsed / args.steps) / 1e9, 1) if b_alg is not None else None,

@@ -39,18 +39,26 @@ struct SiteRec {
     uint32_t seq, i, j, lo;
 };
 
-// What the second pass of a batch needs per site, gathered on the device right behind the first pass (call_kernels.hip
-// call_gather_kernel): the k MS values ending at the match and the k characters of the matched row.
+// What the second pass of a batch needs per site, produced on the device right behind the first pass (call_kernels.hip
+// call_finalize_kernel): the site as {sequence, i, j, row}, the k MS values ending at the match and the k characters of the
+// matched row.  One part per slab, in pinned memory (the downloads land there; nothing is copied again).
 struct SiteWindows {
-    std::vector<SiteRec> recs;   // in arrival order
-    std::vector<uint8_t> win;    // recs.size() records of `stride` bytes
+    struct Part {
+        PinBuf recs, win; // n records of 16 / stride bytes
+        size_t n = 0;
+    };
+    std::vector<std::unique_ptr<Part>> parts;
     uint32_t stride = 0, kpad = 0;
+    const SiteRec &rec(uint32_t part, uint32_t x) const { return parts[part]->recs.as<SiteRec>()[x]; }
+    const uint8_t *win(uint32_t part, uint32_t x) const { return parts[part]->win.as<uint8_t>() + (size_t)x * stride; }
 };
 
 // first pass on the device: sites of sequences [0, n_seqs) with their windows.  Normally the walk itself finds them
 // (call mode of ms_walk_kernel: no intervals are written at all); a slab in which a lane had more than four breakpoints
 // waiting at once, or whose site lists overflowed, is done again the long way (walk with intervals + call_sites_kernel).
-SiteWindows find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, uint32_t threshold)
+// Sites of slab-relative sequence numbers are shifted to batch-wide ones by the caller (SiteRec::seq + Part's first).
+SiteWindows find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, uint32_t threshold,
+                       std::vector<size_t> &part_first_seq)
 {
     SiteWindows all;
     const uint32_t k = idx->host.k;
@@ -58,13 +66,11 @@ SiteWindows find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *of
     all.kpad = (k + 15u) / 16u * 16u;
     hipStream_t stream = nullptr;
     const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
-    DevBuf d_sites, d_count, d_compact, d_win;
+    DevBuf d_sites, d_count, d_prefix, d_recs, d_win;
     const size_t count_bytes = kbo::kCallSegs * 64 + 64;
     d_count.alloc(count_bytes);
-    std::vector<uint32_t> counts(count_bytes / 4);
-    struct Raw { uint32_t a, b, c, d; };
-    std::vector<Raw> raw;
-    std::vector<uint32_t> compact;
+    d_prefix.alloc((kbo::kCallSegs + 1) * 4);
+    std::vector<uint32_t> counts(count_bytes / 4), prefix(kbo::kCallSegs + 1);
     const kbo::DevIndexView view = device_view(idx, current_device());
     for (const Slab &sl : slabs) {
         const size_t ns = sl.s1 - sl.s0;
@@ -99,39 +105,27 @@ SiteWindows find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *of
                 cap = (uint32_t)std::min<uint64_t>((uint64_t)(worst + 16) * kbo::kCallSegs, 0x7FFFFF00u);
                 continue;
             }
-            const size_t first_new = all.recs.size();
-            compact.clear();
-            for (uint32_t g = 0; g < kbo::kCallSegs; g++) {
-                const uint32_t n = counts[g * 16];
-                if (!n) continue;
-                raw.resize(n);
-                HIP_OK(hipMemcpy(raw.data(), d_sites.as<uint8_t>() + (size_t)g * seg_cap * 16, (size_t)n * 16, hipMemcpyDeviceToHost));
-                for (const Raw &x : raw) {
-                    if (by_walk && x.a == 0xFFFFFFFFu) continue; // (a site of an item that the redo pass scanned again)
-                    if (by_walk) { // {slab offset of i, of j, row}: find the sequence
-                        const size_t s = (size_t)(std::upper_bound(off.begin(), off.end(), (uint64_t)x.a) - off.begin()) - 1;
-                        all.recs.push_back(SiteRec{(uint32_t)(sl.s0 + s), (uint32_t)(x.a - off[s]), (uint32_t)(x.b - off[s]), x.c});
-                        compact.push_back(x.b);
-                        compact.push_back(x.c);
-                    } else {
-                        all.recs.push_back(SiteRec{(uint32_t)(sl.s0 + x.a), x.b, x.c, x.d});
-                        compact.push_back((uint32_t)(off[x.a] + x.c));
-                        compact.push_back(x.d);
-                    }
-                }
-            }
-            // the windows of this slab's sites, while its MS values are still on the device
-            const size_t n_new = all.recs.size() - first_new;
+            // the sites of this slab, numbered list by list, and their windows - while its MS values are on the device
+            prefix[0] = 0;
+            for (uint32_t g = 0; g < kbo::kCallSegs; g++) prefix[g + 1] = prefix[g] + counts[g * 16];
+            const size_t n_new = prefix[kbo::kCallSegs];
+            std::unique_ptr<SiteWindows::Part> part(new SiteWindows::Part());
+            part->n = n_new;
             if (n_new) {
-                d_compact.ensure(n_new * 8);
+                d_recs.ensure(n_new * 16);
                 d_win.ensure(n_new * (size_t)all.stride);
-                HIP_OK(hipMemcpyAsync(d_compact.p, compact.data(), n_new * 8, hipMemcpyHostToDevice, stream));
-                HIP_OK(kbo::launch_call_gather(d_compact.p, (uint32_t)n_new, k, B.ms.as<uint8_t>(), view, d_win.as<uint8_t>(), all.stride, stream));
-                all.win.resize(all.recs.size() * (size_t)all.stride);
-                HIP_OK(hipMemcpyAsync(all.win.data() + first_new * (size_t)all.stride, d_win.p, n_new * (size_t)all.stride,
-                                      hipMemcpyDeviceToHost, stream));
+                part->recs.ensure(n_new * 16);
+                part->win.ensure(n_new * (size_t)all.stride);
+                HIP_OK(hipMemcpyAsync(d_prefix.p, prefix.data(), prefix.size() * 4, hipMemcpyHostToDevice, stream));
+                HIP_OK(kbo::launch_call_finalize(d_sites.p, d_count.as<uint32_t>(), d_prefix.as<uint32_t>(), seg_cap, worst, by_walk,
+                                                 B.off.as<uint64_t>(), (uint32_t)ns, k, B.ms.as<uint8_t>(), view, d_recs.p,
+                                                 d_win.as<uint8_t>(), all.stride, stream));
+                HIP_OK(hipMemcpyAsync(part->recs.p, d_recs.p, n_new * 16, hipMemcpyDeviceToHost, stream));
+                HIP_OK(hipMemcpyAsync(part->win.p, d_win.p, n_new * (size_t)all.stride, hipMemcpyDeviceToHost, stream));
                 HIP_OK(hipStreamSynchronize(stream));
             }
+            all.parts.push_back(std::move(part));
+            part_first_seq.push_back(sl.s0);
             break;
         }
     }
@@ -156,6 +150,10 @@ public:
         next_.clear();
         link_.clear();
         len_.clear();
+        const size_t states = 2 * (add_revcomp ? 2 * len : len) + 2; // (at most two states per character)
+        next_.reserve(4 * states);
+        link_.reserve(states);
+        len_.reserve(states);
         new_state(0, -1);
         size_t run = 0;
         for (size_t i = 0; i <= len; i++) {
@@ -248,24 +246,34 @@ extern "C" int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, con
         const uint32_t k = query_idx->host.k;
         const size_t d = random_match_threshold(k, query_idx->host.n_kmers, 4, o.max_error_prob); // variant_calling.rs:260
         CallClock clk;
-        // ---- first pass on the device (MS walk + breakpoint scan), then the windows of every site
-        const SiteWindows sw = find_sites(query_idx, concat, offsets, n_seqs, (uint32_t)d);
+        // ---- first pass on the device (MS walk + breakpoint scan), the sites made ready and their windows gathered there
+        std::vector<size_t> part_seq0;
+        const SiteWindows sw = find_sites(query_idx, concat, offsets, n_seqs, (uint32_t)d, part_seq0);
         clk.lap("first pass (sites + windows)");
-        // ---- sites by sequence (counting sort; a sequence's few sites are put in order of i by its worker)
-        const size_t n_sites = sw.recs.size();
+        // ---- sites by sequence (counting sort over the parts; a sequence's few sites are put in order of i by its worker)
+        struct Ref { uint32_t part, x; };
         std::vector<size_t> first(n_seqs + 1, 0);
-        for (const SiteRec &r : sw.recs) first[r.seq + 1]++;
+        for (size_t p = 0; p < sw.parts.size(); p++) {
+            const SiteRec *r = sw.parts[p]->recs.as<SiteRec>();
+            for (size_t x = 0; x < sw.parts[p]->n; x++)
+                if (r[x].seq != 0xFFFFFFFFu) first[part_seq0[p] + r[x].seq + 1]++; // (void records: sites of items the redo pass scanned again)
+        }
         for (size_t s = 0; s < n_seqs; s++) first[s + 1] += first[s];
-        std::vector<uint32_t> order(n_sites);
+        std::vector<Ref> order(first[n_seqs]);
         {
             std::vector<size_t> fill(first.begin(), first.end() - 1);
-            for (size_t x = 0; x < n_sites; x++) order[fill[sw.recs[x].seq]++] = (uint32_t)x;
+            for (size_t p = 0; p < sw.parts.size(); p++) {
+                const SiteRec *r = sw.parts[p]->recs.as<SiteRec>();
+                for (size_t x = 0; x < sw.parts[p]->n; x++)
+                    if (r[x].seq != 0xFFFFFFFFu) order[fill[part_seq0[p] + r[x].seq]++] = Ref{(uint32_t)p, (uint32_t)x};
+            }
         }
         clk.lap("sites by sequence");
         // ---- second pass, per sequence on host threads.  (The per-sequence index of lib.rs:553 is never built: its build
         // depends on k and add_revcomp only, both checked above, so it cannot fail for one sequence and not for another;
         // a sequence without sites yields no variants either way.)
-        std::vector<std::vector<kbo::Variant>> calls(n_seqs);
+        struct Call { uint32_t i; uint16_t q_from, q_len, r_from, r_len; Ref site; }; // characters: slices of the two k-mers
+        std::vector<std::vector<Call>> calls(n_seqs);
         {
             std::atomic<size_t> next{0};
             std::exception_ptr err;
@@ -275,8 +283,9 @@ extern "C" int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, con
             auto work = [&] {
                 try {
                     RunAutomaton sam;
-                    std::vector<uint32_t> dep(k);
-                    std::vector<uint32_t> mine;
+                    std::vector<uint32_t> dq(k), dr(k);
+                    std::vector<uint8_t> qk(k), rk_spelled;
+                    std::vector<Ref> mine;
                     for (;;) {
                         const size_t s0 = next.fetch_add(16);
                         if (s0 >= n_seqs) break;
@@ -286,37 +295,31 @@ extern "C" int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, con
                             const uint8_t *seq = concat + offsets[s];
                             const size_t len = (size_t)(offsets[s + 1] - offsets[s]);
                             mine.assign(order.begin() + a, order.begin() + b);
-                            std::sort(mine.begin(), mine.end(), [&](uint32_t x, uint32_t y) { return sw.recs[x].i < sw.recs[y].i; });
+                            std::sort(mine.begin(), mine.end(), [&](const Ref &x, const Ref &y) { return sw.rec(x.part, x.x).i < sw.rec(y.part, y.x).i; });
                             sam.build(seq, len, k, revcomp);
-                            const size_t m = mine.size();
-                            std::vector<kbo::CallSite> sites(m);
-                            std::vector<std::vector<uint8_t>> qk(m), rk(m);
-                            std::vector<std::vector<kbo::MsVal>> ms_vs_ref(m), ms_vs_query(m);
-                            for (size_t x = 0; x < m; x++) {
-                                const SiteRec &r = sw.recs[mine[x]];
-                                const uint8_t *w = sw.win.data() + (size_t)mine[x] * sw.stride;
-                                sites[x] = kbo::CallSite{r.i, r.j, r.lo};
+                            for (const Ref &sr : mine) {
+                                const SiteRec &r = sw.rec(sr.part, sr.x);
+                                const uint8_t *w = sw.win(sr.part, sr.x);
                                 // query-side k-mer (variant_calling.rs:46-58, 275) and its walk against the index (:279): the MS
                                 // values of the first pass, capped by the distance from the k-mer's (or the sequence's) first base
-                                qk[x].assign(k, '$');
-                                ms_vs_ref[x].assign(k, kbo::MsVal{0u, 0u, 0u});
                                 for (uint32_t t = 0; t < k; t++) {
                                     const int64_t pos = (int64_t)r.j - (int64_t)(k - 1u) + t;
-                                    if (pos < 0) continue; // '$': the walk restarts behind it
-                                    qk[x][t] = seq[pos];
-                                    const uint32_t since = (uint32_t)std::min<int64_t>(t + 1u, pos + 1);
-                                    ms_vs_ref[x][t].d = std::min<uint32_t>(w[t], since);
+                                    if (pos < 0) { qk[t] = '$'; dr[t] = 0; continue; } // '$': the walk restarts behind it
+                                    qk[t] = seq[pos];
+                                    dr[t] = std::min<uint32_t>(w[t], (uint32_t)std::min<int64_t>(t + 1u, pos + 1));
                                 }
                                 // matched row's k-mer (:276): from the device's path cover, or spelled here when its window crosses a
                                 // path start
-                                if (w[2u * sw.kpad]) nav.access_kmer(r.lo, rk[x]);
-                                else rk[x].assign(w + sw.kpad, w + sw.kpad + k);
-                                // its walk against the sequence's own index (:280)
-                                sam.depths(rk[x].data(), k, dep.data());
-                                ms_vs_query[x].resize(k);
-                                for (uint32_t t = 0; t < k; t++) ms_vs_query[x][t] = kbo::MsVal{dep[t], 0u, 0u};
+                                const uint8_t *rk = w + sw.kpad;
+                                if (w[2u * sw.kpad]) {
+                                    nav.access_kmer(r.lo, rk_spelled);
+                                    rk = rk_spelled.data();
+                                }
+                                sam.depths(rk, k, dq.data()); // its walk against the sequence's own index (:280)
+                                size_t qf, qt, rf, rt;
+                                if (kbo::resolve_variant_ranges(qk.data(), rk, dq.data(), dr.data(), k, d, qf, qt, rf, rt)) // :282-284
+                                    calls[s].push_back(Call{r.i, (uint16_t)qf, (uint16_t)(qt - qf), (uint16_t)rf, (uint16_t)(rt - rf), sr});
                             }
-                            calls[s] = kbo::resolve_call_sites(sites, qk.data(), rk.data(), ms_vs_ref.data(), ms_vs_query.data(), d);
                         }
                     }
                 } catch (...) {
@@ -334,33 +337,52 @@ extern "C" int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, con
             if (err) std::rethrow_exception(err);
         }
         clk.lap("second pass (host threads)");
-        size_t n_var = 0;
-        for (const auto &c : calls) n_var += c.size();
-        // ---- one allocation: records, then the characters
-        size_t chars = 0;
-        for (const auto &c : calls)
-            for (const auto &v : c) chars += v.query_chars.size() + v.ref_chars.size();
+        // ---- one allocation: records, then the characters; filled by the host team, every sequence at its own offsets
+        var_offsets[0] = 0;
+        std::vector<size_t> char0(n_seqs + 1, 0);
+        for (size_t s = 0; s < n_seqs; s++) {
+            size_t ch = 0;
+            for (const Call &c : calls[s]) ch += c.q_len + c.r_len;
+            var_offsets[s + 1] = var_offsets[s] + calls[s].size();
+            char0[s + 1] = char0[s] + ch;
+        }
+        const size_t n_var = var_offsets[n_seqs], chars = char0[n_seqs];
         const size_t head = std::max<size_t>(1, n_var) * sizeof(kbo_variant);
         uint8_t *mem = static_cast<uint8_t *>(std::malloc(head + chars + 1));
         if (!mem) throw std::bad_alloc();
         kbo_variant *rec = reinterpret_cast<kbo_variant *>(mem);
-        uint8_t *cp = mem + head;
-        size_t w = 0;
-        var_offsets[0] = 0;
-        for (size_t s = 0; s < n_seqs; s++) {
-            for (const kbo::Variant &v : calls[s]) {
-                rec[w].query_pos = v.query_pos;
-                rec[w].query_chars = cp;
-                rec[w].query_len = v.query_chars.size();
-                std::memcpy(cp, v.query_chars.data(), v.query_chars.size());
-                cp += v.query_chars.size();
-                rec[w].ref_chars = cp;
-                rec[w].ref_len = v.ref_chars.size();
-                std::memcpy(cp, v.ref_chars.data(), v.ref_chars.size());
-                cp += v.ref_chars.size();
-                w++;
-            }
-            var_offsets[s + 1] = w;
+        {
+            const kbo::HostNav nav(query_idx->host);
+            const size_t piece = 256;
+            HostTeam::get().run((n_seqs + piece - 1) / piece, [&](size_t task) {
+                std::vector<uint8_t> rk_spelled;
+                for (size_t s = task * piece; s < std::min(n_seqs, (task + 1) * piece); s++) {
+                    size_t w = var_offsets[s];
+                    uint8_t *cp = mem + head + char0[s];
+                    const uint8_t *seq = concat + offsets[s];
+                    for (const Call &c : calls[s]) {
+                        const SiteRec &r = sw.rec(c.site.part, c.site.x);
+                        const uint8_t *win = sw.win(c.site.part, c.site.x);
+                        rec[w].query_pos = c.i;
+                        rec[w].query_chars = cp;
+                        rec[w].query_len = c.q_len;
+                        for (uint32_t t = 0; t < c.q_len; t++) { // (a slice of the query-side k-mer: '$' in front of the sequence)
+                            const int64_t pos = (int64_t)r.j - (int64_t)(k - 1u) + c.q_from + t;
+                            *cp++ = pos < 0 ? (uint8_t)'$' : seq[pos];
+                        }
+                        rec[w].ref_chars = cp;
+                        rec[w].ref_len = c.r_len;
+                        const uint8_t *rk = win + sw.kpad;
+                        if (win[2u * sw.kpad] && c.r_len) {
+                            nav.access_kmer(r.lo, rk_spelled);
+                            rk = rk_spelled.data();
+                        }
+                        std::memcpy(cp, rk + c.r_from, c.r_len);
+                        cp += c.r_len;
+                        w++;
+                    }
+                }
+            });
         }
         *out = rec;
         clk.lap("packing");

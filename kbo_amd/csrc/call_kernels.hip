@@ -74,54 +74,86 @@ __global__ __launch_bounds__(256) void call_sites_kernel(const uint8_t *__restri
     }
 }
 
-// The inputs of resolve_variant that the device already holds, per site (one wave each): the k MS values in front of and at
-// the match j - the walk of the query-side k-mer (variant_calling.rs:275, 279) is a fresh walk over a substring of the
-// sequence, and the set of strings that are suffixes of index rows is closed under taking suffixes, so its value at position
-// t is min(MS of the whole sequence there, t + 1): no second walk - and the k characters of the matched row
-// (variant_calling.rs:276 access_kmer), read off the path cover: text[p - k + 1 .. p] for p = pos[row] spells the row as long as
-// no path starts inside (p - k + 1, p]; the first character is the label of the node at p - k + 1.  A window that crosses a
-// path start is flagged and spelled by the host (rank / select on its copy of the index).
-// Record: [0, k) MS bytes (0xFF in front of the slab's first base: the host cuts at the sequence's start anyway),
+// The second pass of a batch starts on the device, right behind the first one (one wave per site, in list order):
+//  * the site's record becomes {sequence, i, j, row} with positions relative to the sequence (binary search over the
+//    offsets; a void record of the walk - an item the redo pass scanned again - stays void: first word ~0);
+//  * the inputs of resolve_variant that the device already holds are gathered: the k MS values in front of and at the
+//    match j - the walk of the query-side k-mer (variant_calling.rs:275, 279) is a fresh walk over a substring of the
+//    sequence, and the set of strings that are suffixes of index rows is closed under taking suffixes, so its value at
+//    position t is min(MS of the whole sequence there, t + 1): no second walk - and the k characters of the matched row
+//    (variant_calling.rs:276 access_kmer), read off the path cover: text[p - k + 1 .. p] for p = pos[row] spells the row as
+//    long as no path starts inside (p - k + 1, p]; the first character is the label of the node at p - k + 1.  A window that
+//    crosses a path start is flagged and spelled by the host (rank / select on its copy of the index).
+// Window record: [0, k) MS bytes (0xFF in front of the batch's first base: the host cuts at the sequence's start anyway),
 // [kpad, kpad + k) row characters, [2 kpad] flag (1 = spell the row on the host).
-__global__ __launch_bounds__(256) void call_gather_kernel(const uint2 *__restrict__ sites, uint32_t n_sites, uint32_t k, uint32_t kpad,
-                                                          const uint8_t *__restrict__ ms, DevIndexView ix, uint8_t *__restrict__ out,
-                                                          uint32_t stride)
+__global__ __launch_bounds__(256) void call_finalize_kernel(const uint4 *__restrict__ lists, const uint32_t *__restrict__ counts,
+                                                            const uint32_t *__restrict__ prefix, uint32_t seg_cap, uint32_t by_walk,
+                                                            const uint64_t *__restrict__ off, uint32_t n_seqs, uint32_t k, uint32_t kpad,
+                                                            const uint8_t *__restrict__ ms, DevIndexView ix, uint4 *__restrict__ out_recs,
+                                                            uint8_t *__restrict__ out_win, uint32_t stride)
 {
-    const uint32_t site = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
-    if (site >= n_sites) return;
-    const uint2 sj = sites[site];
-    uint8_t *rec = out + (size_t)site * stride;
+    const uint32_t g = blockIdx.y, slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (slot >= min(counts[g * 16u], seg_cap)) return;
+    const uint32_t x = prefix[g] + slot;
+    const uint4 v = lists[(size_t)g * seg_cap + slot];
+    if (by_walk && v.x == 0xFFFFFFFFu) {
+        if (lane == 0) out_recs[x] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+        return;
+    }
+    uint32_t seq = v.x, j_off = 0, row = 0;
+    uint4 rec;
+    if (by_walk) { // {offset of i, offset of j, row, 0}: the sequence that holds i
+        uint32_t s0 = 0, s1 = n_seqs;
+        while (s1 - s0 > 1) {
+            const uint32_t m = s0 + (s1 - s0) / 2;
+            if (off[m] <= v.x) s0 = m;
+            else s1 = m;
+        }
+        seq = s0;
+        const uint32_t b0 = (uint32_t)off[s0];
+        rec = make_uint4(seq, v.x - b0, v.y - b0, v.z);
+        j_off = v.y;
+        row = v.z;
+    } else { // {sequence, i, j, row} from call_sites_kernel
+        rec = v;
+        j_off = (uint32_t)off[v.x] + v.z;
+        row = v.w;
+    }
+    if (lane == 0) out_recs[x] = rec;
+    uint8_t *w = out_win + (size_t)x * stride;
     const bool cover = ix.pc_text != nullptr;
-    const int64_t p = cover ? (int64_t)ix.pc_pos[sj.y] : 0;
+    const int64_t p = cover ? (int64_t)ix.pc_pos[row] : 0;
     bool broken = !cover;
     for (uint32_t t = lane; t < k; t += 64u) {
-        const int64_t a = (int64_t)sj.x - (int64_t)(k - 1u) + t;
-        rec[t] = a >= 0 ? ms[a] : (uint8_t)0xFF;
+        const int64_t a = (int64_t)j_off - (int64_t)(k - 1u) + t;
+        w[t] = a >= 0 ? ms[a] : (uint8_t)0xFF;
         uint32_t ch = 0;
         if (cover) {
             const int64_t q = p - (int64_t)(k - 1u) + t;
             if (q >= -(int64_t)kPlanPad) ch = ix.pc_text[q];
             if (t == 0 && q >= 0) { // the node where the window begins: its own last character (the text holds edge labels)
-                const uint32_t row = ix.pc_node[q];
-                ch = row >= ix.C[3] ? 'T' : row >= ix.C[2] ? 'G' : row >= ix.C[1] ? 'C' : row >= ix.C[0] ? 'A' : '$';
+                const uint32_t r0 = ix.pc_node[q];
+                ch = r0 >= ix.C[3] ? 'T' : r0 >= ix.C[2] ? 'G' : r0 >= ix.C[1] ? 'C' : r0 >= ix.C[0] ? 'A' : '$';
             }
             broken = broken || ch == 0;
         }
-        rec[kpad + t] = (uint8_t)ch;
+        w[kpad + t] = (uint8_t)ch;
     }
-    if (__ballot(broken) != 0 && lane == 0) rec[2u * kpad] = 1;
-    else if (lane == 0) rec[2u * kpad] = 0;
+    const bool any_broken = __ballot(broken) != 0;
+    if (lane == 0) w[2u * kpad] = any_broken ? 1 : 0;
 }
 
 } // namespace
 
-hipError_t launch_call_gather(const void *d_sites, uint32_t n_sites, uint32_t k, const uint8_t *d_ms, const DevIndexView &ix,
-                              uint8_t *d_out, uint32_t stride, hipStream_t stream)
+hipError_t launch_call_finalize(const void *d_lists, const uint32_t *d_counts, const uint32_t *d_prefix, uint32_t seg_cap, uint32_t max_count,
+                                bool by_walk, const uint64_t *d_off, uint32_t n_seqs, uint32_t k, const uint8_t *d_ms,
+                                const DevIndexView &ix, void *d_recs, uint8_t *d_win, uint32_t stride, hipStream_t stream)
 {
-    if (n_sites == 0) return hipSuccess;
+    if (max_count == 0) return hipSuccess;
     const uint32_t kpad = (k + 15u) / 16u * 16u;
-    hipLaunchKernelGGL(call_gather_kernel, dim3((n_sites + 3u) / 4u), dim3(256), 0, stream, static_cast<const uint2 *>(d_sites), n_sites, k,
-                       kpad, d_ms, ix, d_out, stride);
+    hipLaunchKernelGGL(call_finalize_kernel, dim3((max_count + 3u) / 4u, kCallSegs), dim3(256), 0, stream, static_cast<const uint4 *>(d_lists),
+                       d_counts, d_prefix, seg_cap, by_walk ? 1u : 0u, d_off, n_seqs, k, kpad, d_ms, ix, static_cast<uint4 *>(d_recs), d_win,
+                       stride);
     return hipGetLastError();
 }
 

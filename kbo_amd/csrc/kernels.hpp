@@ -213,11 +213,14 @@ hipError_t launch_call_sites(const uint8_t *d_ms, const uint32_t *d_lo, const ui
                              uint32_t n_seqs, uint64_t total, uint32_t k, uint32_t threshold, void *d_sites, uint32_t cap,
                              uint32_t *d_count, hipStream_t stream);
 
-// per site {offset of j in the batch, row}: the k MS bytes ending at j and the k characters of the row (call_kernels.hip:
-// call_gather_kernel); record stride = call_gather_stride(k) bytes: MS bytes at 0, characters at kpad, flag byte at 2 kpad
+// behind the first pass of a batch's call: every site of the kCallSegs lists becomes {sequence, i, j, row} (void records stay
+// void) at index d_prefix[list] + slot of d_recs, and its window - the k MS bytes ending at j, the k characters of the row -
+// goes to d_win (call_kernels.hip call_finalize_kernel); record stride = call_gather_stride(k) bytes: MS bytes at 0,
+// characters at kpad, flag byte at 2 kpad
 inline uint32_t call_gather_stride(uint32_t k) { return 2u * ((k + 15u) / 16u * 16u) + 16u; }
-hipError_t launch_call_gather(const void *d_sites, uint32_t n_sites, uint32_t k, const uint8_t *d_ms, const DevIndexView &ix,
-                              uint8_t *d_out, uint32_t stride, hipStream_t stream);
+hipError_t launch_call_finalize(const void *d_lists, const uint32_t *d_counts, const uint32_t *d_prefix, uint32_t seg_cap, uint32_t max_count,
+                                bool by_walk, const uint64_t *d_off, uint32_t n_seqs, uint32_t k, const uint8_t *d_ms,
+                                const DevIndexView &ix, void *d_recs, uint8_t *d_win, uint32_t stride, hipStream_t stream);
 
 constexpr int kWalkThreads = 64; // default workgroup size (waves are independent: no LDS, no barriers)
 void set_walk_threads(int threads); // tuning: 64, 128 or 256

@@ -133,46 +133,44 @@ std::vector<uint8_t> get_kmer_ending_at(const uint8_t *query, size_t end_pos, si
 }
 
 // variant_calling.rs:60-71
-size_t longest_common_suffix(const std::vector<uint8_t> &x, const std::vector<uint8_t> &y)
+size_t longest_common_suffix(const uint8_t *x, const uint8_t *y, size_t k)
 {
     size_t len = 0;
-    for (size_t i = 0; i < std::min(x.size(), y.size()); i++) {
-        if (x[x.size() - 1 - i] == y[y.size() - 1 - i]) len++;
+    for (size_t i = 0; i < k; i++) {
+        if (x[k - 1 - i] == y[k - 1 - i]) len++;
         else break;
     }
     return len;
 }
 
 // variant_calling.rs:73-83
-bool rightmost_significant_peak(const std::vector<MsVal> &ms, size_t thr, size_t &peak)
+bool rightmost_significant_peak(const uint32_t *d, size_t n, size_t thr, size_t &peak)
 {
-    if (ms.empty()) throw RefPanic("assert!(!ms.is_empty())");
-    for (size_t i = ms.size() - 1; i-- > 0;) {
-        if (ms[i].d >= thr && ms[i].d > ms[i + 1].d) { peak = i; return true; }
+    if (n == 0) throw RefPanic("assert!(!ms.is_empty())");
+    for (size_t i = n - 1; i-- > 0;) {
+        if (d[i] >= thr && d[i] > d[i + 1]) { peak = i; return true; }
     }
     return false;
 }
 
-// variant_calling.rs:139-201; returns false for Err(ResolveVariantErr)
-bool resolve_variant(const std::vector<uint8_t> &query_kmer, const std::vector<uint8_t> &ref_kmer,
-                     const std::vector<MsVal> &ms_vs_query, const std::vector<MsVal> &ms_vs_ref, size_t thr,
-                     std::vector<uint8_t> &qchars, std::vector<uint8_t> &rchars)
+} // namespace
+
+// variant_calling.rs:139-201 on plain arrays; the variant's characters as index ranges into the two k-mers
+bool resolve_variant_ranges(const uint8_t *query_kmer, const uint8_t *ref_kmer, const uint32_t *d_vs_query, const uint32_t *d_vs_ref,
+                            size_t k, size_t thr, size_t &q_from, size_t &q_to, size_t &r_from, size_t &r_to)
 {
-    const size_t k = query_kmer.size();
-    if (ref_kmer.size() != k || ms_vs_query.size() != k || ms_vs_ref.size() != k) throw RefPanic("resolve_variant: length asserts");
-    const size_t csl = longest_common_suffix(query_kmer, ref_kmer);
+    const size_t csl = longest_common_suffix(query_kmer, ref_kmer, k);
     if (csl == 0) throw RefPanic("assert!(common_suffix_len > 0)");
     size_t qpeak = 0, rpeak = 0;
-    const bool hq = rightmost_significant_peak(ms_vs_ref, thr, qpeak);
-    const bool hr = rightmost_significant_peak(ms_vs_query, thr, rpeak);
+    const bool hq = rightmost_significant_peak(d_vs_ref, k, thr, qpeak);
+    const bool hr = rightmost_significant_peak(d_vs_query, k, thr, rpeak);
     if (!(hq && hr)) return false;
     const size_t sms = k - csl;
     const long query_gap = (long)sms - (long)qpeak - 1, ref_gap = (long)sms - (long)rpeak - 1;
-    qchars.clear();
-    rchars.clear();
+    q_from = q_to = r_from = r_to = 0;
     if (query_gap > 0 && ref_gap > 0) {
-        qchars.assign(query_kmer.begin() + qpeak + 1, query_kmer.begin() + sms);
-        rchars.assign(ref_kmer.begin() + rpeak + 1, ref_kmer.begin() + sms);
+        q_from = qpeak + 1; q_to = sms;
+        r_from = rpeak + 1; r_to = sms;
         return true;
     }
     const long qo = -query_gap, ro = -ref_gap;
@@ -180,11 +178,29 @@ bool resolve_variant(const std::vector<uint8_t> &query_kmer, const std::vector<u
     const size_t vlen = (size_t)std::labs(qo - ro);
     if (qo > ro) { // deletion in query
         if (rpeak + 1 + vlen > k) throw RefPanic("ref_kmer slice out of range");
-        rchars.assign(ref_kmer.begin() + rpeak + 1, ref_kmer.begin() + rpeak + 1 + vlen);
+        r_from = rpeak + 1; r_to = rpeak + 1 + vlen;
     } else { // insertion in query
         if (qpeak + 1 + vlen > k) throw RefPanic("query_kmer slice out of range");
-        qchars.assign(query_kmer.begin() + qpeak + 1, query_kmer.begin() + qpeak + 1 + vlen);
+        q_from = qpeak + 1; q_to = qpeak + 1 + vlen;
     }
+    return true;
+}
+
+namespace {
+
+// the same on the vectors the single-sequence path carries; returns false for Err(ResolveVariantErr)
+bool resolve_variant(const std::vector<uint8_t> &query_kmer, const std::vector<uint8_t> &ref_kmer,
+                     const std::vector<MsVal> &ms_vs_query, const std::vector<MsVal> &ms_vs_ref, size_t thr,
+                     std::vector<uint8_t> &qchars, std::vector<uint8_t> &rchars)
+{
+    const size_t k = query_kmer.size();
+    if (ref_kmer.size() != k || ms_vs_query.size() != k || ms_vs_ref.size() != k) throw RefPanic("resolve_variant: length asserts");
+    std::vector<uint32_t> dq(k), dr(k);
+    for (size_t i = 0; i < k; i++) { dq[i] = ms_vs_query[i].d; dr[i] = ms_vs_ref[i].d; }
+    size_t qf, qt, rf, rt;
+    if (!resolve_variant_ranges(query_kmer.data(), ref_kmer.data(), dq.data(), dr.data(), k, thr, qf, qt, rf, rt)) return false;
+    qchars.assign(query_kmer.begin() + qf, query_kmer.begin() + qt);
+    rchars.assign(ref_kmer.begin() + rf, ref_kmer.begin() + rt);
     return true;
 }
 

@@ -63,6 +63,11 @@ std::vector<Variant> resolve_call_sites(const std::vector<CallSite> &sites, cons
                                         const std::vector<uint8_t> *ref_kmers, const std::vector<MsVal> *ms_vs_ref,
                                         const std::vector<MsVal> *ms_vs_query, size_t threshold_d);
 
+// resolve_variant (variant_calling.rs:139-201) on plain arrays of k entries each (the depths of the two walks); the
+// variant's characters come back as index ranges into the two k-mers.  false = Err(ResolveVariantErr).
+bool resolve_variant_ranges(const uint8_t *query_kmer, const uint8_t *ref_kmer, const uint32_t *d_vs_query, const uint32_t *d_vs_ref,
+                            size_t k, size_t thr, size_t &q_from, size_t &q_to, size_t &r_from, size_t &r_to);
+
 // translate::add_variants (translate.rs:350-386)
 void add_variants(std::vector<uint8_t> &translation, const std::vector<Variant> &variants);
 

@@ -32,7 +32,7 @@ class PlanCounts(C.Structure):
         "seed_lookups", "seed_extensions", "pos_lookups", "compare_bases", "mismatches",
         "units_counted", "units", "units_head", "units_plain", "node_lookups",
         "walk_accepted", "walk_failed", "walk_contractions", "walk_entry_levels", "walk_short_windows", "walk_iterations_lines",
-        "walk_out_bytes", "unit_distinct_lines", "redo_bases", "redo_iterations")]
+        "walk_out_bytes", "unit_distinct_lines", "unit_distinct_rank_lines", "redo_bases", "redo_iterations")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

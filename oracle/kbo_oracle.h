@@ -170,7 +170,8 @@ typedef struct { /* all u64; per launch (the batch handed in) */
     uint64_t seed_lookups, seed_extensions, pos_lookups, compare_bases, mismatches;
     uint64_t units_counted, units, units_head, units_plain, node_lookups;
     uint64_t walk_accepted, walk_failed, walk_contractions, walk_entry_levels, walk_short_windows, walk_iterations_lines;
-    uint64_t walk_out_bytes, unit_distinct_lines;
+    uint64_t walk_out_bytes, unit_distinct_lines; /* distinct 128-byte lines a unit touches, summed over the units */
+    uint64_t unit_distinct_rank_lines;            /* ... of which rank-block lines (3.3 MB at C2: they stay in a 4 MiB L2) */
     uint64_t redo_bases, redo_iterations;
 } ora_plan_counts;
 

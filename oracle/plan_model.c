@@ -75,17 +75,18 @@ static inline uint32_t pm_nsv(const pm_index *m, uint32_t i) /* smallest j > i w
 #define PM_SET 512
 typedef struct { uint64_t key[PM_SET]; uint32_t used; } pm_set;
 static void pm_set_clear(pm_set *s) { memset(s->key, 0xFF, sizeof s->key); s->used = 0; }
-static void pm_touch(pm_set *s, uint32_t array, uint64_t byte_off)
+static int pm_touch(pm_set *s, uint32_t array, uint64_t byte_off) /* 1 when the line is new to the unit */
 {
-    if (s->used >= PM_SET / 2) return; /* (longer than any unit: stop counting rather than loop) */
+    if (s->used >= PM_SET / 2) return 0; /* (longer than any unit: stop counting rather than loop) */
     const uint64_t k = ((uint64_t)array << 56) | (byte_off >> 7);
     uint32_t h = (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 55) & (PM_SET - 1);
     while (s->key[h] != ~0ull) {
-        if (s->key[h] == k) return;
+        if (s->key[h] == k) return 0;
         h = (h + 1) & (PM_SET - 1);
     }
     s->key[h] = k;
     s->used++;
+    return 1;
 }
 enum { PM_A_RANK = 1, PM_A_ENT = 5, PM_A_LINE = 6, PM_A_UNIT = 7, PM_A_NODE = 8, PM_A_Q = 9, PM_A_OUT = 10 };
 
@@ -247,8 +248,8 @@ static int pm_walk_blocks(const pm_index *m, const uint8_t *q, const pm_unit *u,
             if (c < 4) {
                 l2 = (uint32_t)m->C[c] + pm_rank(m, c, s.l);
                 r2 = (uint32_t)m->C[c] + pm_rank(m, c, s.r);
-                pm_touch(lines, PM_A_RANK + (uint32_t)c, (uint64_t)(s.l / 96u) * 16u);
-                pm_touch(lines, PM_A_RANK + (uint32_t)c, (uint64_t)(s.r / 96u) * 16u);
+                cn->unit_distinct_rank_lines += (uint64_t)pm_touch(lines, PM_A_RANK + (uint32_t)c, (uint64_t)(s.l / 96u) * 16u);
+                cn->unit_distinct_rank_lines += (uint64_t)pm_touch(lines, PM_A_RANK + (uint32_t)c, (uint64_t)(s.r / 96u) * 16u);
             }
             const int ok = l2 < r2, accept = ok || s.d == 0;
             if (!accept) { /* nearest edge bits of c below l / from r on, inside the words the extension loaded */
