@@ -266,6 +266,32 @@ int kbo_find_batch_into(kbo_index_t *idx, const uint8_t *concat, const uint64_t 
                         const kbo_find_opts *opts, kbo_rle *rles, size_t capacity, uint64_t *rle_offsets,
                         size_t *n_runs);
 
+/* ------------------------------------------------------------------ packed batches
+ * The batch entry points above move one byte per base over PCIe in each direction, which is what bounds them (about
+ * 40 Gbp/s host -> host against 140 Gbp/s on the device).  Reads carry 2 bits per base and the alphabet of kbo::matches is
+ * exactly { M, -, X, R } (translate.rs:180-216), so these entry points take and return 2-bit words: a quarter of the bytes,
+ * the same kernels in between (the words are unpacked and packed on the device).
+ * Layout, input and output alike: sequence s of len_s bases occupies ceil(len_s / 16) little-endian u32 words, the
+ * sequences back to back in order (kbo_packed_words() in all); base i of a sequence sits in bits 2 (i mod 16), + 1 of its
+ * word i / 16.  Input: A, C, G, T = 0 .. 3; every other byte of the reads (N, lower case, ...: they break matches like in
+ * the reference) travels in a side list { position in base coordinates (offsets[] space), byte }, positions ascending,
+ * and the 2 bits at such a position are ignored.  Output: M, -, X, R = 0 .. 3.
+ * offsets[] counts BASES as everywhere else (n_seqs + 1 entries).  kbo_pack_reads / kbo_unpack_matches are host helpers
+ * (threaded) for callers that hold bytes; KBO_E_NOMEM from kbo_pack_reads when the reads hold more than exc_cap
+ * non-ACGT bases (*n_exc is set to their number). */
+size_t kbo_packed_words(const uint64_t *offsets, size_t n_seqs);
+int kbo_pack_reads(const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, uint32_t *words_out, uint64_t *exc_pos,
+                   uint8_t *exc_byte, size_t exc_cap, size_t *n_exc);
+int kbo_unpack_matches(const uint32_t *words, const uint64_t *offsets, size_t n_seqs, uint8_t *chars_out);
+/* kbo::matches (lib.rs:612-628) over a packed batch */
+int kbo_matches_batch_packed(kbo_index_t *idx, const uint32_t *words, const uint64_t *offsets, size_t n_seqs,
+                             const uint64_t *exc_pos, const uint8_t *exc_byte, size_t n_exc, double max_error_prob,
+                             uint32_t *words_out);
+/* kbo::find (lib.rs:808-821) over a packed batch: run lengths as kbo_find_batch returns them */
+int kbo_find_batch_packed(kbo_index_t *idx, const uint32_t *words, const uint64_t *offsets, size_t n_seqs,
+                          const uint64_t *exc_pos, const uint8_t *exc_byte, size_t n_exc, const kbo_find_opts *opts,
+                          kbo_rle **rles, uint64_t *rle_offsets);
+
 /* ------------------------------------------------------------------ device-resident path
  * Everything already in the HBM of the current device; kernels are enqueued on `stream`
  * (a hipStream_t) and the call returns immediately.  d_concat must be 16-byte aligned,

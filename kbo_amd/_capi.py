@@ -79,7 +79,8 @@ SYMBOLS = [
     "kbo_release_scratch", "kbo_run_lengths_gapped_batch", "kbo_find_batch_into", "kbo_derand_work_bytes",
     "kbo_run_lengths_work_bytes", "kbo_run_lengths_dev", "kbo_index_device_pair_bytes", "kbo_index_device_plan_bytes",
     "kbo_index_path_cover", "kbo_index_recovery_lines", "kbo_call_batch", "kbo_call_sites_dev", "kbo_call_walk_dev",
-    "kbo_index_save_sbwt", "kbo_index_load_sbwt",
+    "kbo_index_save_sbwt", "kbo_index_load_sbwt", "kbo_packed_words", "kbo_pack_reads", "kbo_unpack_matches",
+    "kbo_matches_batch_packed", "kbo_find_batch_packed",
 ]
 # ... and include/kbo_hip_tuning.h (knobs, experiment switches, test hooks: not part of the drop-in boundary)
 TUNING_SYMBOLS = [
@@ -178,6 +179,11 @@ def lib():
     L.kbo_set_walk_experiment.argtypes = [C.c_int, C.c_int]
     L.kbo_plan_stats_dev.argtypes = [sz, u64, sz, C.c_uint32, vp, vp, vp]
     L.kbo_run_automaton_depths.argtypes = [vp, sz, C.c_uint32, C.c_int, vp, sz, vp]
+    L.kbo_packed_words.argtypes = [vp, sz]; L.kbo_packed_words.restype = sz
+    L.kbo_pack_reads.argtypes = [vp, vp, sz, vp, vp, vp, sz, C.POINTER(sz)]
+    L.kbo_unpack_matches.argtypes = [vp, vp, sz, vp]
+    L.kbo_matches_batch_packed.argtypes = [vp, vp, vp, sz, vp, vp, sz, dbl, vp]
+    L.kbo_find_batch_packed.argtypes = [vp, vp, vp, sz, vp, vp, sz, C.POINTER(FindOpts), C.POINTER(C.POINTER(RLE)), vp]
     L.kbo_set_plan_unit_cap_divisor.argtypes = [C.c_int]
     L.kbo_set_seed_table_depth.argtypes = [C.c_int]
     L.kbo_index_plan_holdoff.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]

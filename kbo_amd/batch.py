@@ -79,6 +79,55 @@ def call_batch(sbwt, concat, offsets, call_opts=None):
     return [allv[int(vo[s]):int(vo[s + 1])] for s in range(n)]
 
 
+def pack_reads(concat, offsets):
+    """bytes -> (u32 words, exception positions u64, exception bytes u8): the layout of kbo_hip.h's packed entry points"""
+    concat, offsets, n = _prep(concat, offsets)
+    words = np.zeros(int(lib().kbo_packed_words(offsets.ctypes.data, n)), dtype=np.uint32)
+    cap = 1024
+    while True:
+        pos, byt, ne = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint8), C.c_size_t(0)
+        rc = lib().kbo_pack_reads(concat.ctypes.data, offsets.ctypes.data, n, words.ctypes.data, pos.ctypes.data, byt.ctypes.data,
+                                  cap, C.byref(ne))
+        if rc == -5 and ne.value > cap:  # KBO_E_NOMEM: more non-ACGT bases than the list held
+            cap = ne.value
+            continue
+        check(rc)
+        return words, pos[:ne.value].copy(), byt[:ne.value].copy()
+
+
+def unpack_matches(words, offsets):
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    out = np.zeros(int(offsets[-1]), dtype=np.uint8)
+    check(lib().kbo_unpack_matches(words.ctypes.data, offsets.ctypes.data, len(offsets) - 1, out.ctypes.data))
+    return out
+
+
+def matches_batch_packed(sbwt, words, offsets, exc_pos, exc_byte, max_error_prob=1e-7):
+    """kbo::matches over 2-bit packed reads -> 2-bit packed characters (M, -, X, R = 0 .. 3), same word layout"""
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    out = np.zeros(len(words), dtype=np.uint32)
+    check(lib().kbo_matches_batch_packed(sbwt._h, words.ctypes.data, offsets.ctypes.data, len(offsets) - 1,
+                                         exc_pos.ctypes.data if len(exc_pos) else None, exc_byte.ctypes.data if len(exc_byte) else None,
+                                         len(exc_pos), max_error_prob, out.ctypes.data))
+    return out
+
+
+def find_batch_packed(sbwt, words, offsets, exc_pos, exc_byte, find_opts=None):
+    from . import FindOpts
+    o = find_opts if find_opts is not None else FindOpts()
+    co = _capi.FindOpts(o.max_error_prob, o.max_gap_len)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    ro = np.zeros(n + 1, dtype=np.uint64)
+    p = C.POINTER(_capi.RLE)()
+    check(lib().kbo_find_batch_packed(sbwt._h, words.ctypes.data, offsets.ctypes.data, n, exc_pos.ctypes.data if len(exc_pos) else None,
+                                      exc_byte.ctypes.data if len(exc_byte) else None, len(exc_pos), C.byref(co), C.byref(p), ro.ctypes.data))
+    total = int(ro[-1])
+    rles = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(max(1, total), 7))[:total].copy()
+    lib().kbo_free(p)
+    return rles, ro
+
+
 def call_batch_arrays(sbwt, concat, offsets, call_opts=None):
     """kbo_call_batch without a Python object per variant -> dict of numpy arrays: var_offsets (n_seqs + 1), query_pos,
     query_len, ref_len (one entry per variant) and chars (per variant its query characters, then its reference

@@ -147,13 +147,8 @@ class RunAutomaton {
 public:
     void build(const uint8_t *seq, size_t len, uint32_t k, bool add_revcomp)
     {
-        next_.clear();
-        link_.clear();
-        len_.clear();
-        const size_t states = 2 * (add_revcomp ? 2 * len : len) + 2; // (at most two states per character)
-        next_.reserve(4 * states);
-        link_.reserve(states);
-        len_.reserve(states);
+        st_.clear();
+        st_.reserve(2 * (add_revcomp ? 2 * len : len) + 2); // (at most two states per character)
         new_state(0, -1);
         size_t run = 0;
         for (size_t i = 0; i <= len; i++) {
@@ -178,55 +173,57 @@ public:
         for (uint32_t t = 0; t < k; t++) {
             const int c = code(kmer[t]);
             if (c < 0) { v = 0; l = 0; out[t] = 0; continue; }
-            while (v != 0 && next_[(size_t)v * 4 + c] < 0) { v = link_[v]; l = (uint32_t)len_[v]; }
-            if (next_[(size_t)v * 4 + c] >= 0) { v = next_[(size_t)v * 4 + c]; l++; }
+            while (v != 0 && st_[v].next[c] < 0) { v = st_[v].link; l = (uint32_t)st_[v].len; }
+            if (st_[v].next[c] >= 0) { v = st_[v].next[c]; l++; }
             else { v = 0; l = 0; }
             out[t] = l < k ? l : k;
         }
     }
 
 private:
+    struct State { // 24 bytes: a state's transitions, suffix link and length share a cache line
+        int32_t next[4], link, len;
+    };
     static int code(uint8_t ch) { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1; }
     int32_t new_state(int32_t length, int32_t link)
     {
-        len_.push_back(length);
-        link_.push_back(link);
-        next_.insert(next_.end(), 4, -1);
-        return (int32_t)len_.size() - 1;
+        st_.push_back(State{{-1, -1, -1, -1}, link, length});
+        return (int32_t)st_.size() - 1;
     }
     int32_t clone_of(int32_t q, int32_t length)
     {
-        const int32_t cl = new_state(length, link_[q]);
-        for (int c = 0; c < 4; c++) next_[(size_t)cl * 4 + c] = next_[(size_t)q * 4 + c];
-        return cl;
+        State c = st_[q];
+        c.len = length;
+        st_.push_back(c);
+        return (int32_t)st_.size() - 1;
     }
     void extend(int c) // (generalised: `last_` may be the root again at the start of every run)
     {
         int32_t p = last_;
-        if (next_[(size_t)p * 4 + c] >= 0) {
-            const int32_t q = next_[(size_t)p * 4 + c];
-            if (len_[p] + 1 == len_[q]) { last_ = q; return; }
-            const int32_t cl = clone_of(q, len_[p] + 1);
-            while (p >= 0 && next_[(size_t)p * 4 + c] == q) { next_[(size_t)p * 4 + c] = cl; p = link_[p]; }
-            link_[q] = cl;
+        if (st_[p].next[c] >= 0) {
+            const int32_t q = st_[p].next[c];
+            if (st_[p].len + 1 == st_[q].len) { last_ = q; return; }
+            const int32_t cl = clone_of(q, st_[p].len + 1);
+            while (p >= 0 && st_[p].next[c] == q) { st_[p].next[c] = cl; p = st_[p].link; }
+            st_[q].link = cl;
             last_ = cl;
             return;
         }
-        const int32_t cur = new_state(len_[p] + 1, 0);
-        while (p >= 0 && next_[(size_t)p * 4 + c] < 0) { next_[(size_t)p * 4 + c] = cur; p = link_[p]; }
+        const int32_t cur = new_state(st_[p].len + 1, 0);
+        while (p >= 0 && st_[p].next[c] < 0) { st_[p].next[c] = cur; p = st_[p].link; }
         if (p >= 0) {
-            const int32_t q = next_[(size_t)p * 4 + c];
-            if (len_[p] + 1 == len_[q]) link_[cur] = q;
+            const int32_t q = st_[p].next[c];
+            if (st_[p].len + 1 == st_[q].len) st_[cur].link = q;
             else {
-                const int32_t cl = clone_of(q, len_[p] + 1);
-                while (p >= 0 && next_[(size_t)p * 4 + c] == q) { next_[(size_t)p * 4 + c] = cl; p = link_[p]; }
-                link_[q] = cl;
-                link_[cur] = cl;
+                const int32_t cl = clone_of(q, st_[p].len + 1);
+                while (p >= 0 && st_[p].next[c] == q) { st_[p].next[c] = cl; p = st_[p].link; }
+                st_[q].link = cl;
+                st_[cur].link = cl;
             }
         }
         last_ = cur;
     }
-    std::vector<int32_t> next_, link_, len_;
+    std::vector<State> st_;
     int32_t last_ = 0;
 };
 

@@ -107,11 +107,23 @@ size_t random_match_threshold(size_t k, size_t n_kmers, size_t alphabet_size, do
 // ---- host_batch.cpp
 struct BatchOnDevice {
     DevBuf q, off, items, ms, lo, hi, plan;
+    DevBuf packed, pscr, exc_pos, exc_byte, packed_out; // packed entry points: 2-bit words in, scanned words per sequence, non-ACGT list, 2-bit words out
     uint64_t total = 0;
     void release()
     {
-        for (DevBuf *b : {&q, &off, &items, &ms, &lo, &hi, &plan}) b->release();
+        for (DevBuf *b : {&q, &off, &items, &ms, &lo, &hi, &plan, &packed, &pscr, &exc_pos, &exc_byte, &packed_out}) b->release();
     }
+};
+// a slab of a packed batch (pack_kernels.hip: sequence s = ceil(len / 16) u32 words, 2 bits per base): what
+// enqueue_walk_host uploads and unpacks into B.q instead of uploading bytes
+struct PackedIn {
+    const uint32_t *words;      // the slab's words (host; pinned or staged by the caller)
+    size_t n_words;
+    const uint64_t *exc_pos;    // non-ACGT bases of the slab: positions in the whole batch's base coordinates, ascending ...
+    const uint8_t *exc_byte;    // ... and their bytes
+    size_t n_exc;
+    uint64_t base;              // the slab's first base in those coordinates
+    uint32_t uniform_len;       // != 0: every sequence of the slab has this many bases (offsets are made on the device)
 };
 struct Slab {
     size_t s0, s1;   // sequences [s0, s1)
@@ -158,7 +170,8 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
                        uint32_t longest = 0 /* longest sequence if the caller knows it */,
                        hipStream_t copy_stream = nullptr /* uploads go here when given ... */,
                        hipEvent_t copied = nullptr /* ... and `stream` waits for this event */,
-                       const CallSink *call = nullptr /* call mode: MS values + sites, no intervals */);
+                       const CallSink *call = nullptr /* call mode: MS values + sites, no intervals */,
+                       const PackedIn *packed = nullptr /* the queries arrive 2-bit packed (concat is not read) */);
 void run_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, bool want_ival,
                    BatchOnDevice &B, hipStream_t stream);
 // A5+A6 over a batch whose offsets are known on the host
@@ -171,6 +184,16 @@ void widen_rles(kbo_rle *dst, const uint32_t *src, size_t n, HostTeam &team);
 // characters are turned into run lengths on the device instead of being downloaded (lib.rs:816-820)
 void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                         double max_error_prob, bool format, uint8_t *chars_out, RleSink *sink = nullptr);
+// the same over 2-bit packed reads (pack_kernels.hip layout) with the non-ACGT bases in a side list; the characters come
+// back 2-bit packed as well (M, -, X, R = 0 .. 3) or, with a sink, as run lengths
+struct PackedBatch {
+    const uint32_t *words;
+    const uint64_t *exc_pos;
+    const uint8_t *exc_byte;
+    size_t n_exc;
+};
+void matches_batch_packed_impl(kbo_index *idx, const PackedBatch &in, const uint64_t *offsets, size_t n_seqs, double max_error_prob,
+                               uint32_t *packed_out, RleSink *sink = nullptr);
 // A1 over a host batch: MS values, and intervals when lo/hi are given
 void ms_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, uint8_t *d_out,
                    uint32_t *lo_out, uint32_t *hi_out);

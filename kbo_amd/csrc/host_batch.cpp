@@ -102,7 +102,7 @@ struct PhaseClock {
 // `items_keep` must stay alive until the stream has been synchronised.
 void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                        bool want_ival, BatchOnDevice &B, std::vector<kbo::WalkItem> &items_keep, hipStream_t stream,
-                       uint32_t longest, hipStream_t copy_stream, hipEvent_t copied, const CallSink *call)
+                       uint32_t longest, hipStream_t copy_stream, hipEvent_t copied, const CallSink *call, const PackedIn *packed)
 {
     KBO_REQUIRE(idx->host.k <= 255, KBO_E_UNSUPPORTED, "k > 255");
     const int dev = current_device();
@@ -133,14 +133,38 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
         B.hi.ensure(total * sizeof(uint32_t));
     }
     hipStream_t up = copy_stream ? copy_stream : stream;
-    HIP_OK(hipMemcpyAsync(B.q.p, concat, total, hipMemcpyHostToDevice, up));
-    HIP_OK(hipMemcpyAsync(B.off.p, offsets, (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, up));
+    const bool uniform = packed && packed->uniform_len != 0;
+    if (packed) { // a quarter of the bytes: 2-bit words + the non-ACGT list; unpacked into B.q below
+        B.packed.ensure(packed->n_words * 4 + 16);
+        HIP_OK(hipMemcpyAsync(B.packed.p, packed->words, packed->n_words * 4, hipMemcpyHostToDevice, up));
+        if (packed->n_exc) {
+            B.exc_pos.ensure(packed->n_exc * 8);
+            B.exc_byte.ensure(packed->n_exc);
+            HIP_OK(hipMemcpyAsync(B.exc_pos.p, packed->exc_pos, packed->n_exc * 8, hipMemcpyHostToDevice, up));
+            HIP_OK(hipMemcpyAsync(B.exc_byte.p, packed->exc_byte, packed->n_exc, hipMemcpyHostToDevice, up));
+        }
+    } else {
+        HIP_OK(hipMemcpyAsync(B.q.p, concat, total, hipMemcpyHostToDevice, up));
+    }
+    if (!uniform) HIP_OK(hipMemcpyAsync(B.off.p, offsets, (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, up));
     if (!device_items)
         HIP_OK(hipMemcpyAsync(B.items.p, items_keep.data(), items_keep.size() * sizeof(kbo::WalkItem),
                               hipMemcpyHostToDevice, up));
     if (copy_stream) {
         HIP_OK(hipEventRecord(copied, copy_stream));
         HIP_OK(hipStreamWaitEvent(stream, copied, 0));
+    }
+    if (packed) {
+        if (uniform) HIP_OK(kbo::launch_uniform_offsets(B.off.as<uint64_t>(), (uint32_t)n_seqs, packed->uniform_len, stream));
+        else {
+            B.pscr.ensure(kbo::chunk_items_scratch_words((uint32_t)n_seqs) * sizeof(uint32_t));
+            HIP_OK(kbo::launch_packed_prefix(B.off.as<uint64_t>(), (uint32_t)n_seqs, B.pscr.as<uint32_t>(), stream));
+        }
+        HIP_OK(kbo::launch_unpack2(B.packed.as<uint32_t>(), (uint32_t)packed->n_words, B.off.as<uint64_t>(), (uint32_t)n_seqs,
+                                   uniform ? (packed->uniform_len + 15u) / 16u : 0u, uniform ? nullptr : B.pscr.as<uint32_t>(),
+                                   B.q.as<uint8_t>(), stream));
+        HIP_OK(kbo::launch_exceptions(B.exc_pos.as<uint64_t>(), B.exc_byte.as<uint8_t>(), (uint32_t)packed->n_exc, packed->base,
+                                      B.q.as<uint8_t>(), stream));
     }
     if (device_items) HIP_OK(kbo::launch_make_items(B.off.as<uint64_t>(), (uint32_t)n_seqs, B.items.as<kbo::WalkItem>(), stream));
     kbo::WalkArgs a{};
@@ -396,6 +420,12 @@ struct BatchJob {
     bool in_pinned, out_pinned; // user buffers the DMA engines reach directly are used in place
     const std::vector<Slab> *slabs;
     PhaseClock *clk;     // phase timing (worker 0 only)
+    // packed mode (kbo_matches_batch_packed / kbo_find_batch_packed): 2-bit words in, 2-bit words (or run lengths) out
+    const PackedBatch *packed = nullptr;
+    uint32_t *packed_out = nullptr;
+    const uint64_t *pw = nullptr;   // first word of every sequence (n_seqs + 1), nullptr when ...
+    uint32_t uniform_len = 0;       // ... all sequences have this many bases
+    uint64_t word_of(size_t s) const { return pw ? pw[s] : (uint64_t)s * ((uniform_len + 15u) / 16u); }
 };
 
 // One device's share of a batch: slabs `first`, `first + stride`, ... rotate through the slots of a
@@ -483,14 +513,32 @@ private:
             longest[t] = m;
         });
         const uint32_t mx = (uint32_t)*std::max_element(longest.begin(), longest.end());
-        const uint8_t *src = job_.concat + sl.b0;
-        if (!job_.in_pinned) {
+        const uint8_t *src = job_.concat ? job_.concat + sl.b0 : nullptr;
+        PackedIn pin{};
+        const uint64_t w0 = job_.packed ? job_.word_of(sl.s0) : 0, w1 = job_.packed ? job_.word_of(sl.s1) : 0;
+        if (job_.packed) {
+            pin.words = job_.packed->words + w0;
+            pin.n_words = (size_t)(w1 - w0);
+            if (!job_.in_pinned) {
+                S.in.ensure(pin.n_words * 4 + 16);
+                team.copy(S.in.p, pin.words, pin.n_words * 4);
+                pin.words = S.in.as<uint32_t>();
+            }
+            const uint64_t *e0 = std::lower_bound(job_.packed->exc_pos, job_.packed->exc_pos + job_.packed->n_exc, sl.b0);
+            const uint64_t *e1 = std::lower_bound(e0, job_.packed->exc_pos + job_.packed->n_exc, sl.b1);
+            pin.exc_pos = e0;
+            pin.exc_byte = job_.packed->exc_byte + (e0 - job_.packed->exc_pos);
+            pin.n_exc = (size_t)(e1 - e0);
+            pin.base = sl.b0;
+            pin.uniform_len = job_.uniform_len;
+        } else if (!job_.in_pinned) {
             S.in.ensure(bytes);
             team.copy(S.in.p, src, bytes);
             src = S.in.as<uint8_t>();
         }
         lap("  offsets + copy in");
-        enqueue_walk_host(job_.idx, src, off, ns, job_.lo_out != nullptr, S.B, S.items, C.st_run, mx, C.st_up, S.copied);
+        enqueue_walk_host(job_.idx, src, off, ns, job_.lo_out != nullptr, S.B, S.items, C.st_run, mx, C.st_up, S.copied, nullptr,
+                          job_.packed ? &pin : nullptr);
         if (job_.ms_out) { // A1 only: MS values (and intervals) straight back
             HIP_OK(hipEventRecord(S.computed, C.st_run));
             HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
@@ -542,8 +590,8 @@ private:
             // engines carry both directions at once (tools/bench_host.py: 37-40 Gbp/s host->host;
             // a small kernel storing into pinned memory, or A5/A6 storing there themselves, gave
             // 28 and 26 Gbp/s).
-            uint8_t *dst = job_.chars_out + sl.b0;
-            if (!job_.out_pinned) {
+            uint8_t *dst = job_.packed_out ? nullptr : job_.chars_out + sl.b0;
+            if (!job_.out_pinned && !job_.packed_out) {
                 S.out.ensure(bytes + 32);
                 dst = S.out.as<uint8_t>();
             }
@@ -551,6 +599,26 @@ private:
             derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, job_.k, job_.threshold,
                                           job_.format ? S.B.q.as<uint8_t>() : nullptr, S.chars.as<uint8_t>(), nullptr,
                                           C.st_run, mx, &S.dt_work);
+            if (job_.packed_out) { // the characters leave as 2-bit words: a quarter of the bytes
+                const size_t nw = (size_t)(w1 - w0);
+                S.B.packed_out.ensure(nw * 4 + 16);
+                HIP_OK(kbo::launch_pack2(S.chars.as<uint8_t>(), (uint32_t)nw, S.B.off.as<uint64_t>(), (uint32_t)ns,
+                                         job_.uniform_len ? (job_.uniform_len + 15u) / 16u : 0u,
+                                         job_.uniform_len ? nullptr : S.B.pscr.as<uint32_t>(), S.B.packed_out.as<uint32_t>(), C.st_run));
+                HIP_OK(hipEventRecord(S.computed, C.st_run));
+                HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
+                uint8_t *pdst = reinterpret_cast<uint8_t *>(job_.packed_out + w0);
+                if (!job_.out_pinned) {
+                    S.out.ensure(nw * 4 + 32);
+                    pdst = S.out.as<uint8_t>();
+                }
+                HIP_OK(hipMemcpyAsync(pdst, S.B.packed_out.p, nw * 4, hipMemcpyDeviceToHost, C.st_down));
+                HIP_OK(hipEventRecord(S.done, C.st_down));
+                S.busy = true;
+                S.out_b0 = w0 * 4; // (finish() copies out_bytes bytes to chars_out + out_b0: chars_out is the packed buffer here)
+                S.out_bytes = nw * 4;
+                return;
+            }
             HIP_OK(hipEventRecord(S.computed, C.st_run));
             HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
             HIP_OK(hipMemcpyAsync(dst, S.chars.p, bytes, hipMemcpyDeviceToHost, C.st_down));
@@ -771,6 +839,73 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
         sink->first.assign(slabs.size(), {});
     }
     if (job.sink_direct && !sink->caller_owns) { // room for 2 runs per sequence to start with (untouched pages cost nothing)
+        sink->all_cap = 2 * n_seqs + 1024;
+        sink->all = static_cast<kbo_rle *>(std::malloc(sink->all_cap * sizeof(kbo_rle)));
+        if (!sink->all) throw std::bad_alloc();
+    }
+    if (sink) sink->direct = job.sink_direct;
+    if (job.sink_direct) sink->rle_offsets[0] = 0;
+    clk.lap("slab list");
+    run_on_devices(job, devices, nd);
+}
+
+// kbo::matches / kbo::find over a batch of 2-bit packed reads: the same pipeline, a quarter of the bytes over PCIe each way
+void matches_batch_packed_impl(kbo_index *idx, const PackedBatch &in, const uint64_t *offsets, size_t n_seqs, double max_error_prob,
+                               uint32_t *packed_out, RleSink *sink)
+{
+    KBO_REQUIRE(idx && in.words && (packed_out || sink), KBO_E_BAD_ARG, "null argument");
+    KBO_REQUIRE(in.n_exc == 0 || (in.exc_pos && in.exc_byte), KBO_E_BAD_ARG, "null exception list");
+    PhaseClock clk;
+    const size_t k = idx->host.k;
+    const size_t threshold = random_match_threshold(k, idx->host.n_kmers, 4, max_error_prob); // lib.rs:620
+    KBO_REQUIRE(offsets, KBO_E_BAD_ARG, "null offsets");
+    KBO_REQUIRE(n_seqs > 0, KBO_E_EMPTY_QUERY, "no sequences");
+    KBO_REQUIRE(n_seqs < 0xFFFFFFFFull, KBO_E_UNSUPPORTED, "more than 2^32-1 sequences per call");
+    KBO_REQUIRE(offsets[0] == 0, KBO_E_BAD_ARG, "offsets[0] must be 0");
+    const OffsetScan scan = scan_offsets(offsets, n_seqs);
+    KBO_REQUIRE(scan.monotone, KBO_E_BAD_ARG, "offsets not monotone");
+    KBO_REQUIRE(scan.shortest > 0, KBO_E_EMPTY_QUERY, "empty query (index.rs:248 assert!(!query.is_empty()))");
+    KBO_REQUIRE(scan.longest < 0xFFFFFFFFull, KBO_E_UNSUPPORTED, "sequence longer than 2^32-1");
+    KBO_REQUIRE(threshold > 1, KBO_E_THRESHOLD_LE_1, "threshold > 1 (derandomize.rs:275, translate.rs:269)");
+    KBO_REQUIRE(scan.shortest > 2, KBO_E_LEN_LE_2, "len > 2 (derandomize.rs:276, translate.rs:270)");
+    for (size_t x = 0; x < in.n_exc; x++) // (ascending, inside the batch: the slabs cut the list by binary search)
+        KBO_REQUIRE(in.exc_pos[x] < offsets[n_seqs] && (x == 0 || in.exc_pos[x] > in.exc_pos[x - 1]), KBO_E_BAD_ARG,
+                    "exception positions must ascend and lie inside the batch");
+    clk.lap("argument checks");
+    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
+    std::vector<int> devices = devices_snapshot();
+    if (devices.empty()) devices.push_back(current_device());
+    const size_t nd = std::min(devices.size(), std::max<size_t>(1, slabs.size()));
+    std::vector<uint64_t> pw;
+    const bool uniform = scan.shortest == scan.longest;
+    if (!uniform) { // first word of every sequence
+        pw.resize(n_seqs + 1);
+        pw[0] = 0;
+        for (size_t s = 0; s < n_seqs; s++) pw[s + 1] = pw[s] + (offsets[s + 1] - offsets[s] + 15) / 16;
+    }
+    BatchJob job;
+    job.idx = idx;
+    job.concat = nullptr;
+    job.offsets = offsets;
+    job.k = (uint32_t)k;
+    job.threshold = (uint32_t)threshold;
+    job.format = false;
+    job.chars_out = reinterpret_cast<uint8_t *>(packed_out); // (finish() copies bytes: the packed words of a slab)
+    job.packed_out = sink ? nullptr : packed_out;
+    job.sink = sink;
+    job.sink_direct = sink && nd == 1;
+    job.packed = &in;
+    job.pw = uniform ? nullptr : pw.data();
+    job.uniform_len = uniform ? (uint32_t)scan.longest : 0u;
+    job.in_pinned = is_pinned_host(in.words);
+    job.out_pinned = sink || is_pinned_host(packed_out);
+    job.slabs = &slabs;
+    job.clk = &clk;
+    if (sink) {
+        sink->runs.assign(slabs.size(), {});
+        sink->first.assign(slabs.size(), {});
+    }
+    if (job.sink_direct && !sink->caller_owns) {
         sink->all_cap = 2 * n_seqs + 1024;
         sink->all = static_cast<kbo_rle *>(std::malloc(sink->all_cap * sizeof(kbo_rle)));
         if (!sink->all) throw std::bad_alloc();

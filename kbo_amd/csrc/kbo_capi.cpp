@@ -789,6 +789,118 @@ int kbo_find_batch_into(kbo_index_t *idx, const uint8_t *concat, const uint64_t 
     });
 }
 
+// ---- 2-bit packed batches (pack_kernels.hip has the layout) ------------------------------------------------------------
+
+size_t kbo_packed_words(const uint64_t *offsets, size_t n_seqs)
+{
+    if (!offsets) return 0;
+    size_t w = 0;
+    for (size_t s = 0; s < n_seqs; s++) w += (size_t)((offsets[s + 1] - offsets[s] + 15) / 16);
+    return w;
+}
+
+int kbo_pack_reads(const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, uint32_t *words_out, uint64_t *exc_pos,
+                   uint8_t *exc_byte, size_t exc_cap, size_t *n_exc)
+{
+    return guarded([&] {
+        KBO_REQUIRE(concat && offsets && words_out && n_exc && (exc_cap == 0 || (exc_pos && exc_byte)), KBO_E_BAD_ARG, "null argument");
+        std::vector<uint64_t> pw(n_seqs + 1, 0);
+        for (size_t s = 0; s < n_seqs; s++) {
+            KBO_REQUIRE(offsets[s + 1] >= offsets[s], KBO_E_BAD_ARG, "offsets not monotone");
+            pw[s + 1] = pw[s] + (offsets[s + 1] - offsets[s] + 15) / 16;
+        }
+        const size_t piece = 4096, n_tasks = (n_seqs + piece - 1) / piece;
+        std::vector<std::vector<std::pair<uint64_t, uint8_t>>> exc(n_tasks); // (in order inside a task, tasks in order)
+        HostTeam::get().run(n_tasks, [&](size_t t) {
+            for (size_t s = t * piece; s < std::min(n_seqs, (t + 1) * piece); s++) {
+                const uint64_t b0 = offsets[s], len = offsets[s + 1] - b0;
+                uint32_t *w = words_out + pw[s];
+                for (uint64_t i0 = 0; i0 < len; i0 += 16) {
+                    uint32_t v = 0;
+                    const uint64_t nb = std::min<uint64_t>(16, len - i0);
+                    for (uint64_t i = 0; i < nb; i++) {
+                        const uint8_t ch = concat[b0 + i0 + i];
+                        const uint32_t c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+                        if (c == 4u) exc[t].emplace_back(b0 + i0 + i, ch);
+                        v |= (c & 3u) << (2 * i);
+                    }
+                    w[i0 / 16] = v;
+                }
+            }
+        });
+        size_t total = 0;
+        for (const auto &e : exc) total += e.size();
+        *n_exc = total;
+        KBO_REQUIRE(total <= exc_cap, KBO_E_NOMEM, "more non-ACGT bases than the exception list holds (*n_exc says how many)");
+        size_t x = 0;
+        for (const auto &e : exc)
+            for (const auto &pr : e) {
+                exc_pos[x] = pr.first;
+                exc_byte[x++] = pr.second;
+            }
+    });
+}
+
+int kbo_unpack_matches(const uint32_t *words, const uint64_t *offsets, size_t n_seqs, uint8_t *chars_out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(words && offsets && chars_out, KBO_E_BAD_ARG, "null argument");
+        std::vector<uint64_t> pw(n_seqs + 1, 0);
+        for (size_t s = 0; s < n_seqs; s++) pw[s + 1] = pw[s] + (offsets[s + 1] - offsets[s] + 15) / 16;
+        const size_t piece = 4096;
+        HostTeam::get().run((n_seqs + piece - 1) / piece, [&](size_t t) {
+            for (size_t s = t * piece; s < std::min(n_seqs, (t + 1) * piece); s++) {
+                const uint64_t b0 = offsets[s], len = offsets[s + 1] - b0;
+                const uint32_t *w = words + pw[s];
+                for (uint64_t i = 0; i < len; i++) chars_out[b0 + i] = (uint8_t)"M-XR"[(w[i / 16] >> (2 * (i % 16))) & 3u];
+            }
+        });
+    });
+}
+
+int kbo_matches_batch_packed(kbo_index_t *idx, const uint32_t *words, const uint64_t *offsets, size_t n_seqs, const uint64_t *exc_pos,
+                             const uint8_t *exc_byte, size_t n_exc, double max_error_prob, uint32_t *words_out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && words && words_out, KBO_E_BAD_ARG, "null argument");
+        const PackedBatch in{words, exc_pos, exc_byte, n_exc};
+        matches_batch_packed_impl(idx, in, offsets, n_seqs, max_error_prob, words_out, nullptr);
+    });
+}
+
+int kbo_find_batch_packed(kbo_index_t *idx, const uint32_t *words, const uint64_t *offsets, size_t n_seqs, const uint64_t *exc_pos,
+                          const uint8_t *exc_byte, size_t n_exc, const kbo_find_opts *opts, kbo_rle **rles, uint64_t *rle_offsets)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && words && rles && rle_offsets, KBO_E_BAD_ARG, "null argument");
+        kbo_find_opts o;
+        if (opts) o = *opts; else kbo_find_opts_default(&o);
+        RleSink sink;
+        sink.max_gap_len = o.max_gap_len;
+        sink.rle_offsets = rle_offsets;
+        const PackedBatch in{words, exc_pos, exc_byte, n_exc};
+        matches_batch_packed_impl(idx, in, offsets, n_seqs, o.max_error_prob, nullptr, &sink);
+        if (sink.direct) { // one device: the records are already in place
+            *rles = sink.all;
+            sink.all = nullptr;
+            return;
+        }
+        // several devices: slabs completed out of order and were kept per slab; put them together
+        const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
+        std::vector<uint64_t> base(slabs.size() + 1, 0);
+        for (size_t i = 0; i < slabs.size(); i++) base[i + 1] = base[i] + sink.runs[i].size();
+        kbo_rle *all = static_cast<kbo_rle *>(std::malloc(std::max<uint64_t>(1, base.back()) * sizeof(kbo_rle)));
+        if (!all) throw std::bad_alloc();
+        rle_offsets[0] = 0;
+        HostTeam::get().run(slabs.size(), [&](size_t i) {
+            if (!sink.runs[i].empty()) std::memcpy(all + base[i], sink.runs[i].data(), sink.runs[i].size() * sizeof(kbo_rle));
+            const size_t ns = slabs[i].s1 - slabs[i].s0;
+            for (size_t q = 1; q <= ns; q++) rle_offsets[slabs[i].s0 + q] = base[i] + sink.first[i][q];
+        });
+        *rles = all;
+    });
+}
+
 int kbo_find(kbo_index_t *idx, const uint8_t *query, size_t len, const kbo_find_opts *opts, kbo_rle **out,
              size_t *n_out)
 {

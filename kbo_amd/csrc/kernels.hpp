@@ -222,6 +222,17 @@ hipError_t launch_call_finalize(const void *d_lists, const uint32_t *d_counts, c
                                 bool by_walk, const uint64_t *d_off, uint32_t n_seqs, uint32_t k, const uint8_t *d_ms,
                                 const DevIndexView &ix, void *d_recs, uint8_t *d_win, uint32_t stride, hipStream_t stream);
 
+// 2-bit packed reads in / packed alignments out (pack_kernels.hip): sequence s occupies ceil(len / 16) u32 words, base i in
+// bits 2 (i mod 16) of word i / 16.  uniform_wps != 0: all sequences have that many words (no prefix needed); otherwise
+// d_scratch holds the scanned words-per-sequence (launch_packed_prefix; chunk_items_scratch_words(n_seqs) u32)
+hipError_t launch_uniform_offsets(uint64_t *d_off, uint32_t n_seqs, uint32_t len, hipStream_t stream);
+hipError_t launch_packed_prefix(const uint64_t *d_off, uint32_t n_seqs, uint32_t *d_scratch, hipStream_t stream);
+hipError_t launch_unpack2(const uint32_t *d_packed, uint32_t n_words, const uint64_t *d_off, uint32_t n_seqs, uint32_t uniform_wps,
+                          const uint32_t *d_scratch, uint8_t *d_q, hipStream_t stream);
+hipError_t launch_exceptions(const uint64_t *d_pos, const uint8_t *d_byte, uint32_t n, uint64_t base, uint8_t *d_q, hipStream_t stream);
+hipError_t launch_pack2(const uint8_t *d_chars, uint32_t n_words, const uint64_t *d_off, uint32_t n_seqs, uint32_t uniform_wps,
+                        const uint32_t *d_scratch, uint32_t *d_packed, hipStream_t stream);
+
 constexpr int kWalkThreads = 64; // default workgroup size (waves are independent: no LDS, no barriers)
 void set_walk_threads(int threads); // tuning: 64, 128 or 256
 void set_walk_experiment(int lane_limit, int dummy_lds_bytes); // experiments behind DESIGN.md section 6

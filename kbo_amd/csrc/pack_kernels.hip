@@ -1,0 +1,148 @@
+// pack_kernels.hip — gfx950 (MI355X, CDNA4): 2-bit packed reads in, 2-bit packed alignments out, for the packed host
+// entry points (kbo_matches_batch_packed / kbo_find_batch_packed).  The host -> host rate of the batch entry points is
+// bound by PCIe at one byte per base each way; reads are 2 bits of information per base and the
+// alphabet of kbo::matches is exactly { M, -, X, R } (translate.rs:180-216), so a quarter of the bytes carry the same.
+//
+// Packed layout (input and output alike): sequence s of len_s bases occupies ceil(len_s / 16) little-endian u32 words
+// starting at word sum_{r<s} ceil(len_r / 16); base i of the sequence sits in bits 2 (i mod 16) .. +1 of word i / 16.
+// Input codes A, C, G, T = 0 .. 3 (non-ACGT bytes travel in a side list and are written over the unpacked base);
+// output codes M, -, X, R = 0 .. 3.  One lane per word: coalesced 4-byte accesses on the packed side, 16-byte blocks of
+// one sequence on the byte side.
+#include "device_util.hpp"
+
+namespace kbo {
+namespace {
+
+// words per sequence (for the scan that gives ragged batches their word prefix)
+__global__ __launch_bounds__(256) void seq_words_kernel(const uint64_t *__restrict__ off, uint32_t n_seqs, uint32_t *__restrict__ words)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n_seqs) return;
+    words[s] = s < n_seqs ? (uint32_t)((off[s + 1] - off[s] + 15u) / 16u) : 0u;
+}
+
+// offsets of a batch of equally long sequences, made on the device (nothing to upload)
+__global__ __launch_bounds__(256) void uniform_offsets_kernel(uint64_t *__restrict__ off, uint32_t n_seqs, uint32_t len)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s <= n_seqs) off[s] = (uint64_t)s * len;
+}
+
+// word w of the packed batch -> (sequence, block of 16 bases inside it).  uniform_wps != 0: every sequence has that many
+// words; otherwise binary search over the scanned word counts (prefix(e) = sums[e / kScanBlock] + data[e])
+__device__ __forceinline__ void locate_word(uint32_t w, uint32_t n_seqs, uint32_t uniform_wps, const uint32_t *data, const uint32_t *sums,
+                                            uint32_t &seq, uint32_t &blk)
+{
+    if (uniform_wps) {
+        seq = w / uniform_wps;
+        blk = w - seq * uniform_wps;
+        return;
+    }
+    uint32_t s0 = 0, s1 = n_seqs; // largest s with prefix(s) <= w
+    while (s1 - s0 > 1) {
+        const uint32_t m = s0 + (s1 - s0) / 2;
+        if (sums[m / kScanBlock] + data[m] <= w) s0 = m;
+        else s1 = m;
+    }
+    seq = s0;
+    blk = w - (sums[s0 / kScanBlock] + data[s0]);
+}
+
+__global__ __launch_bounds__(256) void unpack2_kernel(const uint32_t *__restrict__ packed, uint32_t n_words, const uint64_t *__restrict__ off,
+                                                      uint32_t n_seqs, uint32_t uniform_wps, const uint32_t *__restrict__ data,
+                                                      const uint32_t *__restrict__ sums, uint8_t *__restrict__ q)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    uint32_t seq, blk;
+    locate_word(w, n_seqs, uniform_wps, data, sums, seq, blk);
+    const uint32_t v = packed[w];
+    const uint64_t b0 = off[seq], len = off[seq + 1] - b0;
+    const uint32_t first = blk * 16u, nb = (uint32_t)min((uint64_t)16u, len - first);
+    uint4 o = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const uint32_t ch = (0x54474341u >> (8u * ((v >> (2 * t)) & 3u))) & 0xFFu; // "ACGT"[code]
+        const uint32_t sh = ch << ((t & 3) * 8);
+        if ((t >> 2) == 0) o.x |= sh;
+        else if ((t >> 2) == 1) o.y |= sh;
+        else if ((t >> 2) == 2) o.z |= sh;
+        else o.w |= sh;
+    }
+    uint8_t *dst = q + b0 + first;
+    if (nb == 16u) __builtin_memcpy(dst, &o, 16);
+    else st_partial(dst, o, nb); // (the sequence's last block: the bytes behind it belong to the next sequence)
+}
+
+// non-ACGT bytes of the input, written over the unpacked bases: pos = offset of the base in the (slab's) byte buffer
+__global__ __launch_bounds__(256) void exceptions_kernel(const uint64_t *__restrict__ pos, const uint8_t *__restrict__ byte, uint32_t n,
+                                                         uint64_t base, uint8_t *__restrict__ q)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < n) q[pos[x] - base] = byte[x];
+}
+
+__global__ __launch_bounds__(256) void pack2_kernel(const uint8_t *__restrict__ chars, uint32_t n_words, const uint64_t *__restrict__ off,
+                                                    uint32_t n_seqs, uint32_t uniform_wps, const uint32_t *__restrict__ data,
+                                                    const uint32_t *__restrict__ sums, uint32_t *__restrict__ packed)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    uint32_t seq, blk;
+    locate_word(w, n_seqs, uniform_wps, data, sums, seq, blk);
+    const uint64_t b0 = off[seq], len = off[seq + 1] - b0;
+    const uint32_t first = blk * 16u, nb = (uint32_t)min((uint64_t)16u, len - first);
+    uint4 v;
+    __builtin_memcpy(&v, chars + b0 + first, 16); // (reads up to 15 bytes past the sequence: inside the buffer's slack)
+    uint32_t out = 0;
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const uint32_t word = (t >> 2) == 0 ? v.x : (t >> 2) == 1 ? v.y : (t >> 2) == 2 ? v.z : v.w;
+        const uint32_t ch = (word >> ((t & 3) * 8)) & 0xFFu;
+        const uint32_t code = ch == 'M' ? 0u : ch == '-' ? 1u : ch == 'X' ? 2u : 3u; // translate.rs:180-216: M, -, X, R
+        out |= ((uint32_t)t < nb ? code : 0u) << (2 * t);
+    }
+    packed[w] = out;
+}
+
+} // namespace
+
+hipError_t launch_uniform_offsets(uint64_t *d_off, uint32_t n_seqs, uint32_t len, hipStream_t stream)
+{
+    hipLaunchKernelGGL(uniform_offsets_kernel, dim3((n_seqs + 256u) / 256u), dim3(256), 0, stream, d_off, n_seqs, len);
+    return hipGetLastError();
+}
+
+// d_scratch: chunk_items_scratch_words(n_seqs) u32 (ragged batches only): the scanned words-per-sequence
+hipError_t launch_packed_prefix(const uint64_t *d_off, uint32_t n_seqs, uint32_t *d_scratch, hipStream_t stream)
+{
+    hipLaunchKernelGGL(seq_words_kernel, dim3((n_seqs + 256u) / 256u), dim3(256), 0, stream, d_off, n_seqs, d_scratch);
+    return launch_scan(d_scratch, n_seqs + 1u, d_scratch + n_seqs + 1u, stream);
+}
+
+hipError_t launch_unpack2(const uint32_t *d_packed, uint32_t n_words, const uint64_t *d_off, uint32_t n_seqs, uint32_t uniform_wps,
+                          const uint32_t *d_scratch, uint8_t *d_q, hipStream_t stream)
+{
+    if (n_words == 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack2_kernel, dim3((n_words + 255u) / 256u), dim3(256), 0, stream, d_packed, n_words, d_off, n_seqs, uniform_wps,
+                       d_scratch, d_scratch ? d_scratch + n_seqs + 1u : nullptr, d_q);
+    return hipGetLastError();
+}
+
+hipError_t launch_exceptions(const uint64_t *d_pos, const uint8_t *d_byte, uint32_t n, uint64_t base, uint8_t *d_q, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(exceptions_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, d_pos, d_byte, n, base, d_q);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack2(const uint8_t *d_chars, uint32_t n_words, const uint64_t *d_off, uint32_t n_seqs, uint32_t uniform_wps,
+                        const uint32_t *d_scratch, uint32_t *d_packed, hipStream_t stream)
+{
+    if (n_words == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack2_kernel, dim3((n_words + 255u) / 256u), dim3(256), 0, stream, d_chars, n_words, d_off, n_seqs, uniform_wps,
+                       d_scratch, d_scratch ? d_scratch + n_seqs + 1u : nullptr, d_packed);
+    return hipGetLastError();
+}
+
+} // namespace kbo

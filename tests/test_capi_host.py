@@ -292,3 +292,40 @@ def test_run_automaton_equals_the_walk_of_a_one_sequence_index(oracle, k, revcom
         for x, km in enumerate(kmers):
             d, _, _ = ora.matching_statistics(km.tobytes())
             assert np.array_equal(got[x * k:(x + 1) * k], d.astype(np.uint32)), (k, revcomp, trial, x)
+
+
+def test_pack_reads_and_unpack_matches_round_trip():
+    """The host helpers of the packed entry points (kbo_hip.h): sequence s = ceil(len / 16) u32 words, base i in bits
+    2 (i mod 16) of word i / 16; non-ACGT bytes in an ascending side list; M, -, X, R = 0 .. 3 on the way back."""
+    from kbo_amd import batch
+    rng = np.random.default_rng(77)
+    lens = [1, 3, 15, 16, 17, 31, 32, 33, 150, 151, 1000] + [int(x) for x in rng.integers(1, 400, 200)]
+    seqs = []
+    for n in lens:
+        a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+        if n > 5 and rng.random() < 0.4:
+            a[rng.integers(0, n, 2)] = rng.choice(list(b"Nn$x-"))
+        seqs.append(a)
+    concat = np.concatenate(seqs)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    words, pos, byt = batch.pack_reads(concat, offsets)
+    assert len(words) == sum((n + 15) // 16 for n in lens)
+    assert np.all(np.diff(pos.astype(np.int64)) > 0)
+    back = np.zeros(len(concat), dtype=np.uint8)
+    w = 0
+    for s, n in enumerate(lens):  # unpack by the layout's definition
+        for i in range(n):
+            back[int(offsets[s]) + i] = b"ACGT"[(int(words[w + i // 16]) >> (2 * (i % 16))) & 3]
+        w += (n + 15) // 16
+    back[pos.astype(np.int64)] = byt
+    assert np.array_equal(back, concat)
+    # output side: pack M - X R by the definition, unpack with the helper
+    chars = np.frombuffer(b"M-XR", dtype=np.uint8)[rng.integers(0, 4, len(concat))]
+    code = {77: 0, 45: 1, 88: 2, 82: 3}
+    ow = np.zeros(len(words), dtype=np.uint32)
+    w = 0
+    for s, n in enumerate(lens):
+        for i in range(n):
+            ow[w + i // 16] |= np.uint32(code[int(chars[int(offsets[s]) + i])] << (2 * (i % 16)))
+        w += (n + 15) // 16
+    assert np.array_equal(batch.unpack_matches(ow, offsets), chars)

@@ -819,3 +819,53 @@ def test_full_size_properties(sub_rate):
     dev.run()
     torch.cuda.synchronize()
     assert torch.equal(first, dev.chars)
+
+
+@pytest.mark.gpu
+def test_packed_batches_equal_the_byte_entry_points(oracle):
+    """kbo_matches_batch_packed / kbo_find_batch_packed (2-bit words in, 2-bit words or run lengths out; unpacked and packed
+    on the device) against the oracle and against the byte entry points: equally long reads (offsets made on the device),
+    ragged reads with non-ACGT bytes (side list), slabs of 64 KiB, and the device list (0, 0)."""
+    import ctypes
+    g = synth.genome(300_000, seed=61)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=4))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    rng = np.random.default_rng(62)
+    L = kbo_amd.lib()
+    cases = []
+    c1, o1 = synth.reads(g, 30_000, 150, 0.01, seed=63)
+    cases.append(("uniform 150", c1, o1))
+    c2, o2 = synth.reads(g, 8_000, 128, 0.02, seed=64)
+    cases.append(("uniform 128", c2, o2))
+    lens = rng.integers(3, 700, 6_000)
+    pieces = []
+    for n in lens:
+        a = int(rng.integers(0, len(g) - n))
+        p = g[a:a + n].copy()
+        hit = rng.random(n) < 0.02
+        p[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+        if rng.random() < 0.2:
+            p[rng.integers(0, n, 2)] = rng.choice(list(b"Nnx$"))
+        pieces.append(p)
+    cases.append(("ragged with non-ACGT", np.concatenate(pieces), np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)))
+    for name, concat, offsets in cases:
+        exp_chars = ora.matches_batch(concat, offsets, 1e-7, n_threads=4)
+        words, pos, byt = batch.pack_reads(concat, offsets)
+        for slab, devs in ((32 << 20, None), (1 << 16, None), (1 << 16, (0, 0))):
+            try:
+                L.kbo_set_slab_bytes(slab)
+                if devs:
+                    kbo_amd.check(L.kbo_set_devices((ctypes.c_int * 2)(*devs), 2))
+                out = batch.matches_batch_packed(sbwt, words, offsets, pos, byt)
+                assert np.array_equal(batch.unpack_matches(out, offsets), exp_chars), (name, slab, devs)
+                rles, ro = batch.find_batch_packed(sbwt, words, offsets, pos, byt, kbo_amd.FindOpts(max_gap_len=3))
+                exp_r, exp_o = oracle.run_lengths_batch(exp_chars, offsets, 3)
+                assert np.array_equal(ro, exp_o) and np.array_equal(rles.reshape(-1, 7), exp_r), (name, slab, devs)
+            finally:
+                L.kbo_set_devices(None, 0)
+                L.kbo_set_slab_bytes(32 << 20)
+    # argument checks: exception list out of order / outside the batch
+    words, pos, byt = batch.pack_reads(c2, o2)
+    with pytest.raises(kbo_amd.KboError) as e:
+        batch.matches_batch_packed(sbwt, words, o2, np.array([5, 5], dtype=np.uint64), np.array([78, 78], dtype=np.uint8))
+    assert e.value.code == -4

@@ -18,6 +18,38 @@ sbwt.to_device()
 concat, offsets = synth.reads(g, R, 150, 0.01)
 out = np.zeros(len(concat), dtype=np.uint8)  # allocated and touched once, outside the timed region
 L = kbo_amd.lib()
+if os.environ.get("PACKED"):  # 2-bit words in, 2-bit words / run lengths out (kbo_matches_batch_packed, kbo_find_batch_packed)
+    import ctypes as C
+    from kbo_amd import _capi
+    from oracle import binding as ora
+    words, pos, byt = batch.pack_reads(concat, offsets)
+    wout = np.zeros(len(words), dtype=np.uint32)
+    for slab_mb in [int(x) for x in os.environ.get('SLABS', '32,64,128').split(',')]:
+        L.kbo_set_slab_bytes(slab_mb << 20)
+        best = 1e9
+        for _ in range(5):
+            t0 = time.perf_counter()
+            kbo_amd.check(L.kbo_matches_batch_packed(sbwt._h, words.ctypes.data, offsets.ctypes.data, R, None, None, 0, 1e-7, wout.ctypes.data))
+            best = min(best, time.perf_counter() - t0)
+        print(f"slab {slab_mb:4d} MiB: matches, packed {R * 150 / best / 1e9:6.2f} Gbp/s host->host ({best * 1e3:.1f} ms for {R * 150 / 1e6:.0f} Mbp, "
+              f"{len(words) * 4 / 1e6:.0f} MB each way)", flush=True)
+        co = _capi.FindOpts(1e-7, 0)
+        ro = np.zeros(R + 1, dtype=np.uint64)
+        best = 1e9
+        for _ in range(5):
+            p = C.POINTER(_capi.RLE)()
+            t0 = time.perf_counter()
+            kbo_amd.check(L.kbo_find_batch_packed(sbwt._h, words.ctypes.data, offsets.ctypes.data, R, None, None, 0, C.byref(co), C.byref(p), ro.ctypes.data))
+            best = min(best, time.perf_counter() - t0)
+            L.kbo_free(p)
+        print(f"slab {slab_mb:4d} MiB: find,    packed {R * 150 / best / 1e9:6.2f} Gbp/s host->host ({best * 1e3:.1f} ms, {int(ro[-1])} runs)", flush=True)
+    rows, Carr, lcs = sbwt.export_parts()
+    oi = ora.Index.from_parts(31, sbwt.n_sets(), sbwt.n_kmers(), rows, Carr, lcs)
+    n_chk = min(R, 200_000)
+    exp = oi.matches_batch(concat[:n_chk * 150], offsets[:n_chk + 1], 1e-7, n_threads=16)
+    got = batch.unpack_matches(wout, offsets)
+    print("packed output equals the oracle on the first", n_chk, "reads:", bool(np.array_equal(got[:n_chk * 150], exp)))
+    sys.exit(0)
 for slab_mb in [int(x) for x in os.environ.get('SLABS', '32,64,128,256').split(',')]:
     L.kbo_set_slab_bytes(slab_mb << 20)
     best = 1e9
