@@ -501,18 +501,27 @@ private:
         S.off.ensure((ns + 1) * sizeof(uint64_t));
         uint64_t *off = S.off.as<uint64_t>();
         const uint64_t *offsets = job_.offsets;
-        const size_t piece = 1u << 15, n_tasks = (ns + 1 + piece - 1) / piece;
-        std::vector<uint64_t> longest(n_tasks, 0);
-        team.run(n_tasks, [&](size_t t) {
-            const size_t a = t * piece, b = std::min(ns + 1, a + piece);
-            uint64_t m = 0;
-            for (size_t j = a; j < b; j++) {
-                off[j] = offsets[sl.s0 + j] - sl.b0;
-                if (j < ns) m = std::max(m, offsets[sl.s0 + j + 1] - offsets[sl.s0 + j]);
-            }
-            longest[t] = m;
-        });
-        const uint32_t mx = (uint32_t)*std::max_element(longest.begin(), longest.end());
+        uint32_t mx = 0;
+        if (job_.packed && job_.uniform_len && job_.uniform_len <= 255u) { // (reads: below every chunk length, walk_chunk() >= 256)
+            // equally long reads, packed: the offsets are made on the device and nothing below reads more of the host
+            // copy than its last entry (one item per read, A5/A6 by the longest length)
+            off[0] = 0;
+            off[ns] = bytes;
+            mx = job_.uniform_len;
+        } else {
+            const size_t piece = 1u << 15, n_tasks = (ns + 1 + piece - 1) / piece;
+            std::vector<uint64_t> longest(n_tasks, 0);
+            team.run(n_tasks, [&](size_t t) {
+                const size_t a = t * piece, b = std::min(ns + 1, a + piece);
+                uint64_t m = 0;
+                for (size_t j = a; j < b; j++) {
+                    off[j] = offsets[sl.s0 + j] - sl.b0;
+                    if (j < ns) m = std::max(m, offsets[sl.s0 + j + 1] - offsets[sl.s0 + j]);
+                }
+                longest[t] = m;
+            });
+            mx = (uint32_t)*std::max_element(longest.begin(), longest.end());
+        }
         const uint8_t *src = job_.concat ? job_.concat + sl.b0 : nullptr;
         PackedIn pin{};
         const uint64_t w0 = job_.packed ? job_.word_of(sl.s0) : 0, w1 = job_.packed ? job_.word_of(sl.s1) : 0;
@@ -872,7 +881,9 @@ void matches_batch_packed_impl(kbo_index *idx, const PackedBatch &in, const uint
         KBO_REQUIRE(in.exc_pos[x] < offsets[n_seqs] && (x == 0 || in.exc_pos[x] > in.exc_pos[x - 1]), KBO_E_BAD_ARG,
                     "exception positions must ascend and lie inside the batch");
     clk.lap("argument checks");
-    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
+    // (a slab of a packed batch moves a quarter of the bytes of a byte slab: twice the bases per slab keep the copies long
+    // enough to hide the per-slab costs; tools/bench_host.py PACKED=1: 58 / 72 / 81 Gbp/s at 32 / 64 / 128 MiB of bases)
+    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, std::min<size_t>(2 * g_slab_bytes.load(), 0xC0000000ull));
     std::vector<int> devices = devices_snapshot();
     if (devices.empty()) devices.push_back(current_device());
     const size_t nd = std::min(devices.size(), std::max<size_t>(1, slabs.size()));
