@@ -156,6 +156,8 @@ void check_batch(const void *concat, const uint64_t *offsets, size_t n_seqs);
 void check_len_threshold(const uint64_t *offsets, size_t n_seqs, size_t k, size_t threshold);
 OffsetScan scan_offsets(const uint64_t *offsets, size_t n_seqs);
 std::vector<Slab> make_slabs(const uint64_t *offsets, size_t n_seqs, size_t max_bytes);
+std::vector<Slab> make_slabs_ramped(const uint64_t *offsets, size_t n_seqs, size_t max_bytes); // packed batches
+size_t packed_slab_bytes();
 // upload + A1 over a host batch (asynchronous on `stream`); leaves ms (and lo/hi) on the device.
 // `items_keep` must stay alive until the stream has been synchronised.
 // call mode of the walk (kernels.hpp WalkArgs::call_*): where the sites go

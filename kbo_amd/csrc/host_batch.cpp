@@ -219,6 +219,30 @@ std::vector<Slab> make_slabs(const uint64_t *offsets, size_t n_seqs, size_t max_
     return slabs;
 }
 
+// Slabs of a packed batch: the pipeline's first upload and last download are not hidden behind anything, and its kernels
+// work best on large slabs (the guided walk has a fixed tail per launch: 447 k reads at 96 Gbp/s, 894 k at 122), so the
+// slabs grow from max / 16 by doubling and shrink again towards the end (each at most half of what is left, down to
+// max / 16): long launches in the middle, short copies at both ends.
+std::vector<Slab> make_slabs_ramped(const uint64_t *offsets, size_t n_seqs, size_t max_bytes)
+{
+    std::vector<Slab> slabs;
+    const uint64_t total = offsets[n_seqs], floor_bytes = std::max<uint64_t>(1u << 16, max_bytes / 16);
+    uint64_t grow = floor_bytes;
+    size_t s0 = 0;
+    while (s0 < n_seqs) {
+        const uint64_t left = total - offsets[s0];
+        const uint64_t want = std::min<uint64_t>({(uint64_t)max_bytes, grow, std::max<uint64_t>(floor_bytes, left / 2)});
+        size_t s1 = std::upper_bound(offsets + s0 + 1, offsets + n_seqs + 1, offsets[s0] + want) - offsets - 1;
+        s1 = std::max(s1, s0 + 1);
+        if (total - offsets[s1] < floor_bytes / 2) s1 = n_seqs; // (no crumb at the end)
+        slabs.push_back(Slab{s0, s1, offsets[s0], offsets[s1]});
+        s0 = s1;
+        grow = std::min<uint64_t>(max_bytes, grow * 2);
+    }
+    return slabs;
+}
+size_t packed_slab_bytes() { return std::min<size_t>(4 * g_slab_bytes.load(), 0xC0000000ull); }
+
 // one pass over the offsets of a batch: order, emptiness, shortest and longest sequence
 OffsetScan scan_offsets(const uint64_t *offsets, size_t n_seqs)
 {
@@ -881,9 +905,9 @@ void matches_batch_packed_impl(kbo_index *idx, const PackedBatch &in, const uint
         KBO_REQUIRE(in.exc_pos[x] < offsets[n_seqs] && (x == 0 || in.exc_pos[x] > in.exc_pos[x - 1]), KBO_E_BAD_ARG,
                     "exception positions must ascend and lie inside the batch");
     clk.lap("argument checks");
-    // (a slab of a packed batch moves a quarter of the bytes of a byte slab: twice the bases per slab keep the copies long
-    // enough to hide the per-slab costs; tools/bench_host.py PACKED=1: 58 / 72 / 81 Gbp/s at 32 / 64 / 128 MiB of bases)
-    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, std::min<size_t>(2 * g_slab_bytes.load(), 0xC0000000ull));
+    // (a slab of a packed batch moves a quarter of the bytes of a byte slab: up to four times the bases per slab; tools/
+    // bench_host.py PACKED=1 with equal slabs: 58 / 72 / 81 Gbp/s at 32 / 64 / 128 MiB of bases)
+    const std::vector<Slab> slabs = make_slabs_ramped(offsets, n_seqs, packed_slab_bytes());
     std::vector<int> devices = devices_snapshot();
     if (devices.empty()) devices.push_back(current_device());
     const size_t nd = std::min(devices.size(), std::max<size_t>(1, slabs.size()));

@@ -886,7 +886,7 @@ int kbo_find_batch_packed(kbo_index_t *idx, const uint32_t *words, const uint64_
             return;
         }
         // several devices: slabs completed out of order and were kept per slab; put them together
-        const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, std::min<size_t>(2 * g_slab_bytes.load(), 0xC0000000ull)); // (as matches_batch_packed_impl)
+        const std::vector<Slab> slabs = make_slabs_ramped(offsets, n_seqs, packed_slab_bytes()); // (as matches_batch_packed_impl)
         std::vector<uint64_t> base(slabs.size() + 1, 0);
         for (size_t i = 0; i < slabs.size(); i++) base[i + 1] = base[i] + sink.runs[i].size();
         kbo_rle *all = static_cast<kbo_rle *>(std::malloc(std::max<uint64_t>(1, base.back()) * sizeof(kbo_rle)));
