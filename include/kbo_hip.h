@@ -287,10 +287,16 @@ int kbo_unpack_matches(const uint32_t *words, const uint64_t *offsets, size_t n_
 int kbo_matches_batch_packed(kbo_index_t *idx, const uint32_t *words, const uint64_t *offsets, size_t n_seqs,
                              const uint64_t *exc_pos, const uint8_t *exc_byte, size_t n_exc, double max_error_prob,
                              uint32_t *words_out);
-/* kbo::find (lib.rs:808-821) over a packed batch: run lengths as kbo_find_batch returns them */
+/* kbo::find (lib.rs:808-821) over a packed batch.  The run lengths come back as the seven u32 the device writes (the fields of
+ * format::RLE, format.rs:18-33; a sequence is shorter than 2^32 bases): 28 bytes per run instead of kbo_rle's 56, and no
+ * widening pass on the host - at about 1.15 runs per 150-base read the records are as many bytes as the packed alignments
+ * themselves.  *rles is library-allocated (kbo_free); rle_offsets as for kbo_find_batch. */
+typedef struct {
+    uint32_t start, end, matches, mismatches, jumps, gap_bases, gap_opens;
+} kbo_rle32;
 int kbo_find_batch_packed(kbo_index_t *idx, const uint32_t *words, const uint64_t *offsets, size_t n_seqs,
                           const uint64_t *exc_pos, const uint8_t *exc_byte, size_t n_exc, const kbo_find_opts *opts,
-                          kbo_rle **rles, uint64_t *rle_offsets);
+                          kbo_rle32 **rles, uint64_t *rle_offsets);
 
 /* ------------------------------------------------------------------ device-resident path
  * Everything already in the HBM of the current device; kernels are enqueued on `stream`

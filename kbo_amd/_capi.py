@@ -183,7 +183,7 @@ def lib():
     L.kbo_pack_reads.argtypes = [vp, vp, sz, vp, vp, vp, sz, C.POINTER(sz)]
     L.kbo_unpack_matches.argtypes = [vp, vp, sz, vp]
     L.kbo_matches_batch_packed.argtypes = [vp, vp, vp, sz, vp, vp, sz, dbl, vp]
-    L.kbo_find_batch_packed.argtypes = [vp, vp, vp, sz, vp, vp, sz, C.POINTER(FindOpts), C.POINTER(C.POINTER(RLE)), vp]
+    L.kbo_find_batch_packed.argtypes = [vp, vp, vp, sz, vp, vp, sz, C.POINTER(FindOpts), C.POINTER(vp), vp]
     L.kbo_set_plan_unit_cap_divisor.argtypes = [C.c_int]
     L.kbo_set_seed_table_depth.argtypes = [C.c_int]
     L.kbo_index_plan_holdoff.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]

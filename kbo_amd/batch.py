@@ -119,11 +119,11 @@ def find_batch_packed(sbwt, words, offsets, exc_pos, exc_byte, find_opts=None):
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = len(offsets) - 1
     ro = np.zeros(n + 1, dtype=np.uint64)
-    p = C.POINTER(_capi.RLE)()
+    p = C.c_void_p()
     check(lib().kbo_find_batch_packed(sbwt._h, words.ctypes.data, offsets.ctypes.data, n, exc_pos.ctypes.data if len(exc_pos) else None,
                                       exc_byte.ctypes.data if len(exc_byte) else None, len(exc_pos), C.byref(co), C.byref(p), ro.ctypes.data))
     total = int(ro[-1])
-    rles = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(max(1, total), 7))[:total].copy()
+    rles = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(max(1, total), 7))[:total].astype(np.uint64)  # (kbo_rle32)
     lib().kbo_free(p)
     return rles, ro
 

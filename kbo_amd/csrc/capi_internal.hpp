@@ -143,10 +143,19 @@ struct RleSink {
     size_t all_cap = 0, all_used = 0;
     bool caller_owns = false; // `all` is the caller's buffer of all_cap records: never grown; all_used keeps counting
     bool direct = false;      // set by matches_batch_impl: one worker, records went straight into `all`
+    // compact = true (kbo_find_batch_packed): the records stay the seven u32 the device writes (kbo_rle32), nothing is
+    // widened: all32 / runs32 take the place of all / runs (all_cap and all_used count records either way)
+    bool compact = false;
+    uint32_t *all32 = nullptr;
+    std::vector<std::vector<uint32_t>> runs32;
     // several devices: slabs complete out of order, kept per slab and put together at the end
     std::vector<std::vector<kbo_rle>> runs;
     std::vector<std::vector<uint32_t>> first; // index of the first run of each sequence of the slab, +1 entry
-    ~RleSink() { if (!caller_owns) std::free(all); }
+    ~RleSink()
+    {
+        if (!caller_owns) std::free(all);
+        std::free(all32);
+    }
 };
 constexpr size_t kRleWords = 7; // device run-length records are seven u32; kbo_rle has the reference's usize fields
 
@@ -156,8 +165,7 @@ void check_batch(const void *concat, const uint64_t *offsets, size_t n_seqs);
 void check_len_threshold(const uint64_t *offsets, size_t n_seqs, size_t k, size_t threshold);
 OffsetScan scan_offsets(const uint64_t *offsets, size_t n_seqs);
 std::vector<Slab> make_slabs(const uint64_t *offsets, size_t n_seqs, size_t max_bytes);
-std::vector<Slab> make_slabs_ramped(const uint64_t *offsets, size_t n_seqs, size_t max_bytes); // packed batches
-size_t packed_slab_bytes();
+size_t packed_slab_bytes(); // bases per slab of a packed batch
 // upload + A1 over a host batch (asynchronous on `stream`); leaves ms (and lo/hi) on the device.
 // `items_keep` must stay alive until the stream has been synchronised.
 // call mode of the walk (kernels.hpp WalkArgs::call_*): where the sites go

@@ -219,28 +219,11 @@ std::vector<Slab> make_slabs(const uint64_t *offsets, size_t n_seqs, size_t max_
     return slabs;
 }
 
-// Slabs of a packed batch: the pipeline's first upload and last download are not hidden behind anything, and its kernels
-// work best on large slabs (the guided walk has a fixed tail per launch: 447 k reads at 96 Gbp/s, 894 k at 122), so the
-// slabs grow from max / 16 by doubling and shrink again towards the end (each at most half of what is left, down to
-// max / 16): long launches in the middle, short copies at both ends.
-std::vector<Slab> make_slabs_ramped(const uint64_t *offsets, size_t n_seqs, size_t max_bytes)
-{
-    std::vector<Slab> slabs;
-    const uint64_t total = offsets[n_seqs], floor_bytes = std::max<uint64_t>(1u << 16, max_bytes / 16);
-    uint64_t grow = floor_bytes;
-    size_t s0 = 0;
-    while (s0 < n_seqs) {
-        const uint64_t left = total - offsets[s0];
-        const uint64_t want = std::min<uint64_t>({(uint64_t)max_bytes, grow, std::max<uint64_t>(floor_bytes, left / 2)});
-        size_t s1 = std::upper_bound(offsets + s0 + 1, offsets + n_seqs + 1, offsets[s0] + want) - offsets - 1;
-        s1 = std::max(s1, s0 + 1);
-        if (total - offsets[s1] < floor_bytes / 2) s1 = n_seqs; // (no crumb at the end)
-        slabs.push_back(Slab{s0, s1, offsets[s0], offsets[s1]});
-        s0 = s1;
-        grow = std::min<uint64_t>(max_bytes, grow * 2);
-    }
-    return slabs;
-}
+// Slabs of a packed batch: four times the bases of a byte slab (the same bytes over PCIe).  Large on purpose: the guided
+// walk has a fixed cost of about 0.19 ms per launch whatever the slab holds (its longest chain of units; a slab of 56 k reads
+// spends 0.4 ms in kernels, 21 Gbp/s, one of 894 k reads 1.1 ms, 122 Gbp/s), so slabs that start small and grow - tried, to
+// shorten the pipeline's unhidden first upload and last download - lose more than they hide (tools/bench_host.py PACKED=1,
+// 600 Mbp: equal slabs of 32 / 64 / 128 MiB of bases 58 / 72 / 81 Gbp/s, ramped 8 .. 128 MiB 69).
 size_t packed_slab_bytes() { return std::min<size_t>(4 * g_slab_bytes.load(), 0xC0000000ull); }
 
 // one pass over the offsets of a batch: order, emptiness, shortest and longest sequence
@@ -713,13 +696,21 @@ private:
             if (job_.sink_direct) {
                 if (sink->all_used + total > sink->all_cap && !sink->caller_owns) {
                     const size_t cap = (sink->all_used + total) * 2;
-                    kbo_rle *p = static_cast<kbo_rle *>(std::realloc(sink->all, cap * sizeof(kbo_rle)));
-                    if (!p) throw std::bad_alloc();
-                    sink->all = p;
+                    if (sink->compact) {
+                        uint32_t *p = static_cast<uint32_t *>(std::realloc(sink->all32, cap * kRleWords * sizeof(uint32_t)));
+                        if (!p) throw std::bad_alloc();
+                        sink->all32 = p;
+                    } else {
+                        kbo_rle *p = static_cast<kbo_rle *>(std::realloc(sink->all, cap * sizeof(kbo_rle)));
+                        if (!p) throw std::bad_alloc();
+                        sink->all = p;
+                    }
                     sink->all_cap = cap;
                 }
                 const size_t base = sink->all_used, s0 = (*job_.slabs)[S.slab_id].s0, ns_slab = S.n_seqs;
-                if (base + total <= sink->all_cap) // a caller's buffer that is too small only gets the count
+                if (sink->compact) // the device's records as they are
+                    HostTeam::out().copy(sink->all32 + base * kRleWords, S.out.p, total * kRleWords * sizeof(uint32_t));
+                else if (base + total <= sink->all_cap) // a caller's buffer that is too small only gets the count
                     widen_rles(sink->all + base, S.out.as<uint32_t>(), total, HostTeam::out());
                 const size_t piece = 1u << 15;
                 HostTeam::out().run((ns_slab + piece - 1) / piece, [&](size_t t) {
@@ -728,9 +719,13 @@ private:
                 });
                 sink->all_used += total;
             } else {
-                std::vector<kbo_rle> &runs = sink->runs[S.slab_id];
-                runs.resize(total);
-                widen_rles(runs.data(), S.out.as<uint32_t>(), total, HostTeam::out());
+                if (sink->compact) {
+                    sink->runs32[S.slab_id].assign(S.out.as<uint32_t>(), S.out.as<uint32_t>() + total * kRleWords);
+                } else {
+                    std::vector<kbo_rle> &runs = sink->runs[S.slab_id];
+                    runs.resize(total);
+                    widen_rles(runs.data(), S.out.as<uint32_t>(), total, HostTeam::out());
+                }
                 std::vector<uint32_t> &first = sink->first[S.slab_id];
                 first.resize(S.n_seqs + 1);
                 for (size_t q = 0; q <= S.n_seqs; q++) first[q] = sums[q / 1024] + local[q];
@@ -905,9 +900,7 @@ void matches_batch_packed_impl(kbo_index *idx, const PackedBatch &in, const uint
         KBO_REQUIRE(in.exc_pos[x] < offsets[n_seqs] && (x == 0 || in.exc_pos[x] > in.exc_pos[x - 1]), KBO_E_BAD_ARG,
                     "exception positions must ascend and lie inside the batch");
     clk.lap("argument checks");
-    // (a slab of a packed batch moves a quarter of the bytes of a byte slab: up to four times the bases per slab; tools/
-    // bench_host.py PACKED=1 with equal slabs: 58 / 72 / 81 Gbp/s at 32 / 64 / 128 MiB of bases)
-    const std::vector<Slab> slabs = make_slabs_ramped(offsets, n_seqs, packed_slab_bytes());
+    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, packed_slab_bytes());
     std::vector<int> devices = devices_snapshot();
     if (devices.empty()) devices.push_back(current_device());
     const size_t nd = std::min(devices.size(), std::max<size_t>(1, slabs.size()));
@@ -938,12 +931,18 @@ void matches_batch_packed_impl(kbo_index *idx, const PackedBatch &in, const uint
     job.clk = &clk;
     if (sink) {
         sink->runs.assign(slabs.size(), {});
+        sink->runs32.assign(slabs.size(), {});
         sink->first.assign(slabs.size(), {});
     }
     if (job.sink_direct && !sink->caller_owns) {
         sink->all_cap = 2 * n_seqs + 1024;
-        sink->all = static_cast<kbo_rle *>(std::malloc(sink->all_cap * sizeof(kbo_rle)));
-        if (!sink->all) throw std::bad_alloc();
+        if (sink->compact) {
+            sink->all32 = static_cast<uint32_t *>(std::malloc(sink->all_cap * kRleWords * sizeof(uint32_t)));
+            if (!sink->all32) throw std::bad_alloc();
+        } else {
+            sink->all = static_cast<kbo_rle *>(std::malloc(sink->all_cap * sizeof(kbo_rle)));
+            if (!sink->all) throw std::bad_alloc();
+        }
     }
     if (sink) sink->direct = job.sink_direct;
     if (job.sink_direct) sink->rle_offsets[0] = 0;

@@ -869,35 +869,37 @@ int kbo_matches_batch_packed(kbo_index_t *idx, const uint32_t *words, const uint
 }
 
 int kbo_find_batch_packed(kbo_index_t *idx, const uint32_t *words, const uint64_t *offsets, size_t n_seqs, const uint64_t *exc_pos,
-                          const uint8_t *exc_byte, size_t n_exc, const kbo_find_opts *opts, kbo_rle **rles, uint64_t *rle_offsets)
+                          const uint8_t *exc_byte, size_t n_exc, const kbo_find_opts *opts, kbo_rle32 **rles, uint64_t *rle_offsets)
 {
     return guarded([&] {
         KBO_REQUIRE(idx && words && rles && rle_offsets, KBO_E_BAD_ARG, "null argument");
+        static_assert(sizeof(kbo_rle32) == kRleWords * sizeof(uint32_t), "kbo_rle32 is the device's record");
         kbo_find_opts o;
         if (opts) o = *opts; else kbo_find_opts_default(&o);
         RleSink sink;
         sink.max_gap_len = o.max_gap_len;
         sink.rle_offsets = rle_offsets;
+        sink.compact = true;
         const PackedBatch in{words, exc_pos, exc_byte, n_exc};
         matches_batch_packed_impl(idx, in, offsets, n_seqs, o.max_error_prob, nullptr, &sink);
         if (sink.direct) { // one device: the records are already in place
-            *rles = sink.all;
-            sink.all = nullptr;
+            *rles = reinterpret_cast<kbo_rle32 *>(sink.all32);
+            sink.all32 = nullptr;
             return;
         }
         // several devices: slabs completed out of order and were kept per slab; put them together
-        const std::vector<Slab> slabs = make_slabs_ramped(offsets, n_seqs, packed_slab_bytes()); // (as matches_batch_packed_impl)
+        const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, packed_slab_bytes()); // (as matches_batch_packed_impl)
         std::vector<uint64_t> base(slabs.size() + 1, 0);
-        for (size_t i = 0; i < slabs.size(); i++) base[i + 1] = base[i] + sink.runs[i].size();
-        kbo_rle *all = static_cast<kbo_rle *>(std::malloc(std::max<uint64_t>(1, base.back()) * sizeof(kbo_rle)));
+        for (size_t i = 0; i < slabs.size(); i++) base[i + 1] = base[i] + sink.runs32[i].size() / kRleWords;
+        uint32_t *all = static_cast<uint32_t *>(std::malloc(std::max<uint64_t>(1, base.back()) * kRleWords * sizeof(uint32_t)));
         if (!all) throw std::bad_alloc();
         rle_offsets[0] = 0;
         HostTeam::get().run(slabs.size(), [&](size_t i) {
-            if (!sink.runs[i].empty()) std::memcpy(all + base[i], sink.runs[i].data(), sink.runs[i].size() * sizeof(kbo_rle));
+            if (!sink.runs32[i].empty()) std::memcpy(all + base[i] * kRleWords, sink.runs32[i].data(), sink.runs32[i].size() * sizeof(uint32_t));
             const size_t ns = slabs[i].s1 - slabs[i].s0;
             for (size_t q = 1; q <= ns; q++) rle_offsets[slabs[i].s0 + q] = base[i] + sink.first[i][q];
         });
-        *rles = all;
+        *rles = reinterpret_cast<kbo_rle32 *>(all);
     });
 }
 

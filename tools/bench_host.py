@@ -37,7 +37,7 @@ if os.environ.get("PACKED"):  # 2-bit words in, 2-bit words / run lengths out (k
         ro = np.zeros(R + 1, dtype=np.uint64)
         best = 1e9
         for _ in range(5):
-            p = C.POINTER(_capi.RLE)()
+            p = C.c_void_p()
             t0 = time.perf_counter()
             kbo_amd.check(L.kbo_find_batch_packed(sbwt._h, words.ctypes.data, offsets.ctypes.data, R, None, None, 0, C.byref(co), C.byref(p), ro.ctypes.data))
             best = min(best, time.perf_counter() - t0)
