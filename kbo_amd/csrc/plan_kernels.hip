@@ -257,33 +257,18 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                 if (base < len) {
                     uint32_t mm = (mmw[g >> 1] >> (16 * (g & 1))) & 0xFFFFu;
                     uint4 o4 = make_uint4(0, 0, 0, 0);
-                    const uint32_t d0 = (uint32_t)((int32_t)base - i_last);
-                    if (mm == 0 && d0 >= k) { // k or more bases behind the last mismatch (every second block): k throughout
-                        const uint32_t kk = k * 0x01010101u;
-                        o4 = make_uint4(kk, kk, kk, kk);
-                    } else if (mm == 0 && k <= 111u) {
-                        // no mismatch in the block: the ramp min(d0 + t, k), four values at a time (d0 < k <= 111 keeps every
-                        // byte d0 + t below 128, which is what the byte-wise compare below needs)
-                        const uint32_t kk = k * 0x01010101u;
-                        auto ramp = [&](uint32_t first) -> uint32_t {
-                            const uint32_t a = (d0 + first) * 0x01010101u + 0x03020100u;
-                            const uint32_t ge = (((a | 0x80808080u) - kk) & 0x80808080u) >> 7; // 1 in every byte with a >= k
-                            const uint32_t mask = ge * 0xFFu;
-                            return (a & ~mask) | (kk & mask);
-                        };
-                        o4 = make_uint4(ramp(0u), ramp(4u), ramp(8u), ramp(12u));
-                    } else {
 #pragma unroll
-                        for (int t = 0; t < 16; t++) {
-                            i_last = ((mm >> t) & 1u) ? (int32_t)(base + t) : i_last;
-                            const uint32_t val = min((uint32_t)((int32_t)(base + t) - i_last), k);
-                            const uint32_t sh = val << ((t & 3) * 8);
-                            if ((t >> 2) == 0) o4.x |= sh;
-                            else if ((t >> 2) == 1) o4.y |= sh;
-                            else if ((t >> 2) == 2) o4.z |= sh;
-                            else o4.w |= sh;
-                        }
+                    for (int t = 0; t < 16; t++) {
+                        i_last = ((mm >> t) & 1u) ? (int32_t)(base + t) : i_last;
+                        const uint32_t val = min((uint32_t)((int32_t)(base + t) - i_last), k);
+                        const uint32_t sh = val << ((t & 3) * 8);
+                        if ((t >> 2) == 0) o4.x |= sh;
+                        else if ((t >> 2) == 1) o4.y |= sh;
+                        else if ((t >> 2) == 2) o4.z |= sh;
+                        else o4.w |= sh;
                     }
+                    // (a constant / SWAR-ramp fast path for blocks without a mismatch - nine of ten - was tried: the wave runs
+                    // all three paths anyway, plan_kernel 227 -> 262 us, VALU 79.9 -> 87.6 M instructions.  Removed.)
                     while (mm) { // the item's mismatch list: entry 0 in the item record, entries 1..12 in the list
                         const uint32_t pos = base + (uint32_t)__ffs((int)mm) - 1u;
                         if (cnt == 0) mm0 = pos;
