@@ -1109,7 +1109,7 @@ int kbo_set_devices(const int *devices, int n)
     return guarded([&] {
         KBO_REQUIRE(n >= 0 && (devices || n == 0), KBO_E_BAD_ARG, "bad device list");
         int count = 0;
-        HIP_OK(hipGetDeviceCount(&count));
+        if (n > 0) HIP_OK(hipGetDeviceCount(&count)); // (n == 0, back to the current device, needs no device at all)
         for (int i = 0; i < n; i++) KBO_REQUIRE(devices[i] >= 0 && devices[i] < count, KBO_E_BAD_ARG, "no such device");
         std::lock_guard<std::mutex> g(g_devices_mu);
         g_devices.assign(devices, devices + n);
