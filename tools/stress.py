@@ -85,6 +85,14 @@ while time.time() < t_end:
     assert np.array_equal(d, exp_d), "MS " + tag
     got = batch.matches_batch(sbwt, concat, offsets, p_err)
     assert np.array_equal(got, exp_chars), "chars " + tag
+    if rng.random() < 0.5:  # the packed entry points: 2-bit words in, 2-bit words / 28-byte run-length records out
+        words, epos, ebyt = batch.pack_reads(concat, offsets)
+        pout = batch.matches_batch_packed(sbwt, words, offsets, epos, ebyt, p_err)
+        assert np.array_equal(batch.unpack_matches(pout, offsets), exp_chars), "packed chars " + tag
+        pg = int(rng.choice([0, 2, 50]))
+        prl, pro = batch.find_batch_packed(sbwt, words, offsets, epos, ebyt, kbo_amd.FindOpts(max_error_prob=p_err, max_gap_len=pg))
+        er, eo = ora.run_lengths_batch(exp_chars, offsets, pg)
+        assert np.array_equal(pro, eo) and np.array_equal(prl.reshape(-1, 7), er), "packed rle " + tag
     gap = int(rng.choice([0, 0, 3, 50]))
     rles, ro = batch.find_batch(sbwt, concat, offsets, kbo_amd.FindOpts(max_error_prob=p_err, max_gap_len=gap))
     for s in rng.integers(0, len(lens), 40):

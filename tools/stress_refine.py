@@ -72,6 +72,13 @@ while time.time() < t_end:
         n_refused += 1
     else:
         assert [(v.query_pos, bytes(v.query_chars).decode(), bytes(v.ref_chars).decode()) for v in g] == e, "call " + tag
+    # the same call through kbo_call_batch (site windows from the device, run automaton instead of a per-sequence index)
+    from kbo_amd import batch
+    arr = np.frombuffer(ref, dtype=np.uint8)
+    e2, g2 = both(lambda: batch.call_batch(sbwt, arr, np.array([0, len(ref)], dtype=np.uint64), kbo_amd.CallOpts(p, opts))[0],
+                  lambda: oi.call(ref, k, p)[0], "call_batch " + tag)
+    if e2 is not None:
+        assert [(v.query_pos, bytes(v.query_chars).decode(), bytes(v.ref_chars).decode()) for v in g2] == e2, "call_batch " + tag
     for fg, cv, fmt in ((True, True, True), (True, False, False), (False, True, False)):
         mo = kbo_amd.MapOpts(max_error_prob=p, fill_gaps=fg, call_variants=cv, format=fmt, sbwt_build_opts=opts)
         e, g = both(lambda: kbo_amd.map(ref, sbwt, lcs, mo), lambda: oi.map(ref, k, p, fg, cv, fmt), f"map {fg}{cv}{fmt} " + tag)
