@@ -34,7 +34,6 @@ struct DevCopy {
     DevBuf seed_tab;                 // intervals of all strings of seed_d bases (plan_kernel's seeds)
     uint32_t seed_d = 0;
     DevBuf fat;                      // recovery lines of the guided walk (sbwt_index.hpp)
-    DevBuf lcs8;                     // LCS bytes (hybrid guided walk, experiment)
     uint32_t fat_null = 0;
     DevBuf pc_text, pc_pos, pc_node; // path cover (sbwt_index.hpp PathCover), empty when the plan-guided walk is off
     // Plan hold-off of THIS copy (one index on one device): a batch whose reads differ too much from the index gives the

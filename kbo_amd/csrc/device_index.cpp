@@ -114,13 +114,6 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                     dc->fat_null = (uint32_t)(lines.size() / 128 - 1);
                     idx->plan_bytes += lines.size();
                 }
-                if (std::getenv("KBO_PLAN_LCS8")) { // experiment: the hybrid guided walk's LCS byte array
-                    const size_t nb = idx->host.n_sets + 1 + 48;
-                    dc->lcs8.alloc(nb);
-                    HIP_OK(hipMemset(dc->lcs8.p, 0, nb));
-                    HIP_OK(hipMemcpy(dc->lcs8.p, idx->host.lcs.data(), idx->host.n_sets, hipMemcpyHostToDevice));
-                    idx->plan_bytes += nb;
-                }
                 // seed table: the interval of every string of D bases, so that a seed starts D bases deep.  D = 10 for
                 // indexes that can use it (8 MiB), 8 for small ones, none below k = 8.
                 // (deeper tables for large indexes - 12 bases / 128 MiB from 32 Mi rows, 13 / 512 MiB from 512 Mi rows: the
@@ -182,7 +175,6 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
     v.seed_d = dc->seed_d;
     v.fat = dc->fat.p ? dc->fat.as<uint8_t>() : nullptr;
     v.fat_null = dc->fat_null;
-    v.lcs8 = dc->lcs8.p ? dc->lcs8.as<uint8_t>() : nullptr;
     v.pc_node = dc->pc_node.as<uint32_t>();
     for (int c = 0; c < 4; c++) v.C[c] = (uint32_t)idx->host.C[c];
     v.C[4] = v.n;

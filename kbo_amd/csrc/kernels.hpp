@@ -28,7 +28,6 @@ struct DevIndexView {
     // recovery lines of the guided walk (sbwt_index.hpp make_recovery_lines), nullptr when the device copy has none
     const uint8_t *fat;
     uint32_t fat_null; // line index of an all-zero line (extensions by a non-ACGT byte)
-    const uint8_t *lcs8; // LCS[0 .. n] as bytes (LCS[n] = 0) with 32 zero bytes behind: windows of the hybrid guided walk (experiment)
 };
 
 // One unit of walk work: `len` bases starting at absolute offset `start` of the
@@ -164,7 +163,6 @@ hipError_t launch_plan(WalkArgs &a, hipStream_t stream); // fills in the plan pa
 hipError_t launch_ms_walk_guided(WalkArgs a, uint32_t grid, uint32_t threads, hipStream_t stream);
 void set_guided_walk(int waves_per_cu, int recovery_lines); // tuning: see kbo_set_guided_walk
 bool guided_uses_recovery_lines(const WalkArgs &a);
-int guided_form(const WalkArgs &a); // 0 rank blocks + entries, 1 recovery lines, 2 rank blocks + LCS byte windows (experiment)
 void set_plan_stage(int on); // experiments: plan_kernel with (default) / without its LDS staging
 void set_plan_bail(int units_per_16_items); // tuning: launches with more units than this per 16 items give the plan up
 void set_plan_params(int dmin, int cap, int gap = 0, int chunk = 0); // tuning (<= 0 keeps): seed depth / seed iterations, unit gap / chunk

@@ -905,9 +905,7 @@ __device__ __forceinline__ uint32_t lt4_7(uint32_t x, uint32_t yb)
 // the next one to the right of r, searched in the 16 values [.., l] and [r, ..] of the line(s); when a window ends
 // first (end of the line, long run of equal suffixes) the level is taken from the {lcs, psv, nsv} entries in the
 // next iteration instead.  Everything else is ms_walk_guided_kernel.
-// HYB (experiment): the same one-iteration structure over the 96-row rank blocks (which stay in L2
-// on small indexes) and 16-row windows of a plain LCS byte array (1 B per row) instead of the 128-byte lines.
-template <bool BIG, bool CALL, bool K7, bool HYB = false>
+template <bool BIG, bool CALL, bool K7>
 __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
 {
     const uint32_t n = a.ix.n, k = a.ix.k;
@@ -1079,20 +1077,12 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
 #endif
             if (!(flags & G_BLOCKED)) {
                 const bool ent = (flags & G_ENT) != 0; // this iteration takes one contraction level from the entries
-                const uint32_t bl = HYB ? div96(l) : l >> 6, br = HYB ? div96(r) : r >> 6;
-                const uint32_t ol = HYB ? l - bl * kRankRows : l & 63u, orr = HYB ? r - br * kRankRows : r & 63u;
-                // 16-row windows of LCS values, [.., l] and [r, ..], cut at the line's ends (HYB: rows l - 15 .. l and r .. r + 15
-                // of the byte array, as offsets from the block's first row - they may be negative on the left)
-                const uint32_t wl = HYB ? ol - min(15u, l) : (ol > 15u ? ol - 15u : 0u), wr = HYB ? orr : min(orr, 48u);
+                const uint32_t bl = l >> 6, br = r >> 6, ol = l & 63u, orr = r & 63u;
+                // 16-row windows of LCS values, [.., l] and [r, ..], cut at the line's ends
+                const uint32_t wl = ol > 15u ? ol - 15u : 0u, wr = min(orr, 48u);
                 const bool cnull = cb == ~0u;
                 uint4 xA, xB, wA, wB;
-                if (HYB) {
-                    const uint32_t nblk = a.ix.n_blocks, cblk = cnull ? 4u * nblk : (cb >> 4) * nblk, bmask = cnull ? 0u : ~0u;
-                    xA = ld16(arena, (cblk + (bl & bmask)) << 4);
-                    xB = ld16(arena, (cblk + (br & bmask)) << 4);
-                    wA = ld16u(a.ix.lcs8, l - min(15u, l));
-                    wB = ld16u(a.ix.lcs8, r);
-                } else if (BIG) {
+                if (BIG) {
                     const uint64_t oA = (uint64_t)bl << 7, oB = (uint64_t)br << 7, oN = (uint64_t)null_line << 7;
                     __builtin_memcpy(&xA, fat + (cnull ? oN : oA + cb), 16);
                     __builtin_memcpy(&xB, fat + (cnull ? oN : oB + cb), 16);
@@ -1124,11 +1114,10 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                 // extension tried again after each from the two rank blocks that are already here (a level found in
                 // the windows ends inside the two lines)
                 const uint64_t WA = ((uint64_t)xA.z << 32) | xA.y, WB = ((uint64_t)xB.z << 32) | xB.y;
-                uint32_t l2 = HYB ? rank_eval(xA, ol) : xA.x + (uint32_t)__popcll(WA & ((1ull << ol) - 1ull));
-                uint32_t r2 = HYB ? rank_eval(xB, orr) : xB.x + (uint32_t)__popcll(WB & ((1ull << orr) - 1ull));
+                uint32_t l2 = xA.x + (uint32_t)__popcll(WA & ((1ull << ol) - 1ull));
+                uint32_t r2 = xB.x + (uint32_t)__popcll(WB & ((1ull << orr) - 1ull));
                 bool ok = !ent && l2 < r2;
                 bool short_win = false; // the windows end before the level does
-                bool reload = false;    // (HYB) a level moved l or r out of the rank blocks that are here: extension next iteration
                 st_fail += (!ent && !ok && d != 0) ? 1u : 0u;
                 st_ent += ent ? 1u : 0u;
 #ifdef KBO_WALK_DEBUG
@@ -1145,11 +1134,10 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                 }
 #pragma unroll 1
                 for (uint32_t lev = 0; lev < 4u; lev++) {
-                    const bool need = !ent && !ok && d != 0 && !short_win && !reload;
+                    const bool need = !ent && !ok && d != 0 && !short_win;
                     if (__ballot(need) == 0) break;
                     if (need) {
-                        const uint32_t rowA = HYB ? bl * kRankRows : bl << 6, rowB = HYB ? br * kRankRows : br << 6; // first rows the offsets count from
-                        const uint32_t pl = l - rowA - wl, pr = r - rowB - wr; // 0..15: l and r stay in the windows
+                        const uint32_t pl = l - (bl << 6) - wl, pr = r - (br << 6) - wr; // 0..15: l and r stay in the windows
                         const uint32_t lcs_l = (sel4(wA, pl >> 2) >> ((pl & 3u) * 8u)) & 0xFFu;
                         const uint32_t lcs_r = (sel4(wB, pr >> 2) >> ((pr & 3u) * 8u)) & 0xFFu;
                         const uint32_t lvw = max(lcs_l, lcs_r), yb = lvw * 0x01010101u;
@@ -1170,21 +1158,12 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                         } else if ((need_l && !below) || (need_r && !above)) {
                             short_win = true;
                         } else {
-                            l = need_l ? rowA + wl + (31u - (uint32_t)__clz((int)below)) : l;
-                            r = need_r ? rowB + wr + (uint32_t)__ffs((int)above) - 1u : r;
+                            l = need_l ? (bl << 6) + wl + (31u - (uint32_t)__clz((int)below)) : l;
+                            r = need_r ? (br << 6) + wr + (uint32_t)__ffs((int)above) - 1u : r;
                             d = lvw;
-                            if (HYB) { // the level's ends lie in the windows, but the rank blocks cover 96 rows of their own
-                                if (div96(l) != bl || div96(r) != br) reload = true;
-                                else {
-                                    l2 = rank_eval(xA, l - rowA);
-                                    r2 = rank_eval(xB, r - rowB);
-                                    ok = l2 < r2;
-                                }
-                            } else {
-                                l2 = xA.x + (uint32_t)__popcll(WA & ((1ull << (l - rowA)) - 1ull));
-                                r2 = xB.x + (uint32_t)__popcll(WB & ((1ull << (r - rowB)) - 1ull));
-                                ok = l2 < r2;
-                            }
+                            l2 = xA.x + (uint32_t)__popcll(WA & ((1ull << (l - (bl << 6))) - 1ull));
+                            r2 = xB.x + (uint32_t)__popcll(WB & ((1ull << (r - (br << 6))) - 1ull));
+                            ok = l2 < r2;
                         }
                         st_con++;
 #ifdef KBO_WALK_DEBUG
@@ -1363,13 +1342,7 @@ hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
 
 template <bool CALL> static void launch_guided_variant(const WalkArgs &a, uint32_t grid, uint32_t threads, hipStream_t stream)
 {
-    if (guided_form(a) == 2) { // experiment: rank blocks + LCS byte windows
-        if (a.ix.k <= 127u) {
-            if (a.ix.big) hipLaunchKernelGGL((ms_walk_recovery_kernel<true, CALL, true, true>), dim3(grid), dim3(threads), 0, stream, a);
-            else hipLaunchKernelGGL((ms_walk_recovery_kernel<false, CALL, true, true>), dim3(grid), dim3(threads), 0, stream, a);
-        } else if (a.ix.big) hipLaunchKernelGGL((ms_walk_recovery_kernel<true, CALL, false, true>), dim3(grid), dim3(threads), 0, stream, a);
-        else hipLaunchKernelGGL((ms_walk_recovery_kernel<false, CALL, false, true>), dim3(grid), dim3(threads), 0, stream, a);
-    } else if (guided_uses_recovery_lines(a)) {
+    if (guided_uses_recovery_lines(a)) {
         if (a.ix.k <= 127u) {
             if (a.ix.big) hipLaunchKernelGGL((ms_walk_recovery_kernel<true, CALL, true>), dim3(grid), dim3(threads), 0, stream, a);
             else hipLaunchKernelGGL((ms_walk_recovery_kernel<false, CALL, true>), dim3(grid), dim3(threads), 0, stream, a);

@@ -479,20 +479,13 @@ std::atomic<int> g_guided_fat{-1};
 void set_guided_walk(int waves_per_cu, int recovery_lines)
 {
     if (waves_per_cu >= 0) g_guided_waves_32nds = std::min(32, waves_per_cu);
-    if (recovery_lines >= -1) g_guided_fat = recovery_lines < 0 ? -1 : std::min(recovery_lines, 2);
+    if (recovery_lines >= -1) g_guided_fat = recovery_lines < 0 ? -1 : (recovery_lines != 0 ? 1 : 0);
 }
 bool guided_uses_recovery_lines(const WalkArgs &a)
 {
     static const int env_fat = std::getenv("KBO_PLAN_FAT") ? std::atoi(std::getenv("KBO_PLAN_FAT")) : -1; // experiments
     const int f = env_fat >= 0 ? env_fat : g_guided_fat.load();
-    return a.ix.fat != nullptr && (f < 0 ? a.ix.n >= (24u << 20) : f == 1);
-}
-int guided_form(const WalkArgs &a)
-{
-    static const int env_fat = std::getenv("KBO_PLAN_FAT") ? std::atoi(std::getenv("KBO_PLAN_FAT")) : -1; // experiments
-    const int f = env_fat >= 0 ? env_fat : g_guided_fat.load();
-    if (f == 2 && a.ix.lcs8) return 2;
-    return guided_uses_recovery_lines(a) ? 1 : 0;
+    return a.ix.fat != nullptr && (f < 0 ? a.ix.n >= (24u << 20) : f != 0);
 }
 std::atomic<int> g_pair_min_depth{16};                 // two-base steps only from matches at least this deep
 void set_pair_min_depth(int d) { g_pair_min_depth = d < 0 ? 0 : d; }
@@ -523,7 +516,7 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
         // chunks of 64 units
         static const int env_gw = std::getenv("KBO_GUIDED_WAVES") ? std::atoi(std::getenv("KBO_GUIDED_WAVES")) : 0; // experiments: 32nds
         const int gw_set = env_gw > 0 ? env_gw : g_guided_waves_32nds.load();
-        const int gw = gw_set > 0 ? gw_set : (guided_form(a) == 1 ? 12 : 8);
+        const int gw = gw_set > 0 ? gw_set : (guided_uses_recovery_lines(a) ? 12 : 8);
         const uint32_t gwaves = (uint32_t)std::min<uint64_t>((uint64_t)std::max(1, max_waves * gw / 32),
                                                              ((uint64_t)a.unit_cap + 63) / 64);
         e = launch_ms_walk_guided(a, (gwaves + wpb - 1) / wpb, threads, stream);
