@@ -59,13 +59,18 @@ int kbo_set_plan_unit_cap_divisor(int divisor);
  * launches the copy will still skip planning for; either pointer may be NULL.  KBO_E_BAD_ARG when no such copy exists. */
 int kbo_index_plan_holdoff(kbo_index_t *idx, int device, uint32_t *bails, int *holdoff);
 
-/* inspection: the work counters the plan-guided stage keeps about its own last launch over a device-resident batch - what
+/* instrumentation (default off): launches of the plan-guided stage made while it is on count their own work - per-lane adds
+ * in the walk's hot loop, one atomic per counter and wave at exit: about 1 % of the stage's time, which is why the default
+ * instantiations of the kernels carry none of it */
+int kbo_set_plan_stats(int on);
+/* inspection: the work counters the plan-guided stage kept about its last launch over a device-resident batch (made with
+ * kbo_set_plan_stats(1)) - what
  * the CPU model of the stage (oracle/plan_model.c), whose counts bench.py's roofline prices the stage by, is pinned to
  * (tests/test_gpu_model.py).  Arguments as for the kbo_ms_batch_dev call that ran on d_work; synchronises `stream`.
  * out[0..7]: units walked, accepted extensions, failed extensions, contraction levels, levels taken from the entries
  * (recovery-line form), seed-table look-ups, seed extensions, mismatches against the diagonals;  out[8]: units emitted,
  * [9]: entries of the redo list, [10]: 1 = the plan was given up, [11]: 1 = a walk left through its guard.  Meaningless
- * (stale or zero) when that launch did not plan (plain walk, hold-off, intervals requested). */
+ * (stale or zero) when that launch did not plan (plain walk, hold-off, intervals requested) or did not count. */
 #define KBO_PLAN_STATS 12
 int kbo_plan_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k, const void *d_work,
                        uint64_t out[KBO_PLAN_STATS], void *stream);

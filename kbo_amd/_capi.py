@@ -86,7 +86,7 @@ SYMBOLS = [
 TUNING_SYMBOLS = [
     "kbo_walk_geometry", "kbo_set_walk_waves_per_cu", "kbo_set_walk_threads", "kbo_set_walk_rare", "kbo_set_guided_walk",
     "kbo_set_pair_steps", "kbo_set_force_big_layout", "kbo_set_seed_table_depth", "kbo_set_plan", "kbo_set_plan_tuning",
-    "kbo_set_plan_unit_cap_divisor", "kbo_index_plan_holdoff", "kbo_set_walk_experiment", "kbo_plan_stats_dev", "kbo_run_automaton_depths",
+    "kbo_set_plan_unit_cap_divisor", "kbo_index_plan_holdoff", "kbo_set_walk_experiment", "kbo_plan_stats_dev", "kbo_set_plan_stats", "kbo_run_automaton_depths",
 ]
 
 _lib = None
@@ -184,6 +184,7 @@ def lib():
     L.kbo_unpack_matches.argtypes = [vp, vp, sz, vp]
     L.kbo_matches_batch_packed.argtypes = [vp, vp, vp, sz, vp, vp, sz, dbl, vp]
     L.kbo_find_batch_packed.argtypes = [vp, vp, vp, sz, vp, vp, sz, C.POINTER(FindOpts), C.POINTER(vp), vp]
+    L.kbo_set_plan_stats.argtypes = [C.c_int]
     L.kbo_set_plan_unit_cap_divisor.argtypes = [C.c_int]
     L.kbo_set_seed_table_depth.argtypes = [C.c_int]
     L.kbo_index_plan_holdoff.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]

@@ -85,6 +85,7 @@ extern std::atomic<bool> g_force_big;             // tests: use the 64-bit-offse
 extern std::atomic<uint64_t> g_pair_min_rows;     // indexes with at least this many rows get two-base blocks on the device
 extern std::atomic<size_t> g_slab_bytes;          // host batches are cut into slabs of at most this many query bytes
 extern std::atomic<int> g_plan_cap_div;           // tests: the unit array gets 1/this of its normal capacity
+extern std::atomic<bool> g_plan_stats;            // launches of the plan-guided stage count their own work (kbo_set_plan_stats)
 extern std::atomic<int> g_seed_table_depth;       // tests: bases per seed-table entry of new device copies (0 = by index size)
 extern std::atomic<bool> g_plan_enabled;          // device copies carry a path cover and MS-only batches take the plan-guided walk
 

@@ -14,6 +14,7 @@ std::atomic<uint64_t> g_pair_min_rows{24ull << 20};
 std::atomic<bool> g_plan_enabled{true};
 std::atomic<int> g_plan_cap_div{1};
 std::atomic<int> g_seed_table_depth{0};
+std::atomic<bool> g_plan_stats{false};
 
 int current_device()
 {
@@ -240,7 +241,7 @@ void attach_plan(kbo::WalkArgs &a, void *plan_work, DevCopy::PlanState *ps)
     a.ucount = reinterpret_cast<uint32_t *>(w + L.ucount);
     a.usums = reinterpret_cast<uint32_t *>(w + L.usums);
     a.qctl = reinterpret_cast<uint32_t *>(w + L.qctl);
-    a.pstats = reinterpret_cast<uint32_t *>(w + L.pstats);
+    a.pstats = g_plan_stats.load() ? reinterpret_cast<uint32_t *>(w + L.pstats) : nullptr; // (instrumentation: kbo_set_plan_stats)
     a.redo = w + L.redo;
 }
 

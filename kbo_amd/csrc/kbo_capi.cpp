@@ -1199,6 +1199,12 @@ int kbo_set_plan_unit_cap_divisor(int divisor)
     return KBO_OK;
 }
 
+int kbo_set_plan_stats(int on)
+{
+    g_plan_stats = on != 0;
+    return KBO_OK;
+}
+
 int kbo_set_seed_table_depth(int bases)
 {
     g_seed_table_depth = std::max(0, std::min(bases, 13));

@@ -561,7 +561,9 @@ enum : uint32_t {
 //  * output in words (4 bases), bytes at the two ends of the walked stretch, so that a unit patches the predicted
 //    values without touching its neighbours;
 //  * units come off one queue in chunks of 64 per wave; a lane that finishes takes the next one.
-template <bool BIG, bool CALL>
+// STATS: the kernel counts its own work (kPlanStat*; kbo_set_plan_stats) - instrumentation, compiled out of the default
+// instantiation (about 1 % of the kernel's time)
+template <bool BIG, bool CALL, bool STATS>
 __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
 {
     const uint32_t n = a.ix.n, k = a.ix.k;
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
                     wbase = (out_from - warm) & ~3u;
                     wfirst = (out_from - warm) & 3u; // first byte of the first output word that is this unit's
                     flags = i < bound ? 0u : G_DONE; // (empty units: see plan_emit_kernel)
-                    st_units += i < bound ? 1u : 0u;
+                    if (STATS) st_units += i < bound ? 1u : 0u;
                     want = true;
 #ifdef KBO_WALK_DEBUG
                     dbg_units++;
@@ -759,9 +761,11 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
                 const bool ok = !con && l2 < r2;
                 const bool accept = !con && (l2 < r2 || d == 0);
                 const bool fail = !con && !accept;
-                st_con += con ? 1u : 0u;
-                st_acc += accept ? 1u : 0u;
-                st_fail += fail ? 1u : 0u;
+                if (STATS) {
+                    st_con += con ? 1u : 0u;
+                    st_acc += accept ? 1u : 0u;
+                    st_fail += fail ? 1u : 0u;
+                }
 #ifdef KBO_WALK_DEBUG
                 dbg_con += con ? 1u : 0u;
                 dbg_acc += accept ? 1u : 0u;
@@ -859,7 +863,7 @@ __global__ __launch_bounds__(256) void ms_walk_guided_kernel(WalkArgs a)
             }
         } // hot loop
     }
-    plan_stats_add(a.pstats, kPlanStatUnits, st_units, kPlanStatAccepted, st_acc, kPlanStatFailed, st_fail, kPlanStatLevels, st_con);
+    if (STATS) plan_stats_add(a.pstats, kPlanStatUnits, st_units, kPlanStatAccepted, st_acc, kPlanStatFailed, st_fail, kPlanStatLevels, st_con);
 #ifdef KBO_WALK_DEBUG
     if (a.lo_out == nullptr && a.hi_out != nullptr) { // debug build: hi_out doubles as the counter sink
         if (lane == 0) {
@@ -905,7 +909,7 @@ __device__ __forceinline__ uint32_t lt4_7(uint32_t x, uint32_t yb)
 // the next one to the right of r, searched in the 16 values [.., l] and [r, ..] of the line(s); when a window ends
 // first (end of the line, long run of equal suffixes) the level is taken from the {lcs, psv, nsv} entries in the
 // next iteration instead.  Everything else is ms_walk_guided_kernel.
-template <bool BIG, bool CALL, bool K7>
+template <bool BIG, bool CALL, bool K7, bool STATS>
 __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
 {
     const uint32_t n = a.ix.n, k = a.ix.k;
@@ -1023,7 +1027,7 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                     wbase = (out_from - warm) & ~3u;
                     wfirst = (out_from - warm) & 3u; // first byte of the first output word that is this unit's
                     flags = i < bound ? 0u : G_DONE; // (empty units: see plan_emit_kernel)
-                    st_units += i < bound ? 1u : 0u;
+                    if (STATS) st_units += i < bound ? 1u : 0u;
                     want = true;
 #ifdef KBO_WALK_DEBUG
                     dbg_units++;
@@ -1118,8 +1122,10 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                 uint32_t r2 = xB.x + (uint32_t)__popcll(WB & ((1ull << orr) - 1ull));
                 bool ok = !ent && l2 < r2;
                 bool short_win = false; // the windows end before the level does
-                st_fail += (!ent && !ok && d != 0) ? 1u : 0u;
-                st_ent += ent ? 1u : 0u;
+                if (STATS) {
+                    st_fail += (!ent && !ok && d != 0) ? 1u : 0u;
+                    st_ent += ent ? 1u : 0u;
+                }
 #ifdef KBO_WALK_DEBUG
                 dbg_fail += (!ent && !ok && d != 0) ? 1u : 0u;
 #endif
@@ -1165,7 +1171,7 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                             r2 = xB.x + (uint32_t)__popcll(WB & ((1ull << (r - (br << 6))) - 1ull));
                             ok = l2 < r2;
                         }
-                        st_con++;
+                        if (STATS) st_con++;
 #ifdef KBO_WALK_DEBUG
                         dbg_con++;
                         dbg_short += short_win ? 1u : 0u;
@@ -1178,7 +1184,7 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
                 l = ok ? l2 : l;
                 r = ok ? r2 : r;
                 d = ok ? min(d + 1u, k) : d;
-                st_acc += accept ? 1u : 0u;
+                if (STATS) st_acc += accept ? 1u : 0u;
 #ifdef KBO_WALK_DEBUG
                 dbg_acc += accept ? 1u : 0u;
 #endif
@@ -1254,8 +1260,10 @@ __global__ __launch_bounds__(256) void ms_walk_recovery_kernel(WalkArgs a)
             }
         } // hot loop
     }
-    plan_stats_add(a.pstats, kPlanStatUnits, st_units, kPlanStatAccepted, st_acc, kPlanStatFailed, st_fail, kPlanStatLevels, st_con);
-    plan_stats_add(a.pstats, kPlanStatEntryLevels, st_ent, 0, 0, 0, 0, 0, 0);
+    if (STATS) {
+        plan_stats_add(a.pstats, kPlanStatUnits, st_units, kPlanStatAccepted, st_acc, kPlanStatFailed, st_fail, kPlanStatLevels, st_con);
+        plan_stats_add(a.pstats, kPlanStatEntryLevels, st_ent, 0, 0, 0, 0, 0, 0);
+    }
 #ifdef KBO_WALK_DEBUG
     if (a.lo_out == nullptr && a.hi_out != nullptr) { // debug build: hi_out doubles as the counter sink
         if (lane == 0) {
@@ -1340,22 +1348,26 @@ hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <bool CALL> static void launch_guided_variant(const WalkArgs &a, uint32_t grid, uint32_t threads, hipStream_t stream)
+template <bool CALL, bool STATS> static void launch_guided_variant(const WalkArgs &a, uint32_t grid, uint32_t threads, hipStream_t stream)
 {
     if (guided_uses_recovery_lines(a)) {
         if (a.ix.k <= 127u) {
-            if (a.ix.big) hipLaunchKernelGGL((ms_walk_recovery_kernel<true, CALL, true>), dim3(grid), dim3(threads), 0, stream, a);
-            else hipLaunchKernelGGL((ms_walk_recovery_kernel<false, CALL, true>), dim3(grid), dim3(threads), 0, stream, a);
-        } else if (a.ix.big) hipLaunchKernelGGL((ms_walk_recovery_kernel<true, CALL, false>), dim3(grid), dim3(threads), 0, stream, a);
-        else hipLaunchKernelGGL((ms_walk_recovery_kernel<false, CALL, false>), dim3(grid), dim3(threads), 0, stream, a);
-    } else if (a.ix.big) hipLaunchKernelGGL((ms_walk_guided_kernel<true, CALL>), dim3(grid), dim3(threads), 0, stream, a);
-    else hipLaunchKernelGGL((ms_walk_guided_kernel<false, CALL>), dim3(grid), dim3(threads), 0, stream, a);
+            if (a.ix.big) hipLaunchKernelGGL((ms_walk_recovery_kernel<true, CALL, true, STATS>), dim3(grid), dim3(threads), 0, stream, a);
+            else hipLaunchKernelGGL((ms_walk_recovery_kernel<false, CALL, true, STATS>), dim3(grid), dim3(threads), 0, stream, a);
+        } else if (a.ix.big) hipLaunchKernelGGL((ms_walk_recovery_kernel<true, CALL, false, STATS>), dim3(grid), dim3(threads), 0, stream, a);
+        else hipLaunchKernelGGL((ms_walk_recovery_kernel<false, CALL, false, STATS>), dim3(grid), dim3(threads), 0, stream, a);
+    } else if (a.ix.big) hipLaunchKernelGGL((ms_walk_guided_kernel<true, CALL, STATS>), dim3(grid), dim3(threads), 0, stream, a);
+    else hipLaunchKernelGGL((ms_walk_guided_kernel<false, CALL, STATS>), dim3(grid), dim3(threads), 0, stream, a);
 }
 
 hipError_t launch_ms_walk_guided(WalkArgs a, uint32_t grid, uint32_t threads, hipStream_t stream)
 {
-    if (a.call_sites) launch_guided_variant<true>(a, grid, threads, stream);
-    else launch_guided_variant<false>(a, grid, threads, stream);
+    // (the counting instantiations only when the launch was given a place for its counters: kbo_set_plan_stats)
+    if (a.call_sites) {
+        if (a.pstats) launch_guided_variant<true, true>(a, grid, threads, stream);
+        else launch_guided_variant<true, false>(a, grid, threads, stream);
+    } else if (a.pstats) launch_guided_variant<false, true>(a, grid, threads, stream);
+    else launch_guided_variant<false, false>(a, grid, threads, stream);
     hipLaunchKernelGGL(redo_collect_kernel, dim3((a.n_items + 255u) / 256u), dim3(256), 0, stream, a);
     // call mode: sites of items that go to the redo pass are void (that pass finds them again), the others get their rows
     if (a.call_sites) hipLaunchKernelGGL(call_fix_sites_kernel, dim3(kCallSegs), dim3(256), 0, stream, a);

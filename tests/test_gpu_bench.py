@@ -46,6 +46,14 @@ def test_bench_line_single_process_with_extras(tmp_path):
     assert r["host_to_host"]["value"] > 0
 
 
+def test_bench_c4_shape_strong_scaling_two_ranks(tmp_path):
+    """--config C4 at reduced size: the reads are a fixed set, sharded over the ranks (strong scaling)"""
+    r = _run(["--config", "C4", "--gpus", "2", "--genome", "400000", "--reads", "50001", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"],
+             tmp_path, {"KBO_BENCH_ONE_GPU": "1"})
+    _check_line(r, 2)
+    assert r["scaling"] == "strong" and "50001 x 150 bp reads in all, 25001 per GPU" in r["config"]["workload"]
+
+
 def test_bench_gpus_2_spawns_two_ranks(tmp_path):
     r = _run(["--gpus", "2", "--genome", "400000", "--reads", "30000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1.5"],
              tmp_path, {"KBO_BENCH_ONE_GPU": "1"})

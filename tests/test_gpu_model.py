@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 def _compare(oracle, sbwt, ora, concat, offsets, fat):
     import torch
     L = kbo_amd.lib()
+    L.kbo_set_plan_stats(1)  # (the counting instantiations of the kernels; off by default)
     L.kbo_set_guided_walk(0, fat)
     dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"))
     dev.ms.fill_(0xEE)
