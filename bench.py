@@ -629,13 +629,15 @@ def main(argv=None):
         # fabric-side traffic and L2 misses of the A1 stage, from the committed rocprofv3 passes of this exact
         # workload and walk mode (PMC passes cannot run inside the timed region: separate runs, tools/profile_bench.sh)
         wl_key = f"{args.genome}x{n_mine}x{args.read_len}x{args.sub_rate:g}:{'plan' if planned else 'plain'}"
-        traffic = tsrc = misses = None
+        traffic = tsrc = misses = walk_misses = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 entry = json.load(open(tpath)).get("workloads", {}).get(wl_key)
                 if entry:
                     traffic, misses, tsrc = entry.get("a1_bytes_per_launch"), entry.get("a1_tcc_miss_per_launch"), entry.get("source")
+                    kern = entry.get("kernels", {})
+                    walk_misses = (kern.get("ms_walk_guided_kernel") or kern.get("ms_walk_recovery_kernel") or {}).get("tcc_miss")
             except Exception:
                 pass
         rank_b, lcs_b = sbwt.device_bytes()
@@ -671,7 +673,10 @@ def main(argv=None):
             "fill_rate_frac": round(misses / walk_s / FILL_CEILING_PER_S, 4) if misses else None,
             "fill_rate_ceiling": {"fills_per_s": FILL_CEILING_PER_S, "source": FILL_CEILING_SOURCE},
             "fills_min_per_unit": model["per_unit"]["distinct_lines_beyond_l2"] if model else None,
-            "l2_miss_per_unit": round(misses / max(1, stats["units"]), 2) if misses and planned else None,
+            # measured L2 misses per unit: of the whole stage, and of the walk kernel alone (to set against fills_min_per_unit:
+            # the difference is the rank-block look-ups that miss although the blocks would fit the L2)
+            "l2_miss_per_unit": round(misses / max(1, stats["units"] * bases / dev.total), 2) if misses and planned else None,
+            "walk_kernel_l2_miss_per_unit": round(walk_misses / max(1, stats["units"] * bases / dev.total), 2) if walk_misses and planned else None,
             "frac_reference_algorithm": round(ref_achieved / HBM_PEAK_GBPS, 4) if ref_achieved is not None else None,
             "reference_algorithm_bytes_per_base": round(b_ref, 2) if b_ref is not None else None,
             "cross_check_whole_step_gbps": round(b_alg * bases / (elapsed / args.steps) / 1e9, 1) if b_alg is not None else None,

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Folds a tools/summarize_prof.py summary into profiles/traffic_latest.json (what bench.py quotes as roofline.traffic):
 A1-stage bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 and TCC misses, summed over the stage's kernels, per launch.
-Usage: tools/traffic_from_summary.py <summary.json> <workload key, e.g. 5000000x1000000x150x0.01:plan> <source label>"""
+Usage: tools/traffic_from_summary.py <summary.json> <workload key, e.g. 5000000x1000000x150x0.01:plan> <source label> [launches per step]
+(launches per step: resident slabs per GPU of the workload - C3's 10 M reads are two slabs - so that the figures are per STEP of
+bench.py, like its stage time)"""
 import json
 import os
 import sys
@@ -9,6 +11,7 @@ import sys
 A1 = ("plan_kernel", "plan_count_kernel", "scan_kernel", "plan_emit_kernel", "ms_walk_guided_kernel",
       "ms_walk_recovery_kernel", "redo_collect_kernel", "ms_walk_kernel")
 summ, key, source = json.load(open(sys.argv[1])), sys.argv[2], sys.argv[3]
+per_step_launches = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = os.path.join(root, "profiles", "traffic_latest.json")
 doc = json.load(open(path))
@@ -20,11 +23,13 @@ for k in A1:
     if not d or "FETCH_SIZE" not in d:
         continue
     mult = calls.get(k, per_step) / per_step if k == "scan_kernel" else 1  # (several scan launches per stage)
+    mult *= per_step_launches
     b = int((2 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0)) * 1024 * mult)
     m = int(d.get("TCC_MISS_sum", 0) * mult)
     kern[k] = {"bytes": b, "tcc_miss": m, "tcc_hit": int(d.get("TCC_HIT_sum", 0) * mult)}
     tot_b += b
     tot_m += m
-doc["workloads"][key] = {"source": source, "a1_bytes_per_launch": tot_b, "a1_tcc_miss_per_launch": tot_m, "kernels": kern}
+doc["workloads"][key] = {"source": source, "launches_per_step": per_step_launches, "a1_bytes_per_launch": tot_b,
+                         "a1_tcc_miss_per_launch": tot_m, "kernels": kern}  # (per step of bench.py = per launch x launches per step)
 json.dump(doc, open(path, "w"), indent=1)
 print(key, "bytes", tot_b, "misses", tot_m)
