@@ -145,6 +145,20 @@ int kbo_index_load(const char *path, kbo_index_t **out);
 int kbo_index_save_sbwt(const kbo_index_t *idx, const char *prefix);
 int kbo_index_load_sbwt(const char *prefix, kbo_index_t **out);
 
+/* Sharded indexes.  Row numbers are 32 bits on the device, so an index of 2^32 rows or more - a human genome WITH its reverse
+ * complements, 6.2 * 10^9 rows - cannot be one index here.  kbo_index_build builds such an input as SHARDS: ordinary indexes
+ * over groups of whole sequences, the forward and the reverse-complement strand of every group apart.  The strings (of at
+ * most k characters) that are suffixes of an SBWT's rows are the substrings of its input's ACGT-runs of at least k characters
+ * - a property of the sequences one by one - so the DEPTH of the walk against the index of everything is the maximum of the
+ * depths against the shards, and n_kmers (what the threshold of the derandomisation needs) is counted over the union.
+ * Everything that only needs depths therefore gives the union index's results, bit for bit, by walking every shard:
+ * kbo_matches[_batch][_packed], kbo_map[_batch] without fill_gaps / call_variants, kbo_find[_batch][_packed], kbo_ms_batch /
+ * kbo_matching_statistics without intervals, and the device-resident entry points (d_work: kbo_index_work_bytes).  What needs
+ * ROWS of the union - intervals, kbo_call*, kbo_fill_gaps, full kbo_map, export / save, the path-cover getters - returns
+ * KBO_E_UNSUPPORTED for such a handle.  kbo_index_shards: 1 for an ordinary index; kbo_index_n_sets counts the rows of all
+ * shards. */
+int kbo_index_shards(const kbo_index_t *idx);
+
 /* Upload (idempotent) the device layout to HIP device `device` (-1 = current). */
 int kbo_index_to_device(kbo_index_t *idx, int device);
 /* Bytes of the device-resident layout: rank blocks / contraction entries {lcs,psv,nsv}. */
@@ -310,6 +324,8 @@ int kbo_find_batch_packed(kbo_index_t *idx, const uint32_t *words, const uint64_
  * derandomize/translate kernel (the host entry points reject them like the reference).
  * d_work is device scratch of at least kbo_work_bytes(...) bytes for the batch (16-byte aligned). */
 size_t kbo_work_bytes(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k);
+/* the same for a given index: a sharded index needs total_bases + 32 bytes more (one further shard's MS values) */
+size_t kbo_index_work_bytes(const kbo_index_t *idx, size_t n_seqs, uint64_t total_bases, size_t max_seq_len);
 /* A1 over a batch.  total_bases = offsets[n_seqs] (known to the caller; avoids a device read-back);
  * max_seq_len = length of the longest sequence if the caller knows it, 0 = unknown.  Batches of reads
  * get one work item per sequence; when max_seq_len is unknown or long, the item list is built on the

@@ -35,6 +35,12 @@ int kbo_set_guided_walk(int waves_per_cu, int recovery_lines);
 int kbo_set_pair_steps(uint64_t min_rows, int min_depth);
 /* tests: force the 64-bit-offset contraction-entry layout (device copies made after the call) */
 int kbo_set_force_big_layout(int on);
+/* tests: kbo_index_build makes at least this many shards whatever the size of its input (0 = by size: one index below
+ * 3.76 * 10^9 rows); see kbo_hip.h "Sharded indexes" */
+int kbo_set_index_shards(int shards);
+/* tests: shard i of a sharded index - an ordinary index over its part of the input (n_kmers = its own), BORROWED: it lives as
+ * long as `idx` and must not be freed.  An ordinary index is its own shard 0.  NULL when i is out of range. */
+const kbo_index_t *kbo_index_shard(const kbo_index_t *idx, int i);
 /* tests: depth of the seed table of device copies made after the call (0 = by index size: 8 / 10 / 12 / 13 bases;
  * 1 .. 13 = that many, capped at k).  Large tables are what large indexes get: 12 bases = 128 MiB, 13 = 512 MiB. */
 int kbo_set_seed_table_depth(int bases);

@@ -80,13 +80,13 @@ SYMBOLS = [
     "kbo_run_lengths_work_bytes", "kbo_run_lengths_dev", "kbo_index_device_pair_bytes", "kbo_index_device_plan_bytes",
     "kbo_index_path_cover", "kbo_index_recovery_lines", "kbo_call_batch", "kbo_call_sites_dev", "kbo_call_walk_dev",
     "kbo_index_save_sbwt", "kbo_index_load_sbwt", "kbo_packed_words", "kbo_pack_reads", "kbo_unpack_matches",
-    "kbo_matches_batch_packed", "kbo_find_batch_packed",
+    "kbo_matches_batch_packed", "kbo_find_batch_packed", "kbo_index_shards", "kbo_index_work_bytes",
 ]
 # ... and include/kbo_hip_tuning.h (knobs, experiment switches, test hooks: not part of the drop-in boundary)
 TUNING_SYMBOLS = [
     "kbo_walk_geometry", "kbo_set_walk_waves_per_cu", "kbo_set_walk_threads", "kbo_set_walk_rare", "kbo_set_guided_walk",
     "kbo_set_pair_steps", "kbo_set_force_big_layout", "kbo_set_seed_table_depth", "kbo_set_plan", "kbo_set_plan_tuning",
-    "kbo_set_plan_unit_cap_divisor", "kbo_index_plan_holdoff", "kbo_set_walk_experiment", "kbo_plan_stats_dev", "kbo_set_plan_stats", "kbo_run_automaton_depths",
+    "kbo_set_plan_unit_cap_divisor", "kbo_index_plan_holdoff", "kbo_set_walk_experiment", "kbo_plan_stats_dev", "kbo_set_plan_stats", "kbo_set_index_shards", "kbo_index_shard", "kbo_run_automaton_depths",
 ]
 
 _lib = None
@@ -185,6 +185,10 @@ def lib():
     L.kbo_matches_batch_packed.argtypes = [vp, vp, vp, sz, vp, vp, sz, dbl, vp]
     L.kbo_find_batch_packed.argtypes = [vp, vp, vp, sz, vp, vp, sz, C.POINTER(FindOpts), C.POINTER(vp), vp]
     L.kbo_set_plan_stats.argtypes = [C.c_int]
+    L.kbo_set_index_shards.argtypes = [C.c_int]
+    L.kbo_index_shards.argtypes = [vp]
+    L.kbo_index_shard.argtypes = [vp, C.c_int]; L.kbo_index_shard.restype = vp
+    L.kbo_index_work_bytes.argtypes = [vp, sz, u64, sz]; L.kbo_index_work_bytes.restype = sz
     L.kbo_set_plan_unit_cap_divisor.argtypes = [C.c_int]
     L.kbo_set_seed_table_depth.argtypes = [C.c_int]
     L.kbo_index_plan_holdoff.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]

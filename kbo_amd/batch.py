@@ -184,7 +184,7 @@ class DeviceBatch:
             self.off = torch.from_numpy(offsets.view(np.int64)).to(device)
             self.ms = torch.zeros(pad, dtype=torch.uint8, device=device)
             self.chars = torch.zeros(pad, dtype=torch.uint8, device=device)
-            self.work_bytes = int(lib().kbo_work_bytes(n, self.total, self.max_len, self.k))
+            self.work_bytes = int(lib().kbo_index_work_bytes(sbwt._h, n, self.total, self.max_len))
             self.work = torch.zeros(self.work_bytes // 8 + 2, dtype=torch.int64, device=device)
             self.lo = torch.zeros(self.total, dtype=torch.int32, device=device) if want_intervals else None
             self.hi = torch.zeros(self.total, dtype=torch.int32, device=device) if want_intervals else None

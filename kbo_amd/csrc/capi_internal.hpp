@@ -67,6 +67,15 @@ struct kbo_index {
     // the path cover of the plan-guided walk once it has been computed (or read from an index file), guarded by `mu`:
     // every device copy uploads it from here, kbo_index_save writes it (laying it out is a 26 s pointer chase per 10^8 rows)
     std::unique_ptr<kbo::PathCover> cover;
+    // A SHARDED index (kbo_capi.cpp build_sharded): an index whose rows would not fit 32-bit row numbers (a human genome
+    // with its reverse complements: 6.2 * 10^9 rows) is built as several ordinary indexes over disjoint parts of the input -
+    // groups of sequences, forward and reverse-complement strands apart - and this handle only holds them: host.k,
+    // host.n_kmers (distinct k-mers of the union: what the threshold needs) and host.n_sets (rows over all shards) are set,
+    // host.rows / host.lcs are empty.  The depth of the walk against the union index is the maximum of the depths against
+    // the shards, so everything that only needs depths (matches / map without refinement / find / ms without intervals)
+    // walks every shard and keeps the maximum; what needs rows of the union (intervals, call, fill_gaps, export) is refused.
+    std::vector<std::unique_ptr<kbo_index>> shards;
+    bool sharded() const { return !shards.empty(); }
     ~kbo_index()
     {
         for (auto &kv : dev) delete kv.second;
@@ -85,12 +94,23 @@ extern std::atomic<bool> g_force_big;             // tests: use the 64-bit-offse
 extern std::atomic<uint64_t> g_pair_min_rows;     // indexes with at least this many rows get two-base blocks on the device
 extern std::atomic<size_t> g_slab_bytes;          // host batches are cut into slabs of at most this many query bytes
 extern std::atomic<int> g_plan_cap_div;           // tests: the unit array gets 1/this of its normal capacity
+extern std::atomic<int> g_index_shards;           // tests: kbo_index_build makes at least this many shards (0 = by size)
 extern std::atomic<bool> g_plan_stats;            // launches of the plan-guided stage count their own work (kbo_set_plan_stats)
 extern std::atomic<int> g_seed_table_depth;       // tests: bases per seed-table entry of new device copies (0 = by index size)
 extern std::atomic<bool> g_plan_enabled;          // device copies carry a path cover and MS-only batches take the plan-guided walk
 
 // ---- device_index.cpp
 int current_device();
+// the indexes a walk goes over: the shards of a sharded handle, else the handle itself
+inline std::vector<kbo_index *> shards_of(kbo_index *idx)
+{
+    std::vector<kbo_index *> v;
+    if (idx->sharded()) for (auto &s : idx->shards) v.push_back(s.get());
+    else v.push_back(idx);
+    return v;
+}
+// throws KBO_E_UNSUPPORTED for a sharded handle: `what` needs the rows of ONE index
+void require_unsharded(const kbo_index *idx, const char *what);
 // uploads the index on first use; *plan (optional) receives the copy's plan hold-off state
 kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **plan = nullptr);
 int walk_max_waves();                                     // upper bound on resident walk waves: CUs x waves per CU
@@ -108,11 +128,12 @@ size_t random_match_threshold(size_t k, size_t n_kmers, size_t alphabet_size, do
 // ---- host_batch.cpp
 struct BatchOnDevice {
     DevBuf q, off, items, ms, lo, hi, plan;
+    DevBuf ms_shard; // sharded indexes: the MS values of one further shard, folded into `ms` by maximum
     DevBuf packed, pscr, exc_pos, exc_byte, packed_out; // packed entry points: 2-bit words in, scanned words per sequence, non-ACGT list, 2-bit words out
     uint64_t total = 0;
     void release()
     {
-        for (DevBuf *b : {&q, &off, &items, &ms, &lo, &hi, &plan, &packed, &pscr, &exc_pos, &exc_byte, &packed_out}) b->release();
+        for (DevBuf *b : {&q, &off, &items, &ms, &lo, &hi, &plan, &packed, &pscr, &exc_pos, &exc_byte, &packed_out, &ms_shard}) b->release();
     }
 };
 // a slab of a packed batch (pack_kernels.hip: sequence s = ceil(len / 16) u32 words, 2 bits per base): what

@@ -15,6 +15,7 @@ std::atomic<bool> g_plan_enabled{true};
 std::atomic<int> g_plan_cap_div{1};
 std::atomic<int> g_seed_table_depth{0};
 std::atomic<bool> g_plan_stats{false};
+std::atomic<int> g_index_shards{0};
 
 int current_device()
 {
@@ -35,8 +36,17 @@ void release_transient_arena()
     if (!DevCopy::transient_arena_in_use()) transient_arena().release();
 }
 
+void require_unsharded(const kbo_index *idx, const char *what)
+{
+    if (idx && idx->sharded())
+        throw KboError(KBO_E_UNSUPPORTED, std::string(what) + " needs the rows of one index; this handle is a sharded index (its rows "
+                       "would not fit 32-bit row numbers): only depth-only batches (matches, map without refinement, find, ms "
+                       "without intervals) are supported on it");
+}
+
 kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **plan)
 {
+    require_unsharded(idx, "this operation");
     std::lock_guard<std::mutex> g(idx->mu);
     auto it = idx->dev.find(device);
     if (it == idx->dev.end()) {

@@ -106,8 +106,9 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
 {
     KBO_REQUIRE(idx->host.k <= 255, KBO_E_UNSUPPORTED, "k > 255");
     const int dev = current_device();
-    DevCopy::PlanState *plan_state = nullptr;
-    kbo::DevIndexView view = device_view(idx, dev, &plan_state);
+    const std::vector<kbo_index *> shards = shards_of(idx); // (a sharded index: every shard is walked, the maximum kept)
+    KBO_REQUIRE(shards.size() == 1 || (!want_ival && !call), KBO_E_UNSUPPORTED,
+                "intervals and the call mode need the rows of one index; this handle is a sharded index");
     const uint64_t total = offsets[n_seqs];
     B.total = total;
     // reads (nothing to chunk): the item list is derived from the offsets on the device;
@@ -167,26 +168,33 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
                                       B.q.as<uint8_t>(), stream));
     }
     if (device_items) HIP_OK(kbo::launch_make_items(B.off.as<uint64_t>(), (uint32_t)n_seqs, B.items.as<kbo::WalkItem>(), stream));
-    kbo::WalkArgs a{};
-    a.ix = view;
-    a.q = B.q.as<uint8_t>();
-    a.q_bytes = total;
-    a.items = B.items.as<kbo::WalkItem>();
-    a.n_items = (uint32_t)n_items;
-    a.rounds = 0;
-    a.d_out = B.ms.as<uint8_t>();
-    a.lo_out = want_ival ? B.lo.as<uint32_t>() : nullptr;
-    a.hi_out = want_ival ? B.hi.as<uint32_t>() : nullptr;
-    a.call_sites = call ? static_cast<uint4 *>(call->d_sites) : nullptr;
-    a.call_counts = call ? call->d_counts : nullptr;
-    a.call_cap = call ? call->cap_per_list : 0;
-    a.call_thr = call ? call->threshold : 0;
-    // (no item is longer than this: chunk + k - 1 warm-up bases; call mode: k warm-up + up to k borrowed bases)
-    a.max_item_len = device_items ? longest_seq : (uint32_t)std::min<uint64_t>(chunk + (call ? 2ull * idx->host.k : idx->host.k), 0xFFFFFFFFu);
-    if (view.pc_text && !want_ival) B.plan.ensure(kbo::plan_work_bytes(n_items, total));
-    attach_plan(a, view.pc_text && !want_ival ? B.plan.p : nullptr, plan_state);
-    HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), stream));
-    plan_after_launch(a, stream, plan_state);
+    for (size_t sh = 0; sh < shards.size(); sh++) {
+        DevCopy::PlanState *plan_state = nullptr;
+        const kbo::DevIndexView view = device_view(shards[sh], dev, &plan_state);
+        if (sh > 0) B.ms_shard.ensure(padded);
+        kbo::WalkArgs a{};
+        a.ix = view;
+        a.q = B.q.as<uint8_t>();
+        a.q_bytes = total;
+        a.items = B.items.as<kbo::WalkItem>();
+        a.n_items = (uint32_t)n_items;
+        a.rounds = 0;
+        a.d_out = sh == 0 ? B.ms.as<uint8_t>() : B.ms_shard.as<uint8_t>();
+        a.lo_out = want_ival ? B.lo.as<uint32_t>() : nullptr;
+        a.hi_out = want_ival ? B.hi.as<uint32_t>() : nullptr;
+        a.call_sites = call ? static_cast<uint4 *>(call->d_sites) : nullptr;
+        a.call_counts = call ? call->d_counts : nullptr;
+        a.call_cap = call ? call->cap_per_list : 0;
+        a.call_thr = call ? call->threshold : 0;
+        // (no item is longer than this: chunk + k - 1 warm-up bases; call mode: k warm-up + up to k borrowed bases)
+        a.max_item_len = device_items ? longest_seq : (uint32_t)std::min<uint64_t>(chunk + (call ? 2ull * idx->host.k : idx->host.k), 0xFFFFFFFFu);
+        if (view.pc_text && !want_ival) B.plan.ensure(kbo::plan_work_bytes(n_items, total));
+        attach_plan(a, view.pc_text && !want_ival ? B.plan.p : nullptr, plan_state);
+        HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), stream));
+        plan_after_launch(a, stream, plan_state);
+        // the depth against the union of the shards is the maximum of the depths against each (capi_internal.hpp)
+        if (sh > 0) HIP_OK(kbo::launch_max_bytes(B.ms.as<uint8_t>(), B.ms_shard.as<uint8_t>(), total, stream));
+    }
 }
 
 void run_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,

@@ -245,6 +245,78 @@ void kbo_map_opts_default(kbo_map_opts *o)
     o->sbwt_build_opts.build_select = 1;
 }
 
+namespace {
+// A sharded index (capi_internal.hpp kbo_index::shards): `want` shards or more over disjoint parts of the input - groups of
+// whole sequences of about equal size, and with add_revcomp the forward and the reverse-complement strand of every group
+// apart.  The set of strings (of at most k characters) that are suffixes of rows of an SBWT is the set of substrings of its
+// input's ACGT-runs of at least k characters - a property of the runs, hence of the sequences one by one - so the depth of a
+// walk against the index of everything is the maximum of the depths against the shards.  The threshold of the derandomisation
+// needs the number of distinct k-mers of the union: every shard hands back its sorted k-mers and a merge counts them once.
+void build_sharded(const uint8_t *const *seqs, const size_t *lens, size_t n_seqs, const kbo::BuildParams &p, size_t want, kbo_index &out)
+{
+    const size_t strands = p.add_revcomp ? 2 : 1;
+    const size_t groups = std::max<size_t>(1, std::min(n_seqs, (want + strands - 1) / strands));
+    uint64_t bases = 0;
+    for (size_t s = 0; s < n_seqs; s++) bases += lens[s];
+    // contiguous groups of sequences with about bases / groups bases each
+    std::vector<size_t> first(groups + 1, n_seqs);
+    first[0] = 0;
+    {
+        uint64_t acc = 0;
+        size_t g = 1;
+        for (size_t s = 0; s < n_seqs && g < groups; s++) {
+            acc += lens[s];
+            if (acc >= bases * g / groups && s + 1 < n_seqs) first[g++] = s + 1;
+        }
+    }
+    std::vector<std::vector<uint64_t>> keys;
+    uint32_t key_words = 0;
+    uint64_t n_sets = 0;
+    for (size_t g = 0; g < groups; g++) {
+        if (first[g] >= first[g + 1]) continue;
+        for (size_t st = 0; st < strands; st++) {
+            kbo::BuildParams q = p;
+            q.add_revcomp = false;
+            q.revcomp_only = st == 1;
+            keys.emplace_back();
+            q.keys_out = &keys.back();
+            q.key_words_out = &key_words;
+            std::unique_ptr<kbo_index> sh(new kbo_index());
+            kbo::build_host_index(seqs + first[g], lens + first[g], first[g + 1] - first[g], q, sh->host);
+            n_sets += sh->host.n_sets;
+            out.shards.push_back(std::move(sh));
+        }
+    }
+    // distinct k-mers of the union: a merge over the shards' sorted key lists (equal k-mers have equal keys everywhere)
+    const size_t W = key_words ? key_words : 1;
+    std::vector<size_t> at(keys.size(), 0);
+    uint64_t distinct = 0;
+    auto less = [&](const uint64_t *a, const uint64_t *b) {
+        for (size_t j = 0; j < W; j++)
+            if (a[j] != b[j]) return a[j] < b[j];
+        return false;
+    };
+    uint64_t cur[8]; // (k <= 255: at most 8 words a key)
+    KBO_REQUIRE(W <= 8, KBO_E_UNSUPPORTED, "k-mer keys wider than 8 words");
+    for (;;) {
+        const uint64_t *best = nullptr;
+        for (size_t x = 0; x < keys.size(); x++) {
+            if (at[x] * W >= keys[x].size()) continue;
+            const uint64_t *c = keys[x].data() + at[x] * W;
+            if (!best || less(c, best)) best = c;
+        }
+        if (!best) break;
+        distinct++;
+        std::copy(best, best + W, cur); // (advance every list past this k-mer)
+        for (size_t x = 0; x < keys.size(); x++)
+            while (at[x] * W < keys[x].size() && std::equal(cur, cur + W, keys[x].data() + at[x] * W)) at[x]++;
+    }
+    out.host.k = p.k;
+    out.host.n_kmers = distinct;
+    out.host.n_sets = n_sets; // (rows over all shards; the index of the union would have fewer dummy rows)
+}
+} // namespace
+
 int kbo_index_build(const uint8_t *const *seqs, const size_t *lens, size_t n_seqs,
                     const kbo_build_opts *opts, kbo_index_t **out)
 {
@@ -256,14 +328,18 @@ int kbo_index_build(const uint8_t *const *seqs, const size_t *lens, size_t n_seq
         if (opts) o = *opts; else kbo_build_opts_default(&o);
         kbo::BuildParams p;
         p.k = o.k; p.add_revcomp = o.add_revcomp != 0; p.num_threads = std::max(1u, o.num_threads);
-        kbo_index *idx = new kbo_index();
-        try {
-            kbo::build_host_index(seqs, lens, n_seqs, p, idx->host);
-        } catch (...) {
-            delete idx;
-            throw;
-        }
-        *out = idx;
+        // rows the index would have, at most: one per base and strand (+ dummies).  Beyond 32-bit row numbers (a human genome
+        // with its reverse complements) - or when a test asks for it - the index is built as shards (capi_internal.hpp)
+        uint64_t bases = 0;
+        for (size_t s = 0; s < n_seqs; s++) bases += lens[s];
+        const uint64_t est_rows = bases * (p.add_revcomp ? 2u : 1u);
+        const uint64_t kShardRows = 0xE0000000ull; // (3.76 * 10^9: leaves room for the dummy rows)
+        const int forced = g_index_shards.load();
+        const size_t want = forced > 0 ? (size_t)forced : (size_t)((est_rows + kShardRows - 1) / kShardRows);
+        std::unique_ptr<kbo_index> idx(new kbo_index());
+        if (want <= 1) kbo::build_host_index(seqs, lens, n_seqs, p, idx->host);
+        else build_sharded(seqs, lens, n_seqs, p, want, *idx);
+        *out = idx.release();
     });
 }
 
@@ -298,6 +374,7 @@ int kbo_index_export_parts(const kbo_index_t *idx, uint64_t *const rows[4], uint
 {
     return guarded([&] {
         KBO_REQUIRE(idx && rows && C && lcs, KBO_E_BAD_ARG, "null argument");
+        require_unsharded(idx, "kbo_index_export_parts");
         const size_t nw = (idx->host.n_sets + 63) / 64;
         for (int c = 0; c < 4; c++) {
             C[c] = idx->host.C[c];
@@ -318,6 +395,7 @@ int kbo_index_save(const kbo_index_t *idx_c, const char *path)
     int rc = guarded([&] {
         KBO_REQUIRE(idx && path, KBO_E_BAD_ARG, "null argument");
         std::lock_guard<std::mutex> g(idx->mu);
+        require_unsharded(idx, "kbo_index_save");
         if (g_plan_enabled && !idx->cover && !idx->transient && idx->host.n_sets < 0xFFFFFFF0ull) {
             idx->cover.reset(new kbo::PathCover());
             kbo::make_path_cover(idx->host, *idx->cover);
@@ -351,6 +429,7 @@ int kbo_index_save_sbwt(const kbo_index_t *idx, const char *prefix)
 {
     int rc = guarded([&] {
         KBO_REQUIRE(idx && prefix, KBO_E_BAD_ARG, "null argument");
+        require_unsharded(idx, "kbo_index_save_sbwt");
         kbo::save_sbwt_pair(idx->host, prefix);
     });
     return rc == KBO_E_BAD_ARG && idx && prefix ? KBO_E_IO : rc;
@@ -384,7 +463,7 @@ int kbo_index_to_device(kbo_index_t *idx, int device)
 {
     return guarded([&] {
         KBO_REQUIRE(idx, KBO_E_BAD_ARG, "null index");
-        (void)device_view(idx, device < 0 ? current_device() : device);
+        for (kbo_index *sh : shards_of(idx)) (void)device_view(sh, device < 0 ? current_device() : device);
     });
 }
 
@@ -392,20 +471,28 @@ int kbo_index_device_bytes(const kbo_index_t *idx, uint64_t *rank_bytes, uint64_
 {
     return guarded([&] {
         KBO_REQUIRE(idx, KBO_E_BAD_ARG, "null index");
-        const uint64_t nb = idx->host.n_sets / kbo::kRankRowsPerBlock + 2;
-        if (rank_bytes) *rank_bytes = nb * 16 * 4;
-        if (lcs_bytes) *lcs_bytes = (3 * (idx->host.n_sets + 1) + 4) * sizeof(uint32_t);
+        uint64_t rb = 0, lb = 0; // (a sharded index: over all shards)
+        for (kbo_index *sh : shards_of(const_cast<kbo_index *>(idx))) {
+            rb += (sh->host.n_sets / kbo::kRankRowsPerBlock + 2) * 16 * 4;
+            lb += (3 * (sh->host.n_sets + 1) + 4) * sizeof(uint32_t);
+        }
+        if (rank_bytes) *rank_bytes = rb;
+        if (lcs_bytes) *lcs_bytes = lb;
     });
 }
 
 uint64_t kbo_index_device_pair_bytes(const kbo_index_t *idx)
 {
     if (!idx) return 0;
-    uint64_t bytes = 0; // what the device copies actually carry (none for the 64-bit entry layout)
-    std::lock_guard<std::mutex> g(const_cast<kbo_index *>(idx)->mu);
-    for (const auto &kv : idx->dev)
-        if (kv.second->pair_off) bytes = std::max<uint64_t>(bytes, (kv.second->n_blocks) * 16ull * 16ull);
-    return bytes;
+    uint64_t total = 0; // what the device copies actually carry (none for the 64-bit entry layout)
+    for (kbo_index *sh : shards_of(const_cast<kbo_index *>(idx))) {
+        uint64_t bytes = 0;
+        std::lock_guard<std::mutex> g(sh->mu);
+        for (const auto &kv : sh->dev)
+            if (kv.second->pair_off) bytes = std::max<uint64_t>(bytes, (kv.second->n_blocks) * 16ull * 16ull);
+        total += bytes;
+    }
+    return total;
 }
 
 int kbo_log_rm_max_cdf(size_t t, size_t alphabet_size, size_t n_kmers, double *out)
@@ -573,6 +660,7 @@ int kbo_map(kbo_index_t *idx, const uint8_t *ref_seq, size_t len, const kbo_map_
             matches_batch_impl(idx, ref_seq, off, 1, o.max_error_prob, o.format != 0, out);
             return;
         }
+        require_unsharded(idx, "kbo_map with fill_gaps / call_variants");
         const size_t threshold = random_match_threshold(idx->host.k, idx->host.n_kmers, 4, o.max_error_prob); // lib.rs:731
         std::vector<kbo::MsVal> ms;
         std::vector<uint8_t> refined;
@@ -603,6 +691,7 @@ int kbo_call(kbo_index_t *query_idx, const uint8_t *ref_seq, size_t len, const k
         KBO_REQUIRE(query_idx && ref_seq && out && n_out, KBO_E_BAD_ARG, "null argument");
         *out = nullptr;
         *n_out = 0;
+        require_unsharded(query_idx, "kbo_call");
         KBO_REQUIRE(len > 0, KBO_E_EMPTY_QUERY, "assert!(!query.is_empty()) (index.rs:248)");
         kbo_call_opts o;
         if (opts) o = *opts; else kbo_call_opts_default(&o);
@@ -635,6 +724,7 @@ int kbo_fill_gaps(kbo_index_t *idx, const uint8_t *ref_seq, size_t len, size_t t
     return guarded([&] {
         KBO_REQUIRE(idx && ref_seq && out, KBO_E_BAD_ARG, "null argument");
         std::vector<kbo::MsVal> ms;
+        require_unsharded(idx, "kbo_fill_gaps");
         std::vector<uint8_t> tr;
         ms_and_translation(idx, ref_seq, len, threshold, ms, tr);
         kbo::HostNav nav(idx->host);
@@ -648,6 +738,7 @@ int kbo_nearest_unique_context(kbo_index_t *idx, const uint8_t *ref_seq, size_t 
 {
     return guarded([&] {
         KBO_REQUIRE(idx && ref_seq && kmer_idx && kmer_out && kmer_len, KBO_E_BAD_ARG, "null argument");
+        require_unsharded(idx, "kbo_nearest_unique_context");
         std::vector<std::vector<uint8_t>> one(1, std::vector<uint8_t>(ref_seq, ref_seq + len));
         std::vector<std::vector<kbo::MsVal>> ms;
         make_ms_fn(idx)(one, ms);
@@ -947,6 +1038,13 @@ size_t kbo_work_bytes(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, u
     return dev_work(n_seqs, total_bases, max_seq_len, k).bytes;
 }
 
+size_t kbo_index_work_bytes(const kbo_index_t *idx, size_t n_seqs, uint64_t total_bases, size_t max_seq_len)
+{
+    if (!idx) return 0;
+    const size_t base = dev_work(n_seqs, total_bases, max_seq_len, idx->host.k).bytes;
+    return base + (idx->sharded() ? ((size_t)total_bases + 15) / 16 * 16 + 16 : 0); // + one further shard's MS values
+}
+
 namespace {
 int ms_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs,
                       uint64_t total_bases, size_t max_seq_len, uint8_t *d_ms_out, uint32_t *d_lo_out,
@@ -964,12 +1062,15 @@ int ms_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
         KBO_REQUIRE((d_lo_out == nullptr) == (d_hi_out == nullptr), KBO_E_BAD_ARG, "lo/hi must come together");
 #endif
         hipStream_t s = static_cast<hipStream_t>(stream);
-        DevCopy::PlanState *plan_state = nullptr;
-        kbo::DevIndexView view = device_view(idx, current_device(), &plan_state);
+        const std::vector<kbo_index *> shards = shards_of(idx); // (a sharded index: every shard is walked, the maximum kept)
+        KBO_REQUIRE(shards.size() == 1 || (!d_lo_out && !call), KBO_E_UNSUPPORTED,
+                    "intervals and the call mode need the rows of one index; this handle is a sharded index");
         kbo::WalkItem *items = static_cast<kbo::WalkItem *>(d_work);
         // reads: one item per sequence; batches that hold (or may hold) long sequences: chunks
         const DevWork w = dev_work(n_seqs, total_bases, max_seq_len, idx->host.k);
-        KBO_REQUIRE(work_bytes >= w.bytes, KBO_E_BAD_ARG, "d_work is smaller than kbo_work_bytes() for this batch");
+        const size_t shard_ms = shards.size() > 1 ? ((size_t)total_bases + 15) / 16 * 16 + 16 : 0; // one further shard's MS values
+        KBO_REQUIRE(work_bytes >= w.bytes + shard_ms, KBO_E_BAD_ARG,
+                    "d_work is smaller than kbo_work_bytes() (kbo_index_work_bytes() for a sharded index) for this batch");
         KBO_REQUIRE(total_bases / w.chunk + n_seqs < (1ull << 28), KBO_E_UNSUPPORTED, "more than 2^28 work items per launch");
         if (w.chunked) {
             uint32_t *scratch = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(d_work) +
@@ -978,24 +1079,30 @@ int ms_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
         } else {
             HIP_OK(kbo::launch_make_items(d_offsets, (uint32_t)n_seqs, items, s));
         }
-        kbo::WalkArgs a{};
-        a.ix = view;
-        a.q = d_concat;
-        a.q_bytes = total_bases;
-        a.items = items;
-        a.n_items = w.n_slots;
-        a.rounds = 0;
-        a.d_out = d_ms_out;
-        a.lo_out = d_lo_out;
-        a.hi_out = d_hi_out;
-        a.call_sites = call ? static_cast<uint4 *>(call->d_sites) : nullptr;
-        a.call_counts = call ? call->d_counts : nullptr;
-        a.call_cap = call ? call->cap_per_list : 0;
-        a.call_thr = call ? call->threshold : 0;
-        a.max_item_len = w.chunked ? w.chunk + (call ? 2u : 1u) * idx->host.k : (uint32_t)std::min<size_t>(max_seq_len, 0xFFFFFFFFu);
-        attach_plan(a, static_cast<uint8_t *>(d_work) + w.plan_off, plan_state);
-        HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), s));
-        plan_after_launch(a, s, plan_state);
+        uint8_t *ms_shard = static_cast<uint8_t *>(d_work) + w.bytes; // (16-byte aligned: w.bytes is a multiple of 16)
+        for (size_t sh = 0; sh < shards.size(); sh++) {
+            DevCopy::PlanState *plan_state = nullptr;
+            const kbo::DevIndexView view = device_view(shards[sh], current_device(), &plan_state);
+            kbo::WalkArgs a{};
+            a.ix = view;
+            a.q = d_concat;
+            a.q_bytes = total_bases;
+            a.items = items;
+            a.n_items = w.n_slots;
+            a.rounds = 0;
+            a.d_out = sh == 0 ? d_ms_out : ms_shard;
+            a.lo_out = d_lo_out;
+            a.hi_out = d_hi_out;
+            a.call_sites = call ? static_cast<uint4 *>(call->d_sites) : nullptr;
+            a.call_counts = call ? call->d_counts : nullptr;
+            a.call_cap = call ? call->cap_per_list : 0;
+            a.call_thr = call ? call->threshold : 0;
+            a.max_item_len = w.chunked ? w.chunk + (call ? 2u : 1u) * idx->host.k : (uint32_t)std::min<size_t>(max_seq_len, 0xFFFFFFFFu);
+            attach_plan(a, static_cast<uint8_t *>(d_work) + w.plan_off, plan_state);
+            HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), s));
+            plan_after_launch(a, s, plan_state);
+            if (sh > 0) HIP_OK(kbo::launch_max_bytes(d_ms_out, ms_shard, total_bases, s)); // depth against the union = maximum
+        }
     });
 }
 } // namespace
@@ -1152,6 +1259,7 @@ int kbo_index_recovery_lines(const kbo_index_t *idx, uint8_t *lines, size_t *n_b
 {
     return guarded([&] {
         KBO_REQUIRE(idx && n_bytes, KBO_E_BAD_ARG, "null argument");
+        require_unsharded(idx, "kbo_index_recovery_lines");
         const size_t need = (idx->host.n_sets / kbo::kFatRows + 3) * 128;
         if (lines) {
             KBO_REQUIRE(*n_bytes >= need, KBO_E_BAD_ARG, "buffer smaller than the lines");
@@ -1167,6 +1275,7 @@ int kbo_index_path_cover(const kbo_index_t *idx, uint8_t *text, uint32_t *pos, u
 {
     return guarded([&] {
         KBO_REQUIRE(idx && text && pos && node_at, KBO_E_BAD_ARG, "null argument");
+        require_unsharded(idx, "kbo_index_path_cover");
         kbo_index_t *ix = const_cast<kbo_index_t *>(idx); // (fills the handle's cache of its cover, under its mutex)
         std::lock_guard<std::mutex> g(ix->mu);
         if (!ix->cover) {
@@ -1199,6 +1308,21 @@ int kbo_set_plan_unit_cap_divisor(int divisor)
     return KBO_OK;
 }
 
+int kbo_set_index_shards(int shards)
+{
+    g_index_shards = std::max(0, shards);
+    return KBO_OK;
+}
+
+int kbo_index_shards(const kbo_index_t *idx) { return idx ? (idx->sharded() ? (int)idx->shards.size() : 1) : 0; }
+
+const kbo_index_t *kbo_index_shard(const kbo_index_t *idx, int i)
+{
+    if (!idx || i < 0) return nullptr;
+    if (!idx->sharded()) return i == 0 ? idx : nullptr;
+    return (size_t)i < idx->shards.size() ? idx->shards[(size_t)i].get() : nullptr;
+}
+
 int kbo_set_plan_stats(int on)
 {
     g_plan_stats = on != 0;
@@ -1215,6 +1339,7 @@ int kbo_index_plan_holdoff(kbo_index_t *idx, int device, uint32_t *bails, int *h
 {
     return guarded([&] {
         KBO_REQUIRE(idx, KBO_E_BAD_ARG, "null index");
+        require_unsharded(idx, "kbo_index_plan_holdoff");
         const int dev = device < 0 ? current_device() : device;
         std::lock_guard<std::mutex> g(idx->mu);
         auto it = idx->dev.find(dev);
@@ -1224,7 +1349,13 @@ int kbo_index_plan_holdoff(kbo_index_t *idx, int device, uint32_t *bails, int *h
     });
 }
 
-uint64_t kbo_index_device_plan_bytes(const kbo_index_t *idx) { return idx ? idx->plan_bytes : 0; }
+uint64_t kbo_index_device_plan_bytes(const kbo_index_t *idx)
+{
+    if (!idx) return 0;
+    uint64_t b = 0;
+    for (kbo_index *sh : shards_of(const_cast<kbo_index *>(idx))) b += sh->plan_bytes;
+    return b;
+}
 
 int kbo_set_force_big_layout(int on)
 {

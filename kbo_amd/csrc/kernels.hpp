@@ -233,6 +233,10 @@ hipError_t launch_exceptions(const uint64_t *d_pos, const uint8_t *d_byte, uint3
 hipError_t launch_pack2(const uint8_t *d_chars, uint32_t n_words, const uint64_t *d_off, uint32_t n_seqs, uint32_t uniform_wps,
                         const uint32_t *d_scratch, uint32_t *d_packed, hipStream_t stream);
 
+// a[i] = max(a[i], b[i]) over n bytes (n rounded up to 16: both buffers have that slack): the MS values of a further shard of a
+// sharded index folded into the batch's (pack_kernels.hip)
+hipError_t launch_max_bytes(uint8_t *d_a, const uint8_t *d_b, uint64_t n, hipStream_t stream);
+
 constexpr int kWalkThreads = 64; // default workgroup size (waves are independent: no LDS, no barriers)
 void set_walk_threads(int threads); // tuning: 64, 128 or 256
 void set_walk_experiment(int lane_limit, int dummy_lds_bytes); // experiments behind DESIGN.md section 6

@@ -145,7 +145,41 @@ __global__ __launch_bounds__(256) void pack2_kernel(const uint8_t *__restrict__ 
     packed[w] = out;
 }
 
+// per-byte unsigned maximum of two words
+__device__ __forceinline__ uint32_t max4(uint32_t x, uint32_t y)
+{
+    const uint32_t H = 0x80808080u;
+    // bit 7 of every byte of ge: x >= y there (the top bits decide, else the low seven)
+    const uint32_t lo = ((x | H) - (y & ~H)) & H; // low seven bits: x >= y
+    const uint32_t ge = ((x & ~y) | (~(x ^ y) & lo)) & H;
+    const uint32_t mask = (ge >> 7) * 0xFFu;
+    return (x & mask) | (y & ~mask);
+}
+
+// a = max(a, b) byte by byte, 16 bytes per lane
+__global__ __launch_bounds__(256) void max_bytes_kernel(uint4 *__restrict__ a, const uint4 *__restrict__ b, uint64_t n16)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n16) return;
+    uint4 x = a[i];
+    const uint4 y = b[i];
+    x.x = max4(x.x, y.x);
+    x.y = max4(x.y, y.y);
+    x.z = max4(x.z, y.z);
+    x.w = max4(x.w, y.w);
+    a[i] = x;
+}
+
 } // namespace
+
+hipError_t launch_max_bytes(uint8_t *d_a, const uint8_t *d_b, uint64_t n, hipStream_t stream)
+{
+    const uint64_t n16 = (n + 15) / 16;
+    if (n16 == 0) return hipSuccess;
+    hipLaunchKernelGGL(max_bytes_kernel, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<uint4 *>(d_a),
+                       reinterpret_cast<const uint4 *>(d_b), n16);
+    return hipGetLastError();
+}
 
 hipError_t launch_uniform_offsets(uint64_t *d_off, uint32_t n_seqs, uint32_t len, hipStream_t stream)
 {

@@ -194,7 +194,8 @@ void build_impl(const uint8_t *const *seqs, const size_t *lens, size_t n_seqs, c
         }
     }
     std::vector<Key<W>> kmers;
-    kmers.reserve(total * (p.add_revcomp ? 2 : 1));
+    const bool want_fw = !p.revcomp_only, want_rc = p.add_revcomp || p.revcomp_only;
+    kmers.reserve(total * ((want_fw ? 1 : 0) + (want_rc ? 1 : 0)));
     for (size_t s = 0; s < n_seqs; s++) {
         size_t run = 0;
         Key<W> fw = key_zero<W>(), rc = key_zero<W>();
@@ -205,19 +206,25 @@ void build_impl(const uint8_t *const *seqs, const size_t *lens, size_t n_seqs, c
             fw = shr2(fw);                  // older chars move away from the end
             set_digit(fw, 0, (uint64_t)c);
             for (int j = 0; j < W; j++) fw.w[j] &= mask2k.w[j];
-            if (p.add_revcomp) {            // revcomp k-mer ends with comp(first char)
+            if (want_rc) {                  // revcomp k-mer ends with comp(first char)
                 rc = shl_bits(rc, 2);
                 set_digit(rc, k - 1, (uint64_t)(3 - c));
             }
             if (run >= k) {
-                kmers.push_back(fw);
-                if (p.add_revcomp) kmers.push_back(rc);
+                if (want_fw) kmers.push_back(fw);
+                if (want_rc) kmers.push_back(rc);
             }
         }
     }
     sort_keys(kmers, nt);
     kmers.erase(std::unique(kmers.begin(), kmers.end()), kmers.end());
     const size_t N = kmers.size();
+    if (p.keys_out) { // (sharded build: the caller merges the shards' sorted k-mers to count those of the union)
+        p.keys_out->resize(N * W);
+        for (size_t i = 0; i < N; i++)
+            for (int j = 0; j < W; j++) (*p.keys_out)[i * W + j] = kmers[i].w[j];
+        if (p.key_words_out) *p.key_words_out = W;
+    }
 
     // ---- 2. k-mers without a predecessor -> dummy rows.
     // x has a predecessor iff some y has y[1:] == x[:-1].  In key space

@@ -24,6 +24,12 @@ struct BuildParams {
     uint32_t k = 31;
     bool add_revcomp = false;
     uint32_t num_threads = 1;
+    // sharded indexes (kbo_capi.cpp: an index too large for 32-bit row numbers is built as several, MS = the maximum over
+    // them): only the reverse-complement strand of the input; the sorted distinct k-mers as 64-bit words, key_words per
+    // k-mer (colex keys: equal k-mers have equal keys in every shard), for counting the k-mers of the union
+    bool revcomp_only = false;
+    std::vector<uint64_t> *keys_out = nullptr;
+    uint32_t *key_words_out = nullptr;
 };
 
 // Sort-based construction (colex-sorted padded k-mer rows).  Throws std::runtime_error.

@@ -18,12 +18,13 @@ def _u8(x):
 class SbwtIndexVariant:
     """Stand-in for sbwt::SbwtIndexVariant::SubsetMatrix (+ its LcsArray): owns a kbo_index_t."""
 
-    def __init__(self, handle):
+    def __init__(self, handle, owner=None):
         self._h = handle
+        self._owner = owner  # (a borrowed handle - a shard - keeps its owner alive and is never freed)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and getattr(self, "_owner", None) is None:
             try:
                 lib().kbo_index_free(h)
             except Exception:  # interpreter shutdown: module globals are already gone
@@ -34,6 +35,17 @@ class SbwtIndexVariant:
 
     def n_kmers(self):
         return int(lib().kbo_index_n_kmers(self._h))
+
+    def shards(self):
+        """1 for an ordinary index; the number of shards of an index whose rows would not fit 32-bit row numbers (kbo_hip.h)"""
+        return int(lib().kbo_index_shards(self._h))
+
+    def shard(self, i):
+        """shard i as an (ordinary, borrowed) index: kbo_hip_tuning.h kbo_index_shard"""
+        h = lib().kbo_index_shard(self._h, i)
+        if not h:
+            raise IndexError(i)
+        return SbwtIndexVariant(C.c_void_p(h), owner=self)
 
     def n_sets(self):
         return int(lib().kbo_index_n_sets(self._h))

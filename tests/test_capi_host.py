@@ -329,3 +329,47 @@ def test_pack_reads_and_unpack_matches_round_trip():
             ow[w + i // 16] |= np.uint32(code[int(chars[int(offsets[s]) + i])] << (2 * (i % 16)))
         w += (n + 15) // 16
     assert np.array_equal(batch.unpack_matches(ow, offsets), chars)
+
+
+@pytest.mark.parametrize("revcomp", [False, True])
+def test_sharded_index_counts_the_union(oracle, revcomp):
+    """An index whose rows would not fit 32-bit row numbers is built as shards (groups of sequences, strands apart); forced
+    here on a small input.  n_kmers - what the derandomisation threshold needs - must be the number of distinct k-mers of
+    the union, i.e. what the one index over everything has; what needs rows of that one index is refused."""
+    from kbo_amd import index as kindex
+    rng = np.random.default_rng(17)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = [acgt[rng.integers(0, 4, int(n))].tobytes() for n in rng.integers(200, 3000, 9)]
+    seqs[3] = seqs[0][100:900] + b"N" + seqs[5][:500]     # shared k-mers across groups
+    seqs[7] = bytes(acgt[3 - np.searchsorted(acgt, np.frombuffer(seqs[1], dtype=np.uint8))][::-1])  # the reverse complement of another
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    probe = (seqs[2][50:400] + seqs[6][::-1].translate(comp)[:300] + b"N" + seqs[3][780:830] + seqs[8][-200:]
+             + bytes(acgt[rng.integers(0, 4, 300)]))
+    L = kbo_amd.lib()
+    for k in (5, 31):
+        ora = oracle.Index.build(seqs, k=k, add_revcomp=revcomp)
+        for shards in (2, 3, 7):
+            try:
+                L.kbo_set_index_shards(shards)
+                sbwt, _ = kbo_amd.build(seqs, kbo_amd.BuildOpts(k=k, add_revcomp=revcomp, num_threads=2))
+            finally:
+                L.kbo_set_index_shards(0)
+            assert sbwt.shards() >= min(shards, len(seqs))
+            assert sbwt.k() == k and sbwt.n_kmers() == ora.n_kmers, (k, shards, revcomp)
+            # the shards are ordinary indexes over disjoint parts of the input (rows add up), and the depth of the walk
+            # against the index of everything is the maximum of the depths against them - the oracle on both sides
+            parts = [sbwt.shard(i) for i in range(sbwt.shards())]
+            assert sum(p.n_sets() for p in parts) == sbwt.n_sets() and all(p.shards() == 1 for p in parts)
+            with pytest.raises(IndexError):
+                sbwt.shard(sbwt.shards())
+            d_parts = []
+            for p in parts:
+                rows, Carr, lcs = p.export_parts()
+                d_parts.append(oracle.Index.from_parts(k, p.n_sets(), p.n_kmers(), rows, Carr, lcs).matching_statistics(probe)[0])
+            assert np.array_equal(np.max(d_parts, axis=0), ora.matching_statistics(probe)[0]), (k, shards, revcomp)
+            for refused in (sbwt.export_parts, sbwt.path_cover, lambda: kindex.save_flat("/tmp/never_written.kbohip", sbwt)):
+                with pytest.raises(kbo_amd.KboError) as e:
+                    refused()
+                assert e.value.code == -8  # KBO_E_UNSUPPORTED
+    one, _ = kbo_amd.build(seqs, kbo_amd.BuildOpts(k=31))
+    assert one.shards() == 1

@@ -869,3 +869,79 @@ def test_packed_batches_equal_the_byte_entry_points(oracle):
     with pytest.raises(kbo_amd.KboError) as e:
         batch.matches_batch_packed(sbwt, words, o2, np.array([5, 5], dtype=np.uint64), np.array([78, 78], dtype=np.uint8))
     assert e.value.code == -4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("revcomp", [False, True])
+def test_sharded_index_equals_the_index_of_everything(oracle, revcomp):
+    """n_sets >= 2^32 (a human genome with its reverse complements) is served by SHARDS - ordinary indexes over groups of
+    sequences, strands apart - whose depths are folded by maximum (kbo_hip.h "Sharded indexes"); forced here on a small
+    multi-contig input.  Every depth-only entry point must give what the ONE index over everything gives (the oracle builds
+    that one, with add_revcomp): MS, matches, map with formatting, find, the packed and the device-resident entry points;
+    reads of both strands, with substitutions, N's and junk.  What needs rows of the one index is refused."""
+    import torch
+    rng = np.random.default_rng(71 + int(revcomp))
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGTN", b"TGCAN"):
+        comp[a] = b
+    g = synth.genome(240_000, seed=91)
+    contigs = [g[i * 20_000:(i + 1) * 20_000].copy() for i in range(12)]
+    contigs[4][5000:5003] = ord("N")
+    contigs[9][:3000] = contigs[2][1000:4000]                      # a stretch shared by two groups
+    contigs[11] = comp[contigs[6][2000:9000]][::-1].copy()          # the reverse complement of part of another contig
+    seqs = [c.tobytes() for c in contigs]
+    cat = np.concatenate(contigs)
+    k = 31
+    ora = oracle.Index.build(seqs, k=k, add_revcomp=revcomp)
+    reads = []
+    for r in range(6000):
+        n = int(rng.choice([40, 150, 151, 300]))
+        a = int(rng.integers(0, len(cat) - n))
+        p = cat[a:a + n].copy()
+        hit = rng.random(n) < [0.0, 0.01, 0.03][r % 3]
+        p[hit] = acgt[rng.integers(0, 4, int(hit.sum()))]
+        if r % 2:
+            p = comp[p][::-1].copy()                                 # the other strand
+        if r % 17 == 0:
+            p[int(rng.integers(0, n))] = ord("N")
+        reads.append(p)
+    concat = np.concatenate(reads)
+    offsets = np.concatenate([[0], np.cumsum([len(p) for p in reads])]).astype(np.uint64)
+    exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
+    exp_map = np.frombuffer(oracle.relative_to_ref(concat, exp_chars), dtype=np.uint8)
+    L = kbo_amd.lib()
+    for shards in (2, 5):
+        try:
+            L.kbo_set_index_shards(shards)
+            sbwt, lcs = kbo_amd.build(seqs, kbo_amd.BuildOpts(k=k, add_revcomp=revcomp, num_threads=4))
+        finally:
+            L.kbo_set_index_shards(0)
+        assert sbwt.shards() >= shards and sbwt.n_kmers() == ora.n_kmers
+        for plan in (1, 0):
+            L.kbo_set_plan(plan, 0, 0)
+            d, _, _ = batch.ms_batch(sbwt, concat, offsets)
+            assert np.array_equal(d, exp_d), (shards, plan)
+        L.kbo_set_plan(1, 0, 0)
+        assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars)
+        assert np.array_equal(batch.map_batch(sbwt, concat, offsets, format=True), exp_map)
+        rles, ro = batch.find_batch(sbwt, concat, offsets, kbo_amd.FindOpts(max_gap_len=2))
+        er, eo = oracle.run_lengths_batch(exp_chars, offsets, 2)
+        assert np.array_equal(np.asarray(ro, dtype=np.uint64), eo) and np.array_equal(np.asarray(rles, dtype=np.uint64).reshape(-1, 7), er)
+        words, epos, ebyt = batch.pack_reads(concat, offsets)
+        assert np.array_equal(batch.unpack_matches(batch.matches_batch_packed(sbwt, words, offsets, epos, ebyt), offsets), exp_chars)
+        dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"))
+        dev.ms.fill_(0xEE)
+        dev.run()
+        torch.cuda.synchronize()
+        assert np.array_equal(dev.ms[:dev.total].cpu().numpy(), exp_d) and np.array_equal(dev.chars[:dev.total].cpu().numpy(), exp_chars)
+        # single-sequence entry points: depths yes, intervals / call / full map no
+        q = reads[3].tobytes()
+        assert "".join(kbo_amd.matches(q, sbwt, lcs)) == exp_chars[int(offsets[3]):int(offsets[4])].tobytes().decode()
+        for refused in (lambda: batch.ms_batch(sbwt, concat[:300], np.array([0, 300], dtype=np.uint64), want_intervals=True),
+                        lambda: batch.call_batch(sbwt, concat[:3000], np.array([0, 3000], dtype=np.uint64),
+                                                 kbo_amd.CallOpts(sbwt_build_opts=kbo_amd.BuildOpts(k=k, build_select=True))),
+                        lambda: kbo_amd.map(q, sbwt, lcs, kbo_amd.MapOpts())):
+            with pytest.raises(kbo_amd.KboError) as e:
+                refused()
+            assert e.value.code == -8  # KBO_E_UNSUPPORTED
