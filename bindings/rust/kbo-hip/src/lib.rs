@@ -37,6 +37,7 @@ pub mod ffi {
         pub fn kbo_index_from_parts(k: u32, n_sets: u64, n_kmers: u64, rows: *const *const u64, c: *const u64, lcs: *const u8,
                                     out: *mut *mut KboIndex) -> c_int;
         pub fn kbo_index_free(idx: *mut KboIndex);
+        pub fn kbo_index_shards(idx: *const KboIndex) -> c_int;
         pub fn kbo_index_save(idx: *const KboIndex, path: *const c_char) -> c_int;   // .kbohip: index + path cover
         pub fn kbo_index_load(path: *const c_char, out: *mut *mut KboIndex) -> c_int;
         // index::query_sbwt (index.rs:243-256), kbo::matches / map / find / call (lib.rs:612-628, 720-761, 808-821, 547-573)
@@ -132,6 +133,9 @@ impl GpuIndex {
         check(unsafe { ffi::kbo_index_build(ptrs.as_ptr(), lens.as_ptr(), seqs.len(), &o, &mut h) });
         GpuIndex(h)
     }
+    /// 1 for an ordinary index; more when the input had 3.76e9 rows or more (a human genome with `add_revcomp`) and was built as
+    /// shards: `matches` / `find` / `map` without refinement give the one index's results, `call` / gap filling / save are refused.
+    pub fn shards(&self) -> usize { unsafe { ffi::kbo_index_shards(self.0) as usize } }
     /// An index the sbwt crate already built (what `kbo::build` returns, what kbo-cli loads from `.sbwt` / `.lcs`).
     pub fn from_sbwt(index: &sbwt::SbwtIndexVariant) -> Self {
         let sbwt::SbwtIndexVariant::SubsetMatrix(ref sbwt) = index;
