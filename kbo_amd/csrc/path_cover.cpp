@@ -10,13 +10,17 @@
 //     text[p]     label of the edge node_at[p-1] -> node_at[p] ('A','C','G','T'), 0 where a path starts
 // so "text[p+1] == c" proves that extending the single-row interval {node_at[p]} by c gives {node_at[p+1]}.
 // Built from the subset matrix and the LCS array alone (indexes adopted through kbo_index_from_parts have no
-// text): one streaming pass matches the rows of every (k-1)-suffix group with the group's successors, one
-// pass over the resulting chains numbers them.
+// text): one streaming pass matches the rows of every (k-1)-suffix group with the group's successors, two
+// parallel passes over the resulting chains (cut into segments) number them.
 #include "sbwt_index.hpp"
 
 #include <cstring>
 
+#include <algorithm>
+#include <atomic>
+#include <functional>
 #include <stdexcept>
+#include <thread>
 
 namespace kbo {
 
@@ -63,7 +67,69 @@ void make_path_cover(const HostIndex &h, PathCover &out)
             if (row >= h.C[c]) return (uint8_t)"ACGT"[c];
         return 0; // the root
     };
+    // The chains are followed pointer by pointer - a DRAM miss a row, and a genome without repeats is ONE chain - so they are
+    // cut into segments at "splitters" (the heads, and every row that is a multiple of kSplit: a row is as good as random
+    // along a chain), the segments are measured in parallel, one short sequential pass over the splitters hands every
+    // segment of a head's chain its position - heads in row order, each chain to its end, exactly the layout one thread
+    // following the chains would make - and the segments are laid in parallel.
+    constexpr uint32_t kSplit = 1024;
+    auto is_split = [&](uint32_t u) { return (u & (kSplit - 1)) == 0; }; // (for a row that has a predecessor)
+    std::vector<uint32_t> splitters;
+    for (uint64_t i = 0; i < n; i++)
+        if (!has_pred[i] || is_split((uint32_t)i)) splitters.push_back((uint32_t)i);
+    const size_t ns = splitters.size();
+    std::vector<uint32_t> seg_len(ns), seg_next(ns);
+    std::vector<uint64_t> seg_start(ns, ~0ull);
+    auto index_of = [&](uint32_t row) { return (size_t)(std::lower_bound(splitters.begin(), splitters.end(), row) - splitters.begin()); };
+    auto in_parallel = [&](size_t n_tasks, const std::function<void(size_t)> &fn) {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)hw, n_tasks / 64 + 1}));
+        std::atomic<size_t> nxt{0};
+        auto work = [&] {
+            for (;;) {
+                const size_t a = nxt.fetch_add(16);
+                if (a >= n_tasks) return;
+                for (size_t i = a; i < std::min(n_tasks, a + 16); i++) fn(i);
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+    };
+    in_parallel(ns, [&](size_t s) { // length of the segment that starts at splitter s, and the splitter it runs into
+        uint32_t len = 1, u = next[splitters[s]];
+        while (u != NONE && !is_split(u)) {
+            len++;
+            u = next[u];
+        }
+        seg_len[s] = len;
+        seg_next[s] = u;
+    });
     uint64_t p = 0;
+    for (size_t s = 0; s < ns; s++) {
+        if (has_pred[splitters[s]]) continue; // heads, in row order
+        size_t at = s;
+        for (;;) {
+            seg_start[at] = p;
+            p += seg_len[at];
+            if (seg_next[at] == NONE) break;
+            at = index_of(seg_next[at]);
+        }
+    }
+    in_parallel(ns, [&](size_t s) {
+        uint64_t q = seg_start[s];
+        if (q == ~0ull) return; // (a splitter on a cycle: below)
+        uint32_t u = splitters[s];
+        for (uint32_t j = 0; j < seg_len[s]; j++) {
+            out.pos[u] = (uint32_t)q;
+            out.node_at[q] = u;
+            text[q] = has_pred[u] ? label(u) : 0;
+            q++;
+            u = next[u];
+        }
+    });
+    // whatever is left lies on cycles: each is broken where the row order meets it (few rows, if any: one thread)
     auto lay = [&](uint32_t u) {
         bool start = true;
         while (u != NONE && out.pos[u] == NONE) {
@@ -75,8 +141,6 @@ void make_path_cover(const HostIndex &h, PathCover &out)
             u = next[u];
         }
     };
-    for (uint64_t i = 0; i < n; i++)
-        if (!has_pred[i]) lay((uint32_t)i);
     for (uint64_t i = 0; i < n; i++)
         if (out.pos[i] == NONE) lay((uint32_t)i);
     if (p != n) throw std::runtime_error("path cover: rows left without a position");
