@@ -63,6 +63,8 @@ def parse(argv=None):
                     help="time the first pass of kbo call (C5 shape, scaled): MS walk with intervals + the breakpoint scan "
                          "on the device over 10 kbp reads (defaults: --genome 100000000 --reads 10000 --read-len 10000)")
     ap.add_argument("--no-plan", action="store_true", help="plain walk kernel only (no path cover, no plan-guided walk)")
+    ap.add_argument("--depth-table", type=int, default=0,
+                    help="order of the depth table (kbo_set_depth_table): 0 = by index size, -1 = none (units + guided walk)")
     ap.add_argument("--index-cache", default=None, help="index file (.kbohip, with its path cover) to load instead of building; "
                     "written first if it does not exist")
     args = ap.parse_args(argv)
@@ -235,44 +237,63 @@ def stage_model_leg(args, sbwt, oi, concat, offsets, gpu_d, n_sample=2_000_000):
     cores, _ = usable_cores()
     n = min(len(offsets) - 1, n_sample)
     L = args.read_len
-    P = ora.shipped_plan_params(args.k, sbwt.n_sets())
+    order = sbwt.depth_table_order()
+    P = ora.shipped_plan_params(args.k, sbwt.n_sets(), depth_table=order)
     ms, cn = oi.plan_model(sbwt.path_cover(), P, concat[:n * L], offsets[:n + 1], n_threads=cores)
     same = bool(np.array_equal(ms, gpu_d[:n * L]))
     iters = cn["walk_accepted"] + cn["walk_failed"] + cn["walk_contractions"]
     by = {
         # plan_kernel's streams: the queries, the text of their diagonals, the predicted MS values
         "streams": cn["bases"] + 2 * cn["compare_bases"],
-        # item records: WalkItem read, GuidedItem written and read by count + emit, redo flag, unit counts through the scan,
-        # mismatch lists written once and read twice
-        "item_records": cn["items"] * (16 + 16 + 32 + 1 + 8 + 16) + 6 * max(0, cn["mismatches"] - cn["items"] + cn["items_unseeded"]),
         "seeds": 8 * cn["seed_lookups"] + 32 * cn["seed_extensions"] + 4 * cn["pos_lookups"],
-        # a unit: record written and read, start row, two query blocks, its output bytes
-        "unit_records": cn["units"] * (32 + 32 + 32) + 4 * cn["node_lookups"] + cn["walk_out_bytes"],
-        # the walk: two 16-byte loads per iteration (rank blocks or entries); over recovery lines two rank blocks + two LCS
-        # windows per iteration, two entries per level taken from the entries
-        "walk": (64 * cn["walk_iterations_lines"] + 32 * cn["walk_entry_levels"]) if P.recovery_lines else 32 * iters,
         "redo": 16 * cn["items_flagged"] + 32 * cn["redo_iterations"] + 2 * cn["redo_bases"],
     }
+    if order:
+        # item records: WalkItem read, GuidedItem written and read by the resolve kernel, redo flag written and read,
+        # mismatch lists written once and read once
+        by["item_records"] = cn["items"] * (16 + 16 + 16 + 2) + 4 * max(0, cn["mismatches"] - cn["items"] + cn["items_unseeded"])
+        # the table: one byte per look-up; the bases in front of and behind a mismatch that its look-ups are keyed by
+        # (order + 1 lanes, 32 bases each, overlapping: order + 32 bytes); the values written
+        by["table"] = cn["tab_lookups"] + (order + 32) * cn["mismatches"] + cn["tab_written"]
+    else:
+        # item records: WalkItem read, GuidedItem written and read by count + emit, redo flag, unit counts through the scan,
+        # mismatch lists written once and read twice
+        by["item_records"] = cn["items"] * (16 + 16 + 32 + 1 + 8 + 16) + 6 * max(0, cn["mismatches"] - cn["items"] + cn["items_unseeded"])
+        # a unit: record written and read, start row, two query blocks, its output bytes
+        by["unit_records"] = cn["units"] * (32 + 32 + 32) + 4 * cn["node_lookups"] + cn["walk_out_bytes"]
+        # the walk: two 16-byte loads per iteration (rank blocks or entries); over recovery lines two rank blocks + two LCS
+        # windows per iteration, two entries per level taken from the entries
+        by["walk"] = (64 * cn["walk_iterations_lines"] + 32 * cn["walk_entry_levels"]) if P.recovery_lines else 32 * iters
     total = float(sum(by.values()))
     per_base = {k: round(v / cn["bases"], 4) for k, v in by.items()}
     units = max(1, cn["units"])
     summary = {
-        "sample_reads": n, "ms_equal_to_gpu": same, "gave_up": bool(cn["gave_up"]), "form": "recovery lines" if P.recovery_lines else "rank blocks + entries",
+        "sample_reads": n, "ms_equal_to_gpu": same, "gave_up": bool(cn["gave_up"]),
+        "form": (f"depth table of {order} bases" if order else "recovery lines" if P.recovery_lines else "rank blocks + entries"),
         "parameters": {"seed_table_depth": P.seed_table_depth, "seed_depth": P.seed_depth, "gap": P.gap, "chunk": P.chunk,
-                       "list_cap": P.list_cap, "bail_x16": P.bail_x16},
-        "units_per_read": round(cn["units"] / cn["items"], 4), "unseeded_reads": cn["items_unseeded"], "flagged_reads": cn["items_flagged"],
+                       "list_cap": P.list_cap, "bail_x16": P.bail_x16, "depth_table": order},
+        "unseeded_reads": cn["items_unseeded"], "flagged_reads": cn["items_flagged"],
         "seed_extensions_per_read": round(cn["seed_extensions"] / cn["items"], 3),
-        "per_unit": {"accepted": round(cn["walk_accepted"] / units, 3), "failed": round(cn["walk_failed"] / units, 3),
-                     "contraction_levels": round(cn["walk_contractions"] / units, 3),
-                     "entry_levels": round(cn["walk_entry_levels"] / units, 3),
-                     "iterations": round((cn["walk_iterations_lines"] if P.recovery_lines else iters) / units, 3),
-                     # 128-byte lines one unit touches (record, start row, query, output, index); "beyond_l2" leaves out the
-                     # rank blocks when all of them fit one XCD's 4 MiB L2 (C2: 3.3 MB - they stay resident, shared by all units)
-                     "distinct_lines": round(cn["unit_distinct_lines"] / units, 3),
-                     "distinct_lines_beyond_l2": round((cn["unit_distinct_lines"] - (cn["unit_distinct_rank_lines"]
-                                                        if sbwt.device_bytes()[0] < (4 << 20) else 0)) / units, 3)},
+        "mismatches_per_read": round(cn["mismatches"] / cn["items"], 4),
         "bytes_per_base": per_base,
     }
+    if order:
+        mm = max(1, cn["mismatches"])
+        summary["per_mismatch"] = {"table_lookups": round(cn["tab_lookups"] / mm, 3), "values_written": round(cn["tab_written"] / mm, 3)}
+        # every look-up is a fill of its own (a table far beyond L2, random keys); what else cannot stay in L2: per read the item
+        # record (read twice), per mismatch the query window and the output bytes
+        summary["fills_min_per_read"] = round((cn["tab_lookups"] + 2 * cn["mismatches"]) / cn["items"] + 0.25, 3)
+    else:
+        summary["units_per_read"] = round(cn["units"] / cn["items"], 4)
+        summary["per_unit"] = {"accepted": round(cn["walk_accepted"] / units, 3), "failed": round(cn["walk_failed"] / units, 3),
+                               "contraction_levels": round(cn["walk_contractions"] / units, 3),
+                               "entry_levels": round(cn["walk_entry_levels"] / units, 3),
+                               "iterations": round((cn["walk_iterations_lines"] if P.recovery_lines else iters) / units, 3),
+                               # 128-byte lines one unit touches (record, start row, query, output, index); "beyond_l2" leaves out the
+                               # rank blocks when all of them fit one XCD's 4 MiB L2 (C2: 3.3 MB - they stay resident, shared by all units)
+                               "distinct_lines": round(cn["unit_distinct_lines"] / units, 3),
+                               "distinct_lines_beyond_l2": round((cn["unit_distinct_lines"] - (cn["unit_distinct_rank_lines"]
+                                                                  if sbwt.device_bytes()[0] < (4 << 20) else 0)) / units, 3)}
     return total / cn["bases"], summary, cn
 
 
@@ -518,6 +539,8 @@ def main(argv=None):
         L.kbo_set_walk_waves_per_cu(args.waves_per_cu)
     if args.no_plan:
         L.kbo_set_plan(0, 0, 0)
+    if args.depth_table:
+        L.kbo_set_depth_table(args.depth_table)
 
     # ---- index: replicated.  Rank 0 builds it once (or finds the cache a parent / an earlier run left) and writes the
     # cache, path cover included; the other ranks load it
@@ -628,7 +651,7 @@ def main(argv=None):
                 h2h = host_to_host_leg(args, sbwt, genome)
         # fabric-side traffic and L2 misses of the A1 stage, from the committed rocprofv3 passes of this exact
         # workload and walk mode (PMC passes cannot run inside the timed region: separate runs, tools/profile_bench.sh)
-        wl_key = f"{args.genome}x{n_mine}x{args.read_len}x{args.sub_rate:g}:{'plan' if planned else 'plain'}"
+        wl_key = f"{args.genome}x{n_mine}x{args.read_len}x{args.sub_rate:g}:{('table' if sbwt.depth_table_order() > 0 else 'plan') if planned else 'plain'}"
         traffic = tsrc = misses = walk_misses = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
@@ -637,7 +660,7 @@ def main(argv=None):
                 if entry:
                     traffic, misses, tsrc = entry.get("a1_bytes_per_launch"), entry.get("a1_tcc_miss_per_launch"), entry.get("source")
                     kern = entry.get("kernels", {})
-                    walk_misses = (kern.get("ms_walk_guided_kernel") or kern.get("ms_walk_recovery_kernel") or {}).get("tcc_miss")
+                    walk_misses = (kern.get("dtab_resolve_kernel") or kern.get("ms_walk_guided_kernel") or kern.get("ms_walk_recovery_kernel") or {}).get("tcc_miss")
             except Exception:
                 pass
         rank_b, lcs_b = sbwt.device_bytes()
@@ -646,7 +669,9 @@ def main(argv=None):
         label = (args.config if std else "custom") + ": " + \
             ("kbo find (max_gap_len=0; run lengths on the device)" if args.find else
              "kbo map (fill_gaps=false, call_variants=false, format=true)")
-        a1_kernels = ("plan_kernel + plan_count/scan/emit + ms_walk_guided_kernel (ms_walk_recovery_kernel from 24 Mi rows on) + redo_collect + ms_walk_kernel (flagged reads)"
+        table = planned and sbwt.depth_table_order() > 0
+        a1_kernels = ("plan_kernel + dtab_resolve_kernel (depth table) + redo_collect + ms_walk_kernel (reads the table could not resolve)" if table
+                      else "plan_kernel + plan_count/scan/emit + ms_walk_guided_kernel (ms_walk_recovery_kernel from 24 Mi rows on) + redo_collect + ms_walk_kernel (flagged reads)"
                       if planned else "ms_walk_kernel")
         walk_s = walk_ms * 1e-3
         # what the stage is priced by: its OWN compulsory bytes (B_plan, counted by the model on the timed reads) when it
@@ -656,12 +681,15 @@ def main(argv=None):
         ref_achieved = b_ref * bases / walk_s / 1e9 if b_ref is not None else None
         roofline = {
             "bound": "hbm",
-            "bound_detail": ("L2-miss line fills by their rate and latency: integer gather work, 16 bytes used per 128-byte fill; the guided walk "
+            "bound_detail": ("independent random byte gathers from the depth table (one fill each) + plan_kernel's streams and compare loop "
+                             "(DESIGN.md section 4.2)" if table else
+                             "L2-miss line fills by their rate and latency: integer gather work, 16 bytes used per 128-byte fill; the guided walk "
                              "keeps 8-12 waves per CU so that the lines of the lanes in flight stay in L2 (DESIGN.md sections 4.2, 6)"),
             "achieved": round(achieved, 1) if achieved is not None else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved is not None else None,
-            "frac_meaning": ("compulsory bytes of the plan-guided stage (B_plan: streams, records, two 16-byte loads per walk iteration; counted on "
-                             "the timed reads by oracle/plan_model.c, whose counts equal the kernels' own counters) / A1 stage time / 8 TB/s"
+            "frac_meaning": ("compulsory bytes of the plan-guided stage (B_plan: streams, records, " +
+                             ("one table byte per look-up and the query window of every mismatch" if table else "two 16-byte loads per walk iteration") +
+                             "; counted on the timed reads by oracle/plan_model.c, whose counts equal the kernels' own counters) / A1 stage time / 8 TB/s"
                              if b_plan is not None else "reference-algorithm bytes (SURVEY.md 8(d)) / A1 stage time / 8 TB/s"),
             "algorithmic_bytes_per_base": round(b_alg, 3) if b_alg is not None else None,
             "units_per_launch": bases, "kernel": "A1 stage = " + a1_kernels, "kernel_ms": round(walk_ms, 4),
@@ -672,11 +700,14 @@ def main(argv=None):
             "l2_miss_per_launch": int(misses) if misses else None,
             "fill_rate_frac": round(misses / walk_s / FILL_CEILING_PER_S, 4) if misses else None,
             "fill_rate_ceiling": {"fills_per_s": FILL_CEILING_PER_S, "source": FILL_CEILING_SOURCE},
-            "fills_min_per_unit": model["per_unit"]["distinct_lines_beyond_l2"] if model else None,
+            "fills_min_per_unit": model["per_unit"]["distinct_lines_beyond_l2"] if model and "per_unit" in model else None,
+            "fills_min_per_read": model.get("fills_min_per_read") if model else None,
+            "l2_miss_per_read": round(misses / (bases / args.read_len), 2) if misses else None,
             # measured L2 misses per unit: of the whole stage, and of the walk kernel alone (to set against fills_min_per_unit:
             # the difference is the rank-block look-ups that miss although the blocks would fit the L2)
-            "l2_miss_per_unit": round(misses / max(1, stats["units"] * bases / dev.total), 2) if misses and planned else None,
-            "walk_kernel_l2_miss_per_unit": round(walk_misses / max(1, stats["units"] * bases / dev.total), 2) if walk_misses and planned else None,
+            "l2_miss_per_unit": round(misses / max(1, stats["units"] * bases / dev.total), 2) if misses and planned and not table else None,
+            "walk_kernel_l2_miss_per_unit": round(walk_misses / max(1, stats["units"] * bases / dev.total), 2) if walk_misses and planned and not table else None,
+            "resolve_kernel_l2_miss_per_lookup": round(walk_misses / max(1, stats["tab_lookups"] * bases / dev.total), 3) if walk_misses and table else None,
             "frac_reference_algorithm": round(ref_achieved / HBM_PEAK_GBPS, 4) if ref_achieved is not None else None,
             "reference_algorithm_bytes_per_base": round(b_ref, 2) if b_ref is not None else None,
             "cross_check_whole_step_gbps": round(b_alg * bases / (elapsed / args.steps) / 1e9, 1) if b_alg is not None else None,
@@ -696,7 +727,8 @@ def main(argv=None):
                                       else f"{args.reads} x {args.read_len} bp reads per GPU, ")
                                    + f"{args.sub_rate * 100:g}% substitutions",
                        "index_n_sets": sbwt.n_sets(), "threshold": dev.threshold,
-                       "walk": "plan-guided (path cover + guided walk)" if planned else "plain",
+                       "walk": ("plan-guided (path cover + depth table of %d bases)" % sbwt.depth_table_order() if table else
+                                "plan-guided (path cover + guided walk)" if planned else "plain"),
                        "index_device_bytes": {"rank_blocks": rank_b, "lcs": lcs_b, "two_base_blocks": pair_b,
                                               "path_cover_lines_seed_table": plan_b,
                                               "per_row": round((rank_b + lcs_b + pair_b + plan_b) / sbwt.n_sets(), 2)},

@@ -41,6 +41,23 @@ int kbo_set_index_shards(int shards);
 /* tests: shard i of a sharded index - an ordinary index over its part of the input (n_kmers = its own), BORROWED: it lives as
  * long as `idx` and must not be freed.  An ordinary index is its own shard 0.  NULL when i is out of range. */
 const kbo_index_t *kbo_index_shard(const kbo_index_t *idx, int i);
+/* The depth table of device copies made after the call (kbo_amd/csrc/dtab_kernels.hip): for every string of `order` bases the
+ * longest suffix of it that is a suffix of a row of the index, 4^order bytes of device memory.  With it, the stretches behind
+ * a read's mismatches against the plan's diagonal - where the matching statistic is the length of a random match, about
+ * log4(rows) - cost one independent byte look-up per base instead of a chain of dependent rank look-ups; values deeper than
+ * `order` send their read to the plain walk.  0 = by index size (log4(rows) + 3.2 rounded up, at most 17 and k; none from
+ * about 300 M rows on, or when it would take more than half of the free device memory), 1 .. 17 = that order (capped at k),
+ * < 0 = none: new copies get no table and launches over copies that have one do not use it (until the knob is >= 0 again).
+ * Results are identical with and without it. */
+int kbo_set_depth_table(int order);
+/* inspection / tests: the depth table of the copy of `idx` on `device` (-1 = current; the copy is made if there is none):
+ * *order bases per entry (0: the copy has no table), 4^*order bytes; entry of a string (2-bit digits A, C, G, T = 0 .. 3, the
+ * last base least significant) = length of its longest suffix that is a suffix of a row of the index, or 0x80 | e when the
+ * whole string is, bit c of e set when the string with base c in front of it is one too.  On the device the entries of
+ * three consecutive bases of a read share a 64-byte line, so every entry is there three times; `view` (0 .. 2) says which
+ * copy to hand back, in key order (ignored for tables too small to be grouped).  table == NULL only asks for *n_bytes and
+ * *order. */
+int kbo_index_depth_table(kbo_index_t *idx, int device, int view, uint8_t *table, size_t *n_bytes, int *order);
 /* tests: depth of the seed table of device copies made after the call (0 = by index size: 8 / 10 / 12 / 13 bases;
  * 1 .. 13 = that many, capped at k).  Large tables are what large indexes get: 12 bases = 128 MiB, 13 = 512 MiB. */
 int kbo_set_seed_table_depth(int bases);
@@ -75,9 +92,11 @@ int kbo_set_plan_stats(int on);
  * (tests/test_gpu_model.py).  Arguments as for the kbo_ms_batch_dev call that ran on d_work; synchronises `stream`.
  * out[0..7]: units walked, accepted extensions, failed extensions, contraction levels, levels taken from the entries
  * (recovery-line form), seed-table look-ups, seed extensions, mismatches against the diagonals;  out[8]: units emitted,
- * [9]: entries of the redo list, [10]: 1 = the plan was given up, [11]: 1 = a walk left through its guard.  Meaningless
+ * [9]: entries of the redo list, [10]: 1 = the plan was given up, [11]: 1 = a walk left through its guard;  depth-table form
+ * (kbo_set_depth_table) out[12]: table look-ups, [13]: values written from the table, [14] = [15]: items the table could not
+ * resolve (counted by the lanes / by the launch's control word; out[8] is meaningless in that form).  Meaningless
  * (stale or zero) when that launch did not plan (plain walk, hold-off, intervals requested) or did not count. */
-#define KBO_PLAN_STATS 12
+#define KBO_PLAN_STATS 16
 int kbo_plan_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k, const void *d_work,
                        uint64_t out[KBO_PLAN_STATS], void *stream);
 

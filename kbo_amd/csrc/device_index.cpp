@@ -2,6 +2,8 @@
 // two-base blocks) and the knobs that shape them.
 #include "capi_internal.hpp"
 
+#include <cmath>
+
 #include <atomic>
 #include <cstdlib>
 
@@ -14,6 +16,7 @@ std::atomic<uint64_t> g_pair_min_rows{24ull << 20};
 std::atomic<bool> g_plan_enabled{true};
 std::atomic<int> g_plan_cap_div{1};
 std::atomic<int> g_seed_table_depth{0};
+std::atomic<int> g_depth_table{0}; // depth table of device copies made from now on: 0 = by index size, < 0 = none, else its order
 std::atomic<bool> g_plan_stats{false};
 std::atomic<int> g_index_shards{0};
 
@@ -160,6 +163,56 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                     dc->seed_d = D;
                     idx->plan_bytes += cur.size() * 4;
                 }
+                // depth table (dtab_kernels.hip): for every string of `order` bases the longest suffix of it that is a suffix
+                // of a row.  One independent byte look-up then gives the MS value of a base wherever the value is at most
+                // `order` - i.e. in the stretches behind mismatches, where the match is a random one: about log4(rows) long.
+                // order = log4(rows) + 3.2, rounded up (1.3 % of such stretches run deeper than log4(rows) + 4, 5 % deeper than
+                // + 3, 17 % deeper than + 2: those reads take the plain walk), at most 17 (16 GiB) and at most k; no table where
+                // that leaves less than log4(rows) + 2.9 (300 M rows and more: the guided walk over recovery lines stays).
+                {
+                    const double lg = std::log2((double)std::max<uint64_t>(idx->host.n_sets, 4)) / 2.0;
+                    int order = std::min<int>({(int)std::ceil(lg + 3.2), 17, (int)idx->host.k});
+                    if ((double)order < lg + 2.9 && order < (int)idx->host.k) order = 0;
+                    const int set = g_depth_table.load();
+                    if (set < 0) order = 0;
+                    else if (set > 0) order = std::min<int>({set, 17, (int)idx->host.k});
+                    if (const char *e = std::getenv("KBO_DEPTH_TABLE")) // experiments
+                        order = std::max(0, std::min<int>({std::atoi(e), 17, (int)idx->host.k}));
+                    const uint64_t cap = idx->host.n_sets + 16;
+                    // the look-ups go to the grouped form (three consecutive bases share a line: a third of the fills, four
+                    // times the bytes) when the order allows it
+                    static const int env_grp = std::getenv("KBO_DEPTH_TABLE_GROUPED") ? std::atoi(std::getenv("KBO_DEPTH_TABLE_GROUPED")) : -1; // experiments
+                    bool grouped = order >= 4 && env_grp != 0;
+                    const size_t plain_bytes = kbo::dtab_bytes((uint32_t)std::max(order, 1), false) + 64, tmp_bytes = kbo::dtab_tmp_bytes(cap);
+                    size_t free_b = 0, total_b = 0;
+                    const bool have_info = order > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+                    if (have_info && grouped && (double)(kbo::dtab_bytes((uint32_t)order, true) + plain_bytes + tmp_bytes) > 0.5 * (double)free_b)
+                        grouped = false; // (never more than half of what is free: the batches need the rest)
+                    if (have_info && set <= 0 && !grouped && (double)(plain_bytes + tmp_bytes) > 0.5 * (double)free_b) order = 0;
+                    if (order > 0) {
+                        DevBuf tmp, plain;
+                        plain.alloc(plain_bytes);
+                        tmp.alloc(tmp_bytes);
+                        kbo::DevIndexView bv{};
+                        bv.arena = dc->arena.as<uint4>();
+                        bv.n_blocks = (uint32_t)dc->n_blocks;
+                        bv.n = (uint32_t)idx->host.n_sets;
+                        bv.k = idx->host.k;
+                        HIP_OK(kbo::build_depth_table(bv, (uint32_t)order, plain.as<uint8_t>(), tmp.p, cap, nullptr));
+                        if (grouped) {
+                            tmp.release();
+                            dc->dtab.alloc(kbo::dtab_bytes((uint32_t)order, true) + 64);
+                            HIP_OK(kbo::regroup_depth_table(plain.as<uint8_t>(), (uint32_t)order, dc->dtab.as<uint8_t>(), nullptr));
+                        } else {
+                            std::swap(dc->dtab.p, plain.p);
+                            std::swap(dc->dtab.cap, plain.cap);
+                            std::swap(dc->dtab.dev, plain.dev);
+                        }
+                        dc->dtab_order = (uint32_t)order;
+                        dc->dtab_grouped = grouped;
+                        idx->plan_bytes += kbo::dtab_bytes((uint32_t)order, grouped);
+                    }
+                }
             }
         } catch (...) {
             delete dc;
@@ -184,6 +237,10 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
     v.pc_pos = dc->pc_pos.as<uint32_t>();
     v.seed_tab = dc->seed_d ? dc->seed_tab.as<uint2>() : nullptr;
     v.seed_d = dc->seed_d;
+    const bool use_tab = dc->dtab_order != 0 && g_depth_table.load() >= 0; // (kbo_set_depth_table(-1): launches ignore it)
+    v.dtab = use_tab ? dc->dtab.as<uint8_t>() : nullptr;
+    v.dtab_order = use_tab ? dc->dtab_order : 0u;
+    v.dtab_grouped = dc->dtab_grouped ? 1u : 0u;
     v.fat = dc->fat.p ? dc->fat.as<uint8_t>() : nullptr;
     v.fat_null = dc->fat_null;
     v.pc_node = dc->pc_node.as<uint32_t>();

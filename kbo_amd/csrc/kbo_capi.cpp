@@ -1146,8 +1146,11 @@ int kbo_plan_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, 
         HIP_OK(hipMemcpyAsync(&tot[1], plan + L.usums + (size_t)(last / 1024u) * 4, 4, hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
         for (uint32_t i = 0; i < KBO_PLAN_STATS; i++) out[i] = 0;
-        for (uint32_t sl = 0; sl < kbo::kPlanStatSlots; sl++)
-            for (uint32_t i = 0; i < kbo::kPlanStatWords; i++) out[i] += st[sl * kbo::kPlanStatWords + i];
+        for (uint32_t sl = 0; sl < kbo::kPlanStatSlots; sl++) {
+            for (uint32_t i = 0; i < 8; i++) out[i] += st[sl * kbo::kPlanStatWords + i];
+            for (uint32_t i = 0; i < 3; i++) out[12 + i] += st[sl * kbo::kPlanStatWords + kbo::kPlanStatTabLookups + i];
+        }
+        out[15] = ctl[4];
         out[8] = (uint64_t)tot[0] + tot[1];
         out[9] = ctl[1];
         out[10] = ctl[2];
@@ -1271,6 +1274,39 @@ int kbo_index_recovery_lines(const kbo_index_t *idx, uint8_t *lines, size_t *n_b
     });
 }
 
+int kbo_index_depth_table(kbo_index_t *idx, int device, int view, uint8_t *table, size_t *n_bytes, int *order)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && n_bytes && order && view >= 0 && view < 3, KBO_E_BAD_ARG, "null argument / view not in 0..2");
+        const int dev = device < 0 ? current_device() : device;
+        const kbo::DevIndexView v = device_view(idx, dev); // (no table while kbo_set_depth_table(-1) is in force)
+        const size_t need = v.dtab ? (size_t)1 << (2u * v.dtab_order) : 0;
+        if (table && need) {
+            KBO_REQUIRE(*n_bytes >= need, KBO_E_BAD_ARG, "buffer smaller than the table");
+            int prev = current_device();
+            if (prev != dev) HIP_OK(hipSetDevice(dev));
+            hipError_t e = hipSuccess;
+            if (!v.dtab_grouped) e = hipMemcpy(table, v.dtab, need, hipMemcpyDeviceToHost);
+            else { // the grouped table holds every entry three times: the copy `view` of them, put back in key order
+                std::vector<uint8_t> g(kbo::dtab_bytes(v.dtab_order, true));
+                e = hipMemcpy(g.data(), v.dtab, g.size(), hipMemcpyDeviceToHost);
+                const uint32_t cb = 2u * (v.dtab_order - 2u);
+                const uint64_t cm = (1ull << cb) - 1ull;
+                for (uint64_t key = 0; key < need; key++) {
+                    const uint64_t a = view == 0 ? ((key & cm) << 6) + (key >> cb)
+                                     : view == 1 ? (((key >> 2) & cm) << 6) + 16u + ((key >> (cb + 2u)) << 2) + (key & 3u)
+                                                 : ((key >> 4) << 6) + 32u + (key & 15u);
+                    table[key] = g[a];
+                }
+            }
+            if (prev != dev) (void)hipSetDevice(prev);
+            HIP_OK(e);
+        }
+        *n_bytes = need;
+        *order = (int)v.dtab_order;
+    });
+}
+
 int kbo_index_path_cover(const kbo_index_t *idx, uint8_t *text, uint32_t *pos, uint32_t *node_at)
 {
     return guarded([&] {
@@ -1326,6 +1362,12 @@ const kbo_index_t *kbo_index_shard(const kbo_index_t *idx, int i)
 int kbo_set_plan_stats(int on)
 {
     g_plan_stats = on != 0;
+    return KBO_OK;
+}
+
+int kbo_set_depth_table(int order)
+{
+    g_depth_table = order < 0 ? -1 : std::min(order, 17);
     return KBO_OK;
 }
 

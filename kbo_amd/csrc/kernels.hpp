@@ -28,6 +28,12 @@ struct DevIndexView {
     // recovery lines of the guided walk (sbwt_index.hpp make_recovery_lines), nullptr when the device copy has none
     const uint8_t *fat;
     uint32_t fat_null; // line index of an all-zero line (extensions by a non-ACGT byte)
+    // depth table (dtab_kernels.hip), nullptr / 0 when the device copy has none: for every string of dtab_order bases (2-bit
+    // digits, the newest base least significant) the longest suffix of it that is a suffix of a row; 0x80 | e when all of it
+    // is, bit c of e = so is the string with base c in front of it
+    const uint8_t *dtab;
+    uint32_t dtab_order;
+    uint32_t dtab_grouped; // 1: the entries of three consecutive bases share a 64-byte line (dtab_kernels.hip), 4^(order+1) bytes
 };
 
 // One unit of walk work: `len` bases starting at absolute offset `start` of the
@@ -104,7 +110,8 @@ struct WalkArgs {
     uint32_t unit_cap;
     uint32_t redo_cap;     // WalkItem records the unit array holds (the redo pass's list is built there)
     uint32_t unit_bail;    // more units than this in a launch: the plan is given up, every item takes the plain walk
-    uint32_t *qctl;        // [0] queue head of the guided walk, [1] entries of the redo list, [2] plan given up, [3] a walk left through its guard
+    uint32_t *qctl;        // [0] queue head of the guided walk, [1] entries of the redo list, [2] plan given up, [3] a walk left through its guard,
+                           // [4] (table mode) items the table could not resolve
     uint32_t *pstats;      // work counters of the launch (kPlanStat*): kPlanStatSlots slots of 8 u32, summed by the host
     uint32_t plan_dmin;    // plan_kernel: a seed must be this deep (capped at k) before its row is trusted
     uint32_t plan_cap;     // plan_kernel: seed iterations before an item is given up as unplanned
@@ -118,13 +125,15 @@ struct WalkArgs {
     uint32_t *call_counts;
     uint32_t call_cap;     // records per list
     uint32_t call_thr;     // derandomisation threshold t of the predicate
+    uint32_t table_mode;   // 1: the stretches behind mismatches come from the depth table (set by launch_ms_walk)
     uint32_t max_item_len; // 0 = not known, else no item is longer than this (plan_kernel sizes its LDS staging from it)
     const uint32_t *n_items_dev; // plain kernel: nullptr, or where the number of items is (the redo pass: qctl + 1)
 };
 // Work counters the plan-guided stage keeps about itself (one wave-level atomic per counter and wave, spread over slots):
 // what the CPU model of the stage (oracle/plan_model.c) is pinned to, tests/test_gpu_model.py
 enum : uint32_t { kPlanStatUnits = 0, kPlanStatAccepted, kPlanStatFailed, kPlanStatLevels, kPlanStatEntryLevels,
-                  kPlanStatSeedLookups, kPlanStatSeedExtensions, kPlanStatMismatches, kPlanStatWords };
+                  kPlanStatSeedLookups, kPlanStatSeedExtensions, kPlanStatMismatches,
+                  kPlanStatTabLookups, kPlanStatTabWritten, kPlanStatTabFlagged, kPlanStatPad, kPlanStatWords };
 constexpr uint32_t kPlanStatSlots = 8;
 // where the pieces of a launch's plan work live inside its work buffer (attach_plan)
 struct PlanLayout {
@@ -161,6 +170,16 @@ inline PlanLayout plan_layout(size_t n_items, uint64_t total_bases)
 inline size_t plan_work_bytes(size_t n_items, uint64_t total_bases) { return plan_layout(n_items, total_bases).end + 64; }
 hipError_t launch_plan(WalkArgs &a, hipStream_t stream); // fills in the plan parameters of `a` (the later launches need them)
 hipError_t launch_ms_walk_guided(WalkArgs a, uint32_t grid, uint32_t threads, hipStream_t stream);
+// table mode: plan_kernel, then the stretches behind the mismatches from the depth table, then the list of the items the table
+// could not resolve (for the plain kernel, like the guided walk's redo pass)
+hipError_t launch_plan_table(WalkArgs &a, hipStream_t stream);
+hipError_t launch_dtab_resolve(const WalkArgs &a, hipStream_t stream);
+// the depth table of `order` bases (<= 17, <= k) of the index behind `ix`: 4^order bytes at d_tab; d_tmp: dtab_tmp_bytes(cap)
+// with cap >= n rows + 1.  Synchronous.
+size_t dtab_tmp_bytes(uint64_t frontier_cap);
+inline size_t dtab_bytes(uint32_t order, bool grouped) { return grouped ? (size_t)64 << (2u * (order - 2u)) : (size_t)1 << (2u * order); }
+hipError_t regroup_depth_table(const uint8_t *d_plain, uint32_t order, uint8_t *d_grouped, hipStream_t stream);
+hipError_t build_depth_table(const DevIndexView &ix, uint32_t order, uint8_t *d_tab, void *d_tmp, uint64_t frontier_cap, hipStream_t stream);
 void set_guided_walk(int waves_per_cu, int recovery_lines); // tuning: see kbo_set_guided_walk
 bool guided_uses_recovery_lines(const WalkArgs &a);
 void set_plan_stage(int on); // experiments: plan_kernel with (default) / without its LDS staging

@@ -467,48 +467,61 @@ __global__ __launch_bounds__(256) void plan_emit_kernel(WalkArgs a)
 // pieces).  A flagged item longer than 96 output bases is cut into pieces of 64 with their own warm-up (and, in call mode,
 // borrowed) bases, like the chunks of a long sequence: the redo pass is a handful of items, and one lane walking 800 bases
 // on its own would be most of the stage's time.  A plan that was given up: all items as they are, in order.
-constexpr uint32_t kRedoPiece = 64;
-__global__ __launch_bounds__(256) void redo_collect_kernel(WalkArgs a)
+constexpr uint32_t kRedoPiece = 64, kRedoPieceTable = 32; // (table mode: a few per cent of the reads come here, see below)
+constexpr uint32_t kRedoBlock = 1024;
+__global__ __launch_bounds__(1024) void redo_collect_kernel(WalkArgs a)
 {
+    __shared__ uint32_t wave_tot[kRedoBlock / 64], block_base;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.n_items) return;
+    const bool have = idx < a.n_items;
     WalkItem *list = reinterpret_cast<WalkItem *>(a.units);
-    const uint4 it = ld16(reinterpret_cast<const uint8_t *>(a.items), idx * 16u);
+    uint4 it = make_uint4(0, 0, 0, 0);
+    if (have) it = ld16(reinterpret_cast<const uint8_t *>(a.items), idx * 16u);
     // plan given up: all items, in order.  The same when a wave of the guided walk left through its no-progress guard
     // (qctl[3]; it cannot, but then units are unwalked): every item is walked again in full, so the batch stays exact.
-    const bool gave_up = a.usums[(2u * a.n_items) / kScanBlock] + a.ucount[2u * a.n_items] > a.unit_bail;
-    if (gave_up || a.qctl[3]) {
-        reinterpret_cast<uint4 *>(list)[idx] = it;
+    // (table mode: the plan is given up when the table left more than unit_bail items unresolved)
+    const bool gave_up = a.table_mode ? a.qctl[4] > a.unit_bail
+                                      : a.usums[(2u * a.n_items) / kScanBlock] + a.ucount[2u * a.n_items] > a.unit_bail;
+    if (gave_up || a.qctl[3]) { // (block-uniform)
+        if (have) reinterpret_cast<uint4 *>(list)[idx] = it;
         if (idx == 0) {
             a.qctl[1] = a.n_items;
             if (gave_up) a.qctl[2] = 1; // tells the host (plan_after_launch) that planning did not pay for this batch
         }
         return;
     }
-    // one counter update per wave (returning atomics on one address take about 10 ns each)
-    const bool f = a.redo[idx] != 0;
-    const uint64_t fm = __ballot(f);
-    if (fm == 0) return;
+    // one counter update per block of 1024 items (returning atomics on one address take about 10 ns each: with a few per cent
+    // of the items flagged - the table form - one per wave was 0.13 ms)
+    const bool f = have && a.redo[idx] != 0;
     const uint32_t len = it.z, warm = it.w & 0xFFFFu, tail = it.w >> 16, body = len - warm - tail;
     const uint32_t marg = a.call_sites ? a.ix.k : (a.ix.k > 0 ? a.ix.k - 1u : 0u); // warm-up of a chunk (make_chunk_items_kernel)
-    const uint32_t np = !f ? 0u : (body > kRedoPiece + kRedoPiece / 2u ? (body + kRedoPiece - 1u) / kRedoPiece : 1u);
+    // a flagged item longer than a piece and a half is cut into pieces with their own warm-up: the pass is bound by the
+    // longest chain of dependent look-ups, not by their number (pieces of 64 bases when a handful of items come here, of 32
+    // in table mode)
+    const uint32_t piece = a.table_mode ? kRedoPieceTable : kRedoPiece;
+    const uint32_t np = !f ? 0u : (body > piece + piece / 2u ? (body + piece - 1u) / piece : 1u);
     uint32_t incl = np; // inclusive scan over the wave
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t t = __shfl_up(incl, off);
         if ((int)lane >= off) incl += t;
     }
-    const int last = 63 - (int)__builtin_clzll(__ballot(true));
-    const uint32_t total = __shfl(incl, last);
-    uint32_t base = 0;
-    if ((int)lane == last) base = atomicAdd(a.qctl + 1, total);
-    base = __shfl(base, last) + incl - np;
+    if (lane == 63u) wave_tot[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < blockDim.x / 64u; w++) tot += wave_tot[w];
+        block_base = tot ? atomicAdd(a.qctl + 1, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = block_base + incl - np;
+    for (uint32_t w = 0; w < wv; w++) base += wave_tot[w];
     if (np == 1) {
         if (base < a.redo_cap) reinterpret_cast<uint4 *>(list)[base] = it;
     } else {
         for (uint32_t p = 0; p < np; p++) {
-            const uint32_t out_lo = warm + p * kRedoPiece, out_hi = min(out_lo + kRedoPiece, warm + body);
+            const uint32_t out_lo = warm + p * piece, out_hi = min(out_lo + piece, warm + body);
             const uint32_t w2 = p == 0 ? warm : min(marg, out_lo);
             const uint32_t t2 = a.call_sites ? min(a.ix.k, len - out_hi) : 0u;
             if (base + p < a.redo_cap)
@@ -1299,10 +1312,9 @@ void set_plan_params(int dmin, int cap, int gap, int chunk)
     if (chunk > 0) g_plan_chunk = std::max(16, chunk);
 }
 
-// plan -> unit counts -> scan -> units (the guided walk and the redo pass are launched by launch_ms_walk)
-hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
+// plan_kernel with the parameters of the launch filled into `a` (the later launches need them)
+static hipError_t launch_plan_kernel(WalkArgs &a, hipStream_t stream)
 {
-    if (a.n_items == 0) return hipSuccess;
     // seed depth: a single-row interval is trusted as the item's diagonal from log4(rows) + 3 bases on (measured: 14 on the
     // 5 Mbp index, 16 on the 100 Mbp one - 12 / 13 / 14 / 16 bases: 1.19 / 1.16 / 1.14 / 1.18 ms, 13 / 14 / 15 / 16 / 18:
     // 4.10 / 3.80 / 3.58 / 3.56 / 3.69 ms; shallower seeds put items on wrong diagonals, deeper ones cost extensions)
@@ -1319,12 +1331,9 @@ hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
     // mismatches an item's list holds: 13 for reads (more than that on 150 bases is a wrong diagonal), 29 for the chunks of
     // long sequences (800 bases at 1 % substitutions exceed 13 every twentieth time)
     a.plan_list = (a.max_item_len != 0 && a.max_item_len <= 255u) ? kPlanList : kPlanListMax;
-    // (per read of 150 bases: chunks of long sequences hold several reads' worth of units)
-    a.unit_bail = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(a.n_items, a.q_bytes / 150u) * (uint64_t)g_plan_bail_x16.load() / 16u + 64u, 0xFFFFFFFFu);
     // (queue head, redo count, flags and - behind them - the launch's work counters)
     const hipError_t e = hipMemsetAsync(a.qctl, 0, 64 + kPlanStatSlots * kPlanStatWords * 4, stream);
     if (e != hipSuccess) return e;
-    const uint32_t nb = (a.n_items + 255u) / 256u;
     // LDS for the staged stretch of every wave: 64 items of at most max_item_len bases (not known, or too long for
     // four waves to share 64 KiB: no staging)
     // items that cannot be staged: 10 KB per wave for the transposed write-out of a step's predicted values
@@ -1341,10 +1350,39 @@ hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
     static const int env_blk = std::getenv("KBO_PLAN_BLOCK") ? std::atoi(std::getenv("KBO_PLAN_BLOCK")) : 0; // experiments
     const uint32_t bt = env_blk == 64 || env_blk == 128 ? (uint32_t)env_blk : 256u;
     hipLaunchKernelGGL(plan_kernel, dim3((a.n_items + bt - 1u) / bt), dim3(bt), (bt / 64u) * wave_lds, stream, a, wave_lds, stage_ok);
+    return hipGetLastError();
+}
+
+// plan -> unit counts -> scan -> units (the guided walk and the redo pass are launched by launch_ms_walk)
+hipError_t launch_plan(WalkArgs &a, hipStream_t stream)
+{
+    if (a.n_items == 0) return hipSuccess;
+    a.table_mode = 0;
+    // (per read of 150 bases: chunks of long sequences hold several reads' worth of units)
+    a.unit_bail = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(a.n_items, a.q_bytes / 150u) * (uint64_t)g_plan_bail_x16.load() / 16u + 64u, 0xFFFFFFFFu);
+    const hipError_t e = launch_plan_kernel(a, stream);
+    if (e != hipSuccess) return e;
+    const uint32_t nb = (a.n_items + 255u) / 256u;
     hipLaunchKernelGGL(plan_count_kernel, dim3(nb), dim3(256), 0, stream, a);
     const hipError_t es = launch_scan(a.ucount, 2u * a.n_items + 1u, a.usums, stream);
     if (es != hipSuccess) return es;
     hipLaunchKernelGGL(plan_emit_kernel, dim3(nb), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// table mode (dtab_kernels.hip): plan -> the stretches behind the mismatches from the depth table -> the items it could not
+// resolve listed for the plain kernel.  A launch that leaves more than half of its items unresolved gives the plan up (every
+// item is walked plainly, and the host skips planning for the next launches: plan_after_launch).
+hipError_t launch_plan_table(WalkArgs &a, hipStream_t stream)
+{
+    if (a.n_items == 0) return hipSuccess;
+    a.table_mode = 1;
+    a.unit_bail = a.n_items / 2u + 64u;
+    hipError_t e = launch_plan_kernel(a, stream);
+    if (e != hipSuccess) return e;
+    e = launch_dtab_resolve(a, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(redo_collect_kernel, dim3((a.n_items + kRedoBlock - 1u) / kRedoBlock), dim3(kRedoBlock), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -1368,7 +1406,7 @@ hipError_t launch_ms_walk_guided(WalkArgs a, uint32_t grid, uint32_t threads, hi
         else launch_guided_variant<true, false>(a, grid, threads, stream);
     } else if (a.pstats) launch_guided_variant<false, true>(a, grid, threads, stream);
     else launch_guided_variant<false, false>(a, grid, threads, stream);
-    hipLaunchKernelGGL(redo_collect_kernel, dim3((a.n_items + 255u) / 256u), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(redo_collect_kernel, dim3((a.n_items + kRedoBlock - 1u) / kRedoBlock), dim3(kRedoBlock), 0, stream, a);
     // call mode: sites of items that go to the redo pass are void (that pass finds them again), the others get their rows
     if (a.call_sites) hipLaunchKernelGGL(call_fix_sites_kernel, dim3(kCallSegs), dim3(256), 0, stream, a);
     return hipGetLastError();

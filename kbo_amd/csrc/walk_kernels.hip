@@ -510,17 +510,23 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
     const bool ival = a.lo_out && a.hi_out;
     a.pair_min_d = (uint32_t)g_pair_min_depth.load();
     if (a.gitems && a.glist && a.ix.pc_text && !ival) { // MS values only, index with a path cover: plan, then guided walk
-        hipError_t e = launch_plan(a, stream);
-        if (e != hipSuccess) return e;
-        // the guided kernel takes its units off a queue: a fixed number of resident waves, but no more than there are
-        // chunks of 64 units
-        static const int env_gw = std::getenv("KBO_GUIDED_WAVES") ? std::atoi(std::getenv("KBO_GUIDED_WAVES")) : 0; // experiments: 32nds
-        const int gw_set = env_gw > 0 ? env_gw : g_guided_waves_32nds.load();
-        const int gw = gw_set > 0 ? gw_set : (guided_uses_recovery_lines(a) ? 12 : 8);
-        const uint32_t gwaves = (uint32_t)std::min<uint64_t>((uint64_t)std::max(1, max_waves * gw / 32),
-                                                             ((uint64_t)a.unit_cap + 63) / 64);
-        e = launch_ms_walk_guided(a, (gwaves + wpb - 1) / wpb, threads, stream);
-        if (e != hipSuccess) return e;
+        hipError_t e = hipSuccess;
+        if (a.ix.dtab && !a.call_sites) { // the stretches behind mismatches from the depth table (dtab_kernels.hip): no units
+            e = launch_plan_table(a, stream);
+            if (e != hipSuccess) return e;
+        } else {
+            e = launch_plan(a, stream);
+            if (e != hipSuccess) return e;
+            // the guided kernel takes its units off a queue: a fixed number of resident waves, but no more than there are
+            // chunks of 64 units
+            static const int env_gw = std::getenv("KBO_GUIDED_WAVES") ? std::atoi(std::getenv("KBO_GUIDED_WAVES")) : 0; // experiments: 32nds
+            const int gw_set = env_gw > 0 ? env_gw : g_guided_waves_32nds.load();
+            const int gw = gw_set > 0 ? gw_set : (guided_uses_recovery_lines(a) ? 12 : 8);
+            const uint32_t gwaves = (uint32_t)std::min<uint64_t>((uint64_t)std::max(1, max_waves * gw / 32),
+                                                                 ((uint64_t)a.unit_cap + 63) / 64);
+            e = launch_ms_walk_guided(a, (gwaves + wpb - 1) / wpb, threads, stream);
+            if (e != hipSuccess) return e;
+        }
         // the redo pass: items a unit flagged (its successor's start state was a wrong guess) walked plainly, in full;
         // redo_collect_kernel has listed them where the item records were, one item per lane
         const uint32_t n_orig = a.n_items;

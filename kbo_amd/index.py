@@ -85,6 +85,21 @@ class SbwtIndexVariant:
         check(lib().kbo_index_path_cover(self._h, text.ctypes.data, pos.ctypes.data, node.ctypes.data))
         return text, pos, node
 
+    def depth_table(self, device=-1, view=0):
+        """(uint8[4^order], order) - the depth table of the device copy (kbo_hip_tuning.h kbo_index_depth_table); (empty, 0): none"""
+        nb, order = C.c_size_t(0), C.c_int(0)
+        check(lib().kbo_index_depth_table(self._h, device, view, None, C.byref(nb), C.byref(order)))
+        out = np.zeros(nb.value, dtype=np.uint8)
+        if nb.value:
+            check(lib().kbo_index_depth_table(self._h, device, view, out.ctypes.data, C.byref(nb), C.byref(order)))
+        return out, int(order.value)
+
+    def depth_table_order(self, device=-1):
+        """order of the depth table of the device copy (0: none)"""
+        nb, order = C.c_size_t(0), C.c_int(0)
+        check(lib().kbo_index_depth_table(self._h, device, 0, None, C.byref(nb), C.byref(order)))
+        return int(order.value)
+
     def recovery_lines(self):
         """uint8[n_lines, 128] - the recovery lines of the guided walk (kbo_hip.h: kbo_index_recovery_lines)."""
         nb = C.c_size_t(0)

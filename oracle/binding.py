@@ -23,7 +23,7 @@ class Counters(C.Structure):
 
 class PlanParams(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("seed_table_depth", "seed_depth", "seed_cap", "gap", "chunk", "list_cap", "bail_x16",
-                                          "recovery_lines")]
+                                          "recovery_lines", "depth_table")]
 
 
 class PlanCounts(C.Structure):
@@ -32,7 +32,8 @@ class PlanCounts(C.Structure):
         "seed_lookups", "seed_extensions", "pos_lookups", "compare_bases", "mismatches",
         "units_counted", "units", "units_head", "units_plain", "node_lookups",
         "walk_accepted", "walk_failed", "walk_contractions", "walk_entry_levels", "walk_short_windows", "walk_iterations_lines",
-        "walk_out_bytes", "unit_distinct_lines", "unit_distinct_rank_lines", "redo_bases", "redo_iterations")]
+        "walk_out_bytes", "unit_distinct_lines", "unit_distinct_rank_lines", "redo_bases", "redo_iterations",
+        "tab_lookups", "tab_written", "tab_flagged")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -298,7 +299,17 @@ def _call_sites_batch(self, concat, offsets, threshold, n_threads=1):
 Index.call_sites_batch = _call_sites_batch
 
 
-def shipped_plan_params(k, n_sets, recovery_lines=None):
+def shipped_depth_table_order(k, n_sets):
+    """device_index.cpp: order of the depth table a device copy of an index of n_sets rows gets by default (0 = none)"""
+    import math
+    lg = math.log2(max(n_sets, 4)) / 2.0
+    order = min(int(math.ceil(lg + 3.2)), 17, k)
+    if order < lg + 2.9 and order < k:
+        order = 0
+    return order
+
+
+def shipped_plan_params(k, n_sets, recovery_lines=None, depth_table=None):
     """The parameters the product's plan-guided stage runs with by default on an index of n_sets rows (device_index.cpp:
     seed table depth; plan_kernels.hip launch_plan: seed depth, gap; walk_kernels.hip: recovery lines from 24 Mi rows)."""
     import math
@@ -309,7 +320,8 @@ def shipped_plan_params(k, n_sets, recovery_lines=None):
     elif d == 10 and k >= 12 and n_sets >= (32 << 20):
         d = 12
     return PlanParams(seed_table_depth=d, seed_depth=half_log + 3, seed_cap=64, gap=half_log + 9, chunk=32, list_cap=13,
-                      bail_x16=50, recovery_lines=int(n_sets >= (24 << 20)) if recovery_lines is None else int(recovery_lines))
+                      bail_x16=50, recovery_lines=int(n_sets >= (24 << 20)) if recovery_lines is None else int(recovery_lines),
+                      depth_table=shipped_depth_table_order(k, n_sets) if depth_table is None else int(depth_table))
 
 
 def _plan_model(self, cover, params, concat, offsets, n_threads=1):

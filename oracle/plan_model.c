@@ -96,6 +96,7 @@ enum { PM_A_RANK = 1, PM_A_ENT = 5, PM_A_LINE = 6, PM_A_UNIT = 7, PM_A_NODE = 8,
 typedef struct {
     uint32_t seeded, p0, j_conv, n_mm; /* n_mm capped at 254 like the kernel's record */
     uint16_t mm[PM_LIST_MAX];
+    uint8_t tab_flagged; /* depth-table form: the table could not resolve the item (dtab_resolve_kernel) */
 } pm_plan;
 
 static void pm_plan_item(const pm_index *m, const ora_plan_params *P, const uint8_t *q, uint32_t len, uint8_t *ms,
@@ -382,6 +383,52 @@ static void pm_walk_plain(const pm_index *m, const uint8_t *q, uint32_t len, uin
     cn->redo_bases += len;
 }
 
+/* ------------------------------------------------------------------ depth-table form (dtab_kernels.hip) */
+/* dtab_resolve_kernel on one item: lane j of mismatch m has base i = m + j (up to the next mismatch, the item's end and
+ * order + 1 bases); its look-up gives L = the longest suffix of the bases up to i (inside the item, behind the last non-ACGT
+ * byte) that is a suffix of a row, as far as the table knows: exactly when it is at most `order`, "deeper" otherwise (the
+ * item is flagged) - modelled by a literal walk from the root that starts order + 1 bases in front of the mismatch.  The
+ * lanes in front of the first one with L <= j write their values.  abs0 = offset of the item in the query buffer. */
+static void pm_resolve_item(const pm_index *m, const ora_plan_params *P, const uint8_t *q, uint32_t len, uint64_t abs0, uint8_t *ms,
+                            pm_plan *pl, uint8_t *tmp /* len bytes */, ora_plan_counts *cn)
+{
+    const uint32_t order = P->depth_table < m->k ? P->depth_table : m->k, k = m->k;
+    pl->tab_flagged = 0;
+    if (len == 0) return;
+    if (!pl->seeded || pl->n_mm > P->list_cap) { pl->tab_flagged = 1; cn->tab_flagged++; return; }
+    for (uint32_t t = 0; t < pl->n_mm && !pl->tab_flagged; t++) {
+        const uint32_t mpos = pl->mm[t], nxt = t + 1u < pl->n_mm ? pl->mm[t + 1u] : len;
+        uint32_t hi = mpos + order + 1u;
+        if (hi > nxt) hi = nxt;
+        if (hi > len) hi = len;
+        pm_unit u;
+        memset(&u, 0, sizeof u);
+        u.pos = mpos > order + 1u ? mpos - (order + 1u) : 0u;
+        u.out_from = u.pos;
+        u.bound = hi; u.last_mm = -1; u.head = 1; u.plain = 1;
+        pm_state s0 = {0, m->n, 0};
+        ora_plan_counts c2;
+        memset(&c2, 0, sizeof c2);
+        pm_set dummy;
+        pm_set_clear(&dummy);
+        pm_walk_blocks(m, q, &u, s0, tmp, &c2, &dummy);
+        uint32_t first_conv = ~0u, first_sat = ~0u, Lv[32];
+        for (uint32_t i = mpos; i < hi; i++) {
+            const uint32_t j = i - mpos;
+            cn->tab_lookups += abs0 + i + 1u >= 32u ? 1u : 0u;
+            const int sat = abs0 + i + 1u < 32u || (order < k && tmp[i] > order);
+            Lv[j] = tmp[i] < order ? tmp[i] : order;
+            if (sat) { if (first_sat == ~0u) first_sat = j; }
+            else if (Lv[j] <= j && first_conv == ~0u) first_conv = j;
+        }
+        if (first_sat < first_conv) { pl->tab_flagged = 1; cn->tab_flagged++; break; }
+        for (uint32_t i = mpos; i < hi && i - mpos <= first_conv; i++) {
+            ms[i] = (uint8_t)(Lv[i - mpos] < k ? Lv[i - mpos] : k);
+            cn->tab_written++;
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ driver */
 
 typedef struct {
@@ -407,6 +454,10 @@ static void pm_units_walk(pm_job *j)
         uint8_t *ms = j->ms_out + j->off[r];
         const pm_plan *pl = &j->plans[r - j->begin];
         if (j->gave_up) { pm_walk_plain(m, q, len, ms, &j->cn); continue; }
+        if (P->depth_table) { /* no units: what the table left unresolved takes the plain walk */
+            if (pl->tab_flagged) { j->cn.items_flagged++; pm_walk_plain(m, q, len, ms, &j->cn); }
+            continue;
+        }
         const uint32_t nu = pm_units_of(P, m->k, len, pl, units);
         int flagged = 0;
         for (uint32_t x = 0; x < nu; x++) {
@@ -449,12 +500,17 @@ static void *pm_worker(void *arg)
             if (L > maxlen) maxlen = L;
         }
         pm_unit *units = (pm_unit *)malloc((maxlen / (j->P->chunk ? j->P->chunk : 1) + PM_LIST_MAX + 4) * sizeof(pm_unit));
+        uint8_t *tmp = (uint8_t *)malloc(maxlen + 16);
         for (size_t r = j->begin; r < j->end; r++) {
             const uint32_t len = (uint32_t)(j->off[r + 1] - j->off[r]);
             pm_plan_item(j->m, j->P, j->concat + j->off[r], len, j->ms_out + j->off[r], &j->plans[r - j->begin], &j->cn);
-            j->cn.units_counted += pm_units_of(j->P, j->m->k, len, &j->plans[r - j->begin], units);
+            if (j->P->depth_table)
+                pm_resolve_item(j->m, j->P, j->concat + j->off[r], len, j->off[r], j->ms_out + j->off[r], &j->plans[r - j->begin], tmp, &j->cn);
+            else
+                j->cn.units_counted += pm_units_of(j->P, j->m->k, len, &j->plans[r - j->begin], units);
             if (j->plans[r - j->begin].seeded && j->plans[r - j->begin].n_mm > j->P->list_cap) j->cn.items_list_overflow++;
         }
+        free(tmp);
         free(units);
     } else {
         pm_units_walk(j);
@@ -474,7 +530,7 @@ int ora_plan_model(const ora_index *x, const uint8_t *text, const uint32_t *pos,
                    uint8_t *ms_out, ora_plan_counts *counts)
 {
     if (!x || !text || !pos || !node_at || !P || !concat || !offsets || !ms_out || !counts) return ORA_E_BAD_ARG;
-    if (P->gap < 2 || P->chunk < 1 || P->list_cap + 1u > PM_LIST_MAX || P->seed_table_depth > 13) return ORA_E_BAD_ARG;
+    if (P->gap < 2 || P->chunk < 1 || P->list_cap + 1u > PM_LIST_MAX || P->seed_table_depth > 13 || P->depth_table > 17) return ORA_E_BAD_ARG;
     if (ora_index_n_sets(x) >= 0xFFFFFFF0ull) return ORA_E_BAD_ARG;
     pm_index m;
     memset(&m, 0, sizeof m);
@@ -541,7 +597,10 @@ int ora_plan_model(const ora_index *x, const uint8_t *text, const uint32_t *pos,
             /* plan_emit_kernel's bail-out: more units than bail_x16 / 16 per read of 150 bases -> every item walked plainly */
             const uint64_t per = offsets[n_reads] / 150u > n_reads ? offsets[n_reads] / 150u : n_reads;
             const uint64_t bail = per * P->bail_x16 / 16u + 64u;
-            const int gave_up = units_counted > bail;
+            uint64_t unresolved = 0;
+            for (int t = 0; t < n_threads; t++) unresolved += jobs[t].cn.tab_flagged;
+            /* (depth-table form: the plan is given up when the table leaves more than half of the items unresolved) */
+            const int gave_up = P->depth_table ? unresolved > n_reads / 2u + 64u : units_counted > bail;
             for (int t = 0; t < n_threads; t++) jobs[t].gave_up = gave_up;
             counts->gave_up = (uint64_t)gave_up;
         }

@@ -33,6 +33,7 @@ def shipped_defaults(L):
     L.kbo_set_plan_unit_cap_divisor(1)
     L.kbo_set_plan_stats(0)
     L.kbo_set_index_shards(0)
+    L.kbo_set_depth_table(0)             # depth table by index size
     L.kbo_set_guided_walk(0, -1)         # resident waves and rank blocks / recovery lines by index size
     L.kbo_set_force_big_layout(0)
     L.kbo_set_seed_table_depth(0)

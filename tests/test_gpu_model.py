@@ -12,6 +12,12 @@ from gpu_helpers import adopt, threads
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def guided_walk_only():
+    """these tests are about the units and the guided walk: no depth table (tests/test_gpu_dtab.py has that form)"""
+    kbo_amd.lib().kbo_set_depth_table(-1)
+
+
 def _compare(oracle, sbwt, ora, concat, offsets, fat):
     import torch
     L = kbo_amd.lib()

@@ -11,6 +11,12 @@ from kbo_amd import batch, synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def guided_walk_only():
+    """these tests are about the units and the guided walk: no depth table (tests/test_gpu_dtab.py has that form)"""
+    kbo_amd.lib().kbo_set_depth_table(-1)
+
+
 def _mutate(rng, s, rate):
     b = bytearray(s)
     for i in range(len(b)):

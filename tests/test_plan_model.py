@@ -52,10 +52,19 @@ def test_model_ms_equals_the_literal_walk(oracle, k):
             for seed_tab, seed_depth, gap, chunk, bail in ((8 if k >= 8 else 0, 11, 17, 32, 50), (0, 3, 2, 16, 0xFFFF),
                                                           (min(k, 10), 14, 24, 64, 0xFFFF), (4, 1, 5, 32, 0xFFFF)):
                 P = oracle.PlanParams(seed_table_depth=seed_tab, seed_depth=seed_depth, seed_cap=64, gap=gap, chunk=chunk,
-                                      list_cap=13, bail_x16=bail, recovery_lines=fat)
+                                      list_cap=13, bail_x16=bail, recovery_lines=fat, depth_table=0)
                 ms, cn = ora.plan_model(cover, P, concat, offsets, n_threads=3)
                 assert np.array_equal(ms, exp), (k, rate, fat, seed_tab, seed_depth, gap, chunk, bail)
                 assert cn["bases"] == len(concat) and cn["items"] == len(offsets) - 1
+                if fat == 0:  # the depth-table form (no units): orders from "resolves next to nothing" to "k itself"
+                    for order in (2, 6, 11, 17):
+                        P.depth_table = order
+                        ms, ct = ora.plan_model(cover, P, concat, offsets, n_threads=3)
+                        assert np.array_equal(ms, exp), (k, rate, order, seed_tab, seed_depth)
+                        assert ct["units"] == 0 and ct["tab_written"] <= ct["tab_lookups"] + 32
+                        if min(order, k) == k and not ct["gave_up"]:  # a table of k bases knows every value
+                            assert ct["tab_flagged"] == ct["items_unseeded"] + ct["items_list_overflow"]
+                    P.depth_table = 0
                 if cn["gave_up"]:
                     assert cn["units"] == 0 and cn["redo_bases"] == len(concat)
                 else:
@@ -71,8 +80,15 @@ def test_model_on_the_bench_shape(oracle):
     ora = _adopt(oracle, sbwt)
     concat, offsets = synth.reads(g, 20_000, 150, 0.01)
     _, exp = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
+    P = oracle.shipped_plan_params(31, sbwt.n_sets())
+    assert P.depth_table == 13  # log4(500 k) = 9.5, + 3.2, rounded up
+    ms, cn = ora.plan_model(sbwt.path_cover(), P, concat, offsets, n_threads=4)
+    assert np.array_equal(ms, exp) and not cn["gave_up"] and cn["units"] == 0
+    assert cn["tab_flagged"] < 0.04 * cn["items"]              # few reads go to the plain walk ...
+    assert 8 < cn["tab_lookups"] / cn["mismatches"] <= 14      # ... and a mismatch costs about log4(rows) + 2 look-ups
+    assert cn["items_flagged"] == cn["tab_flagged"] and cn["redo_bases"] == 150 * cn["tab_flagged"]
     for fat in (0, 1):
-        P = oracle.shipped_plan_params(31, sbwt.n_sets(), recovery_lines=fat)
+        P = oracle.shipped_plan_params(31, sbwt.n_sets(), recovery_lines=fat, depth_table=0)
         assert (P.seed_table_depth, P.seed_depth, P.gap) == (8, 12, 18)
         ms, cn = ora.plan_model(sbwt.path_cover(), P, concat, offsets, n_threads=4)
         assert np.array_equal(ms, exp)
@@ -83,5 +99,7 @@ def test_model_on_the_bench_shape(oracle):
     other = synth.genome(200_000, seed=99)
     concat, offsets = synth.reads(other, 5_000, 150, 0.0)
     _, exp = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
-    ms, cn = ora.plan_model(sbwt.path_cover(), oracle.shipped_plan_params(31, sbwt.n_sets()), concat, offsets, n_threads=4)
-    assert np.array_equal(ms, exp) and cn["gave_up"] == 1
+    for dt in (0, None):
+        ms, cn = ora.plan_model(sbwt.path_cover(), oracle.shipped_plan_params(31, sbwt.n_sets(), depth_table=dt), concat, offsets,
+                                n_threads=4)
+        assert np.array_equal(ms, exp) and cn["gave_up"] == 1
