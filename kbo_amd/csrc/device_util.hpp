@@ -88,6 +88,15 @@ __device__ __forceinline__ uint32_t decode_base(uint32_t ch)
     return back == ch ? c : 4u;
 }
 
+// address of a depth-table entry in the grouped layout (dtab_kernels.hip): key = the window's bases, g = position mod 3
+__device__ __forceinline__ uint64_t dtab_grouped_addr(uint64_t key, uint32_t g, uint32_t order)
+{
+    const uint32_t cb = 2u * (order - 2u); // bits of a core
+    const uint64_t cm = (1ull << cb) - 1ull;
+    if (g == 0) return ((key & cm) << 6) + (key >> cb);
+    if (g == 1) return (((key >> 2) & cm) << 6) + 16u + ((key >> (cb + 2u)) << 2) + (key & 3u);
+    return ((key >> 4) << 6) + 32u + (key & 15u);
+}
 // sum of v over the 64 lanes of the wave (all lanes must call it)
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {

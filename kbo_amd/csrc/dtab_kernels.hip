@@ -95,14 +95,6 @@ __global__ __launch_bounds__(256) void dtab_ext_kernel(const DtabRec *recs, uint
 //     slot 32 .. 47   window of i0 + 2 = core . 2 newer bases            (slot = 32 + the newer bases)
 // sit in the 64 bytes of that core: the three look-ups of a triple are ONE line fill (the stage is bound by the number of
 // fills: DESIGN.md section 4.2).  4^(order - 2) cores x 64 bytes = four times the plain table.
-__device__ __forceinline__ uint64_t dtab_grouped_addr(uint64_t key, uint32_t g, uint32_t order)
-{
-    const uint32_t cb = 2u * (order - 2u); // bits of a core
-    const uint64_t cm = (1ull << cb) - 1ull;
-    if (g == 0) return ((key & cm) << 6) + (key >> cb);
-    if (g == 1) return (((key >> 2) & cm) << 6) + 16u + ((key >> (cb + 2u)) << 2) + (key & 3u);
-    return ((key >> 4) << 6) + 32u + (key & 15u);
-}
 __global__ __launch_bounds__(256) void dtab_regroup_kernel(const uint8_t *plain, uint32_t order, uint8_t *grouped)
 {
     const uint64_t core = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // one lane per core: its 48 entries, one 64-byte line
@@ -163,7 +155,9 @@ __device__ __forceinline__ void pack16(const uint4 &v, uint32_t &code, uint32_t 
 //     conv = L <= j: the longest present suffix is the j bases behind the mismatch -> from here to the next mismatch the
 //            predicted values min(k, bases since the mismatch) are exact (a longer suffix further on would contain the absent
 //            string query[m .. i])
-// lanes in front of the first conv write L.  j = order always decides (L <= order), so order + 1 lanes are enough.
+// lanes in front of the first conv write L.  j = order always decides (L <= order), so order + 1 lanes are enough.  A stretch
+// with an UNKNOWN in front of its conv writes nothing and flags the item; the item's other stretches are treated as if it
+// were not (what they write is right, and the plain walk writes it again).
 // STATS: counts its look-ups, written values and flagged items (kPlanStat*), pinned by the CPU model.
 template <int GW, bool STATS>
 __global__ __launch_bounds__(256) void dtab_resolve_kernel(WalkArgs a)
@@ -203,7 +197,7 @@ __global__ __launch_bounds__(256) void dtab_resolve_kernel(WalkArgs a)
         uint32_t nxt = (GW == 16 && t + 1u >= 16u) ? n_b : n_a;
         if (t + 1u >= n_loop) nxt = len;
         const uint32_t i = m + j;
-        const bool act = t < n_loop && !flag && j <= order && i < nxt && i < len;
+        const bool act = t < n_loop && j <= order && i < nxt && i < len; // (every mismatch on its own, flagged item or not)
         uint32_t L = 0;
         bool sat = false;
         if (act) {
@@ -245,6 +239,7 @@ __global__ __launch_bounds__(256) void dtab_resolve_kernel(WalkArgs a)
             if (STATS) st_written++;
         }
     }
+
     if (flag && j == 0) {
         a.redo[gid] = 1;
         if (STATS) st_flag++;

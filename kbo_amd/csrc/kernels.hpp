@@ -126,6 +126,7 @@ struct WalkArgs {
     uint32_t call_cap;     // records per list
     uint32_t call_thr;     // derandomisation threshold t of the predicate
     uint32_t table_mode;   // 1: the stretches behind mismatches come from the depth table (set by launch_ms_walk)
+    uint32_t table_fused;  // 1: plan_kernel did the table look-ups itself (reads; set by launch_plan_table)
     uint32_t max_item_len; // 0 = not known, else no item is longer than this (plan_kernel sizes its LDS staging from it)
     const uint32_t *n_items_dev; // plain kernel: nullptr, or where the number of items is (the redo pass: qctl + 1)
 };

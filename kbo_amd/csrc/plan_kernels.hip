@@ -74,12 +74,20 @@ __device__ __forceinline__ void st_range(uint8_t *o, const uint4 &v, uint32_t lo
 //     those bases and ended on the diagonal's node, so the guided walk may start at the first mismatch.
 constexpr int kPlanStep = 10;           // 16-byte blocks per compare step (reads of up to 160 bases: one step)
 constexpr uint32_t kPlanLdsSlack = 48;  // bytes of a wave's LDS behind the staged stretch (block reads run past an item)
-__global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds, uint32_t stage_ok)
+// FUSE (table mode, reads of at most 160 bases): the predicted values go to a second LDS region next to the staged queries -
+// which therefore stay readable - and every lane then resolves the stretches behind its item's mismatches from the depth
+// table itself (dtab_kernels.hip has the rule and the stand-alone kernel for items that cannot be staged): up to 16
+// independent look-ups per mismatch go out together, their values patch the predictions in LDS, and the item's record and
+// mismatch list never leave the kernel.  wave_lds then = staged stretch + the same again + 64 x 16 bytes of mismatch positions.
+template <bool FUSE>
+__global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds, uint32_t stage_ok, uint32_t stage_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t plan_lds[];
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *sm = plan_lds + (threadIdx.x >> 6) * wave_lds;
+    uint8_t *so = FUSE ? sm + stage_bytes : sm;                  // where the predicted values go (FUSE: their own region)
+    uint8_t *sp = sm + 2u * stage_bytes + lane * 16u;            // FUSE: this lane's mismatch positions (one byte each)
     const uint32_t n = a.ix.n, k = a.ix.k, nblk = a.ix.n_blocks, null_blk = 4u * nblk;
     const uint8_t *arena = reinterpret_cast<const uint8_t *>(a.ix.arena);
     const uint8_t *qb = a.q;
@@ -108,11 +116,11 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
             wave_hi = __shfl(start + len, (int)last);
             out_lo = lo + __shfl(warm, 0);
             base16 = lo & ~15u;
-            staged = __ballot(bad) == 0 && wave_hi > lo && (uint64_t)(wave_hi - base16) + kPlanLdsSlack <= wave_lds;
+            staged = __ballot(bad) == 0 && wave_hi > lo && (uint64_t)(wave_hi - base16) + kPlanLdsSlack <= (FUSE ? stage_bytes : wave_lds);
             soff = start - base16;
         }
     }
-    const bool xpose = !staged && wave_lds >= 64u * 16u * (uint32_t)kPlanStep; // unstaged: outputs transposed through LDS
+    const bool xpose = !FUSE && !staged && wave_lds >= 64u * 16u * (uint32_t)kPlanStep; // unstaged: outputs transposed through LDS
     if (staged) {
         for (uint32_t c = lane * 16u; c < wave_hi - base16; c += 1024u) // (reads <= 15 bytes past the last item)
             *reinterpret_cast<uint4 *>(sm + c) = ld16u(qb, base16 + c);
@@ -271,7 +279,9 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                     // all three paths anyway, plan_kernel 227 -> 262 us, VALU 79.9 -> 87.6 M instructions.  Removed.)
                     while (mm) { // the item's mismatch list: entry 0 in the item record, entries 1..12 in the list
                         const uint32_t pos = base + (uint32_t)__ffs((int)mm) - 1u;
-                        if (cnt == 0) mm0 = pos;
+                        if (FUSE) {
+                            if (cnt < 16u) sp[cnt] = (uint8_t)pos;
+                        } else if (cnt == 0) mm0 = pos;
                         else if (cnt <= a.plan_list) list[cnt - 1u] = (uint16_t)pos;
                         cnt++;
                         mm &= mm - 1u;
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                     const uint32_t nb = olen > base ? min(16u, olen - base) : 0u;
                     const uint32_t lo = min(warm > base ? min(warm - base, 16u) : 0u, nb);
                     if (staged) {
-                        uint8_t *o = sm + soff + base;
+                        uint8_t *o = so + soff + base;
                         if (lo == 0 && nb == 16u) __builtin_memcpy(o, &o4, 16);
                         else st_range(o, o4, lo, nb);
                     } else if (xpose) { // (goes out below, with the other lanes' blocks)
@@ -319,17 +329,138 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
             __builtin_amdgcn_wave_barrier();
         }
     }
+    // ---- FUSE: the stretches behind the mismatches from the depth table (rule and counters: dtab_resolve_kernel).
+    // The wave's mismatches are dealt out to its lanes whatever item they belong to (a lane with five mismatches would
+    // otherwise keep 63 others waiting): work w belongs to the lane whose prefix of mismatch counts covers it.
+    uint32_t st_look = 0, st_written = 0;
+    bool flag = false;
+    if (FUSE) {
+        const uint32_t order = a.ix.dtab_order;
+        flag = have_item && len != 0 && (!staged || !seeded || cnt > a.plan_list + 1u); // (an unstaged wave cannot resolve here)
+        const uint32_t my_n = (plannable && !flag) ? cnt : 0u;
+        uint32_t incl = my_n; // inclusive scan of the counts over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += t;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        uint8_t *spw = sm + 2u * stage_bytes; // the wave's 64 x 16 bytes: positions 0 .. 12, flag at 13, prefix (u16) at 14
+        sp[13] = 0;
+        *reinterpret_cast<uint16_t *>(sp + 14) = (uint16_t)incl;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t omask = (1ull << (2u * order)) - 1ull;
+        for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
+            const uint32_t w = w0 + lane;
+            const bool work = w < total;
+            // owner: the first lane whose inclusive prefix exceeds w
+            uint32_t lo_l = 0, hi_l = 63;
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const uint32_t mid = (lo_l + hi_l) >> 1;
+                const uint32_t pm = *reinterpret_cast<const uint16_t *>(spw + mid * 16u + 14u);
+                if (pm > w) hi_l = mid;
+                else lo_l = mid + 1u;
+            }
+            const uint32_t owner = work ? lo_l : lane;
+            const uint32_t o_incl = __shfl(incl, (int)owner), o_n = __shfl(my_n, (int)owner), o_soff = __shfl(soff, (int)owner),
+                           o_len = __shfl(len, (int)owner), o_warm = __shfl(warm, (int)owner), o_start = __shfl(start, (int)owner);
+            if (work) {
+                const uint32_t t = w - (o_incl - o_n);
+                const uint8_t *osp = spw + owner * 16u;
+                const uint32_t m = osp[t], nxt = t + 1u < o_n ? (uint32_t)osp[t + 1u] : o_len;
+                const uint32_t P = min(min(order + 1u, 16u), min(nxt, o_len) - m); // bases looked up: m .. m + P - 1
+                const uint8_t *qs = sm + o_soff; // the item's bases (intact: the predictions went to `so`)
+                // the bases in front of m: `order` of them are enough (a run that reaches further back counts as "> order")
+                uint64_t code = 0;
+                uint32_t v = 0;
+                for (uint32_t x = m > order ? m - order : 0u; x < m; x++) {
+                    const uint32_t c = decode_base(qs[x]);
+                    code = (code << 2) | (c & 3u);
+                    v = c < 4u ? v + 1u : 0u;
+                }
+                uint32_t tv[16];               // the table's bytes
+                uint64_t meta0 = 0, meta1 = 0; // per base: min(v, 31) | extension base << 5 | no window << 7
+#pragma unroll
+                for (uint32_t j = 0; j < 16; j++) {
+                    tv[j] = 0;
+                    if (j < P) {
+                        const uint32_t i = m + j, c = decode_base(qs[i]);
+                        code = (code << 2) | (c & 3u);
+                        v = c < 4u ? v + 1u : 0u;
+                        const uint64_t key = code & omask;
+                        const bool nowin = (uint64_t)o_start + i + 1u < 32u; // (as the stand-alone kernel: the buffer's first bytes)
+                        const uint64_t me = (uint64_t)(min(v, 31u) | (((uint32_t)(code >> (2u * order)) & 3u) << 5) | (nowin ? 128u : 0u));
+                        if (j < 8) meta0 |= me << (8u * j);
+                        else meta1 |= me << (8u * (j - 8u));
+                        if (!nowin) {
+                            tv[j] = a.ix.dtab_grouped ? a.ix.dtab[dtab_grouped_addr(key, i % 3u, order)] : a.ix.dtab[key];
+                            st_look++;
+                        }
+                    }
+                }
+                // the bases in front of the first one where the longest present suffix is the j bases behind the mismatch
+                bool done = false, sat_any = false;
+                uint32_t n_out = 0;
+                uint32_t outv[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (uint32_t j = 0; j < 16; j++) {
+                    if (j < P && !done && !sat_any) {
+                        const uint32_t me = (uint32_t)((j < 8 ? meta0 >> (8u * j) : meta1 >> (8u * (j - 8u))) & 0xFFu);
+                        const uint32_t vv = me & 31u, eb = (me >> 5) & 3u, byte = tv[j];
+                        uint32_t L = 0;
+                        bool sat = (me & 128u) != 0;
+                        if (!sat) {
+                            if (byte & 0x80u) {
+                                if (vv <= order || order >= k) L = min(vv, order);
+                                else if ((byte >> eb) & 1u) sat = true;
+                                else L = order;
+                            } else {
+                                L = min(byte, vv);
+                            }
+                        }
+                        if (sat) sat_any = true;
+                        else {
+                            outv[j >> 2] |= min(L, k) << (8u * (j & 3u));
+                            n_out = j + 1u;
+                            done = L <= j;
+                        }
+                    }
+                }
+                if (sat_any) spw[owner * 16u + 13u] = 1; // the owner's item goes to the plain walk
+                else {
+#pragma unroll
+                    for (uint32_t j = 0; j < 16; j++)
+                        if (j < n_out && m + j >= o_warm) {
+                            so[o_soff + m + j] = (uint8_t)(outv[j >> 2] >> (8u * (j & 3u)));
+                            st_written++;
+                        }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        flag = flag || sp[13] != 0;
+    }
     if (staged) { // the wave's output bytes [out_lo, wave_hi), in blocks aligned like the staged copy
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (uint32_t c = lane * 16u; c < wave_hi - base16; c += 1024u) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(sm + c);
+            const uint4 v = *reinterpret_cast<const uint4 *>(so + c);
             const uint32_t g0 = base16 + c;
             if (g0 >= out_lo && g0 + 16u <= wave_hi) __builtin_memcpy(a.d_out + g0, &v, 16);
             else st_range(a.d_out + g0, v, out_lo > g0 ? min(out_lo - g0, 16u) : 0u, min(wave_hi - g0, 16u));
         }
     }
     plan_stats_add(a.pstats, kPlanStatSeedLookups, st_lookups, kPlanStatSeedExtensions, st_ext, kPlanStatMismatches, cnt, 0, 0);
+    if (FUSE) {
+        plan_stats_add(a.pstats, kPlanStatTabLookups, st_look, kPlanStatTabWritten, st_written, kPlanStatTabFlagged, flag ? 1u : 0u, 0, 0);
+        const uint64_t fm = __ballot(flag);
+        if (fm && lane == 0) atomicAdd(a.qctl + 4, (uint32_t)__popcll(fm));
+        if (have_item) a.redo[idx] = flag ? 1 : 0;
+        return; // (no record, no list: nothing reads them in this form)
+    }
     if (!have_item) return;
     const uint32_t j_conv = (seeded && clean && (cnt == 0 || mm0 > j0)) ? j0 + 1u : 0u;
     const uint32_t n_mm = seeded ? min(cnt, 254u) : kPlanNone;
@@ -1337,19 +1468,33 @@ static hipError_t launch_plan_kernel(WalkArgs &a, hipStream_t stream)
     // LDS for the staged stretch of every wave: 64 items of at most max_item_len bases (not known, or too long for
     // four waves to share 64 KiB: no staging)
     // items that cannot be staged: 10 KB per wave for the transposed write-out of a step's predicted values
-    uint32_t wave_lds = 64u * 16u * (uint32_t)kPlanStep, stage_ok = 0;
+    uint32_t wave_lds = 64u * 16u * (uint32_t)kPlanStep, stage_ok = 0, stage_bytes = 0;
+    bool fuse = false;
     static const int env_stage = std::getenv("KBO_PLAN_STAGE") ? std::atoi(std::getenv("KBO_PLAN_STAGE")) : -1; // experiments
+    static const int env_fuse = std::getenv("KBO_PLAN_FUSE") ? std::atoi(std::getenv("KBO_PLAN_FUSE")) : 1;      // experiments
     if (a.max_item_len != 0 && (env_stage >= 0 ? env_stage != 0 : g_plan_stage.load() != 0)) {
         const uint64_t need = (64ull * a.max_item_len + 16u + kPlanLdsSlack + 15u) / 16u * 16u;
         if (need <= 16384u) {
             wave_lds = std::max<uint32_t>(wave_lds, (uint32_t)need);
             stage_ok = 1;
+            // table mode, reads: queries and predictions side by side, the look-ups in this kernel (two workgroups of four
+            // waves still share a CU's 160 KB)
+            if (a.table_mode && !a.call_sites && env_fuse != 0 && a.max_item_len <= 16u * (uint32_t)kPlanStep &&
+                a.ix.dtab_order <= 15u && 4u * (2u * need + 1024u) <= 81920u) {
+                fuse = true;
+                stage_bytes = (uint32_t)need;
+                wave_lds = 2u * stage_bytes + 1024u;
+            }
         }
     }
     if (env_stage == 0) wave_lds = 0; // (experiments: neither staging nor the transposed write-out)
     static const int env_blk = std::getenv("KBO_PLAN_BLOCK") ? std::atoi(std::getenv("KBO_PLAN_BLOCK")) : 0; // experiments
     const uint32_t bt = env_blk == 64 || env_blk == 128 ? (uint32_t)env_blk : 256u;
-    hipLaunchKernelGGL(plan_kernel, dim3((a.n_items + bt - 1u) / bt), dim3(bt), (bt / 64u) * wave_lds, stream, a, wave_lds, stage_ok);
+    a.table_fused = fuse ? 1u : 0u;
+    if (fuse)
+        hipLaunchKernelGGL(plan_kernel<true>, dim3((a.n_items + bt - 1u) / bt), dim3(bt), (bt / 64u) * wave_lds, stream, a, wave_lds, stage_ok, stage_bytes);
+    else
+        hipLaunchKernelGGL(plan_kernel<false>, dim3((a.n_items + bt - 1u) / bt), dim3(bt), (bt / 64u) * wave_lds, stream, a, wave_lds, stage_ok, 0u);
     return hipGetLastError();
 }
 
@@ -1380,8 +1525,10 @@ hipError_t launch_plan_table(WalkArgs &a, hipStream_t stream)
     a.unit_bail = a.n_items / 2u + 64u;
     hipError_t e = launch_plan_kernel(a, stream);
     if (e != hipSuccess) return e;
-    e = launch_dtab_resolve(a, stream);
-    if (e != hipSuccess) return e;
+    if (!a.table_fused) { // (reads: plan_kernel has done the look-ups itself)
+        e = launch_dtab_resolve(a, stream);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(redo_collect_kernel, dim3((a.n_items + kRedoBlock - 1u) / kRedoBlock), dim3(kRedoBlock), 0, stream, a);
     return hipGetLastError();
 }

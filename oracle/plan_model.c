@@ -396,7 +396,7 @@ static void pm_resolve_item(const pm_index *m, const ora_plan_params *P, const u
     pl->tab_flagged = 0;
     if (len == 0) return;
     if (!pl->seeded || pl->n_mm > P->list_cap) { pl->tab_flagged = 1; cn->tab_flagged++; return; }
-    for (uint32_t t = 0; t < pl->n_mm && !pl->tab_flagged; t++) {
+    for (uint32_t t = 0; t < pl->n_mm; t++) { /* (every mismatch on its own, flagged item or not) */
         const uint32_t mpos = pl->mm[t], nxt = t + 1u < pl->n_mm ? pl->mm[t + 1u] : len;
         uint32_t hi = mpos + order + 1u;
         if (hi > nxt) hi = nxt;
@@ -421,7 +421,7 @@ static void pm_resolve_item(const pm_index *m, const ora_plan_params *P, const u
             if (sat) { if (first_sat == ~0u) first_sat = j; }
             else if (Lv[j] <= j && first_conv == ~0u) first_conv = j;
         }
-        if (first_sat < first_conv) { pl->tab_flagged = 1; cn->tab_flagged++; break; }
+        if (first_sat < first_conv) { if (!pl->tab_flagged) cn->tab_flagged++; pl->tab_flagged = 1; continue; }
         for (uint32_t i = mpos; i < hi && i - mpos <= first_conv; i++) {
             ms[i] = (uint8_t)(Lv[i - mpos] < k ? Lv[i - mpos] : k);
             cn->tab_written++;
