@@ -45,11 +45,17 @@ const kbo_index_t *kbo_index_shard(const kbo_index_t *idx, int i);
  * longest suffix of it that is a suffix of a row of the index, 4^order bytes of device memory.  With it, the stretches behind
  * a read's mismatches against the plan's diagonal - where the matching statistic is the length of a random match, about
  * log4(rows) - cost one independent byte look-up per base instead of a chain of dependent rank look-ups; values deeper than
- * `order` send their read to the plain walk.  0 = by index size (log4(rows) + 3.2 rounded up, at most 17 and k; none from
- * about 300 M rows on, or when it would take more than half of the free device memory), 1 .. 17 = that order (capped at k),
+ * `order` send their read to the plain walk.  0 = by index size (log4(rows) + 3.2 rounded up, at most 15 and k; none from
+ * 24 Mi rows on - there the guided walk over recovery lines is faster - or when it would take more than half of the free device
+ * memory), 1 .. 17 = that order (capped at k),
  * < 0 = none: new copies get no table and launches over copies that have one do not use it (until the knob is >= 0 again).
  * Results are identical with and without it. */
 int kbo_set_depth_table(int order);
+/* ... with ANCHORS (device copies made after the call): a hash of the strings of `order` bases that are the suffix of exactly
+ * one row, with that row's place in the path cover; a base deeper than the table knows is then read off the path-cover text
+ * instead of sending its read to the plain walk (a tenth of those reads remain).  -1 = when the table's margin over log4(rows)
+ * is below 3.4 bases (default), 0 = never, 1 = always. */
+int kbo_set_depth_table_anchors(int mode);
 /* inspection / tests: the depth table of the copy of `idx` on `device` (-1 = current; the copy is made if there is none):
  * *order bases per entry (0: the copy has no table), 4^*order bytes; entry of a string (2-bit digits A, C, G, T = 0 .. 3, the
  * last base least significant) = length of its longest suffix that is a suffix of a row of the index, or 0x80 | e when the
@@ -94,9 +100,10 @@ int kbo_set_plan_stats(int on);
  * (recovery-line form), seed-table look-ups, seed extensions, mismatches against the diagonals;  out[8]: units emitted,
  * [9]: entries of the redo list, [10]: 1 = the plan was given up, [11]: 1 = a walk left through its guard;  depth-table form
  * (kbo_set_depth_table) out[12]: table look-ups, [13]: values written from the table, [14] = [15]: items the table could not
- * resolve (counted by the lanes / by the launch's control word; out[8] is meaningless in that form).  Meaningless
+ * resolve (counted by the lanes / by the launch's control word; out[8] is meaningless in that form), [16]: bases read off the
+ * path-cover text (anchors), [17]: items resolved without a plan.  Meaningless
  * (stale or zero) when that launch did not plan (plain walk, hold-off, intervals requested) or did not count. */
-#define KBO_PLAN_STATS 16
+#define KBO_PLAN_STATS 20
 int kbo_plan_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k, const void *d_work,
                        uint64_t out[KBO_PLAN_STATS], void *stream);
 

@@ -86,7 +86,7 @@ SYMBOLS = [
 TUNING_SYMBOLS = [
     "kbo_walk_geometry", "kbo_set_walk_waves_per_cu", "kbo_set_walk_threads", "kbo_set_walk_rare", "kbo_set_guided_walk",
     "kbo_set_pair_steps", "kbo_set_force_big_layout", "kbo_set_seed_table_depth", "kbo_set_plan", "kbo_set_plan_tuning",
-    "kbo_set_plan_unit_cap_divisor", "kbo_index_plan_holdoff", "kbo_set_walk_experiment", "kbo_plan_stats_dev", "kbo_set_plan_stats", "kbo_set_index_shards", "kbo_index_shard", "kbo_set_depth_table", "kbo_index_depth_table", "kbo_run_automaton_depths",
+    "kbo_set_plan_unit_cap_divisor", "kbo_index_plan_holdoff", "kbo_set_walk_experiment", "kbo_plan_stats_dev", "kbo_set_plan_stats", "kbo_set_index_shards", "kbo_index_shard", "kbo_set_depth_table", "kbo_set_depth_table_anchors", "kbo_index_depth_table", "kbo_run_automaton_depths",
 ]
 
 _lib = None
@@ -187,6 +187,7 @@ def lib():
     L.kbo_set_plan_stats.argtypes = [C.c_int]
     L.kbo_set_index_shards.argtypes = [C.c_int]
     L.kbo_set_depth_table.argtypes = [C.c_int]
+    L.kbo_set_depth_table_anchors.argtypes = [C.c_int]
     L.kbo_index_depth_table.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.kbo_index_shards.argtypes = [vp]
     L.kbo_index_shard.argtypes = [vp, C.c_int]; L.kbo_index_shard.restype = vp

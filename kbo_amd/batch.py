@@ -201,12 +201,12 @@ class DeviceBatch:
     def plan_stats(self, stream=None):
         """Work counters of the last walk() when it took the plan-guided stage (kbo_hip_tuning.h kbo_plan_stats_dev)."""
         s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
-        out = np.zeros(16, dtype=np.uint64)
+        out = np.zeros(20, dtype=np.uint64)
         check(lib().kbo_plan_stats_dev(self.n_seqs, self.total, self.max_len, self.k, self.work.data_ptr(), out.ctypes.data,
                                        s.cuda_stream))
         names = ("units_walked", "accepted", "failed", "levels", "entry_levels", "seed_lookups", "seed_extensions",
                  "mismatches", "units", "redo_entries", "gave_up", "guard", "tab_lookups", "tab_written", "tab_flagged",
-                 "tab_unresolved")
+                 "tab_unresolved", "tab_anchored", "items_noplan")
         return {n: int(v) for n, v in zip(names, out)}
 
     def derand_translate(self, stream=None):

@@ -36,6 +36,8 @@ struct DevCopy {
     DevBuf dtab;                     // depth table (dtab_kernels.hip): 4^dtab_order bytes
     uint32_t dtab_order = 0;
     bool dtab_grouped = false;
+    DevBuf anchor;                   // anchors of the depth table (kernels.hpp DevIndexView::anchor): 2^anchor_bits slots of 8 bytes
+    uint32_t anchor_bits = 0;
     DevBuf fat;                      // recovery lines of the guided walk (sbwt_index.hpp)
     uint32_t fat_null = 0;
     DevBuf pc_text, pc_pos, pc_node; // path cover (sbwt_index.hpp PathCover), empty when the plan-guided walk is off
@@ -99,6 +101,7 @@ extern std::atomic<size_t> g_slab_bytes;          // host batches are cut into s
 extern std::atomic<int> g_plan_cap_div;           // tests: the unit array gets 1/this of its normal capacity
 extern std::atomic<int> g_index_shards;           // tests: kbo_index_build makes at least this many shards (0 = by size)
 extern std::atomic<bool> g_plan_stats;            // launches of the plan-guided stage count their own work (kbo_set_plan_stats)
+extern std::atomic<int> g_depth_table_anchors;    // ... with anchors: -1 by margin, 0 no, 1 yes
 extern std::atomic<int> g_depth_table;            // depth table of new device copies: 0 = by index size, < 0 none, else its order
 extern std::atomic<int> g_seed_table_depth;       // tests: bases per seed-table entry of new device copies (0 = by index size)
 extern std::atomic<bool> g_plan_enabled;          // device copies carry a path cover and MS-only batches take the plan-guided walk

@@ -17,6 +17,7 @@ std::atomic<bool> g_plan_enabled{true};
 std::atomic<int> g_plan_cap_div{1};
 std::atomic<int> g_seed_table_depth{0};
 std::atomic<int> g_depth_table{0}; // depth table of device copies made from now on: 0 = by index size, < 0 = none, else its order
+std::atomic<int> g_depth_table_anchors{-1}; // ... with anchors: -1 = by the table's margin over log4(rows), 0 = no, 1 = yes
 std::atomic<bool> g_plan_stats{false};
 std::atomic<int> g_index_shards{0};
 
@@ -167,12 +168,15 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                 // of a row.  One independent byte look-up then gives the MS value of a base wherever the value is at most
                 // `order` - i.e. in the stretches behind mismatches, where the match is a random one: about log4(rows) long.
                 // order = log4(rows) + 3.2, rounded up (1.3 % of such stretches run deeper than log4(rows) + 4, 5 % deeper than
-                // + 3, 17 % deeper than + 2: those reads take the plain walk), at most 17 (16 GiB) and at most k; no table where
-                // that leaves less than log4(rows) + 2.9 (300 M rows and more: the guided walk over recovery lines stays).
+                // + 3, 17 % deeper than + 2: those reads take the plain walk), at most 15 (grouped: 4 GiB - look-ups into
+                // 16 GiB and more run at half the rate: C2 with 16 bases 1.16 ms against 0.88) and at most k.  Only for indexes
+                // below 24 Mi rows, the ones the guided walk reads through rank blocks and entries: from there on the walk over
+                // recovery lines is faster than any table (100 Mbp index, A1 per 10 M reads: 10.2 ms against 12.2 - 14.7 with
+                // tables of 16 / 17 bases, plain or grouped), and none where 15 bases are less than log4(rows) + 2.9.
                 {
                     const double lg = std::log2((double)std::max<uint64_t>(idx->host.n_sets, 4)) / 2.0;
-                    int order = std::min<int>({(int)std::ceil(lg + 3.2), 17, (int)idx->host.k});
-                    if ((double)order < lg + 2.9 && order < (int)idx->host.k) order = 0;
+                    int order = std::min<int>({(int)std::ceil(lg + 3.2), 15, (int)idx->host.k});
+                    if (((double)order < lg + 2.9 && order < (int)idx->host.k) || idx->host.n_sets >= (24u << 20)) order = 0;
                     const int set = g_depth_table.load();
                     if (set < 0) order = 0;
                     else if (set > 0) order = std::min<int>({set, 17, (int)idx->host.k});
@@ -198,7 +202,22 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                         bv.n_blocks = (uint32_t)dc->n_blocks;
                         bv.n = (uint32_t)idx->host.n_sets;
                         bv.k = idx->host.k;
-                        HIP_OK(kbo::build_depth_table(bv, (uint32_t)order, plain.as<uint8_t>(), tmp.p, cap, nullptr));
+                        // anchors: the strings of `order` bases that are the suffix of one row only, with that row's place in
+                        // the path cover - what a base deeper than the table knows is read off (dtab_kernels.hip)
+                        const uint32_t abits = kbo::dtab_anchor_bits(idx->host.n_sets, (uint32_t)order);
+                        // (they pay where the table's margin is small - a tenth of the flagged reads - and cost 8 % of the plan
+                        // kernel's time for nothing at C2, where the redo pass is bound by its longest chain, not by its size)
+                        static const int env_anchor = std::getenv("KBO_DEPTH_TABLE_ANCHORS") ? std::atoi(std::getenv("KBO_DEPTH_TABLE_ANCHORS")) : -1; // experiments
+                        const int anch_set = env_anchor >= 0 ? env_anchor : g_depth_table_anchors.load();
+                        const bool want_anchors = anch_set >= 0 ? anch_set != 0 : (double)order < lg + 3.4;
+                        if (want_anchors && order < (int)idx->host.k) {
+                            dc->anchor.alloc(((size_t)1 << abits) * 8 + 64);
+                            dc->anchor_bits = abits;
+                            bv.pc_pos = dc->pc_pos.as<uint32_t>();
+                        }
+                        HIP_OK(kbo::build_depth_table(bv, (uint32_t)order, plain.as<uint8_t>(), tmp.p, cap, nullptr,
+                                                      dc->anchor_bits ? dc->anchor.as<uint64_t>() : nullptr, dc->anchor_bits));
+                        if (dc->anchor_bits) idx->plan_bytes += ((size_t)1 << abits) * 8;
                         if (grouped) {
                             tmp.release();
                             dc->dtab.alloc(kbo::dtab_bytes((uint32_t)order, true) + 64);
@@ -241,6 +260,8 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
     v.dtab = use_tab ? dc->dtab.as<uint8_t>() : nullptr;
     v.dtab_order = use_tab ? dc->dtab_order : 0u;
     v.dtab_grouped = dc->dtab_grouped ? 1u : 0u;
+    v.anchor = (use_tab && dc->anchor_bits) ? dc->anchor.as<uint64_t>() : nullptr;
+    v.anchor_bits = dc->anchor_bits;
     v.fat = dc->fat.p ? dc->fat.as<uint8_t>() : nullptr;
     v.fat_null = dc->fat_null;
     v.pc_node = dc->pc_node.as<uint32_t>();

@@ -97,6 +97,62 @@ __device__ __forceinline__ uint64_t dtab_grouped_addr(uint64_t key, uint32_t g, 
     if (g == 1) return (((key >> 2) & cm) << 6) + 16u + ((key >> (cb + 2u)) << 2) + (key & 3u);
     return ((key >> 4) << 6) + 32u + (key & 15u);
 }
+__device__ __forceinline__ uint64_t dtab_grouped_addr32(uint32_t key, uint32_t g, uint32_t order) // (order <= 16: 32-bit keys)
+{
+    const uint32_t cb = 2u * (order - 2u), cm = (uint32_t)((1ull << cb) - 1ull);
+    const uint32_t core = g == 0 ? key & cm : g == 1 ? (key >> 2) & cm : key >> 4;
+    const uint32_t slot = g == 0 ? key >> cb : g == 1 ? 16u + ((key >> (cb + 2u)) << 2) + (key & 3u) : 32u + (key & 15u);
+    return ((uint64_t)core << 6) + slot;
+}
+// The value of a base the depth table cannot tell (the string of dtab_order bases ending there is a suffix of a row, and so is
+// the string with one more base): when those dtab_order bases are the suffix of exactly one row (an anchor), every longer
+// suffix that is present is a suffix of THAT row, whose characters are the path-cover text in front of its position - read
+// off as long as the text is one path (a 0 is a path start: unknown).  qb(t) = the base t positions in front of the one in
+// question (qb(0) = itself), avail = how many there are (inside the item).  kDtabUnknown: no anchor / not one path.
+constexpr uint32_t kDtabUnknown = 0xFFFFFFFFu;
+template <typename GetBase>
+__device__ __forceinline__ uint32_t dtab_anchor_depth(const DevIndexView &ix, uint32_t avail, GetBase qb)
+{
+    const uint32_t order = ix.dtab_order, k = ix.k;
+    if (!ix.anchor) return kDtabUnknown;
+    uint64_t key = 0;
+    for (uint32_t t = order; t-- > 0;) key = (key << 2) | (decode_base(qb(t)) & 3u); // (all of them are bases: the table said so)
+    const uint64_t mask = ((uint64_t)1 << ix.anchor_bits) - 1ull;
+    uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> (64u - ix.anchor_bits);
+    const uint32_t tag = (uint32_t)key + 1u;
+    uint32_t p = 0;
+    bool found = false;
+    for (uint32_t probe = 0; probe < 64u; probe++) {
+        const uint64_t slot = ix.anchor[h];
+        if (slot == 0) break;
+        if ((uint32_t)(slot >> 32) == tag) {
+            p = (uint32_t)slot;
+            found = true;
+            break;
+        }
+        h = (h + 1u) & mask;
+    }
+    if (!found) return kDtabUnknown;
+    // the text in front of p, 16 bytes at a time (kPlanPad zero bytes in front of the text: a 0 ends it as a path start does)
+    for (uint32_t t0 = 0; t0 < k; t0 += 16u) {
+        uint4 tv = make_uint4(0, 0, 0, 0);
+        if (t0 + 15u <= p + kPlanPad) __builtin_memcpy(&tv, ix.pc_text + (int64_t)p - (int64_t)(t0 + 15u), 16); // text[p-t0-15 .. p-t0]
+#pragma unroll
+        for (uint32_t b = 0; b < 16; b++) {
+            const uint32_t t = t0 + b;
+            if (t >= k) return k;
+            if (t >= avail) return t;
+            const uint32_t qc = qb(t);
+            if (decode_base(qc) >= 4u) return t;
+            const uint32_t w = (15u - b) >> 2, sh = ((15u - b) & 3u) * 8u; // text[p - t] is byte 15 - b of the block
+            const uint32_t tc = ((w == 0 ? tv.x : w == 1 ? tv.y : w == 2 ? tv.z : tv.w) >> sh) & 0xFFu;
+            if (tc == 0) return kDtabUnknown;
+            if (tc != qc) return t >= order ? t : kDtabUnknown; // (in front of `order`: two keys with the same 32-bit tag)
+        }
+    }
+    return k;
+}
+
 // sum of v over the 64 lanes of the wave (all lanes must call it)
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {

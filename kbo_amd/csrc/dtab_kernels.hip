@@ -78,6 +78,23 @@ __global__ __launch_bounds__(256) void dtab_scatter_kernel(const DtabRec *recs, 
     if (t < n) tab[recs[t].key] = value;
 }
 
+// anchors: the strings of `order` characters that are the suffix of exactly one row -> hash slot {key tag, text position of the row}
+__global__ __launch_bounds__(256) void dtab_anchor_kernel(const DtabRec *recs, uint32_t n, const uint32_t *pc_pos, uint64_t *slots, uint32_t bits)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const DtabRec rec = recs[t];
+    if (rec.r != rec.l + 1u) return;
+    const uint64_t mask = ((uint64_t)1 << bits) - 1ull;
+    const uint64_t v = ((uint64_t)((uint32_t)rec.key + 1u) << 32) | pc_pos[rec.l];
+    uint64_t h = (rec.key * 0x9E3779B97F4A7C15ull) >> (64u - bits);
+    for (;;) { // (twice as many slots as strings: always ends)
+        const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(slots + h), 0ull, (unsigned long long)v);
+        if (old == 0ull) return;
+        h = (h + 1u) & mask;
+    }
+}
+
 // the present strings of order + 1 characters: bit (oldest base) of the entry of their last `order` bases
 __global__ __launch_bounds__(256) void dtab_ext_kernel(const DtabRec *recs, uint32_t n, uint32_t order, uint8_t *tab)
 {
@@ -165,29 +182,75 @@ __global__ __launch_bounds__(256) void dtab_resolve_kernel(WalkArgs a)
     const uint32_t gid = (blockIdx.x * blockDim.x + threadIdx.x) / GW, j = threadIdx.x & (GW - 1);
     const uint32_t sub = (threadIdx.x & 63u) / GW; // group inside the wave
     const uint32_t order = a.ix.dtab_order, k = a.ix.k;
-    uint32_t st_look = 0, st_written = 0, st_flag = 0;
+    uint32_t st_look = 0, st_written = 0, st_flag = 0, st_anch = 0;
     bool flag = false;
     const bool have = gid < a.n_items;
     uint4 g = make_uint4(0, 0, 0, kPlanNone << 24);
     if (have) g = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(a.gitems) + (size_t)gid * 16u);
     const uint32_t start = g.x, len = g.z & 0xFFFFu, mm0 = g.w & 0xFFFFu, warm = (g.w >> 16) & 0xFFu, n_mm = g.w >> 24;
     uint32_t n_loop = 0;
+    bool no_plan = false; // no diagonal / more mismatches than the list holds
     if (have && len != 0) {
-        if (n_mm == kPlanNone || n_mm > a.plan_list + 1u) flag = true; // no diagonal / more mismatches than the list holds
+        if (n_mm == kPlanNone || n_mm > a.plan_list + 1u) no_plan = true;
         else n_loop = n_mm;
     }
+    // the value of base i of the item as far as the table knows: false = L, true = deeper than the table tells
+    auto look = [&](uint32_t i, uint32_t &L) -> bool {
+        const uint64_t end1 = (uint64_t)start + i + 1u; // one past the base, in the query buffer
+        L = kDtabUnknown;
+        if (end1 < 32u) return true; // (the first bytes of the buffer: no 32 bytes in front of them; no anchor either)
+        L = 0;
+        const uint8_t *p = a.q + (end1 - 32u);
+        uint4 hi4, lo4;
+        __builtin_memcpy(&lo4, p, 16);      // the older 16 bases
+        __builtin_memcpy(&hi4, p + 16, 16); // the newer 16 bases
+        uint32_t c_old, v_old, c_new, v_new;
+        pack16(lo4, c_old, v_old);
+        pack16(hi4, c_new, v_new);
+        const uint64_t code = ((uint64_t)c_old << 32) | c_new;
+        // consecutive bases ending at the newest byte (bit 15 of v_new), then into the older block
+        const uint32_t run_new = (uint32_t)__clz((int)~(v_new << 16));
+        const uint32_t run_old = (uint32_t)__clz((int)~(v_old << 16));
+        uint32_t v = run_new < 16u ? run_new : 16u + min(run_old, 16u);
+        v = min(v, i + 1u);
+        const uint64_t key = code & ((1ull << (2u * order)) - 1ull);
+        const uint32_t byte = a.ix.dtab_grouped ? a.ix.dtab[dtab_grouped_addr(key, i % 3u, order)] : a.ix.dtab[key];
+        if (STATS) st_look++;
+        if (!(byte & 0x80u)) {
+            L = min(byte, v);
+            return false;
+        }
+        // all `order` bases of the window are a suffix of a row
+        if (v <= order || order >= k) {
+            L = min(v, order);
+            return false;
+        }
+        if (!((byte >> ((uint32_t)(code >> (2u * order)) & 3u)) & 1u)) {
+            L = order;
+            return false;
+        }
+        return true;
+    };
+    // ... and off the path-cover text when the window is an anchor (L == kDtabUnknown on entry: no window, stays unknown)
+    auto anchor = [&](uint32_t i, uint32_t &L) -> bool {
+        if (L == kDtabUnknown) return true;
+        const uint8_t *qi = a.q + (uint64_t)start + i;
+        L = dtab_anchor_depth(a.ix, i + 1u, [qi](uint32_t t) -> uint32_t { return qi[-(int64_t)t]; });
+        if (STATS) st_anch++;
+        return L == kDtabUnknown;
+    };
     // the list: lane t holds mismatch t (t <= 28 < GW * 2: two per lane when GW = 16)
     const uint16_t *list = a.glist + (size_t)gid * a.plan_list;
     uint32_t mine0 = kPlanInf, mine1 = kPlanInf;
     if (j < n_loop) mine0 = j == 0 ? mm0 : (uint32_t)list[j - 1u];
     if (GW == 16 && j + 16u < n_loop) mine1 = (uint32_t)list[j + 15u];
     const uint64_t gmask = (GW == 64 ? ~0ull : ((1ull << GW) - 1ull)) << (sub * GW);
-    const uint32_t max_loop = [&] { // (wave-uniform trip count)
-        uint32_t v = n_loop;
+    auto wave_max = [&](uint32_t v) { // (wave-uniform trip counts)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
         return v;
-    }();
+    };
+    const uint32_t max_loop = wave_max(n_loop);
     for (uint32_t t = 0; t < max_loop; t++) {
         const int src = (int)(sub * GW + (GW == 16 ? (t & 15u) : t));
         const uint32_t m_a = __shfl(mine0, src), m_b = __shfl(mine1, src);
@@ -200,38 +263,13 @@ __global__ __launch_bounds__(256) void dtab_resolve_kernel(WalkArgs a)
         const bool act = t < n_loop && j <= order && i < nxt && i < len; // (every mismatch on its own, flagged item or not)
         uint32_t L = 0;
         bool sat = false;
-        if (act) {
-            const uint64_t end1 = (uint64_t)start + i + 1u; // one past the base, in the query buffer
-            if (end1 < 32u) sat = true;                    // (the first bytes of the buffer: no 32 bytes in front of them)
-            else {
-                const uint8_t *p = a.q + (end1 - 32u);
-                uint4 hi4, lo4;
-                __builtin_memcpy(&lo4, p, 16);      // the older 16 bases
-                __builtin_memcpy(&hi4, p + 16, 16); // the newer 16 bases
-                uint32_t c_old, v_old, c_new, v_new;
-                pack16(lo4, c_old, v_old);
-                pack16(hi4, c_new, v_new);
-                const uint64_t code = ((uint64_t)c_old << 32) | c_new;
-                // consecutive bases ending at the newest byte (bit 15 of v_new), then into the older block
-                const uint32_t run_new = (uint32_t)__clz((int)~(v_new << 16));
-                const uint32_t run_old = (uint32_t)__clz((int)~(v_old << 16));
-                uint32_t v = run_new < 16u ? run_new : 16u + min(run_old, 16u);
-                v = min(v, i + 1u);
-                const uint64_t key = code & ((1ull << (2u * order)) - 1ull);
-                const uint32_t byte = a.ix.dtab_grouped ? a.ix.dtab[dtab_grouped_addr(key, i % 3u, order)] : a.ix.dtab[key];
-                if (STATS) st_look++;
-                if (byte & 0x80u) { // all `order` bases of the window are a suffix of a row
-                    if (v <= order || order >= k) L = min(v, order);
-                    else if ((byte >> ((uint32_t)(code >> (2u * order)) & 3u)) & 1u) sat = true;
-                    else L = order;
-                } else {
-                    L = min(byte, v);
-                }
-            }
-        }
+        if (act) sat = look(i, L);
         const bool conv = act && !sat && L <= j;
-        const uint64_t bc = __ballot(conv) & gmask, bs = __ballot(sat) & gmask;
+        const uint64_t bc = __ballot(conv) & gmask;
         const uint32_t first_conv = bc ? (uint32_t)__ffsll((long long)bc) - 1u - sub * GW : (uint32_t)GW;
+        // the bases in front of the first conv that the table cannot tell: the anchors (their values exceed `order`: no conv)
+        if (sat && j < first_conv) sat = anchor(i, L);
+        const uint64_t bs = __ballot(sat) & gmask;
         const uint32_t first_sat = bs ? (uint32_t)__ffsll((long long)bs) - 1u - sub * GW : (uint32_t)GW;
         if (first_sat < first_conv) flag = true; // (group-uniform: every lane of the group sees the same ballots)
         else if (act && j <= first_conv && i >= warm) {
@@ -239,15 +277,20 @@ __global__ __launch_bounds__(256) void dtab_resolve_kernel(WalkArgs a)
             if (STATS) st_written++;
         }
     }
+    if (no_plan) flag = true; // (a seed on a wrong diagonal, or none: the plain walk)
 
     if (flag && j == 0) {
         a.redo[gid] = 1;
         if (STATS) st_flag++;
     }
-    // items flagged by this wave -> qctl[4] (redo_collect_kernel gives the plan up when most of a launch is flagged)
-    const uint64_t fm = __ballot(flag && j == 0);
-    if (fm && (threadIdx.x & 63u) == 0) atomicAdd(a.qctl + 4, (uint32_t)__popcll(fm));
-    if (STATS) plan_stats_add(a.pstats, kPlanStatTabLookups, st_look, kPlanStatTabWritten, st_written, kPlanStatTabFlagged, st_flag, 0, 0);
+    // items flagged by this wave -> qctl[4] (redo_collect_kernel gives the plan up when most of a launch is flagged), items
+    // without a plan -> qctl[5] (the same: a batch of them is cheaper to walk plainly)
+    const uint64_t fm = __ballot(flag && j == 0), nm = __ballot(no_plan && j == 0);
+    if ((threadIdx.x & 63u) == 0) {
+        if (fm) atomicAdd(a.qctl + 4, (uint32_t)__popcll(fm));
+        if (nm) atomicAdd(a.qctl + 5, (uint32_t)__popcll(nm));
+    }
+    if (STATS) plan_stats_add(a.pstats, kPlanStatTabLookups, st_look, kPlanStatTabWritten, st_written, kPlanStatTabFlagged, st_flag, kPlanStatTabAnchored, st_anch);
 }
 
 } // namespace
@@ -267,8 +310,14 @@ hipError_t regroup_depth_table(const uint8_t *d_plain, uint32_t order, uint8_t *
     return e != hipSuccess ? e : hipGetLastError();
 }
 
-hipError_t build_depth_table(const DevIndexView &ix, uint32_t order, uint8_t *d_tab, void *d_tmp, uint64_t frontier_cap, hipStream_t stream)
+hipError_t build_depth_table(const DevIndexView &ix, uint32_t order, uint8_t *d_tab, void *d_tmp, uint64_t frontier_cap, hipStream_t stream,
+                             uint64_t *d_anchor, uint32_t anchor_bits)
 {
+    if (d_anchor) {
+        if (!ix.pc_pos || anchor_bits < 4u || anchor_bits > 40u) return hipErrorInvalidValue;
+        const hipError_t ea = hipMemsetAsync(d_anchor, 0, ((size_t)1 << anchor_bits) * 8, stream);
+        if (ea != hipSuccess) return ea;
+    }
     if (order == 0 || order > 17u || order > ix.k) return hipErrorInvalidValue;
     DtabRec *fa = reinterpret_cast<DtabRec *>(d_tmp), *fb = fa + frontier_cap;
     uint32_t *count = reinterpret_cast<uint32_t *>(fb + frontier_cap);
@@ -301,6 +350,8 @@ hipError_t build_depth_table(const DevIndexView &ix, uint32_t order, uint8_t *d_
             if (n_out)
                 hipLaunchKernelGGL(dtab_scatter_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, fb, n_out,
                                    (uint8_t)(s == order ? 0x80u : s), d_tab);
+            if (n_out && s == order && d_anchor)
+                hipLaunchKernelGGL(dtab_anchor_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, fb, n_out, ix.pc_pos, d_anchor, anchor_bits);
         } else if (n_out) {
             hipLaunchKernelGGL(dtab_ext_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, fb, n_out, order, d_tab);
         }

@@ -1149,8 +1149,10 @@ int kbo_plan_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, 
         for (uint32_t sl = 0; sl < kbo::kPlanStatSlots; sl++) {
             for (uint32_t i = 0; i < 8; i++) out[i] += st[sl * kbo::kPlanStatWords + i];
             for (uint32_t i = 0; i < 3; i++) out[12 + i] += st[sl * kbo::kPlanStatWords + kbo::kPlanStatTabLookups + i];
+            out[16] += st[sl * kbo::kPlanStatWords + kbo::kPlanStatTabAnchored];
         }
         out[15] = ctl[4];
+        out[17] = ctl[5];
         out[8] = (uint64_t)tot[0] + tot[1];
         out[9] = ctl[1];
         out[10] = ctl[2];
@@ -1368,6 +1370,12 @@ int kbo_set_plan_stats(int on)
 int kbo_set_depth_table(int order)
 {
     g_depth_table = order < 0 ? -1 : std::min(order, 17);
+    return KBO_OK;
+}
+
+int kbo_set_depth_table_anchors(int mode)
+{
+    g_depth_table_anchors = mode < 0 ? -1 : (mode != 0 ? 1 : 0);
     return KBO_OK;
 }
 

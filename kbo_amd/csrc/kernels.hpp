@@ -34,6 +34,12 @@ struct DevIndexView {
     const uint8_t *dtab;
     uint32_t dtab_order;
     uint32_t dtab_grouped; // 1: the entries of three consecutive bases share a 64-byte line (dtab_kernels.hip), 4^(order+1) bytes
+    // anchors of the depth table, nullptr / 0 when there are none: open-addressing hash (2^anchor_bits slots) of the strings of
+    // dtab_order bases that are the suffix of exactly ONE row: slot = (low 32 bits of key + 1) << 32 | text position of that
+    // row in the path cover.  A base whose value the table cannot tell (deeper than dtab_order) is read off the path-cover
+    // text in front of that position
+    const uint64_t *anchor;
+    uint32_t anchor_bits;
 };
 
 // One unit of walk work: `len` bases starting at absolute offset `start` of the
@@ -111,7 +117,7 @@ struct WalkArgs {
     uint32_t redo_cap;     // WalkItem records the unit array holds (the redo pass's list is built there)
     uint32_t unit_bail;    // more units than this in a launch: the plan is given up, every item takes the plain walk
     uint32_t *qctl;        // [0] queue head of the guided walk, [1] entries of the redo list, [2] plan given up, [3] a walk left through its guard,
-                           // [4] (table mode) items the table could not resolve
+                           // [4] (table mode) items the table could not resolve, [5] items without a plan
     uint32_t *pstats;      // work counters of the launch (kPlanStat*): kPlanStatSlots slots of 8 u32, summed by the host
     uint32_t plan_dmin;    // plan_kernel: a seed must be this deep (capped at k) before its row is trusted
     uint32_t plan_cap;     // plan_kernel: seed iterations before an item is given up as unplanned
@@ -127,6 +133,7 @@ struct WalkArgs {
     uint32_t call_thr;     // derandomisation threshold t of the predicate
     uint32_t table_mode;   // 1: the stretches behind mismatches come from the depth table (set by launch_ms_walk)
     uint32_t table_fused;  // 1: plan_kernel did the table look-ups itself (reads; set by launch_plan_table)
+    uint32_t redo_piece;   // table mode: output bases per piece of a flagged item in the redo pass
     uint32_t max_item_len; // 0 = not known, else no item is longer than this (plan_kernel sizes its LDS staging from it)
     const uint32_t *n_items_dev; // plain kernel: nullptr, or where the number of items is (the redo pass: qctl + 1)
 };
@@ -134,7 +141,7 @@ struct WalkArgs {
 // what the CPU model of the stage (oracle/plan_model.c) is pinned to, tests/test_gpu_model.py
 enum : uint32_t { kPlanStatUnits = 0, kPlanStatAccepted, kPlanStatFailed, kPlanStatLevels, kPlanStatEntryLevels,
                   kPlanStatSeedLookups, kPlanStatSeedExtensions, kPlanStatMismatches,
-                  kPlanStatTabLookups, kPlanStatTabWritten, kPlanStatTabFlagged, kPlanStatPad, kPlanStatWords };
+                  kPlanStatTabLookups, kPlanStatTabWritten, kPlanStatTabFlagged, kPlanStatTabAnchored, kPlanStatWords };
 constexpr uint32_t kPlanStatSlots = 8;
 // where the pieces of a launch's plan work live inside its work buffer (attach_plan)
 struct PlanLayout {
@@ -180,7 +187,16 @@ hipError_t launch_dtab_resolve(const WalkArgs &a, hipStream_t stream);
 size_t dtab_tmp_bytes(uint64_t frontier_cap);
 inline size_t dtab_bytes(uint32_t order, bool grouped) { return grouped ? (size_t)64 << (2u * (order - 2u)) : (size_t)1 << (2u * order); }
 hipError_t regroup_depth_table(const uint8_t *d_plain, uint32_t order, uint8_t *d_grouped, hipStream_t stream);
-hipError_t build_depth_table(const DevIndexView &ix, uint32_t order, uint8_t *d_tab, void *d_tmp, uint64_t frontier_cap, hipStream_t stream);
+hipError_t build_depth_table(const DevIndexView &ix, uint32_t order, uint8_t *d_tab, void *d_tmp, uint64_t frontier_cap, hipStream_t stream,
+                             uint64_t *d_anchor = nullptr, uint32_t anchor_bits = 0 /* ix.pc_pos must be set when d_anchor is */);
+// slots (log2) of the anchor hash of an index of n rows and a table of `order` bases: twice the strings it can hold
+inline uint32_t dtab_anchor_bits(uint64_t n_rows, uint32_t order)
+{
+    const uint64_t most = order >= 16u ? n_rows : (n_rows < ((uint64_t)1 << (2u * order)) ? n_rows : (uint64_t)1 << (2u * order));
+    uint32_t b = 4;
+    while (((uint64_t)1 << b) < 2 * most + 16) b++;
+    return b;
+}
 void set_guided_walk(int waves_per_cu, int recovery_lines); // tuning: see kbo_set_guided_walk
 bool guided_uses_recovery_lines(const WalkArgs &a);
 void set_plan_stage(int on); // experiments: plan_kernel with (default) / without its LDS staging

@@ -332,12 +332,15 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
     // ---- FUSE: the stretches behind the mismatches from the depth table (rule and counters: dtab_resolve_kernel).
     // The wave's mismatches are dealt out to its lanes whatever item they belong to (a lane with five mismatches would
     // otherwise keep 63 others waiting): work w belongs to the lane whose prefix of mismatch counts covers it.
-    uint32_t st_look = 0, st_written = 0;
-    bool flag = false;
+    uint32_t st_look = 0, st_written = 0, st_anch = 0;
+    bool flag = false, no_plan = false;
     if (FUSE) {
         const uint32_t order = a.ix.dtab_order;
-        flag = have_item && len != 0 && (!staged || !seeded || cnt > a.plan_list + 1u); // (an unstaged wave cannot resolve here)
-        const uint32_t my_n = (plannable && !flag) ? cnt : 0u;
+        flag = have_item && len != 0 && !staged; // (an unstaged wave cannot resolve here: its items take the plain walk)
+        // no diagonal / more mismatches than the list holds (a seed on a wrong diagonal): the plain walk
+        no_plan = plannable && staged && (!seeded || cnt > a.plan_list + 1u);
+        flag = flag || no_plan;
+        const uint32_t my_n = !plannable || flag ? 0u : cnt;
         uint32_t incl = my_n; // inclusive scan of the counts over the wave
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
         *reinterpret_cast<uint16_t *>(sp + 14) = (uint16_t)incl;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint64_t omask = (1ull << (2u * order)) - 1ull;
+        const uint32_t omask = (uint32_t)((1ull << (2u * order)) - 1ull);
         for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
             const uint32_t w = w0 + lane;
             const bool work = w < total;
@@ -369,12 +372,12 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
             if (work) {
                 const uint32_t t = w - (o_incl - o_n);
                 const uint8_t *osp = spw + owner * 16u;
-                const uint32_t m = osp[t], nxt = t + 1u < o_n ? (uint32_t)osp[t + 1u] : o_len;
+                const uint32_t m = (uint32_t)osp[t];
+                const uint32_t nxt = t + 1u >= o_n ? o_len : (uint32_t)osp[t + 1u];
                 const uint32_t P = min(min(order + 1u, 16u), min(nxt, o_len) - m); // bases looked up: m .. m + P - 1
                 const uint8_t *qs = sm + o_soff; // the item's bases (intact: the predictions went to `so`)
                 // the bases in front of m: `order` of them are enough (a run that reaches further back counts as "> order")
-                uint64_t code = 0;
-                uint32_t v = 0;
+                uint32_t code = 0, v = 0; // (order <= 15 here: `order` + 1 bases are 32 bits)
                 for (uint32_t x = m > order ? m - order : 0u; x < m; x++) {
                     const uint32_t c = decode_base(qs[x]);
                     code = (code << 2) | (c & 3u);
@@ -389,46 +392,57 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                         const uint32_t i = m + j, c = decode_base(qs[i]);
                         code = (code << 2) | (c & 3u);
                         v = c < 4u ? v + 1u : 0u;
-                        const uint64_t key = code & omask;
+                        const uint32_t key = code & omask;
                         const bool nowin = (uint64_t)o_start + i + 1u < 32u; // (as the stand-alone kernel: the buffer's first bytes)
-                        const uint64_t me = (uint64_t)(min(v, 31u) | (((uint32_t)(code >> (2u * order)) & 3u) << 5) | (nowin ? 128u : 0u));
+                        const uint64_t me = (uint64_t)(min(v, 31u) | (((code >> (2u * order)) & 3u) << 5) | (nowin ? 128u : 0u));
                         if (j < 8) meta0 |= me << (8u * j);
                         else meta1 |= me << (8u * (j - 8u));
                         if (!nowin) {
-                            tv[j] = a.ix.dtab_grouped ? a.ix.dtab[dtab_grouped_addr(key, i % 3u, order)] : a.ix.dtab[key];
+                            tv[j] = a.ix.dtab_grouped ? a.ix.dtab[dtab_grouped_addr32(key, i % 3u, order)] : a.ix.dtab[key];
                             st_look++;
                         }
                     }
                 }
-                // the bases in front of the first one where the longest present suffix is the j bases behind the mismatch
-                bool done = false, sat_any = false;
-                uint32_t n_out = 0;
+                // the bases in front of the first one where the longest present suffix is the j bases behind the mismatch:
+                // what the table tells ...
+                bool done = false, unk_any = false;
+                uint32_t n_out = 0, satmask = 0;
                 uint32_t outv[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (uint32_t j = 0; j < 16; j++) {
-                    if (j < P && !done && !sat_any) {
+                    if (j < P && !done) {
                         const uint32_t me = (uint32_t)((j < 8 ? meta0 >> (8u * j) : meta1 >> (8u * (j - 8u))) & 0xFFu);
                         const uint32_t vv = me & 31u, eb = (me >> 5) & 3u, byte = tv[j];
-                        uint32_t L = 0;
-                        bool sat = (me & 128u) != 0;
-                        if (!sat) {
-                            if (byte & 0x80u) {
-                                if (vv <= order || order >= k) L = min(vv, order);
-                                else if ((byte >> eb) & 1u) sat = true;
-                                else L = order;
-                            } else {
-                                L = min(byte, vv);
-                            }
-                        }
-                        if (sat) sat_any = true;
-                        else {
-                            outv[j >> 2] |= min(L, k) << (8u * (j & 3u));
-                            n_out = j + 1u;
-                            done = L <= j;
-                        }
+                        uint32_t L = k + 1u;
+                        if (me & 128u) unk_any = true; // (no window: unknown, and no end of the stretch here)
+                        else if (!(byte & 0x80u)) L = min(byte, vv);
+                        else if (vv <= order || order >= k) L = min(vv, order);
+                        else if ((byte >> eb) & 1u) {
+                            satmask |= 1u << j; // deeper than the table knows
+                            L = k + 1u;         // (more than j in any case: no end of the stretch here)
+                        } else L = order;
+                        outv[j >> 2] |= min(L, k) << (8u * (j & 3u));
+                        n_out = j + 1u;
+                        done = L <= j;
                     }
                 }
-                if (sat_any) spw[owner * 16u + 13u] = 1; // the owner's item goes to the plain walk
+                // ... and what it cannot: off the path-cover text where the window is an anchor
+                while (satmask) {
+                    const uint32_t j = (uint32_t)__ffs((int)satmask) - 1u;
+                    satmask &= satmask - 1u;
+                    const uint8_t *qi = qs + m + j;
+                    const uint32_t La = dtab_anchor_depth(a.ix, m + j + 1u, [qi](uint32_t t2) -> uint32_t { return qi[-(int32_t)t2]; });
+                    st_anch++;
+                    if (La == kDtabUnknown) unk_any = true;
+                    else { // (the slot holds k: anchored values are more than `order`, at most k)
+                        const uint32_t sh = 8u * (j & 3u), w = j >> 2, keep = ~(0xFFu << sh), val = La << sh;
+                        if (w == 0) outv[0] = (outv[0] & keep) | val;
+                        else if (w == 1) outv[1] = (outv[1] & keep) | val;
+                        else if (w == 2) outv[2] = (outv[2] & keep) | val;
+                        else outv[3] = (outv[3] & keep) | val;
+                    }
+                }
+                if (unk_any) spw[owner * 16u + 13u] = 1; // the owner's item goes to the plain walk
                 else {
 #pragma unroll
                     for (uint32_t j = 0; j < 16; j++)
@@ -455,9 +469,13 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
     }
     plan_stats_add(a.pstats, kPlanStatSeedLookups, st_lookups, kPlanStatSeedExtensions, st_ext, kPlanStatMismatches, cnt, 0, 0);
     if (FUSE) {
-        plan_stats_add(a.pstats, kPlanStatTabLookups, st_look, kPlanStatTabWritten, st_written, kPlanStatTabFlagged, flag ? 1u : 0u, 0, 0);
-        const uint64_t fm = __ballot(flag);
-        if (fm && lane == 0) atomicAdd(a.qctl + 4, (uint32_t)__popcll(fm));
+        plan_stats_add(a.pstats, kPlanStatTabLookups, st_look, kPlanStatTabWritten, st_written, kPlanStatTabFlagged, flag ? 1u : 0u,
+                       kPlanStatTabAnchored, st_anch);
+        const uint64_t fm = __ballot(flag), nm = __ballot(no_plan);
+        if (lane == 0) {
+            if (fm) atomicAdd(a.qctl + 4, (uint32_t)__popcll(fm));
+            if (nm) atomicAdd(a.qctl + 5, (uint32_t)__popcll(nm));
+        }
         if (have_item) a.redo[idx] = flag ? 1 : 0;
         return; // (no record, no list: nothing reads them in this form)
     }
@@ -610,7 +628,7 @@ __global__ __launch_bounds__(1024) void redo_collect_kernel(WalkArgs a)
     if (have) it = ld16(reinterpret_cast<const uint8_t *>(a.items), idx * 16u);
     // plan given up: all items, in order.  The same when a wave of the guided walk left through its no-progress guard
     // (qctl[3]; it cannot, but then units are unwalked): every item is walked again in full, so the batch stays exact.
-    // (table mode: the plan is given up when the table left more than unit_bail items unresolved)
+    // (table mode: the plan is given up when more than unit_bail items had no plan or were left unresolved by the table)
     const bool gave_up = a.table_mode ? a.qctl[4] > a.unit_bail
                                       : a.usums[(2u * a.n_items) / kScanBlock] + a.ucount[2u * a.n_items] > a.unit_bail;
     if (gave_up || a.qctl[3]) { // (block-uniform)
@@ -629,7 +647,7 @@ __global__ __launch_bounds__(1024) void redo_collect_kernel(WalkArgs a)
     // a flagged item longer than a piece and a half is cut into pieces with their own warm-up: the pass is bound by the
     // longest chain of dependent look-ups, not by their number (pieces of 64 bases when a handful of items come here, of 32
     // in table mode)
-    const uint32_t piece = a.table_mode ? kRedoPieceTable : kRedoPiece;
+    const uint32_t piece = a.table_mode ? a.redo_piece : kRedoPiece;
     const uint32_t np = !f ? 0u : (body > piece + piece / 2u ? (body + piece - 1u) / piece : 1u);
     uint32_t incl = np; // inclusive scan over the wave
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -1523,6 +1541,8 @@ hipError_t launch_plan_table(WalkArgs &a, hipStream_t stream)
     if (a.n_items == 0) return hipSuccess;
     a.table_mode = 1;
     a.unit_bail = a.n_items / 2u + 64u;
+    static const int env_piece = std::getenv("KBO_REDO_PIECE") ? std::atoi(std::getenv("KBO_REDO_PIECE")) : 0; // experiments
+    a.redo_piece = env_piece >= 4 ? (uint32_t)env_piece : kRedoPieceTable;
     hipError_t e = launch_plan_kernel(a, stream);
     if (e != hipSuccess) return e;
     if (!a.table_fused) { // (reads: plan_kernel has done the look-ups itself)

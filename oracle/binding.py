@@ -23,7 +23,7 @@ class Counters(C.Structure):
 
 class PlanParams(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("seed_table_depth", "seed_depth", "seed_cap", "gap", "chunk", "list_cap", "bail_x16",
-                                          "recovery_lines", "depth_table")]
+                                          "recovery_lines", "depth_table", "depth_anchors")]
 
 
 class PlanCounts(C.Structure):
@@ -33,7 +33,7 @@ class PlanCounts(C.Structure):
         "units_counted", "units", "units_head", "units_plain", "node_lookups",
         "walk_accepted", "walk_failed", "walk_contractions", "walk_entry_levels", "walk_short_windows", "walk_iterations_lines",
         "walk_out_bytes", "unit_distinct_lines", "unit_distinct_rank_lines", "redo_bases", "redo_iterations",
-        "tab_lookups", "tab_written", "tab_flagged")]
+        "tab_lookups", "tab_written", "tab_flagged", "tab_anchored", "items_noplan")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -303,13 +303,19 @@ def shipped_depth_table_order(k, n_sets):
     """device_index.cpp: order of the depth table a device copy of an index of n_sets rows gets by default (0 = none)"""
     import math
     lg = math.log2(max(n_sets, 4)) / 2.0
-    order = min(int(math.ceil(lg + 3.2)), 17, k)
-    if order < lg + 2.9 and order < k:
+    order = min(int(math.ceil(lg + 3.2)), 15, k)
+    if (order < lg + 2.9 and order < k) or n_sets >= (24 << 20):
         order = 0
     return order
 
 
-def shipped_plan_params(k, n_sets, recovery_lines=None, depth_table=None):
+def shipped_depth_table_anchors(k, n_sets, order):
+    """device_index.cpp: whether a device copy's depth table of `order` bases gets anchors by default"""
+    import math
+    return bool(order and order < k and order < math.log2(max(n_sets, 4)) / 2.0 + 3.4)
+
+
+def shipped_plan_params(k, n_sets, recovery_lines=None, depth_table=None, depth_anchors=None):
     """The parameters the product's plan-guided stage runs with by default on an index of n_sets rows (device_index.cpp:
     seed table depth; plan_kernels.hip launch_plan: seed depth, gap; walk_kernels.hip: recovery lines from 24 Mi rows)."""
     import math
@@ -321,7 +327,9 @@ def shipped_plan_params(k, n_sets, recovery_lines=None, depth_table=None):
         d = 12
     return PlanParams(seed_table_depth=d, seed_depth=half_log + 3, seed_cap=64, gap=half_log + 9, chunk=32, list_cap=13,
                       bail_x16=50, recovery_lines=int(n_sets >= (24 << 20)) if recovery_lines is None else int(recovery_lines),
-                      depth_table=shipped_depth_table_order(k, n_sets) if depth_table is None else int(depth_table))
+                      depth_table=shipped_depth_table_order(k, n_sets) if depth_table is None else int(depth_table),
+                      depth_anchors=int(shipped_depth_table_anchors(k, n_sets, shipped_depth_table_order(k, n_sets) if depth_table is None
+                                                                    else int(depth_table)) if depth_anchors is None else depth_anchors))
 
 
 def _plan_model(self, cover, params, concat, offsets, n_threads=1):

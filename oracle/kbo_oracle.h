@@ -165,6 +165,7 @@ typedef struct {
     uint32_t recovery_lines;   /* 0: rank blocks + entries (ms_walk_guided_kernel); 1: recovery lines (>= 24 Mi rows) */
     uint32_t depth_table;      /* 0: units + guided walk; else the order of the depth table (dtab_kernels.hip): the bases
                                 * behind mismatches are looked up, no units                                             */
+    uint32_t depth_anchors;    /* ... with anchors: a base deeper than the table knows is read off the path-cover text     */
 } ora_plan_params;
 
 typedef struct { /* all u64; per launch (the batch handed in) */
@@ -176,6 +177,7 @@ typedef struct { /* all u64; per launch (the batch handed in) */
     uint64_t unit_distinct_rank_lines;            /* ... of which rank-block lines (3.3 MB at C2: they stay in a 4 MiB L2) */
     uint64_t redo_bases, redo_iterations;
     uint64_t tab_lookups, tab_written, tab_flagged; /* depth-table form: look-ups, values written from them, items it could not resolve */
+    uint64_t tab_anchored, items_noplan;            /* ... bases deeper than the table knows (tried through the anchors), items without a plan */
 } ora_plan_counts;
 
 /* text / pos / node_at: the path cover of the index (n_sets entries each: kbo_index_path_cover of the product, whose

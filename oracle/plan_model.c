@@ -384,44 +384,87 @@ static void pm_walk_plain(const pm_index *m, const uint8_t *q, uint32_t len, uin
 }
 
 /* ------------------------------------------------------------------ depth-table form (dtab_kernels.hip) */
-/* dtab_resolve_kernel on one item: lane j of mismatch m has base i = m + j (up to the next mismatch, the item's end and
- * order + 1 bases); its look-up gives L = the longest suffix of the bases up to i (inside the item, behind the last non-ACGT
- * byte) that is a suffix of a row, as far as the table knows: exactly when it is at most `order`, "deeper" otherwise (the
- * item is flagged) - modelled by a literal walk from the root that starts order + 1 bases in front of the mismatch.  The
- * lanes in front of the first one with L <= j write their values.  abs0 = offset of the item in the query buffer. */
+#define PM_UNKNOWN 0xFFFFFFFFu
+/* dtab_anchor_depth: the `order` bases ending at base i are the suffix of exactly one row (else: unknown) - every longer
+ * suffix that is present is a suffix of that row, whose characters are the path-cover text in front of its position */
+static uint32_t pm_anchor_depth(const pm_index *m, uint32_t order, const uint8_t *q, uint32_t i)
+{
+    uint32_t l = 0, r = m->n;
+    for (uint32_t x = i + 1u - order; x <= i; x++) {
+        const int c = pm_code(q[x]);
+        if (c >= 4) return PM_UNKNOWN;
+        const uint32_t l2 = (uint32_t)m->C[c] + pm_rank(m, c, l), r2 = (uint32_t)m->C[c] + pm_rank(m, c, r);
+        if (l2 >= r2) return PM_UNKNOWN;
+        l = l2; r = r2;
+    }
+    if (r != l + 1u) return PM_UNKNOWN;
+    const uint32_t p = m->pos[l];
+    for (uint32_t t = 0; t < m->k; t++) {
+        if (t > i) return t;
+        const uint8_t qc = q[i - t];
+        if (pm_code(qc) >= 4) return t;
+        const uint8_t tc = t <= p ? m->text[p - t] : 0;
+        if (tc == 0) return PM_UNKNOWN;
+        if (tc != qc) return t >= order ? t : PM_UNKNOWN;
+    }
+    return m->k;
+}
+
+/* the literal walk over q[from, to) from the root, depths into tmp (uncounted: it stands for the table's content) */
+static void pm_window_walk(const pm_index *m, const uint8_t *q, uint32_t from, uint32_t to, uint8_t *tmp)
+{
+    pm_unit u;
+    memset(&u, 0, sizeof u);
+    u.pos = from; u.out_from = from; u.bound = to; u.last_mm = -1; u.head = 1; u.plain = 1;
+    pm_state s0 = {0, m->n, 0};
+    ora_plan_counts c2;
+    memset(&c2, 0, sizeof c2);
+    pm_set dummy;
+    pm_set_clear(&dummy);
+    pm_walk_blocks(m, q, &u, s0, tmp, &c2, &dummy);
+}
+
+/* dtab_resolve_kernel / the fused plan_kernel on one item.  With a plan: lane j of mismatch m has base i = m + j (up to the
+ * next mismatch, the item's end and order + 1 bases); the table gives L = the longest suffix of the bases up to i (inside the
+ * item, behind the last non-ACGT byte) that is a suffix of a row when that is at most `order` - modelled by a literal walk from
+ * the root that starts order + 1 bases in front of the mismatch; the bases in front of the first one with L <= j that the table
+ * cannot tell are read off the path-cover text (anchors); one that stays unknown flags the item, else the bases up to that
+ * first one are written.  abs0 = offset of the item in the query buffer. */
 static void pm_resolve_item(const pm_index *m, const ora_plan_params *P, const uint8_t *q, uint32_t len, uint64_t abs0, uint8_t *ms,
                             pm_plan *pl, uint8_t *tmp /* len bytes */, ora_plan_counts *cn)
 {
     const uint32_t order = P->depth_table < m->k ? P->depth_table : m->k, k = m->k;
+    const int anchors = order < k && P->depth_anchors;
     pl->tab_flagged = 0;
     if (len == 0) return;
-    if (!pl->seeded || pl->n_mm > P->list_cap) { pl->tab_flagged = 1; cn->tab_flagged++; return; }
+    if (!pl->seeded || pl->n_mm > P->list_cap) { cn->items_noplan++; pl->tab_flagged = 1; cn->tab_flagged++; return; } /* no plan: the plain walk */
     for (uint32_t t = 0; t < pl->n_mm; t++) { /* (every mismatch on its own, flagged item or not) */
         const uint32_t mpos = pl->mm[t], nxt = t + 1u < pl->n_mm ? pl->mm[t + 1u] : len;
         uint32_t hi = mpos + order + 1u;
         if (hi > nxt) hi = nxt;
         if (hi > len) hi = len;
-        pm_unit u;
-        memset(&u, 0, sizeof u);
-        u.pos = mpos > order + 1u ? mpos - (order + 1u) : 0u;
-        u.out_from = u.pos;
-        u.bound = hi; u.last_mm = -1; u.head = 1; u.plain = 1;
-        pm_state s0 = {0, m->n, 0};
-        ora_plan_counts c2;
-        memset(&c2, 0, sizeof c2);
-        pm_set dummy;
-        pm_set_clear(&dummy);
-        pm_walk_blocks(m, q, &u, s0, tmp, &c2, &dummy);
-        uint32_t first_conv = ~0u, first_sat = ~0u, Lv[32];
+        pm_window_walk(m, q, mpos > order + 1u ? mpos - (order + 1u) : 0u, hi, tmp);
+        uint32_t first_conv = ~0u, Lv[32];
+        uint8_t sat[32];
         for (uint32_t i = mpos; i < hi; i++) {
             const uint32_t j = i - mpos;
-            cn->tab_lookups += abs0 + i + 1u >= 32u ? 1u : 0u;
-            const int sat = abs0 + i + 1u < 32u || (order < k && tmp[i] > order);
-            Lv[j] = tmp[i] < order ? tmp[i] : order;
-            if (sat) { if (first_sat == ~0u) first_sat = j; }
-            else if (Lv[j] <= j && first_conv == ~0u) first_conv = j;
+            const int nowin = abs0 + i + 1u < 32u;
+            cn->tab_lookups += nowin ? 0u : 1u;
+            sat[j] = (uint8_t)(nowin ? 2 : (order < k && tmp[i] > order) ? 1 : 0);
+            Lv[j] = tmp[i];
+            if (!sat[j] && Lv[j] <= j && first_conv == ~0u) first_conv = j;
         }
-        if (first_sat < first_conv) { if (!pl->tab_flagged) cn->tab_flagged++; pl->tab_flagged = 1; continue; }
+        int unknown = 0;
+        for (uint32_t i = mpos; i < hi && i - mpos < first_conv; i++) { /* the table cannot tell: anchors */
+            const uint32_t j = i - mpos;
+            if (sat[j] == 2) unknown = 1;
+            else if (sat[j] == 1) {
+                Lv[j] = anchors ? pm_anchor_depth(m, order, q, i) : PM_UNKNOWN;
+                cn->tab_anchored++;
+                if (Lv[j] == PM_UNKNOWN) unknown = 1;
+            }
+        }
+        if (unknown) { if (!pl->tab_flagged) cn->tab_flagged++; pl->tab_flagged = 1; continue; }
         for (uint32_t i = mpos; i < hi && i - mpos <= first_conv; i++) {
             ms[i] = (uint8_t)(Lv[i - mpos] < k ? Lv[i - mpos] : k);
             cn->tab_written++;
@@ -599,7 +642,7 @@ int ora_plan_model(const ora_index *x, const uint8_t *text, const uint32_t *pos,
             const uint64_t bail = per * P->bail_x16 / 16u + 64u;
             uint64_t unresolved = 0;
             for (int t = 0; t < n_threads; t++) unresolved += jobs[t].cn.tab_flagged;
-            /* (depth-table form: the plan is given up when the table leaves more than half of the items unresolved) */
+            /* (depth-table form: the plan is given up when more than half of the items had no plan or stayed unresolved) */
             const int gave_up = P->depth_table ? unresolved > n_reads / 2u + 64u : units_counted > bail;
             for (int t = 0; t < n_threads; t++) jobs[t].gave_up = gave_up;
             counts->gave_up = (uint64_t)gave_up;

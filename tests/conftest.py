@@ -34,6 +34,7 @@ def shipped_defaults(L):
     L.kbo_set_plan_stats(0)
     L.kbo_set_index_shards(0)
     L.kbo_set_depth_table(0)             # depth table by index size
+    L.kbo_set_depth_table_anchors(-1)    # ... its anchors by its margin
     L.kbo_set_guided_walk(0, -1)         # resident waves and rank blocks / recovery lines by index size
     L.kbo_set_force_big_layout(0)
     L.kbo_set_seed_table_depth(0)

@@ -112,13 +112,14 @@ def test_table_form_equals_the_oracle(oracle, k):
     ora = oracle.Index.build(seqs, k=k)
     exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
     L = kbo_amd.lib()
-    for order in [o for o in (1, 4, 9, 0, 13, 16, 17) if o <= max(k, 1)]:
+    for order, anch in [(o, a) for o, a in ((1, 1), (4, 0), (4, 1), (9, 1), (0, -1), (13, 0), (13, 1), (16, 1), (17, 0)) if o <= max(k, 1)]:
         L.kbo_set_depth_table(order)
+        L.kbo_set_depth_table_anchors(anch)  # (anchors: bases deeper than the table knows are read off the path-cover text)
         sbwt, _ = kbo_amd.build(seqs, kbo_amd.BuildOpts(k=k, num_threads=2))
         assert sbwt.to_device(-1).depth_table_order() == (min(order, k) if order else oracle.shipped_depth_table_order(k, sbwt.n_sets()))
         for _ in range(2):  # (a launch that gave the plan up holds the next one off: both must be exact)
             d, _, _ = batch.ms_batch(sbwt, concat, offsets)
-            assert np.array_equal(d, exp_d), (k, order)
+            assert np.array_equal(d, exp_d), (k, order, anch)
         dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"))
         dev.ms.fill_(0xEE)
         dev.run()
@@ -130,10 +131,10 @@ def test_table_form_equals_the_oracle(oracle, k):
         assert np.array_equal(d, exp_d[:int(offsets[n_r])]), (k, order)
         L.kbo_set_depth_table(-1)  # the same copy without its table: the guided walk
         d, _, _ = batch.ms_batch(sbwt, concat, offsets)
-        assert np.array_equal(d, exp_d), (k, order)
+        assert np.array_equal(d, exp_d), (k, order, anch)
 
 
-def _compare(oracle, sbwt, ora, concat, offsets, order):
+def _compare(oracle, sbwt, ora, concat, offsets, order, anchors):
     import torch
     L = kbo_amd.lib()
     L.kbo_set_plan_stats(1)
@@ -142,12 +143,13 @@ def _compare(oracle, sbwt, ora, concat, offsets, order):
     dev.walk()
     torch.cuda.synchronize()
     st = dev.plan_stats()
-    P = oracle.shipped_plan_params(sbwt.k(), sbwt.n_sets(), depth_table=order)
+    P = oracle.shipped_plan_params(sbwt.k(), sbwt.n_sets(), depth_table=order, depth_anchors=anchors)
     ms, cn = ora.plan_model(sbwt.path_cover(), P, concat, offsets, n_threads=threads())
     assert np.array_equal(dev.ms[:dev.total].cpu().numpy(), ms)
     want = {"seed_lookups": cn["seed_lookups"], "seed_extensions": cn["seed_extensions"], "mismatches": cn["mismatches"],
             "tab_lookups": cn["tab_lookups"], "tab_written": cn["tab_written"], "tab_flagged": cn["tab_flagged"],
-            "tab_unresolved": cn["tab_flagged"], "gave_up": cn["gave_up"], "guard": 0,
+            "tab_unresolved": cn["tab_flagged"], "tab_anchored": cn["tab_anchored"], "items_noplan": cn["items_noplan"],
+            "gave_up": cn["gave_up"], "guard": 0,
             # (the redo list: a flagged read of 150 bases goes there as five pieces of at most 32 bases with their warm-up)
             "redo_entries": len(offsets) - 1 if cn["gave_up"] else 5 * cn["items_flagged"]}
     got = {k: st[k] for k in want}
@@ -155,21 +157,23 @@ def _compare(oracle, sbwt, ora, concat, offsets, order):
     return cn
 
 
-@pytest.mark.parametrize("order", [0, 9, 16])
-def test_model_counts_equal_the_kernels_counters_table_form(oracle, order):
+@pytest.mark.parametrize("order,anchors", [(0, -1), (0, 1), (9, 1), (9, 0), (16, 1)])
+def test_model_counts_equal_the_kernels_counters_table_form(oracle, order, anchors):
     g = synth.genome(2_000_000, seed=2024)
     kbo_amd.lib().kbo_set_depth_table(order)
+    kbo_amd.lib().kbo_set_depth_table_anchors(anchors)
     sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=threads()))
+    anchors = int(oracle.shipped_depth_table_anchors(31, sbwt.n_sets(), order or 14)) if anchors < 0 else anchors
     ora = adopt(oracle, sbwt)
     o = sbwt.to_device(-1).depth_table_order()
     assert o == (order or 14)  # log4(2 M) = 10.5, + 3.2, rounded up
     for sub, seed in ((0.01, 1), (0.03, 2), (0.0, 3)):
         concat, offsets = synth.reads(g, 60_000, 150, sub, seed=seed)
         kbo_amd.lib().kbo_set_plan(1, 0, 0)  # (a launch that gave the plan up - order 9 leaves most reads unresolved - holds the next ones off)
-        cn = _compare(oracle, sbwt, ora, concat, offsets, o)
+        cn = _compare(oracle, sbwt, ora, concat, offsets, o, anchors)
         if order == 0 and sub == 0.01:
-            assert cn["tab_flagged"] < 0.05 * cn["items"] and 9 < cn["tab_lookups"] / cn["mismatches"] < 14
+            assert cn["tab_flagged"] < (0.01 if anchors else 0.05) * cn["items"] and 9 < cn["tab_lookups"] / cn["mismatches"] < 14
     other = synth.genome(300_000, seed=77)  # reads from elsewhere: nothing seeds, the plan is given up
     concat, offsets = synth.reads(other, 20_000, 150, 0.0, seed=4)
     kbo_amd.lib().kbo_set_plan(1, 0, 0)
-    assert _compare(oracle, sbwt, ora, concat, offsets, o)["gave_up"] == 1
+    assert _compare(oracle, sbwt, ora, concat, offsets, o, anchors)["gave_up"] == 1

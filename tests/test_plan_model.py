@@ -52,19 +52,20 @@ def test_model_ms_equals_the_literal_walk(oracle, k):
             for seed_tab, seed_depth, gap, chunk, bail in ((8 if k >= 8 else 0, 11, 17, 32, 50), (0, 3, 2, 16, 0xFFFF),
                                                           (min(k, 10), 14, 24, 64, 0xFFFF), (4, 1, 5, 32, 0xFFFF)):
                 P = oracle.PlanParams(seed_table_depth=seed_tab, seed_depth=seed_depth, seed_cap=64, gap=gap, chunk=chunk,
-                                      list_cap=13, bail_x16=bail, recovery_lines=fat, depth_table=0)
+                                      list_cap=13, bail_x16=bail, recovery_lines=fat, depth_table=0, depth_anchors=0)
                 ms, cn = ora.plan_model(cover, P, concat, offsets, n_threads=3)
                 assert np.array_equal(ms, exp), (k, rate, fat, seed_tab, seed_depth, gap, chunk, bail)
                 assert cn["bases"] == len(concat) and cn["items"] == len(offsets) - 1
                 if fat == 0:  # the depth-table form (no units): orders from "resolves next to nothing" to "k itself"
-                    for order in (2, 6, 11, 17):
-                        P.depth_table = order
+                    for order, anch in ((2, 1), (6, 0), (6, 1), (11, 0), (11, 1), (17, 1)):
+                        P.depth_table, P.depth_anchors = order, anch
                         ms, ct = ora.plan_model(cover, P, concat, offsets, n_threads=3)
                         assert np.array_equal(ms, exp), (k, rate, order, seed_tab, seed_depth)
                         assert ct["units"] == 0 and ct["tab_written"] <= ct["tab_lookups"] + 32
-                        if min(order, k) == k and not ct["gave_up"]:  # a table of k bases knows every value
-                            assert ct["tab_flagged"] == ct["items_unseeded"] + ct["items_list_overflow"]
-                    P.depth_table = 0
+                        assert ct["items_noplan"] == ct["items_unseeded"] + ct["items_list_overflow"]
+                        if min(order, k) == k:  # a table of k bases knows every value (but for the first bytes of the buffer)
+                            assert ct["tab_flagged"] <= ct["items_noplan"] + 1 and ct["tab_anchored"] == 0
+                    P.depth_table = P.depth_anchors = 0
                 if cn["gave_up"]:
                     assert cn["units"] == 0 and cn["redo_bases"] == len(concat)
                 else:
@@ -81,10 +82,14 @@ def test_model_on_the_bench_shape(oracle):
     concat, offsets = synth.reads(g, 20_000, 150, 0.01)
     _, exp = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
     P = oracle.shipped_plan_params(31, sbwt.n_sets())
-    assert P.depth_table == 13  # log4(500 k) = 9.5, + 3.2, rounded up
+    assert P.depth_table == 13 and P.depth_anchors == 0  # log4(500 k) = 9.5, + 3.2, rounded up: a margin of 3.5
+    ms, c0 = ora.plan_model(sbwt.path_cover(), P, concat, offsets, n_threads=4)
+    assert np.array_equal(ms, exp) and not c0["gave_up"] and c0["tab_flagged"] < 0.04 * c0["items"]
+    P.depth_anchors = 1
     ms, cn = ora.plan_model(sbwt.path_cover(), P, concat, offsets, n_threads=4)
     assert np.array_equal(ms, exp) and not cn["gave_up"] and cn["units"] == 0
-    assert cn["tab_flagged"] < 0.04 * cn["items"]              # few reads go to the plain walk ...
+    assert cn["items_noplan"] <= cn["tab_flagged"] < 0.01 * cn["items"]  # next to none but the reads without a plan go to the plain walk ...
+    assert 0 < cn["tab_anchored"] < 0.2 * cn["items"]                     # (the bases deeper than the table knows are read off the text)
     assert 8 < cn["tab_lookups"] / cn["mismatches"] <= 14      # ... and a mismatch costs about log4(rows) + 2 look-ups
     assert cn["items_flagged"] == cn["tab_flagged"] and cn["redo_bases"] == 150 * cn["tab_flagged"]
     for fat in (0, 1):
