@@ -22,7 +22,7 @@ def _run(args, tmp_path, extra_env=None):
     return json.loads(lines[0])
 
 
-def _check_line(r, n_gpus):
+def _check_line(r, n_gpus, table=True):
     assert r["n_gpus"] == n_gpus and r["unit"] == "Mbp/s" and r["higher_is_better"] is True and r["vs_baseline"] is None
     assert r["bit_exact_vs_oracle"] is True
     ro = r["roofline"]
@@ -31,7 +31,11 @@ def _check_line(r, n_gpus):
     assert ro["stage_model"]["ms_equal_to_gpu"] is True
     # the model's counts are the kernels' own (first slab)
     st, m = ro["stage_counters_gpu_first_slab"], ro["stage_model"]
-    assert abs(st["units"] / st["units_walked"] - 1) < 1e-9 and m["units_per_read"] > 1.0
+    if table:  # a small index: the stretches behind mismatches come from the depth table
+        assert "depth table" in r["config"]["walk"] and m["parameters"]["depth_table"] > 0 and st["units"] == 0
+        assert st["tab_lookups"] > 0 and 8 < m["per_mismatch"]["table_lookups"] < 16 and st["tab_flagged"] == st["tab_unresolved"]
+    else:
+        assert abs(st["units"] / st["units_walked"] - 1) < 1e-9 and m["units_per_read"] > 1.0
     assert ro["cross_check_whole_step_gbps"] <= ro["peak"]
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and len(cb["runs_mbps"]) == 3
@@ -44,6 +48,14 @@ def test_bench_line_single_process_with_extras(tmp_path):
     assert len(names) == 5 and any("reverse" in n for n in names) and any("repeat" in n for n in names)
     assert all(v["bit_exact_vs_oracle"] is True and v["value"] > 0 for v in r["sensitivity"])
     assert r["host_to_host"]["value"] > 0
+
+
+def test_bench_line_guided_walk(tmp_path):
+    """--depth-table -1: units and the guided walk (what larger indexes get), priced by the same model"""
+    r = _run(["--genome", "400000", "--reads", "30000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1", "--no-extras", "--depth-table", "-1"],
+             tmp_path)
+    _check_line(r, 1, table=False)
+    assert "guided walk" in r["config"]["walk"]
 
 
 def test_bench_c4_shape_strong_scaling_two_ranks(tmp_path):

@@ -28,7 +28,7 @@ def _compare(oracle, sbwt, ora, concat, offsets, fat):
     dev.walk()
     torch.cuda.synchronize()
     st = dev.plan_stats()
-    P = oracle.shipped_plan_params(sbwt.k(), sbwt.n_sets(), recovery_lines=fat)
+    P = oracle.shipped_plan_params(sbwt.k(), sbwt.n_sets(), recovery_lines=fat, depth_table=0)
     ms, cn = ora.plan_model(sbwt.path_cover(), P, concat, offsets, n_threads=threads())
     assert np.array_equal(dev.ms[:dev.total].cpu().numpy(), ms)
     assert st["gave_up"] == cn["gave_up"] and st["guard"] == 0
