@@ -42,6 +42,9 @@ while time.time() < t_end:
                           int(rng.choice([0, 8, 32, 50, 64, 0xFFFF])))
     L.kbo_set_plan_unit_cap_divisor(int(rng.choice([1, 1, 1, 4, 30])))
     L.kbo_set_guided_walk(int(rng.choice([0, 1, 8, 32])), int(rng.choice([-1, 0, 1])))
+    # depth table: by index size / none / every order from "knows nothing" to 16 (32-lane groups), anchors on and off
+    L.kbo_set_depth_table(int(rng.choice([0, 0, 0, -1, 1, 3, 6, 9, 12, 16])))
+    L.kbo_set_depth_table_anchors(int(rng.choice([-1, 0, 1, 1])))
     two_workers = bool(rng.random() < 0.15)  # the batch spread over a device list (both entries GPU 0)
     import ctypes
     devs = (ctypes.c_int * 2)(0, 0)
