@@ -353,8 +353,9 @@ def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream):
         L_.kbo_set_plan(1, 0, 0)  # (every variant starts with a clean hold-off)
         concat, offsets = synth.reads(genome, n_reads, L, sub, seed=0x5E115 + int(sub * 1000))
         out.append(measure(f"{sub * 100:g}% substitutions", sbwt, oi, concat, offsets,
-                           "above ~4 % the stage gives the plan up on the device and walks plainly (and holds planning off)" if sub > 0.04 else
-                           "error-free: plan_kernel alone, nothing to walk"))
+                           ("7.5 mismatches per read against the diagonal: with the depth table each costs its look-ups; with units (larger "
+                            "indexes) the stage gives the plan up above ~4 % and walks plainly") if sub > 0.04 else
+                           "error-free: plan_kernel alone, nothing behind it"))
     L_.kbo_set_plan(1, 0, 0)
     concat, offsets = synth.reads(genome, n_reads, L, 0.01, seed=0x5E117)
     rc = comp[concat.reshape(-1, L)[:, ::-1]].reshape(-1).copy()
@@ -389,8 +390,8 @@ def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream):
     cat = np.concatenate(contigs)
     concat, offsets = synth.reads(cat, n_reads, L, 0.01, seed=0x5E11B)
     e = measure("repeat-rich genome, 40 contigs", rix, roi, concat, offsets,
-                "a fifth of every contig duplicated from elsewhere + tandem arrays: path cover of many paths, units that do not converge "
-                "before the next group go to the redo pass")
+                "a fifth of every contig duplicated from elsewhere + tandem arrays: path cover of many paths; reads that cross a path "
+                "start or leave their diagonal in a repeat go to the redo pass")
     e["index_n_sets"] = rix.n_sets()
     out.append(e)
     L_.kbo_set_plan(1, 0, 0)
