@@ -180,7 +180,7 @@ class DeviceBatch:
         with torch.cuda.device(device):
             sbwt.to_device(-1)
             self.q = torch.zeros(pad, dtype=torch.uint8, device=device)
-            self.q[:self.total] = torch.from_numpy(concat).to(device)
+            self.q[:self.total] = torch.from_numpy(concat if concat.flags.writeable else concat.copy()).to(device)
             self.off = torch.from_numpy(offsets.view(np.int64)).to(device)
             self.ms = torch.zeros(pad, dtype=torch.uint8, device=device)
             self.chars = torch.zeros(pad, dtype=torch.uint8, device=device)
