@@ -280,9 +280,14 @@ def stage_model_leg(args, sbwt, oi, concat, offsets, gpu_d, n_sample=2_000_000):
     if order:
         mm = max(1, cn["mismatches"])
         summary["per_mismatch"] = {"table_lookups": round(cn["tab_lookups"] / mm, 3), "values_written": round(cn["tab_written"] / mm, 3)}
-        # every look-up is a fill of its own (a table far beyond L2, random keys); what else cannot stay in L2: per read the item
-        # record (read twice), per mismatch the query window and the output bytes
-        summary["fills_min_per_read"] = round((cn["tab_lookups"] + 2 * cn["mismatches"]) / cn["items"] + 0.25, 3)
+        st = max(1, cn["tab_stretches"])  # (the mismatches of reads on a wrong diagonal are not looked up)
+        summary["per_stretch"] = {"table_lookups": round(cn["tab_lookups"] / st, 3), "values_written": round(cn["tab_written"] / st, 3)}
+        # lines that cannot come from L2: the streams (query, text of the diagonal, MS: 3 x read length / 128), a seed-table entry
+        # per look-up and the seed's text position, and the table: the look-ups of a mismatch are consecutive bases, three of
+        # which share a 64-byte line (a run of P bases touches (P + 2) / 3 of them)
+        summary["fills_min_per_read"] = round(3 * L / 128 + (cn["seed_lookups"] + cn["pos_lookups"]) / cn["items"]
+                                              + (cn["tab_lookups"] + 2 * cn["tab_stretches"]) / 3 / cn["items"], 3)
+        summary["stretches_per_read"] = round(cn["tab_stretches"] / cn["items"], 4)
     else:
         summary["units_per_read"] = round(cn["units"] / cn["items"], 4)
         summary["per_unit"] = {"accepted": round(cn["walk_accepted"] / units, 3), "failed": round(cn["walk_failed"] / units, 3),
@@ -653,7 +658,7 @@ def main(argv=None):
         # fabric-side traffic and L2 misses of the A1 stage, from the committed rocprofv3 passes of this exact
         # workload and walk mode (PMC passes cannot run inside the timed region: separate runs, tools/profile_bench.sh)
         wl_key = f"{args.genome}x{n_mine}x{args.read_len}x{args.sub_rate:g}:{('table' if sbwt.depth_table_order() > 0 else 'plan') if planned else 'plain'}"
-        traffic = tsrc = misses = walk_misses = None
+        traffic = tsrc = misses = walk_misses = plan_misses = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
@@ -661,17 +666,20 @@ def main(argv=None):
                 if entry:
                     traffic, misses, tsrc = entry.get("a1_bytes_per_launch"), entry.get("a1_tcc_miss_per_launch"), entry.get("source")
                     kern = entry.get("kernels", {})
-                    walk_misses = (kern.get("dtab_resolve_kernel") or kern.get("ms_walk_guided_kernel") or kern.get("ms_walk_recovery_kernel") or {}).get("tcc_miss")
+                    walk_misses = (kern.get("ms_walk_guided_kernel") or kern.get("ms_walk_recovery_kernel") or {}).get("tcc_miss")
+                    plan_misses = (kern.get("plan_kernel") or {}).get("tcc_miss")
             except Exception:
                 pass
         rank_b, lcs_b = sbwt.device_bytes()
+        dto = sbwt.depth_table_order()
+        dtab_b = 0 if dto == 0 else (4 ** (dto + 1) if dto >= 4 else 4 ** dto)  # (grouped from 4 bases on: DESIGN.md section 4.2)
         pair_b, plan_b = sbwt.device_pair_bytes(), sbwt.device_plan_bytes()
         std = (args.genome, args.reads, args.read_len, args.sub_rate, args.k) in tuple((g, r, 150, 0.01, 31) for g, r, _, _ in PRESETS.values())
         label = (args.config if std else "custom") + ": " + \
             ("kbo find (max_gap_len=0; run lengths on the device)" if args.find else
              "kbo map (fill_gaps=false, call_variants=false, format=true)")
         table = planned and sbwt.depth_table_order() > 0
-        a1_kernels = ("plan_kernel + dtab_resolve_kernel (depth table) + redo_collect + ms_walk_kernel (reads the table could not resolve)" if table
+        a1_kernels = ("plan_kernel (with the depth-table look-ups; dtab_resolve_kernel for items that cannot be staged) + redo_collect + ms_walk_kernel (reads the table could not resolve)" if table
                       else "plan_kernel + plan_count/scan/emit + ms_walk_guided_kernel (ms_walk_recovery_kernel from 24 Mi rows on) + redo_collect + ms_walk_kernel (flagged reads)"
                       if planned else "ms_walk_kernel")
         walk_s = walk_ms * 1e-3
@@ -708,7 +716,7 @@ def main(argv=None):
             # the difference is the rank-block look-ups that miss although the blocks would fit the L2)
             "l2_miss_per_unit": round(misses / max(1, stats["units"] * bases / dev.total), 2) if misses and planned and not table else None,
             "walk_kernel_l2_miss_per_unit": round(walk_misses / max(1, stats["units"] * bases / dev.total), 2) if walk_misses and planned and not table else None,
-            "resolve_kernel_l2_miss_per_lookup": round(walk_misses / max(1, stats["tab_lookups"] * bases / dev.total), 3) if walk_misses and table else None,
+            "plan_kernel_l2_miss_per_read": round(plan_misses / (bases / args.read_len), 2) if plan_misses and table else None,
             "frac_reference_algorithm": round(ref_achieved / HBM_PEAK_GBPS, 4) if ref_achieved is not None else None,
             "reference_algorithm_bytes_per_base": round(b_ref, 2) if b_ref is not None else None,
             "cross_check_whole_step_gbps": round(b_alg * bases / (elapsed / args.steps) / 1e9, 1) if b_alg is not None else None,
@@ -731,8 +739,9 @@ def main(argv=None):
                        "walk": ("plan-guided (path cover + depth table of %d bases)" % sbwt.depth_table_order() if table else
                                 "plan-guided (path cover + guided walk)" if planned else "plain"),
                        "index_device_bytes": {"rank_blocks": rank_b, "lcs": lcs_b, "two_base_blocks": pair_b,
-                                              "path_cover_lines_seed_table": plan_b,
-                                              "per_row": round((rank_b + lcs_b + pair_b + plan_b) / sbwt.n_sets(), 2)},
+                                              "path_cover_lines_seed_table": plan_b - dtab_b, "depth_table": dtab_b,
+                                              "per_row": round((rank_b + lcs_b + pair_b + plan_b - dtab_b) / sbwt.n_sets(), 2),
+                                              "note": "per_row leaves the depth table out: its size depends on log4(rows) only"},
                        "resident_slabs_per_gpu": len(slabs), "index_seconds_rank0": round(t_index, 2),
                        "parallelism": f"index replicated x{world}, reads sharded, no collective"},
             "roofline": roofline,

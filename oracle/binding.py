@@ -33,7 +33,7 @@ class PlanCounts(C.Structure):
         "units_counted", "units", "units_head", "units_plain", "node_lookups",
         "walk_accepted", "walk_failed", "walk_contractions", "walk_entry_levels", "walk_short_windows", "walk_iterations_lines",
         "walk_out_bytes", "unit_distinct_lines", "unit_distinct_rank_lines", "redo_bases", "redo_iterations",
-        "tab_lookups", "tab_written", "tab_flagged", "tab_anchored", "items_noplan")]
+        "tab_lookups", "tab_written", "tab_flagged", "tab_anchored", "items_noplan", "tab_stretches")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

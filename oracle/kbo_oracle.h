@@ -178,6 +178,7 @@ typedef struct { /* all u64; per launch (the batch handed in) */
     uint64_t redo_bases, redo_iterations;
     uint64_t tab_lookups, tab_written, tab_flagged; /* depth-table form: look-ups, values written from them, items it could not resolve */
     uint64_t tab_anchored, items_noplan;            /* ... bases deeper than the table knows (tried through the anchors), items without a plan */
+    uint64_t tab_stretches;                         /* ... mismatches whose stretch was looked up (model only) */
 } ora_plan_counts;
 
 /* text / pos / node_at: the path cover of the index (n_sets entries each: kbo_index_path_cover of the product, whose

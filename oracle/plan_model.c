@@ -440,6 +440,7 @@ static void pm_resolve_item(const pm_index *m, const ora_plan_params *P, const u
     if (!pl->seeded || pl->n_mm > P->list_cap) { cn->items_noplan++; pl->tab_flagged = 1; cn->tab_flagged++; return; } /* no plan: the plain walk */
     for (uint32_t t = 0; t < pl->n_mm; t++) { /* (every mismatch on its own, flagged item or not) */
         const uint32_t mpos = pl->mm[t], nxt = t + 1u < pl->n_mm ? pl->mm[t + 1u] : len;
+        cn->tab_stretches++;
         uint32_t hi = mpos + order + 1u;
         if (hi > nxt) hi = nxt;
         if (hi > len) hi = len;
