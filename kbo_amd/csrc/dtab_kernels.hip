@@ -189,9 +189,10 @@ __global__ __launch_bounds__(256) void dtab_resolve_kernel(WalkArgs a)
     if (have) g = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(a.gitems) + (size_t)gid * 16u);
     const uint32_t start = g.x, len = g.z & 0xFFFFu, mm0 = g.w & 0xFFFFu, warm = (g.w >> 16) & 0xFFu, n_mm = g.w >> 24;
     uint32_t n_loop = 0;
-    bool no_plan = false; // no diagonal / more mismatches than the list holds
+    bool no_plan = false; // no seed, no diagonal: every base of the item from the table
     if (have && len != 0) {
-        if (n_mm == kPlanNone || n_mm > a.plan_list + 1u) no_plan = true;
+        if (n_mm == kPlanNone) no_plan = true;
+        else if (n_mm > a.plan_list + 1u) flag = true; // more mismatches than the list holds (a wrong diagonal): the plain walk
         else n_loop = n_mm;
     }
     // the value of base i of the item as far as the table knows: false = L, true = deeper than the table tells
@@ -277,7 +278,22 @@ __global__ __launch_bounds__(256) void dtab_resolve_kernel(WalkArgs a)
             if (STATS) st_written++;
         }
     }
-    if (no_plan) flag = true; // (a seed on a wrong diagonal, or none: the plain walk)
+    // items without a seed (unrelated reads, the other strand): all their bases, GW at a time -
+    // every value on its own; one the table (and the anchors) cannot tell sends the item to the plain walk
+    const uint32_t n_blk = no_plan ? (len - min(len, warm) + GW - 1u) / GW : 0u, max_blk = wave_max(n_blk);
+    for (uint32_t b = 0; b < max_blk; b++) {
+        const uint32_t i = warm + b * GW + j;
+        const bool act = b < n_blk && i < len;
+        uint32_t L = 0;
+        bool sat = false;
+        if (act) sat = look(i, L);
+        if (sat) sat = anchor(i, L);
+        if (act && !sat) {
+            a.d_out[(uint64_t)start + i] = (uint8_t)min(L, k);
+            if (STATS) st_written++;
+        }
+        if (__ballot(sat) & gmask) flag = true;
+    }
 
     if (flag && j == 0) {
         a.redo[gid] = 1;

@@ -337,10 +337,14 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
     if (FUSE) {
         const uint32_t order = a.ix.dtab_order;
         flag = have_item && len != 0 && !staged; // (an unstaged wave cannot resolve here: its items take the plain walk)
-        // no diagonal / more mismatches than the list holds (a seed on a wrong diagonal): the plain walk
-        no_plan = plannable && staged && (!seeded || cnt > a.plan_list + 1u);
-        flag = flag || no_plan;
-        const uint32_t my_n = !plannable || flag ? 0u : cnt;
+        // more mismatches than the list holds (a seed on a wrong diagonal, an error-dense read): the plain walk
+        flag = flag || (plannable && staged && seeded && cnt > a.plan_list + 1u);
+        // no seed at all (unrelated reads, the other strand): EVERY base of the item from the table, 16 at a time - reads that
+        // match nothing deeper than the table knows (most reads that match nothing) are done with 150 independent look-ups
+        // instead of a walk; one base the table cannot tell sends the item to the plain walk.  (An item that did seed has a
+        // match of log4(rows) + 3 bases and more: looking all its bases up would mostly find what the table cannot tell.)
+        no_plan = plannable && staged && !seeded;
+        const uint32_t my_n = !plannable || flag ? 0u : (no_plan ? (len + 15u) / 16u : cnt);
         uint32_t incl = my_n; // inclusive scan of the counts over the wave
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -368,13 +372,15 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
             }
             const uint32_t owner = work ? lo_l : lane;
             const uint32_t o_incl = __shfl(incl, (int)owner), o_n = __shfl(my_n, (int)owner), o_soff = __shfl(soff, (int)owner),
-                           o_len = __shfl(len, (int)owner), o_warm = __shfl(warm, (int)owner), o_start = __shfl(start, (int)owner);
+                           o_len = __shfl(len, (int)owner), o_warm = __shfl(warm, (int)owner), o_start = __shfl(start, (int)owner),
+                           o_np = __shfl(no_plan ? 1u : 0u, (int)owner);
             if (work) {
                 const uint32_t t = w - (o_incl - o_n);
                 const uint8_t *osp = spw + owner * 16u;
-                const uint32_t m = (uint32_t)osp[t];
-                const uint32_t nxt = t + 1u >= o_n ? o_len : (uint32_t)osp[t + 1u];
-                const uint32_t P = min(min(order + 1u, 16u), min(nxt, o_len) - m); // bases looked up: m .. m + P - 1
+                const bool blockmode = o_np != 0; // 16 bases of an item without a plan: every value on its own, no stretch logic
+                const uint32_t m = blockmode ? 16u * t : (uint32_t)osp[t];
+                const uint32_t nxt = (blockmode || t + 1u >= o_n) ? o_len : (uint32_t)osp[t + 1u];
+                const uint32_t P = min(min(blockmode ? 16u : order + 1u, 16u), min(nxt, o_len) - m); // bases looked up: m .. m + P - 1
                 const uint8_t *qs = sm + o_soff; // the item's bases (intact: the predictions went to `so`)
                 // the bases in front of m: `order` of them are enough (a run that reaches further back counts as "> order")
                 uint32_t code = 0, v = 0; // (order <= 15 here: `order` + 1 bases are 32 bits)
@@ -403,10 +409,10 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                         }
                     }
                 }
-                // the bases in front of the first one where the longest present suffix is the j bases behind the mismatch:
-                // what the table tells ...
-                bool done = false, unk_any = false;
-                uint32_t n_out = 0, satmask = 0;
+                // a stretch: the bases in front of the first one where the longest present suffix is the j bases behind the
+                // mismatch (a block: all of them).  What the table tells ...
+                bool done = false;
+                uint32_t evalmask = 0, unkmask = 0, satmask = 0;
                 uint32_t outv[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (uint32_t j = 0; j < 16; j++) {
@@ -414,16 +420,14 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                         const uint32_t me = (uint32_t)((j < 8 ? meta0 >> (8u * j) : meta1 >> (8u * (j - 8u))) & 0xFFu);
                         const uint32_t vv = me & 31u, eb = (me >> 5) & 3u, byte = tv[j];
                         uint32_t L = k + 1u;
-                        if (me & 128u) unk_any = true; // (no window: unknown, and no end of the stretch here)
+                        if (me & 128u) unkmask |= 1u << j; // (no window: unknown, and no end of the stretch here)
                         else if (!(byte & 0x80u)) L = min(byte, vv);
                         else if (vv <= order || order >= k) L = min(vv, order);
-                        else if ((byte >> eb) & 1u) {
-                            satmask |= 1u << j; // deeper than the table knows
-                            L = k + 1u;         // (more than j in any case: no end of the stretch here)
-                        } else L = order;
+                        else if ((byte >> eb) & 1u) satmask |= 1u << j; // deeper than the table knows (no end of the stretch either)
+                        else L = order;
                         outv[j >> 2] |= min(L, k) << (8u * (j & 3u));
-                        n_out = j + 1u;
-                        done = L <= j;
+                        evalmask |= 1u << j;
+                        done = !blockmode && L <= j;
                     }
                 }
                 // ... and what it cannot: off the path-cover text where the window is an anchor
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                     const uint8_t *qi = qs + m + j;
                     const uint32_t La = dtab_anchor_depth(a.ix, m + j + 1u, [qi](uint32_t t2) -> uint32_t { return qi[-(int32_t)t2]; });
                     st_anch++;
-                    if (La == kDtabUnknown) unk_any = true;
+                    if (La == kDtabUnknown) unkmask |= 1u << j;
                     else { // (the slot holds k: anchored values are more than `order`, at most k)
                         const uint32_t sh = 8u * (j & 3u), w = j >> 2, keep = ~(0xFFu << sh), val = La << sh;
                         if (w == 0) outv[0] = (outv[0] & keep) | val;
@@ -442,15 +446,15 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                         else outv[3] = (outv[3] & keep) | val;
                     }
                 }
-                if (unk_any) spw[owner * 16u + 13u] = 1; // the owner's item goes to the plain walk
-                else {
+                if (unkmask) spw[owner * 16u + 13u] = 1; // the owner's item goes to the plain walk
+                // (a stretch with an unknown base writes nothing; a block writes the bases it knows)
+                const uint32_t wmask = blockmode ? evalmask & ~unkmask : (unkmask ? 0u : evalmask);
 #pragma unroll
-                    for (uint32_t j = 0; j < 16; j++)
-                        if (j < n_out && m + j >= o_warm) {
-                            so[o_soff + m + j] = (uint8_t)(outv[j >> 2] >> (8u * (j & 3u)));
-                            st_written++;
-                        }
-                }
+                for (uint32_t j = 0; j < 16; j++)
+                    if (((wmask >> j) & 1u) && m + j >= o_warm) {
+                        so[o_soff + m + j] = (uint8_t)(outv[j >> 2] >> (8u * (j & 3u)));
+                        st_written++;
+                    }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -429,7 +429,8 @@ static void pm_window_walk(const pm_index *m, const uint8_t *q, uint32_t from, u
  * item, behind the last non-ACGT byte) that is a suffix of a row when that is at most `order` - modelled by a literal walk from
  * the root that starts order + 1 bases in front of the mismatch; the bases in front of the first one with L <= j that the table
  * cannot tell are read off the path-cover text (anchors); one that stays unknown flags the item, else the bases up to that
- * first one are written.  abs0 = offset of the item in the query buffer. */
+ * first one are written.  Without a plan: every base of the item the same way, no stretch logic.  abs0 = offset of the item
+ * in the query buffer. */
 static void pm_resolve_item(const pm_index *m, const ora_plan_params *P, const uint8_t *q, uint32_t len, uint64_t abs0, uint8_t *ms,
                             pm_plan *pl, uint8_t *tmp /* len bytes */, ora_plan_counts *cn)
 {
@@ -437,7 +438,23 @@ static void pm_resolve_item(const pm_index *m, const ora_plan_params *P, const u
     const int anchors = order < k && P->depth_anchors;
     pl->tab_flagged = 0;
     if (len == 0) return;
-    if (!pl->seeded || pl->n_mm > P->list_cap) { cn->items_noplan++; pl->tab_flagged = 1; cn->tab_flagged++; return; } /* no plan: the plain walk */
+    if (pl->seeded && pl->n_mm > P->list_cap) { pl->tab_flagged = 1; cn->tab_flagged++; return; } /* a wrong diagonal: the plain walk */
+    if (!pl->seeded) { /* no seed: every base on its own, no stretch logic */
+        cn->items_noplan++;
+        pm_window_walk(m, q, 0, len, tmp);
+        for (uint32_t i = 0; i < len; i++) {
+            uint32_t L = PM_UNKNOWN;
+            if (abs0 + i + 1u >= 32u) {
+                cn->tab_lookups++;
+                if (order >= k || tmp[i] <= order) L = tmp[i];
+                else { cn->tab_anchored++; if (anchors) L = pm_anchor_depth(m, order, q, i); }
+            }
+            if (L == PM_UNKNOWN) pl->tab_flagged = 1;
+            else { ms[i] = (uint8_t)(L < k ? L : k); cn->tab_written++; }
+        }
+        if (pl->tab_flagged) cn->tab_flagged++;
+        return;
+    }
     for (uint32_t t = 0; t < pl->n_mm; t++) { /* (every mismatch on its own, flagged item or not) */
         const uint32_t mpos = pl->mm[t], nxt = t + 1u < pl->n_mm ? pl->mm[t + 1u] : len;
         cn->tab_stretches++;

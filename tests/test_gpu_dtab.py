@@ -173,7 +173,8 @@ def test_model_counts_equal_the_kernels_counters_table_form(oracle, order, ancho
         cn = _compare(oracle, sbwt, ora, concat, offsets, o, anchors)
         if order == 0 and sub == 0.01:
             assert cn["tab_flagged"] < (0.01 if anchors else 0.05) * cn["items"] and 9 < cn["tab_lookups"] / cn["mismatches"] < 14
-    other = synth.genome(300_000, seed=77)  # reads from elsewhere: nothing seeds, the plan is given up
+    other = synth.genome(300_000, seed=77)  # reads from elsewhere: nothing seeds, every base of every read is looked up
     concat, offsets = synth.reads(other, 20_000, 150, 0.0, seed=4)
     kbo_amd.lib().kbo_set_plan(1, 0, 0)
-    assert _compare(oracle, sbwt, ora, concat, offsets, o, anchors)["gave_up"] == 1
+    cn = _compare(oracle, sbwt, ora, concat, offsets, o, anchors)
+    assert cn["items_noplan"] > 0.7 * cn["items"] and cn["gave_up"] == (1 if o < 12 else 0)  # (a table of 9 bases knows next to nothing)
