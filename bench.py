@@ -673,6 +673,9 @@ def main(argv=None):
         rank_b, lcs_b = sbwt.device_bytes()
         dto = sbwt.depth_table_order()
         dtab_b = 0 if dto == 0 else (4 ** (dto + 1) if dto >= 4 else 4 ** dto)  # (grouped from 4 bases on: DESIGN.md section 4.2)
+        from oracle import binding as _ora_params  # (parameters only: what the device copy was given by default)
+        seed_d = _ora_params.shipped_plan_params(args.k, sbwt.n_sets(), depth_table=dto).seed_table_depth if planned else 0
+        seed_b = 8 * 4 ** seed_d if seed_d else 0
         pair_b, plan_b = sbwt.device_pair_bytes(), sbwt.device_plan_bytes()
         std = (args.genome, args.reads, args.read_len, args.sub_rate, args.k) in tuple((g, r, 150, 0.01, 31) for g, r, _, _ in PRESETS.values())
         label = (args.config if std else "custom") + ": " + \
@@ -739,9 +742,9 @@ def main(argv=None):
                        "walk": ("plan-guided (path cover + depth table of %d bases)" % sbwt.depth_table_order() if table else
                                 "plan-guided (path cover + guided walk)" if planned else "plain"),
                        "index_device_bytes": {"rank_blocks": rank_b, "lcs": lcs_b, "two_base_blocks": pair_b,
-                                              "path_cover_lines_seed_table": plan_b - dtab_b, "depth_table": dtab_b,
-                                              "per_row": round((rank_b + lcs_b + pair_b + plan_b - dtab_b) / sbwt.n_sets(), 2),
-                                              "note": "per_row leaves the depth table out: its size depends on log4(rows) only"},
+                                              "path_cover_lines": plan_b - dtab_b - seed_b, "seed_table": seed_b, "depth_table": dtab_b,
+                                              "per_row": round((rank_b + lcs_b + pair_b + plan_b - dtab_b - seed_b) / sbwt.n_sets(), 2),
+                                              "note": "per_row leaves the seed table and the depth table out: their sizes depend on log4(rows) only"},
                        "resident_slabs_per_gpu": len(slabs), "index_seconds_rank0": round(t_index, 2),
                        "parallelism": f"index replicated x{world}, reads sharded, no collective"},
             "roofline": roofline,

@@ -129,6 +129,16 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                     dc->fat_null = (uint32_t)(lines.size() / 128 - 1);
                     idx->plan_bytes += lines.size();
                 }
+                // (the depth table's order is decided here, ahead of the seed table: an index with a depth table gets its seed
+                // table from the same device build, as deep as a seed has to be)
+                const double lg = std::log2((double)std::max<uint64_t>(idx->host.n_sets, 4)) / 2.0;
+                int order = std::min<int>({(int)std::ceil(lg + 3.2), 15, (int)idx->host.k});
+                if (((double)order < lg + 2.9 && order < (int)idx->host.k) || idx->host.n_sets >= (24u << 20)) order = 0;
+                const int set = g_depth_table.load();
+                if (set < 0) order = 0;
+                else if (set > 0) order = std::min<int>({set, 17, (int)idx->host.k});
+                if (const char *e = std::getenv("KBO_DEPTH_TABLE")) // experiments
+                    order = std::max(0, std::min<int>({std::atoi(e), 17, (int)idx->host.k}));
                 // seed table: the interval of every string of D bases, so that a seed starts D bases deep.  D = 10 for
                 // indexes that can use it (8 MiB), 8 for small ones, none below k = 8.
                 // (deeper tables for large indexes - 12 bases / 128 MiB from 32 Mi rows, 13 / 512 MiB from 512 Mi rows: the
@@ -137,10 +147,20 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                 uint32_t D = idx->host.k >= 10 && idx->host.n_sets >= (1u << 20) ? 10u : (idx->host.k >= 8 ? 8u : 0u);
                 if (D == 10 && idx->host.k >= 13 && idx->host.n_sets >= (512u << 20)) D = 13;
                 else if (D == 10 && idx->host.k >= 12 && idx->host.n_sets >= (32u << 20)) D = 12;
-                if (const int forced = g_seed_table_depth.load()) D = std::min<uint32_t>({(uint32_t)forced, 13u, idx->host.k}); // tests
+                // With a depth table: as many bases as a seed must be deep before its row is trusted (plan_kernel's dmin =
+                // log4(rows) + 3: 14 at C2), at most 14 (2 GiB) - a unique string of that many bases IS the seed, no
+                // extension follows (C2, A1 with 10 / 11 / 12 / 13 / 14 bases: 0.688 / 0.681 / 0.662 / 0.643 / 0.625 ms; seed
+                // extensions per read 4.35 / 3.2 / 2.1 / 1.0 / 0.02) - and built on the device with the depth table.
+                if (order > 0) D = std::min<uint32_t>({(uint32_t)std::lround(lg) + 3u, 14u, idx->host.k, (uint32_t)order});
+                if (const int forced = g_seed_table_depth.load()) D = std::min<uint32_t>({(uint32_t)forced, 14u, idx->host.k}); // tests
                 if (const char *e = std::getenv("KBO_PLAN_SEED_D")) // experiments
-                    D = std::min<uint32_t>({(uint32_t)std::max(0, std::atoi(e)), 13u, idx->host.k});
-                if (D) {
+                    D = std::min<uint32_t>({(uint32_t)std::max(0, std::atoi(e)), 14u, idx->host.k});
+                const bool seed_on_device = order > 0 && D > 0 && (int)D <= order;
+                if (seed_on_device) {
+                    dc->seed_tab.alloc(((size_t)8 << (2u * D)) + 64);
+                    dc->seed_d = D;
+                    idx->plan_bytes += (size_t)8 << (2u * D);
+                } else if (D) {
                     const kbo::HostNav nav(idx->host);
                     std::vector<uint32_t> cur{0u, (uint32_t)idx->host.n_sets}, nxt; // {l, r} pairs, level by level
                     for (uint32_t t = 0; t < D; t++) {
@@ -174,14 +194,6 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                 // recovery lines is faster than any table (100 Mbp index, A1 per 10 M reads: 10.2 ms against 12.2 - 14.7 with
                 // tables of 16 / 17 bases, plain or grouped), and none where 15 bases are less than log4(rows) + 2.9.
                 {
-                    const double lg = std::log2((double)std::max<uint64_t>(idx->host.n_sets, 4)) / 2.0;
-                    int order = std::min<int>({(int)std::ceil(lg + 3.2), 15, (int)idx->host.k});
-                    if (((double)order < lg + 2.9 && order < (int)idx->host.k) || idx->host.n_sets >= (24u << 20)) order = 0;
-                    const int set = g_depth_table.load();
-                    if (set < 0) order = 0;
-                    else if (set > 0) order = std::min<int>({set, 17, (int)idx->host.k});
-                    if (const char *e = std::getenv("KBO_DEPTH_TABLE")) // experiments
-                        order = std::max(0, std::min<int>({std::atoi(e), 17, (int)idx->host.k}));
                     const uint64_t cap = idx->host.n_sets + 16;
                     // the look-ups go to the grouped form (three consecutive bases share a line: a third of the fills, four
                     // times the bytes) when the order allows it
@@ -216,7 +228,8 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                             bv.pc_pos = dc->pc_pos.as<uint32_t>();
                         }
                         HIP_OK(kbo::build_depth_table(bv, (uint32_t)order, plain.as<uint8_t>(), tmp.p, cap, nullptr,
-                                                      dc->anchor_bits ? dc->anchor.as<uint64_t>() : nullptr, dc->anchor_bits));
+                                                      dc->anchor_bits ? dc->anchor.as<uint64_t>() : nullptr, dc->anchor_bits,
+                                                      seed_on_device ? dc->seed_tab.as<uint2>() : nullptr, seed_on_device ? dc->seed_d : 0u));
                         if (dc->anchor_bits) idx->plan_bytes += ((size_t)1 << abits) * 8;
                         if (grouped) {
                             tmp.release();

@@ -78,6 +78,13 @@ __global__ __launch_bounds__(256) void dtab_scatter_kernel(const DtabRec *recs, 
     if (t < n) tab[recs[t].key] = value;
 }
 
+// plan_kernel's seed table: {l, r} of the present strings of seed_d characters (the table is zeroed first: l >= r = absent)
+__global__ __launch_bounds__(256) void dtab_seed_kernel(const DtabRec *recs, uint32_t n, uint2 *seed)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) seed[recs[t].key] = make_uint2(recs[t].l, recs[t].r);
+}
+
 // anchors: the strings of `order` characters that are the suffix of exactly one row -> hash slot {key tag, text position of the row}
 __global__ __launch_bounds__(256) void dtab_anchor_kernel(const DtabRec *recs, uint32_t n, const uint32_t *pc_pos, uint64_t *slots, uint32_t bits)
 {
@@ -327,8 +334,13 @@ hipError_t regroup_depth_table(const uint8_t *d_plain, uint32_t order, uint8_t *
 }
 
 hipError_t build_depth_table(const DevIndexView &ix, uint32_t order, uint8_t *d_tab, void *d_tmp, uint64_t frontier_cap, hipStream_t stream,
-                             uint64_t *d_anchor, uint32_t anchor_bits)
+                             uint64_t *d_anchor, uint32_t anchor_bits, uint2 *d_seed, uint32_t seed_d)
 {
+    if (d_seed) {
+        if (seed_d == 0 || seed_d > order || seed_d > 14u) return hipErrorInvalidValue;
+        const hipError_t es = hipMemsetAsync(d_seed, 0, (size_t)8 << (2u * seed_d), stream);
+        if (es != hipSuccess) return es;
+    }
     if (d_anchor) {
         if (!ix.pc_pos || anchor_bits < 4u || anchor_bits > 40u) return hipErrorInvalidValue;
         const hipError_t ea = hipMemsetAsync(d_anchor, 0, ((size_t)1 << anchor_bits) * 8, stream);
@@ -366,6 +378,7 @@ hipError_t build_depth_table(const DevIndexView &ix, uint32_t order, uint8_t *d_
             if (n_out)
                 hipLaunchKernelGGL(dtab_scatter_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, fb, n_out,
                                    (uint8_t)(s == order ? 0x80u : s), d_tab);
+            if (n_out && s == seed_d && d_seed) hipLaunchKernelGGL(dtab_seed_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, fb, n_out, d_seed);
             if (n_out && s == order && d_anchor)
                 hipLaunchKernelGGL(dtab_anchor_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, fb, n_out, ix.pc_pos, d_anchor, anchor_bits);
         } else if (n_out) {

@@ -1381,7 +1381,7 @@ int kbo_set_depth_table_anchors(int mode)
 
 int kbo_set_seed_table_depth(int bases)
 {
-    g_seed_table_depth = std::max(0, std::min(bases, 13));
+    g_seed_table_depth = std::max(0, std::min(bases, 14));
     return KBO_OK;
 }
 

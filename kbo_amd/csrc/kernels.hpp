@@ -188,7 +188,8 @@ size_t dtab_tmp_bytes(uint64_t frontier_cap);
 inline size_t dtab_bytes(uint32_t order, bool grouped) { return grouped ? (size_t)64 << (2u * (order - 2u)) : (size_t)1 << (2u * order); }
 hipError_t regroup_depth_table(const uint8_t *d_plain, uint32_t order, uint8_t *d_grouped, hipStream_t stream);
 hipError_t build_depth_table(const DevIndexView &ix, uint32_t order, uint8_t *d_tab, void *d_tmp, uint64_t frontier_cap, hipStream_t stream,
-                             uint64_t *d_anchor = nullptr, uint32_t anchor_bits = 0 /* ix.pc_pos must be set when d_anchor is */);
+                             uint64_t *d_anchor = nullptr, uint32_t anchor_bits = 0 /* ix.pc_pos must be set when d_anchor is */,
+                             uint2 *d_seed = nullptr, uint32_t seed_d = 0 /* <= order: plan_kernel's seed table ({l, r} per string) */);
 // slots (log2) of the anchor hash of an index of n rows and a table of `order` bases: twice the strings it can hold
 inline uint32_t dtab_anchor_bits(uint64_t n_rows, uint32_t order)
 {

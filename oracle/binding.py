@@ -60,8 +60,16 @@ def build_lib():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
-def _load():
+def _stale():
+    """the library is missing or older than one of its sources"""
     if not os.path.exists(_LIB_PATH):
+        return True
+    t = os.path.getmtime(_LIB_PATH)
+    return any(os.path.getmtime(os.path.join(_HERE, f)) > t for f in os.listdir(_HERE) if f.endswith((".c", ".h")) or f == "Makefile")
+
+
+def _load():
+    if _stale():
         build_lib()
     lib = C.CDLL(_LIB_PATH)
     vp, u8p, u64p, i64p, u32p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), \
@@ -317,19 +325,21 @@ def shipped_depth_table_anchors(k, n_sets, order):
 
 def shipped_plan_params(k, n_sets, recovery_lines=None, depth_table=None, depth_anchors=None):
     """The parameters the product's plan-guided stage runs with by default on an index of n_sets rows (device_index.cpp:
-    seed table depth; plan_kernels.hip launch_plan: seed depth, gap; walk_kernels.hip: recovery lines from 24 Mi rows)."""
+    depth table, seed table depth; plan_kernels.hip launch_plan: seed depth, gap; walk_kernels.hip: recovery lines from 24 Mi rows)."""
     import math
     half_log = int(math.floor(math.log2(max(n_sets, 4)) / 2.0 + 0.5))  # std::lround(log2(n) / 2)
+    order = shipped_depth_table_order(k, n_sets) if depth_table is None else int(depth_table)
     d = 10 if (k >= 10 and n_sets >= (1 << 20)) else (8 if k >= 8 else 0)
     if d == 10 and k >= 13 and n_sets >= (512 << 20):
         d = 13
     elif d == 10 and k >= 12 and n_sets >= (32 << 20):
         d = 12
+    if order > 0:  # with a depth table: as deep as a seed must be, at most 14 (device_index.cpp)
+        d = min(half_log + 3, 14, k, order)
     return PlanParams(seed_table_depth=d, seed_depth=half_log + 3, seed_cap=64, gap=half_log + 9, chunk=32, list_cap=13,
                       bail_x16=50, recovery_lines=int(n_sets >= (24 << 20)) if recovery_lines is None else int(recovery_lines),
-                      depth_table=shipped_depth_table_order(k, n_sets) if depth_table is None else int(depth_table),
-                      depth_anchors=int(shipped_depth_table_anchors(k, n_sets, shipped_depth_table_order(k, n_sets) if depth_table is None
-                                                                    else int(depth_table)) if depth_anchors is None else depth_anchors))
+                      depth_table=order,
+                      depth_anchors=int(shipped_depth_table_anchors(k, n_sets, order) if depth_anchors is None else depth_anchors))
 
 
 def _plan_model(self, cover, params, concat, offsets, n_threads=1):

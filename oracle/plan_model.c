@@ -591,7 +591,7 @@ int ora_plan_model(const ora_index *x, const uint8_t *text, const uint32_t *pos,
                    uint8_t *ms_out, ora_plan_counts *counts)
 {
     if (!x || !text || !pos || !node_at || !P || !concat || !offsets || !ms_out || !counts) return ORA_E_BAD_ARG;
-    if (P->gap < 2 || P->chunk < 1 || P->list_cap + 1u > PM_LIST_MAX || P->seed_table_depth > 13 || P->depth_table > 17) return ORA_E_BAD_ARG;
+    if (P->gap < 2 || P->chunk < 1 || P->list_cap + 1u > PM_LIST_MAX || P->seed_table_depth > 14 || P->depth_table > 17) return ORA_E_BAD_ARG;
     if (ora_index_n_sets(x) >= 0xFFFFFFF0ull) return ORA_E_BAD_ARG;
     pm_index m;
     memset(&m, 0, sizeof m);
