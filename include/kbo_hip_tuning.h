@@ -45,16 +45,17 @@ const kbo_index_t *kbo_index_shard(const kbo_index_t *idx, int i);
  * longest suffix of it that is a suffix of a row of the index, 4^order bytes of device memory.  With it, the stretches behind
  * a read's mismatches against the plan's diagonal - where the matching statistic is the length of a random match, about
  * log4(rows) - cost one independent byte look-up per base instead of a chain of dependent rank look-ups; values deeper than
- * `order` send their read to the plain walk.  0 = by index size (log4(rows) + 3.2 rounded up, at most 15 and k; none from
- * 24 Mi rows on - there the guided walk over recovery lines is faster - or when it would take more than half of the free device
- * memory), 1 .. 17 = that order (capped at k),
+ * `order` send their read to the plain walk.  0 = by index size (log4(rows) + 3.2 rounded up, at most 17 and k; none from
+ * about 3 * 10^8 rows on - 17 bases are then too few - or when it would take more than half of the free device memory),
+ * 1 .. 17 = that order (capped at k),
  * < 0 = none: new copies get no table and launches over copies that have one do not use it (until the knob is >= 0 again).
  * Results are identical with and without it. */
 int kbo_set_depth_table(int order);
 /* ... with ANCHORS (device copies made after the call): a hash of the strings of `order` bases that are the suffix of exactly
  * one row, with that row's place in the path cover; a base deeper than the table knows is then read off the path-cover text
- * instead of sending its read to the plain walk (a tenth of those reads remain).  -1 = when the table's margin over log4(rows)
- * is below 3.4 bases (default), 0 = never, 1 = always. */
+ * instead of sending its read to the plain walk (a tenth of those reads remain) - at the price of two more dependent loads for
+ * every wave with such a base, which cost more than the shorter redo pass saved wherever it was measured.  -1 / 0 = none
+ * (default), 1 = build and use them. */
 int kbo_set_depth_table_anchors(int mode);
 /* inspection / tests: the depth table of the copy of `idx` on `device` (-1 = current; the copy is made if there is none):
  * *order bases per entry (0: the copy has no table), 4^*order bytes; entry of a string (2-bit digits A, C, G, T = 0 .. 3, the

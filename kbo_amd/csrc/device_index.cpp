@@ -132,8 +132,8 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                 // (the depth table's order is decided here, ahead of the seed table: an index with a depth table gets its seed
                 // table from the same device build, as deep as a seed has to be)
                 const double lg = std::log2((double)std::max<uint64_t>(idx->host.n_sets, 4)) / 2.0;
-                int order = std::min<int>({(int)std::ceil(lg + 3.2), 15, (int)idx->host.k});
-                if (((double)order < lg + 2.9 && order < (int)idx->host.k) || idx->host.n_sets >= (24u << 20)) order = 0;
+                int order = std::min<int>({(int)std::ceil(lg + 3.2), 17, (int)idx->host.k});
+                if ((double)order < lg + 2.9 && order < (int)idx->host.k) order = 0;
                 const int set = g_depth_table.load();
                 if (set < 0) order = 0;
                 else if (set > 0) order = std::min<int>({set, 17, (int)idx->host.k});
@@ -188,11 +188,11 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                 // of a row.  One independent byte look-up then gives the MS value of a base wherever the value is at most
                 // `order` - i.e. in the stretches behind mismatches, where the match is a random one: about log4(rows) long.
                 // order = log4(rows) + 3.2, rounded up (1.3 % of such stretches run deeper than log4(rows) + 4, 5 % deeper than
-                // + 3, 17 % deeper than + 2: those reads take the plain walk), at most 15 (grouped: 4 GiB - look-ups into
-                // 16 GiB and more run at half the rate: C2 with 16 bases 1.16 ms against 0.88) and at most k.  Only for indexes
-                // below 24 Mi rows, the ones the guided walk reads through rank blocks and entries: from there on the walk over
-                // recovery lines is faster than any table (100 Mbp index, A1 per 10 M reads: 10.2 ms against 12.2 - 14.7 with
-                // tables of 16 / 17 bases, plain or grouped), and none where 15 bases are less than log4(rows) + 2.9.
+                // + 3, 17 % deeper than + 2: those reads take the plain walk), at most 17 and k: 15 bases at C2 (4 GiB
+                // grouped), 17 at C3 / C4 (64 GiB grouped, 16 GiB plain when that does not fit); none where 17 bases are less
+                // than log4(rows) + 2.9 (from 3 * 10^8 rows on: the guided walk over recovery lines stays).  Measured, A1:
+                // C2 15 / 16 bases 0.625 / 0.638 ms (guided walk 0.915); C3 per 10 M reads 17 grouped / 17 plain / 16 grouped
+                // / 16 plain 7.35 / 8.88 / 9.18 / 9.86 ms (guided walk 10.15); C4 17 bases 101.9 ms (guided walk 111.5).
                 {
                     const uint64_t cap = idx->host.n_sets + 16;
                     // the look-ups go to the grouped form (three consecutive bases share a line: a third of the fills, four
@@ -217,11 +217,11 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                         // anchors: the strings of `order` bases that are the suffix of one row only, with that row's place in
                         // the path cover - what a base deeper than the table knows is read off (dtab_kernels.hip)
                         const uint32_t abits = kbo::dtab_anchor_bits(idx->host.n_sets, (uint32_t)order);
-                        // (they pay where the table's margin is small - a tenth of the flagged reads - and cost 8 % of the plan
-                        // kernel's time for nothing at C2, where the redo pass is bound by its longest chain, not by its size)
+                        // (a tenth of the flagged reads - and every wave with an anchored lane waits for two more dependent loads:
+                        // slower wherever it was measured)
                         static const int env_anchor = std::getenv("KBO_DEPTH_TABLE_ANCHORS") ? std::atoi(std::getenv("KBO_DEPTH_TABLE_ANCHORS")) : -1; // experiments
                         const int anch_set = env_anchor >= 0 ? env_anchor : g_depth_table_anchors.load();
-                        const bool want_anchors = anch_set >= 0 ? anch_set != 0 : (double)order < lg + 3.4;
+                        const bool want_anchors = anch_set > 0; // (off unless asked for: C3 with / without 8.24 / 7.35 ms, C2 0.72 / 0.68)
                         if (want_anchors && order < (int)idx->host.k) {
                             dc->anchor.alloc(((size_t)1 << abits) * 8 + 64);
                             dc->anchor_bits = abits;

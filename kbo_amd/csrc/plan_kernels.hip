@@ -24,6 +24,7 @@
 #include "device_util.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -79,7 +80,8 @@ constexpr uint32_t kPlanLdsSlack = 48;  // bytes of a wave's LDS behind the stag
 // table itself (dtab_kernels.hip has the rule and the stand-alone kernel for items that cannot be staged): up to 16
 // independent look-ups per mismatch go out together, their values patch the predictions in LDS, and the item's record and
 // mismatch list never leave the kernel.  wave_lds then = staged stretch + the same again + 64 x 16 bytes of mismatch positions.
-template <bool FUSE>
+// NP = bases a stretch can take: 16 (tables of up to 15 bases: 32-bit keys) or 18 (16 / 17 bases).
+template <bool FUSE, int NP = 16>
 __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds, uint32_t stage_ok, uint32_t stage_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t plan_lds[];
@@ -357,7 +359,8 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
         *reinterpret_cast<uint16_t *>(sp + 14) = (uint16_t)incl;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint32_t omask = (uint32_t)((1ull << (2u * order)) - 1ull);
+        using code_t = typename std::conditional<NP == 16, uint32_t, uint64_t>::type; // `order` + 1 bases as 2-bit digits
+        const code_t omask = (code_t)((1ull << (2u * order)) - 1ull);
         for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
             const uint32_t w = w0 + lane;
             const bool work = w < total;
@@ -380,31 +383,34 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                 const bool blockmode = o_np != 0; // 16 bases of an item without a plan: every value on its own, no stretch logic
                 const uint32_t m = blockmode ? 16u * t : (uint32_t)osp[t];
                 const uint32_t nxt = (blockmode || t + 1u >= o_n) ? o_len : (uint32_t)osp[t + 1u];
-                const uint32_t P = min(min(blockmode ? 16u : order + 1u, 16u), min(nxt, o_len) - m); // bases looked up: m .. m + P - 1
+                const uint32_t P = min(min(blockmode ? 16u : order + 1u, (uint32_t)NP), min(nxt, o_len) - m); // bases looked up: m .. m + P - 1
                 const uint8_t *qs = sm + o_soff; // the item's bases (intact: the predictions went to `so`)
                 // the bases in front of m: `order` of them are enough (a run that reaches further back counts as "> order")
-                uint32_t code = 0, v = 0; // (order <= 15 here: `order` + 1 bases are 32 bits)
+                code_t code = 0;
+                uint32_t v = 0;
                 for (uint32_t x = m > order ? m - order : 0u; x < m; x++) {
                     const uint32_t c = decode_base(qs[x]);
                     code = (code << 2) | (c & 3u);
                     v = c < 4u ? v + 1u : 0u;
                 }
-                uint32_t tv[16];               // the table's bytes
-                uint64_t meta0 = 0, meta1 = 0; // per base: min(v, 31) | extension base << 5 | no window << 7
+                uint32_t tv[NP];               // the table's bytes
+                uint64_t meta0 = 0, meta1 = 0, meta2 = 0; // per base: min(v, 31) | extension base << 5 | no window << 7
 #pragma unroll
-                for (uint32_t j = 0; j < 16; j++) {
+                for (uint32_t j = 0; j < (uint32_t)NP; j++) {
                     tv[j] = 0;
                     if (j < P) {
                         const uint32_t i = m + j, c = decode_base(qs[i]);
                         code = (code << 2) | (c & 3u);
                         v = c < 4u ? v + 1u : 0u;
-                        const uint32_t key = code & omask;
+                        const code_t key = code & omask;
                         const bool nowin = (uint64_t)o_start + i + 1u < 32u; // (as the stand-alone kernel: the buffer's first bytes)
-                        const uint64_t me = (uint64_t)(min(v, 31u) | (((code >> (2u * order)) & 3u) << 5) | (nowin ? 128u : 0u));
+                        const uint64_t me = (uint64_t)(min(v, 31u) | (((uint32_t)(code >> (2u * order)) & 3u) << 5) | (nowin ? 128u : 0u));
                         if (j < 8) meta0 |= me << (8u * j);
-                        else meta1 |= me << (8u * (j - 8u));
+                        else if (j < 16) meta1 |= me << (8u * (j - 8u));
+                        else meta2 |= me << (8u * (j - 16u));
                         if (!nowin) {
-                            tv[j] = a.ix.dtab_grouped ? a.ix.dtab[dtab_grouped_addr32(key, i % 3u, order)] : a.ix.dtab[key];
+                            tv[j] = !a.ix.dtab_grouped ? a.ix.dtab[key]
+                                                         : a.ix.dtab[NP == 16 ? dtab_grouped_addr32((uint32_t)key, i % 3u, order) : dtab_grouped_addr((uint64_t)key, i % 3u, order)];
                             st_look++;
                         }
                     }
@@ -413,11 +419,11 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                 // mismatch (a block: all of them).  What the table tells ...
                 bool done = false;
                 uint32_t evalmask = 0, unkmask = 0, satmask = 0;
-                uint32_t outv[4] = {0, 0, 0, 0};
+                uint32_t outv[5] = {0, 0, 0, 0, 0};
 #pragma unroll
-                for (uint32_t j = 0; j < 16; j++) {
+                for (uint32_t j = 0; j < (uint32_t)NP; j++) {
                     if (j < P && !done) {
-                        const uint32_t me = (uint32_t)((j < 8 ? meta0 >> (8u * j) : meta1 >> (8u * (j - 8u))) & 0xFFu);
+                        const uint32_t me = (uint32_t)((j < 8 ? meta0 >> (8u * j) : j < 16 ? meta1 >> (8u * (j - 8u)) : meta2 >> (8u * (j - 16u))) & 0xFFu);
                         const uint32_t vv = me & 31u, eb = (me >> 5) & 3u, byte = tv[j];
                         uint32_t L = k + 1u;
                         if (me & 128u) unkmask |= 1u << j; // (no window: unknown, and no end of the stretch here)
@@ -443,14 +449,15 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                         if (w == 0) outv[0] = (outv[0] & keep) | val;
                         else if (w == 1) outv[1] = (outv[1] & keep) | val;
                         else if (w == 2) outv[2] = (outv[2] & keep) | val;
-                        else outv[3] = (outv[3] & keep) | val;
+                        else if (w == 3) outv[3] = (outv[3] & keep) | val;
+                        else outv[4] = (outv[4] & keep) | val;
                     }
                 }
                 if (unkmask) spw[owner * 16u + 13u] = 1; // the owner's item goes to the plain walk
                 // (a stretch with an unknown base writes nothing; a block writes the bases it knows)
                 const uint32_t wmask = blockmode ? evalmask & ~unkmask : (unkmask ? 0u : evalmask);
 #pragma unroll
-                for (uint32_t j = 0; j < 16; j++)
+                for (uint32_t j = 0; j < (uint32_t)NP; j++)
                     if (((wmask >> j) & 1u) && m + j >= o_warm) {
                         so[o_soff + m + j] = (uint8_t)(outv[j >> 2] >> (8u * (j & 3u)));
                         st_written++;
@@ -1502,7 +1509,7 @@ static hipError_t launch_plan_kernel(WalkArgs &a, hipStream_t stream)
             // table mode, reads: queries and predictions side by side, the look-ups in this kernel (two workgroups of four
             // waves still share a CU's 160 KB)
             if (a.table_mode && !a.call_sites && env_fuse != 0 && a.max_item_len <= 16u * (uint32_t)kPlanStep &&
-                a.ix.dtab_order <= 15u && 4u * (2u * need + 1024u) <= 81920u) {
+                a.ix.dtab_order <= 17u && 4u * (2u * need + 1024u) <= 81920u) {
                 fuse = true;
                 stage_bytes = (uint32_t)need;
                 wave_lds = 2u * stage_bytes + 1024u;
@@ -1514,9 +1521,12 @@ static hipError_t launch_plan_kernel(WalkArgs &a, hipStream_t stream)
     const uint32_t bt = env_blk == 64 || env_blk == 128 ? (uint32_t)env_blk : 256u;
     a.table_fused = fuse ? 1u : 0u;
     if (fuse)
-        hipLaunchKernelGGL(plan_kernel<true>, dim3((a.n_items + bt - 1u) / bt), dim3(bt), (bt / 64u) * wave_lds, stream, a, wave_lds, stage_ok, stage_bytes);
+        if (a.ix.dtab_order <= 15u)
+            hipLaunchKernelGGL((plan_kernel<true, 16>), dim3((a.n_items + bt - 1u) / bt), dim3(bt), (bt / 64u) * wave_lds, stream, a, wave_lds, stage_ok, stage_bytes);
+        else
+            hipLaunchKernelGGL((plan_kernel<true, 18>), dim3((a.n_items + bt - 1u) / bt), dim3(bt), (bt / 64u) * wave_lds, stream, a, wave_lds, stage_ok, stage_bytes);
     else
-        hipLaunchKernelGGL(plan_kernel<false>, dim3((a.n_items + bt - 1u) / bt), dim3(bt), (bt / 64u) * wave_lds, stream, a, wave_lds, stage_ok, 0u);
+        hipLaunchKernelGGL((plan_kernel<false, 16>), dim3((a.n_items + bt - 1u) / bt), dim3(bt), (bt / 64u) * wave_lds, stream, a, wave_lds, stage_ok, 0u);
     return hipGetLastError();
 }
 

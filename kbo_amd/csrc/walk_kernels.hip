@@ -511,7 +511,11 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
     a.pair_min_d = (uint32_t)g_pair_min_depth.load();
     if (a.gitems && a.glist && a.ix.pc_text && !ival) { // MS values only, index with a path cover: plan, then guided walk
         hipError_t e = hipSuccess;
-        if (a.ix.dtab && !a.call_sites) { // the stretches behind mismatches from the depth table (dtab_kernels.hip): no units
+        // the stretches behind mismatches from the depth table (dtab_kernels.hip): no units.  On large indexes only for reads,
+        // whose look-ups plan_kernel does itself; items that cannot be staged there keep units + the guided walk over recovery
+        // lines (the stand-alone resolve kernel is no faster than that walk: 4.3 against 3.9 ms per 5 M reads at C3)
+        const bool reads = a.max_item_len != 0 && a.max_item_len <= 160u;
+        if (a.ix.dtab && !a.call_sites && (reads || a.ix.n < (24u << 20))) {
             e = launch_plan_table(a, stream);
             if (e != hipSuccess) return e;
         } else {

@@ -311,16 +311,15 @@ def shipped_depth_table_order(k, n_sets):
     """device_index.cpp: order of the depth table a device copy of an index of n_sets rows gets by default (0 = none)"""
     import math
     lg = math.log2(max(n_sets, 4)) / 2.0
-    order = min(int(math.ceil(lg + 3.2)), 15, k)
-    if (order < lg + 2.9 and order < k) or n_sets >= (24 << 20):
+    order = min(int(math.ceil(lg + 3.2)), 17, k)
+    if order < lg + 2.9 and order < k:
         order = 0
     return order
 
 
 def shipped_depth_table_anchors(k, n_sets, order):
-    """device_index.cpp: whether a device copy's depth table of `order` bases gets anchors by default"""
-    import math
-    return bool(order and order < k and order < math.log2(max(n_sets, 4)) / 2.0 + 3.4)
+    """device_index.cpp: whether a device copy's depth table gets anchors by default (it does not: kbo_set_depth_table_anchors)"""
+    return False
 
 
 def shipped_plan_params(k, n_sets, recovery_lines=None, depth_table=None, depth_anchors=None):
