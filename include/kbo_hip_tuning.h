@@ -53,9 +53,9 @@ const kbo_index_t *kbo_index_shard(const kbo_index_t *idx, int i);
 int kbo_set_depth_table(int order);
 /* ... with ANCHORS (device copies made after the call): a hash of the strings of `order` bases that are the suffix of exactly
  * one row, with that row's place in the path cover; a base deeper than the table knows is then read off the path-cover text
- * instead of sending its read to the plain walk (a tenth of those reads remain) - at the price of two more dependent loads for
- * every wave with such a base, which cost more than the shorter redo pass saved wherever it was measured.  -1 / 0 = none
- * (default), 1 = build and use them. */
+ * (by a kernel of its own behind the plan kernel) instead of sending its read to the plain walk; a quarter of those reads
+ * remain.  Measured: slower at C2 (the redo pass is bound by its longest chain, not by its size), 4 % faster at C3.
+ * -1 / 0 = none (default), 1 = build and use them. */
 int kbo_set_depth_table_anchors(int mode);
 /* inspection / tests: the depth table of the copy of `idx` on `device` (-1 = current; the copy is made if there is none):
  * *order bases per entry (0: the copy has no table), 4^*order bytes; entry of a string (2-bit digits A, C, G, T = 0 .. 3, the

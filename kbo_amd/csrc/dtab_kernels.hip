@@ -170,6 +170,58 @@ __device__ __forceinline__ void pack16(const uint4 &v, uint32_t &code, uint32_t 
     }
 }
 
+// the value of base i of an item (start = its offset in the query buffer) as far as the table knows: false = L, true = deeper
+// than the table tells (L == kDtabUnknown then: no window at all, the first bytes of the buffer)
+template <bool STATS>
+__device__ __forceinline__ bool dtab_look(const WalkArgs &a, uint32_t start, uint32_t i, uint32_t &L, uint32_t &st_look)
+{
+    const uint32_t order = a.ix.dtab_order, k = a.ix.k;
+    const uint64_t end1 = (uint64_t)start + i + 1u; // one past the base, in the query buffer
+    L = kDtabUnknown;
+    if (end1 < 32u) return true; // (no 32 bytes in front of them; no anchor either)
+    L = 0;
+    const uint8_t *p = a.q + (end1 - 32u);
+    uint4 hi4, lo4;
+    __builtin_memcpy(&lo4, p, 16);      // the older 16 bases
+    __builtin_memcpy(&hi4, p + 16, 16); // the newer 16 bases
+    uint32_t c_old, v_old, c_new, v_new;
+    pack16(lo4, c_old, v_old);
+    pack16(hi4, c_new, v_new);
+    const uint64_t code = ((uint64_t)c_old << 32) | c_new;
+    // consecutive bases ending at the newest byte (bit 15 of v_new), then into the older block
+    const uint32_t run_new = (uint32_t)__clz((int)~(v_new << 16));
+    const uint32_t run_old = (uint32_t)__clz((int)~(v_old << 16));
+    uint32_t v = run_new < 16u ? run_new : 16u + min(run_old, 16u);
+    v = min(v, i + 1u);
+    const uint64_t key = code & ((1ull << (2u * order)) - 1ull);
+    const uint32_t byte = a.ix.dtab_grouped ? a.ix.dtab[dtab_grouped_addr(key, i % 3u, order)] : a.ix.dtab[key];
+    if (STATS) st_look++;
+    if (!(byte & 0x80u)) {
+        L = min(byte, v);
+        return false;
+    }
+    // all `order` bases of the window are a suffix of a row
+    if (v <= order || order >= k) {
+        L = min(v, order);
+        return false;
+    }
+    if (!((byte >> ((uint32_t)(code >> (2u * order)) & 3u)) & 1u)) {
+        L = order;
+        return false;
+    }
+    return true;
+}
+// ... and off the path-cover text when the window is an anchor (L == kDtabUnknown on entry: no window, stays unknown)
+template <bool STATS>
+__device__ __forceinline__ bool dtab_anchor_at(const WalkArgs &a, uint32_t start, uint32_t i, uint32_t &L, uint32_t &st_anch)
+{
+    if (L == kDtabUnknown) return true;
+    const uint8_t *qi = a.q + (uint64_t)start + i;
+    L = dtab_anchor_depth(a.ix, i + 1u, [qi](uint32_t t) -> uint32_t { return qi[-(int64_t)t]; });
+    if (STATS) st_anch++;
+    return L == kDtabUnknown;
+}
+
 // -------------------------------------------------------------------------------------------------------------
 // dtab_resolve_kernel<GW>: GW (16 or 32 >= order + 1) lanes per work item.  For every mismatch m of the item's list, lane j
 // has base i = m + j (up to the next mismatch, the item's end, and order + 1 bases):
@@ -202,51 +254,8 @@ __global__ __launch_bounds__(256) void dtab_resolve_kernel(WalkArgs a)
         else if (n_mm > a.plan_list + 1u) flag = true; // more mismatches than the list holds (a wrong diagonal): the plain walk
         else n_loop = n_mm;
     }
-    // the value of base i of the item as far as the table knows: false = L, true = deeper than the table tells
-    auto look = [&](uint32_t i, uint32_t &L) -> bool {
-        const uint64_t end1 = (uint64_t)start + i + 1u; // one past the base, in the query buffer
-        L = kDtabUnknown;
-        if (end1 < 32u) return true; // (the first bytes of the buffer: no 32 bytes in front of them; no anchor either)
-        L = 0;
-        const uint8_t *p = a.q + (end1 - 32u);
-        uint4 hi4, lo4;
-        __builtin_memcpy(&lo4, p, 16);      // the older 16 bases
-        __builtin_memcpy(&hi4, p + 16, 16); // the newer 16 bases
-        uint32_t c_old, v_old, c_new, v_new;
-        pack16(lo4, c_old, v_old);
-        pack16(hi4, c_new, v_new);
-        const uint64_t code = ((uint64_t)c_old << 32) | c_new;
-        // consecutive bases ending at the newest byte (bit 15 of v_new), then into the older block
-        const uint32_t run_new = (uint32_t)__clz((int)~(v_new << 16));
-        const uint32_t run_old = (uint32_t)__clz((int)~(v_old << 16));
-        uint32_t v = run_new < 16u ? run_new : 16u + min(run_old, 16u);
-        v = min(v, i + 1u);
-        const uint64_t key = code & ((1ull << (2u * order)) - 1ull);
-        const uint32_t byte = a.ix.dtab_grouped ? a.ix.dtab[dtab_grouped_addr(key, i % 3u, order)] : a.ix.dtab[key];
-        if (STATS) st_look++;
-        if (!(byte & 0x80u)) {
-            L = min(byte, v);
-            return false;
-        }
-        // all `order` bases of the window are a suffix of a row
-        if (v <= order || order >= k) {
-            L = min(v, order);
-            return false;
-        }
-        if (!((byte >> ((uint32_t)(code >> (2u * order)) & 3u)) & 1u)) {
-            L = order;
-            return false;
-        }
-        return true;
-    };
-    // ... and off the path-cover text when the window is an anchor (L == kDtabUnknown on entry: no window, stays unknown)
-    auto anchor = [&](uint32_t i, uint32_t &L) -> bool {
-        if (L == kDtabUnknown) return true;
-        const uint8_t *qi = a.q + (uint64_t)start + i;
-        L = dtab_anchor_depth(a.ix, i + 1u, [qi](uint32_t t) -> uint32_t { return qi[-(int64_t)t]; });
-        if (STATS) st_anch++;
-        return L == kDtabUnknown;
-    };
+    auto look = [&](uint32_t i, uint32_t &L) -> bool { return dtab_look<STATS>(a, start, i, L, st_look); };
+    auto anchor = [&](uint32_t i, uint32_t &L) -> bool { return dtab_anchor_at<STATS>(a, start, i, L, st_anch); };
     // the list: lane t holds mismatch t (t <= 28 < GW * 2: two per lane when GW = 16)
     const uint16_t *list = a.glist + (size_t)gid * a.plan_list;
     uint32_t mine0 = kPlanInf, mine1 = kPlanInf;
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(256) void dtab_resolve_kernel(WalkArgs a)
         uint32_t L = 0;
         bool sat = false;
         if (act) sat = look(i, L);
-        if (sat) sat = anchor(i, L);
+        if (STATS && sat && L != kDtabUnknown) st_anch++; // (deeper than the table knows: no anchors for items without a plan)
         if (act && !sat) {
             a.d_out[(uint64_t)start + i] = (uint8_t)min(L, k);
             if (STATS) st_written++;
@@ -314,6 +323,59 @@ __global__ __launch_bounds__(256) void dtab_resolve_kernel(WalkArgs a)
         if (nm) atomicAdd(a.qctl + 5, (uint32_t)__popcll(nm));
     }
     if (STATS) plan_stats_add(a.pstats, kPlanStatTabLookups, st_look, kPlanStatTabWritten, st_written, kPlanStatTabFlagged, st_flag, kPlanStatTabAnchored, st_anch);
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// dtab_stretch_kernel: the stretches the fused plan_kernel could not finish from the table alone (a base deeper than the
+// table knows in front of the stretch's end), with the anchors.  plan_kernel leaves them in a per-wave list (DtabStretchBlock:
+// it would otherwise wait, all 64 lanes, for the two dependent loads of one lane's anchor); here 32 lanes take one stretch,
+// one base each, like dtab_resolve_kernel: what the table tells, the anchors for the bases in front of the first end, the
+// values written when all of them are known - else the item is flagged (once) for the plain walk.
+template <bool STATS>
+__global__ __launch_bounds__(64) void dtab_stretch_kernel(WalkArgs a, uint32_t n_waves)
+{
+    const uint32_t w = blockIdx.x; // the plan_kernel wave whose list this is
+    if (w >= n_waves) return;
+    const uint8_t *blk = reinterpret_cast<const uint8_t *>(a.units) + (size_t)w * kDtabStretchBlockBytes;
+    const uint32_t count = min(*reinterpret_cast<const uint32_t *>(blk), kDtabStretchCap);
+    if (count == 0) return;
+    const uint32_t lane = threadIdx.x, sub = lane >> 5, j = lane & 31u;
+    const uint32_t order = a.ix.dtab_order, k = a.ix.k;
+    const uint64_t gmask = 0xFFFFFFFFull << (32u * sub);
+    uint32_t st_written = 0, st_flag = 0, st_anch = 0, st_dummy = 0;
+    for (uint32_t e0 = 0; e0 < count; e0 += 2u) {
+        const uint32_t e = e0 + sub;
+        const bool have = e < count;
+        uint4 ent = make_uint4(0, 0, 0, 0);
+        if (have) ent = *reinterpret_cast<const uint4 *>(blk + 16u + (size_t)e * 16u);
+        const uint32_t item = ent.x, start = ent.y, m = ent.z & 0xFFFFu, nxt = ent.z >> 16, len = ent.w & 0xFFFFu, warm = ent.w >> 16;
+        const uint32_t i = m + j;
+        const bool act = have && j <= order && i < nxt && i < len;
+        uint32_t L = 0;
+        bool sat = false;
+        if (act) sat = dtab_look<false>(a, start, i, L, st_dummy); // (the look-ups were counted by plan_kernel)
+        const bool conv = act && !sat && L <= j;
+        const uint64_t bc = __ballot(conv) & gmask;
+        const uint32_t first_conv = bc ? (uint32_t)__ffsll((long long)bc) - 1u - 32u * sub : 32u;
+        if (sat && j < first_conv) sat = dtab_anchor_at<STATS>(a, start, i, L, st_anch);
+        const uint64_t bs = __ballot(sat) & gmask;
+        const uint32_t first_sat = bs ? (uint32_t)__ffsll((long long)bs) - 1u - 32u * sub : 32u;
+        if (first_sat < first_conv) { // still unknown: the item takes the plain walk (flagged and counted once)
+            if (have && j == 0) {
+                uint32_t *word = reinterpret_cast<uint32_t *>(a.redo + (item & ~3u));
+                const uint32_t bit = 1u << (8u * (item & 3u));
+                const uint32_t old = atomicOr(word, bit);
+                if (!(old & (0xFFu << (8u * (item & 3u))))) {
+                    atomicAdd(a.qctl + 4, 1u);
+                    if (STATS) st_flag++;
+                }
+            }
+        } else if (act && j <= first_conv && i >= warm) {
+            a.d_out[(uint64_t)start + i] = (uint8_t)min(L, k);
+            if (STATS) st_written++;
+        }
+    }
+    if (STATS) plan_stats_add(a.pstats, kPlanStatTabWritten, st_written, kPlanStatTabFlagged, st_flag, kPlanStatTabAnchored, st_anch, 0, 0);
 }
 
 } // namespace
@@ -399,6 +461,15 @@ hipError_t build_depth_table(const DevIndexView &ix, uint32_t order, uint8_t *d_
     }
     e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+// behind the fused plan_kernel: the stretches it left to the anchors (n_waves = its waves)
+hipError_t launch_dtab_stretches(const WalkArgs &a, uint32_t n_waves, hipStream_t stream)
+{
+    if (n_waves == 0) return hipSuccess;
+    if (a.pstats) hipLaunchKernelGGL((dtab_stretch_kernel<true>), dim3(n_waves), dim3(64), 0, stream, a, n_waves);
+    else hipLaunchKernelGGL((dtab_stretch_kernel<false>), dim3(n_waves), dim3(64), 0, stream, a, n_waves);
     return hipGetLastError();
 }
 

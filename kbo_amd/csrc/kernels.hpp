@@ -182,6 +182,11 @@ hipError_t launch_ms_walk_guided(WalkArgs a, uint32_t grid, uint32_t threads, hi
 // could not resolve (for the plain kernel, like the guided walk's redo pass)
 hipError_t launch_plan_table(WalkArgs &a, hipStream_t stream);
 hipError_t launch_dtab_resolve(const WalkArgs &a, hipStream_t stream);
+// stretches the fused plan_kernel leaves to the anchors: one block per plan_kernel wave in the unit array (free in table mode
+// until redo_collect_kernel builds its list there): {count, pad[3]} + kDtabStretchCap entries {item, start, m | next << 16,
+// len | warm << 16}; a wave with more of them flags the items of the rest
+constexpr uint32_t kDtabStretchCap = 96, kDtabStretchBlockBytes = 16u + kDtabStretchCap * 16u;
+hipError_t launch_dtab_stretches(const WalkArgs &a, uint32_t n_waves, hipStream_t stream);
 // the depth table of `order` bases (<= 17, <= k) of the index behind `ix`: 4^order bytes at d_tab; d_tmp: dtab_tmp_bytes(cap)
 // with cap >= n rows + 1.  Synchronous.
 size_t dtab_tmp_bytes(uint64_t frontier_cap);

@@ -361,6 +361,13 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
         __builtin_amdgcn_wave_barrier();
         using code_t = typename std::conditional<NP == 16, uint32_t, uint64_t>::type; // `order` + 1 bases as 2-bit digits
         const code_t omask = (code_t)((1ull << (2u * order)) - 1ull);
+        // stretches with a base deeper than the table knows are left to the anchors - when the copy has them - in the wave's
+        // list for dtab_stretch_kernel (kernels.hpp DtabStretch*): an anchor is two more dependent loads, and all 64 lanes
+        // would wait for the one that needs them
+        const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        uint8_t *sblk = reinterpret_cast<uint8_t *>(a.units) + (size_t)wave_id * kDtabStretchBlockBytes;
+        const bool have_anchors = a.ix.anchor != nullptr;
+        uint32_t n_def = 0; // (wave-uniform)
         for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
             const uint32_t w = w0 + lane;
             const bool work = w < total;
@@ -376,13 +383,15 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
             const uint32_t owner = work ? lo_l : lane;
             const uint32_t o_incl = __shfl(incl, (int)owner), o_n = __shfl(my_n, (int)owner), o_soff = __shfl(soff, (int)owner),
                            o_len = __shfl(len, (int)owner), o_warm = __shfl(warm, (int)owner), o_start = __shfl(start, (int)owner),
-                           o_np = __shfl(no_plan ? 1u : 0u, (int)owner);
+                           o_np = __shfl(no_plan ? 1u : 0u, (int)owner), o_idx = __shfl(idx, (int)owner);
+            uint32_t m = 0, nxt = 0, evalmask = 0, unkmask = 0, satmask = 0;
+            uint32_t outv[5] = {0, 0, 0, 0, 0};
+            const bool blockmode = o_np != 0; // 16 bases of an item without a plan: every value on its own, no stretch logic
             if (work) {
                 const uint32_t t = w - (o_incl - o_n);
                 const uint8_t *osp = spw + owner * 16u;
-                const bool blockmode = o_np != 0; // 16 bases of an item without a plan: every value on its own, no stretch logic
-                const uint32_t m = blockmode ? 16u * t : (uint32_t)osp[t];
-                const uint32_t nxt = (blockmode || t + 1u >= o_n) ? o_len : (uint32_t)osp[t + 1u];
+                m = blockmode ? 16u * t : (uint32_t)osp[t];
+                nxt = (blockmode || t + 1u >= o_n) ? o_len : (uint32_t)osp[t + 1u];
                 const uint32_t P = min(min(blockmode ? 16u : order + 1u, (uint32_t)NP), min(nxt, o_len) - m); // bases looked up: m .. m + P - 1
                 const uint8_t *qs = sm + o_soff; // the item's bases (intact: the predictions went to `so`)
                 // the bases in front of m: `order` of them are enough (a run that reaches further back counts as "> order")
@@ -416,10 +425,8 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                     }
                 }
                 // a stretch: the bases in front of the first one where the longest present suffix is the j bases behind the
-                // mismatch (a block: all of them).  What the table tells ...
+                // mismatch (a block: all of them), as far as the table tells
                 bool done = false;
-                uint32_t evalmask = 0, unkmask = 0, satmask = 0;
-                uint32_t outv[5] = {0, 0, 0, 0, 0};
 #pragma unroll
                 for (uint32_t j = 0; j < (uint32_t)NP; j++) {
                     if (j < P && !done) {
@@ -436,26 +443,29 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                         done = !blockmode && L <= j;
                     }
                 }
-                // ... and what it cannot: off the path-cover text where the window is an anchor
-                while (satmask) {
-                    const uint32_t j = (uint32_t)__ffs((int)satmask) - 1u;
-                    satmask &= satmask - 1u;
-                    const uint8_t *qi = qs + m + j;
-                    const uint32_t La = dtab_anchor_depth(a.ix, m + j + 1u, [qi](uint32_t t2) -> uint32_t { return qi[-(int32_t)t2]; });
-                    st_anch++;
-                    if (La == kDtabUnknown) unkmask |= 1u << j;
-                    else { // (the slot holds k: anchored values are more than `order`, at most k)
-                        const uint32_t sh = 8u * (j & 3u), w = j >> 2, keep = ~(0xFFu << sh), val = La << sh;
-                        if (w == 0) outv[0] = (outv[0] & keep) | val;
-                        else if (w == 1) outv[1] = (outv[1] & keep) | val;
-                        else if (w == 2) outv[2] = (outv[2] & keep) | val;
-                        else if (w == 3) outv[3] = (outv[3] & keep) | val;
-                        else outv[4] = (outv[4] & keep) | val;
-                    }
+            }
+            // bases deeper than the table knows: a stretch goes to the wave's list when the copy has anchors (and nothing else
+            // is unknown in it); otherwise - and for the blocks of an item without a plan - they are unknown
+            const bool defer = work && have_anchors && !blockmode && satmask != 0 && unkmask == 0;
+            const uint64_t dm = __ballot(defer);
+            if (dm) {
+                const uint32_t slot = n_def + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
+                if (defer) {
+                    if (slot < kDtabStretchCap)
+                        *reinterpret_cast<uint4 *>(sblk + 16u + (size_t)slot * 16u) = make_uint4(o_idx, o_start, m | (nxt << 16), o_len | (o_warm << 16));
+                    else unkmask |= satmask; // (no room in the list: the item takes the plain walk)
+                }
+                n_def += (uint32_t)__popcll(dm);
+            }
+            if (work) {
+                const bool deferred = defer && !(unkmask & satmask);
+                if (!deferred) {
+                    st_anch += (uint32_t)__popc(satmask); // (counted as tried, like the stand-alone kernel without anchors)
+                    unkmask |= satmask;
                 }
                 if (unkmask) spw[owner * 16u + 13u] = 1; // the owner's item goes to the plain walk
-                // (a stretch with an unknown base writes nothing; a block writes the bases it knows)
-                const uint32_t wmask = blockmode ? evalmask & ~unkmask : (unkmask ? 0u : evalmask);
+                // (a stretch with an unknown base - or one left to the anchors - writes nothing; a block writes the bases it knows)
+                const uint32_t wmask = deferred ? 0u : blockmode ? evalmask & ~unkmask : (unkmask ? 0u : evalmask);
 #pragma unroll
                 for (uint32_t j = 0; j < (uint32_t)NP; j++)
                     if (((wmask >> j) & 1u) && m + j >= o_warm) {
@@ -464,6 +474,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                     }
             }
         }
+        if (have_anchors && lane == 0) *reinterpret_cast<uint32_t *>(sblk) = min(n_def, kDtabStretchCap);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         flag = flag || sp[13] != 0;
@@ -1565,6 +1576,9 @@ hipError_t launch_plan_table(WalkArgs &a, hipStream_t stream)
     if (e != hipSuccess) return e;
     if (!a.table_fused) { // (reads: plan_kernel has done the look-ups itself)
         e = launch_dtab_resolve(a, stream);
+        if (e != hipSuccess) return e;
+    } else if (a.ix.anchor) { // ... and left the stretches with bases deeper than the table knows to the anchors
+        e = launch_dtab_stretches(a, (a.n_items + 63u) / 64u, stream);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(redo_collect_kernel, dim3((a.n_items + kRedoBlock - 1u) / kRedoBlock), dim3(kRedoBlock), 0, stream, a);

@@ -447,7 +447,7 @@ static void pm_resolve_item(const pm_index *m, const ora_plan_params *P, const u
             if (abs0 + i + 1u >= 32u) {
                 cn->tab_lookups++;
                 if (order >= k || tmp[i] <= order) L = tmp[i];
-                else { cn->tab_anchored++; if (anchors) L = pm_anchor_depth(m, order, q, i); }
+                else cn->tab_anchored++; /* (deeper than the table knows: no anchors for items without a plan) */
             }
             if (L == PM_UNKNOWN) pl->tab_flagged = 1;
             else { ms[i] = (uint8_t)(L < k ? L : k); cn->tab_written++; }
