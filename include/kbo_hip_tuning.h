@@ -46,7 +46,7 @@ const kbo_index_t *kbo_index_shard(const kbo_index_t *idx, int i);
  * a read's mismatches against the plan's diagonal - where the matching statistic is the length of a random match, about
  * log4(rows) - cost one independent byte look-up per base instead of a chain of dependent rank look-ups; values deeper than
  * `order` send their read to the plain walk.  0 = by index size (log4(rows) + 3.2 rounded up, at most 17 and k; none from
- * about 3 * 10^8 rows on - 17 bases are then too few - or when it would take more than half of the free device memory),
+ * about 1.2 * 10^9 rows on - 17 bases are then too few - or when it would take more than half of the free device memory),
  * 1 .. 17 = that order (capped at k),
  * < 0 = none: new copies get no table and launches over copies that have one do not use it (until the knob is >= 0 again).
  * Results are identical with and without it. */
@@ -55,7 +55,8 @@ int kbo_set_depth_table(int order);
  * one row, with that row's place in the path cover; a base deeper than the table knows is then read off the path-cover text
  * (by a kernel of its own behind the plan kernel) instead of sending its read to the plain walk; a quarter of those reads
  * remain.  Measured: slower at C2 (the redo pass is bound by its longest chain, not by its size), 4 % faster at C3.
- * -1 / 0 = none (default), 1 = build and use them. */
+ * -1 = where the table's margin over log4(rows) is below 2.9 bases (3 * 10^8 rows and more: there the table only wins with
+ * them; default), 0 = never, 1 = always. */
 int kbo_set_depth_table_anchors(int mode);
 /* inspection / tests: the depth table of the copy of `idx` on `device` (-1 = current; the copy is made if there is none):
  * *order bases per entry (0: the copy has no table), 4^*order bytes; entry of a string (2-bit digits A, C, G, T = 0 .. 3, the

@@ -133,7 +133,10 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                 // table from the same device build, as deep as a seed has to be)
                 const double lg = std::log2((double)std::max<uint64_t>(idx->host.n_sets, 4)) / 2.0;
                 int order = std::min<int>({(int)std::ceil(lg + 3.2), 17, (int)idx->host.k});
-                if ((double)order < lg + 2.9 && order < (int)idx->host.k) order = 0;
+                // (a margin of 1.9 .. 2.9 bases - a 1 Gbp index - pays with anchors only: 2 M reads, A1 2.83 ms with the guided
+                // walk, 3.17 with the table alone - a fifth of the reads flagged -, 2.67 with its anchors)
+                const bool thin_margin = (double)order < lg + 2.9 && order < (int)idx->host.k;
+                if ((double)order < lg + 1.9 && order < (int)idx->host.k) order = 0;
                 const int set = g_depth_table.load();
                 if (set < 0) order = 0;
                 else if (set > 0) order = std::min<int>({set, 17, (int)idx->host.k});
@@ -190,7 +193,7 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                 // order = log4(rows) + 3.2, rounded up (1.3 % of such stretches run deeper than log4(rows) + 4, 5 % deeper than
                 // + 3, 17 % deeper than + 2: those reads take the plain walk), at most 17 and k: 15 bases at C2 (4 GiB
                 // grouped), 17 at C3 / C4 (64 GiB grouped, 16 GiB plain when that does not fit); none where 17 bases are less
-                // than log4(rows) + 2.9 (from 3 * 10^8 rows on: the guided walk over recovery lines stays).  Measured, A1:
+                // than log4(rows) + 1.9 (from 1.2 * 10^9 rows on: the guided walk over recovery lines stays).  Measured, A1:
                 // C2 15 / 16 bases 0.625 / 0.638 ms (guided walk 0.915); C3 per 10 M reads 17 grouped / 17 plain / 16 grouped
                 // / 16 plain 7.35 / 8.88 / 9.18 / 9.86 ms (guided walk 10.15); C4 17 bases 101.9 ms (guided walk 111.5).
                 {
@@ -221,7 +224,8 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                         // slower wherever it was measured)
                         static const int env_anchor = std::getenv("KBO_DEPTH_TABLE_ANCHORS") ? std::atoi(std::getenv("KBO_DEPTH_TABLE_ANCHORS")) : -1; // experiments
                         const int anch_set = env_anchor >= 0 ? env_anchor : g_depth_table_anchors.load();
-                        const bool want_anchors = anch_set > 0; // (off unless asked for: C3 with / without 8.24 / 7.35 ms, C2 0.72 / 0.68)
+                        // (off unless asked for - C2 0.662 / 0.622 ms with / without, C3 6.55 / 6.80 - or the margin is thin)
+                        const bool want_anchors = anch_set > 0 || (anch_set < 0 && thin_margin);
                         if (want_anchors && order < (int)idx->host.k) {
                             dc->anchor.alloc(((size_t)1 << abits) * 8 + 64);
                             dc->anchor_bits = abits;

@@ -640,7 +640,8 @@ __global__ __launch_bounds__(256) void plan_emit_kernel(WalkArgs a)
 // on its own would be most of the stage's time.  A plan that was given up: all items as they are, in order.
 constexpr uint32_t kRedoPiece = 64, kRedoPieceTable = 32; // (table mode: a few per cent of the reads come here, see below)
 constexpr uint32_t kRedoBlock = 1024;
-constexpr uint32_t kRedoWholeFrom = 80000; // flagged items from which the redo pass walks them whole (table mode)
+constexpr uint32_t kRedoWholeFrom = 50000; // flagged items from which the redo pass walks them whole (table mode): their
+                                           // pieces of 32 would be more than half of the lanes the device holds
 __global__ __launch_bounds__(1024) void redo_collect_kernel(WalkArgs a)
 {
     __shared__ uint32_t wave_tot[kRedoBlock / 64], block_base;
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(1024) void redo_collect_kernel(WalkArgs a)
     // longest chain of dependent look-ups, not by their number (pieces of 64 bases when a handful of items come here, of 32
     // in table mode)
     // (table mode: pieces of 32 while the pass is bound by its longest chain - C2: 20 k flagged reads, 16 / 32 / 64 bases
-    // 0.692 / 0.679 / 0.706 ms -, whole reads once there are enough of them to fill the device, when the warm-up bases of the
+    // 0.692 / 0.679 / 0.706 ms -, whole reads once there are enough of them to fill the device (50 k: 250 k pieces), when the warm-up bases of the
     // pieces are what costs - C3: 233 k flagged reads per slab, 16 / 32 / 64 / whole 7.99 / 7.34 / 7.05 / 6.76 ms)
     const uint32_t piece = a.table_mode ? (a.qctl[4] > kRedoWholeFrom ? 0xFFFFu : a.redo_piece) : kRedoPiece;
     const uint32_t np = !f ? 0u : (body > piece + piece / 2u ? (body + piece - 1u) / piece : 1u);

@@ -312,14 +312,16 @@ def shipped_depth_table_order(k, n_sets):
     import math
     lg = math.log2(max(n_sets, 4)) / 2.0
     order = min(int(math.ceil(lg + 3.2)), 17, k)
-    if order < lg + 2.9 and order < k:
+    if order < lg + 1.9 and order < k:
         order = 0
     return order
 
 
 def shipped_depth_table_anchors(k, n_sets, order):
-    """device_index.cpp: whether a device copy's depth table gets anchors by default (it does not: kbo_set_depth_table_anchors)"""
-    return False
+    """device_index.cpp: whether a device copy's depth table gets anchors by default: only where its margin over log4(rows) is
+    thin (below 2.9 bases: a 1 Gbp index)"""
+    import math
+    return bool(order and order < k and order < math.log2(max(n_sets, 4)) / 2.0 + 2.9)
 
 
 def shipped_plan_params(k, n_sets, recovery_lines=None, depth_table=None, depth_anchors=None):
