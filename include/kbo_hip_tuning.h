@@ -64,7 +64,7 @@ int kbo_set_depth_table_anchors(int mode);
  * whole string is, bit c of e set when the string with base c in front of it is one too.  On the device the entries of
  * three consecutive bases of a read share a 64-byte line, so every entry is there three times; `view` (0 .. 2) says which
  * copy to hand back, in key order (ignored for tables too small to be grouped).  table == NULL only asks for *n_bytes and
- * *order. */
+ * *order; tables of more than 14 bases are not handed back (KBO_E_UNSUPPORTED). */
 int kbo_index_depth_table(kbo_index_t *idx, int device, int view, uint8_t *table, size_t *n_bytes, int *order);
 /* tests: depth of the seed table of device copies made after the call (0 = by index size: 8 / 10 / 12 / 13 bases;
  * 1 .. 13 = that many, capped at k).  Large tables are what large indexes get: 12 bases = 128 MiB, 13 = 512 MiB. */

@@ -208,6 +208,11 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                     if (have_info && grouped && (double)(kbo::dtab_bytes((uint32_t)order, true) + plain_bytes + tmp_bytes) > 0.5 * (double)free_b)
                         grouped = false; // (never more than half of what is free: the batches need the rest)
                     if (have_info && set <= 0 && !grouped && (double)(plain_bytes + tmp_bytes) > 0.5 * (double)free_b) order = 0;
+                    if (order == 0 && seed_on_device) { // (no room for the table: no device build either - seeds start at the root)
+                        idx->plan_bytes -= (size_t)8 << (2u * dc->seed_d);
+                        dc->seed_tab.release();
+                        dc->seed_d = 0;
+                    }
                     if (order > 0) {
                         DevBuf tmp, plain;
                         plain.alloc(plain_bytes);

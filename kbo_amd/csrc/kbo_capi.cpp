@@ -1285,6 +1285,7 @@ int kbo_index_depth_table(kbo_index_t *idx, int device, int view, uint8_t *table
         const size_t need = v.dtab ? (size_t)1 << (2u * v.dtab_order) : 0;
         if (table && need) {
             KBO_REQUIRE(*n_bytes >= need, KBO_E_BAD_ARG, "buffer smaller than the table");
+            KBO_REQUIRE(v.dtab_order <= 14u, KBO_E_UNSUPPORTED, "tables of more than 14 bases are not handed back (a test hook: GiBs through a host copy)");
             int prev = current_device();
             if (prev != dev) HIP_OK(hipSetDevice(dev));
             hipError_t e = hipSuccess;
