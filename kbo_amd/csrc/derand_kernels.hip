@@ -8,6 +8,8 @@
 // Integer / byte work only.  Wavefront = 64 lanes.
 #include "device_util.hpp"
 
+#include <cstdlib>
+
 #include <algorithm>
 
 namespace kbo {
@@ -162,13 +164,18 @@ __device__ __forceinline__ uint32_t fmt_word(uint32_t ch, uint32_t rf)
 // sequence in the same step, so with sequences whose common length is a multiple of 32 bytes the flat image
 // puts 8..64 lanes on one bank (reads of 128 or 256 bases: 3.2x slower); the padding spreads them.
 template <bool SKEW>
-__global__ __launch_bounds__(64) void derand_translate_lds_kernel(
+__global__ __launch_bounds__(256) void derand_translate_lds_kernel(
     const uint8_t *__restrict__ ms, const uint64_t *__restrict__ off, uint32_t n_seqs, uint32_t k,
-    uint32_t t, const uint8_t *__restrict__ ref, uint8_t *__restrict__ out, uint32_t lds_bytes)
+    uint32_t t, const uint8_t *__restrict__ ref, uint8_t *__restrict__ out, uint32_t lds_bytes, uint32_t wave_lds)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t s0 = blockIdx.x * 64u;
+    // (the waves of a workgroup are independent - each has its own slice of the LDS and its own 64 sequences - and wait for
+    // nobody: wave barriers around the staged copy instead of workgroup barriers, C2 0.137 -> 0.127 ms; one, two or four
+    // waves a workgroup make no difference)
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
+    uint8_t *lds = lds_all + (threadIdx.x >> 6) * wave_lds;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t s0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u;
+    if (s0 >= n_seqs) return;
     const uint32_t s = s0 + lane;
     const uint32_t s_end = min(s0 + 64u, n_seqs);
     const uint64_t base = off[s0];
@@ -186,7 +193,8 @@ __global__ __launch_bounds__(64) void derand_translate_lds_kernel(
             *reinterpret_cast<uint4 *>(lds + o) = v;
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
     if (s < n_seqs) {
         const uint32_t b = (uint32_t)(off[s] - base), len = (uint32_t)(off[s + 1] - off[s]);
@@ -239,7 +247,8 @@ __global__ __launch_bounds__(64) void derand_translate_lds_kernel(
             at(b + 0) = (uint8_t)((x_cur > T && in_next) ? (uint32_t)'R' : plain(x_cur, x_next, K));
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
     for (uint32_t o = lane * 16u; o < span; o += 1024u) { // stage out
         uint4 c;
@@ -550,13 +559,18 @@ hipError_t launch_derand_translate(const uint8_t *d_ms, const uint64_t *d_offset
     // short sequences: LDS-staged kernel (64 sequences per wave must fit the LDS budget)
     if (max_seq_len > 0 && max_seq_len <= 480 && d_derand_out == nullptr) {
         const uint32_t lds_bytes = ((64u * max_seq_len + 15u) / 16u) * 16u + 16u;
-        if (max_seq_len % 32u == 0) // e.g. reads of 128 or 256 bases: padded LDS image (see the kernel)
-            hipLaunchKernelGGL((derand_translate_lds_kernel<true>), dim3((n_seqs + 63) / 64), dim3(64),
-                               lds_bytes + lds_bytes / 32u + 16u, stream, d_ms, d_offsets, n_seqs, k, threshold, d_ref,
-                               d_chars_out, lds_bytes);
+        static const int env_wpb = std::getenv("KBO_DT_WAVES") ? std::atoi(std::getenv("KBO_DT_WAVES")) : 0; // experiments
+        const bool skew = max_seq_len % 32u == 0; // e.g. reads of 128 or 256 bases: padded LDS image (see the kernel)
+        const uint32_t wave_lds = ((skew ? lds_bytes + lds_bytes / 32u + 16u : lds_bytes) + 15u) / 16u * 16u;
+        uint32_t wpb = env_wpb >= 1 && env_wpb <= 4 ? (uint32_t)env_wpb : 4u;
+        while (wpb > 1u && wpb * wave_lds > 65536u) wpb--; // (a workgroup's LDS)
+        const uint32_t n_waves = (n_seqs + 63u) / 64u;
+        if (skew)
+            hipLaunchKernelGGL((derand_translate_lds_kernel<true>), dim3((n_waves + wpb - 1u) / wpb), dim3(64u * wpb), wpb * wave_lds, stream,
+                               d_ms, d_offsets, n_seqs, k, threshold, d_ref, d_chars_out, lds_bytes, wave_lds);
         else
-            hipLaunchKernelGGL((derand_translate_lds_kernel<false>), dim3((n_seqs + 63) / 64), dim3(64), lds_bytes, stream,
-                               d_ms, d_offsets, n_seqs, k, threshold, d_ref, d_chars_out, lds_bytes);
+            hipLaunchKernelGGL((derand_translate_lds_kernel<false>), dim3((n_waves + wpb - 1u) / wpb), dim3(64u * wpb), wpb * wave_lds, stream,
+                               d_ms, d_offsets, n_seqs, k, threshold, d_ref, d_chars_out, lds_bytes, wave_lds);
         return hipGetLastError();
     }
     // long reads / contigs with scratch available: one lane per piece, then the flagged sequences again
