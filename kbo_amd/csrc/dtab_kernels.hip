@@ -147,29 +147,6 @@ __global__ __launch_bounds__(256) void dtab_regroup_kernel(const uint8_t *plain,
     o[3] = make_uint4(0, 0, 0, 0);
 }
 
-// 16 ASCII bases -> 2-bit digits (first byte most significant) and a mask of the bytes that are A, C, G or T (bit t = byte t)
-__device__ __forceinline__ void pack16(const uint4 &v, uint32_t &code, uint32_t &valid)
-{
-    code = 0;
-    valid = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const uint32_t x = w == 0 ? v.x : w == 1 ? v.y : w == 2 ? v.z : v.w;
-        uint32_t c2 = (x >> 1) & 0x03030303u;
-        c2 ^= (x >> 2) & 0x01010101u;
-        // the byte each code stands for, compared with the byte that is there
-        uint32_t back = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b++) back |= ((0x54474341u >> (8u * ((c2 >> (8 * b)) & 3u))) & 0xFFu) << (8 * b);
-        const uint32_t diff = back ^ x;
-        const uint32_t nz = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u; // bit 7 of every byte that differs
-        const uint32_t okb = (((nz >> 7) * 0x01020408u) >> 24) ^ 0xFu;                    // bits 0..3: bytes that are bases
-        valid |= okb << (4 * w);
-        const uint32_t d8 = ((c2 << 6) | (c2 >> 4) | (c2 >> 14) | (c2 >> 24)) & 0xFFu; // b0 b1 b2 b3 as 2-bit digits
-        code = (code << 8) | d8;
-    }
-}
-
 // the value of base i of an item (start = its offset in the query buffer) as far as the table knows: false = L, true = deeper
 // than the table tells (L == kDtabUnknown then: no window at all, the first bytes of the buffer)
 template <bool STATS>

@@ -75,11 +75,15 @@ __device__ __forceinline__ void st_range(uint8_t *o, const uint4 &v, uint32_t lo
 //     those bases and ended on the diagonal's node, so the guided walk may start at the first mismatch.
 constexpr int kPlanStep = 10;           // 16-byte blocks per compare step (reads of up to 160 bases: one step)
 constexpr uint32_t kPlanLdsSlack = 48;  // bytes of a wave's LDS behind the staged stretch (block reads run past an item)
-// FUSE (table mode, reads of at most 160 bases): the predicted values go to a second LDS region next to the staged queries -
-// which therefore stay readable - and every lane then resolves the stretches behind its item's mismatches from the depth
-// table itself (dtab_kernels.hip has the rule and the stand-alone kernel for items that cannot be staged): up to 16
+constexpr uint32_t kPlanPackBytes = 15u * 64u * 4u; // FUSE: the wave's queries as 2-bit digits + validity bits
+// FUSE (table mode, reads of at most 160 bases): the wave keeps a 2-bit copy of its queries next to the staged stretch (the
+// predicted values overwrite the bytes), and every lane then resolves the stretches behind mismatches from the depth table
+// itself (dtab_kernels.hip has the rule and the stand-alone kernel for items that cannot be staged): up to 16 / 18
 // independent look-ups per mismatch go out together, their values patch the predictions in LDS, and the item's record and
-// mismatch list never leave the kernel.  wave_lds then = staged stretch + the same again + 64 x 16 bytes of mismatch positions.
+// mismatch list never leave the kernel.  wave_lds = staged stretch + 3840 bytes of digits + 64 x 16 bytes of mismatch
+// positions: 14.5 KB for reads of 150 bases, eleven one-wave workgroups a CU (a second full region for the predictions
+// instead - 20.4 KB, eight waves a CU - was 0.625 ms at C2: the kernel waits on memory half of its time, and with half of
+// those waves it takes 0.93).
 // NP = bases a stretch can take: 16 (tables of up to 15 bases: 32-bit keys) or 18 (16 / 17 bases).
 template <bool FUSE, int NP = 16>
 __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds, uint32_t stage_ok, uint32_t stage_bytes)
@@ -88,8 +92,12 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *sm = plan_lds + (threadIdx.x >> 6) * wave_lds;
-    uint8_t *so = FUSE ? sm + stage_bytes : sm;                  // where the predicted values go (FUSE: their own region)
-    uint8_t *sp = sm + 2u * stage_bytes + lane * 16u;            // FUSE: this lane's mismatch positions (one byte each)
+    uint8_t *so = sm;                                            // the predicted values go over the staged queries
+    // FUSE: the queries survive as 2-bit digits next to the staged stretch - word w of lane L at pk[w * 64 + L]: ten words of 16
+    // bases each (the first base most significant), five words of "is A, C, G or T" bits (bit t mod 32 of word 10 + t / 32) -
+    // followed by the lanes' mismatch positions (16 bytes each)
+    uint32_t *pk = reinterpret_cast<uint32_t *>(sm + stage_bytes);
+    uint8_t *sp = sm + stage_bytes + kPlanPackBytes + lane * 16u;
     const uint32_t n = a.ix.n, k = a.ix.k, nblk = a.ix.n_blocks, null_blk = 4u * nblk;
     const uint8_t *arena = reinterpret_cast<const uint8_t *>(a.ix.arena);
     const uint8_t *qb = a.q;
@@ -128,6 +136,22 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
             *reinterpret_cast<uint4 *>(sm + c) = ld16u(qb, base16 + c);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+    if (FUSE && staged) { // the 2-bit copy of the item (its bases are overwritten by the predictions further down)
+        uint32_t vw[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t g = 0; g < (uint32_t)kPlanStep; g++) {
+            uint32_t code = 0, valid = 0;
+            if (plannable && 16u * g < len) {
+                uint4 qv;
+                __builtin_memcpy(&qv, sm + soff + 16u * g, 16);
+                pack16(qv, code, valid);
+            }
+            pk[g * 64u + lane] = code;
+            vw[g >> 1] |= valid << (16u * (g & 1u));
+        }
+#pragma unroll
+        for (uint32_t w = 0; w < 5; w++) pk[(10u + w) * 64u + lane] = vw[w];
     }
     auto qld = [&](uint32_t x) -> uint4 { // 16 bytes of the item from base x on
         uint4 v;
@@ -354,7 +378,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
             if ((int)lane >= off) incl += t;
         }
         const uint32_t total = __shfl(incl, 63);
-        uint8_t *spw = sm + 2u * stage_bytes; // the wave's 64 x 16 bytes: positions 0 .. 12, flag at 13, prefix (u16) at 14
+        uint8_t *spw = sm + stage_bytes + kPlanPackBytes; // the wave's 64 x 16 bytes: positions 0 .. 12, flag at 13, prefix (u16) at 14
         sp[13] = 0;
         *reinterpret_cast<uint16_t *>(sp + 14) = (uint16_t)incl;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -393,14 +417,28 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                 m = blockmode ? 16u * t : (uint32_t)osp[t];
                 nxt = (blockmode || t + 1u >= o_n) ? o_len : (uint32_t)osp[t + 1u];
                 const uint32_t P = min(min(blockmode ? 16u : order + 1u, (uint32_t)NP), min(nxt, o_len) - m); // bases looked up: m .. m + P - 1
-                const uint8_t *qs = sm + o_soff; // the item's bases (intact: the predictions went to `so`)
+                // the owner's bases, from its 2-bit copy: base x = digit 15 - x mod 16 of word x / 16, its validity bit x
+                uint32_t cw_i = ~0u, cw = 0, vw_i = ~0u, vw = 0;
+                auto base_at = [&](uint32_t x, uint32_t &ok) -> uint32_t {
+                    if ((x >> 4) != cw_i) {
+                        cw_i = x >> 4;
+                        cw = pk[cw_i * 64u + owner];
+                    }
+                    if ((x >> 5) != vw_i) {
+                        vw_i = x >> 5;
+                        vw = pk[(10u + vw_i) * 64u + owner];
+                    }
+                    ok = (vw >> (x & 31u)) & 1u;
+                    return (cw >> (2u * (15u - (x & 15u)))) & 3u;
+                };
                 // the bases in front of m: `order` of them are enough (a run that reaches further back counts as "> order")
                 code_t code = 0;
                 uint32_t v = 0;
                 for (uint32_t x = m > order ? m - order : 0u; x < m; x++) {
-                    const uint32_t c = decode_base(qs[x]);
-                    code = (code << 2) | (c & 3u);
-                    v = c < 4u ? v + 1u : 0u;
+                    uint32_t ok;
+                    const uint32_t c = base_at(x, ok);
+                    code = (code << 2) | c;
+                    v = ok ? v + 1u : 0u;
                 }
                 uint32_t tv[NP];               // the table's bytes
                 uint64_t meta0 = 0, meta1 = 0, meta2 = 0; // per base: min(v, 31) | extension base << 5 | no window << 7
@@ -408,9 +446,11 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                 for (uint32_t j = 0; j < (uint32_t)NP; j++) {
                     tv[j] = 0;
                     if (j < P) {
-                        const uint32_t i = m + j, c = decode_base(qs[i]);
-                        code = (code << 2) | (c & 3u);
-                        v = c < 4u ? v + 1u : 0u;
+                        const uint32_t i = m + j;
+                        uint32_t ok;
+                        const uint32_t c = base_at(i, ok);
+                        code = (code << 2) | c;
+                        v = ok ? v + 1u : 0u;
                         const code_t key = code & omask;
                         const bool nowin = (uint64_t)o_start + i + 1u < 32u; // (as the stand-alone kernel: the buffer's first bytes)
                         const uint64_t me = (uint64_t)(min(v, 31u) | (((uint32_t)(code >> (2u * order)) & 3u) << 5) | (nowin ? 128u : 0u));
@@ -1524,17 +1564,17 @@ static hipError_t launch_plan_kernel(WalkArgs &a, hipStream_t stream)
             stage_ok = 1;
             // table mode, reads: queries and predictions side by side, the look-ups in this kernel (two workgroups of four
             // waves still share a CU's 160 KB)
-            if (a.table_mode && !a.call_sites && env_fuse != 0 && a.max_item_len <= 16u * (uint32_t)kPlanStep &&
-                a.ix.dtab_order <= 17u && 4u * (2u * need + 1024u) <= 81920u) {
+            if (a.table_mode && !a.call_sites && env_fuse != 0 && a.max_item_len <= 16u * (uint32_t)kPlanStep && a.ix.dtab_order <= 17u) {
                 fuse = true;
                 stage_bytes = (uint32_t)need;
-                wave_lds = 2u * stage_bytes + 1024u;
+                wave_lds = stage_bytes + kPlanPackBytes + 1024u;
             }
         }
     }
     if (env_stage == 0) wave_lds = 0; // (experiments: neither staging nor the transposed write-out)
     static const int env_blk = std::getenv("KBO_PLAN_BLOCK") ? std::atoi(std::getenv("KBO_PLAN_BLOCK")) : 0; // experiments
-    const uint32_t bt = env_blk == 64 || env_blk == 128 ? (uint32_t)env_blk : 256u;
+    // (fused: one wave a workgroup - the LDS of a CU then holds eleven of them instead of two workgroups of four)
+    const uint32_t bt = env_blk == 64 || env_blk == 128 || env_blk == 256 ? (uint32_t)env_blk : (fuse ? 64u : 256u);
     a.table_fused = fuse ? 1u : 0u;
     if (fuse)
         if (a.ix.dtab_order <= 15u)
