@@ -132,7 +132,8 @@ __global__ __launch_bounds__(64) void rle0_lds_kernel(const uint8_t *__restrict_
             *reinterpret_cast<uint4 *>(lds + o) = v;
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // (one wave a workgroup: nobody else to wait for)
+    __builtin_amdgcn_wave_barrier();
     if (s >= n_seqs) return;
     const uint32_t b = (uint32_t)(off[s] - base), len = (uint32_t)(off[s + 1] - off[s]);
     const uint32_t first = EMIT ? sums[s / kScanBlock] + counts[s] : 0u;
