@@ -111,6 +111,19 @@ __device__ __forceinline__ void pack16(const uint4 &v, uint32_t &code, uint32_t 
     }
 }
 
+// 16 ASCII bases -> 2-bit digits (first byte most significant); a byte that is no base gives some digit
+__device__ __forceinline__ uint32_t digits16(const uint4 &v)
+{
+    uint32_t code = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t x = w == 0 ? v.x : w == 1 ? v.y : w == 2 ? v.z : v.w;
+        uint32_t c2 = (x >> 1) & 0x03030303u;
+        c2 ^= (x >> 2) & 0x01010101u;
+        code = (code << 8) | (((c2 << 6) | (c2 >> 4) | (c2 >> 14) | (c2 >> 24)) & 0xFFu);
+    }
+    return code;
+}
 // address of a depth-table entry in the grouped layout (dtab_kernels.hip): key = the window's bases, g = position mod 3
 __device__ __forceinline__ uint64_t dtab_grouped_addr(uint64_t key, uint32_t g, uint32_t order)
 {

@@ -75,7 +75,7 @@ __device__ __forceinline__ void st_range(uint8_t *o, const uint4 &v, uint32_t lo
 //     those bases and ended on the diagonal's node, so the guided walk may start at the first mismatch.
 constexpr int kPlanStep = 10;           // 16-byte blocks per compare step (reads of up to 160 bases: one step)
 constexpr uint32_t kPlanLdsSlack = 48;  // bytes of a wave's LDS behind the staged stretch (block reads run past an item)
-constexpr uint32_t kPlanPackBytes = 15u * 64u * 4u; // FUSE: the wave's queries as 2-bit digits + validity bits
+constexpr uint32_t kPlanPackBytes = 10u * 64u * 4u; // FUSE: the wave's queries as 2-bit digits
 // FUSE (table mode, reads of at most 160 bases): the wave keeps a 2-bit copy of its queries next to the staged stretch (the
 // predicted values overwrite the bytes), and every lane then resolves the stretches behind mismatches from the depth table
 // itself (dtab_kernels.hip has the rule and the stand-alone kernel for items that cannot be staged): up to 16 / 18
@@ -93,9 +93,9 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *sm = plan_lds + (threadIdx.x >> 6) * wave_lds;
     uint8_t *so = sm;                                            // the predicted values go over the staged queries
-    // FUSE: the queries survive as 2-bit digits next to the staged stretch - word w of lane L at pk[w * 64 + L]: ten words of 16
-    // bases each (the first base most significant), five words of "is A, C, G or T" bits (bit t mod 32 of word 10 + t / 32) -
-    // followed by the lanes' mismatch positions (16 bytes each)
+    // FUSE: the queries survive as 2-bit digits next to the staged stretch - word w of lane L at pk[w * 64 + L], ten words of 16
+    // bases each (the first base most significant; an item with a byte that is no base takes the plain walk: no validity
+    // bits) - followed by the lanes' mismatch positions (16 bytes each)
     uint32_t *pk = reinterpret_cast<uint32_t *>(sm + stage_bytes);
     uint8_t *sp = sm + stage_bytes + kPlanPackBytes + lane * 16u;
     const uint32_t n = a.ix.n, k = a.ix.k, nblk = a.ix.n_blocks, null_blk = 4u * nblk;
@@ -138,20 +138,16 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
         __builtin_amdgcn_wave_barrier();
     }
     if (FUSE && staged) { // the 2-bit copy of the item (its bases are overwritten by the predictions further down)
-        uint32_t vw[5] = {0, 0, 0, 0, 0};
 #pragma unroll
         for (uint32_t g = 0; g < (uint32_t)kPlanStep; g++) {
-            uint32_t code = 0, valid = 0;
+            uint32_t code = 0;
             if (plannable && 16u * g < len) {
                 uint4 qv;
                 __builtin_memcpy(&qv, sm + soff + 16u * g, 16);
-                pack16(qv, code, valid);
+                code = digits16(qv);
             }
             pk[g * 64u + lane] = code;
-            vw[g >> 1] |= valid << (16u * (g & 1u));
         }
-#pragma unroll
-        for (uint32_t w = 0; w < 5; w++) pk[(10u + w) * 64u + lane] = vw[w];
     }
     auto qld = [&](uint32_t x) -> uint4 { // 16 bytes of the item from base x on
         uint4 v;
@@ -251,6 +247,7 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
     uint16_t *list = a.glist + (size_t)idx * a.plan_list;
     int32_t i_last = -1;
     uint32_t cnt = 0, mm0 = kPlanInf;
+    bool has_invalid = false; // FUSE: the item has a byte that is not A, C, G or T
     for (uint32_t base0 = 0;; base0 += 16u * kPlanStep) {
         const bool act = seeded && base0 < len;
         if (__ballot(act) == 0) break;
@@ -307,6 +304,9 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                         const uint32_t pos = base + (uint32_t)__ffs((int)mm) - 1u;
                         if (FUSE) {
                             if (cnt < 16u) sp[cnt] = (uint8_t)pos;
+                            // (a byte that is no base is a mismatch against any text: the only places to look for one.  The
+                            // item's bytes of this block are still there: its predictions are written below)
+                            if (staged) has_invalid = has_invalid || decode_base(sm[soff + pos]) >= 4u;
                         } else if (cnt == 0) mm0 = pos;
                         else if (cnt <= a.plan_list) list[cnt - 1u] = (uint16_t)pos;
                         cnt++;
@@ -370,6 +370,12 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
         // instead of a walk; one base the table cannot tell sends the item to the plain walk.  (An item that did seed has a
         // match of log4(rows) + 3 bases and more: looking all its bases up would mostly find what the table cannot tell.)
         no_plan = plannable && staged && !seeded;
+        if (__ballot(no_plan)) { // (their bytes were never compared with a text - nor overwritten: look for one that is no base)
+            if (no_plan)
+                for (uint32_t x = 0; x < len; x++) has_invalid = has_invalid || decode_base(sm[soff + x]) >= 4u;
+        }
+        // an item with a byte that is no base: the plain walk (the 2-bit copy cannot say where a window ends)
+        flag = flag || (plannable && has_invalid);
         const uint32_t my_n = !plannable || flag ? 0u : (no_plan ? (len + 15u) / 16u : cnt);
         uint32_t incl = my_n; // inclusive scan of the counts over the wave
 #pragma unroll
@@ -417,29 +423,19 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                 m = blockmode ? 16u * t : (uint32_t)osp[t];
                 nxt = (blockmode || t + 1u >= o_n) ? o_len : (uint32_t)osp[t + 1u];
                 const uint32_t P = min(min(blockmode ? 16u : order + 1u, (uint32_t)NP), min(nxt, o_len) - m); // bases looked up: m .. m + P - 1
-                // the owner's bases, from its 2-bit copy: base x = digit 15 - x mod 16 of word x / 16, its validity bit x
-                uint32_t cw_i = ~0u, cw = 0, vw_i = ~0u, vw = 0;
-                auto base_at = [&](uint32_t x, uint32_t &ok) -> uint32_t {
+                // the owner's bases, from its 2-bit copy: base x = digit 15 - x mod 16 of word x / 16 (all of them are bases)
+                uint32_t cw_i = ~0u, cw = 0;
+                auto base_at = [&](uint32_t x) -> uint32_t {
                     if ((x >> 4) != cw_i) {
                         cw_i = x >> 4;
                         cw = pk[cw_i * 64u + owner];
                     }
-                    if ((x >> 5) != vw_i) {
-                        vw_i = x >> 5;
-                        vw = pk[(10u + vw_i) * 64u + owner];
-                    }
-                    ok = (vw >> (x & 31u)) & 1u;
                     return (cw >> (2u * (15u - (x & 15u)))) & 3u;
                 };
                 // the bases in front of m: `order` of them are enough (a run that reaches further back counts as "> order")
                 code_t code = 0;
-                uint32_t v = 0;
-                for (uint32_t x = m > order ? m - order : 0u; x < m; x++) {
-                    uint32_t ok;
-                    const uint32_t c = base_at(x, ok);
-                    code = (code << 2) | c;
-                    v = ok ? v + 1u : 0u;
-                }
+                uint32_t v = m > order ? order : m; // bases in front of m, inside the item
+                for (uint32_t x = m - v; x < m; x++) code = (code << 2) | base_at(x);
                 uint32_t tv[NP];               // the table's bytes
                 uint64_t meta0 = 0, meta1 = 0, meta2 = 0; // per base: min(v, 31) | extension base << 5 | no window << 7
 #pragma unroll
@@ -447,10 +443,8 @@ __global__ __launch_bounds__(256) void plan_kernel(WalkArgs a, uint32_t wave_lds
                     tv[j] = 0;
                     if (j < P) {
                         const uint32_t i = m + j;
-                        uint32_t ok;
-                        const uint32_t c = base_at(i, ok);
-                        code = (code << 2) | c;
-                        v = ok ? v + 1u : 0u;
+                        code = (code << 2) | base_at(i);
+                        v++;
                         const code_t key = code & omask;
                         const bool nowin = (uint64_t)o_start + i + 1u < 32u; // (as the stand-alone kernel: the buffer's first bytes)
                         const uint64_t me = (uint64_t)(min(v, 31u) | (((uint32_t)(code >> (2u * order)) & 3u) << 5) | (nowin ? 128u : 0u));

@@ -439,6 +439,8 @@ static void pm_resolve_item(const pm_index *m, const ora_plan_params *P, const u
     pl->tab_flagged = 0;
     if (len == 0) return;
     if (pl->seeded && pl->n_mm > P->list_cap) { pl->tab_flagged = 1; cn->tab_flagged++; return; } /* a wrong diagonal: the plain walk */
+    for (uint32_t i = 0; i < len; i++) /* a byte that is no base: the plain walk (the fused kernel's 2-bit copy of the item) */
+        if (pm_code(q[i]) >= 4) { pl->tab_flagged = 1; cn->tab_flagged++; if (!pl->seeded) cn->items_noplan++; return; }
     if (!pl->seeded) { /* no seed: every base on its own, no stretch logic */
         cn->items_noplan++;
         pm_window_walk(m, q, 0, len, tmp);
