@@ -55,8 +55,8 @@ int kbo_set_depth_table(int order);
  * one row, with that row's place in the path cover; a base deeper than the table knows is then read off the path-cover text
  * (by a kernel of its own behind the plan kernel) instead of sending its read to the plain walk; a quarter of those reads
  * remain.  Measured: slower at C2 (the redo pass is bound by its longest chain, not by its size), 4 % faster at C3.
- * -1 = where the table's margin over log4(rows) is below 2.9 bases (3 * 10^8 rows and more: there the table only wins with
- * them; default), 0 = never, 1 = always. */
+ * -1 = on indexes of 24 Mi rows and more whose table's margin over log4(rows) is below 3.75 bases (default: there the reads left to the plain walk are many
+ * enough for it to pay - C4 +12 %, C3 +4 % - and from 3 * 10^8 rows on the table only wins with them), 0 = never, 1 = always. */
 int kbo_set_depth_table_anchors(int mode);
 /* inspection / tests: the depth table of the copy of `idx` on `device` (-1 = current; the copy is made if there is none):
  * *order bases per entry (0: the copy has no table), 4^*order bytes; entry of a string (2-bit digits A, C, G, T = 0 .. 3, the

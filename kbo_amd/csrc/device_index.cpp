@@ -135,7 +135,10 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                 int order = std::min<int>({(int)std::ceil(lg + 3.2), 17, (int)idx->host.k});
                 // (a margin of 1.9 .. 2.9 bases - a 1 Gbp index - pays with anchors only: 2 M reads, A1 2.83 ms with the guided
                 // walk, 3.17 with the table alone - a fifth of the reads flagged -, 2.67 with its anchors)
-                const bool thin_margin = (double)order < lg + 2.9 && order < (int)idx->host.k;
+                // ... and below 3.75 bases the reads the table leaves to the plain walk are many enough for the anchors to pay
+                // (C4, margin 3.05: A1 per 100 M reads 76.7 -> 67.1 ms; C3, 3.7: 6.80 -> 6.55; C2, 3.9: 0.62 -> 0.66, slower)
+                // (only on indexes of 24 Mi rows and more: smaller ones see batches whose redo pass is a few long chains)
+                const bool thin_margin = (double)order < lg + 3.75 && order < (int)idx->host.k && idx->host.n_sets >= (24u << 20);
                 if ((double)order < lg + 1.9 && order < (int)idx->host.k) order = 0;
                 const int set = g_depth_table.load();
                 if (set < 0) order = 0;

@@ -318,10 +318,10 @@ def shipped_depth_table_order(k, n_sets):
 
 
 def shipped_depth_table_anchors(k, n_sets, order):
-    """device_index.cpp: whether a device copy's depth table gets anchors by default: only where its margin over log4(rows) is
-    thin (below 2.9 bases: a 1 Gbp index)"""
+    """device_index.cpp: whether a device copy's depth table gets anchors by default: where its margin over log4(rows) is
+    below 3.75 bases and the index has 24 Mi rows or more (C3, C4, a 1 Gbp index; not C2)"""
     import math
-    return bool(order and order < k and order < math.log2(max(n_sets, 4)) / 2.0 + 2.9)
+    return bool(order and order < k and order < math.log2(max(n_sets, 4)) / 2.0 + 3.75 and n_sets >= (24 << 20))
 
 
 def shipped_plan_params(k, n_sets, recovery_lines=None, depth_table=None, depth_anchors=None):
