@@ -8,7 +8,7 @@ import json
 import os
 import sys
 
-A1 = ("plan_kernel", "dtab_resolve_kernel", "plan_count_kernel", "scan_kernel", "plan_emit_kernel", "ms_walk_guided_kernel",
+A1 = ("plan_kernel", "dtab_resolve_kernel", "dtab_stretch_kernel", "plan_count_kernel", "scan_kernel", "plan_emit_kernel", "ms_walk_guided_kernel",
       "ms_walk_recovery_kernel", "redo_collect_kernel", "ms_walk_kernel")
 summ, key, source = json.load(open(sys.argv[1])), sys.argv[2], sys.argv[3]
 per_step_launches = int(sys.argv[4]) if len(sys.argv) > 4 else 1
