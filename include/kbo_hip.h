@@ -378,7 +378,9 @@ int kbo_index_path_cover(const kbo_index_t *idx, uint8_t *text, uint32_t *pos, u
  * 32..63, 0 } for c = A, C, G, T, then the 64 LCS bytes of those rows (0 beyond the last row).  n_sets / 64 + 2 lines and
  * one all-zero line; *n_bytes receives the size, lines == NULL only asks for it. */
 int kbo_index_recovery_lines(const kbo_index_t *idx, uint8_t *lines, size_t *n_bytes);
-/* bytes of path cover + recovery lines + seed table a device copy of this index carries (0 = none) */
+/* bytes of path cover + recovery lines + seed table + depth table (and its anchors) a device copy of this index carries (0 =
+ * none).  The two tables are sized by log4(rows), not by the index: up to 2 GiB + 64 GiB (kbo_hip_tuning.h: kbo_set_depth_table,
+ * INTEGRATION.md "Device memory: the depth table"). */
 uint64_t kbo_index_device_plan_bytes(const kbo_index_t *idx);
 
 /* Tuning knobs, experiment switches and test hooks (none of them changes a result) are declared in kbo_hip_tuning.h. */
