@@ -165,6 +165,19 @@ int kbo_index_to_device(kbo_index_t *idx, int device);
 int kbo_index_device_bytes(const kbo_index_t *idx, uint64_t *rank_bytes, uint64_t *lcs_bytes);
 /* bytes of two-base extension blocks a device copy of this index carries (0 = none, see kbo_set_pair_steps) */
 uint64_t kbo_index_device_pair_bytes(const kbo_index_t *idx);
+/* What the copy of `idx` on `device` (-1 = current) holds and what making it cost - the index is built once and queried many
+ * times (index.rs:56-99 is not part of any query), but the plan structures are sized by log4(rows), not by the index, so a
+ * caller that serves few queries per index wants to see the bill.  Bytes by part; entries_64bit = the contraction entries sit
+ * in their own allocation behind 64-bit offsets (rank blocks + entries >= 4 GiB); seconds of host work + upload by part
+ * (cover: laying out the path cover, 0 when the handle had one already - from an index file or an earlier copy).
+ * KBO_E_BAD_ARG when there is no such copy, KBO_E_UNSUPPORTED for a sharded handle (ask its shards). */
+typedef struct {
+    uint64_t rank_bytes, entry_bytes, pair_bytes;                           /* what every walk needs */
+    uint64_t cover_bytes, lines_bytes, seed_bytes, dtab_bytes, anchor_bytes; /* the plan structures (0: the copy has none) */
+    uint32_t entries_64bit, seed_depth, dtab_order, dtab_grouped;
+    double layout_seconds, upload_seconds, cover_seconds, lines_seconds, seed_seconds, dtab_seconds;
+} kbo_device_layout;
+int kbo_index_device_layout(kbo_index_t *idx, int device, kbo_device_layout *out);
 
 /* ------------------------------------------------------------------ A3 (host, f64)
  * derandomize::log_rm_max_cdf (derandomize.rs:91-100) and

@@ -55,6 +55,17 @@ class Variant(C.Structure):
                 ("ref_chars", C.POINTER(C.c_uint8)), ("ref_len", C.c_size_t)]
 
 
+class DeviceLayout(C.Structure):  # kbo_device_layout
+    _fields_ = [(n, C.c_uint64) for n in ("rank_bytes", "entry_bytes", "pair_bytes", "cover_bytes", "lines_bytes", "seed_bytes",
+                                         "dtab_bytes", "anchor_bytes")] + \
+               [(n, C.c_uint32) for n in ("entries_64bit", "seed_depth", "dtab_order", "dtab_grouped")] + \
+               [(n, C.c_double) for n in ("layout_seconds", "upload_seconds", "cover_seconds", "lines_seconds", "seed_seconds",
+                                          "dtab_seconds")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 class RLE(C.Structure):
     """kbo::format::RLE (format.rs:18-33)."""
     _fields_ = [(n, C.c_uint64) for n in
@@ -81,6 +92,7 @@ SYMBOLS = [
     "kbo_index_path_cover", "kbo_index_recovery_lines", "kbo_call_batch", "kbo_call_sites_dev", "kbo_call_walk_dev",
     "kbo_index_save_sbwt", "kbo_index_load_sbwt", "kbo_packed_words", "kbo_pack_reads", "kbo_unpack_matches",
     "kbo_matches_batch_packed", "kbo_find_batch_packed", "kbo_index_shards", "kbo_index_work_bytes",
+    "kbo_index_device_layout",
 ]
 # ... and include/kbo_hip_tuning.h (knobs, experiment switches, test hooks: not part of the drop-in boundary)
 TUNING_SYMBOLS = [
@@ -202,6 +214,7 @@ def lib():
     L.kbo_call_walk_dev.argtypes = [vp, vp, vp, sz, u64, sz, sz, vp, vp, sz, vp, vp, sz, vp]
     L.kbo_index_device_plan_bytes.argtypes = [vp]
     L.kbo_index_device_plan_bytes.restype = C.c_uint64
+    L.kbo_index_device_layout.argtypes = [vp, C.c_int, C.POINTER(DeviceLayout)]
     _lib = L
     return L
 

@@ -41,6 +41,12 @@ struct DevCopy {
     DevBuf fat;                      // recovery lines of the guided walk (sbwt_index.hpp)
     uint32_t fat_null = 0;
     DevBuf pc_text, pc_pos, pc_node; // path cover (sbwt_index.hpp PathCover), empty when the plan-guided walk is off
+    // what making this copy cost (kbo_index_device_layout): seconds of host work / device builds / uploads, by part
+    struct Setup {
+        double layout_s = 0, cover_s = 0, lines_s = 0, seed_s = 0, dtab_s = 0, upload_s = 0;
+        uint64_t rank_bytes = 0, entry_bytes = 0, pair_bytes = 0, cover_bytes = 0, lines_bytes = 0, seed_bytes = 0, dtab_bytes = 0,
+                 anchor_bytes = 0;
+    } setup;
     // Plan hold-off of THIS copy (one index on one device): a batch whose reads differ too much from the index gives the
     // plan up on the device; the host learns of it one launch late (asynchronous 8-byte copy into `bailed`, pinned, never
     // waited for) and then skips planning for the next kPlanHoldoff launches over this copy - and over no other.

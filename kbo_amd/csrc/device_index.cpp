@@ -5,6 +5,7 @@
 #include <cmath>
 
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 
 namespace kbo_host {
@@ -61,12 +62,17 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
         const size_t est_rank = (idx->host.n_sets / 96 + 2) * 64, est_ent = (idx->host.n_sets + 2) * 12;
         const bool want_pairs = idx->host.n_sets >= g_pair_min_rows && !g_force_big &&
                                 est_rank * 5 + est_ent + 64 < 0xFFFFFFF0ull;
+        using clk = std::chrono::steady_clock;
+        auto since = [](clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); };
+        clk::time_point t0 = clk::now();
         kbo::DeviceLayout lay;
         kbo::make_device_layout(idx->host, lay, want_pairs);
         int prev = current_device();
         if (prev != device) HIP_OK(hipSetDevice(device));
         DevCopy *dc = new DevCopy();
+        dc->setup.layout_s = since(t0);
         try {
+            t0 = clk::now();
             const size_t per = lay.n_blocks * 16;
             // arena = rank blocks of A,C,G,T | one all-zero "null" block | contraction entries.
             // When that exceeds the 32-bit offset range (n_sets * 12 B of entries >= ~4 GiB) the
@@ -105,13 +111,20 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
             dc->n_blocks = lay.n_blocks;
             idx->rank_bytes = per * 4;
             idx->lcs_bytes = ent_bytes;
+            dc->setup.rank_bytes = rank_bytes;
+            dc->setup.entry_bytes = ent_bytes;
+            dc->setup.pair_bytes = pair_bytes;
+            dc->setup.upload_s = since(t0);
             if (g_plan_enabled && !idx->transient) { // path cover for the plan-guided walk: 9 bytes per row
                 HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&dc->plan.bailed), 64, hipHostMallocDefault));
                 dc->plan.bailed[0] = dc->plan.bailed[1] = 0;
+                t0 = clk::now();
                 if (!idx->cover) { // (idx->mu is held)
                     idx->cover.reset(new kbo::PathCover());
                     kbo::make_path_cover(idx->host, *idx->cover);
                 }
+                dc->setup.cover_s = since(t0);
+                t0 = clk::now();
                 const kbo::PathCover &pc = *idx->cover;
                 static_assert(kbo::PathCover::kPad == kbo::kPlanPad, "text padding");
                 dc->pc_text.alloc(pc.text.size() + 16);
@@ -121,13 +134,18 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                 HIP_OK(hipMemcpy(dc->pc_pos.p, pc.pos.data(), pc.pos.size() * 4, hipMemcpyHostToDevice));
                 HIP_OK(hipMemcpy(dc->pc_node.p, pc.node_at.data(), pc.node_at.size() * 4, hipMemcpyHostToDevice));
                 idx->plan_bytes = pc.text.size() + pc.pos.size() * 4 + pc.node_at.size() * 4;
+                dc->setup.cover_bytes = idx->plan_bytes;
+                dc->setup.upload_s += since(t0);
                 {
+                    t0 = clk::now();
                     std::vector<uint8_t> lines;
                     kbo::make_recovery_lines(idx->host, lines);
                     dc->fat.alloc(lines.size() + 16);
                     HIP_OK(hipMemcpy(dc->fat.p, lines.data(), lines.size(), hipMemcpyHostToDevice));
                     dc->fat_null = (uint32_t)(lines.size() / 128 - 1);
                     idx->plan_bytes += lines.size();
+                    dc->setup.lines_bytes = lines.size();
+                    dc->setup.lines_s = since(t0);
                 }
                 // (the depth table's order is decided here, ahead of the seed table: an index with a depth table gets its seed
                 // table from the same device build, as deep as a seed has to be)
@@ -167,6 +185,7 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                     dc->seed_d = D;
                     idx->plan_bytes += (size_t)8 << (2u * D);
                 } else if (D) {
+                    t0 = clk::now();
                     const kbo::HostNav nav(idx->host);
                     std::vector<uint32_t> cur{0u, (uint32_t)idx->host.n_sets}, nxt; // {l, r} pairs, level by level
                     for (uint32_t t = 0; t < D; t++) {
@@ -189,6 +208,7 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                     HIP_OK(hipMemcpy(dc->seed_tab.p, cur.data(), cur.size() * 4, hipMemcpyHostToDevice));
                     dc->seed_d = D;
                     idx->plan_bytes += cur.size() * 4;
+                    dc->setup.seed_s = since(t0);
                 }
                 // depth table (dtab_kernels.hip): for every string of `order` bases the longest suffix of it that is a suffix
                 // of a row.  One independent byte look-up then gives the MS value of a base wherever the value is at most
@@ -217,6 +237,7 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                         dc->seed_d = 0;
                     }
                     if (order > 0) {
+                        t0 = clk::now();
                         DevBuf tmp, plain;
                         plain.alloc(plain_bytes);
                         tmp.alloc(tmp_bytes);
@@ -255,7 +276,12 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                         dc->dtab_order = (uint32_t)order;
                         dc->dtab_grouped = grouped;
                         idx->plan_bytes += kbo::dtab_bytes((uint32_t)order, grouped);
+                        HIP_OK(hipDeviceSynchronize());
+                        dc->setup.dtab_s = since(t0);
+                        dc->setup.dtab_bytes = kbo::dtab_bytes((uint32_t)order, grouped);
+                        dc->setup.anchor_bytes = dc->anchor_bits ? ((uint64_t)1 << dc->anchor_bits) * 8 : 0;
                     }
+                    dc->setup.seed_bytes = dc->seed_d ? (uint64_t)8 << (2u * dc->seed_d) : 0;
                 }
             }
         } catch (...) {

@@ -1400,6 +1400,38 @@ int kbo_index_plan_holdoff(kbo_index_t *idx, int device, uint32_t *bails, int *h
     });
 }
 
+int kbo_index_device_layout(kbo_index_t *idx, int device, kbo_device_layout *out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && out, KBO_E_BAD_ARG, "null argument");
+        require_unsharded(idx, "kbo_index_device_layout");
+        const int dev = device < 0 ? current_device() : device;
+        std::lock_guard<std::mutex> g(idx->mu);
+        auto it = idx->dev.find(dev);
+        KBO_REQUIRE(it != idx->dev.end(), KBO_E_BAD_ARG, "the index has no copy on that device");
+        const DevCopy &dc = *it->second;
+        *out = kbo_device_layout{};
+        out->rank_bytes = dc.setup.rank_bytes;
+        out->entry_bytes = dc.setup.entry_bytes;
+        out->pair_bytes = dc.setup.pair_bytes;
+        out->cover_bytes = dc.setup.cover_bytes;
+        out->lines_bytes = dc.setup.lines_bytes;
+        out->seed_bytes = dc.setup.seed_bytes;
+        out->dtab_bytes = dc.setup.dtab_bytes;
+        out->anchor_bytes = dc.setup.anchor_bytes;
+        out->entries_64bit = dc.big ? 1u : 0u;
+        out->seed_depth = dc.seed_d;
+        out->dtab_order = dc.dtab_order;
+        out->dtab_grouped = dc.dtab_grouped ? 1u : 0u;
+        out->layout_seconds = dc.setup.layout_s;
+        out->upload_seconds = dc.setup.upload_s;
+        out->cover_seconds = dc.setup.cover_s;
+        out->lines_seconds = dc.setup.lines_s;
+        out->seed_seconds = dc.setup.seed_s;
+        out->dtab_seconds = dc.setup.dtab_s;
+    });
+}
+
 uint64_t kbo_index_device_plan_bytes(const kbo_index_t *idx)
 {
     if (!idx) return 0;

@@ -1,0 +1,490 @@
+// map_kernels.hip — gfx950 (MI355X, CDNA4): kbo::map / kbo::matches for a batch of READS in one launch.
+//
+// The chain the reference runs per sequence (lib.rs:735-738 for map, lib.rs:624-627 for matches / find):
+//     index::query_sbwt (index.rs:243-256)  ->  derandomize_ms_vec (derandomize.rs:269-288)  ->  translate_ms_vec
+//     (translate.rs:263-293)  [-> format::relative_to_ref (format.rs:266-287)]
+// as ONE kernel over 64 reads per wave, everything 2-bit packed except the bytes that leave:
+//
+//   map_reads_kernel   0. the wave's stretch of the query buffer (its 64 reads lie back to back) is loaded once, in whole
+//                         lines, and turned into 2-bit digits on the way into LDS (a quarter of the bytes; a byte that is no
+//                         base sends its read to the plain walk);
+//                      1. seed: the first D bases of a read - D = what a seed must be deep, log4(rows) + 3 - are looked up in
+//                         a table of text positions (DevIndexView::seed_pos): one load gives the read's diagonal of the
+//                         path-cover text (plan_kernels.hip has the idea; there it took a table of intervals and a second,
+//                         dependent load of the row's position);
+//                      2. compare: 16 bases per XOR against the 2-bit text (DevIndexView::pc_tm: text and path-start marks
+//                         interleaved, 0.5 B per row: 2.5 MB on a 5 Mbp index, L2-resident where the byte text was not);
+//                      3. the stretches behind the mismatches from the depth table (dtab_kernels.hip has the rule), the wave's
+//                         mismatches dealt out to its lanes as in plan_kernel<FUSE>; the MS values - k where nothing
+//                         happened, the ramp behind a mismatch, the table's values right behind it - are put together in LDS
+//                         bytes by the lane that resolved the mismatch;
+//                      4. derandomize + translate, right to left, one lane per read, in place over those bytes;
+//                      5. the characters leave in whole lines, relative_to_ref applied on the way out (the bases come from the
+//                         2-bit copy).
+//   Reads it cannot finish - a base deeper than the table knows, more mismatches than a list holds, no seed and a deep match,
+//   a byte that is no base - are flagged exactly as plan_kernel<FUSE> flags them; redo_collect_kernel + the plain walk give
+//   their MS values and launch_derand_flagged their characters.  Nothing depends on a diagonal being right.
+//
+//   pack_text_kernel / seed_pos_kernel   build pc_tm and seed_pos on the device from the byte text and the interval table.
+//
+// Integer / byte work only: no MFMA.  One 64-lane wave per workgroup (the LDS of a CU then holds twelve of them).
+#include "device_util.hpp"
+
+#include <type_traits>
+
+namespace kbo {
+namespace {
+
+// stores bytes [lo, hi) of a 16-byte block to o + lo .. o + hi (0 <= lo <= hi <= 16)
+__device__ __forceinline__ void st_range16(uint8_t *o, const uint4 &v, uint32_t lo, uint32_t hi)
+{
+#pragma unroll
+    for (uint32_t t = 0; t < 16; t++) {
+        const uint32_t w = (t >> 2) == 0 ? v.x : (t >> 2) == 1 ? v.y : (t >> 2) == 2 ? v.z : v.w;
+        if (t >= lo && t < hi) o[t] = (uint8_t)(w >> ((t & 3u) * 8u));
+    }
+}
+
+// bit 2 (15 - j) set for every bit j of the low 16 bits of x that is set (the marks of 16 positions, spread to the digit grid)
+__device__ __forceinline__ uint32_t spread_marks(uint32_t x)
+{
+    x = __builtin_bitreverse32(x) >> 16; // bit j -> bit 15 - j
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+// pc_tm[u] = { 2-bit digits of text positions [16 u - kPlanPad, 16 u - kPlanPad + 16), first one most significant;
+//              01 at every position that matches nothing: a path start, the padding, beyond the text }
+__global__ __launch_bounds__(256) void pack_text_kernel(const uint8_t *__restrict__ text_padded, uint64_t n_bytes, uint2 *__restrict__ out,
+                                                        uint64_t n_units)
+{
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_units) return;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    const uint64_t b = 16ull * u;
+    if (b + 16u <= n_bytes) v = *reinterpret_cast<const uint4 *>(text_padded + b);
+    else if (b < n_bytes) {
+        uint8_t tmp[16];
+        for (uint32_t t = 0; t < 16; t++) tmp[t] = b + t < n_bytes ? text_padded[b + t] : (uint8_t)0;
+        __builtin_memcpy(&v, tmp, 16);
+    }
+    uint32_t code, valid;
+    pack16(v, code, valid);
+    out[u] = make_uint2(code, spread_marks(~valid & 0xFFFFu));
+}
+
+__global__ __launch_bounds__(256) void seed_pos_kernel(const uint2 *__restrict__ seed_tab, const uint32_t *__restrict__ pc_pos,
+                                                       uint32_t *__restrict__ out, uint64_t n)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n) return;
+    const uint2 iv = seed_tab[w];
+    out[w] = iv.x < iv.y ? pc_pos[iv.x] : 0xFFFFFFFFu;
+}
+
+constexpr uint32_t kMapWords = 10;       // 16-base words per read: reads of up to 160 bases
+constexpr uint32_t kMapSlack = 48;       // bytes of the byte region behind the staged stretch
+
+// NP = bases a stretch can take: 16 (tables of up to 15 bases: 32-bit keys) or 18 (16 / 17 bases)
+template <int NP>
+__global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stage_bytes, uint32_t lin_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t map_lds[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t idx = blockIdx.x * 64u + lane;
+    uint8_t *so = map_lds;                                                       // MS bytes, then characters: the wave's stretch
+    uint32_t *lin = reinterpret_cast<uint32_t *>(map_lds + stage_bytes) + 4;     // the stretch as 2-bit digits (lin[-1] = 0)
+    uint8_t *spw = map_lds + stage_bytes + 4u * (lin_words + 4u);                // 64 x 16 bytes: mismatch positions 0 .. 12, flag, prefix
+    uint8_t *sp = spw + lane * 16u;
+    const uint32_t n = a.ix.n, k = a.ix.k;
+    const uint8_t *qb = a.q;
+    uint32_t start = 0, len = 0, warm = 0, tail = 0;
+    const bool have_item = idx < a.n_items;
+    if (have_item) {
+        const uint4 it = ld16(reinterpret_cast<const uint8_t *>(a.items), idx * 16u);
+        start = it.x; // launches cover < 4 GiB of query
+        len = it.z;
+        warm = it.w & 0xFFFFu;
+        tail = it.w >> 16;
+    }
+    const bool plannable = have_item && len > 0;
+    const uint32_t cap = a.plan_cap;
+
+    // ---- 0. the wave's stretch: reads back to back, whole (no warm-up bases: these are reads, not chunks)
+    const uint64_t have = __ballot(have_item); // (item lanes are the wave's first lanes)
+    if (have == 0) return;
+    const uint32_t last = (uint32_t)__popcll(have) - 1u;
+    const uint32_t nxt_start = __shfl_down(start, 1);
+    const bool bad_item = have_item && ((lane < last && nxt_start != start + len) || warm != 0 || tail != 0 || len > 16u * kMapWords);
+    const uint32_t lo = __shfl(start, 0), wave_hi = __shfl(start + len, (int)last);
+    const uint32_t base16 = lo & ~15u, soff = start - base16, span = wave_hi - base16;
+    const bool staged = __ballot(bad_item) == 0 && wave_hi > lo && (uint64_t)span + kMapSlack <= stage_bytes;
+    if (!staged) { // (cannot happen for a batch of reads the host sent here; if it does, every item takes the plain walk)
+        if (have_item) a.redo[idx] = len != 0 ? 1 : 0;
+        const uint64_t fm = __ballot(have_item && len != 0);
+        if (lane == 0 && fm) atomicAdd(a.qctl + 4, (uint32_t)__popcll(fm));
+        return;
+    }
+    const uint32_t nblk = (span + 15u) >> 4;
+    bool has_invalid = false;
+    if (lane == 0) lin[-1] = 0;
+    for (uint32_t c0 = 0; c0 < nblk + 2u; c0 += 64u) {
+        const uint32_t c = c0 + lane;
+        uint32_t code = 0, valid = 0xFFFFu;
+        if (c < nblk) {
+            const uint4 v = ld16u(qb, base16 + 16u * c); // (reads <= 15 bytes past the last read)
+            pack16(v, code, valid);
+            // only the bytes of this wave's reads count: [lo, wave_hi)
+            const uint32_t b0 = base16 + 16u * c;
+            const uint32_t from = lo > b0 ? lo - b0 : 0u, to = min(16u, wave_hi - b0);
+            const uint32_t inr = ((1u << to) - 1u) & ~((1u << from) - 1u);
+            valid |= ~inr;
+        }
+        if (c < lin_words) lin[c] = code;
+        uint64_t bm = __ballot((valid & 0xFFFFu) != 0xFFFFu);
+        while (bm) { // (rare: a byte that is no base - its read, and a neighbour that shares the block, take the plain walk)
+            const uint32_t L = (uint32_t)__ffsll((long long)bm) - 1u;
+            bm &= bm - 1ull;
+            const uint32_t blo = 16u * (c0 + L);
+            has_invalid = has_invalid || (plannable && soff < blo + 16u && soff + len > blo);
+        }
+    }
+    for (uint32_t c = lane * 16u; c < span + 16u; c += 1024u) // MS bytes: k wherever nothing says otherwise
+        *reinterpret_cast<uint4 *>(so + c) = make_uint4(k * 0x01010101u, k * 0x01010101u, k * 0x01010101u, k * 0x01010101u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // 16 bases of the stretch from base S on (first one most significant) / the 16 bases ending at base E (last one least)
+    auto from_base = [&](uint32_t S) -> uint32_t {
+        const uint32_t W = S >> 4, r = S & 15u;
+        const uint64_t V = ((uint64_t)lin[W] << 32) | lin[W + 1u];
+        return (uint32_t)(V >> (32u - 2u * r));
+    };
+    auto ending_at = [&](uint32_t E) -> uint64_t { // (17 + E mod 16 bases are there: enough for the windows of every table)
+        const uint32_t W = E >> 4, r = E & 15u;
+        const uint64_t V = ((uint64_t)lin[(int32_t)W - 1] << 32) | lin[W];
+        return V >> (2u * (15u - r));
+    };
+    auto base_at = [&](uint32_t S) -> uint32_t { return (lin[S >> 4] >> (2u * (15u - (S & 15u)))) & 3u; };
+
+    // ---- 1. seed: one table look-up gives the diagonal
+    uint32_t qw[kMapWords];
+#pragma unroll
+    for (uint32_t g = 0; g < kMapWords; g++) qw[g] = (plannable && 16u * g < len) ? from_base(soff + 16u * g) : 0u;
+    const uint32_t D = a.ix.seed_d;
+    const uint32_t dmask = D >= 16u ? 0xFFFFFFFFu : ((1u << (2u * D)) - 1u);
+    const uint32_t jmax = min(len, cap);
+    uint32_t e = D - 1u, p0 = 0, st_lookups = 0;
+    bool seeded = false;
+    for (;;) {
+        const bool act = plannable && !has_invalid && !seeded && e < jmax;
+        if (__ballot(act) == 0) break;
+        if (act) {
+            const uint32_t key = (uint32_t)ending_at(soff + e) & dmask;
+            const uint32_t tp = a.ix.seed_pos[key];
+            st_lookups++;
+            if (tp != 0xFFFFFFFFu) {
+                seeded = true;
+                p0 = tp - e;
+            } else e += (D + 1u) / 2u;
+        }
+    }
+
+    // ---- 2. compare with the text on the diagonal
+    uint32_t cnt = 0;
+    if (__ballot(seeded)) {
+        uint32_t mmw[kMapWords];
+#pragma unroll
+        for (uint32_t g = 0; g < kMapWords; g++) mmw[g] = 0;
+        if (seeded) {
+            const uint32_t q0 = p0 + kPlanPad, r = q0 & 15u;
+            const uint8_t *tp = reinterpret_cast<const uint8_t *>(a.ix.pc_tm) + (size_t)(q0 >> 4) * 8u;
+            uint4 L[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) __builtin_memcpy(&L[i], tp + 16 * i, 16);
+            uint32_t T[12], M[12];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                T[2 * i] = L[i].x;
+                M[2 * i] = L[i].y;
+                T[2 * i + 1] = L[i].z;
+                M[2 * i + 1] = L[i].w;
+            }
+#pragma unroll
+            for (uint32_t g = 0; g < kMapWords; g++) {
+                if (16u * g < len) {
+                    const uint32_t tw = (uint32_t)((((uint64_t)T[g] << 32) | T[g + 1]) >> (32u - 2u * r));
+                    const uint32_t mk = (uint32_t)((((uint64_t)M[g] << 32) | M[g + 1]) >> (32u - 2u * r));
+                    const uint32_t x = qw[g] ^ tw;
+                    uint32_t mm = (x | (x >> 1) | mk) & 0x55555555u;
+                    const uint32_t nb = len - 16u * g;
+                    if (nb < 16u) mm &= ~0u << (32u - 2u * nb);
+                    mmw[g] = mm;
+                    cnt += (uint32_t)__popc(mm);
+                }
+            }
+        }
+        uint32_t filled = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < kMapWords; g++) {
+            uint32_t mm = mmw[g];
+            while (__ballot(mm != 0)) {
+                if (mm) {
+                    const uint32_t j = (uint32_t)__clz((int)mm) >> 1;
+                    if (filled < 13u) sp[filled] = (uint8_t)(16u * g + j);
+                    filled++;
+                    mm &= ~(0x40000000u >> (2u * j));
+                }
+            }
+        }
+    }
+    // the ramp of a read's first bases (depth i + 1 while nothing mismatches: the bases equal a path of the text)
+    bool flag = plannable && seeded && cnt > a.plan_list + 1u; // more mismatches than the list holds: the plain walk
+    const bool no_plan = plannable && !seeded && !has_invalid; // no seed at all: every base from the table, 16 at a time
+    flag = flag || (plannable && has_invalid);
+    {
+        const uint32_t first_mm = (seeded && cnt > 0) ? (uint32_t)sp[0] : len;
+        const uint32_t lim = (seeded && !flag) ? min(min(k - 1u, first_mm), len) : 0u;
+        const uint32_t most = min(k - 1u, 16u * kMapWords);
+        for (uint32_t i = 0; i < most; i++) {
+            if (__ballot(i < lim) == 0) break;
+            if (i < lim) so[soff + i] = (uint8_t)(i + 1u);
+        }
+    }
+
+    // ---- 3. the stretches behind the mismatches from the depth table (rule: dtab_kernels.hip), dealt out to the lanes
+    uint32_t st_look = 0, st_written = 0, st_anch = 0;
+    {
+        const uint32_t order = a.ix.dtab_order;
+        const uint32_t my_n = !plannable || flag ? 0u : (no_plan ? (len + 15u) / 16u : cnt);
+        uint32_t incl = my_n;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += t;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        sp[13] = 0;
+        *reinterpret_cast<uint16_t *>(sp + 14) = (uint16_t)incl;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        using code_t = typename std::conditional<NP == 16, uint32_t, uint64_t>::type;
+        const code_t omask = (code_t)((1ull << (2u * order)) - 1ull);
+        for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
+            const uint32_t w = w0 + lane;
+            const bool work = w < total;
+            uint32_t lo_l = 0, hi_l = 63; // owner: the first lane whose inclusive prefix exceeds w
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const uint32_t mid = (lo_l + hi_l) >> 1;
+                const uint32_t pm = *reinterpret_cast<const uint16_t *>(spw + mid * 16u + 14u);
+                if (pm > w) hi_l = mid;
+                else lo_l = mid + 1u;
+            }
+            const uint32_t owner = work ? lo_l : lane;
+            const uint32_t o_incl = __shfl(incl, (int)owner), o_n = __shfl(my_n, (int)owner), o_soff = __shfl(soff, (int)owner),
+                           o_len = __shfl(len, (int)owner), o_np = __shfl(no_plan ? 1u : 0u, (int)owner);
+            const bool blockmode = o_np != 0;
+            if (work) {
+                const uint32_t t = w - (o_incl - o_n);
+                const uint8_t *osp = spw + owner * 16u;
+                const uint32_t m = blockmode ? 16u * t : (uint32_t)osp[t];
+                const uint32_t nxt = (blockmode || t + 1u >= o_n) ? o_len : (uint32_t)osp[t + 1u];
+                const uint32_t P = min(min(blockmode ? 16u : order + 1u, (uint32_t)NP), min(nxt, o_len) - m); // bases looked up: m .. m + P - 1
+                uint32_t tv[NP];
+                uint32_t evalmask = 0, unkmask = 0, satmask = 0;
+                uint32_t outv[5] = {0, 0, 0, 0, 0};
+                // window ending at base i of the owner's read: its `order` newest bases are the key; v = bases it has inside the read
+#pragma unroll
+                for (uint32_t j = 0; j < (uint32_t)NP; j++) {
+                    tv[j] = 0;
+                    if (j < P) {
+                        const uint32_t i = m + j;
+                        const code_t key = (code_t)ending_at(o_soff + i) & omask;
+                        // (bases in front of the read inside the window belong to its neighbour, or are zeros: the rule cuts the value
+                        // to the bases that count, min(byte, v), and suffixes of a present string are present)
+                        tv[j] = !a.ix.dtab_grouped ? a.ix.dtab[key]
+                                                   : a.ix.dtab[NP == 16 ? dtab_grouped_addr32((uint32_t)key, i % 3u, order) : dtab_grouped_addr((uint64_t)key, i % 3u, order)];
+                        st_look++;
+                    }
+                }
+                bool done = false;
+                uint32_t n_eval = 0; // bases the stretch decided (a block: all of them)
+#pragma unroll
+                for (uint32_t j = 0; j < (uint32_t)NP; j++) {
+                    if (j < P && !done) {
+                        const uint32_t i = m + j;
+                        const uint32_t vv = min(i + 1u, 31u); // bases of the read up to and including i
+                        const uint32_t byte = tv[j];
+                        uint32_t Lv = k + 1u;
+                        if (!(byte & 0x80u)) Lv = min(byte, vv);
+                        else if (vv <= order || order >= k) Lv = min(vv, order);
+                        else {
+                            // all `order` bases are a suffix of a row: deeper when the base in front of them extends it
+                            const uint32_t eb = base_at(o_soff + i - order); // (vv > order: that base is the read's own)
+                            if ((byte >> eb) & 1u) satmask |= 1u << j;
+                            else Lv = order;
+                        }
+                        outv[j >> 2] |= min(Lv, k) << (8u * (j & 3u));
+                        evalmask |= 1u << j;
+                        n_eval = j + 1u;
+                        done = !blockmode && Lv <= j;
+                    }
+                }
+                st_anch += (uint32_t)__popc(satmask);
+                unkmask |= satmask;
+                if (unkmask) spw[owner * 16u + 13u] = 1; // the owner's read goes to the plain walk
+                // (a stretch with an unknown base writes nothing; a block writes the bases it knows)
+                const uint32_t wmask = blockmode ? evalmask & ~unkmask : (unkmask ? 0u : evalmask);
+#pragma unroll
+                for (uint32_t j = 0; j < (uint32_t)NP; j++)
+                    if ((wmask >> j) & 1u) {
+                        so[o_soff + m + j] = (uint8_t)(outv[j >> 2] >> (8u * (j & 3u)));
+                        st_written++;
+                    }
+                // behind the stretch: the ramp up to the next mismatch (depth = bases since this one), k from k bases on (in place)
+                if (!blockmode && !unkmask) {
+                    const uint32_t rend = min(nxt - m, k);
+                    for (uint32_t j = n_eval; j < rend; j++) so[o_soff + m + j] = (uint8_t)j;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        flag = flag || sp[13] != 0;
+    }
+    // ---- the MS values themselves, when the caller wants them too (whole lines)
+    if (a.map_want_ms) {
+        for (uint32_t c = lane * 16u; c < span; c += 1024u) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(so + c);
+            const uint32_t g0 = base16 + c;
+            if (g0 >= lo && g0 + 16u <= wave_hi) __builtin_memcpy(a.d_out + g0, &v, 16);
+            else st_range16(a.d_out + g0, v, lo > g0 ? min(lo - g0, 16u) : 0u, min(wave_hi - g0, 16u));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- 4. derandomize_ms_vec + translate_ms_vec, right to left, in place (derand_kernels.hip has the derivation of the
+    // closed form of the 'R','R' look-ahead): x = derandomised value, window (x_prev, x_cur, x_next) = x[p-1], x[p], x[p+1]
+    if (plannable && !flag && len >= 3u) {
+        const int K = (int)k, T = (int)a.map_thr;
+        const uint32_t Tm1 = (uint32_t)(T - 1);
+        uint8_t *at = so + soff;
+        auto step = [&](int av, int x_cur) { return (av == K) ? K : ((av > T && x_cur < av) ? av : x_cur - 1); };
+        auto plain = [&](int x_cur, int next, int prev) -> uint32_t {
+            return x_cur <= 0 ? ((next == 1 && prev > 0) ? (uint32_t)'X' : (uint32_t)'-') : (uint32_t)'M';
+        };
+        int av = at[len - 1];
+        int x_cur = av > T ? av : 0; // derandomize.rs:282
+        int a_below = at[len - 2];
+        int x_prev = step(a_below, x_cur);
+        bool in_cur = (uint32_t)(x_cur - 1) < Tm1, gt_cur = x_cur > T;
+        at[len - 1] = (uint8_t)((gt_cur && in_cur) ? (uint32_t)'R' : plain(x_cur, x_cur, x_prev));
+        int x_next = x_cur;
+        bool in_next = in_cur;
+        x_cur = x_prev;
+        gt_cur = x_cur > T;
+        in_cur = (uint32_t)(x_cur - 1) < Tm1;
+        a_below = at[len - 3];
+#pragma unroll 4
+        for (uint32_t p = len - 2; p >= 2; p--) {
+            x_prev = step(a_below, x_cur);
+            a_below = at[p - 2];
+            const bool gt_prev = x_prev > T;
+            const bool is_r = (gt_prev && in_cur) || (gt_cur && in_next);
+            at[p] = (uint8_t)(is_r ? (uint32_t)'R' : plain(x_cur, x_next, x_prev));
+            x_next = x_cur;
+            in_next = in_cur;
+            x_cur = x_prev;
+            gt_cur = gt_prev;
+            in_cur = (uint32_t)(x_cur - 1) < Tm1;
+        }
+        x_prev = step(a_below, x_cur); // a_below == at[0]
+        at[1] = (uint8_t)((gt_cur && in_next) ? (uint32_t)'R' : plain(x_cur, x_next, K));
+        x_next = x_cur;
+        in_next = in_cur;
+        x_cur = x_prev;
+        at[0] = (uint8_t)((x_cur > T && in_next) ? (uint32_t)'R' : plain(x_cur, x_next, K));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- 5. the characters leave in whole lines; format::relative_to_ref (format.rs:270-286) on the way: 'M' and 'R' keep the
+    // read's base, everything else becomes '-' (flagged reads' bytes are rewritten by launch_derand_flagged)
+    for (uint32_t c = lane * 16u; c < span; c += 1024u) {
+        uint4 v = *reinterpret_cast<const uint4 *>(so + c);
+        if (a.map_fmt) {
+            const uint32_t dg = lin[c >> 4];
+            auto fmt4 = [&](uint32_t ch, uint32_t d8) -> uint32_t { // four characters and the four bases behind them
+                const uint32_t sel = ((d8 >> 6) & 3u) | (((d8 >> 4) & 3u) << 8) | (((d8 >> 2) & 3u) << 16) | ((d8 & 3u) << 24);
+                const uint32_t letters = __builtin_amdgcn_perm(0u, 0x54474341u, sel);
+                const uint32_t keep = ((ch >> 6) & (ch | ~(ch >> 3)) & 0x01010101u) * 0xFFu; // bytes that are 'M' or 'R' (of M - X R)
+                return (letters & keep) | (0x2D2D2D2Du & ~keep);
+            };
+            v.x = fmt4(v.x, dg >> 24);
+            v.y = fmt4(v.y, (dg >> 16) & 0xFFu);
+            v.z = fmt4(v.z, (dg >> 8) & 0xFFu);
+            v.w = fmt4(v.w, dg & 0xFFu);
+        }
+        const uint32_t g0 = base16 + c;
+        if (g0 >= lo && g0 + 16u <= wave_hi) __builtin_memcpy(a.chars_out + g0, &v, 16);
+        else st_range16(a.chars_out + g0, v, lo > g0 ? min(lo - g0, 16u) : 0u, min(wave_hi - g0, 16u));
+    }
+    plan_stats_add(a.pstats, kPlanStatSeedLookups, st_lookups, kPlanStatSeedExtensions, 0u, kPlanStatMismatches, seeded ? cnt : 0u, 0, 0);
+    plan_stats_add(a.pstats, kPlanStatTabLookups, st_look, kPlanStatTabWritten, st_written, kPlanStatTabFlagged, flag ? 1u : 0u,
+                   kPlanStatTabAnchored, st_anch);
+    const uint64_t fm = __ballot(flag), nm = __ballot(no_plan);
+    if (lane == 0) {
+        if (fm) atomicAdd(a.qctl + 4, (uint32_t)__popcll(fm));
+        if (nm) atomicAdd(a.qctl + 5, (uint32_t)__popcll(nm));
+    }
+    if (have_item) a.redo[idx] = flag ? 1 : 0;
+}
+
+} // namespace
+
+hipError_t launch_pack_text(const uint8_t *d_text_padded, uint64_t n_bytes, uint2 *d_out, uint64_t n_units, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pack_text_kernel, dim3((unsigned)((n_units + 255) / 256)), dim3(256), 0, stream, d_text_padded, n_bytes, d_out, n_units);
+    return hipGetLastError();
+}
+
+hipError_t launch_seed_pos(const uint2 *d_seed_tab, const uint32_t *d_pc_pos, uint32_t *d_out, uint32_t seed_d, hipStream_t stream)
+{
+    const uint64_t n = 1ull << (2u * seed_d);
+    hipLaunchKernelGGL(seed_pos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_seed_tab, d_pc_pos, d_out, n);
+    return hipGetLastError();
+}
+
+bool map_reads_applies(const WalkArgs &a)
+{
+    return a.ix.dtab && a.ix.pc_tm && a.ix.seed_pos && a.ix.seed_d >= 4u && a.ix.seed_d <= 14u && a.ix.dtab_order >= 4u && a.ix.dtab_order <= 17u &&
+           a.ix.dtab_order <= a.ix.k && !a.call_sites && !a.lo_out && a.max_item_len != 0 && a.max_item_len <= 16u * kMapWords && a.redo && a.qctl &&
+           a.units;
+}
+
+// the kernel + the list of the reads it could not finish (redo_collect_kernel, for the plain walk: launch_map_reads_redo)
+hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
+{
+    if (a.n_items == 0) return hipSuccess;
+    a.table_mode = 1;
+    a.table_fused = 1;
+    a.unit_bail = a.n_items / 2u + 64u;
+    a.plan_list = kPlanList;
+    hipError_t e = hipMemsetAsync(a.qctl, 0, 64 + kPlanStatSlots * kPlanStatWords * 4, stream);
+    if (e != hipSuccess) return e;
+    const uint32_t stage_bytes = (64u * a.max_item_len + 16u + kMapSlack + 15u) / 16u * 16u;
+    const uint32_t lin_words = stage_bytes / 16u + 4u;
+    const uint32_t lds = stage_bytes + 4u * (lin_words + 4u) + 1024u;
+    if (a.ix.dtab_order <= 15u)
+        hipLaunchKernelGGL((map_reads_kernel<16>), dim3((a.n_items + 63u) / 64u), dim3(64), lds, stream, a, stage_bytes, lin_words);
+    else
+        hipLaunchKernelGGL((map_reads_kernel<18>), dim3((a.n_items + 63u) / 64u), dim3(64), lds, stream, a, stage_bytes, lin_words);
+    return hipGetLastError();
+}
+
+} // namespace kbo

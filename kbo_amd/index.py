@@ -67,6 +67,12 @@ class SbwtIndexVariant:
         """Bytes of path cover (plan-guided walk) in the device copies of this index (0 = none)."""
         return int(lib().kbo_index_device_plan_bytes(self._h))
 
+    def device_layout(self, device=-1):
+        """what the copy on `device` holds and what making it cost (kbo_hip.h kbo_device_layout) as a dict"""
+        lay = _capi.DeviceLayout()
+        check(lib().kbo_index_device_layout(self._h, device, C.byref(lay)))
+        return lay.as_dict()
+
     def export_parts(self):
         """(rows[4] uint64 words, C[4], lcs bytes) — the abstract index content."""
         n = self.n_sets()

@@ -117,6 +117,7 @@ def _load():
     lib.ora_add_variants.argtypes = [vp, C.c_size_t, C.POINTER(OVariant), C.c_size_t]
     lib.ora_fill_gaps.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_size_t, C.c_double, vp]
     lib.ora_map.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_double, C.c_int, C.c_int, C.c_int, vp]
+    lib.ora_kmer_colex_ranks.argtypes = [vp, C.c_size_t, C.c_uint32, vp, C.c_size_t, C.c_int, vp, vp]
     return lib
 
 
@@ -420,6 +421,17 @@ def relative_to_ref(ref_seq, aln):
     out = np.zeros(len(a), dtype=np.uint8)
     lib().ora_relative_to_ref(r.ctypes.data, a.ctypes.data, len(a), out.ctypes.data)
     return out.tobytes()
+
+
+def kmer_colex_ranks(seq, k, kmers, n_threads=1):
+    """index_check.c: for each k-mer of `kmers` (an [m, k] uint8 array) the number of k-mer occurrences in `seq` that are
+    colex-smaller and the number equal to it - counted off the text, no index involved -> (less uint64[m], equal uint64[m])"""
+    s = _bytes(seq)
+    km = np.ascontiguousarray(kmers, dtype=np.uint8).reshape(-1, k)
+    less = np.zeros(len(km), dtype=np.uint64)
+    eq = np.zeros(len(km), dtype=np.uint64)
+    _chk(lib().ora_kmer_colex_ranks(s.ctypes.data, len(s), k, km.ctypes.data, len(km), n_threads, less.ctypes.data, eq.ctypes.data))
+    return less, eq
 
 
 def add_variants(translation, variant_buf, n):

@@ -187,6 +187,13 @@ int ora_plan_model(const ora_index *idx, const uint8_t *text, const uint32_t *po
                    const ora_plan_params *params, const uint8_t *concat, const uint64_t *offsets, size_t n_reads,
                    int n_threads, uint8_t *ms_out, ora_plan_counts *counts);
 
+/* ---- index_check.c: ranks of k-mers among the k-mers of a text, counted straight off the text (a check of an index's row
+ * order that passes through no index builder).  For each of the m query k-mers (k <= 64 bytes each, back to back):
+ * less_out = occurrences of colex-smaller k-mers in seq (windows with a non-ACGT byte do not count), equal_out =
+ * occurrences of the k-mer itself; a query with a non-ACGT byte gets (UINT64_MAX, 0). */
+int ora_kmer_colex_ranks(const uint8_t *seq, size_t len, uint32_t k, const uint8_t *kmers, size_t m, int n_threads,
+                         uint64_t *less_out, uint64_t *equal_out);
+
 #ifdef __cplusplus
 }
 #endif
