@@ -359,6 +359,20 @@ int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, siz
                              uint64_t total_bases, size_t k, size_t threshold, const uint8_t *d_ref,
                              uint8_t *d_chars_out, size_t max_seq_len, void *d_work, size_t work_bytes,
                              void *stream);
+/* kbo::map with fill_gaps = false and call_variants = false (lib.rs:726-738; format != 0: + relative_to_ref, lib.rs:756-757) or
+ * kbo::matches (lib.rs:612-628; format = 0) over a device-resident batch, the whole chain MS -> derandomize_ms_vec ->
+ * translate_ms_vec enqueued on `stream`; the threshold comes from the index and max_error_prob (lib.rs:620, 731).  Batches of
+ * reads (max_seq_len <= 160) over an index copy that carries a depth table run as ONE kernel (kbo_amd/csrc/map_kernels.hip): the
+ * MS values never leave the chip unless want_ms != 0.  Other batches run as kbo_ms_batch_dev + kbo_derand_translate_dev
+ * (max_seq_len <= 480 here: longer sequences need kbo_derand_translate_dev's scratch - call the two yourself).
+ * d_ms: total_bases bytes + 16, 4-byte aligned: the MS value of every base when want_ms != 0 or the batch takes the two-kernel
+ * route, otherwise scratch (the reads the one kernel leaves to the plain walk pass through it).  d_work / work_bytes as for
+ * kbo_ms_batch_dev; d_concat needs 16 readable bytes of slack behind the batch.  Sequences of fewer than 3 bases (the
+ * reference asserts, derandomize.rs:276) are left unwritten, as by kbo_derand_translate_dev.  *fused (optional) = 1 when the
+ * batch took the one kernel. */
+int kbo_map_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
+                      size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
+                      void *d_work, size_t work_bytes, void *stream, int *fused);
 /* format::run_lengths_gapped over device-resident characters (the output of kbo_derand_translate_dev
  * without d_ref), enqueued on `stream`.  d_work: kbo_run_lengths_work_bytes(n_seqs) bytes; afterwards
  * word s of d_work plus word (n_seqs + 1 + s / 1024) is the index of sequence s's first run, and the

@@ -92,7 +92,7 @@ SYMBOLS = [
     "kbo_index_path_cover", "kbo_index_recovery_lines", "kbo_call_batch", "kbo_call_sites_dev", "kbo_call_walk_dev",
     "kbo_index_save_sbwt", "kbo_index_load_sbwt", "kbo_packed_words", "kbo_pack_reads", "kbo_unpack_matches",
     "kbo_matches_batch_packed", "kbo_find_batch_packed", "kbo_index_shards", "kbo_index_work_bytes",
-    "kbo_index_device_layout",
+    "kbo_index_device_layout", "kbo_map_batch_dev",
 ]
 # ... and include/kbo_hip_tuning.h (knobs, experiment switches, test hooks: not part of the drop-in boundary)
 TUNING_SYMBOLS = [
@@ -214,6 +214,7 @@ def lib():
     L.kbo_call_walk_dev.argtypes = [vp, vp, vp, sz, u64, sz, sz, vp, vp, sz, vp, vp, sz, vp]
     L.kbo_index_device_plan_bytes.argtypes = [vp]
     L.kbo_index_device_plan_bytes.restype = C.c_uint64
+    L.kbo_map_batch_dev.argtypes = [vp, vp, vp, sz, u64, sz, dbl, C.c_int, C.c_int, vp, vp, vp, sz, vp, C.POINTER(C.c_int)]
     L.kbo_index_device_layout.argtypes = [vp, C.c_int, C.POINTER(DeviceLayout)]
     _lib = L
     return L

@@ -165,7 +165,7 @@ class DeviceBatch:
     pointers and the torch stream).  run() = A1 walk kernel, then fused A5+A6 kernel."""
 
     def __init__(self, sbwt, concat, offsets, device, max_error_prob=1e-7, want_intervals=False,
-                 format=False):  # noqa: A002
+                 format=False, want_ms=True):  # noqa: A002
         import torch
         self.torch = torch
         self.sbwt = sbwt
@@ -189,6 +189,9 @@ class DeviceBatch:
             self.lo = torch.zeros(self.total, dtype=torch.int32, device=device) if want_intervals else None
             self.hi = torch.zeros(self.total, dtype=torch.int32, device=device) if want_intervals else None
         self.format = format
+        self.want_ms = want_ms
+        self.max_error_prob = max_error_prob
+        self.fused = None  # set by run(): True when the last run() took the one-kernel route (map_kernels.hip)
 
     def walk(self, stream=None):
         s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
@@ -246,5 +249,16 @@ class DeviceBatch:
         return self.rle_records[:total].cpu().numpy().view(np.uint32), first
 
     def run(self, stream=None):
-        self.walk(stream)
-        self.derand_translate(stream)
+        """kbo::map (format) / kbo::matches over the batch: kbo_map_batch_dev - one kernel for reads over an index copy with a
+        depth table (self.ms then holds every MS value only when want_ms), else walk() + derand_translate()."""
+        if self.lo is not None or self.max_len == 0 or self.max_len > 480:
+            self.walk(stream)
+            self.derand_translate(stream)
+            self.fused = False
+            return
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        fused = C.c_int(0)
+        check(lib().kbo_map_batch_dev(self.sbwt._h, self.q.data_ptr(), self.off.data_ptr(), self.n_seqs, self.total, self.max_len,
+                                      self.max_error_prob, int(self.format), int(self.want_ms), self.ms.data_ptr(), self.chars.data_ptr(),
+                                      self.work.data_ptr(), self.work_bytes, s.cuda_stream, C.byref(fused)))
+        self.fused = bool(fused.value)

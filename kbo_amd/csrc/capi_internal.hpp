@@ -41,6 +41,7 @@ struct DevCopy {
     DevBuf fat;                      // recovery lines of the guided walk (sbwt_index.hpp)
     uint32_t fat_null = 0;
     DevBuf pc_text, pc_pos, pc_node; // path cover (sbwt_index.hpp PathCover), empty when the plan-guided walk is off
+    DevBuf pc_tm, seed_pos;          // map_reads_kernel's 2-bit text + marks and its table of seed positions (copies with a depth table)
     // what making this copy cost (kbo_index_device_layout): seconds of host work / device builds / uploads, by part
     struct Setup {
         double layout_s = 0, cover_s = 0, lines_s = 0, seed_s = 0, dtab_s = 0, upload_s = 0;

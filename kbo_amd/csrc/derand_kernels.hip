@@ -103,14 +103,10 @@ __device__ __forceinline__ void dt_step_mid(DtState &st, const uint4 &cur, const
 // One lane per sequence, right to left, one 16-byte block (relative to the sequence start,
 // unaligned global accesses) at a time with the block below it already in flight; inside a
 // block the 16 positions are unrolled so every byte access is a constant bit-field.
-__global__ __launch_bounds__(256) void derand_translate_kernel(
-    const uint8_t *__restrict__ ms, const uint64_t *__restrict__ off, uint32_t n_seqs, uint32_t k,
-    uint32_t t, const uint8_t *__restrict__ ref, uint8_t *__restrict__ out, int32_t *__restrict__ derand_out,
-    uint32_t max_len, const uint32_t *__restrict__ only)
+__device__ __forceinline__ void derand_one_sequence(
+    const uint8_t *__restrict__ ms, const uint64_t *__restrict__ off, uint32_t s, uint32_t k,
+    uint32_t t, const uint8_t *__restrict__ ref, uint8_t *__restrict__ out, int32_t *__restrict__ derand_out, uint32_t max_len)
 {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_seqs) return;
-    if (only && !only[s]) return; // second pass of the piece-wise path: flagged sequences only
     const uint64_t b = off[s], e = off[s + 1];
     const uint32_t len = (uint32_t)(e - b);
     if (len < 3) return;       // the host side rejects these (derandomize.rs:276)
@@ -121,7 +117,6 @@ __global__ __launch_bounds__(256) void derand_translate_kernel(
     const uint8_t *refb = fmt ? ref + b : msb;
     uint8_t *outb = out + b;
     int32_t *dout = derand_out ? derand_out + b : nullptr;
-
     const uint32_t nblk = (len + 15u) >> 4;
     uint4 cur = ld16u(msb, 16u * (nblk - 1u));
     uint4 rcur = fmt ? ld16u(refb, 16u * (nblk - 1u)) : make_uint4(0, 0, 0, 0);
@@ -141,6 +136,43 @@ __global__ __launch_bounds__(256) void derand_translate_kernel(
         cur = below;
         rcur = rbelow;
     }
+}
+
+__global__ __launch_bounds__(256) void derand_translate_kernel(
+    const uint8_t *__restrict__ ms, const uint64_t *__restrict__ off, uint32_t n_seqs, uint32_t k,
+    uint32_t t, const uint8_t *__restrict__ ref, uint8_t *__restrict__ out, int32_t *__restrict__ derand_out,
+    uint32_t max_len, const uint32_t *__restrict__ only)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seqs) return;
+    if (only && !only[s]) return; // second pass of the piece-wise path: flagged sequences only
+    derand_one_sequence(ms, off, s, k, t, ref, out, derand_out, max_len);
+}
+
+// behind map_reads_kernel (map_kernels.hip): the sequences with flags[s] != 0 - a few per cent, one or two per wave of that
+// kernel - gathered per block of 4096 into a list in LDS first, so that the lanes that run the pass sit in the same waves (one
+// lane per sequence straight off the flags: nearly every wave runs the whole pass for its one flagged lane, 115 us at C2)
+constexpr uint32_t kFlaggedPerBlock = 4096;
+__global__ __launch_bounds__(256) void derand_flagged_kernel(
+    const uint8_t *__restrict__ ms, const uint64_t *__restrict__ off, uint32_t n_seqs, uint32_t k, uint32_t t,
+    const uint8_t *__restrict__ ref, uint8_t *__restrict__ out, uint32_t max_len, const uint8_t *__restrict__ flags)
+{
+    __shared__ uint32_t list[kFlaggedPerBlock];
+    __shared__ uint32_t cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const uint32_t i0 = blockIdx.x * kFlaggedPerBlock + threadIdx.x * 16u;
+    if (i0 < n_seqs) {
+        const uint4 f = *reinterpret_cast<const uint4 *>(flags + i0); // (the flag array is padded to 16 bytes)
+#pragma unroll
+        for (uint32_t b = 0; b < 16; b++) {
+            const uint32_t w = (b >> 2) == 0 ? f.x : (b >> 2) == 1 ? f.y : (b >> 2) == 2 ? f.z : f.w;
+            if (((w >> (8u * (b & 3u))) & 0xFFu) != 0 && i0 + b < n_seqs) list[atomicAdd(&cnt, 1u)] = i0 + b;
+        }
+    }
+    __syncthreads();
+    const uint32_t c = cnt;
+    for (uint32_t j = threadIdx.x; j < c; j += blockDim.x) derand_one_sequence(ms, off, list[j], k, t, ref, out, nullptr, max_len);
 }
 
 // ---- LDS-staged variant for batches of short sequences (reads) -------------------------
@@ -596,6 +628,15 @@ hipError_t launch_derand_translate(const uint8_t *d_ms, const uint64_t *d_offset
     hipLaunchKernelGGL(derand_translate_kernel, dim3((n_seqs + 255) / 256), dim3(256), 0, stream, d_ms,
                        d_offsets, n_seqs, k, threshold, d_ref, d_chars_out, d_derand_out, per_lane_max_len,
                        (const uint32_t *)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_derand_flagged(const uint8_t *d_ms, const uint64_t *d_offsets, uint32_t n_seqs, uint32_t k, uint32_t threshold,
+                                 const uint8_t *d_ref, uint8_t *d_chars_out, const uint8_t *d_flags, uint32_t max_seq_len, hipStream_t stream)
+{
+    if (n_seqs == 0) return hipSuccess;
+    hipLaunchKernelGGL(derand_flagged_kernel, dim3((n_seqs + kFlaggedPerBlock - 1u) / kFlaggedPerBlock), dim3(256), 0, stream, d_ms, d_offsets,
+                       n_seqs, k, threshold, d_ref, d_chars_out, max_seq_len, d_flags);
     return hipGetLastError();
 }
 

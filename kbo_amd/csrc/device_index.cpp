@@ -282,6 +282,21 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                         dc->setup.anchor_bytes = dc->anchor_bits ? ((uint64_t)1 << dc->anchor_bits) * 8 : 0;
                     }
                     dc->setup.seed_bytes = dc->seed_d ? (uint64_t)8 << (2u * dc->seed_d) : 0;
+                    // what map_reads_kernel reads (map_kernels.hip): the text as 2-bit digits with its path-start marks (0.5 B per
+                    // row) and the seed table as text positions (4 B per string of seed_d bases), both made on the device
+                    if (dc->dtab_order >= 4 && dc->seed_d >= 4) {
+                        t0 = clk::now();
+                        const uint64_t units = kbo::pack_text_units(idx->host.n_sets);
+                        dc->pc_tm.alloc(units * 8 + 64);
+                        HIP_OK(kbo::launch_pack_text(dc->pc_text.as<uint8_t>(), pc.text.size(), dc->pc_tm.as<uint2>(), units, nullptr));
+                        dc->seed_pos.alloc(((size_t)4 << (2u * dc->seed_d)) + 64);
+                        HIP_OK(kbo::launch_seed_pos(dc->seed_tab.as<uint2>(), dc->pc_pos.as<uint32_t>(), dc->seed_pos.as<uint32_t>(), dc->seed_d, nullptr));
+                        HIP_OK(hipDeviceSynchronize());
+                        dc->setup.cover_bytes += units * 8;
+                        dc->setup.seed_bytes += (uint64_t)4 << (2u * dc->seed_d);
+                        idx->plan_bytes += units * 8 + ((size_t)4 << (2u * dc->seed_d));
+                        dc->setup.seed_s += since(t0);
+                    }
                 }
             }
         } catch (...) {
@@ -316,6 +331,8 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
     v.fat = dc->fat.p ? dc->fat.as<uint8_t>() : nullptr;
     v.fat_null = dc->fat_null;
     v.pc_node = dc->pc_node.as<uint32_t>();
+    v.pc_tm = (use_tab && dc->pc_tm.p) ? dc->pc_tm.as<uint2>() : nullptr;
+    v.seed_pos = (use_tab && dc->seed_pos.p) ? dc->seed_pos.as<uint32_t>() : nullptr;
     for (int c = 0; c < 4; c++) v.C[c] = (uint32_t)idx->host.C[c];
     v.C[4] = v.n;
     return v;

@@ -1189,6 +1189,65 @@ size_t kbo_run_lengths_work_bytes(size_t n_seqs)
     return kbo::chunk_items_scratch_words((uint32_t)std::min<size_t>(n_seqs, 0xFFFFFFFEu)) * sizeof(uint32_t) + 16;
 }
 
+int kbo_map_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
+                      size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
+                      void *d_work, size_t work_bytes, void *stream, int *fused)
+{
+    if (fused) *fused = 0;
+    bool done = false;
+    size_t threshold = 0;
+    int rc = guarded([&] {
+        KBO_REQUIRE(idx && d_concat && d_offsets && d_ms && d_chars_out && d_work, KBO_E_BAD_ARG, "null argument");
+        KBO_REQUIRE(n_seqs > 0 && total_bases > 0, KBO_E_EMPTY_QUERY, "empty batch");
+        KBO_REQUIRE(n_seqs < (1ull << 28) && total_bases < 0xFFFFFF00ull, KBO_E_UNSUPPORTED,
+                    "one launch covers < 2^28 sequences and < 4 GiB of query: split the batch");
+        KBO_REQUIRE(((uintptr_t)d_concat & 15) == 0 && ((uintptr_t)d_ms & 3) == 0 && ((uintptr_t)d_chars_out & 3) == 0 &&
+                        ((uintptr_t)d_work & 15) == 0,
+                    KBO_E_BAD_ARG, "d_concat/d_work must be 16-byte, d_ms/d_chars_out 4-byte aligned");
+        KBO_REQUIRE(max_seq_len > 0 && max_seq_len <= 480, KBO_E_UNSUPPORTED,
+                    "kbo_map_batch_dev takes batches of reads (max_seq_len 1 .. 480); longer sequences: kbo_ms_batch_dev + kbo_derand_translate_dev");
+        threshold = random_match_threshold(idx->host.k, idx->host.n_kmers, 4, max_error_prob);
+        KBO_REQUIRE(threshold > 1, KBO_E_THRESHOLD_LE_1, "threshold > 1 (derandomize.rs:275)");
+        if (idx->sharded() || max_seq_len > 160) return; // (two kernels, below)
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const DevWork w = dev_work(n_seqs, total_bases, max_seq_len, idx->host.k);
+        if (w.chunked) return;
+        KBO_REQUIRE(work_bytes >= w.bytes, KBO_E_BAD_ARG, "d_work is smaller than kbo_work_bytes() for this batch");
+        DevCopy::PlanState *plan_state = nullptr;
+        const kbo::DevIndexView view = device_view(idx, current_device(), &plan_state);
+        kbo::WalkItem *items = static_cast<kbo::WalkItem *>(d_work);
+        kbo::WalkArgs a{};
+        a.ix = view;
+        a.q = d_concat;
+        a.q_bytes = total_bases;
+        a.items = items;
+        a.n_items = w.n_slots;
+        a.d_out = d_ms;
+        a.max_item_len = (uint32_t)max_seq_len;
+        attach_plan(a, static_cast<uint8_t *>(d_work) + w.plan_off, plan_state);
+        a.chars_out = d_chars_out;
+        a.map_thr = (uint32_t)threshold;
+        a.map_fmt = format ? 1u : 0u;
+        a.map_want_ms = want_ms ? 1u : 0u;
+        if (!a.gitems || !kbo::map_reads_applies(a)) return; // (no plan structures, or the copy is held off: two kernels)
+        HIP_OK(kbo::launch_make_items(d_offsets, (uint32_t)n_seqs, items, s));
+        HIP_OK(kbo::launch_map_reads(a, s));
+        HIP_OK(kbo::launch_redo_pass(a, s));
+        HIP_OK(kbo::launch_derand_flagged(d_ms, d_offsets, (uint32_t)n_seqs, idx->host.k, (uint32_t)threshold, format ? d_concat : nullptr,
+                                          d_chars_out, a.redo, (uint32_t)max_seq_len, s));
+        plan_after_launch(a, s, plan_state);
+        done = true;
+    });
+    if (rc != KBO_OK || done) {
+        if (fused && done) *fused = 1;
+        return rc;
+    }
+    rc = ms_batch_dev_impl(idx, d_concat, d_offsets, n_seqs, total_bases, max_seq_len, d_ms, nullptr, nullptr, d_work, work_bytes, stream, nullptr);
+    if (rc != KBO_OK) return rc;
+    return kbo_derand_translate_dev(d_ms, d_offsets, n_seqs, total_bases, idx->host.k, threshold, format ? d_concat : nullptr, d_chars_out,
+                                    max_seq_len, nullptr, 0, stream);
+}
+
 int kbo_run_lengths_dev(const uint8_t *d_chars, const uint64_t *d_offsets, size_t n_seqs, size_t max_seq_len,
                         size_t max_gap_len, void *d_work, uint32_t *d_records, size_t capacity, void *stream)
 {

@@ -40,6 +40,12 @@ struct DevIndexView {
     // text in front of that position
     const uint64_t *anchor;
     uint32_t anchor_bits;
+    // what map_reads_kernel (map_kernels.hip) reads instead of the byte text and the interval table, nullptr when the copy has
+    // none: pc_tm[u] = { 2-bit digits of text positions [16 u - kPlanPad, + 16), first one most significant; 01 at every
+    // position that matches nothing (path start, padding) }; seed_pos[key of seed_d bases] = text position of the first row
+    // whose k-mer ends with them, 0xFFFFFFFF when there is none
+    const uint2 *pc_tm;
+    const uint32_t *seed_pos;
 };
 
 // One unit of walk work: `len` bases starting at absolute offset `start` of the
@@ -136,6 +142,10 @@ struct WalkArgs {
     uint32_t redo_piece;   // table mode: output bases per piece of a flagged item in the redo pass
     uint32_t max_item_len; // 0 = not known, else no item is longer than this (plan_kernel sizes its LDS staging from it)
     const uint32_t *n_items_dev; // plain kernel: nullptr, or where the number of items is (the redo pass: qctl + 1)
+    // map_reads_kernel (map_kernels.hip): where the characters go, the derandomisation threshold, 1 = format::relative_to_ref
+    // on the way out, 1 = the MS values go to d_out as well
+    uint8_t *chars_out;
+    uint32_t map_thr, map_fmt, map_want_ms;
 };
 // Work counters the plan-guided stage keeps about itself (one wave-level atomic per counter and wave, spread over slots):
 // what the CPU model of the stage (oracle/plan_model.c) is pinned to, tests/test_gpu_model.py
@@ -182,6 +192,23 @@ hipError_t launch_ms_walk_guided(WalkArgs a, uint32_t grid, uint32_t threads, hi
 // could not resolve (for the plain kernel, like the guided walk's redo pass)
 hipError_t launch_plan_table(WalkArgs &a, hipStream_t stream);
 hipError_t launch_dtab_resolve(const WalkArgs &a, hipStream_t stream);
+// ---- kbo::map / matches for a batch of reads in one launch (map_kernels.hip)
+// the 2-bit text with its path-start marks from the padded byte text (n_bytes = kPlanPad + n_sets + kPlanPad), n_units of
+// 16 positions; the text positions of the seed table's intervals
+hipError_t launch_pack_text(const uint8_t *d_text_padded, uint64_t n_bytes, uint2 *d_out, uint64_t n_units, hipStream_t stream);
+inline uint64_t pack_text_units(uint64_t n_sets) { return (n_sets + kPlanPad + 256u) / 16u + 2u; }
+hipError_t launch_seed_pos(const uint2 *d_seed_tab, const uint32_t *d_pc_pos, uint32_t *d_out, uint32_t seed_d, hipStream_t stream);
+// true when the launch described by `a` (plan work attached, chars_out set) can take map_reads_kernel: reads of at most 160
+// bases, MS values / characters only, an index copy with a depth table, the 2-bit text and the position table
+bool map_reads_applies(const WalkArgs &a);
+// the kernel; the reads it could not finish are flagged in a.redo (launch_redo_pass walks them, launch_derand_flagged
+// translates them)
+hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream);
+// the list of the flagged items (redo_collect_kernel) and their plain walk; `a` as the plan launch left it
+hipError_t launch_redo_pass(WalkArgs a, hipStream_t stream);
+// A5 + A6 (+ relative_to_ref) for the sequences with flags[s] != 0 only, one lane each
+hipError_t launch_derand_flagged(const uint8_t *d_ms, const uint64_t *d_offsets, uint32_t n_seqs, uint32_t k, uint32_t threshold,
+                                 const uint8_t *d_ref, uint8_t *d_chars_out, const uint8_t *d_flags, uint32_t max_seq_len, hipStream_t stream);
 // stretches the fused plan_kernel leaves to the anchors: one block per plan_kernel wave in the unit array (free in table mode
 // until redo_collect_kernel builds its list there): {count, pad[3]} + kDtabStretchCap entries {item, start, m | next << 16,
 // len | warm << 16}; a wave with more of them flags the items of the rest

@@ -30,9 +30,12 @@
 // Integer / byte work only: no MFMA.  One 64-lane wave per workgroup (the LDS of a CU then holds twelve of them).
 #include "device_util.hpp"
 
+#include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 namespace kbo {
+extern std::atomic<int> g_plan_cap; // plan_kernels.hip: bases of a read in which a seed may start (kbo_set_plan)
 namespace {
 
 // stores bytes [lo, hi) of a 16-byte block to o + lo .. o + hi (0 <= lo <= hi <= 16)
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
     uint32_t *lin = reinterpret_cast<uint32_t *>(map_lds + stage_bytes) + 4;     // the stretch as 2-bit digits (lin[-1] = 0)
     uint8_t *spw = map_lds + stage_bytes + 4u * (lin_words + 4u);                // 64 x 16 bytes: mismatch positions 0 .. 12, flag, prefix
     uint8_t *sp = spw + lane * 16u;
-    const uint32_t n = a.ix.n, k = a.ix.k;
+    const uint32_t k = a.ix.k;
     const uint8_t *qb = a.q;
     uint32_t start = 0, len = 0, warm = 0, tail = 0;
     const bool have_item = idx < a.n_items;
@@ -475,6 +478,9 @@ hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
     a.table_fused = 1;
     a.unit_bail = a.n_items / 2u + 64u;
     a.plan_list = kPlanList;
+    a.plan_cap = (uint32_t)g_plan_cap.load();
+    static const int env_piece = std::getenv("KBO_REDO_PIECE") ? std::atoi(std::getenv("KBO_REDO_PIECE")) : 0; // experiments
+    a.redo_piece = env_piece >= 4 ? (uint32_t)env_piece : 32u;
     hipError_t e = hipMemsetAsync(a.qctl, 0, 64 + kPlanStatSlots * kPlanStatWords * 4, stream);
     if (e != hipSuccess) return e;
     const uint32_t stage_bytes = (64u * a.max_item_len + 16u + kMapSlack + 15u) / 16u * 16u;

@@ -1620,6 +1620,12 @@ hipError_t launch_plan_table(WalkArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
+hipError_t launch_redo_collect(const WalkArgs &a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(redo_collect_kernel, dim3((a.n_items + kRedoBlock - 1u) / kRedoBlock), dim3(kRedoBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
 template <bool CALL, bool STATS> static void launch_guided_variant(const WalkArgs &a, uint32_t grid, uint32_t threads, hipStream_t stream)
 {
     if (guided_uses_recovery_lines(a)) {

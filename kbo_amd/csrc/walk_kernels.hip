@@ -492,6 +492,42 @@ void set_pair_min_depth(int d) { g_pair_min_depth = d < 0 ? 0 : d; }
 void set_walk_rare(int period) { g_rare_period = std::max(1, std::min(1024, period)); }
 void set_walk_threads(int t) { g_walk_threads = (t == 64 || t == 128 || t == 256) ? t : kWalkThreads; }
 
+// the redo pass: items a unit flagged (its successor's start state was a wrong guess) - or, in table mode, items the table
+// could not resolve - walked plainly, in full; redo_collect_kernel has listed them where the units were, one item per lane
+static hipError_t launch_redo_walk(WalkArgs a, hipStream_t stream)
+{
+    const uint32_t n_orig = a.n_items;
+    a.items = reinterpret_cast<const WalkItem *>(a.units); // (the unit array is free by now: see redo_collect_kernel)
+    a.n_items = a.redo_cap;
+    a.n_items_dev = a.qctl + 1;
+    a.gitems = nullptr;
+    a.rounds = 1;
+    a.rare_period = (uint32_t)g_rare_period.load();
+    a.lane_limit = (uint32_t)g_walk_lane_limit.load();
+    a.pair_min_d = (uint32_t)g_pair_min_depth.load();
+#ifdef KBO_WALK_DEBUG
+    a.hi_out = nullptr; // (counters build: the counter sink belongs to the guided kernel)
+#endif
+    // (one item per lane, so that a few hundred flagged items spread over waves; nearly all of these waves find no
+    // item and leave at once - workgroups of four waves: a quarter of the dispatches)
+    const uint32_t rwaves = (n_orig + 63u) / 64u;
+    const dim3 rgrid((rwaves + 3u) / 4u), rblock(256);
+    if (a.call_sites) { // (call mode: the flagged items' scan with their walk)
+        if (a.ix.big) hipLaunchKernelGGL((ms_walk_kernel<false, true, false, true>), rgrid, rblock, 0, stream, a);
+        else hipLaunchKernelGGL((ms_walk_kernel<false, false, false, true>), rgrid, rblock, 0, stream, a);
+    } else if (a.ix.big) hipLaunchKernelGGL((ms_walk_kernel<false, true, false>), rgrid, rblock, 0, stream, a);
+    else hipLaunchKernelGGL((ms_walk_kernel<false, false, false>), rgrid, rblock, 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_redo_collect(const WalkArgs &a, hipStream_t stream); // plan_kernels.hip
+hipError_t launch_redo_pass(WalkArgs a, hipStream_t stream)
+{
+    const hipError_t e = launch_redo_collect(a, stream);
+    if (e != hipSuccess) return e;
+    return launch_redo_walk(a, stream);
+}
+
 hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
 {
     if (a.n_items == 0) return hipSuccess;
@@ -531,27 +567,7 @@ hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream)
             e = launch_ms_walk_guided(a, (gwaves + wpb - 1) / wpb, threads, stream);
             if (e != hipSuccess) return e;
         }
-        // the redo pass: items a unit flagged (its successor's start state was a wrong guess) walked plainly, in full;
-        // redo_collect_kernel has listed them where the item records were, one item per lane
-        const uint32_t n_orig = a.n_items;
-        a.items = reinterpret_cast<const WalkItem *>(a.units); // (the unit array is free by now: see redo_collect_kernel)
-        a.n_items = a.redo_cap;
-        a.n_items_dev = a.qctl + 1;
-        a.gitems = nullptr;
-        a.rounds = 1;
-#ifdef KBO_WALK_DEBUG
-        a.hi_out = nullptr; // (counters build: the counter sink belongs to the guided kernel)
-#endif
-        // (one item per lane, so that a few hundred flagged items spread over waves; nearly all of these waves find no
-        // item and leave at once - workgroups of four waves: a quarter of the dispatches)
-        const uint32_t rwaves = (n_orig + 63u) / 64u;
-        const dim3 rgrid((rwaves + 3u) / 4u), rblock(256);
-        if (a.call_sites) { // (call mode: the flagged items' scan with their walk)
-            if (a.ix.big) hipLaunchKernelGGL((ms_walk_kernel<false, true, false, true>), rgrid, rblock, 0, stream, a);
-            else hipLaunchKernelGGL((ms_walk_kernel<false, false, false, true>), rgrid, rblock, 0, stream, a);
-        } else if (a.ix.big) hipLaunchKernelGGL((ms_walk_kernel<false, true, false>), rgrid, rblock, 0, stream, a);
-        else hipLaunchKernelGGL((ms_walk_kernel<false, false, false>), rgrid, rblock, 0, stream, a);
-        return hipGetLastError();
+        return launch_redo_walk(a, stream);
     }
     if (a.call_sites) { // call mode: MS values + the breakpoint scan, no intervals written
         if (a.ix.big) hipLaunchKernelGGL((ms_walk_kernel<false, true, false, true>), grid, block, lds, stream, a);

@@ -1,0 +1,169 @@
+"""kbo_map_batch_dev's one-kernel route (kbo_amd/csrc/map_kernels.hip: MS -> derandomize -> translate [-> relative_to_ref]
+for 64 reads per wave, 2-bit packed) against the CPU oracle, every base: read shapes (ragged lengths down to 3 bases, reads
+shorter than a seed), contents (substitutions up to 8 %, indels, junk heads, N and lower-case bytes, unrelated reads, reads of
+the other strand), index shapes (several contigs with repeats: many paths in the cover; k from 11 to 63), both stretch widths
+of the kernel (tables of up to 15 bases / of 16 and 17), with and without formatting, with and without the MS values."""
+import numpy as np
+import pytest
+
+import kbo_amd
+from kbo_amd import batch, synth
+from gpu_helpers import threads
+
+pytestmark = pytest.mark.gpu
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _mutate(rng, reads, sub=0.0, indel=0.0, junk=0, n_rate=0.0, lower=0.0):
+    """list of uint8 arrays -> list of uint8 arrays"""
+    out = []
+    for r in reads:
+        r = r.copy()
+        if sub:
+            hit = rng.random(len(r)) < sub
+            r[hit] = ACGT[rng.integers(0, 4, int(hit.sum()))]
+        if junk:
+            r[:junk] = ACGT[rng.integers(0, 4, min(junk, len(r)))]
+        if indel and len(r) > 40 and rng.random() < indel:
+            p = int(rng.integers(10, len(r) - 10))
+            if rng.random() < 0.5:
+                r = np.concatenate([r[:p], r[p + int(rng.integers(1, 4)):]])
+            else:
+                r = np.concatenate([r[:p], ACGT[rng.integers(0, 4, int(rng.integers(1, 4)))], r[p:]])
+        if n_rate and rng.random() < n_rate:
+            r[int(rng.integers(0, len(r)))] = ord("N")
+        if lower and rng.random() < lower:
+            p = int(rng.integers(0, len(r)))
+            r[p] = r[p] | 0x20
+        out.append(r)
+    return out
+
+
+def _batch_of(reads):
+    concat = np.concatenate(reads)
+    offsets = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+    return concat, offsets
+
+
+def _check(oracle, ora, sbwt, concat, offsets, p=1e-7, expect_fused=True):
+    import torch
+    exp_chars, exp_d = ora.matches_batch(concat, offsets, p, n_threads=threads(), want_d=True)
+    exp_map = np.frombuffer(oracle.relative_to_ref(concat, exp_chars), dtype=np.uint8)
+    for fmt, want_ms in ((False, True), (True, False)):
+        dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"), max_error_prob=p, format=fmt, want_ms=want_ms)
+        dev.ms.fill_(0xEE)
+        dev.chars.fill_(0xEE)
+        kbo_amd.lib().kbo_set_plan(1, 0, 0)  # (a batch that gave the plan up - 8 % substitutions - holds the copy off: clear it)
+        dev.run()
+        torch.cuda.synchronize()
+        assert dev.fused == expect_fused
+        got = dev.chars[:dev.total].cpu().numpy()
+        want = exp_map if fmt else exp_chars
+        if not np.array_equal(got, want):
+            bad = np.flatnonzero(got != want)
+            s = int(np.searchsorted(offsets, bad[0], side="right")) - 1
+            a, b = int(offsets[s]), int(offsets[s + 1])
+            raise AssertionError("read %d (len %d) of %d: first bad base %d\n got  %s\n want %s\n read %s\n ms   %s" % (
+                s, b - a, len(offsets) - 1, int(bad[0]) - a, got[a:b].tobytes(), want[a:b].tobytes(), concat[a:b].tobytes(), list(exp_d[a:b])))
+        if want_ms:
+            assert np.array_equal(dev.ms[:dev.total].cpu().numpy(), exp_d)
+        del dev
+
+
+@pytest.mark.parametrize("k", [31, 11, 19, 51, 63])
+def test_read_shapes_and_contents(oracle, k):
+    rng = np.random.default_rng(100 + k)
+    g = synth.genome(300_000, seed=900 + k)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=k, num_threads=threads()))
+    ora = oracle.Index.build([g.tobytes()], k=k)
+    sbwt.to_device(-1)
+    assert sbwt.depth_table_order() > 0
+
+    def take(n, lo, hi):
+        lens = rng.integers(lo, hi + 1, n)
+        starts = rng.integers(0, len(g) - 200, n)
+        return [g[a:a + l] for a, l in zip(starts, lens)]
+    other = synth.genome(50_000, seed=77)
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    sets = [
+        _mutate(rng, take(5000, 150, 150), sub=0.01),
+        _mutate(rng, take(3000, 150, 150)),                              # error-free
+        _mutate(rng, take(3000, 150, 150), sub=0.05),
+        _mutate(rng, take(2000, 150, 150), sub=0.08),                    # most reads overflow their mismatch list
+        _mutate(rng, take(4000, 3, 160), sub=0.01),                      # ragged, down to three bases
+        _mutate(rng, take(2000, 3, 30), sub=0.02),                       # shorter than a seed
+        _mutate(rng, take(3000, 100, 157), sub=0.01, indel=0.5),
+        _mutate(rng, take(3000, 150, 150), sub=0.01, junk=12),           # the first seed fails
+        _mutate(rng, take(3000, 140, 160), sub=0.01, n_rate=0.2, lower=0.1),
+        [other[a:a + 150] for a in rng.integers(0, len(other) - 150, 2000)],            # unrelated
+        [comp[g[a:a + 150]][::-1].copy() for a in rng.integers(0, len(g) - 150, 2000)],  # the other strand
+        _mutate(rng, take(777, 128, 128), sub=0.01),                     # lengths that are multiples of 16 / 32
+        _mutate(rng, take(63, 160, 160), sub=0.01),                      # less than one wave
+    ]
+    for reads in sets:
+        _check(oracle, ora, sbwt, *_batch_of(reads))
+    mixed = [r for reads in sets for r in reads[:300]]
+    order = rng.permutation(len(mixed))
+    _check(oracle, ora, sbwt, *_batch_of([mixed[i] for i in order]))
+    _check(oracle, ora, sbwt, *_batch_of([mixed[i] for i in order][:500]), p=0.01)  # a low threshold: anchors and 'R's
+
+
+def test_many_paths_and_both_stretch_widths(oracle):
+    """several contigs that share repeats (the cover has many paths: path starts inside reads), separated by N; then the same
+    reads with a table of 16 and of 17 bases forced onto the small index (the kernel's 18-base stretches, 64-bit keys)."""
+    rng = np.random.default_rng(5)
+    L = kbo_amd.lib()
+    base = synth.genome(60_000, seed=31)
+    rep = synth.genome(800, seed=32)
+    contigs = []
+    for c in range(12):
+        a = int(rng.integers(0, 50_000))
+        piece = base[a:a + int(rng.integers(3000, 9000))].copy()
+        ins = int(rng.integers(100, len(piece) - 900))
+        contigs.append(np.concatenate([piece[:ins], rep, piece[ins:]]))
+    seqs = [c.tobytes() for c in contigs]
+    cat = np.concatenate(contigs)
+    k = 31
+    ora = oracle.Index.build(seqs, k=k)
+    reads = []
+    for c in contigs:
+        for a in rng.integers(0, len(c) - 160, 400):
+            reads.append(c[a:a + int(rng.integers(60, 161))])
+    reads = _mutate(rng, reads, sub=0.015)
+    reads += [cat[a:a + 150] for a in rng.integers(0, len(cat) - 150, 1500)]  # reads across contig junctions
+    concat, offsets = _batch_of(reads)
+    for order in (0, 16, 17, 9):
+        L.kbo_set_depth_table(order)
+        sbwt, _ = kbo_amd.build(seqs, kbo_amd.BuildOpts(k=k, num_threads=threads()))
+        sbwt.to_device(-1)
+        if order:
+            assert sbwt.depth_table_order() == order
+        _check(oracle, ora, sbwt, concat, offsets)
+    L.kbo_set_depth_table(0)
+
+
+def test_c2_shape_the_one_kernel_every_read(oracle):
+    """the batch bench.py times (5 Mbp index, 1 M reads of 150 bases, 1 % substitutions), formatted and not, every read"""
+    g = synth.genome(5_000_000)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=threads()))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    concat, offsets = synth.reads(g, 1_000_000, 150, 0.01)
+    _check(oracle, ora, sbwt, concat, offsets)
+
+
+def test_routes_that_are_not_the_one_kernel(oracle):
+    """reads longer than 160 bases, a copy without a depth table, a held-off copy: kbo_map_batch_dev takes the two kernels"""
+    L = kbo_amd.lib()
+    rng = np.random.default_rng(9)
+    g = synth.genome(200_000, seed=11)
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=threads()))
+    reads = _mutate(rng, [g[a:a + 300] for a in rng.integers(0, len(g) - 300, 2000)], sub=0.01)
+    _check(oracle, ora, sbwt, *_batch_of(reads), expect_fused=False)
+    L.kbo_set_depth_table(-1)
+    sb2, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=threads()))
+    reads = _mutate(rng, [g[a:a + 150] for a in rng.integers(0, len(g) - 150, 2000)], sub=0.01)
+    _check(oracle, ora, sb2, *_batch_of(reads), expect_fused=False)
+    L.kbo_set_depth_table(0)
