@@ -91,8 +91,20 @@ __global__ __launch_bounds__(256) void seed_pos_kernel(const uint2 *__restrict__
 constexpr uint32_t kMapWords = 10;       // 16-base words per read: reads of up to 160 bases
 constexpr uint32_t kMapSlack = 48;       // bytes of the byte region behind the staged stretch
 
-// NP = bases a stretch can take: 16 (tables of up to 15 bases: 32-bit keys) or 18 (16 / 17 bases)
-template <int NP>
+// NP = bases a stretch can take: 16 (tables of up to 15 bases: 32-bit keys) or 18 (16 / 17 bases).
+// DIRECT: the characters straight from the mismatch positions, no MS bytes at all.  Where the table's order is at most the
+// derandomisation threshold t (and t < k: always, with the default error probability) every value the table certifies - the
+// stretch behind a mismatch - is <= t, and derandomize_ms_val (derandomize.rs:233-246) then never anchors inside a stretch:
+// with x the derandomised value, j the distance to the last mismatch m, L the distance from m to the next one (or the end),
+//     x[m + j] = k for j >= k,  j + d otherwise, one d per segment:  d = 0 when L > k;  at the read's end d = 0 when L - 1 > t,
+//     else -(L - 1);  else with d' the next segment's:  d = 0 when d' - L <= -2 and L - 1 > t (the ramp's top value anchors),
+//     else d' - L
+// (derivation: DESIGN.md section 4.9; the in-place pass of the other instantiation is the literal recurrence, and
+// tests/test_gpu_map_reads.py runs both against the oracle).  x rises by one per base inside a segment and is <= 0 behind
+// a break, so translate_ms_val (translate.rs:180-216) never sees its 'R' case: every base is 'M' except the -d + 1 bases
+// from a mismatch on - '-', or 'X' for a lone mismatch whose left neighbour is positive - and the two first bases of the
+// read, whose `prev` is k (translate.rs:277).  The table look-ups only have to PROVE that nothing is deeper than `order`.
+template <int NP, bool DIRECT>
 __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stage_bytes, uint32_t lin_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t map_lds[];
@@ -140,6 +152,8 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
         if (c < nblk) {
             const uint4 v = ld16u(qb, base16 + 16u * c); // (reads <= 15 bytes past the last read)
             pack16(v, code, valid);
+            // DIRECT: the characters start out as what nearly all of them are - 'M', or with relative_to_ref the read's own bases
+            if (DIRECT) *reinterpret_cast<uint4 *>(so + 16u * c) = a.map_fmt ? v : make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);
             // only the bytes of this wave's reads count: [lo, wave_hi)
             const uint32_t b0 = base16 + 16u * c;
             const uint32_t from = lo > b0 ? lo - b0 : 0u, to = min(16u, wave_hi - b0);
@@ -155,8 +169,9 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
             has_invalid = has_invalid || (plannable && soff < blo + 16u && soff + len > blo);
         }
     }
-    for (uint32_t c = lane * 16u; c < span + 16u; c += 1024u) // MS bytes: k wherever nothing says otherwise
-        *reinterpret_cast<uint4 *>(so + c) = make_uint4(k * 0x01010101u, k * 0x01010101u, k * 0x01010101u, k * 0x01010101u);
+    if (!DIRECT)
+        for (uint32_t c = lane * 16u; c < span + 16u; c += 1024u) // MS bytes: k wherever nothing says otherwise
+            *reinterpret_cast<uint4 *>(so + c) = make_uint4(k * 0x01010101u, k * 0x01010101u, k * 0x01010101u, k * 0x01010101u);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -248,7 +263,7 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
     bool flag = plannable && seeded && cnt > a.plan_list + 1u; // more mismatches than the list holds: the plain walk
     const bool no_plan = plannable && !seeded && !has_invalid; // no seed at all: every base from the table, 16 at a time
     flag = flag || (plannable && has_invalid);
-    {
+    if (!DIRECT) {
         const uint32_t first_mm = (seeded && cnt > 0) ? (uint32_t)sp[0] : len;
         const uint32_t lim = (seeded && !flag) ? min(min(k - 1u, first_mm), len) : 0u;
         const uint32_t most = min(k - 1u, 16u * kMapWords);
@@ -342,16 +357,19 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
                 if (unkmask) spw[owner * 16u + 13u] = 1; // the owner's read goes to the plain walk
                 // (a stretch with an unknown base writes nothing; a block writes the bases it knows)
                 const uint32_t wmask = blockmode ? evalmask & ~unkmask : (unkmask ? 0u : evalmask);
+                if (DIRECT) st_written += (uint32_t)__popc(wmask); // (counted, not written: the values themselves change nothing)
+                else {
 #pragma unroll
-                for (uint32_t j = 0; j < (uint32_t)NP; j++)
-                    if ((wmask >> j) & 1u) {
-                        so[o_soff + m + j] = (uint8_t)(outv[j >> 2] >> (8u * (j & 3u)));
-                        st_written++;
+                    for (uint32_t j = 0; j < (uint32_t)NP; j++)
+                        if ((wmask >> j) & 1u) {
+                            so[o_soff + m + j] = (uint8_t)(outv[j >> 2] >> (8u * (j & 3u)));
+                            st_written++;
+                        }
+                    // behind the stretch: the ramp up to the next mismatch (depth = bases since this one), k from k bases on (in place)
+                    if (!blockmode && !unkmask) {
+                        const uint32_t rend = min(nxt - m, k);
+                        for (uint32_t j = n_eval; j < rend; j++) so[o_soff + m + j] = (uint8_t)j;
                     }
-                // behind the stretch: the ramp up to the next mismatch (depth = bases since this one), k from k bases on (in place)
-                if (!blockmode && !unkmask) {
-                    const uint32_t rend = min(nxt - m, k);
-                    for (uint32_t j = n_eval; j < rend; j++) so[o_soff + m + j] = (uint8_t)j;
                 }
             }
         }
@@ -360,7 +378,7 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
         flag = flag || sp[13] != 0;
     }
     // ---- the MS values themselves, when the caller wants them too (whole lines)
-    if (a.map_want_ms) {
+    if (!DIRECT && a.map_want_ms) {
         for (uint32_t c = lane * 16u; c < span; c += 1024u) {
             const uint4 v = *reinterpret_cast<const uint4 *>(so + c);
             const uint32_t g0 = base16 + c;
@@ -373,7 +391,56 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
 
     // ---- 4. derandomize_ms_vec + translate_ms_vec, right to left, in place (derand_kernels.hip has the derivation of the
     // closed form of the 'R','R' look-ahead): x = derandomised value, window (x_prev, x_cur, x_next) = x[p-1], x[p], x[p+1]
-    if (plannable && !flag && len >= 3u) {
+    if (DIRECT) {
+        // the characters that are not 'M', segment by segment from the right (header): e = the break to the right (the read's
+        // end first), dn = its segment's d, cand = the base at e waits for its left neighbour to decide between 'X' and '-'
+        const int K = (int)k, T = (int)a.map_thr;
+        const uint8_t cX = a.map_fmt ? (uint8_t)'-' : (uint8_t)'X'; // (relative_to_ref: 'X' becomes '-' as well)
+        uint8_t *at = so + soff;
+        const bool live = plannable && !flag && len >= 3u;
+        if (__ballot(live && no_plan)) { // no seed, and the table vouches for every base (<= order <= t): x <= 0 throughout
+            if (live && no_plan)
+                for (uint32_t i = 0; i < len; i++) at[i] = (uint8_t)'-';
+        }
+        int e = (int)len, dn = 0;
+        bool at_end = true, cand = false;
+        for (int q = (int)cnt - 1;; q--) {
+            const bool act = live && seeded && q >= -1;
+            if (__ballot(act) == 0) break;
+            if (act) {
+                const int m = q >= 0 ? (int)sp[q] : -1;
+                const int L = e - m, jl = L - 1;
+                int d;
+                if (L > K) d = 0;
+                else if (at_end) d = jl > T ? 0 : -jl;
+                else {
+                    const int din = dn - L;
+                    d = (din <= -2 && jl > T) ? 0 : din;
+                }
+                const int xt = L > K ? K : jl + d; // x of the segment's last base (the left neighbour of e)
+                if (cand) at[e] = ((e <= 1 ? K : xt) > 0) ? cX : (uint8_t)'-';
+                cand = false;
+                if (d == 0) {
+                    if (q >= 0) { // x[m] = 0: 'X' when next == 1 and prev > 0 (translate.rs:204-210)
+                        const int next = L > 1 ? 1 : (at_end ? 0 : dn);
+                        if (next == 1) cand = true;
+                        else at[m] = (uint8_t)'-';
+                    }
+                } else {
+                    const int j0 = q >= 0 ? 0 : 1, j1 = min(-d, jl); // bases with x <= 0
+                    for (int j = j0; j <= j1; j++) at[m + j] = (uint8_t)'-';
+                    // the base with x = 0 whose successor (x = 1) is in the segment: an 'X' when it is one of the read's two
+                    // first bases, whose prev is k
+                    const int pz = m - d;
+                    if (-d + 1 <= jl && pz >= 0 && pz <= 1) at[pz] = cX;
+                }
+                dn = d;
+                e = m;
+                at_end = false;
+            }
+        }
+        (void)K;
+    } else if (plannable && !flag && len >= 3u) {
         const int K = (int)k, T = (int)a.map_thr;
         const uint32_t Tm1 = (uint32_t)(T - 1);
         uint8_t *at = so + soff;
@@ -420,7 +487,7 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
     // read's base, everything else becomes '-' (flagged reads' bytes are rewritten by launch_derand_flagged)
     for (uint32_t c = lane * 16u; c < span; c += 1024u) {
         uint4 v = *reinterpret_cast<const uint4 *>(so + c);
-        if (a.map_fmt) {
+        if (!DIRECT && a.map_fmt) {
             const uint32_t dg = lin[c >> 4];
             auto fmt4 = [&](uint32_t ch, uint32_t d8) -> uint32_t { // four characters and the four bases behind them
                 const uint32_t sel = ((d8 >> 6) & 3u) | (((d8 >> 4) & 3u) << 8) | (((d8 >> 2) & 3u) << 16) | ((d8 & 3u) << 24);
@@ -486,10 +553,18 @@ hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
     const uint32_t stage_bytes = (64u * a.max_item_len + 16u + kMapSlack + 15u) / 16u * 16u;
     const uint32_t lin_words = stage_bytes / 16u + 4u;
     const uint32_t lds = stage_bytes + 4u * (lin_words + 4u) + 1024u;
-    if (a.ix.dtab_order <= 15u)
-        hipLaunchKernelGGL((map_reads_kernel<16>), dim3((a.n_items + 63u) / 64u), dim3(64), lds, stream, a, stage_bytes, lin_words);
-    else
-        hipLaunchKernelGGL((map_reads_kernel<18>), dim3((a.n_items + 63u) / 64u), dim3(64), lds, stream, a, stage_bytes, lin_words);
+    // the characters straight from the mismatch positions where no table value can anchor (order <= t < k) and the MS values
+    // are not asked for; else the MS bytes in LDS and the literal pass over them
+    static const int env_direct = std::getenv("KBO_MAP_DIRECT") ? std::atoi(std::getenv("KBO_MAP_DIRECT")) : 1; // experiments
+    const bool direct = env_direct != 0 && !a.map_want_ms && a.ix.dtab_order <= a.map_thr && a.map_thr < a.ix.k;
+    const dim3 grid((a.n_items + 63u) / 64u), block(64);
+    if (a.ix.dtab_order <= 15u) {
+        if (direct) hipLaunchKernelGGL((map_reads_kernel<16, true>), grid, block, lds, stream, a, stage_bytes, lin_words);
+        else hipLaunchKernelGGL((map_reads_kernel<16, false>), grid, block, lds, stream, a, stage_bytes, lin_words);
+    } else {
+        if (direct) hipLaunchKernelGGL((map_reads_kernel<18, true>), grid, block, lds, stream, a, stage_bytes, lin_words);
+        else hipLaunchKernelGGL((map_reads_kernel<18, false>), grid, block, lds, stream, a, stage_bytes, lin_words);
+    }
     return hipGetLastError();
 }
 

@@ -50,7 +50,7 @@ def _check(oracle, ora, sbwt, concat, offsets, p=1e-7, expect_fused=True):
     import torch
     exp_chars, exp_d = ora.matches_batch(concat, offsets, p, n_threads=threads(), want_d=True)
     exp_map = np.frombuffer(oracle.relative_to_ref(concat, exp_chars), dtype=np.uint8)
-    for fmt, want_ms in ((False, True), (True, False)):
+    for fmt, want_ms in ((False, True), (True, False), (False, False)):  # (without the MS values: the kernel's direct form)
         dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"), max_error_prob=p, format=fmt, want_ms=want_ms)
         dev.ms.fill_(0xEE)
         dev.chars.fill_(0xEE)
