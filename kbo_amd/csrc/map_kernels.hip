@@ -103,7 +103,14 @@ constexpr uint32_t kMapSlack = 48;       // bytes of the byte region behind the 
 // tests/test_gpu_map_reads.py runs both against the oracle).  x rises by one per base inside a segment and is <= 0 behind
 // a break, so translate_ms_val (translate.rs:180-216) never sees its 'R' case: every base is 'M' except the -d + 1 bases
 // from a mismatch on - '-', or 'X' for a lone mismatch whose left neighbour is positive - and the two first bases of the
-// read, whose `prev` is k (translate.rs:277).  The table look-ups only have to PROVE that nothing is deeper than `order`.
+// read, whose `prev` is k (translate.rs:277).
+// What the table has to PROVE for that is only that no string of t + 1 bases that contains a mismatch is a substring of the index
+// (the matching statistic is then at most t wherever it is not the distance to the last mismatch).  A present string of t + 1
+// bases has every window of `order` bases inside it present, and the windows inside it that contain the mismatch m end at
+// cov = t - order + 2 consecutive bases: so the windows ending at m, m + cov, m + 2 cov, .., m + order - 1 - three of them at
+// C2 (15 bases, t = 22) and C3 (17, 24) - each not a suffix of any row (bit 7 of their entries clear), rule every such string
+// out: three byte look-ups per mismatch instead of the fourteen of the value-by-value rule, no rule to evaluate.  A read
+// without a seed has every string of t + 1 bases ruled out the same way (a window every cov bases): all its bases are '-'.
 template <int NP, bool DIRECT>
 __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stage_bytes, uint32_t lin_words)
 {
@@ -277,7 +284,12 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
     uint32_t st_look = 0, st_written = 0, st_anch = 0;
     {
         const uint32_t order = a.ix.dtab_order;
-        const uint32_t my_n = !plannable || flag ? 0u : (no_plan ? (len + 15u) / 16u : cnt);
+        // DIRECT: cov = bases between two windows of the proof (header), n_e = windows per mismatch (<= 4: launch_map_reads);
+        // a read without a seed: windows ending at order - 1, + cov, .. and at its last base, four per unit of work
+        const uint32_t thr = a.map_thr, cov = DIRECT ? thr - order + 2u : 1u;
+        const uint32_t n_blockwin = (DIRECT && len > thr) ? (len - order + cov - 1u) / cov + 1u : 0u;
+        const uint32_t my_n = !plannable || flag ? 0u : DIRECT ? (no_plan ? (n_blockwin + 3u) / 4u : (len > thr ? cnt : 0u))
+                                                               : (no_plan ? (len + 15u) / 16u : cnt);
         uint32_t incl = my_n;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -306,7 +318,40 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
             const uint32_t o_incl = __shfl(incl, (int)owner), o_n = __shfl(my_n, (int)owner), o_soff = __shfl(soff, (int)owner),
                            o_len = __shfl(len, (int)owner), o_np = __shfl(no_plan ? 1u : 0u, (int)owner);
             const bool blockmode = o_np != 0;
-            if (work) {
+            if (DIRECT) {
+                if (work) {
+                    const uint32_t t = w - (o_incl - o_n);
+                    const uint32_t m = blockmode ? 0u : (uint32_t)spw[owner * 16u + t];
+                    uint32_t bytes[4];
+                    bool use[4];
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; i++) {
+                        // the base the window ends at, and whether the window counts: inside the read, `order` bases long, and not the
+                        // same window again (the last one of a mismatch is clamped to m + order - 1, of a read to its last base)
+                        uint32_t ee;
+                        if (blockmode) {
+                            const uint32_t u = 4u * t + i;
+                            ee = min(order - 1u + u * cov, o_len - 1u);
+                            use[i] = o_len >= order && (u == 0u || order - 1u + (u - 1u) * cov < o_len - 1u);
+                        } else {
+                            ee = m + min(i * cov, order - 1u);
+                            use[i] = ee < o_len && ee + 1u >= order && (i == 0u || (i - 1u) * cov < order - 1u);
+                        }
+                        bytes[i] = 0;
+                        if (use[i]) {
+                            const code_t key = (code_t)ending_at(o_soff + ee) & omask;
+                            bytes[i] = !a.ix.dtab_grouped ? a.ix.dtab[key]
+                                                          : a.ix.dtab[NP == 16 ? dtab_grouped_addr32((uint32_t)key, ee % 3u, order) : dtab_grouped_addr((uint64_t)key, ee % 3u, order)];
+                            st_look++;
+                        }
+                    }
+                    const uint32_t any = (bytes[0] | bytes[1] | bytes[2] | bytes[3]) & 0x80u;
+                    if (any) {
+                        spw[owner * 16u + 13u] = 1; // a window that is a suffix of a row: the proof fails, the read takes the plain walk
+                        st_anch++;
+                    }
+                }
+            } else if (work) {
                 const uint32_t t = w - (o_incl - o_n);
                 const uint8_t *osp = spw + owner * 16u;
                 const uint32_t m = blockmode ? 16u * t : (uint32_t)osp[t];
@@ -357,19 +402,16 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
                 if (unkmask) spw[owner * 16u + 13u] = 1; // the owner's read goes to the plain walk
                 // (a stretch with an unknown base writes nothing; a block writes the bases it knows)
                 const uint32_t wmask = blockmode ? evalmask & ~unkmask : (unkmask ? 0u : evalmask);
-                if (DIRECT) st_written += (uint32_t)__popc(wmask); // (counted, not written: the values themselves change nothing)
-                else {
 #pragma unroll
-                    for (uint32_t j = 0; j < (uint32_t)NP; j++)
-                        if ((wmask >> j) & 1u) {
-                            so[o_soff + m + j] = (uint8_t)(outv[j >> 2] >> (8u * (j & 3u)));
-                            st_written++;
-                        }
-                    // behind the stretch: the ramp up to the next mismatch (depth = bases since this one), k from k bases on (in place)
-                    if (!blockmode && !unkmask) {
-                        const uint32_t rend = min(nxt - m, k);
-                        for (uint32_t j = n_eval; j < rend; j++) so[o_soff + m + j] = (uint8_t)j;
+                for (uint32_t j = 0; j < (uint32_t)NP; j++)
+                    if ((wmask >> j) & 1u) {
+                        so[o_soff + m + j] = (uint8_t)(outv[j >> 2] >> (8u * (j & 3u)));
+                        st_written++;
                     }
+                // behind the stretch: the ramp up to the next mismatch (depth = bases since this one), k from k bases on (in place)
+                if (!blockmode && !unkmask) {
+                    const uint32_t rend = min(nxt - m, k);
+                    for (uint32_t j = n_eval; j < rend; j++) so[o_soff + m + j] = (uint8_t)j;
                 }
             }
         }
@@ -556,7 +598,9 @@ hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
     // the characters straight from the mismatch positions where no table value can anchor (order <= t < k) and the MS values
     // are not asked for; else the MS bytes in LDS and the literal pass over them
     static const int env_direct = std::getenv("KBO_MAP_DIRECT") ? std::atoi(std::getenv("KBO_MAP_DIRECT")) : 1; // experiments
-    const bool direct = env_direct != 0 && !a.map_want_ms && a.ix.dtab_order <= a.map_thr && a.map_thr < a.ix.k;
+    // (and the proof takes at most four windows per mismatch: cov = t - order + 2 bases apart over order bases)
+    const bool direct = env_direct != 0 && !a.map_want_ms && a.ix.dtab_order <= a.map_thr && a.map_thr < a.ix.k &&
+                        (a.ix.dtab_order - 1u + (a.map_thr - a.ix.dtab_order + 2u) - 1u) / (a.map_thr - a.ix.dtab_order + 2u) + 1u <= 4u;
     const dim3 grid((a.n_items + 63u) / 64u), block(64);
     if (a.ix.dtab_order <= 15u) {
         if (direct) hipLaunchKernelGGL((map_reads_kernel<16, true>), grid, block, lds, stream, a, stage_bytes, lin_words);
