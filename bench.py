@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """bench.py — kbo map query throughput on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path (A1: the plan-guided MS walk; A5/A6: the fused derandomize / translate kernel,
-i.e. kbo::map with fill_gaps=false, call_variants=false, lib.rs:735-738) over one batch of synthetic reads already
-resident in HBM.  Default workload = BASELINE config C2: 5 Mbp iid genome, k=31 SBWT, 1 M x 150 bp forward reads with
+One "step" = one pass of the hot path - kbo::map with fill_gaps=false, call_variants=false (lib.rs:735-738, 756-757): MS ->
+derandomize -> translate -> relative_to_ref - over one batch of synthetic reads already resident in HBM, through
+kbo_map_batch_dev: ONE kernel for the reads (kbo_amd/csrc/map_kernels.hip) + the plain walk of the few per cent it leaves
+(--two-kernels: the round-3 route, the plan-guided MS walk and the derandomize / translate kernel one after the other).  Default workload = BASELINE config C2: 5 Mbp iid genome, k=31 SBWT, 1 M x 150 bp forward reads with
 1 % substitutions per GPU (weak scaling: every rank holds the replicated index and its own reads; no collective on the data
 path).  Prints ONE JSON line on rank 0.
 
@@ -63,6 +64,8 @@ def parse(argv=None):
                     help="time the first pass of kbo call (C5 shape, scaled): MS walk with intervals + the breakpoint scan "
                          "on the device over 10 kbp reads (defaults: --genome 100000000 --reads 10000 --read-len 10000)")
     ap.add_argument("--no-plan", action="store_true", help="plain walk kernel only (no path cover, no plan-guided walk)")
+    ap.add_argument("--two-kernels", action="store_true", help="kbo_ms_batch_dev + kbo_derand_translate_dev instead of kbo_map_batch_dev "
+                    "(the MS values of every base go through HBM)")
     ap.add_argument("--depth-table", type=int, default=0,
                     help="order of the depth table (kbo_set_depth_table): 0 = by index size, -1 = none (units + guided walk)")
     ap.add_argument("--index-cache", default=None, help="index file (.kbohip, with its path cover) to load instead of building; "
@@ -82,6 +85,20 @@ def parse(argv=None):
     args.find = args.find or (preset[2] and not args.custom)
     args.scaling = preset[3]
     return args
+
+
+def build_sha16():
+    """A fingerprint of what a profile was taken of: bench.py and every source of the HIP extension.  tools/profile_bench.sh stores
+    it next to the counters it collects; a line printed by a different build quotes no traffic figure (a committed
+    profile must not decorate the line of a later build)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in [os.path.join(ROOT, "bench.py")] + sorted(glob.glob(os.path.join(ROOT, "kbo_amd", "csrc", "*.h*")) +
+                                                       glob.glob(os.path.join(ROOT, "kbo_amd", "csrc", "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def usable_cores():
@@ -302,8 +319,21 @@ def stage_model_leg(args, sbwt, oi, concat, offsets, gpu_d, n_sample=2_000_000):
     return total / cn["bases"], summary, cn
 
 
-def run_batch(dev, stream, find, steps, warmup, torch, device):
-    """warm-up + timed steps of one resident batch -> (elapsed s, a1 ms, a5/a6 ms, rle ms | None)"""
+def run_batch(dev, stream, find, steps, warmup, torch, device, two_kernels=False):
+    """warm-up + timed steps of one resident batch -> (elapsed s, a1 ms, a5/a6 ms, rle ms | None); with kbo_map_batch_dev
+    (not two_kernels) a1 = the whole call and a5/a6 = 0"""
+    if not two_kernels:
+        for _ in range(warmup):
+            dev.run(stream)
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(steps):
+            dev.run(stream)
+        e1.record(stream)
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0, e0.elapsed_time(e1) / steps, 0.0, None
     for _ in range(warmup):
         dev.run(stream)
         if find:
@@ -340,17 +370,19 @@ def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream):
         comp[a] = b
 
     def measure(name, ix, o, concat, offsets, note):
-        dev = batch.DeviceBatch(ix, concat, offsets, device=device, format=True)
-        elapsed, a1, dt, _ = run_batch(dev, stream, False, 5, 2, torch, device)
-        dev.format = False
-        dev.derand_translate(stream)
-        torch.cuda.synchronize(device)
+        dev = batch.DeviceBatch(ix, concat, offsets, device=device, format=True, want_ms=False)
+        elapsed, a1, dt, _ = run_batch(dev, stream, False, 5, 2, torch, device, args.two_kernels)
+        fused = dev.fused
         n_chk = min(n_reads, 20_000)
         exp_chars, exp_d = o.matches_batch(concat[:n_chk * L], offsets[:n_chk + 1], 1e-7, n_threads=cores, want_d=True)
-        ok = bool(np.array_equal(dev.ms[:n_chk * L].cpu().numpy(), exp_d) and np.array_equal(dev.chars[:n_chk * L].cpu().numpy(), exp_chars))
+        exp_map = np.frombuffer(ora.relative_to_ref(concat[:n_chk * L], exp_chars), dtype=np.uint8)
+        ok = bool(np.array_equal(dev.chars[:n_chk * L].cpu().numpy(), exp_map))  # (what the timed steps left behind)
+        dev.walk(stream)
+        torch.cuda.synchronize(device)
+        ok = bool(ok and np.array_equal(dev.ms[:n_chk * L].cpu().numpy(), exp_d))
         del dev
-        return {"variant": name, "value": round(n_reads * L * 5 / elapsed / 1e6, 1), "unit": "Mbp/s", "a1_stage_ms": round(a1, 4),
-                "derand_translate_ms": round(dt, 4), "bit_exact_vs_oracle": ok, "note": note}
+        return {"variant": name, "value": round(n_reads * L * 5 / elapsed / 1e6, 1), "unit": "Mbp/s", "one_kernel": fused,
+                "step_ms": round(a1 + dt, 4), "bit_exact_vs_oracle": ok, "note": note}
 
     out = []
     L_ = kbo_amd.lib()
@@ -569,7 +601,7 @@ def main(argv=None):
     for s0 in range(0, n_mine, SLAB_READS):
         ns = min(SLAB_READS, n_mine - s0)
         concat, offsets = synth.reads(genome, ns, args.read_len, args.sub_rate, first_read=first + s0)
-        slabs.append(batch.DeviceBatch(sbwt, concat, offsets, device=device, format=not args.find))
+        slabs.append(batch.DeviceBatch(sbwt, concat, offsets, device=device, format=not args.find, want_ms=False))
         if s0 == 0:
             concat0, offsets0 = concat, offsets  # (rank 0's parity gate and CPU baseline use the first slab)
     bases = n_mine * args.read_len
@@ -584,10 +616,15 @@ def main(argv=None):
         for i, dev in enumerate(slabs):
             if events is not None:
                 events[i][0].record(stream)
-            dev.walk(stream)
-            if events is not None:
-                events[i][1].record(stream)
-            dev.derand_translate(stream)
+            if args.two_kernels:
+                dev.walk(stream)
+                if events is not None:
+                    events[i][1].record(stream)
+                dev.derand_translate(stream)
+            else:  # kbo_map_batch_dev: one kernel for the reads + the plain walk of the reads it leaves
+                dev.run(stream)
+                if events is not None:
+                    events[i][1].record(stream)
             if events is not None:
                 events[i][2].record(stream)
             if args.find:  # kbo::find (lib.rs:816-820): run lengths of the characters, still on the device
@@ -598,12 +635,20 @@ def main(argv=None):
     for _ in range(args.warmup):
         one_step()
     sync_all()
+    one_kernel = (not args.two_kernels) and all(d.fused for d in slabs)
     ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in slabs] for _ in range(args.steps)]
+    import ctypes as _C
+    L.kbo_set_stage_timing(1 if one_kernel else 0)  # (three event records per call: the dominant kernel's own duration, live)
     t0 = time.perf_counter()
     for s in range(args.steps):
         one_step(ev[s])
     sync_all()
     elapsed = time.perf_counter() - t0
+    L.kbo_set_stage_timing(0)
+    k_sum, r_sum, n_calls = _C.c_double(0), _C.c_double(0), _C.c_int(0)
+    L.kbo_stage_timing_read(_C.byref(k_sum), _C.byref(r_sum), _C.byref(n_calls))
+    map_kernel_ms = k_sum.value / args.steps if one_kernel and n_calls.value else None  # per step (all slabs)
+    map_redo_ms = r_sum.value / args.steps if one_kernel and n_calls.value else None
     walk_ms = float(np.mean([sum(e[0].elapsed_time(e[1]) for e in step) for step in ev]))
     dt_ms = float(np.mean([sum(e[1].elapsed_time(e[2]) for e in step) for step in ev]))
     rle_ms = float(np.mean([sum(e[2].elapsed_time(e[3]) for e in step) for step in ev])) if args.find else None
@@ -627,7 +672,12 @@ def main(argv=None):
         dev = slabs[0]
         # the stage's own work counters: one more launch over the first slab with the counting instantiations of the
         # kernels (instrumentation, off inside the timed region: about 1 % of the stage's time)
+        timed_chars = dev.chars[:dev.total].cpu().numpy()  # what the timed steps left behind (formatted unless --find)
         L.kbo_set_plan_stats(1)
+        if one_kernel:
+            dev.run(stream)
+            torch.cuda.synchronize(device)
+            map_stats = dev.plan_stats(stream)
         dev.walk(stream)
         torch.cuda.synchronize(device)
         stats = dev.plan_stats(stream)
@@ -649,7 +699,12 @@ def main(argv=None):
             torch.cuda.synchronize(device)
             cpu, b_ref, exact, ops = cpu_baseline_leg(args, oi, concat0, offsets0, gpu_d, dev.chars.cpu().numpy())
             dev.format = fmt
-            if planned and not stats["gave_up"]:
+            # EVERY read of the slab: the characters the timed steps wrote (kbo::map's output) and the MS values, against the oracle
+            exp_chars, exp_d = oi.matches_batch(concat0, offsets0, 1e-7, n_threads=usable_cores()[0], want_d=True)
+            exp_out = np.frombuffer(ora.relative_to_ref(concat0, exp_chars), dtype=np.uint8) if fmt else exp_chars
+            exact = bool(exact and np.array_equal(timed_chars, exp_out) and np.array_equal(gpu_d[:dev.total], exp_d))
+            del exp_chars, exp_d, exp_out
+            if planned and not stats["gave_up"] and not one_kernel:
                 b_plan, model, _ = stage_model_leg(args, sbwt, oi, concat0, offsets0, gpu_d)
                 exact = bool(exact and model["ms_equal_to_gpu"])
             if world == 1 and not args.no_extras and (args.extras or not args.custom):
@@ -657,12 +712,17 @@ def main(argv=None):
                 h2h = host_to_host_leg(args, sbwt, genome)
         # fabric-side traffic and L2 misses of the A1 stage, from the committed rocprofv3 passes of this exact
         # workload and walk mode (PMC passes cannot run inside the timed region: separate runs, tools/profile_bench.sh)
-        wl_key = f"{args.genome}x{n_mine}x{args.read_len}x{args.sub_rate:g}:{('table' if sbwt.depth_table_order() > 0 else 'plan') if planned else 'plain'}"
+        wl_key = f"{args.genome}x{n_mine}x{args.read_len}x{args.sub_rate:g}:{('map' if one_kernel else 'table' if sbwt.depth_table_order() > 0 else 'plan') if planned else 'plain'}"
+        sha = build_sha16()
         traffic = tsrc = misses = walk_misses = plan_misses = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 entry = json.load(open(tpath)).get("workloads", {}).get(wl_key)
+                if entry and one_kernel and entry.get("build_sha16") != sha:
+                    tsrc = "none: %s was taken of another build (%s, this one is %s) - tools/profile_bench.sh renews it" % (
+                        entry.get("source"), entry.get("build_sha16"), sha)
+                    entry = None
                 if entry:
                     traffic, misses, tsrc = entry.get("a1_bytes_per_launch"), entry.get("a1_tcc_miss_per_launch"), entry.get("source")
                     kern = entry.get("kernels", {})
@@ -670,6 +730,7 @@ def main(argv=None):
                     plan_misses = (kern.get("plan_kernel") or {}).get("tcc_miss")
             except Exception:
                 pass
+        lay = sbwt.device_layout()
         rank_b, lcs_b = sbwt.device_bytes()
         dto = sbwt.depth_table_order()
         dtab_b = 0 if dto == 0 else (4 ** (dto + 1) if dto >= 4 else 4 ** dto)  # (grouped from 4 bases on: DESIGN.md section 4.2)
@@ -726,6 +787,41 @@ def main(argv=None):
             "stage_model": model,
             "stage_counters_gpu_first_slab": stats if planned else None,
         }
+        if one_kernel:
+            # the dominant kernel priced by its OWN compulsory bytes, counted by the kernel itself on the first slab (kbo_set_plan_stats:
+            # one extra launch behind the timed region): what it must read and write however well it is written
+            c = map_stats
+            seeded = dev.n_seqs - c["items_noplan"]
+            by = {"query_bytes_in": dev.total, "characters_out": dev.total, "item_records_and_flags": 17 * dev.n_seqs,
+                  "seed_positions": 4 * c["seed_lookups"], "text_2bit_and_marks": 96 * seeded, "depth_table_bytes": c["tab_lookups"]}
+            b_map = sum(by.values()) / dev.total
+            k_s = map_kernel_ms * 1e-3
+            achieved = b_map * bases / k_s / 1e9
+            lines_min = (2 * dev.total / 128 + c["seed_lookups"] + c["tab_lookups"]) / dev.n_seqs  # streams + one line per table access
+            roofline = {
+                "bound": "hbm",
+                "bound_detail": "random fills: per read one seed-position look-up, three depth-table bytes per mismatch (each a line of its own), "
+                                "the 2-bit text on the diagonal (L2 / Infinity Cache) and 2 B per base of streams; integer work, no MFMA",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "frac_meaning": "compulsory bytes of map_reads_kernel (counted by the kernel on the timed reads: bytes_by_part) x bases per step / "
+                                "its own duration (HIP events around it in every timed step) / 8 TB/s",
+                "algorithmic_bytes_per_base": round(b_map, 3), "bytes_by_part_first_slab": by, "units_per_launch": bases,
+                "kernel": "map_reads_kernel (kbo_amd/csrc/map_kernels.hip): MS -> derandomize -> translate -> relative_to_ref of every read it can finish",
+                "kernel_ms": round(map_kernel_ms, 4), "redo_pass_ms": round(map_redo_ms, 4),
+                "redo_pass": "redo_collect + ms_walk_kernel + derand_flagged over the %.2f %% of the reads the kernel leaves (a chain of dependent "
+                             "look-ups: its time is the chain's, not the reads')" % (100.0 * c["tab_unresolved"] / dev.n_seqs),
+                "traffic": int(traffic) if traffic else None, "traffic_source": tsrc,
+                "traffic_frac": round(traffic / k_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
+                "wasted_traffic": round(traffic / (b_map * bases), 3) if traffic else None,
+                "l2_miss_per_launch": int(misses) if misses else None,
+                "fill_rate_frac": round(misses / k_s / FILL_CEILING_PER_S, 4) if misses else None,
+                "fill_rate_ceiling": {"fills_per_s": FILL_CEILING_PER_S, "source": FILL_CEILING_SOURCE},
+                "fills_min_per_read": round(lines_min, 2), "l2_miss_per_read": round(misses / (bases / args.read_len), 2) if misses else None,
+                "frac_reference_algorithm": round(b_ref * bases / k_s / 1e9 / HBM_PEAK_GBPS, 4) if b_ref is not None else None,
+                "reference_algorithm_bytes_per_base": round(b_ref, 2) if b_ref is not None else None,
+                "cross_check_whole_step_gbps": round(b_map * bases / (elapsed / args.steps) / 1e9, 1),
+                "stage_counters_gpu_first_slab": c, "build_sha16": sha,
+            }
         result = {
             "metric": f"query Mbp/sec for kbo {'find' if args.find else 'map'}, k={args.k}, {args.genome / 1e6:g} Mbp SBWT; bit-exact MS vs CPU",
             "value": round(total_bases * args.steps / elapsed / 1e6, 1),
@@ -739,17 +835,27 @@ def main(argv=None):
                                       else f"{args.reads} x {args.read_len} bp reads per GPU, ")
                                    + f"{args.sub_rate * 100:g}% substitutions",
                        "index_n_sets": sbwt.n_sets(), "threshold": dev.threshold,
-                       "walk": ("plan-guided (path cover + depth table of %d bases)" % sbwt.depth_table_order() if table else
+                       "walk": ("kbo_map_batch_dev: one kernel per batch of reads (path cover as 2-bit text, seed positions, depth table of %d bases)" % sbwt.depth_table_order()
+                                if one_kernel else "plan-guided (path cover + depth table of %d bases)" % sbwt.depth_table_order() if table else
                                 "plan-guided (path cover + guided walk)" if planned else "plain"),
-                       "index_device_bytes": {"rank_blocks": rank_b, "lcs": lcs_b, "two_base_blocks": pair_b,
-                                              "path_cover_lines": plan_b - dtab_b - seed_b, "seed_table": seed_b, "depth_table": dtab_b,
-                                              "per_row": round((rank_b + lcs_b + pair_b + plan_b - dtab_b - seed_b) / sbwt.n_sets(), 2),
-                                              "note": "per_row leaves the seed table and the depth table out: their sizes depend on log4(rows) only"},
+                       # (from the library: kbo_index_device_layout - what the copy really holds, and what making it cost)
+                       "index_device_bytes": {kk: v for kk, v in lay.items() if kk.endswith("_bytes")} | {
+                           "total": sum(v for kk, v in lay.items() if kk.endswith("_bytes")),
+                           "per_row_without_tables": round(sum(lay[kk] for kk in ("rank_bytes", "entry_bytes", "pair_bytes", "cover_bytes", "lines_bytes")) / sbwt.n_sets(), 2),
+                           "depth_table_order": lay["dtab_order"], "depth_table_layout": "grouped" if lay["dtab_grouped"] else "plain",
+                           "seed_table_depth": lay["seed_depth"], "entries_64bit": lay["entries_64bit"],
+                           "note": "the seed table(s) and the depth table are sized by log4(rows), not by the index"},
+                       "setup_seconds": {kk[:-8]: round(v, 3) for kk, v in lay.items() if kk.endswith("_seconds")} | {
+                           "total": round(sum(v for kk, v in lay.items() if kk.endswith("_seconds")), 3),
+                           "note": "this rank's device copy: host layout of rank blocks / entries, uploads, path cover (0 when the index "
+                                   "file carried it), recovery lines, seed table(s), depth table; index build or load is index_seconds_rank0"},
                        "resident_slabs_per_gpu": len(slabs), "index_seconds_rank0": round(t_index, 2),
                        "parallelism": f"index replicated x{world}, reads sharded, no collective"},
             "roofline": roofline,
-            "kernels_ms": {"a1_stage": round(walk_ms, 4), "derand_translate": round(dt_ms, 4),
-                           **({"run_lengths": round(rle_ms, 4)} if args.find else {})},
+            "kernels_ms": ({"map_reads_kernel": round(map_kernel_ms, 4), "redo_pass": round(map_redo_ms, 4),
+                            "kbo_map_batch_dev": round(walk_ms, 4)} if one_kernel else
+                           {"a1_stage": round(walk_ms, 4), "derand_translate": round(dt_ms, 4)}) |
+                          ({"run_lengths": round(rle_ms, 4)} if args.find else {}),
             "cpu_baseline": cpu,
             "bit_exact_vs_oracle": exact,
             "reference_ops_per_base": ops,

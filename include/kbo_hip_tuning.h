@@ -109,6 +109,13 @@ int kbo_set_plan_stats(int on);
 int kbo_plan_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k, const void *d_work,
                        uint64_t out[KBO_PLAN_STATS], void *stream);
 
+/* instrumentation (default off): while on, every kbo_map_batch_dev call that takes the one-kernel route records HIP events on its
+ * stream around map_reads_kernel and behind the redo pass (three event records per call).  kbo_stage_timing_read waits for the
+ * recorded calls, returns their number and the sums of the two intervals in milliseconds - the kernel itself / the reads it left
+ * to the plain walk (list, walk, their derandomize + translate) - and forgets them.  bench.py prices its roofline by the first. */
+int kbo_set_stage_timing(int on);
+int kbo_stage_timing_read(double *kernel_ms_sum, double *redo_ms_sum, int *n_calls);
+
 /* test hook: what kbo_call_batch answers the reference-side walks of its sites with (variant_calling.rs:280: the matched
  * row's k-mer against the index the reference builds of the sequence itself, lib.rs:553) - the depths of the walk of each
  * of n_kmers k-mers (k bytes each, back to back) against the SBWT of `seq` built with (k, add_revcomp), computed from a

@@ -1189,6 +1189,55 @@ size_t kbo_run_lengths_work_bytes(size_t n_seqs)
     return kbo::chunk_items_scratch_words((uint32_t)std::min<size_t>(n_seqs, 0xFFFFFFFEu)) * sizeof(uint32_t) + 16;
 }
 
+namespace {
+// kbo_set_stage_timing: event triples of the one-kernel route's calls (guarded by g_timing_mu)
+std::atomic<int> g_stage_timing{0};
+std::mutex g_timing_mu;
+struct StageEvents { hipEvent_t e0, e1, e2; };
+std::vector<StageEvents> g_timing_pool, g_timing_used;
+StageEvents timing_take()
+{
+    std::lock_guard<std::mutex> g(g_timing_mu);
+    StageEvents ev{};
+    if (!g_timing_pool.empty()) {
+        ev = g_timing_pool.back();
+        g_timing_pool.pop_back();
+    } else {
+        HIP_OK(hipEventCreate(&ev.e0));
+        HIP_OK(hipEventCreate(&ev.e1));
+        HIP_OK(hipEventCreate(&ev.e2));
+    }
+    return ev;
+}
+} // namespace
+
+int kbo_set_stage_timing(int on)
+{
+    g_stage_timing = on != 0;
+    return KBO_OK;
+}
+
+int kbo_stage_timing_read(double *kernel_ms_sum, double *redo_ms_sum, int *n_calls)
+{
+    return guarded([&] {
+        std::lock_guard<std::mutex> g(g_timing_mu);
+        double a = 0, b = 0;
+        for (const StageEvents &ev : g_timing_used) {
+            HIP_OK(hipEventSynchronize(ev.e2));
+            float x = 0, y = 0;
+            HIP_OK(hipEventElapsedTime(&x, ev.e0, ev.e1));
+            HIP_OK(hipEventElapsedTime(&y, ev.e1, ev.e2));
+            a += x;
+            b += y;
+            g_timing_pool.push_back(ev);
+        }
+        if (kernel_ms_sum) *kernel_ms_sum = a;
+        if (redo_ms_sum) *redo_ms_sum = b;
+        if (n_calls) *n_calls = (int)g_timing_used.size();
+        g_timing_used.clear();
+    });
+}
+
 int kbo_map_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
                       size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
                       void *d_work, size_t work_bytes, void *stream, int *fused)
@@ -1231,10 +1280,22 @@ int kbo_map_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
         a.map_want_ms = want_ms ? 1u : 0u;
         if (!a.gitems || !kbo::map_reads_applies(a)) return; // (no plan structures, or the copy is held off: two kernels)
         HIP_OK(kbo::launch_make_items(d_offsets, (uint32_t)n_seqs, items, s));
+        const bool timing = g_stage_timing.load() != 0;
+        StageEvents ev{};
+        if (timing) {
+            ev = timing_take();
+            HIP_OK(hipEventRecord(ev.e0, s));
+        }
         HIP_OK(kbo::launch_map_reads(a, s));
+        if (timing) HIP_OK(hipEventRecord(ev.e1, s));
         HIP_OK(kbo::launch_redo_pass(a, s));
         HIP_OK(kbo::launch_derand_flagged(d_ms, d_offsets, (uint32_t)n_seqs, idx->host.k, (uint32_t)threshold, format ? d_concat : nullptr,
                                           d_chars_out, a.redo, (uint32_t)max_seq_len, s));
+        if (timing) {
+            HIP_OK(hipEventRecord(ev.e2, s));
+            std::lock_guard<std::mutex> g(g_timing_mu);
+            g_timing_used.push_back(ev);
+        }
         plan_after_launch(a, s, plan_state);
         done = true;
     });

@@ -13,7 +13,7 @@ out = sys.argv[1]
 
 
 def short(name):
-    m = re.search(r"(\w+_kernel|__amd_rocclr_\w+|vectorized_elementwise_kernel)", name)
+    m = re.search(r"(map_reads_kernel|\w+_kernel|__amd_rocclr_\w+|vectorized_elementwise_kernel)", name)
     return m.group(1) if m else name[:40]
 
 

@@ -8,6 +8,7 @@ import json
 import os
 import sys
 
+MAP = ("map_reads_kernel",)  # workload keys that end in ":map": the one kernel of kbo_map_batch_dev, priced on its own
 A1 = ("plan_kernel", "dtab_resolve_kernel", "dtab_stretch_kernel", "plan_count_kernel", "scan_kernel", "plan_emit_kernel", "ms_walk_guided_kernel",
       "ms_walk_recovery_kernel", "redo_collect_kernel", "ms_walk_kernel")
 summ, key, source = json.load(open(sys.argv[1])), sys.argv[2], sys.argv[3]
@@ -16,9 +17,10 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = os.path.join(root, "profiles", "traffic_latest.json")
 doc = json.load(open(path))
 calls = {k["kernel"]: k["calls"] for k in summ["kernel_stats"]}
-per_step = min(c for k, c in calls.items() if k in ("plan_kernel", "ms_walk_kernel"))  # launches of the stage in the run
+is_map = key.endswith(":map")
+per_step = min(c for k, c in calls.items() if k in (("map_reads_kernel",) if is_map else ("plan_kernel", "ms_walk_kernel")))  # launches of the stage in the run
 kern, tot_b, tot_m = {}, 0, 0
-for k in A1:
+for k in (MAP if is_map else A1):
     d = summ["pmc_avg_per_launch"].get(k)
     if not d or "FETCH_SIZE" not in d:
         continue
@@ -29,7 +31,9 @@ for k in A1:
     kern[k] = {"bytes": b, "tcc_miss": m, "tcc_hit": int(d.get("TCC_HIT_sum", 0) * mult)}
     tot_b += b
     tot_m += m
+sys.path.insert(0, root)
+import bench  # noqa: E402  (build_sha16: what this profile was taken of)
 doc["workloads"][key] = {"source": source, "launches_per_step": per_step_launches, "a1_bytes_per_launch": tot_b,
-                         "a1_tcc_miss_per_launch": tot_m, "kernels": kern}  # (per step of bench.py = per launch x launches per step)
+                         "a1_tcc_miss_per_launch": tot_m, "kernels": kern, "build_sha16": bench.build_sha16()}  # (per step of bench.py = per launch x launches per step)
 json.dump(doc, open(path, "w"), indent=1)
 print(key, "bytes", tot_b, "misses", tot_m)
