@@ -658,7 +658,7 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     # per-rank stage times (skew between ranks shows here)
-    per_rank_t = torch.tensor([walk_ms, dt_ms], dtype=torch.float64, device=t.device)
+    per_rank_t = torch.tensor([map_kernel_ms if map_kernel_ms is not None else walk_ms, dt_ms], dtype=torch.float64, device=t.device)
     if world > 1:
         gathered = [torch.zeros_like(per_rank_t) for _ in range(world)]
         dist.all_gather(gathered, per_rank_t)
@@ -807,7 +807,8 @@ def main(argv=None):
                                 "its own duration (HIP events around it in every timed step) / 8 TB/s",
                 "algorithmic_bytes_per_base": round(b_map, 3), "bytes_by_part_first_slab": by, "units_per_launch": bases,
                 "kernel": "map_reads_kernel (kbo_amd/csrc/map_kernels.hip): MS -> derandomize -> translate -> relative_to_ref of every read it can finish",
-                "kernel_ms": round(map_kernel_ms, 4), "redo_pass_ms": round(map_redo_ms, 4),
+                "kernel_ms": round(map_kernel_ms, 4), "kernel_ms_per_rank": {"min": round(min(walk_all), 4), "max": round(max(walk_all), 4)},
+                "redo_pass_ms": round(map_redo_ms, 4),
                 "redo_pass": "redo_collect + ms_walk_kernel + derand_flagged over the %.2f %% of the reads the kernel leaves (a chain of dependent "
                              "look-ups: its time is the chain's, not the reads')" % (100.0 * c["tab_unresolved"] / dev.n_seqs),
                 "traffic": int(traffic) if traffic else None, "traffic_source": tsrc,

@@ -1,5 +1,6 @@
-"""bench.py end to end on the GPU box, at reduced size: the single-process line (roofline priced by the stage model, CPU
-baseline, sensitivity variants, host-to-host rate) and `--gpus 2` started from a plain `python bench.py` (the parent builds
+"""bench.py end to end on the GPU box, at reduced size: the single-process line (kbo_map_batch_dev's one kernel priced by its own
+counters; with --two-kernels / without a depth table the round-3 route priced by the stage model; CPU baseline, sensitivity
+variants, host-to-host rate) and `--gpus 2` started from a plain `python bench.py` (the parent builds
 the index cache on the host and spawns the ranks; with KBO_BENCH_ONE_GPU=1 both ranks share cuda:0 over gloo - a functional
 test of the multi-process path, its numbers mean nothing)."""
 import json
@@ -22,12 +23,23 @@ def _run(args, tmp_path, extra_env=None):
     return json.loads(lines[0])
 
 
-def _check_line(r, n_gpus, table=True):
+def _check_line(r, n_gpus, table=True, one_kernel=True):
     assert r["n_gpus"] == n_gpus and r["unit"] == "Mbp/s" and r["higher_is_better"] is True and r["vs_baseline"] is None
     assert r["bit_exact_vs_oracle"] is True
     ro = r["roofline"]
     assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0
     assert 0 < ro["frac"] <= 1.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and len(cb["runs_mbps"]) == 3
+    assert r["config"]["setup_seconds"]["total"] > 0 and r["config"]["index_device_bytes"]["total"] > 0
+    if one_kernel:  # kbo_map_batch_dev: the kernel's own counters price it, its duration comes from events inside the library
+        assert ro["kernel"].startswith("map_reads_kernel") and "one kernel" in r["config"]["walk"]
+        st = ro["stage_counters_gpu_first_slab"]
+        assert st["tab_lookups"] > 0 and st["seed_lookups"] > 0 and st["mismatches"] > 0
+        assert 0 < ro["kernel_ms"] <= r["kernels_ms"]["kbo_map_batch_dev"] * 1.05 and ro["redo_pass_ms"] > 0
+        assert 2.0 < ro["algorithmic_bytes_per_base"] < 4.0 and ro["build_sha16"]
+        assert ro["cross_check_whole_step_gbps"] <= ro["peak"]
+        return
     assert ro["stage_model"]["ms_equal_to_gpu"] is True
     # the model's counts are the kernels' own (first slab)
     st, m = ro["stage_counters_gpu_first_slab"], ro["stage_model"]
@@ -37,8 +49,12 @@ def _check_line(r, n_gpus, table=True):
     else:
         assert abs(st["units"] / st["units_walked"] - 1) < 1e-9 and m["units_per_read"] > 1.0
     assert ro["cross_check_whole_step_gbps"] <= ro["peak"]
-    cb = r["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and len(cb["runs_mbps"]) == 3
+
+
+def test_bench_line_two_kernels(tmp_path):
+    """--two-kernels: round 3's route (plan_kernel with the table look-ups, then the derandomize / translate kernel), priced by the model"""
+    r = _run(["--genome", "400000", "--reads", "30000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1", "--no-extras", "--two-kernels"], tmp_path)
+    _check_line(r, 1, one_kernel=False)
 
 
 def test_bench_line_single_process_with_extras(tmp_path):
@@ -54,7 +70,7 @@ def test_bench_line_guided_walk(tmp_path):
     """--depth-table -1: units and the guided walk (what larger indexes get), priced by the same model"""
     r = _run(["--genome", "400000", "--reads", "30000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1", "--no-extras", "--depth-table", "-1"],
              tmp_path)
-    _check_line(r, 1, table=False)
+    _check_line(r, 1, table=False, one_kernel=False)
     assert "guided walk" in r["config"]["walk"]
 
 
