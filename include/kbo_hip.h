@@ -257,7 +257,10 @@ int kbo_nearest_unique_context(kbo_index_t *idx, const uint8_t *ref_seq, size_t 
 int kbo_find(kbo_index_t *idx, const uint8_t *query, size_t len, const kbo_find_opts *opts,
              kbo_rle **out, size_t *n_out);
 /* format::run_lengths_gapped (format.rs:143-193) and relative_to_ref (format.rs:266-287)
- * on byte-wide alignment strings (host; sequential variable-length output). */
+ * on byte-wide alignment strings (host; sequential variable-length output).  KBO_E_REF_PANIC for an alignment that starts
+ * with 'R': the reference evaluates aln[i - 1] with i = 0 there (format.rs:175) and panics; translate_ms_vec never produces
+ * one (an 'R' needs a derandomised value above the threshold, the first base's is at most 1), so the pipeline's entry points
+ * cannot run into it. */
 int kbo_run_lengths_gapped(const uint8_t *aln, size_t len, size_t max_gap_len, kbo_rle **out,
                            size_t *n_out);
 /* format::run_lengths_gapped over a batch of alignments on the GPU (one lane per alignment): runs of

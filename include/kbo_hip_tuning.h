@@ -58,6 +58,17 @@ int kbo_set_depth_table(int order);
  * -1 = on indexes of 24 Mi rows and more whose table's margin over log4(rows) is below 3.75 bases (default: there the reads left to the plain walk are many
  * enough for it to pay - C4 +12 %, C3 +4 % - and from 3 * 10^8 rows on the table only wins with them), 0 = never, 1 = always. */
 int kbo_set_depth_table_anchors(int mode);
+/* bytes the seed + depth tables of a device copy may take while they are built (device copies made after the call): 0 = half of the
+ * device memory that is free at that moment (default).  A table that does not fit is degraded - grouped layout -> plain layout
+ * (a quarter of the bytes) -> fewer bases -> none (the copy then gets the host-built seed table and the guided walk) - never an
+ * error, also when its order was forced with kbo_set_depth_table. */
+int kbo_set_plan_table_budget(uint64_t bytes);
+/* When a device copy makes its plan structures (path cover, recovery lines, seed and depth tables, 2-bit text): kbo_index_to_device
+ * makes them at once; a copy made implicitly by a first query makes them once the batches that went through it add up to `bases`
+ * bases - until then MS-only batches take the plain walk, with the same results.  -1 = by index size (default): at once when they
+ * cost under a tenth of a second (up to ~ 1.5 * 10^6 rows), else after the bases whose saving pays for them (65 ns per row without
+ * a stored path cover, 15 ns with one, against 7 ps saved per base: ~ 50 Gbp for a 5 Mbp index); 0 = always at once. */
+int kbo_set_plan_lazy(int64_t bases);
 /* inspection / tests: the depth table of the copy of `idx` on `device` (-1 = current; the copy is made if there is none):
  * *order bases per entry (0: the copy has no table), 4^*order bytes; entry of a string (2-bit digits A, C, G, T = 0 .. 3, the
  * last base least significant) = length of its longest suffix that is a suffix of a row of the index, or 0x80 | e when the

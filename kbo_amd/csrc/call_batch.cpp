@@ -71,7 +71,7 @@ SiteWindows find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *of
     d_count.alloc(count_bytes);
     d_prefix.alloc((kbo::kCallSegs + 1) * 4);
     std::vector<uint32_t> counts(count_bytes / 4), prefix(kbo::kCallSegs + 1);
-    const kbo::DevIndexView view = device_view(idx, current_device());
+    const kbo::DevIndexView view = device_view(idx, current_device(), nullptr, offsets[n_seqs]);
     for (const Slab &sl : slabs) {
         const size_t ns = sl.s1 - sl.s0;
         std::vector<uint64_t> off(ns + 1);
@@ -147,6 +147,10 @@ class RunAutomaton {
 public:
     void build(const uint8_t *seq, size_t len, uint32_t k, bool add_revcomp)
     {
+        // (state numbers are 32-bit, two states per character and strand: 96 bytes per base with reverse complements - a
+        // sequence this long is a genome, and kbo_call with it as ref_seq walks a real index of it: refine.cpp)
+        KBO_REQUIRE((add_revcomp ? 2 : 1) * (uint64_t)len < (1ull << 29), KBO_E_UNSUPPORTED,
+                    "kbo_call_batch: a sequence of 2^29 bases or more (2^28 with add_revcomp); call kbo_call for it");
         st_.clear();
         st_.reserve(2 * (add_revcomp ? 2 * len : len) + 2); // (at most two states per character)
         new_state(0, -1);

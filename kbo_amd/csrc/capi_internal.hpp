@@ -43,6 +43,8 @@ struct DevCopy {
     DevBuf pc_text, pc_pos, pc_node; // path cover (sbwt_index.hpp PathCover), empty when the plan-guided walk is off
     DevBuf pc_tm, seed_pos;          // map_reads_kernel's 2-bit text + marks and its table of seed positions (copies with a depth table)
     // what making this copy cost (kbo_index_device_layout): seconds of host work / device builds / uploads, by part
+    bool plan_built = false;         // path cover, recovery lines, tables: made by the first use that pays for them (device_index.cpp)
+    uint64_t bases_seen = 0;         // bases of the batches that asked for this copy so far (guarded by the index's mutex)
     struct Setup {
         double layout_s = 0, cover_s = 0, lines_s = 0, seed_s = 0, dtab_s = 0, upload_s = 0;
         uint64_t rank_bytes = 0, entry_bytes = 0, pair_bytes = 0, cover_bytes = 0, lines_bytes = 0, seed_bytes = 0, dtab_bytes = 0,
@@ -59,7 +61,14 @@ struct DevCopy {
     } plan;
     ~DevCopy()
     {
-        if (plan.bailed) (void)hipHostFree(plan.bailed);
+        if (plan.bailed) { // (a launch's 8-byte copy into it may still be in flight: plan_after_launch never waits for it)
+            int prev = -1;
+            (void)hipGetDevice(&prev);
+            if (arena.dev >= 0 && arena.dev != prev) (void)hipSetDevice(arena.dev);
+            (void)hipDeviceSynchronize();
+            if (arena.dev >= 0 && arena.dev != prev && prev >= 0) (void)hipSetDevice(prev);
+            (void)hipHostFree(plan.bailed);
+        }
         if (arena_borrowed) {
             arena.p = nullptr;
             arena.cap = 0;
@@ -112,6 +121,8 @@ extern std::atomic<int> g_depth_table_anchors;    // ... with anchors: -1 by mar
 extern std::atomic<int> g_depth_table;            // depth table of new device copies: 0 = by index size, < 0 none, else its order
 extern std::atomic<int> g_seed_table_depth;       // tests: bases per seed-table entry of new device copies (0 = by index size)
 extern std::atomic<bool> g_plan_enabled;          // device copies carry a path cover and MS-only batches take the plan-guided walk
+extern std::atomic<uint64_t> g_plan_table_budget; // bytes a copy's tables may take (0 = half of the free device memory)
+extern std::atomic<int64_t> g_plan_lazy_bases;    // bases through a copy before it builds its plan structures (-1 = by index size)
 
 // ---- device_index.cpp
 int current_device();
@@ -125,8 +136,10 @@ inline std::vector<kbo_index *> shards_of(kbo_index *idx)
 }
 // throws KBO_E_UNSUPPORTED for a sharded handle: `what` needs the rows of ONE index
 void require_unsharded(const kbo_index *idx, const char *what);
-// uploads the index on first use; *plan (optional) receives the copy's plan hold-off state
-kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **plan = nullptr);
+// uploads the index on first use; *plan (optional) receives the copy's plan hold-off state.  work_bases: the bases of the batch
+// that asks (a copy makes its plan structures - cover, tables - once the bases it has seen pay for them); prepare: make them now
+kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **plan = nullptr, uint64_t work_bases = 0,
+                              bool prepare = false);
 int walk_max_waves();                                     // upper bound on resident walk waves: CUs x waves per CU
 // points a.gitems / a.glist into `plan_work` (>= kbo::plan_work_bytes(n_items) bytes, 16-byte aligned) when the index
 // view carries a path cover and the launch wants MS values only; otherwise leaves them null (plain walk)
@@ -211,13 +224,23 @@ struct CallSink {
     uint32_t cap_per_list;
     uint32_t threshold;
 };
+// what the caller wants behind the walk (kbo::matches / map): when the slab is a batch of reads over a copy with a depth table,
+// enqueue_walk_host runs map_reads_kernel (map_kernels.hip) - characters straight into d_chars, no MS values in memory - and
+// sets `done`; otherwise it leaves the MS values in B.ms as ever and the caller runs A5 / A6
+struct FusedMap {
+    uint8_t *d_chars;   // >= total + 16 bytes
+    uint32_t threshold;
+    bool format;        // + format::relative_to_ref
+    bool done = false;
+};
 void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, bool want_ival,
                        BatchOnDevice &B, std::vector<kbo::WalkItem> &items_keep, hipStream_t stream,
                        uint32_t longest = 0 /* longest sequence if the caller knows it */,
                        hipStream_t copy_stream = nullptr /* uploads go here when given ... */,
                        hipEvent_t copied = nullptr /* ... and `stream` waits for this event */,
                        const CallSink *call = nullptr /* call mode: MS values + sites, no intervals */,
-                       const PackedIn *packed = nullptr /* the queries arrive 2-bit packed (concat is not read) */);
+                       const PackedIn *packed = nullptr /* the queries arrive 2-bit packed (concat is not read) */,
+                       FusedMap *map = nullptr /* kbo::matches / map: the one kernel where it applies */);
 void run_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, bool want_ival,
                    BatchOnDevice &B, hipStream_t stream);
 // A5+A6 over a batch whose offsets are known on the host

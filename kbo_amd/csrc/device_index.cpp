@@ -20,6 +20,8 @@ std::atomic<int> g_seed_table_depth{0};
 std::atomic<int> g_depth_table{0}; // depth table of device copies made from now on: 0 = by index size, < 0 = none, else its order
 std::atomic<int> g_depth_table_anchors{-1}; // ... with anchors: -1 = by the table's margin over log4(rows), 0 = no, 1 = yes
 std::atomic<bool> g_plan_stats{false};
+std::atomic<uint64_t> g_plan_table_budget{0}; // bytes a copy's seed + depth tables may take while they are built: 0 = half of what is free
+std::atomic<int64_t> g_plan_lazy_bases{-1};   // bases through a copy before it builds its plan structures: -1 = by index size, 0 = at once
 std::atomic<int> g_index_shards{0};
 
 int current_device()
@@ -49,7 +51,218 @@ void require_unsharded(const kbo_index *idx, const char *what)
                        "without intervals) are supported on it");
 }
 
-kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **plan)
+namespace {
+using clk = std::chrono::steady_clock;
+double since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
+
+// The plan structures of a copy (path cover, recovery lines, seed table(s), depth table, 2-bit text): everything that is sized
+// by log4(rows) or needs the host's pointer chase.  Called with idx->mu held and the copy's device current.
+void build_plan_structures(kbo_index *idx, DevCopy *dc)
+{
+    clk::time_point t0 = clk::now();
+    // (device builds run on a stream of their own, so that a first use inside the slab pipeline does not serialise against
+    // every blocking stream of the device: only this stream is waited for)
+    hipStream_t bs = nullptr;
+    HIP_OK(hipStreamCreateWithFlags(&bs, hipStreamNonBlocking));
+    struct StreamGuard {
+        hipStream_t s;
+        ~StreamGuard() { (void)hipStreamDestroy(s); }
+    } guard{bs};
+    if (!dc->plan.bailed) {
+        HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&dc->plan.bailed), 64, hipHostMallocDefault));
+        dc->plan.bailed[0] = dc->plan.bailed[1] = 0;
+    }
+    if (!idx->cover) { // (idx->mu is held)
+        idx->cover.reset(new kbo::PathCover());
+        kbo::make_path_cover(idx->host, *idx->cover);
+    }
+    dc->setup.cover_s = since(t0);
+    t0 = clk::now();
+    const kbo::PathCover &pc = *idx->cover;
+    static_assert(kbo::PathCover::kPad == kbo::kPlanPad, "text padding");
+    dc->pc_text.alloc(pc.text.size() + 16);
+    dc->pc_pos.alloc(pc.pos.size() * 4 + 16);
+    dc->pc_node.alloc(pc.node_at.size() * 4 + 16);
+    HIP_OK(hipMemcpy(dc->pc_text.p, pc.text.data(), pc.text.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dc->pc_pos.p, pc.pos.data(), pc.pos.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dc->pc_node.p, pc.node_at.data(), pc.node_at.size() * 4, hipMemcpyHostToDevice));
+    idx->plan_bytes = pc.text.size() + pc.pos.size() * 4 + pc.node_at.size() * 4;
+    dc->setup.cover_bytes = idx->plan_bytes;
+    dc->setup.upload_s += since(t0);
+    {
+        t0 = clk::now();
+        std::vector<uint8_t> lines;
+        kbo::make_recovery_lines(idx->host, lines);
+        dc->fat.alloc(lines.size() + 16);
+        HIP_OK(hipMemcpy(dc->fat.p, lines.data(), lines.size(), hipMemcpyHostToDevice));
+        dc->fat_null = (uint32_t)(lines.size() / 128 - 1);
+        idx->plan_bytes += lines.size();
+        dc->setup.lines_bytes = lines.size();
+        dc->setup.lines_s = since(t0);
+    }
+    // ---- the depth table (dtab_kernels.hip): for every string of `order` bases the longest suffix of it that is a suffix of a
+    // row.  order = log4(rows) + 3.2, rounded up (1.3 % of the stretches behind mismatches run deeper than log4(rows) + 4, 5 %
+    // deeper than + 3, 17 % deeper than + 2: those reads take the plain walk), at most 17 and k: 15 bases at C2 (4 GiB
+    // grouped), 17 at C3 / C4 (64 GiB grouped); none where 17 bases are less than log4(rows) + 1.9 (from 1.2 * 10^9 rows on: the
+    // guided walk over recovery lines stays).  Measured, A1: C2 15 / 16 bases 0.625 / 0.638 ms (guided walk 0.915); C3 per
+    // 10 M reads 17 grouped / 17 plain / 16 grouped / 16 plain 7.35 / 8.88 / 9.18 / 9.86 ms (guided walk 10.15).
+    const double lg = std::log2((double)std::max<uint64_t>(idx->host.n_sets, 4)) / 2.0;
+    int order = std::min<int>({(int)std::ceil(lg + 3.2), 17, (int)idx->host.k});
+    // (a margin of 1.9 .. 2.9 bases - a 1 Gbp index - pays with anchors only; below 3.75 bases the reads the table leaves to
+    // the plain walk are many enough for the anchors to pay - C4, margin 3.05: A1 per 100 M reads 76.7 -> 67.1 ms; C3, 3.7:
+    // 6.80 -> 6.55; C2, 3.9: 0.62 -> 0.66, slower - and only on indexes of 24 Mi rows and more)
+    if ((double)order < lg + 1.9 && order < (int)idx->host.k) order = 0;
+    const int set = g_depth_table.load();
+    if (set < 0) order = 0;
+    else if (set > 0) order = std::min<int>({set, 17, (int)idx->host.k});
+    if (const char *e = std::getenv("KBO_DEPTH_TABLE")) // experiments
+        order = std::max(0, std::min<int>({std::atoi(e), 17, (int)idx->host.k}));
+    // ---- what it may take: the budget of the copy's tables (kbo_set_plan_table_budget; 0 = half of what is free now - the
+    // batches need the rest).  The grouped layout (three consecutive bases share a 64-byte line: a third of the fills, four
+    // times the bytes) when it fits, else the plain one, else a table of fewer bases (while it still reaches log4(rows) + 1.9),
+    // else none: a copy never fails, and never holds more than it was allowed, because of its tables.  Forced orders alike.
+    static const int env_grp = std::getenv("KBO_DEPTH_TABLE_GROUPED") ? std::atoi(std::getenv("KBO_DEPTH_TABLE_GROUPED")) : -1; // experiments
+    bool grouped = order >= 4 && env_grp != 0;
+    const uint64_t cap = idx->host.n_sets + 16;
+    {
+        size_t free_b = 0, total_b = 0;
+        uint64_t budget = g_plan_table_budget.load();
+        if (budget == 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = free_b / 2;
+        const size_t tmp_bytes = kbo::dtab_tmp_bytes(cap);
+        auto need = [&](int o, bool grp) { // peak during the build: the plain table, the frontier, and the grouped copy
+            return (uint64_t)kbo::dtab_bytes((uint32_t)o, false) + tmp_bytes + (grp ? kbo::dtab_bytes((uint32_t)o, true) : 0) + (((uint64_t)12) << (2u * std::min(o, 14)));
+        };
+        while (order > 0 && budget != 0 && need(order, grouped) > budget) {
+            if (grouped) grouped = false;
+            else {
+                order--;
+                grouped = order >= 4 && env_grp != 0;
+                if ((double)order < lg + 1.9 && set <= 0) order = 0;
+            }
+        }
+    }
+    const bool thin_margin = order > 0 && (double)order < lg + 3.75 && order < (int)idx->host.k && idx->host.n_sets >= (24u << 20);
+    // ---- the seed table: the interval of every string of D bases, so that a seed starts D bases deep.  Without a depth
+    // table: 10 bases for indexes that can use them (8 MiB), 8 for small ones, none below k = 8; 12 bases / 128 MiB from 32 Mi
+    // rows, 13 / 512 MiB from 512 Mi rows (the extensions they save are line fills there), built on the host.  With one: as
+    // many bases as a seed must be deep before its row is trusted (log4(rows) + 3: 14 at C2), at most 14 (2 GiB) - a unique
+    // string of that many bases IS the seed - built on the device with the depth table.
+    uint32_t D = idx->host.k >= 10 && idx->host.n_sets >= (1u << 20) ? 10u : (idx->host.k >= 8 ? 8u : 0u);
+    if (D == 10 && idx->host.k >= 13 && idx->host.n_sets >= (512u << 20)) D = 13;
+    else if (D == 10 && idx->host.k >= 12 && idx->host.n_sets >= (32u << 20)) D = 12;
+    if (order > 0) D = std::min<uint32_t>({(uint32_t)std::lround(lg) + 3u, 14u, idx->host.k, (uint32_t)order});
+    if (const int forced = g_seed_table_depth.load()) D = std::min<uint32_t>({(uint32_t)forced, 14u, idx->host.k}); // tests
+    if (const char *e = std::getenv("KBO_PLAN_SEED_D")) // experiments
+        D = std::min<uint32_t>({(uint32_t)std::max(0, std::atoi(e)), 14u, idx->host.k});
+    const bool seed_on_device = order > 0 && D > 0 && (int)D <= order;
+    if (seed_on_device) {
+        dc->seed_tab.alloc(((size_t)8 << (2u * D)) + 64);
+        dc->seed_d = D;
+        idx->plan_bytes += (size_t)8 << (2u * D);
+    } else if (D) {
+        t0 = clk::now();
+        const kbo::HostNav nav(idx->host);
+        std::vector<uint32_t> cur{0u, (uint32_t)idx->host.n_sets}, nxt; // {l, r} pairs, level by level
+        for (uint32_t t = 0; t < D; t++) {
+            nxt.resize(cur.size() * 4);
+            for (size_t p = 0; p < cur.size() / 2; p++) {
+                const uint32_t l = cur[2 * p], r = cur[2 * p + 1];
+                for (int c = 0; c < 4; c++) {
+                    uint32_t l2 = 0, r2 = 0;
+                    if (l < r) {
+                        l2 = (uint32_t)(idx->host.C[c] + nav.rank(c, l));
+                        r2 = (uint32_t)(idx->host.C[c] + nav.rank(c, r));
+                    }
+                    nxt[2 * (4 * p + c)] = l2;
+                    nxt[2 * (4 * p + c) + 1] = r2;
+                }
+            }
+            cur.swap(nxt);
+        }
+        dc->seed_tab.alloc(cur.size() * 4);
+        HIP_OK(hipMemcpy(dc->seed_tab.p, cur.data(), cur.size() * 4, hipMemcpyHostToDevice));
+        dc->seed_d = D;
+        idx->plan_bytes += cur.size() * 4;
+        dc->setup.seed_s = since(t0);
+    }
+    if (order > 0) {
+        t0 = clk::now();
+        DevBuf tmp, plain;
+        plain.alloc(kbo::dtab_bytes((uint32_t)order, false) + 64);
+        tmp.alloc(kbo::dtab_tmp_bytes(cap));
+        kbo::DevIndexView bv{};
+        bv.arena = dc->arena.as<uint4>();
+        bv.n_blocks = (uint32_t)dc->n_blocks;
+        bv.n = (uint32_t)idx->host.n_sets;
+        bv.k = idx->host.k;
+        // anchors: the strings of `order` bases that are the suffix of one row only, with that row's place in the path cover -
+        // what a base deeper than the table knows is read off (dtab_kernels.hip)
+        const uint32_t abits = kbo::dtab_anchor_bits(idx->host.n_sets, (uint32_t)order);
+        static const int env_anchor = std::getenv("KBO_DEPTH_TABLE_ANCHORS") ? std::atoi(std::getenv("KBO_DEPTH_TABLE_ANCHORS")) : -1; // experiments
+        const int anch_set = env_anchor >= 0 ? env_anchor : g_depth_table_anchors.load();
+        const bool want_anchors = anch_set > 0 || (anch_set < 0 && thin_margin);
+        if (want_anchors && order < (int)idx->host.k) {
+            dc->anchor.alloc(((size_t)1 << abits) * 8 + 64);
+            dc->anchor_bits = abits;
+            bv.pc_pos = dc->pc_pos.as<uint32_t>();
+        }
+        HIP_OK(kbo::build_depth_table(bv, (uint32_t)order, plain.as<uint8_t>(), tmp.p, cap, bs,
+                                      dc->anchor_bits ? dc->anchor.as<uint64_t>() : nullptr, dc->anchor_bits,
+                                      seed_on_device ? dc->seed_tab.as<uint2>() : nullptr, seed_on_device ? dc->seed_d : 0u));
+        if (dc->anchor_bits) idx->plan_bytes += ((size_t)1 << abits) * 8;
+        if (grouped) {
+            tmp.release();
+            dc->dtab.alloc(kbo::dtab_bytes((uint32_t)order, true) + 64);
+            HIP_OK(kbo::regroup_depth_table(plain.as<uint8_t>(), (uint32_t)order, dc->dtab.as<uint8_t>(), bs));
+        } else {
+            std::swap(dc->dtab.p, plain.p);
+            std::swap(dc->dtab.cap, plain.cap);
+            std::swap(dc->dtab.dev, plain.dev);
+        }
+        dc->dtab_order = (uint32_t)order;
+        dc->dtab_grouped = grouped;
+        idx->plan_bytes += kbo::dtab_bytes((uint32_t)order, grouped);
+        HIP_OK(hipStreamSynchronize(bs));
+        dc->setup.dtab_s = since(t0);
+        dc->setup.dtab_bytes = kbo::dtab_bytes((uint32_t)order, grouped);
+        dc->setup.anchor_bytes = dc->anchor_bits ? ((uint64_t)1 << dc->anchor_bits) * 8 : 0;
+    }
+    dc->setup.seed_bytes = dc->seed_d ? (uint64_t)8 << (2u * dc->seed_d) : 0;
+    // what map_reads_kernel reads (map_kernels.hip): the text as 2-bit digits with its path-start marks (0.5 B per row) and the
+    // seed table as text positions (4 B per string of seed_d bases), both made on the device
+    if (dc->dtab_order >= 4 && dc->seed_d >= 4) {
+        t0 = clk::now();
+        const uint64_t units = kbo::pack_text_units(idx->host.n_sets);
+        dc->pc_tm.alloc(units * 8 + 64);
+        HIP_OK(kbo::launch_pack_text(dc->pc_text.as<uint8_t>(), pc.text.size(), dc->pc_tm.as<uint2>(), units, bs));
+        dc->seed_pos.alloc(((size_t)4 << (2u * dc->seed_d)) + 64);
+        HIP_OK(kbo::launch_seed_pos(dc->seed_tab.as<uint2>(), dc->pc_pos.as<uint32_t>(), dc->seed_pos.as<uint32_t>(), dc->seed_d, bs));
+        HIP_OK(hipStreamSynchronize(bs));
+        dc->setup.cover_bytes += units * 8;
+        dc->setup.seed_bytes += (uint64_t)4 << (2u * dc->seed_d);
+        idx->plan_bytes += units * 8 + ((size_t)4 << (2u * dc->seed_d));
+        dc->setup.seed_s += since(t0);
+    }
+    dc->plan_built = true;
+}
+
+// bases a copy must have seen - or be about to see - before its plan structures pay for themselves: making them costs the
+// host's pointer chase over the rows (unless the handle carries a cover already) and the device builds, about 50 ns + 15 ns per
+// row on the GPU box (0.08 + 0.02 s at 5 * 10^6 rows, 8.3 + 3.5 s at 2.5 * 10^8), and with them a base costs about 7 ps less
+// (plain walk ~ 100 Gbp/s, the one kernel ~ 320; tools/bench_setup.py has the table).  Indexes whose structures take under
+// a tenth of a second get them at once.
+uint64_t plan_break_even_bases(const kbo_index *idx)
+{
+    const int64_t set = g_plan_lazy_bases.load();
+    if (set >= 0) return (uint64_t)set;
+    const double rows = (double)idx->host.n_sets;
+    const double setup_s = rows * ((idx->cover ? 0.0 : 50e-9) + 15e-9);
+    if (setup_s < 0.1) return 0;
+    return (uint64_t)(setup_s / 7e-12);
+}
+} // namespace
+
+kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **plan, uint64_t work_bases, bool prepare)
 {
     require_unsharded(idx, "this operation");
     std::lock_guard<std::mutex> g(idx->mu);
@@ -62,8 +275,6 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
         const size_t est_rank = (idx->host.n_sets / 96 + 2) * 64, est_ent = (idx->host.n_sets + 2) * 12;
         const bool want_pairs = idx->host.n_sets >= g_pair_min_rows && !g_force_big &&
                                 est_rank * 5 + est_ent + 64 < 0xFFFFFFF0ull;
-        using clk = std::chrono::steady_clock;
-        auto since = [](clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); };
         clk::time_point t0 = clk::now();
         kbo::DeviceLayout lay;
         kbo::make_device_layout(idx->host, lay, want_pairs);
@@ -115,190 +326,6 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
             dc->setup.entry_bytes = ent_bytes;
             dc->setup.pair_bytes = pair_bytes;
             dc->setup.upload_s = since(t0);
-            if (g_plan_enabled && !idx->transient) { // path cover for the plan-guided walk: 9 bytes per row
-                HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&dc->plan.bailed), 64, hipHostMallocDefault));
-                dc->plan.bailed[0] = dc->plan.bailed[1] = 0;
-                t0 = clk::now();
-                if (!idx->cover) { // (idx->mu is held)
-                    idx->cover.reset(new kbo::PathCover());
-                    kbo::make_path_cover(idx->host, *idx->cover);
-                }
-                dc->setup.cover_s = since(t0);
-                t0 = clk::now();
-                const kbo::PathCover &pc = *idx->cover;
-                static_assert(kbo::PathCover::kPad == kbo::kPlanPad, "text padding");
-                dc->pc_text.alloc(pc.text.size() + 16);
-                dc->pc_pos.alloc(pc.pos.size() * 4 + 16);
-                dc->pc_node.alloc(pc.node_at.size() * 4 + 16);
-                HIP_OK(hipMemcpy(dc->pc_text.p, pc.text.data(), pc.text.size(), hipMemcpyHostToDevice));
-                HIP_OK(hipMemcpy(dc->pc_pos.p, pc.pos.data(), pc.pos.size() * 4, hipMemcpyHostToDevice));
-                HIP_OK(hipMemcpy(dc->pc_node.p, pc.node_at.data(), pc.node_at.size() * 4, hipMemcpyHostToDevice));
-                idx->plan_bytes = pc.text.size() + pc.pos.size() * 4 + pc.node_at.size() * 4;
-                dc->setup.cover_bytes = idx->plan_bytes;
-                dc->setup.upload_s += since(t0);
-                {
-                    t0 = clk::now();
-                    std::vector<uint8_t> lines;
-                    kbo::make_recovery_lines(idx->host, lines);
-                    dc->fat.alloc(lines.size() + 16);
-                    HIP_OK(hipMemcpy(dc->fat.p, lines.data(), lines.size(), hipMemcpyHostToDevice));
-                    dc->fat_null = (uint32_t)(lines.size() / 128 - 1);
-                    idx->plan_bytes += lines.size();
-                    dc->setup.lines_bytes = lines.size();
-                    dc->setup.lines_s = since(t0);
-                }
-                // (the depth table's order is decided here, ahead of the seed table: an index with a depth table gets its seed
-                // table from the same device build, as deep as a seed has to be)
-                const double lg = std::log2((double)std::max<uint64_t>(idx->host.n_sets, 4)) / 2.0;
-                int order = std::min<int>({(int)std::ceil(lg + 3.2), 17, (int)idx->host.k});
-                // (a margin of 1.9 .. 2.9 bases - a 1 Gbp index - pays with anchors only: 2 M reads, A1 2.83 ms with the guided
-                // walk, 3.17 with the table alone - a fifth of the reads flagged -, 2.67 with its anchors)
-                // ... and below 3.75 bases the reads the table leaves to the plain walk are many enough for the anchors to pay
-                // (C4, margin 3.05: A1 per 100 M reads 76.7 -> 67.1 ms; C3, 3.7: 6.80 -> 6.55; C2, 3.9: 0.62 -> 0.66, slower)
-                // (only on indexes of 24 Mi rows and more: smaller ones see batches whose redo pass is a few long chains)
-                const bool thin_margin = (double)order < lg + 3.75 && order < (int)idx->host.k && idx->host.n_sets >= (24u << 20);
-                if ((double)order < lg + 1.9 && order < (int)idx->host.k) order = 0;
-                const int set = g_depth_table.load();
-                if (set < 0) order = 0;
-                else if (set > 0) order = std::min<int>({set, 17, (int)idx->host.k});
-                if (const char *e = std::getenv("KBO_DEPTH_TABLE")) // experiments
-                    order = std::max(0, std::min<int>({std::atoi(e), 17, (int)idx->host.k}));
-                // seed table: the interval of every string of D bases, so that a seed starts D bases deep.  D = 10 for
-                // indexes that can use it (8 MiB), 8 for small ones, none below k = 8.
-                // (deeper tables for large indexes - 12 bases / 128 MiB from 32 Mi rows, 13 / 512 MiB from 512 Mi rows: the
-                // extensions they save are line fills there; 100 Mbp index, A1 per 3 M reads: 3.60 / 3.52 / 3.46 ms with 10 /
-                // 12 / 13 bases.  On a 5 Mbp index 11 - 13 bases change nothing.)
-                uint32_t D = idx->host.k >= 10 && idx->host.n_sets >= (1u << 20) ? 10u : (idx->host.k >= 8 ? 8u : 0u);
-                if (D == 10 && idx->host.k >= 13 && idx->host.n_sets >= (512u << 20)) D = 13;
-                else if (D == 10 && idx->host.k >= 12 && idx->host.n_sets >= (32u << 20)) D = 12;
-                // With a depth table: as many bases as a seed must be deep before its row is trusted (plan_kernel's dmin =
-                // log4(rows) + 3: 14 at C2), at most 14 (2 GiB) - a unique string of that many bases IS the seed, no
-                // extension follows (C2, A1 with 10 / 11 / 12 / 13 / 14 bases: 0.688 / 0.681 / 0.662 / 0.643 / 0.625 ms; seed
-                // extensions per read 4.35 / 3.2 / 2.1 / 1.0 / 0.02) - and built on the device with the depth table.
-                if (order > 0) D = std::min<uint32_t>({(uint32_t)std::lround(lg) + 3u, 14u, idx->host.k, (uint32_t)order});
-                if (const int forced = g_seed_table_depth.load()) D = std::min<uint32_t>({(uint32_t)forced, 14u, idx->host.k}); // tests
-                if (const char *e = std::getenv("KBO_PLAN_SEED_D")) // experiments
-                    D = std::min<uint32_t>({(uint32_t)std::max(0, std::atoi(e)), 14u, idx->host.k});
-                const bool seed_on_device = order > 0 && D > 0 && (int)D <= order;
-                if (seed_on_device) {
-                    dc->seed_tab.alloc(((size_t)8 << (2u * D)) + 64);
-                    dc->seed_d = D;
-                    idx->plan_bytes += (size_t)8 << (2u * D);
-                } else if (D) {
-                    t0 = clk::now();
-                    const kbo::HostNav nav(idx->host);
-                    std::vector<uint32_t> cur{0u, (uint32_t)idx->host.n_sets}, nxt; // {l, r} pairs, level by level
-                    for (uint32_t t = 0; t < D; t++) {
-                        nxt.resize(cur.size() * 4);
-                        for (size_t p = 0; p < cur.size() / 2; p++) {
-                            const uint32_t l = cur[2 * p], r = cur[2 * p + 1];
-                            for (int c = 0; c < 4; c++) {
-                                uint32_t l2 = 0, r2 = 0;
-                                if (l < r) {
-                                    l2 = (uint32_t)(idx->host.C[c] + nav.rank(c, l));
-                                    r2 = (uint32_t)(idx->host.C[c] + nav.rank(c, r));
-                                }
-                                nxt[2 * (4 * p + c)] = l2;
-                                nxt[2 * (4 * p + c) + 1] = r2;
-                            }
-                        }
-                        cur.swap(nxt);
-                    }
-                    dc->seed_tab.alloc(cur.size() * 4);
-                    HIP_OK(hipMemcpy(dc->seed_tab.p, cur.data(), cur.size() * 4, hipMemcpyHostToDevice));
-                    dc->seed_d = D;
-                    idx->plan_bytes += cur.size() * 4;
-                    dc->setup.seed_s = since(t0);
-                }
-                // depth table (dtab_kernels.hip): for every string of `order` bases the longest suffix of it that is a suffix
-                // of a row.  One independent byte look-up then gives the MS value of a base wherever the value is at most
-                // `order` - i.e. in the stretches behind mismatches, where the match is a random one: about log4(rows) long.
-                // order = log4(rows) + 3.2, rounded up (1.3 % of such stretches run deeper than log4(rows) + 4, 5 % deeper than
-                // + 3, 17 % deeper than + 2: those reads take the plain walk), at most 17 and k: 15 bases at C2 (4 GiB
-                // grouped), 17 at C3 / C4 (64 GiB grouped, 16 GiB plain when that does not fit); none where 17 bases are less
-                // than log4(rows) + 1.9 (from 1.2 * 10^9 rows on: the guided walk over recovery lines stays).  Measured, A1:
-                // C2 15 / 16 bases 0.625 / 0.638 ms (guided walk 0.915); C3 per 10 M reads 17 grouped / 17 plain / 16 grouped
-                // / 16 plain 7.35 / 8.88 / 9.18 / 9.86 ms (guided walk 10.15); C4 17 bases 101.9 ms (guided walk 111.5).
-                {
-                    const uint64_t cap = idx->host.n_sets + 16;
-                    // the look-ups go to the grouped form (three consecutive bases share a line: a third of the fills, four
-                    // times the bytes) when the order allows it
-                    static const int env_grp = std::getenv("KBO_DEPTH_TABLE_GROUPED") ? std::atoi(std::getenv("KBO_DEPTH_TABLE_GROUPED")) : -1; // experiments
-                    bool grouped = order >= 4 && env_grp != 0;
-                    const size_t plain_bytes = kbo::dtab_bytes((uint32_t)std::max(order, 1), false) + 64, tmp_bytes = kbo::dtab_tmp_bytes(cap);
-                    size_t free_b = 0, total_b = 0;
-                    const bool have_info = order > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess;
-                    if (have_info && grouped && (double)(kbo::dtab_bytes((uint32_t)order, true) + plain_bytes + tmp_bytes) > 0.5 * (double)free_b)
-                        grouped = false; // (never more than half of what is free: the batches need the rest)
-                    if (have_info && set <= 0 && !grouped && (double)(plain_bytes + tmp_bytes) > 0.5 * (double)free_b) order = 0;
-                    if (order == 0 && seed_on_device) { // (no room for the table: no device build either - seeds start at the root)
-                        idx->plan_bytes -= (size_t)8 << (2u * dc->seed_d);
-                        dc->seed_tab.release();
-                        dc->seed_d = 0;
-                    }
-                    if (order > 0) {
-                        t0 = clk::now();
-                        DevBuf tmp, plain;
-                        plain.alloc(plain_bytes);
-                        tmp.alloc(tmp_bytes);
-                        kbo::DevIndexView bv{};
-                        bv.arena = dc->arena.as<uint4>();
-                        bv.n_blocks = (uint32_t)dc->n_blocks;
-                        bv.n = (uint32_t)idx->host.n_sets;
-                        bv.k = idx->host.k;
-                        // anchors: the strings of `order` bases that are the suffix of one row only, with that row's place in
-                        // the path cover - what a base deeper than the table knows is read off (dtab_kernels.hip)
-                        const uint32_t abits = kbo::dtab_anchor_bits(idx->host.n_sets, (uint32_t)order);
-                        // (a tenth of the flagged reads - and every wave with an anchored lane waits for two more dependent loads:
-                        // slower wherever it was measured)
-                        static const int env_anchor = std::getenv("KBO_DEPTH_TABLE_ANCHORS") ? std::atoi(std::getenv("KBO_DEPTH_TABLE_ANCHORS")) : -1; // experiments
-                        const int anch_set = env_anchor >= 0 ? env_anchor : g_depth_table_anchors.load();
-                        // (off unless asked for - C2 0.662 / 0.622 ms with / without, C3 6.55 / 6.80 - or the margin is thin)
-                        const bool want_anchors = anch_set > 0 || (anch_set < 0 && thin_margin);
-                        if (want_anchors && order < (int)idx->host.k) {
-                            dc->anchor.alloc(((size_t)1 << abits) * 8 + 64);
-                            dc->anchor_bits = abits;
-                            bv.pc_pos = dc->pc_pos.as<uint32_t>();
-                        }
-                        HIP_OK(kbo::build_depth_table(bv, (uint32_t)order, plain.as<uint8_t>(), tmp.p, cap, nullptr,
-                                                      dc->anchor_bits ? dc->anchor.as<uint64_t>() : nullptr, dc->anchor_bits,
-                                                      seed_on_device ? dc->seed_tab.as<uint2>() : nullptr, seed_on_device ? dc->seed_d : 0u));
-                        if (dc->anchor_bits) idx->plan_bytes += ((size_t)1 << abits) * 8;
-                        if (grouped) {
-                            tmp.release();
-                            dc->dtab.alloc(kbo::dtab_bytes((uint32_t)order, true) + 64);
-                            HIP_OK(kbo::regroup_depth_table(plain.as<uint8_t>(), (uint32_t)order, dc->dtab.as<uint8_t>(), nullptr));
-                        } else {
-                            std::swap(dc->dtab.p, plain.p);
-                            std::swap(dc->dtab.cap, plain.cap);
-                            std::swap(dc->dtab.dev, plain.dev);
-                        }
-                        dc->dtab_order = (uint32_t)order;
-                        dc->dtab_grouped = grouped;
-                        idx->plan_bytes += kbo::dtab_bytes((uint32_t)order, grouped);
-                        HIP_OK(hipDeviceSynchronize());
-                        dc->setup.dtab_s = since(t0);
-                        dc->setup.dtab_bytes = kbo::dtab_bytes((uint32_t)order, grouped);
-                        dc->setup.anchor_bytes = dc->anchor_bits ? ((uint64_t)1 << dc->anchor_bits) * 8 : 0;
-                    }
-                    dc->setup.seed_bytes = dc->seed_d ? (uint64_t)8 << (2u * dc->seed_d) : 0;
-                    // what map_reads_kernel reads (map_kernels.hip): the text as 2-bit digits with its path-start marks (0.5 B per
-                    // row) and the seed table as text positions (4 B per string of seed_d bases), both made on the device
-                    if (dc->dtab_order >= 4 && dc->seed_d >= 4) {
-                        t0 = clk::now();
-                        const uint64_t units = kbo::pack_text_units(idx->host.n_sets);
-                        dc->pc_tm.alloc(units * 8 + 64);
-                        HIP_OK(kbo::launch_pack_text(dc->pc_text.as<uint8_t>(), pc.text.size(), dc->pc_tm.as<uint2>(), units, nullptr));
-                        dc->seed_pos.alloc(((size_t)4 << (2u * dc->seed_d)) + 64);
-                        HIP_OK(kbo::launch_seed_pos(dc->seed_tab.as<uint2>(), dc->pc_pos.as<uint32_t>(), dc->seed_pos.as<uint32_t>(), dc->seed_d, nullptr));
-                        HIP_OK(hipDeviceSynchronize());
-                        dc->setup.cover_bytes += units * 8;
-                        dc->setup.seed_bytes += (uint64_t)4 << (2u * dc->seed_d);
-                        idx->plan_bytes += units * 8 + ((size_t)4 << (2u * dc->seed_d));
-                        dc->setup.seed_s += since(t0);
-                    }
-                }
-            }
         } catch (...) {
             delete dc;
             if (prev != device) (void)hipSetDevice(prev);
@@ -308,6 +335,22 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
         it = idx->dev.emplace(device, dc).first;
     }
     DevCopy *dc = it->second;
+    // ---- the plan structures: at once when asked for (kbo_index_to_device) or cheap, else once the copy has seen the bases that
+    // pay for them (plan_break_even_bases); a copy that may not hold them walks plainly, with the same results
+    if (!dc->plan_built && g_plan_enabled && !idx->transient) {
+        dc->bases_seen += work_bases;
+        if (prepare || dc->bases_seen >= plan_break_even_bases(idx)) {
+            int prev = current_device();
+            if (prev != device) HIP_OK(hipSetDevice(device));
+            try {
+                build_plan_structures(idx, dc);
+            } catch (...) {
+                if (prev != device) (void)hipSetDevice(prev);
+                throw;
+            }
+            if (prev != device) HIP_OK(hipSetDevice(prev));
+        }
+    }
     if (plan) *plan = &dc->plan;
     kbo::DevIndexView v;
     v.arena = dc->arena.as<uint4>();

@@ -102,7 +102,7 @@ struct PhaseClock {
 // `items_keep` must stay alive until the stream has been synchronised.
 void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                        bool want_ival, BatchOnDevice &B, std::vector<kbo::WalkItem> &items_keep, hipStream_t stream,
-                       uint32_t longest, hipStream_t copy_stream, hipEvent_t copied, const CallSink *call, const PackedIn *packed)
+                       uint32_t longest, hipStream_t copy_stream, hipEvent_t copied, const CallSink *call, const PackedIn *packed, FusedMap *map)
 {
     KBO_REQUIRE(idx->host.k <= 255, KBO_E_UNSUPPORTED, "k > 255");
     const int dev = current_device();
@@ -170,7 +170,7 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
     if (device_items) HIP_OK(kbo::launch_make_items(B.off.as<uint64_t>(), (uint32_t)n_seqs, B.items.as<kbo::WalkItem>(), stream));
     for (size_t sh = 0; sh < shards.size(); sh++) {
         DevCopy::PlanState *plan_state = nullptr;
-        const kbo::DevIndexView view = device_view(shards[sh], dev, &plan_state);
+        const kbo::DevIndexView view = device_view(shards[sh], dev, &plan_state, total);
         if (sh > 0) B.ms_shard.ensure(padded);
         kbo::WalkArgs a{};
         a.ix = view;
@@ -190,6 +190,21 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
         a.max_item_len = device_items ? longest_seq : (uint32_t)std::min<uint64_t>(chunk + (call ? 2ull * idx->host.k : idx->host.k), 0xFFFFFFFFu);
         if (view.pc_text && !want_ival) B.plan.ensure(kbo::plan_work_bytes(n_items, total));
         attach_plan(a, view.pc_text && !want_ival ? B.plan.p : nullptr, plan_state);
+        if (map && shards.size() == 1 && device_items && !call) { // kbo::matches / map over reads: the one kernel where it applies
+            a.chars_out = map->d_chars;
+            a.map_thr = map->threshold;
+            a.map_fmt = map->format ? 1u : 0u;
+            a.map_want_ms = 0;
+            if (a.gitems && kbo::map_reads_applies(a)) {
+                HIP_OK(kbo::launch_map_reads(a, stream));
+                HIP_OK(kbo::launch_redo_pass(a, stream));
+                HIP_OK(kbo::launch_derand_flagged(B.ms.as<uint8_t>(), B.off.as<uint64_t>(), (uint32_t)n_seqs, idx->host.k, map->threshold,
+                                                  map->format ? B.q.as<uint8_t>() : nullptr, map->d_chars, a.redo, longest_seq, stream));
+                plan_after_launch(a, stream, plan_state);
+                map->done = true;
+                return;
+            }
+        }
         HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), stream));
         plan_after_launch(a, stream, plan_state);
         // the depth against the union of the shards is the maximum of the depths against each (capi_internal.hpp)
@@ -561,8 +576,13 @@ private:
             src = S.in.as<uint8_t>();
         }
         lap("  offsets + copy in");
+        FusedMap fm{nullptr, job_.threshold, job_.format && !job_.sink};
+        if (!job_.ms_out) { // kbo::matches / map / find: the characters' buffer first, so that the one kernel can write into it
+            S.chars.ensure(((bytes + 15) / 16) * 16 + 32);
+            fm.d_chars = S.chars.as<uint8_t>();
+        }
         enqueue_walk_host(job_.idx, src, off, ns, job_.lo_out != nullptr, S.B, S.items, C.st_run, mx, C.st_up, S.copied, nullptr,
-                          job_.packed ? &pin : nullptr);
+                          job_.packed ? &pin : nullptr, job_.ms_out ? nullptr : &fm);
         if (job_.ms_out) { // A1 only: MS values (and intervals) straight back
             HIP_OK(hipEventRecord(S.computed, C.st_run));
             HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
@@ -587,9 +607,9 @@ private:
         } else if (job_.sink) {
             // characters stay on the device; run lengths are counted, scanned and (speculatively, into
             // the room the slot has) emitted right behind A5/A6; the completing thread downloads them
-            S.chars.ensure(((S.B.total + 15) / 16) * 16 + 32);
-            derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, job_.k, job_.threshold,
-                                          nullptr, S.chars.as<uint8_t>(), nullptr, C.st_run, mx, &S.dt_work);
+            if (!fm.done)
+                derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, job_.k, job_.threshold,
+                                              nullptr, S.chars.as<uint8_t>(), nullptr, C.st_run, mx, &S.dt_work);
             const uint32_t gap = (uint32_t)std::min<size_t>(job_.sink->max_gap_len, 0xFFFFFFFFu);
             S.rle_scratch.ensure(kbo::chunk_items_scratch_words((uint32_t)ns) * sizeof(uint32_t));
             S.rle_total.ensure(16);
@@ -619,10 +639,10 @@ private:
                 S.out.ensure(bytes + 32);
                 dst = S.out.as<uint8_t>();
             }
-            S.chars.ensure(((S.B.total + 15) / 16) * 16 + 16);
-            derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, job_.k, job_.threshold,
-                                          job_.format ? S.B.q.as<uint8_t>() : nullptr, S.chars.as<uint8_t>(), nullptr,
-                                          C.st_run, mx, &S.dt_work);
+            if (!fm.done)
+                derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, job_.k, job_.threshold,
+                                              job_.format ? S.B.q.as<uint8_t>() : nullptr, S.chars.as<uint8_t>(), nullptr,
+                                              C.st_run, mx, &S.dt_work);
             if (job_.packed_out) { // the characters leave as 2-bit words: a quarter of the bytes
                 const size_t nw = (size_t)(w1 - w0);
                 S.B.packed_out.ensure(nw * 4 + 16);

@@ -159,8 +159,9 @@ kbo_variant *pack_variants(const std::vector<kbo::Variant> &v)
     return out;
 }
 
-// format.rs:143-193, statement for statement (sequential, variable-length output: host)
-void run_lengths_gapped_impl(const uint8_t *aln, size_t len, size_t max_gap_len, std::vector<kbo_rle> &out)
+// format.rs:143-193, statement for statement (sequential, variable-length output: host).  Returns false where the reference
+// panics: an 'R' at position 0 that starts a run makes format.rs:175 evaluate aln[i - 1] with i = 0 (usize underflow).
+bool run_lengths_gapped_impl(const uint8_t *aln, size_t len, size_t max_gap_len, std::vector<kbo_rle> &out)
 {
     size_t i = 0;
     bool match_start = false;
@@ -184,9 +185,8 @@ void run_lengths_gapped_impl(const uint8_t *aln, size_t len, size_t max_gap_len,
                 rle.gap_bases += is_gap;
                 rle.mismatches += (!is_match && !is_gap);
                 rle.end = (is_match || !is_gap) ? i + 1 : rle.end;
-                // the reference indexes aln[i - 1] unguarded (format.rs:175) and would panic
-                // on an 'R' at position 0; guarded here
-                rle.jumps += (aln[i] == 'R' && i > 0 && aln[i - 1] == 'R');
+                if (aln[i] == 'R' && i == 0) return false; // (format.rs:175: aln[i - 1] with i = 0)
+                rle.jumps += (aln[i] == 'R' && aln[i - 1] == 'R');
                 within_gap_bases += (aln[i] == '-');
                 i += 1;
                 if (within_gap_bases > max_gap_len || (is_gap && i == len && rle.gap_opens > 0)) {
@@ -201,6 +201,7 @@ void run_lengths_gapped_impl(const uint8_t *aln, size_t len, size_t max_gap_len,
             i += 1;
         }
     }
+    return true;
 }
 
 kbo_rle *copy_rles(const std::vector<kbo_rle> &v)
@@ -282,7 +283,14 @@ void build_sharded(const uint8_t *const *seqs, const size_t *lens, size_t n_seqs
             q.keys_out = &keys.back();
             q.key_words_out = &key_words;
             std::unique_ptr<kbo_index> sh(new kbo_index());
-            kbo::build_host_index(seqs + first[g], lens + first[g], first[g + 1] - first[g], q, sh->host);
+            try {
+                kbo::build_host_index(seqs + first[g], lens + first[g], first[g + 1] - first[g], q, sh->host);
+            } catch (const std::runtime_error &e) { // (a shard that is itself too large: sequences are never cut)
+                throw KboError(KBO_E_UNSUPPORTED,
+                               std::string("sharded build: shard ") + std::to_string(out.shards.size()) + " (sequences " + std::to_string(first[g]) + " .. " +
+                               std::to_string(first[g + 1] - 1) + ", " + (st ? "reverse-complement" : "forward") + " strand) failed: " + e.what() +
+                               " - shards hold whole sequences, so one sequence with 2^32 or more distinct k-mers cannot be indexed");
+            }
             n_sets += sh->host.n_sets;
             out.shards.push_back(std::move(sh));
         }
@@ -463,7 +471,7 @@ int kbo_index_to_device(kbo_index_t *idx, int device)
 {
     return guarded([&] {
         KBO_REQUIRE(idx, KBO_E_BAD_ARG, "null index");
-        for (kbo_index *sh : shards_of(idx)) (void)device_view(sh, device < 0 ? current_device() : device);
+        for (kbo_index *sh : shards_of(idx)) (void)device_view(sh, device < 0 ? current_device() : device, nullptr, 0, true);
     });
 }
 
@@ -755,7 +763,8 @@ int kbo_run_lengths_gapped(const uint8_t *aln, size_t len, size_t max_gap_len, k
     return guarded([&] {
         KBO_REQUIRE((aln || len == 0) && out && n_out, KBO_E_BAD_ARG, "null argument");
         std::vector<kbo_rle> v;
-        run_lengths_gapped_impl(aln, len, max_gap_len, v);
+        KBO_REQUIRE(run_lengths_gapped_impl(aln, len, max_gap_len, v), KBO_E_REF_PANIC,
+                    "an 'R' at position 0: the reference indexes aln[i - 1] there (format.rs:175) and panics");
         *out = copy_rles(v);
         *n_out = v.size();
     });
@@ -1082,7 +1091,7 @@ int ms_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
         uint8_t *ms_shard = static_cast<uint8_t *>(d_work) + w.bytes; // (16-byte aligned: w.bytes is a multiple of 16)
         for (size_t sh = 0; sh < shards.size(); sh++) {
             DevCopy::PlanState *plan_state = nullptr;
-            const kbo::DevIndexView view = device_view(shards[sh], current_device(), &plan_state);
+            const kbo::DevIndexView view = device_view(shards[sh], current_device(), &plan_state, total_bases);
             kbo::WalkArgs a{};
             a.ix = view;
             a.q = d_concat;
@@ -1263,7 +1272,7 @@ int kbo_map_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
         if (w.chunked) return;
         KBO_REQUIRE(work_bytes >= w.bytes, KBO_E_BAD_ARG, "d_work is smaller than kbo_work_bytes() for this batch");
         DevCopy::PlanState *plan_state = nullptr;
-        const kbo::DevIndexView view = device_view(idx, current_device(), &plan_state);
+        const kbo::DevIndexView view = device_view(idx, current_device(), &plan_state, total_bases);
         kbo::WalkItem *items = static_cast<kbo::WalkItem *>(d_work);
         kbo::WalkArgs a{};
         a.ix = view;
@@ -1401,7 +1410,7 @@ int kbo_index_depth_table(kbo_index_t *idx, int device, int view, uint8_t *table
     return guarded([&] {
         KBO_REQUIRE(idx && n_bytes && order && view >= 0 && view < 3, KBO_E_BAD_ARG, "null argument / view not in 0..2");
         const int dev = device < 0 ? current_device() : device;
-        const kbo::DevIndexView v = device_view(idx, dev); // (no table while kbo_set_depth_table(-1) is in force)
+        const kbo::DevIndexView v = device_view(idx, dev, nullptr, 0, true); // (no table while kbo_set_depth_table(-1) is in force)
         const size_t need = v.dtab ? (size_t)1 << (2u * v.dtab_order) : 0;
         if (table && need) {
             KBO_REQUIRE(*n_bytes >= need, KBO_E_BAD_ARG, "buffer smaller than the table");
@@ -1485,6 +1494,18 @@ const kbo_index_t *kbo_index_shard(const kbo_index_t *idx, int i)
 int kbo_set_plan_stats(int on)
 {
     g_plan_stats = on != 0;
+    return KBO_OK;
+}
+
+int kbo_set_plan_table_budget(uint64_t bytes)
+{
+    g_plan_table_budget = bytes;
+    return KBO_OK;
+}
+
+int kbo_set_plan_lazy(int64_t bases)
+{
+    g_plan_lazy_bases = bases < 0 ? -1 : bases;
     return KBO_OK;
 }
 

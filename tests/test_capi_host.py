@@ -104,6 +104,12 @@ def test_format_golden(golden, oracle):  # format.rs:295-330
             assert got == oracle.run_lengths_gapped(aln, gap)
         ref = "".join(rng.choice(list("ACGT"), size=len(aln)))
         assert format.relative_to_ref(ref, aln) == oracle.relative_to_ref(ref, aln)
+    # an alignment that starts with 'R': format.rs:175 evaluates aln[i - 1] with i = 0 and panics; mirrored as KBO_E_REF_PANIC
+    for aln in ("RRM", "R", "RM-M"):
+        with pytest.raises(kbo_amd.KboError) as e:
+            format.run_lengths_gapped(aln, 0)
+        assert e.value.code == -11
+    assert [r.start for r in format.run_lengths_gapped("-RRM", 0)] == [1]  # (behind a gap it is an ordinary run)
     assert format.relative_to_ref("ACGTAC", "MRIXD-") == b"ACG---"
     assert format.relative_to_ref("ACGT", "MGNM") == b"AGNT"
 

@@ -166,6 +166,8 @@ def test_big_layout_at_50mbp(oracle, plan_restore):
     L.kbo_set_force_big_layout(1)
     g = synth.genome(50_000_000, seed=777)
     sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
+    sbwt.to_device(-1)  # (with its plan structures: a copy made by a first query would wait for the bases that pay for them)
+    assert sbwt.device_layout()["entries_64bit"] == 1 and sbwt.device_plan_bytes() > 0
     ora = _adopt(oracle, sbwt)
     concat, offsets = synth.reads(g, 300_000, 150, 0.02, seed=5)
     exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=_threads(), want_d=True)
@@ -204,6 +206,42 @@ def test_forced_seed_tables(oracle, plan_restore, depth):
         d, _, _ = batch.ms_batch(sbwt, concat, offsets)
         assert np.array_equal(d, exp_d), (depth, sub, junk)
         assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars), (depth, sub, junk)
+
+
+def test_plan_structures_wait_for_the_bases_that_pay_for_them(oracle, plan_restore):
+    """kbo's own call pattern is one map / find / call per index (lib.rs:553, 720-761): a copy made by a first query holds the
+    rank blocks and the contraction entries only - 63 MB for a 5 Mbp index, not 7.6 GB of cover and tables - and takes the plain
+    walk; kbo_index_to_device (or the bases that pay for them) adds the plan structures.  Same results either way."""
+    L = plan_restore
+    g = synth.genome(5_000_000)
+    sbwt, lcs = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    ref = bytes(g[1_000_000:1_010_000].tobytes())
+    got = kbo_amd.map(ref, sbwt, lcs, kbo_amd.MapOpts())              # one 10 kbp sequence on a fresh index
+    assert got == ora.map(ref, 31, 1e-7, True, True, True)
+    lay = sbwt.device_layout()
+    assert sbwt.device_plan_bytes() == 0 and lay["cover_bytes"] == 0 and lay["dtab_bytes"] == 0
+    assert lay["rank_bytes"] + lay["entry_bytes"] + lay["pair_bytes"] < 200 << 20
+    concat, offsets = synth.reads(g, 100_000, 150, 0.01)
+    exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=_threads(), want_d=True)
+    assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars)  # 15 Mbp: far from what 7.6 GB of tables cost
+    assert sbwt.device_plan_bytes() == 0
+    L.kbo_set_plan_lazy(20_000_000)                                     # a copy that has seen 20 Mbp makes them
+    assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars)
+    assert sbwt.device_plan_bytes() > 0 and sbwt.depth_table_order() == 15
+    assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp_chars)  # (now through the one kernel)
+    d, _, _ = batch.ms_batch(sbwt, concat, offsets)
+    assert np.array_equal(d, exp_d)
+    # a budget the grouped table does not fit: the plain layout; one that nothing fits: no table, the host-built seed table
+    for budget, want_order, want_grouped in ((6 << 30, 15, 0), (64 << 20, 0, 0)):
+        L.kbo_set_plan_table_budget(budget)
+        s2, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
+        s2.to_device(-1)
+        lay = s2.device_layout()
+        assert (lay["dtab_order"], lay["dtab_grouped"]) == (want_order, want_grouped) and lay["seed_depth"] in (14, 10)
+        assert lay["dtab_bytes"] + lay["seed_bytes"] <= max(budget, 16 << 20)
+        assert np.array_equal(batch.matches_batch(s2, concat, offsets), exp_chars)
+        del s2
 
 
 def test_hold_off_is_per_index(oracle, plan_restore):
