@@ -41,7 +41,7 @@ struct DevIndexView {
     const uint64_t *anchor;
     uint32_t anchor_bits;
     // what map_reads_kernel (map_kernels.hip) reads instead of the byte text and the interval table, nullptr when the copy has
-    // none: pc_tm[u] = { 2-bit digits of text positions [16 u - kPlanPad, + 16), first one most significant; 01 at every
+    // none: pc_tm[u] = { 2-bit digits of text positions [16 u - kMapPad, + 16), first one most significant; 01 at every
     // position that matches nothing (path start, padding) }; seed_pos[key of seed_d bases] = text position of the first row
     // whose k-mer ends with them, 0xFFFFFFFF when there is none
     const uint2 *pc_tm;
@@ -196,7 +196,9 @@ hipError_t launch_dtab_resolve(const WalkArgs &a, hipStream_t stream);
 // the 2-bit text with its path-start marks from the padded byte text (n_bytes = kPlanPad + n_sets + kPlanPad), n_units of
 // 16 positions; the text positions of the seed table's intervals
 hipError_t launch_pack_text(const uint8_t *d_text_padded, uint64_t n_bytes, uint2 *d_out, uint64_t n_units, hipStream_t stream);
-inline uint64_t pack_text_units(uint64_t n_sets) { return (n_sets + kPlanPad + 256u) / 16u + 2u; }
+// (a read's diagonal may start up to 160 bases in front of the text - it is seeded from its last bases too - and end 176 behind it)
+constexpr uint32_t kMapPad = 192;
+inline uint64_t pack_text_units(uint64_t n_sets) { return (n_sets + kMapPad + 256u) / 16u + 2u; }
 hipError_t launch_seed_pos(const uint2 *d_seed_tab, const uint32_t *d_pc_pos, uint32_t *d_out, uint32_t seed_d, hipStream_t stream);
 // true when the launch described by `a` (plan work attached, chars_out set) can take map_reads_kernel: reads of at most 160
 // bases, MS values / characters only, an index copy with a depth table, the 2-bit text and the position table

@@ -59,16 +59,19 @@ __device__ __forceinline__ uint32_t spread_marks(uint32_t x)
     return x;
 }
 
-// pc_tm[u] = { 2-bit digits of text positions [16 u - kPlanPad, 16 u - kPlanPad + 16), first one most significant;
-//              01 at every position that matches nothing: a path start, the padding, beyond the text }
+// pc_tm[u] = { 2-bit digits of text positions [16 u - kMapPad, 16 u - kMapPad + 16), first one most significant;
+//              01 at every position that matches nothing: a path start, the padding, in front of / beyond the text }
+// (text_padded holds positions -kPlanPad .. : kMapPad - kPlanPad is a multiple of 16)
 __global__ __launch_bounds__(256) void pack_text_kernel(const uint8_t *__restrict__ text_padded, uint64_t n_bytes, uint2 *__restrict__ out,
                                                         uint64_t n_units)
 {
+    static_assert(kMapPad >= kPlanPad && (kMapPad - kPlanPad) % 16u == 0, "padding of the 2-bit text");
     const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= n_units) return;
     uint4 v = make_uint4(0, 0, 0, 0);
-    const uint64_t b = 16ull * u;
-    if (b + 16u <= n_bytes) v = *reinterpret_cast<const uint4 *>(text_padded + b);
+    const uint64_t b = 16ull * u - (kMapPad - kPlanPad); // (wraps for the units in front of the byte text: they stay all marks)
+    if (16ull * u < kMapPad - kPlanPad) {
+    } else if (b + 16u <= n_bytes) v = *reinterpret_cast<const uint4 *>(text_padded + b);
     else if (b < n_bytes) {
         uint8_t tmp[16];
         for (uint32_t t = 0; t < 16; t++) tmp[t] = b + t < n_bytes ? text_padded[b + t] : (uint8_t)0;
@@ -218,40 +221,150 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
         }
     }
 
-    // ---- 2. compare with the text on the diagonal
-    uint32_t cnt = 0;
-    if (__ballot(seeded)) {
-        uint32_t mmw[kMapWords];
+    // ---- 2. compare with the text on the diagonal: mm[g] has bit 2 (15 - j) set where base 16 g + j differs from the text (or the
+    // text has a mark there: a path start, the padding)
+    auto compare = [&](uint32_t pd, uint32_t (&mm)[kMapWords]) -> uint32_t {
+        const uint32_t q0 = pd + kMapPad, r = q0 & 15u;
+        const uint8_t *tp = reinterpret_cast<const uint8_t *>(a.ix.pc_tm) + (size_t)(q0 >> 4) * 8u;
+        uint4 L[6];
 #pragma unroll
-        for (uint32_t g = 0; g < kMapWords; g++) mmw[g] = 0;
-        if (seeded) {
-            const uint32_t q0 = p0 + kPlanPad, r = q0 & 15u;
-            const uint8_t *tp = reinterpret_cast<const uint8_t *>(a.ix.pc_tm) + (size_t)(q0 >> 4) * 8u;
-            uint4 L[6];
+        for (int i = 0; i < 6; i++) __builtin_memcpy(&L[i], tp + 16 * i, 16);
+        uint32_t T[12], M[12];
 #pragma unroll
-            for (int i = 0; i < 6; i++) __builtin_memcpy(&L[i], tp + 16 * i, 16);
-            uint32_t T[12], M[12];
+        for (int i = 0; i < 6; i++) {
+            T[2 * i] = L[i].x;
+            M[2 * i] = L[i].y;
+            T[2 * i + 1] = L[i].z;
+            M[2 * i + 1] = L[i].w;
+        }
+        uint32_t c = 0;
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-                T[2 * i] = L[i].x;
-                M[2 * i] = L[i].y;
-                T[2 * i + 1] = L[i].z;
-                M[2 * i + 1] = L[i].w;
+        for (uint32_t g = 0; g < kMapWords; g++) {
+            mm[g] = 0;
+            if (16u * g < len) {
+                const uint32_t tw = (uint32_t)((((uint64_t)T[g] << 32) | T[g + 1]) >> (32u - 2u * r));
+                const uint32_t mk = (uint32_t)((((uint64_t)M[g] << 32) | M[g + 1]) >> (32u - 2u * r));
+                const uint32_t x = qw[g] ^ tw;
+                uint32_t m1 = (x | (x >> 1) | mk) & 0x55555555u;
+                const uint32_t nb = len - 16u * g;
+                if (nb < 16u) m1 &= ~0u << (32u - 2u * nb);
+                mm[g] = m1;
+                c += (uint32_t)__popc(m1);
             }
+        }
+        return c;
+    };
+    uint32_t cnt = 0;
+    uint32_t junction = 0xFFu; // DIRECT: index in the read's list of the entry that is no mismatch but the last base of its first diagonal
+    uint32_t mmw[kMapWords];
 #pragma unroll
-            for (uint32_t g = 0; g < kMapWords; g++) {
-                if (16u * g < len) {
-                    const uint32_t tw = (uint32_t)((((uint64_t)T[g] << 32) | T[g + 1]) >> (32u - 2u * r));
-                    const uint32_t mk = (uint32_t)((((uint64_t)M[g] << 32) | M[g + 1]) >> (32u - 2u * r));
-                    const uint32_t x = qw[g] ^ tw;
-                    uint32_t mm = (x | (x >> 1) | mk) & 0x55555555u;
-                    const uint32_t nb = len - 16u * g;
-                    if (nb < 16u) mm &= ~0u << (32u - 2u * nb);
-                    mmw[g] = mm;
-                    cnt += (uint32_t)__popc(mm);
+    for (uint32_t g = 0; g < kMapWords; g++) mmw[g] = 0;
+    if (__ballot(seeded)) {
+        if (seeded) cnt = compare(p0, mmw);
+    }
+    // ---- 2b. (DIRECT) a SECOND diagonal for a read that leaves its first - an insertion or a deletion, a chimera, or a first seed
+    // that sat on a substitution and matched elsewhere (3 reads in 1000; all their bases mismatch from there on) -, and for a read
+    // whose first bases gave no seed: seeded from its LAST bases backwards; the read is cut where the two diagonals together
+    // mismatch least - [0, g) on the first, [g, len) on the second.  The cut is a break like a mismatch (nothing deeper than the
+    // threshold may run through it: the table proves that too), except that its base g - 1 keeps the value of the first
+    // diagonal: list entry `junction`.  Whatever is chosen here only decides how many reads take the plain walk.
+    if (DIRECT) {
+        const bool need2 = plannable && !has_invalid && len >= 2u * D && (!seeded || cnt > a.plan_list + 1u);
+        if (__ballot(need2)) {
+            uint32_t pB = 0, eb = len - 1u;
+            bool seedB = false;
+            const uint32_t lowest = len > cap ? len - cap : 0u;
+            for (;;) {
+                const bool act = need2 && !seedB && eb + 1u >= D + lowest && eb + 1u >= D;
+                if (__ballot(act) == 0) break;
+                if (act) {
+                    const uint32_t key = (uint32_t)ending_at(soff + eb) & dmask;
+                    const uint32_t tp = a.ix.seed_pos[key];
+                    st_lookups++;
+                    if (tp != 0xFFFFFFFFu) {
+                        seedB = true;
+                        pB = tp - eb;
+                    } else eb -= min(eb, (D + 1u) / 2u);
+                }
+            }
+            const bool two = seedB && (!seeded || pB != p0);
+            if (__ballot(two)) {
+                uint32_t mmB[kMapWords];
+#pragma unroll
+                for (uint32_t g = 0; g < kMapWords; g++) mmB[g] = 0;
+                uint32_t cB = 0;
+                if (two) cB = compare(pB, mmB);
+                if (two && !seeded) { // no first diagonal: the whole read on the second
+#pragma unroll
+                    for (uint32_t g = 0; g < kMapWords; g++) mmw[g] = mmB[g];
+                    cnt = cB;
+                    p0 = pB;
+                    seeded = true;
+                } else if (two) {
+                    // the cut: first by words (mismatches of the first diagonal in front of word w + of the second from it on) ...
+                    uint32_t best_w = 0, best_c = cB, run = 0, suf = cB;
+#pragma unroll
+                    for (uint32_t w = 0; w < kMapWords; w++) {
+                        run += (uint32_t)__popc(mmw[w]);
+                        suf -= (uint32_t)__popc(mmB[w]);
+                        if (16u * (w + 1u) <= len + 15u && run + suf < best_c) {
+                            best_c = run + suf;
+                            best_w = w + 1u;
+                        }
+                    }
+                    // ... then base by base through the word in front of that boundary and the one behind it
+                    const uint32_t w0 = best_w > 0u ? best_w - 1u : 0u;
+                    uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = cB; // the two words of either mask, the cost of cutting at 16 w0
+#pragma unroll
+                    for (uint32_t w = 0; w < kMapWords; w++) {
+                        a0 = w == w0 ? mmw[w] : a0;
+                        a1 = w == w0 + 1u ? mmw[w] : a1;
+                        b0 = w == w0 ? mmB[w] : b0;
+                        b1 = w == w0 + 1u ? mmB[w] : b1;
+                        if (w < w0) c0 = c0 + (uint32_t)__popc(mmw[w]) - (uint32_t)__popc(mmB[w]);
+                    }
+                    uint32_t gcut = 16u * w0, cmin = c0, cc = c0;
+                    for (uint32_t x = 0; x < 32u; x++) { // cutting behind base 16 w0 + x instead of in front of it
+                        const uint32_t wa = x < 16u ? a0 : a1, wb = x < 16u ? b0 : b1, sh = 2u * (15u - (x & 15u));
+                        cc = cc + ((wa >> sh) & 1u) - ((wb >> sh) & 1u);
+                        if (16u * w0 + x + 1u <= len && cc < cmin) {
+                            cmin = cc;
+                            gcut = 16u * w0 + x + 1u;
+                        }
+                    }
+                    if (gcut == 0u) { // all of it on the second diagonal
+#pragma unroll
+                        for (uint32_t g = 0; g < kMapWords; g++) mmw[g] = mmB[g];
+                        cnt = cB;
+                        p0 = pB;
+                    } else if (gcut < len) {
+                        // bases [0, gcut) keep the first diagonal's marks, [gcut, len) get the second's; base gcut - 1 gets a mark as
+                        // the junction unless it mismatches already (a mismatch there is the same break)
+                        uint32_t jm = 0xFFu, before = 0;
+                        cnt = 0;
+#pragma unroll
+                        for (uint32_t g = 0; g < kMapWords; g++) {
+                            const uint32_t lo_b = 16u * g; // bases of this word: [lo_b, lo_b + 16)
+                            uint32_t keepA = gcut <= lo_b ? 0u : (gcut >= lo_b + 16u ? ~0u : ~0u << (32u - 2u * (gcut - lo_b)));
+                            uint32_t m1 = (mmw[g] & keepA) | (mmB[g] & ~keepA);
+                            if (gcut - 1u >= lo_b && gcut - 1u < lo_b + 16u) {
+                                const uint32_t bit = 0x40000000u >> (2u * (gcut - 1u - lo_b));
+                                if (!(m1 & bit)) {
+                                    jm = before + (uint32_t)__popc(m1 & ~(bit | (bit - 1u))); // entries in front of it
+                                    m1 |= bit;
+                                }
+                            }
+                            before += (uint32_t)__popc(m1);
+                            mmw[g] = m1;
+                            cnt += (uint32_t)__popc(m1);
+                        }
+                        junction = jm;
+                    }
                 }
             }
         }
+    }
+    if (__ballot(seeded)) {
         uint32_t filled = 0;
 #pragma unroll
         for (uint32_t g = 0; g < kMapWords; g++) {
@@ -316,7 +429,7 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
             }
             const uint32_t owner = work ? lo_l : lane;
             const uint32_t o_incl = __shfl(incl, (int)owner), o_n = __shfl(my_n, (int)owner), o_soff = __shfl(soff, (int)owner),
-                           o_len = __shfl(len, (int)owner), o_np = __shfl(no_plan ? 1u : 0u, (int)owner);
+                           o_len = __shfl(len, (int)owner), o_np = __shfl(no_plan ? 1u : 0u, (int)owner), o_junc = __shfl(junction, (int)owner);
             const bool blockmode = o_np != 0;
             if (DIRECT) {
                 if (work) {
@@ -334,8 +447,10 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
                             ee = min(order - 1u + u * cov, o_len - 1u);
                             use[i] = o_len >= order && (u == 0u || order - 1u + (u - 1u) * cov < o_len - 1u);
                         } else {
-                            ee = m + min(i * cov, order - 1u);
-                            use[i] = ee < o_len && ee + 1u >= order && (i == 0u || (i - 1u) * cov < order - 1u);
+                            // (the junction of two diagonals: the windows that hold both its bases, m and m + 1)
+                            const uint32_t jn = t == o_junc ? 1u : 0u;
+                            ee = m + jn + min(i * cov, order - 1u - jn);
+                            use[i] = ee < o_len && ee + 1u >= order && (i == 0u || (i - 1u) * cov < order - 1u - jn);
                         }
                         bytes[i] = 0;
                         if (use[i]) {
@@ -450,37 +565,49 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
             const bool act = live && seeded && q >= -1;
             if (__ballot(act) == 0) break;
             if (act) {
+                // break q: a mismatch at m (its own x is the segment's j = 0), or - the read's head (m = -1) and the junction of two
+                // diagonals (m = the last base of the first) - a break BEHIND base m: the segment starts at j = 1
                 const int m = q >= 0 ? (int)sp[q] : -1;
+                const int j0 = (q < 0 || (uint32_t)q == junction) ? 1 : 0;
                 const int L = e - m, jl = L - 1;
-                int d;
-                if (L > K) d = 0;
-                else if (at_end) d = jl > T ? 0 : -jl;
-                else {
-                    const int din = dn - L;
-                    d = (din <= -2 && jl > T) ? 0 : din;
-                }
-                const int xt = L > K ? K : jl + d; // x of the segment's last base (the left neighbour of e)
-                if (cand) at[e] = ((e <= 1 ? K : xt) > 0) ? cX : (uint8_t)'-';
-                cand = false;
-                if (d == 0) {
-                    if (q >= 0) { // x[m] = 0: 'X' when next == 1 and prev > 0 (translate.rs:204-210)
-                        const int next = L > 1 ? 1 : (at_end ? 0 : dn);
-                        if (next == 1) cand = true;
-                        else at[m] = (uint8_t)'-';
+                if (jl >= j0) { // (else an empty segment - a head in front of a mismatch at base 0, a junction right in front of the next break)
+                    int d;
+                    if (L > K) d = 0;
+                    else if (at_end) d = jl > T ? 0 : -jl;
+                    else {
+                        const int din = dn - L;
+                        d = (din <= -2 && jl > T) ? 0 : din;
                     }
-                } else {
-                    const int j0 = q >= 0 ? 0 : 1, j1 = min(-d, jl); // bases with x <= 0
-                    for (int j = j0; j <= j1; j++) at[m + j] = (uint8_t)'-';
-                    // the base with x = 0 whose successor (x = 1) is in the segment: an 'X' when it is one of the read's two
-                    // first bases, whose prev is k
-                    const int pz = m - d;
-                    if (-d + 1 <= jl && pz >= 0 && pz <= 1) at[pz] = cX;
+                    const int xt = L > K ? K : jl + d; // x of the segment's last base (the left neighbour of e)
+                    if (cand) at[e] = ((e <= 1 ? K : xt) > 0) ? cX : (uint8_t)'-';
+                    cand = false;
+                    // the junction to the right starts with x = 1 and this segment ends above the threshold: translate_ms_val's
+                    // ('R', 'R') (translate.rs:195-203; the second 'R' under translate_ms_vec's position rules, :282-288);
+                    // relative_to_ref keeps the read's bases for both
+                    if (!at_end && dn == 1 && xt > T && !a.map_fmt) {
+                        at[e - 1] = (uint8_t)'R';
+                        if (e >= 2 && e < (int)len - 1) at[e] = (uint8_t)'R';
+                    }
+                    if (-d == j0) { // the segment's first base has x = 0: 'X' when next == 1 and prev > 0 (translate.rs:204-210)
+                        const int next = -d + 1 <= jl ? 1 : (at_end ? 0 : dn);
+                        if (next == 1) cand = true;
+                        else at[m - d] = (uint8_t)'-';
+                    } else if (-d > j0) {
+                        const int j1 = min(-d, jl); // bases with x <= 0
+                        for (int j = j0; j <= j1; j++) at[m + j] = (uint8_t)'-';
+                        // the base with x = 0 whose successor has x = 1: an 'X' when it is one of the read's two first bases, whose
+                        // prev is k (elsewhere its prev is the x = -1 in front of it)
+                        const int pz = m - d;
+                        const int nz = -d + 1 <= jl ? 1 : (-d == jl ? (at_end ? 0 : dn) : 0);
+                        if (nz == 1 && pz >= 0 && pz <= 1) at[pz] = cX;
+                    }
+                    dn = d + j0; // x of the base the next segment to the left ends in front of
+                    e = m + j0;
+                    at_end = false;
                 }
-                dn = d;
-                e = m;
-                at_end = false;
             }
         }
+        if (cand) at[e] = cX; // (the read's first base: its prev is k)
         (void)K;
     } else if (plannable && !flag && len >= 3u) {
         const int K = (int)k, T = (int)a.map_thr;

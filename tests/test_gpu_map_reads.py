@@ -64,8 +64,9 @@ def _check(oracle, ora, sbwt, concat, offsets, p=1e-7, expect_fused=True):
             bad = np.flatnonzero(got != want)
             s = int(np.searchsorted(offsets, bad[0], side="right")) - 1
             a, b = int(offsets[s]), int(offsets[s + 1])
-            raise AssertionError("read %d (len %d) of %d: first bad base %d\n got  %s\n want %s\n read %s\n ms   %s" % (
-                s, b - a, len(offsets) - 1, int(bad[0]) - a, got[a:b].tobytes(), want[a:b].tobytes(), concat[a:b].tobytes(), list(exp_d[a:b])))
+            raise AssertionError("format %s, MS wanted %s: read %d (len %d) of %d: first bad base %d, %d bad bases in %d reads\n got  %s\n want %s\n read %s\n ms   %s" % (
+                fmt, want_ms, s, b - a, len(offsets) - 1, int(bad[0]) - a, len(bad), len(np.unique(np.searchsorted(offsets, bad, side="right"))),
+                got[a:b].tobytes(), want[a:b].tobytes(), concat[a:b].tobytes(), [int(v) for v in exp_d[a:b]]))
         if want_ms:
             assert np.array_equal(dev.ms[:dev.total].cpu().numpy(), exp_d)
         del dev
@@ -99,6 +100,9 @@ def test_read_shapes_and_contents(oracle, k):
         _mutate(rng, take(3000, 140, 160), sub=0.01, n_rate=0.2, lower=0.1),
         [other[a:a + 150] for a in rng.integers(0, len(other) - 150, 2000)],            # unrelated
         [comp[g[a:a + 150]][::-1].copy() for a in rng.integers(0, len(g) - 150, 2000)],  # the other strand
+        _mutate(rng, take(3000, 150, 150), sub=0.01, junk=70),           # no seed in the first 64 bases: seeded from the back
+        [np.concatenate([a[:int(c)], b[int(c):]]) for a, b, c in zip(take(3000, 150, 150), take(3000, 150, 150), rng.integers(20, 131, 3000))],  # chimeras
+        _mutate(rng, _mutate(rng, take(2000, 120, 154), indel=1.0), sub=0.01, indel=1.0),  # two insertions / deletions
         _mutate(rng, take(777, 128, 128), sub=0.01),                     # lengths that are multiples of 16 / 32
         _mutate(rng, take(63, 160, 160), sub=0.01),                      # less than one wave
     ]
