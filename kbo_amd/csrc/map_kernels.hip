@@ -271,11 +271,13 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
     if (DIRECT) {
         const bool need2 = plannable && !has_invalid && len >= 2u * D && (!seeded || cnt > a.plan_list + 1u);
         if (__ballot(need2)) {
-            uint32_t pB = 0, eb = len - 1u;
+            uint32_t pB = 0, eb = len - 1u, tries = 0;
             bool seedB = false;
             const uint32_t lowest = len > cap ? len - cap : 0u;
-            for (;;) {
-                const bool act = need2 && !seedB && eb + 1u >= D + lowest && eb + 1u >= D;
+            // (three windows: a read that follows a second diagonal to its end has a seed there unless substitutions sit in all of
+            // them; every further window is another dependent load for the whole wave - reads that match nothing pay them all)
+            for (;; tries++) {
+                const bool act = need2 && !seedB && tries < 3u && eb + 1u >= D + lowest && eb + 1u >= D;
                 if (__ballot(act) == 0) break;
                 if (act) {
                     const uint32_t key = (uint32_t)ending_at(soff + eb) & dmask;
