@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void seed_pos_kernel(const uint2 *__restrict__
     out[w] = iv.x < iv.y ? pc_pos[iv.x] : 0xFFFFFFFFu;
 }
 
+__device__ __forceinline__ bool thr_gt(uint32_t thr, uint32_t order) { return thr > order; } // (windows order .. thr apart exist)
 constexpr uint32_t kMapWords = 10;       // 16-base words per read: reads of up to 160 bases
 constexpr uint32_t kMapSlack = 48;       // bytes of the byte region behind the staged stretch
 
@@ -202,8 +203,28 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
     uint32_t qw[kMapWords];
 #pragma unroll
     for (uint32_t g = 0; g < kMapWords; g++) qw[g] = (plannable && 16u * g < len) ? from_base(soff + 16u * g) : 0u;
-    const uint32_t D = a.ix.seed_d;
+    // A seed is a window of the read whose text position a table knows: the D = log4(rows) + 3 <= 14 bases of seed_pos (any row that
+    // ends with them: good while such a string is rare in the index - 2 % of all strings at 5 * 10^6 rows - but at 2.5 * 10^8 rows
+    // a string of 14 bases occurs 0.9 times by chance and half of those seeds sat on another occurrence), or, where the copy has
+    // them, the ANCHORS of its depth table: the strings of `order` (16, 17) bases that are the suffix of exactly one row, hashed to
+    // that row's text position.  A wrong seed costs nothing but the second attempt: the compare step shows it.
+    const bool by_anchor = a.ix.anchor != nullptr && a.ix.dtab_order >= 12u;
+    const uint32_t D = by_anchor ? a.ix.dtab_order : a.ix.seed_d;
     const uint32_t dmask = D >= 16u ? 0xFFFFFFFFu : ((1u << (2u * D)) - 1u);
+    auto seed_at = [&](uint32_t e_) -> uint32_t { // text position of the base e_ of the read by the window that ends there, or ~0
+        const uint64_t win = ending_at(soff + e_);
+        if (!by_anchor) return a.ix.seed_pos[(uint32_t)win & dmask];
+        const uint64_t key = win & ((1ull << (2u * D)) - 1ull), amask = ((uint64_t)1 << a.ix.anchor_bits) - 1ull;
+        uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> (64u - a.ix.anchor_bits);
+        const uint32_t tag = (uint32_t)key + 1u;
+        for (uint32_t probe = 0; probe < 16u; probe++) {
+            const uint64_t slot = a.ix.anchor[h];
+            if (slot == 0) break;
+            if ((uint32_t)(slot >> 32) == tag) return (uint32_t)slot;
+            h = (h + 1u) & amask;
+        }
+        return 0xFFFFFFFFu;
+    };
     const uint32_t jmax = min(len, cap);
     uint32_t e = D - 1u, p0 = 0, st_lookups = 0;
     bool seeded = false;
@@ -211,8 +232,7 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
         const bool act = plannable && !has_invalid && !seeded && e < jmax;
         if (__ballot(act) == 0) break;
         if (act) {
-            const uint32_t key = (uint32_t)ending_at(soff + e) & dmask;
-            const uint32_t tp = a.ix.seed_pos[key];
+            const uint32_t tp = seed_at(e);
             st_lookups++;
             if (tp != 0xFFFFFFFFu) {
                 seeded = true;
@@ -280,8 +300,7 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
                 const bool act = need2 && !seedB && tries < 3u && eb + 1u >= D + lowest && eb + 1u >= D;
                 if (__ballot(act) == 0) break;
                 if (act) {
-                    const uint32_t key = (uint32_t)ending_at(soff + eb) & dmask;
-                    const uint32_t tp = a.ix.seed_pos[key];
+                    const uint32_t tp = seed_at(eb);
                     st_lookups++;
                     if (tp != 0xFFFFFFFFu) {
                         seedB = true;
@@ -401,8 +420,12 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
         const uint32_t order = a.ix.dtab_order;
         // DIRECT: cov = bases between two windows of the proof (header), n_e = windows per mismatch (<= 4: launch_map_reads);
         // a read without a seed: windows ending at order - 1, + cov, .. and at its last base, four per unit of work
-        const uint32_t thr = a.map_thr, cov = DIRECT ? thr - order + 2u : 1u;
-        const uint32_t n_blockwin = (DIRECT && len > thr) ? (len - order + cov - 1u) / cov + 1u : 0u;
+        // (with anchors - copies whose table has a thin margin over log4(rows): C3, C4 - the windows of a mismatch stand two bases
+        // closer, so that one of them may be present as long as its exact depth, read off the path-cover text, is at most
+        // order + 1: header)
+        const bool have_anch = DIRECT && a.ix.anchor != nullptr && thr_gt(a.map_thr, order);
+        const uint32_t thr = a.map_thr, covb = DIRECT ? thr - order + 2u : 1u, cov = have_anch ? thr - order : covb;
+        const uint32_t n_blockwin = (DIRECT && len > thr) ? (len - order + covb - 1u) / covb + 1u : 0u;
         const uint32_t my_n = !plannable || flag ? 0u : DIRECT ? (no_plan ? (n_blockwin + 3u) / 4u : (len > thr ? cnt : 0u))
                                                                : (no_plan ? (len + 15u) / 16u : cnt);
         uint32_t incl = my_n;
@@ -437,36 +460,53 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
                 if (work) {
                     const uint32_t t = w - (o_incl - o_n);
                     const uint32_t m = blockmode ? 0u : (uint32_t)spw[owner * 16u + t];
-                    uint32_t bytes[4];
-                    bool use[4];
+                    uint32_t bytes[4], ee[4];
+                    bool use[4], lastw[4];
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; i++) {
                         // the base the window ends at, and whether the window counts: inside the read, `order` bases long, and not the
                         // same window again (the last one of a mismatch is clamped to m + order - 1, of a read to its last base)
-                        uint32_t ee;
                         if (blockmode) {
                             const uint32_t u = 4u * t + i;
-                            ee = min(order - 1u + u * cov, o_len - 1u);
-                            use[i] = o_len >= order && (u == 0u || order - 1u + (u - 1u) * cov < o_len - 1u);
+                            ee[i] = min(order - 1u + u * covb, o_len - 1u);
+                            use[i] = o_len >= order && (u == 0u || order - 1u + (u - 1u) * covb < o_len - 1u);
+                            lastw[i] = true;
                         } else {
                             // (the junction of two diagonals: the windows that hold both its bases, m and m + 1)
                             const uint32_t jn = t == o_junc ? 1u : 0u;
-                            ee = m + jn + min(i * cov, order - 1u - jn);
-                            use[i] = ee < o_len && ee + 1u >= order && (i == 0u || (i - 1u) * cov < order - 1u - jn);
+                            ee[i] = m + jn + min(i * cov, order - 1u - jn);
+                            use[i] = ee[i] < o_len && ee[i] + 1u >= order && (i == 0u || (i - 1u) * cov < order - 1u - jn);
+                            lastw[i] = i * cov >= order - 1u - jn; // the window that starts at the break: nothing stands behind it
                         }
                         bytes[i] = 0;
                         if (use[i]) {
-                            const code_t key = (code_t)ending_at(o_soff + ee) & omask;
+                            const code_t key = (code_t)ending_at(o_soff + ee[i]) & omask;
                             bytes[i] = !a.ix.dtab_grouped ? a.ix.dtab[key]
-                                                          : a.ix.dtab[NP == 16 ? dtab_grouped_addr32((uint32_t)key, ee % 3u, order) : dtab_grouped_addr((uint64_t)key, ee % 3u, order)];
+                                                          : a.ix.dtab[NP == 16 ? dtab_grouped_addr32((uint32_t)key, ee[i] % 3u, order) : dtab_grouped_addr((uint64_t)key, ee[i] % 3u, order)];
                             st_look++;
                         }
                     }
-                    const uint32_t any = (bytes[0] | bytes[1] | bytes[2] | bytes[3]) & 0x80u;
-                    if (any) {
-                        spw[owner * 16u + 13u] = 1; // a window that is a suffix of a row: the proof fails, the read takes the plain walk
-                        st_anch++;
+                    bool fail = false;
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; i++) {
+                        if (use[i] && (bytes[i] & 0x80u)) { // the window is a suffix of a row
+                            if (!have_anch || lastw[i]) fail = true;
+                            else {
+                                // its exact depth off the path-cover text (dtab_anchor_depth: the window is the suffix of ONE row, whose
+                                // characters stand in the text in front of its position).  Strings through the break that end
+                                // between this window and the next start no further left than this depth says: with the next
+                                // window (or the read's end) g bases on, none is longer than depth + g - 1
+                                const uint32_t e_i = ee[i];
+                                const uint32_t V = dtab_anchor_depth(a.ix, e_i + 1u, [&](uint32_t tt) -> uint32_t {
+                                    return (0x54474341u >> (8u * base_at(o_soff + e_i - tt))) & 0xFFu;
+                                });
+                                const uint32_t nxt_e = (i + 1u < 4u && use[i + 1u < 4u ? i + 1u : i]) ? ee[i + 1u < 4u ? i + 1u : i] : o_len;
+                                st_anch++;
+                                if (V == kDtabUnknown || V + (nxt_e - e_i) - 1u > thr) fail = true;
+                            }
+                        }
                     }
+                    if (fail) spw[owner * 16u + 13u] = 1; // the proof fails: the read takes the plain walk
                 }
             } else if (work) {
                 const uint32_t t = w - (o_incl - o_n);
@@ -728,8 +768,9 @@ hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
     // are not asked for; else the MS bytes in LDS and the literal pass over them
     static const int env_direct = std::getenv("KBO_MAP_DIRECT") ? std::atoi(std::getenv("KBO_MAP_DIRECT")) : 1; // experiments
     // (and the proof takes at most four windows per mismatch: cov = t - order + 2 bases apart over order bases)
+    const uint32_t sp_w = (a.ix.anchor && a.map_thr > a.ix.dtab_order) ? a.map_thr - a.ix.dtab_order : a.map_thr - a.ix.dtab_order + 2u;
     const bool direct = env_direct != 0 && !a.map_want_ms && a.ix.dtab_order <= a.map_thr && a.map_thr < a.ix.k &&
-                        (a.ix.dtab_order - 1u + (a.map_thr - a.ix.dtab_order + 2u) - 1u) / (a.map_thr - a.ix.dtab_order + 2u) + 1u <= 4u;
+                        (a.ix.dtab_order - 1u + sp_w - 1u) / sp_w + 1u <= 4u;
     const dim3 grid((a.n_items + 63u) / 64u), block(64);
     if (a.ix.dtab_order <= 15u) {
         if (direct) hipLaunchKernelGGL((map_reads_kernel<16, true>), grid, block, lds, stream, a, stage_bytes, lin_words);

@@ -138,14 +138,19 @@ def test_many_paths_and_both_stretch_widths(oracle):
     reads = _mutate(rng, reads, sub=0.015)
     reads += [cat[a:a + 150] for a in rng.integers(0, len(cat) - 150, 1500)]  # reads across contig junctions
     concat, offsets = _batch_of(reads)
-    for order in (0, 16, 17, 9):
+    for order, anchors in ((0, 0), (16, 0), (17, 0), (9, 0), (9, 1), (10, 1), (12, 1)):
+        # (anchors on a table with a thin margin - what indexes of 24 Mi rows and more get: windows that are present are priced by
+        # their exact depth off the path-cover text instead of failing the read's proof)
         L.kbo_set_depth_table(order)
+        L.kbo_set_depth_table_anchors(anchors)
         sbwt, _ = kbo_amd.build(seqs, kbo_amd.BuildOpts(k=k, num_threads=threads()))
         sbwt.to_device(-1)
         if order:
             assert sbwt.depth_table_order() == order
+        assert (sbwt.device_layout()["anchor_bytes"] > 0) == bool(anchors)
         _check(oracle, ora, sbwt, concat, offsets)
     L.kbo_set_depth_table(0)
+    L.kbo_set_depth_table_anchors(-1)
 
 
 def test_c2_shape_the_one_kernel_every_read(oracle):
