@@ -758,7 +758,9 @@ hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
     a.plan_list = kPlanList;
     a.plan_cap = (uint32_t)g_plan_cap.load();
     static const int env_piece = std::getenv("KBO_REDO_PIECE") ? std::atoi(std::getenv("KBO_REDO_PIECE")) : 0; // experiments
-    a.redo_piece = env_piece >= 4 ? (uint32_t)env_piece : 32u;
+    // (pieces of 16 bases + k - 1 warm-up bases: the pass is as long as its longest chain, and the kernel leaves it under 2 % of the reads:
+    // 32 / 16 / 8 bases at C2 0.422 / 0.414 / 0.472 ms per step)
+    a.redo_piece = env_piece >= 4 ? (uint32_t)env_piece : 16u;
     hipError_t e = hipMemsetAsync(a.qctl, 0, 64 + kPlanStatSlots * kPlanStatWords * 4, stream);
     if (e != hipSuccess) return e;
     const uint32_t stage_bytes = (64u * a.max_item_len + 16u + kMapSlack + 15u) / 16u * 16u;

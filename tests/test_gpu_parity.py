@@ -467,6 +467,10 @@ def test_run_lengths_on_the_device_full_alphabet(oracle):
             assert got == oracle.run_lengths_gapped(short[s], 0), (longest, s, short[s][:80])
     # the single-sequence host implementation agrees too
     for s in range(0, len(alns), 97):
+        if alns[s][:1] == b"R":  # (the reference panics there, format.rs:175: mirrored as KBO_E_REF_PANIC by the single-sequence entry)
+            with pytest.raises(kbo_amd.KboError):
+                kformat.run_lengths_gapped(alns[s], 3)
+            continue
         assert [tuple(r.__dict__.values()) for r in kformat.run_lengths_gapped(alns[s], 3)] == oracle.run_lengths_gapped(alns[s], 3)
 
 

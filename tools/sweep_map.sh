@@ -1,2 +1,2 @@
-# experiments on map_reads_kernel (C2): characters through LDS or straight to memory, resident waves (LDS padding)
-for I in 1 0; do for P in 0 2000 4500 8000; do echo "INLDS=$I PAD=$P: $(CHECK=${CHECK:-0} KBO_MAP_INLDS=$I KBO_MAP_LDS_PAD=$P python tools/exp_map.py 2>&1 | tail -1)"; done; done
+# experiments on kbo_map_batch_dev at C2: anchors on the 15-base table (seeds + present windows), bases per piece of the redo pass
+for A in 0 1; do for PC in 32 16 8; do echo "ANCHORS=$A PIECE=$PC: $(CHECK=0 KBO_DEPTH_TABLE_ANCHORS=$A KBO_REDO_PIECE=$PC python tools/exp_map.py 2>&1 | tail -1)"; done; done
