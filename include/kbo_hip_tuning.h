@@ -120,6 +120,11 @@ int kbo_set_plan_stats(int on);
 int kbo_plan_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k, const void *d_work,
                        uint64_t out[KBO_PLAN_STATS], void *stream);
 
+/* inspection: which reads the last planned launch over a device-resident batch of READS (kbo_ms_batch_dev, kbo_map_batch_dev: one
+ * item per sequence) left to the plain walk - flags_out[s] != 0 - read out of the launch's work buffer.  Arguments as for that call;
+ * synchronises `stream`. */
+int kbo_plan_flags_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k, const void *d_work, uint8_t *flags_out, void *stream);
+
 /* instrumentation (default off): while on, every kbo_map_batch_dev call that takes the one-kernel route records HIP events on its
  * stream around map_reads_kernel and behind the redo pass (three event records per call).  kbo_stage_timing_read waits for the
  * recorded calls, returns their number and the sums of the two intervals in milliseconds - the kernel itself / the reads it left

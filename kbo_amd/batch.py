@@ -212,6 +212,13 @@ class DeviceBatch:
                  "tab_unresolved", "tab_anchored", "items_noplan")
         return {n: int(v) for n, v in zip(names, out)}
 
+    def plan_flags(self, stream=None):
+        """uint8[n_seqs]: which reads the last planned launch left to the plain walk (kbo_hip_tuning.h kbo_plan_flags_dev)"""
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        out = np.zeros(self.n_seqs, dtype=np.uint8)
+        check(lib().kbo_plan_flags_dev(self.n_seqs, self.total, self.max_len, self.k, self.work.data_ptr(), out.ctypes.data, s.cuda_stream))
+        return out
+
     def derand_translate(self, stream=None):
         s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
         if self.max_len == 0 or self.max_len > 480:  # long reads / contigs: scratch for the piece-wise kernel

@@ -1169,6 +1169,19 @@ int kbo_plan_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, 
     });
 }
 
+int kbo_plan_flags_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k, const void *d_work, uint8_t *flags_out, void *stream)
+{
+    return guarded([&] {
+        KBO_REQUIRE(d_work && flags_out && n_seqs > 0 && total_bases > 0, KBO_E_BAD_ARG, "null / empty argument");
+        const DevWork w = dev_work(n_seqs, total_bases, max_seq_len, k);
+        KBO_REQUIRE(!w.chunked, KBO_E_UNSUPPORTED, "one item per sequence only (reads)");
+        const kbo::PlanLayout L = kbo::plan_layout(w.n_slots, total_bases);
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        HIP_OK(hipMemcpyAsync(flags_out, static_cast<const uint8_t *>(d_work) + w.plan_off + L.redo, n_seqs, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+    });
+}
+
 size_t kbo_derand_work_bytes(size_t n_seqs, uint64_t total_bases)
 {
     return kbo::derand_piece_work_bytes((uint32_t)std::min<size_t>(n_seqs, 0xFFFFFFFEu), total_bases);

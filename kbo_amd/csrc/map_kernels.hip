@@ -276,6 +276,7 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
     };
     uint32_t cnt = 0;
     uint32_t junction = 0xFFu; // DIRECT: index in the read's list of the entry that is no mismatch but the last base of its first diagonal
+    uint32_t jov = 0;          // ... and the bases in front of the cut that lie on both diagonals
     uint32_t mmw[kMapWords];
 #pragma unroll
     for (uint32_t g = 0; g < kMapWords; g++) mmw[g] = 0;
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
                     for (uint32_t w = 0; w < kMapWords; w++) {
                         run += (uint32_t)__popc(mmw[w]);
                         suf -= (uint32_t)__popc(mmB[w]);
-                        if (16u * (w + 1u) <= len + 15u && run + suf < best_c) {
+                        if (16u * (w + 1u) <= len + 15u && run + suf <= best_c) { // (ties: the rightmost)
                             best_c = run + suf;
                             best_w = w + 1u;
                         }
@@ -348,11 +349,12 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
                     for (uint32_t x = 0; x < 32u; x++) { // cutting behind base 16 w0 + x instead of in front of it
                         const uint32_t wa = x < 16u ? a0 : a1, wb = x < 16u ? b0 : b1, sh = 2u * (15u - (x & 15u));
                         cc = cc + ((wa >> sh) & 1u) - ((wb >> sh) & 1u);
-                        if (16u * w0 + x + 1u <= len && cc < cmin) {
+                        if (16u * w0 + x + 1u <= len && cc <= cmin) { // (ties: the rightmost - the first diagonal as far as it matches)
                             cmin = cc;
                             gcut = 16u * w0 + x + 1u;
                         }
                     }
+                    if (cB <= cmin) gcut = 0u; // (the second diagonal alone is as good: no cut)
                     if (gcut == 0u) { // all of it on the second diagonal
 #pragma unroll
                         for (uint32_t g = 0; g < kMapWords; g++) mmw[g] = mmB[g];
@@ -362,11 +364,13 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
                         // bases [0, gcut) keep the first diagonal's marks, [gcut, len) get the second's; base gcut - 1 gets a mark as
                         // the junction unless it mismatches already (a mismatch there is the same break)
                         uint32_t jm = 0xFFu, before = 0;
+                        int32_t lastA = -1; // the first diagonal's last mismatch in front of the cut
                         cnt = 0;
 #pragma unroll
                         for (uint32_t g = 0; g < kMapWords; g++) {
                             const uint32_t lo_b = 16u * g; // bases of this word: [lo_b, lo_b + 16)
                             uint32_t keepA = gcut <= lo_b ? 0u : (gcut >= lo_b + 16u ? ~0u : ~0u << (32u - 2u * (gcut - lo_b)));
+                            if (mmw[g] & keepA) lastA = (int32_t)(lo_b + 15u - ((uint32_t)__builtin_ctz(mmw[g] & keepA) >> 1));
                             uint32_t m1 = (mmw[g] & keepA) | (mmB[g] & ~keepA);
                             if (gcut - 1u >= lo_b && gcut - 1u < lo_b + 16u) {
                                 const uint32_t bit = 0x40000000u >> (2u * (gcut - 1u - lo_b));
@@ -380,6 +384,31 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
                             cnt += (uint32_t)__popc(m1);
                         }
                         junction = jm;
+                        // the bases right in front of the cut that lie on the second diagonal as well (an insertion or deletion inside
+                        // a run of equal bases, a base that matches both by chance): its ramp starts that much earlier, and the
+                        // windows of its proof have to reach back to the base in front of them
+                        if (jm != 0xFFu) {
+                            const uint32_t E = gcut - 1u, W = E >> 4;
+                            uint32_t wlo = 0, whi = 0;
+#pragma unroll
+                            for (uint32_t g = 0; g < kMapWords; g++) {
+                                wlo = g == W ? mmB[g] : wlo;
+                                whi = g + 1u == W ? mmB[g] : whi;
+                            }
+                            const uint64_t V = ((((uint64_t)whi << 32) | wlo) >> (2u * (15u - (E & 15u)))) & 0x5555555555555555ull; // flag of base E - x at bit 2 x
+                            const uint32_t run0 = V ? (uint32_t)__builtin_ctzll(V) >> 1 : 17u;
+                            if (lastA >= 0 && run0 >= E - (uint32_t)lastA) {
+                                // every base between the first diagonal's last mismatch and the cut lies on the second diagonal as
+                                // well (the last inserted base, then a base or two that match both by chance): that mismatch is the
+                                // break, the second diagonal's stretch starts behind it - no entry of its own for the cut
+                                const uint32_t bit = 0x40000000u >> (2u * (E & 15u));
+#pragma unroll
+                                for (uint32_t g = 0; g < kMapWords; g++) mmw[g] = g == W ? mmw[g] & ~bit : mmw[g];
+                                cnt--;
+                                junction = 0xFFu;
+                            } else
+                                jov = min(min(run0, a.ix.dtab_order >= 3u ? a.ix.dtab_order - 3u : 0u), min(E - (uint32_t)(lastA + 1), gcut - 1u));
+                        }
                     }
                 }
             }
@@ -454,7 +483,7 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
             }
             const uint32_t owner = work ? lo_l : lane;
             const uint32_t o_incl = __shfl(incl, (int)owner), o_n = __shfl(my_n, (int)owner), o_soff = __shfl(soff, (int)owner),
-                           o_len = __shfl(len, (int)owner), o_np = __shfl(no_plan ? 1u : 0u, (int)owner), o_junc = __shfl(junction, (int)owner);
+                           o_len = __shfl(len, (int)owner), o_np = __shfl(no_plan ? 1u : 0u, (int)owner), o_junc = __shfl(junction, (int)owner), o_jov = __shfl(jov, (int)owner);
             const bool blockmode = o_np != 0;
             if (DIRECT) {
                 if (work) {
@@ -473,8 +502,9 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
                             lastw[i] = true;
                         } else {
                             // (the junction of two diagonals: the windows that hold both its bases, m and m + 1)
-                            const uint32_t jn = t == o_junc ? 1u : 0u;
-                            ee[i] = m + jn + min(i * cov, order - 1u - jn);
+                            // (and the bases in front of m that lie on the second diagonal too: the windows reach back over them)
+                            const uint32_t jn = t == o_junc ? 1u + o_jov : 0u, j1 = t == o_junc ? 1u : 0u;
+                            ee[i] = m + j1 + min(i * cov, order - 1u - jn);
                             use[i] = ee[i] < o_len && ee[i] + 1u >= order && (i == 0u || (i - 1u) * cov < order - 1u - jn);
                             lastw[i] = i * cov >= order - 1u - jn; // the window that starts at the break: nothing stands behind it
                         }
@@ -609,8 +639,9 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
             if (act) {
                 // break q: a mismatch at m (its own x is the segment's j = 0), or - the read's head (m = -1) and the junction of two
                 // diagonals (m = the last base of the first) - a break BEHIND base m: the segment starts at j = 1
-                const int m = q >= 0 ? (int)sp[q] : -1;
-                const int j0 = (q < 0 || (uint32_t)q == junction) ? 1 : 0;
+                const bool isj = q >= 0 && (uint32_t)q == junction;
+                const int m = q >= 0 ? (int)sp[q] - (isj ? (int)jov : 0) : -1;
+                const int j0 = (q < 0 ? 1 : 0) + (isj ? 1 + (int)jov : 0);
                 const int L = e - m, jl = L - 1;
                 if (jl >= j0) { // (else an empty segment - a head in front of a mismatch at base 0, a junction right in front of the next break)
                     int d;
@@ -626,7 +657,7 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
                     // the junction to the right starts with x = 1 and this segment ends above the threshold: translate_ms_val's
                     // ('R', 'R') (translate.rs:195-203; the second 'R' under translate_ms_vec's position rules, :282-288);
                     // relative_to_ref keeps the read's bases for both
-                    if (!at_end && dn == 1 && xt > T && !a.map_fmt) {
+                    if (!at_end && dn > 0 && dn < T && xt > T && !a.map_fmt) {
                         at[e - 1] = (uint8_t)'R';
                         if (e >= 2 && e < (int)len - 1) at[e] = (uint8_t)'R';
                     }

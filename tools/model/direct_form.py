@@ -34,13 +34,18 @@ def literal(a, k, t):
     return ''.join(res)
 
 
-def direct(n, breaks, junction, K, T):
-    """breaks: sorted positions; junction: index into breaks or None.  Mirrors the kernel's loop."""
+def direct(n, breaks, junction, K, T, ov=0):
+    """breaks: sorted positions; junction: index into breaks or None; ov: bases in front of the junction that lie on BOTH diagonals
+    (the second diagonal's ramp starts that much earlier).  Mirrors the kernel's loop."""
     at = ['M'] * n
     e, dn, at_end, cand = n, 0, True, False
+    e_junction = False
     for q in range(len(breaks) - 1, -2, -1):
         m = breaks[q] if q >= 0 else -1
         j0 = 1 if (q < 0 or q == junction) else 0
+        if q >= 0 and q == junction:
+            m -= ov
+            j0 += ov
         L = e - m
         jl = L - 1
         if jl < j0:  # an empty segment (a head in front of a mismatch at base 0, a junction right in front of the next break)
@@ -57,7 +62,7 @@ def direct(n, breaks, junction, K, T):
             at[e] = 'X' if (K if e <= 1 else xt) > 0 else '-'
         cand = False
         # the junction to the right starts with x = 1 (its d is 0) and this segment ends above the threshold: translate's 'R','R'
-        if not at_end and dn == 1 and xt > T:
+        if not at_end and 0 < dn < T and xt > T and e_junction:
             at[e - 1] = 'R'
             if 2 <= e < n - 1:
                 at[e] = 'R'
@@ -77,13 +82,14 @@ def direct(n, breaks, junction, K, T):
                     at[pz] = 'X'
         dn = d + j0
         e = m + j0
+        e_junction = q >= 0 and q == junction
         at_end = False
     if cand:
         at[e] = 'X'
     return ''.join(at)
 
 
-def make_a(n, breaks, junction, K, T, rng):
+def make_a(n, breaks, junction, K, T, rng, ov=0):
     """matching statistics consistent with the breaks: distance to the last break where that exceeds what runs through a break
     (any value <= T there), never more than possible (<= i + 1, rises by at most one)"""
     a = []
@@ -91,7 +97,7 @@ def make_a(n, breaks, junction, K, T, rng):
     bi = 0
     for i in range(n):
         while bi < len(breaks) and breaks[bi] + (1 if bi == junction else 0) <= i:
-            last = breaks[bi]
+            last = breaks[bi] - (ov if bi == junction else 0)  # (the second diagonal matched `ov` bases in front of the junction too)
             bi += 1
         j = i - last
         base = min(j, K)
@@ -100,7 +106,7 @@ def make_a(n, breaks, junction, K, T, rng):
             v = max(base, min(rng.randint(0, T), i + 1, K, (a[-1] + 1) if a else 1))
             if v > T:
                 v = base
-        if last >= 0 and j == 0 and not (junction is not None and breaks[junction] == last):
+        if last >= 0 and j == 0 and not (junction is not None and breaks[junction] - ov == last):
             v = min(rng.randint(0, T), i + 1, (a[-1] + 1) if a else 1)  # the mismatch itself: whatever runs through it
         a.append(v)
     return a
@@ -116,18 +122,20 @@ def main():
         n = rng.randint(3, 160)
         nb = rng.choice([0, 1, 1, 2, 2, 3, 5, 9])
         breaks = sorted(rng.sample(range(n), min(nb, n)))
-        junction = None
-        if breaks and rng.random() < 0.3:
+        junction, ov = None, 0
+        if breaks and rng.random() < 0.4:
             qj = rng.randrange(len(breaks))
             if breaks[qj] + 1 < n:
                 junction = qj
-        a = make_a(n, breaks, junction, K, T, rng)
+                prev = breaks[qj - 1] if qj > 0 else -1
+                ov = rng.randint(0, max(0, min(12, breaks[qj] - prev - 1)))  # the overlap lies behind the previous break
+        a = make_a(n, breaks, junction, K, T, rng, ov)
         want = literal(a, K, T)
-        got = direct(n, breaks, junction, K, T)
+        got = direct(n, breaks, junction, K, T, ov)
         if want != got:
             bad += 1
             if bad <= 8:
-                print("K", K, "T", T, "n", n, "breaks", breaks, "junction", junction)
+                print("K", K, "T", T, "n", n, "breaks", breaks, "junction", junction, "ov", ov)
                 print(" a   ", a)
                 print(" want", want)
                 print(" got ", got)
