@@ -4,7 +4,11 @@
 One "step" = one pass of the hot path - kbo::map with fill_gaps=false, call_variants=false (lib.rs:735-738, 756-757): MS ->
 derandomize -> translate -> relative_to_ref - over one batch of synthetic reads already resident in HBM, through
 kbo_map_batch_dev: ONE kernel for the reads (kbo_amd/csrc/map_kernels.hip) + the plain walk of the few per cent it leaves
-(--two-kernels: the round-3 route, the plan-guided MS walk and the derandomize / translate kernel one after the other).  Default workload = BASELINE config C2: 5 Mbp iid genome, k=31 SBWT, 1 M x 150 bp forward reads with
+(--two-kernels: the round-3 route, the plan-guided MS walk and the derandomize / translate kernel one after the other).
+TWO batches are in flight: consecutive steps take two resident batches of the same shape in turn (different reads, own
+buffers), and a batch's second pass runs on a second stream (kbo_map_batch_dev_tail) beside the next batch's kernel; every step's
+work - both passes - ends inside the timed region.  --one-at-a-time: a single stream (also reported in the line:
+`one_batch_at_a_time`).  Default workload = BASELINE config C2: 5 Mbp iid genome, k=31 SBWT, 1 M x 150 bp forward reads with
 1 % substitutions per GPU (weak scaling: every rank holds the replicated index and its own reads; no collective on the data
 path).  Prints ONE JSON line on rank 0.
 
@@ -40,7 +44,7 @@ SLAB_READS = 8_000_000      # reads per device-resident slab (one launch covers 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=sorted(PRESETS), default="C2",
                     help="BASELINE.json workload: C2 = kbo map, 5 Mbp index, 1 M x 150 bp reads per GPU (the metric config); "
@@ -66,6 +70,7 @@ def parse(argv=None):
     ap.add_argument("--no-plan", action="store_true", help="plain walk kernel only (no path cover, no plan-guided walk)")
     ap.add_argument("--two-kernels", action="store_true", help="kbo_ms_batch_dev + kbo_derand_translate_dev instead of kbo_map_batch_dev "
                     "(the MS values of every base go through HBM)")
+    ap.add_argument("--one-at-a-time", action="store_true", help="one stream: a batch's second pass before the next batch's kernel")
     ap.add_argument("--depth-table", type=int, default=0,
                     help="order of the depth table (kbo_set_depth_table): 0 = by index size, -1 = none (units + guided walk)")
     ap.add_argument("--index-cache", default=None, help="index file (.kbohip, with its path cover) to load instead of building; "
@@ -319,18 +324,38 @@ def stage_model_leg(args, sbwt, oi, concat, offsets, gpu_d, n_sample=2_000_000):
     return total / cn["bases"], summary, cn
 
 
-def run_batch(dev, stream, find, steps, warmup, torch, device, two_kernels=False):
-    """warm-up + timed steps of one resident batch -> (elapsed s, a1 ms, a5/a6 ms, rle ms | None); with kbo_map_batch_dev
-    (not two_kernels) a1 = the whole call and a5/a6 = 0"""
+def run_piped(devs, stream, tail, steps, torch):
+    """`steps` batches through kbo_map_batch_dev_tail, the resident batches in `devs` in turn: the kernel on `stream`, the second
+    pass on `tail`; a batch's buffers are used again only behind its last second pass (its `done` event)"""
+    for i in range(steps):
+        dev = devs[i % len(devs)]
+        if getattr(dev, "done", None) is None:
+            dev.done = torch.cuda.Event()
+        else:
+            stream.wait_event(dev.done)
+        dev.run(stream, tail_stream=tail)
+        dev.done.record(tail)
+
+
+def run_batch(devs, stream, find, steps, warmup, torch, device, two_kernels=False, tail=None):
+    """warm-up + timed steps over the resident batches `devs` in turn (one, or two of the same shape when `tail` is a second
+    stream) -> (elapsed s, a1 ms, a5/a6 ms, rle ms | None); with kbo_map_batch_dev (not two_kernels) a1 = the whole step and a5/a6 = 0"""
+    dev = devs[0]
     if not two_kernels:
-        for _ in range(warmup):
-            dev.run(stream)
+        def go(n):
+            if tail is not None:
+                run_piped(devs, stream, tail, n, torch)
+            else:
+                for i in range(n):
+                    devs[i % len(devs)].run(stream)
+        go(warmup)
         torch.cuda.synchronize(device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record(stream)
-        for _ in range(steps):
-            dev.run(stream)
+        go(steps)
+        if tail is not None:
+            stream.wait_stream(tail)
         e1.record(stream)
         torch.cuda.synchronize(device)
         return time.perf_counter() - t0, e0.elapsed_time(e1) / steps, 0.0, None
@@ -404,10 +429,10 @@ def indel_reads(genome, n_reads, L, sub_rate, indel_rate, seed, many=False):
     return out, np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(L)
 
 
-def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream):
+def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, tail=None):
     """SURVEY.md 8(d) asks for 0 % and 5 % variants of C2; VERDICT adds what the iid forward reads hide: reads from the
     other strand (the index has no reverse complements), reads from elsewhere, a repeat-rich genome of many contigs.  Each:
-    a resident batch of the C2 shape, 2 warm-up + 5 timed steps, every one of its first 20 000 reads against the oracle."""
+    a resident batch of the C2 shape, 2 warm-up + 6 timed steps (two sets of buffers in flight as in the headline), every one of its first 20 000 reads against the oracle."""
     import kbo_amd
     from kbo_amd import batch, synth
     from oracle import binding as ora
@@ -419,7 +444,10 @@ def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream):
 
     def measure(name, ix, o, concat, offsets, note):
         dev = batch.DeviceBatch(ix, concat, offsets, device=device, format=True, want_ms=False)
-        elapsed, a1, dt, _ = run_batch(dev, stream, False, 5, 2, torch, device, args.two_kernels)
+        devs = [dev]
+        if tail is not None and dev.max_len <= 160:  # (two in flight as in the headline: the same reads, a second set of buffers)
+            devs.append(batch.DeviceBatch(ix, concat, offsets, device=device, format=True, want_ms=False))
+        elapsed, a1, dt, _ = run_batch(devs, stream, False, 6, 2, torch, device, args.two_kernels, tail if len(devs) > 1 else None)
         fused = dev.fused
         n_all = len(offsets) - 1
         n_chk = max(1, min(n_all, int(np.searchsorted(offsets, 3_000_000))))  # the reads of the first 3 Mbp
@@ -430,8 +458,8 @@ def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream):
         dev.walk(stream)
         torch.cuda.synchronize(device)
         ok = bool(ok and np.array_equal(dev.ms[:n_b].cpu().numpy(), exp_d))
-        del dev
-        return {"variant": name, "value": round(int(offsets[-1]) * 5 / elapsed / 1e6, 1), "unit": "Mbp/s", "one_kernel": fused,
+        del dev, devs
+        return {"variant": name, "value": round(int(offsets[-1]) * 6 / elapsed / 1e6, 1), "unit": "Mbp/s", "one_kernel": fused,
                 "step_ms": round(a1 + dt, 4), "bit_exact_vs_oracle": ok, "note": note}
 
     out = []
@@ -661,13 +689,25 @@ def main(argv=None):
     # ---- reads: sharded by rank.  weak scaling (C2, C3): args.reads per rank; strong (C4): args.reads in all
     n_mine, first = shard(args, rank, world)
     stream = torch.cuda.current_stream(device)
-    slabs = []
-    for s0 in range(0, n_mine, SLAB_READS):
-        ns = min(SLAB_READS, n_mine - s0)
-        concat, offsets = synth.reads(genome, ns, args.read_len, args.sub_rate, first_read=first + s0)
-        slabs.append(batch.DeviceBatch(sbwt, concat, offsets, device=device, format=not args.find, want_ms=False))
-        if s0 == 0:
-            concat0, offsets0 = concat, offsets  # (rank 0's parity gate and CPU baseline use the first slab)
+    # two batches in flight (module docstring): a batch's second pass on `tail` beside the next batch's kernel on `stream`
+    piped = not args.two_kernels and not args.one_at_a_time
+    tail = torch.cuda.Stream(device) if piped else None
+    n_slabs = (n_mine + SLAB_READS - 1) // SLAB_READS
+    n_sets = 2 if piped and n_slabs == 1 else 1  # (several slabs per step are several batches already)
+    sets, first_slab = [], []
+    for b in range(n_sets):
+        slabs = []
+        for s0 in range(0, n_mine, SLAB_READS):
+            ns = min(SLAB_READS, n_mine - s0)
+            # (the second set: the reads behind every rank's first set)
+            concat, offsets = synth.reads(genome, ns, args.read_len, args.sub_rate, first_read=first + s0 + b * max(world, 1) * args.reads)
+            slabs.append(batch.DeviceBatch(sbwt, concat, offsets, device=device, format=not args.find, want_ms=False))
+            slabs[-1].done = None
+            if s0 == 0:
+                first_slab.append((concat, offsets))  # (rank 0's parity gate and CPU baseline use the first slab of either set)
+        sets.append(slabs)
+    slabs = sets[0]
+    concat0, offsets0 = first_slab[0]
     bases = n_mine * args.read_len
 
     def sync_all():
@@ -676,36 +716,48 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    def one_step(events=None):
-        for i, dev in enumerate(slabs):
+    def one_step(step, events=None, on_tail=None):
+        on_tail = piped if on_tail is None else on_tail
+        for i, dev in enumerate(sets[step % n_sets]):
+            if on_tail and dev.done is not None:
+                stream.wait_event(dev.done)  # its buffers are free again behind its last second pass
             if events is not None:
                 events[i][0].record(stream)
+            last = tail if on_tail else stream
             if args.two_kernels:
                 dev.walk(stream)
                 if events is not None:
                     events[i][1].record(stream)
                 dev.derand_translate(stream)
-            else:  # kbo_map_batch_dev: one kernel for the reads + the plain walk of the reads it leaves
-                dev.run(stream)
+            else:  # kbo_map_batch_dev[_tail]: one kernel for the reads + the plain walk of the reads it leaves
+                dev.run(stream, tail_stream=tail if on_tail else None)
                 if events is not None:
-                    events[i][1].record(stream)
-            if events is not None:
-                events[i][2].record(stream)
+                    events[i][1].record(last)
+            if events is not None and (args.two_kernels or args.find):
+                events[i][2].record(last)
             if args.find:  # kbo::find (lib.rs:816-820): run lengths of the characters, still on the device
-                dev.run_lengths(0, stream)
-            if events is not None:
-                events[i][3].record(stream)
+                dev.run_lengths(0, last)
+                if events is not None:
+                    events[i][3].record(last)
+            if on_tail:
+                if dev.done is None:
+                    dev.done = torch.cuda.Event()
+                dev.done.record(tail)
 
-    for _ in range(args.warmup):
-        one_step()
+    for b in range(n_sets):  # every resident batch once before anything else: which route it takes (and the lazy parts of the copy)
+        one_step(b, None, on_tail=False)
     sync_all()
-    one_kernel = (not args.two_kernels) and all(d.fused for d in slabs)
+    one_kernel = (not args.two_kernels) and all(d.fused for sl in sets for d in sl)
+    piped = piped and one_kernel  # (the two-kernel route has no second pass to set aside)
+    for w in range(args.warmup):
+        one_step(w)
+    sync_all()
     ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in slabs] for _ in range(args.steps)]
     import ctypes as _C
-    L.kbo_set_stage_timing(1 if one_kernel else 0)  # (three event records per call: the dominant kernel's own duration, live)
+    L.kbo_set_stage_timing(1 if one_kernel else 0)  # (event records per call: the dominant kernel's own duration, live)
     t0 = time.perf_counter()
     for s in range(args.steps):
-        one_step(ev[s])
+        one_step(args.warmup + s, ev[s])
     sync_all()
     elapsed = time.perf_counter() - t0
     L.kbo_set_stage_timing(0)
@@ -714,8 +766,26 @@ def main(argv=None):
     map_kernel_ms = k_sum.value / args.steps if one_kernel and n_calls.value else None  # per step (all slabs)
     map_redo_ms = r_sum.value / args.steps if one_kernel and n_calls.value else None
     walk_ms = float(np.mean([sum(e[0].elapsed_time(e[1]) for e in step) for step in ev]))
-    dt_ms = float(np.mean([sum(e[1].elapsed_time(e[2]) for e in step) for step in ev]))
+    dt_ms = float(np.mean([sum(e[1].elapsed_time(e[2]) for e in step) for step in ev])) if args.two_kernels else 0.0
     rle_ms = float(np.mean([sum(e[2].elapsed_time(e[3]) for e in step) for step in ev])) if args.find else None
+    # what the timed steps left behind (formatted unless --find): the first slab of either set, for rank 0's parity gate
+    timed_chars_sets = [sl[0].chars[:sl[0].total].cpu().numpy() for sl in sets] if rank == 0 else None
+    serial = None
+    if piped and rank == 0 and world == 1:  # the same steps on one stream, for the record
+        n_ser = max(1, min(args.steps, 10))
+        L.kbo_set_stage_timing(1 if one_kernel else 0)
+        t1 = time.perf_counter()
+        for s in range(n_ser):
+            one_step(s, None, on_tail=False)
+        sync_all()
+        t1 = time.perf_counter() - t1
+        L.kbo_set_stage_timing(0)
+        ks, rs, nc = _C.c_double(0), _C.c_double(0), _C.c_int(0)
+        L.kbo_stage_timing_read(_C.byref(ks), _C.byref(rs), _C.byref(nc))
+        serial = {"value": round(bases * n_ser / t1 / 1e6, 1), "unit": "Mbp/s", "ms_per_step": round(t1 / n_ser * 1e3, 4), "steps": n_ser,
+                  "map_reads_kernel_ms": round(ks.value / n_ser, 4) if one_kernel and nc.value else None,
+                  "second_pass_ms": round(rs.value / n_ser, 4) if one_kernel and nc.value else None,
+                  "note": "kbo_map_batch_dev on one stream: every batch's second pass before the next batch's kernel"}
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device if not one_gpu or world == 1 else "cpu")
     if world > 1:
@@ -728,7 +798,7 @@ def main(argv=None):
         dist.all_gather(gathered, per_rank_t)
         walk_all = [float(g[0].item()) for g in gathered]
     else:
-        walk_all = [walk_ms]
+        walk_all = [float(per_rank_t[0].item())]
     total_bases = args.reads * args.read_len if args.scaling == "strong" else world * bases
 
     result = None
@@ -736,7 +806,7 @@ def main(argv=None):
         dev = slabs[0]
         # the stage's own work counters: one more launch over the first slab with the counting instantiations of the
         # kernels (instrumentation, off inside the timed region: about 1 % of the stage's time)
-        timed_chars = dev.chars[:dev.total].cpu().numpy()  # what the timed steps left behind (formatted unless --find)
+        timed_chars = timed_chars_sets[0]
         L.kbo_set_plan_stats(1)
         if one_kernel:
             dev.run(stream)
@@ -767,12 +837,17 @@ def main(argv=None):
             exp_chars, exp_d = oi.matches_batch(concat0, offsets0, 1e-7, n_threads=usable_cores()[0], want_d=True)
             exp_out = np.frombuffer(ora.relative_to_ref(concat0, exp_chars), dtype=np.uint8) if fmt else exp_chars
             exact = bool(exact and np.array_equal(timed_chars, exp_out) and np.array_equal(gpu_d[:dev.total], exp_d))
+            for b in range(1, n_sets):  # ... and of the other batch in flight
+                cb, ob = first_slab[b]
+                exp_chars = oi.matches_batch(cb, ob, 1e-7, n_threads=usable_cores()[0])
+                exp_out = np.frombuffer(ora.relative_to_ref(cb, exp_chars), dtype=np.uint8) if fmt else exp_chars
+                exact = bool(exact and np.array_equal(timed_chars_sets[b], exp_out))
             del exp_chars, exp_d, exp_out
             if planned and not stats["gave_up"] and not one_kernel:
                 b_plan, model, _ = stage_model_leg(args, sbwt, oi, concat0, offsets0, gpu_d)
                 exact = bool(exact and model["ms_equal_to_gpu"])
             if world == 1 and not args.no_extras and (args.extras or not args.custom):
-                sens = sensitivity_leg(args, genome, sbwt, oi, torch, device, stream)
+                sens = sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, tail)
                 h2h = host_to_host_leg(args, sbwt, genome)
         # fabric-side traffic and L2 misses of the A1 stage, from the committed rocprofv3 passes of this exact
         # workload and walk mode (PMC passes cannot run inside the timed region: separate runs, tools/profile_bench.sh)
@@ -915,12 +990,16 @@ def main(argv=None):
                            "note": "this rank's device copy: host layout of rank blocks / entries, uploads, path cover (0 when the index "
                                    "file carried it), recovery lines, seed table(s), depth table; index build or load is index_seconds_rank0"},
                        "resident_slabs_per_gpu": len(slabs), "index_seconds_rank0": round(t_index, 2),
+                       "batches_in_flight": ("2: consecutive steps take %s in turn; a batch's second pass runs on a second stream "
+                                             "(kbo_map_batch_dev_tail) beside the next batch's kernel; all of every step's work ends inside the timed region"
+                                             % ("two resident batches of this shape (different reads)" if n_sets == 2 else "the step's slabs")) if piped else 1,
                        "parallelism": f"index replicated x{world}, reads sharded, no collective"},
             "roofline": roofline,
             "kernels_ms": ({"map_reads_kernel": round(map_kernel_ms, 4), "redo_pass": round(map_redo_ms, 4),
                             "kbo_map_batch_dev": round(walk_ms, 4)} if one_kernel else
                            {"a1_stage": round(walk_ms, 4), "derand_translate": round(dt_ms, 4)}) |
                           ({"run_lengths": round(rle_ms, 4)} if args.find else {}),
+            "one_batch_at_a_time": serial,
             "cpu_baseline": cpu,
             "bit_exact_vs_oracle": exact,
             "reference_ops_per_base": ops,

@@ -255,7 +255,7 @@ class DeviceBatch:
         first = w[n + 1 + np.arange(n + 1) // 1024] + w[:n + 1]
         return self.rle_records[:total].cpu().numpy().view(np.uint32), first
 
-    def run(self, stream=None):
+    def run(self, stream=None, tail_stream=None):
         """kbo::map (format) / kbo::matches over the batch: kbo_map_batch_dev - one kernel for reads over an index copy with a
         depth table (self.ms then holds every MS value only when want_ms), else walk() + derand_translate()."""
         if self.lo is not None or self.max_len == 0 or self.max_len > 480:
@@ -265,7 +265,13 @@ class DeviceBatch:
             return
         s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
         fused = C.c_int(0)
-        check(lib().kbo_map_batch_dev(self.sbwt._h, self.q.data_ptr(), self.off.data_ptr(), self.n_seqs, self.total, self.max_len,
-                                      self.max_error_prob, int(self.format), int(self.want_ms), self.ms.data_ptr(), self.chars.data_ptr(),
-                                      self.work.data_ptr(), self.work_bytes, s.cuda_stream, C.byref(fused)))
+        if tail_stream is not None:  # the second pass on another stream (kbo_hip.h kbo_map_batch_dev_tail): complete when both have drained
+            check(lib().kbo_map_batch_dev_tail(self.sbwt._h, self.q.data_ptr(), self.off.data_ptr(), self.n_seqs, self.total, self.max_len,
+                                               self.max_error_prob, int(self.format), int(self.want_ms), self.ms.data_ptr(),
+                                               self.chars.data_ptr(), self.work.data_ptr(), self.work_bytes, s.cuda_stream,
+                                               tail_stream.cuda_stream, C.byref(fused)))
+        else:
+            check(lib().kbo_map_batch_dev(self.sbwt._h, self.q.data_ptr(), self.off.data_ptr(), self.n_seqs, self.total, self.max_len,
+                                          self.max_error_prob, int(self.format), int(self.want_ms), self.ms.data_ptr(), self.chars.data_ptr(),
+                                          self.work.data_ptr(), self.work_bytes, s.cuda_stream, C.byref(fused)))
         self.fused = bool(fused.value)

@@ -1215,7 +1215,7 @@ namespace {
 // kbo_set_stage_timing: event triples of the one-kernel route's calls (guarded by g_timing_mu)
 std::atomic<int> g_stage_timing{0};
 std::mutex g_timing_mu;
-struct StageEvents { hipEvent_t e0, e1, e2; };
+struct StageEvents { hipEvent_t e0, e1, e1t, e2; };
 std::vector<StageEvents> g_timing_pool, g_timing_used;
 StageEvents timing_take()
 {
@@ -1227,6 +1227,7 @@ StageEvents timing_take()
     } else {
         HIP_OK(hipEventCreate(&ev.e0));
         HIP_OK(hipEventCreate(&ev.e1));
+        HIP_OK(hipEventCreate(&ev.e1t));
         HIP_OK(hipEventCreate(&ev.e2));
     }
     return ev;
@@ -1248,7 +1249,7 @@ int kbo_stage_timing_read(double *kernel_ms_sum, double *redo_ms_sum, int *n_cal
             HIP_OK(hipEventSynchronize(ev.e2));
             float x = 0, y = 0;
             HIP_OK(hipEventElapsedTime(&x, ev.e0, ev.e1));
-            HIP_OK(hipEventElapsedTime(&y, ev.e1, ev.e2));
+            HIP_OK(hipEventElapsedTime(&y, ev.e1t, ev.e2));
             a += x;
             b += y;
             g_timing_pool.push_back(ev);
@@ -1260,9 +1261,19 @@ int kbo_stage_timing_read(double *kernel_ms_sum, double *redo_ms_sum, int *n_cal
     });
 }
 
-int kbo_map_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
-                      size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
-                      void *d_work, size_t work_bytes, void *stream, int *fused)
+namespace {
+// one fence event per host thread: hipStreamWaitEvent takes the event's state at the time of the call, so recording it again for the
+// next batch does not disturb a wait that is already queued
+hipEvent_t tail_fence()
+{
+    thread_local hipEvent_t ev = nullptr;
+    if (!ev) HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    return ev;
+}
+
+int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
+                       size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
+                       void *d_work, size_t work_bytes, void *stream, void *tail_stream, bool split, int *fused)
 {
     if (fused) *fused = 0;
     bool done = false;
@@ -1310,15 +1321,28 @@ int kbo_map_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
         }
         HIP_OK(kbo::launch_map_reads(a, s));
         if (timing) HIP_OK(hipEventRecord(ev.e1, s));
-        HIP_OK(kbo::launch_redo_pass(a, s));
+        hipStream_t ts = s;
+        if (split && static_cast<hipStream_t>(tail_stream) != s) { // the second pass on the caller's other stream, behind the kernel
+            ts = static_cast<hipStream_t>(tail_stream);
+            hipEvent_t fence = tail_fence();
+            HIP_OK(hipEventRecord(fence, s));
+            HIP_OK(hipStreamWaitEvent(ts, fence, 0));
+            // (beside another batch's kernel the pass costs by the look-ups it takes away from that kernel rather than by its longest
+            // chain: longer pieces, fewer warm-up bases.  Pieces of 16 / 24 / 32 / 48 / 64 bases at C2, two batches in flight:
+            // 0.341 / 0.324 / 0.316 / 0.343 / 0.337 ms per batch)
+            static const bool env_piece = std::getenv("KBO_REDO_PIECE") != nullptr;
+            if (!env_piece) a.redo_piece = 32u;
+        }
+        if (timing) HIP_OK(hipEventRecord(ev.e1t, ts)); // (when the second pass starts: behind the kernel and behind what `ts` held)
+        HIP_OK(kbo::launch_redo_pass(a, ts));
         HIP_OK(kbo::launch_derand_flagged(d_ms, d_offsets, (uint32_t)n_seqs, idx->host.k, (uint32_t)threshold, format ? d_concat : nullptr,
-                                          d_chars_out, a.redo, (uint32_t)max_seq_len, s));
+                                          d_chars_out, a.redo, (uint32_t)max_seq_len, ts));
         if (timing) {
-            HIP_OK(hipEventRecord(ev.e2, s));
+            HIP_OK(hipEventRecord(ev.e2, ts));
             std::lock_guard<std::mutex> g(g_timing_mu);
             g_timing_used.push_back(ev);
         }
-        plan_after_launch(a, s, plan_state);
+        plan_after_launch(a, ts, plan_state);
         done = true;
     });
     if (rc != KBO_OK || done) {
@@ -1329,6 +1353,23 @@ int kbo_map_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
     if (rc != KBO_OK) return rc;
     return kbo_derand_translate_dev(d_ms, d_offsets, n_seqs, total_bases, idx->host.k, threshold, format ? d_concat : nullptr, d_chars_out,
                                     max_seq_len, nullptr, 0, stream);
+}
+} // namespace
+
+int kbo_map_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
+                      size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
+                      void *d_work, size_t work_bytes, void *stream, int *fused)
+{
+    return map_batch_dev_impl(idx, d_concat, d_offsets, n_seqs, total_bases, max_seq_len, max_error_prob, format, want_ms, d_ms, d_chars_out,
+                              d_work, work_bytes, stream, nullptr, false, fused);
+}
+
+int kbo_map_batch_dev_tail(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
+                           size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
+                           void *d_work, size_t work_bytes, void *stream, void *tail_stream, int *fused)
+{
+    return map_batch_dev_impl(idx, d_concat, d_offsets, n_seqs, total_bases, max_seq_len, max_error_prob, format, want_ms, d_ms, d_chars_out,
+                              d_work, work_bytes, stream, tail_stream, true, fused);
 }
 
 int kbo_run_lengths_dev(const uint8_t *d_chars, const uint64_t *d_offsets, size_t n_seqs, size_t max_seq_len,

@@ -39,6 +39,8 @@ def _check_line(r, n_gpus, table=True, one_kernel=True):
         assert 0 < ro["kernel_ms"] <= r["kernels_ms"]["kbo_map_batch_dev"] * 1.05 and ro["redo_pass_ms"] > 0
         assert 2.0 < ro["algorithmic_bytes_per_base"] < 4.0 and ro["build_sha16"]
         assert ro["cross_check_whole_step_gbps"] <= ro["peak"]
+        if n_gpus == 1:  # two batches in flight; the same steps on one stream beside them
+            assert str(r["config"]["batches_in_flight"]).startswith("2") and r["one_batch_at_a_time"]["value"] > 0
         return
     assert ro["stage_model"]["ms_equal_to_gpu"] is True
     # the model's counts are the kernels' own (first slab)

@@ -176,3 +176,43 @@ def test_routes_that_are_not_the_one_kernel(oracle):
     reads = _mutate(rng, [g[a:a + 150] for a in rng.integers(0, len(g) - 150, 2000)], sub=0.01)
     _check(oracle, ora, sb2, *_batch_of(reads), expect_fused=False)
     L.kbo_set_depth_table(0)
+
+
+def test_two_batches_in_flight(oracle):
+    """kbo_map_batch_dev_tail: the kernel on one stream, the second pass on another, beside the next batch's kernel; a batch's
+    buffers are used again behind its own second pass.  Three batches of different shapes in turn, several rounds, then every read."""
+    import torch
+    rng = np.random.default_rng(21)
+    g = synth.genome(400_000, seed=41)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=threads()))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    dev0 = torch.device("cuda:0")
+    S, T = torch.cuda.Stream(dev0), torch.cuda.Stream(dev0)
+    kbo_amd.lib().kbo_set_plan(1, 0, 0)
+    sets = []
+    for n, sub, fmt in ((40_000, 0.01, True), (25_000, 0.02, False), (33_333, 0.0, True)):
+        reads = _mutate(rng, [g[a:a + int(l)] for a, l in zip(rng.integers(0, len(g) - 200, n), rng.integers(30, 158, n))], sub=sub, indel=0.2)  # (an insertion adds up to 3 bases: 160 at most)
+        concat, offsets = _batch_of(reads)
+        dev = batch.DeviceBatch(sbwt, concat, offsets, device=dev0, format=fmt, want_ms=False)
+        exp_chars = ora.matches_batch(concat, offsets, 1e-7, n_threads=threads())
+        want = np.frombuffer(oracle.relative_to_ref(concat, exp_chars), dtype=np.uint8) if fmt else exp_chars
+        sets.append((dev, want, torch.cuda.Event()))
+    with torch.cuda.stream(S):
+        for rnd in range(4):
+            for dev, _, done in sets:
+                if rnd:
+                    S.wait_event(done)
+                    dev.chars.fill_(0xEE)  # (on S, behind the batch's last second pass)
+                kbo_amd.lib().kbo_set_plan(1, 0, 0)  # (no hold-off behind the batch with 2 % substitutions)
+                dev.run(S, tail_stream=T)
+                assert dev.fused
+                done.record(T)
+    torch.cuda.synchronize()
+    for dev, want, _ in sets:
+        assert np.array_equal(dev.chars[:dev.total].cpu().numpy(), want)
+    # tail_stream == stream is kbo_map_batch_dev
+    dev, want, _ = sets[0]
+    dev.chars.fill_(0xEE)
+    dev.run(S, tail_stream=S)
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.chars[:dev.total].cpu().numpy(), want)

@@ -1,35 +1,73 @@
-#!/usr/bin/env python3
-"""A5/A6 of batch i on a second stream while A1 of batch i+1 runs (C2 workload): step time with and without."""
-import os, sys, time
-import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""Two batches in flight: batch i's second pass (kbo_map_batch_dev_tail) on a second stream beside batch i+1's kernel, against
+one batch after the other on one stream.  python tools/exp_overlap.py [genome] [reads]"""
+import os, sys, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import kbo_amd
 from kbo_amd import batch, synth
-G = int(os.environ.get("G", 5_000_000)); R = int(os.environ.get("R", 1_000_000)); K = int(os.environ.get("K", 40))
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
+R = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+NB = int(os.environ.get("NB", "2"))
+device = torch.device("cuda:0")
 g = synth.genome(G)
 sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=16))
-concat, offsets = synth.reads(g, R, 150, 0.01)
-dev = torch.device("cuda:0")
-B = [batch.DeviceBatch(sbwt, concat, offsets, device=dev, format=True) for _ in range(2)]
-sA, sB = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-for b in B:
-    b.run(sA)
+devs = []
+for b in range(NB):
+    concat, offsets = synth.reads(g, R, 150, 0.01, seed=100 + b)
+    devs.append(batch.DeviceBatch(sbwt, concat, offsets, device=device, format=True, want_ms=False))
+PRI = int(os.environ.get("PRI", "0"))
+NT = int(os.environ.get("NT", "1"))
+S = torch.cuda.Stream(device)
+Ts = [torch.cuda.Stream(device, priority=PRI) for _ in range(NT)]
+T = Ts[0]
+done = [torch.cuda.Event() for _ in devs]
+
+
+def serial(steps):
+    for i in range(steps):
+        devs[i % NB].run(S)
+
+
+def piped(steps):
+    for i in range(steps):
+        b = i % NB
+        S.wait_event(done[b])  # the batch's buffers are free again once its last second pass is through
+        devs[b].run(S, tail_stream=Ts[i % NT])
+        done[b].record(Ts[i % NT])
+
+
+def timed(fn, steps=40, warm=4):
+    fn(warm)
+    torch.cuda.synchronize()
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(S)
+    fn(steps)
+    for t in Ts:
+        S.wait_stream(t)
+    e.record(S)
+    torch.cuda.synchronize()
+    return a.elapsed_time(e) / steps
+
+
+for d in devs:
+    d.run(S)
 torch.cuda.synchronize()
-ref = B[0].chars.clone()
+ref = [d.chars[:d.total].clone() for d in devs]
+import ctypes as C
+L = kbo_amd.lib()
 
-def serial():
-    for i in range(K):
-        B[i % 2].run(sA)
 
-def overlapped():
-    ev1 = [torch.cuda.Event() for _ in range(2)]; ev2 = [torch.cuda.Event() for _ in range(2)]
-    for i in range(K):
-        b = B[i % 2]
-        if i >= 2: sA.wait_event(ev2[i % 2])
-        b.walk(sA); ev1[i % 2].record(sA)
-        sB.wait_event(ev1[i % 2]); b.derand_translate(sB); ev2[i % 2].record(sB)
+def staged(fn):
+    L.kbo_set_stage_timing(1)
+    t = timed(fn)
+    a, b, n = C.c_double(), C.c_double(), C.c_int()
+    L.kbo_stage_timing_read(C.byref(a), C.byref(b), C.byref(n))
+    L.kbo_set_stage_timing(0)
+    print("  kernel %.4f ms, second pass %.4f ms (from its start on its stream) over %d calls" % (a.value / n.value, b.value / n.value, n.value))
+    return t
 
-for name, fn in (("serial", serial), ("overlapped", overlapped), ("serial", serial), ("overlapped", overlapped)):
-    torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    ok = bool(torch.equal(B[0].chars, ref) and torch.equal(B[1].chars, ref))
-    print(f"{name}: {dt / K * 1e3:.3f} ms per step, {R * 150 / (dt / K) / 1e9:.1f} Gbp/s, chars equal: {ok}", flush=True)
+
+ts = staged(serial)
+tp = staged(piped)
+ok = all(bool((d.chars[:d.total] == r).all()) for d, r in zip(devs, ref))
+print("serial %.4f ms/step = %.1f Gbp/s; two in flight %.4f ms/step = %.1f Gbp/s; equal %s" % (ts, devs[0].total / ts / 1e6, tp, devs[0].total / tp / 1e6, ok))
