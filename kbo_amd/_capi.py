@@ -92,14 +92,14 @@ SYMBOLS = [
     "kbo_index_path_cover", "kbo_index_recovery_lines", "kbo_call_batch", "kbo_call_sites_dev", "kbo_call_walk_dev",
     "kbo_index_save_sbwt", "kbo_index_load_sbwt", "kbo_packed_words", "kbo_pack_reads", "kbo_unpack_matches",
     "kbo_matches_batch_packed", "kbo_find_batch_packed", "kbo_index_shards", "kbo_index_work_bytes",
-    "kbo_index_device_layout", "kbo_map_batch_dev",
+    "kbo_index_device_layout", "kbo_map_batch_dev", "kbo_map_batch_dev_tail",
 ]
 # ... and include/kbo_hip_tuning.h (knobs, experiment switches, test hooks: not part of the drop-in boundary)
 TUNING_SYMBOLS = [
     "kbo_walk_geometry", "kbo_set_walk_waves_per_cu", "kbo_set_walk_threads", "kbo_set_walk_rare", "kbo_set_guided_walk",
     "kbo_set_pair_steps", "kbo_set_force_big_layout", "kbo_set_seed_table_depth", "kbo_set_plan", "kbo_set_plan_tuning",
     "kbo_set_plan_unit_cap_divisor", "kbo_index_plan_holdoff", "kbo_set_walk_experiment", "kbo_plan_stats_dev", "kbo_set_plan_stats", "kbo_set_index_shards", "kbo_index_shard", "kbo_set_depth_table", "kbo_set_depth_table_anchors", "kbo_index_depth_table", "kbo_run_automaton_depths",
-    "kbo_set_stage_timing", "kbo_stage_timing_read", "kbo_set_plan_table_budget", "kbo_set_plan_lazy", "kbo_plan_flags_dev", "kbo_map_batch_dev_tail",
+    "kbo_set_stage_timing", "kbo_stage_timing_read", "kbo_set_plan_table_budget", "kbo_set_plan_lazy", "kbo_plan_flags_dev",
 ]
 
 _lib = None
