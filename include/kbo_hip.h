@@ -394,6 +394,28 @@ int kbo_map_batch_dev_tail(kbo_index_t *idx, const uint8_t *d_concat, const uint
 size_t kbo_run_lengths_work_bytes(size_t n_seqs);
 int kbo_run_lengths_dev(const uint8_t *d_chars, const uint64_t *d_offsets, size_t n_seqs, size_t max_seq_len,
                         size_t max_gap_len, void *d_work, uint32_t *d_records, size_t capacity, void *stream);
+/* Options of ONE index handle: what the process-wide setters below and in kbo_hip_tuning.h (kbo_set_devices, kbo_set_slab_bytes,
+ * kbo_set_plan, kbo_set_depth_table, kbo_set_depth_table_anchors) decide for every index, decided for this one - two indexes of one
+ * process (a small reference next to a large one; a service with one handle per tenant) no longer share them.  A field left at its
+ * "inherit" value follows the process-wide setting at the time of use.  Set them before the handle's first batch / before
+ * kbo_index_to_device: like the process-wide setters, depth_table* shape device copies made from then on (an existing copy keeps
+ * its table; depth_table = -1 makes launches ignore it), plan = 0 stops planned launches at once, devices and slab_bytes apply to
+ * the next host batch.  Not to be changed while a batch of this handle is in flight on another thread.  A sharded index hands its
+ * options on to its shards. */
+#define KBO_OPT_INHERIT (-2147483647 - 1)
+#define KBO_OPT_MAX_DEVICES 16
+typedef struct kbo_index_opts {
+    uint32_t struct_size;        /* sizeof(kbo_index_opts_t), as filled in by kbo_index_opts_default: the struct may grow */
+    int32_t plan;                /* KBO_OPT_INHERIT | 0 = plain walk only | 1 = path cover + tables on its device copies, planned launches */
+    int32_t depth_table;         /* KBO_OPT_INHERIT | 0 = order by index size | -1 = none | 1 .. 17 = bases per entry */
+    int32_t depth_table_anchors; /* KBO_OPT_INHERIT | -1 = by the table's margin over log4(rows) | 0 = no | 1 = yes */
+    uint64_t slab_bytes;         /* 0 = inherit | query bytes per slab of its host batches (clamped to 64 KiB .. 3.75 GiB) */
+    int32_t n_devices;           /* -1 = inherit | 0 = the current device | 1 .. 16 = devices[0 .. n) */
+    int32_t devices[KBO_OPT_MAX_DEVICES];
+} kbo_index_opts_t;
+int kbo_index_opts_default(kbo_index_opts_t *opts); /* every field "inherit" */
+int kbo_index_set_opts(kbo_index_t *idx, const kbo_index_opts_t *opts);
+int kbo_index_get_opts(const kbo_index_t *idx, kbo_index_opts_t *opts);
 /* Devices the host batch entry points (kbo_matches_batch / kbo_map_batch / kbo_find_batch) spread
  * their slabs over: index replicated per device, one submitting + one completing host thread and
  * three stage streams (upload, kernels, download) per device, disjoint output slices, no collective.

@@ -55,6 +55,15 @@ class Variant(C.Structure):
                 ("ref_chars", C.POINTER(C.c_uint8)), ("ref_len", C.c_size_t)]
 
 
+OPT_INHERIT = -2147483648
+
+
+class IndexOpts(C.Structure):
+    """kbo_hip.h kbo_index_opts_t"""
+    _fields_ = [("struct_size", C.c_uint32), ("plan", C.c_int32), ("depth_table", C.c_int32), ("depth_table_anchors", C.c_int32),
+                ("slab_bytes", C.c_uint64), ("n_devices", C.c_int32), ("devices", C.c_int32 * 16)]
+
+
 class DeviceLayout(C.Structure):  # kbo_device_layout
     _fields_ = [(n, C.c_uint64) for n in ("rank_bytes", "entry_bytes", "pair_bytes", "cover_bytes", "lines_bytes", "seed_bytes",
                                          "dtab_bytes", "anchor_bytes")] + \
@@ -93,6 +102,7 @@ SYMBOLS = [
     "kbo_index_save_sbwt", "kbo_index_load_sbwt", "kbo_packed_words", "kbo_pack_reads", "kbo_unpack_matches",
     "kbo_matches_batch_packed", "kbo_find_batch_packed", "kbo_index_shards", "kbo_index_work_bytes",
     "kbo_index_device_layout", "kbo_map_batch_dev", "kbo_map_batch_dev_tail",
+    "kbo_index_opts_default", "kbo_index_set_opts", "kbo_index_get_opts",
 ]
 # ... and include/kbo_hip_tuning.h (knobs, experiment switches, test hooks: not part of the drop-in boundary)
 TUNING_SYMBOLS = [
@@ -221,6 +231,9 @@ def lib():
     L.kbo_set_stage_timing.argtypes = [C.c_int]
     L.kbo_stage_timing_read.argtypes = [C.POINTER(dbl), C.POINTER(dbl), C.POINTER(C.c_int)]
     L.kbo_map_batch_dev.argtypes = [vp, vp, vp, sz, u64, sz, dbl, C.c_int, C.c_int, vp, vp, vp, sz, vp, C.POINTER(C.c_int)]
+    L.kbo_index_opts_default.argtypes = [C.POINTER(IndexOpts)]
+    L.kbo_index_set_opts.argtypes = [vp, C.POINTER(IndexOpts)]
+    L.kbo_index_get_opts.argtypes = [vp, C.POINTER(IndexOpts)]
     L.kbo_map_batch_dev_tail.argtypes = [vp, vp, vp, sz, u64, sz, dbl, C.c_int, C.c_int, vp, vp, vp, sz, vp, vp, C.POINTER(C.c_int)]
     L.kbo_index_device_layout.argtypes = [vp, C.c_int, C.POINTER(DeviceLayout)]
     _lib = L

@@ -65,7 +65,7 @@ SiteWindows find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *of
     all.stride = kbo::call_gather_stride(k);
     all.kpad = (k + 15u) / 16u * 16u;
     hipStream_t stream = nullptr;
-    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
+    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, slab_bytes_for(idx));
     DevBuf d_sites, d_count, d_prefix, d_recs, d_win;
     const size_t count_bytes = kbo::kCallSegs * 64 + 64;
     d_count.alloc(count_bytes);

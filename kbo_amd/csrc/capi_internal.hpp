@@ -4,6 +4,7 @@
 //   kbo_capi.cpp      the extern "C" entry points.
 #pragma once
 #include <atomic>
+#include <cstdint>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -79,9 +80,22 @@ struct DevCopy {
 
 } // namespace kbo_host
 
+// per-handle options (kbo_index_set_opts, kbo_hip.h): what the process-wide knobs of kbo_hip_tuning.h set for every index, set
+// for this one; kOptInherit = follow the process-wide value
+constexpr int kOptInherit = INT32_MIN;
+struct HandleOpts {
+    std::atomic<int> plan{kOptInherit};                // 0 = plain walk only, 1 = plan structures + planned launches
+    std::atomic<int> depth_table{kOptInherit};         // as kbo_set_depth_table: 0 by index size, < 0 none, else the order
+    std::atomic<int> depth_table_anchors{kOptInherit}; // as kbo_set_depth_table_anchors
+    std::atomic<size_t> slab_bytes{0};                 // 0 = inherit
+    int n_devices = -1;                                // -1 = inherit (guarded by kbo_index::mu, with `devices`)
+    std::vector<int> devices;
+};
+
 struct kbo_index {
     kbo::HostIndex host;
     std::mutex mu;
+    HandleOpts opts;
     std::map<int, kbo_host::DevCopy *> dev;
     uint64_t rank_bytes = 0, lcs_bytes = 0, plan_bytes = 0;
     bool transient = false; // an index that serves one small batch (kbo::call builds one per sequence): no path cover
@@ -110,6 +124,12 @@ extern std::atomic<int> g_waves_per_cu;           // walk: resident waves per CU
 extern std::vector<int> g_devices;   // guarded by g_devices_mu: read it through devices_snapshot()
 extern std::mutex g_devices_mu;
 std::vector<int> devices_snapshot();
+// the same knobs as one index sees them (its own options first: HandleOpts)
+bool plan_enabled(const kbo_index *idx);
+int depth_table_setting(const kbo_index *idx);
+int depth_table_anchor_setting(const kbo_index *idx);
+size_t slab_bytes_for(const kbo_index *idx);
+std::vector<int> devices_for(kbo_index *idx);
 //   // devices the host batch entry points spread slabs over (empty = current)
 extern std::atomic<bool> g_force_big;             // tests: use the 64-bit-offset entry layout regardless of size
 extern std::atomic<uint64_t> g_pair_min_rows;     // indexes with at least this many rows get two-base blocks on the device
@@ -214,7 +234,7 @@ void check_batch(const void *concat, const uint64_t *offsets, size_t n_seqs);
 void check_len_threshold(const uint64_t *offsets, size_t n_seqs, size_t k, size_t threshold);
 OffsetScan scan_offsets(const uint64_t *offsets, size_t n_seqs);
 std::vector<Slab> make_slabs(const uint64_t *offsets, size_t n_seqs, size_t max_bytes);
-size_t packed_slab_bytes(); // bases per slab of a packed batch
+size_t packed_slab_bytes(const kbo_index *idx); // bases per slab of a packed batch
 // upload + A1 over a host batch (asynchronous on `stream`); leaves ms (and lo/hi) on the device.
 // `items_keep` must stay alive until the stream has been synchronised.
 // call mode of the walk (kernels.hpp WalkArgs::call_*): where the sites go

@@ -19,6 +19,22 @@ std::atomic<int> g_plan_cap_div{1};
 std::atomic<int> g_seed_table_depth{0};
 std::atomic<int> g_depth_table{0}; // depth table of device copies made from now on: 0 = by index size, < 0 = none, else its order
 std::atomic<int> g_depth_table_anchors{-1}; // ... with anchors: -1 = by the table's margin over log4(rows), 0 = no, 1 = yes
+
+bool plan_enabled(const kbo_index *idx)
+{
+    const int v = idx ? idx->opts.plan.load() : kOptInherit;
+    return v == kOptInherit ? g_plan_enabled.load() : v != 0;
+}
+int depth_table_setting(const kbo_index *idx)
+{
+    const int v = idx ? idx->opts.depth_table.load() : kOptInherit;
+    return v == kOptInherit ? g_depth_table.load() : v;
+}
+int depth_table_anchor_setting(const kbo_index *idx)
+{
+    const int v = idx ? idx->opts.depth_table_anchors.load() : kOptInherit;
+    return v == kOptInherit ? g_depth_table_anchors.load() : v;
+}
 std::atomic<bool> g_plan_stats{false};
 std::atomic<uint64_t> g_plan_table_budget{0}; // bytes a copy's seed + depth tables may take while they are built: 0 = half of what is free
 std::atomic<int64_t> g_plan_lazy_bases{-1};   // bases through a copy before it builds its plan structures: -1 = by index size, 0 = at once
@@ -112,7 +128,7 @@ void build_plan_structures(kbo_index *idx, DevCopy *dc)
     // the plain walk are many enough for the anchors to pay - C4, margin 3.05: A1 per 100 M reads 76.7 -> 67.1 ms; C3, 3.7:
     // 6.80 -> 6.55; C2, 3.9: 0.62 -> 0.66, slower - and only on indexes of 24 Mi rows and more)
     if ((double)order < lg + 1.9 && order < (int)idx->host.k) order = 0;
-    const int set = g_depth_table.load();
+    const int set = depth_table_setting(idx);
     if (set < 0) order = 0;
     else if (set > 0) order = std::min<int>({set, 17, (int)idx->host.k});
     if (const char *e = std::getenv("KBO_DEPTH_TABLE")) // experiments
@@ -199,7 +215,7 @@ void build_plan_structures(kbo_index *idx, DevCopy *dc)
         // what a base deeper than the table knows is read off (dtab_kernels.hip)
         const uint32_t abits = kbo::dtab_anchor_bits(idx->host.n_sets, (uint32_t)order);
         static const int env_anchor = std::getenv("KBO_DEPTH_TABLE_ANCHORS") ? std::atoi(std::getenv("KBO_DEPTH_TABLE_ANCHORS")) : -1; // experiments
-        const int anch_set = env_anchor >= 0 ? env_anchor : g_depth_table_anchors.load();
+        const int anch_set = env_anchor >= 0 ? env_anchor : depth_table_anchor_setting(idx);
         const bool want_anchors = anch_set > 0 || (anch_set < 0 && thin_margin);
         if (want_anchors && order < (int)idx->host.k) {
             dc->anchor.alloc(((size_t)1 << abits) * 8 + 64);
@@ -337,7 +353,8 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
     DevCopy *dc = it->second;
     // ---- the plan structures: at once when asked for (kbo_index_to_device) or cheap, else once the copy has seen the bases that
     // pay for them (plan_break_even_bases); a copy that may not hold them walks plainly, with the same results
-    if (!dc->plan_built && g_plan_enabled && !idx->transient) {
+    const bool plan_on = plan_enabled(idx); // (this index's own option first: kbo_index_set_opts)
+    if (!dc->plan_built && plan_on && !idx->transient) {
         dc->bases_seen += work_bases;
         if (prepare || dc->bases_seen >= plan_break_even_bases(idx)) {
             int prev = current_device();
@@ -361,11 +378,11 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
     v.big = dc->big ? 1u : 0u;
     v.n = (uint32_t)idx->host.n_sets;
     v.k = idx->host.k;
-    v.pc_text = dc->pc_text.p ? dc->pc_text.as<uint8_t>() + kbo::kPlanPad : nullptr;
+    v.pc_text = (plan_on && dc->pc_text.p) ? dc->pc_text.as<uint8_t>() + kbo::kPlanPad : nullptr; // (no text, no planned launch: attach_plan)
     v.pc_pos = dc->pc_pos.as<uint32_t>();
     v.seed_tab = dc->seed_d ? dc->seed_tab.as<uint2>() : nullptr;
     v.seed_d = dc->seed_d;
-    const bool use_tab = dc->dtab_order != 0 && g_depth_table.load() >= 0; // (kbo_set_depth_table(-1): launches ignore it)
+    const bool use_tab = dc->dtab_order != 0 && depth_table_setting(idx) >= 0; // (set to -1 since the copy was made: launches ignore it)
     v.dtab = use_tab ? dc->dtab.as<uint8_t>() : nullptr;
     v.dtab_order = use_tab ? dc->dtab_order : 0u;
     v.dtab_grouped = dc->dtab_grouped ? 1u : 0u;
@@ -411,7 +428,7 @@ void attach_plan(kbo::WalkArgs &a, void *plan_work, DevCopy::PlanState *ps)
     if (a.call_sites && !env_pc) return;
     a.unit_bail = 0;
     a.unit_cap = a.plan_dmin = a.plan_cap = a.plan_gap = a.plan_chunk = 0;
-    if (!g_plan_enabled || !plan_work || !a.ix.pc_text || (a.lo_out && a.hi_out) || a.n_items == 0) return;
+    if (!plan_work || !a.ix.pc_text || (a.lo_out && a.hi_out) || a.n_items == 0) return;
     if (ps) {
         const uint32_t epoch = g_plan_epoch.load();
         if (ps->epoch.exchange(epoch) != epoch) { // an explicit kbo_set_plan(1, ..) since: plan the next launch

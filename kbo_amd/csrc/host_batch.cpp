@@ -17,6 +17,14 @@ std::vector<int> devices_snapshot()
     std::lock_guard<std::mutex> g(g_devices_mu);
     return g_devices;
 }
+std::vector<int> devices_for(kbo_index *idx)
+{
+    if (idx) {
+        std::lock_guard<std::mutex> g(idx->mu);
+        if (idx->opts.n_devices >= 0) return idx->opts.devices;
+    }
+    return devices_snapshot();
+}
 
 // ---- work decomposition ------------------------------------------------------------------
 // Reads become one item each.  Longer sequences are cut into chunks that restart the walk
@@ -247,7 +255,12 @@ std::vector<Slab> make_slabs(const uint64_t *offsets, size_t n_seqs, size_t max_
 // spends 0.4 ms in kernels, 21 Gbp/s, one of 894 k reads 1.1 ms, 122 Gbp/s), so slabs that start small and grow - tried, to
 // shorten the pipeline's unhidden first upload and last download - lose more than they hide (tools/bench_host.py PACKED=1,
 // 600 Mbp: equal slabs of 32 / 64 / 128 MiB of bases 58 / 72 / 81 Gbp/s, ramped 8 .. 128 MiB 69).
-size_t packed_slab_bytes() { return std::min<size_t>(4 * g_slab_bytes.load(), 0xC0000000ull); }
+size_t slab_bytes_for(const kbo_index *idx)
+{
+    const size_t v = idx ? idx->opts.slab_bytes.load() : 0;
+    return v ? v : g_slab_bytes.load();
+}
+size_t packed_slab_bytes(const kbo_index *idx) { return std::min<size_t>(4 * slab_bytes_for(idx), 0xC0000000ull); }
 
 // one pass over the offsets of a batch: order, emptiness, shortest and longest sequence
 OffsetScan scan_offsets(const uint64_t *offsets, size_t n_seqs)
@@ -872,8 +885,8 @@ void matches_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *o
     KBO_REQUIRE(threshold > 1, KBO_E_THRESHOLD_LE_1, "threshold > 1 (derandomize.rs:275, translate.rs:269)");
     KBO_REQUIRE(scan.shortest > 2, KBO_E_LEN_LE_2, "len > 2 (derandomize.rs:276, translate.rs:270)");
     clk.lap("argument checks");
-    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
-    std::vector<int> devices = devices_snapshot();
+    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, slab_bytes_for(idx));
+    std::vector<int> devices = devices_for(idx);
     if (devices.empty()) devices.push_back(current_device());
     const size_t nd = std::min(devices.size(), std::max<size_t>(1, slabs.size()));
     BatchJob job;
@@ -928,8 +941,8 @@ void matches_batch_packed_impl(kbo_index *idx, const PackedBatch &in, const uint
         KBO_REQUIRE(in.exc_pos[x] < offsets[n_seqs] && (x == 0 || in.exc_pos[x] > in.exc_pos[x - 1]), KBO_E_BAD_ARG,
                     "exception positions must ascend and lie inside the batch");
     clk.lap("argument checks");
-    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, packed_slab_bytes());
-    std::vector<int> devices = devices_snapshot();
+    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, packed_slab_bytes(idx));
+    std::vector<int> devices = devices_for(idx);
     if (devices.empty()) devices.push_back(current_device());
     const size_t nd = std::min(devices.size(), std::max<size_t>(1, slabs.size()));
     std::vector<uint64_t> pw;
@@ -994,8 +1007,8 @@ void ms_batch_impl(kbo_index *idx, const uint8_t *concat, const uint64_t *offset
     KBO_REQUIRE(scan.longest < 0xFFFFFFFFull, KBO_E_UNSUPPORTED, "sequence longer than 2^32-1");
     PhaseClock clk;
     // intervals cost 8 more bytes per base on the device and on the way back: smaller slabs
-    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, lo_out ? std::max<size_t>(1u << 16, g_slab_bytes.load() / 4) : g_slab_bytes.load());
-    std::vector<int> devices = devices_snapshot();
+    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, lo_out ? std::max<size_t>(1u << 16, slab_bytes_for(idx) / 4) : slab_bytes_for(idx));
+    std::vector<int> devices = devices_for(idx);
     if (devices.empty()) devices.push_back(current_device());
     const size_t nd = std::min(devices.size(), std::max<size_t>(1, slabs.size()));
     BatchJob job;

@@ -404,11 +404,11 @@ int kbo_index_save(const kbo_index_t *idx_c, const char *path)
         KBO_REQUIRE(idx && path, KBO_E_BAD_ARG, "null argument");
         std::lock_guard<std::mutex> g(idx->mu);
         require_unsharded(idx, "kbo_index_save");
-        if (g_plan_enabled && !idx->cover && !idx->transient && idx->host.n_sets < 0xFFFFFFF0ull) {
+        if (plan_enabled(idx) && !idx->cover && !idx->transient && idx->host.n_sets < 0xFFFFFFF0ull) {
             idx->cover.reset(new kbo::PathCover());
             kbo::make_path_cover(idx->host, *idx->cover);
         }
-        kbo::save_host_index(idx->host, path, g_plan_enabled ? idx->cover.get() : nullptr);
+        kbo::save_host_index(idx->host, path, plan_enabled(idx) ? idx->cover.get() : nullptr);
     });
     return rc == KBO_E_BAD_ARG && idx && path ? KBO_E_IO : rc;
 }
@@ -850,7 +850,7 @@ size_t find_batch_impl(kbo_index_t *idx, const uint8_t *concat, const uint64_t *
         return sink.all_used;
     }
     // several devices: slabs completed out of order and were kept per slab; put them together
-    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, g_slab_bytes);
+    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, slab_bytes_for(idx));
     std::vector<uint64_t> base(slabs.size() + 1, 0);
     for (size_t i = 0; i < slabs.size(); i++) base[i + 1] = base[i] + sink.runs[i].size();
     kbo_rle *all = buf;
@@ -988,7 +988,7 @@ int kbo_find_batch_packed(kbo_index_t *idx, const uint32_t *words, const uint64_
             return;
         }
         // several devices: slabs completed out of order and were kept per slab; put them together
-        const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, packed_slab_bytes()); // (as matches_batch_packed_impl)
+        const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, packed_slab_bytes(idx)); // (as matches_batch_packed_impl)
         std::vector<uint64_t> base(slabs.size() + 1, 0);
         for (size_t i = 0; i < slabs.size(); i++) base[i + 1] = base[i] + sink.runs32[i].size() / kRleWords;
         uint32_t *all = static_cast<uint32_t *>(std::malloc(std::max<uint64_t>(1, base.back()) * kRleWords * sizeof(uint32_t)));
@@ -1408,6 +1408,69 @@ int kbo_set_devices(const int *devices, int n)
         for (int i = 0; i < n; i++) KBO_REQUIRE(devices[i] >= 0 && devices[i] < count, KBO_E_BAD_ARG, "no such device");
         std::lock_guard<std::mutex> g(g_devices_mu);
         g_devices.assign(devices, devices + n);
+    });
+}
+
+// ---- per-handle options
+int kbo_index_opts_default(kbo_index_opts_t *opts)
+{
+    return guarded([&] {
+        KBO_REQUIRE(opts, KBO_E_BAD_ARG, "null argument");
+        std::memset(opts, 0, sizeof *opts);
+        opts->struct_size = (uint32_t)sizeof *opts;
+        opts->plan = opts->depth_table = opts->depth_table_anchors = KBO_OPT_INHERIT;
+        opts->n_devices = -1;
+    });
+}
+
+namespace {
+void apply_opts(kbo_index *idx, const kbo_index_opts_t &o)
+{
+    idx->opts.plan = o.plan == KBO_OPT_INHERIT ? kOptInherit : (o.plan != 0 ? 1 : 0);
+    idx->opts.depth_table = o.depth_table == KBO_OPT_INHERIT ? kOptInherit : (o.depth_table < 0 ? -1 : std::min(o.depth_table, 17));
+    idx->opts.depth_table_anchors =
+        o.depth_table_anchors == KBO_OPT_INHERIT ? kOptInherit : (o.depth_table_anchors < 0 ? -1 : (o.depth_table_anchors != 0 ? 1 : 0));
+    idx->opts.slab_bytes = o.slab_bytes ? std::max<size_t>(1u << 16, std::min<size_t>(o.slab_bytes, 0xF0000000ull)) : 0;
+    {
+        std::lock_guard<std::mutex> g(idx->mu);
+        idx->opts.n_devices = o.n_devices;
+        idx->opts.devices.assign(o.devices, o.devices + std::max(0, o.n_devices));
+    }
+    if (o.plan != KBO_OPT_INHERIT && o.plan != 0) plan_reset_holdoff();
+    for (auto &sh : idx->shards) apply_opts(sh.get(), o); // (a sharded index: its shards are what gets copied and walked)
+}
+} // namespace
+
+int kbo_index_set_opts(kbo_index_t *idx, const kbo_index_opts_t *opts)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && opts, KBO_E_BAD_ARG, "null argument");
+        KBO_REQUIRE(opts->struct_size == sizeof *opts, KBO_E_BAD_ARG, "kbo_index_opts_t: struct_size is not this library's (fill it with kbo_index_opts_default)");
+        KBO_REQUIRE(opts->n_devices >= -1 && opts->n_devices <= KBO_OPT_MAX_DEVICES, KBO_E_BAD_ARG, "n_devices: -1 .. KBO_OPT_MAX_DEVICES");
+        if (opts->n_devices > 0) {
+            int count = 0;
+            HIP_OK(hipGetDeviceCount(&count));
+            for (int i = 0; i < opts->n_devices; i++) KBO_REQUIRE(opts->devices[i] >= 0 && opts->devices[i] < count, KBO_E_BAD_ARG, "no such device");
+        }
+        apply_opts(idx, *opts);
+    });
+}
+
+int kbo_index_get_opts(const kbo_index_t *idx_c, kbo_index_opts_t *opts)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx_c && opts, KBO_E_BAD_ARG, "null argument");
+        kbo_index *idx = const_cast<kbo_index *>(idx_c);
+        std::memset(opts, 0, sizeof *opts);
+        opts->struct_size = (uint32_t)sizeof *opts;
+        auto out = [](int v) { return v == kOptInherit ? KBO_OPT_INHERIT : v; };
+        opts->plan = out(idx->opts.plan.load());
+        opts->depth_table = out(idx->opts.depth_table.load());
+        opts->depth_table_anchors = out(idx->opts.depth_table_anchors.load());
+        opts->slab_bytes = idx->opts.slab_bytes.load();
+        std::lock_guard<std::mutex> g(idx->mu);
+        opts->n_devices = idx->opts.n_devices;
+        for (int i = 0; i < idx->opts.n_devices; i++) opts->devices[i] = idx->opts.devices[(size_t)i];
     });
 }
 

@@ -73,6 +73,34 @@ class SbwtIndexVariant:
         check(lib().kbo_index_device_layout(self._h, device, C.byref(lay)))
         return lay.as_dict()
 
+    def set_opts(self, plan=None, depth_table=None, depth_table_anchors=None, slab_bytes=None, devices=None):
+        """options of this handle alone (kbo_hip.h kbo_index_opts_t); None = leave the field as it is.  To follow the process-wide
+        setting again pass _capi.OPT_INHERIT (devices: -1)."""
+        o = _capi.IndexOpts()
+        check(lib().kbo_index_get_opts(self._h, C.byref(o)))
+        if plan is not None:
+            o.plan = int(plan)
+        if depth_table is not None:
+            o.depth_table = int(depth_table)
+        if depth_table_anchors is not None:
+            o.depth_table_anchors = int(depth_table_anchors)
+        if slab_bytes is not None:
+            o.slab_bytes = int(slab_bytes)
+        if devices is not None:
+            if devices == -1:
+                o.n_devices = -1
+            else:
+                o.n_devices = len(devices)
+                for i, d in enumerate(devices):
+                    o.devices[i] = int(d)
+        check(lib().kbo_index_set_opts(self._h, C.byref(o)))
+
+    def get_opts(self):
+        o = _capi.IndexOpts()
+        check(lib().kbo_index_get_opts(self._h, C.byref(o)))
+        return {"plan": o.plan, "depth_table": o.depth_table, "depth_table_anchors": o.depth_table_anchors, "slab_bytes": int(o.slab_bytes),
+                "devices": None if o.n_devices < 0 else [int(o.devices[i]) for i in range(o.n_devices)]}
+
     def export_parts(self):
         """(rows[4] uint64 words, C[4], lcs bytes) — the abstract index content."""
         n = self.n_sets()

@@ -145,6 +145,29 @@ def test_empty_query_and_map_opts_checks():
     assert e.value.code == -6
 
 
+def test_index_opts_round_trip_and_checks(tmp_path):
+    """kbo_index_opts_t needs no GPU until a batch runs: defaults inherit everything, set / get round trip, the struct's size and
+    the device count are checked"""
+    L = kbo_amd.lib()
+    o = _capi.IndexOpts()
+    kbo_amd.check(L.kbo_index_opts_default(C.byref(o)))
+    assert o.struct_size == C.sizeof(_capi.IndexOpts) and o.plan == o.depth_table == o.depth_table_anchors == _capi.OPT_INHERIT
+    assert o.slab_bytes == 0 and o.n_devices == -1
+    sbwt, _ = kbo_amd.build([b"ACGTTGCATGCATGCAAGTCGATCGATTTGACCATG" * 3], kbo_amd.BuildOpts(k=7))
+    assert sbwt.get_opts() == {"plan": _capi.OPT_INHERIT, "depth_table": _capi.OPT_INHERIT, "depth_table_anchors": _capi.OPT_INHERIT,
+                               "slab_bytes": 0, "devices": None}
+    sbwt.set_opts(plan=0, depth_table=99, depth_table_anchors=5, slab_bytes=1, devices=[])
+    assert sbwt.get_opts() == {"plan": 0, "depth_table": 17, "depth_table_anchors": 1, "slab_bytes": 1 << 16, "devices": []}
+    sbwt.set_opts(depth_table=-5)
+    assert sbwt.get_opts()["depth_table"] == -1 and sbwt.get_opts()["plan"] == 0
+    o.struct_size = 12
+    assert L.kbo_index_set_opts(sbwt._h, C.byref(o)) == -4
+    kbo_amd.check(L.kbo_index_opts_default(C.byref(o)))
+    o.n_devices = 17
+    assert L.kbo_index_set_opts(sbwt._h, C.byref(o)) == -4
+    assert L.kbo_index_set_opts(None, C.byref(o)) == -4 and L.kbo_index_get_opts(sbwt._h, None) == -4
+
+
 def test_compute_fails_loudly_without_gpu():
     """No CPU fallback: on a machine without a HIP device every compute call is an error."""
     import torch

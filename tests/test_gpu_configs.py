@@ -277,6 +277,54 @@ def test_hold_off_is_per_index(oracle, plan_restore):
     assert state(a)[1] == 0
 
 
+def test_options_are_per_handle(oracle, plan_restore):
+    """kbo_index_set_opts: two indexes of one process with different settings of what used to be process-wide only - plan on / off,
+    the depth table's order, the slab size and the devices of host batches.  Same results from every one of them."""
+    import torch
+    g = synth.genome(300_000, seed=51)
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    concat, offsets = synth.reads(g, 30_000, 150, 0.01, seed=3)
+    exp_chars, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=_threads(), want_d=True)
+    a, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
+    b, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
+    c, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
+    a.set_opts(plan=0)
+    b.set_opts(depth_table=11, depth_table_anchors=1, slab_bytes=1 << 20, devices=[0])
+    assert a.get_opts()["plan"] == 0 and c.get_opts()["plan"] == kbo_amd._capi.OPT_INHERIT and b.get_opts()["devices"] == [0]
+    for ix in (a, b, c):
+        ix.to_device(-1)
+    assert a.device_plan_bytes() == 0 and a.depth_table_order() == 0          # no cover, no tables: the plain walk
+    assert b.depth_table_order() == 11 and b.device_layout()["anchor_bytes"] > 0
+    assert c.depth_table_order() not in (0, 11) and c.device_layout()["anchor_bytes"] == 0  # the shipped choice for this size
+    fused = {}
+    for name, ix in (("a", a), ("b", b), ("c", c)):
+        assert np.array_equal(batch.matches_batch(ix, concat, offsets), exp_chars), name  # (b: 5 slabs of 1 MiB)
+        dev = batch.DeviceBatch(ix, concat, offsets, device=torch.device("cuda:0"), format=False, want_ms=True)
+        dev.run()
+        torch.cuda.synchronize()
+        fused[name] = dev.fused
+        assert np.array_equal(dev.chars[:dev.total].cpu().numpy(), exp_chars) and np.array_equal(dev.ms[:dev.total].cpu().numpy(), exp_d), name
+    assert fused == {"a": False, "b": True, "c": True}
+    # switched off on a handle whose copy has the structures: its launches stop planning at once; switched on again: they plan again
+    c.set_opts(plan=0)
+    dev = batch.DeviceBatch(c, concat, offsets, device=torch.device("cuda:0"), format=False, want_ms=True)
+    dev.run()
+    torch.cuda.synchronize()
+    assert not dev.fused and np.array_equal(dev.chars[:dev.total].cpu().numpy(), exp_chars)
+    c.set_opts(plan=kbo_amd._capi.OPT_INHERIT)
+    dev.run()
+    torch.cuda.synchronize()
+    assert dev.fused and np.array_equal(dev.chars[:dev.total].cpu().numpy(), exp_chars)
+    # the process-wide switch still rules the handles that inherit, and only those
+    plan_restore.kbo_set_plan(0, 0, 0)
+    b.set_opts(plan=1)
+    for ix, want in ((b, True), (c, False)):
+        dev = batch.DeviceBatch(ix, concat, offsets, device=torch.device("cuda:0"), format=False, want_ms=True)
+        dev.run()
+        torch.cuda.synchronize()
+        assert dev.fused == want and np.array_equal(dev.chars[:dev.total].cpu().numpy(), exp_chars)
+
+
 def test_call_batch_equals_per_sequence_call(oracle):
     """kbo_call_batch (first pass + breakpoint scan on the device for the whole batch) against kbo::call per sequence:
     the oracle's literal restatement, and the single-sequence entry point.  Reads with substitutions, insertions and
