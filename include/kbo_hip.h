@@ -385,6 +385,20 @@ int kbo_map_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
 int kbo_map_batch_dev_tail(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
                            size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
                            void *d_work, size_t work_bytes, void *stream, void *tail_stream, int *fused);
+/* kbo::matches (lib.rs:612-628) over a device-resident PACKED batch of reads (the layout of kbo_matches_batch_packed: kbo_packed_words()
+ * words, every read starts a word; d_offsets counts bases), through the one kernel's packed-native form: the words go into the kernel
+ * as they are and the characters leave it as words (M, -, X, R = 0 .. 3) - a quarter of a byte per base each way; only the reads it
+ * leaves to the second pass are ever unpacked.  uniform_len = the length of every read if they are all equally long, else 0;
+ * d_exc_pos / d_exc_byte / n_exc: the non-ACGT list on the device (positions in base coordinates, ascending) or NULL / 0;
+ * d_scratch: kbo_matches_packed_dev_scratch_bytes() bytes, 16-byte aligned; d_work / work_bytes as for kbo_ms_batch_dev;
+ * tail_stream as for kbo_map_batch_dev_tail (pass `stream` for one stream).  KBO_E_UNSUPPORTED when the batch or this copy of
+ * the index cannot take that kernel (reads longer than 160 bases, no depth table, a threshold below the table's order):
+ * kbo_matches_batch_packed takes any batch. */
+size_t kbo_matches_packed_dev_scratch_bytes(size_t n_seqs, uint64_t total_bases);
+int kbo_matches_packed_dev(kbo_index_t *idx, const uint32_t *d_words, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
+                           size_t max_seq_len, size_t uniform_len, const uint64_t *d_exc_pos, const uint8_t *d_exc_byte, size_t n_exc,
+                           double max_error_prob, uint32_t *d_words_out, void *d_scratch, void *d_work, size_t work_bytes, void *stream,
+                           void *tail_stream);
 /* format::run_lengths_gapped over device-resident characters (the output of kbo_derand_translate_dev
  * without d_ref), enqueued on `stream`.  d_work: kbo_run_lengths_work_bytes(n_seqs) bytes; afterwards
  * word s of d_work plus word (n_seqs + 1 + s / 1024) is the index of sequence s's first run, and the

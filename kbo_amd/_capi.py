@@ -102,7 +102,7 @@ SYMBOLS = [
     "kbo_index_save_sbwt", "kbo_index_load_sbwt", "kbo_packed_words", "kbo_pack_reads", "kbo_unpack_matches",
     "kbo_matches_batch_packed", "kbo_find_batch_packed", "kbo_index_shards", "kbo_index_work_bytes",
     "kbo_index_device_layout", "kbo_map_batch_dev", "kbo_map_batch_dev_tail",
-    "kbo_index_opts_default", "kbo_index_set_opts", "kbo_index_get_opts",
+    "kbo_index_opts_default", "kbo_index_set_opts", "kbo_index_get_opts", "kbo_matches_packed_dev", "kbo_matches_packed_dev_scratch_bytes",
 ]
 # ... and include/kbo_hip_tuning.h (knobs, experiment switches, test hooks: not part of the drop-in boundary)
 TUNING_SYMBOLS = [
@@ -231,6 +231,9 @@ def lib():
     L.kbo_set_stage_timing.argtypes = [C.c_int]
     L.kbo_stage_timing_read.argtypes = [C.POINTER(dbl), C.POINTER(dbl), C.POINTER(C.c_int)]
     L.kbo_map_batch_dev.argtypes = [vp, vp, vp, sz, u64, sz, dbl, C.c_int, C.c_int, vp, vp, vp, sz, vp, C.POINTER(C.c_int)]
+    L.kbo_matches_packed_dev_scratch_bytes.argtypes = [sz, u64]
+    L.kbo_matches_packed_dev_scratch_bytes.restype = sz
+    L.kbo_matches_packed_dev.argtypes = [vp, vp, vp, sz, u64, sz, sz, vp, vp, sz, dbl, vp, vp, vp, sz, vp, vp]
     L.kbo_index_opts_default.argtypes = [C.POINTER(IndexOpts)]
     L.kbo_index_set_opts.argtypes = [vp, C.POINTER(IndexOpts)]
     L.kbo_index_get_opts.argtypes = [vp, C.POINTER(IndexOpts)]

@@ -160,6 +160,47 @@ def variants_of(res, s):
     return out
 
 
+class PackedDeviceBatch:
+    """A batch of reads resident in HBM as 2-bit words (kbo_hip.h kbo_matches_packed_dev): run() = kbo::matches through the one
+    kernel's packed-native form, the characters as 2-bit words in self.words_out (unpack_matches() for bytes)."""
+
+    def __init__(self, sbwt, concat, offsets, device, max_error_prob=1e-7):
+        import torch
+        self.torch, self.sbwt, self.device = torch, sbwt, device
+        concat, offsets, n = _prep(concat, offsets)
+        self.offsets = offsets
+        self.n_seqs, self.total = n, int(offsets[-1])
+        lens = np.diff(offsets.astype(np.int64))
+        self.max_len = int(lens.max()) if n else 0
+        self.uniform_len = self.max_len if n and int(lens.min()) == self.max_len else 0
+        self.max_error_prob = max_error_prob
+        words, pos, byt = pack_reads(concat, offsets)
+        self.n_exc = len(pos)
+        with torch.cuda.device(device):
+            sbwt.to_device(-1)
+            self.words = torch.from_numpy(words.view(np.int32)).to(device)
+            self.words_out = torch.zeros(len(words) + 4, dtype=torch.int32, device=device)
+            self.off = torch.from_numpy(offsets.view(np.int64)).to(device)
+            self.exc_pos = torch.from_numpy(pos.view(np.int64)).to(device) if self.n_exc else None
+            self.exc_byte = torch.from_numpy(byt).to(device) if self.n_exc else None
+            self.scratch = torch.zeros(int(lib().kbo_matches_packed_dev_scratch_bytes(n, self.total)) // 8 + 2, dtype=torch.int64, device=device)
+            self.work_bytes = int(lib().kbo_index_work_bytes(sbwt._h, n, self.total, self.max_len))
+            self.work = torch.zeros(self.work_bytes // 8 + 2, dtype=torch.int64, device=device)
+
+    def run(self, stream=None, tail_stream=None):
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        t = tail_stream if tail_stream is not None else s
+        check(lib().kbo_matches_packed_dev(self.sbwt._h, self.words.data_ptr(), self.off.data_ptr(), self.n_seqs, self.total, self.max_len,
+                                           self.uniform_len, self.exc_pos.data_ptr() if self.n_exc else None,
+                                           self.exc_byte.data_ptr() if self.n_exc else None, self.n_exc, self.max_error_prob,
+                                           self.words_out.data_ptr(), self.scratch.data_ptr(), self.work.data_ptr(), self.work_bytes,
+                                           s.cuda_stream, t.cuda_stream))
+
+    def chars(self):
+        """the characters as bytes, on the host"""
+        return unpack_matches(self.words_out[:len(self.words)].cpu().numpy().view(np.uint32), self.offsets)
+
+
 class DeviceBatch:
     """A batch of reads resident in HBM (torch owns the memory, the C ABI gets raw
     pointers and the torch stream).  run() = A1 walk kernel, then fused A5+A6 kernel."""

@@ -176,11 +176,12 @@ size_t random_match_threshold(size_t k, size_t n_kmers, size_t alphabet_size, do
 struct BatchOnDevice {
     DevBuf q, off, items, ms, lo, hi, plan;
     DevBuf ms_shard; // sharded indexes: the MS values of one further shard, folded into `ms` by maximum
-    DevBuf packed, pscr, exc_pos, exc_byte, packed_out; // packed entry points: 2-bit words in, scanned words per sequence, non-ACGT list, 2-bit words out
+    DevBuf packed, pscr, exc_pos, exc_byte, packed_out, exc_flag; // (exc_flag: one byte per read of a packed-native launch)
+    // packed entry points: 2-bit words in, scanned words per sequence, non-ACGT list, 2-bit words out
     uint64_t total = 0;
     void release()
     {
-        for (DevBuf *b : {&q, &off, &items, &ms, &lo, &hi, &plan, &packed, &pscr, &exc_pos, &exc_byte, &packed_out, &ms_shard}) b->release();
+        for (DevBuf *b : {&q, &off, &items, &ms, &lo, &hi, &plan, &packed, &pscr, &exc_pos, &exc_byte, &packed_out, &exc_flag, &ms_shard}) b->release();
     }
 };
 // a slab of a packed batch (pack_kernels.hip: sequence s = ceil(len / 16) u32 words, 2 bits per base): what
@@ -252,6 +253,15 @@ struct FusedMap {
     uint32_t threshold;
     bool format;        // + format::relative_to_ref
     bool done = false;
+    // a packed batch whose characters leave packed as well: where their words go (nw words + 16 bytes); packed_done = the kernel
+    // wrote them there itself (its packed-native form), else the characters are in d_chars as for any batch
+    uint32_t *d_packed_out = nullptr;
+    bool packed_done = false;
+    // a second stream for the second pass (the plain walk of the reads the kernel leaves), so that the next slab's kernel need
+    // not wait for it, and an event to order it behind the kernel; `results` = the stream the slab's characters are complete on
+    hipStream_t tail = nullptr;
+    hipEvent_t fence = nullptr;
+    hipStream_t results = nullptr;
 };
 void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, bool want_ival,
                        BatchOnDevice &B, std::vector<kbo::WalkItem> &items_keep, hipStream_t stream,

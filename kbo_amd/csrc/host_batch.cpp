@@ -169,12 +169,32 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
             B.pscr.ensure(kbo::chunk_items_scratch_words((uint32_t)n_seqs) * sizeof(uint32_t));
             HIP_OK(kbo::launch_packed_prefix(B.off.as<uint64_t>(), (uint32_t)n_seqs, B.pscr.as<uint32_t>(), stream));
         }
-        HIP_OK(kbo::launch_unpack2(B.packed.as<uint32_t>(), (uint32_t)packed->n_words, B.off.as<uint64_t>(), (uint32_t)n_seqs,
-                                   uniform ? (packed->uniform_len + 15u) / 16u : 0u, uniform ? nullptr : B.pscr.as<uint32_t>(),
-                                   B.q.as<uint8_t>(), stream));
+    }
+    // the bytes of a packed batch: only when something needs them (the one kernel takes the words as they are)
+    const uint32_t wps = uniform ? (packed->uniform_len + 15u) / 16u : 0u;
+    bool have_bytes = !packed;
+    auto need_bytes = [&] {
+        if (have_bytes) return;
+        have_bytes = true;
+        HIP_OK(kbo::launch_unpack2(B.packed.as<uint32_t>(), (uint32_t)packed->n_words, B.off.as<uint64_t>(), (uint32_t)n_seqs, wps,
+                                   uniform ? nullptr : B.pscr.as<uint32_t>(), B.q.as<uint8_t>(), stream));
         HIP_OK(kbo::launch_exceptions(B.exc_pos.as<uint64_t>(), B.exc_byte.as<uint8_t>(), (uint32_t)packed->n_exc, packed->base,
                                       B.q.as<uint8_t>(), stream));
-    }
+    };
+    static const int env_native = std::getenv("KBO_PACKED_NATIVE") ? std::atoi(std::getenv("KBO_PACKED_NATIVE")) : 1; // experiments
+    // (off: beside the copies and the next slabs' kernels the pass finishes late and the downloads wait for it - 600 Mbp host to host,
+    // packed 118 -> 95 Gbp/s, bytes 39 -> 40 Gbp/s with a tail stream of the highest priority, 78 / 26 Gbp/s with an ordinary one)
+    static const int env_tail = std::getenv("KBO_HOST_TAIL") ? std::atoi(std::getenv("KBO_HOST_TAIL")) : 0; // experiments
+    // the stream the second pass of the one-kernel route goes to: the caller's tail stream behind the kernel (kbo_capi.cpp
+    // map_batch_dev_impl has the pieces' size), or the kernel's own
+    auto second_pass_stream = [&](kbo::WalkArgs &a) -> hipStream_t {
+        if (!map || !map->tail || !map->fence || !env_tail) return stream;
+        HIP_OK(hipEventRecord(map->fence, stream));
+        HIP_OK(hipStreamWaitEvent(map->tail, map->fence, 0));
+        a.redo_piece = 32u;
+        map->results = map->tail;
+        return map->tail;
+    };
     if (device_items) HIP_OK(kbo::launch_make_items(B.off.as<uint64_t>(), (uint32_t)n_seqs, B.items.as<kbo::WalkItem>(), stream));
     for (size_t sh = 0; sh < shards.size(); sh++) {
         DevCopy::PlanState *plan_state = nullptr;
@@ -203,16 +223,50 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
             a.map_thr = map->threshold;
             a.map_fmt = map->format ? 1u : 0u;
             a.map_want_ms = 0;
+            if (packed && env_native && a.gitems && kbo::map_reads_packed_applies(a, map->d_packed_out != nullptr)) {
+                // packed-native: the words go into the kernel as they are and (kbo_matches_batch_packed) the characters leave it
+                // as words; only the reads it leaves to the plain walk get their bytes, and their characters are packed behind it
+                a.qp = B.packed.as<uint32_t>();
+                a.qp_wps = wps;
+                a.qp_data = uniform ? nullptr : B.pscr.as<uint32_t>();
+                a.qp_sums = uniform ? nullptr : B.pscr.as<uint32_t>() + n_seqs + 1u;
+                a.packed_out = map->d_packed_out;
+                if (packed->n_exc) {
+                    B.exc_flag.ensure(n_seqs + 16);
+                    HIP_OK(hipMemsetAsync(B.exc_flag.p, 0, n_seqs, stream));
+                    HIP_OK(kbo::launch_flag_exceptions(B.exc_pos.as<uint64_t>(), (uint32_t)packed->n_exc, packed->base, B.off.as<uint64_t>(),
+                                                       (uint32_t)n_seqs, B.exc_flag.as<uint8_t>(), stream));
+                    a.qp_exc = B.exc_flag.as<uint8_t>();
+                }
+                HIP_OK(kbo::launch_map_reads(a, stream));
+                hipStream_t ts = second_pass_stream(a);
+                HIP_OK(kbo::launch_unpack_flagged(a.qp, B.off.as<uint64_t>(), (uint32_t)n_seqs, wps, a.qp_data, a.redo, B.q.as<uint8_t>(), ts));
+                HIP_OK(kbo::launch_exceptions(B.exc_pos.as<uint64_t>(), B.exc_byte.as<uint8_t>(), (uint32_t)packed->n_exc, packed->base,
+                                              B.q.as<uint8_t>(), ts));
+                HIP_OK(kbo::launch_redo_pass(a, ts));
+                HIP_OK(kbo::launch_derand_flagged(B.ms.as<uint8_t>(), B.off.as<uint64_t>(), (uint32_t)n_seqs, idx->host.k, map->threshold,
+                                                  map->format ? B.q.as<uint8_t>() : nullptr, map->d_chars, a.redo, longest_seq, ts));
+                if (map->d_packed_out) {
+                    HIP_OK(kbo::launch_pack_flagged(map->d_chars, B.off.as<uint64_t>(), (uint32_t)n_seqs, wps, a.qp_data, a.redo, map->d_packed_out, ts));
+                    map->packed_done = true;
+                }
+                plan_after_launch(a, ts, plan_state);
+                map->done = true;
+                return;
+            }
+            need_bytes();
             if (a.gitems && kbo::map_reads_applies(a)) {
                 HIP_OK(kbo::launch_map_reads(a, stream));
-                HIP_OK(kbo::launch_redo_pass(a, stream));
+                hipStream_t ts = second_pass_stream(a);
+                HIP_OK(kbo::launch_redo_pass(a, ts));
                 HIP_OK(kbo::launch_derand_flagged(B.ms.as<uint8_t>(), B.off.as<uint64_t>(), (uint32_t)n_seqs, idx->host.k, map->threshold,
-                                                  map->format ? B.q.as<uint8_t>() : nullptr, map->d_chars, a.redo, longest_seq, stream));
-                plan_after_launch(a, stream, plan_state);
+                                                  map->format ? B.q.as<uint8_t>() : nullptr, map->d_chars, a.redo, longest_seq, ts));
+                plan_after_launch(a, ts, plan_state);
                 map->done = true;
                 return;
             }
         }
+        need_bytes();
         HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), stream));
         plan_after_launch(a, stream, plan_state);
         // the depth against the union of the shards is the maximum of the depths against each (capi_internal.hpp)
@@ -308,7 +362,7 @@ struct HostSlot {
     DevBuf chars;
     PinBuf in, out, off, lo_pin, hi_pin;
     std::vector<kbo::WalkItem> items;
-    hipEvent_t copied = nullptr, computed = nullptr, done = nullptr;
+    hipEvent_t copied = nullptr, computed = nullptr, done = nullptr, fence = nullptr;
     bool busy = false;     // a slab is in flight in this slot
     uint64_t out_b0 = 0, out_bytes = 0;
     // run-length output (kbo_find_batch): per-sequence first-run indices + block sums, the records,
@@ -324,21 +378,25 @@ struct HostCtx {
     // one stream per stage, so that every stage runs one slab at a time, in order, next to the
     // other two stages: upload (copy engine), kernels, download (copy kernel)
     hipStream_t st_up = nullptr, st_run = nullptr, st_down = nullptr;
+    hipStream_t st_tail = nullptr; // the second pass of the one-kernel route: beside the next slab's kernel
     explicit HostCtx(int d) : dev(d)
     {
         for (hipStream_t *st : {&st_up, &st_run, &st_down}) HIP_OK(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+        int pr_lo = 0, pr_hi = 0; // (the second pass is a chain of dependent look-ups of a few waves: it goes first wherever it can)
+        HIP_OK(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
+        HIP_OK(hipStreamCreateWithPriority(&st_tail, hipStreamNonBlocking, pr_hi));
         for (HostSlot &S : slot)
-            for (hipEvent_t *e : {&S.copied, &S.computed, &S.done}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+            for (hipEvent_t *e : {&S.copied, &S.computed, &S.done, &S.fence}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     ~HostCtx()
     {
         int prev = 0;
         (void)hipGetDevice(&prev);
         (void)hipSetDevice(dev);
-        for (hipStream_t st : {st_up, st_run, st_down})
+        for (hipStream_t st : {st_up, st_run, st_down, st_tail})
             if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
         for (HostSlot &S : slot)
-            for (hipEvent_t e : {S.copied, S.computed, S.done})
+            for (hipEvent_t e : {S.copied, S.computed, S.done, S.fence})
                 if (e) (void)hipEventDestroy(e);
         for (HostSlot &S : slot) { // buffers belong to `dev`
             S.B.release();
@@ -374,7 +432,7 @@ struct CtxLease { // takes a context of the device out of the pool (or makes one
             S.busy = false;
         }
         if (busy)
-            for (hipStream_t st : {ctx->st_up, ctx->st_run, ctx->st_down}) (void)hipStreamSynchronize(st);
+            for (hipStream_t st : {ctx->st_up, ctx->st_run, ctx->st_down, ctx->st_tail}) (void)hipStreamSynchronize(st);
         // keep at most kPooledPerDevice contexts per device (each holds ~0.8 GB of device and ~0.3 GB of
         // pinned memory at the default slab size); the scratch of further concurrent callers is freed
         std::unique_lock<std::mutex> g(g_ctx_mu);
@@ -590,12 +648,20 @@ private:
         }
         lap("  offsets + copy in");
         FusedMap fm{nullptr, job_.threshold, job_.format && !job_.sink};
+        fm.tail = C.st_tail;
+        fm.fence = S.fence;
         if (!job_.ms_out) { // kbo::matches / map / find: the characters' buffer first, so that the one kernel can write into it
             S.chars.ensure(((bytes + 15) / 16) * 16 + 32);
             fm.d_chars = S.chars.as<uint8_t>();
+            if (job_.packed_out && !job_.sink) { // (the words' buffer as well: the packed-native kernel writes them itself)
+                S.B.packed_out.ensure((size_t)(w1 - w0) * 4 + 16);
+                fm.d_packed_out = S.B.packed_out.as<uint32_t>();
+            }
         }
         enqueue_walk_host(job_.idx, src, off, ns, job_.lo_out != nullptr, S.B, S.items, C.st_run, mx, C.st_up, S.copied, nullptr,
                           job_.packed ? &pin : nullptr, job_.ms_out ? nullptr : &fm);
+        // (the one-kernel route with its second pass on the tail stream: what follows the characters follows them there)
+        hipStream_t st_res = (fm.done && fm.results) ? fm.results : C.st_run;
         if (job_.ms_out) { // A1 only: MS values (and intervals) straight back
             HIP_OK(hipEventRecord(S.computed, C.st_run));
             HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
@@ -622,7 +688,7 @@ private:
             // the room the slot has) emitted right behind A5/A6; the completing thread downloads them
             if (!fm.done)
                 derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, job_.k, job_.threshold,
-                                              nullptr, S.chars.as<uint8_t>(), nullptr, C.st_run, mx, &S.dt_work);
+                                              nullptr, S.chars.as<uint8_t>(), nullptr, st_res, mx, &S.dt_work);
             const uint32_t gap = (uint32_t)std::min<size_t>(job_.sink->max_gap_len, 0xFFFFFFFFu);
             S.rle_scratch.ensure(kbo::chunk_items_scratch_words((uint32_t)ns) * sizeof(uint32_t));
             S.rle_total.ensure(16);
@@ -632,13 +698,13 @@ private:
                 S.rles.ensure(S.rle_capacity * kRleWords * sizeof(uint32_t));
             }
             HIP_OK(kbo::launch_rle_count(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
-                                         S.rle_scratch.as<uint32_t>(), S.rle_total.as<uint32_t>(), C.st_run, mx));
-            HIP_OK(hipMemcpyAsync(S.rle_total_pin.p, S.rle_total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, C.st_run));
+                                         S.rle_scratch.as<uint32_t>(), S.rle_total.as<uint32_t>(), st_res, mx));
+            HIP_OK(hipMemcpyAsync(S.rle_total_pin.p, S.rle_total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_res));
             HIP_OK(kbo::launch_rle_emit(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
                                         S.rle_scratch.as<uint32_t>(), S.rles.as<uint32_t>(), (uint32_t)S.rle_capacity,
-                                        C.st_run, mx));
+                                        st_res, mx));
             S.longest = mx;
-            HIP_OK(hipEventRecord(S.computed, C.st_run));
+            HIP_OK(hipEventRecord(S.computed, st_res));
             HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
             S.slab_id = slab_id;
             S.n_seqs = ns;
@@ -655,14 +721,15 @@ private:
             if (!fm.done)
                 derand_translate_host_offsets(S.B.ms.as<uint8_t>(), S.B.off.as<uint64_t>(), off, ns, job_.k, job_.threshold,
                                               job_.format ? S.B.q.as<uint8_t>() : nullptr, S.chars.as<uint8_t>(), nullptr,
-                                              C.st_run, mx, &S.dt_work);
+                                              st_res, mx, &S.dt_work);
             if (job_.packed_out) { // the characters leave as 2-bit words: a quarter of the bytes
                 const size_t nw = (size_t)(w1 - w0);
                 S.B.packed_out.ensure(nw * 4 + 16);
-                HIP_OK(kbo::launch_pack2(S.chars.as<uint8_t>(), (uint32_t)nw, S.B.off.as<uint64_t>(), (uint32_t)ns,
-                                         job_.uniform_len ? (job_.uniform_len + 15u) / 16u : 0u,
-                                         job_.uniform_len ? nullptr : S.B.pscr.as<uint32_t>(), S.B.packed_out.as<uint32_t>(), C.st_run));
-                HIP_OK(hipEventRecord(S.computed, C.st_run));
+                if (!fm.packed_done)
+                    HIP_OK(kbo::launch_pack2(S.chars.as<uint8_t>(), (uint32_t)nw, S.B.off.as<uint64_t>(), (uint32_t)ns,
+                                             job_.uniform_len ? (job_.uniform_len + 15u) / 16u : 0u,
+                                             job_.uniform_len ? nullptr : S.B.pscr.as<uint32_t>(), S.B.packed_out.as<uint32_t>(), st_res));
+                HIP_OK(hipEventRecord(S.computed, st_res));
                 HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
                 uint8_t *pdst = reinterpret_cast<uint8_t *>(job_.packed_out + w0);
                 if (!job_.out_pinned) {
@@ -676,7 +743,7 @@ private:
                 S.out_bytes = nw * 4;
                 return;
             }
-            HIP_OK(hipEventRecord(S.computed, C.st_run));
+            HIP_OK(hipEventRecord(S.computed, st_res));
             HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
             HIP_OK(hipMemcpyAsync(dst, S.chars.p, bytes, hipMemcpyDeviceToHost, C.st_down));
             HIP_OK(hipEventRecord(S.done, C.st_down));

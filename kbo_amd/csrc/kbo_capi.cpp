@@ -1372,6 +1372,112 @@ int kbo_map_batch_dev_tail(kbo_index_t *idx, const uint8_t *d_concat, const uint
                               d_work, work_bytes, stream, tail_stream, true, fused);
 }
 
+namespace {
+struct PackedScratch { size_t q, ms, chars, pscr, exc, bytes; };
+PackedScratch packed_scratch(size_t n_seqs, uint64_t total_bases)
+{
+    auto up = [](size_t v) { return (v + 63) / 64 * 64; };
+    PackedScratch L{};
+    const size_t padded = up(total_bases + 32);
+    L.q = 0;
+    L.ms = L.q + padded;
+    L.chars = L.ms + padded;
+    L.pscr = L.chars + padded;
+    L.exc = L.pscr + up(kbo::chunk_items_scratch_words((uint32_t)n_seqs) * sizeof(uint32_t));
+    L.bytes = L.exc + up(n_seqs + 16);
+    return L;
+}
+} // namespace
+
+size_t kbo_matches_packed_dev_scratch_bytes(size_t n_seqs, uint64_t total_bases) { return packed_scratch(n_seqs, total_bases).bytes; }
+
+int kbo_matches_packed_dev(kbo_index_t *idx, const uint32_t *d_words, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
+                           size_t max_seq_len, size_t uniform_len, const uint64_t *d_exc_pos, const uint8_t *d_exc_byte, size_t n_exc,
+                           double max_error_prob, uint32_t *d_words_out, void *d_scratch, void *d_work, size_t work_bytes, void *stream,
+                           void *tail_stream)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && d_words && d_offsets && d_words_out && d_scratch && d_work, KBO_E_BAD_ARG, "null argument");
+        KBO_REQUIRE(n_exc == 0 || (d_exc_pos && d_exc_byte), KBO_E_BAD_ARG, "exception list missing");
+        KBO_REQUIRE(n_seqs > 0 && total_bases > 0, KBO_E_EMPTY_QUERY, "empty batch");
+        KBO_REQUIRE(n_seqs < (1ull << 28) && total_bases < 0xFFFFFF00ull && n_exc < 0xFFFFFFFFull, KBO_E_UNSUPPORTED,
+                    "one launch covers < 2^28 sequences and < 4 GiB of query: split the batch");
+        KBO_REQUIRE(((uintptr_t)d_scratch & 15) == 0 && ((uintptr_t)d_work & 15) == 0 && ((uintptr_t)d_words & 3) == 0 && ((uintptr_t)d_words_out & 3) == 0,
+                    KBO_E_BAD_ARG, "d_scratch/d_work must be 16-byte, the words 4-byte aligned");
+        KBO_REQUIRE(max_seq_len > 0 && max_seq_len <= 160 && !idx->sharded(), KBO_E_UNSUPPORTED,
+                    "kbo_matches_packed_dev: reads of at most 160 bases over an unsharded index (else: kbo_matches_batch_packed)");
+        const size_t threshold = random_match_threshold(idx->host.k, idx->host.n_kmers, 4, max_error_prob);
+        KBO_REQUIRE(threshold > 1, KBO_E_THRESHOLD_LE_1, "threshold > 1 (derandomize.rs:275)");
+        hipStream_t s = static_cast<hipStream_t>(stream), ts = static_cast<hipStream_t>(tail_stream);
+        const DevWork w = dev_work(n_seqs, total_bases, max_seq_len, idx->host.k);
+        KBO_REQUIRE(!w.chunked, KBO_E_UNSUPPORTED, "reads only");
+        KBO_REQUIRE(work_bytes >= w.bytes, KBO_E_BAD_ARG, "d_work is smaller than kbo_work_bytes() for this batch");
+        const PackedScratch L = packed_scratch(n_seqs, total_bases);
+        uint8_t *sc = static_cast<uint8_t *>(d_scratch);
+        uint8_t *q = sc + L.q, *ms = sc + L.ms, *chars = sc + L.chars, *exc = sc + L.exc;
+        uint32_t *pscr = uniform_len ? nullptr : reinterpret_cast<uint32_t *>(sc + L.pscr);
+        const uint32_t wps = uniform_len ? (uint32_t)((uniform_len + 15) / 16) : 0u;
+        DevCopy::PlanState *plan_state = nullptr;
+        const kbo::DevIndexView view = device_view(idx, current_device(), &plan_state, total_bases);
+        kbo::WalkItem *items = static_cast<kbo::WalkItem *>(d_work);
+        kbo::WalkArgs a{};
+        a.ix = view;
+        a.q = q;
+        a.q_bytes = total_bases;
+        a.items = items;
+        a.n_items = w.n_slots;
+        a.d_out = ms;
+        a.max_item_len = (uint32_t)max_seq_len;
+        attach_plan(a, static_cast<uint8_t *>(d_work) + w.plan_off, plan_state);
+        a.chars_out = chars;
+        a.map_thr = (uint32_t)threshold;
+        a.map_fmt = 0;
+        a.map_want_ms = 0;
+        KBO_REQUIRE(a.gitems && kbo::map_reads_packed_applies(a, true), KBO_E_UNSUPPORTED,
+                    "this copy of the index cannot take the packed-native kernel (no depth table, a held-off copy, a threshold below the "
+                    "table's order): kbo_matches_batch_packed takes any batch");
+        if (pscr) HIP_OK(kbo::launch_packed_prefix(d_offsets, (uint32_t)n_seqs, pscr, s));
+        HIP_OK(kbo::launch_make_items(d_offsets, (uint32_t)n_seqs, items, s));
+        a.qp = d_words;
+        a.qp_wps = wps;
+        a.qp_data = pscr;
+        a.qp_sums = pscr ? pscr + n_seqs + 1u : nullptr;
+        a.packed_out = d_words_out;
+        if (n_exc) {
+            HIP_OK(hipMemsetAsync(exc, 0, n_seqs, s));
+            HIP_OK(kbo::launch_flag_exceptions(d_exc_pos, (uint32_t)n_exc, 0, d_offsets, (uint32_t)n_seqs, exc, s));
+            a.qp_exc = exc;
+        }
+        const bool timing = g_stage_timing.load() != 0;
+        StageEvents ev{};
+        if (timing) {
+            ev = timing_take();
+            HIP_OK(hipEventRecord(ev.e0, s));
+        }
+        HIP_OK(kbo::launch_map_reads(a, s));
+        if (timing) HIP_OK(hipEventRecord(ev.e1, s));
+        if (ts != s) {
+            hipEvent_t fence = tail_fence();
+            HIP_OK(hipEventRecord(fence, s));
+            HIP_OK(hipStreamWaitEvent(ts, fence, 0));
+            static const bool env_piece = std::getenv("KBO_REDO_PIECE") != nullptr;
+            if (!env_piece) a.redo_piece = 32u;
+        }
+        if (timing) HIP_OK(hipEventRecord(ev.e1t, ts));
+        HIP_OK(kbo::launch_unpack_flagged(d_words, d_offsets, (uint32_t)n_seqs, wps, pscr, a.redo, q, ts));
+        HIP_OK(kbo::launch_exceptions(d_exc_pos, d_exc_byte, (uint32_t)n_exc, 0, q, ts));
+        HIP_OK(kbo::launch_redo_pass(a, ts));
+        HIP_OK(kbo::launch_derand_flagged(ms, d_offsets, (uint32_t)n_seqs, idx->host.k, (uint32_t)threshold, nullptr, chars, a.redo, (uint32_t)max_seq_len, ts));
+        HIP_OK(kbo::launch_pack_flagged(chars, d_offsets, (uint32_t)n_seqs, wps, pscr, a.redo, d_words_out, ts));
+        if (timing) {
+            HIP_OK(hipEventRecord(ev.e2, ts));
+            std::lock_guard<std::mutex> g(g_timing_mu);
+            g_timing_used.push_back(ev);
+        }
+        plan_after_launch(a, ts, plan_state);
+    });
+}
+
 int kbo_run_lengths_dev(const uint8_t *d_chars, const uint64_t *d_offsets, size_t n_seqs, size_t max_seq_len,
                         size_t max_gap_len, void *d_work, uint32_t *d_records, size_t capacity, void *stream)
 {

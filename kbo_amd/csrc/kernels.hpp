@@ -146,6 +146,14 @@ struct WalkArgs {
     // on the way out, 1 = the MS values go to d_out as well
     uint8_t *chars_out;
     uint32_t map_thr, map_fmt, map_want_ms;
+    // ... its packed-native instantiations (pack_kernels.hip has the layout): the reads as 2-bit words - qp_wps words per read, or
+    // 0 and the scanned words-per-read (qp_data / qp_sums) -, one byte per read that is non-zero where the read holds a byte that
+    // is no base (nullptr: none does), and, when the characters leave packed as well, where their words go
+    const uint32_t *qp;
+    uint32_t qp_wps;
+    const uint32_t *qp_data, *qp_sums;
+    const uint8_t *qp_exc;
+    uint32_t *packed_out;
 };
 // Work counters the plan-guided stage keeps about itself (one wave-level atomic per counter and wave, spread over slots):
 // what the CPU model of the stage (oracle/plan_model.c) is pinned to, tests/test_gpu_model.py
@@ -206,6 +214,16 @@ bool map_reads_applies(const WalkArgs &a);
 // the kernel; the reads it could not finish are flagged in a.redo (launch_redo_pass walks them, launch_derand_flagged
 // translates them)
 hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream);
+bool map_reads_direct(const WalkArgs &a);
+bool map_reads_packed_applies(const WalkArgs &a, bool packed_out); // (a.qp set: the reads as 2-bit words; a.packed_out: the characters too)
+// packed-native batches (pack_kernels.hip): exc[s] = 1 for every read that holds a listed byte (d_exc zeroed first); the bytes of the
+// flagged reads from their words (for the plain walk; the listed bytes then go over them: launch_exceptions); the characters of
+// the flagged reads into their words
+hipError_t launch_flag_exceptions(const uint64_t *d_pos, uint32_t n, uint64_t base, const uint64_t *d_off, uint32_t n_seqs, uint8_t *d_exc, hipStream_t stream);
+hipError_t launch_unpack_flagged(const uint32_t *d_packed, const uint64_t *d_off, uint32_t n_seqs, uint32_t uniform_wps, const uint32_t *d_scratch,
+                                 const uint8_t *d_flags, uint8_t *d_q, hipStream_t stream);
+hipError_t launch_pack_flagged(const uint8_t *d_chars, const uint64_t *d_off, uint32_t n_seqs, uint32_t uniform_wps, const uint32_t *d_scratch,
+                               const uint8_t *d_flags, uint32_t *d_packed, hipStream_t stream);
 // the list of the flagged items (redo_collect_kernel) and their plain walk; `a` as the plan launch left it
 hipError_t launch_redo_pass(WalkArgs a, hipStream_t stream);
 // A5 + A6 (+ relative_to_ref) for the sequences with flags[s] != 0 only, one lane each

@@ -115,7 +115,28 @@ constexpr uint32_t kMapSlack = 48;       // bytes of the byte region behind the 
 // C2 (15 bases, t = 22) and C3 (17, 24) - each not a suffix of any row (bit 7 of their entries clear), rule every such string
 // out: three byte look-ups per mismatch instead of the fourteen of the value-by-value rule, no rule to evaluate.  A read
 // without a seed has every string of t + 1 bases ruled out the same way (a window every cov bases): all its bases are '-'.
-template <int NP, bool DIRECT>
+// IO: 0 = the reads as bytes, the characters as bytes;  1 = the reads as 2-bit words (kbo_matches_batch_packed's layout: every read
+// starts a word, first base in the lowest bits), the characters as bytes;  2 = both as 2-bit words (DIRECT without relative_to_ref
+// only: the alphabet is M - X R).  The words go straight into the digit string (every read then starts a word of it: 16 bases of
+// padding at most between two reads), no byte of a read is ever staged, and with IO = 2 a base costs a quarter of a byte each way.
+// Reads that hold a byte that is no base come with a flag (launch_flag_exceptions) and take the plain walk, like the reads this
+// kernel cannot finish: launch_unpack_flagged gives those their bytes, launch_pack_flagged packs their characters.
+__device__ __forceinline__ uint32_t reverse_digits(uint32_t w)
+{
+    const uint32_t r = __builtin_bitreverse32(w);
+    return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+}
+// 16 characters of { M - X R } -> their codes 0 .. 3, first character in the lowest bits ('M' 4D, '-' 2D, 'X' 58, 'R' 52)
+__device__ __forceinline__ uint32_t pack_chars16(const uint4 &v)
+{
+    auto four = [](uint32_t x) -> uint32_t {
+        const uint32_t hi = (x >> 4) & 0x01010101u, lo = ((x >> 5) | ((x >> 4) & ~(x >> 3))) & 0x01010101u;
+        return (((lo | (hi << 1)) * 0x01041040u) >> 24) & 0xFFu;
+    };
+    return four(v.x) | (four(v.y) << 8) | (four(v.z) << 16) | (four(v.w) << 24);
+}
+
+template <int NP, bool DIRECT, int IO = 0>
 __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stage_bytes, uint32_t lin_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t map_lds[];
@@ -146,17 +167,36 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
     const uint32_t nxt_start = __shfl_down(start, 1);
     const bool bad_item = have_item && ((lane < last && nxt_start != start + len) || warm != 0 || tail != 0 || len > 16u * kMapWords);
     const uint32_t lo = __shfl(start, 0), wave_hi = __shfl(start + len, (int)last);
-    const uint32_t base16 = lo & ~15u, soff = start - base16, span = wave_hi - base16;
-    const bool staged = __ballot(bad_item) == 0 && wave_hi > lo && (uint64_t)span + kMapSlack <= stage_bytes;
+    // ooff: where the read's characters (MS bytes) stand in the byte region, soff: where its bases stand in the digit string
+    const uint32_t base16 = lo & ~15u, ooff_b = start - base16, span_b = wave_hi - base16;
+    uint32_t wst = 0; // IO != 0: the read's first word
+    if (IO != 0 && have_item) wst = a.qp_wps ? idx * a.qp_wps : a.qp_sums[idx / kScanBlock] + a.qp_data[idx];
+    const uint32_t nw_mine = (len + 15u) >> 4;
+    const uint32_t w_lo = __shfl(wst, 0), w_hi = __shfl(wst + nw_mine, (int)last), nwords = w_hi - w_lo;
+    const uint32_t soff = IO != 0 ? 16u * (wst - w_lo) : ooff_b, ooff = IO == 2 ? soff : ooff_b;
+    const uint32_t span = IO == 2 ? 16u * nwords : span_b;
+    const uint32_t nxt_wst = __shfl_down(wst, 1);
+    const bool bad_words = IO != 0 && have_item && lane < last && nxt_wst != wst + nw_mine;
+    const bool staged = __ballot(bad_item || bad_words) == 0 && wave_hi > lo && (uint64_t)span + kMapSlack <= stage_bytes &&
+                        (IO == 0 || (uint64_t)16u * nwords + kMapSlack <= stage_bytes);
     if (!staged) { // (cannot happen for a batch of reads the host sent here; if it does, every item takes the plain walk)
         if (have_item) a.redo[idx] = len != 0 ? 1 : 0;
         const uint64_t fm = __ballot(have_item && len != 0);
         if (lane == 0 && fm) atomicAdd(a.qctl + 4, (uint32_t)__popcll(fm));
         return;
     }
-    const uint32_t nblk = (span + 15u) >> 4;
+    const uint32_t nblk = IO != 0 ? nwords : (span + 15u) >> 4;
     bool has_invalid = false;
     if (lane == 0) lin[-1] = 0;
+    if (IO != 0) {
+        for (uint32_t c0 = 0; c0 < nblk + 2u; c0 += 64u) {
+            const uint32_t c = c0 + lane;
+            if (c < lin_words) lin[c] = c < nblk ? reverse_digits(a.qp[w_lo + c]) : 0u;
+        }
+        for (uint32_t c = lane * 16u; c < span + 16u; c += 1024u)
+            *reinterpret_cast<uint4 *>(so + c) = make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);
+        has_invalid = plannable && a.qp_exc != nullptr && a.qp_exc[idx] != 0;
+    } else
     for (uint32_t c0 = 0; c0 < nblk + 2u; c0 += 64u) {
         const uint32_t c = c0 + lane;
         uint32_t code = 0, valid = 0xFFFFu;
@@ -625,7 +665,7 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
         // end first), dn = its segment's d, cand = the base at e waits for its left neighbour to decide between 'X' and '-'
         const int K = (int)k, T = (int)a.map_thr;
         const uint8_t cX = a.map_fmt ? (uint8_t)'-' : (uint8_t)'X'; // (relative_to_ref: 'X' becomes '-' as well)
-        uint8_t *at = so + soff;
+        uint8_t *at = so + ooff;
         const bool live = plannable && !flag && len >= 3u;
         if (__ballot(live && no_plan)) { // no seed, and the table vouches for every base (<= order <= t): x <= 0 throughout
             if (live && no_plan)
@@ -727,6 +767,9 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
 
     // ---- 5. the characters leave in whole lines; format::relative_to_ref (format.rs:270-286) on the way: 'M' and 'R' keep the
     // read's base, everything else becomes '-' (flagged reads' bytes are rewritten by launch_derand_flagged)
+    if (IO == 2) { // as 2-bit words, where the read's own words stand in the batch
+        for (uint32_t c = lane; c < nwords; c += 64u) a.packed_out[w_lo + c] = pack_chars16(*reinterpret_cast<const uint4 *>(so + 16u * c));
+    } else
     for (uint32_t c = lane * 16u; c < span; c += 1024u) {
         uint4 v = *reinterpret_cast<const uint4 *>(so + c);
         if (!DIRECT && a.map_fmt) {
@@ -779,6 +822,19 @@ bool map_reads_applies(const WalkArgs &a)
            a.units;
 }
 
+// the characters straight from the mismatch positions where no table value can anchor (order <= t < k) and the MS values
+// are not asked for; else the MS bytes in LDS and the literal pass over them
+bool map_reads_direct(const WalkArgs &a)
+{
+    static const int env_direct = std::getenv("KBO_MAP_DIRECT") ? std::atoi(std::getenv("KBO_MAP_DIRECT")) : 1; // experiments
+    // (and the proof takes at most four windows per mismatch: cov = t - order + 2 bases apart over order bases)
+    const uint32_t sp_w = (a.ix.anchor && a.map_thr > a.ix.dtab_order) ? a.map_thr - a.ix.dtab_order : a.map_thr - a.ix.dtab_order + 2u;
+    return env_direct != 0 && !a.map_want_ms && a.ix.dtab_order <= a.map_thr && a.map_thr < a.ix.k && (a.ix.dtab_order - 1u + sp_w - 1u) / sp_w + 1u <= 4u;
+}
+
+// the packed-native instantiations: the direct form only, and the characters packed only without relative_to_ref
+bool map_reads_packed_applies(const WalkArgs &a, bool packed_out) { return map_reads_applies(a) && map_reads_direct(a) && !(packed_out && a.map_fmt); }
+
 // the kernel + the list of the reads it could not finish (redo_collect_kernel, for the plain walk: launch_map_reads_redo)
 hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
 {
@@ -794,22 +850,23 @@ hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
     a.redo_piece = env_piece >= 4 ? (uint32_t)env_piece : 16u;
     hipError_t e = hipMemsetAsync(a.qctl, 0, 64 + kPlanStatSlots * kPlanStatWords * 4, stream);
     if (e != hipSuccess) return e;
-    const uint32_t stage_bytes = (64u * a.max_item_len + 16u + kMapSlack + 15u) / 16u * 16u;
+    const bool direct = map_reads_direct(a);
+    const int io = a.qp ? (a.packed_out ? 2 : 1) : 0;
+    if (io != 0 && (!direct || (io == 2 && a.map_fmt))) return hipErrorInvalidValue; // (callers ask map_reads_packed_applies first)
+    // (packed: every read starts a word of the digit string and, with the characters packed as well, of the byte region)
+    const uint32_t stage_bytes = io ? (64u * 16u * ((a.max_item_len + 15u) / 16u) + 32u + kMapSlack) : (64u * a.max_item_len + 16u + kMapSlack + 15u) / 16u * 16u;
     const uint32_t lin_words = stage_bytes / 16u + 4u;
     const uint32_t lds = stage_bytes + 4u * (lin_words + 4u) + 1024u;
-    // the characters straight from the mismatch positions where no table value can anchor (order <= t < k) and the MS values
-    // are not asked for; else the MS bytes in LDS and the literal pass over them
-    static const int env_direct = std::getenv("KBO_MAP_DIRECT") ? std::atoi(std::getenv("KBO_MAP_DIRECT")) : 1; // experiments
-    // (and the proof takes at most four windows per mismatch: cov = t - order + 2 bases apart over order bases)
-    const uint32_t sp_w = (a.ix.anchor && a.map_thr > a.ix.dtab_order) ? a.map_thr - a.ix.dtab_order : a.map_thr - a.ix.dtab_order + 2u;
-    const bool direct = env_direct != 0 && !a.map_want_ms && a.ix.dtab_order <= a.map_thr && a.map_thr < a.ix.k &&
-                        (a.ix.dtab_order - 1u + sp_w - 1u) / sp_w + 1u <= 4u;
     const dim3 grid((a.n_items + 63u) / 64u), block(64);
     if (a.ix.dtab_order <= 15u) {
-        if (direct) hipLaunchKernelGGL((map_reads_kernel<16, true>), grid, block, lds, stream, a, stage_bytes, lin_words);
+        if (io == 2) hipLaunchKernelGGL((map_reads_kernel<16, true, 2>), grid, block, lds, stream, a, stage_bytes, lin_words);
+        else if (io == 1) hipLaunchKernelGGL((map_reads_kernel<16, true, 1>), grid, block, lds, stream, a, stage_bytes, lin_words);
+        else if (direct) hipLaunchKernelGGL((map_reads_kernel<16, true>), grid, block, lds, stream, a, stage_bytes, lin_words);
         else hipLaunchKernelGGL((map_reads_kernel<16, false>), grid, block, lds, stream, a, stage_bytes, lin_words);
     } else {
-        if (direct) hipLaunchKernelGGL((map_reads_kernel<18, true>), grid, block, lds, stream, a, stage_bytes, lin_words);
+        if (io == 2) hipLaunchKernelGGL((map_reads_kernel<18, true, 2>), grid, block, lds, stream, a, stage_bytes, lin_words);
+        else if (io == 1) hipLaunchKernelGGL((map_reads_kernel<18, true, 1>), grid, block, lds, stream, a, stage_bytes, lin_words);
+        else if (direct) hipLaunchKernelGGL((map_reads_kernel<18, true>), grid, block, lds, stream, a, stage_bytes, lin_words);
         else hipLaunchKernelGGL((map_reads_kernel<18, false>), grid, block, lds, stream, a, stage_bytes, lin_words);
     }
     return hipGetLastError();

@@ -145,6 +145,68 @@ __global__ __launch_bounds__(256) void pack2_kernel(const uint8_t *__restrict__ 
     packed[w] = out;
 }
 
+// ---- packed-native batches (map_kernels.hip, IO != 0): what the few reads that take the plain walk need
+// exc[s] = 1 for the read that holds listed byte x (pos = its offset in the byte layout of the slab)
+__global__ __launch_bounds__(256) void flag_exceptions_kernel(const uint64_t *__restrict__ pos, uint32_t n, uint64_t base,
+                                                              const uint64_t *__restrict__ off, uint32_t n_seqs, uint8_t *__restrict__ exc)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    const uint64_t p = pos[x] - base;
+    uint32_t s0 = 0, s1 = n_seqs; // largest s with off[s] <= p
+    while (s1 - s0 > 1) {
+        const uint32_t m = s0 + (s1 - s0) / 2;
+        if (off[m] <= p) s0 = m;
+        else s1 = m;
+    }
+    exc[s0] = 1;
+}
+
+__device__ __forceinline__ uint32_t first_word_of(uint32_t s, uint32_t uniform_wps, const uint32_t *data, const uint32_t *sums)
+{
+    return uniform_wps ? s * uniform_wps : sums[s / kScanBlock] + data[s];
+}
+
+// one lane per read looks at its flag; the wave then does its flagged reads one after the other, a lane per base (two reads
+// in a hundred come here: a lane walking its own read alone was 40 us, sixteen lanes per read over all reads 30)
+__global__ __launch_bounds__(256) void unpack_flagged_kernel(const uint32_t *__restrict__ packed, const uint64_t *__restrict__ off, uint32_t n_seqs,
+                                                             uint32_t uniform_wps, const uint32_t *__restrict__ data, const uint32_t *__restrict__ sums,
+                                                             const uint8_t *__restrict__ flags, uint8_t *__restrict__ q)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    uint64_t fm = __ballot(s < n_seqs && flags[s] != 0);
+    while (fm) {
+        const uint32_t r = s - lane + (uint32_t)__ffsll((long long)fm) - 1u;
+        fm &= fm - 1ull;
+        const uint64_t b0 = off[r];
+        const uint32_t len = (uint32_t)(off[r + 1] - b0), w0 = first_word_of(r, uniform_wps, data, sums);
+        for (uint32_t i = lane; i < len; i += 64u)
+            q[b0 + i] = (uint8_t)((0x54474341u >> (8u * ((packed[w0 + (i >> 4)] >> (2u * (i & 15u))) & 3u))) & 0xFFu);
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_flagged_kernel(const uint8_t *__restrict__ chars, const uint64_t *__restrict__ off, uint32_t n_seqs,
+                                                           uint32_t uniform_wps, const uint32_t *__restrict__ data, const uint32_t *__restrict__ sums,
+                                                           const uint8_t *__restrict__ flags, uint32_t *__restrict__ packed)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    uint64_t fm = __ballot(s < n_seqs && flags[s] != 0);
+    while (fm) {
+        const uint32_t r = s - lane + (uint32_t)__ffsll((long long)fm) - 1u;
+        fm &= fm - 1ull;
+        const uint64_t b0 = off[r];
+        const uint32_t len = (uint32_t)(off[r + 1] - b0), w0 = first_word_of(r, uniform_wps, data, sums);
+        for (uint32_t i0 = 0; i0 < len; i0 += 64u) { // 64 bases = four words: sixteen lanes put a word together
+            const uint32_t i = i0 + lane;
+            const uint32_t ch = i < len ? chars[b0 + i] : (uint32_t)'M';
+            uint32_t v = (ch == 'M' ? 0u : ch == '-' ? 1u : ch == 'X' ? 2u : 3u) << (2u * (lane & 15u)); // translate.rs:180-216: M, -, X, R
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) v |= __shfl_xor(v, o);
+            if ((lane & 15u) == 0 && i < len) packed[w0 + (i >> 4)] = v;
+        }
+    }
+}
+
 // per-byte unsigned maximum of two words
 __device__ __forceinline__ uint32_t max4(uint32_t x, uint32_t y)
 {
@@ -207,6 +269,31 @@ hipError_t launch_exceptions(const uint64_t *d_pos, const uint8_t *d_byte, uint3
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(exceptions_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, d_pos, d_byte, n, base, d_q);
+    return hipGetLastError();
+}
+
+hipError_t launch_flag_exceptions(const uint64_t *d_pos, uint32_t n, uint64_t base, const uint64_t *d_off, uint32_t n_seqs, uint8_t *d_exc, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(flag_exceptions_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, d_pos, n, base, d_off, n_seqs, d_exc);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_flagged(const uint32_t *d_packed, const uint64_t *d_off, uint32_t n_seqs, uint32_t uniform_wps, const uint32_t *d_scratch,
+                                 const uint8_t *d_flags, uint8_t *d_q, hipStream_t stream)
+{
+    if (n_seqs == 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_flagged_kernel, dim3((n_seqs + 255u) / 256u), dim3(256), 0, stream, d_packed, d_off, n_seqs,
+                       uniform_wps, d_scratch, d_scratch ? d_scratch + n_seqs + 1u : nullptr, d_flags, d_q);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_flagged(const uint8_t *d_chars, const uint64_t *d_off, uint32_t n_seqs, uint32_t uniform_wps, const uint32_t *d_scratch,
+                               const uint8_t *d_flags, uint32_t *d_packed, hipStream_t stream)
+{
+    if (n_seqs == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_flagged_kernel, dim3((n_seqs + 255u) / 256u), dim3(256), 0, stream, d_chars, d_off, n_seqs,
+                       uniform_wps, d_scratch, d_scratch ? d_scratch + n_seqs + 1u : nullptr, d_flags, d_packed);
     return hipGetLastError();
 }
 

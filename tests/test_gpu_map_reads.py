@@ -216,3 +216,46 @@ def test_two_batches_in_flight(oracle):
     dev.run(S, tail_stream=S)
     torch.cuda.synchronize()
     assert np.array_equal(dev.chars[:dev.total].cpu().numpy(), want)
+
+
+def test_packed_native_kernel_device_resident(oracle):
+    """kbo_matches_packed_dev: the reads as 2-bit words into the kernel, the characters as 2-bit words out of it - ragged and equally
+    long reads, reads with bytes that are no bases (the side list), indels, reads the kernel leaves to the second pass, with and
+    without a tail stream - against the oracle, every read; and the host entry point kbo_matches_batch_packed over the same reads."""
+    import torch
+    rng = np.random.default_rng(33)
+    g = synth.genome(500_000, seed=43)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=threads()))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    dev0 = torch.device("cuda:0")
+    T = torch.cuda.Stream(dev0)
+
+    def take(n, lo, hi):
+        return [g[a:a + int(l)] for a, l in zip(rng.integers(0, len(g) - 200, n), rng.integers(lo, hi + 1, n))]
+    sets = [
+        _mutate(rng, take(30_000, 150, 150), sub=0.01),                                   # equally long: words per read known
+        _mutate(rng, take(20_000, 3, 157), sub=0.02, indel=0.3),                          # ragged, down to three bases
+        _mutate(rng, take(10_000, 100, 160), sub=0.01, n_rate=0.3, lower=0.2),            # the side list
+        _mutate(rng, take(5_000, 128, 128), sub=0.06),                                    # multiples of 16; many reads left to the second pass
+        _mutate(rng, take(63, 17, 160), sub=0.01),
+    ]
+    for reads in sets:
+        concat, offsets = _batch_of(reads)
+        want = ora.matches_batch(concat, offsets, 1e-7, n_threads=threads())
+        kbo_amd.lib().kbo_set_plan(1, 0, 0)
+        pb = batch.PackedDeviceBatch(sbwt, concat, offsets, device=dev0)
+        for tail in (None, T):
+            pb.words_out.fill_(-1)
+            pb.run(tail_stream=tail)
+            torch.cuda.synchronize()
+            got = pb.chars()
+            if not np.array_equal(got, want):
+                bad = np.flatnonzero(got != want)
+                s = int(np.searchsorted(offsets, bad[0], side="right")) - 1
+                a, b = int(offsets[s]), int(offsets[s + 1])
+                raise AssertionError("read %d (len %d): %d bad bases\n got  %s\n want %s" % (s, b - a, len(bad), got[a:b].tobytes(), want[a:b].tobytes()))
+        # the bits behind a read's last base inside its last word are zero, as from the byte route + pack
+        words, pos, byt = batch.pack_reads(concat, offsets)
+        host = batch.matches_batch_packed(sbwt, words, offsets, pos, byt)
+        assert np.array_equal(host, pb.words_out[:len(words)].cpu().numpy().view(np.uint32))
+        assert np.array_equal(batch.unpack_matches(host, offsets), want)

@@ -14,7 +14,7 @@ import csv, glob, sys, os, collections, re
 acc = collections.defaultdict(float); cnt = collections.defaultdict(set)
 for f in glob.glob(os.path.join(sys.argv[1], '**', '*counter_collection.csv'), recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r'(ms_walk\w*<[^>]*>|ms_walk\w*|plan_\w+|map_reads\w+|derand\w+|redo_\w+|rle\w+)', r['Kernel_Name'])
+        m = re.search(r'(ms_walk\w*<[^>]*>|ms_walk\w*|plan_\w+|map_reads\w+<[^>]*>|map_reads\w+|derand\w+|redo_\w+|rle\w+)', r['Kernel_Name'])
         if not m: continue
         name = m.group(1)
         key = (name, r['Counter_Name'])
