@@ -438,7 +438,7 @@ int kbo_set_devices(const int *devices, int n);
 /* Host helper threads used by the host batch entry points for the staging copies between pageable
  * user buffers and pinned memory (two teams of this size; default min(8, cores)). */
 int kbo_set_host_threads(int n);
-/* host batches are processed in slabs of at most this many query bytes (default 32 MiB) */
+/* host batches are processed in slabs of at most this many query bytes (default 16 MiB) */
 int kbo_set_slab_bytes(size_t bytes);
 /* Frees the per-device scratch (streams, device buffers, pinned staging) the host batch entry
  * points keep between calls, and the calling thread's own caches (kbo_call / kbo_call_batch keep a

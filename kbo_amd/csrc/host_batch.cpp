@@ -287,7 +287,7 @@ void run_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offset
 // (a) one launch stays below the 32-bit offset limits and (b) the H2D copy of slab i+1 and
 // the D2H copy of slab i-1 overlap the kernels of slab i (two streams, user buffers pinned
 // in place with hipHostRegister when that succeeds).
-std::atomic<size_t> g_slab_bytes{32ull << 20}; // tools/bench_host.py: best of 8..128 MiB on the C2 reads
+std::atomic<size_t> g_slab_bytes{16ull << 20}; // tools/bench_host.py, 600 Mbp of C2 reads through the one kernel: 16 / 24 / 32 / 64 MiB 39 / 36 / 32-39 / 31 Gbp/s (bytes), 121 / 89 / 104 Gbp/s (packed)
 
 
 std::vector<Slab> make_slabs(const uint64_t *offsets, size_t n_seqs, size_t max_bytes)

@@ -40,7 +40,7 @@ def shipped_defaults(L):
     L.kbo_set_seed_table_depth(0)
     L.kbo_set_pair_steps(24 << 20, 16)
     L.kbo_set_walk_waves_per_cu(0)
-    L.kbo_set_slab_bytes(32 << 20)
+    L.kbo_set_slab_bytes(16 << 20)
     L.kbo_set_devices(None, 0)
     L.kbo_set_plan_table_budget(0)       # the tables of a copy: half of the free device memory
     L.kbo_set_plan_lazy(-1)              # plan structures of implicitly made copies: by index size
