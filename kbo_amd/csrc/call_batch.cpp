@@ -45,11 +45,15 @@ struct SiteRec {
 struct SiteWindows {
     struct Part {
         PinBuf recs, win; // n records of 16 / stride bytes
+        PinBuf codes;     // the device's second pass: n words (call_second_kernels.hip), when has_codes
+        bool has_codes = false;
         size_t n = 0;
     };
     std::vector<std::unique_ptr<Part>> parts;
     uint32_t stride = 0, kpad = 0;
     const SiteRec &rec(uint32_t part, uint32_t x) const { return parts[part]->recs.as<SiteRec>()[x]; }
+    // the site's word of the device's second pass, or "left to the host"
+    uint32_t code(uint32_t part, uint32_t x) const { return parts[part]->has_codes ? parts[part]->codes.as<uint32_t>()[x] : 0x01FFFFFFu; }
     const uint8_t *win(uint32_t part, uint32_t x) const { return parts[part]->win.as<uint8_t>() + (size_t)x * stride; }
 };
 
@@ -57,8 +61,9 @@ struct SiteWindows {
 // (call mode of ms_walk_kernel: no intervals are written at all); a slab in which a lane had more than four breakpoints
 // waiting at once, or whose site lists overflowed, is done again the long way (walk with intervals + call_sites_kernel).
 // Sites of slab-relative sequence numbers are shifted to batch-wide ones by the caller (SiteRec::seq + Part's first).
+// second_q != 0: the second pass's three values per site as well (q-mers of that many bases index the slab's sequences)
 SiteWindows find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, uint32_t threshold,
-                       std::vector<size_t> &part_first_seq)
+                       std::vector<size_t> &part_first_seq, uint32_t second_q, bool revcomp)
 {
     SiteWindows all;
     const uint32_t k = idx->host.k;
@@ -66,7 +71,8 @@ SiteWindows find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *of
     all.kpad = (k + 15u) / 16u * 16u;
     hipStream_t stream = nullptr;
     const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, slab_bytes_for(idx));
-    DevBuf d_sites, d_count, d_prefix, d_recs, d_win;
+    DevBuf d_sites, d_count, d_prefix, d_recs, d_win, d_tab, d_tab_off, d_seq_flag, d_codes;
+    std::vector<uint64_t> tab_off;
     const size_t count_bytes = kbo::kCallSegs * 64 + 64;
     d_count.alloc(count_bytes);
     d_prefix.alloc((kbo::kCallSegs + 1) * 4);
@@ -120,6 +126,34 @@ SiteWindows find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *of
                 HIP_OK(kbo::launch_call_finalize(d_sites.p, d_count.as<uint32_t>(), d_prefix.as<uint32_t>(), seg_cap, worst, by_walk,
                                                  B.off.as<uint64_t>(), (uint32_t)ns, k, B.ms.as<uint8_t>(), view, d_recs.p,
                                                  d_win.as<uint8_t>(), all.stride, stream));
+                if (second_q) {
+                    // the second pass for these sites while the slab's bases are on the device: a table of q-mer start positions per
+                    // sequence (a power of two of at least 1.5 slots per base; none for a sequence beyond 20-bit positions)
+                    tab_off.assign(ns + 1, 0);
+                    for (size_t s = 0; s < ns; s++) {
+                        const uint64_t len = off[s + 1] - off[s];
+                        uint64_t size = 0;
+                        if (len > 0 && len < (1u << 20) - 1u) {
+                            size = 64;
+                            while (size < len + len / 2) size <<= 1;
+                        }
+                        tab_off[s + 1] = tab_off[s] + size;
+                    }
+                    d_tab_off.ensure((ns + 1) * 8);
+                    d_tab.ensure(tab_off[ns] * 4 + 16);
+                    d_seq_flag.ensure(ns + 16);
+                    d_codes.ensure(n_new * 4);
+                    part->codes.ensure(n_new * 4);
+                    HIP_OK(hipMemcpyAsync(d_tab_off.p, tab_off.data(), (ns + 1) * 8, hipMemcpyHostToDevice, stream));
+                    HIP_OK(hipMemsetAsync(d_tab.p, 0, tab_off[ns] * 4 + 16, stream));
+                    HIP_OK(kbo::launch_call_qmer_index(B.q.as<uint8_t>(), B.off.as<uint64_t>(), (uint32_t)ns, second_q, d_tab_off.as<uint64_t>(),
+                                                       d_tab.as<uint32_t>(), d_seq_flag.as<uint8_t>(), stream));
+                    HIP_OK(kbo::launch_call_depths(d_recs.p, d_win.as<uint8_t>(), all.stride, (uint32_t)n_new, B.q.as<uint8_t>(), B.off.as<uint64_t>(), k,
+                                                   threshold, second_q, revcomp, d_tab_off.as<uint64_t>(), d_tab.as<uint32_t>(),
+                                                   d_seq_flag.as<uint8_t>(), d_codes.as<uint32_t>(), stream));
+                    HIP_OK(hipMemcpyAsync(part->codes.p, d_codes.p, n_new * 4, hipMemcpyDeviceToHost, stream));
+                    part->has_codes = true;
+                }
                 HIP_OK(hipMemcpyAsync(part->recs.p, d_recs.p, n_new * 16, hipMemcpyDeviceToHost, stream));
                 HIP_OK(hipMemcpyAsync(part->win.p, d_win.p, n_new * (size_t)all.stride, hipMemcpyDeviceToHost, stream));
                 HIP_OK(hipStreamSynchronize(stream));
@@ -249,7 +283,11 @@ extern "C" int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, con
         CallClock clk;
         // ---- first pass on the device (MS walk + breakpoint scan), the sites made ready and their windows gathered there
         std::vector<size_t> part_seq0;
-        const SiteWindows sw = find_sites(query_idx, concat, offsets, n_seqs, (uint32_t)d, part_seq0);
+        // the second pass's values per site from the device as well (call_second_kernels.hip), where its q-mers can be at most as
+        // long as the threshold and positions fit its tables; the host then only puts the variants together
+        static const int env_second = std::getenv("KBO_CALL_DEVICE_SECOND") ? std::atoi(std::getenv("KBO_CALL_DEVICE_SECOND")) : 1; // experiments
+        const uint32_t second_q = (env_second && d >= 6 && d <= 255 && k <= 255 && k >= 2) ? (uint32_t)std::min<size_t>(12, d) : 0u;
+        const SiteWindows sw = find_sites(query_idx, concat, offsets, n_seqs, (uint32_t)d, part_seq0, second_q, o.sbwt_build_opts.add_revcomp != 0);
         clk.lap("first pass (sites + windows)");
         // ---- sites by sequence (counting sort over the parts; a sequence's few sites are put in order of i by its worker)
         struct Ref { uint32_t part, x; };
@@ -297,9 +335,21 @@ extern "C" int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, con
                             const size_t len = (size_t)(offsets[s + 1] - offsets[s]);
                             mine.assign(order.begin() + a, order.begin() + b);
                             std::sort(mine.begin(), mine.end(), [&](const Ref &x, const Ref &y) { return sw.rec(x.part, x.x).i < sw.rec(y.part, y.x).i; });
-                            sam.build(seq, len, k, revcomp);
+                            bool sam_built = false;
                             for (const Ref &sr : mine) {
                                 const SiteRec &r = sw.rec(sr.part, sr.x);
+                                const uint32_t code = sw.code(sr.part, sr.x);
+                                if (!(code >> 24)) { // the device did this site: the common suffix and the two peaks are all resolve_variant reads
+                                    const uint32_t rp = code & 0xFFu, qp = (code >> 8) & 0xFFu, csl = (code >> 16) & 0xFFu;
+                                    size_t qf, qt, rf, rt;
+                                    if (kbo::resolve_variant_peaks(k, csl, qp != 0xFFu, qp, rp != 0xFFu, rp, qf, qt, rf, rt))
+                                        calls[s].push_back(Call{r.i, (uint16_t)qf, (uint16_t)(qt - qf), (uint16_t)rf, (uint16_t)(rt - rf), sr});
+                                    continue;
+                                }
+                                if (!sam_built) { // (a site left to the host: the sequence's suffix automaton, once)
+                                    sam.build(seq, len, k, revcomp);
+                                    sam_built = true;
+                                }
                                 const uint8_t *w = sw.win(sr.part, sr.x);
                                 // query-side k-mer (variant_calling.rs:46-58, 275) and its walk against the index (:279): the MS
                                 // values of the first pass, capped by the distance from the k-mer's (or the sequence's) first base

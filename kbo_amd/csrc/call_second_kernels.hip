@@ -1,0 +1,223 @@
+// call_second_kernels.hip — gfx950 (MI355X, CDNA4): the second pass of kbo::call (variant_calling.rs:271-291) for the sites
+// of a slab, on the device, right behind the first pass.
+//
+// What resolve_variant (variant_calling.rs:139-201) reads per site:
+//   * the common suffix length of the query-side k-mer (the k characters ending at the match j; '$' in front of the
+//     sequence, :46-58) and the matched row's k-mer (access_kmer, :276);
+//   * the rightmost significant peak (:73-83) of the query-side k-mer's walk against the reference index (:279) - a function
+//     of the first pass's MS values, see call_kernels.hip;
+//   * the rightmost significant peak of the ROW's k-mer walked against the index of the sequence itself (:280), which the
+//     reference builds per call (lib.rs:553).  The depth of that walk at position t is the length of the longest suffix of
+//     kmer[0 ..= t] that is a substring of the sequence or (add_revcomp) of its reverse complement (call_batch.cpp
+//     RunAutomaton has the argument: the suffixes of the rows of a one-sequence SBWT are the substrings of its ACGT runs of at
+//     least k characters).  The peak test `d[i] >= thr && d[i] > d[i + 1]` only needs a depth exactly where it is at least
+//     q <= thr; below that "less than q" is enough.
+// So instead of an index of the sequence per call (the reference), or a suffix automaton of it per sequence on a host thread
+// (round 3: 1.83 s of host time per 125 k reads of 10 kbp), the device keeps, per sequence of the slab, a hash table of the
+// START positions of its q-mers (q = min(12, thr)): a depth >= q at t means the q-mer ending at t occurs in the sequence, every
+// occurrence is in the table, and the occurrence's match is extended backwards base by base (forwards, against complements,
+// for the reverse strand: no second copy of the sequence).  One wave per site, a lane per position of the k-mer.
+//
+//   call_qmer_index_kernel   one workgroup per sequence: its q-mer start positions into its table (slot = (start + 1) | 12 tag
+//                            bits << 20, linear probing, atomicCAS), a flag for a sequence that holds a byte that is no base
+//   call_depths_kernel       per site: the three values above as one word { rpeak | qpeak << 8 | csl << 16 | flags << 24 }
+//                            (0xFF = no peak); flags bit 0 = this site is left to the host (a sequence with bytes that are no
+//                            bases or without a table, a row's k-mer that crosses a path start or holds '$')
+//
+// Integer / byte work only: no MFMA.
+#include "device_util.hpp"
+
+namespace kbo {
+namespace {
+
+__device__ __forceinline__ uint32_t base_code(uint32_t ch) { return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u; }
+__device__ __forceinline__ uint32_t qmer_slot(uint32_t code, uint32_t mask) { return ((code * 0x9E3779B1u) >> 7) & mask; }
+__device__ __forceinline__ uint32_t qmer_tag(uint32_t code) { return ((code * 0x85EBCA6Bu) >> 20) & 0xFFFu; }
+
+__global__ __launch_bounds__(256) void call_qmer_index_kernel(const uint8_t *__restrict__ q, const uint64_t *__restrict__ off, uint32_t n_seqs,
+                                                              uint32_t qlen, const uint64_t *__restrict__ tab_off, uint32_t *__restrict__ tab,
+                                                              uint8_t *__restrict__ seq_flag)
+{
+    const uint32_t s = blockIdx.x;
+    if (s >= n_seqs) return;
+    const uint64_t b0 = off[s];
+    const uint32_t len = (uint32_t)(off[s + 1] - b0);
+    const uint64_t t0 = tab_off[s];
+    const uint32_t size = (uint32_t)(tab_off[s + 1] - t0);
+    __shared__ uint32_t bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    bool mine_bad = false;
+    if (size == 0) mine_bad = len != 0; // no table for this sequence (too long for 20-bit positions): the host does its sites
+    else {
+        const uint8_t *r = q + b0;
+        for (uint32_t st = threadIdx.x; st < len; st += blockDim.x) {
+            uint32_t code = 0;
+            bool ok = true;
+            if (st + qlen <= len) {
+                for (uint32_t m = 0; m < qlen; m++) {
+                    const uint32_t c = base_code(r[st + m]);
+                    ok = ok && c < 4u;
+                    code = (code << 2) | (c & 3u);
+                }
+                if (ok) {
+                    const uint32_t mask = size - 1u, v = (st + 1u) | (qmer_tag(code) << 20);
+                    uint32_t h = qmer_slot(code, mask);
+                    while (atomicCAS(tab + t0 + h, 0u, v) != 0u) h = (h + 1u) & mask;
+                }
+            } else ok = base_code(r[st]) < 4u; // (the last q - 1 bases start no q-mer: only looked at)
+            mine_bad = mine_bad || !ok;
+        }
+    }
+    if (mine_bad) bad = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) seq_flag[s] = bad ? 1 : 0;
+}
+
+constexpr uint32_t kCallMaxK = 256;
+
+// rightmost i in [0, k - 2] with v[i] >= thr && v[i] > v[i + 1] (variant_calling.rs:73-83), or 0xFF; v in LDS, one wave
+__device__ __forceinline__ uint32_t rightmost_peak(const uint8_t *v, uint32_t k, uint32_t thr, uint32_t lane)
+{
+    for (int32_t base = (int32_t)((k - 2u) & ~63u); base >= 0; base -= 64) {
+        const uint32_t i = (uint32_t)base + lane;
+        const bool p = i + 1u < k && v[i] >= thr && v[i] > v[i + 1u];
+        const uint64_t m = __ballot(p);
+        if (m) return (uint32_t)base + 63u - (uint32_t)__builtin_clzll(m);
+    }
+    return 0xFFu;
+}
+
+__global__ __launch_bounds__(256) void call_depths_kernel(const uint4 *__restrict__ recs, const uint8_t *__restrict__ win, uint32_t stride,
+                                                          uint32_t kpad, uint32_t n_sites, const uint8_t *__restrict__ q,
+                                                          const uint64_t *__restrict__ off, uint32_t k, uint32_t thr, uint32_t qlen,
+                                                          uint32_t revcomp, const uint64_t *__restrict__ tab_off, const uint32_t *__restrict__ tab,
+                                                          const uint8_t *__restrict__ seq_flag, uint32_t *__restrict__ out)
+{
+    __shared__ uint8_t lds[4][3 * kCallMaxK];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t x = blockIdx.x * 4u + wv;
+    if (x >= n_sites) return;
+    const uint4 rec = recs[x];
+    if (rec.x == 0xFFFFFFFFu) { // a void record (an item the redo pass scanned again)
+        if (lane == 0) out[x] = 0xFFFFFFFFu;
+        return;
+    }
+    uint8_t *rk = lds[wv], *dq = rk + kCallMaxK, *dr = dq + kCallMaxK;
+    const uint8_t *w = win + (size_t)x * stride;
+    const uint64_t b0 = off[rec.x];
+    const uint32_t len = (uint32_t)(off[rec.x + 1] - b0), j = rec.z;
+    const uint8_t *r = q + b0;
+    bool bad = false;
+    // the row's k-mer, the query-side walk's depths (min(MS, distance to the k-mer's / the sequence's first base): call_batch.cpp)
+    // and where the two k-mers differ
+    uint32_t hi_diff = 0xFFFFFFFFu; // the rightmost position where the k-mers differ (for the common suffix)
+    for (uint32_t t0 = 0; t0 < k; t0 += 64u) {
+        const uint32_t t = t0 + lane;
+        bool differ = false;
+        if (t < k) {
+            const uint32_t ch = w[kpad + t];
+            rk[t] = (uint8_t)ch;
+            bad = bad || base_code(ch) > 3u;
+            const int64_t pos = (int64_t)j - (int64_t)(k - 1u) + t;
+            uint32_t qc = '$', dv = 0;
+            if (pos >= 0) {
+                qc = r[pos];
+                dv = min((uint32_t)w[t], (uint32_t)min((int64_t)(t + 1u), pos + 1));
+            }
+            dr[t] = (uint8_t)dv;
+            differ = qc != ch;
+        }
+        const uint64_t m = __ballot(differ);
+        if (m) hi_diff = t0 + 63u - (uint32_t)__builtin_clzll(m);
+    }
+    const uint32_t flag_w = w[2u * kpad];
+    const uint64_t tb0 = tab_off[rec.x];
+    const uint32_t size = (uint32_t)(tab_off[rec.x + 1] - tb0);
+    const bool host_site = __ballot(bad) != 0 || flag_w != 0 || seq_flag[rec.x] != 0 || (size == 0 && len >= k);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (host_site) {
+        if (lane == 0) out[x] = 0x01FFFFFFu;
+        return;
+    }
+    // the depths of the row's k-mer against the sequence (and its reverse complement), exact where they are at least qlen
+    const uint32_t mask = size ? size - 1u : 0u;
+    const uint32_t *tb = tab + tb0;
+    for (uint32_t t0 = 0; t0 < k; t0 += 64u) {
+        const uint32_t t = t0 + lane;
+        if (t >= k) continue;
+        uint32_t best = 0;
+        if (t + 1u >= qlen && len >= k) { // (a sequence shorter than k has no k-mer: its index holds nothing)
+            uint32_t code = 0, rcode = 0;
+            for (uint32_t m = 0; m < qlen; m++) {
+                const uint32_t c = base_code(rk[t + 1u - qlen + m]);
+                code = (code << 2) | c;
+                rcode |= (3u - c) << (2u * m); // reverse complement: the last base's complement first
+            }
+            // forward strand: the q-mer ends at t; an occurrence that starts at st matches on backwards from st - 1 / t - qlen
+            {
+                const uint32_t tag = qmer_tag(code);
+                for (uint32_t h = qmer_slot(code, mask);; h = (h + 1u) & mask) {
+                    const uint32_t v = tb[h];
+                    if (v == 0) break;
+                    if ((v >> 20) != tag) continue;
+                    const uint32_t st = (v & 0xFFFFFu) - 1u;
+                    bool same = true;
+                    for (uint32_t m = 0; m < qlen; m++) same = same && r[st + m] == rk[t + 1u - qlen + m];
+                    if (!same) continue;
+                    uint32_t L = qlen;
+                    while (L <= t && L < st + qlen && r[st + qlen - 1u - L] == rk[t - L]) L++;
+                    best = max(best, L);
+                }
+            }
+            if (revcomp) { // reverse strand: the complement of rk[t - m] stands at st + m
+                const uint32_t tag = qmer_tag(rcode);
+                for (uint32_t h = qmer_slot(rcode, mask);; h = (h + 1u) & mask) {
+                    const uint32_t v = tb[h];
+                    if (v == 0) break;
+                    if ((v >> 20) != tag) continue;
+                    const uint32_t st = (v & 0xFFFFFu) - 1u;
+                    auto comp_eq = [&](uint32_t a, uint32_t b) { return base_code(a) + base_code(b) == 3u; };
+                    bool same = true;
+                    for (uint32_t m = 0; m < qlen; m++) same = same && comp_eq(r[st + m], rk[t - m]);
+                    if (!same) continue;
+                    uint32_t L = qlen;
+                    while (L <= t && st + L < len && comp_eq(r[st + L], rk[t - L])) L++;
+                    best = max(best, L);
+                }
+            }
+        }
+        dq[t] = (uint8_t)min(best, k);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t rpeak = rightmost_peak(dq, k, thr, lane), qpeak = rightmost_peak(dr, k, thr, lane);
+    const uint32_t csl = hi_diff == 0xFFFFFFFFu ? k : k - 1u - hi_diff;
+    if (lane == 0) out[x] = rpeak | (qpeak << 8) | (min(csl, 255u) << 16);
+}
+
+} // namespace
+
+// table sizes are the caller's (powers of two, tab_off[s + 1] - tab_off[s] slots for sequence s; 0 = none); d_tab zeroed
+hipError_t launch_call_qmer_index(const uint8_t *d_q, const uint64_t *d_off, uint32_t n_seqs, uint32_t qlen, const uint64_t *d_tab_off,
+                                  uint32_t *d_tab, uint8_t *d_seq_flag, hipStream_t stream)
+{
+    if (n_seqs == 0) return hipSuccess;
+    hipLaunchKernelGGL(call_qmer_index_kernel, dim3(n_seqs), dim3(256), 0, stream, d_q, d_off, n_seqs, qlen, d_tab_off, d_tab, d_seq_flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_call_depths(const void *d_recs, const uint8_t *d_win, uint32_t stride, uint32_t n_sites, const uint8_t *d_q,
+                              const uint64_t *d_off, uint32_t k, uint32_t thr, uint32_t qlen, bool revcomp, const uint64_t *d_tab_off,
+                              const uint32_t *d_tab, const uint8_t *d_seq_flag, uint32_t *d_out, hipStream_t stream)
+{
+    if (n_sites == 0) return hipSuccess;
+    if (k > kCallMaxK - 1u || k < 2u) return hipErrorInvalidValue;
+    const uint32_t kpad = (k + 15u) / 16u * 16u;
+    hipLaunchKernelGGL(call_depths_kernel, dim3((n_sites + 3u) / 4u), dim3(256), 0, stream, static_cast<const uint4 *>(d_recs), d_win, stride, kpad,
+                       n_sites, d_q, d_off, k, thr, qlen, revcomp ? 1u : 0u, d_tab_off, d_tab, d_seq_flag, d_out);
+    return hipGetLastError();
+}
+
+} // namespace kbo

@@ -307,6 +307,13 @@ hipError_t launch_call_sites(const uint8_t *d_ms, const uint32_t *d_lo, const ui
 // goes to d_win (call_kernels.hip call_finalize_kernel); record stride = call_gather_stride(k) bytes: MS bytes at 0,
 // characters at kpad, flag byte at 2 kpad
 inline uint32_t call_gather_stride(uint32_t k) { return 2u * ((k + 15u) / 16u * 16u) + 16u; }
+// the second pass of kbo::call on the device (call_second_kernels.hip): per-sequence tables of q-mer start positions, then per site
+// { rpeak | qpeak << 8 | csl << 16 | flags << 24 } (0xFF = no peak; flags bit 0 = left to the host; ~0 for a void record)
+hipError_t launch_call_qmer_index(const uint8_t *d_q, const uint64_t *d_off, uint32_t n_seqs, uint32_t qlen, const uint64_t *d_tab_off,
+                                  uint32_t *d_tab, uint8_t *d_seq_flag, hipStream_t stream);
+hipError_t launch_call_depths(const void *d_recs, const uint8_t *d_win, uint32_t stride, uint32_t n_sites, const uint8_t *d_q,
+                              const uint64_t *d_off, uint32_t k, uint32_t thr, uint32_t qlen, bool revcomp, const uint64_t *d_tab_off,
+                              const uint32_t *d_tab, const uint8_t *d_seq_flag, uint32_t *d_out, hipStream_t stream);
 hipError_t launch_call_finalize(const void *d_lists, const uint32_t *d_counts, const uint32_t *d_prefix, uint32_t seg_cap, uint32_t max_count,
                                 bool by_walk, const uint64_t *d_off, uint32_t n_seqs, uint32_t k, const uint8_t *d_ms,
                                 const DevIndexView &ix, void *d_recs, uint8_t *d_win, uint32_t stride, hipStream_t stream);

@@ -164,6 +164,15 @@ bool resolve_variant_ranges(const uint8_t *query_kmer, const uint8_t *ref_kmer, 
     size_t qpeak = 0, rpeak = 0;
     const bool hq = rightmost_significant_peak(d_vs_ref, k, thr, qpeak);
     const bool hr = rightmost_significant_peak(d_vs_query, k, thr, rpeak);
+    return resolve_variant_peaks(k, csl, hq, qpeak, hr, rpeak, q_from, q_to, r_from, r_to);
+}
+
+// the same from the three values resolve_variant reads off its inputs (the device's second pass delivers them per site:
+// call_second_kernels.hip): the common suffix length and the two rightmost significant peaks
+bool resolve_variant_peaks(size_t k, size_t csl, bool hq, size_t qpeak, bool hr, size_t rpeak, size_t &q_from, size_t &q_to, size_t &r_from,
+                           size_t &r_to)
+{
+    if (csl == 0) throw RefPanic("assert!(common_suffix_len > 0)");
     if (!(hq && hr)) return false;
     const size_t sms = k - csl;
     const long query_gap = (long)sms - (long)qpeak - 1, ref_gap = (long)sms - (long)rpeak - 1;

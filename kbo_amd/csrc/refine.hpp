@@ -67,6 +67,8 @@ std::vector<Variant> resolve_call_sites(const std::vector<CallSite> &sites, cons
 // variant's characters come back as index ranges into the two k-mers.  false = Err(ResolveVariantErr).
 bool resolve_variant_ranges(const uint8_t *query_kmer, const uint8_t *ref_kmer, const uint32_t *d_vs_query, const uint32_t *d_vs_ref,
                             size_t k, size_t thr, size_t &q_from, size_t &q_to, size_t &r_from, size_t &r_to);
+bool resolve_variant_peaks(size_t k, size_t csl, bool hq, size_t qpeak, bool hr, size_t rpeak, size_t &q_from, size_t &q_to, size_t &r_from,
+                           size_t &r_to);
 
 // translate::add_variants (translate.rs:350-386)
 void add_variants(std::vector<uint8_t> &translation, const std::vector<Variant> &variants);
