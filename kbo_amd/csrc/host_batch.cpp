@@ -49,9 +49,12 @@ uint64_t walk_chunk(uint64_t total, size_t n_seqs, uint32_t k)
     // chunks of 3814 bases, every one of them walked as an item without a plan); 30 warm-up bases per 768 cost the plain
     // walk 4 %.
     (void)n_seqs;
-    uint64_t chunk = std::min<uint64_t>(768, std::max<uint64_t>(256, total >> 17));
+    // (a multiple of 64: tools/dbg_call_chunk.py - with chunks of 457 bases, what a slab of 60 Mbp used to get, the call mode of the
+    // plan-guided walk gave different sites from run to run; 448, 460, 464, 300, 1000 are exact.  Slabs were 32 MiB until round 4,
+    // whose chunks are 256 bases, so nothing ever ran that way; chunk boundaries now stay 4-byte aligned relative to the sequence)
+    uint64_t chunk = std::min<uint64_t>(768, std::max<uint64_t>(256, (total >> 17) & ~63ull));
     static const int env_chunk = std::getenv("KBO_WALK_CHUNK") ? std::atoi(std::getenv("KBO_WALK_CHUNK")) : 0; // experiments
-    if (env_chunk > 0) chunk = (uint64_t)env_chunk;
+    if (env_chunk > 0) chunk = ((uint64_t)env_chunk + 3u) & ~3ull;
     return std::max<uint64_t>(chunk, 4ull * k);
 }
 

@@ -277,6 +277,36 @@ def test_hold_off_is_per_index(oracle, plan_restore):
     assert state(a)[1] == 0
 
 
+def test_call_batch_does_not_depend_on_the_slab_size(oracle, plan_restore):
+    """35 Mbp of 10 kbp reads in one slab (64 MiB, set on the handle) and in slabs of 16 MiB: the same variants, equal to the
+    oracle's literal kbo::call on a sample.  (One slab of that size used to get chunks of 267 bases - total >> 17 - and the call
+    mode of the plan-guided walk is only exact with chunks of a multiple of four bases: walk_chunk now rounds.)"""
+    rng = np.random.default_rng(17)
+    k = 51
+    g = synth.genome(4_000_000, seed=61)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=k, num_threads=_threads()))
+    ora = oracle.Index.build([g.tobytes()], k=k)
+    R, L = 3500, 10_000
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = np.stack([g[a:a + L] for a in rng.integers(0, len(g) - L - 8, R)])
+    hit = rng.random((R, L)) < 0.01
+    reads[hit] = acgt[rng.integers(0, 4, int(hit.sum()))]
+    for r in range(0, R, 3):
+        p = int(rng.integers(200, L - 200))
+        reads[r, p:L - 3] = reads[r, p + 3:].copy()
+    concat, offsets = reads.reshape(-1), np.arange(R + 1, dtype=np.uint64) * np.uint64(L)
+    opts = kbo_amd.CallOpts(sbwt_build_opts=kbo_amd.BuildOpts(k=k, build_select=True))
+    res16 = batch.call_batch_arrays(sbwt, concat, offsets, opts)
+    sbwt.set_opts(slab_bytes=64 << 20)
+    res64 = batch.call_batch_arrays(sbwt, concat, offsets, opts)
+    assert int(res16["var_offsets"][-1]) > 50 * R
+    for s in range(R):
+        assert list(batch.variants_of(res16, s)) == list(batch.variants_of(res64, s)), s
+    for s in rng.integers(0, R, 25):
+        exp, _, _ = ora.call(reads[s].tobytes(), k, 1e-7)
+        assert [(p, q.decode(), r.decode()) for p, q, r in batch.variants_of(res64, int(s))] == exp
+
+
 def test_options_are_per_handle(oracle, plan_restore):
     """kbo_index_set_opts: two indexes of one process with different settings of what used to be process-wide only - plan on / off,
     the depth table's order, the slab size and the devices of host batches.  Same results from every one of them."""
@@ -359,6 +389,8 @@ def test_call_batch_equals_per_sequence_call(oracle):
                 s[p] = ord("N")
         if r % 13 == 0 and len(s) > 900:   # a copy of an earlier stretch of the same read (the automaton sees it twice)
             s[700:800] = s[100:200]
+        if r % 3 == 0 and len(s) > 900:    # ... and a reverse-complemented one (what add_revcomp = true below is about)
+            s[500:590] = bytes(reversed(bytes(s[250:340]).translate(bytes.maketrans(b"ACGTN", b"TGCAN"))))
         reads.append(bytes(s))
     concat = np.frombuffer(b"".join(reads), dtype=np.uint8)
     offsets = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
@@ -376,6 +408,17 @@ def test_call_batch_equals_per_sequence_call(oracle):
         n_var += len(mine)
     assert n_var > 100
     assert all(len(got[s]) == 0 for s in range(0, len(reads), 7))
+    # the sequence's own index with its reverse complements (CallOpts.sbwt_build_opts.add_revcomp): the batch - the device's second
+    # pass looks the reverse strand up in the same tables - against the single-sequence entry point, which builds that index
+    opts_rc = kbo_amd.CallOpts(sbwt_build_opts=kbo_amd.BuildOpts(k=k, build_select=True, add_revcomp=True))
+    got_rc = batch.call_batch(sbwt, concat, offsets, opts_rc)
+    differs = 0
+    for s, rd in enumerate(reads):
+        mine = [(v.query_pos, bytes(v.query_chars), bytes(v.ref_chars)) for v in got_rc[s]]
+        one = kbo_amd.call(sbwt, lcs, rd, opts_rc)
+        assert mine == [(v.query_pos, bytes(v.query_chars), bytes(v.ref_chars)) for v in one], s
+        differs += mine != [(v.query_pos, bytes(v.query_chars), bytes(v.ref_chars)) for v in got[s]]
+    assert differs > 0  # (the reverse-complemented stretches change some calls: the option is not a no-op here)
 
 
 def test_host_batches_over_two_distinct_devices(oracle):

@@ -17,6 +17,8 @@ CHECK = int(os.environ.get("CHECK", 200))
 g = synth.genome(G)
 sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=K, num_threads=16))
 sbwt.to_device()
+if os.environ.get("SLAB_MB"):
+    kbo_amd.lib().kbo_set_slab_bytes(int(os.environ["SLAB_MB"]) << 20)
 rng = np.random.default_rng(7)
 acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
 t0 = time.perf_counter()
