@@ -28,6 +28,9 @@ pub mod ffi {
     #[repr(C)] pub struct KboCallOpts { pub max_error_prob: f64, pub sbwt_build_opts: KboBuildOpts }
     #[repr(C)] pub struct KboVariant { pub query_pos: u64, pub query_chars: *const u8, pub query_len: usize,
                                        pub ref_chars: *const u8, pub ref_len: usize }
+    pub const KBO_OPT_INHERIT: i32 = i32::MIN;
+    #[repr(C)] pub struct KboIndexOpts { pub struct_size: u32, pub plan: i32, pub depth_table: i32, pub depth_table_anchors: i32,
+                                         pub slab_bytes: u64, pub n_devices: i32, pub devices: [i32; 16] }
     extern "C" {
         pub fn kbo_last_error() -> *const c_char;
         pub fn kbo_free(p: *mut c_void);
@@ -65,6 +68,26 @@ pub mod ffi {
         pub fn kbo_find_batch_packed(idx: *mut KboIndex, words: *const u32, offsets: *const u64, n_seqs: usize, exc_pos: *const u64,
                                      exc_byte: *const u8, n_exc: usize, opts: *const KboFindOpts, rles: *mut *mut KboRle32,
                                      rle_offsets: *mut u64) -> c_int;
+        // device-resident batches on a hipStream_t (kbo_hip.h): kbo::map / matches for reads as ONE kernel; `_tail`: its second
+        // pass on a second stream, beside the next batch's kernel; packed: 2-bit words in and out
+        pub fn kbo_work_bytes(n_seqs: usize, total_bases: u64, max_seq_len: usize, k: u32) -> usize;
+        pub fn kbo_index_to_device(idx: *mut KboIndex, device: c_int) -> c_int;
+        pub fn kbo_map_batch_dev(idx: *mut KboIndex, d_concat: *const u8, d_offsets: *const u64, n_seqs: usize, total_bases: u64,
+                                 max_seq_len: usize, p: f64, format: c_int, want_ms: c_int, d_ms: *mut u8, d_chars_out: *mut u8,
+                                 d_work: *mut c_void, work_bytes: usize, stream: *mut c_void, fused: *mut c_int) -> c_int;
+        pub fn kbo_map_batch_dev_tail(idx: *mut KboIndex, d_concat: *const u8, d_offsets: *const u64, n_seqs: usize, total_bases: u64,
+                                      max_seq_len: usize, p: f64, format: c_int, want_ms: c_int, d_ms: *mut u8, d_chars_out: *mut u8,
+                                      d_work: *mut c_void, work_bytes: usize, stream: *mut c_void, tail_stream: *mut c_void,
+                                      fused: *mut c_int) -> c_int;
+        pub fn kbo_matches_packed_dev_scratch_bytes(n_seqs: usize, total_bases: u64) -> usize;
+        pub fn kbo_matches_packed_dev(idx: *mut KboIndex, d_words: *const u32, d_offsets: *const u64, n_seqs: usize, total_bases: u64,
+                                      max_seq_len: usize, uniform_len: usize, d_exc_pos: *const u64, d_exc_byte: *const u8, n_exc: usize,
+                                      p: f64, d_words_out: *mut u32, d_scratch: *mut c_void, d_work: *mut c_void, work_bytes: usize,
+                                      stream: *mut c_void, tail_stream: *mut c_void) -> c_int;
+        // options of one handle (what kbo_set_plan / kbo_set_depth_table* / kbo_set_devices / kbo_set_slab_bytes set process-wide)
+        pub fn kbo_index_opts_default(opts: *mut KboIndexOpts) -> c_int;
+        pub fn kbo_index_set_opts(idx: *mut KboIndex, opts: *const KboIndexOpts) -> c_int;
+        pub fn kbo_index_get_opts(idx: *const KboIndex, opts: *mut KboIndexOpts) -> c_int;
     }
 }
 

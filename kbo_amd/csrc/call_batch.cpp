@@ -130,6 +130,7 @@ SiteWindows find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *of
                     // the second pass for these sites while the slab's bases are on the device: a table of q-mer start positions per
                     // sequence (a power of two of at least 1.5 slots per base; none for a sequence beyond 20-bit positions)
                     tab_off.assign(ns + 1, 0);
+                    uint32_t max_slots = 0;
                     for (size_t s = 0; s < ns; s++) {
                         const uint64_t len = off[s + 1] - off[s];
                         uint64_t size = 0;
@@ -138,6 +139,7 @@ SiteWindows find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *of
                             while (size < len + len / 2) size <<= 1;
                         }
                         tab_off[s + 1] = tab_off[s] + size;
+                        max_slots = (uint32_t)std::max<uint64_t>(max_slots, size);
                     }
                     d_tab_off.ensure((ns + 1) * 8);
                     d_tab.ensure(tab_off[ns] * 4 + 16);
@@ -145,9 +147,8 @@ SiteWindows find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *of
                     d_codes.ensure(n_new * 4);
                     part->codes.ensure(n_new * 4);
                     HIP_OK(hipMemcpyAsync(d_tab_off.p, tab_off.data(), (ns + 1) * 8, hipMemcpyHostToDevice, stream));
-                    HIP_OK(hipMemsetAsync(d_tab.p, 0, tab_off[ns] * 4 + 16, stream));
                     HIP_OK(kbo::launch_call_qmer_index(B.q.as<uint8_t>(), B.off.as<uint64_t>(), (uint32_t)ns, second_q, d_tab_off.as<uint64_t>(),
-                                                       d_tab.as<uint32_t>(), d_seq_flag.as<uint8_t>(), stream));
+                                                       d_tab.as<uint32_t>(), d_seq_flag.as<uint8_t>(), tab_off[ns], max_slots, stream));
                     HIP_OK(kbo::launch_call_depths(d_recs.p, d_win.as<uint8_t>(), all.stride, (uint32_t)n_new, B.q.as<uint8_t>(), B.off.as<uint64_t>(), k,
                                                    threshold, second_q, revcomp, d_tab_off.as<uint64_t>(), d_tab.as<uint32_t>(),
                                                    d_seq_flag.as<uint8_t>(), d_codes.as<uint32_t>(), stream));

@@ -27,6 +27,9 @@
 // Integer / byte work only: no MFMA.
 #include "device_util.hpp"
 
+#include <algorithm>
+#include <atomic>
+
 namespace kbo {
 namespace {
 
@@ -34,6 +37,38 @@ __device__ __forceinline__ uint32_t base_code(uint32_t ch) { return ch == 'A' ? 
 __device__ __forceinline__ uint32_t qmer_slot(uint32_t code, uint32_t mask) { return ((code * 0x9E3779B1u) >> 7) & mask; }
 __device__ __forceinline__ uint32_t qmer_tag(uint32_t code) { return ((code * 0x85EBCA6Bu) >> 20) & 0xFFFu; }
 
+// the q-mer start positions of one sequence into `table` (global memory or LDS; size slots, zeroed); returns "holds a byte that is no base"
+template <typename TablePtr>
+__device__ __forceinline__ bool index_sequence(const uint8_t *r, uint32_t len, uint32_t qlen, TablePtr table, uint32_t size)
+{
+    bool mine_bad = false;
+    // four start positions per lane and round: the 16 bases from the first of them on as 2-bit digits, then one shift per q-mer
+    const uint32_t mask = size - 1u;
+    for (uint32_t st0 = 4u * threadIdx.x; st0 < len; st0 += 4u * blockDim.x) {
+        uint64_t digits = 0;  // base st0 + m in bits 2 (15 - m)
+        uint32_t invalid = 0; // bit m: base st0 + m is no base (or lies behind the sequence)
+#pragma unroll
+        for (uint32_t m = 0; m < 16u; m++) {
+            const uint32_t c = st0 + m < len ? base_code(r[st0 + m]) : 4u;
+            digits = (digits << 2) | (c & 3u);
+            invalid |= (c > 3u ? 1u : 0u) << m;
+            if (st0 + m < len && c > 3u) mine_bad = true;
+        }
+        const uint32_t span = (1u << qlen) - 1u;
+#pragma unroll
+        for (uint32_t v4 = 0; v4 < 4u; v4++) {
+            const uint32_t st = st0 + v4;
+            if (st + qlen > len || ((invalid >> v4) & span)) continue;
+            const uint32_t code = (uint32_t)(digits >> (2u * (16u - qlen - v4))) & ((1u << (2u * qlen)) - 1u);
+            const uint32_t v = (st + 1u) | (qmer_tag(code) << 20);
+            uint32_t h = qmer_slot(code, mask);
+            while (atomicCAS(table + h, 0u, v) != 0u) h = (h + 1u) & mask;
+        }
+    }
+    return mine_bad;
+}
+
+// tables in global memory (zeroed by the caller): sequences whose table does not fit the LDS
 __global__ __launch_bounds__(256) void call_qmer_index_kernel(const uint8_t *__restrict__ q, const uint64_t *__restrict__ off, uint32_t n_seqs,
                                                               uint32_t qlen, const uint64_t *__restrict__ tab_off, uint32_t *__restrict__ tab,
                                                               uint8_t *__restrict__ seq_flag)
@@ -47,30 +82,34 @@ __global__ __launch_bounds__(256) void call_qmer_index_kernel(const uint8_t *__r
     __shared__ uint32_t bad;
     if (threadIdx.x == 0) bad = 0;
     __syncthreads();
-    bool mine_bad = false;
-    if (size == 0) mine_bad = len != 0; // no table for this sequence (too long for 20-bit positions): the host does its sites
-    else {
-        const uint8_t *r = q + b0;
-        for (uint32_t st = threadIdx.x; st < len; st += blockDim.x) {
-            uint32_t code = 0;
-            bool ok = true;
-            if (st + qlen <= len) {
-                for (uint32_t m = 0; m < qlen; m++) {
-                    const uint32_t c = base_code(r[st + m]);
-                    ok = ok && c < 4u;
-                    code = (code << 2) | (c & 3u);
-                }
-                if (ok) {
-                    const uint32_t mask = size - 1u, v = (st + 1u) | (qmer_tag(code) << 20);
-                    uint32_t h = qmer_slot(code, mask);
-                    while (atomicCAS(tab + t0 + h, 0u, v) != 0u) h = (h + 1u) & mask;
-                }
-            } else ok = base_code(r[st]) < 4u; // (the last q - 1 bases start no q-mer: only looked at)
-            mine_bad = mine_bad || !ok;
-        }
-    }
+    // (no table for a sequence too long for 20-bit positions: the host does its sites)
+    const bool mine_bad = size == 0 ? len != 0 : index_sequence(q + b0, len, qlen, tab + t0, size);
     if (mine_bad) bad = 1;
     __syncthreads();
+    if (threadIdx.x == 0) seq_flag[s] = bad ? 1 : 0;
+}
+
+// the same with the table put together in LDS (up to 32 Ki slots: sequences of up to 21 k bases) and written out in whole lines:
+// returning atomics on global memory were 1.2 ms per slab of 1 600 reads of 10 kbp (16 M of them), the LDS's are not measurable
+__global__ __launch_bounds__(256) void call_qmer_index_lds_kernel(const uint8_t *__restrict__ q, const uint64_t *__restrict__ off, uint32_t n_seqs,
+                                                                  uint32_t qlen, const uint64_t *__restrict__ tab_off, uint32_t *__restrict__ tab,
+                                                                  uint8_t *__restrict__ seq_flag)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_tab[];
+    const uint32_t s = blockIdx.x;
+    if (s >= n_seqs) return;
+    const uint64_t b0 = off[s];
+    const uint32_t len = (uint32_t)(off[s + 1] - b0);
+    const uint64_t t0 = tab_off[s];
+    const uint32_t size = (uint32_t)(tab_off[s + 1] - t0);
+    __shared__ uint32_t bad;
+    if (threadIdx.x == 0) bad = 0;
+    for (uint32_t i = threadIdx.x * 4u; i < size; i += blockDim.x * 4u) *reinterpret_cast<uint4 *>(lds_tab + i) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const bool mine_bad = size == 0 ? len != 0 : index_sequence(q + b0, len, qlen, lds_tab, size);
+    if (mine_bad) bad = 1;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x * 4u; i < size; i += blockDim.x * 4u) *reinterpret_cast<uint4 *>(tab + t0 + i) = *reinterpret_cast<const uint4 *>(lds_tab + i);
     if (threadIdx.x == 0) seq_flag[s] = bad ? 1 : 0;
 }
 
@@ -199,11 +238,25 @@ __global__ __launch_bounds__(256) void call_depths_kernel(const uint4 *__restric
 
 } // namespace
 
-// table sizes are the caller's (powers of two, tab_off[s + 1] - tab_off[s] slots for sequence s; 0 = none); d_tab zeroed
+// table sizes are the caller's (powers of two >= 64, tab_off[s + 1] - tab_off[s] slots for sequence s; 0 = none).  max_slots = the
+// largest of them: up to 32 Ki the tables are put together in LDS (d_tab need not be zeroed), else in global memory (d_tab zeroed)
 hipError_t launch_call_qmer_index(const uint8_t *d_q, const uint64_t *d_off, uint32_t n_seqs, uint32_t qlen, const uint64_t *d_tab_off,
-                                  uint32_t *d_tab, uint8_t *d_seq_flag, hipStream_t stream)
+                                  uint32_t *d_tab, uint8_t *d_seq_flag, uint64_t total_slots, uint32_t max_slots, hipStream_t stream)
 {
     if (n_seqs == 0) return hipSuccess;
+    if (max_slots <= 32768u) {
+        const uint32_t lds = std::max(max_slots, 64u) * 4u;
+        static std::atomic<uint32_t> attr_set{0};
+        if (attr_set.load() < lds) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(call_qmer_index_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            if (e != hipSuccess) return e;
+            attr_set.store(131072u);
+        }
+        hipLaunchKernelGGL(call_qmer_index_lds_kernel, dim3(n_seqs), dim3(256), lds, stream, d_q, d_off, n_seqs, qlen, d_tab_off, d_tab, d_seq_flag);
+        return hipGetLastError();
+    }
+    const hipError_t e = hipMemsetAsync(d_tab, 0, total_slots * 4, stream);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(call_qmer_index_kernel, dim3(n_seqs), dim3(256), 0, stream, d_q, d_off, n_seqs, qlen, d_tab_off, d_tab, d_seq_flag);
     return hipGetLastError();
 }

@@ -42,6 +42,8 @@ struct DevCopy {
     DevBuf fat;                      // recovery lines of the guided walk (sbwt_index.hpp)
     uint32_t fat_null = 0;
     DevBuf pc_text, pc_pos, pc_node; // path cover (sbwt_index.hpp PathCover), empty when the plan-guided walk is off
+    DevBuf dfilt;                    // ... and the filter in front of the depth table (dfilt_bases bases per string; small indexes)
+    uint32_t dfilt_bases = 0;
     DevBuf pc_tm, seed_pos;          // map_reads_kernel's 2-bit text + marks and its table of seed positions (copies with a depth table)
     // what making this copy cost (kbo_index_device_layout): seconds of host work / device builds / uploads, by part
     bool plan_built = false;         // path cover, recovery lines, tables: made by the first use that pays for them (device_index.cpp)

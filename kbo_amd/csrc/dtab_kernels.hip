@@ -372,9 +372,25 @@ hipError_t regroup_depth_table(const uint8_t *d_plain, uint32_t order, uint8_t *
     return e != hipSuccess ? e : hipGetLastError();
 }
 
-hipError_t build_depth_table(const DevIndexView &ix, uint32_t order, uint8_t *d_tab, void *d_tmp, uint64_t frontier_cap, hipStream_t stream,
-                             uint64_t *d_anchor, uint32_t anchor_bits, uint2 *d_seed, uint32_t seed_d)
+namespace {
+// the table of level F as one bit per string: "these F bases are a suffix of a row" (map_kernels.hip's filter)
+__global__ __launch_bounds__(256) void dtab_filter_kernel(const uint8_t *__restrict__ tab, uint32_t F, uint32_t *__restrict__ out, uint64_t n_words)
 {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    const uint4 a = *reinterpret_cast<const uint4 *>(tab + 32u * w), b = *reinterpret_cast<const uint4 *>(tab + 32u * w + 16u);
+    const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t bits = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < 32u; t++) bits |= (((v[t >> 2] >> (8u * (t & 3u))) & 0xFFu) == F ? 1u : 0u) << t;
+    out[w] = bits;
+}
+} // namespace
+
+hipError_t build_depth_table(const DevIndexView &ix, uint32_t order, uint8_t *d_tab, void *d_tmp, uint64_t frontier_cap, hipStream_t stream,
+                             uint64_t *d_anchor, uint32_t anchor_bits, uint2 *d_seed, uint32_t seed_d, uint32_t *d_filter, uint32_t filter_bases)
+{
+    if (d_filter && (filter_bases < 3u || filter_bases >= order)) return hipErrorInvalidValue;
     if (d_seed) {
         if (seed_d == 0 || seed_d > order || seed_d > 14u) return hipErrorInvalidValue;
         const hipError_t es = hipMemsetAsync(d_seed, 0, (size_t)8 << (2u * seed_d), stream);
@@ -417,6 +433,10 @@ hipError_t build_depth_table(const DevIndexView &ix, uint32_t order, uint8_t *d_
             if (n_out)
                 hipLaunchKernelGGL(dtab_scatter_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, fb, n_out,
                                    (uint8_t)(s == order ? 0x80u : s), d_tab);
+            if (d_filter && s == filter_bases) { // (the table of this level is complete: T[key] == s <=> the string is present)
+                const uint64_t n_words = ((uint64_t)1 << (2u * s)) / 32u;
+                hipLaunchKernelGGL(dtab_filter_kernel, dim3((uint32_t)((n_words + 255) / 256)), dim3(256), 0, stream, d_tab, s, d_filter, n_words);
+            }
             if (n_out && s == seed_d && d_seed) hipLaunchKernelGGL(dtab_seed_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, fb, n_out, d_seed);
             if (n_out && s == order && d_anchor)
                 hipLaunchKernelGGL(dtab_anchor_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, fb, n_out, ix.pc_pos, d_anchor, anchor_bits);
@@ -426,6 +446,10 @@ hipError_t build_depth_table(const DevIndexView &ix, uint32_t order, uint8_t *d_
         std::swap(fa, fb);
         n_in = n_out;
         if (n_in == 0) { // nothing this long: the deeper levels are copies of this one
+            if (d_filter && s < filter_bases) { // (no string of filter_bases bases is present)
+                e = hipMemsetAsync(d_filter, 0, ((size_t)1 << (2u * filter_bases)) / 8u, stream);
+                if (e != hipSuccess) return e;
+            }
             for (uint32_t s2 = s + 1; s2 <= order; s2++) {
                 const size_t quad = (size_t)1 << (2u * (s2 - 1u));
                 for (int c = 1; c < 4; c++) {

@@ -46,6 +46,10 @@ struct DevIndexView {
     // whose k-mer ends with them, 0xFFFFFFFF when there is none
     const uint2 *pc_tm;
     const uint32_t *seed_pos;
+    // ... and its filter in front of the depth table (small indexes): bit [key of dfilt_bases bases] set where that string is a
+    // suffix of a row - 4^dfilt_bases / 8 bytes (2 MB for 12 bases: stays in L2), nullptr when the copy has none
+    const uint32_t *dfilt;
+    uint32_t dfilt_bases;
 };
 
 // One unit of walk work: `len` bases starting at absolute offset `start` of the
@@ -241,7 +245,9 @@ inline size_t dtab_bytes(uint32_t order, bool grouped) { return grouped ? (size_
 hipError_t regroup_depth_table(const uint8_t *d_plain, uint32_t order, uint8_t *d_grouped, hipStream_t stream);
 hipError_t build_depth_table(const DevIndexView &ix, uint32_t order, uint8_t *d_tab, void *d_tmp, uint64_t frontier_cap, hipStream_t stream,
                              uint64_t *d_anchor = nullptr, uint32_t anchor_bits = 0 /* ix.pc_pos must be set when d_anchor is */,
-                             uint2 *d_seed = nullptr, uint32_t seed_d = 0 /* <= order: plan_kernel's seed table ({l, r} per string) */);
+                             uint2 *d_seed = nullptr, uint32_t seed_d = 0 /* <= order: plan_kernel's seed table ({l, r} per string) */,
+                             uint32_t *d_filter = nullptr, uint32_t filter_bases = 0 /* < order: one bit per string of that many bases,
+                             set where it is a suffix of a row (4^filter_bases / 8 bytes) */);
 // slots (log2) of the anchor hash of an index of n rows and a table of `order` bases: twice the strings it can hold
 inline uint32_t dtab_anchor_bits(uint64_t n_rows, uint32_t order)
 {
@@ -310,7 +316,7 @@ inline uint32_t call_gather_stride(uint32_t k) { return 2u * ((k + 15u) / 16u * 
 // the second pass of kbo::call on the device (call_second_kernels.hip): per-sequence tables of q-mer start positions, then per site
 // { rpeak | qpeak << 8 | csl << 16 | flags << 24 } (0xFF = no peak; flags bit 0 = left to the host; ~0 for a void record)
 hipError_t launch_call_qmer_index(const uint8_t *d_q, const uint64_t *d_off, uint32_t n_seqs, uint32_t qlen, const uint64_t *d_tab_off,
-                                  uint32_t *d_tab, uint8_t *d_seq_flag, hipStream_t stream);
+                                  uint32_t *d_tab, uint8_t *d_seq_flag, uint64_t total_slots, uint32_t max_slots, hipStream_t stream);
 hipError_t launch_call_depths(const void *d_recs, const uint8_t *d_win, uint32_t stride, uint32_t n_sites, const uint8_t *d_q,
                               const uint64_t *d_off, uint32_t k, uint32_t thr, uint32_t qlen, bool revcomp, const uint64_t *d_tab_off,
                               const uint32_t *d_tab, const uint8_t *d_seq_flag, uint32_t *d_out, hipStream_t stream);

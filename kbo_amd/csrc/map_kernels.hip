@@ -14,6 +14,11 @@
 //                         dependent load of the row's position);
 //                      2. compare: 16 bases per XOR against the 2-bit text (DevIndexView::pc_tm: text and path-start marks
 //                         interleaved, 0.5 B per row: 2.5 MB on a 5 Mbp index, L2-resident where the byte text was not);
+//                      2b. (direct form) a read that leaves its diagonal - an insertion, a deletion, a chimera, a first seed that
+//                         sat elsewhere - gets a SECOND diagonal seeded from its last bases and is cut where the two together
+//                         mismatch least, behind the stretch both match (the cut is a break like a mismatch, with the second
+//                         diagonal's ramp starting in front of it by the bases both match; no break of its own when it stands
+//                         right behind a mismatch);
 //                      3. the stretches behind the mismatches from the depth table (dtab_kernels.hip has the rule), the wave's
 //                         mismatches dealt out to its lanes as in plan_kernel<FUSE>; the MS values - k where nothing
 //                         happened, the ramp behind a mismatch, the table's values right behind it - are put together in LDS
@@ -24,6 +29,9 @@
 //   Reads it cannot finish - a base deeper than the table knows, more mismatches than a list holds, no seed and a deep match,
 //   a byte that is no base - are flagged exactly as plan_kernel<FUSE> flags them; redo_collect_kernel + the plain walk give
 //   their MS values and launch_derand_flagged their characters.  Nothing depends on a diagonal being right.
+//
+//   (IO = 1, 2)        packed-native: the reads come as 2-bit words (kbo_matches_batch_packed's layout) and go into the digit
+//                      string as they are; with IO = 2 the characters leave as 2-bit words as well.
 //
 //   pack_text_kernel / seed_pos_kernel   build pc_tm and seed_pos on the device from the byte text and the interval table.
 //
@@ -484,7 +492,7 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
     }
 
     // ---- 3. the stretches behind the mismatches from the depth table (rule: dtab_kernels.hip), dealt out to the lanes
-    uint32_t st_look = 0, st_written = 0, st_anch = 0;
+    uint32_t st_look = 0, st_written = 0, st_anch = 0, st_filt = 0; // (direct form: st_written = windows the filter settled)
     {
         const uint32_t order = a.ix.dtab_order;
         // DIRECT: cov = bases between two windows of the proof (header), n_e = windows per mismatch (<= 4: launch_map_reads);
@@ -530,7 +538,7 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
                     const uint32_t t = w - (o_incl - o_n);
                     const uint32_t m = blockmode ? 0u : (uint32_t)spw[owner * 16u + t];
                     uint32_t bytes[4], ee[4];
-                    bool use[4], lastw[4];
+                    bool use[4], lastw[4], look[4];
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; i++) {
                         // the base the window ends at, and whether the window counts: inside the read, `order` bases long, and not the
@@ -549,7 +557,47 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
                             lastw[i] = i * cov >= order - 1u - jn; // the window that starts at the break: nothing stands behind it
                         }
                         bytes[i] = 0;
-                        if (use[i]) {
+                        look[i] = use[i];
+                    }
+                    // the filter in front of the table (small indexes: DevIndexView::dfilt, 2 MB the L2 keeps): a window is absent as
+                    // soon as F of its bases are - F bases that hold the whole break (the mismatch; the junction's bases and what
+                    // lies on both diagonals in front of it), or the window would only repeat what the text says.  Two of them
+                    // where two differ: the rightmost and the leftmost such stretch inside the window.  Three windows in four
+                    // never reach the table (a line fill each) at C2
+                    if (a.ix.dfilt) {
+                        const uint32_t F = a.ix.dfilt_bases, fmask = (1u << (2u * F)) - 1u;
+                        uint32_t zlo, zhi; // the break inside the read (a read without a seed: any stretch will do)
+                        if (blockmode) zlo = zhi = 0xFFFFFFFFu;
+                        else if (t == o_junc) { zlo = m - o_jov; zhi = m + 1u; }
+                        else zlo = zhi = m;
+                        if (blockmode || zhi - zlo < F) {
+                            uint32_t fw[4][2];
+                            bool two[4];
+#pragma unroll
+                            for (uint32_t i = 0; i < 4u; i++) {
+                                fw[i][0] = fw[i][1] = 0xFFFFFFFFu;
+                                two[i] = false;
+                                if (use[i]) {
+                                    const uint32_t e = ee[i], left = e - (order - F); // (ends of the rightmost / leftmost stretch of F bases)
+                                    const uint32_t e1 = blockmode ? e : min(e, zlo + F - 1u), e2 = blockmode ? left : max(zhi, left);
+                                    const uint32_t k1 = (uint32_t)ending_at(o_soff + e1) & fmask, k2 = (uint32_t)ending_at(o_soff + e2) & fmask;
+                                    fw[i][0] = a.ix.dfilt[k1 >> 5] >> (k1 & 31u);
+                                    two[i] = e2 != e1;
+                                    if (two[i]) fw[i][1] = a.ix.dfilt[k2 >> 5] >> (k2 & 31u);
+                                    st_filt += two[i] ? 2u : 1u;
+                                }
+                            }
+#pragma unroll
+                            for (uint32_t i = 0; i < 4u; i++)
+                                if (use[i] && !((fw[i][0] & 1u) && (!two[i] || (fw[i][1] & 1u)))) {
+                                    look[i] = false; // absent: nothing to look up (bytes[i] stays 0: an absent window)
+                                    st_written++;
+                                }
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; i++) {
+                        if (look[i]) {
                             const code_t key = (code_t)ending_at(o_soff + ee[i]) & omask;
                             bytes[i] = !a.ix.dtab_grouped ? a.ix.dtab[key]
                                                           : a.ix.dtab[NP == 16 ? dtab_grouped_addr32((uint32_t)key, ee[i] % 3u, order) : dtab_grouped_addr((uint64_t)key, ee[i] % 3u, order)];
@@ -789,7 +837,7 @@ __global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stag
         if (g0 >= lo && g0 + 16u <= wave_hi) __builtin_memcpy(a.chars_out + g0, &v, 16);
         else st_range16(a.chars_out + g0, v, lo > g0 ? min(lo - g0, 16u) : 0u, min(wave_hi - g0, 16u));
     }
-    plan_stats_add(a.pstats, kPlanStatSeedLookups, st_lookups, kPlanStatSeedExtensions, 0u, kPlanStatMismatches, seeded ? cnt : 0u, 0, 0);
+    plan_stats_add(a.pstats, kPlanStatSeedLookups, st_lookups, kPlanStatSeedExtensions, st_filt /* (this kernel: filter look-ups) */, kPlanStatMismatches, seeded ? cnt : 0u, 0, 0);
     plan_stats_add(a.pstats, kPlanStatTabLookups, st_look, kPlanStatTabWritten, st_written, kPlanStatTabFlagged, flag ? 1u : 0u,
                    kPlanStatTabAnchored, st_anch);
     const uint64_t fm = __ballot(flag), nm = __ballot(no_plan);
