@@ -939,8 +939,11 @@ def main(argv=None):
             lines_min = (2 * dev.total / 128 + c["seed_lookups"] + c["tab_lookups"]) / dev.n_seqs  # streams + one line per table access
             roofline = {
                 "bound": "hbm",
-                "bound_detail": "random fills: per read one seed-position look-up, three depth-table bytes per mismatch (each a line of its own), "
-                                "the 2-bit text on the diagonal (L2 / Infinity Cache) and 2 B per base of streams; integer work, no MFMA",
+                "bound_detail": "integer gather work, no MFMA: per read one seed-position look-up, three depth-table bytes per mismatch (each a line "
+                                "of its own), the 2-bit text on the diagonal (L2 / Infinity Cache) and 2 B per base of streams.  Not bound by those "
+                                "fills any more (a filter that removes a quarter of the L2 misses changes nothing, DESIGN.md 4.1): the wave's own "
+                                "chain - about six dependent memory rounds and 4 300 VALU instructions per 64 reads - is what is left"
+                                + ("; the timed kernels ran beside the other batch's second pass (batches_in_flight)" if piped else ""),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "frac_meaning": "compulsory bytes of map_reads_kernel (counted by the kernel on the timed reads: bytes_by_part) x bases per step / "
                                 "its own duration (HIP events around it in every timed step) / 8 TB/s",

@@ -38,6 +38,7 @@
 // Integer / byte work only: no MFMA.  One 64-lane wave per workgroup (the LDS of a CU then holds twelve of them).
 #include "device_util.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
@@ -145,11 +146,14 @@ __device__ __forceinline__ uint32_t pack_chars16(const uint4 &v)
 }
 
 template <int NP, bool DIRECT, int IO = 0>
-__global__ __launch_bounds__(64) void map_reads_kernel(WalkArgs a, uint32_t stage_bytes, uint32_t lin_words)
+__global__ __launch_bounds__(256) void map_reads_kernel(WalkArgs a, uint32_t stage_bytes, uint32_t lin_words)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t map_lds[];
+    extern __shared__ __attribute__((aligned(16))) uint8_t map_lds_all[];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t idx = blockIdx.x * 64u + lane;
+    // (the waves of a workgroup share nothing: each has its own part of the LDS and never waits for another)
+    const uint32_t wave_lds = (stage_bytes + 4u * (lin_words + 4u) + 1024u + 15u) & ~15u;
+    uint8_t *map_lds = map_lds_all + (threadIdx.x >> 6) * wave_lds;
+    const uint32_t idx = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane;
     uint8_t *so = map_lds;                                                       // MS bytes, then characters: the wave's stretch
     uint32_t *lin = reinterpret_cast<uint32_t *>(map_lds + stage_bytes) + 4;     // the stretch as 2-bit digits (lin[-1] = 0)
     uint8_t *spw = map_lds + stage_bytes + 4u * (lin_words + 4u);                // 64 x 16 bytes: mismatch positions 0 .. 12, flag, prefix
@@ -904,8 +908,12 @@ hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
     // (packed: every read starts a word of the digit string and, with the characters packed as well, of the byte region)
     const uint32_t stage_bytes = io ? (64u * 16u * ((a.max_item_len + 15u) / 16u) + 32u + kMapSlack) : (64u * a.max_item_len + 16u + kMapSlack + 15u) / 16u * 16u;
     const uint32_t lin_words = stage_bytes / 16u + 4u;
-    const uint32_t lds = stage_bytes + 4u * (lin_words + 4u) + 1024u;
-    const dim3 grid((a.n_items + 63u) / 64u), block(64);
+    const uint32_t lds_wave = (stage_bytes + 4u * (lin_words + 4u) + 1024u + 15u) & ~15u;
+    static const int env_wpb = std::getenv("KBO_MAP_WPB") ? std::atoi(std::getenv("KBO_MAP_WPB")) : 1; // experiments: waves per workgroup
+    const uint32_t wpb = (uint32_t)std::min(4, std::max(1, env_wpb));
+    const uint32_t n_waves = (a.n_items + 63u) / 64u;
+    const dim3 grid((n_waves + wpb - 1u) / wpb), block(64u * wpb);
+    const uint32_t lds = lds_wave * wpb;
     if (a.ix.dtab_order <= 15u) {
         if (io == 2) hipLaunchKernelGGL((map_reads_kernel<16, true, 2>), grid, block, lds, stream, a, stage_bytes, lin_words);
         else if (io == 1) hipLaunchKernelGGL((map_reads_kernel<16, true, 1>), grid, block, lds, stream, a, stage_bytes, lin_words);
