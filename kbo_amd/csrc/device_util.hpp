@@ -111,6 +111,24 @@ __device__ __forceinline__ void pack16(const uint4 &v, uint32_t &code, uint32_t 
     }
 }
 
+// the same for a block whose 16 bytes all count: the digits, and whether any byte is no base (a quarter of pack16's instructions:
+// the letters the digits stand for come from one byte permute, the digits of four bytes are gathered by one multiplication, and
+// no per-byte mask is made - map_kernels.hip spent 40 % of its vector instructions in pack16)
+__device__ __forceinline__ void pack16_whole(const uint4 &v, uint32_t &code, bool &any_invalid)
+{
+    code = 0;
+    uint32_t diff = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t x = w == 0 ? v.x : w == 1 ? v.y : w == 2 ? v.z : v.w;
+        uint32_t c2 = (x >> 1) & 0x03030303u;
+        c2 ^= (x >> 2) & 0x01010101u;
+        diff |= __builtin_amdgcn_perm(0u, 0x54474341u, c2) ^ x;      // "ACGT"[digit] against the byte that is there
+        code = (code << 8) | ((c2 * 0x40100401u) >> 24);            // b0 b1 b2 b3 as 2-bit digits, b0 first
+    }
+    any_invalid = diff != 0;
+}
+
 // 16 ASCII bases -> 2-bit digits (first byte most significant); a byte that is no base gives some digit
 __device__ __forceinline__ uint32_t digits16(const uint4 &v)
 {

@@ -97,7 +97,9 @@ __global__ __launch_bounds__(256) void seed_pos_kernel(const uint2 *__restrict__
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n) return;
     const uint2 iv = seed_tab[w];
-    out[w] = iv.x < iv.y ? pc_pos[iv.x] : 0xFFFFFFFFu;
+    // (bit 31: more than one row ends with this string - the position is the first one's; text positions are below 2^31 wherever
+    // this table is made: copies with a depth table have at most 1.2 * 10^9 rows)
+    out[w] = iv.x < iv.y ? (pc_pos[iv.x] | (iv.y - iv.x > 1u ? 0x80000000u : 0u)) : 0xFFFFFFFFu;
 }
 
 __device__ __forceinline__ bool thr_gt(uint32_t thr, uint32_t order) { return thr > order; } // (windows order .. thr apart exist)
@@ -208,29 +210,53 @@ __global__ __launch_bounds__(256) void map_reads_kernel(WalkArgs a, uint32_t sta
         for (uint32_t c = lane * 16u; c < span + 16u; c += 1024u)
             *reinterpret_cast<uint4 *>(so + c) = make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);
         has_invalid = plannable && a.qp_exc != nullptr && a.qp_exc[idx] != 0;
-    } else
-    for (uint32_t c0 = 0; c0 < nblk + 2u; c0 += 64u) {
-        const uint32_t c = c0 + lane;
-        uint32_t code = 0, valid = 0xFFFFu;
-        if (c < nblk) {
-            const uint4 v = ld16u(qb, base16 + 16u * c); // (reads <= 15 bytes past the last read)
-            pack16(v, code, valid);
-            // DIRECT: the characters start out as what nearly all of them are - 'M', or with relative_to_ref the read's own bases
-            if (DIRECT) *reinterpret_cast<uint4 *>(so + 16u * c) = a.map_fmt ? v : make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);
-            // only the bytes of this wave's reads count: [lo, wave_hi)
-            const uint32_t b0 = base16 + 16u * c;
-            const uint32_t from = lo > b0 ? lo - b0 : 0u, to = min(16u, wave_hi - b0);
-            const uint32_t inr = ((1u << to) - 1u) & ~((1u << from) - 1u);
-            valid |= ~inr;
+    } else {
+    // (six blocks per lane in flight: the loads of a stretch go out in two rounds instead of one per 1 KB (eleven: the compiler
+    // keeps the blocks in scratch, 296 us against 231) - a wave's life is the
+    // sum of its dependent memory rounds, 19 of them before this, and the kernel's time follows it: neither fewer fills, nor fewer
+    // instructions, nor more resident waves had changed it)
+    constexpr uint32_t kStageUnroll = 6;
+    for (uint32_t c00 = 0; c00 < nblk + 2u; c00 += 64u * kStageUnroll) {
+        uint4 vv[kStageUnroll];
+#pragma unroll
+        for (uint32_t u = 0; u < kStageUnroll; u++) {
+            const uint32_t c = c00 + 64u * u + lane;
+            vv[u] = make_uint4(0, 0, 0, 0);
+            if (c < nblk) vv[u] = ld16u(qb, base16 + 16u * c); // (reads <= 15 bytes past the last read)
         }
-        if (c < lin_words) lin[c] = code;
-        uint64_t bm = __ballot((valid & 0xFFFFu) != 0xFFFFu);
-        while (bm) { // (rare: a byte that is no base - its read, and a neighbour that shares the block, take the plain walk)
-            const uint32_t L = (uint32_t)__ffsll((long long)bm) - 1u;
-            bm &= bm - 1ull;
-            const uint32_t blo = 16u * (c0 + L);
-            has_invalid = has_invalid || (plannable && soff < blo + 16u && soff + len > blo);
+#pragma unroll
+        for (uint32_t u = 0; u < kStageUnroll; u++) {
+            const uint32_t c0 = c00 + 64u * u;
+            if (c0 >= nblk + 2u) break;
+            const uint32_t c = c0 + lane;
+            uint32_t code = 0, valid = 0xFFFFu;
+            if (c < nblk) {
+                const uint4 v = vv[u];
+                // DIRECT: the characters start out as what nearly all of them are - 'M', or with relative_to_ref the read's own bases
+                if (DIRECT) *reinterpret_cast<uint4 *>(so + 16u * c) = a.map_fmt ? v : make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);
+                // only the bytes of this wave's reads count: [lo, wave_hi)
+                const uint32_t b0 = base16 + 16u * c;
+                const uint32_t from = lo > b0 ? lo - b0 : 0u, to = min(16u, wave_hi - b0);
+                if (from == 0u && to == 16u) { // (all but the wave's first and last block)
+                    bool bad;
+                    pack16_whole(v, code, bad);
+                    valid = bad ? 0u : 0xFFFFu;
+                } else {
+                    pack16(v, code, valid);
+                    const uint32_t inr = ((1u << to) - 1u) & ~((1u << from) - 1u);
+                    valid |= ~inr;
+                }
+            }
+            if (c < lin_words) lin[c] = code;
+            uint64_t bm = __ballot((valid & 0xFFFFu) != 0xFFFFu);
+            while (bm) { // (rare: a byte that is no base - its read, and a neighbour that shares the block, take the plain walk)
+                const uint32_t L = (uint32_t)__ffsll((long long)bm) - 1u;
+                bm &= bm - 1ull;
+                const uint32_t blo = 16u * (c0 + L);
+                has_invalid = has_invalid || (plannable && soff < blo + 16u && soff + len > blo);
+            }
         }
+    }
     }
     if (!DIRECT)
         for (uint32_t c = lane * 16u; c < span + 16u; c += 1024u) // MS bytes: k wherever nothing says otherwise
@@ -278,19 +304,31 @@ __global__ __launch_bounds__(256) void map_reads_kernel(WalkArgs a, uint32_t sta
         return 0xFFFFFFFFu;
     };
     const uint32_t jmax = min(len, cap);
-    uint32_t e = D - 1u, p0 = 0, st_lookups = 0;
-    bool seeded = false;
+    uint32_t e = D - 1u, p0 = 0, st_lookups = 0, p_amb = 0;
+    bool seeded = false, have_amb = false;
     for (;;) {
         const bool act = plannable && !has_invalid && !seeded && e < jmax;
         if (__ballot(act) == 0) break;
         if (act) {
             const uint32_t tp = seed_at(e);
             st_lookups++;
-            if (tp != 0xFFFFFFFFu) {
+            if (tp != 0xFFFFFFFFu && (by_anchor || !(tp & 0x80000000u) || (a.rounds & 1u))) { // (a.rounds: experiment switches)
                 seeded = true;
-                p0 = tp - e;
-            } else e += (D + 1u) / 2u;
+                p0 = (by_anchor ? tp : (tp & 0x7FFFFFFFu)) - e;
+            } else {
+                // a string that ends several rows (2 % of the seeds at 5 * 10^6 rows, the wrong row half of the time - and a wrong
+                // diagonal sends the whole wave through the second-diagonal search): kept for later, the next window first
+                if (tp != 0xFFFFFFFFu && !have_amb) {
+                    have_amb = true;
+                    p_amb = (tp & 0x7FFFFFFFu) - e;
+                }
+                e += (D + 1u) / 2u;
+            }
         }
+    }
+    if (plannable && !has_invalid && !seeded && have_amb) { // (no window that ends one row only: a repeat - its first copy will do)
+        seeded = true;
+        p0 = p_amb;
     }
 
     // ---- 2. compare with the text on the diagonal: mm[g] has bit 2 (15 - j) set where base 16 g + j differs from the text (or the
@@ -357,7 +395,7 @@ __global__ __launch_bounds__(256) void map_reads_kernel(WalkArgs a, uint32_t sta
                     st_lookups++;
                     if (tp != 0xFFFFFFFFu) {
                         seedB = true;
-                        pB = tp - eb;
+                        pB = (by_anchor ? tp : (tp & 0x7FFFFFFFu)) - eb;
                     } else eb -= min(eb, (D + 1u) / 2u);
                 }
             }
@@ -896,6 +934,8 @@ hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
     a.unit_bail = a.n_items / 2u + 64u;
     a.plan_list = kPlanList;
     a.plan_cap = (uint32_t)g_plan_cap.load();
+    static const int env_x = std::getenv("KBO_MAP_X") ? std::atoi(std::getenv("KBO_MAP_X")) : 0; // experiments: bit 0 = ambiguous seeds as they come
+    a.rounds = (uint32_t)env_x;
     static const int env_piece = std::getenv("KBO_REDO_PIECE") ? std::atoi(std::getenv("KBO_REDO_PIECE")) : 0; // experiments
     // (pieces of 16 bases + k - 1 warm-up bases: the pass is as long as its longest chain, and the kernel leaves it under 2 % of the reads:
     // 32 / 16 / 8 bases at C2 0.422 / 0.414 / 0.472 ms per step)
@@ -913,7 +953,8 @@ hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
     const uint32_t wpb = (uint32_t)std::min(4, std::max(1, env_wpb));
     const uint32_t n_waves = (a.n_items + 63u) / 64u;
     const dim3 grid((n_waves + wpb - 1u) / wpb), block(64u * wpb);
-    const uint32_t lds = lds_wave * wpb;
+    static const int env_pad = std::getenv("KBO_MAP_LDS_PAD") ? std::atoi(std::getenv("KBO_MAP_LDS_PAD")) : 0; // experiments: fewer resident waves
+    const uint32_t lds = lds_wave * wpb + (uint32_t)env_pad;
     if (a.ix.dtab_order <= 15u) {
         if (io == 2) hipLaunchKernelGGL((map_reads_kernel<16, true, 2>), grid, block, lds, stream, a, stage_bytes, lin_words);
         else if (io == 1) hipLaunchKernelGGL((map_reads_kernel<16, true, 1>), grid, block, lds, stream, a, stage_bytes, lin_words);
