@@ -32,6 +32,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime spreads a process's streams over 4 hardware queues by default.  This process has torch's current stream, the
+# second-pass stream and the three stage streams of the host batch pipeline: with 4 queues the pipeline's upload, kernel and
+# download streams share queues with each other and stop overlapping (kbo_map_batch 21 instead of 40 Gbp/s, packed 72 instead of
+# 123: tools/dbg_h2h3.py).  Read by the runtime when it starts, so set before anything touches the GPU; a value given from outside wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 FILL_CEILING_PER_S = 56e9   # L2-miss line fills/s this part delivers to dependent 16-byte gathers from tables beyond L2:
@@ -819,6 +824,10 @@ def main(argv=None):
         gpu_d = dev.ms.cpu().numpy()
         cpu = b_ref = exact = ops = b_plan = model = None
         sens = h2h = None
+        if world == 1 and not args.no_cpu_baseline and not args.no_extras and (args.extras or not args.custom):
+            # (first of the legs behind the timed region: its pinned staging buffers are made by its first call, and behind the
+            # oracle's and the variants' gigabytes of host allocations they come out of scattered pages - 21 instead of 40 Gbp/s)
+            h2h = host_to_host_leg(args, sbwt, genome)
         planned = (not args.no_plan) and sbwt.device_plan_bytes() > 0
         if not args.no_cpu_baseline:
             from oracle import binding as ora
@@ -848,7 +857,6 @@ def main(argv=None):
                 exact = bool(exact and model["ms_equal_to_gpu"])
             if world == 1 and not args.no_extras and (args.extras or not args.custom):
                 sens = sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, tail)
-                h2h = host_to_host_leg(args, sbwt, genome)
         # fabric-side traffic and L2 misses of the A1 stage, from the committed rocprofv3 passes of this exact
         # workload and walk mode (PMC passes cannot run inside the timed region: separate runs, tools/profile_bench.sh)
         wl_key = f"{args.genome}x{n_mine}x{args.read_len}x{args.sub_rate:g}:{('map' if one_kernel else 'table' if sbwt.depth_table_order() > 0 else 'plan') if planned else 'plain'}"

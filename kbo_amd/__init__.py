@@ -7,10 +7,16 @@ include/kbo_hip.h.  All matching-statistics / derandomize / translate compute ru
 hand-written gfx950 HIP kernels; there is no CPU fallback.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Optional
 
 import numpy as np
+
+# The host batch pipeline keeps three streams per device (upload, kernels, download) next to whatever the caller uses; the HIP runtime
+# maps a process's streams onto 4 hardware queues unless told otherwise, and streams that share a queue do not overlap
+# (INTEGRATION.md "Streams and hardware queues").  Only effective before the runtime starts; a value from outside wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from . import _capi, derandomize, format, gap_filling, index, translate, variant_calling  # noqa: F401
 from ._capi import KboError, check, lib  # noqa: F401

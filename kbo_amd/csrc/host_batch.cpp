@@ -385,9 +385,11 @@ struct HostCtx {
     explicit HostCtx(int d) : dev(d)
     {
         for (hipStream_t *st : {&st_up, &st_run, &st_down}) HIP_OK(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
-        int pr_lo = 0, pr_hi = 0; // (the second pass is a chain of dependent look-ups of a few waves: it goes first wherever it can)
-        HIP_OK(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
-        HIP_OK(hipStreamCreateWithPriority(&st_tail, hipStreamNonBlocking, pr_hi));
+        if (std::getenv("KBO_HOST_TAIL") && std::atoi(std::getenv("KBO_HOST_TAIL")) != 0) { // (experiment: enqueue_walk_host; every stream takes part of a hardware queue)
+            int pr_lo = 0, pr_hi = 0; // (the second pass is a chain of dependent look-ups of a few waves: it goes first wherever it can)
+            HIP_OK(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
+            HIP_OK(hipStreamCreateWithPriority(&st_tail, hipStreamNonBlocking, pr_hi));
+        }
         for (HostSlot &S : slot)
             for (hipEvent_t *e : {&S.copied, &S.computed, &S.done, &S.fence}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
@@ -435,7 +437,8 @@ struct CtxLease { // takes a context of the device out of the pool (or makes one
             S.busy = false;
         }
         if (busy)
-            for (hipStream_t st : {ctx->st_up, ctx->st_run, ctx->st_down, ctx->st_tail}) (void)hipStreamSynchronize(st);
+            for (hipStream_t st : {ctx->st_up, ctx->st_run, ctx->st_down, ctx->st_tail})
+                if (st) (void)hipStreamSynchronize(st);
         // keep at most kPooledPerDevice contexts per device (each holds ~0.8 GB of device and ~0.3 GB of
         // pinned memory at the default slab size); the scratch of further concurrent callers is freed
         std::unique_lock<std::mutex> g(g_ctx_mu);
