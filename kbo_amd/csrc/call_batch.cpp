@@ -11,6 +11,9 @@
 #include "capi_internal.hpp"
 
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <cstdlib>
 #include <cstdio>
 #include <chrono>
@@ -57,15 +60,107 @@ struct SiteWindows {
     const uint8_t *win(uint32_t part, uint32_t x) const { return parts[part]->win.as<uint8_t>() + (size_t)x * stride; }
 };
 
+// host threads that take tasks while the calling thread drives the device (kbo_call_batch: the sites of slab i are resolved while
+// the device walks slab i + 1); wait() returns when nothing is queued or running and rethrows the first exception a task threw
+class AsyncPool {
+public:
+    explicit AsyncPool(unsigned n)
+    {
+        for (unsigned t = 0; t < n; t++) threads_.emplace_back([this] { loop(); });
+    }
+    ~AsyncPool()
+    {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    void submit(std::function<void()> f)
+    {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            queue_.push_back(std::move(f));
+            pending_++;
+        }
+        cv_.notify_one();
+    }
+    void wait() // (the caller helps: a pool of 0 threads still works)
+    {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                if (queue_.empty()) {
+                    done_cv_.wait(g, [&] { return pending_ == 0 || !queue_.empty(); });
+                    if (pending_ == 0) break;
+                    continue;
+                }
+                f = std::move(queue_.front());
+                queue_.pop_front();
+            }
+            run(f);
+        }
+        std::exception_ptr e;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            std::swap(e, err_);
+        }
+        if (e) std::rethrow_exception(e);
+    }
+    bool failed()
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        return (bool)err_;
+    }
+
+private:
+    void run(std::function<void()> &f)
+    {
+        try {
+            f();
+        } catch (...) {
+            std::lock_guard<std::mutex> g(mu_);
+            if (!err_) err_ = std::current_exception();
+        }
+        std::lock_guard<std::mutex> g(mu_);
+        if (--pending_ == 0 || !queue_.empty()) done_cv_.notify_all();
+    }
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return stop_ || !queue_.empty(); });
+                if (queue_.empty()) return; // (stop_)
+                f = std::move(queue_.front());
+                queue_.pop_front();
+            }
+            run(f);
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    std::deque<std::function<void()>> queue_;
+    std::vector<std::thread> threads_;
+    size_t pending_ = 0;
+    bool stop_ = false;
+    std::exception_ptr err_;
+};
+
 // first pass on the device: sites of sequences [0, n_seqs) with their windows.  Normally the walk itself finds them
 // (call mode of ms_walk_kernel: no intervals are written at all); a slab in which a lane had more than four breakpoints
 // waiting at once, or whose site lists overflowed, is done again the long way (walk with intervals + call_sites_kernel).
 // Sites of slab-relative sequence numbers are shifted to batch-wide ones by the caller (SiteRec::seq + Part's first).
 // second_q != 0: the second pass's three values per site as well (q-mers of that many bases index the slab's sequences)
-SiteWindows find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, uint32_t threshold,
-                       std::vector<size_t> &part_first_seq, uint32_t second_q, bool revcomp)
+// on_part(part, its index, its first sequence, its sequences): called once the part's records are on the host
+// (`all` is the caller's: the parts have to outlive whatever on_part started, also when this function throws)
+void find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, uint32_t threshold,
+                std::vector<size_t> &part_first_seq, uint32_t second_q, bool revcomp,
+                const std::function<void(SiteWindows::Part *, uint32_t, size_t, size_t)> &on_part, SiteWindows &all)
 {
-    SiteWindows all;
     const uint32_t k = idx->host.k;
     all.stride = kbo::call_gather_stride(k);
     all.kpad = (k + 15u) / 16u * 16u;
@@ -161,10 +256,10 @@ SiteWindows find_sites(kbo_index *idx, const uint8_t *concat, const uint64_t *of
             }
             all.parts.push_back(std::move(part));
             part_first_seq.push_back(sl.s0);
+            if (on_part) on_part(all.parts.back().get(), (uint32_t)(all.parts.size() - 1), sl.s0, ns);
             break;
         }
     }
-    return all;
 }
 
 // ---- the reference-side walk of a site (variant_calling.rs:280: the matched row's k-mer against the index of the sequence
@@ -288,107 +383,110 @@ extern "C" int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, con
         // long as the threshold and positions fit its tables; the host then only puts the variants together
         static const int env_second = std::getenv("KBO_CALL_DEVICE_SECOND") ? std::atoi(std::getenv("KBO_CALL_DEVICE_SECOND")) : 1; // experiments
         const uint32_t second_q = (env_second && d >= 6 && d <= 255 && k <= 255 && k >= 2) ? (uint32_t)std::min<size_t>(12, d) : 0u;
-        const SiteWindows sw = find_sites(query_idx, concat, offsets, n_seqs, (uint32_t)d, part_seq0, second_q, o.sbwt_build_opts.add_revcomp != 0);
-        clk.lap("first pass (sites + windows)");
-        // ---- sites by sequence (counting sort over the parts; a sequence's few sites are put in order of i by its worker)
+        // ---- second pass, per sequence, on host threads that take a slab's sites as soon as its records are on the host - while the
+        // device walks the next slabs.  (The per-sequence index of lib.rs:553 is never built: its build depends on k and add_revcomp
+        // only, both checked above, so it cannot fail for one sequence and not for another; a sequence without sites yields no
+        // variants either way.)
         struct Ref { uint32_t part, x; };
-        std::vector<size_t> first(n_seqs + 1, 0);
-        for (size_t p = 0; p < sw.parts.size(); p++) {
-            const SiteRec *r = sw.parts[p]->recs.as<SiteRec>();
-            for (size_t x = 0; x < sw.parts[p]->n; x++)
-                if (r[x].seq != 0xFFFFFFFFu) first[part_seq0[p] + r[x].seq + 1]++; // (void records: sites of items the redo pass scanned again)
-        }
-        for (size_t s = 0; s < n_seqs; s++) first[s + 1] += first[s];
-        std::vector<Ref> order(first[n_seqs]);
-        {
-            std::vector<size_t> fill(first.begin(), first.end() - 1);
-            for (size_t p = 0; p < sw.parts.size(); p++) {
-                const SiteRec *r = sw.parts[p]->recs.as<SiteRec>();
-                for (size_t x = 0; x < sw.parts[p]->n; x++)
-                    if (r[x].seq != 0xFFFFFFFFu) order[fill[part_seq0[p] + r[x].seq]++] = Ref{(uint32_t)p, (uint32_t)x};
-            }
-        }
-        clk.lap("sites by sequence");
-        // ---- second pass, per sequence on host threads.  (The per-sequence index of lib.rs:553 is never built: its build
-        // depends on k and add_revcomp only, both checked above, so it cannot fail for one sequence and not for another;
-        // a sequence without sites yields no variants either way.)
         struct Call { uint32_t i; uint16_t q_from, q_len, r_from, r_len; Ref site; }; // characters: slices of the two k-mers
         std::vector<std::vector<Call>> calls(n_seqs);
-        {
-            std::atomic<size_t> next{0};
-            std::exception_ptr err;
-            std::mutex mu;
-            const kbo::HostNav nav(query_idx->host);
-            const bool revcomp = o.sbwt_build_opts.add_revcomp != 0;
-            auto work = [&] {
-                try {
-                    RunAutomaton sam;
-                    std::vector<uint32_t> dq(k), dr(k);
-                    std::vector<uint8_t> qk(k), rk_spelled;
-                    std::vector<Ref> mine;
-                    for (;;) {
-                        const size_t s0 = next.fetch_add(16);
-                        if (s0 >= n_seqs) break;
-                        for (size_t s = s0; s < std::min(n_seqs, s0 + 16); s++) {
-                            const size_t a = first[s], b = first[s + 1];
-                            if (a == b) continue;
-                            const uint8_t *seq = concat + offsets[s];
-                            const size_t len = (size_t)(offsets[s + 1] - offsets[s]);
-                            mine.assign(order.begin() + a, order.begin() + b);
-                            std::sort(mine.begin(), mine.end(), [&](const Ref &x, const Ref &y) { return sw.rec(x.part, x.x).i < sw.rec(y.part, y.x).i; });
-                            bool sam_built = false;
-                            for (const Ref &sr : mine) {
-                                const SiteRec &r = sw.rec(sr.part, sr.x);
-                                const uint32_t code = sw.code(sr.part, sr.x);
-                                if (!(code >> 24)) { // the device did this site: the common suffix and the two peaks are all resolve_variant reads
-                                    const uint32_t rp = code & 0xFFu, qp = (code >> 8) & 0xFFu, csl = (code >> 16) & 0xFFu;
-                                    size_t qf, qt, rf, rt;
-                                    if (kbo::resolve_variant_peaks(k, csl, qp != 0xFFu, qp, rp != 0xFFu, rp, qf, qt, rf, rt))
-                                        calls[s].push_back(Call{r.i, (uint16_t)qf, (uint16_t)(qt - qf), (uint16_t)rf, (uint16_t)(rt - rf), sr});
-                                    continue;
-                                }
-                                if (!sam_built) { // (a site left to the host: the sequence's suffix automaton, once)
-                                    sam.build(seq, len, k, revcomp);
-                                    sam_built = true;
-                                }
-                                const uint8_t *w = sw.win(sr.part, sr.x);
-                                // query-side k-mer (variant_calling.rs:46-58, 275) and its walk against the index (:279): the MS
-                                // values of the first pass, capped by the distance from the k-mer's (or the sequence's) first base
-                                for (uint32_t t = 0; t < k; t++) {
-                                    const int64_t pos = (int64_t)r.j - (int64_t)(k - 1u) + t;
-                                    if (pos < 0) { qk[t] = '$'; dr[t] = 0; continue; } // '$': the walk restarts behind it
-                                    qk[t] = seq[pos];
-                                    dr[t] = std::min<uint32_t>(w[t], (uint32_t)std::min<int64_t>(t + 1u, pos + 1));
-                                }
-                                // matched row's k-mer (:276): from the device's path cover, or spelled here when its window crosses a
-                                // path start
-                                const uint8_t *rk = w + sw.kpad;
-                                if (w[2u * sw.kpad]) {
-                                    nav.access_kmer(r.lo, rk_spelled);
-                                    rk = rk_spelled.data();
-                                }
-                                sam.depths(rk, k, dq.data()); // its walk against the sequence's own index (:280)
-                                size_t qf, qt, rf, rt;
-                                if (kbo::resolve_variant_ranges(qk.data(), rk, dq.data(), dr.data(), k, d, qf, qt, rf, rt)) // :282-284
-                                    calls[s].push_back(Call{r.i, (uint16_t)qf, (uint16_t)(qt - qf), (uint16_t)rf, (uint16_t)(rt - rf), sr});
-                            }
-                        }
+        SiteWindows sw; // (declared in front of the pool: its parts outlive the tasks that read them)
+        const kbo::HostNav nav(query_idx->host);
+        const bool revcomp = o.sbwt_build_opts.add_revcomp != 0;
+        const uint32_t stride = kbo::call_gather_stride(k), kpad = (k + 15u) / 16u * 16u;
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)hw, (n_seqs + 15) / 16}));
+        AsyncPool pool(nt - 1u); // (the calling thread joins in wait())
+        struct PartOrder { // a part's sites by sequence: sequence s (of the part) has xs[first[s] .. first[s + 1])
+            std::vector<uint32_t> first, xs;
+        };
+        // the sequences [a, b) of a part
+        auto resolve_block = [&, k, d, stride, kpad, revcomp](const SiteWindows::Part *part, uint32_t part_index, size_t seq0,
+                                                                  std::shared_ptr<const PartOrder> po, size_t a, size_t b) {
+            const SiteRec *recs = part->recs.as<SiteRec>();
+            const uint32_t *codes = part->has_codes ? part->codes.as<uint32_t>() : nullptr;
+            RunAutomaton sam;
+            std::vector<uint32_t> dq(k), dr(k), mine;
+            std::vector<uint8_t> qk(k), rk_spelled;
+            for (size_t ls = a; ls < b; ls++) {
+                const size_t fa = po->first[ls], fb = po->first[ls + 1];
+                if (fa == fb) continue;
+                const size_t s = seq0 + ls;
+                const uint8_t *seq = concat + offsets[s];
+                const size_t len = (size_t)(offsets[s + 1] - offsets[s]);
+                mine.assign(po->xs.begin() + fa, po->xs.begin() + fb);
+                std::sort(mine.begin(), mine.end(), [&](uint32_t x, uint32_t y) { return recs[x].i < recs[y].i; });
+                std::vector<Call> &out_calls = calls[s];
+                out_calls.reserve(mine.size());
+                bool sam_built = false;
+                for (const uint32_t x : mine) {
+                    const SiteRec &r = recs[x];
+                    const Ref sr{part_index, x};
+                    const uint32_t code = codes ? codes[x] : 0x01FFFFFFu;
+                    if (!(code >> 24)) { // the device did this site: the common suffix and the two peaks are all resolve_variant reads
+                        const uint32_t rp = code & 0xFFu, qp = (code >> 8) & 0xFFu, csl = (code >> 16) & 0xFFu;
+                        size_t qf, qt, rf, rt;
+                        if (kbo::resolve_variant_peaks(k, csl, qp != 0xFFu, qp, rp != 0xFFu, rp, qf, qt, rf, rt))
+                            out_calls.push_back(Call{r.i, (uint16_t)qf, (uint16_t)(qt - qf), (uint16_t)rf, (uint16_t)(rt - rf), sr});
+                        continue;
                     }
-                } catch (...) {
-                    std::lock_guard<std::mutex> g(mu);
-                    if (!err) err = std::current_exception();
-                    next.store(n_seqs); // (the others stop at their next sequences)
+                    if (!sam_built) { // (a site left to the host: the sequence's suffix automaton, once)
+                        sam.build(seq, len, k, revcomp);
+                        sam_built = true;
+                    }
+                    const uint8_t *w = part->win.as<uint8_t>() + (size_t)x * stride;
+                    // query-side k-mer (variant_calling.rs:46-58, 275) and its walk against the index (:279): the MS
+                    // values of the first pass, capped by the distance from the k-mer's (or the sequence's) first base
+                    for (uint32_t t = 0; t < k; t++) {
+                        const int64_t pos = (int64_t)r.j - (int64_t)(k - 1u) + t;
+                        if (pos < 0) { qk[t] = '$'; dr[t] = 0; continue; } // '$': the walk restarts behind it
+                        qk[t] = seq[pos];
+                        dr[t] = std::min<uint32_t>(w[t], (uint32_t)std::min<int64_t>(t + 1u, pos + 1));
+                    }
+                    // matched row's k-mer (:276): from the device's path cover, or spelled here when its window crosses a path start
+                    const uint8_t *rk = w + kpad;
+                    if (w[2u * kpad]) {
+                        nav.access_kmer(r.lo, rk_spelled);
+                        rk = rk_spelled.data();
+                    }
+                    sam.depths(rk, k, dq.data()); // its walk against the sequence's own index (:280)
+                    size_t qf, qt, rf, rt;
+                    if (kbo::resolve_variant_ranges(qk.data(), rk, dq.data(), dr.data(), k, d, qf, qt, rf, rt)) // :282-284
+                        out_calls.push_back(Call{r.i, (uint16_t)qf, (uint16_t)(qt - qf), (uint16_t)rf, (uint16_t)(rt - rf), sr});
                 }
-            };
-            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-            const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)hw, (n_seqs + 15) / 16}));
-            std::vector<std::thread> th;
-            for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
-            work();
-            for (auto &x : th) x.join();
-            if (err) std::rethrow_exception(err);
-        }
-        clk.lap("second pass (host threads)");
+            }
+        };
+        // a part: its sites by sequence (counting sort; void records - sites of items the redo pass scanned again - dropped), then
+        // blocks of its sequences as tasks of their own
+        auto on_part = [&](SiteWindows::Part *part, uint32_t part_index, size_t seq0, size_t ns) {
+            if (part->n == 0 || pool.failed()) return;
+            pool.submit([&, part, part_index, seq0, ns] {
+                const SiteRec *recs = part->recs.as<SiteRec>();
+                auto po = std::make_shared<PartOrder>();
+                po->first.assign(ns + 1, 0);
+                size_t valid = 0;
+                for (size_t x = 0; x < part->n; x++)
+                    if (recs[x].seq != 0xFFFFFFFFu) { po->first[recs[x].seq + 1]++; valid++; }
+                for (size_t ls = 0; ls < ns; ls++) po->first[ls + 1] += po->first[ls];
+                po->xs.resize(valid);
+                {
+                    std::vector<uint32_t> fill(po->first.begin(), po->first.end() - 1);
+                    for (size_t x = 0; x < part->n; x++)
+                        if (recs[x].seq != 0xFFFFFFFFu) po->xs[fill[recs[x].seq]++] = (uint32_t)x;
+                }
+                const size_t block = 128;
+                std::shared_ptr<const PartOrder> cpo = po;
+                for (size_t a = 0; a < ns; a += block) {
+                    const size_t b = std::min(ns, a + block);
+                    if (po->first[a] == po->first[b]) continue;
+                    pool.submit([&, part, part_index, seq0, cpo, a, b] { resolve_block(part, part_index, seq0, cpo, a, b); });
+                }
+            });
+        };
+        find_sites(query_idx, concat, offsets, n_seqs, (uint32_t)d, part_seq0, second_q, revcomp, on_part, sw);
+        clk.lap("first pass (sites + windows; second pass of earlier slabs beside it)");
+        pool.wait();
+        clk.lap("second pass (what was left of it)");
         // ---- one allocation: records, then the characters; filled by the host team, every sequence at its own offsets
         var_offsets[0] = 0;
         std::vector<size_t> char0(n_seqs + 1, 0);
