@@ -940,17 +940,18 @@ def main(argv=None):
             c = map_stats
             seeded = dev.n_seqs - c["items_noplan"]
             by = {"query_bytes_in": dev.total, "characters_out": dev.total, "item_records_and_flags": 17 * dev.n_seqs,
-                  "seed_positions": 4 * c["seed_lookups"], "text_2bit_and_marks": 96 * seeded, "depth_table_bytes": c["tab_lookups"]}
+                  "seed_positions": 4 * c["seed_lookups"], "text_2bit_and_marks": 96 * seeded, "depth_table_bytes": c["tab_lookups"],
+                  "filter_words": 4 * c["seed_extensions"]}  # (seed_extensions: this kernel counts its filter look-ups there)
             b_map = sum(by.values()) / dev.total
             k_s = map_kernel_ms * 1e-3
             achieved = b_map * bases / k_s / 1e9
-            lines_min = (2 * dev.total / 128 + c["seed_lookups"] + c["tab_lookups"]) / dev.n_seqs  # streams + one line per table access
+            lines_min = (2 * dev.total / 128 + c["seed_lookups"] + c["tab_lookups"]) / dev.n_seqs  # streams + one line per table access (the filter's 2 MB stay in L2)
             roofline = {
                 "bound": "hbm",
                 "bound_detail": "integer gather work, no MFMA: per read one seed-position look-up, three depth-table bytes per mismatch (each a line "
-                                "of its own), the 2-bit text on the diagonal (L2 / Infinity Cache) and 2 B per base of streams.  Not bound by those "
-                                "fills any more (a filter that removes a quarter of the L2 misses changes nothing, DESIGN.md 4.1): the wave's own "
-                                "chain - about six dependent memory rounds and 4 300 VALU instructions per 64 reads - is what is left"
+                                "of its own; four in five settled by a 2 MB filter in L2 before they reach the table), the 2-bit text on the diagonal "
+                                "(L2 / Infinity Cache) and 2 B per base of streams.  Alone the kernel is not bound by its fills (with or without the "
+                                "filter: the same time), nor by its instructions: the wave's own chain of dependent loads is what is left (DESIGN.md 4.1)"
                                 + ("; the timed kernels ran beside the other batch's second pass (batches_in_flight)" if piped else ""),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "frac_meaning": "compulsory bytes of map_reads_kernel (counted by the kernel on the timed reads: bytes_by_part) x bases per step / "

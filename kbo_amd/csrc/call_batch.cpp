@@ -374,6 +374,8 @@ extern "C" int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, con
         if (opts) o = *opts; else kbo_call_opts_default(&o);
         KBO_REQUIRE(o.sbwt_build_opts.k == query_idx->host.k, KBO_E_K_MISMATCH,
                     "assert!(sbwt_ref.k() == sbwt_query.k()) (lib.rs:559)");
+        KBO_REQUIRE(!query_idx->sharded(), KBO_E_UNSUPPORTED,
+                    "intervals and the call mode need the rows of one index; this handle is a sharded index");
         const uint32_t k = query_idx->host.k;
         const size_t d = random_match_threshold(k, query_idx->host.n_kmers, 4, o.max_error_prob); // variant_calling.rs:260
         CallClock clk;

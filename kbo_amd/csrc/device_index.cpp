@@ -224,10 +224,10 @@ void build_plan_structures(kbo_index *idx, DevCopy *dc)
         }
         // the filter in front of the table (map_kernels.hip): one bit per string of F bases, F the shortest that leaves at most half
         // of the strings present, where that is a table the L2 keeps (<= 12 bases: 2 MB) and shorter than the depth table's own.
-        // OFF unless asked for (KBO_DEPTH_FILTER=-1: by size, n: that many bases): at C2 it keeps four table look-ups in five from
-        // the table - L2 misses 8.68 M -> 6.61 M, fetched bytes - 28 % - and the kernel takes 0.268 instead of 0.257 ms: the
-        // kernel is not bound by its fills (LABNOTES round 4)
-        static const int env_filter = std::getenv("KBO_DEPTH_FILTER") ? std::atoi(std::getenv("KBO_DEPTH_FILTER")) : 0; // experiments
+        // At C2 it keeps four table look-ups in five from the table - L2 misses 8.68 M -> 6.61 M, fetched bytes - 28 %.  The kernel
+        // alone is no faster for it (0.251 against 0.248 ms: it is not bound by its fills, LABNOTES round 4), but beside another
+        // batch's second pass it is: two batches in flight 0.332 -> 0.308 ms per batch.  KBO_DEPTH_FILTER=0: none, n: that many bases
+        static const int env_filter = std::getenv("KBO_DEPTH_FILTER") ? std::atoi(std::getenv("KBO_DEPTH_FILTER")) : -1; // experiments
         uint32_t fb = 0;
         for (uint32_t f = 6; f <= 12u; f++)
             if (2ull * idx->host.n_sets <= (1ull << (2u * f))) { fb = f; break; }
