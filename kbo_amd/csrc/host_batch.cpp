@@ -304,6 +304,18 @@ std::vector<Slab> make_slabs(const uint64_t *offsets, size_t n_seqs, size_t max_
         slabs.push_back(Slab{s0, s1, offsets[s0], offsets[s1]});
         s0 = s1;
     }
+    // the last slab in halves and quarters: what the pipeline cannot hide is the last slab's way through it (upload, kernels,
+    // download, copy out - 1.1 ms of a 4.8 ms call over 600 Mbp of packed reads), and that way is shorter for a smaller slab
+    static const int env_taper = std::getenv("KBO_SLAB_TAPER") ? std::atoi(std::getenv("KBO_SLAB_TAPER")) : 1; // experiments
+    if (env_taper && slabs.size() >= 3) {
+        const Slab last = slabs.back();
+        const size_t n = last.s1 - last.s0;
+        if (n >= 64) {
+            slabs.pop_back();
+            const size_t cut[4] = {last.s0, last.s0 + n / 2, last.s0 + n / 2 + n / 4, last.s1};
+            for (int i = 0; i < 3; i++) slabs.push_back(Slab{cut[i], cut[i + 1], offsets[cut[i]], offsets[cut[i + 1]]});
+        }
+    }
     return slabs;
 }
 
