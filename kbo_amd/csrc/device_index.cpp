@@ -216,7 +216,11 @@ void build_plan_structures(kbo_index *idx, DevCopy *dc)
         const uint32_t abits = kbo::dtab_anchor_bits(idx->host.n_sets, (uint32_t)order);
         static const int env_anchor = std::getenv("KBO_DEPTH_TABLE_ANCHORS") ? std::atoi(std::getenv("KBO_DEPTH_TABLE_ANCHORS")) : -1; // experiments
         const int anch_set = env_anchor >= 0 ? env_anchor : depth_table_anchor_setting(idx);
-        const bool want_anchors = anch_set > 0 || (anch_set < 0 && thin_margin);
+        // (small indexes as well - where the filter in front of the table applies: the one kernel then prices a window that is present by
+        // chance by its exact depth instead of leaving the read to the second pass: 1.9 % -> 0.8 % of the reads at C2, second pass
+        // 0.187 -> 0.141 ms; 128 MB at 5 * 10^6 rows)
+        const bool small_index = 2ull * idx->host.n_sets <= (1ull << 24);
+        const bool want_anchors = anch_set > 0 || (anch_set < 0 && (thin_margin || small_index));
         if (want_anchors && order < (int)idx->host.k) {
             dc->anchor.alloc(((size_t)1 << abits) * 8 + 64);
             dc->anchor_bits = abits;

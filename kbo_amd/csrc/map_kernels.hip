@@ -286,7 +286,9 @@ __global__ __launch_bounds__(256) void map_reads_kernel(WalkArgs a, uint32_t sta
     // a string of 14 bases occurs 0.9 times by chance and half of those seeds sat on another occurrence), or, where the copy has
     // them, the ANCHORS of its depth table: the strings of `order` (16, 17) bases that are the suffix of exactly one row, hashed to
     // that row's text position.  A wrong seed costs nothing but the second attempt: the compare step shows it.
-    const bool by_anchor = a.ix.anchor != nullptr && a.ix.dtab_order >= 12u;
+    // (where the seed table's strings are nearly as long as the anchors' - small indexes: 14 against 15 bases - the table's one
+    // load is the better seed: kernel 0.241 against 0.270 ms at C2; the anchors then only price windows that are present)
+    const bool by_anchor = a.ix.anchor != nullptr && a.ix.dtab_order >= 12u && a.ix.dtab_order > a.ix.seed_d + 1u;
     const uint32_t D = by_anchor ? a.ix.dtab_order : a.ix.seed_d;
     const uint32_t dmask = D >= 16u ? 0xFFFFFFFFu : ((1u << (2u * D)) - 1u);
     auto seed_at = [&](uint32_t e_) -> uint32_t { // text position of the base e_ of the read by the window that ends there, or ~0

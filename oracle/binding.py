@@ -320,9 +320,12 @@ def shipped_depth_table_order(k, n_sets):
 
 def shipped_depth_table_anchors(k, n_sets, order):
     """device_index.cpp: whether a device copy's depth table gets anchors by default: where its margin over log4(rows) is
-    below 3.75 bases and the index has 24 Mi rows or more (C3, C4, a 1 Gbp index; not C2)"""
+    below 3.75 bases and the index has 24 Mi rows or more (C3, C4, a 1 Gbp index), and on small indexes (2 x rows <= 2^24: C2),
+    where the one kernel prices a window that is present by chance with them"""
     import math
-    return bool(order and order < k and order < math.log2(max(n_sets, 4)) / 2.0 + 3.75 and n_sets >= (24 << 20))
+    if not order or order >= k:
+        return False
+    return bool((order < math.log2(max(n_sets, 4)) / 2.0 + 3.75 and n_sets >= (24 << 20)) or 2 * n_sets <= (1 << 24))
 
 
 def shipped_plan_params(k, n_sets, recovery_lines=None, depth_table=None, depth_anchors=None):

@@ -319,13 +319,13 @@ def test_options_are_per_handle(oracle, plan_restore):
     b, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
     c, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=_threads()))
     a.set_opts(plan=0)
-    b.set_opts(depth_table=11, depth_table_anchors=1, slab_bytes=1 << 20, devices=[0])
+    b.set_opts(depth_table=11, depth_table_anchors=0, slab_bytes=1 << 20, devices=[0])
     assert a.get_opts()["plan"] == 0 and c.get_opts()["plan"] == kbo_amd._capi.OPT_INHERIT and b.get_opts()["devices"] == [0]
     for ix in (a, b, c):
         ix.to_device(-1)
     assert a.device_plan_bytes() == 0 and a.depth_table_order() == 0          # no cover, no tables: the plain walk
-    assert b.depth_table_order() == 11 and b.device_layout()["anchor_bytes"] > 0
-    assert c.depth_table_order() not in (0, 11) and c.device_layout()["anchor_bytes"] == 0  # the shipped choice for this size
+    assert b.depth_table_order() == 11 and b.device_layout()["anchor_bytes"] == 0
+    assert c.depth_table_order() not in (0, 11) and c.device_layout()["anchor_bytes"] > 0  # the shipped choice for this size (small: anchors)
     fused = {}
     for name, ix in (("a", a), ("b", b), ("c", c)):
         assert np.array_equal(batch.matches_batch(ix, concat, offsets), exp_chars), name  # (b: 5 slabs of 1 MiB)

@@ -84,7 +84,8 @@ def test_model_on_the_bench_shape(oracle):
     concat, offsets = synth.reads(g, 20_000, 150, 0.01)
     _, exp = ora.matches_batch(concat, offsets, 1e-7, n_threads=4, want_d=True)
     P = oracle.shipped_plan_params(31, sbwt.n_sets())
-    assert P.depth_table == 13 and P.depth_anchors == 0  # log4(500 k) = 9.5, + 3.2, rounded up: a margin of 3.5
+    assert P.depth_table == 13 and P.depth_anchors == 1  # log4(500 k) = 9.5, + 3.2, rounded up; anchors: a small index (round 4)
+    P.depth_anchors = 0
     ms, c0 = ora.plan_model(sbwt.path_cover(), P, concat, offsets, n_threads=4)
     assert np.array_equal(ms, exp) and not c0["gave_up"] and c0["tab_flagged"] < 0.04 * c0["items"]
     P.depth_anchors = 1
