@@ -153,6 +153,8 @@ struct WalkArgs {
     // ... its packed-native instantiations (pack_kernels.hip has the layout): the reads as 2-bit words - qp_wps words per read, or
     // 0 and the scanned words-per-read (qp_data / qp_sums) -, one byte per read that is non-zero where the read holds a byte that
     // is no base (nullptr: none does), and, when the characters leave packed as well, where their words go
+    const uint64_t *seq_off; // (reads: the batch's offsets instead of the item list - item s is sequence s, whole: the list is then
+                             // only made for the second pass)
     const uint32_t *qp;
     uint32_t qp_wps;
     const uint32_t *qp_data, *qp_sums;

@@ -164,9 +164,13 @@ __global__ __launch_bounds__(256) void map_reads_kernel(WalkArgs a, uint32_t sta
     const uint8_t *qb = a.q;
     uint32_t start = 0, len = 0, warm = 0, tail = 0;
     const bool have_item = idx < a.n_items;
-    if (have_item) {
+    if (have_item && a.seq_off) { // (8 bytes per read instead of a 16-byte record somebody had to write first)
+        const uint64_t o0 = a.seq_off[idx], o1 = a.seq_off[idx + 1u];
+        start = (uint32_t)o0; // launches cover < 4 GiB of query
+        len = (uint32_t)(o1 - o0);
+    } else if (have_item) {
         const uint4 it = ld16(reinterpret_cast<const uint8_t *>(a.items), idx * 16u);
-        start = it.x; // launches cover < 4 GiB of query
+        start = it.x;
         len = it.z;
         warm = it.w & 0xFFFFu;
         tail = it.w >> 16;
