@@ -939,7 +939,7 @@ def main(argv=None):
             # one extra launch behind the timed region): what it must read and write however well it is written
             c = map_stats
             seeded = dev.n_seqs - c["items_noplan"]
-            by = {"query_bytes_in": dev.total, "characters_out": dev.total, "item_records_and_flags": 17 * dev.n_seqs,
+            by = {"query_bytes_in": dev.total, "characters_out": dev.total, "offsets_and_flags": 9 * dev.n_seqs,
                   "seed_positions": 4 * c["seed_lookups"], "text_2bit_and_marks": 96 * seeded, "depth_table_bytes": c["tab_lookups"],
                   "filter_words": 4 * c["seed_extensions"]}  # (seed_extensions: this kernel counts its filter look-ups there)
             b_map = sum(by.values()) / dev.total
