@@ -246,12 +246,9 @@ hipError_t launch_call_qmer_index(const uint8_t *d_q, const uint64_t *d_off, uin
     if (n_seqs == 0) return hipSuccess;
     if (max_slots <= 32768u) {
         const uint32_t lds = std::max(max_slots, 64u) * 4u;
-        static std::atomic<uint32_t> attr_set{0};
-        if (attr_set.load() < lds) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(call_qmer_index_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-            if (e != hipSuccess) return e;
-            attr_set.store(131072u);
-        }
+        // (per device and cheap: set every time rather than remembered per process)
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(call_qmer_index_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(call_qmer_index_lds_kernel, dim3(n_seqs), dim3(256), lds, stream, d_q, d_off, n_seqs, qlen, d_tab_off, d_tab, d_seq_flag);
         return hipGetLastError();
     }
