@@ -153,13 +153,15 @@ __global__ __launch_bounds__(256) void map_reads_kernel(WalkArgs a, uint32_t sta
     extern __shared__ __attribute__((aligned(16))) uint8_t map_lds_all[];
     const uint32_t lane = threadIdx.x & 63u;
     // (the waves of a workgroup share nothing: each has its own part of the LDS and never waits for another)
-    const uint32_t wave_lds = (stage_bytes + 4u * (lin_words + 4u) + 1024u + 15u) & ~15u;
+    const uint32_t wave_lds = (stage_bytes + 4u * (lin_words + 4u) + 1024u + 528u + 15u) & ~15u; // (+ 64 pending anchor checks and their counter)
     uint8_t *map_lds = map_lds_all + (threadIdx.x >> 6) * wave_lds;
     const uint32_t idx = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane;
     uint8_t *so = map_lds;                                                       // MS bytes, then characters: the wave's stretch
     uint32_t *lin = reinterpret_cast<uint32_t *>(map_lds + stage_bytes) + 4;     // the stretch as 2-bit digits (lin[-1] = 0)
     uint8_t *spw = map_lds + stage_bytes + 4u * (lin_words + 4u);                // 64 x 16 bytes: mismatch positions 0 .. 12, flag, prefix
     uint8_t *sp = spw + lane * 16u;
+    uint2 *pend = reinterpret_cast<uint2 *>(spw + 1024u); // DIRECT: windows that are present and wait for their exact depth (64 entries)
+    uint32_t *pend_n = reinterpret_cast<uint32_t *>(spw + 1024u + 512u);
     const uint32_t k = a.ix.k;
     const uint8_t *qb = a.q;
     uint32_t start = 0, len = 0, warm = 0, tail = 0;
@@ -561,6 +563,7 @@ __global__ __launch_bounds__(256) void map_reads_kernel(WalkArgs a, uint32_t sta
         }
         const uint32_t total = __shfl(incl, 63);
         sp[13] = 0;
+        if (lane == 0) *pend_n = 0;
         *reinterpret_cast<uint16_t *>(sp + 14) = (uint16_t)incl;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(256) void map_reads_kernel(WalkArgs a, uint32_t sta
                                     const uint32_t e1 = blockmode ? e : min(e, zlo + F - 1u), e2 = blockmode ? left : max(zhi, left);
                                     const uint32_t k1 = (uint32_t)ending_at(o_soff + e1) & fmask, k2 = (uint32_t)ending_at(o_soff + e2) & fmask;
                                     fw[i][0] = a.ix.dfilt[k1 >> 5] >> (k1 & 31u);
-                                    two[i] = e2 != e1;
+                                    two[i] = e2 != e1 && (a.rounds & 2u); // (a.rounds bit 1, experiment: a second stretch - fewer table look-ups, 1.4 % slower)
                                     if (two[i]) fw[i][1] = a.ix.dfilt[k2 >> 5] >> (k2 & 31u);
                                     st_filt += two[i] ? 2u : 1u;
                                 }
@@ -658,17 +661,15 @@ __global__ __launch_bounds__(256) void map_reads_kernel(WalkArgs a, uint32_t sta
                         if (use[i] && (bytes[i] & 0x80u)) { // the window is a suffix of a row
                             if (!have_anch || lastw[i]) fail = true;
                             else {
-                                // its exact depth off the path-cover text (dtab_anchor_depth: the window is the suffix of ONE row, whose
-                                // characters stand in the text in front of its position).  Strings through the break that end
-                                // between this window and the next start no further left than this depth says: with the next
-                                // window (or the read's end) g bases on, none is longer than depth + g - 1
+                                // its exact depth off the path-cover text decides - behind the loop, all such windows of the wave at once
+                                // (one in 200 windows: looked up here, a hash probe and two loads of text for ONE lane held every
+                                // round of the loop up: the proof was 95 us of the kernel's 240 with it, 75 without anchors)
                                 const uint32_t e_i = ee[i];
-                                const uint32_t V = dtab_anchor_depth(a.ix, e_i + 1u, [&](uint32_t tt) -> uint32_t {
-                                    return (0x54474341u >> (8u * base_at(o_soff + e_i - tt))) & 0xFFu;
-                                });
                                 const uint32_t nxt_e = (i + 1u < 4u && use[i + 1u < 4u ? i + 1u : i]) ? ee[i + 1u < 4u ? i + 1u : i] : o_len;
                                 st_anch++;
-                                if (V == kDtabUnknown || V + (nxt_e - e_i) - 1u > thr) fail = true;
+                                const uint32_t slot = atomicAdd(pend_n, 1u);
+                                if (slot < 64u) pend[slot] = make_uint2(o_soff + e_i, owner | (e_i << 8) | ((nxt_e - e_i) << 16));
+                                else fail = true; // (no room: the plain walk decides)
                             }
                         }
                     }
@@ -740,6 +741,22 @@ __global__ __launch_bounds__(256) void map_reads_kernel(WalkArgs a, uint32_t sta
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (DIRECT && have_anch) {
+            // a present window's exact depth (dtab_anchor_depth: the window is the suffix of ONE row, whose characters stand in the text in
+            // front of its position).  Strings through the break that end between this window and the next start no further left than
+            // this depth says: with the next window (or the read's end) g bases on, none is longer than depth + g - 1
+            const uint32_t n_pend = min(*pend_n, 64u);
+            if (lane < n_pend) {
+                const uint2 pe = pend[lane];
+                const uint32_t p_owner = pe.y & 0xFFu, e_i = (pe.y >> 8) & 0xFFu, gap = pe.y >> 16, at_e = pe.x;
+                const uint32_t V = dtab_anchor_depth(a.ix, e_i + 1u, [&](uint32_t tt) -> uint32_t {
+                    return (0x54474341u >> (8u * base_at(at_e - tt))) & 0xFFu;
+                });
+                if (V == kDtabUnknown || V + gap - 1u > thr) spw[p_owner * 16u + 13u] = 1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         flag = flag || sp[13] != 0;
     }
     // ---- the MS values themselves, when the caller wants them too (whole lines)
@@ -954,7 +971,7 @@ hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
     // (packed: every read starts a word of the digit string and, with the characters packed as well, of the byte region)
     const uint32_t stage_bytes = io ? (64u * 16u * ((a.max_item_len + 15u) / 16u) + 32u + kMapSlack) : (64u * a.max_item_len + 16u + kMapSlack + 15u) / 16u * 16u;
     const uint32_t lin_words = stage_bytes / 16u + 4u;
-    const uint32_t lds_wave = (stage_bytes + 4u * (lin_words + 4u) + 1024u + 15u) & ~15u;
+    const uint32_t lds_wave = (stage_bytes + 4u * (lin_words + 4u) + 1024u + 528u + 15u) & ~15u;
     static const int env_wpb = std::getenv("KBO_MAP_WPB") ? std::atoi(std::getenv("KBO_MAP_WPB")) : 1; // experiments: waves per workgroup
     const uint32_t wpb = (uint32_t)std::min(4, std::max(1, env_wpb));
     const uint32_t n_waves = (a.n_items + 63u) / 64u;
