@@ -43,6 +43,12 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef KBO_STAGE_UNROLL
+#define KBO_STAGE_UNROLL 6
+#endif
+#ifndef KBO_MAP_LB
+#define KBO_MAP_LB 256 // (threads per workgroup the kernel is compiled for: KBO_MAP_WPB waves of 64)
+#endif
 namespace kbo {
 extern std::atomic<int> g_plan_cap; // plan_kernels.hip: bases of a read in which a seed may start (kbo_set_plan)
 namespace {
@@ -148,7 +154,7 @@ __device__ __forceinline__ uint32_t pack_chars16(const uint4 &v)
 }
 
 template <int NP, bool DIRECT, int IO = 0>
-__global__ __launch_bounds__(256) void map_reads_kernel(WalkArgs a, uint32_t stage_bytes, uint32_t lin_words)
+__global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint32_t stage_bytes, uint32_t lin_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t map_lds_all[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -217,11 +223,11 @@ __global__ __launch_bounds__(256) void map_reads_kernel(WalkArgs a, uint32_t sta
             *reinterpret_cast<uint4 *>(so + c) = make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);
         has_invalid = plannable && a.qp_exc != nullptr && a.qp_exc[idx] != 0;
     } else {
-    // (six blocks per lane in flight: the loads of a stretch go out in two rounds instead of one per 1 KB (eleven: the compiler
-    // keeps the blocks in scratch, 296 us against 231) - a wave's life is the
+    // (six blocks per lane in flight: the loads of a stretch go out in two rounds instead of one per 1 KB (eight or eleven at a time:
+    // the same, 217 - 219 us) - a wave's life is the
     // sum of its dependent memory rounds, 19 of them before this, and the kernel's time follows it: neither fewer fills, nor fewer
     // instructions, nor more resident waves had changed it)
-    constexpr uint32_t kStageUnroll = 6;
+    constexpr uint32_t kStageUnroll = KBO_STAGE_UNROLL;
     for (uint32_t c00 = 0; c00 < nblk + 2u; c00 += 64u * kStageUnroll) {
         uint4 vv[kStageUnroll];
 #pragma unroll
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(256) void map_reads_kernel(WalkArgs a, uint32_t sta
 #pragma unroll
         for (uint32_t u = 0; u < kStageUnroll; u++) {
             const uint32_t c0 = c00 + 64u * u;
-            if (c0 >= nblk + 2u) break;
+            if (c0 < nblk + 2u) {
             const uint32_t c = c0 + lane;
             uint32_t code = 0, valid = 0xFFFFu;
             if (c < nblk) {
@@ -260,6 +266,7 @@ __global__ __launch_bounds__(256) void map_reads_kernel(WalkArgs a, uint32_t sta
                 bm &= bm - 1ull;
                 const uint32_t blo = 16u * (c0 + L);
                 has_invalid = has_invalid || (plannable && soff < blo + 16u && soff + len > blo);
+            }
             }
         }
     }
