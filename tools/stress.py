@@ -52,17 +52,20 @@ while time.time() < t_end:
     sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=k, num_threads=4, add_revcomp=rc))
     oi = ora.Index.build([g.tobytes()], k=k, add_revcomp=rc)
     # batch: reads of one length, ragged reads, a few long pieces
-    shape = rng.choice(["uniform", "ragged", "long", "mixed"])
+    shape = rng.choice(["uniform", "ragged", "long", "mixed", "reads", "reads"])
     lens = []
     if shape in ("uniform", "mixed"):
         lens += [int(rng.choice([32, 100, 128, 150, 151, 250, 256, 480]))] * int(rng.integers(100, 3000))
     if shape in ("ragged", "mixed"):
         lens += list(rng.integers(3, 600, int(rng.integers(100, 3000))))
+    if shape == "reads":  # what the one kernel takes: at most 160 bases
+        lens += list(rng.integers(3, 158, int(rng.integers(100, 6000))))
     if shape in ("long", "mixed"):
         lens += list(rng.integers(481, 90_000, int(rng.integers(1, 12))))
     lens = [int(min(n, len(g) - 1)) for n in lens if n >= 3]
     rng.shuffle(lens)
     sub = float(rng.choice([0.0, 0.01, 0.05, 0.3]))
+    indel = bool(rng.random() < 0.4)
     pieces = []
     for n in lens:
         s0 = int(rng.integers(0, len(g) - n))
@@ -71,6 +74,13 @@ while time.time() < t_end:
         p[hit] = ACGT[rng.integers(0, 4, int(hit.sum()))]
         if rng.random() < 0.05:
             p[rng.integers(0, n, max(1, n // 50))] = ord("N")
+        if indel and n > 30 and rng.random() < 0.4:  # an insertion or a deletion of 1 - 3 bases, the length kept
+            q = int(rng.integers(5, n - 5))
+            w = int(rng.integers(1, 4))
+            if rng.random() < 0.5:
+                p = np.concatenate([p[:q], p[q + w:], ACGT[rng.integers(0, 4, w)]])
+            else:
+                p = np.concatenate([p[:q], ACGT[rng.integers(0, 4, w)], p[q:n - w]])
         pieces.append(p)
     concat = np.concatenate(pieces)
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
@@ -112,6 +122,20 @@ while time.time() < t_end:
     want = np.frombuffer(ora.relative_to_ref(concat, exp_chars), dtype=np.uint8) if dev.format else exp_chars
     assert np.array_equal(dev.ms.cpu().numpy()[:len(concat)], exp_d), "dev MS " + tag
     assert np.array_equal(dev.chars.cpu().numpy()[:len(concat)], want), "dev chars " + tag
+    if 0 < dev.max_len <= 160:  # the one kernel's direct form (no MS values), its second pass on a tail stream; the packed-native form
+        tail = torch.cuda.Stream("cuda:0")
+        d2 = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"), max_error_prob=p_err, format=dev.format, want_ms=False)
+        d2.chars.fill_(0xEE)
+        d2.run(tail_stream=tail if rng.random() < 0.5 else None)
+        torch.cuda.synchronize()
+        assert np.array_equal(d2.chars.cpu().numpy()[:len(concat)], want), "direct form chars (fused %s) " % d2.fused + tag
+        try:
+            pb = batch.PackedDeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"), max_error_prob=p_err)
+            pb.run(tail_stream=tail if rng.random() < 0.5 else None)
+            torch.cuda.synchronize()
+            assert np.array_equal(pb.chars(), exp_chars), "packed-native chars " + tag
+        except kbo_amd.KboError as e:
+            assert e.code == -8, "packed-native: " + str(e) + " " + tag  # KBO_E_UNSUPPORTED: this copy cannot take that kernel
     if rng.random() < 0.15 and not rc:  # kbo::call over a few of the sequences as a batch vs the oracle, one by one
         pick = [int(x) for x in rng.integers(0, len(lens), 6) if lens[int(x)] >= 3]
         if pick:
