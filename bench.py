@@ -734,13 +734,19 @@ def main(argv=None):
                 if events is not None:
                     events[i][1].record(stream)
                 dev.derand_translate(stream)
+            elif args.find:  # kbo::find (lib.rs:816-820) as one call: the characters and their run lengths (kbo_find_batch_dev: the kernel
+                # counts the runs of the reads it finishes, the records are one more pass over the characters)
+                dev.run_find(0, stream, tail_stream=tail if on_tail else None)
+                if events is not None:
+                    for e in events[i][1:]:
+                        e.record(last)
             else:  # kbo_map_batch_dev[_tail]: one kernel for the reads + the plain walk of the reads it leaves
                 dev.run(stream, tail_stream=tail if on_tail else None)
                 if events is not None:
                     events[i][1].record(last)
-            if events is not None and (args.two_kernels or args.find):
+            if events is not None and args.two_kernels:
                 events[i][2].record(last)
-            if args.find:  # kbo::find (lib.rs:816-820): run lengths of the characters, still on the device
+            if args.find and args.two_kernels:  # (the round-3 route: run lengths as a call of their own)
                 dev.run_lengths(0, last)
                 if events is not None:
                     events[i][3].record(last)
@@ -772,7 +778,7 @@ def main(argv=None):
     map_redo_ms = r_sum.value / args.steps if one_kernel and n_calls.value else None
     walk_ms = float(np.mean([sum(e[0].elapsed_time(e[1]) for e in step) for step in ev]))
     dt_ms = float(np.mean([sum(e[1].elapsed_time(e[2]) for e in step) for step in ev])) if args.two_kernels else 0.0
-    rle_ms = float(np.mean([sum(e[2].elapsed_time(e[3]) for e in step) for step in ev])) if args.find else None
+    rle_ms = float(np.mean([sum(e[2].elapsed_time(e[3]) for e in step) for step in ev])) if args.find and args.two_kernels else None  # (else: inside the call)
     # what the timed steps left behind (formatted unless --find): the first slab of either set, for rank 0's parity gate
     timed_chars_sets = [sl[0].chars[:sl[0].total].cpu().numpy() for sl in sets] if rank == 0 else None
     serial = None
@@ -1010,7 +1016,7 @@ def main(argv=None):
             "kernels_ms": ({"map_reads_kernel": round(map_kernel_ms, 4), "redo_pass": round(map_redo_ms, 4),
                             "kbo_map_batch_dev": round(walk_ms, 4)} if one_kernel else
                            {"a1_stage": round(walk_ms, 4), "derand_translate": round(dt_ms, 4)}) |
-                          ({"run_lengths": round(rle_ms, 4)} if args.find else {}),
+                          ({"run_lengths": round(rle_ms, 4)} if rle_ms is not None else {}),
             "one_batch_at_a_time": serial,
             "cpu_baseline": cpu,
             "bit_exact_vs_oracle": exact,

@@ -385,6 +385,14 @@ int kbo_map_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
 int kbo_map_batch_dev_tail(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
                            size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
                            void *d_work, size_t work_bytes, void *stream, void *tail_stream, int *fused);
+/* kbo::find (lib.rs:808-821) over a device-resident batch: kbo_map_batch_dev_tail with format = 0, then format::run_lengths_gapped
+ * (format.rs:143-193) of the characters - kbo_run_lengths_dev's buffers and record layout (d_rle_work: kbo_run_lengths_work_bytes()) -
+ * enqueued behind the second pass on `tail_stream` (pass `stream` for one stream).  With max_gap_len = 0 (FindOpts' default) the one
+ * kernel counts the runs of every read it finishes while the characters are in LDS, and the run lengths are ONE pass over the
+ * characters instead of two (count, then emit). */
+int kbo_find_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
+                       size_t max_seq_len, double max_error_prob, size_t max_gap_len, uint8_t *d_ms, uint8_t *d_chars_out, void *d_work,
+                       size_t work_bytes, void *d_rle_work, uint32_t *d_records, size_t capacity, void *stream, void *tail_stream, int *fused);
 /* kbo::matches (lib.rs:612-628) over a device-resident PACKED batch of reads (the layout of kbo_matches_batch_packed: kbo_packed_words()
  * words, every read starts a word; d_offsets counts bases), through the one kernel's packed-native form: the words go into the kernel
  * as they are and the characters leave it as words (M, -, X, R = 0 .. 3) - a quarter of a byte per base each way; only the reads it

@@ -103,6 +103,7 @@ SYMBOLS = [
     "kbo_matches_batch_packed", "kbo_find_batch_packed", "kbo_index_shards", "kbo_index_work_bytes",
     "kbo_index_device_layout", "kbo_map_batch_dev", "kbo_map_batch_dev_tail",
     "kbo_index_opts_default", "kbo_index_set_opts", "kbo_index_get_opts", "kbo_matches_packed_dev", "kbo_matches_packed_dev_scratch_bytes",
+    "kbo_find_batch_dev",
 ]
 # ... and include/kbo_hip_tuning.h (knobs, experiment switches, test hooks: not part of the drop-in boundary)
 TUNING_SYMBOLS = [
@@ -234,6 +235,7 @@ def lib():
     L.kbo_matches_packed_dev_scratch_bytes.argtypes = [sz, u64]
     L.kbo_matches_packed_dev_scratch_bytes.restype = sz
     L.kbo_matches_packed_dev.argtypes = [vp, vp, vp, sz, u64, sz, sz, vp, vp, sz, dbl, vp, vp, vp, sz, vp, vp]
+    L.kbo_find_batch_dev.argtypes = [vp, vp, vp, sz, u64, sz, dbl, sz, vp, vp, vp, sz, vp, vp, sz, vp, vp, C.POINTER(C.c_int)]
     L.kbo_index_opts_default.argtypes = [C.POINTER(IndexOpts)]
     L.kbo_index_set_opts.argtypes = [vp, C.POINTER(IndexOpts)]
     L.kbo_index_get_opts.argtypes = [vp, C.POINTER(IndexOpts)]

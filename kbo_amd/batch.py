@@ -287,6 +287,24 @@ class DeviceBatch:
                                         self.rle_work.data_ptr(), self.rle_records.data_ptr(), self.rle_capacity,
                                         s.cuda_stream))
 
+    def run_find(self, max_gap_len=0, stream=None, tail_stream=None, runs_per_seq=2):
+        """kbo::find over the batch (kbo_hip.h kbo_find_batch_dev): the characters (unformatted) and their run lengths, as
+        run() + run_lengths() leave them; with max_gap_len = 0 the one kernel counts the runs itself"""
+        torch = self.torch
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        t = tail_stream if tail_stream is not None else s
+        if getattr(self, "rle_work", None) is None:
+            wb = int(lib().kbo_run_lengths_work_bytes(self.n_seqs))
+            self.rle_work = torch.zeros(wb // 4 + 1, dtype=torch.int32, device=self.device)
+            self.rle_capacity = runs_per_seq * self.n_seqs + 16
+            self.rle_records = torch.zeros((self.rle_capacity, 7), dtype=torch.int32, device=self.device)
+        fused = C.c_int(0)
+        check(lib().kbo_find_batch_dev(self.sbwt._h, self.q.data_ptr(), self.off.data_ptr(), self.n_seqs, self.total, self.max_len,
+                                       self.max_error_prob, max_gap_len, self.ms.data_ptr(), self.chars.data_ptr(), self.work.data_ptr(),
+                                       self.work_bytes, self.rle_work.data_ptr(), self.rle_records.data_ptr(), self.rle_capacity,
+                                       s.cuda_stream, t.cuda_stream, C.byref(fused)))
+        self.fused = bool(fused.value)
+
     def run_lengths_host(self):
         """-> (records [n_runs, 7] uint32, first-run index per sequence uint32 [n_seqs + 1]) on the host"""
         w = self.rle_work.cpu().numpy().view(np.uint32)

@@ -1271,9 +1271,18 @@ hipEvent_t tail_fence()
     return ev;
 }
 
+// kbo::find behind the characters (kbo_find_batch_dev): format::run_lengths_gapped into d_records
+struct FindTail {
+    size_t max_gap_len;
+    void *d_rle_work;
+    uint32_t *d_records;
+    size_t capacity;
+};
+
 int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
                        size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
-                       void *d_work, size_t work_bytes, void *stream, void *tail_stream, bool split, int *fused)
+                       void *d_work, size_t work_bytes, void *stream, void *tail_stream, bool split, int *fused,
+                       const FindTail *find = nullptr)
 {
     if (fused) *fused = 0;
     bool done = false;
@@ -1313,6 +1322,11 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
         a.map_want_ms = want_ms ? 1u : 0u;
         if (!a.gitems || !kbo::map_reads_applies(a)) return; // (no plan structures, or the copy is held off: two kernels)
         a.seq_off = d_offsets; // (the kernel reads the offsets themselves; the item list is the second pass's: made on its stream)
+        // kbo::find with max_gap_len = 0: the kernel counts the runs of the reads it finishes (their characters are in LDS anyway), so
+        // that format::run_lengths_gapped is one pass over the characters instead of two
+        uint32_t *rle_scratch = find ? static_cast<uint32_t *>(find->d_rle_work) : nullptr;
+        const bool count_in_kernel = find && find->max_gap_len == 0 && !format && !want_ms && kbo::map_reads_direct(a);
+        if (count_in_kernel) a.run_counts = rle_scratch;
         const bool timing = g_stage_timing.load() != 0;
         StageEvents ev{};
         if (timing) {
@@ -1344,6 +1358,16 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
             g_timing_used.push_back(ev);
         }
         plan_after_launch(a, ts, plan_state);
+        if (find) { // the run lengths, behind the second pass
+            uint32_t *total = rle_scratch + kbo::chunk_items_scratch_words((uint32_t)n_seqs); // last word of the work buffer
+            const uint32_t gap = (uint32_t)std::min<size_t>(find->max_gap_len, 0xFFFFFFFFu), cap = (uint32_t)std::min<size_t>(find->capacity, 0xFFFFFFFFu);
+            if (count_in_kernel) {
+                HIP_OK(kbo::launch_rle0_count_flagged(d_chars_out, d_offsets, (uint32_t)n_seqs, a.redo, rle_scratch, ts));
+                HIP_OK(kbo::launch_rle_scan_counts((uint32_t)n_seqs, rle_scratch, total, ts));
+            } else
+                HIP_OK(kbo::launch_rle_count(d_chars_out, d_offsets, (uint32_t)n_seqs, gap, rle_scratch, total, ts, (uint32_t)max_seq_len));
+            if (cap) HIP_OK(kbo::launch_rle_emit(d_chars_out, d_offsets, (uint32_t)n_seqs, gap, rle_scratch, find->d_records, cap, ts, (uint32_t)max_seq_len));
+        }
         done = true;
     });
     if (rc != KBO_OK || done) {
@@ -1352,10 +1376,25 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
     }
     rc = ms_batch_dev_impl(idx, d_concat, d_offsets, n_seqs, total_bases, max_seq_len, d_ms, nullptr, nullptr, d_work, work_bytes, stream, nullptr);
     if (rc != KBO_OK) return rc;
-    return kbo_derand_translate_dev(d_ms, d_offsets, n_seqs, total_bases, idx->host.k, threshold, format ? d_concat : nullptr, d_chars_out,
-                                    max_seq_len, nullptr, 0, stream);
+    rc = kbo_derand_translate_dev(d_ms, d_offsets, n_seqs, total_bases, idx->host.k, threshold, format ? d_concat : nullptr, d_chars_out,
+                                  max_seq_len, nullptr, 0, stream);
+    if (rc != KBO_OK || !find) return rc;
+    return kbo_run_lengths_dev(d_chars_out, d_offsets, n_seqs, max_seq_len, find->max_gap_len, find->d_rle_work, find->d_records, find->capacity, stream);
 }
 } // namespace
+
+int kbo_find_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
+                       size_t max_seq_len, double max_error_prob, size_t max_gap_len, uint8_t *d_ms, uint8_t *d_chars_out, void *d_work,
+                       size_t work_bytes, void *d_rle_work, uint32_t *d_records, size_t capacity, void *stream, void *tail_stream, int *fused)
+{
+    if (!d_rle_work || (!d_records && capacity) || ((uintptr_t)d_rle_work & 3) || ((uintptr_t)d_records & 3) || n_seqs >= (1ull << 31)) {
+        last_error() = "kbo_find_batch_dev: bad run-length buffers";
+        return KBO_E_BAD_ARG;
+    }
+    const FindTail ft{max_gap_len, d_rle_work, d_records, capacity};
+    return map_batch_dev_impl(idx, d_concat, d_offsets, n_seqs, total_bases, max_seq_len, max_error_prob, 0, 0, d_ms, d_chars_out, d_work,
+                              work_bytes, stream, tail_stream, true, fused, &ft);
+}
 
 int kbo_map_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
                       size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,

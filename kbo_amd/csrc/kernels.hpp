@@ -153,6 +153,8 @@ struct WalkArgs {
     // ... its packed-native instantiations (pack_kernels.hip has the layout): the reads as 2-bit words - qp_wps words per read, or
     // 0 and the scanned words-per-read (qp_data / qp_sums) -, one byte per read that is non-zero where the read holds a byte that
     // is no base (nullptr: none does), and, when the characters leave packed as well, where their words go
+    uint32_t *run_counts;    // (kbo::find with max_gap_len == 0: the number of runs - maximal stretches without '-' - of every read the
+                             // kernel finishes itself, or nullptr: format::run_lengths_gapped then needs no counting pass of its own)
     const uint64_t *seq_off; // (reads: the batch's offsets instead of the item list - item s is sequence s, whole: the list is then
                              // only made for the second pass)
     const uint32_t *qp;
@@ -278,6 +280,9 @@ hipError_t launch_make_chunk_items(const uint64_t *d_offsets, uint32_t n_seqs, u
 // sequence s is d_scratch[n_seqs + 1 + s / 1024] + d_scratch[s] and *d_total the number of runs
 hipError_t launch_rle_count(const uint8_t *d_chars, const uint64_t *d_offsets, uint32_t n_seqs, uint32_t max_gap_len,
                             uint32_t *d_scratch, uint32_t *d_total, hipStream_t stream, uint32_t max_seq_len = 0);
+hipError_t launch_rle_scan_counts(uint32_t n_seqs, uint32_t *d_scratch, uint32_t *d_total, hipStream_t stream);
+hipError_t launch_rle0_count_flagged(const uint8_t *d_chars, const uint64_t *d_offsets, uint32_t n_seqs, const uint8_t *d_flags,
+                                     uint32_t *d_counts, hipStream_t stream);
 hipError_t launch_rle_emit(const uint8_t *d_chars, const uint64_t *d_offsets, uint32_t n_seqs, uint32_t max_gap_len,
                            uint32_t *d_scratch, uint32_t *d_rles, uint32_t capacity, hipStream_t stream,
                            uint32_t max_seq_len = 0 /* longest sequence if known: reads take the LDS-staged kernels */);

@@ -883,6 +883,26 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
         x_cur = x_prev;
         at[0] = (uint8_t)((x_cur > T && in_next) ? (uint32_t)'R' : plain(x_cur, x_next, K));
     }
+    // kbo::find: the runs of the read (format::run_lengths_gapped with max_gap_len = 0 closes a run at every '-': rle_kernels.hip),
+    // counted off the characters while they are in LDS - four at a time, a start wherever a character that is not '-' follows one
+    // that is (or the read's head)
+    if (DIRECT && a.run_counts && have_item) {
+        uint32_t n_runs = 0;
+        if (plannable && !flag) {
+            const uint32_t b0 = ooff, b1 = ooff + len;
+            uint32_t carry = 0; // the character in front of the word was not a '-' (bit 7)
+            for (uint32_t wa = b0 & ~3u; wa < b1; wa += 4u) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(so + wa) ^ 0x2D2D2D2Du; // zero bytes: '-'
+                uint32_t nd = (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;            // bit 7 of every byte that is not '-'
+                // bytes outside [b0, b1) count as '-'
+                const uint32_t lo_cut = wa < b0 ? b0 - wa : 0u, hi_cut = wa + 4u > b1 ? wa + 4u - b1 : 0u;
+                nd &= (0xFFFFFFFFu << (8u * lo_cut)) & (0xFFFFFFFFu >> (8u * hi_cut));
+                n_runs += (uint32_t)__popc(nd & ~((nd << 8) | carry));
+                carry = nd >> 24;
+            }
+        }
+        a.run_counts[idx] = n_runs;
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 

@@ -217,6 +217,25 @@ static void launch_rle_pass(const uint8_t *d_chars, const uint64_t *d_offsets, u
     }
 }
 
+// kbo_find_batch_dev: map_reads_kernel counted the runs of the reads it finished itself (max_gap_len == 0: the maximal stretches
+// without '-'); the reads it left to the second pass are counted here, one lane per read looking at its flag (a handful in a hundred)
+__global__ __launch_bounds__(256) void rle0_count_flagged_kernel(const uint8_t *__restrict__ chars, const uint64_t *__restrict__ off,
+                                                                 uint32_t n_seqs, const uint8_t *__restrict__ flags, uint32_t *__restrict__ counts)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seqs || !flags[s]) return;
+    const uint64_t b = off[s];
+    const uint32_t len = (uint32_t)(off[s + 1] - b);
+    uint32_t n = 0, in_run = 0;
+    for (uint32_t i = 0; i < len; i++) {
+        const uint32_t c = chars[b + i];
+        const uint32_t run = (c != '-' && c != ' ') ? 1u : 0u;
+        n += run & ~in_run;
+        in_run = run;
+    }
+    counts[s] = n;
+}
+
 // total number of runs (the scan's grand total) -> one word the host can read after the stream
 __global__ void rle_total_kernel(const uint32_t *__restrict__ local, const uint32_t *__restrict__ sums, uint32_t n_seqs,
                                  uint32_t *__restrict__ total)
@@ -241,6 +260,28 @@ hipError_t launch_rle_count(const uint8_t *d_chars, const uint64_t *d_offsets, u
     const hipError_t es = launch_scan(local, n, sums, stream);
     if (es != hipSuccess) return es;
     hipLaunchKernelGGL(rle_total_kernel, dim3(1), dim3(64), 0, stream, local, sums, n_seqs, d_total);
+    return hipGetLastError();
+}
+
+// the same with the counts given (d_scratch[0 .. n_seqs): map_reads_kernel's, then launch_rle0_count_flagged's): scan + total only
+hipError_t launch_rle_scan_counts(uint32_t n_seqs, uint32_t *d_scratch, uint32_t *d_total, hipStream_t stream)
+{
+    if (n_seqs == 0) return hipSuccess;
+    const uint32_t n = n_seqs + 1;
+    uint32_t *local = d_scratch, *sums = d_scratch + n;
+    const hipError_t e = hipMemsetAsync(local + n_seqs, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const hipError_t es = launch_scan(local, n, sums, stream);
+    if (es != hipSuccess) return es;
+    hipLaunchKernelGGL(rle_total_kernel, dim3(1), dim3(64), 0, stream, local, sums, n_seqs, d_total);
+    return hipGetLastError();
+}
+
+hipError_t launch_rle0_count_flagged(const uint8_t *d_chars, const uint64_t *d_offsets, uint32_t n_seqs, const uint8_t *d_flags,
+                                     uint32_t *d_counts, hipStream_t stream)
+{
+    if (n_seqs == 0) return hipSuccess;
+    hipLaunchKernelGGL(rle0_count_flagged_kernel, dim3((n_seqs + 255u) / 256u), dim3(256), 0, stream, d_chars, d_offsets, n_seqs, d_flags, d_counts);
     return hipGetLastError();
 }
 

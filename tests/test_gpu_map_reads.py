@@ -259,3 +259,43 @@ def test_packed_native_kernel_device_resident(oracle):
         host = batch.matches_batch_packed(sbwt, words, offsets, pos, byt)
         assert np.array_equal(host, pb.words_out[:len(words)].cpu().numpy().view(np.uint32))
         assert np.array_equal(batch.unpack_matches(host, offsets), want)
+
+
+def test_find_on_the_device_counts_runs_in_the_kernel(oracle):
+    """kbo_find_batch_dev: the characters and format::run_lengths_gapped of them for a device-resident batch.  With max_gap_len = 0 the
+    one kernel counts the runs of the reads it finishes (and a small kernel those of the reads it leaves to the second pass), so the
+    records come from one pass over the characters; with a gap length the usual two.  Against the oracle's literal run lengths, every
+    read: ragged reads down to 3 bases, substitutions to 6 %, indels, N's, unrelated reads (no run at all), with and without a tail
+    stream; sequences longer than the kernel takes (two kernels, then count + emit)."""
+    import torch
+    rng = np.random.default_rng(77)
+    g = synth.genome(400_000, seed=71)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=threads()))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    dev0 = torch.device("cuda:0")
+    T = torch.cuda.Stream(dev0)
+    other = synth.genome(30_000, seed=5)
+
+    def take(n, lo, hi):
+        return [g[a:a + int(l)] for a, l in zip(rng.integers(0, len(g) - 700, n), rng.integers(lo, hi + 1, n))]
+    sets = [
+        (_mutate(rng, take(20_000, 150, 150), sub=0.01), True),
+        (_mutate(rng, take(15_000, 3, 157), sub=0.03, indel=0.3, n_rate=0.1), True),
+        (_mutate(rng, take(5_000, 120, 160), sub=0.06) + [other[a:a + 150] for a in rng.integers(0, len(other) - 150, 2000)], True),
+        (_mutate(rng, take(3_000, 100, 470), sub=0.01), False),  # longer than 160 bases: not the one kernel
+    ]
+    for reads, one_kernel in sets:
+        concat, offsets = _batch_of(reads)
+        exp_chars = ora.matches_batch(concat, offsets, 1e-7, n_threads=threads())
+        for gap in (0, 3):
+            exp_r, exp_o = oracle.run_lengths_batch(exp_chars, offsets, gap)
+            for tail in (None, T):
+                kbo_amd.lib().kbo_set_plan(1, 0, 0)
+                dev = batch.DeviceBatch(sbwt, concat, offsets, device=dev0, format=False, want_ms=False)
+                dev.run_find(gap, tail_stream=tail, runs_per_seq=4)
+                torch.cuda.synchronize()
+                assert dev.fused == one_kernel
+                assert np.array_equal(dev.chars[:dev.total].cpu().numpy(), exp_chars)
+                recs, first = dev.run_lengths_host()
+                assert np.array_equal(np.asarray(first, dtype=np.uint64), exp_o), (gap, tail is not None)
+                assert np.array_equal(np.asarray(recs, dtype=np.uint64).reshape(-1, 7), exp_r), (gap, tail is not None)
