@@ -264,6 +264,10 @@ struct FusedMap {
     hipStream_t tail = nullptr;
     hipEvent_t fence = nullptr;
     hipStream_t results = nullptr;
+    // kbo::find with max_gap_len = 0: where the number of runs of every sequence goes (rle scratch, n_seqs + 1 words); counted = the
+    // one kernel (and, for the reads of its second pass, rle0_count_flagged_kernel) filled it: scan + emit are what is left
+    uint32_t *run_counts = nullptr;
+    bool counted = false;
 };
 void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, bool want_ival,
                        BatchOnDevice &B, std::vector<kbo::WalkItem> &items_keep, hipStream_t stream,

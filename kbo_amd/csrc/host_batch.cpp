@@ -241,6 +241,8 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
                                                        (uint32_t)n_seqs, B.exc_flag.as<uint8_t>(), stream));
                     a.qp_exc = B.exc_flag.as<uint8_t>();
                 }
+                const bool count_runs = map->run_counts && !map->format && !map->d_packed_out;
+                if (count_runs) a.run_counts = map->run_counts;
                 HIP_OK(kbo::launch_map_reads(a, stream));
                 hipStream_t ts = second_pass_stream(a);
                 HIP_OK(kbo::launch_unpack_flagged(a.qp, B.off.as<uint64_t>(), (uint32_t)n_seqs, wps, a.qp_data, a.redo, B.q.as<uint8_t>(), ts));
@@ -253,17 +255,27 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
                     HIP_OK(kbo::launch_pack_flagged(map->d_chars, B.off.as<uint64_t>(), (uint32_t)n_seqs, wps, a.qp_data, a.redo, map->d_packed_out, ts));
                     map->packed_done = true;
                 }
+                if (count_runs) {
+                    HIP_OK(kbo::launch_rle0_count_flagged(map->d_chars, B.off.as<uint64_t>(), (uint32_t)n_seqs, a.redo, map->run_counts, ts));
+                    map->counted = true;
+                }
                 plan_after_launch(a, ts, plan_state);
                 map->done = true;
                 return;
             }
             need_bytes();
             if (a.gitems && kbo::map_reads_applies(a)) {
+                const bool count_runs = map->run_counts && !map->format && kbo::map_reads_direct(a);
+                if (count_runs) a.run_counts = map->run_counts;
                 HIP_OK(kbo::launch_map_reads(a, stream));
                 hipStream_t ts = second_pass_stream(a);
                 HIP_OK(kbo::launch_redo_pass(a, ts));
                 HIP_OK(kbo::launch_derand_flagged(B.ms.as<uint8_t>(), B.off.as<uint64_t>(), (uint32_t)n_seqs, idx->host.k, map->threshold,
                                                   map->format ? B.q.as<uint8_t>() : nullptr, map->d_chars, a.redo, longest_seq, ts));
+                if (count_runs) {
+                    HIP_OK(kbo::launch_rle0_count_flagged(map->d_chars, B.off.as<uint64_t>(), (uint32_t)n_seqs, a.redo, map->run_counts, ts));
+                    map->counted = true;
+                }
                 plan_after_launch(a, ts, plan_state);
                 map->done = true;
                 return;
@@ -668,6 +680,10 @@ private:
         FusedMap fm{nullptr, job_.threshold, job_.format && !job_.sink};
         fm.tail = C.st_tail;
         fm.fence = S.fence;
+        if (job_.sink && job_.sink->max_gap_len == 0) { // kbo::find, FindOpts' default: the one kernel counts the runs itself
+            S.rle_scratch.ensure(kbo::chunk_items_scratch_words((uint32_t)ns) * sizeof(uint32_t));
+            fm.run_counts = S.rle_scratch.as<uint32_t>();
+        }
         if (!job_.ms_out) { // kbo::matches / map / find: the characters' buffer first, so that the one kernel can write into it
             S.chars.ensure(((bytes + 15) / 16) * 16 + 32);
             fm.d_chars = S.chars.as<uint8_t>();
@@ -715,8 +731,11 @@ private:
                 S.rle_capacity = 2 * ns + 16;
                 S.rles.ensure(S.rle_capacity * kRleWords * sizeof(uint32_t));
             }
-            HIP_OK(kbo::launch_rle_count(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
-                                         S.rle_scratch.as<uint32_t>(), S.rle_total.as<uint32_t>(), st_res, mx));
+            if (fm.done && fm.counted) // (counts are there: scan + total)
+                HIP_OK(kbo::launch_rle_scan_counts((uint32_t)ns, S.rle_scratch.as<uint32_t>(), S.rle_total.as<uint32_t>(), st_res));
+            else
+                HIP_OK(kbo::launch_rle_count(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
+                                             S.rle_scratch.as<uint32_t>(), S.rle_total.as<uint32_t>(), st_res, mx));
             HIP_OK(hipMemcpyAsync(S.rle_total_pin.p, S.rle_total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_res));
             HIP_OK(kbo::launch_rle_emit(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
                                         S.rle_scratch.as<uint32_t>(), S.rles.as<uint32_t>(), (uint32_t)S.rle_capacity,
