@@ -79,6 +79,12 @@ pub mod ffi {
                                       max_seq_len: usize, p: f64, format: c_int, want_ms: c_int, d_ms: *mut u8, d_chars_out: *mut u8,
                                       d_work: *mut c_void, work_bytes: usize, stream: *mut c_void, tail_stream: *mut c_void,
                                       fused: *mut c_int) -> c_int;
+        // kbo::find for a device-resident batch: the characters, then format::run_lengths_gapped of them (records of seven u32)
+        pub fn kbo_run_lengths_work_bytes(n_seqs: usize) -> usize;
+        pub fn kbo_find_batch_dev(idx: *mut KboIndex, d_concat: *const u8, d_offsets: *const u64, n_seqs: usize, total_bases: u64,
+                                  max_seq_len: usize, p: f64, max_gap_len: usize, d_ms: *mut u8, d_chars_out: *mut u8, d_work: *mut c_void,
+                                  work_bytes: usize, d_rle_work: *mut c_void, d_records: *mut u32, capacity: usize, stream: *mut c_void,
+                                  tail_stream: *mut c_void, fused: *mut c_int) -> c_int;
         pub fn kbo_matches_packed_dev_scratch_bytes(n_seqs: usize, total_bases: u64) -> usize;
         pub fn kbo_matches_packed_dev(idx: *mut KboIndex, d_words: *const u32, d_offsets: *const u64, n_seqs: usize, total_bases: u64,
                                       max_seq_len: usize, uniform_len: usize, d_exc_pos: *const u64, d_exc_byte: *const u8, n_exc: usize,
