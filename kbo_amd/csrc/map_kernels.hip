@@ -674,10 +674,17 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                                 // round of the loop up: the proof was 95 us of the kernel's 240 with it, 75 without anchors)
                                 const uint32_t e_i = ee[i];
                                 const uint32_t nxt_e = (i + 1u < 4u && use[i + 1u < 4u ? i + 1u : i]) ? ee[i + 1u < 4u ? i + 1u : i] : o_len;
-                                st_anch++;
-                                const uint32_t slot = atomicAdd(pend_n, 1u);
-                                if (slot < 64u) pend[slot] = make_uint2(o_soff + e_i, owner | (e_i << 8) | ((nxt_e - e_i) << 16));
-                                else fail = true; // (no room: the plain walk decides)
+                                // (the entry's low bits say which bases in front of the window extend it: three times in four the read's
+                                // own does not - the depth is the window's length, nothing to look up)
+                                const bool deeper = e_i >= order && order < k && ((bytes[i] >> base_at(o_soff + e_i - order)) & 1u);
+                                if (!deeper) {
+                                    if (order + (nxt_e - e_i) - 1u > thr) fail = true;
+                                } else {
+                                    st_anch++;
+                                    const uint32_t slot = atomicAdd(pend_n, 1u);
+                                    if (slot < 64u) pend[slot] = make_uint2(o_soff + e_i, owner | (e_i << 8) | ((nxt_e - e_i) << 16));
+                                    else fail = true; // (no room: the plain walk decides)
+                                }
                             }
                         }
                     }
