@@ -1321,7 +1321,7 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
         a.map_fmt = format ? 1u : 0u;
         a.map_want_ms = want_ms ? 1u : 0u;
         if (!a.gitems || !kbo::map_reads_applies(a)) return; // (no plan structures, or the copy is held off: two kernels)
-        a.seq_off = d_offsets; // (the kernel reads the offsets themselves; the item list is the second pass's: made on its stream)
+        a.seq_off = d_offsets; // (the kernel and redo_collect_kernel read the offsets themselves: no item list is made)
         // kbo::find with max_gap_len = 0: the kernel counts the runs of the reads it finishes (their characters are in LDS anyway), so
         // that format::run_lengths_gapped is one pass over the characters instead of two
         uint32_t *rle_scratch = find ? static_cast<uint32_t *>(find->d_rle_work) : nullptr;
@@ -1348,8 +1348,7 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
             if (!env_piece) a.redo_piece = 32u;
         }
         if (timing) HIP_OK(hipEventRecord(ev.e1t, ts)); // (when the second pass starts: behind the kernel and behind what `ts` held)
-        HIP_OK(kbo::launch_make_items(d_offsets, (uint32_t)n_seqs, items, ts));
-        HIP_OK(kbo::launch_redo_pass(a, ts));
+        HIP_OK(kbo::launch_redo_pass(a, ts)); // (redo_collect_kernel reads the offsets as well: no item list at all)
         HIP_OK(kbo::launch_derand_flagged(d_ms, d_offsets, (uint32_t)n_seqs, idx->host.k, (uint32_t)threshold, format ? d_concat : nullptr,
                                           d_chars_out, a.redo, (uint32_t)max_seq_len, ts));
         if (timing) {
@@ -1477,7 +1476,7 @@ int kbo_matches_packed_dev(kbo_index_t *idx, const uint32_t *d_words, const uint
                     "this copy of the index cannot take the packed-native kernel (no depth table, a held-off copy, a threshold below the "
                     "table's order): kbo_matches_batch_packed takes any batch");
         if (pscr) HIP_OK(kbo::launch_packed_prefix(d_offsets, (uint32_t)n_seqs, pscr, s));
-        a.seq_off = d_offsets; // (the item list is the second pass's: made on its stream)
+        a.seq_off = d_offsets; // (no item list: the kernels read the offsets)
         a.qp = d_words;
         a.qp_wps = wps;
         a.qp_data = pscr;
@@ -1504,7 +1503,6 @@ int kbo_matches_packed_dev(kbo_index_t *idx, const uint32_t *d_words, const uint
             if (!env_piece) a.redo_piece = 32u;
         }
         if (timing) HIP_OK(hipEventRecord(ev.e1t, ts));
-        HIP_OK(kbo::launch_make_items(d_offsets, (uint32_t)n_seqs, items, ts));
         HIP_OK(kbo::launch_unpack_flagged(d_words, d_offsets, (uint32_t)n_seqs, wps, pscr, a.redo, q, ts));
         HIP_OK(kbo::launch_exceptions(d_exc_pos, d_exc_byte, (uint32_t)n_exc, 0, q, ts));
         HIP_OK(kbo::launch_redo_pass(a, ts));

@@ -683,7 +683,10 @@ __global__ __launch_bounds__(1024) void redo_collect_kernel(WalkArgs a)
     const bool have = idx < a.n_items;
     WalkItem *list = reinterpret_cast<WalkItem *>(a.units);
     uint4 it = make_uint4(0, 0, 0, 0);
-    if (have) it = ld16(reinterpret_cast<const uint8_t *>(a.items), idx * 16u);
+    if (have && a.seq_off) { // (map_reads_kernel's batches: item s is sequence s, whole - no item list was ever written)
+        const uint64_t o0 = a.seq_off[idx], o1 = a.seq_off[idx + 1u];
+        it = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), (uint32_t)(o1 - o0), 0u);
+    } else if (have) it = ld16(reinterpret_cast<const uint8_t *>(a.items), idx * 16u);
     // plan given up: all items, in order.  The same when a wave of the guided walk left through its no-progress guard
     // (qctl[3]; it cannot, but then units are unwalked): every item is walked again in full, so the batch stays exact.
     // (table mode: the plan is given up when more than unit_bail items had no plan or were left unresolved by the table)

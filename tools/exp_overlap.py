@@ -41,7 +41,11 @@ def timed(fn, steps=40, warm=4):
     torch.cuda.synchronize()
     a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(S)
+    import time as _t
+    t0 = _t.perf_counter()
     fn(steps)
+    global ENQ
+    ENQ = (_t.perf_counter() - t0) / steps * 1e3
     for t in Ts:
         S.wait_stream(t)
     e.record(S)
@@ -70,4 +74,5 @@ def staged(fn):
 ts = staged(serial)
 tp = staged(piped)
 ok = all(bool((d.chars[:d.total] == r).all()) for d, r in zip(devs, ref))
+print("host enqueue of the last loop %.4f ms per step" % ENQ)
 print("serial %.4f ms/step = %.1f Gbp/s; two in flight %.4f ms/step = %.1f Gbp/s; equal %s" % (ts, devs[0].total / ts / 1e6, tp, devs[0].total / tp / 1e6, ok))
