@@ -93,3 +93,12 @@ def test_bench_gpus_2_spawns_two_ranks(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "kbo_bench_iid_400000_k31.kbohip"))  # built once by the parent, loaded by the ranks
     lo, hi = r["roofline"]["kernel_ms_per_rank"]["min"], r["roofline"]["kernel_ms_per_rank"]["max"]
     assert 0 < lo <= hi
+
+
+def test_bench_call_line(tmp_path):
+    """--call: the first pass of kbo call timed on the device (sites of every read against the oracle's first pass), and the whole
+    kbo_call_batch beside it (a sample of reads against the oracle's literal call)"""
+    r = _run(["--call", "--genome", "2000000", "--reads", "600", "--k", "51", "--steps", "2", "--warmup", "1"], tmp_path)
+    assert r["bit_exact_vs_oracle"] is True and r["value"] > 0 and r["kernels_ms"]["ms_walk_call_mode"] > 0
+    w = r["whole_call"]
+    assert w["entry_point"] == "kbo_call_batch" and w["variants"] > 600 and w["us_per_read"] > 0 and w["equal_to_oracle_call_on_sampled_reads"] == 40
