@@ -1262,11 +1262,12 @@ int kbo_stage_timing_read(double *kernel_ms_sum, double *redo_ms_sum, int *n_cal
 }
 
 namespace {
-// one fence event per host thread: hipStreamWaitEvent takes the event's state at the time of the call, so recording it again for the
-// next batch does not disturb a wait that is already queued
+// one fence event per host thread and device: hipStreamWaitEvent takes the event's state at the time of the call, so recording it
+// again for the next batch does not disturb a wait that is already queued
 hipEvent_t tail_fence()
 {
-    thread_local hipEvent_t ev = nullptr;
+    thread_local std::map<int, hipEvent_t> evs;
+    hipEvent_t &ev = evs[current_device()];
     if (!ev) HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     return ev;
 }
@@ -1322,6 +1323,7 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
         a.map_want_ms = want_ms ? 1u : 0u;
         if (!a.gitems || !kbo::map_reads_applies(a)) return; // (no plan structures, or the copy is held off: two kernels)
         a.seq_off = d_offsets; // (the kernel and redo_collect_kernel read the offsets themselves: no item list is made)
+        a.host_bailed = plan_state ? plan_state->bailed : nullptr; // (set by redo_collect_kernel itself: no 8-byte copy behind the launch)
         // kbo::find with max_gap_len = 0: the kernel counts the runs of the reads it finishes (their characters are in LDS anyway), so
         // that format::run_lengths_gapped is one pass over the characters instead of two
         uint32_t *rle_scratch = find ? static_cast<uint32_t *>(find->d_rle_work) : nullptr;
@@ -1356,7 +1358,7 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
             std::lock_guard<std::mutex> g(g_timing_mu);
             g_timing_used.push_back(ev);
         }
-        plan_after_launch(a, ts, plan_state);
+        if (!a.host_bailed) plan_after_launch(a, ts, plan_state);
         if (find) { // the run lengths, behind the second pass
             uint32_t *total = rle_scratch + kbo::chunk_items_scratch_words((uint32_t)n_seqs); // last word of the work buffer
             const uint32_t gap = (uint32_t)std::min<size_t>(find->max_gap_len, 0xFFFFFFFFu), cap = (uint32_t)std::min<size_t>(find->capacity, 0xFFFFFFFFu);

@@ -153,6 +153,8 @@ struct WalkArgs {
     // ... its packed-native instantiations (pack_kernels.hip has the layout): the reads as 2-bit words - qp_wps words per read, or
     // 0 and the scanned words-per-read (qp_data / qp_sums) -, one byte per read that is non-zero where the read holds a byte that
     // is no base (nullptr: none does), and, when the characters leave packed as well, where their words go
+    uint32_t *host_bailed;   // (map_reads_kernel's route: pinned host word redo_collect_kernel sets when the plan is given up - the copy's
+                             // hold-off, DevCopy::PlanState::bailed - instead of an 8-byte copy behind every launch)
     uint32_t *run_counts;    // (kbo::find with max_gap_len == 0: the number of runs - maximal stretches without '-' - of every read the
                              // kernel finishes itself, or nullptr: format::run_lengths_gapped then needs no counting pass of its own)
     const uint64_t *seq_off; // (reads: the batch's offsets instead of the item list - item s is sequence s, whole: the list is then

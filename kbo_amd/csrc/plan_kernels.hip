@@ -697,6 +697,7 @@ __global__ __launch_bounds__(1024) void redo_collect_kernel(WalkArgs a)
         if (idx == 0) {
             a.qctl[1] = a.n_items;
             if (gave_up) a.qctl[2] = 1; // tells the host (plan_after_launch) that planning did not pay for this batch
+            if (gave_up && a.host_bailed) *a.host_bailed = 1u; // (... straight into its pinned word where the launch gave one)
         }
         return;
     }

@@ -299,3 +299,31 @@ def test_find_on_the_device_counts_runs_in_the_kernel(oracle):
                 recs, first = dev.run_lengths_host()
                 assert np.array_equal(np.asarray(first, dtype=np.uint64), exp_o), (gap, tail is not None)
                 assert np.array_equal(np.asarray(recs, dtype=np.uint64).reshape(-1, 7), exp_r), (gap, tail is not None)
+
+
+def test_a_batch_that_gives_the_plan_up_holds_the_copy_off(oracle):
+    """12 % substitutions through the one kernel: most reads are left to the second pass, redo_collect_kernel gives the plan up and says
+    so in the copy's pinned word; the next launches over that copy take the two kernels (exact either way) until kbo_set_plan(1, ..)."""
+    import torch
+    rng = np.random.default_rng(3)
+    g = synth.genome(300_000, seed=19)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=threads()))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    dev0 = torch.device("cuda:0")
+    bad = _batch_of(_mutate(rng, [g[a:a + 150] for a in rng.integers(0, len(g) - 150, 20_000)], sub=0.12))
+    good = _batch_of(_mutate(rng, [g[a:a + 150] for a in rng.integers(0, len(g) - 150, 20_000)], sub=0.01))
+    want_bad = ora.matches_batch(*bad, 1e-7, n_threads=threads())
+    want_good = ora.matches_batch(*good, 1e-7, n_threads=threads())
+    kbo_amd.lib().kbo_set_plan(1, 0, 0)
+    d_bad = batch.DeviceBatch(sbwt, *bad, device=dev0, format=False, want_ms=False)
+    d_good = batch.DeviceBatch(sbwt, *good, device=dev0, format=False, want_ms=False)
+    d_bad.run()
+    torch.cuda.synchronize()
+    assert d_bad.fused and np.array_equal(d_bad.chars[:d_bad.total].cpu().numpy(), want_bad)
+    d_good.run()  # (the copy is held off now)
+    torch.cuda.synchronize()
+    assert not d_good.fused and np.array_equal(d_good.chars[:d_good.total].cpu().numpy(), want_good)
+    kbo_amd.lib().kbo_set_plan(1, 0, 0)
+    d_good.run()
+    torch.cuda.synchronize()
+    assert d_good.fused and np.array_equal(d_good.chars[:d_good.total].cpu().numpy(), want_good)
