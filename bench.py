@@ -49,7 +49,7 @@ SLAB_READS = 8_000_000      # reads per device-resident slab (one launch covers 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)  # (0.26 ms each: a timed region of 50 ms - one stall of the host does not decide the line)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=sorted(PRESETS), default="C2",
                     help="BASELINE.json workload: C2 = kbo map, 5 Mbp index, 1 M x 150 bp reads per GPU (the metric config); "
@@ -791,11 +791,15 @@ def main(argv=None):
     ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in slabs] for _ in range(args.steps)]
     import ctypes as _C
     L.kbo_set_stage_timing(1 if one_kernel else 0)  # (event records per call: the dominant kernel's own duration, live)
+    import gc
+    gc.collect()
+    gc.disable()  # (the timed region is tens of milliseconds of enqueueing: no collector pause inside it)
     t0 = time.perf_counter()
     for s in range(args.steps):
         one_step(args.warmup + s, ev[s])
     sync_all()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     L.kbo_set_stage_timing(0)
     k_sum, r_sum, n_calls = _C.c_double(0), _C.c_double(0), _C.c_int(0)
     L.kbo_stage_timing_read(_C.byref(k_sum), _C.byref(r_sum), _C.byref(n_calls))
