@@ -10,6 +10,8 @@ R = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 NB = int(os.environ.get("NB", "2"))
 device = torch.device("cuda:0")
 g = synth.genome(G)
+if os.environ.get("PAIR"):
+    kbo_amd.lib().kbo_set_pair_steps(0, int(os.environ["PAIR"]))  # two-base steps of the plain walk on this small index too
 sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=16))
 devs = []
 for b in range(NB):
