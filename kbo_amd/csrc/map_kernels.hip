@@ -396,15 +396,91 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
     // threshold may run through it: the table proves that too), except that its base g - 1 keeps the value of the first
     // diagonal: list entry `junction`.  Whatever is chosen here only decides how many reads take the plain walk.
     if (DIRECT) {
-        const bool need2 = plannable && !has_invalid && len >= 2u * D && (!seeded || cnt > a.plan_list + 1u);
+        // (also a read whose list would hold its mismatches but has six of them among its first or its last 16 bases: a break
+        // within 16 + 8 bases of an end - windows behind it lie on the other diagonal, are in the index, and fail the proof)
+        const uint32_t listmax = a.plan_list + 1u;
+        uint32_t tail_c = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < kMapWords; g++) {
+            const uint32_t lo_b = 16u * g, t0 = len - 16u;
+            if (lo_b + 16u > t0 && lo_b < len) tail_c += (uint32_t)__popc(mmw[g] & (t0 > lo_b ? (1u << (2u * (16u - (t0 - lo_b)))) - 1u : ~0u));
+        }
+        const bool dense = seeded && len >= 32u && (tail_c >= 6u || (uint32_t)__popc(mmw[0]) >= 6u) && !(a.rounds & 8u);
+        const bool need2 = plannable && !has_invalid && len >= 2u * D && (!seeded || cnt > listmax || dense);
         if (__ballot(need2)) {
             uint32_t pB = 0, eb = len - 1u, tries = 0;
             bool seedB = false;
             const uint32_t lowest = len > cap ? len - cap : 0u;
+            // A second diagonal one to three bases beside the first - a short insertion or deletion, most of what this phase sees -
+            // needs no table: the read's last 16 bases against the text at p0 - 3 .. p0 + 3, out of three units of the text that
+            // the compare step has just had in cache, instead of one to three dependent look-ups in a table that is not.  The
+            // same for its first 16 bases: the seed then came from behind the break (a substitution in the read's first window),
+            // and the diagonal found beside it becomes the first one.  (a first diagonal that explains less than a third of the
+            // read is a wrong seed: the table.)
+            const bool near = need2 && seeded && 10u * cnt <= 7u * len && !(a.rounds & 8u);
+            bool front = false;
+            uint32_t pA = 0;
+            if (__ballot(near)) {
+                if (near) {
+                    // qb: the text base three in front of the 16 bases on p0; -> fewest mismatches over the six shifts, j = shift + 3
+                    const uint32_t qt = p0 + kMapPad + len - 19u, qh = p0 + kMapPad - 3u;
+                    const uint8_t *tt = reinterpret_cast<const uint8_t *>(a.ix.pc_tm) + (size_t)(qt >> 4) * 8u;
+                    const uint8_t *th = reinterpret_cast<const uint8_t *>(a.ix.pc_tm) + (size_t)(qh >> 4) * 8u;
+                    uint2 U[3], H[3];
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        __builtin_memcpy(&U[i], tt + 8 * i, 8);
+                        __builtin_memcpy(&H[i], th + 8 * i, 8);
+                    }
+                    // (a break within 16 bases of that end: the 8 bases at the end, all of them - 6 / 4^8 by chance)
+                    auto beside = [&](const uint2 (&X)[3], uint32_t qb, uint32_t word, uint32_t end8, uint32_t &best_j) -> uint32_t {
+                        uint32_t best = 99u, j8 = 3u;
+                        best_j = 3u;
+#pragma unroll
+                        for (uint32_t j = 0; j < 7u; j++) {
+                            if (j == 3u) continue;
+                            const uint32_t rel = (qb & 15u) + j, r = rel & 15u;
+                            const uint2 hi = rel < 16u ? X[0] : X[1], lo = rel < 16u ? X[1] : X[2];
+                            const uint32_t tw = (uint32_t)((((uint64_t)hi.x << 32) | lo.x) >> (32u - 2u * r));
+                            const uint32_t mk = (uint32_t)((((uint64_t)hi.y << 32) | lo.y) >> (32u - 2u * r));
+                            const uint32_t x = word ^ tw;
+                            const uint32_t mb = (x | (x >> 1) | mk) & 0x55555555u, c = (uint32_t)__popc(mb);
+                            if (c < best) {
+                                best = c;
+                                best_j = j;
+                            }
+                            if ((mb & end8) == 0u) j8 = j;
+                        }
+                        if (best > 2u && j8 != 3u) {
+                            best = 0u;
+                            best_j = j8;
+                        }
+                        return best;
+                    };
+                    uint32_t jt, jh;
+                    const uint32_t ct = beside(U, qt, from_base(soff + len - 16u), 0x0000FFFFu, jt), ch = beside(H, qh, qw[0], 0xFFFF0000u, jh);
+                    // (by chance: 6 * 1129 / 4^16 = 1.6e-6 - and then it costs a flag, not a wrong character)
+                    if (ct <= 2u) {
+                        seedB = true;
+                        pB = p0 + jt - 3u;
+                    } else if (ch <= 2u) {
+                        front = true;
+                        pA = p0 + jh - 3u;
+                    }
+                }
+            }
+            if (__ballot(front)) {
+                if (front) { // the seed's diagonal is the second one
+                    pB = p0;
+                    p0 = pA;
+                    cnt = compare(p0, mmw);
+                    seedB = true;
+                }
+            }
             // (three windows: a read that follows a second diagonal to its end has a seed there unless substitutions sit in all of
             // them; every further window is another dependent load for the whole wave - reads that match nothing pay them all)
             for (;; tries++) {
-                const bool act = need2 && !seedB && tries < 3u && eb + 1u >= D + lowest && eb + 1u >= D;
+                const bool act = need2 && !seedB && (!seeded || cnt > listmax) && tries < 3u && eb + 1u >= D + lowest && eb + 1u >= D;
                 if (__ballot(act) == 0) break;
                 if (act) {
                     const uint32_t tp = seed_at(eb);

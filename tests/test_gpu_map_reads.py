@@ -114,6 +114,41 @@ def test_read_shapes_and_contents(oracle, k):
     _check(oracle, ora, sbwt, *_batch_of([mixed[i] for i in order][:500]), p=0.01)  # a low threshold: anchors and 'R's
 
 
+@pytest.mark.parametrize("k", [31, 21])
+def test_insertions_and_deletions_near_either_end(oracle, k):
+    """the second diagonal found beside the first one (the read's first / last 16 or 8 bases against the text one to three bases
+    off: map_kernels.hip 2b) - breaks 1 .. 40 bases from either end, with substitutions on top, lengths from 28 up, and a genome
+    with short-period tandem arrays, where several shifts fit the same bases; every read against the oracle.
+    Semantics: /root/reference/src/translate.rs:188-206 (what an insertion / a deletion looks like in the characters)"""
+    rng = np.random.default_rng(4100 + k)
+    g = synth.genome(400_000, seed=4200 + k)
+    for _ in range(300):  # tandem arrays of period 1 - 4, 10 - 60 bases long
+        a = int(rng.integers(0, len(g) - 100))
+        unit = ACGT[rng.integers(0, 4, int(rng.integers(1, 5)))]
+        n = int(rng.integers(10, 61))
+        g[a:a + n] = np.tile(unit, n // len(unit) + 1)[:n]
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=k, num_threads=threads()))
+    ora = oracle.Index.build([g.tobytes()], k=k)
+    sbwt.to_device(-1)
+    reads = []
+    for i in range(24_000):
+        L = int(rng.integers(28, 158))
+        a = int(rng.integers(0, len(g) - 200))
+        r = g[a:a + L + 4].copy()
+        d = int(rng.integers(1, min(41, L - 1)))
+        pos = d if i % 2 else L - d  # from the front / from the back
+        z = int(rng.integers(1, 5))   # (four bases: beyond what the search beside the diagonal covers)
+        if rng.random() < 0.5:
+            r = np.concatenate([r[:pos], r[pos + z:]])
+        else:
+            r = np.concatenate([r[:pos], ACGT[rng.integers(0, 4, z)], r[pos:]])
+        r = r[:L]
+        hit = rng.random(len(r)) < (0.0, 0.01, 0.03)[i % 3]
+        r[hit] = ACGT[rng.integers(0, 4, int(hit.sum()))]
+        reads.append(r)
+    _check(oracle, ora, sbwt, *_batch_of(reads))
+
+
 def test_many_paths_and_both_stretch_widths(oracle):
     """several contigs that share repeats (the cover has many paths: path starts inside reads), separated by N; then the same
     reads with a table of 16 and of 17 bases forced onto the small index (the kernel's 18-base stretches, 64-bit keys)."""

@@ -15,7 +15,11 @@ if os.environ.get("PAIR"):
 sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=16))
 devs = []
 for b in range(NB):
-    concat, offsets = synth.reads(g, R, 150, 0.01, seed=100 + b)
+    if os.environ.get("INDEL"):  # bench.py's indel variant: 1 % substitutions + INDEL per base start an insertion / deletion of 1 - 3 bases
+        import bench
+        concat, offsets = bench.indel_reads(g, R, 150, 0.01, float(os.environ["INDEL"]), seed=0x5E11C + b)
+    else:
+        concat, offsets = synth.reads(g, R, 150, float(os.environ.get("SUB", "0.01")), seed=100 + b)
     devs.append(batch.DeviceBatch(sbwt, concat, offsets, device=device, format=True, want_ms=False))
 PRI = int(os.environ.get("PRI", "0"))
 NT = int(os.environ.get("NT", "1"))
@@ -59,6 +63,7 @@ for d in devs:
     d.run(S)
 torch.cuda.synchronize()
 ref = [d.chars[:d.total].clone() for d in devs]
+print("flagged reads per batch:", [int((d.plan_flags() != 0).sum()) for d in devs])
 import ctypes as C
 L = kbo_amd.lib()
 
