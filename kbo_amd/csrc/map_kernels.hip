@@ -743,7 +743,20 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; i++) {
                         if (use[i] && (bytes[i] & 0x80u)) { // the window is a suffix of a row
-                            if (!have_anch || lastw[i]) fail = true;
+                            if (have_anch && lastw[i] && t != o_junc && order < k && ee[i] >= order && !(a.rounds & 16u) &&
+                                !((bytes[i] >> base_at(o_soff + ee[i] - order)) & 1u)) {
+                                // the window that STARTS at the mismatch m (one substitution in 170 has it: its 14 bases behind m
+                                // occur elsewhere behind the read's base).  Not deeper: no string through m that ends with it has
+                                // more than `order` bases.  And one that ends further right holds the window's bases + the next one:
+                                // the entry of the window one base on says whether the read's base at m extends THAT to the left
+                                // (behind the loop too).  Without this the read's only way was the plain walk: 0.6 % per mismatch
+                                const uint32_t e1 = ee[i] + 1u;
+                                if (e1 < o_len) {
+                                    const uint32_t slot = atomicAdd(pend_n, 1u);
+                                    if (slot < 64u) pend[slot] = make_uint2(o_soff + e1, owner | (e1 << 8) | 0x80000000u);
+                                    else fail = true;
+                                }
+                            } else if (!have_anch || lastw[i]) fail = true;
                             else {
                                 // its exact depth off the path-cover text decides - behind the loop, all such windows of the wave at once
                                 // (one in 200 windows: looked up here, a hash probe and two loads of text for ONE lane held every
@@ -839,11 +852,18 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
             const uint32_t n_pend = min(*pend_n, 64u);
             if (lane < n_pend) {
                 const uint2 pe = pend[lane];
-                const uint32_t p_owner = pe.y & 0xFFu, e_i = (pe.y >> 8) & 0xFFu, gap = pe.y >> 16, at_e = pe.x;
-                const uint32_t V = dtab_anchor_depth(a.ix, e_i + 1u, [&](uint32_t tt) -> uint32_t {
-                    return (0x54474341u >> (8u * base_at(at_e - tt))) & 0xFFu;
-                });
-                if (V == kDtabUnknown || V + gap - 1u > thr) spw[p_owner * 16u + 13u] = 1;
+                const uint32_t p_owner = pe.y & 0xFFu, e_i = (pe.y >> 8) & 0xFFu, gap = (pe.y >> 16) & 0x7FFFu, at_e = pe.x;
+                if (pe.y >> 31) { // the window one base behind the one that starts at a mismatch: extended to the left by the read's base there?
+                    const code_t key = (code_t)ending_at(at_e) & omask;
+                    const uint32_t byte = !a.ix.dtab_grouped ? a.ix.dtab[key]
+                                                             : a.ix.dtab[NP == 16 ? dtab_grouped_addr32((uint32_t)key, e_i % 3u, order) : dtab_grouped_addr((uint64_t)key, e_i % 3u, order)];
+                    if ((byte & 0x80u) && ((byte >> base_at(at_e - order)) & 1u)) spw[p_owner * 16u + 13u] = 1;
+                } else {
+                    const uint32_t V = dtab_anchor_depth(a.ix, e_i + 1u, [&](uint32_t tt) -> uint32_t {
+                        return (0x54474341u >> (8u * base_at(at_e - tt))) & 0xFFu;
+                    });
+                    if (V == kDtabUnknown || V + gap - 1u > thr) spw[p_owner * 16u + 13u] = 1;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();

@@ -337,7 +337,7 @@ def test_find_on_the_device_counts_runs_in_the_kernel(oracle):
 
 
 def test_a_batch_that_gives_the_plan_up_holds_the_copy_off(oracle):
-    """12 % substitutions through the one kernel: most reads are left to the second pass, redo_collect_kernel gives the plan up and says
+    """20 % substitutions through the one kernel (15 % of the bases differ: 22 mismatches a read, its list holds 13): most reads are left to the second pass, redo_collect_kernel gives the plan up and says
     so in the copy's pinned word; the next launches over that copy take the two kernels (exact either way) until kbo_set_plan(1, ..)."""
     import torch
     rng = np.random.default_rng(3)
@@ -345,7 +345,7 @@ def test_a_batch_that_gives_the_plan_up_holds_the_copy_off(oracle):
     sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=threads()))
     ora = oracle.Index.build([g.tobytes()], k=31)
     dev0 = torch.device("cuda:0")
-    bad = _batch_of(_mutate(rng, [g[a:a + 150] for a in rng.integers(0, len(g) - 150, 20_000)], sub=0.12))
+    bad = _batch_of(_mutate(rng, [g[a:a + 150] for a in rng.integers(0, len(g) - 150, 20_000)], sub=0.20))
     good = _batch_of(_mutate(rng, [g[a:a + 150] for a in rng.integers(0, len(g) - 150, 20_000)], sub=0.01))
     want_bad = ora.matches_batch(*bad, 1e-7, n_threads=threads())
     want_good = ora.matches_batch(*good, 1e-7, n_threads=threads())
