@@ -5,10 +5,11 @@ One "step" = one pass of the hot path - kbo::map with fill_gaps=false, call_vari
 derandomize -> translate -> relative_to_ref - over one batch of synthetic reads already resident in HBM, through
 kbo_map_batch_dev: ONE kernel for the reads (kbo_amd/csrc/map_kernels.hip) + the plain walk of the few per cent it leaves
 (--two-kernels: the round-3 route, the plan-guided MS walk and the derandomize / translate kernel one after the other).
-TWO batches are in flight: consecutive steps take two resident batches of the same shape in turn (different reads, own
-buffers), and a batch's second pass runs on a second stream (kbo_map_batch_dev_tail) beside the next batch's kernel; every step's
-work - both passes - ends inside the timed region.  --one-at-a-time: a single stream (also reported in the line:
-`one_batch_at_a_time`).  Default workload = BASELINE config C2: 5 Mbp iid genome, k=31 SBWT, 1 M x 150 bp forward reads with
+Batches are in flight on TWO PIPELINES of two streams each: a batch's kernel on its pipeline's first stream, its second pass on
+the second one (kbo_map_batch_dev_tail) beside the pipeline's next kernel; consecutive steps go to the pipelines in turn and take
+four resident batches of the same shape in turn (different reads, own buffers), so two kernels and two second passes share
+the device at any time; every step's work - both passes - ends inside the timed region.  --one-at-a-time: a single stream
+(also reported in the line: `one_batch_at_a_time`).  Default workload = BASELINE config C2: 5 Mbp iid genome, k=31 SBWT, 1 M x 150 bp forward reads with
 1 % substitutions per GPU (weak scaling: every rank holds the replicated index and its own reads; no collective on the data
 path).  Prints ONE JSON line on rank 0.
 
@@ -76,6 +77,8 @@ def parse(argv=None):
     ap.add_argument("--two-kernels", action="store_true", help="kbo_ms_batch_dev + kbo_derand_translate_dev instead of kbo_map_batch_dev "
                     "(the MS values of every base go through HBM)")
     ap.add_argument("--one-at-a-time", action="store_true", help="one stream: a batch's second pass before the next batch's kernel")
+    ap.add_argument("--pipelines", type=int, default=2, help="pipelines of two streams (kernel; second pass) the steps go to in turn, "
+                    "two resident batches each (1: round 4's first form, two batches in flight; 3 is slower than 2)")
     ap.add_argument("--depth-table", type=int, default=0,
                     help="order of the depth table (kbo_set_depth_table): 0 = by index size, -1 = none (units + guided walk)")
     ap.add_argument("--index-cache", default=None, help="index file (.kbohip, with its path cover) to load instead of building; "
@@ -329,11 +332,12 @@ def stage_model_leg(args, sbwt, oi, concat, offsets, gpu_d, n_sample=2_000_000):
     return total / cn["bases"], summary, cn
 
 
-def run_piped(devs, stream, tail, steps, torch):
-    """`steps` batches through kbo_map_batch_dev_tail, the resident batches in `devs` in turn: the kernel on `stream`, the second
-    pass on `tail`; a batch's buffers are used again only behind its last second pass (its `done` event)"""
+def run_piped(devs, pipes, steps, torch):
+    """`steps` batches through kbo_map_batch_dev_tail, the resident batches in `devs` in turn, the pipelines `pipes` = [(kernel
+    stream, second-pass stream), ..] in turn; a batch's buffers are used again only behind its last second pass (its `done` event)"""
     for i in range(steps):
         dev = devs[i % len(devs)]
+        stream, tail = pipes[i % len(pipes)]
         if getattr(dev, "done", None) is None:
             dev.done = torch.cuda.Event()
         else:
@@ -342,14 +346,14 @@ def run_piped(devs, stream, tail, steps, torch):
         dev.done.record(tail)
 
 
-def run_batch(devs, stream, find, steps, warmup, torch, device, two_kernels=False, tail=None):
-    """warm-up + timed steps over the resident batches `devs` in turn (one, or two of the same shape when `tail` is a second
-    stream) -> (elapsed s, a1 ms, a5/a6 ms, rle ms | None); with kbo_map_batch_dev (not two_kernels) a1 = the whole step and a5/a6 = 0"""
+def run_batch(devs, stream, find, steps, warmup, torch, device, two_kernels=False, pipes=None):
+    """warm-up + timed steps over the resident batches `devs` in turn (one, or two per pipeline of the same shape with `pipes`, see
+    run_piped) -> (elapsed s, a1 ms, a5/a6 ms, rle ms | None); with kbo_map_batch_dev (not two_kernels) a1 = the whole step and a5/a6 = 0"""
     dev = devs[0]
     if not two_kernels:
         def go(n):
-            if tail is not None:
-                run_piped(devs, stream, tail, n, torch)
+            if pipes is not None:
+                run_piped(devs, pipes, n, torch)
             else:
                 for i in range(n):
                     devs[i % len(devs)].run(stream)
@@ -359,8 +363,9 @@ def run_batch(devs, stream, find, steps, warmup, torch, device, two_kernels=Fals
         t0 = time.perf_counter()
         e0.record(stream)
         go(steps)
-        if tail is not None:
-            stream.wait_stream(tail)
+        for ks, ts in (pipes or []):
+            stream.wait_stream(ks)
+            stream.wait_stream(ts)
         e1.record(stream)
         torch.cuda.synchronize(device)
         return time.perf_counter() - t0, e0.elapsed_time(e1) / steps, 0.0, None
@@ -434,10 +439,10 @@ def indel_reads(genome, n_reads, L, sub_rate, indel_rate, seed, many=False):
     return out, np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(L)
 
 
-def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, tail=None):
+def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, pipes=None):
     """SURVEY.md 8(d) asks for 0 % and 5 % variants of C2; VERDICT adds what the iid forward reads hide: reads from the
     other strand (the index has no reverse complements), reads from elsewhere, a repeat-rich genome of many contigs.  Each:
-    a resident batch of the C2 shape, 2 warm-up + 6 timed steps (two sets of buffers in flight as in the headline), every one of its first 20 000 reads against the oracle."""
+    a resident batch of the C2 shape, 4 warm-up + 12 timed steps (four sets of buffers in flight on two pipelines as in the headline), every one of its first 20 000 reads against the oracle."""
     import kbo_amd
     from kbo_amd import batch, synth
     from oracle import binding as ora
@@ -450,9 +455,10 @@ def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, tail=None):
     def measure(name, ix, o, concat, offsets, note):
         dev = batch.DeviceBatch(ix, concat, offsets, device=device, format=True, want_ms=False)
         devs = [dev]
-        if tail is not None and dev.max_len <= 160:  # (two in flight as in the headline: the same reads, a second set of buffers)
-            devs.append(batch.DeviceBatch(ix, concat, offsets, device=device, format=True, want_ms=False))
-        elapsed, a1, dt, _ = run_batch(devs, stream, False, 6, 2, torch, device, args.two_kernels, tail if len(devs) > 1 else None)
+        if pipes is not None and dev.max_len <= 160:  # (in flight as in the headline: the same reads, further sets of buffers)
+            for _ in range(2 * len(pipes) - 1):
+                devs.append(batch.DeviceBatch(ix, concat, offsets, device=device, format=True, want_ms=False))
+        elapsed, a1, dt, _ = run_batch(devs, stream, False, 12, 4, torch, device, args.two_kernels, pipes if len(devs) > 1 else None)
         fused = dev.fused
         n_all = len(offsets) - 1
         n_chk = max(1, min(n_all, int(np.searchsorted(offsets, 3_000_000))))  # the reads of the first 3 Mbp
@@ -464,7 +470,7 @@ def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, tail=None):
         torch.cuda.synchronize(device)
         ok = bool(ok and np.array_equal(dev.ms[:n_b].cpu().numpy(), exp_d))
         del dev, devs
-        return {"variant": name, "value": round(int(offsets[-1]) * 6 / elapsed / 1e6, 1), "unit": "Mbp/s", "one_kernel": fused,
+        return {"variant": name, "value": round(int(offsets[-1]) * 12 / elapsed / 1e6, 1), "unit": "Mbp/s", "one_kernel": fused,
                 "step_ms": round(a1 + dt, 4), "bit_exact_vs_oracle": ok, "note": note}
 
     out = []
@@ -719,11 +725,14 @@ def main(argv=None):
     # ---- reads: sharded by rank.  weak scaling (C2, C3): args.reads per rank; strong (C4): args.reads in all
     n_mine, first = shard(args, rank, world)
     stream = torch.cuda.current_stream(device)
-    # two batches in flight (module docstring): a batch's second pass on `tail` beside the next batch's kernel on `stream`
+    # batches in flight (module docstring): two pipelines, on each a batch's second pass on the second stream beside the next
+    # batch's kernel on the first
     piped = not args.two_kernels and not args.one_at_a_time
-    tail = torch.cuda.Stream(device) if piped else None
+    n_pipes = max(1, args.pipelines) if piped else 1
+    pipes = [(stream if p == 0 else torch.cuda.Stream(device), torch.cuda.Stream(device)) for p in range(n_pipes)] if piped else None
     n_slabs = (n_mine + SLAB_READS - 1) // SLAB_READS
-    n_sets = 2 if piped and n_slabs == 1 else 1  # (several slabs per step are several batches already)
+    # (several slabs per step are several batches already; fewer than two per pipeline: a second set of them)
+    n_sets = (2 * n_pipes if n_slabs == 1 else 2 if n_slabs < 2 * n_pipes else 1) if piped else 1
     sets, first_slab = [], []
     for b in range(n_sets):
         slabs = []
@@ -746,9 +755,12 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    stream0 = stream
+
     def one_step(step, events=None, on_tail=None):
         on_tail = piped if on_tail is None else on_tail
         for i, dev in enumerate(sets[step % n_sets]):
+            stream, tail = pipes[(step * len(slabs) + i) % n_pipes] if on_tail else (stream0, None)
             if on_tail and dev.done is not None:
                 stream.wait_event(dev.done)  # its buffers are free again behind its last second pass
             if events is not None:
@@ -891,7 +903,7 @@ def main(argv=None):
                 b_plan, model, _ = stage_model_leg(args, sbwt, oi, concat0, offsets0, gpu_d)
                 exact = bool(exact and model["ms_equal_to_gpu"])
             if world == 1 and not args.no_extras and (args.extras or not args.custom):
-                sens = sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, tail)
+                sens = sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, pipes if piped else None)
         # fabric-side traffic and L2 misses of the A1 stage, from the committed rocprofv3 passes of this exact
         # workload and walk mode (PMC passes cannot run inside the timed region: separate runs, tools/profile_bench.sh)
         wl_key = f"{args.genome}x{n_mine}x{args.read_len}x{args.sub_rate:g}:{('map' if one_kernel else 'table' if sbwt.depth_table_order() > 0 else 'plan') if planned else 'plain'}"
@@ -978,7 +990,12 @@ def main(argv=None):
                   "seed_positions": 4 * c["seed_lookups"], "text_2bit_and_marks": 96 * seeded, "depth_table_bytes": c["tab_lookups"],
                   "filter_words": 4 * c["seed_extensions"]}  # (seed_extensions: this kernel counts its filter look-ups there)
             b_map = sum(by.values()) / dev.total
-            k_s = map_kernel_ms * 1e-3
+            # the kernel's duration, launch by launch (HIP events around it).  With two pipelines two launches share the device
+            # for the whole of their durations: the device's time per launch is then the timed region / launches, not a launch's
+            # own duration - the bytes are priced by that (never less than duration / pipelines), the duration is printed beside it
+            k_launch_s = map_kernel_ms * 1e-3
+            shared = piped and n_pipes > 1
+            k_s = max(elapsed / args.steps, k_launch_s / n_pipes) if shared else k_launch_s
             achieved = b_map * bases / k_s / 1e9
             lines_min = (2 * dev.total / 128 + c["seed_lookups"] + c["tab_lookups"]) / dev.n_seqs  # streams + one line per table access (the filter's 2 MB stay in L2)
             roofline = {
@@ -987,10 +1004,21 @@ def main(argv=None):
                                 "of its own; four in five settled by a 2 MB filter in L2 before they reach the table), the 2-bit text on the diagonal "
                                 "(L2 / Infinity Cache) and 2 B per base of streams.  Alone the kernel is not bound by its fills (with or without the "
                                 "filter: the same time), nor by its instructions: the wave's own chain of dependent loads is what is left (DESIGN.md 4.1)"
-                                + ("; the timed kernels ran beside the other batch's second pass (batches_in_flight)" if piped else ""),
+                                + ("; the timed kernels ran beside the other batches' kernels and second passes (batches_in_flight)" if piped else ""),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "frac_meaning": "compulsory bytes of map_reads_kernel (counted by the kernel on the timed reads: bytes_by_part) x bases per step / "
-                                "its own duration (HIP events around it in every timed step) / 8 TB/s",
+                "frac_meaning": "compulsory bytes of map_reads_kernel (counted by the kernel on the timed reads: bytes_by_part) x bases per step / " +
+                                ("the device's time per launch / 8 TB/s.  %d launches share the device at any time (one per pipeline), each for the "
+                                 "whole of its duration (kernel_ms: HIP events around every launch of the timed region, what rocprofv3 shows per "
+                                 "dispatch), so the device's time per launch is the timed region / launches = ms_per_step, second passes included "
+                                 "(never taken below kernel_ms / pipelines).  per_launch_duration prices the same bytes by kernel_ms as if the "
+                                 "launch had the device to itself; alone is the kernel with nothing beside it (one_batch_at_a_time)" % n_pipes
+                                 if shared else "its own duration (HIP events around it in every timed step) / 8 TB/s"),
+                "launches_sharing_the_device": n_pipes if shared else 1,
+                "device_ms_per_launch": round(k_s * 1e3, 4),
+                "per_launch_duration": {"achieved": round(b_map * bases / k_launch_s / 1e9, 1), "frac": round(b_map * bases / k_launch_s / 1e9 / HBM_PEAK_GBPS, 4)},
+                "alone": ({"kernel_ms": serial["map_reads_kernel_ms"], "achieved": round(b_map * bases / (serial["map_reads_kernel_ms"] * 1e-3) / 1e9, 1),
+                           "frac": round(b_map * bases / (serial["map_reads_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+                          if serial and serial.get("map_reads_kernel_ms") else None),
                 "algorithmic_bytes_per_base": round(b_map, 3), "bytes_by_part_first_slab": by, "units_per_launch": bases,
                 "kernel": "map_reads_kernel (kbo_amd/csrc/map_kernels.hip): MS -> derandomize -> translate -> relative_to_ref of every read it can finish",
                 "kernel_ms": round(map_kernel_ms, 4), "kernel_ms_per_rank": {"min": round(min(walk_all), 4), "max": round(max(walk_all), 4)},
@@ -1037,9 +1065,10 @@ def main(argv=None):
                            "note": "this rank's device copy: host layout of rank blocks / entries, uploads, path cover (0 when the index "
                                    "file carried it), recovery lines, seed table(s), depth table; index build or load is index_seconds_rank0"},
                        "resident_slabs_per_gpu": len(slabs), "index_seconds_rank0": round(t_index, 2),
-                       "batches_in_flight": ("2: consecutive steps take %s in turn; a batch's second pass runs on a second stream "
-                                             "(kbo_map_batch_dev_tail) beside the next batch's kernel; all of every step's work ends inside the timed region"
-                                             % ("two resident batches of this shape (different reads)" if n_sets == 2 else "the step's slabs")) if piped else 1,
+                       "batches_in_flight": ("%d on %d pipeline(s) of two streams: consecutive launches go to the pipelines in turn and take %s in turn; on a "
+                                             "pipeline a batch's second pass runs on the second stream (kbo_map_batch_dev_tail) beside the next "
+                                             "batch's kernel on the first; all of every step's work ends inside the timed region"
+                                             % (2 * n_pipes, n_pipes, ("%d resident batches of this shape (different reads)" % n_sets) if n_sets > 1 else "the step's slabs")) if piped else 1,
                        "parallelism": f"index replicated x{world}, reads sharded, no collective"},
             "roofline": roofline,
             "kernels_ms": ({"map_reads_kernel": round(map_kernel_ms, 4), "redo_pass": round(map_redo_ms, 4),

@@ -39,8 +39,12 @@ def _check_line(r, n_gpus, table=True, one_kernel=True):
         assert 0 < ro["kernel_ms"] <= r["kernels_ms"]["kbo_map_batch_dev"] * 1.05 and ro["redo_pass_ms"] > 0
         assert 2.0 < ro["algorithmic_bytes_per_base"] < 4.0 and ro["build_sha16"]
         assert ro["cross_check_whole_step_gbps"] <= ro["peak"]
-        if n_gpus == 1:  # two batches in flight; the same steps on one stream beside them
-            assert str(r["config"]["batches_in_flight"]).startswith("2") and r["one_batch_at_a_time"]["value"] > 0
+        if n_gpus == 1:  # four batches in flight on two pipelines; the same steps on one stream beside them
+            assert str(r["config"]["batches_in_flight"]).startswith("4 on 2 pipeline") and r["one_batch_at_a_time"]["value"] > 0
+            # two launches share the device: the bytes are priced by the device's time per launch, never less than half a launch's duration
+            assert ro["launches_sharing_the_device"] == 2 and ro["device_ms_per_launch"] >= ro["kernel_ms"] / 2 - 1e-4
+            assert ro["device_ms_per_launch"] >= r["ms_per_step"] - 1e-3
+            assert 0 < ro["per_launch_duration"]["frac"] <= 1.0 and 0 < ro["alone"]["frac"] <= 1.0 and ro["alone"]["kernel_ms"] > 0
         return
     assert ro["stage_model"]["ms_equal_to_gpu"] is True
     # the model's counts are the kernels' own (first slab)

@@ -34,12 +34,19 @@ def serial(steps):
         devs[i % NB].run(S)
 
 
+NS = int(os.environ.get("NS", "1"))  # kernel streams (NS = 2 with NB = 3: the next kernel starts while this one drains)
+Ss = [S] + [torch.cuda.Stream(device) for _ in range(NS - 1)]
+
+
 def piped(steps):
     for i in range(steps):
         b = i % NB
-        S.wait_event(done[b])  # the batch's buffers are free again once its last second pass is through
-        devs[b].run(S, tail_stream=Ts[i % NT])
+        s = Ss[i % NS]
+        s.wait_event(done[b])  # the batch's buffers are free again once its last second pass is through
+        devs[b].run(s, tail_stream=Ts[i % NT])
         done[b].record(Ts[i % NT])
+    for s in Ss[1:]:
+        S.wait_stream(s)
 
 
 def timed(fn, steps=40, warm=4):
