@@ -33,6 +33,11 @@ int kbo_set_guided_walk(int waves_per_cu, int recovery_lines);
  * (default 24 Mi; 0 = always, UINT64_MAX = never; applies to device copies made after the call), used by the walk from
  * matches at least min_depth deep (default 16; < 0 keeps it). */
 int kbo_set_pair_steps(uint64_t min_rows, int min_depth);
+/* Host batches (kbo_matches_batch / kbo_map_batch / kbo_find_batch and the packed forms): caller's buffers that are pinned
+ * already (hipHostMalloc / hipHostRegister) are used in place - no staging copies, no host threads busy - instead of being
+ * staged through the slots' own pinned buffers like pageable ones.  Default 0: staged is the faster of the two on the MI355X
+ * boxes this was measured on (600 Mbp: 34.9 against 27.7 Gbp/s, packed 123 against 104).  Environment: KBO_HOST_INPLACE. */
+int kbo_set_host_in_place(int on);
 /* tests: force the 64-bit-offset contraction-entry layout (device copies made after the call) */
 int kbo_set_force_big_layout(int on);
 /* tests: kbo_index_build makes at least this many shards whatever the size of its input (0 = by size: one index below

@@ -111,6 +111,7 @@ TUNING_SYMBOLS = [
     "kbo_set_pair_steps", "kbo_set_force_big_layout", "kbo_set_seed_table_depth", "kbo_set_plan", "kbo_set_plan_tuning",
     "kbo_set_plan_unit_cap_divisor", "kbo_index_plan_holdoff", "kbo_set_walk_experiment", "kbo_plan_stats_dev", "kbo_set_plan_stats", "kbo_set_index_shards", "kbo_index_shard", "kbo_set_depth_table", "kbo_set_depth_table_anchors", "kbo_index_depth_table", "kbo_run_automaton_depths",
     "kbo_set_stage_timing", "kbo_stage_timing_read", "kbo_set_plan_table_budget", "kbo_set_plan_lazy", "kbo_plan_flags_dev",
+    "kbo_set_host_in_place",
 ]
 
 _lib = None
@@ -188,6 +189,7 @@ def lib():
     L.kbo_set_walk_rare.argtypes = [C.c_int]
     L.kbo_set_slab_bytes.argtypes = [sz]
     L.kbo_set_force_big_layout.argtypes = [C.c_int]
+    L.kbo_set_host_in_place.argtypes = [C.c_int]
     L.kbo_set_host_threads.argtypes = [C.c_int]
     L.kbo_release_scratch.argtypes = []
     L.kbo_set_pair_steps.argtypes = [C.c_uint64, C.c_int]

@@ -135,6 +135,7 @@ std::vector<int> devices_for(kbo_index *idx);
 //   // devices the host batch entry points spread slabs over (empty = current)
 extern std::atomic<bool> g_force_big;             // tests: use the 64-bit-offset entry layout regardless of size
 extern std::atomic<uint64_t> g_pair_min_rows;     // indexes with at least this many rows get two-base blocks on the device
+extern std::atomic<int> g_host_in_place;         // host batches use a caller's pinned buffers in place instead of staging them (kbo_set_host_in_place)
 extern std::atomic<size_t> g_slab_bytes;          // host batches are cut into slabs of at most this many query bytes
 extern std::atomic<int> g_plan_cap_div;           // tests: the unit array gets 1/this of its normal capacity
 extern std::atomic<int> g_index_shards;           // tests: kbo_index_build makes at least this many shards (0 = by size)

@@ -302,6 +302,7 @@ void run_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *offset
 // (a) one launch stays below the 32-bit offset limits and (b) the H2D copy of slab i+1 and
 // the D2H copy of slab i-1 overlap the kernels of slab i (two streams, user buffers pinned
 // in place with hipHostRegister when that succeeds).
+std::atomic<int> g_host_in_place{std::getenv("KBO_HOST_INPLACE") ? std::atoi(std::getenv("KBO_HOST_INPLACE")) : 0};
 std::atomic<size_t> g_slab_bytes{16ull << 20}; // tools/bench_host.py, 600 Mbp of C2 reads through the one kernel: 16 / 24 / 32 / 64 MiB 39 / 36 / 32-39 / 31 Gbp/s (bytes), 121 / 89 / 104 Gbp/s (packed)
 
 
@@ -371,6 +372,10 @@ OffsetScan scan_offsets(const uint64_t *offsets, size_t n_seqs)
 
 bool is_pinned_host(const void *ptr) // memory the DMA engines can reach without staging
 {
+    // (off by default: on the MI355X boxes here the copies between a caller's large pinned buffers and the device run at 28 GB/s
+    // each way, those between the slots' small staging buffers and the device at 38 - the host team's copies included: 600 Mbp
+    // of pinned reads 27.7 in place against 34.9 Gbp/s staged, packed 104 against 123.  kbo_set_host_in_place(1) / KBO_HOST_INPLACE=1)
+    if (!g_host_in_place.load()) return false;
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
         (void)hipGetLastError();

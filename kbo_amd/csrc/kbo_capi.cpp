@@ -1851,6 +1851,12 @@ int kbo_set_force_big_layout(int on)
     return KBO_OK;
 }
 
+int kbo_set_host_in_place(int on)
+{
+    g_host_in_place = on != 0;
+    return KBO_OK;
+}
+
 int kbo_set_slab_bytes(size_t bytes)
 {
     g_slab_bytes = std::max<size_t>(1u << 16, std::min<size_t>(bytes, 0xF0000000ull));

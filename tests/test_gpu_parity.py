@@ -641,18 +641,22 @@ def test_host_batches_concurrent_callers_and_pinned_buffers(oracle):
                 t.join()
             for i, (concat, offsets, exp) in enumerate(work):
                 assert np.array_equal(got[i], exp), f"thread {i} rep {rep}"
-        # pinned input and output (torch pinned tensors viewed as numpy): no staging copies
+        # pinned input and output (torch pinned tensors viewed as numpy): staged like pageable ones by default, used in place
+        # - no staging copies - with kbo_set_host_in_place(1)
         concat, offsets, exp = work[0]
         pin_in = torch.empty(len(concat), dtype=torch.uint8).pin_memory()
         pin_in.numpy()[:] = concat
-        pin_out = torch.zeros(len(concat), dtype=torch.uint8).pin_memory()
-        kbo_amd.check(kbo_amd.lib().kbo_matches_batch(sbwt._h, pin_in.data_ptr(), offsets.ctypes.data, len(offsets) - 1,
-                                                      1e-7, pin_out.data_ptr()))
-        assert np.array_equal(pin_out.numpy(), exp)
+        for in_place in (0, 1):
+            pin_out = torch.zeros(len(concat), dtype=torch.uint8).pin_memory()
+            kbo_amd.lib().kbo_set_host_in_place(in_place)
+            kbo_amd.check(kbo_amd.lib().kbo_matches_batch(sbwt._h, pin_in.data_ptr(), offsets.ctypes.data, len(offsets) - 1,
+                                                          1e-7, pin_out.data_ptr()))
+            assert np.array_equal(pin_out.numpy(), exp)
         kbo_amd.check(kbo_amd.lib().kbo_release_scratch())
         assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp)
     finally:
-        kbo_amd.lib().kbo_set_slab_bytes(32 << 20)
+        kbo_amd.lib().kbo_set_slab_bytes(16 << 20)
+        kbo_amd.lib().kbo_set_host_in_place(0)
 
 
 def test_two_base_steps_parity(oracle):

@@ -18,12 +18,29 @@ sbwt.to_device()
 concat, offsets = synth.reads(g, R, 150, 0.01)
 out = np.zeros(len(concat), dtype=np.uint8)  # allocated and touched once, outside the timed region
 L = kbo_amd.lib()
+PINNED = bool(os.environ.get("PINNED"))  # the caller's buffers in pinned memory (hipHostMalloc): used in place, no staging copies
+
+
+def pinned_like(a):
+    import torch
+    t = torch.empty(a.shape, dtype=getattr(torch, str(a.dtype)), pin_memory=True)
+    v = t.numpy()
+    v[...] = a
+    _KEEP.append(t)
+    return v
+
+
+_KEEP = []
+if PINNED:
+    concat, out = pinned_like(concat), pinned_like(out)
 if os.environ.get("PACKED"):  # 2-bit words in, 2-bit words / run lengths out (kbo_matches_batch_packed, kbo_find_batch_packed)
     import ctypes as C
     from kbo_amd import _capi
     from oracle import binding as ora
     words, pos, byt = batch.pack_reads(concat, offsets)
     wout = np.zeros(len(words), dtype=np.uint32)
+    if PINNED:
+        words, wout = pinned_like(words), pinned_like(wout)
     for slab_mb in [int(x) for x in os.environ.get('SLABS', '32,64,128').split(',')]:
         L.kbo_set_slab_bytes(slab_mb << 20)
         best = 1e9
