@@ -731,13 +731,15 @@ def main(argv=None):
     n_pipes = max(1, args.pipelines) if piped else 1
     pipes = [(stream if p == 0 else torch.cuda.Stream(device), torch.cuda.Stream(device)) for p in range(n_pipes)] if piped else None
     n_slabs = (n_mine + SLAB_READS - 1) // SLAB_READS
+    # (slabs of equal size: the pipelines take the slabs in turn, and with 8 M + 2 M reads - C3 - one of them had four fifths of the work)
+    slab_reads = max(1, (n_mine + max(1, n_slabs) - 1) // max(1, n_slabs))
     # (several slabs per step are several batches already; fewer than two per pipeline: a second set of them)
     n_sets = (2 * n_pipes if n_slabs == 1 else 2 if n_slabs < 2 * n_pipes else 1) if piped else 1
     sets, first_slab = [], []
     for b in range(n_sets):
         slabs = []
-        for s0 in range(0, n_mine, SLAB_READS):
-            ns = min(SLAB_READS, n_mine - s0)
+        for s0 in range(0, n_mine, slab_reads):
+            ns = min(slab_reads, n_mine - s0)
             # (the second set: the reads behind every rank's first set)
             concat, offsets = synth.reads(genome, ns, args.read_len, args.sub_rate, first_read=first + s0 + b * max(world, 1) * args.reads)
             slabs.append(batch.DeviceBatch(sbwt, concat, offsets, device=device, format=not args.find, want_ms=False))
