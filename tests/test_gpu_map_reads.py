@@ -197,6 +197,46 @@ def test_c2_shape_the_one_kernel_every_read(oracle):
     _check(oracle, ora, sbwt, concat, offsets)
 
 
+def test_how_many_reads_the_kernel_leaves_to_the_second_pass():
+    """C2's index (5 Mbp, k = 31): the share of the reads map_reads_kernel flags for the plain walk (kbo_plan_flags_dev) - reads
+    with 1 % substitutions (0.37 %; a window that starts at a mismatch and is in the index is settled by the next
+    window's entry), and reads with one insertion / deletion of 1 - 3 bases anywhere on top (1.1 %, flat over its position: the
+    second diagonal found beside the first).  Loose bounds: what they guard is the mechanism, not the last tenth of a per cent."""
+    import torch
+    g = synth.genome(5_000_000)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=threads()))
+    dev0 = torch.device("cuda:0")
+    N, LEN = 100_000, 150
+    concat, offsets = synth.reads(g, N, LEN, 0.01)
+    dev = batch.DeviceBatch(sbwt, concat, offsets, device=dev0, format=False, want_ms=False)
+    dev.run()
+    torch.cuda.synchronize()
+    assert dev.fused
+    share = float((dev.plan_flags() != 0).mean())
+    assert share < 0.008, share
+    rng = np.random.default_rng(3)
+    start = rng.integers(8, len(g) - LEN - 8, N)
+    pos = rng.integers(1, LEN - 1, N)
+    size = rng.integers(1, 4, N)
+    ins = rng.random(N) < 0.5
+    i = np.arange(LEN)[None, :]
+    shift = np.where(i >= pos[:, None], np.where(ins[:, None], -np.minimum(size[:, None], i - pos[:, None]), size[:, None]), 0)
+    reads = g[start[:, None] + i + shift]
+    new = ins[:, None] & (i >= pos[:, None]) & (i < (pos + size)[:, None])
+    reads = np.where(new, ACGT[rng.integers(0, 4, (N, LEN))], reads)
+    hit = rng.random((N, LEN)) < 0.01
+    reads = np.where(hit, ACGT[(np.searchsorted(ACGT, reads) + rng.integers(1, 4, (N, LEN))) % 4], reads)
+    concat = np.ascontiguousarray(reads.reshape(-1))
+    dev = batch.DeviceBatch(sbwt, concat, offsets, device=dev0, format=False, want_ms=False)
+    dev.run()
+    torch.cuda.synchronize()
+    fl = dev.plan_flags() != 0
+    assert dev.fused and float(fl.mean()) < 0.03, float(fl.mean())
+    for lo, hi in ((10, 30), (120, 140)):  # (breaks near either end were 12 - 25 % before the search beside the diagonal)
+        sel = (pos >= lo) & (pos < hi)
+        assert float(fl[sel].mean()) < 0.06, (lo, hi, float(fl[sel].mean()))
+
+
 def test_routes_that_are_not_the_one_kernel(oracle):
     """reads longer than 160 bases, a copy without a depth table, a held-off copy: kbo_map_batch_dev takes the two kernels"""
     L = kbo_amd.lib()
