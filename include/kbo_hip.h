@@ -376,12 +376,13 @@ int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, siz
 int kbo_map_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
                       size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
                       void *d_work, size_t work_bytes, void *stream, int *fused);
-/* The same with the second pass - the plain walk over the few reads the one kernel leaves to it (2 % at 1 % substitutions), a chain of
- * dependent look-ups that takes 0.15 ms however few they are - enqueued on `tail_stream`, ordered behind the kernel on `stream` by an
+/* The same with the second pass - the plain walk over the few reads the one kernel leaves to it (0.4 % at 1 % substitutions), a chain of
+ * dependent look-ups that takes 0.13 ms however few they are - enqueued on `tail_stream`, ordered behind the kernel on `stream` by an
  * event: a caller with several batches in flight (own d_ms / d_chars_out / d_work each) keeps `stream` busy with the next batch's
  * kernel meanwhile.  The batch's outputs are complete when BOTH streams have reached this point; whatever touches this batch's
  * buffers next - on either stream - has to be ordered behind `tail_stream`.  tail_stream == stream: kbo_map_batch_dev.  The two-kernel
- * route (*fused = 0) runs on `stream` alone. */
+ * route (*fused = 0) runs on `stream` alone.  Two such pairs of streams that take the batches in turn, two batches in flight on
+ * each, keep the device fuller still (INTEGRATION.md "Several batches in flight"; bench.py: 747 against 587 Gbp/s at C2). */
 int kbo_map_batch_dev_tail(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
                            size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
                            void *d_work, size_t work_bytes, void *stream, void *tail_stream, int *fused);
