@@ -42,7 +42,8 @@ def piped(steps):
     for i in range(steps):
         b = i % NB
         s = Ss[i % NS]
-        s.wait_event(done[b])  # the batch's buffers are free again once its last second pass is through
+        if not os.environ.get("NOWAIT"):  # (NOWAIT=1, measurement only: what the cross-stream wait in front of every kernel costs)
+            s.wait_event(done[b])  # the batch's buffers are free again once its last second pass is through
         devs[b].run(s, tail_stream=Ts[i % NT])
         done[b].record(Ts[i % NT])
     for s in Ss[1:]:
