@@ -1,0 +1,52 @@
+"""A brute-force model (CPU, no library) of the rule map_reads_kernel uses for the window of `order` bases that STARTS at a mismatch m
+and is in the index (kbo_amd/csrc/map_kernels.hip, the proof's loop): when the read's base in front of the window does not extend
+it (the entry's left-extension bit) and the read's base at m does not extend the window one base further on (that window's entry,
+or that window is absent), no string of the read that runs through m and ends at or behind the window's last base is in the index
+with more than `order` bases.  The same for a read without a seed, where every window is judged like that.  Checked against all
+substrings of a random text with many chance repeats.  Semantics of the values it protects: /root/reference/src/derandomize.rs:221-288
+(values above the threshold are what the closed form must not miss)."""
+import numpy as np
+
+
+def _substrings(text, max_len):
+    s = set()
+    for L in range(1, max_len + 1):
+        for a in range(len(text) - L + 1):
+            s.add(text[a:a + L])
+    return s
+
+
+def test_window_that_starts_at_a_mismatch():
+    rng = np.random.default_rng(11)
+    order, max_len = 4, 9
+    accepted = refused = 0
+    for trial in range(30):
+        text = "".join(rng.choice(list("ACGT"), 260, p=[0.4, 0.3, 0.2, 0.1]))  # skewed: windows of 4 bases repeat by chance
+        index = _substrings(text, max_len)
+        for _ in range(300):
+            L = int(rng.integers(order + 3, 30))
+            a = int(rng.integers(0, len(text) - L))
+            read = list(text[a:a + L])
+            m = int(rng.integers(1, L - order))           # the mismatch; the window [m, e] lies inside the read
+            read[m] = rng.choice([c for c in "ACGT" if c != read[m]])
+            read = "".join(read)
+            e = m + order - 1
+            window = read[m:e + 1]
+            if window not in index:
+                continue                                   # (an absent window: the ordinary case, nothing to model)
+            deeper = read[m - 1] + window in index         # entry of the window: its left-extension bit for the read's base
+            nxt = read[m + 1:e + 2] if e + 1 < L else None  # the window one base on, if the read has that base
+            extends = nxt is not None and nxt in index and (read[m] + nxt) in index  # its entry: present, and extended by read[m]
+            ok = (not deeper) and not extends
+            # brute force: the longest string through m that ends at or behind e and is in the index
+            longest = 0
+            for x in range(0, m + 1):
+                for y in range(e, L):
+                    if y - x + 1 <= max_len and read[x:y + 1] in index:
+                        longest = max(longest, y - x + 1)
+            if ok:
+                accepted += 1
+                assert longest <= order, (text, read, m, longest)
+            else:
+                refused += 1
+    assert accepted > 200 and refused > 50  # (both branches were really exercised)
