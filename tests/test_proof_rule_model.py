@@ -50,3 +50,43 @@ def test_window_that_starts_at_a_mismatch():
             else:
                 refused += 1
     assert accepted > 200 and refused > 50  # (both branches were really exercised)
+
+
+def test_read_without_a_seed_every_window_judged_that_way():
+    """a read that seeds nowhere: windows of `order` bases ending at order - 1, + cov, .. and at the read's last base, cov = t - order + 2
+    (any string of t + 1 bases holds one of them whole).  Every window absent, or present but neither extended to the left by the
+    base in front of it nor - one base on - by its own first base: no string of t + 1 bases of the read is in the index."""
+    rng = np.random.default_rng(12)
+    order, t = 4, 6
+    cov = t - order + 2
+    passed = flagged = with_present = 0
+    for trial in range(30):
+        text = "".join(rng.choice(list("ACGT"), 200, p=[0.4, 0.3, 0.2, 0.1]))
+        index = _substrings(text, t + 2)
+        for _ in range(400):
+            L = int(rng.integers(t + 1, 24))
+            read = "".join(rng.choice(list("ACGT"), L, p=[0.1, 0.2, 0.3, 0.4]))  # (the other end of the alphabet: few windows present)
+            ends = sorted({min(order - 1 + u * cov, L - 1) for u in range((L - order + cov - 1) // cov + 1)})
+            fail = any_present = False
+            for e in ends:
+                s = e - order + 1
+                w = read[s:e + 1]
+                if w not in index:
+                    continue
+                any_present = True
+                if s == 0:
+                    fail = True      # (no base in front of it: the kernel leaves such a read to the plain walk)
+                    continue
+                deeper = read[s - 1] + w in index
+                nxt = read[s + 1:e + 2] if e + 1 < L else None
+                extends = nxt is not None and nxt in index and (read[s] + nxt) in index
+                if deeper or extends:
+                    fail = True
+            if fail:
+                flagged += 1
+                continue
+            passed += 1
+            with_present += any_present
+            for a in range(0, L - t):
+                assert read[a:a + t + 1] not in index, (text, read, a)
+    assert passed > 500 and flagged > 100 and with_present > 50
