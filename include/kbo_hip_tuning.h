@@ -129,6 +129,13 @@ int kbo_plan_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, 
  * item per sequence) left to the plain walk - flags_out[s] != 0 - read out of the launch's work buffer.  Arguments as for that call;
  * synchronises `stream`. */
 int kbo_plan_flags_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k, const void *d_work, uint8_t *flags_out, void *stream);
+/* inspection: what the last kbo_map_batch_dev / kbo_find_batch_dev call over sequences of more than 160 bases did when it took
+ * the one kernel for sequences of any length (long_kernels.hip); arguments as for that call, synchronises `stream`.
+ * out[0]: pieces, [1]: pieces whose proof failed (plain walk + literal recurrences), [2]: their sub-items, [3]: seed look-ups,
+ * [4]: filter look-ups, [5]: depth-table look-ups, [6]: of those, second look-ups behind a window that was present. */
+#define KBO_LONG_STATS 8
+int kbo_long_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k, const void *d_work, uint64_t out[KBO_LONG_STATS],
+                       void *stream);
 
 /* instrumentation (default off): while on, every kbo_map_batch_dev call that takes the one-kernel route records HIP events on its
  * stream around map_reads_kernel and behind the redo pass (three event records per call).  kbo_stage_timing_read waits for the

@@ -260,6 +260,14 @@ class DeviceBatch:
         check(lib().kbo_plan_flags_dev(self.n_seqs, self.total, self.max_len, self.k, self.work.data_ptr(), out.ctypes.data, s.cuda_stream))
         return out
 
+    def long_stats(self, stream=None):
+        """What the last run() / run_find() did when it took the kernel for sequences of any length (kbo_hip_tuning.h kbo_long_stats_dev)."""
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        out = np.zeros(8, dtype=np.uint64)
+        check(lib().kbo_long_stats_dev(self.n_seqs, self.total, self.max_len, self.k, self.work.data_ptr(), out.ctypes.data, s.cuda_stream))
+        names = ("pieces", "flagged", "sub_items", "seed_lookups", "filter_lookups", "table_lookups", "second_lookups")
+        return {n: int(v) for n, v in zip(names, out)}
+
     def derand_translate(self, stream=None):
         s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
         if self.max_len == 0 or self.max_len > 480:  # long reads / contigs: scratch for the piece-wise kernel
@@ -316,8 +324,9 @@ class DeviceBatch:
 
     def run(self, stream=None, tail_stream=None):
         """kbo::map (format) / kbo::matches over the batch: kbo_map_batch_dev - one kernel for reads over an index copy with a
-        depth table (self.ms then holds every MS value only when want_ms), else walk() + derand_translate()."""
-        if self.lo is not None or self.max_len == 0 or self.max_len > 480:
+        depth table (self.ms then holds every MS value only when want_ms), one wave per piece for longer sequences when the MS
+        values are not asked for (long_kernels.hip), else the walk + the derandomize / translate kernels."""
+        if self.lo is not None:
             self.walk(stream)
             self.derand_translate(stream)
             self.fused = False

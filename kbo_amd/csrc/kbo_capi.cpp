@@ -1025,6 +1025,8 @@ struct DevWork {
     bool chunked;
     uint32_t chunk, n_slots;
     size_t bytes, plan_off;
+    size_t long_off, long_bytes;     // batches with sequences of more than 160 bases: work of map_long_kernel (long_kernels.hip) ...
+    size_t derand_off, derand_bytes; // ... and of the piece-wise derandomize + translate kernel behind the walk when it does not apply
 };
 DevWork dev_work(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k)
 {
@@ -1038,6 +1040,15 @@ DevWork dev_work(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32
     w.bytes = (w.bytes + 15) / 16 * 16;
     w.plan_off = w.bytes; // work of the plan-guided walk behind it
     w.bytes += kbo::plan_work_bytes(std::max<uint64_t>(1, slots), total_bases);
+    w.bytes = (w.bytes + 63) / 64 * 64;
+    w.long_off = w.derand_off = w.bytes;
+    w.long_bytes = w.derand_bytes = 0;
+    if (max_seq_len == 0 || max_seq_len > 160) {
+        w.long_bytes = (kbo::long_work_bytes(n_seqs, total_bases, k) + 63) / 64 * 64;
+        w.derand_bytes = (kbo::derand_piece_work_bytes((uint32_t)std::min<size_t>(n_seqs, 0xFFFFFFFEu), total_bases) + 63) / 64 * 64;
+        w.derand_off = w.long_off + w.long_bytes;
+        w.bytes += w.long_bytes + w.derand_bytes;
+    }
     return w;
 }
 } // namespace
@@ -1057,7 +1068,8 @@ size_t kbo_index_work_bytes(const kbo_index_t *idx, size_t n_seqs, uint64_t tota
 namespace {
 int ms_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs,
                       uint64_t total_bases, size_t max_seq_len, uint8_t *d_ms_out, uint32_t *d_lo_out,
-                      uint32_t *d_hi_out, void *d_work, size_t work_bytes, void *stream, const CallSink *call)
+                      uint32_t *d_hi_out, void *d_work, size_t work_bytes, void *stream, const CallSink *call,
+                      bool count_bases = true /* false: the caller's own device_view() has counted this batch for the copy's lazy plan structures */)
 {
     return guarded([&] {
         KBO_REQUIRE(idx && d_concat && d_offsets && d_ms_out && d_work, KBO_E_BAD_ARG, "null argument");
@@ -1091,7 +1103,7 @@ int ms_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
         uint8_t *ms_shard = static_cast<uint8_t *>(d_work) + w.bytes; // (16-byte aligned: w.bytes is a multiple of 16)
         for (size_t sh = 0; sh < shards.size(); sh++) {
             DevCopy::PlanState *plan_state = nullptr;
-            const kbo::DevIndexView view = device_view(shards[sh], current_device(), &plan_state, total_bases);
+            const kbo::DevIndexView view = device_view(shards[sh], current_device(), &plan_state, count_bases ? total_bases : 0);
             kbo::WalkArgs a{};
             a.ix = view;
             a.q = d_concat;
@@ -1179,6 +1191,28 @@ int kbo_plan_flags_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, 
         hipStream_t s = static_cast<hipStream_t>(stream);
         HIP_OK(hipMemcpyAsync(flags_out, static_cast<const uint8_t *>(d_work) + w.plan_off + L.redo, n_seqs, hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
+    });
+}
+
+int kbo_long_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k, const void *d_work, uint64_t out[KBO_LONG_STATS],
+                       void *stream)
+{
+    return guarded([&] {
+        KBO_REQUIRE(d_work && out && n_seqs > 0 && total_bases > 0, KBO_E_BAD_ARG, "null / empty argument");
+        const DevWork w = dev_work(n_seqs, total_bases, max_seq_len, k);
+        KBO_REQUIRE(w.long_bytes != 0, KBO_E_UNSUPPORTED, "not a batch of long sequences");
+        uint32_t ctl[8], st[kbo::kPlanStatSlots * kbo::kPlanStatWords];
+        HIP_OK(kbo::long_read_stats(static_cast<const uint8_t *>(d_work) + w.long_off, n_seqs, total_bases, k, ctl, st, static_cast<hipStream_t>(stream)));
+        for (uint32_t i = 0; i < KBO_LONG_STATS; i++) out[i] = 0;
+        out[0] = ctl[0];
+        out[1] = ctl[4];
+        out[2] = ctl[1];
+        for (uint32_t sl = 0; sl < kbo::kPlanStatSlots; sl++) {
+            out[3] += st[sl * kbo::kPlanStatWords + kbo::kPlanStatSeedLookups];
+            out[4] += st[sl * kbo::kPlanStatWords + kbo::kPlanStatSeedExtensions];
+            out[5] += st[sl * kbo::kPlanStatWords + kbo::kPlanStatTabLookups];
+            out[6] += st[sl * kbo::kPlanStatWords + kbo::kPlanStatTabAnchored];
+        }
     });
 }
 
@@ -1286,7 +1320,7 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
                        const FindTail *find = nullptr)
 {
     if (fused) *fused = 0;
-    bool done = false;
+    bool done = false, counted = false; // (counted: device_view() has seen this batch's bases for the copy's lazy plan structures)
     size_t threshold = 0;
     int rc = guarded([&] {
         KBO_REQUIRE(idx && d_concat && d_offsets && d_ms && d_chars_out && d_work, KBO_E_BAD_ARG, "null argument");
@@ -1296,17 +1330,45 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
         KBO_REQUIRE(((uintptr_t)d_concat & 15) == 0 && ((uintptr_t)d_ms & 3) == 0 && ((uintptr_t)d_chars_out & 3) == 0 &&
                         ((uintptr_t)d_work & 15) == 0,
                     KBO_E_BAD_ARG, "d_concat/d_work must be 16-byte, d_ms/d_chars_out 4-byte aligned");
-        KBO_REQUIRE(max_seq_len > 0 && max_seq_len <= 480, KBO_E_UNSUPPORTED,
-                    "kbo_map_batch_dev takes batches of reads (max_seq_len 1 .. 480); longer sequences: kbo_ms_batch_dev + kbo_derand_translate_dev");
         threshold = random_match_threshold(idx->host.k, idx->host.n_kmers, 4, max_error_prob);
         KBO_REQUIRE(threshold > 1, KBO_E_THRESHOLD_LE_1, "threshold > 1 (derandomize.rs:275)");
-        if (idx->sharded() || max_seq_len > 160) return; // (two kernels, below)
+        if (idx->sharded()) return; // (two kernels, below)
         hipStream_t s = static_cast<hipStream_t>(stream);
         const DevWork w = dev_work(n_seqs, total_bases, max_seq_len, idx->host.k);
-        if (w.chunked) return;
         KBO_REQUIRE(work_bytes >= w.bytes, KBO_E_BAD_ARG, "d_work is smaller than kbo_work_bytes() for this batch");
         DevCopy::PlanState *plan_state = nullptr;
+        if (max_seq_len == 0 || max_seq_len > 160) {
+            // sequences of any length: one wave per piece of a sequence (long_kernels.hip), the pieces whose proof fails by the
+            // plain walk + the literal recurrences behind it (on the tail stream when the caller gave one)
+            if (want_ms || !w.long_bytes) return;
+            const kbo::DevIndexView view = device_view(idx, current_device(), &plan_state, total_bases);
+            counted = true;
+            if (!kbo::map_long_applies(view, (uint32_t)threshold)) return;
+            kbo::LongArgs la{};
+            HIP_OK(kbo::launch_map_long(view, d_concat, d_offsets, (uint32_t)n_seqs, total_bases, (uint32_t)threshold, format != 0, d_chars_out,
+                                        static_cast<uint8_t *>(d_work) + w.long_off, s, la));
+            hipStream_t ts = s;
+            if (split && static_cast<hipStream_t>(tail_stream) != s) {
+                ts = static_cast<hipStream_t>(tail_stream);
+                hipEvent_t fence = tail_fence();
+                HIP_OK(hipEventRecord(fence, s));
+                HIP_OK(hipStreamWaitEvent(ts, fence, 0));
+            }
+            HIP_OK(kbo::launch_map_long_redo(la, d_ms, ts));
+            if (find) {
+                uint32_t *rle_scratch = static_cast<uint32_t *>(find->d_rle_work);
+                uint32_t *total = rle_scratch + kbo::chunk_items_scratch_words((uint32_t)n_seqs);
+                const uint32_t gap = (uint32_t)std::min<size_t>(find->max_gap_len, 0xFFFFFFFFu), cap = (uint32_t)std::min<size_t>(find->capacity, 0xFFFFFFFFu);
+                const uint32_t longest = (uint32_t)std::min<size_t>(max_seq_len, 0xFFFFFFFFu);
+                HIP_OK(kbo::launch_rle_count(d_chars_out, d_offsets, (uint32_t)n_seqs, gap, rle_scratch, total, ts, longest));
+                if (cap) HIP_OK(kbo::launch_rle_emit(d_chars_out, d_offsets, (uint32_t)n_seqs, gap, rle_scratch, find->d_records, cap, ts, longest));
+            }
+            done = true;
+            return;
+        }
+        if (w.chunked) return;
         const kbo::DevIndexView view = device_view(idx, current_device(), &plan_state, total_bases);
+        counted = true;
         kbo::WalkItem *items = static_cast<kbo::WalkItem *>(d_work);
         kbo::WalkArgs a{};
         a.ix = view;
@@ -1375,10 +1437,11 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
         if (fused && done) *fused = 1;
         return rc;
     }
-    rc = ms_batch_dev_impl(idx, d_concat, d_offsets, n_seqs, total_bases, max_seq_len, d_ms, nullptr, nullptr, d_work, work_bytes, stream, nullptr);
+    rc = ms_batch_dev_impl(idx, d_concat, d_offsets, n_seqs, total_bases, max_seq_len, d_ms, nullptr, nullptr, d_work, work_bytes, stream, nullptr, !counted);
     if (rc != KBO_OK) return rc;
+    const DevWork w = dev_work(n_seqs, total_bases, max_seq_len, idx->host.k);
     rc = kbo_derand_translate_dev(d_ms, d_offsets, n_seqs, total_bases, idx->host.k, threshold, format ? d_concat : nullptr, d_chars_out,
-                                  max_seq_len, nullptr, 0, stream);
+                                  max_seq_len, w.derand_bytes ? static_cast<uint8_t *>(d_work) + w.derand_off : nullptr, w.derand_bytes, stream);
     if (rc != KBO_OK || !find) return rc;
     return kbo_run_lengths_dev(d_chars_out, d_offsets, n_seqs, max_seq_len, find->max_gap_len, find->d_rle_work, find->d_records, find->capacity, stream);
 }

@@ -348,6 +348,36 @@ hipError_t launch_pack2(const uint8_t *d_chars, uint32_t n_words, const uint64_t
 // sharded index folded into the batch's (pack_kernels.hip)
 hipError_t launch_max_bytes(uint8_t *d_a, const uint8_t *d_b, uint64_t n, hipStream_t stream);
 
+// ---- kbo::map / matches for sequences of any length in one launch (long_kernels.hip): one wave per PIECE of a sequence - `own`
+// bases inside a region of at most kLongRegion bases (k bases of the sequence in front of them, k + 1 behind)
+constexpr uint32_t kLongRegion = 1008; // (+ up to 15 bases of alignment: 64 words of 16 positions)
+constexpr uint32_t kLongOwnMin = 256;  // own bases a piece must have for the kernel to apply (k <= 375)
+struct LongArgs {
+    DevIndexView ix;
+    const uint8_t *q;     // concatenated queries (ASCII), 16-byte aligned
+    uint64_t q_bytes;
+    const void *items;    // per piece { first byte of its region, that byte's place in its sequence, the sequence's length, own0 | own_n << 10 }
+    uint32_t n_items;     // slots (those past the batch's last piece are empty)
+    uint8_t *chars_out;
+    uint8_t *redo;        // per piece: 1 = its proof failed (the plain walk + the literal recurrences decide: launch_map_long_redo)
+    uint8_t *xin;         // per piece: the derandomised value of its first own base, 0 .. k (<= 0 as 0)
+    uint32_t *qctl;       // [0] pieces, [1] sub-items of the flagged pieces, [4] flagged pieces
+    uint32_t *pstats;     // work counters (kPlanStat*)
+    uint32_t thr, fmt, ca; // derandomisation threshold, 1 = format::relative_to_ref on the way out, bases of a region behind the own ones
+    void *subs;           // WalkItem records of the flagged pieces' sub-items
+    uint32_t sub_cap;
+};
+size_t long_work_bytes(size_t n_seqs, uint64_t total_bases, uint32_t k); // bytes of work memory of a launch (0: k too large)
+// true when the copy has what the kernel needs (depth table of fewer bases than the threshold, 2-bit text, seed positions)
+bool map_long_applies(const DevIndexView &ix, uint32_t thr);
+hipError_t launch_map_long(const DevIndexView &ix, const uint8_t *d_q, const uint64_t *d_off, uint32_t n_seqs, uint64_t total_bases, uint32_t thr,
+                           bool fmt, uint8_t *d_chars, void *d_work, hipStream_t stream, LongArgs &a);
+hipError_t launch_map_long_redo(const LongArgs &a, uint8_t *d_ms, hipStream_t stream);
+// the control words (8) and work counters of the last launch over d_work; synchronises the stream
+hipError_t long_read_stats(const void *d_work, size_t n_seqs, uint64_t total_bases, uint32_t k, uint32_t ctl[8], uint32_t *stats, hipStream_t stream);
+// the plain walk over a list of items whose number is counted on the device (walk_kernels.hip): `lanes` lanes share them
+hipError_t launch_walk_list(WalkArgs a, const WalkItem *d_list, uint32_t cap, const uint32_t *d_count, uint32_t lanes, hipStream_t stream);
+
 constexpr int kWalkThreads = 64; // default workgroup size (waves are independent: no LDS, no barriers)
 void set_walk_threads(int threads); // tuning: 64, 128 or 256
 void set_walk_experiment(int lane_limit, int dummy_lds_bytes); // experiments behind DESIGN.md section 6

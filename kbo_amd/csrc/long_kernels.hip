@@ -1,0 +1,794 @@
+// long_kernels.hip — gfx950 (MI355X, CDNA4): kbo::map / kbo::matches for sequences of ANY length in one launch.
+//
+// The chain the reference runs per sequence (lib.rs:735-738 for map, lib.rs:624-627 for matches / find):
+//     index::query_sbwt (index.rs:243-256)  ->  derandomize_ms_vec (derandomize.rs:269-288)  ->  translate_ms_vec
+//     (translate.rs:263-293)  [-> format::relative_to_ref (format.rs:266-287)]
+// for contigs, whole reference sequences (kbo::map streams one through the query's index: lib.rs:720-761) and long reads.
+// map_kernels.hip does this for reads of up to 160 bases, one LANE per read; here ONE WAVE takes a PIECE of a sequence: `own`
+// bases [s, s + n) inside a region [s - k, s + n + k + 1) of at most 1008 bases, lane w holding the 16 positions of word w.
+//
+//   map_long_kernel  0. the region is loaded once (16 B per lane), turned into 2-bit digits, kept in LDS;
+//                    1. STRETCHES: intervals of the region that equal a path of the index's text on one diagonal.  A seed
+//                       (DevIndexView::seed_pos, or the anchors of the depth table) gives a diagonal; the 2-bit text around it
+//                       (pc_tm) is staged in LDS once and the whole region compared with it in one step (a word per lane).
+//                       Where 6 of 16 bases mismatch the diagonal is lost: the 64 lanes try the 64 diagonals beside it (an
+//                       insertion or deletion of up to 32 bases) on the 32 bases behind the loss - the diagonal on which the read
+//                       goes on soonest wins - and only then the seed table again.  Consecutive diagonals alternate between two
+//                       BIT PLANES (1 = the base lies in a stretch of that plane), so that two stretches may overlap (an
+//                       insertion inside a run of equal bases lies on both diagonals);
+//                    2. everything else is a function of the two planes, word-parallel (tools/model/long_form.py has the
+//                       derivation and checks it against the oracle):
+//                         cov(i)  i lies in a stretch of more than t bases          G(i)  ... at depth > t
+//                         chars   'M' where cov; else 'X' if cov(i + 1) and (i <= 1 or cov(i - 1)) else '-';
+//                                 'R','R' at i, i + 1 where G(i), not G(i + 1), cov(i + 1)     (translate.rs:195-203, :282-288)
+//                         U(e)    the window of `order` bases that ends at e lies in no single stretch;
+//                    3. PROOF from the depth table (dtab_kernels.hip): the characters above are derandomize_ms_vec + translate_ms_vec
+//                       of the true matching statistics provided that no string of t + 1 bases that lies in no single stretch is in
+//                       the index.  Per maximal run of U: its first end, every c-th from there (c = t - order: a window may then
+//                       be present as long as nothing deeper than order + 1 ends there), and its last end, are looked up - behind
+//                       the filter where the copy has one; a window that is present AND extended to the left by the read's base
+//                       needs the window one base back not to be both; the run's last window - it starts at the last base in
+//                       front of the next stretch - needs the window one base on not to be extended by that base.  The wave's
+//                       look-ups are dealt to its lanes; a piece whose proof fails is FLAGGED;
+//                    4. the characters of the own bases leave in whole lines; x at the piece's first own base goes to xin[]
+//                       (what the piece to the left needs should it be flagged).
+//   flagged pieces   long_redo_items_kernel lists them in sub-items of 32 bases for the plain walk (walk_kernels.hip), which gives
+//                    their matching statistics; long_derand_kernel runs the literal recurrences over them right to left, from
+//                    xin[] of the piece to the right (runs of flagged pieces in one go).
+//
+// Integer / bit work only: no MFMA.  Four independent waves per workgroup, 2 KB of LDS each.
+#include "device_util.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace kbo {
+namespace {
+
+constexpr uint32_t kLongTextUnits = 76; // staged units of 16 text positions: 64 in front of the region's diagonal, 1024, 128 behind
+constexpr uint32_t kLongListCap = 384;  // look-ups a piece may ask for (more: flagged)
+constexpr uint32_t kLongTH = 6;         // mismatches in 16 bases that end a diagonal
+constexpr uint32_t kLongRun = 10;       // matching bases that start one
+constexpr uint32_t kLongLds = 2048;     // bytes of LDS per wave
+
+__device__ __forceinline__ uint32_t funnel2(uint32_t hi, uint32_t lo, uint32_t r) // 16 digits from digit r of hi on
+{
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (32u - 2u * r));
+}
+// mismatch bits on the digit grid (bit 2 (15 - j) for base j) -> bit j for base j
+__device__ __forceinline__ uint32_t grid_to_mask16(uint32_t m)
+{
+    m &= 0x55555555u;
+    m = (m | (m >> 1)) & 0x33333333u;
+    m = (m | (m >> 2)) & 0x0F0F0F0Fu;
+    m = (m | (m >> 4)) & 0x00FF00FFu;
+    m = (m | (m >> 8)) & 0x0000FFFFu;
+    return __builtin_bitreverse32(m) >> 16;
+}
+// bits t of a word at grid position xa with lo <= xa + t < hi
+__device__ __forceinline__ uint32_t range16(int32_t xa, int32_t lo, int32_t hi)
+{
+    const int32_t a = min(max(lo - xa, 0), 16), b = min(max(hi - xa, 0), 16);
+    return b > a ? (((1u << b) - 1u) & ~((1u << a) - 1u)) : 0u;
+}
+// AND over the L positions that end at each bit (bits in front of bit 0 count as 0), 1 <= L <= 63
+__device__ __forceinline__ uint64_t erode_end(uint64_t h, uint32_t L)
+{
+    const uint64_t s2 = h & (h << 1), s4 = s2 & (s2 << 2), s8 = s4 & (s4 << 4), s16 = s8 & (s8 << 8), s32 = s16 & (s16 << 16);
+    uint64_t r = ~0ull;
+    uint32_t pos = 0;
+    if (L & 32u) { r &= s32 << pos; pos += 32u; }
+    if (L & 16u) { r &= s16 << pos; pos += 16u; }
+    if (L & 8u) { r &= s8 << pos; pos += 8u; }
+    if (L & 4u) { r &= s4 << pos; pos += 4u; }
+    if (L & 2u) { r &= s2 << pos; pos += 2u; }
+    if (L & 1u) { r &= h << pos; }
+    return r;
+}
+// OR over the L positions that start at each bit (bits behind bit 63 count as 0)
+__device__ __forceinline__ uint64_t dilate_fwd(uint64_t f, uint32_t L)
+{
+    const uint64_t d2 = f | (f >> 1), d4 = d2 | (d2 >> 2), d8 = d4 | (d4 >> 4), d16 = d8 | (d8 >> 8), d32 = d16 | (d16 >> 16);
+    uint64_t r = 0;
+    uint32_t pos = 0;
+    if (L & 32u) { r |= d32 >> pos; pos += 32u; }
+    if (L & 16u) { r |= d16 >> pos; pos += 16u; }
+    if (L & 8u) { r |= d8 >> pos; pos += 8u; }
+    if (L & 4u) { r |= d4 >> pos; pos += 4u; }
+    if (L & 2u) { r |= d2 >> pos; pos += 2u; }
+    if (L & 1u) { r |= f >> pos; }
+    return r;
+}
+// 4 bits -> 4 bytes of 0xFF / 0x00
+__device__ __forceinline__ uint32_t spread4(uint32_t m4) { return (((m4 & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu; }
+
+__device__ __forceinline__ uint32_t shfl_up0(uint32_t v, uint32_t d, uint32_t lane) // 0 where there is no such lane
+{
+    const uint32_t t = __shfl_up(v, d);
+    return lane >= d ? t : 0u;
+}
+__device__ __forceinline__ uint32_t shfl_down0(uint32_t v, uint32_t d, uint32_t lane)
+{
+    const uint32_t t = __shfl_down(v, d);
+    return lane + d < 64u ? t : 0u;
+}
+
+__global__ __launch_bounds__(256) void long_count_kernel(const uint64_t *__restrict__ off, uint32_t n_seqs, uint32_t own, uint32_t *__restrict__ counts)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n_seqs) return;
+    counts[s] = s < n_seqs ? (uint32_t)((off[s + 1] - off[s] + own - 1u) / own) : 0u;
+}
+
+// piece t -> { first byte of its region, that byte's position in its sequence, the sequence's length, own0 | own_n << 10 }
+__global__ __launch_bounds__(256) void long_items_kernel(const uint64_t *__restrict__ off, const uint32_t *__restrict__ local, const uint32_t *__restrict__ sums,
+                                                         uint32_t n_seqs, uint32_t own, uint32_t cb, uint32_t n_slots, uint4 *__restrict__ items,
+                                                         uint32_t *__restrict__ n_pieces)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    auto first_item = [&](uint32_t s) { return sums[s / kScanBlock] + local[s]; };
+    if (t == 0) *n_pieces = first_item(n_seqs);
+    if (t >= n_slots) return;
+    uint4 it = make_uint4(0, 0, 0, 0);
+    if (t < first_item(n_seqs)) {
+        uint32_t lo = 0, hi = n_seqs; // largest s with first_item(s) <= t (empty sequences own no piece)
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (first_item(mid) <= t) lo = mid;
+            else hi = mid;
+        }
+        const uint64_t b = off[lo], len = off[lo + 1] - b;
+        const uint64_t s0 = (uint64_t)(t - first_item(lo)) * own;
+        const uint32_t own0 = (uint32_t)min(s0, (uint64_t)cb), own_n = (uint32_t)min((uint64_t)own, len - s0);
+        it = make_uint4((uint32_t)(b + s0 - own0), (uint32_t)(s0 - own0), (uint32_t)len, own0 | (own_n << 10));
+    }
+    items[t] = it;
+}
+
+__global__ __launch_bounds__(256) void map_long_kernel(LongArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t long_lds_all[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t piece = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (piece >= a.n_items) return; // (wave-uniform; the waves of a workgroup share nothing)
+    uint8_t *lds = long_lds_all + (threadIdx.x >> 6) * kLongLds;
+    uint32_t *lin = reinterpret_cast<uint32_t *>(lds) + 2;              // digits of word w, w = -2 .. 67         (280 B)
+    uint16_t *invl = reinterpret_cast<uint16_t *>(lds + 288) + 2;       // bytes that are no base, per word       (144 B)
+    uint16_t *ufl = reinterpret_cast<uint16_t *>(lds + 432) + 2;        // U of the filter's strings, per word    (144 B)
+    uint16_t *zal = reinterpret_cast<uint16_t *>(lds + 576) + 2;        // the two planes, per word               (2 x 144 B)
+    uint16_t *zbl = reinterpret_cast<uint16_t *>(lds + 720) + 2;
+    uint2 *tx = reinterpret_cast<uint2 *>(lds + 864);                   // staged text units                      (608 B)
+    uint16_t *list = reinterpret_cast<uint16_t *>(lds + 864);           // look-ups: position | 0x400 ext | 0x800 last (768 B; where the
+                                                                        // text was: it is not needed any more when the list is made)
+
+    const uint4 it = reinterpret_cast<const uint4 *>(a.items)[piece];
+    const uint32_t q_off = it.x, g0 = it.y, seqlen = it.z, own0 = it.w & 0x3FFu, own_n = (it.w >> 10) & 0x7FFu;
+    if (own_n == 0 || seqlen < 3u) { // (a slot past the batch's last piece; derandomize.rs:274-276 asserts on fewer than 3 values: left unwritten)
+        if (lane == 0) a.redo[piece] = 0;
+        return;
+    }
+    const uint32_t r0 = q_off & 15u, base16 = q_off - r0;
+    const uint32_t R = min(seqlen - g0, own0 + own_n + a.ca), xe = r0 + R; // the region on the grid: [r0, xe)
+    const uint32_t nblk = (xe + 15u) >> 4;
+    const uint32_t k = a.ix.k, thr = a.thr, order = a.ix.dtab_order;
+    const int32_t xa = (int32_t)(16u * lane);
+
+    // ---- 0. the region -> 2-bit digits
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (lane < nblk) v = ld16(a.q, base16 + 16u * lane); // (reads <= 15 bytes in front of / behind the region: the buffer's own)
+    uint32_t code, valid;
+    pack16(v, code, valid);
+    const uint32_t inr16 = range16(xa, (int32_t)r0, (int32_t)xe);
+    const uint32_t inv16 = ~valid & inr16 & 0xFFFFu;
+    lin[lane] = code;
+    invl[lane] = (uint16_t)inv16;
+    if (lane < 2u) {
+        lin[(int32_t)lane - 2] = 0;
+        invl[(int32_t)lane - 2] = 0;
+        ufl[(int32_t)lane - 2] = 0;
+        zal[(int32_t)lane - 2] = 0;
+        zbl[(int32_t)lane - 2] = 0;
+    }
+    if (lane < 4u) {
+        lin[64u + lane] = 0;
+        invl[64u + lane] = 0;
+        ufl[64u + lane] = 0;
+        zal[64u + lane] = 0;
+        zbl[64u + lane] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    auto from_base = [&](uint32_t S) -> uint32_t { // 16 bases from S on, first one most significant
+        const uint32_t W = S >> 4, r = S & 15u;
+        return funnel2(lin[W], lin[W + 1u], r);
+    };
+    auto ending_at = [&](uint32_t E) -> uint64_t { // the 17 + E mod 16 bases ending at E, last one least significant
+        const uint32_t W = E >> 4, r = E & 15u;
+        const uint64_t V = ((uint64_t)lin[(int32_t)W - 1] << 32) | lin[W];
+        return V >> (2u * (15u - r));
+    };
+    auto base_at = [&](uint32_t S) -> uint32_t { return (lin[S >> 4] >> (2u * (15u - (S & 15u)))) & 3u; };
+    auto inv_span = [&](uint32_t E, uint32_t L) -> bool { // any byte that is no base among the L <= 33 positions ending at E
+        const int32_t W = (int32_t)(E >> 4);
+        const uint32_t r = E & 15u;
+        const uint64_t V = (uint64_t)invl[W - 2] | ((uint64_t)invl[W - 1] << 16) | ((uint64_t)invl[W] << 32);
+        return ((V >> (33u + r - L)) & ((1ull << L) - 1ull)) != 0;
+    };
+
+    // ---- 1. stretches
+    const bool by_anchor = a.ix.anchor != nullptr && order >= 12u && order > a.ix.seed_d + 1u; // (as map_reads_kernel seeds)
+    const uint32_t D = by_anchor ? order : a.ix.seed_d;
+    const uint32_t dmask = D >= 16u ? 0xFFFFFFFFu : ((1u << (2u * D)) - 1u);
+    auto seed_at = [&](uint32_t e_) -> uint32_t { // text position of grid position e_ by the window that ends there (bit 31: one of several), or ~0
+        const uint64_t win = ending_at(e_);
+        if (!by_anchor) return a.ix.seed_pos[(uint32_t)win & dmask];
+        const uint64_t key = win & ((1ull << (2u * D)) - 1ull), amask = ((uint64_t)1 << a.ix.anchor_bits) - 1ull;
+        uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> (64u - a.ix.anchor_bits);
+        const uint32_t tag = (uint32_t)key + 1u;
+        for (uint32_t probe = 0; probe < 16u; probe++) {
+            const uint64_t slot = a.ix.anchor[h];
+            if (slot == 0) break;
+            if ((uint32_t)(slot >> 32) == tag) return (uint32_t)slot & 0x7FFFFFFFu;
+            h = (h + 1u) & amask;
+        }
+        return 0xFFFFFFFFu;
+    };
+    uint32_t st_seed = 0, st_look = 0, st_filt = 0, st_second = 0;
+    // windows ending at c + D - 1 + D j, j < nl: the first that ends one row only, else the first that ends any
+    auto seed_round = [&](uint32_t c, uint32_t nl, int32_t &dl, uint32_t &A) -> bool {
+        const uint32_t e_ = c + D - 1u + D * lane;
+        const bool ok = lane < nl && e_ < xe && !inv_span(e_, D);
+        uint32_t tp = 0xFFFFFFFFu;
+        if (ok) {
+            tp = seed_at(e_);
+            st_seed++;
+        }
+        const uint64_t hit_any = __ballot(tp != 0xFFFFFFFFu), hit_one = __ballot(tp != 0xFFFFFFFFu && !(tp >> 31));
+        if (!hit_any) return false;
+        const int src = (int)__builtin_ctzll(hit_one ? hit_one : hit_any);
+        const uint32_t tps = __shfl(tp, src) & 0x7FFFFFFFu, es = c + D - 1u + D * (uint32_t)src;
+        dl = (int32_t)tps - (int32_t)es;
+        A = es - D + 1u;
+        return true;
+    };
+    const int32_t n_units = (int32_t)(((uint64_t)a.ix.n + kMapPad + 256u) / 16u + 2u); // (pack_text_units)
+    int32_t tbase = 0, stage_dl = 0;
+    bool staged = false;
+    auto stage_text = [&](int32_t dl) {
+        const int32_t u0 = (dl + (int32_t)kMapPad - 64) >> 4; // (arithmetic shift: floor)
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t c = lane; c < kLongTextUnits; c += 64u) {
+            const int32_t u = u0 + (int32_t)c;
+            tx[c] = (u >= 0 && u < n_units) ? a.ix.pc_tm[u] : make_uint2(0u, 0x55555555u);
+        }
+        tbase = u0 * 16 - (int32_t)kMapPad;
+        stage_dl = dl;
+        staged = true;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto compare = [&](int32_t dl) -> uint32_t { // bit j: position 16 lane + j does not equal the text on diagonal dl (or is no base / outside)
+        const uint32_t idx0 = (uint32_t)(dl + xa - tbase), unit = idx0 >> 4, r = idx0 & 15u;
+        const uint2 t0 = tx[unit], t1 = tx[unit + 1u];
+        const uint32_t x = code ^ funnel2(t0.x, t1.x, r);
+        return grid_to_mask16(x | (x >> 1) | funnel2(t0.y, t1.y, r)) | inv16 | (~inr16 & 0xFFFFu);
+    };
+    // the assignment of a diagonal reaches back from A over sparse mismatches, up to a mismatch with TH of them in the 16 bases ending at it
+    auto left_start = [&](uint32_t mm, uint32_t A, int32_t lower) -> uint32_t {
+        const uint32_t m = mm & inr16 & range16(xa, lower, (int32_t)A);
+        const uint32_t view = shfl_up0(m, 1, lane) | (m << 16);
+        uint32_t hits = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 16u; j++)
+            if (((m >> j) & 1u) && (uint32_t)__popc((view >> (j + 1u)) & 0xFFFFu) >= kLongTH) hits |= 1u << j;
+        const uint64_t bal = __ballot(hits != 0);
+        if (!bal) return (uint32_t)lower;
+        const int L = 63 - (int)__builtin_clzll(bal);
+        const uint32_t hl = __shfl(hits, L);
+        return 16u * (uint32_t)L + (31u - (uint32_t)__builtin_clz(hl)) + 1u;
+    };
+
+    uint32_t ZA = 0, ZB = 0; // the planes: bit j = position 16 lane + j lies in a stretch
+    {
+        int32_t endz[2] = {(int32_t)r0 - 1, (int32_t)r0 - 1};
+        const int32_t J = (int32_t)order - 3;
+        uint32_t cur = 0, c = r0, A = 0, start = 0, mm = 0;
+        int32_t dl = 0;
+        bool have = false;
+        for (uint32_t iter = 0; iter < 96u; iter++) {
+            if (!have) {
+                int32_t dn = 0;
+                uint32_t An = 0;
+                bool ok = seed_round(c, 4u, dn, An);
+                if (!ok) ok = seed_round(c + 4u * D, 64u, dn, An);
+                if (!ok) break;
+                dl = dn;
+                A = An;
+                have = true;
+                if (!staged || dl - stage_dl > 24 || stage_dl - dl > 24) stage_text(dl);
+                mm = compare(dl);
+                start = left_start(mm, A, max(max((int32_t)r0, endz[cur] + 1), endz[cur ^ 1u] - J));
+            }
+            // where the diagonal is lost: the first 16 bases from A on with TH mismatches; f = the first of them
+            uint32_t f = xe;
+            {
+                const uint32_t mr = mm & inr16;
+                const uint32_t view = mr | (shfl_down0(mr, 1, lane) << 16);
+                uint32_t loss = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < 16u; j++)
+                    if ((uint32_t)__popc((view >> j) & 0xFFFFu) >= kLongTH) loss |= 1u << j;
+                loss &= range16(xa, (int32_t)A, (int32_t)xe);
+                const uint64_t bal = __ballot(loss != 0);
+                if (bal) {
+                    const int L = (int)__builtin_ctzll(bal);
+                    const uint32_t j = (uint32_t)__builtin_ctz(__shfl(loss, L));
+                    const uint32_t vw = __shfl(view, L) >> j;
+                    f = 16u * (uint32_t)L + j + (uint32_t)__builtin_ctz(vw);
+                }
+            }
+            const uint32_t add = range16(xa, (int32_t)start, (int32_t)f) & ~mm & 0xFFFFu;
+            if (cur == 0) ZA |= add;
+            else ZB |= add;
+            endz[cur] = (int32_t)f;
+            if (f >= xe) break;
+            // the next diagonal: of the 64 beside this one, the one on which the read goes on soonest - the first run of kLongRun
+            // matching bases among the 32 behind f (ties: the longer run, then the nearer diagonal)
+            bool found = false;
+            int32_t d2 = 0;
+            uint32_t A2 = 0;
+            if (f + 1u + kLongRun <= xe) {
+                const uint32_t S = f + 1u;
+                const uint32_t w0 = from_base(S), w1 = from_base(S + 16u);
+                const int32_t W = (int32_t)(S >> 4);
+                const uint64_t iv = ((uint64_t)invl[W] | ((uint64_t)invl[W + 1] << 16) | ((uint64_t)invl[W + 2] << 32)) >> (S & 15u);
+                const int32_t sft = (int32_t)lane - 32;
+                const uint32_t idx0 = (uint32_t)(dl + sft + (int32_t)S - tbase), unit = idx0 >> 4, r = idx0 & 15u;
+                const uint2 t0 = tx[unit], t1 = tx[unit + 1u], t2 = tx[unit + 2u];
+                const uint32_t x0 = w0 ^ funnel2(t0.x, t1.x, r), x1 = w1 ^ funnel2(t1.x, t2.x, r);
+                uint32_t m32 = grid_to_mask16(x0 | (x0 >> 1) | funnel2(t0.y, t1.y, r)) | (grid_to_mask16(x1 | (x1 >> 1) | funnel2(t1.y, t2.y, r)) << 16) |
+                               (uint32_t)iv;
+                const uint32_t n_in = xe - S;
+                if (n_in < 32u) m32 |= ~0u << n_in;
+                const uint32_t z = ~m32, e2 = z & (z >> 1), e4 = e2 & (e2 >> 2), e8 = e4 & (e4 >> 4), e10 = e8 & (e2 >> 8);
+                uint32_t key = 0xFFFFFFFFu;
+                if (e10) {
+                    const uint32_t at = (uint32_t)__builtin_ctz(e10);
+                    const uint32_t rest = ~(z >> at); // (bit `run`: the first mismatch behind the run; beyond bit 31 - at: zeros shifted in read as mismatches)
+                    const uint32_t run = rest ? (uint32_t)__builtin_ctz(rest) : 32u;
+                    const uint32_t as = (uint32_t)(sft < 0 ? -sft : sft);
+                    key = (at << 16) | ((63u - run) << 8) | (as << 1) | (sft > 0 ? 1u : 0u);
+                }
+                uint32_t best = key;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor(best, o));
+                if (best != 0xFFFFFFFFu) {
+                    const uint32_t as = (best >> 1) & 0x7Fu;
+                    found = true;
+                    d2 = dl + ((best & 1u) ? (int32_t)as : -(int32_t)as);
+                    A2 = S + (best >> 16);
+                }
+            }
+            if (!found) found = seed_round(f + 4u, 4u, d2, A2);
+            if (!found) {
+                have = false;
+                c = f + 4u + 4u * D;
+                continue;
+            }
+            if (d2 == dl) { // the same diagonal after all (a cluster of substitutions): on with it
+                start = f;
+                A = A2;
+                continue;
+            }
+            if (d2 - stage_dl > 24 || stage_dl - d2 > 24) stage_text(d2);
+            mm = compare(d2);
+            cur ^= 1u;
+            start = left_start(mm, A2, max(max((int32_t)r0, (int32_t)f - J), endz[cur] + 1));
+            dl = d2;
+            A = A2;
+        }
+    }
+
+    // ---- 2. the planes -> G, cov, characters, U
+    auto hist64 = [&](uint32_t z) -> uint64_t { // positions [16 (lane - 3), 16 lane + 16): this lane's at bits 48 .. 63
+        return (uint64_t)shfl_up0(z, 3, lane) | ((uint64_t)shfl_up0(z, 2, lane) << 16) | ((uint64_t)shfl_up0(z, 1, lane) << 32) | ((uint64_t)z << 48);
+    };
+    auto fwd64 = [&](uint32_t z) -> uint64_t { // positions [16 lane, 16 lane + 64)
+        return (uint64_t)z | ((uint64_t)shfl_down0(z, 1, lane) << 16) | ((uint64_t)shfl_down0(z, 2, lane) << 32) | ((uint64_t)shfl_down0(z, 3, lane) << 48);
+    };
+    const uint64_t HA = hist64(ZA), HB = hist64(ZB);
+    const uint32_t G = (uint32_t)((erode_end(HA, thr + 1u) | erode_end(HB, thr + 1u)) >> 48);
+    const uint32_t cov = (uint32_t)dilate_fwd(fwd64(G), thr + 1u) & 0xFFFFu;
+    const uint32_t cov_prev = ((cov << 1) | (shfl_up0(cov, 1, lane) >> 15)) & 0xFFFFu;
+    const uint32_t cov_next = ((cov >> 1) | (shfl_down0(cov, 1, lane) << 15)) & 0xFFFFu;
+    const uint32_t G_next = ((G >> 1) | (shfl_down0(G, 1, lane) << 15)) & 0xFFFFu;
+    // (positions of the sequence: grid x stands for base g0 + x - r0)
+    const int32_t gx = (int32_t)r0 - (int32_t)g0; // grid position of the sequence's base 0 (may be negative)
+    const uint32_t first_two = range16(xa, gx, gx + 2);
+    const uint32_t isX = ~cov & cov_next & (cov_prev | first_two) & inr16;
+    const uint32_t R1 = G & ~G_next & cov_next;
+    // (the second 'R' at base p needs 2 <= p < len - 1: translate.rs:282-288)
+    const uint32_t R2 = ((R1 << 1) | (shfl_up0(R1, 1, lane) >> 15)) & range16(xa, gx + 2, gx + (int32_t)min(seqlen - 1u, 0x3FFFFFFFu));
+    const uint32_t isR = (R1 | R2) & 0xFFFFu;
+    const uint32_t isM = cov & ~isR;
+    const uint32_t U = ~(uint32_t)((erode_end(HA, order) | erode_end(HB, order)) >> 48) & inr16 & range16(xa, (int32_t)(r0 + order - 1u), (int32_t)xe);
+    const uint32_t F = a.ix.dfilt ? a.ix.dfilt_bases : 0u;
+    if (F) ufl[lane] = (uint16_t)(~(uint32_t)((erode_end(HA, F) | erode_end(HB, F)) >> 48) & inr16 & range16(xa, (int32_t)(r0 + F - 1u), (int32_t)xe));
+    zal[lane] = (uint16_t)ZA;
+    zbl[lane] = (uint16_t)ZB;
+
+    // ---- 3. the proof
+    bool flag = false;
+    {
+        const uint32_t c = thr - order, M = c * (47u / c);
+        uint64_t apmask = 0;
+        for (uint32_t p = 0; p <= M; p += c) apmask |= 1ull << p;
+        uint32_t gridm = 0; // positions of this word that are multiples of c
+        for (uint32_t j = ((uint32_t)xa + c - 1u) / c * c - (uint32_t)xa; j < 16u; j += c) gridm |= 1u << j;
+        const uint64_t HU = hist64(U);
+        const uint32_t U_next = ((U >> 1) | (shfl_down0(U, 1, lane) << 15)) & 0xFFFFu;
+        uint32_t normal = 0, lastf = 0, extn = 0;
+        uint32_t um = U;
+        while (um) {
+            const uint32_t j = (uint32_t)__builtin_ctz(um);
+            um &= um - 1u;
+            const uint64_t h48 = (HU >> j) & 0xFFFFFFFFFFFFull;
+            const uint32_t rl = (uint32_t)__builtin_clzll(~(h48 << 16)); // U positions right in front of this one (48: that many or more)
+            const bool point = rl <= M ? ((apmask >> rl) & 1ull) != 0 : ((gridm >> j) & 1u) != 0;
+            const bool last = !((U_next >> j) & 1u);
+            if (point) {
+                normal |= 1u << j;
+                if (last) lastf |= 1u << j;
+            } else if (last) {
+                if ((uint32_t)xa + j + 1u < xe) extn |= 1u << j;
+                else normal |= 1u << j;
+            }
+        }
+        const uint32_t ext = ((extn << 1) | (shfl_up0(extn, 1, lane) >> 15)) & 0xFFFFu;
+        const uint32_t mine = (uint32_t)__popc(normal) + (uint32_t)__popc(ext);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += t;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        __builtin_amdgcn_wave_barrier(); // (the list goes where the text was)
+        if (total > kLongListCap) flag = true;
+        else {
+            uint32_t at = incl - mine;
+            uint32_t nm = normal;
+            while (nm) {
+                const uint32_t j = (uint32_t)__builtin_ctz(nm);
+                nm &= nm - 1u;
+                list[at++] = (uint16_t)(((uint32_t)xa + j) | (((lastf >> j) & 1u) ? 0x800u : 0u));
+            }
+            uint32_t em = ext;
+            while (em) {
+                const uint32_t j = (uint32_t)__builtin_ctz(em);
+                em &= em - 1u;
+                list[at++] = (uint16_t)(((uint32_t)xa + j) | 0x400u);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t omask = (1ull << (2u * order)) - 1ull;
+        auto table = [&](uint32_t e_, uint32_t g) -> uint32_t { // the entry of the window ending at e_ (g: its place in the grouped line)
+            const uint64_t key = ending_at(e_) & omask;
+            st_look++;
+            return a.ix.dtab_grouped ? a.ix.dtab[dtab_grouped_addr(key, g, order)] : a.ix.dtab[key];
+        };
+        // the window ending at e_ is in the index AND the read's base in front of it extends it
+        auto present_ext = [&](uint32_t byte, uint32_t e_) -> bool {
+            return (byte & 0x80u) && e_ >= r0 + order && !inv_span(e_ - order, 1u) && ((byte >> base_at(e_ - order)) & 1u);
+        };
+        for (uint32_t i0 = 0; !flag && i0 < total; i0 += 64u) {
+            const uint32_t i = i0 + lane;
+            bool act = i < total;
+            const uint32_t ent = act ? (uint32_t)list[i] : 0u;
+            const uint32_t x = ent & 0x3FFu;
+            const bool is_ext = (ent & 0x400u) != 0, is_last = (ent & 0x800u) != 0;
+            // (a window with a byte that is no base is in no index; the string an ext look-up asks about holds the base in front)
+            if (act && (inv_span(x, order) || (is_ext && inv_span(x - order, 1u)))) act = false;
+            if (F) { // the filter: a string of F bases of the window that lies in no single stretch - absent: so is the window
+                bool fl = false;
+                uint32_t ef = 0;
+                if (act && is_ext) {
+                    ef = x - order + F - 1u;
+                    fl = true;
+                } else if (act) {
+                    const int32_t W = (int32_t)(x >> 4);
+                    const uint32_t r = x & 15u;
+                    uint32_t V = (uint32_t)ufl[W - 1] | ((uint32_t)ufl[W] << 16); // positions 16 (W - 1) .. 16 W + 15
+                    V &= (2u << (16u + r)) - 1u;                                // <= x
+                    const uint32_t lowbit = 16u + r - (order - F);              // >= x - order + F
+                    V &= ~((1u << lowbit) - 1u);
+                    if (V) {
+                        ef = 16u * (uint32_t)(W - 1) + (31u - (uint32_t)__builtin_clz(V));
+                        fl = true;
+                    }
+                }
+                if (fl) {
+                    const uint32_t fk = (uint32_t)ending_at(ef) & ((1u << (2u * F)) - 1u);
+                    st_filt++;
+                    if (!((a.ix.dfilt[fk >> 5] >> (fk & 31u)) & 1u)) act = false; // absent
+                }
+            }
+            uint32_t byte = 0;
+            if (act) byte = table(x, 1u);
+            bool fail = false;
+            bool need_back = false, need_on = false;
+            if (act && is_ext) fail = present_ext(byte, x);
+            else if (act && (byte & 0x80u)) {
+                need_back = present_ext(byte, x);
+                need_on = is_last && x + 1u < xe;
+            }
+            if (__ballot(need_back)) { // something of order + 1 bases ends here: nothing of order + 2 may
+                if (need_back) {
+                    st_second++;
+                    if (x < r0 + order) fail = true; // (no window one base back inside the region)
+                    else if (!inv_span(x - 1u, order)) fail = present_ext(table(x - 1u, 0u), x - 1u);
+                }
+            }
+            if (__ballot(need_on)) { // the run's last window is present: the one inside the next stretch must not be extended by the base in front
+                if (need_on && !fail) {
+                    st_second++;
+                    if (!inv_span(x + 1u, order + 1u)) fail = present_ext(table(x + 1u, 2u), x + 1u);
+                }
+            }
+            if (__ballot(fail)) flag = true;
+        }
+    }
+
+    // ---- 4. the characters of the own bases, in whole lines; format::relative_to_ref (format.rs:270-286) on the way
+    {
+        uint32_t w[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; q++) {
+            const uint32_t eM = spread4(isM >> (4u * q)), eX = spread4(isX >> (4u * q)), eR = spread4(isR >> (4u * q));
+            if (a.fmt) {
+                const uint32_t d8 = (code >> (24u - 8u * q)) & 0xFFu;
+                const uint32_t sel = ((d8 >> 6) & 3u) | (((d8 >> 4) & 3u) << 8) | (((d8 >> 2) & 3u) << 16) | ((d8 & 3u) << 24);
+                const uint32_t letters = __builtin_amdgcn_perm(0u, 0x54474341u, sel), keep = eM | eR;
+                w[q] = (letters & keep) | (0x2D2D2D2Du & ~keep);
+            } else
+                w[q] = (eM & 0x4D4D4D4Du) | (eX & 0x58585858u) | (eR & 0x52525252u) | (~(eM | eX | eR) & 0x2D2D2D2Du);
+        }
+        const uint4 out = make_uint4(w[0], w[1], w[2], w[3]);
+        const int32_t o_lo = (int32_t)(r0 + own0), o_hi = o_lo + (int32_t)own_n;
+        const uint32_t lo_t = (uint32_t)min(max(o_lo - xa, 0), 16), hi_t = (uint32_t)min(max(o_hi - xa, 0), 16);
+        uint8_t *dst = a.chars_out + base16 + 16u * lane;
+        if (lo_t == 0u && hi_t == 16u) __builtin_memcpy(dst, &out, 16);
+        else if (hi_t > lo_t) {
+#pragma unroll
+            for (uint32_t t = 0; t < 16u; t++)
+                if (t >= lo_t && t < hi_t) dst[t] = (uint8_t)(w[t >> 2] >> ((t & 3u) * 8u));
+        }
+    }
+    // x of the first own base, 0 .. k (what derandomize_ms_vec gives there: the depth in the stretch of more than t bases that
+    // covers it, 0 when none does) - for the piece to the left, should that one be flagged
+    if (lane == 0) {
+        const uint32_t xs = r0 + own0;
+        uint32_t best = 0;
+        for (uint32_t p = 0; p < 2u; p++) {
+            const uint16_t *zl = p == 0 ? zal : zbl;
+            auto bit = [&](uint32_t x) -> bool { return x >= r0 && x < xe && ((zl[x >> 4] >> (x & 15u)) & 1u); };
+            if (!bit(xs)) continue;
+            uint32_t Lp = 1, Rp = 0;
+            while (Lp <= k && xs >= Lp && bit(xs - Lp)) Lp++;
+            while (Lp + Rp <= thr && bit(xs + 1u + Rp)) Rp++;
+            if (Lp + Rp > thr) best = max(best, min(Lp, k));
+        }
+        a.xin[piece] = (uint8_t)best;
+        a.redo[piece] = flag ? 1 : 0;
+        if (flag) atomicAdd(a.qctl + 4, 1u);
+    }
+    plan_stats_add(a.pstats, kPlanStatSeedLookups, st_seed, kPlanStatSeedExtensions, st_filt, kPlanStatTabLookups, st_look, kPlanStatTabAnchored, st_second);
+}
+
+// ---- flagged pieces: sub-items of 32 bases (+ k - 1 warm-up bases) for the plain walk: the MS values of [s - 1, s + n)
+constexpr uint32_t kLongSub = 32;
+__global__ __launch_bounds__(256) void long_redo_items_kernel(LongArgs a, WalkItem *__restrict__ out, uint32_t cap, uint32_t *__restrict__ count)
+{
+    const uint32_t piece = blockIdx.x * blockDim.x + threadIdx.x;
+    if (piece >= a.n_items || !a.redo[piece]) return;
+    const uint4 it = reinterpret_cast<const uint4 *>(a.items)[piece];
+    const uint32_t own0 = it.w & 0x3FFu, own_n = (it.w >> 10) & 0x7FFu;
+    if (own_n == 0) return;
+    const uint32_t s = it.y + own0;                  // the piece's first own base in its sequence
+    const uint64_t seq0 = (uint64_t)it.x - it.y;     // the sequence's first byte
+    const uint32_t lo = s > 0 ? s - 1u : 0u, hi = s + own_n, n_sub = (hi - lo + kLongSub - 1u) / kLongSub;
+    const uint32_t base = atomicAdd(count, n_sub);
+    const uint32_t warm_max = a.ix.k > 0 ? a.ix.k - 1u : 0u;
+    for (uint32_t p = 0; p < n_sub; p++) {
+        const uint32_t o0 = lo + p * kLongSub, o1 = min(o0 + kLongSub, hi), warm = min(o0, warm_max);
+        WalkItem w;
+        w.start = seq0 + o0 - warm;
+        w.len = o1 - o0 + warm;
+        w.warm = warm;
+        if (base + p < cap) out[base + p] = w;
+    }
+}
+
+// derandomize_ms_vec (derandomize.rs:269-288) + translate_ms_vec (translate.rs:263-293) over the flagged pieces, literally, right to
+// left: one lane per RUN of flagged pieces - the lane of its rightmost piece, which starts from x of the base behind it (xin of the
+// unflagged piece to the right; the sequence's end: derandomize.rs:282) and goes on through the flagged pieces to its left
+__global__ __launch_bounds__(64) void long_derand_kernel(LongArgs a, const uint8_t *__restrict__ ms)
+{
+    const uint32_t piece = blockIdx.x * blockDim.x + threadIdx.x;
+    if (piece >= a.n_items || !a.redo[piece]) return;
+    const uint4 *items = reinterpret_cast<const uint4 *>(a.items);
+    const uint4 it = items[piece];
+    const uint32_t own0 = it.w & 0x3FFu, own_n = (it.w >> 10) & 0x7FFu, seqlen = it.z;
+    if (own_n == 0) return;
+    const uint32_t s = it.y + own0, e = s + own_n; // own bases [s, e) of the sequence
+    const bool at_end = e >= seqlen;
+    if (!at_end && piece + 1u < a.n_items && a.redo[piece + 1u]) return; // (the lane of a piece further right takes this one)
+    const uint64_t seq0 = (uint64_t)it.x - it.y;
+    const uint8_t *m = ms + seq0;
+    const uint8_t *qs = a.q + seq0;
+    uint8_t *out = a.chars_out + seq0;
+    const int K = (int)a.ix.k, T = (int)a.thr;
+    // the run's first base: back over the flagged pieces of this sequence
+    uint32_t lo = s, pp = piece;
+    while (lo > 0 && pp > 0 && a.redo[pp - 1u]) {
+        const uint4 pit = items[pp - 1u];
+        const uint32_t p_n = (pit.w >> 10) & 0x7FFu, p_s = pit.y + (pit.w & 0x3FFu);
+        if (p_n == 0 || (uint64_t)pit.x - pit.y != seq0 || p_s + p_n != lo) break;
+        lo = p_s;
+        pp--;
+    }
+    auto step = [&](int av, int x) { return av == K ? K : ((av > T && x < av) ? av : x - 1); };
+    auto val = [&](int cur, int next, int prev) -> uint32_t { // translate_ms_val's first character
+        if (cur > T && next > 0 && next < T) return (uint32_t)'R';
+        if (cur <= 0) return (next == 1 && prev > 0) ? (uint32_t)'X' : (uint32_t)'-';
+        return (uint32_t)'M';
+    };
+    // x[p] for p = e - 1 down to lo - 1 (the base in front of the run gives `prev` of its first base); characters of [lo, e)
+    int x_next, x_cur;
+    uint32_t p = e - 1u;
+    if (at_end) {
+        const int av = m[p];
+        x_cur = av > T ? av : 0; // derandomize.rs:282
+        x_next = x_cur;          // translate.rs:279: next of the last base is its own value
+    } else {
+        x_next = (int)a.xin[piece + 1u];
+        x_cur = step((int)m[p], x_next);
+    }
+    for (;;) {
+        const int x_prev = p > 0 ? step((int)m[p - 1u], x_cur) : K;
+        const int prev = p > 1 ? x_prev : K; // translate.rs:277
+        // res[p] = 'R' when 2 <= p < len - 1 and the base in front starts an ('R','R') (translate.rs:282-288), else val(..).0
+        uint32_t ch;
+        if (p >= 2u && p < seqlen - 1u && x_prev > T && x_cur > 0 && x_cur < T) ch = (uint32_t)'R';
+        else ch = val(x_cur, p + 1u < seqlen ? x_next : x_cur, prev);
+        if (a.fmt) ch = (ch == (uint32_t)'M' || ch == (uint32_t)'R') ? (uint32_t)qs[p] : (uint32_t)'-';
+        out[p] = (uint8_t)ch;
+        if (p == lo) break;
+        x_next = x_cur;
+        x_cur = x_prev;
+        p--;
+    }
+}
+
+} // namespace
+
+namespace {
+struct LongLayout {
+    size_t items, scan, redo, xin, ctl, pstats, subs, end;
+    uint32_t own, n_slots, sub_cap;
+};
+LongLayout long_layout(size_t n_seqs, uint64_t total_bases, uint32_t k)
+{
+    LongLayout L{};
+    L.own = kLongRegion - 2u * k - 1u;
+    const uint64_t slots = total_bases / L.own + n_seqs + 1;
+    L.n_slots = (uint32_t)std::min<uint64_t>(slots, 0x7FFFFF00ull);
+    size_t w = 0;
+    L.items = w;
+    w += slots * 16;
+    L.scan = w;
+    w += (chunk_items_scratch_words((uint32_t)n_seqs) * 4 + 15) / 16 * 16;
+    L.redo = w;
+    w += (slots + 15) / 16 * 16;
+    L.xin = w;
+    w += (slots + 15) / 16 * 16;
+    L.ctl = w; // [0] pieces, [1] sub-items of the flagged pieces, [4] flagged pieces
+    w += 256;
+    L.pstats = w;
+    w += kPlanStatSlots * kPlanStatWords * 4;
+    L.subs = w; // sub-items of the flagged pieces: all of them, at worst
+    const uint64_t cap = total_bases / kLongSub + 3 * slots + 64;
+    L.sub_cap = (uint32_t)std::min<uint64_t>(cap, 0x7FFFFF00ull);
+    w += cap * sizeof(WalkItem);
+    L.end = w + 64;
+    return L;
+}
+} // namespace
+
+size_t long_work_bytes(size_t n_seqs, uint64_t total_bases, uint32_t k)
+{
+    if (2u * k + 1u + kLongOwnMin > kLongRegion) return 0;
+    return long_layout(n_seqs, total_bases, k).end;
+}
+
+bool map_long_applies(const DevIndexView &ix, uint32_t thr)
+{
+    static const int env_on = std::getenv("KBO_MAP_LONG") ? std::atoi(std::getenv("KBO_MAP_LONG")) : 1; // experiments
+    if (!(env_on != 0 && ix.dtab && ix.pc_tm && ix.seed_pos && ix.seed_d >= 4u && ix.seed_d <= 14u && ix.dtab_order >= 4u && ix.dtab_order <= 17u &&
+          ix.dtab_order < thr && thr < ix.k && thr <= 47u && 2u * ix.k + 1u + kLongOwnMin <= kLongRegion))
+        return false;
+    if (ix.dfilt && (ix.dfilt_bases >= ix.dtab_order || ix.dtab_order - ix.dfilt_bases > 5u || ix.dfilt_bases > 16u)) return false;
+    // (the proof takes a window every thr - order bases: at most six per mismatch)
+    const uint32_t c = thr - ix.dtab_order;
+    return (ix.dtab_order + c - 1u) / c + 1u <= 6u;
+}
+
+// the pieces of the batch and the kernel; `a` as launch_map_long_redo needs it
+hipError_t launch_map_long(const DevIndexView &ix, const uint8_t *d_q, const uint64_t *d_off, uint32_t n_seqs, uint64_t total_bases, uint32_t thr,
+                           bool fmt, uint8_t *d_chars, void *d_work, hipStream_t stream, LongArgs &a)
+{
+    const LongLayout L = long_layout(n_seqs, total_bases, ix.k);
+    uint8_t *w = static_cast<uint8_t *>(d_work);
+    uint32_t *local = reinterpret_cast<uint32_t *>(w + L.scan), *sums = local + n_seqs + 1u;
+    uint32_t *ctl = reinterpret_cast<uint32_t *>(w + L.ctl);
+    hipError_t e = hipMemsetAsync(ctl, 0, 256 + kPlanStatSlots * kPlanStatWords * 4, stream);
+    if (e != hipSuccess) return e;
+    // pieces per sequence, their scan, the items (the grid covers the most pieces the batch can have; slots past the last are empty)
+    hipLaunchKernelGGL(long_count_kernel, dim3((n_seqs + 1u + 255u) / 256u), dim3(256), 0, stream, d_off, n_seqs, L.own, local);
+    e = launch_scan(local, n_seqs + 1u, sums, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(long_items_kernel, dim3((L.n_slots + 255u) / 256u), dim3(256), 0, stream, d_off, local, sums, n_seqs, L.own, ix.k, L.n_slots,
+                       reinterpret_cast<uint4 *>(w + L.items), ctl);
+    a = LongArgs{};
+    a.ix = ix;
+    a.q = d_q;
+    a.items = w + L.items;
+    a.n_items = L.n_slots;
+    a.chars_out = d_chars;
+    a.redo = w + L.redo;
+    a.xin = w + L.xin;
+    a.qctl = ctl;
+    a.pstats = reinterpret_cast<uint32_t *>(w + L.pstats);
+    a.thr = thr;
+    a.fmt = fmt ? 1u : 0u;
+    a.ca = ix.k + 1u;
+    a.subs = w + L.subs;
+    a.sub_cap = L.sub_cap;
+    a.q_bytes = total_bases;
+    static const int env_wpb = std::getenv("KBO_LONG_WPB") ? std::atoi(std::getenv("KBO_LONG_WPB")) : 4; // experiments: waves per workgroup
+    const uint32_t wpb = (uint32_t)std::min(4, std::max(1, env_wpb));
+    hipLaunchKernelGGL(map_long_kernel, dim3((L.n_slots + wpb - 1u) / wpb), dim3(64u * wpb), kLongLds * wpb, stream, a);
+    return hipGetLastError();
+}
+
+// the flagged pieces: their matching statistics by the plain walk (into d_ms), then the literal recurrences
+hipError_t launch_map_long_redo(const LongArgs &a, uint8_t *d_ms, hipStream_t stream)
+{
+    hipLaunchKernelGGL(long_redo_items_kernel, dim3((a.n_items + 255u) / 256u), dim3(256), 0, stream, a, static_cast<WalkItem *>(a.subs), a.sub_cap, a.qctl + 1);
+    WalkArgs wa{};
+    wa.ix = a.ix;
+    wa.q = a.q;
+    wa.q_bytes = a.q_bytes;
+    wa.d_out = d_ms;
+    // (a few per cent of the pieces are flagged, 32 sub-items each: a lane per sub-item while there are as many as two per piece)
+    const uint32_t lanes = (uint32_t)std::min<uint64_t>((uint64_t)a.n_items * 2u + 4096u, a.sub_cap);
+    hipError_t e = launch_walk_list(wa, static_cast<const WalkItem *>(a.subs), a.sub_cap, a.qctl + 1, lanes, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(long_derand_kernel, dim3((a.n_items + 63u) / 64u), dim3(64), 0, stream, a, d_ms);
+    return hipGetLastError();
+}
+
+hipError_t long_read_stats(const void *d_work, size_t n_seqs, uint64_t total_bases, uint32_t k, uint32_t ctl[8], uint32_t *stats, hipStream_t stream)
+{
+    const LongLayout L = long_layout(n_seqs, total_bases, k);
+    const uint8_t *w = static_cast<const uint8_t *>(d_work);
+    hipError_t e = hipMemcpyAsync(ctl, w + L.ctl, 32, hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(stats, w + L.pstats, kPlanStatSlots * kPlanStatWords * 4, hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(stream);
+}
+
+} // namespace kbo

@@ -520,6 +520,27 @@ static hipError_t launch_redo_walk(WalkArgs a, hipStream_t stream)
     return hipGetLastError();
 }
 
+// the plain walk over a list whose length is on the device (long_kernels.hip: the sub-items of the flagged pieces)
+hipError_t launch_walk_list(WalkArgs a, const WalkItem *d_list, uint32_t cap, const uint32_t *d_count, uint32_t lanes, hipStream_t stream)
+{
+    if (cap == 0 || lanes == 0) return hipSuccess;
+    a.items = d_list;
+    a.n_items = cap;
+    a.n_items_dev = d_count;
+    a.gitems = nullptr;
+    a.call_sites = nullptr;
+    a.lo_out = a.hi_out = nullptr;
+    a.rounds = 1;
+    a.rare_period = (uint32_t)g_rare_period.load();
+    a.lane_limit = (uint32_t)g_walk_lane_limit.load();
+    a.pair_min_d = (uint32_t)g_pair_min_depth.load();
+    const uint32_t waves = (lanes + 63u) / 64u;
+    const dim3 grid((waves + 3u) / 4u), block(256);
+    if (a.ix.big) hipLaunchKernelGGL((ms_walk_kernel<false, true, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((ms_walk_kernel<false, false, false>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_redo_collect(const WalkArgs &a, hipStream_t stream); // plan_kernels.hip
 hipError_t launch_redo_pass(WalkArgs a, hipStream_t stream)
 {
