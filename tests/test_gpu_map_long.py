@@ -152,16 +152,36 @@ def test_long_sequences_every_base(oracle, k):
 
 
 def test_reads_and_contigs_in_one_batch(oracle):
-    """a batch of an assembly's shape: whole contigs, fragments of every length down to 1 base, reads"""
+    """a batch of an assembly's shape: whole contigs, fragments of every length down to 3 bases, reads; sequences of 1 and 2 bases
+    among them are left unwritten (derandomize.rs:274-276 asserts on fewer than 3 values)"""
+    import torch
     rng = np.random.default_rng(77)
     contigs = _genome(rng, 600_000, contigs=2)
     sbwt, _ = kbo_amd.build(contigs, kbo_amd.BuildOpts(k=31, num_threads=threads()))
     ora = oracle.Index.build([c.tobytes() for c in contigs], k=31)
-    seqs = _sequences(rng, contigs, 40, [1, 2, 3, 5, 17, 31, 60, 150, 160, 161, 300, 5000], 0.01, 0.001)
+    seqs = _sequences(rng, contigs, 60, [3, 4, 5, 17, 31, 60, 150, 160, 161, 300, 5000], 0.01, 0.001)
+    seqs = [q for q in seqs if len(q) >= 3]
     seqs.append(_mutate(rng, contigs[0], 0.01, 0.0005, 0.3))  # a whole contig against its own index, 300 kbp
     seqs.append(contigs[1][1000:200_000].copy())
     concat, offsets = _batch_of(seqs)
     _check(oracle, ora, sbwt, concat, offsets)
+    # the same with sequences of 1 and 2 bases in between
+    exp = ora.matches_batch(concat, offsets, 1e-7, n_threads=threads())
+    mixed, want = [], []
+    for i, q in enumerate(seqs):
+        mixed.append(q)
+        want.append(exp[int(offsets[i]):int(offsets[i + 1])])
+        if i % 3 == 0:
+            tiny = ACGT[rng.integers(0, 4, 1 + i % 2)]
+            mixed.append(tiny)
+            want.append(np.full(len(tiny), 0xEE, dtype=np.uint8))
+    c2, o2 = _batch_of(mixed)
+    dev = batch.DeviceBatch(sbwt, c2, o2, device=torch.device("cuda:0"), want_ms=False)
+    dev.chars.fill_(0xEE)
+    dev.run()
+    torch.cuda.synchronize()
+    assert dev.fused
+    assert np.array_equal(dev.chars[:dev.total].cpu().numpy(), np.concatenate(want))
 
 
 def test_one_megabase_sequence(oracle):

@@ -46,7 +46,7 @@ def _batch_of(reads):
     return concat, offsets
 
 
-def _check(oracle, ora, sbwt, concat, offsets, p=1e-7, expect_fused=True):
+def _check(oracle, ora, sbwt, concat, offsets, p=1e-7, expect_fused=True, expect_fused_without_ms=None):
     import torch
     exp_chars, exp_d = ora.matches_batch(concat, offsets, p, n_threads=threads(), want_d=True)
     exp_map = np.frombuffer(oracle.relative_to_ref(concat, exp_chars), dtype=np.uint8)
@@ -57,7 +57,7 @@ def _check(oracle, ora, sbwt, concat, offsets, p=1e-7, expect_fused=True):
         kbo_amd.lib().kbo_set_plan(1, 0, 0)  # (a batch that gave the plan up - 8 % substitutions - holds the copy off: clear it)
         dev.run()
         torch.cuda.synchronize()
-        assert dev.fused == expect_fused
+        assert dev.fused == (expect_fused if want_ms or expect_fused_without_ms is None else expect_fused_without_ms)
         got = dev.chars[:dev.total].cpu().numpy()
         want = exp_map if fmt else exp_chars
         if not np.array_equal(got, want):
@@ -238,14 +238,15 @@ def test_how_many_reads_the_kernel_leaves_to_the_second_pass():
 
 
 def test_routes_that_are_not_the_one_kernel(oracle):
-    """reads longer than 160 bases, a copy without a depth table, a held-off copy: kbo_map_batch_dev takes the two kernels"""
+    """reads longer than 160 bases with the MS values wanted, a copy without a depth table, a held-off copy: kbo_map_batch_dev takes
+    the two kernels (longer reads without the MS values: the kernel for sequences of any length, long_kernels.hip)"""
     L = kbo_amd.lib()
     rng = np.random.default_rng(9)
     g = synth.genome(200_000, seed=11)
     ora = oracle.Index.build([g.tobytes()], k=31)
     sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=threads()))
     reads = _mutate(rng, [g[a:a + 300] for a in rng.integers(0, len(g) - 300, 2000)], sub=0.01)
-    _check(oracle, ora, sbwt, *_batch_of(reads), expect_fused=False)
+    _check(oracle, ora, sbwt, *_batch_of(reads), expect_fused=False, expect_fused_without_ms=True)
     L.kbo_set_depth_table(-1)
     sb2, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=threads()))
     reads = _mutate(rng, [g[a:a + 150] for a in rng.integers(0, len(g) - 150, 2000)], sub=0.01)
@@ -357,7 +358,7 @@ def test_find_on_the_device_counts_runs_in_the_kernel(oracle):
         (_mutate(rng, take(20_000, 150, 150), sub=0.01), True),
         (_mutate(rng, take(15_000, 3, 157), sub=0.03, indel=0.3, n_rate=0.1), True),
         (_mutate(rng, take(5_000, 120, 160), sub=0.06) + [other[a:a + 150] for a in rng.integers(0, len(other) - 150, 2000)], True),
-        (_mutate(rng, take(3_000, 100, 470), sub=0.01), False),  # longer than 160 bases: not the one kernel
+        (_mutate(rng, take(3_000, 100, 470), sub=0.01), True),  # longer than 160 bases: the kernel for sequences of any length
     ]
     for reads, one_kernel in sets:
         concat, offsets = _batch_of(reads)
