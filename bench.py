@@ -466,11 +466,16 @@ def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, pipes=None):
         exp_chars, exp_d = o.matches_batch(concat[:n_b], offsets[:n_chk + 1], 1e-7, n_threads=cores, want_d=True)
         exp_map = np.frombuffer(ora.relative_to_ref(concat[:n_b], exp_chars), dtype=np.uint8)
         ok = bool(np.array_equal(dev.chars[:n_b].cpu().numpy(), exp_map))  # (what the timed steps left behind)
+        extra = {}
+        if fused and dev.max_len > 160:  # (sequences of any length: what the kernel's pieces did)
+            st = dev.long_stats()
+            extra = {"pieces": st["pieces"], "flagged_pieces": st["flagged"], "table_lookups_per_kb": round(1e3 * st["table_lookups"] / max(1, int(offsets[-1])), 2),
+                     "filter_lookups_per_kb": round(1e3 * st["filter_lookups"] / max(1, int(offsets[-1])), 2)}
         dev.walk(stream)
         torch.cuda.synchronize(device)
         ok = bool(ok and np.array_equal(dev.ms[:n_b].cpu().numpy(), exp_d))
         del dev, devs
-        return {"variant": name, "value": round(int(offsets[-1]) * 12 / elapsed / 1e6, 1), "unit": "Mbp/s", "one_kernel": fused,
+        return {**extra, "variant": name, "value": round(int(offsets[-1]) * 12 / elapsed / 1e6, 1), "unit": "Mbp/s", "one_kernel": fused,
                 "step_ms": round(a1 + dt, 4), "bit_exact_vs_oracle": ok, "note": note}
 
     out = []
@@ -489,13 +494,19 @@ def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, pipes=None):
     out.append(measure("1% substitutions + 0.2% insertions / deletions", sbwt, oi, concat, offsets,
                        "a read with an insertion or a deletion follows two diagonals of the text: the kernel seeds the second from the "
                        "read's last bases and cuts the read where the two together mismatch least"))
-    # ONT-like reads (C5's premise): 10 kbp, 5 % errors of which half are insertions / deletions.  Long sequences take the two-kernel
-    # route (chunks, units + the guided walk or the table's stand-alone kernel), not the one kernel
+    # sequences of more than 160 bases - what kbo::map / find / call are called with (lib.rs:612-628, 720-761): one wave per piece
+    # of a sequence (long_kernels.hip), the pieces whose proof fails by the plain walk + the literal recurrences behind it
+    L_.kbo_set_plan(1, 0, 0)
+    n_long = max(100, n_reads * L // 10_000)
+    concat, offsets = synth.reads(genome, n_long, 10_000, 0.01, seed=0x5E11E)
+    out.append(measure("10 kbp reads, 1% substitutions", sbwt, oi, concat, offsets,
+                       "pieces of 945 own bases inside regions of 1008; a seed per piece, the text on its diagonal staged in LDS"))
+    # ONT-like reads (C5's premise): 10 kbp, 5 % errors of which half are insertions / deletions
     L_.kbo_set_plan(1, 0, 0)
     n_long = max(100, n_reads * L // 10_000 // 2)
     concat, offsets = indel_reads(genome, n_long, 10_000, 0.025, 0.025 / 2, seed=0x5E11D, many=True)
     out.append(measure("ONT-like: 10 kbp reads, 2.5% substitutions + 2.5% insertions / deletions", sbwt, oi, concat, offsets,
-                       "long sequences are cut into chunks with k - 1 warm-up bases; at this error rate the plan is given up and the plain walk runs"))
+                       "a diagonal is lost every 80 bases: the 64 lanes of the piece's wave try the 64 diagonals beside it"))
     L_.kbo_set_plan(1, 0, 0)
     concat, offsets = synth.reads(genome, n_reads, L, 0.01, seed=0x5E117)
     rc = comp[concat.reshape(-1, L)[:, ::-1]].reshape(-1).copy()

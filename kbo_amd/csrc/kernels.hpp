@@ -361,10 +361,12 @@ struct LongArgs {
     uint8_t *chars_out;
     uint8_t *redo;        // per piece: 1 = its proof failed (the plain walk + the literal recurrences decide: launch_map_long_redo)
     uint8_t *xin;         // per piece: the derandomised value of its first own base, 0 .. k (<= 0 as 0)
-    uint32_t *qctl;       // [0] pieces, [1] sub-items of the flagged pieces, [4] flagged pieces
+    uint32_t *qctl;       // [0] pieces, [1] sub-items of the flagged pieces, [2] flagged pieces listed, [4] flagged pieces
     uint32_t *pstats;     // work counters (kPlanStat*)
+    uint32_t xexp;        // experiment switches (KBO_LONG_X): timing only, results are wrong with any of them
     uint32_t thr, fmt, ca; // derandomisation threshold, 1 = format::relative_to_ref on the way out, bases of a region behind the own ones
     void *subs;           // WalkItem records of the flagged pieces' sub-items
+    uint32_t *flist;      // the flagged pieces, listed (qctl[2] of them)
     uint32_t sub_cap;
 };
 size_t long_work_bytes(size_t n_seqs, uint64_t total_bases, uint32_t k); // bytes of work memory of a launch (0: k too large)

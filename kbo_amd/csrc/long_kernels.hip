@@ -50,6 +50,9 @@ constexpr uint32_t kLongListCap = 384;  // look-ups a piece may ask for (more: f
 constexpr uint32_t kLongTH = 6;         // mismatches in 16 bases that end a diagonal
 constexpr uint32_t kLongRun = 10;       // matching bases that start one
 constexpr uint32_t kLongLds = 2048;     // bytes of LDS per wave
+#ifndef KBO_LONG_WPE
+#define KBO_LONG_WPE 8
+#endif
 
 __device__ __forceinline__ uint32_t funnel2(uint32_t hi, uint32_t lo, uint32_t r) // 16 digits from digit r of hi on
 {
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void long_items_kernel(const uint64_t *__restr
     items[t] = it;
 }
 
-__global__ __launch_bounds__(256) void map_long_kernel(LongArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WPE))) void map_long_kernel(LongArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t long_lds_all[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -216,6 +219,7 @@ __global__ __launch_bounds__(256) void map_long_kernel(LongArgs a)
         return ((V >> (33u + r - L)) & ((1ull << L) - 1ull)) != 0;
     };
 
+    if (a.xexp & 16u) return;
     // ---- 1. stretches
     const bool by_anchor = a.ix.anchor != nullptr && order >= 12u && order > a.ix.seed_d + 1u; // (as map_reads_kernel seeds)
     const uint32_t D = by_anchor ? order : a.ix.seed_d;
@@ -390,6 +394,7 @@ __global__ __launch_bounds__(256) void map_long_kernel(LongArgs a)
         }
     }
 
+    if (a.xexp & 32u) return;
     // ---- 2. the planes -> G, cov, characters, U
     auto hist64 = [&](uint32_t z) -> uint64_t { // positions [16 (lane - 3), 16 lane + 16): this lane's at bits 48 .. 63
         return (uint64_t)shfl_up0(z, 3, lane) | ((uint64_t)shfl_up0(z, 2, lane) << 16) | ((uint64_t)shfl_up0(z, 1, lane) << 32) | ((uint64_t)z << 48);
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(256) void map_long_kernel(LongArgs a)
 
     // ---- 3. the proof
     bool flag = false;
-    {
+    if (!(a.xexp & 1u)) {
         const uint32_t c = thr - order, M = c * (47u / c);
         uint64_t apmask = 0;
         for (uint32_t p = 0; p <= M; p += c) apmask |= 1ull << p;
@@ -491,7 +496,7 @@ __global__ __launch_bounds__(256) void map_long_kernel(LongArgs a)
             const bool is_ext = (ent & 0x400u) != 0, is_last = (ent & 0x800u) != 0;
             // (a window with a byte that is no base is in no index; the string an ext look-up asks about holds the base in front)
             if (act && (inv_span(x, order) || (is_ext && inv_span(x - order, 1u)))) act = false;
-            if (F) { // the filter: a string of F bases of the window that lies in no single stretch - absent: so is the window
+            if (F && !(a.xexp & 2u)) { // the filter: a string of F bases of the window that lies in no single stretch - absent: so is the window
                 bool fl = false;
                 uint32_t ef = 0;
                 if (act && is_ext) {
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(256) void map_long_kernel(LongArgs a)
                 }
             }
             uint32_t byte = 0;
-            if (act) byte = table(x, 1u);
+            if (act && !(a.xexp & 4u)) byte = table(x, 1u);
             bool fail = false;
             bool need_back = false, need_on = false;
             if (act && is_ext) fail = present_ext(byte, x);
@@ -567,29 +572,54 @@ __global__ __launch_bounds__(256) void map_long_kernel(LongArgs a)
         }
     }
     // x of the first own base, 0 .. k (what derandomize_ms_vec gives there: the depth in the stretch of more than t bases that
-    // covers it, 0 when none does) - for the piece to the left, should that one be flagged
-    if (lane == 0) {
-        const uint32_t xs = r0 + own0;
+    // covers it, 0 when none does) - for the piece to the left, should that one be flagged.  Per plane: the ones that end at that
+    // base (Lp) and those behind it (Rp), through the words that are all ones by one ballot
+    {
+        const uint32_t xs = r0 + own0, Lo = xs >> 4, b = xs & 15u;
         uint32_t best = 0;
+#pragma unroll
         for (uint32_t p = 0; p < 2u; p++) {
-            const uint16_t *zl = p == 0 ? zal : zbl;
-            auto bit = [&](uint32_t x) -> bool { return x >= r0 && x < xe && ((zl[x >> 4] >> (x & 15u)) & 1u); };
-            if (!bit(xs)) continue;
-            uint32_t Lp = 1, Rp = 0;
-            while (Lp <= k && xs >= Lp && bit(xs - Lp)) Lp++;
-            while (Lp + Rp <= thr && bit(xs + 1u + Rp)) Rp++;
+            const uint32_t w = p == 0 ? ZA : ZB;
+            const uint64_t full = __ballot(w == 0xFFFFu);
+            const uint32_t wo = __shfl(w, (int)Lo);
+            if (!((wo >> b) & 1u)) continue; // (wave-uniform)
+            // down from bit b of word Lo
+            uint32_t Lp;
+            const uint32_t zd = ~wo & ((2u << b) - 1u);
+            if (zd) Lp = b - (31u - (uint32_t)__builtin_clz(zd));
+            else {
+                const uint64_t nf = ~full & ((1ull << Lo) - 1ull); // words below Lo that are not all ones
+                const uint32_t hi = nf ? 63u - (uint32_t)__builtin_clzll(nf) : 0u, n_full = nf ? Lo - 1u - hi : Lo;
+                const uint32_t wp = nf ? (uint32_t)__shfl(w, (int)hi) : 0u;
+                const uint32_t part = nf ? (uint32_t)__builtin_clz(~(wp << 16)) : 0u; // ones from bit 15 of that word down
+                Lp = b + 1u + 16u * n_full + min(part, 16u);
+            }
+            // up from bit b + 1
+            uint32_t Rp;
+            const uint32_t zu = ~wo & 0xFFFFu & ~((2u << b) - 1u);
+            if (zu) Rp = (uint32_t)__builtin_ctz(zu) - b - 1u;
+            else {
+                const uint64_t nf = Lo < 63u ? (~full & (~0ull << (Lo + 1u))) : 0ull;
+                const uint32_t lo_l = nf ? (uint32_t)__builtin_ctzll(nf) : 64u, n_full = nf ? lo_l - Lo - 1u : 63u - Lo;
+                const uint32_t wn = nf ? (uint32_t)__shfl(w, (int)lo_l) : 0u;
+                const uint32_t part = nf ? (uint32_t)__builtin_ctz(~wn) : 0u; // ones from bit 0 of that word up
+                Rp = 15u - b + 16u * n_full + min(part, 16u);
+            }
             if (Lp + Rp > thr) best = max(best, min(Lp, k));
         }
-        a.xin[piece] = (uint8_t)best;
-        a.redo[piece] = flag ? 1 : 0;
-        if (flag) atomicAdd(a.qctl + 4, 1u);
+        if (lane == 0) {
+            a.xin[piece] = (uint8_t)best;
+            a.redo[piece] = flag ? 1 : 0;
+            if (flag) atomicAdd(a.qctl + 4, 1u);
+        }
     }
     plan_stats_add(a.pstats, kPlanStatSeedLookups, st_seed, kPlanStatSeedExtensions, st_filt, kPlanStatTabLookups, st_look, kPlanStatTabAnchored, st_second);
 }
 
 // ---- flagged pieces: sub-items of 32 bases (+ k - 1 warm-up bases) for the plain walk: the MS values of [s - 1, s + n)
 constexpr uint32_t kLongSub = 32;
-__global__ __launch_bounds__(256) void long_redo_items_kernel(LongArgs a, WalkItem *__restrict__ out, uint32_t cap, uint32_t *__restrict__ count)
+__global__ __launch_bounds__(256) void long_redo_items_kernel(LongArgs a, WalkItem *__restrict__ out, uint32_t cap, uint32_t *__restrict__ count,
+                                                              uint32_t *__restrict__ flist)
 {
     const uint32_t piece = blockIdx.x * blockDim.x + threadIdx.x;
     if (piece >= a.n_items || !a.redo[piece]) return;
@@ -600,6 +630,7 @@ __global__ __launch_bounds__(256) void long_redo_items_kernel(LongArgs a, WalkIt
     const uint64_t seq0 = (uint64_t)it.x - it.y;     // the sequence's first byte
     const uint32_t lo = s > 0 ? s - 1u : 0u, hi = s + own_n, n_sub = (hi - lo + kLongSub - 1u) / kLongSub;
     const uint32_t base = atomicAdd(count, n_sub);
+    flist[atomicAdd(count + 1, 1u)] = piece; // (count + 1 = qctl[2]: the flagged pieces, listed for long_derand_kernel)
     const uint32_t warm_max = a.ix.k > 0 ? a.ix.k - 1u : 0u;
     for (uint32_t p = 0; p < n_sub; p++) {
         const uint32_t o0 = lo + p * kLongSub, o1 = min(o0 + kLongSub, hi), warm = min(o0, warm_max);
@@ -612,63 +643,106 @@ __global__ __launch_bounds__(256) void long_redo_items_kernel(LongArgs a, WalkIt
 }
 
 // derandomize_ms_vec (derandomize.rs:269-288) + translate_ms_vec (translate.rs:263-293) over the flagged pieces, literally, right to
-// left: one lane per RUN of flagged pieces - the lane of its rightmost piece, which starts from x of the base behind it (xin of the
-// unflagged piece to the right; the sequence's end: derandomize.rs:282) and goes on through the flagged pieces to its left
-__global__ __launch_bounds__(64) void long_derand_kernel(LongArgs a, const uint8_t *__restrict__ ms)
+// left: one WAVE per run of flagged pieces - the wave of its rightmost piece, which starts from x of the base behind it (xin of the
+// unflagged piece to the right; the sequence's end: derandomize.rs:282) and goes on through the flagged pieces to its left.  Per
+// piece the wave stages the MS bytes of [s - 1, e) (and the bases, for relative_to_ref) in LDS, one lane runs the recurrence over
+// them (a dependent chain of four operations per base), and the wave stores the characters in whole lines.
+constexpr uint32_t kLongDerandLds = 3u * 1040u;
+__global__ __launch_bounds__(64) void long_derand_kernel(LongArgs a, const uint8_t *__restrict__ ms, const uint32_t *__restrict__ flist)
 {
-    const uint32_t piece = blockIdx.x * blockDim.x + threadIdx.x;
-    if (piece >= a.n_items || !a.redo[piece]) return;
+    __shared__ __attribute__((aligned(16))) uint8_t dl_lds[kLongDerandLds];
+    uint8_t *msl = dl_lds, *ql = dl_lds + 1040, *ol = dl_lds + 2080;
+    const uint32_t lane = threadIdx.x;
     const uint4 *items = reinterpret_cast<const uint4 *>(a.items);
-    const uint4 it = items[piece];
-    const uint32_t own0 = it.w & 0x3FFu, own_n = (it.w >> 10) & 0x7FFu, seqlen = it.z;
-    if (own_n == 0) return;
-    const uint32_t s = it.y + own0, e = s + own_n; // own bases [s, e) of the sequence
-    const bool at_end = e >= seqlen;
-    if (!at_end && piece + 1u < a.n_items && a.redo[piece + 1u]) return; // (the lane of a piece further right takes this one)
-    const uint64_t seq0 = (uint64_t)it.x - it.y;
-    const uint8_t *m = ms + seq0;
-    const uint8_t *qs = a.q + seq0;
-    uint8_t *out = a.chars_out + seq0;
+    const uint32_t n_flagged = min(a.qctl[2], a.n_items);
     const int K = (int)a.ix.k, T = (int)a.thr;
-    // the run's first base: back over the flagged pieces of this sequence
-    uint32_t lo = s, pp = piece;
-    while (lo > 0 && pp > 0 && a.redo[pp - 1u]) {
-        const uint4 pit = items[pp - 1u];
-        const uint32_t p_n = (pit.w >> 10) & 0x7FFu, p_s = pit.y + (pit.w & 0x3FFu);
-        if (p_n == 0 || (uint64_t)pit.x - pit.y != seq0 || p_s + p_n != lo) break;
-        lo = p_s;
-        pp--;
-    }
     auto step = [&](int av, int x) { return av == K ? K : ((av > T && x < av) ? av : x - 1); };
     auto val = [&](int cur, int next, int prev) -> uint32_t { // translate_ms_val's first character
         if (cur > T && next > 0 && next < T) return (uint32_t)'R';
         if (cur <= 0) return (next == 1 && prev > 0) ? (uint32_t)'X' : (uint32_t)'-';
         return (uint32_t)'M';
     };
-    // x[p] for p = e - 1 down to lo - 1 (the base in front of the run gives `prev` of its first base); characters of [lo, e)
-    int x_next, x_cur;
-    uint32_t p = e - 1u;
-    if (at_end) {
-        const int av = m[p];
-        x_cur = av > T ? av : 0; // derandomize.rs:282
-        x_next = x_cur;          // translate.rs:279: next of the last base is its own value
-    } else {
-        x_next = (int)a.xin[piece + 1u];
-        x_cur = step((int)m[p], x_next);
-    }
-    for (;;) {
-        const int x_prev = p > 0 ? step((int)m[p - 1u], x_cur) : K;
-        const int prev = p > 1 ? x_prev : K; // translate.rs:277
-        // res[p] = 'R' when 2 <= p < len - 1 and the base in front starts an ('R','R') (translate.rs:282-288), else val(..).0
-        uint32_t ch;
-        if (p >= 2u && p < seqlen - 1u && x_prev > T && x_cur > 0 && x_cur < T) ch = (uint32_t)'R';
-        else ch = val(x_cur, p + 1u < seqlen ? x_next : x_cur, prev);
-        if (a.fmt) ch = (ch == (uint32_t)'M' || ch == (uint32_t)'R') ? (uint32_t)qs[p] : (uint32_t)'-';
-        out[p] = (uint8_t)ch;
-        if (p == lo) break;
-        x_next = x_cur;
-        x_cur = x_prev;
-        p--;
+    for (uint32_t fi = blockIdx.x; fi < n_flagged; fi += gridDim.x) {
+        uint32_t piece = flist[fi];
+        uint4 it = items[piece];
+        uint32_t own0 = it.w & 0x3FFu, own_n = (it.w >> 10) & 0x7FFu;
+        const uint32_t seqlen = it.z;
+        if (own_n == 0) continue;
+        uint32_t s = it.y + own0, e = s + own_n; // own bases [s, e) of the sequence
+        const bool at_end = e >= seqlen;
+        if (!at_end && piece + 1u < a.n_items && a.redo[piece + 1u]) continue; // (the wave of a piece further right takes this one)
+        const uint64_t seq0 = (uint64_t)it.x - it.y;
+        const uint8_t *m = ms + seq0;
+        const uint8_t *qs = a.q + seq0;
+        uint8_t *out = a.chars_out + seq0;
+        int x_right = at_end ? 0 : (int)a.xin[piece + 1u]; // x of base e
+        for (bool first = true;; first = false) {
+            // the MS bytes of [s - 1, e) (index 0: base s - 1) and the bases of [s, e)
+            const uint32_t b0 = s > 0 ? s - 1u : 0u, skip = s > 0 ? 0u : 1u, n_ms = e - b0;
+            __syncthreads();
+            const uint64_t room = a.q_bytes - seq0; // bytes of the two buffers from the sequence's first on
+            for (uint32_t c = 16u * lane; c < n_ms; c += 1024u) {
+                if ((uint64_t)b0 + c + 16u <= room) {
+                    const uint4 v = ld16u(m, b0 + c);
+                    __builtin_memcpy(msl + skip + c, &v, 16);
+                } else
+                    for (uint32_t t = 0; t < 16u && c + t < n_ms; t++) msl[skip + c + t] = m[b0 + c + t];
+            }
+            if (a.fmt)
+                for (uint32_t c = 16u * lane; c < own_n; c += 1024u) {
+                    if ((uint64_t)s + c + 16u <= room) {
+                        const uint4 v = ld16u(qs, s + c);
+                        __builtin_memcpy(ql + c, &v, 16);
+                    } else
+                        for (uint32_t t = 0; t < 16u && c + t < own_n; t++) ql[c + t] = qs[s + c + t];
+                }
+            __syncthreads();
+            if (lane == 0) {
+                // x[p] for p = e - 1 down to s; msl[1 + (p - s)] = MS of base p, msl[0] = MS of base s - 1
+                int x_next, x_cur;
+                uint32_t p = e - 1u;
+                if (first && at_end) {
+                    const int av = msl[1u + (p - s)];
+                    x_cur = av > T ? av : 0; // derandomize.rs:282
+                    x_next = x_cur;          // translate.rs:279: next of the last base is its own value
+                } else {
+                    x_next = x_right;
+                    x_cur = step((int)msl[1u + (p - s)], x_next);
+                }
+                for (;;) {
+                    const int x_prev = p > 0 ? step((int)msl[p - s], x_cur) : K;
+                    const int prev = p > 1 ? x_prev : K; // translate.rs:277
+                    // res[p] = 'R' when 2 <= p < len - 1 and the base in front starts an ('R','R') (translate.rs:282-288), else val(..).0
+                    uint32_t ch;
+                    if (p >= 2u && p < seqlen - 1u && x_prev > T && x_cur > 0 && x_cur < T) ch = (uint32_t)'R';
+                    else ch = val(x_cur, p + 1u < seqlen ? x_next : x_cur, prev);
+                    if (a.fmt) ch = (ch == (uint32_t)'M' || ch == (uint32_t)'R') ? (uint32_t)ql[p - s] : (uint32_t)'-';
+                    ol[p - s] = (uint8_t)ch;
+                    if (p == s) break;
+                    x_next = x_cur;
+                    x_cur = x_prev;
+                    p--;
+                }
+                x_right = x_cur; // x of base s: what the piece to the left starts from
+            }
+            __syncthreads();
+            for (uint32_t c = 16u * lane; c < own_n; c += 1024u) {
+                uint4 v;
+                __builtin_memcpy(&v, ol + c, 16);
+                if (c + 16u <= own_n) __builtin_memcpy(out + s + c, &v, 16);
+                else st_partial(out + s + c, v, own_n - c);
+            }
+            x_right = __shfl(x_right, 0);
+            // the flagged piece to the left, if it is this sequence's
+            if (s == 0 || piece == 0 || !a.redo[piece - 1u]) break;
+            const uint4 pit = items[piece - 1u];
+            const uint32_t p_n = (pit.w >> 10) & 0x7FFu, p_s = pit.y + (pit.w & 0x3FFu);
+            if (p_n == 0 || (uint64_t)pit.x - pit.y != seq0 || p_s + p_n != s) break;
+            piece--;
+            s = p_s;
+            e = p_s + p_n;
+            own_n = p_n;
+        }
     }
 }
 
@@ -676,7 +750,7 @@ __global__ __launch_bounds__(64) void long_derand_kernel(LongArgs a, const uint8
 
 namespace {
 struct LongLayout {
-    size_t items, scan, redo, xin, ctl, pstats, subs, end;
+    size_t items, scan, redo, xin, flist, ctl, pstats, subs, end;
     uint32_t own, n_slots, sub_cap;
 };
 LongLayout long_layout(size_t n_seqs, uint64_t total_bases, uint32_t k)
@@ -694,7 +768,9 @@ LongLayout long_layout(size_t n_seqs, uint64_t total_bases, uint32_t k)
     w += (slots + 15) / 16 * 16;
     L.xin = w;
     w += (slots + 15) / 16 * 16;
-    L.ctl = w; // [0] pieces, [1] sub-items of the flagged pieces, [4] flagged pieces
+    L.flist = w;
+    w += (slots * 4 + 15) / 16 * 16;
+    L.ctl = w; // [0] pieces, [1] sub-items of the flagged pieces, [2] flagged pieces listed, [4] flagged pieces
     w += 256;
     L.pstats = w;
     w += kPlanStatSlots * kPlanStatWords * 4;
@@ -753,8 +829,11 @@ hipError_t launch_map_long(const DevIndexView &ix, const uint8_t *d_q, const uin
     a.pstats = reinterpret_cast<uint32_t *>(w + L.pstats);
     a.thr = thr;
     a.fmt = fmt ? 1u : 0u;
+    static const int env_x = std::getenv("KBO_LONG_X") ? std::atoi(std::getenv("KBO_LONG_X")) : 0; // experiments: phases left out (timing only)
+    a.xexp = (uint32_t)env_x;
     a.ca = ix.k + 1u;
     a.subs = w + L.subs;
+    a.flist = reinterpret_cast<uint32_t *>(w + L.flist);
     a.sub_cap = L.sub_cap;
     a.q_bytes = total_bases;
     static const int env_wpb = std::getenv("KBO_LONG_WPB") ? std::atoi(std::getenv("KBO_LONG_WPB")) : 4; // experiments: waves per workgroup
@@ -766,7 +845,8 @@ hipError_t launch_map_long(const DevIndexView &ix, const uint8_t *d_q, const uin
 // the flagged pieces: their matching statistics by the plain walk (into d_ms), then the literal recurrences
 hipError_t launch_map_long_redo(const LongArgs &a, uint8_t *d_ms, hipStream_t stream)
 {
-    hipLaunchKernelGGL(long_redo_items_kernel, dim3((a.n_items + 255u) / 256u), dim3(256), 0, stream, a, static_cast<WalkItem *>(a.subs), a.sub_cap, a.qctl + 1);
+    hipLaunchKernelGGL(long_redo_items_kernel, dim3((a.n_items + 255u) / 256u), dim3(256), 0, stream, a, static_cast<WalkItem *>(a.subs), a.sub_cap, a.qctl + 1,
+                       a.flist);
     WalkArgs wa{};
     wa.ix = a.ix;
     wa.q = a.q;
@@ -776,7 +856,8 @@ hipError_t launch_map_long_redo(const LongArgs &a, uint8_t *d_ms, hipStream_t st
     const uint32_t lanes = (uint32_t)std::min<uint64_t>((uint64_t)a.n_items * 2u + 4096u, a.sub_cap);
     hipError_t e = launch_walk_list(wa, static_cast<const WalkItem *>(a.subs), a.sub_cap, a.qctl + 1, lanes, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(long_derand_kernel, dim3((a.n_items + 63u) / 64u), dim3(64), 0, stream, a, d_ms);
+    // (a wave per run of flagged pieces; the list's length is on the device: the waves share it)
+    hipLaunchKernelGGL(long_derand_kernel, dim3(std::min<uint32_t>(a.n_items, 16384u)), dim3(64), 0, stream, a, d_ms, a.flist);
     return hipGetLastError();
 }
 
