@@ -129,6 +129,10 @@ int kbo_plan_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, 
  * item per sequence) left to the plain walk - flags_out[s] != 0 - read out of the launch's work buffer.  Arguments as for that call;
  * synchronises `stream`. */
 int kbo_plan_flags_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k, const void *d_work, uint8_t *flags_out, void *stream);
+/* the kernel for sequences of more than 160 bases (long_kernels.hip: one wave per piece of a sequence): 0 = never (such batches
+ * take the walk + the derandomize / translate kernels), 1 = wherever the index copy has what it needs (default), 2 = as 1 with
+ * EVERY piece sent to its second pass (plain walk + literal recurrences) - a test hook, exact like the others. */
+int kbo_set_map_long(int mode);
 /* inspection: what the last kbo_map_batch_dev / kbo_find_batch_dev call over sequences of more than 160 bases did when it took
  * the one kernel for sequences of any length (long_kernels.hip); arguments as for that call, synchronises `stream`.
  * out[0]: pieces, [1]: pieces whose proof failed (plain walk + literal recurrences), [2]: their sub-items, [3]: seed look-ups,

@@ -1194,6 +1194,12 @@ int kbo_plan_flags_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, 
     });
 }
 
+int kbo_set_map_long(int mode)
+{
+    kbo::set_map_long(mode);
+    return KBO_OK;
+}
+
 int kbo_long_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k, const void *d_work, uint64_t out[KBO_LONG_STATS],
                        void *stream)
 {

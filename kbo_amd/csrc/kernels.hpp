@@ -363,6 +363,7 @@ struct LongArgs {
     uint8_t *xin;         // per piece: the derandomised value of its first own base, 0 .. k (<= 0 as 0)
     uint32_t *qctl;       // [0] pieces, [1] sub-items of the flagged pieces, [2] flagged pieces listed, [4] flagged pieces
     uint32_t *pstats;     // work counters (kPlanStat*)
+    uint32_t ppw;         // consecutive pieces a wave takes
     uint32_t xexp;        // experiment switches (KBO_LONG_X): timing only, results are wrong with any of them
     uint32_t thr, fmt, ca; // derandomisation threshold, 1 = format::relative_to_ref on the way out, bases of a region behind the own ones
     void *subs;           // WalkItem records of the flagged pieces' sub-items
@@ -372,6 +373,7 @@ struct LongArgs {
 size_t long_work_bytes(size_t n_seqs, uint64_t total_bases, uint32_t k); // bytes of work memory of a launch (0: k too large)
 // true when the copy has what the kernel needs (depth table of fewer bases than the threshold, 2-bit text, seed positions)
 bool map_long_applies(const DevIndexView &ix, uint32_t thr);
+void set_map_long(int mode); // tuning / tests: see kbo_set_map_long
 hipError_t launch_map_long(const DevIndexView &ix, const uint8_t *d_q, const uint64_t *d_off, uint32_t n_seqs, uint64_t total_bases, uint32_t thr,
                            bool fmt, uint8_t *d_chars, void *d_work, hipStream_t stream, LongArgs &a);
 hipError_t launch_map_long_redo(const LongArgs &a, uint8_t *d_ms, hipStream_t stream);

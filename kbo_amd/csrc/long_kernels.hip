@@ -40,9 +40,12 @@
 #include "device_util.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 namespace kbo {
+std::atomic<int> g_map_long{1}; // kbo_set_map_long: 0 = never, 1 = where it applies, 2 = ... and every piece flagged (tests of the second pass)
+void set_map_long(int mode) { g_map_long = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 namespace {
 
 constexpr uint32_t kLongTextUnits = 76; // staged units of 16 text positions: 64 in front of the region's diagonal, 1024, 128 behind
@@ -51,7 +54,7 @@ constexpr uint32_t kLongTH = 6;         // mismatches in 16 bases that end a dia
 constexpr uint32_t kLongRun = 10;       // matching bases that start one
 constexpr uint32_t kLongLds = 2048;     // bytes of LDS per wave
 #ifndef KBO_LONG_WPE
-#define KBO_LONG_WPE 8
+#define KBO_LONG_WPE 4
 #endif
 
 __device__ __forceinline__ uint32_t funnel2(uint32_t hi, uint32_t lo, uint32_t r) // 16 digits from digit r of hi on
@@ -148,472 +151,564 @@ __global__ __launch_bounds__(256) void long_items_kernel(const uint64_t *__restr
     items[t] = it;
 }
 
+// the doubling chain of erode_end, kept for several lengths over the same bits
+struct EroChain {
+    uint64_t s1, s2, s4, s8, s16, s32;
+};
+__device__ __forceinline__ EroChain ero_chain(uint64_t h)
+{
+    EroChain c;
+    c.s1 = h;
+    c.s2 = h & (h << 1);
+    c.s4 = c.s2 & (c.s2 << 2);
+    c.s8 = c.s4 & (c.s4 << 4);
+    c.s16 = c.s8 & (c.s8 << 8);
+    c.s32 = c.s16 & (c.s16 << 16);
+    return c;
+}
+__device__ __forceinline__ uint64_t ero_at(const EroChain &c, uint32_t L) // AND over the L positions that end at each bit
+{
+    uint64_t r = ~0ull;
+    uint32_t pos = 0;
+    if (L & 32u) { r &= c.s32 << pos; pos += 32u; }
+    if (L & 16u) { r &= c.s16 << pos; pos += 16u; }
+    if (L & 8u) { r &= c.s8 << pos; pos += 8u; }
+    if (L & 4u) { r &= c.s4 << pos; pos += 4u; }
+    if (L & 2u) { r &= c.s2 << pos; pos += 2u; }
+    if (L & 1u) { r &= c.s1 << pos; }
+    return r;
+}
+
+// One wave takes a.ppw consecutive pieces, one after the other: the next piece's bases are on their way while this one is
+// worked on, and a piece that continues the sequence of the one before starts on that one's last diagonal - its text is
+// on its way too - instead of asking the seed table (a wrong guess is lost at once and found again like any lost diagonal).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WPE))) void map_long_kernel(LongArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t long_lds_all[];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t piece = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (piece >= a.n_items) return; // (wave-uniform; the waves of a workgroup share nothing)
+    const uint32_t p_first = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * a.ppw;
+    if (p_first >= a.n_items) return; // (wave-uniform; the waves of a workgroup share nothing)
+    const uint32_t n_mine = min(a.ppw, a.n_items - p_first);
     uint8_t *lds = long_lds_all + (threadIdx.x >> 6) * kLongLds;
     uint32_t *lin = reinterpret_cast<uint32_t *>(lds) + 2;              // digits of word w, w = -2 .. 67         (280 B)
     uint16_t *invl = reinterpret_cast<uint16_t *>(lds + 288) + 2;       // bytes that are no base, per word       (144 B)
     uint16_t *ufl = reinterpret_cast<uint16_t *>(lds + 432) + 2;        // U of the filter's strings, per word    (144 B)
-    uint16_t *zal = reinterpret_cast<uint16_t *>(lds + 576) + 2;        // the two planes, per word               (2 x 144 B)
-    uint16_t *zbl = reinterpret_cast<uint16_t *>(lds + 720) + 2;
-    uint2 *tx = reinterpret_cast<uint2 *>(lds + 864);                   // staged text units                      (608 B)
-    uint16_t *list = reinterpret_cast<uint16_t *>(lds + 864);           // look-ups: position | 0x400 ext | 0x800 last (768 B; where the
+    uint2 *tx = reinterpret_cast<uint2 *>(lds + 576);                   // staged text units                      (608 B)
+    uint16_t *list = reinterpret_cast<uint16_t *>(lds + 576);           // look-ups: position | 0x400 ext | 0x800 last (768 B; where the
                                                                         // text was: it is not needed any more when the list is made)
-
-    const uint4 it = reinterpret_cast<const uint4 *>(a.items)[piece];
-    const uint32_t q_off = it.x, g0 = it.y, seqlen = it.z, own0 = it.w & 0x3FFu, own_n = (it.w >> 10) & 0x7FFu;
-    if (own_n == 0 || seqlen < 3u) { // (a slot past the batch's last piece; derandomize.rs:274-276 asserts on fewer than 3 values: left unwritten)
-        if (lane == 0) a.redo[piece] = 0;
-        return;
-    }
-    const uint32_t r0 = q_off & 15u, base16 = q_off - r0;
-    const uint32_t R = min(seqlen - g0, own0 + own_n + a.ca), xe = r0 + R; // the region on the grid: [r0, xe)
-    const uint32_t nblk = (xe + 15u) >> 4;
     const uint32_t k = a.ix.k, thr = a.thr, order = a.ix.dtab_order;
     const int32_t xa = (int32_t)(16u * lane);
-
-    // ---- 0. the region -> 2-bit digits
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (lane < nblk) v = ld16(a.q, base16 + 16u * lane); // (reads <= 15 bytes in front of / behind the region: the buffer's own)
-    uint32_t code, valid;
-    pack16(v, code, valid);
-    const uint32_t inr16 = range16(xa, (int32_t)r0, (int32_t)xe);
-    const uint32_t inv16 = ~valid & inr16 & 0xFFFFu;
-    lin[lane] = code;
-    invl[lane] = (uint16_t)inv16;
+    const uint4 itv = lane < n_mine ? reinterpret_cast<const uint4 *>(a.items)[p_first + lane] : make_uint4(0, 0, 0, 0);
     if (lane < 2u) {
         lin[(int32_t)lane - 2] = 0;
         invl[(int32_t)lane - 2] = 0;
         ufl[(int32_t)lane - 2] = 0;
-        zal[(int32_t)lane - 2] = 0;
-        zbl[(int32_t)lane - 2] = 0;
     }
     if (lane < 4u) {
         lin[64u + lane] = 0;
         invl[64u + lane] = 0;
         ufl[64u + lane] = 0;
-        zal[64u + lane] = 0;
-        zbl[64u + lane] = 0;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    auto from_base = [&](uint32_t S) -> uint32_t { // 16 bases from S on, first one most significant
-        const uint32_t W = S >> 4, r = S & 15u;
-        return funnel2(lin[W], lin[W + 1u], r);
-    };
-    auto ending_at = [&](uint32_t E) -> uint64_t { // the 17 + E mod 16 bases ending at E, last one least significant
-        const uint32_t W = E >> 4, r = E & 15u;
-        const uint64_t V = ((uint64_t)lin[(int32_t)W - 1] << 32) | lin[W];
-        return V >> (2u * (15u - r));
-    };
-    auto base_at = [&](uint32_t S) -> uint32_t { return (lin[S >> 4] >> (2u * (15u - (S & 15u)))) & 3u; };
-    auto inv_span = [&](uint32_t E, uint32_t L) -> bool { // any byte that is no base among the L <= 33 positions ending at E
-        const int32_t W = (int32_t)(E >> 4);
-        const uint32_t r = E & 15u;
-        const uint64_t V = (uint64_t)invl[W - 2] | ((uint64_t)invl[W - 1] << 16) | ((uint64_t)invl[W] << 32);
-        return ((V >> (33u + r - L)) & ((1ull << L) - 1ull)) != 0;
-    };
-
-    if (a.xexp & 16u) return;
-    // ---- 1. stretches
+    const uint32_t F = a.ix.dfilt ? a.ix.dfilt_bases : 0u;
     const bool by_anchor = a.ix.anchor != nullptr && order >= 12u && order > a.ix.seed_d + 1u; // (as map_reads_kernel seeds)
     const uint32_t D = by_anchor ? order : a.ix.seed_d;
     const uint32_t dmask = D >= 16u ? 0xFFFFFFFFu : ((1u << (2u * D)) - 1u);
-    auto seed_at = [&](uint32_t e_) -> uint32_t { // text position of grid position e_ by the window that ends there (bit 31: one of several), or ~0
-        const uint64_t win = ending_at(e_);
-        if (!by_anchor) return a.ix.seed_pos[(uint32_t)win & dmask];
-        const uint64_t key = win & ((1ull << (2u * D)) - 1ull), amask = ((uint64_t)1 << a.ix.anchor_bits) - 1ull;
-        uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> (64u - a.ix.anchor_bits);
-        const uint32_t tag = (uint32_t)key + 1u;
-        for (uint32_t probe = 0; probe < 16u; probe++) {
-            const uint64_t slot = a.ix.anchor[h];
-            if (slot == 0) break;
-            if ((uint32_t)(slot >> 32) == tag) return (uint32_t)slot & 0x7FFFFFFFu;
-            h = (h + 1u) & amask;
-        }
-        return 0xFFFFFFFFu;
-    };
-    uint32_t st_seed = 0, st_look = 0, st_filt = 0, st_second = 0;
-    // windows ending at c + D - 1 + D j, j < nl: the first that ends one row only, else the first that ends any
-    auto seed_round = [&](uint32_t c, uint32_t nl, int32_t &dl, uint32_t &A) -> bool {
-        const uint32_t e_ = c + D - 1u + D * lane;
-        const bool ok = lane < nl && e_ < xe && !inv_span(e_, D);
-        uint32_t tp = 0xFFFFFFFFu;
-        if (ok) {
-            tp = seed_at(e_);
-            st_seed++;
-        }
-        const uint64_t hit_any = __ballot(tp != 0xFFFFFFFFu), hit_one = __ballot(tp != 0xFFFFFFFFu && !(tp >> 31));
-        if (!hit_any) return false;
-        const int src = (int)__builtin_ctzll(hit_one ? hit_one : hit_any);
-        const uint32_t tps = __shfl(tp, src) & 0x7FFFFFFFu, es = c + D - 1u + D * (uint32_t)src;
-        dl = (int32_t)tps - (int32_t)es;
-        A = es - D + 1u;
-        return true;
-    };
     const int32_t n_units = (int32_t)(((uint64_t)a.ix.n + kMapPad + 256u) / 16u + 2u); // (pack_text_units)
-    int32_t tbase = 0, stage_dl = 0;
-    bool staged = false;
-    auto stage_text = [&](int32_t dl) {
-        const int32_t u0 = (dl + (int32_t)kMapPad - 64) >> 4; // (arithmetic shift: floor)
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t c = lane; c < kLongTextUnits; c += 64u) {
-            const int32_t u = u0 + (int32_t)c;
-            tx[c] = (u >= 0 && u < n_units) ? a.ix.pc_tm[u] : make_uint2(0u, 0x55555555u);
-        }
-        tbase = u0 * 16 - (int32_t)kMapPad;
-        stage_dl = dl;
-        staged = true;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-    auto compare = [&](int32_t dl) -> uint32_t { // bit j: position 16 lane + j does not equal the text on diagonal dl (or is no base / outside)
-        const uint32_t idx0 = (uint32_t)(dl + xa - tbase), unit = idx0 >> 4, r = idx0 & 15u;
-        const uint2 t0 = tx[unit], t1 = tx[unit + 1u];
-        const uint32_t x = code ^ funnel2(t0.x, t1.x, r);
-        return grid_to_mask16(x | (x >> 1) | funnel2(t0.y, t1.y, r)) | inv16 | (~inr16 & 0xFFFFu);
-    };
-    // the assignment of a diagonal reaches back from A over sparse mismatches, up to a mismatch with TH of them in the 16 bases ending at it
-    auto left_start = [&](uint32_t mm, uint32_t A, int32_t lower) -> uint32_t {
-        const uint32_t m = mm & inr16 & range16(xa, lower, (int32_t)A);
-        const uint32_t view = shfl_up0(m, 1, lane) | (m << 16);
-        uint32_t hits = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < 16u; j++)
-            if (((m >> j) & 1u) && (uint32_t)__popc((view >> (j + 1u)) & 0xFFFFu) >= kLongTH) hits |= 1u << j;
-        const uint64_t bal = __ballot(hits != 0);
-        if (!bal) return (uint32_t)lower;
-        const int L = 63 - (int)__builtin_clzll(bal);
-        const uint32_t hl = __shfl(hits, L);
-        return 16u * (uint32_t)L + (31u - (uint32_t)__builtin_clz(hl)) + 1u;
-    };
+    const uint32_t cstep = thr - order, Mrun = cstep * (47u / cstep);
+    uint32_t st_seed = 0, st_look = 0, st_filt = 0, st_second = 0;
 
-    uint32_t ZA = 0, ZB = 0; // the planes: bit j = position 16 lane + j lies in a stretch
+    // the bases of the wave's first piece
+    uint4 vq = make_uint4(0, 0, 0, 0);
     {
-        int32_t endz[2] = {(int32_t)r0 - 1, (int32_t)r0 - 1};
-        const int32_t J = (int32_t)order - 3;
-        uint32_t cur = 0, c = r0, A = 0, start = 0, mm = 0;
-        int32_t dl = 0;
-        bool have = false;
-        for (uint32_t iter = 0; iter < 96u; iter++) {
-            if (!have) {
-                int32_t dn = 0;
-                uint32_t An = 0;
-                bool ok = seed_round(c, 4u, dn, An);
-                if (!ok) ok = seed_round(c + 4u * D, 64u, dn, An);
-                if (!ok) break;
-                dl = dn;
-                A = An;
-                have = true;
-                if (!staged || dl - stage_dl > 24 || stage_dl - dl > 24) stage_text(dl);
-                mm = compare(dl);
-                start = left_start(mm, A, max(max((int32_t)r0, endz[cur] + 1), endz[cur ^ 1u] - J));
-            }
-            // where the diagonal is lost: the first 16 bases from A on with TH mismatches; f = the first of them
-            uint32_t f = xe;
-            {
-                const uint32_t mr = mm & inr16;
-                const uint32_t view = mr | (shfl_down0(mr, 1, lane) << 16);
-                uint32_t loss = 0;
-#pragma unroll
-                for (uint32_t j = 0; j < 16u; j++)
-                    if ((uint32_t)__popc((view >> j) & 0xFFFFu) >= kLongTH) loss |= 1u << j;
-                loss &= range16(xa, (int32_t)A, (int32_t)xe);
-                const uint64_t bal = __ballot(loss != 0);
-                if (bal) {
-                    const int L = (int)__builtin_ctzll(bal);
-                    const uint32_t j = (uint32_t)__builtin_ctz(__shfl(loss, L));
-                    const uint32_t vw = __shfl(view, L) >> j;
-                    f = 16u * (uint32_t)L + j + (uint32_t)__builtin_ctz(vw);
-                }
-            }
-            const uint32_t add = range16(xa, (int32_t)start, (int32_t)f) & ~mm & 0xFFFFu;
-            if (cur == 0) ZA |= add;
-            else ZB |= add;
-            endz[cur] = (int32_t)f;
-            if (f >= xe) break;
-            // the next diagonal: of the 64 beside this one, the one on which the read goes on soonest - the first run of kLongRun
-            // matching bases among the 32 behind f (ties: the longer run, then the nearer diagonal)
-            bool found = false;
-            int32_t d2 = 0;
-            uint32_t A2 = 0;
-            if (f + 1u + kLongRun <= xe) {
-                const uint32_t S = f + 1u;
-                const uint32_t w0 = from_base(S), w1 = from_base(S + 16u);
-                const int32_t W = (int32_t)(S >> 4);
-                const uint64_t iv = ((uint64_t)invl[W] | ((uint64_t)invl[W + 1] << 16) | ((uint64_t)invl[W + 2] << 32)) >> (S & 15u);
-                const int32_t sft = (int32_t)lane - 32;
-                const uint32_t idx0 = (uint32_t)(dl + sft + (int32_t)S - tbase), unit = idx0 >> 4, r = idx0 & 15u;
-                const uint2 t0 = tx[unit], t1 = tx[unit + 1u], t2 = tx[unit + 2u];
-                const uint32_t x0 = w0 ^ funnel2(t0.x, t1.x, r), x1 = w1 ^ funnel2(t1.x, t2.x, r);
-                uint32_t m32 = grid_to_mask16(x0 | (x0 >> 1) | funnel2(t0.y, t1.y, r)) | (grid_to_mask16(x1 | (x1 >> 1) | funnel2(t1.y, t2.y, r)) << 16) |
-                               (uint32_t)iv;
-                const uint32_t n_in = xe - S;
-                if (n_in < 32u) m32 |= ~0u << n_in;
-                const uint32_t z = ~m32, e2 = z & (z >> 1), e4 = e2 & (e2 >> 2), e8 = e4 & (e4 >> 4), e10 = e8 & (e2 >> 8);
-                uint32_t key = 0xFFFFFFFFu;
-                if (e10) {
-                    const uint32_t at = (uint32_t)__builtin_ctz(e10);
-                    const uint32_t rest = ~(z >> at); // (bit `run`: the first mismatch behind the run; beyond bit 31 - at: zeros shifted in read as mismatches)
-                    const uint32_t run = rest ? (uint32_t)__builtin_ctz(rest) : 32u;
-                    const uint32_t as = (uint32_t)(sft < 0 ? -sft : sft);
-                    key = (at << 16) | ((63u - run) << 8) | (as << 1) | (sft > 0 ? 1u : 0u);
-                }
-                uint32_t best = key;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor(best, o));
-                if (best != 0xFFFFFFFFu) {
-                    const uint32_t as = (best >> 1) & 0x7Fu;
-                    found = true;
-                    d2 = dl + ((best & 1u) ? (int32_t)as : -(int32_t)as);
-                    A2 = S + (best >> 16);
-                }
-            }
-            if (!found) found = seed_round(f + 4u, 4u, d2, A2);
-            if (!found) {
-                have = false;
-                c = f + 4u + 4u * D;
-                continue;
-            }
-            if (d2 == dl) { // the same diagonal after all (a cluster of substitutions): on with it
-                start = f;
-                A = A2;
-                continue;
-            }
-            if (d2 - stage_dl > 24 || stage_dl - d2 > 24) stage_text(d2);
-            mm = compare(d2);
-            cur ^= 1u;
-            start = left_start(mm, A2, max(max((int32_t)r0, (int32_t)f - J), endz[cur] + 1));
-            dl = d2;
-            A = A2;
-        }
+        const uint32_t q0 = __shfl(itv.x, 0), g00 = __shfl(itv.y, 0), sl0 = __shfl(itv.z, 0), w0 = __shfl(itv.w, 0);
+        const uint32_t R0 = min(sl0 - g00, (w0 & 0x3FFu) + ((w0 >> 10) & 0x7FFu) + a.ca), n0 = ((q0 & 15u) + R0 + 15u) >> 4;
+        if (((w0 >> 10) & 0x7FFu) != 0u && lane < n0) vq = ld16(a.q, (q0 & ~15u) + 16u * lane);
     }
+    bool pred = false;      // this piece goes on where the last one ended: on diagonal pred_dl, with its text in tn0 / tn1 (units from pred_u0 on)
+    int32_t pred_dl = 0, pred_u0 = 0;
+    uint2 tn0 = make_uint2(0, 0), tn1 = make_uint2(0, 0);
 
-    if (a.xexp & 32u) return;
-    // ---- 2. the planes -> G, cov, characters, U
-    auto hist64 = [&](uint32_t z) -> uint64_t { // positions [16 (lane - 3), 16 lane + 16): this lane's at bits 48 .. 63
-        return (uint64_t)shfl_up0(z, 3, lane) | ((uint64_t)shfl_up0(z, 2, lane) << 16) | ((uint64_t)shfl_up0(z, 1, lane) << 32) | ((uint64_t)z << 48);
-    };
-    auto fwd64 = [&](uint32_t z) -> uint64_t { // positions [16 lane, 16 lane + 64)
-        return (uint64_t)z | ((uint64_t)shfl_down0(z, 1, lane) << 16) | ((uint64_t)shfl_down0(z, 2, lane) << 32) | ((uint64_t)shfl_down0(z, 3, lane) << 48);
-    };
-    const uint64_t HA = hist64(ZA), HB = hist64(ZB);
-    const uint32_t G = (uint32_t)((erode_end(HA, thr + 1u) | erode_end(HB, thr + 1u)) >> 48);
-    const uint32_t cov = (uint32_t)dilate_fwd(fwd64(G), thr + 1u) & 0xFFFFu;
-    const uint32_t cov_prev = ((cov << 1) | (shfl_up0(cov, 1, lane) >> 15)) & 0xFFFFu;
-    const uint32_t cov_next = ((cov >> 1) | (shfl_down0(cov, 1, lane) << 15)) & 0xFFFFu;
-    const uint32_t G_next = ((G >> 1) | (shfl_down0(G, 1, lane) << 15)) & 0xFFFFu;
-    // (positions of the sequence: grid x stands for base g0 + x - r0)
-    const int32_t gx = (int32_t)r0 - (int32_t)g0; // grid position of the sequence's base 0 (may be negative)
-    const uint32_t first_two = range16(xa, gx, gx + 2);
-    const uint32_t isX = ~cov & cov_next & (cov_prev | first_two) & inr16;
-    const uint32_t R1 = G & ~G_next & cov_next;
-    // (the second 'R' at base p needs 2 <= p < len - 1: translate.rs:282-288)
-    const uint32_t R2 = ((R1 << 1) | (shfl_up0(R1, 1, lane) >> 15)) & range16(xa, gx + 2, gx + (int32_t)min(seqlen - 1u, 0x3FFFFFFFu));
-    const uint32_t isR = (R1 | R2) & 0xFFFFu;
-    const uint32_t isM = cov & ~isR;
-    const uint32_t U = ~(uint32_t)((erode_end(HA, order) | erode_end(HB, order)) >> 48) & inr16 & range16(xa, (int32_t)(r0 + order - 1u), (int32_t)xe);
-    const uint32_t F = a.ix.dfilt ? a.ix.dfilt_bases : 0u;
-    if (F) ufl[lane] = (uint16_t)(~(uint32_t)((erode_end(HA, F) | erode_end(HB, F)) >> 48) & inr16 & range16(xa, (int32_t)(r0 + F - 1u), (int32_t)xe));
-    zal[lane] = (uint16_t)ZA;
-    zbl[lane] = (uint16_t)ZB;
+    for (uint32_t pi = 0; pi < n_mine; pi++) {
+        const uint32_t piece = p_first + pi;
+        const uint32_t q_off = __shfl(itv.x, (int)pi), g0 = __shfl(itv.y, (int)pi), seqlen = __shfl(itv.z, (int)pi), itw = __shfl(itv.w, (int)pi);
+        const uint32_t own0 = itw & 0x3FFu, own_n = (itw >> 10) & 0x7FFu;
+        // (the next piece, whose bases are asked for as soon as this one's are in LDS)
+        const bool have_next = pi + 1u < n_mine;
+        const uint32_t nq_off = have_next ? __shfl(itv.x, (int)pi + 1) : 0u, ng0 = have_next ? __shfl(itv.y, (int)pi + 1) : 0u,
+                       nseqlen = have_next ? __shfl(itv.z, (int)pi + 1) : 0u, nitw = have_next ? __shfl(itv.w, (int)pi + 1) : 0u;
+        const uint32_t nown0 = nitw & 0x3FFu, nown_n = (nitw >> 10) & 0x7FFu;
+        const uint32_t nR = min(nseqlen - ng0, nown0 + nown_n + a.ca), nnblk = ((nq_off & 15u) + nR + 15u) >> 4;
+        const bool skip = own_n == 0 || seqlen < 3u; // (a slot past the batch's last piece; derandomize.rs:274-276 asserts on fewer than 3 values: left unwritten)
+        const uint32_t r0 = q_off & 15u, base16 = q_off - r0;
+        const uint32_t R = min(seqlen - g0, own0 + own_n + a.ca), xe = r0 + R; // the region on the grid: [r0, xe)
 
-    // ---- 3. the proof
-    bool flag = false;
-    if (!(a.xexp & 1u)) {
-        const uint32_t c = thr - order, M = c * (47u / c);
-        uint64_t apmask = 0;
-        for (uint32_t p = 0; p <= M; p += c) apmask |= 1ull << p;
-        uint32_t gridm = 0; // positions of this word that are multiples of c
-        for (uint32_t j = ((uint32_t)xa + c - 1u) / c * c - (uint32_t)xa; j < 16u; j += c) gridm |= 1u << j;
-        const uint64_t HU = hist64(U);
-        const uint32_t U_next = ((U >> 1) | (shfl_down0(U, 1, lane) << 15)) & 0xFFFFu;
-        uint32_t normal = 0, lastf = 0, extn = 0;
-        uint32_t um = U;
-        while (um) {
-            const uint32_t j = (uint32_t)__builtin_ctz(um);
-            um &= um - 1u;
-            const uint64_t h48 = (HU >> j) & 0xFFFFFFFFFFFFull;
-            const uint32_t rl = (uint32_t)__builtin_clzll(~(h48 << 16)); // U positions right in front of this one (48: that many or more)
-            const bool point = rl <= M ? ((apmask >> rl) & 1ull) != 0 : ((gridm >> j) & 1u) != 0;
-            const bool last = !((U_next >> j) & 1u);
-            if (point) {
-                normal |= 1u << j;
-                if (last) lastf |= 1u << j;
-            } else if (last) {
-                if ((uint32_t)xa + j + 1u < xe) extn |= 1u << j;
-                else normal |= 1u << j;
-            }
+        // ---- 0. the region -> 2-bit digits
+        uint32_t code = 0, valid = 0xFFFFu;
+        if (!skip) {
+            bool anyinv;
+            pack16_whole(vq, code, anyinv);
+            const uint32_t inr_ = range16(xa, (int32_t)r0, (int32_t)xe);
+            // (a byte that is no base, or this lane's word is not all the region's: the per-byte mask)
+            if (__ballot(anyinv && inr_ != 0u)) pack16(vq, code, valid);
         }
-        const uint32_t ext = ((extn << 1) | (shfl_up0(extn, 1, lane) >> 15)) & 0xFFFFu;
-        const uint32_t mine = (uint32_t)__popc(normal) + (uint32_t)__popc(ext);
-        uint32_t incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o);
-            if ((int)lane >= o) incl += t;
+        if (have_next && nown_n != 0u) {
+            vq = make_uint4(0, 0, 0, 0);
+            if (lane < nnblk) vq = ld16(a.q, (nq_off & ~15u) + 16u * lane); // (reads <= 15 bytes in front of / behind the region: the buffer's own)
         }
-        const uint32_t total = __shfl(incl, 63);
-        __builtin_amdgcn_wave_barrier(); // (the list goes where the text was)
-        if (total > kLongListCap) flag = true;
-        else {
-            uint32_t at = incl - mine;
-            uint32_t nm = normal;
-            while (nm) {
-                const uint32_t j = (uint32_t)__builtin_ctz(nm);
-                nm &= nm - 1u;
-                list[at++] = (uint16_t)(((uint32_t)xa + j) | (((lastf >> j) & 1u) ? 0x800u : 0u));
-            }
-            uint32_t em = ext;
-            while (em) {
-                const uint32_t j = (uint32_t)__builtin_ctz(em);
-                em &= em - 1u;
-                list[at++] = (uint16_t)(((uint32_t)xa + j) | 0x400u);
-            }
+        if (skip) {
+            if (lane == 0) a.redo[piece] = 0;
+            pred = false;
+            continue;
         }
+        const uint32_t inr16 = range16(xa, (int32_t)r0, (int32_t)xe);
+        const uint32_t inv16 = ~valid & inr16 & 0xFFFFu;
+        __builtin_amdgcn_wave_barrier();
+        lin[lane] = code;
+        invl[lane] = (uint16_t)inv16;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint64_t omask = (1ull << (2u * order)) - 1ull;
-        auto table = [&](uint32_t e_, uint32_t g) -> uint32_t { // the entry of the window ending at e_ (g: its place in the grouped line)
-            const uint64_t key = ending_at(e_) & omask;
-            st_look++;
-            return a.ix.dtab_grouped ? a.ix.dtab[dtab_grouped_addr(key, g, order)] : a.ix.dtab[key];
+        if (a.xexp & 16u) continue;
+
+        auto from_base = [&](uint32_t S) -> uint32_t { // 16 bases from S on, first one most significant
+            const uint32_t W = S >> 4, r = S & 15u;
+            return funnel2(lin[W], lin[W + 1u], r);
         };
-        // the window ending at e_ is in the index AND the read's base in front of it extends it
-        auto present_ext = [&](uint32_t byte, uint32_t e_) -> bool {
-            return (byte & 0x80u) && e_ >= r0 + order && !inv_span(e_ - order, 1u) && ((byte >> base_at(e_ - order)) & 1u);
+        auto ending_at = [&](uint32_t E) -> uint64_t { // the 17 + E mod 16 bases ending at E, last one least significant
+            const uint32_t W = E >> 4, r = E & 15u;
+            const uint64_t V = ((uint64_t)lin[(int32_t)W - 1] << 32) | lin[W];
+            return V >> (2u * (15u - r));
         };
-        for (uint32_t i0 = 0; !flag && i0 < total; i0 += 64u) {
-            const uint32_t i = i0 + lane;
-            bool act = i < total;
-            const uint32_t ent = act ? (uint32_t)list[i] : 0u;
-            const uint32_t x = ent & 0x3FFu;
-            const bool is_ext = (ent & 0x400u) != 0, is_last = (ent & 0x800u) != 0;
-            // (a window with a byte that is no base is in no index; the string an ext look-up asks about holds the base in front)
-            if (act && (inv_span(x, order) || (is_ext && inv_span(x - order, 1u)))) act = false;
-            if (F && !(a.xexp & 2u)) { // the filter: a string of F bases of the window that lies in no single stretch - absent: so is the window
-                bool fl = false;
-                uint32_t ef = 0;
-                if (act && is_ext) {
-                    ef = x - order + F - 1u;
-                    fl = true;
-                } else if (act) {
-                    const int32_t W = (int32_t)(x >> 4);
-                    const uint32_t r = x & 15u;
-                    uint32_t V = (uint32_t)ufl[W - 1] | ((uint32_t)ufl[W] << 16); // positions 16 (W - 1) .. 16 W + 15
-                    V &= (2u << (16u + r)) - 1u;                                // <= x
-                    const uint32_t lowbit = 16u + r - (order - F);              // >= x - order + F
-                    V &= ~((1u << lowbit) - 1u);
-                    if (V) {
-                        ef = 16u * (uint32_t)(W - 1) + (31u - (uint32_t)__builtin_clz(V));
-                        fl = true;
+        auto base_at = [&](uint32_t S) -> uint32_t { return (lin[S >> 4] >> (2u * (15u - (S & 15u)))) & 3u; };
+        auto inv_span = [&](uint32_t E, uint32_t L) -> bool { // any byte that is no base among the L <= 33 positions ending at E
+            const int32_t W = (int32_t)(E >> 4);
+            const uint32_t r = E & 15u;
+            const uint64_t V = (uint64_t)invl[W - 2] | ((uint64_t)invl[W - 1] << 16) | ((uint64_t)invl[W] << 32);
+            return ((V >> (33u + r - L)) & ((1ull << L) - 1ull)) != 0;
+        };
+
+        // ---- 1. stretches
+        auto seed_at = [&](uint32_t e_) -> uint32_t { // text position of grid position e_ by the window that ends there (bit 31: one of several), or ~0
+            const uint64_t win = ending_at(e_);
+            if (!by_anchor) return a.ix.seed_pos[(uint32_t)win & dmask];
+            const uint64_t key = win & ((1ull << (2u * D)) - 1ull), amask = ((uint64_t)1 << a.ix.anchor_bits) - 1ull;
+            uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> (64u - a.ix.anchor_bits);
+            const uint32_t tag = (uint32_t)key + 1u;
+            for (uint32_t probe = 0; probe < 16u; probe++) {
+                const uint64_t slot = a.ix.anchor[h];
+                if (slot == 0) break;
+                if ((uint32_t)(slot >> 32) == tag) return (uint32_t)slot & 0x7FFFFFFFu;
+                h = (h + 1u) & amask;
+            }
+            return 0xFFFFFFFFu;
+        };
+        // windows ending at c + D - 1 + D j, j < nl: the first that ends one row only, else the first that ends any
+        auto seed_round = [&](uint32_t c, uint32_t nl, int32_t &dl, uint32_t &A) -> bool {
+            const uint32_t e_ = c + D - 1u + D * lane;
+            const bool ok = lane < nl && e_ < xe && !inv_span(e_, D);
+            uint32_t tp = 0xFFFFFFFFu;
+            if (ok) {
+                tp = seed_at(e_);
+                st_seed++;
+            }
+            const uint64_t hit_any = __ballot(tp != 0xFFFFFFFFu), hit_one = __ballot(tp != 0xFFFFFFFFu && !(tp >> 31));
+            if (!hit_any) return false;
+            const int src = (int)__builtin_ctzll(hit_one ? hit_one : hit_any);
+            const uint32_t tps = __shfl(tp, src) & 0x7FFFFFFFu, es = c + D - 1u + D * (uint32_t)src;
+            dl = (int32_t)tps - (int32_t)es;
+            A = es - D + 1u;
+            return true;
+        };
+        int32_t tbase = 0, stage_dl = 0;
+        bool staged = false;
+        auto stage_text = [&](int32_t dl) {
+            const int32_t u0 = (dl + (int32_t)kMapPad - 64) >> 4; // (arithmetic shift: floor)
+            for (uint32_t c = lane; c < kLongTextUnits; c += 64u) {
+                const int32_t u = u0 + (int32_t)c;
+                tx[c] = (u >= 0 && u < n_units) ? a.ix.pc_tm[u] : make_uint2(0u, 0x55555555u);
+            }
+            tbase = u0 * 16 - (int32_t)kMapPad;
+            stage_dl = dl;
+            staged = true;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        auto compare = [&](int32_t dl) -> uint32_t { // bit j: position 16 lane + j does not equal the text on diagonal dl (or is no base / outside)
+            const uint32_t idx0 = (uint32_t)(dl + xa - tbase), unit = idx0 >> 4, r = idx0 & 15u;
+            const uint2 t0 = tx[unit], t1 = tx[unit + 1u];
+            const uint32_t x = code ^ funnel2(t0.x, t1.x, r);
+            return grid_to_mask16(x | (x >> 1) | funnel2(t0.y, t1.y, r)) | inv16 | (~inr16 & 0xFFFFu);
+        };
+        // the assignment of a diagonal reaches back from A over sparse mismatches, up to a mismatch with TH of them in the 16 bases ending at it
+        auto left_start = [&](uint32_t mm, uint32_t A, int32_t lower) -> uint32_t {
+            const uint32_t m = mm & inr16 & range16(xa, lower, (int32_t)A);
+            const uint32_t view = shfl_up0(m, 1, lane) | (m << 16);
+            uint32_t hits = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 16u; j++)
+                if (((m >> j) & 1u) && (uint32_t)__popc((view >> (j + 1u)) & 0xFFFFu) >= kLongTH) hits |= 1u << j;
+            const uint64_t bal = __ballot(hits != 0);
+            if (!bal) return (uint32_t)lower;
+            const int L = 63 - (int)__builtin_clzll(bal);
+            const uint32_t hl = __shfl(hits, L);
+            return 16u * (uint32_t)L + (31u - (uint32_t)__builtin_clz(hl)) + 1u;
+        };
+
+        uint32_t ZA = 0, ZB = 0; // the planes: bit j = position 16 lane + j lies in a stretch
+        bool end_on_diag = false; // the region's last bases lie on the diagonal end_dl
+        int32_t end_dl = 0;
+        {
+            int32_t endz[2] = {(int32_t)r0 - 1, (int32_t)r0 - 1};
+            const int32_t J = (int32_t)order - 3;
+            uint32_t cur = 0, c = r0, A = 0, start = 0, mm = 0;
+            int32_t dl = 0;
+            bool have = false;
+            if (pred) { // on from the piece before: its last diagonal, the text already here
+                tx[lane] = tn0;
+                if (lane < kLongTextUnits - 64u) tx[64u + lane] = tn1;
+                tbase = pred_u0 * 16 - (int32_t)kMapPad;
+                stage_dl = pred_dl;
+                staged = true;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                dl = pred_dl;
+                have = true;
+                A = start = r0;
+                mm = compare(dl);
+            }
+            for (uint32_t iter = 0; iter < 96u; iter++) {
+                if (!have) {
+                    int32_t dn = 0;
+                    uint32_t An = 0;
+                    bool ok = seed_round(c, 4u, dn, An);
+                    if (!ok) ok = seed_round(c + 4u * D, 64u, dn, An);
+                    if (!ok) break;
+                    dl = dn;
+                    A = An;
+                    have = true;
+                    if (!staged || dl - stage_dl > 24 || stage_dl - dl > 24) stage_text(dl);
+                    mm = compare(dl);
+                    start = left_start(mm, A, max(max((int32_t)r0, endz[cur] + 1), endz[cur ^ 1u] - J));
+                }
+                // where the diagonal is lost: the first 16 bases from A on with TH mismatches; f = the first of them
+                uint32_t f = xe;
+                {
+                    const uint32_t mr = mm & inr16;
+                    const uint32_t view = mr | (shfl_down0(mr, 1, lane) << 16);
+                    uint32_t loss = 0;
+                    if (__ballot((uint32_t)__popc(view) >= kLongTH)) { // (no word pair with TH mismatches: nothing is lost)
+#pragma unroll
+                        for (uint32_t j = 0; j < 16u; j++)
+                            if ((uint32_t)__popc((view >> j) & 0xFFFFu) >= kLongTH) loss |= 1u << j;
+                        loss &= range16(xa, (int32_t)A, (int32_t)xe);
+                    }
+                    const uint64_t bal = __ballot(loss != 0);
+                    if (bal) {
+                        const int L = (int)__builtin_ctzll(bal);
+                        const uint32_t j = (uint32_t)__builtin_ctz(__shfl(loss, L));
+                        const uint32_t vw = __shfl(view, L) >> j;
+                        f = 16u * (uint32_t)L + j + (uint32_t)__builtin_ctz(vw);
                     }
                 }
-                if (fl) {
-                    const uint32_t fk = (uint32_t)ending_at(ef) & ((1u << (2u * F)) - 1u);
-                    st_filt++;
-                    if (!((a.ix.dfilt[fk >> 5] >> (fk & 31u)) & 1u)) act = false; // absent
+                const uint32_t add = range16(xa, (int32_t)start, (int32_t)f) & ~mm & 0xFFFFu;
+                if (cur == 0) ZA |= add;
+                else ZB |= add;
+                endz[cur] = (int32_t)f;
+                if (f >= xe) {
+                    end_on_diag = true;
+                    end_dl = dl;
+                    break;
                 }
-            }
-            uint32_t byte = 0;
-            if (act && !(a.xexp & 4u)) byte = table(x, 1u);
-            bool fail = false;
-            bool need_back = false, need_on = false;
-            if (act && is_ext) fail = present_ext(byte, x);
-            else if (act && (byte & 0x80u)) {
-                need_back = present_ext(byte, x);
-                need_on = is_last && x + 1u < xe;
-            }
-            if (__ballot(need_back)) { // something of order + 1 bases ends here: nothing of order + 2 may
-                if (need_back) {
-                    st_second++;
-                    if (x < r0 + order) fail = true; // (no window one base back inside the region)
-                    else if (!inv_span(x - 1u, order)) fail = present_ext(table(x - 1u, 0u), x - 1u);
+                // the next diagonal: of the 64 beside this one, the one on which the read goes on soonest - the first run of kLongRun
+                // matching bases among the 32 behind f (ties: the longer run, then the nearer diagonal)
+                bool found = false;
+                int32_t d2 = 0;
+                uint32_t A2 = 0;
+                if (f + 1u + kLongRun <= xe) {
+                    const uint32_t S = f + 1u;
+                    const uint32_t w0 = from_base(S), w1 = from_base(S + 16u);
+                    const int32_t W = (int32_t)(S >> 4);
+                    const uint64_t iv = ((uint64_t)invl[W] | ((uint64_t)invl[W + 1] << 16) | ((uint64_t)invl[W + 2] << 32)) >> (S & 15u);
+                    const int32_t sft = (int32_t)lane - 32;
+                    const uint32_t idx0 = (uint32_t)(dl + sft + (int32_t)S - tbase), unit = idx0 >> 4, r = idx0 & 15u;
+                    const uint2 t0 = tx[unit], t1 = tx[unit + 1u], t2 = tx[unit + 2u];
+                    const uint32_t x0 = w0 ^ funnel2(t0.x, t1.x, r), x1 = w1 ^ funnel2(t1.x, t2.x, r);
+                    uint32_t m32 = grid_to_mask16(x0 | (x0 >> 1) | funnel2(t0.y, t1.y, r)) | (grid_to_mask16(x1 | (x1 >> 1) | funnel2(t1.y, t2.y, r)) << 16) |
+                                   (uint32_t)iv;
+                    const uint32_t n_in = xe - S;
+                    if (n_in < 32u) m32 |= ~0u << n_in;
+                    const uint32_t z = ~m32, e2 = z & (z >> 1), e4 = e2 & (e2 >> 2), e8 = e4 & (e4 >> 4), e10 = e8 & (e2 >> 8);
+                    uint32_t key = 0xFFFFFFFFu;
+                    if (e10) {
+                        const uint32_t at = (uint32_t)__builtin_ctz(e10);
+                        const uint32_t rest = ~(z >> at); // (bit `run`: the first mismatch behind the run; beyond bit 31 - at: zeros shifted in read as mismatches)
+                        const uint32_t run = rest ? (uint32_t)__builtin_ctz(rest) : 32u;
+                        const uint32_t as = (uint32_t)(sft < 0 ? -sft : sft);
+                        key = (at << 16) | ((63u - run) << 8) | (as << 1) | (sft > 0 ? 1u : 0u);
+                    }
+                    uint32_t best = key;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor(best, o));
+                    if (best != 0xFFFFFFFFu) {
+                        const uint32_t as = (best >> 1) & 0x7Fu;
+                        found = true;
+                        d2 = dl + ((best & 1u) ? (int32_t)as : -(int32_t)as);
+                        A2 = S + (best >> 16);
+                    }
                 }
-            }
-            if (__ballot(need_on)) { // the run's last window is present: the one inside the next stretch must not be extended by the base in front
-                if (need_on && !fail) {
-                    st_second++;
-                    if (!inv_span(x + 1u, order + 1u)) fail = present_ext(table(x + 1u, 2u), x + 1u);
+                if (!found) found = seed_round(f + 4u, 4u, d2, A2);
+                if (!found) {
+                    have = false;
+                    c = f + 4u + 4u * D;
+                    continue;
                 }
+                if (d2 == dl) { // the same diagonal after all (a cluster of substitutions): on with it
+                    start = f;
+                    A = A2;
+                    continue;
+                }
+                if (d2 - stage_dl > 24 || stage_dl - d2 > 24) stage_text(d2);
+                mm = compare(d2);
+                cur ^= 1u;
+                start = left_start(mm, A2, max(max((int32_t)r0, (int32_t)f - J), endz[cur] + 1));
+                dl = d2;
+                A = A2;
             }
-            if (__ballot(fail)) flag = true;
         }
-    }
+        // the piece that goes on with this sequence: its diagonal (in its own grid) and its text, asked for now
+        pred = false;
+        if (have_next && nown_n != 0u && end_on_diag && nown0 != 0u && nq_off - ng0 == q_off - g0 && ng0 + nown0 == g0 + own0 + own_n) {
+            pred = true;
+            pred_dl = end_dl + ((int32_t)r0 - (int32_t)g0) - ((int32_t)(nq_off & 15u) - (int32_t)ng0);
+            pred_u0 = (pred_dl + (int32_t)kMapPad - 64) >> 4;
+            const int32_t u_a = pred_u0 + (int32_t)lane, u_b = u_a + 64;
+            tn0 = (u_a >= 0 && u_a < n_units) ? a.ix.pc_tm[u_a] : make_uint2(0u, 0x55555555u);
+            tn1 = (lane < kLongTextUnits - 64u && u_b >= 0 && u_b < n_units) ? a.ix.pc_tm[u_b] : make_uint2(0u, 0x55555555u);
+        }
+        if (a.xexp & 32u) continue;
 
-    // ---- 4. the characters of the own bases, in whole lines; format::relative_to_ref (format.rs:270-286) on the way
-    {
-        uint32_t w[4];
+        // ---- 2. the planes -> G, cov, characters, U
+        auto hist64 = [&](uint32_t z) -> uint64_t { // positions [16 (lane - 3), 16 lane + 16): this lane's at bits 48 .. 63
+            return (uint64_t)shfl_up0(z, 3, lane) | ((uint64_t)shfl_up0(z, 2, lane) << 16) | ((uint64_t)shfl_up0(z, 1, lane) << 32) | ((uint64_t)z << 48);
+        };
+        auto fwd64 = [&](uint32_t z) -> uint64_t { // positions [16 lane, 16 lane + 64)
+            return (uint64_t)z | ((uint64_t)shfl_down0(z, 1, lane) << 16) | ((uint64_t)shfl_down0(z, 2, lane) << 32) | ((uint64_t)shfl_down0(z, 3, lane) << 48);
+        };
+        const EroChain CA = ero_chain(hist64(ZA)), CB = ero_chain(hist64(ZB));
+        const uint32_t G = (uint32_t)((ero_at(CA, thr + 1u) | ero_at(CB, thr + 1u)) >> 48);
+        const uint32_t cov = (uint32_t)dilate_fwd(fwd64(G), thr + 1u) & 0xFFFFu;
+        const uint32_t cov_prev = ((cov << 1) | (shfl_up0(cov, 1, lane) >> 15)) & 0xFFFFu;
+        const uint32_t cov_next = ((cov >> 1) | (shfl_down0(cov, 1, lane) << 15)) & 0xFFFFu;
+        const uint32_t G_next = ((G >> 1) | (shfl_down0(G, 1, lane) << 15)) & 0xFFFFu;
+        // (positions of the sequence: grid x stands for base g0 + x - r0)
+        const int32_t gx = (int32_t)r0 - (int32_t)g0; // grid position of the sequence's base 0 (may be negative)
+        const uint32_t first_two = range16(xa, gx, gx + 2);
+        const uint32_t isX = ~cov & cov_next & (cov_prev | first_two) & inr16;
+        const uint32_t R1 = G & ~G_next & cov_next;
+        // (the second 'R' at base p needs 2 <= p < len - 1: translate.rs:282-288)
+        const uint32_t R2 = ((R1 << 1) | (shfl_up0(R1, 1, lane) >> 15)) & range16(xa, gx + 2, gx + (int32_t)min(seqlen - 1u, 0x3FFFFFFFu));
+        const uint32_t isR = (R1 | R2) & 0xFFFFu;
+        const uint32_t isM = cov & ~isR;
+        const uint32_t U = ~(uint32_t)((ero_at(CA, order) | ero_at(CB, order)) >> 48) & inr16 & range16(xa, (int32_t)(r0 + order - 1u), (int32_t)xe);
+        if (F) ufl[lane] = (uint16_t)(~(uint32_t)((ero_at(CA, F) | ero_at(CB, F)) >> 48) & inr16 & range16(xa, (int32_t)(r0 + F - 1u), (int32_t)xe));
+
+        // ---- 3. the proof
+        bool flag = false;
+        if (!(a.xexp & 1u) && __ballot(U != 0u)) {
+            // the points of every run of U: its first position and every cstep-th from there while the run's start is known (Mrun
+            // positions back), every cstep-th position of the grid beyond
+            const uint64_t HU = hist64(U);
+            const uint64_t P0 = HU & ~(HU << 1);
+            const uint64_t Ec1 = erode_end(HU, cstep + 1u);
+            uint64_t Ej = HU, pts = P0;
+            for (uint32_t jc = cstep; jc <= Mrun; jc += cstep) {
+                Ej &= Ec1 << (jc - cstep);
+                pts |= (P0 << jc) & Ej;
+            }
+            const uint64_t far = Ej & (HU << (Mrun + 1u)); // the run started more than Mrun positions back
+            uint32_t gridm = 0; // positions of this word that are multiples of cstep
+            for (uint32_t j = ((uint32_t)xa + cstep - 1u) / cstep * cstep - (uint32_t)xa; j < 16u; j += cstep) gridm |= 1u << j;
+            const uint32_t point = ((uint32_t)(pts >> 48) | (gridm & (uint32_t)(far >> 48))) & U;
+            const uint32_t U_next = ((U >> 1) | (shfl_down0(U, 1, lane) << 15)) & 0xFFFFu;
+            const uint32_t lastU = U & ~U_next;                  // the last window of a run
+            const uint32_t lastf = lastU & point;                // ... that is a point: the window one base on is looked up too when it is present
+            uint32_t extn = lastU & ~point;                      // ... that is none: the window one base on is looked up instead
+            const uint32_t at_end = extn & range16(xa, (int32_t)xe - 1, (int32_t)xe); // (nothing behind the region: the window itself)
+            extn &= ~at_end;
+            const uint32_t normal = point | at_end;
+            const uint32_t ext = ((extn << 1) | (shfl_up0(extn, 1, lane) >> 15)) & 0xFFFFu;
+            const uint32_t mine = (uint32_t)__popc(normal) + (uint32_t)__popc(ext);
+            uint32_t incl = mine;
 #pragma unroll
-        for (uint32_t q = 0; q < 4u; q++) {
-            const uint32_t eM = spread4(isM >> (4u * q)), eX = spread4(isX >> (4u * q)), eR = spread4(isR >> (4u * q));
-            if (a.fmt) {
-                const uint32_t d8 = (code >> (24u - 8u * q)) & 0xFFu;
-                const uint32_t sel = ((d8 >> 6) & 3u) | (((d8 >> 4) & 3u) << 8) | (((d8 >> 2) & 3u) << 16) | ((d8 & 3u) << 24);
-                const uint32_t letters = __builtin_amdgcn_perm(0u, 0x54474341u, sel), keep = eM | eR;
-                w[q] = (letters & keep) | (0x2D2D2D2Du & ~keep);
-            } else
-                w[q] = (eM & 0x4D4D4D4Du) | (eX & 0x58585858u) | (eR & 0x52525252u) | (~(eM | eX | eR) & 0x2D2D2D2Du);
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o);
+                if ((int)lane >= o) incl += t;
+            }
+            const uint32_t total = __shfl(incl, 63);
+            __builtin_amdgcn_wave_barrier(); // (the list goes where the text was)
+            if (total > kLongListCap) flag = true;
+            else {
+                uint32_t at = incl - mine;
+                uint32_t nm = normal;
+                while (nm) {
+                    const uint32_t j = (uint32_t)__builtin_ctz(nm);
+                    nm &= nm - 1u;
+                    list[at++] = (uint16_t)(((uint32_t)xa + j) | (((lastf >> j) & 1u) ? 0x800u : 0u));
+                }
+                uint32_t em = ext;
+                while (em) {
+                    const uint32_t j = (uint32_t)__builtin_ctz(em);
+                    em &= em - 1u;
+                    list[at++] = (uint16_t)(((uint32_t)xa + j) | 0x400u);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t omask = (1ull << (2u * order)) - 1ull;
+            auto table = [&](uint32_t e_, uint32_t g) -> uint32_t { // the entry of the window ending at e_ (g: its place in the grouped line)
+                const uint64_t key = ending_at(e_) & omask;
+                st_look++;
+                return a.ix.dtab_grouped ? a.ix.dtab[dtab_grouped_addr(key, g, order)] : a.ix.dtab[key];
+            };
+            // the window ending at e_ is in the index AND the read's base in front of it extends it
+            auto present_ext = [&](uint32_t byte, uint32_t e_) -> bool {
+                return (byte & 0x80u) && e_ >= r0 + order && !inv_span(e_ - order, 1u) && ((byte >> base_at(e_ - order)) & 1u);
+            };
+            for (uint32_t i0 = 0; !flag && i0 < total; i0 += 64u) {
+                const uint32_t i = i0 + lane;
+                bool act = i < total;
+                const uint32_t ent = act ? (uint32_t)list[i] : 0u;
+                const uint32_t x = ent & 0x3FFu;
+                const bool is_ext = (ent & 0x400u) != 0, is_last = (ent & 0x800u) != 0;
+                // (a window with a byte that is no base is in no index; the string an ext look-up asks about holds the base in front)
+                if (act && (inv_span(x, order) || (is_ext && inv_span(x - order, 1u)))) act = false;
+                if (F && !(a.xexp & 2u)) { // the filter: a string of F bases of the window that lies in no single stretch - absent: so is the window
+                    bool fl = false;
+                    uint32_t ef = 0;
+                    if (act && is_ext) {
+                        ef = x - order + F - 1u;
+                        fl = true;
+                    } else if (act) {
+                        const int32_t W = (int32_t)(x >> 4);
+                        const uint32_t r = x & 15u;
+                        uint32_t V = (uint32_t)ufl[W - 1] | ((uint32_t)ufl[W] << 16); // positions 16 (W - 1) .. 16 W + 15
+                        V &= (2u << (16u + r)) - 1u;                                // <= x
+                        const uint32_t lowbit = 16u + r - (order - F);              // >= x - order + F
+                        V &= ~((1u << lowbit) - 1u);
+                        if (V) {
+                            ef = 16u * (uint32_t)(W - 1) + (31u - (uint32_t)__builtin_clz(V));
+                            fl = true;
+                        }
+                    }
+                    if (fl) {
+                        const uint32_t fk = (uint32_t)ending_at(ef) & ((1u << (2u * F)) - 1u);
+                        st_filt++;
+                        if (!((a.ix.dfilt[fk >> 5] >> (fk & 31u)) & 1u)) act = false; // absent
+                    }
+                }
+                uint32_t byte = 0;
+                if (act && !(a.xexp & 4u)) byte = table(x, 1u);
+                bool fail = false;
+                bool need_back = false, need_on = false;
+                if (act && is_ext) fail = present_ext(byte, x);
+                else if (act && (byte & 0x80u)) {
+                    need_back = present_ext(byte, x);
+                    need_on = is_last && x + 1u < xe;
+                }
+                if (__ballot(need_back)) { // something of order + 1 bases ends here: nothing of order + 2 may
+                    if (need_back) {
+                        st_second++;
+                        if (x < r0 + order) fail = true; // (no window one base back inside the region)
+                        else if (!inv_span(x - 1u, order)) fail = present_ext(table(x - 1u, 0u), x - 1u);
+                    }
+                }
+                if (__ballot(need_on)) { // the run's last window is present: the one inside the next stretch must not be extended by the base in front
+                    if (need_on && !fail) {
+                        st_second++;
+                        if (!inv_span(x + 1u, order + 1u)) fail = present_ext(table(x + 1u, 2u), x + 1u);
+                    }
+                }
+                if (__ballot(fail)) flag = true;
+            }
         }
-        const uint4 out = make_uint4(w[0], w[1], w[2], w[3]);
-        const int32_t o_lo = (int32_t)(r0 + own0), o_hi = o_lo + (int32_t)own_n;
-        const uint32_t lo_t = (uint32_t)min(max(o_lo - xa, 0), 16), hi_t = (uint32_t)min(max(o_hi - xa, 0), 16);
-        uint8_t *dst = a.chars_out + base16 + 16u * lane;
-        if (lo_t == 0u && hi_t == 16u) __builtin_memcpy(dst, &out, 16);
-        else if (hi_t > lo_t) {
+
+        // ---- 4. the characters of the own bases, in whole lines; format::relative_to_ref (format.rs:270-286) on the way
+        {
+            uint32_t w[4];
 #pragma unroll
-            for (uint32_t t = 0; t < 16u; t++)
-                if (t >= lo_t && t < hi_t) dst[t] = (uint8_t)(w[t >> 2] >> ((t & 3u) * 8u));
+            for (uint32_t q = 0; q < 4u; q++) {
+                const uint32_t eM = spread4(isM >> (4u * q)), eX = spread4(isX >> (4u * q)), eR = spread4(isR >> (4u * q));
+                if (a.fmt) {
+                    const uint32_t d8 = (code >> (24u - 8u * q)) & 0xFFu;
+                    const uint32_t sel = ((d8 >> 6) & 3u) | (((d8 >> 4) & 3u) << 8) | (((d8 >> 2) & 3u) << 16) | ((d8 & 3u) << 24);
+                    const uint32_t letters = __builtin_amdgcn_perm(0u, 0x54474341u, sel), keep = eM | eR;
+                    w[q] = (letters & keep) | (0x2D2D2D2Du & ~keep);
+                } else
+                    w[q] = (eM & 0x4D4D4D4Du) | (eX & 0x58585858u) | (eR & 0x52525252u) | (~(eM | eX | eR) & 0x2D2D2D2Du);
+            }
+            const uint4 out = make_uint4(w[0], w[1], w[2], w[3]);
+            const int32_t o_lo = (int32_t)(r0 + own0), o_hi = o_lo + (int32_t)own_n;
+            const uint32_t lo_t = (uint32_t)min(max(o_lo - xa, 0), 16), hi_t = (uint32_t)min(max(o_hi - xa, 0), 16);
+            uint8_t *dst = a.chars_out + base16 + 16u * lane;
+            if (lo_t == 0u && hi_t == 16u) __builtin_memcpy(dst, &out, 16);
+            else if (hi_t > lo_t) {
+#pragma unroll
+                for (uint32_t t = 0; t < 16u; t++)
+                    if (t >= lo_t && t < hi_t) dst[t] = (uint8_t)(w[t >> 2] >> ((t & 3u) * 8u));
+            }
+        }
+        // x of the first own base, 0 .. k (what derandomize_ms_vec gives there: the depth in the stretch of more than t bases that
+        // covers it, 0 when none does) - for the piece to the left, should that one be flagged.  Per plane: the ones that end at that
+        // base (Lp) and those behind it (Rp), through the words that are all ones by one ballot
+        {
+            const uint32_t xs = r0 + own0, Lo = xs >> 4, b = xs & 15u;
+            uint32_t best = 0;
+#pragma unroll
+            for (uint32_t p = 0; p < 2u; p++) {
+                const uint32_t w = p == 0 ? ZA : ZB;
+                const uint64_t full = __ballot(w == 0xFFFFu);
+                const uint32_t wo = __shfl(w, (int)Lo);
+                if (!((wo >> b) & 1u)) continue; // (wave-uniform)
+                // down from bit b of word Lo
+                uint32_t Lp;
+                const uint32_t zd = ~wo & ((2u << b) - 1u);
+                if (zd) Lp = b - (31u - (uint32_t)__builtin_clz(zd));
+                else {
+                    const uint64_t nf = ~full & ((1ull << Lo) - 1ull); // words below Lo that are not all ones
+                    const uint32_t hi = nf ? 63u - (uint32_t)__builtin_clzll(nf) : 0u, n_full = nf ? Lo - 1u - hi : Lo;
+                    const uint32_t wp = nf ? (uint32_t)__shfl(w, (int)hi) : 0u;
+                    const uint32_t part = nf ? (uint32_t)__builtin_clz(~(wp << 16)) : 0u; // ones from bit 15 of that word down
+                    Lp = b + 1u + 16u * n_full + min(part, 16u);
+                }
+                // up from bit b + 1
+                uint32_t Rp;
+                const uint32_t zu = ~wo & 0xFFFFu & ~((2u << b) - 1u);
+                if (zu) Rp = (uint32_t)__builtin_ctz(zu) - b - 1u;
+                else {
+                    const uint64_t nf = Lo < 63u ? (~full & (~0ull << (Lo + 1u))) : 0ull;
+                    const uint32_t lo_l = nf ? (uint32_t)__builtin_ctzll(nf) : 64u, n_full = nf ? lo_l - Lo - 1u : 63u - Lo;
+                    const uint32_t wn = nf ? (uint32_t)__shfl(w, (int)lo_l) : 0u;
+                    const uint32_t part = nf ? (uint32_t)__builtin_ctz(~wn) : 0u; // ones from bit 0 of that word up
+                    Rp = 15u - b + 16u * n_full + min(part, 16u);
+                }
+                if (Lp + Rp > thr) best = max(best, min(Lp, k));
+            }
+            if (lane == 0) {
+                a.xin[piece] = (uint8_t)best;
+                const bool fl = flag || (a.xexp & 64u) != 0; // (64: every piece to the second pass - tests)
+                a.redo[piece] = fl ? 1 : 0;
+                if (fl) atomicAdd(a.qctl + 4, 1u);
+            }
         }
     }
-    // x of the first own base, 0 .. k (what derandomize_ms_vec gives there: the depth in the stretch of more than t bases that
-    // covers it, 0 when none does) - for the piece to the left, should that one be flagged.  Per plane: the ones that end at that
-    // base (Lp) and those behind it (Rp), through the words that are all ones by one ballot
-    {
-        const uint32_t xs = r0 + own0, Lo = xs >> 4, b = xs & 15u;
-        uint32_t best = 0;
-#pragma unroll
-        for (uint32_t p = 0; p < 2u; p++) {
-            const uint32_t w = p == 0 ? ZA : ZB;
-            const uint64_t full = __ballot(w == 0xFFFFu);
-            const uint32_t wo = __shfl(w, (int)Lo);
-            if (!((wo >> b) & 1u)) continue; // (wave-uniform)
-            // down from bit b of word Lo
-            uint32_t Lp;
-            const uint32_t zd = ~wo & ((2u << b) - 1u);
-            if (zd) Lp = b - (31u - (uint32_t)__builtin_clz(zd));
-            else {
-                const uint64_t nf = ~full & ((1ull << Lo) - 1ull); // words below Lo that are not all ones
-                const uint32_t hi = nf ? 63u - (uint32_t)__builtin_clzll(nf) : 0u, n_full = nf ? Lo - 1u - hi : Lo;
-                const uint32_t wp = nf ? (uint32_t)__shfl(w, (int)hi) : 0u;
-                const uint32_t part = nf ? (uint32_t)__builtin_clz(~(wp << 16)) : 0u; // ones from bit 15 of that word down
-                Lp = b + 1u + 16u * n_full + min(part, 16u);
-            }
-            // up from bit b + 1
-            uint32_t Rp;
-            const uint32_t zu = ~wo & 0xFFFFu & ~((2u << b) - 1u);
-            if (zu) Rp = (uint32_t)__builtin_ctz(zu) - b - 1u;
-            else {
-                const uint64_t nf = Lo < 63u ? (~full & (~0ull << (Lo + 1u))) : 0ull;
-                const uint32_t lo_l = nf ? (uint32_t)__builtin_ctzll(nf) : 64u, n_full = nf ? lo_l - Lo - 1u : 63u - Lo;
-                const uint32_t wn = nf ? (uint32_t)__shfl(w, (int)lo_l) : 0u;
-                const uint32_t part = nf ? (uint32_t)__builtin_ctz(~wn) : 0u; // ones from bit 0 of that word up
-                Rp = 15u - b + 16u * n_full + min(part, 16u);
-            }
-            if (Lp + Rp > thr) best = max(best, min(Lp, k));
-        }
-        if (lane == 0) {
-            a.xin[piece] = (uint8_t)best;
-            a.redo[piece] = flag ? 1 : 0;
-            if (flag) atomicAdd(a.qctl + 4, 1u);
-        }
+    // (two sums instead of four: seed and second look-ups stay below 2^16 per wave, filter and table look-ups as well)
+    const uint32_t s0 = wave_sum(st_seed | (st_second << 16)), s1 = wave_sum(st_filt | (st_look << 16));
+    if (lane == 0 && a.pstats) {
+        uint32_t *st = a.pstats + ((p_first / a.ppw) % kPlanStatSlots) * kPlanStatWords;
+        atomicAdd(st + kPlanStatSeedLookups, s0 & 0xFFFFu);
+        atomicAdd(st + kPlanStatTabAnchored, s0 >> 16);
+        atomicAdd(st + kPlanStatSeedExtensions, s1 & 0xFFFFu);
+        atomicAdd(st + kPlanStatTabLookups, s1 >> 16);
     }
-    plan_stats_add(a.pstats, kPlanStatSeedLookups, st_seed, kPlanStatSeedExtensions, st_filt, kPlanStatTabLookups, st_look, kPlanStatTabAnchored, st_second);
 }
 
 // ---- flagged pieces: sub-items of 32 bases (+ k - 1 warm-up bases) for the plain walk: the MS values of [s - 1, s + n)
@@ -642,97 +737,191 @@ __global__ __launch_bounds__(256) void long_redo_items_kernel(LongArgs a, WalkIt
     }
 }
 
-// derandomize_ms_vec (derandomize.rs:269-288) + translate_ms_vec (translate.rs:263-293) over the flagged pieces, literally, right to
-// left: one WAVE per run of flagged pieces - the wave of its rightmost piece, which starts from x of the base behind it (xin of the
-// unflagged piece to the right; the sequence's end: derandomize.rs:282) and goes on through the flagged pieces to its left.  Per
-// piece the wave stages the MS bytes of [s - 1, e) (and the bases, for relative_to_ref) in LDS, one lane runs the recurrence over
-// them (a dependent chain of four operations per base), and the wave stores the characters in whole lines.
-constexpr uint32_t kLongDerandLds = 3u * 1040u;
+// derandomize_ms_vec (derandomize.rs:269-288) + translate_ms_vec (translate.rs:263-293) over the flagged pieces, from their true MS
+// values: one WAVE per run of flagged pieces - the wave of its rightmost piece, which starts from x of the base behind it (xin of
+// the unflagged piece to the right; the sequence's end: derandomize.rs:282) and goes on through the flagged pieces to its left - a
+// lane per 16 bases.  The recurrence x[p] = F(a[p], x[p + 1]) (derandomize.rs:233-246) in parallel:
+//   * x <= a wherever a < k, and a rises by at most one per base.  So at a base with a > t ("good") x is a or a - 1: with
+//     d = a - x, d[p] = 0 when a[p] = k or the base to the right is not good or has a smaller a; d[p] = not d[p + 1] when it has the
+//     same a; d[p] = d[p + 1] when it has a + 1: a one-bit recurrence of resets, copies and negations - composed per lane, then
+//     across the lanes by a scan of (mask, constant) pairs;
+//   * everywhere else x[p] = x[q] - (q - p) with q the next good base to the right (or the base behind the piece): x - p is
+//     copied from there - a scan of "take mine if I have one";
+//   * translate_ms_vec's window (x[p - 1], x[p], x[p + 1]) from the neighbouring lanes.
 __global__ __launch_bounds__(64) void long_derand_kernel(LongArgs a, const uint8_t *__restrict__ ms, const uint32_t *__restrict__ flist)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t dl_lds[kLongDerandLds];
-    uint8_t *msl = dl_lds, *ql = dl_lds + 1040, *ol = dl_lds + 2080;
     const uint32_t lane = threadIdx.x;
     const uint4 *items = reinterpret_cast<const uint4 *>(a.items);
     const uint32_t n_flagged = min(a.qctl[2], a.n_items);
     const int K = (int)a.ix.k, T = (int)a.thr;
     auto step = [&](int av, int x) { return av == K ? K : ((av > T && x < av) ? av : x - 1); };
-    auto val = [&](int cur, int next, int prev) -> uint32_t { // translate_ms_val's first character
-        if (cur > T && next > 0 && next < T) return (uint32_t)'R';
-        if (cur <= 0) return (next == 1 && prev > 0) ? (uint32_t)'X' : (uint32_t)'-';
-        return (uint32_t)'M';
-    };
     for (uint32_t fi = blockIdx.x; fi < n_flagged; fi += gridDim.x) {
         uint32_t piece = flist[fi];
-        uint4 it = items[piece];
-        uint32_t own0 = it.w & 0x3FFu, own_n = (it.w >> 10) & 0x7FFu;
+        const uint4 it = items[piece];
+        uint32_t own_n = (it.w >> 10) & 0x7FFu;
         const uint32_t seqlen = it.z;
         if (own_n == 0) continue;
-        uint32_t s = it.y + own0, e = s + own_n; // own bases [s, e) of the sequence
+        uint32_t s = it.y + (it.w & 0x3FFu), e = s + own_n; // own bases [s, e) of the sequence
         const bool at_end = e >= seqlen;
         if (!at_end && piece + 1u < a.n_items && a.redo[piece + 1u]) continue; // (the wave of a piece further right takes this one)
         const uint64_t seq0 = (uint64_t)it.x - it.y;
+        const uint64_t room = a.q_bytes - seq0; // bytes of the two buffers from the sequence's first on
         const uint8_t *m = ms + seq0;
         const uint8_t *qs = a.q + seq0;
         uint8_t *out = a.chars_out + seq0;
-        int x_right = at_end ? 0 : (int)a.xin[piece + 1u]; // x of base e
-        for (bool first = true;; first = false) {
-            // the MS bytes of [s - 1, e) (index 0: base s - 1) and the bases of [s, e)
-            const uint32_t b0 = s > 0 ? s - 1u : 0u, skip = s > 0 ? 0u : 1u, n_ms = e - b0;
-            __syncthreads();
-            const uint64_t room = a.q_bytes - seq0; // bytes of the two buffers from the sequence's first on
-            for (uint32_t c = 16u * lane; c < n_ms; c += 1024u) {
-                if ((uint64_t)b0 + c + 16u <= room) {
-                    const uint4 v = ld16u(m, b0 + c);
-                    __builtin_memcpy(msl + skip + c, &v, 16);
-                } else
-                    for (uint32_t t = 0; t < 16u && c + t < n_ms; t++) msl[skip + c + t] = m[b0 + c + t];
-            }
-            if (a.fmt)
-                for (uint32_t c = 16u * lane; c < own_n; c += 1024u) {
-                    if ((uint64_t)s + c + 16u <= room) {
-                        const uint4 v = ld16u(qs, s + c);
-                        __builtin_memcpy(ql + c, &v, 16);
-                    } else
-                        for (uint32_t t = 0; t < 16u && c + t < own_n; t++) ql[c + t] = qs[s + c + t];
+        // x of base e; at the sequence's end a value that makes the last base's x what derandomize.rs:282 says: a > t ? a : 0
+        int x_right = at_end ? 1 : (int)a.xin[piece + 1u];
+        for (;;) {
+            const uint32_t n = own_n, p0 = s + 16u * lane; // this lane's bases: p0 .. p0 + 15, those below e
+            const uint32_t cnt = p0 < e ? min(16u, e - p0) : 0u;
+            // their MS values (a byte that would lie behind the buffers is not read)
+            uint32_t av[16];
+            {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (cnt && (uint64_t)p0 + 16u <= room) v = ld16u(m, p0);
+                else if (cnt) {
+                    uint8_t tmp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    for (uint32_t t = 0; t < 16u && (uint64_t)p0 + t < room; t++) tmp[t] = m[p0 + t];
+                    __builtin_memcpy(&v, tmp, 16);
                 }
-            __syncthreads();
-            if (lane == 0) {
-                // x[p] for p = e - 1 down to s; msl[1 + (p - s)] = MS of base p, msl[0] = MS of base s - 1
-                int x_next, x_cur;
-                uint32_t p = e - 1u;
-                if (first && at_end) {
-                    const int av = msl[1u + (p - s)];
-                    x_cur = av > T ? av : 0; // derandomize.rs:282
-                    x_next = x_cur;          // translate.rs:279: next of the last base is its own value
-                } else {
-                    x_next = x_right;
-                    x_cur = step((int)msl[1u + (p - s)], x_next);
+#pragma unroll
+                for (uint32_t t = 0; t < 16u; t++) {
+                    const uint32_t w = (t >> 2) == 0 ? v.x : (t >> 2) == 1 ? v.y : (t >> 2) == 2 ? v.z : v.w;
+                    av[t] = t < cnt ? (w >> ((t & 3u) * 8u)) & 0xFFu : 0u;
                 }
-                for (;;) {
-                    const int x_prev = p > 0 ? step((int)msl[p - s], x_cur) : K;
-                    const int prev = p > 1 ? x_prev : K; // translate.rs:277
-                    // res[p] = 'R' when 2 <= p < len - 1 and the base in front starts an ('R','R') (translate.rs:282-288), else val(..).0
-                    uint32_t ch;
-                    if (p >= 2u && p < seqlen - 1u && x_prev > T && x_cur > 0 && x_cur < T) ch = (uint32_t)'R';
-                    else ch = val(x_cur, p + 1u < seqlen ? x_next : x_cur, prev);
-                    if (a.fmt) ch = (ch == (uint32_t)'M' || ch == (uint32_t)'R') ? (uint32_t)ql[p - s] : (uint32_t)'-';
-                    ol[p - s] = (uint8_t)ch;
-                    if (p == s) break;
-                    x_next = x_cur;
-                    x_cur = x_prev;
-                    p--;
+            }
+            uint4 qv = make_uint4(0, 0, 0, 0);
+            if (a.fmt && cnt) {
+                if ((uint64_t)p0 + 16u <= room) qv = ld16u(qs, p0);
+                else {
+                    uint8_t tmp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    for (uint32_t t = 0; t < 16u && (uint64_t)p0 + t < room; t++) tmp[t] = qs[p0 + t];
+                    __builtin_memcpy(&qv, tmp, 16);
                 }
-                x_right = x_cur; // x of base s: what the piece to the left starts from
             }
-            __syncthreads();
-            for (uint32_t c = 16u * lane; c < own_n; c += 1024u) {
-                uint4 v;
-                __builtin_memcpy(&v, ol + c, 16);
-                if (c + 16u <= own_n) __builtin_memcpy(out + s + c, &v, 16);
-                else st_partial(out + s + c, v, own_n - c);
+            const int a_left = s > 0 ? (int)m[s - 1u] : K; // MS of the base in front of the piece (base -1: anything, its x is not used)
+            // the value to the right of this lane's last base: the next lane's first, or (the piece's last lane) none: the boundary
+            const uint32_t a_first_next = __shfl_down(av[0], 1);
+            const bool last_lane = cnt != 0 && p0 + cnt == e;
+            // ---- d within good runs: per base (mask, constant), d = constant ^ (mask & d of the base to the right)
+            uint32_t mk[16], cs[16];
+            uint32_t M = 1, C = 0; // the lane's composition, from its last base down to its first: d_first = C ^ (M & d_in)
+#pragma unroll
+            for (int t = 15; t >= 0; t--) {
+                const uint32_t an = t == 15 ? a_first_next : av[t == 15 ? 15 : t + 1];
+                const bool in = (uint32_t)t < cnt, is_last = last_lane && (uint32_t)t + 1u == cnt;
+                const bool good = in && (int)av[t] > T;
+                uint32_t mm = 0, cc = 0;
+                if (is_last) cc = (good && (int)av[t] != K && x_right == (int)av[t]) ? 1u : 0u; // (x_right = a + 1: the decrement gives a as well)
+                else if (good && (int)av[t] != K && (int)an > T) {
+                    mm = (an == av[t] || an == av[t] + 1u) ? 1u : 0u;
+                    cc = an == av[t] ? 1u : 0u;
+                }
+                if (!in) { // (bases behind the piece in its last lane: pass d through - it is not used)
+                    mm = 1;
+                    cc = 0;
+                }
+                mk[t] = mm;
+                cs[t] = cc;
+                // compose: this base applied after what is to its right
+                C = cc ^ (mm & C);
+                M = mm & M;
             }
-            x_right = __shfl(x_right, 0);
+            // suffix scan over the lanes (lane L needs the composition of the lanes to its right applied to d = 0 behind the piece)
+            uint32_t SM = M, SC = C; // composition of lanes L .. L + 2^i - 1
+            uint32_t din = 0;        // d of the first base of lane L + 1
+            {
+                // exclusive: start from the right neighbour's inclusive composition
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t m2 = __shfl_down(SM, o), c2 = __shfl_down(SC, o);
+                    if (lane + (uint32_t)o < 64u) { // lanes [L, L + o) then [L + o, L + 2 o): f_L(f_{L+o}(d))
+                        SC = SC ^ (SM & c2);
+                        SM = SM & m2;
+                    }
+                }
+                // SC now = d of this lane's first base when d = 0 behind everything (the masks see to it that the boundary is a reset)
+                din = __shfl_down(SC, 1);
+                if (lane == 63u) din = 0;
+            }
+            int xv[16];
+            // d of every base, then x of the good ones; Y = x - position for the others
+            int Yin; // x - position of the next good base to the right of this lane (or of the base behind the piece)
+            {
+                uint32_t d = din;
+                uint32_t has = 0;
+                int firstY = 0;
+#pragma unroll
+                for (int t = 15; t >= 0; t--) {
+                    d = cs[t] ^ (mk[t] & d);
+                    const bool good = (uint32_t)t < cnt && (int)av[t] > T;
+                    xv[t] = (int)av[t] - (int)d;
+                    if (good) {
+                        has = 1;
+                        firstY = xv[t] - (int)(p0 + (uint32_t)t);
+                    }
+                }
+                // suffix scan: the leftmost good base of the nearest lane to the right that has one
+                uint32_t H = has;
+                int Y = firstY;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t h2 = __shfl_down(H, o);
+                    const int y2 = __shfl_down(Y, o);
+                    if (lane + (uint32_t)o < 64u && !H) {
+                        H = h2;
+                        Y = y2;
+                    }
+                }
+                const uint32_t Hn = __shfl_down(H, 1);
+                const int Yn = __shfl_down(Y, 1);
+                const int Yb = x_right - (int)e;
+                Yin = (lane < 63u && Hn) ? Yn : Yb;
+            }
+            {
+                int carry = Yin;
+#pragma unroll
+                for (int t = 15; t >= 0; t--) {
+                    const bool in = (uint32_t)t < cnt;
+                    const bool good = in && (int)av[t] > T;
+                    if (good) carry = xv[t] - (int)(p0 + (uint32_t)t);
+                    else if (in) xv[t] = carry + (int)(p0 + (uint32_t)t);
+                }
+            }
+            // ---- translate_ms_vec: (x[p - 1], x[p], x[p + 1])
+            const int x_first = __shfl(xv[0], 0); // x of base s
+            const int x_front = s > 0 ? step(a_left, x_first) : K; // x of base s - 1
+            int x_prev_in = __shfl_up(xv[15], 1);
+            if (lane == 0) x_prev_in = x_front;
+            int x_next_in = __shfl_down(xv[0], 1); // (the next lane's first base; the piece's last base: the base behind it)
+            uint32_t ow[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t t = 0; t < 16u; t++) {
+                const uint32_t p = p0 + t;
+                const bool lastb = last_lane && t + 1u == cnt;
+                const int cur = xv[t];
+                const int prv = t == 0 ? x_prev_in : xv[t == 0 ? 0 : t - 1];
+                int nxt = t == 15 ? x_next_in : xv[t == 15 ? 15 : t + 1];
+                if (lastb) nxt = x_right;
+                if (p + 1u >= seqlen) nxt = cur; // translate.rs:279
+                const int prev = p > 1u ? prv : K; // translate.rs:277
+                // res[p] = 'R' when 2 <= p < len - 1 and the base in front starts an ('R','R') (translate.rs:282-288), else translate_ms_val's first
+                const bool r2 = p >= 2u && p + 1u < seqlen && prv > T && cur > 0 && cur < T;
+                const bool r1 = cur > T && nxt > 0 && nxt < T;
+                uint32_t ch = cur <= 0 ? ((nxt == 1 && prev > 0) ? (uint32_t)'X' : (uint32_t)'-') : (uint32_t)'M';
+                ch = (r1 || r2) ? (uint32_t)'R' : ch;
+                if (a.fmt) {
+                    const uint32_t qw = (t >> 2) == 0 ? qv.x : (t >> 2) == 1 ? qv.y : (t >> 2) == 2 ? qv.z : qv.w;
+                    ch = (ch == (uint32_t)'M' || ch == (uint32_t)'R') ? ((qw >> ((t & 3u) * 8u)) & 0xFFu) : (uint32_t)'-';
+                }
+                ow[t >> 2] |= ch << ((t & 3u) * 8u);
+            }
+            if (cnt == 16u) {
+                const uint4 v = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                __builtin_memcpy(out + p0, &v, 16);
+            } else if (cnt) st_partial(out + p0, make_uint4(ow[0], ow[1], ow[2], ow[3]), cnt);
+            x_right = x_first; // x of base s: what the piece to the left starts from
+            (void)n;
             // the flagged piece to the left, if it is this sequence's
             if (s == 0 || piece == 0 || !a.redo[piece - 1u]) break;
             const uint4 pit = items[piece - 1u];
@@ -792,7 +981,7 @@ size_t long_work_bytes(size_t n_seqs, uint64_t total_bases, uint32_t k)
 bool map_long_applies(const DevIndexView &ix, uint32_t thr)
 {
     static const int env_on = std::getenv("KBO_MAP_LONG") ? std::atoi(std::getenv("KBO_MAP_LONG")) : 1; // experiments
-    if (!(env_on != 0 && ix.dtab && ix.pc_tm && ix.seed_pos && ix.seed_d >= 4u && ix.seed_d <= 14u && ix.dtab_order >= 4u && ix.dtab_order <= 17u &&
+    if (!(env_on != 0 && g_map_long.load() != 0 && ix.dtab && ix.pc_tm && ix.seed_pos && ix.seed_d >= 4u && ix.seed_d <= 14u && ix.dtab_order >= 4u && ix.dtab_order <= 17u &&
           ix.dtab_order < thr && thr < ix.k && thr <= 47u && 2u * ix.k + 1u + kLongOwnMin <= kLongRegion))
         return false;
     if (ix.dfilt && (ix.dfilt_bases >= ix.dtab_order || ix.dtab_order - ix.dfilt_bases > 5u || ix.dfilt_bases > 16u)) return false;
@@ -830,7 +1019,9 @@ hipError_t launch_map_long(const DevIndexView &ix, const uint8_t *d_q, const uin
     a.thr = thr;
     a.fmt = fmt ? 1u : 0u;
     static const int env_x = std::getenv("KBO_LONG_X") ? std::atoi(std::getenv("KBO_LONG_X")) : 0; // experiments: phases left out (timing only)
-    a.xexp = (uint32_t)env_x;
+    a.xexp = (uint32_t)env_x | (g_map_long.load() == 2 ? 64u : 0u);
+    static const int env_ppw = std::getenv("KBO_LONG_PPW") ? std::atoi(std::getenv("KBO_LONG_PPW")) : 8; // experiments: pieces per wave
+    a.ppw = (uint32_t)std::min(64, std::max(1, env_ppw));
     a.ca = ix.k + 1u;
     a.subs = w + L.subs;
     a.flist = reinterpret_cast<uint32_t *>(w + L.flist);
@@ -838,7 +1029,8 @@ hipError_t launch_map_long(const DevIndexView &ix, const uint8_t *d_q, const uin
     a.q_bytes = total_bases;
     static const int env_wpb = std::getenv("KBO_LONG_WPB") ? std::atoi(std::getenv("KBO_LONG_WPB")) : 4; // experiments: waves per workgroup
     const uint32_t wpb = (uint32_t)std::min(4, std::max(1, env_wpb));
-    hipLaunchKernelGGL(map_long_kernel, dim3((L.n_slots + wpb - 1u) / wpb), dim3(64u * wpb), kLongLds * wpb, stream, a);
+    const uint32_t n_waves = (L.n_slots + a.ppw - 1u) / a.ppw;
+    hipLaunchKernelGGL(map_long_kernel, dim3((n_waves + wpb - 1u) / wpb), dim3(64u * wpb), kLongLds * wpb, stream, a);
     return hipGetLastError();
 }
 
@@ -857,7 +1049,7 @@ hipError_t launch_map_long_redo(const LongArgs &a, uint8_t *d_ms, hipStream_t st
     hipError_t e = launch_walk_list(wa, static_cast<const WalkItem *>(a.subs), a.sub_cap, a.qctl + 1, lanes, stream);
     if (e != hipSuccess) return e;
     // (a wave per run of flagged pieces; the list's length is on the device: the waves share it)
-    hipLaunchKernelGGL(long_derand_kernel, dim3(std::min<uint32_t>(a.n_items, 16384u)), dim3(64), 0, stream, a, d_ms, a.flist);
+    hipLaunchKernelGGL(long_derand_kernel, dim3(std::min<uint32_t>(a.n_items, 32768u)), dim3(64), 0, stream, a, d_ms, a.flist);
     return hipGetLastError();
 }
 

@@ -44,6 +44,7 @@ def shipped_defaults(L):
     L.kbo_set_devices(None, 0)
     L.kbo_set_plan_table_budget(0)       # the tables of a copy: half of the free device memory
     L.kbo_set_plan_lazy(-1)              # plan structures of implicitly made copies: by index size
+    L.kbo_set_map_long(1)                # sequences of more than 160 bases: the one kernel where it applies
 
 
 @pytest.fixture(autouse=True)

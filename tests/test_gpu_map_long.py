@@ -151,6 +151,23 @@ def test_long_sequences_every_base(oracle, k):
         print(k, name, st)
 
 
+def test_every_piece_through_the_second_pass(oracle):
+    """kbo_set_map_long(2): every piece is flagged, so every character comes from the plain walk's MS values and the parallel form
+    of the literal recurrences (long_derand_kernel: runs of flagged pieces, sequence ends, relative_to_ref)"""
+    rng = np.random.default_rng(81)
+    contigs = _genome(rng, 300_000, contigs=2)
+    sbwt, _ = kbo_amd.build(contigs, kbo_amd.BuildOpts(k=31, num_threads=threads()))
+    ora = oracle.Index.build([c.tobytes() for c in contigs], k=31)
+    kbo_amd.lib().kbo_set_map_long(2)
+    for sub, indel, big in ((0.0, 0.0, 0.0), (0.01, 0.0, 0.0), (0.05, 0.0, 0.0), (0.025, 0.0125, 0.0), (0.01, 0.002, 0.5)):
+        seqs = _sequences(rng, contigs, 50, [3, 4, 5, 16, 17, 161, 200, 700, 961, 962, 1500, 3000, 10_000], sub, indel, big)
+        seqs = [q for q in seqs if len(q) >= 3]
+        concat, offsets = _batch_of(seqs)
+        st = _check(oracle, ora, sbwt, concat, offsets)
+        assert st["flagged"] == st["pieces"]
+    kbo_amd.lib().kbo_set_map_long(1)
+
+
 def test_reads_and_contigs_in_one_batch(oracle):
     """a batch of an assembly's shape: whole contigs, fragments of every length down to 3 bases, reads; sequences of 1 and 2 bases
     among them are left unwritten (derandomize.rs:274-276 asserts on fewer than 3 values)"""
