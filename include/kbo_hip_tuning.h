@@ -135,9 +135,11 @@ int kbo_plan_flags_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, 
 int kbo_set_map_long(int mode);
 /* inspection: what the last kbo_map_batch_dev / kbo_find_batch_dev call over sequences of more than 160 bases did when it took
  * the one kernel for sequences of any length (long_kernels.hip); arguments as for that call, synchronises `stream`.
- * out[0]: pieces, [1]: pieces whose proof failed (plain walk + literal recurrences), [2]: their sub-items, [3]: seed look-ups,
- * [4]: filter look-ups, [5]: depth-table look-ups, [6]: of those, second look-ups behind a window that was present. */
-#define KBO_LONG_STATS 8
+ * out[0]: pieces, [1]: pieces whose proof failed (plain walk + literal recurrences), [2]: their sub-items; with kbo_set_plan_stats(1) [3]: seed look-ups,
+ * [4]: filter look-ups, [5]: depth-table look-ups, [6]: of those, second look-ups behind a window that was present;
+ * [8..12] (experiments, KBO_LONG_X & 128): shader cycles of the waves' first lanes by phase - staging, stretches, planes to
+ * characters, proof, output. */
+#define KBO_LONG_STATS 16
 int kbo_long_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k, const void *d_work, uint64_t out[KBO_LONG_STATS],
                        void *stream);
 

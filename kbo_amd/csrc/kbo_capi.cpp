@@ -1207,12 +1207,13 @@ int kbo_long_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, 
         KBO_REQUIRE(d_work && out && n_seqs > 0 && total_bases > 0, KBO_E_BAD_ARG, "null / empty argument");
         const DevWork w = dev_work(n_seqs, total_bases, max_seq_len, k);
         KBO_REQUIRE(w.long_bytes != 0, KBO_E_UNSUPPORTED, "not a batch of long sequences");
-        uint32_t ctl[8], st[kbo::kPlanStatSlots * kbo::kPlanStatWords];
+        uint32_t ctl[32], st[kbo::kPlanStatSlots * kbo::kPlanStatWords];
         HIP_OK(kbo::long_read_stats(static_cast<const uint8_t *>(d_work) + w.long_off, n_seqs, total_bases, k, ctl, st, static_cast<hipStream_t>(stream)));
         for (uint32_t i = 0; i < KBO_LONG_STATS; i++) out[i] = 0;
         out[0] = ctl[0];
         out[1] = ctl[4];
         out[2] = ctl[1];
+        for (uint32_t i = 0; i < 5 && 8 + i < KBO_LONG_STATS; i++) out[8 + i] = (uint64_t)ctl[16 + i] << 4; // (KBO_LONG_X & 128: shader cycles by phase)
         for (uint32_t sl = 0; sl < kbo::kPlanStatSlots; sl++) {
             out[3] += st[sl * kbo::kPlanStatWords + kbo::kPlanStatSeedLookups];
             out[4] += st[sl * kbo::kPlanStatWords + kbo::kPlanStatSeedExtensions];
@@ -1352,7 +1353,7 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
             if (!kbo::map_long_applies(view, (uint32_t)threshold)) return;
             kbo::LongArgs la{};
             HIP_OK(kbo::launch_map_long(view, d_concat, d_offsets, (uint32_t)n_seqs, total_bases, (uint32_t)threshold, format != 0, d_chars_out,
-                                        static_cast<uint8_t *>(d_work) + w.long_off, s, la));
+                                        static_cast<uint8_t *>(d_work) + w.long_off, s, la, g_plan_stats.load()));
             hipStream_t ts = s;
             if (split && static_cast<hipStream_t>(tail_stream) != s) {
                 ts = static_cast<hipStream_t>(tail_stream);

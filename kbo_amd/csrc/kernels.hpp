@@ -375,10 +375,10 @@ size_t long_work_bytes(size_t n_seqs, uint64_t total_bases, uint32_t k); // byte
 bool map_long_applies(const DevIndexView &ix, uint32_t thr);
 void set_map_long(int mode); // tuning / tests: see kbo_set_map_long
 hipError_t launch_map_long(const DevIndexView &ix, const uint8_t *d_q, const uint64_t *d_off, uint32_t n_seqs, uint64_t total_bases, uint32_t thr,
-                           bool fmt, uint8_t *d_chars, void *d_work, hipStream_t stream, LongArgs &a);
+                           bool fmt, uint8_t *d_chars, void *d_work, hipStream_t stream, LongArgs &a, bool count /* work counters: kbo_set_plan_stats */);
 hipError_t launch_map_long_redo(const LongArgs &a, uint8_t *d_ms, hipStream_t stream);
-// the control words (8) and work counters of the last launch over d_work; synchronises the stream
-hipError_t long_read_stats(const void *d_work, size_t n_seqs, uint64_t total_bases, uint32_t k, uint32_t ctl[8], uint32_t *stats, hipStream_t stream);
+// the control words (32) and work counters of the last launch over d_work; synchronises the stream
+hipError_t long_read_stats(const void *d_work, size_t n_seqs, uint64_t total_bases, uint32_t k, uint32_t ctl[32], uint32_t *stats, hipStream_t stream);
 // the plain walk over a list of items whose number is counted on the device (walk_kernels.hip): `lanes` lanes share them
 hipError_t launch_walk_list(WalkArgs a, const WalkItem *d_list, uint32_t cap, const uint32_t *d_count, uint32_t lanes, hipStream_t stream);
 

@@ -54,7 +54,7 @@ constexpr uint32_t kLongTH = 6;         // mismatches in 16 bases that end a dia
 constexpr uint32_t kLongRun = 10;       // matching bases that start one
 constexpr uint32_t kLongLds = 2048;     // bytes of LDS per wave
 #ifndef KBO_LONG_WPE
-#define KBO_LONG_WPE 4
+#define KBO_LONG_WPE 5
 #endif
 
 __device__ __forceinline__ uint32_t funnel2(uint32_t hi, uint32_t lo, uint32_t r) // 16 digits from digit r of hi on
@@ -108,22 +108,38 @@ __device__ __forceinline__ uint64_t dilate_fwd(uint64_t f, uint32_t L)
 // 4 bits -> 4 bytes of 0xFF / 0x00
 __device__ __forceinline__ uint32_t spread4(uint32_t m4) { return (((m4 & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu; }
 
-__device__ __forceinline__ uint32_t shfl_up0(uint32_t v, uint32_t d, uint32_t lane) // 0 where there is no such lane
+// the value of the lane d (1 .. 3) below / above, 0 where there is no such lane: wave shifts of the data-parallel primitives (one
+// vector instruction each, no trip through the LDS crossbar as ds_bpermute makes)
+__device__ __forceinline__ uint32_t shfl_up0(uint32_t v, uint32_t d, uint32_t)
 {
-    const uint32_t t = __shfl_up(v, d);
-    return lane >= d ? t : 0u;
+    v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true); // wave_shr:1
+    if (d >= 2u) v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);
+    if (d >= 3u) v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);
+    return v;
 }
-__device__ __forceinline__ uint32_t shfl_down0(uint32_t v, uint32_t d, uint32_t lane)
+__device__ __forceinline__ uint32_t shfl_down0(uint32_t v, uint32_t d, uint32_t)
 {
-    const uint32_t t = __shfl_down(v, d);
-    return lane + d < 64u ? t : 0u;
+    v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true); // wave_shl:1
+    if (d >= 2u) v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true);
+    if (d >= 3u) v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true);
+    return v;
 }
 
+// Pieces of a sequence whose first byte is byte b of the buffer: the first one's own bases end where a 16-byte block of the buffer
+// ends, the others' own bases are `own` (a multiple of 16) each - so that every piece but a sequence's first and last stores its
+// characters in whole aligned blocks (one store instruction a piece; partial blocks only at the two ends of a sequence)
+__device__ __forceinline__ uint32_t long_first_own(uint64_t b, uint32_t own) { return own - (uint32_t)((b + own) & 15u); }
 __global__ __launch_bounds__(256) void long_count_kernel(const uint64_t *__restrict__ off, uint32_t n_seqs, uint32_t own, uint32_t *__restrict__ counts)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s > n_seqs) return;
-    counts[s] = s < n_seqs ? (uint32_t)((off[s + 1] - off[s] + own - 1u) / own) : 0u;
+    uint32_t n = 0;
+    if (s < n_seqs) {
+        const uint64_t b = off[s], len = off[s + 1] - b;
+        const uint32_t l1 = long_first_own(b, own);
+        n = len == 0 ? 0u : (len <= l1 ? 1u : 1u + (uint32_t)((len - l1 + own - 1u) / own));
+    }
+    counts[s] = n;
 }
 
 // piece t -> { first byte of its region, that byte's position in its sequence, the sequence's length, own0 | own_n << 10 }
@@ -144,8 +160,9 @@ __global__ __launch_bounds__(256) void long_items_kernel(const uint64_t *__restr
             else hi = mid;
         }
         const uint64_t b = off[lo], len = off[lo + 1] - b;
-        const uint64_t s0 = (uint64_t)(t - first_item(lo)) * own;
-        const uint32_t own0 = (uint32_t)min(s0, (uint64_t)cb), own_n = (uint32_t)min((uint64_t)own, len - s0);
+        const uint32_t j = t - first_item(lo), l1 = long_first_own(b, own);
+        const uint64_t s0 = j == 0 ? 0 : (uint64_t)l1 + (uint64_t)(j - 1u) * own;
+        const uint32_t own0 = (uint32_t)min(s0, (uint64_t)cb), own_n = (uint32_t)min((uint64_t)(j == 0 ? l1 : own), len - s0);
         it = make_uint4((uint32_t)(b + s0 - own0), (uint32_t)(s0 - own0), (uint32_t)len, own0 | (own_n << 10));
     }
     items[t] = it;
@@ -186,7 +203,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t long_lds_all[];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t p_first = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * a.ppw;
+    // (made uniform for the compiler: the items are then scalar loads, and what is derived from them lives in scalar registers)
+    const uint32_t p_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * a.ppw));
     if (p_first >= a.n_items) return; // (wave-uniform; the waves of a workgroup share nothing)
     const uint32_t n_mine = min(a.ppw, a.n_items - p_first);
     uint8_t *lds = long_lds_all + (threadIdx.x >> 6) * kLongLds;
@@ -198,7 +216,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                                                                         // text was: it is not needed any more when the list is made)
     const uint32_t k = a.ix.k, thr = a.thr, order = a.ix.dtab_order;
     const int32_t xa = (int32_t)(16u * lane);
-    const uint4 itv = lane < n_mine ? reinterpret_cast<const uint4 *>(a.items)[p_first + lane] : make_uint4(0, 0, 0, 0);
+    // (the items through the scalar unit - constant address space, uniform index: no vector load whose wait would take the queue of
+    // vector loads and stores with it -, each one two pieces ahead of its use)
+    typedef uint32_t item_words_t __attribute__((ext_vector_type(4)));
+    typedef const item_words_t __attribute__((address_space(4))) *const_items_t;
+    const const_items_t items_c = (const_items_t)(uintptr_t)a.items;
+    auto item_at = [&](uint32_t i) -> uint4 {
+        const item_words_t v = items_c[i];
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    const uint32_t p_last = p_first + n_mine - 1u;
     if (lane < 2u) {
         lin[(int32_t)lane - 2] = 0;
         invl[(int32_t)lane - 2] = 0;
@@ -217,10 +244,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
     const uint32_t cstep = thr - order, Mrun = cstep * (47u / cstep);
     uint32_t st_seed = 0, st_look = 0, st_filt = 0, st_second = 0;
 
+    uint4 it_c = item_at(p_first), it_n = item_at(min(p_first + 1u, p_last));
     // the bases of the wave's first piece
     uint4 vq = make_uint4(0, 0, 0, 0);
     {
-        const uint32_t q0 = __shfl(itv.x, 0), g00 = __shfl(itv.y, 0), sl0 = __shfl(itv.z, 0), w0 = __shfl(itv.w, 0);
+        const uint32_t q0 = it_c.x, g00 = it_c.y, sl0 = it_c.z, w0 = it_c.w;
         const uint32_t R0 = min(sl0 - g00, (w0 & 0x3FFu) + ((w0 >> 10) & 0x7FFu) + a.ca), n0 = ((q0 & 15u) + R0 + 15u) >> 4;
         if (((w0 >> 10) & 0x7FFu) != 0u && lane < n0) vq = ld16(a.q, (q0 & ~15u) + 16u * lane);
     }
@@ -228,14 +256,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
     int32_t pred_dl = 0, pred_u0 = 0;
     uint2 tn0 = make_uint2(0, 0), tn1 = make_uint2(0, 0);
 
+    const bool stamps = (a.xexp & 128u) != 0; // (experiments: shader cycles per phase, summed into qctl[16 ..] in units of 16)
+    uint32_t cyc[5] = {0, 0, 0, 0, 0};
+    auto stamp = [&](uint32_t slot, uint64_t &t_last) {
+        if (!stamps) return;
+        const uint64_t t = __builtin_amdgcn_s_memtime();
+        cyc[slot] += (uint32_t)(t - t_last);
+        t_last = t;
+    };
+    uint64_t t_last = stamps ? __builtin_amdgcn_s_memtime() : 0;
     for (uint32_t pi = 0; pi < n_mine; pi++) {
         const uint32_t piece = p_first + pi;
-        const uint32_t q_off = __shfl(itv.x, (int)pi), g0 = __shfl(itv.y, (int)pi), seqlen = __shfl(itv.z, (int)pi), itw = __shfl(itv.w, (int)pi);
+        const uint4 itc = it_c, itn = it_n;
+        it_c = it_n;
+        it_n = item_at(min(piece + 2u, p_last));
+        const uint32_t q_off = itc.x, g0 = itc.y, seqlen = itc.z, itw = itc.w;
         const uint32_t own0 = itw & 0x3FFu, own_n = (itw >> 10) & 0x7FFu;
         // (the next piece, whose bases are asked for as soon as this one's are in LDS)
         const bool have_next = pi + 1u < n_mine;
-        const uint32_t nq_off = have_next ? __shfl(itv.x, (int)pi + 1) : 0u, ng0 = have_next ? __shfl(itv.y, (int)pi + 1) : 0u,
-                       nseqlen = have_next ? __shfl(itv.z, (int)pi + 1) : 0u, nitw = have_next ? __shfl(itv.w, (int)pi + 1) : 0u;
+        const uint32_t nq_off = itn.x, ng0 = itn.y, nseqlen = itn.z, nitw = have_next ? itn.w : 0u;
         const uint32_t nown0 = nitw & 0x3FFu, nown_n = (nitw >> 10) & 0x7FFu;
         const uint32_t nR = min(nseqlen - ng0, nown0 + nown_n + a.ca), nnblk = ((nq_off & 15u) + nR + 15u) >> 4;
         const bool skip = own_n == 0 || seqlen < 3u; // (a slot past the batch's last piece; derandomize.rs:274-276 asserts on fewer than 3 values: left unwritten)
@@ -268,6 +307,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (a.xexp & 16u) continue;
+        stamp(0, t_last); // staging
 
         auto from_base = [&](uint32_t S) -> uint32_t { // 16 bases from S on, first one most significant
             const uint32_t W = S >> 4, r = S & 15u;
@@ -279,7 +319,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
             return V >> (2u * (15u - r));
         };
         auto base_at = [&](uint32_t S) -> uint32_t { return (lin[S >> 4] >> (2u * (15u - (S & 15u)))) & 3u; };
+        const bool any_inv = __ballot(inv16 != 0u) != 0; // (wave-uniform: nearly always false)
         auto inv_span = [&](uint32_t E, uint32_t L) -> bool { // any byte that is no base among the L <= 33 positions ending at E
+            if (!any_inv) return false;
             const int32_t W = (int32_t)(E >> 4);
             const uint32_t r = E & 15u;
             const uint64_t V = (uint64_t)invl[W - 2] | ((uint64_t)invl[W - 1] << 16) | ((uint64_t)invl[W] << 32);
@@ -485,16 +527,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
             tn1 = (lane < kLongTextUnits - 64u && u_b >= 0 && u_b < n_units) ? a.ix.pc_tm[u_b] : make_uint2(0u, 0x55555555u);
         }
         if (a.xexp & 32u) continue;
+        stamp(1, t_last); // stretches
 
         // ---- 2. the planes -> G, cov, characters, U
         auto hist64 = [&](uint32_t z) -> uint64_t { // positions [16 (lane - 3), 16 lane + 16): this lane's at bits 48 .. 63
-            return (uint64_t)shfl_up0(z, 3, lane) | ((uint64_t)shfl_up0(z, 2, lane) << 16) | ((uint64_t)shfl_up0(z, 1, lane) << 32) | ((uint64_t)z << 48);
+            const uint32_t z1 = shfl_up0(z, 1, lane), z2 = shfl_up0(z1, 1, lane), z3 = shfl_up0(z2, 1, lane);
+            return (uint64_t)z3 | ((uint64_t)z2 << 16) | ((uint64_t)z1 << 32) | ((uint64_t)z << 48);
         };
         auto fwd64 = [&](uint32_t z) -> uint64_t { // positions [16 lane, 16 lane + 64)
-            return (uint64_t)z | ((uint64_t)shfl_down0(z, 1, lane) << 16) | ((uint64_t)shfl_down0(z, 2, lane) << 32) | ((uint64_t)shfl_down0(z, 3, lane) << 48);
+            const uint32_t z1 = shfl_down0(z, 1, lane), z2 = shfl_down0(z1, 1, lane), z3 = shfl_down0(z2, 1, lane);
+            return (uint64_t)z | ((uint64_t)z1 << 16) | ((uint64_t)z2 << 32) | ((uint64_t)z3 << 48);
         };
-        const EroChain CA = ero_chain(hist64(ZA)), CB = ero_chain(hist64(ZB));
-        const uint32_t G = (uint32_t)((ero_at(CA, thr + 1u) | ero_at(CB, thr + 1u)) >> 48);
+        // (plane by plane: most pieces never leave their first diagonal, and the second plane is empty)
+        uint32_t G, inO, inF = 0;
+        {
+            const EroChain CA = ero_chain(hist64(ZA));
+            G = (uint32_t)(ero_at(CA, thr + 1u) >> 48);
+            inO = (uint32_t)(ero_at(CA, order) >> 48);
+            if (F) inF = (uint32_t)(ero_at(CA, F) >> 48);
+        }
+        if (__ballot(ZB != 0u)) {
+            const EroChain CB = ero_chain(hist64(ZB));
+            G |= (uint32_t)(ero_at(CB, thr + 1u) >> 48);
+            inO |= (uint32_t)(ero_at(CB, order) >> 48);
+            if (F) inF |= (uint32_t)(ero_at(CB, F) >> 48);
+        }
         const uint32_t cov = (uint32_t)dilate_fwd(fwd64(G), thr + 1u) & 0xFFFFu;
         const uint32_t cov_prev = ((cov << 1) | (shfl_up0(cov, 1, lane) >> 15)) & 0xFFFFu;
         const uint32_t cov_next = ((cov >> 1) | (shfl_down0(cov, 1, lane) << 15)) & 0xFFFFu;
@@ -508,9 +565,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
         const uint32_t R2 = ((R1 << 1) | (shfl_up0(R1, 1, lane) >> 15)) & range16(xa, gx + 2, gx + (int32_t)min(seqlen - 1u, 0x3FFFFFFFu));
         const uint32_t isR = (R1 | R2) & 0xFFFFu;
         const uint32_t isM = cov & ~isR;
-        const uint32_t U = ~(uint32_t)((ero_at(CA, order) | ero_at(CB, order)) >> 48) & inr16 & range16(xa, (int32_t)(r0 + order - 1u), (int32_t)xe);
-        if (F) ufl[lane] = (uint16_t)(~(uint32_t)((ero_at(CA, F) | ero_at(CB, F)) >> 48) & inr16 & range16(xa, (int32_t)(r0 + F - 1u), (int32_t)xe));
+        const uint32_t U = ~inO & inr16 & range16(xa, (int32_t)(r0 + order - 1u), (int32_t)xe);
+        if (F) ufl[lane] = (uint16_t)(~inF & inr16 & range16(xa, (int32_t)(r0 + F - 1u), (int32_t)xe));
 
+        stamp(2, t_last); // analysis
         // ---- 3. the proof
         bool flag = false;
         if (!(a.xexp & 1u) && __ballot(U != 0u)) {
@@ -520,11 +578,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
             const uint64_t P0 = HU & ~(HU << 1);
             const uint64_t Ec1 = erode_end(HU, cstep + 1u);
             uint64_t Ej = HU, pts = P0;
-            for (uint32_t jc = cstep; jc <= Mrun; jc += cstep) {
+            uint64_t far = 0; // the run started more than Mrun positions back
+            for (uint32_t jc = cstep;; jc += cstep) {
+                if (jc > Mrun) {
+                    far = Ej & (HU << (Mrun + 1u));
+                    break;
+                }
                 Ej &= Ec1 << (jc - cstep);
+                if (!__ballot((Ej >> 48) != 0)) break; // (no run of the piece is that long)
                 pts |= (P0 << jc) & Ej;
             }
-            const uint64_t far = Ej & (HU << (Mrun + 1u)); // the run started more than Mrun positions back
             uint32_t gridm = 0; // positions of this word that are multiples of cstep
             for (uint32_t j = ((uint32_t)xa + cstep - 1u) / cstep * cstep - (uint32_t)xa; j < 16u; j += cstep) gridm |= 1u << j;
             const uint32_t point = ((uint32_t)(pts >> 48) | (gridm & (uint32_t)(far >> 48))) & U;
@@ -631,6 +694,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
             }
         }
 
+        stamp(3, t_last); // proof
         // ---- 4. the characters of the own bases, in whole lines; format::relative_to_ref (format.rs:270-286) on the way
         {
             uint32_t w[4];
@@ -650,10 +714,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
             const uint32_t lo_t = (uint32_t)min(max(o_lo - xa, 0), 16), hi_t = (uint32_t)min(max(o_hi - xa, 0), 16);
             uint8_t *dst = a.chars_out + base16 + 16u * lane;
             if (lo_t == 0u && hi_t == 16u) __builtin_memcpy(dst, &out, 16);
-            else if (hi_t > lo_t) {
+            else if (hi_t > lo_t) { // (the first and the last word of the own bases: whole 4-byte words, then bytes)
 #pragma unroll
-                for (uint32_t t = 0; t < 16u; t++)
-                    if (t >= lo_t && t < hi_t) dst[t] = (uint8_t)(w[t >> 2] >> ((t & 3u) * 8u));
+                for (uint32_t q = 0; q < 4u; q++) {
+                    if (4u * q >= lo_t && 4u * q + 4u <= hi_t) __builtin_memcpy(dst + 4u * q, &w[q], 4);
+                    else if (4u * q + 4u > lo_t && 4u * q < hi_t) {
+#pragma unroll
+                        for (uint32_t t = 4u * q; t < 4u * q + 4u; t++)
+                            if (t >= lo_t && t < hi_t) dst[t] = (uint8_t)(w[q] >> ((t & 3u) * 8u));
+                    }
+                }
             }
         }
         // x of the first own base, 0 .. k (what derandomize_ms_vec gives there: the depth in the stretch of more than t bases that
@@ -699,10 +769,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                 if (fl) atomicAdd(a.qctl + 4, 1u);
             }
         }
+        stamp(4, t_last); // output
     }
+    if (stamps && lane == 0)
+        for (uint32_t i = 0; i < 5u; i++) atomicAdd(a.qctl + 16u + i, cyc[i] >> 4);
+    // the wave's work counters, when the launch counts (kbo_set_plan_stats): every wave adding to a handful of words was a third of
+    // the kernel's time - atomics on one address take about 10 ns each, whoever sends them
+    if (!a.pstats) return;
     // (two sums instead of four: seed and second look-ups stay below 2^16 per wave, filter and table look-ups as well)
     const uint32_t s0 = wave_sum(st_seed | (st_second << 16)), s1 = wave_sum(st_filt | (st_look << 16));
-    if (lane == 0 && a.pstats) {
+    if (lane == 0) {
         uint32_t *st = a.pstats + ((p_first / a.ppw) % kPlanStatSlots) * kPlanStatWords;
         atomicAdd(st + kPlanStatSeedLookups, s0 & 0xFFFFu);
         atomicAdd(st + kPlanStatTabAnchored, s0 >> 16);
@@ -945,8 +1021,8 @@ struct LongLayout {
 LongLayout long_layout(size_t n_seqs, uint64_t total_bases, uint32_t k)
 {
     LongLayout L{};
-    L.own = kLongRegion - 2u * k - 1u;
-    const uint64_t slots = total_bases / L.own + n_seqs + 1;
+    L.own = (kLongRegion - 2u * k - 1u) & ~15u; // (a multiple of 16: long_first_own)
+    const uint64_t slots = total_bases / L.own + 2 * n_seqs + 1; // (a sequence's first piece may be up to 15 bases short)
     L.n_slots = (uint32_t)std::min<uint64_t>(slots, 0x7FFFFF00ull);
     size_t w = 0;
     L.items = w;
@@ -992,7 +1068,7 @@ bool map_long_applies(const DevIndexView &ix, uint32_t thr)
 
 // the pieces of the batch and the kernel; `a` as launch_map_long_redo needs it
 hipError_t launch_map_long(const DevIndexView &ix, const uint8_t *d_q, const uint64_t *d_off, uint32_t n_seqs, uint64_t total_bases, uint32_t thr,
-                           bool fmt, uint8_t *d_chars, void *d_work, hipStream_t stream, LongArgs &a)
+                           bool fmt, uint8_t *d_chars, void *d_work, hipStream_t stream, LongArgs &a, bool count)
 {
     const LongLayout L = long_layout(n_seqs, total_bases, ix.k);
     uint8_t *w = static_cast<uint8_t *>(d_work);
@@ -1015,7 +1091,7 @@ hipError_t launch_map_long(const DevIndexView &ix, const uint8_t *d_q, const uin
     a.redo = w + L.redo;
     a.xin = w + L.xin;
     a.qctl = ctl;
-    a.pstats = reinterpret_cast<uint32_t *>(w + L.pstats);
+    a.pstats = count ? reinterpret_cast<uint32_t *>(w + L.pstats) : nullptr; // (instrumentation: kbo_set_plan_stats)
     a.thr = thr;
     a.fmt = fmt ? 1u : 0u;
     static const int env_x = std::getenv("KBO_LONG_X") ? std::atoi(std::getenv("KBO_LONG_X")) : 0; // experiments: phases left out (timing only)
@@ -1053,11 +1129,11 @@ hipError_t launch_map_long_redo(const LongArgs &a, uint8_t *d_ms, hipStream_t st
     return hipGetLastError();
 }
 
-hipError_t long_read_stats(const void *d_work, size_t n_seqs, uint64_t total_bases, uint32_t k, uint32_t ctl[8], uint32_t *stats, hipStream_t stream)
+hipError_t long_read_stats(const void *d_work, size_t n_seqs, uint64_t total_bases, uint32_t k, uint32_t ctl[32], uint32_t *stats, hipStream_t stream)
 {
     const LongLayout L = long_layout(n_seqs, total_bases, k);
     const uint8_t *w = static_cast<const uint8_t *>(d_work);
-    hipError_t e = hipMemcpyAsync(ctl, w + L.ctl, 32, hipMemcpyDeviceToHost, stream);
+    hipError_t e = hipMemcpyAsync(ctl, w + L.ctl, 128, hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return e;
     e = hipMemcpyAsync(stats, w + L.pstats, kPlanStatSlots * kPlanStatWords * 4, hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return e;

@@ -1,4 +1,3 @@
-# timing only: occupancy variants and pieces per wave
-python -m pytest tests/test_gpu_map_long.py -x -q -m gpu 2>&1 | tail -3
-for w in 4 5 6 8; do for ppw in 8; do echo "WPE=$w PPW=$ppw"; KBO_LONG_PPW=$ppw KBO_HIP_LIB=$PWD/kbo_amd/libkbo_hip_w$w.so python tools/exp_long.py --variants 1pct,clean --no-check --steps 10 2>&1 | grep "Gbp"; done; done
-for ppw in 1 4 16; do echo "WPE=5 PPW=$ppw"; KBO_LONG_PPW=$ppw KBO_HIP_LIB=$PWD/kbo_amd/libkbo_hip_w5.so python tools/exp_long.py --variants 1pct,clean --no-check --steps 10 2>&1 | grep "Gbp"; done
+# timing only: phases of map_long_kernel left out (KBO_LONG_X), the kernel alone (rocprofv3 stats)
+for x in 16 32 1 0; do echo "X=$x"; KBO_LONG_X=$x tools/stats_long.sh ab$x --variants ${1:-1pct} --steps 10 2>&1 | grep "map_long_kernel"; done
+for ppw in 4 16; do echo "PPW=$ppw"; KBO_LONG_PPW=$ppw tools/stats_long.sh abp$ppw --variants ${1:-1pct} --steps 10 2>&1 | grep "map_long_kernel"; done

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--variants", default="1pct,ont")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--count", action="store_true", help="work counters of the kernel (kbo_set_plan_stats: slower)")
     ap.add_argument("--tail", action="store_true", help="the flagged pieces' pass on a second stream, two batches in flight")
     args = ap.parse_args()
     import torch
@@ -35,6 +36,7 @@ def main():
     t0 = time.perf_counter()
     sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=args.k, num_threads=cores))
     sbwt.to_device(-1)
+    kbo_amd.lib().kbo_set_plan_stats(1 if args.count else 0)
     print("index built + on the device in %.1f s; depth table of %d bases" % (time.perf_counter() - t0, sbwt.depth_table_order()), flush=True)
     oi = None
     if not args.no_check:
@@ -75,6 +77,8 @@ def main():
         line = "%-6s %7.1f Gbp/s  %.3f ms per batch of %d Mbases; pieces %d flagged %d (%.2f %%) sub-items %d; per kb: seeds %.2f filter %.2f table %.2f second %.3f" % (
             name, total / ms / 1e6, ms, total // 1_000_000, st["pieces"], st["flagged"], 100.0 * st["flagged"] / max(1, st["pieces"]), st["sub_items"],
             1e3 * st["seed_lookups"] / total, 1e3 * st["filter_lookups"] / total, 1e3 * st["table_lookups"] / total, 1e3 * st["second_lookups"] / total)
+        if st.get("cyc_staging"):
+            line += "  cycles per piece: " + " ".join("%s %d" % (k_[4:], st[k_] // max(1, st["pieces"])) for k_ in st if k_.startswith("cyc_"))
         if oi is not None:
             n_chk = max(1, int(np.searchsorted(offsets, 3_000_000)))
             n_b = int(offsets[n_chk])
