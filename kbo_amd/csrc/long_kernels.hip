@@ -129,6 +129,19 @@ __device__ __forceinline__ uint32_t shfl_down0(uint32_t v, uint32_t d, uint32_t)
 // ends, the others' own bases are `own` (a multiple of 16) each - so that every piece but a sequence's first and last stores its
 // characters in whole aligned blocks (one store instruction a piece; partial blocks only at the two ends of a sequence)
 __device__ __forceinline__ uint32_t long_first_own(uint64_t b, uint32_t own) { return own - (uint32_t)((b + own) & 15u); }
+// the minimum over the wave's 64 lanes, in every lane: swaps inside quads, mirrors inside rows of 16, two broadcasts across the rows
+// - six vector instructions, no trip through the LDS crossbar (tools/ubench/dpp_min.hip checks the encodings on the device)
+__device__ __forceinline__ uint32_t wave_min_dpp(uint32_t v)
+{
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false)); // row_half_mirror
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false)); // row_mirror
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false)); // row_bcast:15 into rows 1, 3
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false)); // row_bcast:31 into rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __global__ __launch_bounds__(256) void long_count_kernel(const uint64_t *__restrict__ off, uint32_t n_seqs, uint32_t own, uint32_t *__restrict__ counts)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -252,6 +265,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
         const uint32_t R0 = min(sl0 - g00, (w0 & 0x3FFu) + ((w0 >> 10) & 0x7FFu) + a.ca), n0 = ((q0 & 15u) + R0 + 15u) >> 4;
         if (((w0 >> 10) & 0x7FFu) != 0u && lane < n0) vq = ld16(a.q, (q0 & ~15u) + 16u * lane);
     }
+    // the digits of a piece's 16 bases per lane and which of them are bases: packed as soon as the bytes are there, a piece ahead
+    auto pack_piece = [&](const uint4 &v, uint32_t q_off_, uint32_t R_, uint32_t &code_, uint32_t &valid_) {
+        bool anyinv;
+        pack16_whole(v, code_, anyinv);
+        valid_ = 0xFFFFu;
+        const uint32_t inr_ = range16(xa, (int32_t)(q_off_ & 15u), (int32_t)((q_off_ & 15u) + R_));
+        // (a byte that is no base, or this lane's word is not all the region's: the per-byte mask)
+        if (__ballot(anyinv && inr_ != 0u)) pack16(v, code_, valid_);
+    };
+    uint32_t code_c = 0, valid_c = 0xFFFFu;
+    {
+        const uint32_t q0 = it_c.x, g00 = it_c.y, sl0 = it_c.z, w0 = it_c.w;
+        pack_piece(vq, q0, min(sl0 - g00, (w0 & 0x3FFu) + ((w0 >> 10) & 0x7FFu) + a.ca), code_c, valid_c);
+    }
+    bool pred_in_lds = false; // ... and that text is in LDS already
     bool pred = false;      // this piece goes on where the last one ended: on diagonal pred_dl, with its text in tn0 / tn1 (units from pred_u0 on)
     int32_t pred_dl = 0, pred_u0 = 0;
     uint2 tn0 = make_uint2(0, 0), tn1 = make_uint2(0, 0);
@@ -281,22 +309,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
         const uint32_t r0 = q_off & 15u, base16 = q_off - r0;
         const uint32_t R = min(seqlen - g0, own0 + own_n + a.ca), xe = r0 + R; // the region on the grid: [r0, xe)
 
-        // ---- 0. the region -> 2-bit digits
-        uint32_t code = 0, valid = 0xFFFFu;
-        if (!skip) {
-            bool anyinv;
-            pack16_whole(vq, code, anyinv);
-            const uint32_t inr_ = range16(xa, (int32_t)r0, (int32_t)xe);
-            // (a byte that is no base, or this lane's word is not all the region's: the per-byte mask)
-            if (__ballot(anyinv && inr_ != 0u)) pack16(vq, code, valid);
-        }
+        // ---- 0. the region's 2-bit digits (packed at the end of the last round); the next piece's bases are asked for now and
+        // packed at the end of this round, BEFORE this piece's characters are stored: loads and stores leave one queue in order,
+        // and a wait for those bases at the top of the next round would be a wait for these stores
+        const uint32_t code = code_c, valid = valid_c;
         if (have_next && nown_n != 0u) {
             vq = make_uint4(0, 0, 0, 0);
             if (lane < nnblk) vq = ld16(a.q, (nq_off & ~15u) + 16u * lane); // (reads <= 15 bytes in front of / behind the region: the buffer's own)
         }
+        bool tx_next = false; // the next piece's text is in LDS already (finish_round)
+        auto finish_round = [&]() {
+            if (have_next && nown_n != 0u) pack_piece(vq, nq_off, nR, code_c, valid_c);
+            if (pred) { // (the proof's list is done with: the text of the next piece goes where it was)
+                __builtin_amdgcn_wave_barrier();
+                tx[lane] = tn0;
+                if (lane < kLongTextUnits - 64u) tx[64u + lane] = tn1;
+                tx_next = true;
+            }
+        };
         if (skip) {
             if (lane == 0) a.redo[piece] = 0;
             pred = false;
+            pred_in_lds = false;
+            finish_round();
             continue;
         }
         const uint32_t inr16 = range16(xa, (int32_t)r0, (int32_t)xe);
@@ -306,7 +341,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
         invl[lane] = (uint16_t)inv16;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (a.xexp & 16u) continue;
+        if (a.xexp & 16u) {
+            pred = false;
+            pred_in_lds = false;
+            finish_round();
+            continue;
+        }
         stamp(0, t_last); // staging
 
         auto from_base = [&](uint32_t S) -> uint32_t { // 16 bases from S on, first one most significant
@@ -384,17 +424,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
         auto left_start = [&](uint32_t mm, uint32_t A, int32_t lower) -> uint32_t {
             const uint32_t m = mm & inr16 & range16(xa, lower, (int32_t)A);
             const uint32_t view = shfl_up0(m, 1, lane) | (m << 16);
+            if (!__ballot((uint32_t)__popc(view) >= kLongTH)) return (uint32_t)lower; // (no word pair with TH mismatches)
+            // (the windows end at every fourth base: the last one with TH mismatches, and the last mismatch inside it)
             uint32_t hits = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < 16u; j++)
-                if (((m >> j) & 1u) && (uint32_t)__popc((view >> (j + 1u)) & 0xFFFFu) >= kLongTH) hits |= 1u << j;
+            for (uint32_t j = 3; j < 16u; j += 4u)
+                if ((uint32_t)__popc((view >> (j + 1u)) & 0xFFFFu) >= kLongTH) hits |= 1u << j;
             const uint64_t bal = __ballot(hits != 0);
             if (!bal) return (uint32_t)lower;
             const int L = 63 - (int)__builtin_clzll(bal);
-            const uint32_t hl = __shfl(hits, L);
-            return 16u * (uint32_t)L + (31u - (uint32_t)__builtin_clz(hl)) + 1u;
+            const uint32_t j = 31u - (uint32_t)__builtin_clz(__shfl(hits, L));
+            const uint32_t w = (__shfl(view, L) >> (j + 1u)) & 0xFFFFu; // the window's mismatches: bit 15 = base 16 L + j
+            return 16u * (uint32_t)L + j - (uint32_t)(__builtin_clz(w) - 16) + 1u;
         };
 
+        const bool pred_now = pred;
         uint32_t ZA = 0, ZB = 0; // the planes: bit j = position 16 lane + j lies in a stretch
         bool end_on_diag = false; // the region's last bases lie on the diagonal end_dl
         int32_t end_dl = 0;
@@ -404,9 +448,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
             uint32_t cur = 0, c = r0, A = 0, start = 0, mm = 0;
             int32_t dl = 0;
             bool have = false;
-            if (pred) { // on from the piece before: its last diagonal, the text already here
-                tx[lane] = tn0;
-                if (lane < kLongTextUnits - 64u) tx[64u + lane] = tn1;
+            if (pred_now) { // on from the piece before: its last diagonal, the text already here
+                if (!pred_in_lds) {
+                    tx[lane] = tn0;
+                    if (lane < kLongTextUnits - 64u) tx[64u + lane] = tn1;
+                }
                 tbase = pred_u0 * 16 - (int32_t)kMapPad;
                 stage_dl = pred_dl;
                 staged = true;
@@ -434,14 +480,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                 // where the diagonal is lost: the first 16 bases from A on with TH mismatches; f = the first of them
                 uint32_t f = xe;
                 {
-                    const uint32_t mr = mm & inr16;
+                    // (the windows start at every fourth base: where one holds TH mismatches from A on, so does one of these within three
+                    // bases or one mismatch of it - whatever is chosen here only decides how many pieces take the second pass)
+                    const uint32_t mr = mm & inr16 & range16(xa, (int32_t)A, (int32_t)xe);
                     const uint32_t view = mr | (shfl_down0(mr, 1, lane) << 16);
                     uint32_t loss = 0;
                     if (__ballot((uint32_t)__popc(view) >= kLongTH)) { // (no word pair with TH mismatches: nothing is lost)
 #pragma unroll
-                        for (uint32_t j = 0; j < 16u; j++)
+                        for (uint32_t j = 0; j < 16u; j += 4u)
                             if ((uint32_t)__popc((view >> j) & 0xFFFFu) >= kLongTH) loss |= 1u << j;
-                        loss &= range16(xa, (int32_t)A, (int32_t)xe);
                     }
                     const uint64_t bal = __ballot(loss != 0);
                     if (bal) {
@@ -487,9 +534,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                         const uint32_t as = (uint32_t)(sft < 0 ? -sft : sft);
                         key = (at << 16) | ((63u - run) << 8) | (as << 1) | (sft > 0 ? 1u : 0u);
                     }
-                    uint32_t best = key;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor(best, o));
+                    const uint32_t best = wave_min_dpp(key);
                     if (best != 0xFFFFFFFFu) {
                         const uint32_t as = (best >> 1) & 0x7Fu;
                         found = true;
@@ -526,7 +571,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
             tn0 = (u_a >= 0 && u_a < n_units) ? a.ix.pc_tm[u_a] : make_uint2(0u, 0x55555555u);
             tn1 = (lane < kLongTextUnits - 64u && u_b >= 0 && u_b < n_units) ? a.ix.pc_tm[u_b] : make_uint2(0u, 0x55555555u);
         }
-        if (a.xexp & 32u) continue;
+        if (a.xexp & 32u) {
+            finish_round();
+            pred_in_lds = tx_next;
+            continue;
+        }
         stamp(1, t_last); // stretches
 
         // ---- 2. the planes -> G, cov, characters, U
@@ -695,6 +744,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
         }
 
         stamp(3, t_last); // proof
+        finish_round();
+        pred_in_lds = tx_next;
         // ---- 4. the characters of the own bases, in whole lines; format::relative_to_ref (format.rs:270-286) on the way
         {
             uint32_t w[4];
