@@ -178,13 +178,14 @@ size_t random_match_threshold(size_t k, size_t n_kmers, size_t alphabet_size, do
 // ---- host_batch.cpp
 struct BatchOnDevice {
     DevBuf q, off, items, ms, lo, hi, plan;
+    DevBuf longw; // work of the kernel for sequences of more than 160 bases (long_kernels.hip)
     DevBuf ms_shard; // sharded indexes: the MS values of one further shard, folded into `ms` by maximum
     DevBuf packed, pscr, exc_pos, exc_byte, packed_out, exc_flag; // (exc_flag: one byte per read of a packed-native launch)
     // packed entry points: 2-bit words in, scanned words per sequence, non-ACGT list, 2-bit words out
     uint64_t total = 0;
     void release()
     {
-        for (DevBuf *b : {&q, &off, &items, &ms, &lo, &hi, &plan, &packed, &pscr, &exc_pos, &exc_byte, &packed_out, &exc_flag, &ms_shard}) b->release();
+        for (DevBuf *b : {&q, &off, &items, &ms, &lo, &hi, &plan, &longw, &packed, &pscr, &exc_pos, &exc_byte, &packed_out, &exc_flag, &ms_shard}) b->release();
     }
 };
 // a slab of a packed batch (pack_kernels.hip: sequence s = ceil(len / 16) u32 words, 2 bits per base): what

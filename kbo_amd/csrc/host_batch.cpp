@@ -281,6 +281,21 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
                 return;
             }
         }
+        if (map && shards.size() == 1 && !call && !want_ival && longest_seq > 160u && kbo::map_long_applies(view, map->threshold)) {
+            // kbo::matches / map / find over sequences of more than 160 bases - contigs, whole reference sequences, long reads:
+            // one wave per piece of a sequence (long_kernels.hip), its flagged pieces by the plain walk + the literal recurrences
+            const size_t wb = kbo::long_work_bytes(n_seqs, total, idx->host.k);
+            if (wb) {
+                need_bytes();
+                B.longw.ensure(wb);
+                kbo::LongArgs la{};
+                HIP_OK(kbo::launch_map_long(view, B.q.as<uint8_t>(), B.off.as<uint64_t>(), (uint32_t)n_seqs, total, map->threshold, map->format,
+                                            map->d_chars, B.longw.p, stream, la, g_plan_stats.load()));
+                HIP_OK(kbo::launch_map_long_redo(la, B.ms.as<uint8_t>(), stream));
+                map->done = true;
+                return;
+            }
+        }
         need_bytes();
         HIP_OK(kbo::launch_ms_walk(a, walk_max_waves(), stream));
         plan_after_launch(a, stream, plan_state);

@@ -231,3 +231,26 @@ def test_find_over_long_sequences(oracle):
         want_recs, want_first = oracle.run_lengths_batch(exp_chars, offsets, gap)
         assert np.array_equal(np.asarray(first, dtype=np.uint64), want_first), gap
         assert np.array_equal(np.asarray(recs, dtype=np.uint64).reshape(-1, 7), want_recs), gap
+
+
+def test_host_entry_points_over_long_sequences(oracle):
+    """kbo_matches_batch / kbo_map_batch / kbo_find_batch and the single-sequence kbo::matches / map / find over host buffers: the
+    slabs of a batch with sequences of more than 160 bases take the kernel for sequences of any length (host_batch.cpp)"""
+    rng = np.random.default_rng(83)
+    contigs = _genome(rng, 400_000, contigs=2)
+    sbwt, _ = kbo_amd.build(contigs, kbo_amd.BuildOpts(k=31, num_threads=threads()))
+    sbwt.to_device(-1)  # (the plan structures now, not once the copy has seen the bases that pay for them)
+    ora = oracle.Index.build([c.tobytes() for c in contigs], k=31)
+    seqs = [q for q in _sequences(rng, contigs, 80, [5, 150, 161, 500, 3000, 20_000, 100_000], 0.01, 0.002, 0.3) if len(q) >= 3]
+    concat, offsets = _batch_of(seqs)
+    exp = ora.matches_batch(concat, offsets, 1e-7, n_threads=threads())
+    assert np.array_equal(batch.matches_batch(sbwt, concat, offsets), exp)
+    assert np.array_equal(batch.map_batch(sbwt, concat, offsets), np.frombuffer(oracle.relative_to_ref(concat, exp), dtype=np.uint8))
+    for gap in (0, 50):
+        rles, ro = batch.find_batch(sbwt, concat, offsets, kbo_amd.FindOpts(max_gap_len=gap))
+        want_recs, want_first = oracle.run_lengths_batch(exp, offsets, gap)
+        assert np.array_equal(ro, want_first), gap
+        got = np.array([tuple(r) for r in rles], dtype=np.uint64).reshape(-1, 7) if isinstance(rles, list) else rles
+        assert np.array_equal(got, want_recs), gap
+    q = seqs[-1]
+    assert kbo_amd.matches(q.tobytes(), sbwt) == [chr(v) for v in exp[int(offsets[-2]):]]
