@@ -455,7 +455,7 @@ def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, pipes=None):
     def measure(name, ix, o, concat, offsets, note):
         dev = batch.DeviceBatch(ix, concat, offsets, device=device, format=True, want_ms=False)
         devs = [dev]
-        if pipes is not None and dev.max_len <= 160:  # (in flight as in the headline: the same reads, further sets of buffers)
+        if pipes is not None:  # (in flight as in the headline: the same reads, further sets of buffers)
             for _ in range(2 * len(pipes) - 1):
                 devs.append(batch.DeviceBatch(ix, concat, offsets, device=device, format=True, want_ms=False))
         elapsed, a1, dt, _ = run_batch(devs, stream, False, 12, 4, torch, device, args.two_kernels, pipes if len(devs) > 1 else None)
@@ -469,8 +469,7 @@ def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, pipes=None):
         extra = {}
         if fused and dev.max_len > 160:  # (sequences of any length: what the kernel's pieces did)
             st = dev.long_stats()
-            extra = {"pieces": st["pieces"], "flagged_pieces": st["flagged"], "table_lookups_per_kb": round(1e3 * st["table_lookups"] / max(1, int(offsets[-1])), 2),
-                     "filter_lookups_per_kb": round(1e3 * st["filter_lookups"] / max(1, int(offsets[-1])), 2)}
+            extra = {"pieces": st["pieces"], "flagged_pieces": st["flagged"]}  # (flagged: to the plain walk + the literal recurrences)
         dev.walk(stream)
         torch.cuda.synchronize(device)
         ok = bool(ok and np.array_equal(dev.ms[:n_b].cpu().numpy(), exp_d))

@@ -47,6 +47,7 @@ struct DevCopy {
     DevBuf pc_tm, seed_pos;          // map_reads_kernel's 2-bit text + marks and its table of seed positions (copies with a depth table)
     // what making this copy cost (kbo_index_device_layout): seconds of host work / device builds / uploads, by part
     bool plan_built = false;         // path cover, recovery lines, tables: made by the first use that pays for them (device_index.cpp)
+    bool plan_failed = false;        // ... or could not be made (no memory): not tried again on every call; the copy walks plainly
     uint64_t bases_seen = 0;         // bases of the batches that asked for this copy so far (guarded by the index's mutex)
     struct Setup {
         double layout_s = 0, cover_s = 0, lines_s = 0, seed_s = 0, dtab_s = 0, upload_s = 0;

@@ -145,8 +145,10 @@ void build_plan_structures(kbo_index *idx, DevCopy *dc)
         uint64_t budget = g_plan_table_budget.load();
         if (budget == 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = free_b / 2;
         const size_t tmp_bytes = kbo::dtab_tmp_bytes(cap);
-        auto need = [&](int o, bool grp) { // peak during the build: the plain table, the frontier, and the grouped copy
-            return (uint64_t)kbo::dtab_bytes((uint32_t)o, false) + tmp_bytes + (grp ? kbo::dtab_bytes((uint32_t)o, true) : 0) + (((uint64_t)12) << (2u * std::min(o, 14)));
+        auto need = [&](int o, bool grp) { // peak during the build: the plain table, the frontier, the grouped copy, the seed table and its
+                                           // positions, the anchor hash (whether or not this copy gets one), the 2-bit text and the filter
+            return (uint64_t)kbo::dtab_bytes((uint32_t)o, false) + tmp_bytes + (grp ? kbo::dtab_bytes((uint32_t)o, true) : 0) + (((uint64_t)12) << (2u * std::min(o, 14))) +
+                   ((uint64_t)8 << kbo::dtab_anchor_bits(idx->host.n_sets, (uint32_t)o)) + idx->host.n_sets + (4u << 20);
         };
         while (order > 0 && budget != 0 && need(order, grouped) > budget) {
             if (grouped) grouped = false;
@@ -375,18 +377,33 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
     // ---- the plan structures: at once when asked for (kbo_index_to_device) or cheap, else once the copy has seen the bases that
     // pay for them (plan_break_even_bases); a copy that may not hold them walks plainly, with the same results
     const bool plan_on = plan_enabled(idx); // (this index's own option first: kbo_index_set_opts)
-    if (!dc->plan_built && plan_on && !idx->transient) {
+    if (!dc->plan_built && !dc->plan_failed && plan_on && !idx->transient) {
         dc->bases_seen += work_bases;
         if (prepare || dc->bases_seen >= plan_break_even_bases(idx)) {
             int prev = current_device();
             if (prev != device) HIP_OK(hipSetDevice(device));
             try {
                 build_plan_structures(idx, dc);
+            } catch (const KboError &e) {
+                // A copy never fails because of its plan structures: what was made so far is released (a half-built set - a seed
+                // table's depth without its table, a text without its positions - must not reach a launch), the copy is marked so
+                // that the build is not paid again by every later call, and it walks plainly - with the same results.  An explicit
+                // kbo_index_to_device still reports the failure.
+                for (DevBuf *b : {&dc->pc_text, &dc->pc_pos, &dc->pc_node, &dc->fat, &dc->seed_tab, &dc->dtab, &dc->anchor, &dc->dfilt, &dc->pc_tm, &dc->seed_pos})
+                    b->release();
+                dc->seed_d = dc->dtab_order = dc->anchor_bits = dc->dfilt_bases = 0;
+                dc->dtab_grouped = false;
+                dc->fat_null = 0;
+                dc->plan_failed = true;
+                (void)hipGetLastError();
+                if (prev != device) (void)hipSetDevice(prev);
+                if (prepare) throw;
+                last_error() = std::string("plan structures not built (the copy walks plainly): ") + e.what();
             } catch (...) {
                 if (prev != device) (void)hipSetDevice(prev);
                 throw;
             }
-            if (prev != device) HIP_OK(hipSetDevice(prev));
+            if (prev != device && !dc->plan_failed) HIP_OK(hipSetDevice(prev));
         }
     }
     if (plan) *plan = &dc->plan;

@@ -64,6 +64,7 @@ void make_items_host(const uint64_t *offsets, size_t n_seqs, uint32_t k, std::ve
 {
     const uint64_t total = offsets[n_seqs] - offsets[0];
     const uint64_t chunk = walk_chunk(total, n_seqs, k);
+    KBO_REQUIRE(!call || (chunk & 3u) == 0, KBO_E_BAD_ARG, "call mode: chunks of a multiple of four bases (kernels.hpp launch_make_chunk_items)");
     items.clear();
     for (size_t s = 0; s < n_seqs; s++) {
         const uint64_t b = offsets[s], e = offsets[s + 1];

@@ -271,7 +271,8 @@ void set_plan_params(int dmin, int cap, int gap = 0, int chunk = 0); // tuning (
 // offsets (n_seqs+1) -> one item per sequence
 hipError_t launch_make_items(const uint64_t *d_offsets, uint32_t n_seqs, WalkItem *d_items,
                              hipStream_t stream);
-// offsets -> items of at most `chunk` emitted bases (+ k-1 warm-up bases), n_slots >= total/chunk + n_seqs item
+// offsets -> items of at most `chunk` emitted bases (+ k-1 warm-up bases; call mode: `chunk` a multiple of 4, else
+// hipErrorInvalidValue: see the launcher), n_slots >= total/chunk + n_seqs item
 // slots are written (unused ones as empty items); d_scratch: chunk_items_scratch_words(n_seqs) u32
 size_t chunk_items_scratch_words(uint32_t n_seqs);
 hipError_t launch_make_chunk_items(const uint64_t *d_offsets, uint32_t n_seqs, uint32_t chunk, uint32_t k,

@@ -67,7 +67,7 @@ def test_bench_line_single_process_with_extras(tmp_path):
     r = _run(["--genome", "400000", "--reads", "30000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1.5", "--extras"], tmp_path)
     _check_line(r, 1)
     names = [v["variant"] for v in r["sensitivity"]]
-    assert len(names) == 7 and any("reverse" in n for n in names) and any("repeat" in n for n in names)
+    assert len(names) == 8 and any("reverse" in n for n in names) and any("repeat" in n for n in names) and any("10 kbp reads, 1%" in n for n in names)
     assert any("insertions / deletions" in n and "ONT" not in n for n in names) and any("ONT-like" in n for n in names)
     assert all(v["bit_exact_vs_oracle"] is True and v["value"] > 0 for v in r["sensitivity"])
     assert r["host_to_host"]["value"] > 0
