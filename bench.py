@@ -548,6 +548,43 @@ def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, pipes=None):
     return out
 
 
+def ms_leg(args, sbwt, oi, concat, offsets, torch, device, stream, pipes):
+    """The forms of the API that return the MATCHING STATISTICS (index.rs:243-256; `metric` says "bit-exact MS"): kbo_ms_batch_dev (MS
+    bytes only) and kbo_map_batch_dev with want_ms (map_reads_kernel's MS-emitting instantiation: MS bytes + characters), each timed
+    over the headline's batch - resident, 4 warm-up + 12 timed steps, in flight like the headline where the entry point has a tail
+    stream - and every MS byte (and character) of the batch compared with the oracle."""
+    from kbo_amd import batch
+    from oracle import binding as ora
+    cores, _ = usable_cores()
+    exp_chars, exp_d = oi.matches_batch(concat, offsets, 1e-7, n_threads=cores, want_d=True)
+    exp_map = np.frombuffer(ora.relative_to_ref(concat, exp_chars), dtype=np.uint8)
+    total = int(offsets[-1])
+    out = {}
+    # kbo_ms_batch_dev: the walk alone (plan + depth table + second pass inside it), MS bytes out
+    dev = batch.DeviceBatch(sbwt, concat, offsets, device=device, format=True, want_ms=True)
+    for _ in range(4):
+        dev.walk(stream)
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(12):
+        dev.walk(stream)
+    e1.record(stream)
+    torch.cuda.synchronize(device)
+    ms = e0.elapsed_time(e1) / 12
+    out["kbo_ms_batch_dev"] = {"value": round(total / ms / 1e3, 1), "unit": "Mbp/s", "step_ms": round(ms, 4), "bytes_out_per_base": 1,
+                               "bit_exact_vs_oracle": bool(np.array_equal(dev.ms[:total].cpu().numpy(), exp_d))}
+    del dev
+    # kbo_map_batch_dev(want_ms): the one kernel in its MS-emitting form, MS bytes + formatted characters out
+    devs = [batch.DeviceBatch(sbwt, concat, offsets, device=device, format=True, want_ms=True) for _ in range(2 * len(pipes) if pipes else 1)]
+    elapsed, _, _, _ = run_batch(devs, stream, False, 12, 4, torch, device, False, pipes)
+    ok = all(bool(np.array_equal(d.ms[:total].cpu().numpy(), exp_d) and np.array_equal(d.chars[:total].cpu().numpy(), exp_map)) for d in devs)
+    out["kbo_map_batch_dev_want_ms"] = {"value": round(total * 12 / elapsed / 1e6, 1), "unit": "Mbp/s", "step_ms": round(elapsed / 12 * 1e3, 4),
+                                        "bytes_out_per_base": 2, "one_kernel": bool(devs[0].fused), "batches_in_flight": len(devs),
+                                        "bit_exact_vs_oracle": ok}
+    return out
+
+
 def host_to_host_leg(args, sbwt, genome):
     """The product entry point a binding calls: kbo_map_batch over pageable host buffers (H2D, kernels, D2H in a three-stage
     slab pipeline); PCIe-inclusive, never the reported value.  4 x the batch, best of 3."""
@@ -882,7 +919,7 @@ def main(argv=None):
         L.kbo_set_plan_stats(0)
         gpu_d = dev.ms.cpu().numpy()
         cpu = b_ref = exact = ops = b_plan = model = None
-        sens = h2h = None
+        sens = h2h = ms_var = None
         if world == 1 and not args.no_cpu_baseline and not args.no_extras and (args.extras or not args.custom):
             # (first of the legs behind the timed region: its pinned staging buffers are made by its first call, and behind the
             # oracle's and the variants' gigabytes of host allocations they come out of scattered pages - 21 instead of 40 Gbp/s)
@@ -916,6 +953,7 @@ def main(argv=None):
                 exact = bool(exact and model["ms_equal_to_gpu"])
             if world == 1 and not args.no_extras and (args.extras or not args.custom):
                 sens = sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, pipes if piped else None)
+                ms_var = ms_leg(args, sbwt, oi, concat0, offsets0, torch, device, stream, pipes if piped else None)
         # fabric-side traffic and L2 misses of the A1 stage, from the committed rocprofv3 passes of this exact
         # workload and walk mode (PMC passes cannot run inside the timed region: separate runs, tools/profile_bench.sh)
         wl_key = f"{args.genome}x{n_mine}x{args.read_len}x{args.sub_rate:g}:{('map' if one_kernel else 'table' if sbwt.depth_table_order() > 0 else 'plan') if planned else 'plain'}"
@@ -940,8 +978,7 @@ def main(argv=None):
         rank_b, lcs_b = sbwt.device_bytes()
         dto = sbwt.depth_table_order()
         dtab_b = 0 if dto == 0 else (4 ** (dto + 1) if dto >= 4 else 4 ** dto)  # (grouped from 4 bases on: DESIGN.md section 4.2)
-        from oracle import binding as _ora_params  # (parameters only: what the device copy was given by default)
-        seed_d = _ora_params.shipped_plan_params(args.k, sbwt.n_sets(), depth_table=dto).seed_table_depth if planned else 0
+        seed_d = int(lay["seed_depth"]) if planned else 0  # (from the library: kbo_index_device_layout - what the copy really holds)
         seed_b = 8 * 4 ** seed_d if seed_d else 0
         pair_b, plan_b = sbwt.device_pair_bytes(), sbwt.device_plan_bytes()
         std = (args.genome, args.reads, args.read_len, args.sub_rate, args.k) in tuple((g, r, 150, 0.01, 31) for g, r, _, _ in PRESETS.values())
@@ -1092,6 +1129,7 @@ def main(argv=None):
             "bit_exact_vs_oracle": exact,
             "reference_ops_per_base": ops,
             "sensitivity": sens,
+            "ms_variant": ms_var,
             "host_to_host": h2h,
         }
         print(json.dumps(result), flush=True)

@@ -245,3 +245,61 @@ pub fn call_batch(idx: &GpuIndex, seqs: &[Vec<u8>], opts: &kbo::CallOpts) -> Vec
     unsafe { ffi::kbo_free(p as *mut c_void) };
     out
 }
+
+/// The recipe that turns SURVEY.md section 8(f) 4 from "unpinned" into "pinned" on a machine that has the `sbwt` crate and an MI355X
+/// (neither is in the image this was written in: never compiled, never run).  The reference's own test inputs (index.rs:262-275,
+/// lib.rs:600-609, lib.rs:786-805): the index the crate builds, handed over by `export_sbwt_parts` -> `kbo_index_from_parts`, must
+/// give what `sbwt::StreamingIndex::matching_statistics` gives - depths AND intervals - and `matches` / `find` must give the crate's.
+#[cfg(test)]
+mod pin_against_the_crate {
+    use super::*;
+
+    fn crate_ms(query: &[u8], index: &sbwt::SbwtIndexVariant, lcs: &sbwt::LcsArray) -> Vec<(usize, Range<usize>)> {
+        kbo::index::query_sbwt(query, index, lcs) // index.rs:243-256: StreamingIndex::new + matching_statistics
+    }
+
+    #[test]
+    fn query_sbwt_of_the_handed_over_index_equals_the_crates() {
+        // index.rs:265-268
+        let reference: Vec<Vec<u8>> = vec![b"AAAGAACCA-TCAGGGCG".to_vec()];
+        let query = b"CAAGCCACTCATTGGGTC".to_vec();
+        let mut opts = kbo::BuildOpts::default();
+        opts.k = 3;
+        let (sbwt, lcs) = kbo::index::build_sbwt_from_vecs(&reference, &Some(opts));
+        let gpu = GpuIndex::from_sbwt(&sbwt);
+        let want = crate_ms(&query, &sbwt, &lcs);
+        assert_eq!(want.iter().map(|x| x.0).collect::<Vec<_>>(), vec![1, 2, 2, 3, 2, 2, 3, 2, 1, 2, 3, 1, 1, 1, 2, 3, 1, 2]); // index.rs:270
+        assert_eq!(query_sbwt(&query, &gpu), want); // depths and intervals
+    }
+
+    #[test]
+    fn random_genome_every_position() {
+        // 50 kbp, k = 31, 1 % substitutions, a few N: depths and intervals of 200 reads of 150 bases and of one 20 kbp sequence
+        let mut x = 0x6B626F0001u64;
+        let mut next = || { x = x.wrapping_add(0x9E3779B97F4A7C15); let mut z = x; z = (z ^ (z >> 30)).wrapping_mul(0xBF58476D1CE4E5B9);
+                            z = (z ^ (z >> 27)).wrapping_mul(0x94D049BB133111EB); z ^ (z >> 31) };
+        let genome: Vec<u8> = (0..50_000).map(|_| b"ACGT"[(next() >> 62) as usize]).collect();
+        let (sbwt, lcs) = kbo::index::build_sbwt_from_vecs(&[genome.clone()], &Some(kbo::BuildOpts::default()));
+        let gpu = GpuIndex::from_sbwt(&sbwt);
+        let mut reads: Vec<Vec<u8>> = (0..200).map(|_| { let s = (next() % (50_000 - 150)) as usize; genome[s..s + 150].to_vec() }).collect();
+        reads.push(genome[10_000..30_000].to_vec());
+        for r in reads.iter_mut() {
+            for b in r.iter_mut() { let v = next(); if (v & 0xFFFF) < 655 { *b = b"ACGT"[(v >> 62) as usize]; } else if (v & 0xFFFFF) == 7 { *b = b'N'; } }
+            assert_eq!(query_sbwt(r, &gpu), crate_ms(r, &sbwt, &lcs));
+        }
+    }
+
+    #[test]
+    fn matches_and_find_equal_the_crates() {
+        // lib.rs:600-609
+        let reference: Vec<Vec<u8>> = vec![b"AAAGAACCA-TCAGGGCG".to_vec()];
+        let query = b"GTGACTATGAGGAT".to_vec();
+        let mut opts = kbo::BuildOpts::default();
+        opts.k = 3;
+        let (sbwt, lcs) = kbo::build(&reference, opts);
+        let gpu = GpuIndex::from_sbwt(&sbwt);
+        assert_eq!(matches(&query, &gpu, kbo::MatchOpts::default()), kbo::matches(&query, &sbwt, &lcs, kbo::MatchOpts::default()));
+        assert_eq!(matches(&query, &gpu, kbo::MatchOpts::default()).iter().collect::<String>(), "---------MMM--"); // lib.rs:607
+        assert_eq!(find(&query, &gpu, kbo::FindOpts::default()), kbo::find(&query, &sbwt, &lcs, kbo::FindOpts::default()));
+    }
+}

@@ -764,8 +764,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
             const int32_t o_lo = (int32_t)(r0 + own0), o_hi = o_lo + (int32_t)own_n;
             const uint32_t lo_t = (uint32_t)min(max(o_lo - xa, 0), 16), hi_t = (uint32_t)min(max(o_hi - xa, 0), 16);
             uint8_t *dst = a.chars_out + base16 + 16u * lane;
-            if (lo_t == 0u && hi_t == 16u) __builtin_memcpy(dst, &out, 16);
-            else if (hi_t > lo_t) { // (the first and the last word of the own bases: whole 4-byte words, then bytes)
+            const bool whole = lo_t == 0u && hi_t == 16u, part = !whole && hi_t > lo_t;
+            if (whole) __builtin_memcpy(dst, &out, 16);
+            // (pieces start and end where 16-byte blocks of the buffer do, but for a sequence's first and last: rarely any partial block)
+            if (__ballot(part) != 0 && part) { // (the first and the last word of the own bases: whole 4-byte words, then bytes)
 #pragma unroll
                 for (uint32_t q = 0; q < 4u; q++) {
                     if (4u * q >= lo_t && 4u * q + 4u <= hi_t) __builtin_memcpy(dst + 4u * q, &w[q], 4);
