@@ -266,7 +266,7 @@ class DeviceBatch:
         out = np.zeros(16, dtype=np.uint64)
         check(lib().kbo_long_stats_dev(self.n_seqs, self.total, self.max_len, self.k, self.work.data_ptr(), out.ctypes.data, s.cuda_stream))
         names = ("pieces", "flagged", "sub_items", "seed_lookups", "filter_lookups", "table_lookups", "second_lookups", "_",
-                 "cyc_staging", "cyc_stretches", "cyc_planes", "cyc_proof", "cyc_output")
+                 "cyc_staging", "cyc_stretches", "cyc_planes", "cyc_proof", "cyc_output", "band_tried", "band_taken")
         return {n: int(v) for n, v in zip(names, out) if n != "_"}
 
     def derand_translate(self, stream=None):

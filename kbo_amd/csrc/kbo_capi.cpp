@@ -1219,6 +1219,8 @@ int kbo_long_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, 
             out[4] += st[sl * kbo::kPlanStatWords + kbo::kPlanStatSeedExtensions];
             out[5] += st[sl * kbo::kPlanStatWords + kbo::kPlanStatTabLookups];
             out[6] += st[sl * kbo::kPlanStatWords + kbo::kPlanStatTabAnchored];
+            out[13] += st[sl * kbo::kPlanStatWords + kbo::kPlanStatUnits];
+            out[14] += st[sl * kbo::kPlanStatWords + kbo::kPlanStatAccepted];
         }
     });
 }

@@ -54,7 +54,7 @@ constexpr uint32_t kLongTH = 6;         // mismatches in 16 bases that end a dia
 constexpr uint32_t kLongRun = 10;       // matching bases that start one
 constexpr uint32_t kLongLds = 2048;     // bytes of LDS per wave
 #ifndef KBO_LONG_WPE
-#define KBO_LONG_WPE 5
+#define KBO_LONG_WPE 4
 #endif
 
 __device__ __forceinline__ uint32_t funnel2(uint32_t hi, uint32_t lo, uint32_t r) // 16 digits from digit r of hi on
@@ -71,39 +71,36 @@ __device__ __forceinline__ uint32_t grid_to_mask16(uint32_t m)
     m = (m | (m >> 8)) & 0x0000FFFFu;
     return __builtin_bitreverse32(m) >> 16;
 }
+// bit j for base j -> bit 2 (15 - j) on the digit grid
+__device__ __forceinline__ uint32_t grid_from_mask16(uint32_t m)
+{
+    m = __builtin_bitreverse32(m) >> 16; // base j at bit 15 - j
+    m = (m | (m << 8)) & 0x00FF00FFu;
+    m = (m | (m << 4)) & 0x0F0F0F0Fu;
+    m = (m | (m << 2)) & 0x33333333u;
+    m = (m | (m << 1)) & 0x55555555u;
+    return m;
+}
 // bits t of a word at grid position xa with lo <= xa + t < hi
 __device__ __forceinline__ uint32_t range16(int32_t xa, int32_t lo, int32_t hi)
 {
     const int32_t a = min(max(lo - xa, 0), 16), b = min(max(hi - xa, 0), 16);
     return b > a ? (((1u << b) - 1u) & ~((1u << a) - 1u)) : 0u;
 }
-// AND over the L positions that end at each bit (bits in front of bit 0 count as 0), 1 <= L <= 63
+// AND over the L positions that end at each bit (bits in front of bit 0 count as 0), 1 <= L <= 63: by doubling up to the largest
+// power of two p <= L, then two windows of p (see ero_at)
 __device__ __forceinline__ uint64_t erode_end(uint64_t h, uint32_t L)
 {
-    const uint64_t s2 = h & (h << 1), s4 = s2 & (s2 << 2), s8 = s4 & (s4 << 4), s16 = s8 & (s8 << 8), s32 = s16 & (s16 << 16);
-    uint64_t r = ~0ull;
-    uint32_t pos = 0;
-    if (L & 32u) { r &= s32 << pos; pos += 32u; }
-    if (L & 16u) { r &= s16 << pos; pos += 16u; }
-    if (L & 8u) { r &= s8 << pos; pos += 8u; }
-    if (L & 4u) { r &= s4 << pos; pos += 4u; }
-    if (L & 2u) { r &= s2 << pos; pos += 2u; }
-    if (L & 1u) { r &= h << pos; }
-    return r;
+    const uint32_t lg = 31u - (uint32_t)__builtin_clz(L);
+    for (uint32_t w = 0; w < lg; w++) h &= h << (1u << w);
+    return h & (h << (L - (1u << lg)));
 }
 // OR over the L positions that start at each bit (bits behind bit 63 count as 0)
 __device__ __forceinline__ uint64_t dilate_fwd(uint64_t f, uint32_t L)
 {
-    const uint64_t d2 = f | (f >> 1), d4 = d2 | (d2 >> 2), d8 = d4 | (d4 >> 4), d16 = d8 | (d8 >> 8), d32 = d16 | (d16 >> 16);
-    uint64_t r = 0;
-    uint32_t pos = 0;
-    if (L & 32u) { r |= d32 >> pos; pos += 32u; }
-    if (L & 16u) { r |= d16 >> pos; pos += 16u; }
-    if (L & 8u) { r |= d8 >> pos; pos += 8u; }
-    if (L & 4u) { r |= d4 >> pos; pos += 4u; }
-    if (L & 2u) { r |= d2 >> pos; pos += 2u; }
-    if (L & 1u) { r |= f >> pos; }
-    return r;
+    const uint32_t lg = 31u - (uint32_t)__builtin_clz(L);
+    for (uint32_t w = 0; w < lg; w++) f |= f >> (1u << w);
+    return f | (f >> (L - (1u << lg)));
 }
 // 4 bits -> 4 bytes of 0xFF / 0x00
 __device__ __forceinline__ uint32_t spread4(uint32_t m4) { return (((m4 & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu; }
@@ -196,17 +193,15 @@ __device__ __forceinline__ EroChain ero_chain(uint64_t h)
     c.s32 = c.s16 & (c.s16 << 16);
     return c;
 }
-__device__ __forceinline__ uint64_t ero_at(const EroChain &c, uint32_t L) // AND over the L positions that end at each bit
+// AND over the L positions that end at each bit, 1 <= L <= 63: two windows of the largest power of two below L + 1 cover them
+// (overlapping windows do not matter to an AND) - one shift and one AND whatever L is, and two small numbers per length instead of
+// the six conditions of a bit-by-bit composition (which the compiler kept in scalar registers it did not have: a third of this
+// phase's instructions were lane reads of spilled ones)
+__device__ __forceinline__ uint64_t ero_at(const EroChain &c, uint32_t L)
 {
-    uint64_t r = ~0ull;
-    uint32_t pos = 0;
-    if (L & 32u) { r &= c.s32 << pos; pos += 32u; }
-    if (L & 16u) { r &= c.s16 << pos; pos += 16u; }
-    if (L & 8u) { r &= c.s8 << pos; pos += 8u; }
-    if (L & 4u) { r &= c.s4 << pos; pos += 4u; }
-    if (L & 2u) { r &= c.s2 << pos; pos += 2u; }
-    if (L & 1u) { r &= c.s1 << pos; }
-    return r;
+    const uint32_t lg = 31u - (uint32_t)__builtin_clz(L);
+    const uint64_t sp = lg == 0u ? c.s1 : lg == 1u ? c.s2 : lg == 2u ? c.s4 : lg == 3u ? c.s8 : lg == 4u ? c.s16 : c.s32;
+    return sp & (sp << (L - (1u << lg)));
 }
 
 // One wave takes a.ppw consecutive pieces, one after the other: the next piece's bases are on their way while this one is
@@ -255,7 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
     const uint32_t dmask = D >= 16u ? 0xFFFFFFFFu : ((1u << (2u * D)) - 1u);
     const int32_t n_units = (int32_t)(((uint64_t)a.ix.n + kMapPad + 256u) / 16u + 2u); // (pack_text_units)
     const uint32_t cstep = thr - order, Mrun = cstep * (47u / cstep);
-    uint32_t st_seed = 0, st_look = 0, st_filt = 0, st_second = 0;
+    uint32_t st_seed = 0, st_look = 0, st_filt = 0, st_second = 0, st_band = 0; // (st_band: wave-uniform; tried | taken << 16)
 
     uint4 it_c = item_at(p_first), it_n = item_at(min(p_first + 1u, p_last));
     // the bases of the wave's first piece
@@ -447,7 +442,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
             const int32_t J = (int32_t)order - 3;
             uint32_t cur = 0, c = r0, A = 0, start = 0, mm = 0;
             int32_t dl = 0;
-            bool have = false;
+            bool have = false, band_tried = false;
             if (pred_now) { // on from the piece before: its last diagonal, the text already here
                 if (!pred_in_lds) {
                     tx[lane] = tn0;
@@ -506,6 +501,160 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                     end_on_diag = true;
                     end_dl = dl;
                     break;
+                }
+                // ---- the first loss of a piece: ALL its words at once, each on the diagonal of the band dl - kBand .. dl + kBand it matches
+                // best.  A sequence with an insertion or deletion every 80 bases leaves its diagonal a dozen times a piece, by a
+                // base or two each time: one pass of every lane over the band instead of a dozen rounds of this loop (each of which
+                // every lane takes part in).  A word that matches none (a junction inside it, a cluster of substitutions) is cut
+                // between its neighbours' diagonals where the two together mismatch least.  Any word left without a diagonal: the
+                // band was not it (a long insertion, a join) - the planes are dropped and the loop goes on as before.
+                if (!band_tried && !(a.xexp & 8u)) {
+                    band_tried = true;
+                    constexpr int kBand = 6;
+                    const uint32_t idx0 = (uint32_t)(dl - kBand + xa - tbase), unit = idx0 >> 4, r0b = idx0 & 15u;
+                    const uint2 t0 = tx[unit], t1 = tx[unit + 1u], t2 = tx[unit + 2u];
+                    // 48 digits of text and marks from digit r0b of the first unit on: the word on the band's s-th diagonal is 16 of them
+                    auto band_mask = [&](uint32_t sidx) -> uint32_t { // mismatches on the digit grid (bit 2 (15 - j) = base j)
+                        const uint32_t rr = r0b + sidx, hi = rr >> 4, r = rr & 15u; // rr <= 15 + 12
+                        const uint32_t a0 = hi ? t1.x : t0.x, a1 = hi ? t2.x : t1.x, b0 = hi ? t1.y : t0.y, b1 = hi ? t2.y : t1.y;
+                        const uint32_t x = code ^ funnel2(a0, a1, r);
+                        return (x | (x >> 1) | funnel2(b0, b1, r)) & 0x55555555u;
+                    };
+                    const uint32_t gin = grid_from_mask16(inr16 & ~inv16); // the word's bases that count, on the digit grid
+                    uint32_t best_c = 99u, best_s = (uint32_t)kBand;
+#pragma unroll
+                    for (int o = 0; o <= 2 * kBand; o++) { // (from the middle outwards: of equal counts the nearer diagonal)
+                        const uint32_t sidx = (uint32_t)(kBand + ((o & 1) ? -((o + 1) / 2) : (o / 2)));
+                        const uint32_t c = (uint32_t)__popc(band_mask(sidx) & gin);
+                        if (c < best_c) {
+                            best_c = c;
+                            best_s = sidx;
+                        }
+                    }
+                    const uint32_t n_in = (uint32_t)__popc(inr16);
+                    const bool in_lane = n_in != 0u;
+                    const bool decided = in_lane && best_c <= 2u && (n_in - (uint32_t)__popc(inv16)) >= 8u; // (at least 8 bases that say so)
+                    const uint64_t dec = __ballot(decided), inl = __ballot(in_lane);
+                    bool ok = dec != 0;
+                    if (ok) {
+                        // sR: the diagonal this word hands on to the right (its own when decided, else the next decided word's - the
+                        // last one's behind that); sL: what the word to the left hands on (the first word: its own)
+                        const uint64_t above = lane < 63u ? dec >> (lane + 1u) : 0ull, below = dec & ((1ull << lane) - 1ull);
+                        const uint32_t src = decided ? lane : above ? lane + 1u + (uint32_t)__builtin_ctzll(above) : 63u - (uint32_t)__builtin_clzll(below | 1ull);
+                        const uint32_t sR = __shfl(best_s, (int)src);
+                        uint32_t sL = (uint32_t)__builtin_amdgcn_update_dpp((int)sR, (int)sR, 0x138, 0xF, 0xF, false); // wave_shr:1, lane 0 keeps its own
+                        if (lane == 0) sL = sR;
+                        const uint32_t mR = grid_to_mask16(band_mask(sR)) | inv16 | (~inr16 & 0xFFFFu);
+                        const bool change = in_lane && sL != sR;
+                        uint32_t inbits = 0, outbits = ~mR & 0xFFFFu; // bits of the in-coming / out-going diagonal's stretches in this word
+                        uint32_t f1_w = 16u;   // (a word with a change: where its in-coming stretch ends)
+                        bool hole = false, soft = false, open_left = false; // open_left: the out-going stretch starts at the word's first base - and may start earlier
+                        if (__ballot(change)) {
+                            if (change) {
+                                const uint32_t mL = grid_to_mask16(band_mask(sL)) | inv16 | (~inr16 & 0xFFFFu);
+                                // the cut: bases [0, c) on the in-coming diagonal, [c, 16) on the out-going one
+                                uint32_t cost = (uint32_t)__popc(mR & inr16), bestc = cost, cut = 0;
+#pragma unroll
+                                for (uint32_t c = 1; c <= 16u; c++) {
+                                    cost += ((mL >> (c - 1u)) & 1u & (inr16 >> (c - 1u))) - ((mR >> (c - 1u)) & 1u & (inr16 >> (c - 1u)));
+                                    if (cost <= bestc) { // (ties: the rightmost - the in-coming diagonal as far as it matches)
+                                        bestc = cost;
+                                        cut = c;
+                                    }
+                                }
+                                if (bestc > 3u) {
+                                    // no cut explains the word: two changes inside it, or a change and a cluster of substitutions.  The in-coming
+                                    // stretch then ends at its first mismatch, the out-going one starts behind its last, and what lies between is
+                                    // in no stretch (whatever matches there is shorter than a word, hence than the table's windows - unless it
+                                    // is not, and then the proof says so).  A few such words a piece; more: the band was not it
+                                    soft = true;
+                                    const uint32_t f1 = mL ? (uint32_t)__builtin_ctz(mL) : 16u;
+                                    uint32_t b2 = mR ? 32u - (uint32_t)__builtin_clz(mR) : 0u;
+                                    b2 = max(b2, f1 > (uint32_t)J ? f1 - (uint32_t)J : 0u);
+                                    f1_w = f1;
+                                    inbits = ~mL & ((1u << f1) - 1u) & 0xFFFFu;
+                                    outbits = b2 < 16u ? (~mR & (0xFFFFu << b2) & 0xFFFFu) : 0u;
+                                } else {
+                                    // the in-coming stretch ends at its first mismatch from the cut on; the out-going one starts behind its last
+                                    // mismatch in front of the cut, at most J bases in front of that end - and never at the word's first base (a
+                                    // base that is in no stretch of its plane keeps the plane's stretches apart: header)
+                                    const uint32_t mLc = mL & (0xFFFFu << cut) & 0xFFFFu;
+                                    const uint32_t f1 = mLc ? (uint32_t)__builtin_ctz(mLc) : 16u;
+                                    const uint32_t mRc = mR & ((1u << cut) - 1u);
+                                    uint32_t b2 = mRc ? 32u - (uint32_t)__builtin_clz(mRc) : 0u;
+                                    b2 = max(b2, f1 > (uint32_t)J ? f1 - (uint32_t)J : 0u);
+                                    open_left = b2 == 0u;
+                                    f1_w = f1;
+                                    inbits = ~mL & ((1u << f1) - 1u) & 0xFFFFu;
+                                    outbits = b2 < 16u ? (~mR & (0xFFFFu << b2) & 0xFFFFu) : 0u;
+                                }
+                            }
+                        }
+                        // (a word that matches no diagonal of the band and stands between two words on one: its bases as they are on that
+                        // one - two changes that cancel, a cluster of substitutions -, counted with the words no cut explains)
+                        if (in_lane && !decided && !change && (uint32_t)__popc(mR & inr16) > 5u) soft = true;
+                        if (hole) inbits = outbits = 0;
+                        ok = __ballot(hole) == 0 && __popcll(__ballot(soft)) <= 3;
+                        if (ok) {
+                            const uint64_t ch = __ballot(change);
+                            const uint32_t p_in = (uint32_t)__popcll(ch & ((1ull << lane) - 1ull)) & 1u, p_out = p_in ^ (change ? 1u : 0u);
+                            // a stretch that starts at its word's first base goes on to the LEFT, into the last bases of the word in front,
+                            // as far as those lie on its diagonal (a junction in a word's last bases: that word chose the other diagonal
+                            // and the one behind it carries the change): by at most J bases in all with what lies on both (f1 of the word
+                            // with the change), and never up to the end of a stretch of the same plane in that word.  That word looks.
+                            uint32_t extbits = 0;
+                            {
+                                const uint32_t nx = shfl_down0((open_left && change && !hole ? 1u : 0u) | (f1_w << 1) | (sR << 8), 1, lane);
+                                if (__ballot(nx & 1u)) {
+                                    if (nx & 1u) {
+                                        const uint32_t f1n = (nx >> 1) & 0x7Fu, sRn = nx >> 8;
+                                        const uint32_t mX = grid_to_mask16(band_mask(sRn)) | inv16 | (~inr16 & 0xFFFFu);
+                                        uint32_t ext = mX ? (uint32_t)__builtin_clz(mX << 16) : 16u; // bases at the word's end on that diagonal
+                                        ext = min(ext, f1n < (uint32_t)J ? (uint32_t)J - f1n : 0u);
+                                        // (this word's own in-coming stretch lies in the same plane when it has a change itself)
+                                        ext = min(ext, change ? (f1_w < 15u ? 15u - f1_w : 0u) : 15u);
+                                        extbits = ext ? (0xFFFFu << (16u - ext)) & 0xFFFFu : 0u;
+                                    }
+                                }
+                            }
+                            // ... and an in-coming stretch that reaches its word's last base goes on to the RIGHT, into the first bases of the word
+                            // behind, as far as those lie on its diagonal (a junction in a word's last bases whose first base behind it matches
+                            // both diagonals): within J bases of where the out-going stretch started, and short of that word's own
+                            // out-going stretch when it lies in the same plane (a change there too).  That word looks.
+                            uint32_t rextbits = 0;
+                            {
+                                const uint32_t b2_w = (outbits & 0xFFFFu) ? (uint32_t)__builtin_ctz(outbits) : 16u; // (where this word's out-going stretch starts)
+                                const uint32_t pv = shfl_up0((change && !hole && f1_w == 16u ? 1u : 0u) | (b2_w << 1) | (sL << 8), 1, lane);
+                                if (__ballot(pv & 1u)) {
+                                    if (pv & 1u) {
+                                        const uint32_t b2p = (pv >> 1) & 0x7Fu, sLp = pv >> 8;
+                                        const uint32_t mX = grid_to_mask16(band_mask(sLp)) | inv16 | (~inr16 & 0xFFFFu);
+                                        uint32_t ext = mX ? (uint32_t)__builtin_ctz(mX) : 16u; // bases at the word's start on that diagonal
+                                        const uint32_t over = 16u - min(b2p, 16u); // what the two stretches share in the word in front
+                                        ext = min(ext, over < (uint32_t)J ? (uint32_t)J - over : 0u);
+                                        ext = min(ext, change ? (b2_w > 0u ? b2_w - 1u : 0u) : 15u);
+                                        rextbits = (1u << ext) - 1u;
+                                    }
+                                }
+                            }
+                            // (and a stretch that starts at its word's first base right behind a word whose in-coming stretch of the same plane
+                            // runs to that word's end: not its first base - a base in neither keeps the two apart)
+                            {
+                                const uint32_t pv = shfl_up0((change && f1_w == 16u ? 1u : 0u), 1, lane);
+                                if (change && open_left && pv && !(shfl_up0(extbits, 1, lane) != 0u)) outbits &= ~1u;
+                            }
+                            const uint32_t p_ext = p_out ^ 1u; // (the plane the word behind hands on: it has a change)
+                            const uint32_t p_rext = p_in ^ 1u; // (the plane the word in front took in: it has a change)
+                            ZA = (p_in == 0u ? inbits : 0u) | (p_out == 0u ? outbits : 0u) | (p_ext == 0u ? extbits : 0u) | (p_rext == 0u ? rextbits : 0u);
+                            ZB = (p_in == 1u ? inbits : 0u) | (p_out == 1u ? outbits : 0u) | (p_ext == 1u ? extbits : 0u) | (p_rext == 1u ? rextbits : 0u);
+                            const uint32_t last_l = 63u - (uint32_t)__builtin_clzll(inl);
+                            end_on_diag = true;
+                            end_dl = dl - kBand + (int32_t)__shfl(sR, (int)last_l);
+                            st_band += 0x10001u;
+                            break;
+                        }
+                    }
+                    st_band += 1u; // (tried, not taken)
                 }
                 // the next diagonal: of the 64 beside this one, the one on which the read goes on soonest - the first run of kLongRun
                 // matching bases among the 32 behind f (ties: the longer run, then the nearer diagonal)
@@ -837,6 +986,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
         atomicAdd(st + kPlanStatTabAnchored, s0 >> 16);
         atomicAdd(st + kPlanStatSeedExtensions, s1 & 0xFFFFu);
         atomicAdd(st + kPlanStatTabLookups, s1 >> 16);
+        atomicAdd(st + kPlanStatUnits, st_band & 0xFFFFu);    // pieces that tried all their words on a band of diagonals at once
+        atomicAdd(st + kPlanStatAccepted, st_band >> 16);     // ... and kept the result
     }
 }
 

@@ -1,3 +1,3 @@
-# timing only: phases of map_long_kernel left out (KBO_LONG_X), the kernel alone (rocprofv3 stats)
-for x in 16 32 1 6 4 0; do echo "X=$x"; KBO_LONG_X=$x tools/stats_long.sh ab$x --variants ${1:-1pct} --steps 10 2>&1 | grep "map_long_kernel"; done
-for ppw in 4 16; do echo "PPW=$ppw"; KBO_LONG_PPW=$ppw tools/stats_long.sh abp$ppw --variants ${1:-1pct} --steps 10 2>&1 | grep "map_long_kernel"; done
+python -m pytest tests/test_gpu_map_long.py -x -q -m gpu 2>&1 | tail -2
+echo "WPE=5"; tools/stats_long.sh a5 --variants ont,1pct,big --steps 10 2>&1 | grep "Gbp\|map_long"
+echo "WPE=4"; KBO_HIP_LIB=$PWD/kbo_amd/libkbo_hip_w4.so tools/stats_long.sh a4 --variants ont,1pct,big --steps 10 2>&1 | grep "Gbp\|map_long"

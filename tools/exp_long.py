@@ -77,6 +77,8 @@ def main():
         line = "%-6s %7.1f Gbp/s  %.3f ms per batch of %d Mbases; pieces %d flagged %d (%.2f %%) sub-items %d; per kb: seeds %.2f filter %.2f table %.2f second %.3f" % (
             name, total / ms / 1e6, ms, total // 1_000_000, st["pieces"], st["flagged"], 100.0 * st["flagged"] / max(1, st["pieces"]), st["sub_items"],
             1e3 * st["seed_lookups"] / total, 1e3 * st["filter_lookups"] / total, 1e3 * st["table_lookups"] / total, 1e3 * st["second_lookups"] / total)
+        if st.get("band_tried"):
+            line += "  band tried %d taken %d" % (st["band_tried"], st["band_taken"])
         if st.get("cyc_staging"):
             line += "  cycles per piece: " + " ".join("%s %d" % (k_[4:], st[k_] // max(1, st["pieces"])) for k_ in st if k_.startswith("cyc_"))
         if oi is not None:
