@@ -52,7 +52,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)  # (0.26 ms each: a timed region of 50 ms - one stall of the host does not decide the line)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=sorted(PRESETS), default="C2",
+    ap.add_argument("--config", choices=sorted(PRESETS) + ["C5"], default="C2",
                     help="BASELINE.json workload: C2 = kbo map, 5 Mbp index, 1 M x 150 bp reads per GPU (the metric config); "
                          "C3 = kbo find, 100 Mbp index, 10 M reads per GPU (SURVEY.md 8(d)'s designated roofline run); "
                          "C4 = kbo map, 250 Mbp index, 100 M reads sharded over the GPUs")
@@ -84,6 +84,17 @@ def parse(argv=None):
     ap.add_argument("--index-cache", default=None, help="index file (.kbohip, with its path cover) to load instead of building; "
                     "written first if it does not exist")
     args = ap.parse_args(argv)
+    if args.config == "C5":  # kbo call, 3 Gbp index, k = 63, 1 M x 10 kbp reads over 8 GPUs: one GPU's share (125 k reads)
+        args.call = True
+        args.c5 = args.genome is None and args.reads is None
+        args.genome = args.genome if args.genome is not None else 3_000_000_000
+        args.reads = args.reads if args.reads is not None else 125_000
+        args.k = args.k if args.k != 31 else 63
+        if args.steps == 200:
+            args.steps = 3
+        args.warmup = min(args.warmup, 1)
+    else:
+        args.c5 = False
     if args.call:
         args.genome = args.genome if args.genome is not None else 100_000_000
         args.reads = args.reads if args.reads is not None else 10_000
@@ -702,13 +713,45 @@ def main_call(args):
     except kbo_amd.KboError as e:  # (a threshold the reference refuses, a sharded index: said, not hidden)
         whole = {"error": str(e)}
     bases = dev.total
+    # ---- roofline of the first pass: SURVEY.md 8(d)'s bytes of the reference algorithm - 64 B per distinct rank block an extension
+    # touches + 1 B per LCS element a contraction reads + 1 B of query in (the MS values stay on the device; sites leave) -, the op
+    # counts by the oracle on a sample of the same reads; the walk kernel's duration from the events around every launch
+    roofline = cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import binding as ora
+        n_s = max(1, min(args.reads, int(20_000_000 // args.read_len)))  # ~20 Mbases of the timed reads
+        cn = ora.Counters()
+        t1 = time.perf_counter()
+        oi.matches_batch(concat[:n_s * args.read_len], offsets[:n_s + 1], 1e-7, n_threads=cores, counters=cn)
+        c = cn.as_dict()
+        sb = n_s * args.read_len
+        b_alg = (64.0 * c.get("rank_blocks", 0) + c.get("lcs_reads", 0)) / sb + 1.0
+        ach = b_alg * bases / (walk_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                    "traffic": None, "algorithmic_bytes_per_base": round(b_alg, 2), "units_per_launch": bases,
+                    "kernel": "the call mode of the walk (plan_kernel + guided walk over recovery lines, or ms_walk_kernel<CALL>): MS values + breakpoint scan",
+                    "kernel_ms": round(walk_ms, 4), "counted_on": f"{n_s} of the timed reads by the oracle (SURVEY.md 8(d))",
+                    "note": "no depth table at this index size (17 bases would be present by chance): the walk is the round-3 route; "
+                            "the one kernel for sequences of any length (long_kernels.hip) needs a table"}
+        # ---- CPU baseline: the oracle's literal kbo::call (per-sequence index build + both passes) on a bounded sample, one thread a read
+        n_c = min(args.reads, 64)
+        t1 = time.perf_counter()
+        import concurrent.futures as cf
+        with cf.ThreadPoolExecutor(max_workers=cores) as ex:
+            list(ex.map(lambda s_: oi.call(concat[int(offsets[s_]):int(offsets[s_ + 1])].tobytes(), args.k, 1e-7), range(n_c)))
+        dt = time.perf_counter() - t1
+        cpu = {"value": round(n_c * args.read_len / dt / 1e6, 2), "unit": "Mbp/s", "cores": cores, "kind": "port",
+               "sample": f"oracle.call (kbo::call, lib.rs:547-573) on the first {n_c} reads, {cores} threads, one read each at a time"}
     print(json.dumps({
-        "metric": f"query Mbp/sec for kbo call first pass (MS walk whose lanes run the breakpoint scan; sites only leave the device), k={args.k}, "
+        "metric": (f"query Mbp/sec for kbo call, k={args.k}, {args.genome / 1e6:g} Mbp SBWT, {args.read_len} bp reads (first pass device-resident; "
+                   "whole_call: host sequences in, variants out)") if args.c5 else
+                  f"query Mbp/sec for kbo call first pass (MS walk whose lanes run the breakpoint scan; sites only leave the device), k={args.k}, "
                   f"{args.genome / 1e6:g} Mbp SBWT",
+        "roofline": roofline, "cpu_baseline": cpu,
         "value": round(bases * args.steps / elapsed / 1e6, 1), "unit": "Mbp/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"C5 shape, scaled: kbo call first pass, {args.genome / 1e6:g} Mbp iid genome SBWT k={args.k}, "
+        "config": {"workload": ("C5, one GPU's share of 8: " if args.c5 else "C5 shape, scaled: ") + f"kbo call first pass, {args.genome / 1e6:g} Mbp iid genome SBWT k={args.k}, "
                                f"{args.reads} x {args.read_len} bp reads, {args.sub_rate * 100:g}% substitutions",
                    "threshold": thr, "sites_per_step": n_sites, "bytes_leaving_the_device_per_base": round(16 * n_sites / bases, 4)},
         "kernels_ms": {"ms_walk_call_mode": round(walk_ms, 4)},

@@ -234,11 +234,13 @@ void build_plan_structures(kbo_index *idx, DevCopy *dc)
         // alone is no faster for it (0.251 against 0.248 ms: it is not bound by its fills, LABNOTES round 4), but beside another
         // batch's second pass it is: two batches in flight 0.332 -> 0.308 ms per batch.  KBO_DEPTH_FILTER=0: none, n: that many bases
         static const int env_filter = std::getenv("KBO_DEPTH_FILTER") ? std::atoi(std::getenv("KBO_DEPTH_FILTER")) : -1; // experiments
+        // (round 5, C3: a filter of 14 bases - 32 MB, the Infinity Cache's rather than an L2's - by KBO_DEPTH_FILTER=14: 348 against 354
+        // Gbp/s without; larger indexes keep none)
         uint32_t fb = 0;
         for (uint32_t f = 6; f <= 12u; f++)
             if (2ull * idx->host.n_sets <= (1ull << (2u * f))) { fb = f; break; }
         if (env_filter >= 0) fb = (uint32_t)env_filter;
-        if (fb < 6u || fb > 13u || fb + 2u > (uint32_t)order) fb = 0;
+        if (fb < 6u || fb > 15u || fb + 2u > (uint32_t)order) fb = 0;
         if (fb) {
             dc->dfilt.alloc((((size_t)1 << (2u * fb)) / 8u) + 64);
             dc->dfilt_bases = fb;
