@@ -366,8 +366,10 @@ int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, siz
  * kbo::matches (lib.rs:612-628; format = 0) over a device-resident batch, the whole chain MS -> derandomize_ms_vec ->
  * translate_ms_vec enqueued on `stream`; the threshold comes from the index and max_error_prob (lib.rs:620, 731).  Batches of
  * reads (max_seq_len <= 160) over an index copy that carries a depth table run as ONE kernel (kbo_amd/csrc/map_kernels.hip): the
- * MS values never leave the chip unless want_ms != 0.  Other batches run as kbo_ms_batch_dev + kbo_derand_translate_dev
- * (max_seq_len <= 480 here: longer sequences need kbo_derand_translate_dev's scratch - call the two yourself).
+ * MS values never leave the chip unless want_ms != 0.  Batches with LONGER sequences - contigs, whole reference sequences, long reads:
+ * what kbo::map / matches / find are called with (lib.rs:612-628, 720-761) - run as one kernel too when want_ms == 0 (one wave per
+ * piece of a sequence, kbo_amd/csrc/long_kernels.hip: max_seq_len > 160 or 0 = unknown; any length below 4 GiB per launch).  Other
+ * batches run as kbo_ms_batch_dev + kbo_derand_translate_dev (d_work carries the scratch of both).
  * d_ms: total_bases bytes + 16, 4-byte aligned: the MS value of every base when want_ms != 0 or the batch takes the two-kernel
  * route, otherwise scratch (the reads the one kernel leaves to the plain walk pass through it).  d_work / work_bytes as for
  * kbo_ms_batch_dev; d_concat needs 16 readable bytes of slack behind the batch.  Sequences of fewer than 3 bases (the
@@ -386,6 +388,24 @@ int kbo_map_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
 int kbo_map_batch_dev_tail(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
                            size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
                            void *d_work, size_t work_bytes, void *stream, void *tail_stream, int *fused);
+/* ---- several batches in flight, the library's own arrangement (what bench.py's headline is measured with): `pipelines` pairs of
+ * (kernel stream, second-pass stream) that take the batches in turn, two slots - work and MS buffers, a completion event - per
+ * pipeline, so that a batch's second pass runs beside the next batches' kernels.  max_* size the slots' buffers: a batch may not
+ * exceed them.  The batch's own buffers (d_concat, d_offsets, d_chars_out) stay the caller's and must stay valid and untouched
+ * until the batch is complete.
+ *   kbo_map_stream_submit   enqueues kbo::map (format != 0) / kbo::matches of one device-resident batch and returns at once;
+ *                           ready_stream (optional): the stream whose work so far produces the batch's inputs - the pipeline waits
+ *                           for it on the device; *ticket (optional) names the batch
+ *   kbo_map_stream_wait     blocks the calling thread until that batch is complete;  kbo_map_stream_wait_on makes `stream` wait for
+ *                           it on the device instead;  kbo_map_stream_sync: every batch submitted so far */
+typedef struct kbo_map_stream kbo_map_stream_t;
+int kbo_map_stream_create(kbo_index_t *idx, int pipelines, size_t max_seqs, uint64_t max_bases, size_t max_seq_len, kbo_map_stream_t **out);
+int kbo_map_stream_submit(kbo_map_stream_t *ms, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
+                          size_t max_seq_len, double max_error_prob, int format, uint8_t *d_chars_out, void *ready_stream, uint64_t *ticket);
+int kbo_map_stream_wait(kbo_map_stream_t *ms, uint64_t ticket);
+int kbo_map_stream_wait_on(kbo_map_stream_t *ms, uint64_t ticket, void *stream);
+int kbo_map_stream_sync(kbo_map_stream_t *ms);
+void kbo_map_stream_free(kbo_map_stream_t *ms);
 /* kbo::find (lib.rs:808-821) over a device-resident batch: kbo_map_batch_dev_tail with format = 0, then format::run_lengths_gapped
  * (format.rs:143-193) of the characters - kbo_run_lengths_dev's buffers and record layout (d_rle_work: kbo_run_lengths_work_bytes()) -
  * enqueued behind the second pass on `tail_stream` (pass `stream` for one stream).  With max_gap_len = 0 (FindOpts' default) the one

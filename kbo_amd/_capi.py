@@ -103,7 +103,8 @@ SYMBOLS = [
     "kbo_matches_batch_packed", "kbo_find_batch_packed", "kbo_index_shards", "kbo_index_work_bytes",
     "kbo_index_device_layout", "kbo_map_batch_dev", "kbo_map_batch_dev_tail",
     "kbo_index_opts_default", "kbo_index_set_opts", "kbo_index_get_opts", "kbo_matches_packed_dev", "kbo_matches_packed_dev_scratch_bytes",
-    "kbo_find_batch_dev",
+    "kbo_find_batch_dev", "kbo_map_stream_create", "kbo_map_stream_submit", "kbo_map_stream_wait", "kbo_map_stream_wait_on",
+    "kbo_map_stream_sync", "kbo_map_stream_free",
 ]
 # ... and include/kbo_hip_tuning.h (knobs, experiment switches, test hooks: not part of the drop-in boundary)
 TUNING_SYMBOLS = [
@@ -233,6 +234,13 @@ def lib():
     L.kbo_set_plan_table_budget.argtypes = [C.c_uint64]
     L.kbo_set_plan_lazy.argtypes = [C.c_int64]
     L.kbo_set_map_long.argtypes = [C.c_int]
+    L.kbo_map_stream_create.argtypes = [vp, C.c_int, sz, u64, sz, vp]
+    L.kbo_map_stream_submit.argtypes = [vp, vp, vp, sz, u64, sz, C.c_double, C.c_int, vp, vp, vp]
+    L.kbo_map_stream_wait.argtypes = [vp, u64]
+    L.kbo_map_stream_wait_on.argtypes = [vp, u64, vp]
+    L.kbo_map_stream_sync.argtypes = [vp]
+    L.kbo_map_stream_free.argtypes = [vp]
+    L.kbo_map_stream_free.restype = None
     L.kbo_set_stage_timing.argtypes = [C.c_int]
     L.kbo_stage_timing_read.argtypes = [C.POINTER(dbl), C.POINTER(dbl), C.POINTER(C.c_int)]
     L.kbo_map_batch_dev.argtypes = [vp, vp, vp, sz, u64, sz, dbl, C.c_int, C.c_int, vp, vp, vp, sz, vp, C.POINTER(C.c_int)]

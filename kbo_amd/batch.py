@@ -344,3 +344,42 @@ class DeviceBatch:
                                           self.max_error_prob, int(self.format), int(self.want_ms), self.ms.data_ptr(), self.chars.data_ptr(),
                                           self.work.data_ptr(), self.work_bytes, s.cuda_stream, C.byref(fused)))
         self.fused = bool(fused.value)
+
+
+class MapStream:
+    """Several device-resident batches in flight through the library's own pipelines (kbo_hip.h kbo_map_stream_*): pairs of (kernel
+    stream, second-pass stream) that take the batches in turn, two slots of work memory each."""
+
+    def __init__(self, sbwt, max_seqs, max_bases, max_seq_len, pipelines=2):
+        self.sbwt = sbwt
+        h = C.c_void_p()
+        check(lib().kbo_map_stream_create(sbwt._h, pipelines, max_seqs, max_bases, max_seq_len, C.byref(h)))
+        self._h = h
+
+    def submit(self, dev, ready_stream=None):
+        """kbo::map (dev.format) / kbo::matches of a DeviceBatch's sequences into dev.chars -> ticket"""
+        t = C.c_uint64(0)
+        check(lib().kbo_map_stream_submit(self._h, dev.q.data_ptr(), dev.off.data_ptr(), dev.n_seqs, dev.total, dev.max_len, dev.max_error_prob,
+                                          int(dev.format), dev.chars.data_ptr(), ready_stream.cuda_stream if ready_stream is not None else None,
+                                          C.byref(t)))
+        return int(t.value)
+
+    def wait(self, ticket):
+        check(lib().kbo_map_stream_wait(self._h, ticket))
+
+    def wait_on(self, ticket, stream):
+        check(lib().kbo_map_stream_wait_on(self._h, ticket, stream.cuda_stream))
+
+    def sync(self):
+        check(lib().kbo_map_stream_sync(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().kbo_map_stream_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

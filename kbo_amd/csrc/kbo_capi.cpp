@@ -17,6 +17,7 @@
 #include <functional>
 #include <memory>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <new>
@@ -1483,6 +1484,158 @@ int kbo_map_batch_dev_tail(kbo_index_t *idx, const uint8_t *d_concat, const uint
 {
     return map_batch_dev_impl(idx, d_concat, d_offsets, n_seqs, total_bases, max_seq_len, max_error_prob, format, want_ms, d_ms, d_chars_out,
                               d_work, work_bytes, stream, tail_stream, true, fused);
+}
+
+// ---- kbo_map_stream_*: pipelines of (kernel stream, second-pass stream), two slots each
+struct kbo_map_stream {
+    kbo_index_t *idx = nullptr;
+    int device = 0;
+    struct Pipe { hipStream_t ks = nullptr, ts = nullptr; };
+    struct Slot {
+        DevBuf work, ms;
+        hipEvent_t done = nullptr;
+        uint64_t ticket = 0; // the batch that used it last (0: none yet)
+    };
+    std::vector<Pipe> pipes;
+    std::deque<Slot> slots; // 2 per pipeline (a deque: the buffers do not move)
+    size_t max_seqs = 0, max_seq_len = 0, work_bytes = 0;
+    uint64_t max_bases = 0, next = 0;
+    hipEvent_t ready = nullptr, kdone = nullptr;
+    std::mutex mu;
+};
+
+int kbo_map_stream_create(kbo_index_t *idx, int pipelines, size_t max_seqs, uint64_t max_bases, size_t max_seq_len, kbo_map_stream_t **out)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && out && max_seqs > 0 && max_bases > 0, KBO_E_BAD_ARG, "null / empty argument");
+        KBO_REQUIRE(pipelines >= 1 && pipelines <= 8, KBO_E_BAD_ARG, "1 .. 8 pipelines");
+        *out = nullptr;
+        std::unique_ptr<kbo_map_stream> m(new kbo_map_stream());
+        m->idx = idx;
+        m->device = current_device();
+        m->max_seqs = max_seqs;
+        m->max_bases = max_bases;
+        m->max_seq_len = max_seq_len;
+        m->work_bytes = kbo_index_work_bytes(idx, max_seqs, max_bases, max_seq_len);
+        m->pipes.resize((size_t)pipelines);
+        m->slots.resize(2 * (size_t)pipelines);
+        for (auto &p : m->pipes) {
+            HIP_OK(hipStreamCreateWithFlags(&p.ks, hipStreamNonBlocking));
+            HIP_OK(hipStreamCreateWithFlags(&p.ts, hipStreamNonBlocking));
+        }
+        for (auto &sl : m->slots) {
+            sl.work.alloc(m->work_bytes + 64);
+            sl.ms.alloc(((size_t)max_bases + 15) / 16 * 16 + 64);
+            HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        }
+        HIP_OK(hipEventCreateWithFlags(&m->ready, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&m->kdone, hipEventDisableTiming));
+        *out = m.release();
+    });
+}
+
+int kbo_map_stream_submit(kbo_map_stream_t *m, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
+                          size_t max_seq_len, double max_error_prob, int format, uint8_t *d_chars_out, void *ready_stream, uint64_t *ticket)
+{
+    if (!m) {
+        last_error() = "kbo_map_stream_submit: null stream";
+        return KBO_E_BAD_ARG;
+    }
+    std::lock_guard<std::mutex> g(m->mu);
+    int rc = guarded([&] {
+        KBO_REQUIRE(n_seqs <= m->max_seqs && total_bases <= m->max_bases, KBO_E_BAD_ARG, "the batch exceeds what the stream's slots were made for");
+        KBO_REQUIRE(kbo_index_work_bytes(m->idx, n_seqs, total_bases, max_seq_len) <= m->work_bytes, KBO_E_BAD_ARG,
+                    "the batch needs more work memory than the stream's slots have (max_seq_len of kbo_map_stream_create)");
+    });
+    if (rc != KBO_OK) return rc;
+    const uint64_t n = m->next;
+    kbo_map_stream::Pipe &p = m->pipes[n % m->pipes.size()];
+    kbo_map_stream::Slot &sl = m->slots[n % m->slots.size()];
+    rc = guarded([&] {
+        // the slot's buffers are free again behind its last batch; the inputs are there behind what ready_stream holds so far
+        if (sl.ticket) HIP_OK(hipStreamWaitEvent(p.ks, sl.done, 0));
+        if (ready_stream) {
+            HIP_OK(hipEventRecord(m->ready, static_cast<hipStream_t>(ready_stream)));
+            HIP_OK(hipStreamWaitEvent(p.ks, m->ready, 0));
+        }
+    });
+    if (rc != KBO_OK) return rc;
+    rc = map_batch_dev_impl(m->idx, d_concat, d_offsets, n_seqs, total_bases, max_seq_len, max_error_prob, format, 0, sl.ms.as<uint8_t>(), d_chars_out,
+                            sl.work.p, m->work_bytes, p.ks, p.ts, true, nullptr);
+    if (rc != KBO_OK) return rc;
+    rc = guarded([&] { // complete when both streams have come this far
+        HIP_OK(hipEventRecord(m->kdone, p.ks));
+        HIP_OK(hipStreamWaitEvent(p.ts, m->kdone, 0));
+        HIP_OK(hipEventRecord(sl.done, p.ts));
+    });
+    if (rc != KBO_OK) return rc;
+    m->next = n + 1;
+    sl.ticket = n + 1;
+    if (ticket) *ticket = n + 1;
+    return KBO_OK;
+}
+
+namespace {
+// the event of the batch with this ticket while its slot has not been reused (then the batch is long complete): nullptr = complete
+hipEvent_t map_stream_event(kbo_map_stream_t *m, uint64_t ticket)
+{
+    KBO_REQUIRE(m && ticket >= 1 && ticket <= m->next, KBO_E_BAD_ARG, "no such batch");
+    kbo_map_stream::Slot &sl = m->slots[(ticket - 1) % m->slots.size()];
+    return sl.ticket == ticket ? sl.done : nullptr;
+}
+} // namespace
+
+int kbo_map_stream_wait(kbo_map_stream_t *m, uint64_t ticket)
+{
+    return guarded([&] {
+        hipEvent_t ev;
+        {
+            KBO_REQUIRE(m, KBO_E_BAD_ARG, "null stream");
+            std::lock_guard<std::mutex> g(m->mu);
+            ev = map_stream_event(m, ticket);
+        }
+        if (ev) HIP_OK(hipEventSynchronize(ev));
+    });
+}
+
+int kbo_map_stream_wait_on(kbo_map_stream_t *m, uint64_t ticket, void *stream)
+{
+    return guarded([&] {
+        KBO_REQUIRE(m, KBO_E_BAD_ARG, "null stream");
+        std::lock_guard<std::mutex> g(m->mu);
+        hipEvent_t ev = map_stream_event(m, ticket);
+        if (ev) HIP_OK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), ev, 0));
+    });
+}
+
+int kbo_map_stream_sync(kbo_map_stream_t *m)
+{
+    return guarded([&] {
+        KBO_REQUIRE(m, KBO_E_BAD_ARG, "null stream");
+        std::lock_guard<std::mutex> g(m->mu);
+        for (auto &p : m->pipes) {
+            HIP_OK(hipStreamSynchronize(p.ks));
+            HIP_OK(hipStreamSynchronize(p.ts));
+        }
+    });
+}
+
+void kbo_map_stream_free(kbo_map_stream_t *m)
+{
+    if (!m) return;
+    for (auto &p : m->pipes) {
+        if (p.ks) (void)hipStreamSynchronize(p.ks);
+        if (p.ts) (void)hipStreamSynchronize(p.ts);
+    }
+    for (auto &sl : m->slots)
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    if (m->ready) (void)hipEventDestroy(m->ready);
+    if (m->kdone) (void)hipEventDestroy(m->kdone);
+    for (auto &p : m->pipes) {
+        if (p.ks) (void)hipStreamDestroy(p.ks);
+        if (p.ts) (void)hipStreamDestroy(p.ts);
+    }
+    delete m;
 }
 
 namespace {

@@ -254,3 +254,35 @@ def test_host_entry_points_over_long_sequences(oracle):
         assert np.array_equal(got, want_recs), gap
     q = seqs[-1]
     assert kbo_amd.matches(q.tobytes(), sbwt) == [chr(v) for v in exp[int(offsets[-2]):]]
+
+
+def test_map_stream_batches_in_flight(oracle):
+    """kbo_map_stream_*: the library's own pipelines - batches of reads and of long sequences in turn, several rounds through the same
+    slots, every base of every batch"""
+    import torch
+    rng = np.random.default_rng(85)
+    contigs = _genome(rng, 400_000, contigs=2)
+    sbwt, _ = kbo_amd.build(contigs, kbo_amd.BuildOpts(k=31, num_threads=threads()))
+    sbwt.to_device(-1)
+    ora = oracle.Index.build([c.tobytes() for c in contigs], k=31)
+    dev0 = torch.device("cuda:0")
+    sets = []
+    for lengths, n, fmt in (([150], 4000, True), ([700, 3000, 20_000], 40, False), ([60, 100, 159], 3000, False), ([10_000], 30, True)):
+        seqs = [q for q in _sequences(rng, contigs, n, lengths, 0.01, 0.002, 0.0, spice=False) if len(q) >= 3]
+        concat, offsets = _batch_of(seqs)
+        exp = ora.matches_batch(concat, offsets, 1e-7, n_threads=threads())
+        want = np.frombuffer(oracle.relative_to_ref(concat, exp), dtype=np.uint8) if fmt else exp
+        sets.append((batch.DeviceBatch(sbwt, concat, offsets, device=dev0, format=fmt, want_ms=False), want))
+    ms = batch.MapStream(sbwt, max(d.n_seqs for d, _ in sets), max(d.total for d, _ in sets), 0, pipelines=2)
+    for rnd in range(3):
+        tickets = []
+        for d, _ in sets:
+            d.chars.fill_(0xEE)
+        torch.cuda.synchronize(dev0)
+        for d, _ in sets:
+            tickets.append(ms.submit(d))
+        for (d, want), t in zip(sets, tickets):
+            ms.wait(t)
+            assert np.array_equal(d.chars[:d.total].cpu().numpy(), want), rnd
+    ms.sync()
+    ms.close()
