@@ -139,8 +139,9 @@ int kbo_set_map_long(int mode);
  * [4]: filter look-ups, [5]: depth-table look-ups, [6]: of those, second look-ups behind a window that was present;
  * [8..12] (experiments, KBO_LONG_X & 128): shader cycles of the waves' first lanes by phase - staging, stretches, planes to
  * characters, proof, output; [13], [14] (kbo_set_plan_stats): pieces that tried all their words on a band of diagonals at once /
- * that kept the result. */
-#define KBO_LONG_STATS 16
+ * that kept the result; [16..24] (kbo_set_plan_stats): flagged pieces by what flagged them - other, list too long, a window one base
+ * on present and extended, the window one base back, the one inside the next stretch; [21..24]: the last four after the band pass. */
+#define KBO_LONG_STATS 25
 int kbo_long_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k, const void *d_work, uint64_t out[KBO_LONG_STATS],
                        void *stream);
 

@@ -263,10 +263,11 @@ class DeviceBatch:
     def long_stats(self, stream=None):
         """What the last run() / run_find() did when it took the kernel for sequences of any length (kbo_hip_tuning.h kbo_long_stats_dev)."""
         s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
-        out = np.zeros(16, dtype=np.uint64)
+        out = np.zeros(25, dtype=np.uint64)
         check(lib().kbo_long_stats_dev(self.n_seqs, self.total, self.max_len, self.k, self.work.data_ptr(), out.ctypes.data, s.cuda_stream))
         names = ("pieces", "flagged", "sub_items", "seed_lookups", "filter_lookups", "table_lookups", "second_lookups", "_",
-                 "cyc_staging", "cyc_stretches", "cyc_planes", "cyc_proof", "cyc_output", "band_tried", "band_taken")
+                 "cyc_staging", "cyc_stretches", "cyc_planes", "cyc_proof", "cyc_output", "band_tried", "band_taken", "_",
+                 "why_other", "why_list", "why_ext", "why_back", "why_on", "why_band_list", "why_band_ext", "why_band_back", "why_band_on")
         return {n: int(v) for n, v in zip(names, out) if n != "_"}
 
     def derand_translate(self, stream=None):

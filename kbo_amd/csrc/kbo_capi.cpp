@@ -1215,6 +1215,7 @@ int kbo_long_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, 
         out[1] = ctl[4];
         out[2] = ctl[1];
         for (uint32_t i = 0; i < 5 && 8 + i < KBO_LONG_STATS; i++) out[8 + i] = (uint64_t)ctl[16 + i] << 4; // (KBO_LONG_X & 128: shader cycles by phase)
+        for (uint32_t i = 0; i < 9 && 16 + i < KBO_LONG_STATS; i++) out[16 + i] = ctl[8 + i]; // (why flagged: list cap / ext / back / on; +4: after the band pass)
         for (uint32_t sl = 0; sl < kbo::kPlanStatSlots; sl++) {
             out[3] += st[sl * kbo::kPlanStatWords + kbo::kPlanStatSeedLookups];
             out[4] += st[sl * kbo::kPlanStatWords + kbo::kPlanStatSeedExtensions];

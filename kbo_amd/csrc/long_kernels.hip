@@ -436,6 +436,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
         const bool pred_now = pred;
         uint32_t ZA = 0, ZB = 0; // the planes: bit j = position 16 lane + j lies in a stretch
         bool end_on_diag = false; // the region's last bases lie on the diagonal end_dl
+        bool band_took = false;
         int32_t end_dl = 0;
         {
             int32_t endz[2] = {(int32_t)r0 - 1, (int32_t)r0 - 1};
@@ -651,6 +652,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                             end_on_diag = true;
                             end_dl = dl - kBand + (int32_t)__shfl(sR, (int)last_l);
                             st_band += 0x10001u;
+                            band_took = true;
                             break;
                         }
                     }
@@ -769,6 +771,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
         stamp(2, t_last); // analysis
         // ---- 3. the proof
         bool flag = false;
+        uint32_t why = 0; // (counted with the work counters: what sent the piece to the second pass)
         if (!(a.xexp & 1u) && __ballot(U != 0u)) {
             // the points of every run of U: its first position and every cstep-th from there while the run's start is known (Mrun
             // positions back), every cstep-th position of the grid beyond
@@ -806,7 +809,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
             }
             const uint32_t total = __shfl(incl, 63);
             __builtin_amdgcn_wave_barrier(); // (the list goes where the text was)
-            if (total > kLongListCap) flag = true;
+            if (total > kLongListCap) {
+                flag = true;
+                why = 1u;
+            }
             else {
                 uint32_t at = incl - mine;
                 uint32_t nm = normal;
@@ -875,11 +881,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                     need_back = present_ext(byte, x);
                     need_on = is_last && x + 1u < xe;
                 }
-                if (__ballot(need_back)) { // something of order + 1 bases ends here: nothing of order + 2 may
+                if (__ballot(need_back)) {
+                    // order + 1 bases of the read end here and are in the index.  The windows of t + 1 bases that hold them end at x ..
+                    // x + cstep - 1.  A string of order + 1 bases ending at x - j that is absent rules out those ending at x + cstep - j
+                    // or before, one ending at x + i those ending at x + i or later: any pair with i + j <= cstep + 1 (j = 1 alone) will
+                    // do.  (A string that starts in front of the region or ends behind it lies in none of the windows that matter; one
+                    // with a byte that is no base is absent.)  A chance match of order + 2 bases - one in some thousand windows - is
+                    // what most flagged pieces of reads with substitutions only were flagged for; each further base divides that by four.
                     if (need_back) {
-                        st_second++;
-                        if (x < r0 + order) fail = true; // (no window one base back inside the region)
-                        else if (!inv_span(x - 1u, order)) fail = present_ext(table(x - 1u, 0u), x - 1u);
+                        auto both = [&](uint32_t e_, uint32_t g) -> bool {
+                            if (e_ < r0 + order || e_ >= xe || inv_span(e_, order)) return false;
+                            st_second++;
+                            return present_ext(table(e_, g), e_);
+                        };
+                        uint32_t j = 1;
+                        while (j <= cstep && both(x - j, j == 1u ? 0u : 1u)) j++;
+                        fail = j > cstep;
+                        if (!fail && j > 1u) {
+                            uint32_t i = 1;
+                            while (i <= cstep + 1u - j && both(x + i, i == 1u ? 2u : 1u)) i++;
+                            fail = i > cstep + 1u - j;
+                        }
                     }
                 }
                 if (__ballot(need_on)) { // the run's last window is present: the one inside the next stretch must not be extended by the base in front
@@ -888,7 +910,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                         if (!inv_span(x + 1u, order + 1u)) fail = present_ext(table(x + 1u, 2u), x + 1u);
                     }
                 }
-                if (__ballot(fail)) flag = true;
+                if (__ballot(fail)) {
+                    flag = true;
+                    why = __ballot(fail && is_ext) ? 2u : __ballot(fail && need_back) ? 3u : 4u;
+                }
             }
         }
 
@@ -969,6 +994,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                 const bool fl = flag || (a.xexp & 64u) != 0; // (64: every piece to the second pass - tests)
                 a.redo[piece] = fl ? 1 : 0;
                 if (fl) atomicAdd(a.qctl + 4, 1u);
+                if (fl && a.pstats) atomicAdd(a.qctl + 8u + why + (band_took ? 4u : 0u), 1u);
             }
         }
         stamp(4, t_last); // output

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--count", action="store_true", help="work counters of the kernel (kbo_set_plan_stats: slower)")
     ap.add_argument("--tail", action="store_true", help="the flagged pieces' pass on a second stream, two batches in flight")
+    ap.add_argument("--pipes", type=int, default=0, help="the library's own pipelines (kbo_map_stream_*), two batches in flight each")
     args = ap.parse_args()
     import torch
 
@@ -58,7 +59,29 @@ def main():
             concat, offsets = bench.indel_reads(g, max(1, n // 2), args.len, 0.01, 0.002, seed=0x5E121, many=True)
         else:
             raise SystemExit("unknown variant " + name)
-        devs = [batch.DeviceBatch(sbwt, concat, offsets, device=dev0, format=True, want_ms=False) for _ in range(2 if args.tail else 1)]
+        devs = [batch.DeviceBatch(sbwt, concat, offsets, device=dev0, format=True, want_ms=False) for _ in range(2 * args.pipes if args.pipes else 2 if args.tail else 1)]
+        if args.pipes:
+            mstr = batch.MapStream(sbwt, devs[0].n_seqs, devs[0].total, 0, pipelines=args.pipes)
+            for i in range(4):
+                mstr.submit(devs[i % len(devs)])
+            mstr.sync()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                mstr.submit(devs[i % len(devs)])
+            mstr.sync()
+            ms = (time.perf_counter() - t0) * 1e3 / args.steps
+            total = int(offsets[-1])
+            line = "%-6s %7.1f Gbp/s  %.3f ms per batch of %d Mbases (%d pipelines, host clock)" % (name, total / ms / 1e6, ms, total // 1_000_000, args.pipes)
+            if oi is not None:
+                n_chk = max(1, int(np.searchsorted(offsets, 3_000_000)))
+                n_b = int(offsets[n_chk])
+                exp = oi.matches_batch(concat[:n_b], offsets[:n_chk + 1], 1e-7, n_threads=cores)
+                exp = np.frombuffer(ora.relative_to_ref(concat[:n_b], exp), dtype=np.uint8)
+                line += "  bit-exact %s" % all(bool(np.array_equal(d.chars[:n_b].cpu().numpy(), exp)) for d in devs)
+            print(line, flush=True)
+            mstr.close()
+            del devs
+            continue
         with torch.cuda.stream(stream):
             for i in range(3):
                 devs[i % len(devs)].run(stream, tail)
@@ -79,6 +102,8 @@ def main():
             1e3 * st["seed_lookups"] / total, 1e3 * st["filter_lookups"] / total, 1e3 * st["table_lookups"] / total, 1e3 * st["second_lookups"] / total)
         if st.get("band_tried"):
             line += "  band tried %d taken %d" % (st["band_tried"], st["band_taken"])
+        if args.count:
+            line += "  why: " + " ".join("%s %d" % (k_[4:], st[k_]) for k_ in st if k_.startswith("why_"))
         if st.get("cyc_staging"):
             line += "  cycles per piece: " + " ".join("%s %d" % (k_[4:], st[k_] // max(1, st["pieces"])) for k_ in st if k_.startswith("cyc_"))
         if oi is not None:

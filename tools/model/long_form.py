@@ -293,9 +293,26 @@ def analyse(ix, qc, P, g0, seqlen, own0, own1, st, grid_off=0):
             if not pr:
                 continue
             if ext:
-                st.second += 1
-                pr0, ext0 = look(x - 1) if x - 1 >= order - 1 else (True, True)
-                if pr0 and ext0:
+                # order + 1 bases end at x.  The windows of t + 1 bases that hold them end at x .. x + c - 1.  A string of
+                # order + 1 bases ending at x - j that is absent rules out those ending at x + c - j or before; one ending at
+                # x + i, those ending at x + i or later: any pair with i + j <= c + 1 (j = 1 alone) will do.  (A string that
+                # starts in front of the region or ends behind it is in none of the windows that matter.)
+                def both(e_):
+                    if e_ - order < 0 or e_ >= R:
+                        return False
+                    st.second += 1
+                    pr_, ext_ = look(e_)
+                    return pr_ and ext_
+                j = 1
+                while j <= c and both(x - j):
+                    j += 1
+                ok = j <= c
+                if ok and j > 1:
+                    i = 1
+                    while i <= c + 1 - j and both(x + i):
+                        i += 1
+                    ok = i <= c + 1 - j
+                if not ok:
                     flagged, reason = True, "deeper than order + 1"
                     break
             if x == u1 and x + 1 < R:
