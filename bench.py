@@ -343,18 +343,10 @@ def stage_model_leg(args, sbwt, oi, concat, offsets, gpu_d, n_sample=2_000_000):
     return total / cn["bases"], summary, cn
 
 
-def run_piped(devs, pipes, steps, torch):
-    """`steps` batches through kbo_map_batch_dev_tail, the resident batches in `devs` in turn, the pipelines `pipes` = [(kernel
-    stream, second-pass stream), ..] in turn; a batch's buffers are used again only behind its last second pass (its `done` event)"""
-    for i in range(steps):
-        dev = devs[i % len(devs)]
-        stream, tail = pipes[i % len(pipes)]
-        if getattr(dev, "done", None) is None:
-            dev.done = torch.cuda.Event()
-        else:
-            stream.wait_event(dev.done)
-        dev.run(stream, tail_stream=tail)
-        dev.done.record(tail)
+def run_piped(devs, mstream, steps):
+    """`steps` batches through the library's pipelines (kbo_hip.h kbo_map_stream_*: pairs of kernel stream and second-pass stream that
+    take the batches in turn, two slots each), the resident batches in `devs` in turn -> their tickets"""
+    return [mstream.submit(devs[i % len(devs)]) for i in range(steps)]
 
 
 def run_batch(devs, stream, find, steps, warmup, torch, device, two_kernels=False, pipes=None):
@@ -362,24 +354,29 @@ def run_batch(devs, stream, find, steps, warmup, torch, device, two_kernels=Fals
     run_piped) -> (elapsed s, a1 ms, a5/a6 ms, rle ms | None); with kbo_map_batch_dev (not two_kernels) a1 = the whole step and a5/a6 = 0"""
     dev = devs[0]
     if not two_kernels:
+        from kbo_amd import batch
+        mstream = batch.MapStream(dev.sbwt, max(d.n_seqs for d in devs), max(d.total for d in devs), max(d.max_len for d in devs), pipelines=pipes) if pipes else None
+
         def go(n):
-            if pipes is not None:
-                run_piped(devs, pipes, n, torch)
-            else:
-                for i in range(n):
-                    devs[i % len(devs)].run(stream)
+            if mstream is not None:
+                return run_piped(devs, mstream, n)
+            for i in range(n):
+                devs[i % len(devs)].run(stream)
+            return []
         go(warmup)
         torch.cuda.synchronize(device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record(stream)
-        go(steps)
-        for ks, ts in (pipes or []):
-            stream.wait_stream(ks)
-            stream.wait_stream(ts)
+        tickets = go(steps)
+        for t in tickets[-2 * (pipes or 1):]:  # (the event behind the timed batches: the slots that may still be busy)
+            mstream.wait_on(t, stream)
         e1.record(stream)
         torch.cuda.synchronize(device)
-        return time.perf_counter() - t0, e0.elapsed_time(e1) / steps, 0.0, None
+        elapsed = time.perf_counter() - t0
+        if mstream is not None:
+            mstream.close()
+        return elapsed, e0.elapsed_time(e1) / steps, 0.0, None
     for _ in range(warmup):
         dev.run(stream)
         if find:
@@ -467,7 +464,7 @@ def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, pipes=None):
         dev = batch.DeviceBatch(ix, concat, offsets, device=device, format=True, want_ms=False)
         devs = [dev]
         if pipes is not None:  # (in flight as in the headline: the same reads, further sets of buffers)
-            for _ in range(2 * len(pipes) - 1):
+            for _ in range(2 * pipes - 1):
                 devs.append(batch.DeviceBatch(ix, concat, offsets, device=device, format=True, want_ms=False))
         elapsed, a1, dt, _ = run_batch(devs, stream, False, 12, 4, torch, device, args.two_kernels, pipes if len(devs) > 1 else None)
         fused = dev.fused
@@ -587,7 +584,7 @@ def ms_leg(args, sbwt, oi, concat, offsets, torch, device, stream, pipes):
                                "bit_exact_vs_oracle": bool(np.array_equal(dev.ms[:total].cpu().numpy(), exp_d))}
     del dev
     # kbo_map_batch_dev(want_ms): the one kernel in its MS-emitting form, MS bytes + formatted characters out
-    devs = [batch.DeviceBatch(sbwt, concat, offsets, device=device, format=True, want_ms=True) for _ in range(2 * len(pipes) if pipes else 1)]
+    devs = [batch.DeviceBatch(sbwt, concat, offsets, device=device, format=True, want_ms=True) for _ in range(2 * pipes if pipes else 1)]
     elapsed, _, _, _ = run_batch(devs, stream, False, 12, 4, torch, device, False, pipes)
     ok = all(bool(np.array_equal(d.ms[:total].cpu().numpy(), exp_d) and np.array_equal(d.chars[:total].cpu().numpy(), exp_map)) for d in devs)
     out["kbo_map_batch_dev_want_ms"] = {"value": round(total * 12 / elapsed / 1e6, 1), "unit": "Mbp/s", "step_ms": round(elapsed / 12 * 1e3, 4),
@@ -819,7 +816,9 @@ def main(argv=None):
     # batch's kernel on the first
     piped = not args.two_kernels and not args.one_at_a_time
     n_pipes = max(1, args.pipelines) if piped else 1
-    pipes = [(stream if p == 0 else torch.cuda.Stream(device), torch.cuda.Stream(device)) for p in range(n_pipes)] if piped else None
+    # (kbo::find has no entry point of that kind yet: its pipelines are pairs of torch streams here, kbo_find_batch_dev's tail stream)
+    pipes = [(stream if p == 0 else torch.cuda.Stream(device), torch.cuda.Stream(device)) for p in range(n_pipes)] if piped and args.find else None
+    mstream = None
     n_slabs = (n_mine + SLAB_READS - 1) // SLAB_READS
     # (slabs of equal size: the pipelines take the slabs in turn, and with 8 M + 2 M reads - C3 - one of them had four fifths of the work)
     slab_reads = max(1, (n_mine + max(1, n_slabs) - 1) // max(1, n_slabs))
@@ -852,6 +851,9 @@ def main(argv=None):
     def one_step(step, events=None, on_tail=None):
         on_tail = piped if on_tail is None else on_tail
         for i, dev in enumerate(sets[step % n_sets]):
+            if on_tail and mstream is not None:  # kbo_map_stream_*: the library's pipelines take the batches in turn
+                mstream.submit(dev)
+                continue
             stream, tail = pipes[(step * len(slabs) + i) % n_pipes] if on_tail else (stream0, None)
             if on_tail and dev.done is not None:
                 stream.wait_event(dev.done)  # its buffers are free again behind its last second pass
@@ -889,6 +891,9 @@ def main(argv=None):
     sync_all()
     one_kernel = (not args.two_kernels) and all(d.fused for sl in sets for d in sl)
     piped = piped and one_kernel  # (the two-kernel route has no second pass to set aside)
+    if piped and not args.find:
+        every = [d for sl in sets for d in sl]
+        mstream = batch.MapStream(sbwt, max(d.n_seqs for d in every), max(d.total for d in every), max(d.max_len for d in every), pipelines=n_pipes)
     for w in range(args.warmup):
         one_step(w)
     sync_all()
@@ -909,7 +914,9 @@ def main(argv=None):
     L.kbo_stage_timing_read(_C.byref(k_sum), _C.byref(r_sum), _C.byref(n_calls))
     map_kernel_ms = k_sum.value / args.steps if one_kernel and n_calls.value else None  # per step (all slabs)
     map_redo_ms = r_sum.value / args.steps if one_kernel and n_calls.value else None
-    walk_ms = float(np.mean([sum(e[0].elapsed_time(e[1]) for e in step) for step in ev]))
+    # (a call's span: from events around it - or, through kbo_map_stream_*, whose streams are the library's, the two intervals it timed itself)
+    walk_ms = (map_kernel_ms + map_redo_ms) if mstream is not None and map_kernel_ms is not None else \
+        float(np.mean([sum(e[0].elapsed_time(e[1]) for e in step) for step in ev]))
     dt_ms = float(np.mean([sum(e[1].elapsed_time(e[2]) for e in step) for step in ev])) if args.two_kernels else 0.0
     rle_ms = float(np.mean([sum(e[2].elapsed_time(e[3]) for e in step) for step in ev])) if args.find and args.two_kernels else None  # (else: inside the call)
     # what the timed steps left behind (formatted unless --find): the first slab of either set, for rank 0's parity gate
@@ -995,8 +1002,8 @@ def main(argv=None):
                 b_plan, model, _ = stage_model_leg(args, sbwt, oi, concat0, offsets0, gpu_d)
                 exact = bool(exact and model["ms_equal_to_gpu"])
             if world == 1 and not args.no_extras and (args.extras or not args.custom):
-                sens = sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, pipes if piped else None)
-                ms_var = ms_leg(args, sbwt, oi, concat0, offsets0, torch, device, stream, pipes if piped else None)
+                sens = sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, n_pipes if piped else None)
+                ms_var = ms_leg(args, sbwt, oi, concat0, offsets0, torch, device, stream, n_pipes if piped else None)
         # fabric-side traffic and L2 misses of the A1 stage, from the committed rocprofv3 passes of this exact
         # workload and walk mode (PMC passes cannot run inside the timed region: separate runs, tools/profile_bench.sh)
         wl_key = f"{args.genome}x{n_mine}x{args.read_len}x{args.sub_rate:g}:{('map' if one_kernel else 'table' if sbwt.depth_table_order() > 0 else 'plan') if planned else 'plain'}"
@@ -1157,8 +1164,8 @@ def main(argv=None):
                            "note": "this rank's device copy: host layout of rank blocks / entries, uploads, path cover (0 when the index "
                                    "file carried it), recovery lines, seed table(s), depth table; index build or load is index_seconds_rank0"},
                        "resident_slabs_per_gpu": len(slabs), "index_seconds_rank0": round(t_index, 2),
-                       "batches_in_flight": ("%d on %d pipeline(s) of two streams: consecutive launches go to the pipelines in turn and take %s in turn; on a "
-                                             "pipeline a batch's second pass runs on the second stream (kbo_map_batch_dev_tail) beside the next "
+                       "batches_in_flight": ("%d on %d pipeline(s) of two streams (kbo_map_stream_*: the library's own; kbo::find: kbo_find_batch_dev's tail stream): consecutive launches go to the pipelines in turn and take %s in turn; on a "
+                                             "pipeline a batch's second pass runs on the second stream beside the next "
                                              "batch's kernel on the first; all of every step's work ends inside the timed region"
                                              % (2 * n_pipes, n_pipes, ("%d resident batches of this shape (different reads)" % n_sets) if n_sets > 1 else "the step's slabs")) if piped else 1,
                        "parallelism": f"index replicated x{world}, reads sharded, no collective"},

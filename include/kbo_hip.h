@@ -394,14 +394,16 @@ int kbo_map_batch_dev_tail(kbo_index_t *idx, const uint8_t *d_concat, const uint
  * exceed them.  The batch's own buffers (d_concat, d_offsets, d_chars_out) stay the caller's and must stay valid and untouched
  * until the batch is complete.
  *   kbo_map_stream_submit   enqueues kbo::map (format != 0) / kbo::matches of one device-resident batch and returns at once;
+ *                           d_ms_out (optional, padded as d_chars_out): the derandomized matching statistics too, one byte a base;
  *                           ready_stream (optional): the stream whose work so far produces the batch's inputs - the pipeline waits
- *                           for it on the device; *ticket (optional) names the batch
+ *                           for it on the device; *ticket (optional) names the batch; *fused (optional) as kbo_map_batch_dev's
  *   kbo_map_stream_wait     blocks the calling thread until that batch is complete;  kbo_map_stream_wait_on makes `stream` wait for
  *                           it on the device instead;  kbo_map_stream_sync: every batch submitted so far */
 typedef struct kbo_map_stream kbo_map_stream_t;
 int kbo_map_stream_create(kbo_index_t *idx, int pipelines, size_t max_seqs, uint64_t max_bases, size_t max_seq_len, kbo_map_stream_t **out);
 int kbo_map_stream_submit(kbo_map_stream_t *ms, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
-                          size_t max_seq_len, double max_error_prob, int format, uint8_t *d_chars_out, void *ready_stream, uint64_t *ticket);
+                          size_t max_seq_len, double max_error_prob, int format, uint8_t *d_ms_out, uint8_t *d_chars_out, void *ready_stream,
+                          uint64_t *ticket, int *fused);
 int kbo_map_stream_wait(kbo_map_stream_t *ms, uint64_t ticket);
 int kbo_map_stream_wait_on(kbo_map_stream_t *ms, uint64_t ticket, void *stream);
 int kbo_map_stream_sync(kbo_map_stream_t *ms);

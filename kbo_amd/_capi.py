@@ -235,7 +235,7 @@ def lib():
     L.kbo_set_plan_lazy.argtypes = [C.c_int64]
     L.kbo_set_map_long.argtypes = [C.c_int]
     L.kbo_map_stream_create.argtypes = [vp, C.c_int, sz, u64, sz, vp]
-    L.kbo_map_stream_submit.argtypes = [vp, vp, vp, sz, u64, sz, C.c_double, C.c_int, vp, vp, vp]
+    L.kbo_map_stream_submit.argtypes = [vp, vp, vp, sz, u64, sz, C.c_double, C.c_int, vp, vp, vp, vp, C.POINTER(C.c_int)]
     L.kbo_map_stream_wait.argtypes = [vp, u64]
     L.kbo_map_stream_wait_on.argtypes = [vp, u64, vp]
     L.kbo_map_stream_sync.argtypes = [vp]

@@ -358,11 +358,14 @@ class MapStream:
         self._h = h
 
     def submit(self, dev, ready_stream=None):
-        """kbo::map (dev.format) / kbo::matches of a DeviceBatch's sequences into dev.chars -> ticket"""
+        """kbo::map (dev.format) / kbo::matches of a DeviceBatch's sequences into dev.chars (and the matching statistics into dev.ms
+        when the batch was made with want_ms) -> ticket"""
         t = C.c_uint64(0)
+        fused = C.c_int(0)
         check(lib().kbo_map_stream_submit(self._h, dev.q.data_ptr(), dev.off.data_ptr(), dev.n_seqs, dev.total, dev.max_len, dev.max_error_prob,
-                                          int(dev.format), dev.chars.data_ptr(), ready_stream.cuda_stream if ready_stream is not None else None,
-                                          C.byref(t)))
+                                          int(dev.format), dev.ms.data_ptr() if dev.want_ms else None, dev.chars.data_ptr(),
+                                          ready_stream.cuda_stream if ready_stream is not None else None, C.byref(t), C.byref(fused)))
+        dev.fused = bool(fused.value)
         return int(t.value)
 
     def wait(self, ticket):

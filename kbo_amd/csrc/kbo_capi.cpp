@@ -1536,7 +1536,8 @@ int kbo_map_stream_create(kbo_index_t *idx, int pipelines, size_t max_seqs, uint
 }
 
 int kbo_map_stream_submit(kbo_map_stream_t *m, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
-                          size_t max_seq_len, double max_error_prob, int format, uint8_t *d_chars_out, void *ready_stream, uint64_t *ticket)
+                          size_t max_seq_len, double max_error_prob, int format, uint8_t *d_ms_out, uint8_t *d_chars_out, void *ready_stream,
+                          uint64_t *ticket, int *fused)
 {
     if (!m) {
         last_error() = "kbo_map_stream_submit: null stream";
@@ -1561,8 +1562,8 @@ int kbo_map_stream_submit(kbo_map_stream_t *m, const uint8_t *d_concat, const ui
         }
     });
     if (rc != KBO_OK) return rc;
-    rc = map_batch_dev_impl(m->idx, d_concat, d_offsets, n_seqs, total_bases, max_seq_len, max_error_prob, format, 0, sl.ms.as<uint8_t>(), d_chars_out,
-                            sl.work.p, m->work_bytes, p.ks, p.ts, true, nullptr);
+    rc = map_batch_dev_impl(m->idx, d_concat, d_offsets, n_seqs, total_bases, max_seq_len, max_error_prob, format, d_ms_out ? 1 : 0,
+                            d_ms_out ? d_ms_out : sl.ms.as<uint8_t>(), d_chars_out, sl.work.p, m->work_bytes, p.ks, p.ts, true, fused);
     if (rc != KBO_OK) return rc;
     rc = guarded([&] { // complete when both streams have come this far
         HIP_OK(hipEventRecord(m->kdone, p.ks));

@@ -267,22 +267,26 @@ def test_map_stream_batches_in_flight(oracle):
     ora = oracle.Index.build([c.tobytes() for c in contigs], k=31)
     dev0 = torch.device("cuda:0")
     sets = []
-    for lengths, n, fmt in (([150], 4000, True), ([700, 3000, 20_000], 40, False), ([60, 100, 159], 3000, False), ([10_000], 30, True)):
+    for lengths, n, fmt, want_ms in (([150], 4000, True, False), ([700, 3000, 20_000], 40, False, False), ([60, 100, 159], 3000, False, True),
+                                     ([10_000], 30, True, False)):
         seqs = [q for q in _sequences(rng, contigs, n, lengths, 0.01, 0.002, 0.0, spice=False) if len(q) >= 3]
         concat, offsets = _batch_of(seqs)
-        exp = ora.matches_batch(concat, offsets, 1e-7, n_threads=threads())
+        exp, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=threads(), want_d=True)
         want = np.frombuffer(oracle.relative_to_ref(concat, exp), dtype=np.uint8) if fmt else exp
-        sets.append((batch.DeviceBatch(sbwt, concat, offsets, device=dev0, format=fmt, want_ms=False), want))
-    ms = batch.MapStream(sbwt, max(d.n_seqs for d, _ in sets), max(d.total for d, _ in sets), 0, pipelines=2)
+        sets.append((batch.DeviceBatch(sbwt, concat, offsets, device=dev0, format=fmt, want_ms=want_ms), want, exp_d))
+    ms = batch.MapStream(sbwt, max(d.n_seqs for d, _, _ in sets), max(d.total for d, _, _ in sets), 0, pipelines=2)
     for rnd in range(3):
         tickets = []
-        for d, _ in sets:
+        for d, _, _ in sets:
             d.chars.fill_(0xEE)
+            d.ms.fill_(0xEE)
         torch.cuda.synchronize(dev0)
-        for d, _ in sets:
+        for d, _, _ in sets:
             tickets.append(ms.submit(d))
-        for (d, want), t in zip(sets, tickets):
+        for (d, want, want_d), t in zip(sets, tickets):
             ms.wait(t)
             assert np.array_equal(d.chars[:d.total].cpu().numpy(), want), rnd
+            if d.want_ms:  # (d_ms_out: the derandomized matching statistics of every base too)
+                assert np.array_equal(d.ms[:d.total].cpu().numpy(), want_d), rnd
     ms.sync()
     ms.close()
