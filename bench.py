@@ -475,8 +475,9 @@ def sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, pipes=None):
         exp_map = np.frombuffer(ora.relative_to_ref(concat[:n_b], exp_chars), dtype=np.uint8)
         ok = bool(np.array_equal(dev.chars[:n_b].cpu().numpy(), exp_map))  # (what the timed steps left behind)
         extra = {}
-        if fused and dev.max_len > 160:  # (sequences of any length: what the kernel's pieces did)
-            st = dev.long_stats()
+        if fused and dev.max_len > 160:  # (sequences of any length: what the kernel's pieces did - one more call, over the batch's own work buffer)
+            dev.run(stream)
+            st = dev.long_stats(stream)
             extra = {"pieces": st["pieces"], "flagged_pieces": st["flagged"]}  # (flagged: to the plain walk + the literal recurrences)
         dev.walk(stream)
         torch.cuda.synchronize(device)

@@ -1017,24 +1017,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
     }
 }
 
-// ---- flagged pieces: sub-items of 32 bases (+ k - 1 warm-up bases) for the plain walk: the MS values of [s - 1, s + n)
+// ---- flagged pieces: sub-items of 8 / 16 / 32 bases (+ k - 1 warm-up bases) for the plain walk: the MS values of [s - 1, s + n).
+// The walk is a chain of dependent steps, as long as a sub-item with its warm-up: while the flagged pieces are few, short sub-items
+// (more lanes, each done sooner) - as long as there are not more of them than the device holds lanes at once.  One pair of atomics
+// per workgroup: every flagged piece adding to the same two words took 50 us for three thousand of them.
 constexpr uint32_t kLongSub = 32;
-__global__ __launch_bounds__(256) void long_redo_items_kernel(LongArgs a, WalkItem *__restrict__ out, uint32_t cap, uint32_t *__restrict__ count,
-                                                              uint32_t *__restrict__ flist)
+constexpr uint32_t kLongSubLanes = 100000;
+__global__ __launch_bounds__(1024) void long_redo_items_kernel(LongArgs a, WalkItem *__restrict__ out, uint32_t cap, uint32_t *__restrict__ count,
+                                                               uint32_t *__restrict__ flist)
 {
-    const uint32_t piece = blockIdx.x * blockDim.x + threadIdx.x;
-    if (piece >= a.n_items || !a.redo[piece]) return;
-    const uint4 it = reinterpret_cast<const uint4 *>(a.items)[piece];
-    const uint32_t own0 = it.w & 0x3FFu, own_n = (it.w >> 10) & 0x7FFu;
-    if (own_n == 0) return;
-    const uint32_t s = it.y + own0;                  // the piece's first own base in its sequence
-    const uint64_t seq0 = (uint64_t)it.x - it.y;     // the sequence's first byte
-    const uint32_t lo = s > 0 ? s - 1u : 0u, hi = s + own_n, n_sub = (hi - lo + kLongSub - 1u) / kLongSub;
-    const uint32_t base = atomicAdd(count, n_sub);
-    flist[atomicAdd(count + 1, 1u)] = piece; // (count + 1 = qctl[2]: the flagged pieces, listed for long_derand_kernel)
+    __shared__ uint32_t s_sub[16], s_fl[16], s_base[2];
+    const uint32_t piece = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t n_fl = a.qctl[4], own_max = (kLongRegion - 2u * a.ix.k - 1u) & ~15u;
+    uint32_t sub = kLongSub;
+    for (uint32_t s_ = 8u; s_ < kLongSub; s_ <<= 1) {
+        const uint64_t n = (uint64_t)n_fl * ((own_max + s_) / s_);
+        if (n <= kLongSubLanes && n + 64u <= cap) {
+            sub = s_;
+            break;
+        }
+    }
+    bool fl = piece < a.n_items && a.redo[piece] != 0;
+    uint32_t s = 0, own_n = 0;
+    uint64_t seq0 = 0;
+    if (fl) {
+        const uint4 it = reinterpret_cast<const uint4 *>(a.items)[piece];
+        const uint32_t own0 = it.w & 0x3FFu;
+        own_n = (it.w >> 10) & 0x7FFu;
+        s = it.y + own0;                  // the piece's first own base in its sequence
+        seq0 = (uint64_t)it.x - it.y;     // the sequence's first byte
+        fl = own_n != 0u;
+    }
+    const uint32_t lo = s > 0 ? s - 1u : 0u, hi = s + own_n, n_sub = fl ? (hi - lo + sub - 1u) / sub : 0u;
+    // this piece's place among the workgroup's: within the wave, then across the waves
+    uint32_t incl = n_sub;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if ((int)lane >= o) incl += t;
+    }
+    const uint64_t bal = __ballot(fl);
+    if (lane == 63u) {
+        s_sub[wv] = incl;
+        s_fl[wv] = (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t ts = 0, tf = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); w++) {
+            const uint32_t a_ = s_sub[w], b_ = s_fl[w];
+            s_sub[w] = ts;
+            s_fl[w] = tf;
+            ts += a_;
+            tf += b_;
+        }
+        s_base[0] = ts ? atomicAdd(count, ts) : 0u;
+        s_base[1] = tf ? atomicAdd(count + 1, tf) : 0u; // (count + 1 = qctl[2]: the flagged pieces, listed for long_derand_kernel)
+    }
+    __syncthreads();
+    if (!fl) return;
+    const uint32_t base = s_base[0] + s_sub[wv] + incl - n_sub;
+    flist[s_base[1] + s_fl[wv] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = piece;
     const uint32_t warm_max = a.ix.k > 0 ? a.ix.k - 1u : 0u;
     for (uint32_t p = 0; p < n_sub; p++) {
-        const uint32_t o0 = lo + p * kLongSub, o1 = min(o0 + kLongSub, hi), warm = min(o0, warm_max);
+        const uint32_t o0 = lo + p * sub, o1 = min(o0 + sub, hi), warm = min(o0, warm_max);
         WalkItem w;
         w.start = seq0 + o0 - warm;
         w.len = o1 - o0 + warm;
@@ -1343,19 +1389,19 @@ hipError_t launch_map_long(const DevIndexView &ix, const uint8_t *d_q, const uin
 // the flagged pieces: their matching statistics by the plain walk (into d_ms), then the literal recurrences
 hipError_t launch_map_long_redo(const LongArgs &a, uint8_t *d_ms, hipStream_t stream)
 {
-    hipLaunchKernelGGL(long_redo_items_kernel, dim3((a.n_items + 255u) / 256u), dim3(256), 0, stream, a, static_cast<WalkItem *>(a.subs), a.sub_cap, a.qctl + 1,
+    hipLaunchKernelGGL(long_redo_items_kernel, dim3((a.n_items + 1023u) / 1024u), dim3(1024), 0, stream, a, static_cast<WalkItem *>(a.subs), a.sub_cap, a.qctl + 1,
                        a.flist);
     WalkArgs wa{};
     wa.ix = a.ix;
     wa.q = a.q;
     wa.q_bytes = a.q_bytes;
     wa.d_out = d_ms;
-    // (a few per cent of the pieces are flagged, 32 sub-items each: a lane per sub-item while there are as many as two per piece)
-    const uint32_t lanes = (uint32_t)std::min<uint64_t>((uint64_t)a.n_items * 2u + 4096u, a.sub_cap);
+    // (a few per cent of the pieces are flagged: a lane per sub-item while there are kLongSubLanes or two per piece)
+    const uint32_t lanes = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)a.n_items * 2u + 4096u, kLongSubLanes + 4096u), a.sub_cap);
     hipError_t e = launch_walk_list(wa, static_cast<const WalkItem *>(a.subs), a.sub_cap, a.qctl + 1, lanes, stream);
     if (e != hipSuccess) return e;
     // (a wave per run of flagged pieces; the list's length is on the device: the waves share it)
-    hipLaunchKernelGGL(long_derand_kernel, dim3(std::min<uint32_t>(a.n_items, 32768u)), dim3(64), 0, stream, a, d_ms, a.flist);
+    hipLaunchKernelGGL(long_derand_kernel, dim3(std::min<uint32_t>(a.n_items, 4096u)), dim3(64), 0, stream, a, d_ms, a.flist);
     return hipGetLastError();
 }
 

@@ -30,7 +30,8 @@ for g in groups:
     for r in rows[lo:]:
         s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
         if s > t_end: break
-        name = r['Kernel_Name'].split('(')[0].split('::')[-1][:34]
+        import re as _re
+        name = (_re.findall(r'([A-Za-z_0-9]+_kernel|__amd_rocclr_[A-Za-z]+)', r['Kernel_Name']) or [r['Kernel_Name'][:34]])[0][:34]
         print("%9.1f .. %9.1f us (%7.1f)  q%-3s %s  grid %s wg %s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, r.get('Queue_Id', '?'), name.ljust(34),
                                                                   r.get('Grid_Size_X', r.get('Grid_Size', '?')), r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?'))))
 PY
