@@ -268,7 +268,7 @@ struct FusedMap {
     hipEvent_t fence = nullptr;
     hipStream_t results = nullptr;
     // kbo::find with max_gap_len = 0: where the number of runs of every sequence goes (rle scratch, n_seqs + 1 words); counted = the
-    // one kernel (and, for the reads of its second pass, rle0_count_flagged_kernel) filled it: scan + emit are what is left
+    // one kernel (and, for the reads of its second pass, derand_flagged_kernel) filled it: scan + emit are what is left
     uint32_t *run_counts = nullptr;
     bool counted = false;
 };

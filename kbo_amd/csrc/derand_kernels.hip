@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void derand_translate_kernel(
 constexpr uint32_t kFlaggedPerBlock = 4096;
 __global__ __launch_bounds__(256) void derand_flagged_kernel(
     const uint8_t *__restrict__ ms, const uint64_t *__restrict__ off, uint32_t n_seqs, uint32_t k, uint32_t t,
-    const uint8_t *__restrict__ ref, uint8_t *__restrict__ out, uint32_t max_len, const uint8_t *__restrict__ flags)
+    const uint8_t *__restrict__ ref, uint8_t *__restrict__ out, uint32_t max_len, const uint8_t *__restrict__ flags,
+    uint32_t *__restrict__ run_counts)
 {
     __shared__ uint32_t list[kFlaggedPerBlock];
     __shared__ uint32_t cnt;
@@ -172,7 +173,31 @@ __global__ __launch_bounds__(256) void derand_flagged_kernel(
     }
     __syncthreads();
     const uint32_t c = cnt;
-    for (uint32_t j = threadIdx.x; j < c; j += blockDim.x) derand_one_sequence(ms, off, list[j], k, t, ref, out, nullptr, max_len);
+    for (uint32_t j = threadIdx.x; j < c; j += blockDim.x) {
+        const uint32_t s = list[j];
+        derand_one_sequence(ms, off, s, k, t, ref, out, nullptr, max_len);
+        // kbo::find with max_gap_len = 0 (format.rs:143-193): the runs of this sequence - the maximal stretches without '-' -
+        // counted by the lane that has just written its characters (unformatted: M - X R, bit 5 says '-'), 16 at a time; a kernel
+        // of its own that looked at every sequence's flag for this took 0.14 ms per 5 M reads
+        if (run_counts) {
+            const uint64_t b = off[s];
+            const uint32_t len = (uint32_t)(off[s + 1] - b);
+            uint32_t n = 0, prev_gap = 1;
+            for (uint32_t i0 = 0; i0 < len; i0 += 16u) {
+                const uint4 v = ld16u(out + b, i0); // (reads <= 15 bytes behind the sequence: the buffer is padded)
+                uint32_t E = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < 4u; q++) {
+                    const uint32_t d = q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
+                    E |= ((((d >> 5) & 0x01010101u) * 0x01020408u) >> 24) << (4u * q);
+                }
+                const uint32_t nv = min(16u, len - i0), valid = nv == 16u ? 0xFFFFu : (1u << nv) - 1u;
+                n += (uint32_t)__popc(~E & ((E << 1) | prev_gap) & valid); // a character that is no gap behind one that is
+                prev_gap = (E >> 15) & 1u;
+            }
+            run_counts[s] = len < 3u ? 0u : n;
+        }
+    }
 }
 
 // ---- LDS-staged variant for batches of short sequences (reads) -------------------------
@@ -632,11 +657,12 @@ hipError_t launch_derand_translate(const uint8_t *d_ms, const uint64_t *d_offset
 }
 
 hipError_t launch_derand_flagged(const uint8_t *d_ms, const uint64_t *d_offsets, uint32_t n_seqs, uint32_t k, uint32_t threshold,
-                                 const uint8_t *d_ref, uint8_t *d_chars_out, const uint8_t *d_flags, uint32_t max_seq_len, hipStream_t stream)
+                                 const uint8_t *d_ref, uint8_t *d_chars_out, const uint8_t *d_flags, uint32_t max_seq_len, hipStream_t stream,
+                                 uint32_t *d_run_counts)
 {
     if (n_seqs == 0) return hipSuccess;
     hipLaunchKernelGGL(derand_flagged_kernel, dim3((n_seqs + kFlaggedPerBlock - 1u) / kFlaggedPerBlock), dim3(256), 0, stream, d_ms, d_offsets,
-                       n_seqs, k, threshold, d_ref, d_chars_out, max_seq_len, d_flags);
+                       n_seqs, k, threshold, d_ref, d_chars_out, max_seq_len, d_flags, d_ref ? nullptr : d_run_counts);
     return hipGetLastError();
 }
 

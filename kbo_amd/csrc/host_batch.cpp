@@ -251,15 +251,13 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
                                               B.q.as<uint8_t>(), ts));
                 HIP_OK(kbo::launch_redo_pass(a, ts));
                 HIP_OK(kbo::launch_derand_flagged(B.ms.as<uint8_t>(), B.off.as<uint64_t>(), (uint32_t)n_seqs, idx->host.k, map->threshold,
-                                                  map->format ? B.q.as<uint8_t>() : nullptr, map->d_chars, a.redo, longest_seq, ts));
+                                                  map->format ? B.q.as<uint8_t>() : nullptr, map->d_chars, a.redo, longest_seq, ts,
+                                                  count_runs ? map->run_counts : nullptr));
                 if (map->d_packed_out) {
                     HIP_OK(kbo::launch_pack_flagged(map->d_chars, B.off.as<uint64_t>(), (uint32_t)n_seqs, wps, a.qp_data, a.redo, map->d_packed_out, ts));
                     map->packed_done = true;
                 }
-                if (count_runs) {
-                    HIP_OK(kbo::launch_rle0_count_flagged(map->d_chars, B.off.as<uint64_t>(), (uint32_t)n_seqs, a.redo, map->run_counts, ts));
-                    map->counted = true;
-                }
+                if (count_runs) map->counted = true;
                 plan_after_launch(a, ts, plan_state);
                 map->done = true;
                 return;
@@ -272,11 +270,9 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
                 hipStream_t ts = second_pass_stream(a);
                 HIP_OK(kbo::launch_redo_pass(a, ts));
                 HIP_OK(kbo::launch_derand_flagged(B.ms.as<uint8_t>(), B.off.as<uint64_t>(), (uint32_t)n_seqs, idx->host.k, map->threshold,
-                                                  map->format ? B.q.as<uint8_t>() : nullptr, map->d_chars, a.redo, longest_seq, ts));
-                if (count_runs) {
-                    HIP_OK(kbo::launch_rle0_count_flagged(map->d_chars, B.off.as<uint64_t>(), (uint32_t)n_seqs, a.redo, map->run_counts, ts));
-                    map->counted = true;
-                }
+                                                  map->format ? B.q.as<uint8_t>() : nullptr, map->d_chars, a.redo, longest_seq, ts,
+                                                  count_runs ? map->run_counts : nullptr)); // (the flagged reads' runs counted on the way)
+                if (count_runs) map->counted = true;
                 plan_after_launch(a, ts, plan_state);
                 map->done = true;
                 return;
@@ -756,11 +752,11 @@ private:
                 HIP_OK(kbo::launch_rle_scan_counts((uint32_t)ns, S.rle_scratch.as<uint32_t>(), S.rle_total.as<uint32_t>(), st_res));
             else
                 HIP_OK(kbo::launch_rle_count(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
-                                             S.rle_scratch.as<uint32_t>(), S.rle_total.as<uint32_t>(), st_res, mx));
+                                             S.rle_scratch.as<uint32_t>(), S.rle_total.as<uint32_t>(), st_res, mx, true));
             HIP_OK(hipMemcpyAsync(S.rle_total_pin.p, S.rle_total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st_res));
             HIP_OK(kbo::launch_rle_emit(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, gap,
                                         S.rle_scratch.as<uint32_t>(), S.rles.as<uint32_t>(), (uint32_t)S.rle_capacity,
-                                        st_res, mx));
+                                        st_res, mx, true)); // (the characters are the kernels' own: M - X R)
             S.longest = mx;
             HIP_OK(hipEventRecord(S.computed, st_res));
             HIP_OK(hipStreamWaitEvent(C.st_down, S.computed, 0));
@@ -828,7 +824,7 @@ private:
             HIP_OK(kbo::launch_rle_emit(S.chars.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)S.n_seqs,
                                         (uint32_t)std::min<size_t>(job_.sink->max_gap_len, 0xFFFFFFFFu),
                                         S.rle_scratch.as<uint32_t>(), S.rles.as<uint32_t>(), (uint32_t)S.rle_capacity,
-                                        C.st_down, S.longest));
+                                        C.st_down, S.longest, true));
         }
         const size_t words = kbo::chunk_items_scratch_words((uint32_t)S.n_seqs);
         S.out.ensure(std::max<size_t>(16, (size_t)total * kRleWords * sizeof(uint32_t)));

@@ -1371,8 +1371,8 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
                 uint32_t *total = rle_scratch + kbo::chunk_items_scratch_words((uint32_t)n_seqs);
                 const uint32_t gap = (uint32_t)std::min<size_t>(find->max_gap_len, 0xFFFFFFFFu), cap = (uint32_t)std::min<size_t>(find->capacity, 0xFFFFFFFFu);
                 const uint32_t longest = (uint32_t)std::min<size_t>(max_seq_len, 0xFFFFFFFFu);
-                HIP_OK(kbo::launch_rle_count(d_chars_out, d_offsets, (uint32_t)n_seqs, gap, rle_scratch, total, ts, longest));
-                if (cap) HIP_OK(kbo::launch_rle_emit(d_chars_out, d_offsets, (uint32_t)n_seqs, gap, rle_scratch, find->d_records, cap, ts, longest));
+                HIP_OK(kbo::launch_rle_count(d_chars_out, d_offsets, (uint32_t)n_seqs, gap, rle_scratch, total, ts, longest, true));
+                if (cap) HIP_OK(kbo::launch_rle_emit(d_chars_out, d_offsets, (uint32_t)n_seqs, gap, rle_scratch, find->d_records, cap, ts, longest, true));
             }
             done = true;
             return;
@@ -1425,7 +1425,7 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
         if (timing) HIP_OK(hipEventRecord(ev.e1t, ts)); // (when the second pass starts: behind the kernel and behind what `ts` held)
         HIP_OK(kbo::launch_redo_pass(a, ts)); // (redo_collect_kernel reads the offsets as well: no item list at all)
         HIP_OK(kbo::launch_derand_flagged(d_ms, d_offsets, (uint32_t)n_seqs, idx->host.k, (uint32_t)threshold, format ? d_concat : nullptr,
-                                          d_chars_out, a.redo, (uint32_t)max_seq_len, ts));
+                                          d_chars_out, a.redo, (uint32_t)max_seq_len, ts, count_in_kernel ? rle_scratch : nullptr));
         if (timing) {
             HIP_OK(hipEventRecord(ev.e2, ts));
             std::lock_guard<std::mutex> g(g_timing_mu);
@@ -1435,12 +1435,11 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
         if (find) { // the run lengths, behind the second pass
             uint32_t *total = rle_scratch + kbo::chunk_items_scratch_words((uint32_t)n_seqs); // last word of the work buffer
             const uint32_t gap = (uint32_t)std::min<size_t>(find->max_gap_len, 0xFFFFFFFFu), cap = (uint32_t)std::min<size_t>(find->capacity, 0xFFFFFFFFu);
-            if (count_in_kernel) {
-                HIP_OK(kbo::launch_rle0_count_flagged(d_chars_out, d_offsets, (uint32_t)n_seqs, a.redo, rle_scratch, ts));
+            if (count_in_kernel) { // (the flagged reads' counts: launch_derand_flagged's)
                 HIP_OK(kbo::launch_rle_scan_counts((uint32_t)n_seqs, rle_scratch, total, ts));
             } else
-                HIP_OK(kbo::launch_rle_count(d_chars_out, d_offsets, (uint32_t)n_seqs, gap, rle_scratch, total, ts, (uint32_t)max_seq_len));
-            if (cap) HIP_OK(kbo::launch_rle_emit(d_chars_out, d_offsets, (uint32_t)n_seqs, gap, rle_scratch, find->d_records, cap, ts, (uint32_t)max_seq_len));
+                HIP_OK(kbo::launch_rle_count(d_chars_out, d_offsets, (uint32_t)n_seqs, gap, rle_scratch, total, ts, (uint32_t)max_seq_len, true));
+            if (cap) HIP_OK(kbo::launch_rle_emit(d_chars_out, d_offsets, (uint32_t)n_seqs, gap, rle_scratch, find->d_records, cap, ts, (uint32_t)max_seq_len, true));
         }
         done = true;
     });

@@ -236,9 +236,11 @@ hipError_t launch_pack_flagged(const uint8_t *d_chars, const uint64_t *d_off, ui
                                const uint8_t *d_flags, uint32_t *d_packed, hipStream_t stream);
 // the list of the flagged items (redo_collect_kernel) and their plain walk; `a` as the plan launch left it
 hipError_t launch_redo_pass(WalkArgs a, hipStream_t stream);
-// A5 + A6 (+ relative_to_ref) for the sequences with flags[s] != 0 only, one lane each
+// A5 + A6 (+ relative_to_ref) for the sequences with flags[s] != 0 only, one lane each; d_run_counts (unformatted characters only):
+// the number of runs of each of those sequences for format::run_lengths_gapped with max_gap_len = 0, next to map_reads_kernel's own
 hipError_t launch_derand_flagged(const uint8_t *d_ms, const uint64_t *d_offsets, uint32_t n_seqs, uint32_t k, uint32_t threshold,
-                                 const uint8_t *d_ref, uint8_t *d_chars_out, const uint8_t *d_flags, uint32_t max_seq_len, hipStream_t stream);
+                                 const uint8_t *d_ref, uint8_t *d_chars_out, const uint8_t *d_flags, uint32_t max_seq_len, hipStream_t stream,
+                                 uint32_t *d_run_counts = nullptr);
 // stretches the fused plan_kernel leaves to the anchors: one block per plan_kernel wave in the unit array (free in table mode
 // until redo_collect_kernel builds its list there): {count, pad[3]} + kDtabStretchCap entries {item, start, m | next << 16,
 // len | warm << 16}; a wave with more of them flags the items of the rest
@@ -282,13 +284,13 @@ hipError_t launch_make_chunk_items(const uint64_t *d_offsets, uint32_t n_seqs, u
 // {start, end, matches, mismatches, jumps, gap_bases, gap_opens}; after launch_rle_count the first-run index of
 // sequence s is d_scratch[n_seqs + 1 + s / 1024] + d_scratch[s] and *d_total the number of runs
 hipError_t launch_rle_count(const uint8_t *d_chars, const uint64_t *d_offsets, uint32_t n_seqs, uint32_t max_gap_len,
-                            uint32_t *d_scratch, uint32_t *d_total, hipStream_t stream, uint32_t max_seq_len = 0);
+                            uint32_t *d_scratch, uint32_t *d_total, hipStream_t stream, uint32_t max_seq_len = 0,
+                            bool own_alphabet = false /* the characters are translate_ms_vec's own, unformatted: M - X R and nothing else */);
 hipError_t launch_rle_scan_counts(uint32_t n_seqs, uint32_t *d_scratch, uint32_t *d_total, hipStream_t stream);
-hipError_t launch_rle0_count_flagged(const uint8_t *d_chars, const uint64_t *d_offsets, uint32_t n_seqs, const uint8_t *d_flags,
-                                     uint32_t *d_counts, hipStream_t stream);
 hipError_t launch_rle_emit(const uint8_t *d_chars, const uint64_t *d_offsets, uint32_t n_seqs, uint32_t max_gap_len,
                            uint32_t *d_scratch, uint32_t *d_rles, uint32_t capacity, hipStream_t stream,
-                           uint32_t max_seq_len = 0 /* longest sequence if known: reads take the LDS-staged kernels */);
+                           uint32_t max_seq_len = 0 /* longest sequence if known: reads take the LDS-staged kernels */,
+                           bool own_alphabet = false);
 // A1: k-bounded matching statistics over all items
 hipError_t launch_ms_walk(WalkArgs a, int max_waves, hipStream_t stream);
 // A5+A6 (+ optional relative_to_ref when ref != nullptr, + optional i32 derandomised

@@ -198,14 +198,104 @@ __global__ __launch_bounds__(64) void rle0_lds_kernel(const uint8_t *__restrict_
     if (!EMIT) counts[s] = n_out;
 }
 
+// The same for characters that are translate_ms_vec's own (translate.rs:180-216: 'M' 4D, '-' 2D, 'X' 58, 'R' 52 and nothing else - kbo::find's
+// tail, lib.rs:816-820): bit 5 of a character says '-', bit 1 'R', bit 0 without bit 5 'M'.  Four characters a word: the three bits of each
+// gathered by a multiplication (bits 0, 8, 16, 24 of x land in bits 24 .. 27 of x * 0x01020408, nothing else does), a lane's 16 characters from
+// five aligned words of its LDS row - a fifth of the instructions of the byte-by-byte classification above, which took as long as
+// map_reads_kernel itself at C3.
+template <bool EMIT>
+__global__ __launch_bounds__(64) void rle0_own_kernel(const uint8_t *__restrict__ chars, const uint64_t *__restrict__ off,
+                                                      uint32_t n_seqs, uint32_t *__restrict__ counts,
+                                                      const uint32_t *__restrict__ sums, uint32_t *__restrict__ out,
+                                                      uint32_t capacity, uint32_t lds_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t s0 = blockIdx.x * 64u;
+    const uint32_t s = s0 + lane;
+    const uint32_t s_end = min(s0 + 64u, n_seqs);
+    const uint64_t base = off[s0];
+    const uint32_t span = (uint32_t)(off[s_end] - base);
+    if (span > lds_bytes) return; // cannot happen: the host sizes lds_bytes from the longest sequence
+    for (uint32_t o = lane * 16u; o < span; o += 1024u) // stage in (reads <= 15 B past the span)
+        *reinterpret_cast<uint4 *>(lds + o) = ld16u(chars + base, o);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // (one wave a workgroup: nobody else to wait for)
+    __builtin_amdgcn_wave_barrier();
+    if (s >= n_seqs) return;
+    const uint32_t b = (uint32_t)(off[s] - base), len = (uint32_t)(off[s + 1] - off[s]);
+    const uint32_t first = EMIT ? sums[s / kScanBlock] + counts[s] : 0u;
+    const uint32_t *row = reinterpret_cast<const uint32_t *>(lds) + (b >> 2);
+    const uint32_t sh = b & 3u;
+    uint32_t n_out = 0, in_run = 0, start = 0, end = 0, matches = 0, mismatches = 0, jumps = 0, prev_r = 0;
+    auto close = [&]() {
+        if (EMIT) {
+            const uint32_t slot = first + n_out;
+            if (slot < capacity) {
+                const uint32_t rec[7] = {start, end, matches, mismatches, jumps, 0u, 0u};
+                __builtin_memcpy(out + (uint64_t)slot * 7u, rec, 28);
+            }
+        }
+        n_out++;
+        in_run = 0;
+    };
+    uint32_t carry = row[0];
+    for (uint32_t i0 = 0; i0 < len; i0 += 16u) {
+        const uint32_t n = min(16u, len - i0);
+        uint32_t E = 0, M1 = 0, R = 0; // bit j describes character i0 + j: '-' / bit 0 / 'R'
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; q++) {
+            const uint32_t nxt = row[(i0 >> 2) + q + 1u]; // (up to 7 bytes behind the row: the staged span is padded)
+            const uint32_t d = __builtin_amdgcn_alignbyte(nxt, carry, sh);
+            carry = nxt;
+            E |= ((((d >> 5) & 0x01010101u) * 0x01020408u) >> 24) << (4u * q);
+            R |= ((((d >> 1) & 0x01010101u) * 0x01020408u) >> 24) << (4u * q);
+            M1 |= (((d & 0x01010101u) * 0x01020408u) >> 24) << (4u * q);
+        }
+        const uint32_t valid = n == 16u ? 0xFFFFu : (1u << n) - 1u;
+        const uint32_t M = (M1 & ~E) | R;
+        const uint32_t RR = R & ((R << 1) | prev_r); // 'R' right after an 'R' (format.rs:175)
+        prev_r = (R >> 15) & 1u;                     // only meaningful when n == 16 (no block follows otherwise)
+        uint32_t cur = 0;
+        while (cur < n) {
+            if (in_run) {
+                const uint32_t ev = E & valid & (~0u << cur);
+                const uint32_t e = ev ? (uint32_t)__ffs((int)ev) - 1u : n;
+                const uint32_t seg = ((1u << e) - 1u) & (~0u << cur); // characters [cur, e) of the block
+                matches += __popc(M & seg);
+                mismatches += __popc(~M & seg);
+                jumps += __popc(RR & seg);
+                if (seg) end = i0 + (32u - (uint32_t)__clz((int)seg)); // (no 'D' here: end moves past every character, format.rs:172)
+                if (e < n) { // a '-' ends the run (its gap is taken back out: net nothing)
+                    close();
+                    cur = e + 1u;
+                } else {
+                    cur = n;
+                }
+            } else {
+                const uint32_t ne = ~E & valid & (~0u << cur);
+                if (!ne) break;
+                cur = (uint32_t)__ffs((int)ne) - 1u;
+                in_run = 1;
+                start = i0 + cur;
+                end = matches = mismatches = jumps = 0;
+            }
+        }
+    }
+    if (in_run) close();
+    if (!EMIT) counts[s] = n_out;
+}
+
 template <bool EMIT>
 static void launch_rle_pass(const uint8_t *d_chars, const uint64_t *d_offsets, uint32_t n_seqs, uint32_t max_gap_len,
                             uint32_t *local, const uint32_t *sums, uint32_t *d_rles, uint32_t capacity, uint32_t max_seq_len,
-                            hipStream_t stream)
+                            hipStream_t stream, bool own_alphabet)
 {
     if (max_seq_len > 0 && max_seq_len <= 480 && max_gap_len == 0) {
         const uint32_t lds_bytes = ((64u * max_seq_len + 15u) / 16u) * 16u + 16u;
-        if (max_seq_len % 32u == 0)
+        if (own_alphabet)
+            hipLaunchKernelGGL((rle0_own_kernel<EMIT>), dim3((n_seqs + 63) / 64), dim3(64), lds_bytes + 16u, stream, d_chars, d_offsets, n_seqs, local,
+                               sums, d_rles, capacity, lds_bytes);
+        else if (max_seq_len % 32u == 0)
             hipLaunchKernelGGL((rle0_lds_kernel<EMIT, true>), dim3((n_seqs + 63) / 64), dim3(64), lds_bytes + lds_bytes / 32u + 16u,
                                stream, d_chars, d_offsets, n_seqs, local, sums, d_rles, capacity, lds_bytes);
         else
@@ -215,25 +305,6 @@ static void launch_rle_pass(const uint8_t *d_chars, const uint64_t *d_offsets, u
         hipLaunchKernelGGL((rle_kernel<EMIT>), dim3((n_seqs + 255) / 256), dim3(256), 0, stream, d_chars, d_offsets, n_seqs,
                            max_gap_len, local, sums, d_rles, capacity);
     }
-}
-
-// kbo_find_batch_dev: map_reads_kernel counted the runs of the reads it finished itself (max_gap_len == 0: the maximal stretches
-// without '-'); the reads it left to the second pass are counted here, one lane per read looking at its flag (a handful in a hundred)
-__global__ __launch_bounds__(256) void rle0_count_flagged_kernel(const uint8_t *__restrict__ chars, const uint64_t *__restrict__ off,
-                                                                 uint32_t n_seqs, const uint8_t *__restrict__ flags, uint32_t *__restrict__ counts)
-{
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_seqs || !flags[s]) return;
-    const uint64_t b = off[s];
-    const uint32_t len = (uint32_t)(off[s + 1] - b);
-    uint32_t n = 0, in_run = 0;
-    for (uint32_t i = 0; i < len; i++) {
-        const uint32_t c = chars[b + i];
-        const uint32_t run = (c != '-' && c != ' ') ? 1u : 0u;
-        n += run & ~in_run;
-        in_run = run;
-    }
-    counts[s] = n;
 }
 
 // total number of runs (the scan's grand total) -> one word the host can read after the stream
@@ -249,21 +320,21 @@ __global__ void rle_total_kernel(const uint32_t *__restrict__ local, const uint3
 // d_scratch: chunk_items_scratch_words(n_seqs) u32 (per-sequence first-run index, block sums);
 // d_total: one u32.  Records beyond `capacity` are counted but not written (the caller re-emits).
 hipError_t launch_rle_count(const uint8_t *d_chars, const uint64_t *d_offsets, uint32_t n_seqs, uint32_t max_gap_len,
-                            uint32_t *d_scratch, uint32_t *d_total, hipStream_t stream, uint32_t max_seq_len)
+                            uint32_t *d_scratch, uint32_t *d_total, hipStream_t stream, uint32_t max_seq_len, bool own_alphabet)
 {
     if (n_seqs == 0) return hipSuccess;
     const uint32_t n = n_seqs + 1;
     uint32_t *local = d_scratch, *sums = d_scratch + n;
     const hipError_t e = hipMemsetAsync(local + n_seqs, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    launch_rle_pass<false>(d_chars, d_offsets, n_seqs, max_gap_len, local, nullptr, nullptr, 0u, max_seq_len, stream);
+    launch_rle_pass<false>(d_chars, d_offsets, n_seqs, max_gap_len, local, nullptr, nullptr, 0u, max_seq_len, stream, own_alphabet);
     const hipError_t es = launch_scan(local, n, sums, stream);
     if (es != hipSuccess) return es;
     hipLaunchKernelGGL(rle_total_kernel, dim3(1), dim3(64), 0, stream, local, sums, n_seqs, d_total);
     return hipGetLastError();
 }
 
-// the same with the counts given (d_scratch[0 .. n_seqs): map_reads_kernel's, then launch_rle0_count_flagged's): scan + total only
+// the same with the counts given (d_scratch[0 .. n_seqs): map_reads_kernel's and, for the reads of its second pass, launch_derand_flagged's): scan + total only
 hipError_t launch_rle_scan_counts(uint32_t n_seqs, uint32_t *d_scratch, uint32_t *d_total, hipStream_t stream)
 {
     if (n_seqs == 0) return hipSuccess;
@@ -277,21 +348,13 @@ hipError_t launch_rle_scan_counts(uint32_t n_seqs, uint32_t *d_scratch, uint32_t
     return hipGetLastError();
 }
 
-hipError_t launch_rle0_count_flagged(const uint8_t *d_chars, const uint64_t *d_offsets, uint32_t n_seqs, const uint8_t *d_flags,
-                                     uint32_t *d_counts, hipStream_t stream)
-{
-    if (n_seqs == 0) return hipSuccess;
-    hipLaunchKernelGGL(rle0_count_flagged_kernel, dim3((n_seqs + 255u) / 256u), dim3(256), 0, stream, d_chars, d_offsets, n_seqs, d_flags, d_counts);
-    return hipGetLastError();
-}
-
 hipError_t launch_rle_emit(const uint8_t *d_chars, const uint64_t *d_offsets, uint32_t n_seqs, uint32_t max_gap_len,
                            uint32_t *d_scratch, uint32_t *d_rles, uint32_t capacity, hipStream_t stream,
-                           uint32_t max_seq_len)
+                           uint32_t max_seq_len, bool own_alphabet)
 {
     if (n_seqs == 0) return hipSuccess;
     uint32_t *local = d_scratch, *sums = d_scratch + n_seqs + 1;
-    launch_rle_pass<true>(d_chars, d_offsets, n_seqs, max_gap_len, local, sums, d_rles, capacity, max_seq_len, stream);
+    launch_rle_pass<true>(d_chars, d_offsets, n_seqs, max_gap_len, local, sums, d_rles, capacity, max_seq_len, stream, own_alphabet);
     return hipGetLastError();
 }
 

@@ -339,7 +339,7 @@ def test_packed_native_kernel_device_resident(oracle):
 
 def test_find_on_the_device_counts_runs_in_the_kernel(oracle):
     """kbo_find_batch_dev: the characters and format::run_lengths_gapped of them for a device-resident batch.  With max_gap_len = 0 the
-    one kernel counts the runs of the reads it finishes (and a small kernel those of the reads it leaves to the second pass), so the
+    one kernel counts the runs of the reads it finishes (and the second pass those of the reads left to it), so the
     records come from one pass over the characters; with a gap length the usual two.  Against the oracle's literal run lengths, every
     read: ragged reads down to 3 bases, substitutions to 6 %, indels, N's, unrelated reads (no run at all), with and without a tail
     stream; sequences longer than the kernel takes (two kernels, then count + emit)."""
