@@ -14,6 +14,7 @@ use std::os::raw::{c_char, c_int, c_void};
 pub mod ffi {
     use super::*;
     #[repr(C)] pub struct KboIndex { _private: [u8; 0] }
+    #[repr(C)] pub struct KboMapStream { _private: [u8; 0] }
     #[repr(C)] #[derive(Clone, Copy, Debug, PartialEq)]
     pub struct KboRle { pub start: u64, pub end: u64, pub matches: u64, pub mismatches: u64,
                         pub jumps: u64, pub gap_bases: u64, pub gap_opens: u64 }
@@ -79,6 +80,16 @@ pub mod ffi {
                                       max_seq_len: usize, p: f64, format: c_int, want_ms: c_int, d_ms: *mut u8, d_chars_out: *mut u8,
                                       d_work: *mut c_void, work_bytes: usize, stream: *mut c_void, tail_stream: *mut c_void,
                                       fused: *mut c_int) -> c_int;
+        // several batches in flight through the library's own pipelines (kbo_hip.h kbo_map_stream_*): tickets instead of streams
+        pub fn kbo_map_stream_create(idx: *mut KboIndex, pipelines: c_int, max_seqs: usize, max_bases: u64, max_seq_len: usize,
+                                     out: *mut *mut KboMapStream) -> c_int;
+        pub fn kbo_map_stream_submit(ms: *mut KboMapStream, d_concat: *const u8, d_offsets: *const u64, n_seqs: usize, total_bases: u64,
+                                     max_seq_len: usize, p: f64, format: c_int, d_ms_out: *mut u8, d_chars_out: *mut u8,
+                                     ready_stream: *mut c_void, ticket: *mut u64, fused: *mut c_int) -> c_int;
+        pub fn kbo_map_stream_wait(ms: *mut KboMapStream, ticket: u64) -> c_int;
+        pub fn kbo_map_stream_wait_on(ms: *mut KboMapStream, ticket: u64, stream: *mut c_void) -> c_int;
+        pub fn kbo_map_stream_sync(ms: *mut KboMapStream) -> c_int;
+        pub fn kbo_map_stream_free(ms: *mut KboMapStream);
         // kbo::find for a device-resident batch: the characters, then format::run_lengths_gapped of them (records of seven u32)
         pub fn kbo_run_lengths_work_bytes(n_seqs: usize) -> usize;
         pub fn kbo_find_batch_dev(idx: *mut KboIndex, d_concat: *const u8, d_offsets: *const u64, n_seqs: usize, total_bases: u64,

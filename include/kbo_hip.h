@@ -373,7 +373,8 @@ int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, siz
  * d_ms: total_bases bytes + 16, 4-byte aligned: the MS value of every base when want_ms != 0 or the batch takes the two-kernel
  * route, otherwise scratch (the reads the one kernel leaves to the plain walk pass through it).  d_work / work_bytes as for
  * kbo_ms_batch_dev; d_concat needs 16 readable bytes of slack behind the batch.  Sequences of fewer than 3 bases (the
- * reference asserts, derandomize.rs:276) are left unwritten, as by kbo_derand_translate_dev.  *fused (optional) = 1 when the
+ * reference asserts, derandomize.rs:276) have no alignment: their bytes of d_chars_out (and d_ms) are unspecified - left unwritten by the
+ * two-kernel route, overwritten by the one kernel, whose stores are whole lines - and kbo_find_batch_dev reports no run for them.  *fused (optional) = 1 when the
  * batch took the one kernel. */
 int kbo_map_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
                       size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,

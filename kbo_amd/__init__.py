@@ -15,8 +15,10 @@ import numpy as np
 
 # The host batch pipeline keeps three streams per device (upload, kernels, download) next to whatever the caller uses; the HIP runtime
 # maps a process's streams onto 4 hardware queues unless told otherwise, and streams that share a queue do not overlap
-# (INTEGRATION.md "Streams and hardware queues").  Only effective before the runtime starts; a value from outside wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (INTEGRATION.md "Streams and hardware queues").  Only effective before the runtime starts; a value from outside wins, and
+# KBO_KEEP_HW_QUEUES=1 leaves the variable alone altogether (a process that shares the runtime with other HIP users and wants its default).
+if not os.environ.get("KBO_KEEP_HW_QUEUES"):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from . import _capi, derandomize, format, gap_filling, index, translate, variant_calling  # noqa: F401
 from ._capi import KboError, check, lib  # noqa: F401

@@ -991,7 +991,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
     // that is (or the read's head)
     if (DIRECT && a.run_counts && have_item) {
         uint32_t n_runs = 0;
-        if (plannable && !flag) {
+        if (plannable && !flag && len >= 3u) { // (fewer than 3 bases: no alignment - the reference asserts, derandomize.rs:274-276 - and no run)
             const uint32_t b0 = ooff, b1 = ooff + len;
             uint32_t carry = 0; // the character in front of the word was not a '-' (bit 7)
             for (uint32_t wa = b0 & ~3u; wa < b1; wa += 4u) {

@@ -239,7 +239,9 @@ __global__ __launch_bounds__(64) void rle0_own_kernel(const uint8_t *__restrict_
         in_run = 0;
     };
     uint32_t carry = row[0];
-    for (uint32_t i0 = 0; i0 < len; i0 += 16u) {
+    // (a sequence of fewer than 3 bases has no alignment - the reference asserts, derandomize.rs:274-276 - and no run: what the kernels
+    // in front counted for it)
+    for (uint32_t i0 = 0; len >= 3u && i0 < len; i0 += 16u) {
         const uint32_t n = min(16u, len - i0);
         uint32_t E = 0, M1 = 0, R = 0; // bit j describes character i0 + j: '-' / bit 0 / 'R'
 #pragma unroll
