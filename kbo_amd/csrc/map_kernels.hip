@@ -111,6 +111,10 @@ __global__ __launch_bounds__(256) void seed_pos_kernel(const uint2 *__restrict__
 __device__ __forceinline__ bool thr_gt(uint32_t thr, uint32_t order) { return thr > order; } // (windows order .. thr apart exist)
 constexpr uint32_t kMapWords = 10;       // 16-base words per read: reads of up to 160 bases
 constexpr uint32_t kMapSlack = 48;       // bytes of the byte region behind the staged stretch
+// windows that are in the index and wait for the anchors / the windows around them, per wave (two or three at 1 % substitutions, a
+// dozen at 5 %; more: their reads take the plain walk).  20: a wave of 64 reads of 150 bases then takes 13 312 bytes of LDS - 26
+// allocation units of 512 - and a CU holds TWELVE of them; with 64 entries it held eleven
+constexpr uint32_t kMapPend = 20, kMapPendBytes = kMapPend * 8u + 16u;
 
 // NP = bases a stretch can take: 16 (tables of up to 15 bases: 32-bit keys) or 18 (16 / 17 bases).
 // DIRECT: the characters straight from the mismatch positions, no MS bytes at all.  Where the table's order is at most the
@@ -159,15 +163,15 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
     extern __shared__ __attribute__((aligned(16))) uint8_t map_lds_all[];
     const uint32_t lane = threadIdx.x & 63u;
     // (the waves of a workgroup share nothing: each has its own part of the LDS and never waits for another)
-    const uint32_t wave_lds = (stage_bytes + 4u * (lin_words + 4u) + 1024u + 528u + 15u) & ~15u; // (+ 64 pending anchor checks and their counter)
+    const uint32_t wave_lds = (stage_bytes + 4u * (lin_words + 4u) + 1024u + kMapPendBytes + 15u) & ~15u; // (+ the pending windows and their counter)
     uint8_t *map_lds = map_lds_all + (threadIdx.x >> 6) * wave_lds;
     const uint32_t idx = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane;
     uint8_t *so = map_lds;                                                       // MS bytes, then characters: the wave's stretch
     uint32_t *lin = reinterpret_cast<uint32_t *>(map_lds + stage_bytes) + 4;     // the stretch as 2-bit digits (lin[-1] = 0)
     uint8_t *spw = map_lds + stage_bytes + 4u * (lin_words + 4u);                // 64 x 16 bytes: mismatch positions 0 .. 12, flag, prefix
     uint8_t *sp = spw + lane * 16u;
-    uint2 *pend = reinterpret_cast<uint2 *>(spw + 1024u); // DIRECT: windows that are present and wait for their exact depth (64 entries)
-    uint32_t *pend_n = reinterpret_cast<uint32_t *>(spw + 1024u + 512u);
+    uint2 *pend = reinterpret_cast<uint2 *>(spw + 1024u); // DIRECT: windows that are present and wait for their exact depth (kMapPend entries)
+    uint32_t *pend_n = reinterpret_cast<uint32_t *>(spw + 1024u + kMapPend * 8u);
     const uint32_t k = a.ix.k;
     const uint8_t *qb = a.q;
     uint32_t start = 0, len = 0, warm = 0, tail = 0;
@@ -611,6 +615,16 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
             }
         }
     }
+    // (DIRECT) a diagonal on which every third base mismatches is no diagonal of this read: a seed of D bases that some other place of
+    // the index shares by chance - one window in fifty at 5 * 10^6 rows, so one read in fourteen of another genome or the other
+    // strand.  Such a read is judged like one without a seed (every window of the proof: absent, or settled by the windows
+    // around it) instead of being left to the plain walk for its list's length.
+    if (DIRECT && seeded && cnt > a.plan_list + 1u && 3u * cnt > len && !(a.rounds & 64u)) { // (a.rounds bit 6, experiment: off)
+        seeded = false;
+        junction = 0xFFu;
+        jov = 0;
+        cnt = 0;
+    }
     // the ramp of a read's first bases (depth i + 1 while nothing mismatches: the bases equal a path of the text)
     bool flag = plannable && seeded && cnt > a.plan_list + 1u; // more mismatches than the list holds: the plain walk
     const bool no_plan = plannable && !seeded && !has_invalid; // no seed at all: every base from the table, 16 at a time
@@ -740,6 +754,16 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                         }
                     }
                     bool fail = false;
+                    // a window that IS in the index and that neither the anchors nor its place settle: the windows around it may (behind
+                    // the loop, with the anchors' windows: `pend`) - unless it belongs to a junction
+                    auto ask_around = [&](uint32_t e_) {
+                        if (order < k && (blockmode || t != o_junc) && !(a.rounds & 32u)) { // (a.rounds bit 5, experiment: off)
+                            const uint32_t slot = atomicAdd(pend_n, 1u);
+                            if (slot < kMapPend) pend[slot] = make_uint2(o_soff + e_, owner | (e_ << 8) | (0x7FFFu << 16));
+                            else fail = true;
+                        } else
+                            fail = true;
+                    };
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; i++) {
                         if (use[i] && (bytes[i] & 0x80u)) { // the window is a suffix of a row
@@ -753,10 +777,10 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                                 const uint32_t e1 = ee[i] + 1u;
                                 if (e1 < o_len) {
                                     const uint32_t slot = atomicAdd(pend_n, 1u);
-                                    if (slot < 64u) pend[slot] = make_uint2(o_soff + e1, owner | (e1 << 8) | 0x80000000u);
+                                    if (slot < kMapPend) pend[slot] = make_uint2(o_soff + e1, owner | (e1 << 8) | 0x80000000u);
                                     else fail = true;
                                 }
-                            } else if (!have_anch || lastw[i]) fail = true;
+                            } else if (!have_anch || lastw[i]) ask_around(ee[i]);
                             else {
                                 // its exact depth off the path-cover text decides - behind the loop, all such windows of the wave at once
                                 // (one in 200 windows: looked up here, a hash probe and two loads of text for ONE lane held every
@@ -767,11 +791,11 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                                 // own does not - the depth is the window's length, nothing to look up)
                                 const bool deeper = e_i >= order && order < k && ((bytes[i] >> base_at(o_soff + e_i - order)) & 1u);
                                 if (!deeper) {
-                                    if (order + (nxt_e - e_i) - 1u > thr) fail = true;
+                                    if (order + (nxt_e - e_i) - 1u > thr) ask_around(e_i);
                                 } else {
                                     st_anch++;
                                     const uint32_t slot = atomicAdd(pend_n, 1u);
-                                    if (slot < 64u) pend[slot] = make_uint2(o_soff + e_i, owner | (e_i << 8) | ((nxt_e - e_i) << 16));
+                                    if (slot < kMapPend) pend[slot] = make_uint2(o_soff + e_i, owner | (e_i << 8) | ((nxt_e - e_i) << 16));
                                     else fail = true; // (no room: the plain walk decides)
                                 }
                             }
@@ -845,24 +869,93 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (DIRECT && have_anch) {
+        if (DIRECT) {
             // a present window's exact depth (dtab_anchor_depth: the window is the suffix of ONE row, whose characters stand in the text in
             // front of its position).  Strings through the break that end between this window and the next start no further left than
             // this depth says: with the next window (or the read's end) g bases on, none is longer than depth + g - 1
-            const uint32_t n_pend = min(*pend_n, 64u);
+            const uint32_t n_pend = min(*pend_n, kMapPend);
+            bool around = false; // this lane's window is left to the windows around it
+            uint32_t w_e = 0, w_owner = 0, w_at = 0;
             if (lane < n_pend) {
                 const uint2 pe = pend[lane];
                 const uint32_t p_owner = pe.y & 0xFFu, e_i = (pe.y >> 8) & 0xFFu, gap = (pe.y >> 16) & 0x7FFFu, at_e = pe.x;
+                w_owner = p_owner;
+                w_e = e_i;
+                w_at = at_e;
                 if (pe.y >> 31) { // the window one base behind the one that starts at a mismatch: extended to the left by the read's base there?
                     const code_t key = (code_t)ending_at(at_e) & omask;
                     const uint32_t byte = !a.ix.dtab_grouped ? a.ix.dtab[key]
                                                              : a.ix.dtab[NP == 16 ? dtab_grouped_addr32((uint32_t)key, e_i % 3u, order) : dtab_grouped_addr((uint64_t)key, e_i % 3u, order)];
-                    if ((byte & 0x80u) && ((byte >> base_at(at_e - order)) & 1u)) spw[p_owner * 16u + 13u] = 1;
-                } else {
+                    if ((byte & 0x80u) && ((byte >> base_at(at_e - order)) & 1u)) { // (the window in question: the one in front of it)
+                        around = true;
+                        w_e = e_i - 1u;
+                        w_at = at_e - 1u;
+                    }
+                } else if (gap == 0x7FFFu) around = true;
+                else {
                     const uint32_t V = dtab_anchor_depth(a.ix, e_i + 1u, [&](uint32_t tt) -> uint32_t {
                         return (0x54474341u >> (8u * base_at(at_e - tt))) & 0xFFu;
                     });
-                    if (V == kDtabUnknown || V + gap - 1u > thr) spw[p_owner * 16u + 13u] = 1;
+                    if (V == kDtabUnknown || V + gap - 1u > thr) around = true;
+                }
+                if (around && (a.rounds & 32u)) { // (experiment: as before the rule below)
+                    spw[p_owner * 16u + 13u] = 1;
+                    around = false;
+                }
+            }
+            // ... and what neither settles, by the windows AROUND it.  The strings of thr + 1 bases that hold the window ending at e end at
+            // e .. e + c, c = thr + 1 - order (all of them through the break the window was looked up for), inside the read from
+            // thr on.  A window ending at e + i that is absent - or whose string with the read's base in front of it is: its entry's
+            // left-extension bit - rules out those ending at e + i or later; one ending at e - j those ending at e - j + c or before (a
+            // base fewer when only its extended string is absent; j = 0: the window's own bit).  Two or three more look-ups, most of
+            // them in the line the window's own entry came from, for one window in some hundred; without it the read took the plain
+            // walk: every seventh read of another genome, every twentieth with 5 % substitutions.  Brute-force check of the rule:
+            // tests/test_proof_rule_model.py
+            const uint32_t w_len = __shfl(len, (int)w_owner);
+            if (__ballot(around)) {
+                if (around) {
+                    const uint32_t soff_ = w_at - w_e, e = w_e;
+                    auto tab_at = [&](uint32_t w_) -> uint32_t {
+                        const code_t key = (code_t)ending_at(soff_ + w_) & omask;
+                        st_look++;
+                        return !a.ix.dtab_grouped ? a.ix.dtab[key]
+                                                  : a.ix.dtab[NP == 16 ? dtab_grouped_addr32((uint32_t)key, w_ % 3u, order) : dtab_grouped_addr((uint64_t)key, w_ % 3u, order)];
+                    };
+                    auto ext_of = [&](uint32_t byte_, uint32_t w_) -> bool { return ((byte_ >> base_at(soff_ + w_ - order)) & 1u) != 0; }; // (w_ >= order)
+                    const uint32_t c = thr + 1u - order;
+                    const uint32_t e_lo = max(e, thr), e_hi = min(e + c, w_len - 1u);
+                    bool ok = e_lo > e_hi;
+                    if (!ok) {
+                        uint32_t R = 0xFFFFFFFFu; // strings ending at R or later are ruled out
+                        for (uint32_t i2 = 1; i2 <= c + 1u; i2++) {
+                            const uint32_t w_ = e + i2;
+                            if (w_ > e_hi) {
+                                R = e_hi + 1u;
+                                break;
+                            }
+                            const uint32_t b_ = tab_at(w_);
+                            if (!(b_ & 0x80u) || !ext_of(b_, w_)) {
+                                R = w_;
+                                break;
+                            }
+                        }
+                        if (R != 0xFFFFFFFFu) {
+                            if (R - 1u < e_lo) ok = true;
+                            else if (e >= order && !ext_of(tab_at(e), e) && e + c >= R) ok = true;
+                            else
+                                for (uint32_t j = 1; j <= c; j++) {
+                                    if (e < j + order - 1u) break; // (no such window inside the read)
+                                    const uint32_t w_ = e - j;
+                                    if (w_ + c + 1u < R) break;
+                                    const uint32_t b_ = tab_at(w_);
+                                    if (!(b_ & 0x80u) || (w_ >= order && !ext_of(b_, w_) && w_ + c >= R)) {
+                                        ok = true;
+                                        break;
+                                    }
+                                }
+                        }
+                    }
+                    if (!ok) spw[w_owner * 16u + 13u] = 1;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1102,7 +1195,7 @@ hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
     // (packed: every read starts a word of the digit string and, with the characters packed as well, of the byte region)
     const uint32_t stage_bytes = io ? (64u * 16u * ((a.max_item_len + 15u) / 16u) + 32u + kMapSlack) : (64u * a.max_item_len + 16u + kMapSlack + 15u) / 16u * 16u;
     const uint32_t lin_words = stage_bytes / 16u + 4u;
-    const uint32_t lds_wave = (stage_bytes + 4u * (lin_words + 4u) + 1024u + 528u + 15u) & ~15u;
+    const uint32_t lds_wave = (stage_bytes + 4u * (lin_words + 4u) + 1024u + kMapPendBytes + 15u) & ~15u;
     static const int env_wpb = std::getenv("KBO_MAP_WPB") ? std::atoi(std::getenv("KBO_MAP_WPB")) : 1; // experiments: waves per workgroup
     const uint32_t wpb = (uint32_t)std::min(4, std::max(1, env_wpb));
     const uint32_t n_waves = (a.n_items + 63u) / 64u;
