@@ -639,6 +639,9 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
         }
     }
 
+    // (DIRECT) a window that is in the index and is left to the windows around it: asked for in stage 3, judged at the kernel's end
+    bool w_around = false;
+    uint32_t w_e = 0, w_owner = 0, w_at = 0, w_len = 0, w_pre[6] = {0, 0, 0, 0, 0, 0};
     // ---- 3. the stretches behind the mismatches from the depth table (rule: dtab_kernels.hip), dealt out to the lanes
     uint32_t st_look = 0, st_written = 0, st_anch = 0, st_filt = 0; // (direct form: st_written = windows the filter settled)
     {
@@ -875,7 +878,6 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
             // this depth says: with the next window (or the read's end) g bases on, none is longer than depth + g - 1
             const uint32_t n_pend = min(*pend_n, kMapPend);
             bool around = false; // this lane's window is left to the windows around it
-            uint32_t w_e = 0, w_owner = 0, w_at = 0;
             if (lane < n_pend) {
                 const uint2 pe = pend[lane];
                 const uint32_t p_owner = pe.y & 0xFFu, e_i = (pe.y >> 8) & 0xFFu, gap = (pe.y >> 16) & 0x7FFFu, at_e = pe.x;
@@ -903,59 +905,26 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                     around = false;
                 }
             }
-            // ... and what neither settles, by the windows AROUND it.  The strings of thr + 1 bases that hold the window ending at e end at
-            // e .. e + c, c = thr + 1 - order (all of them through the break the window was looked up for), inside the read from
-            // thr on.  A window ending at e + i that is absent - or whose string with the read's base in front of it is: its entry's
-            // left-extension bit - rules out those ending at e + i or later; one ending at e - j those ending at e - j + c or before (a
-            // base fewer when only its extended string is absent; j = 0: the window's own bit).  Two or three more look-ups, most of
-            // them in the line the window's own entry came from, for one window in some hundred; without it the read took the plain
-            // walk: every seventh read of another genome, every twentieth with 5 % substitutions.  Brute-force check of the rule:
-            // tests/test_proof_rule_model.py
-            const uint32_t w_len = __shfl(len, (int)w_owner);
+            // ... and what neither settles, by the windows AROUND it (rule: at the kernel's end, where it is evaluated).  Here only the
+            // entries of e - 2 .. e + 3 are asked for - nearly always all it takes -, so that no wave waits for them: the characters are
+            // made in the meantime, and a read that turns out flagged after all has them rewritten by the second pass like any other
+            w_len = __shfl(len, (int)w_owner);
+            w_around = around;
             if (__ballot(around)) {
                 if (around) {
-                    const uint32_t soff_ = w_at - w_e, e = w_e;
-                    auto tab_at = [&](uint32_t w_) -> uint32_t {
-                        const code_t key = (code_t)ending_at(soff_ + w_) & omask;
-                        st_look++;
-                        return !a.ix.dtab_grouped ? a.ix.dtab[key]
-                                                  : a.ix.dtab[NP == 16 ? dtab_grouped_addr32((uint32_t)key, w_ % 3u, order) : dtab_grouped_addr((uint64_t)key, w_ % 3u, order)];
-                    };
-                    auto ext_of = [&](uint32_t byte_, uint32_t w_) -> bool { return ((byte_ >> base_at(soff_ + w_ - order)) & 1u) != 0; }; // (w_ >= order)
-                    const uint32_t c = thr + 1u - order;
-                    const uint32_t e_lo = max(e, thr), e_hi = min(e + c, w_len - 1u);
-                    bool ok = e_lo > e_hi;
-                    if (!ok) {
-                        uint32_t R = 0xFFFFFFFFu; // strings ending at R or later are ruled out
-                        for (uint32_t i2 = 1; i2 <= c + 1u; i2++) {
-                            const uint32_t w_ = e + i2;
-                            if (w_ > e_hi) {
-                                R = e_hi + 1u;
-                                break;
-                            }
-                            const uint32_t b_ = tab_at(w_);
-                            if (!(b_ & 0x80u) || !ext_of(b_, w_)) {
-                                R = w_;
-                                break;
-                            }
-                        }
-                        if (R != 0xFFFFFFFFu) {
-                            if (R - 1u < e_lo) ok = true;
-                            else if (e >= order && !ext_of(tab_at(e), e) && e + c >= R) ok = true;
-                            else
-                                for (uint32_t j = 1; j <= c; j++) {
-                                    if (e < j + order - 1u) break; // (no such window inside the read)
-                                    const uint32_t w_ = e - j;
-                                    if (w_ + c + 1u < R) break;
-                                    const uint32_t b_ = tab_at(w_);
-                                    if (!(b_ & 0x80u) || (w_ >= order && !ext_of(b_, w_) && w_ + c >= R)) {
-                                        ok = true;
-                                        break;
-                                    }
-                                }
+                    const uint32_t soff_ = w_at - w_e;
+                    const uint32_t e_lo = max(w_e, thr), e_hi = min(w_e + thr + 1u - order, w_len - 1u);
+#pragma unroll
+                    for (uint32_t q = 0; q < 6u; q++) {
+                        const uint32_t w_ = w_e + q - 2u; // (e >= order - 1 >= 2)
+                        w_pre[q] = 0;
+                        if (e_lo <= e_hi && w_ + 1u >= order && w_ < w_len) {
+                            const code_t key = (code_t)ending_at(soff_ + w_) & omask;
+                            st_look++;
+                            w_pre[q] = !a.ix.dtab_grouped ? a.ix.dtab[key]
+                                                          : a.ix.dtab[NP == 16 ? dtab_grouped_addr32((uint32_t)key, w_ % 3u, order) : dtab_grouped_addr((uint64_t)key, w_ % 3u, order)];
                         }
                     }
-                    if (!ok) spw[w_owner * 16u + 13u] = 1;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1125,6 +1094,63 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
         const uint32_t g0 = base16 + c;
         if (g0 >= lo && g0 + 16u <= wave_hi) __builtin_memcpy(a.chars_out + g0, &v, 16);
         else st_range16(a.chars_out + g0, v, lo > g0 ? min(lo - g0, 16u) : 0u, min(wave_hi - g0, 16u));
+    }
+    // ---- the windows that were left to the windows around them (stage 3).  The strings of thr + 1 bases that hold the window ending at
+    // e end at e .. e + c, c = thr + 1 - order (all of them through the break the window was looked up for), inside the read from thr
+    // on.  A window ending at e + i that is absent - or whose string with the read's base in front of it is: its entry's
+    // left-extension bit - rules out those ending at e + i or later; one ending at e - j those ending at e - j + c or before (a base
+    // fewer when only its extended string is absent; j = 0: the window's own bit).  Without it the read took the plain walk: every
+    // seventh read of another genome, every twentieth with 5 % substitutions.  Brute-force check of the rule:
+    // tests/test_proof_rule_model.py
+    if (DIRECT && __ballot(w_around)) {
+        const uint32_t order = a.ix.dtab_order, thr = a.map_thr;
+        if (w_around) {
+            const uint32_t soff_ = w_at - w_e, e = w_e;
+            auto ext_of = [&](uint32_t byte_, uint32_t w_) -> bool { return ((byte_ >> base_at(soff_ + w_ - order)) & 1u) != 0; }; // (w_ >= order)
+            auto entry = [&](uint32_t w_) -> uint32_t {
+                const uint32_t q = w_ + 2u - e; // (unsigned: far to the left wraps to a large value)
+                // (further out: "present, and extended by every base" - no more trips to the table, each of which the whole wave would wait
+                // for.  A window that the six entries do not settle mostly stands in a true repeat, where nine more would not either)
+                return q == 0u ? w_pre[0] : q == 1u ? w_pre[1] : q == 2u ? w_pre[2] : q == 3u ? w_pre[3] : q == 4u ? w_pre[4] : q == 5u ? w_pre[5] : 0xFFu;
+            };
+            const uint32_t c = thr + 1u - order;
+            const uint32_t e_lo = max(e, thr), e_hi = min(e + c, w_len - 1u);
+            bool ok = e_lo > e_hi;
+            if (!ok) {
+                uint32_t R = 0xFFFFFFFFu; // strings ending at R or later are ruled out
+                for (uint32_t i2 = 1; i2 <= c + 1u; i2++) {
+                    const uint32_t w_ = e + i2;
+                    if (w_ > e_hi) {
+                        R = e_hi + 1u;
+                        break;
+                    }
+                    const uint32_t b_ = entry(w_);
+                    if (!(b_ & 0x80u) || !ext_of(b_, w_)) {
+                        R = w_;
+                        break;
+                    }
+                }
+                if (R != 0xFFFFFFFFu) {
+                    if (R - 1u < e_lo) ok = true;
+                    else if (e >= order && !ext_of(entry(e), e) && e + c >= R) ok = true;
+                    else
+                        for (uint32_t j = 1; j <= c; j++) {
+                            if (e < j + order - 1u) break; // (no such window inside the read)
+                            const uint32_t w_ = e - j;
+                            if (w_ + c + 1u < R) break;
+                            const uint32_t b_ = entry(w_);
+                            if (!(b_ & 0x80u) || (w_ >= order && !ext_of(b_, w_) && w_ + c >= R)) {
+                                ok = true;
+                                break;
+                            }
+                        }
+                }
+            }
+            if (!ok) spw[w_owner * 16u + 13u] = 1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        flag = flag || sp[13] != 0;
     }
     plan_stats_add(a.pstats, kPlanStatSeedLookups, st_lookups, kPlanStatSeedExtensions, st_filt /* (this kernel: filter look-ups) */, kPlanStatMismatches, seeded ? cnt : 0u, 0, 0);
     plan_stats_add(a.pstats, kPlanStatTabLookups, st_look, kPlanStatTabWritten, st_written, kPlanStatTabFlagged, flag ? 1u : 0u,
