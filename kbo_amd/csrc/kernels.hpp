@@ -159,6 +159,8 @@ struct WalkArgs {
                              // kernel finishes itself, or nullptr: format::run_lengths_gapped then needs no counting pass of its own)
     const uint64_t *seq_off; // (reads: the batch's offsets instead of the item list - item s is sequence s, whole: the list is then
                              // only made for the second pass)
+    uint32_t uniform_len;    // (... and when every sequence has max_item_len bases - n_items * max_item_len == q_bytes says so without
+                             // looking at an offset - read s starts at seq_off[0] + s * uniform_len: one dependent load less per wave)
     const uint32_t *qp;
     uint32_t qp_wps;
     const uint32_t *qp_data, *qp_sums;

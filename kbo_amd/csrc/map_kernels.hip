@@ -176,7 +176,10 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
     const uint8_t *qb = a.q;
     uint32_t start = 0, len = 0, warm = 0, tail = 0;
     const bool have_item = idx < a.n_items;
-    if (have_item && a.seq_off) { // (8 bytes per read instead of a 16-byte record somebody had to write first)
+    if (have_item && a.seq_off && a.uniform_len) { // (reads of one length: no offset but the batch's first is looked at)
+        start = (uint32_t)a.seq_off[0] + idx * a.uniform_len;
+        len = a.uniform_len;
+    } else if (have_item && a.seq_off) { // (8 bytes per read instead of a 16-byte record somebody had to write first)
         const uint64_t o0 = a.seq_off[idx], o1 = a.seq_off[idx + 1u];
         start = (uint32_t)o0; // launches cover < 4 GiB of query
         len = (uint32_t)(o1 - o0);
@@ -1216,6 +1219,8 @@ hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
     hipError_t e = hipMemsetAsync(a.qctl, 0, 64 + kPlanStatSlots * kPlanStatWords * 4, stream);
     if (e != hipSuccess) return e;
     const bool direct = map_reads_direct(a);
+    static const bool env_nouni = std::getenv("KBO_MAP_NO_UNIFORM") != nullptr; // experiments
+    a.uniform_len = (a.seq_off && !env_nouni && a.max_item_len != 0 && (uint64_t)a.n_items * a.max_item_len == a.q_bytes) ? a.max_item_len : 0u;
     const int io = a.qp ? (a.packed_out ? 2 : 1) : 0;
     if (io != 0 && (!direct || (io == 2 && a.map_fmt))) return hipErrorInvalidValue; // (callers ask map_reads_packed_applies first)
     // (packed: every read starts a word of the digit string and, with the characters packed as well, of the byte region)
