@@ -430,6 +430,9 @@ def main(argv=None):
                                       else f"{args.reads} x {args.read_len} bp reads per GPU, ")
                                    + f"{args.sub_rate * 100:g}% substitutions",
                        "index_n_sets": sbwt.n_sets(), "threshold": dev.threshold,
+                       "timed_output": ("format::run_lengths_gapped records + the characters" if args.find else "kbo::map's characters, one byte a base") +
+                                       "; the matching statistics of every read are compared with the oracle's behind the timed region, and the entry "
+                                       "points that RETURN them are timed in ms_variant",
                        "walk": ("kbo_map_batch_dev: one kernel per batch of reads (path cover as 2-bit text, seed positions, depth table of %d bases)" % sbwt.depth_table_order()
                                 if one_kernel else "plan-guided (path cover + depth table of %d bases)" % sbwt.depth_table_order() if table else
                                 "plan-guided (path cover + guided walk)" if planned else "plain"),

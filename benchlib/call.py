@@ -115,7 +115,11 @@ def main_call(args):
                     "kernel": "the call mode of the walk (plan_kernel + guided walk over recovery lines, or ms_walk_kernel<CALL>): MS values + breakpoint scan",
                     "kernel_ms": round(walk_ms, 4), "counted_on": f"{n_s} of the timed reads by the oracle (SURVEY.md 8(d))",
                     "note": "no depth table at this index size (17 bases would be present by chance): the walk is the round-3 route; "
-                            "the one kernel for sequences of any length (long_kernels.hip) needs a table"}
+                            "the one kernel for sequences of any length (long_kernels.hip) needs a table",
+                    "frac_meaning": "SURVEY.md 8(d)'s bytes of the REFERENCE algorithm (64 B per rank block an extension of its walk touches, counted by the "
+                                    "oracle) over the walk's duration and the HBM peak: the plan-guided walk skips most of those extensions (bases on a "
+                                    "diagonal cost a comparison with the text), so this is how fast the reference's work is disposed of, not the share of "
+                                    "the HBM bandwidth the kernels use - that takes the PMC passes (`traffic`), not taken at this size"}
         # ---- CPU baseline: the oracle's literal kbo::call (per-sequence index build + both passes) on a bounded sample, one thread a read
         n_c = min(args.reads, 64)
         t1 = time.perf_counter()

@@ -91,13 +91,14 @@ def parse(argv=None):
 
 
 def build_sha16():
-    """A fingerprint of what a profile was taken of: bench.py and every source of the HIP extension.  tools/profile_bench.sh stores
+    """A fingerprint of what a profile was taken of: bench.py with its parts (benchlib/) and every source of the HIP extension.  tools/profile_bench.sh stores
     it next to the counters it collects; a line printed by a different build quotes no traffic figure (a committed
     profile must not decorate the line of a later build)."""
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in [os.path.join(ROOT, "bench.py")] + sorted(glob.glob(os.path.join(ROOT, "kbo_amd", "csrc", "*.h*")) +
+    for f in [os.path.join(ROOT, "bench.py")] + sorted(glob.glob(os.path.join(ROOT, "benchlib", "*.py"))) + \
+            sorted(glob.glob(os.path.join(ROOT, "kbo_amd", "csrc", "*.h*")) +
                                                        glob.glob(os.path.join(ROOT, "kbo_amd", "csrc", "*.cpp"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
