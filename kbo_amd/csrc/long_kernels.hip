@@ -50,6 +50,13 @@ namespace {
 
 constexpr uint32_t kLongTextUnits = 76; // staged units of 16 text positions: 64 in front of the region's diagonal, 1024, 128 behind
 constexpr uint32_t kLongListCap = 384;  // look-ups a piece may ask for (more: flagged)
+// experiments (KBO_LONG_X: phases left out, cycle stamps): compiled in only with -DKBO_LONG_EXPERIMENTS - their state lives across the
+// whole piece loop in a kernel that spills scalar registers as it is
+#ifdef KBO_LONG_EXPERIMENTS
+constexpr bool kLongExp = true;
+#else
+constexpr bool kLongExp = false;
+#endif
 constexpr uint32_t kLongTH = 6;         // mismatches in 16 bases that end a diagonal
 constexpr uint32_t kLongRun = 10;       // matching bases that start one
 constexpr uint32_t kLongLds = 2048;     // bytes of LDS per wave
@@ -207,6 +214,8 @@ __device__ __forceinline__ uint64_t ero_at(const EroChain &c, uint32_t L)
 // One wave takes a.ppw consecutive pieces, one after the other: the next piece's bases are on their way while this one is
 // worked on, and a piece that continues the sequence of the one before starts on that one's last diagonal - its text is
 // on its way too - instead of asking the seed table (a wrong guess is lost at once and found again like any lost diagonal).
+// STATS: the kernel counts its own work (kbo_set_plan_stats) - instrumentation, compiled out of the default instantiation
+template <bool STATS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WPE))) void map_long_kernel(LongArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t long_lds_all[];
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
     int32_t pred_dl = 0, pred_u0 = 0;
     uint2 tn0 = make_uint2(0, 0), tn1 = make_uint2(0, 0);
 
-    const bool stamps = (a.xexp & 128u) != 0; // (experiments: shader cycles per phase, summed into qctl[16 ..] in units of 16)
+    const bool stamps = kLongExp && (a.xexp & 128u) != 0; // (experiments: shader cycles per phase, summed into qctl[16 ..] in units of 16)
     uint32_t cyc[5] = {0, 0, 0, 0, 0};
     auto stamp = [&](uint32_t slot, uint64_t &t_last) {
         if (!stamps) return;
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
         invl[lane] = (uint16_t)inv16;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (a.xexp & 16u) {
+        if (kLongExp && (a.xexp & 16u)) {
             pred = false;
             pred_in_lds = false;
             finish_round();
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
             uint32_t tp = 0xFFFFFFFFu;
             if (ok) {
                 tp = seed_at(e_);
-                st_seed++;
+                if (STATS) st_seed++;
             }
             const uint64_t hit_any = __ballot(tp != 0xFFFFFFFFu), hit_one = __ballot(tp != 0xFFFFFFFFu && !(tp >> 31));
             if (!hit_any) return false;
@@ -509,7 +518,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                 // every lane takes part in).  A word that matches none (a junction inside it, a cluster of substitutions) is cut
                 // between its neighbours' diagonals where the two together mismatch least.  Any word left without a diagonal: the
                 // band was not it (a long insertion, a join) - the planes are dropped and the loop goes on as before.
-                if (!band_tried && !(a.xexp & 8u)) {
+                if (!band_tried && !(kLongExp && (a.xexp & 8u))) {
                     band_tried = true;
                     constexpr int kBand = 6;
                     const uint32_t idx0 = (uint32_t)(dl - kBand + xa - tbase), unit = idx0 >> 4, r0b = idx0 & 15u;
@@ -651,12 +660,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                             const uint32_t last_l = 63u - (uint32_t)__builtin_clzll(inl);
                             end_on_diag = true;
                             end_dl = dl - kBand + (int32_t)__shfl(sR, (int)last_l);
-                            st_band += 0x10001u;
+                            if (STATS) st_band += 0x10001u;
                             band_took = true;
                             break;
                         }
                     }
-                    st_band += 1u; // (tried, not taken)
+                    if (STATS) st_band += 1u; // (tried, not taken)
                 }
                 // the next diagonal: of the 64 beside this one, the one on which the read goes on soonest - the first run of kLongRun
                 // matching bases among the 32 behind f (ties: the longer run, then the nearer diagonal)
@@ -722,7 +731,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
             tn0 = (u_a >= 0 && u_a < n_units) ? a.ix.pc_tm[u_a] : make_uint2(0u, 0x55555555u);
             tn1 = (lane < kLongTextUnits - 64u && u_b >= 0 && u_b < n_units) ? a.ix.pc_tm[u_b] : make_uint2(0u, 0x55555555u);
         }
-        if (a.xexp & 32u) {
+        if (kLongExp && (a.xexp & 32u)) {
             finish_round();
             pred_in_lds = tx_next;
             continue;
@@ -772,7 +781,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
         // ---- 3. the proof
         bool flag = false;
         uint32_t why = 0; // (counted with the work counters: what sent the piece to the second pass)
-        if (!(a.xexp & 1u) && __ballot(U != 0u)) {
+        if (!(kLongExp && (a.xexp & 1u)) && __ballot(U != 0u)) {
             // the points of every run of U: its first position and every cstep-th from there while the run's start is known (Mrun
             // positions back), every cstep-th position of the grid beyond
             const uint64_t HU = hist64(U);
@@ -811,7 +820,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
             __builtin_amdgcn_wave_barrier(); // (the list goes where the text was)
             if (total > kLongListCap) {
                 flag = true;
-                why = 1u;
+                if (STATS) why = 1u;
             }
             else {
                 uint32_t at = incl - mine;
@@ -833,7 +842,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
             const uint64_t omask = (1ull << (2u * order)) - 1ull;
             auto table = [&](uint32_t e_, uint32_t g) -> uint32_t { // the entry of the window ending at e_ (g: its place in the grouped line)
                 const uint64_t key = ending_at(e_) & omask;
-                st_look++;
+                if (STATS) st_look++;
                 return a.ix.dtab_grouped ? a.ix.dtab[dtab_grouped_addr(key, g, order)] : a.ix.dtab[key];
             };
             // the window ending at e_ is in the index AND the read's base in front of it extends it
@@ -848,7 +857,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                 const bool is_ext = (ent & 0x400u) != 0, is_last = (ent & 0x800u) != 0;
                 // (a window with a byte that is no base is in no index; the string an ext look-up asks about holds the base in front)
                 if (act && (inv_span(x, order) || (is_ext && inv_span(x - order, 1u)))) act = false;
-                if (F && !(a.xexp & 2u)) { // the filter: a string of F bases of the window that lies in no single stretch - absent: so is the window
+                if (F && !(kLongExp && (a.xexp & 2u))) { // the filter: a string of F bases of the window that lies in no single stretch - absent: so is the window
                     bool fl = false;
                     uint32_t ef = 0;
                     if (act && is_ext) {
@@ -868,12 +877,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                     }
                     if (fl) {
                         const uint32_t fk = (uint32_t)ending_at(ef) & ((1u << (2u * F)) - 1u);
-                        st_filt++;
+                        if (STATS) st_filt++;
                         if (!((a.ix.dfilt[fk >> 5] >> (fk & 31u)) & 1u)) act = false; // absent
                     }
                 }
                 uint32_t byte = 0;
-                if (act && !(a.xexp & 4u)) byte = table(x, 1u);
+                if (act && !(kLongExp && (a.xexp & 4u))) byte = table(x, 1u);
                 bool fail = false;
                 bool need_back = false, need_on = false;
                 if (act && is_ext) fail = present_ext(byte, x);
@@ -891,7 +900,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                     if (need_back) {
                         auto both = [&](uint32_t e_, uint32_t g) -> bool {
                             if (e_ < r0 + order || e_ >= xe || inv_span(e_, order)) return false;
-                            st_second++;
+                            if (STATS) st_second++;
                             return present_ext(table(e_, g), e_);
                         };
                         uint32_t j = 1;
@@ -906,13 +915,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                 }
                 if (__ballot(need_on)) { // the run's last window is present: the one inside the next stretch must not be extended by the base in front
                     if (need_on && !fail) {
-                        st_second++;
+                        if (STATS) st_second++;
                         if (!inv_span(x + 1u, order + 1u)) fail = present_ext(table(x + 1u, 2u), x + 1u);
                     }
                 }
                 if (__ballot(fail)) {
                     flag = true;
-                    why = __ballot(fail && is_ext) ? 2u : __ballot(fail && need_back) ? 3u : 4u;
+                    if (STATS) why = __ballot(fail && is_ext) ? 2u : __ballot(fail && need_back) ? 3u : 4u;
                 }
             }
         }
@@ -994,7 +1003,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                 const bool fl = flag || (a.xexp & 64u) != 0; // (64: every piece to the second pass - tests)
                 a.redo[piece] = fl ? 1 : 0;
                 if (fl) atomicAdd(a.qctl + 4, 1u);
-                if (fl && a.pstats) atomicAdd(a.qctl + 8u + why + (band_took ? 4u : 0u), 1u);
+                if (STATS && fl && a.pstats) atomicAdd(a.qctl + 8u + why + (band_took ? 4u : 0u), 1u);
             }
         }
         stamp(4, t_last); // output
@@ -1003,7 +1012,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
         for (uint32_t i = 0; i < 5u; i++) atomicAdd(a.qctl + 16u + i, cyc[i] >> 4);
     // the wave's work counters, when the launch counts (kbo_set_plan_stats): every wave adding to a handful of words was a third of
     // the kernel's time - atomics on one address take about 10 ns each, whoever sends them
-    if (!a.pstats) return;
+    if (!STATS || !a.pstats) return;
     // (two sums instead of four: seed and second look-ups stay below 2^16 per wave, filter and table look-ups as well)
     const uint32_t s0 = wave_sum(st_seed | (st_second << 16)), s1 = wave_sum(st_filt | (st_look << 16));
     if (lane == 0) {
@@ -1382,7 +1391,8 @@ hipError_t launch_map_long(const DevIndexView &ix, const uint8_t *d_q, const uin
     static const int env_wpb = std::getenv("KBO_LONG_WPB") ? std::atoi(std::getenv("KBO_LONG_WPB")) : 4; // experiments: waves per workgroup
     const uint32_t wpb = (uint32_t)std::min(4, std::max(1, env_wpb));
     const uint32_t n_waves = (L.n_slots + a.ppw - 1u) / a.ppw;
-    hipLaunchKernelGGL(map_long_kernel, dim3((n_waves + wpb - 1u) / wpb), dim3(64u * wpb), kLongLds * wpb, stream, a);
+    if (a.pstats) hipLaunchKernelGGL(map_long_kernel<true>, dim3((n_waves + wpb - 1u) / wpb), dim3(64u * wpb), kLongLds * wpb, stream, a);
+    else hipLaunchKernelGGL(map_long_kernel<false>, dim3((n_waves + wpb - 1u) / wpb), dim3(64u * wpb), kLongLds * wpb, stream, a);
     return hipGetLastError();
 }
 

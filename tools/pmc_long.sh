@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box: PMC counters per kernel (separate passes, --kernel-trace only) of tools/exp_long.py.
 # Usage: tools/pmc_long.sh <tag> [exp_long.py arguments]
+# (KBO_LONG_X - phases of map_long_kernel left out - needs a library built with -DKBO_LONG_EXPERIMENTS: `make -C kbo_amd/csrc CXXFLAGS="-O3 -std=c++17 -fPIC -DKBO_LONG_EXPERIMENTS"` after touching long_kernels.hip)
 TAG=${1:-x}; shift || true
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$ROOT/gpurun_out/pmc_long_$TAG"
