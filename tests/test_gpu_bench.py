@@ -111,6 +111,18 @@ def test_bench_call_line(tmp_path):
     assert w["entry_point"] == "kbo_call_batch" and w["variants"] > 600 and w["us_per_read"] > 0 and w["equal_to_oracle_call_on_sampled_reads"] == 40
 
 
+def test_bench_c5_line_at_reduced_size(tmp_path):
+    """--config C5 with a small genome: the line's shape - roofline of the first pass by the oracle's counts, cpu_baseline = oracle.call on a
+    sample - and its checks: the sites of EVERY read (300 of 10 kbp, k = 63) against the oracle's first pass, 40 reads of kbo_call_batch
+    against the oracle's literal kbo::call"""
+    r = _run(["--config", "C5", "--genome", "3000000", "--reads", "300", "--steps", "2"], tmp_path)
+    assert r["bit_exact_vs_oracle"] is True and r["value"] > 0 and "k=63" in r["metric"] and "kbo call" in r["metric"]
+    ro, cb = r["roofline"], r["cpu_baseline"]
+    assert ro["bound"] == "hbm" and 0 < ro["frac"] and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3 and ro["units_per_launch"] == 300 * 10000
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "oracle" in cb["sample"]
+    assert r["whole_call"]["equal_to_oracle_call_on_sampled_reads"] == 40 and r["config"]["sites_per_step"] > 300
+
+
 def test_bench_c5_at_its_real_size(tmp_path):
     """bench.py --config C5 as it is: the 3 Gbp index, k = 63, 125 000 reads of 10 kbp - every site of the first pass against the oracle's,
     40 sampled reads of kbo_call_batch against the oracle's literal kbo::call (>= 200 reads' sites are compared many times over: all
