@@ -260,7 +260,8 @@ def ms_leg(args, sbwt, oi, concat, offsets, torch, device, stream, pipes):
     exp_map = np.frombuffer(ora.relative_to_ref(concat, exp_chars), dtype=np.uint8)
     total = int(offsets[-1])
     out = {}
-    # kbo_ms_batch_dev: the walk alone (plan + depth table + second pass inside it), MS bytes out
+    # kbo_ms_batch_dev: MS bytes out and nothing else - for reads over a copy with a depth table map_reads_kernel's MS-emitting form stopped
+    # behind the values + the plain walk of the reads it leaves (one stream: the entry point has no tail stream)
     dev = batch.DeviceBatch(sbwt, concat, offsets, device=device, format=True, want_ms=True)
     for _ in range(4):
         dev.walk(stream)
@@ -274,7 +275,23 @@ def ms_leg(args, sbwt, oi, concat, offsets, torch, device, stream, pipes):
     ms = e0.elapsed_time(e1) / 12
     out["kbo_ms_batch_dev"] = {"value": round(total / ms / 1e3, 1), "unit": "Mbp/s", "step_ms": round(ms, 4), "bytes_out_per_base": 1,
                                "bit_exact_vs_oracle": bool(np.array_equal(dev.ms[:total].cpu().numpy(), exp_d))}
-    del dev
+    # ... and the caller's way to keep the device full with it: resident batches in turn on two streams of its own (a call is
+    # asynchronous on its stream; its second pass then runs beside the other stream's kernel)
+    devs = [dev] + [batch.DeviceBatch(sbwt, concat, offsets, device=device, format=True, want_ms=True) for _ in range(3)]
+    streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)]
+
+    def go(n):
+        for i in range(n):
+            devs[i % 4].walk(streams[i % 2])
+    go(8)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    go(40)
+    torch.cuda.synchronize(device)
+    el = time.perf_counter() - t0
+    out["kbo_ms_batch_dev"]["two_streams"] = {"value": round(total * 40 / el / 1e6, 1), "unit": "Mbp/s", "steps": 40, "step_ms": round(el / 40 * 1e3, 4),
+                                              "batches_in_flight": 4, "bit_exact_vs_oracle": all(bool(np.array_equal(d.ms[:total].cpu().numpy(), exp_d)) for d in devs)}
+    del dev, devs
     # kbo_map_batch_dev(want_ms): the one kernel in its MS-emitting form, MS bytes + formatted characters out
     devs = [batch.DeviceBatch(sbwt, concat, offsets, device=device, format=True, want_ms=True) for _ in range(2 * pipes if pipes else 1)]
     elapsed, _, _, _ = run_batch(devs, stream, False, 40, 8, torch, device, False, pipes)

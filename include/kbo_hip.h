@@ -348,7 +348,12 @@ size_t kbo_index_work_bytes(const kbo_index_t *idx, size_t n_seqs, uint64_t tota
  * device from the offsets: sequences are cut into chunks that restart the walk k-1 bases upstream
  * (the MS of a base depends only on the k bases ending at it), so a few long sequences still fill the
  * device.  Same results either way - provided max_seq_len, when given, is not SMALLER than the longest sequence: the
- * kernels size their work items (16-bit lengths) and LDS stretches from it; pass 0 when in doubt. */
+ * kernels size their work items (16-bit lengths) and LDS stretches from it; pass 0 when in doubt.
+ * Reads (max_seq_len <= 160) over a copy with a depth table, intervals not asked for: ONE kernel puts the values together (k where
+ * nothing happened, the ramps behind the mismatches, the table's values behind them) and the plain walk finishes the reads it leaves -
+ * 320 Gbp/s at C2, 386 with resident batches in turn on two streams of the caller's (the plan-guided walk it replaces there: 242);
+ * every other batch - chunks of long sequences, intervals (d_lo_out / d_hi_out: the colexicographic intervals, index.rs:243-256),
+ * sharded indexes - takes the plan-guided walk. */
 int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets,
                      size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint8_t *d_ms_out,
                      uint32_t *d_lo_out, uint32_t *d_hi_out, void *d_work, size_t work_bytes, void *stream);

@@ -133,6 +133,10 @@ int kbo_plan_flags_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, 
  * take the walk + the derandomize / translate kernels), 1 = wherever the index copy has what it needs (default), 2 = as 1 with
  * EVERY piece sent to its second pass (plain walk + literal recurrences) - a test hook, exact like the others. */
 int kbo_set_map_long(int mode);
+/* kbo_ms_batch_dev over a batch of reads (<= 160 bases, no intervals) and a copy with a depth table: 1 (default) = map_reads_kernel in its
+ * MS-emitting form, stopped behind the values; 0 = the plan-guided walk as for every other batch (also taken while kbo_set_plan_stats is
+ * on: the work counters are that walk's). */
+int kbo_set_ms_one_kernel(int on);
 /* inspection: what the last kbo_map_batch_dev / kbo_find_batch_dev call over sequences of more than 160 bases did when it took
  * the one kernel for sequences of any length (long_kernels.hip); arguments as for that call, synchronises `stream`.
  * out[0]: pieces, [1]: pieces whose proof failed (plain walk + literal recurrences), [2]: their sub-items; with kbo_set_plan_stats(1) [3]: seed look-ups,

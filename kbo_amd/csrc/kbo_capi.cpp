@@ -1067,6 +1067,7 @@ size_t kbo_index_work_bytes(const kbo_index_t *idx, size_t n_seqs, uint64_t tota
 }
 
 namespace {
+std::atomic<bool> g_ms_one_kernel{true}; // kbo_ms_batch_dev: batches of reads through map_reads_kernel's MS-emitting form (kbo_set_ms_one_kernel)
 int ms_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs,
                       uint64_t total_bases, size_t max_seq_len, uint8_t *d_ms_out, uint32_t *d_lo_out,
                       uint32_t *d_hi_out, void *d_work, size_t work_bytes, void *stream, const CallSink *call,
@@ -1094,6 +1095,37 @@ int ms_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
         KBO_REQUIRE(work_bytes >= w.bytes + shard_ms, KBO_E_BAD_ARG,
                     "d_work is smaller than kbo_work_bytes() (kbo_index_work_bytes() for a sharded index) for this batch");
         KBO_REQUIRE(total_bases / w.chunk + n_seqs < (1ull << 28), KBO_E_UNSUPPORTED, "more than 2^28 work items per launch");
+        // a batch of reads over a copy with a depth table, nothing but the MS values asked for: map_reads_kernel in the form that puts
+        // the values together in LDS (k where nothing happened, the ramps behind the mismatches, the table's values right behind them),
+        // stopping there - no characters are made - and the plain walk for the reads it leaves (C2: 0.33 against 0.61 ms per
+        // 1 M reads for the plan-guided walk below, which stays what larger batches' chunks, the intervals, the call mode and the
+        // work counters take)
+        if (shards.size() == 1 && !d_lo_out && !call && !w.chunked && max_seq_len > 0 && g_ms_one_kernel.load() != 0 && !g_plan_stats.load()) {
+            DevCopy::PlanState *plan_state = nullptr;
+            const kbo::DevIndexView view = device_view(idx, current_device(), &plan_state, count_bases ? total_bases : 0);
+            kbo::WalkArgs a{};
+            a.ix = view;
+            a.q = d_concat;
+            a.q_bytes = total_bases;
+            a.items = items;
+            a.n_items = w.n_slots;
+            a.d_out = d_ms_out;
+            a.max_item_len = (uint32_t)max_seq_len;
+            attach_plan(a, static_cast<uint8_t *>(d_work) + w.plan_off, plan_state);
+            a.chars_out = nullptr;
+            a.map_thr = idx->host.k; // (no value is derandomised here)
+            a.map_fmt = 0;
+            a.map_want_ms = 1;
+            count_bases = false; // (this batch is counted: the walk below, should the copy not have what the kernel needs, must not count it again)
+            if (a.gitems && kbo::map_reads_applies(a)) {
+                a.seq_off = d_offsets;
+                a.host_bailed = plan_state ? plan_state->bailed : nullptr;
+                HIP_OK(kbo::launch_map_reads(a, s));
+                HIP_OK(kbo::launch_redo_pass(a, s));
+                if (!a.host_bailed) plan_after_launch(a, s, plan_state);
+                return;
+            }
+        }
         if (w.chunked) {
             uint32_t *scratch = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(d_work) +
                                                             ((size_t)w.n_slots * sizeof(kbo::WalkItem) + 15) / 16 * 16);
@@ -1198,6 +1230,12 @@ int kbo_plan_flags_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, 
 int kbo_set_map_long(int mode)
 {
     kbo::set_map_long(mode);
+    return KBO_OK;
+}
+
+int kbo_set_ms_one_kernel(int on)
+{
+    g_ms_one_kernel = on != 0;
     return KBO_OK;
 }
 

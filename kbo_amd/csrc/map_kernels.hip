@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
         }
         if (cand) at[e] = cX; // (the read's first base: its prev is k)
         (void)K;
-    } else if (plannable && !flag && len >= 3u) {
+    } else if (a.chars_out != nullptr && plannable && !flag && len >= 3u) { // (chars_out == nullptr: kbo_ms_batch_dev - the MS values were all that was asked for)
         const int K = (int)k, T = (int)a.map_thr;
         const uint32_t Tm1 = (uint32_t)(T - 1);
         uint8_t *at = so + soff;
@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
     // read's base, everything else becomes '-' (flagged reads' bytes are rewritten by launch_derand_flagged)
     if (IO == 2) { // as 2-bit words, where the read's own words stand in the batch
         for (uint32_t c = lane; c < nwords; c += 64u) a.packed_out[w_lo + c] = pack_chars16(*reinterpret_cast<const uint4 *>(so + 16u * c));
-    } else
+    } else if (DIRECT || a.chars_out != nullptr)
     for (uint32_t c = lane * 16u; c < span; c += 1024u) {
         uint4 v = *reinterpret_cast<const uint4 *>(so + c);
         if (!DIRECT && a.map_fmt) {

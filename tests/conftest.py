@@ -45,6 +45,7 @@ def shipped_defaults(L):
     L.kbo_set_plan_table_budget(0)       # the tables of a copy: half of the free device memory
     L.kbo_set_plan_lazy(-1)              # plan structures of implicitly made copies: by index size
     L.kbo_set_map_long(1)                # sequences of more than 160 bases: the one kernel where it applies
+    L.kbo_set_ms_one_kernel(1)           # kbo_ms_batch_dev over reads: the one kernel's MS-emitting form
 
 
 @pytest.fixture(autouse=True)

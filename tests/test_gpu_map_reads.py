@@ -403,3 +403,42 @@ def test_a_batch_that_gives_the_plan_up_holds_the_copy_off(oracle):
     d_good.run()
     torch.cuda.synchronize()
     assert d_good.fused and np.array_equal(d_good.chars[:d_good.total].cpu().numpy(), want_good)
+
+
+def test_ms_values_alone_through_the_one_kernel(oracle):
+    """kbo_ms_batch_dev over reads and a copy with a depth table: map_reads_kernel in its MS-emitting form, stopped behind the values (no
+    characters are made), the plain walk for the reads it leaves.  Every MS byte against the oracle's (index.rs:243-256), next to the
+    plan-guided walk (kbo_set_ms_one_kernel(0)) over the same batch; intervals asked for: the walk, as before."""
+    import torch
+    rng = np.random.default_rng(91)
+    g = synth.genome(400_000, seed=17)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=threads()))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    dev0 = torch.device("cuda:0")
+    L = kbo_amd.lib()
+    other = synth.genome(30_000, seed=6)
+
+    def take(n, lo, hi):
+        return [g[a:a + int(l)] for a, l in zip(rng.integers(0, len(g) - 200, n), rng.integers(lo, hi + 1, n))]
+    sets = [_mutate(rng, take(20_000, 150, 150), sub=0.01), _mutate(rng, take(8_000, 3, 160), sub=0.04, indel=0.3, n_rate=0.1),
+            _mutate(rng, take(3_000, 150, 150), sub=0.08) + [other[a:a + 150] for a in rng.integers(0, len(other) - 150, 2000)]]
+    for reads in sets:
+        concat, offsets = _batch_of(reads)
+        _, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=threads(), want_d=True)
+        for one_kernel in (1, 0):
+            L.kbo_set_ms_one_kernel(one_kernel)
+            dev = batch.DeviceBatch(sbwt, concat, offsets, device=dev0, format=False, want_ms=True)
+            dev.ms.fill_(0xEE)
+            dev.walk()
+            torch.cuda.synchronize()
+            assert np.array_equal(dev.ms[:dev.total].cpu().numpy(), exp_d), one_kernel
+            if one_kernel:  # (the kernel ran: its flags are in the work buffer - a few per cent of such reads at most)
+                fl = dev.plan_flags()
+                assert 0 < int(np.count_nonzero(fl)) < len(fl) // 2
+            del dev
+        L.kbo_set_ms_one_kernel(1)
+        dev = batch.DeviceBatch(sbwt, concat, offsets, device=dev0, format=False, want_ms=True, want_intervals=True)
+        dev.walk()
+        torch.cuda.synchronize()
+        assert np.array_equal(dev.ms[:dev.total].cpu().numpy(), exp_d)
+        del dev
