@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
         t_last = t;
     };
     uint64_t t_last = stamps ? __builtin_amdgcn_s_memtime() : 0;
+    bool need_xin = true; // (x of this piece's first own base: see below)
     for (uint32_t pi = 0; pi < n_mine; pi++) {
         const uint32_t piece = p_first + pi;
         const uint4 itc = it_c, itn = it_n;
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
         };
         if (skip) {
             if (lane == 0) a.redo[piece] = 0;
+            need_xin = false;
             pred = false;
             pred_in_lds = false;
             finish_round();
@@ -934,14 +936,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
             uint32_t w[4];
 #pragma unroll
             for (uint32_t q = 0; q < 4u; q++) {
-                const uint32_t eM = spread4(isM >> (4u * q)), eX = spread4(isX >> (4u * q)), eR = spread4(isR >> (4u * q));
-                if (a.fmt) {
+                if (a.fmt) { // ('M' and 'R' keep the read's base, everything else is '-': one mask)
                     const uint32_t d8 = (code >> (24u - 8u * q)) & 0xFFu;
                     const uint32_t sel = ((d8 >> 6) & 3u) | (((d8 >> 4) & 3u) << 8) | (((d8 >> 2) & 3u) << 16) | ((d8 & 3u) << 24);
-                    const uint32_t letters = __builtin_amdgcn_perm(0u, 0x54474341u, sel), keep = eM | eR;
+                    const uint32_t letters = __builtin_amdgcn_perm(0u, 0x54474341u, sel), keep = spread4((isM | isR) >> (4u * q));
                     w[q] = (letters & keep) | (0x2D2D2D2Du & ~keep);
-                } else
+                } else {
+                    const uint32_t eM = spread4(isM >> (4u * q)), eX = spread4(isX >> (4u * q)), eR = spread4(isR >> (4u * q));
                     w[q] = (eM & 0x4D4D4D4Du) | (eX & 0x58585858u) | (eR & 0x52525252u) | (~(eM | eX | eR) & 0x2D2D2D2Du);
+                }
             }
             const uint4 out = make_uint4(w[0], w[1], w[2], w[3]);
             const int32_t o_lo = (int32_t)(r0 + own0), o_hi = o_lo + (int32_t)own_n;
@@ -965,7 +968,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
         // x of the first own base, 0 .. k (what derandomize_ms_vec gives there: the depth in the stretch of more than t bases that
         // covers it, 0 when none does) - for the piece to the left, should that one be flagged.  Per plane: the ones that end at that
         // base (Lp) and those behind it (Rp), through the words that are all ones by one ballot
-        {
+        // (only the piece behind a flagged one is ever asked for it - long_derand_kernel starts a run of flagged pieces from the xin of
+        // the piece to its right: worked out for the wave's first piece, whose left neighbour is another wave's, and behind a piece
+        // this wave has just flagged)
+        const bool fl = flag || (a.xexp & 64u) != 0; // (64: every piece to the second pass - tests)
+        if (need_xin) {
             const uint32_t xs = r0 + own0, Lo = xs >> 4, b = xs & 15u;
             uint32_t best = 0;
 #pragma unroll
@@ -998,14 +1005,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                 }
                 if (Lp + Rp > thr) best = max(best, min(Lp, k));
             }
-            if (lane == 0) {
-                a.xin[piece] = (uint8_t)best;
-                const bool fl = flag || (a.xexp & 64u) != 0; // (64: every piece to the second pass - tests)
-                a.redo[piece] = fl ? 1 : 0;
-                if (fl) atomicAdd(a.qctl + 4, 1u);
-                if (STATS && fl && a.pstats) atomicAdd(a.qctl + 8u + why + (band_took ? 4u : 0u), 1u);
-            }
+            if (lane == 0) a.xin[piece] = (uint8_t)best;
         }
+        if (lane == 0) {
+            a.redo[piece] = fl ? 1 : 0;
+            if (fl) atomicAdd(a.qctl + 4, 1u);
+            if (STATS && fl && a.pstats) atomicAdd(a.qctl + 8u + why + (band_took ? 4u : 0u), 1u);
+        }
+        need_xin = fl;
         stamp(4, t_last); // output
     }
     if (stamps && lane == 0)
