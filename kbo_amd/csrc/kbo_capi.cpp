@@ -1540,6 +1540,24 @@ struct kbo_map_stream {
     uint64_t max_bases = 0, next = 0;
     hipEvent_t ready = nullptr, kdone = nullptr;
     std::mutex mu;
+    kbo_map_stream() = default;
+    kbo_map_stream(const kbo_map_stream &) = delete;
+    kbo_map_stream &operator=(const kbo_map_stream &) = delete;
+    ~kbo_map_stream() // (also what a create that fails half-way leaves: whatever it had made so far)
+    {
+        for (auto &p : pipes) {
+            if (p.ks) (void)hipStreamSynchronize(p.ks);
+            if (p.ts) (void)hipStreamSynchronize(p.ts);
+        }
+        for (auto &sl : slots)
+            if (sl.done) (void)hipEventDestroy(sl.done);
+        if (ready) (void)hipEventDestroy(ready);
+        if (kdone) (void)hipEventDestroy(kdone);
+        for (auto &p : pipes) {
+            if (p.ks) (void)hipStreamDestroy(p.ks);
+            if (p.ts) (void)hipStreamDestroy(p.ts);
+        }
+    }
 };
 
 int kbo_map_stream_create(kbo_index_t *idx, int pipelines, size_t max_seqs, uint64_t max_bases, size_t max_seq_len, kbo_map_stream_t **out)
@@ -1661,20 +1679,7 @@ int kbo_map_stream_sync(kbo_map_stream_t *m)
 
 void kbo_map_stream_free(kbo_map_stream_t *m)
 {
-    if (!m) return;
-    for (auto &p : m->pipes) {
-        if (p.ks) (void)hipStreamSynchronize(p.ks);
-        if (p.ts) (void)hipStreamSynchronize(p.ts);
-    }
-    for (auto &sl : m->slots)
-        if (sl.done) (void)hipEventDestroy(sl.done);
-    if (m->ready) (void)hipEventDestroy(m->ready);
-    if (m->kdone) (void)hipEventDestroy(m->kdone);
-    for (auto &p : m->pipes) {
-        if (p.ks) (void)hipStreamDestroy(p.ks);
-        if (p.ts) (void)hipStreamDestroy(p.ts);
-    }
-    delete m;
+    delete m; // (waits for what its streams still hold)
 }
 
 namespace {

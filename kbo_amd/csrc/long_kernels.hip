@@ -13,7 +13,9 @@
 //                       (pc_tm) is staged in LDS once and the whole region compared with it in one step (a word per lane).
 //                       Where 6 of 16 bases mismatch the diagonal is lost: the 64 lanes try the 64 diagonals beside it (an
 //                       insertion or deletion of up to 32 bases) on the 32 bases behind the loss - the diagonal on which the read
-//                       goes on soonest wins - and only then the seed table again.  Consecutive diagonals alternate between two
+//                       goes on soonest wins - and only then the seed table again.  The first loss of a piece tries all its
+//                       words at once on the 13 diagonals around the lost one (an insertion or deletion every 80 bases: one pass
+//                       instead of a dozen rounds).  Consecutive diagonals alternate between two
 //                       BIT PLANES (1 = the base lies in a stretch of that plane), so that two stretches may overlap (an
 //                       insertion inside a run of equal bases lies on both diagonals);
 //                    2. everything else is a function of the two planes, word-parallel (tools/model/long_form.py has the
@@ -27,12 +29,14 @@
 //                       the index.  Per maximal run of U: its first end, every c-th from there (c = t - order: a window may then
 //                       be present as long as nothing deeper than order + 1 ends there), and its last end, are looked up - behind
 //                       the filter where the copy has one; a window that is present AND extended to the left by the read's base
-//                       needs the window one base back not to be both; the run's last window - it starts at the last base in
-//                       front of the next stretch - needs the window one base on not to be extended by that base.  The wave's
-//                       look-ups are dealt to its lanes; a piece whose proof fails is FLAGGED;
+//                       (order + 1 bases in the index) is ruled out by any pair of absent strings of order + 1 bases around it - one
+//                       ending j bases back, one i bases on, i + j <= c + 1 (j = 1 alone will do); the run's last window - it
+//                       starts at the last base in front of the next stretch - needs the window one base on not to be extended
+//                       by that base.  The wave's look-ups are dealt to its lanes; a piece whose proof fails is FLAGGED;
 //                    4. the characters of the own bases leave in whole lines; x at the piece's first own base goes to xin[]
-//                       (what the piece to the left needs should it be flagged).
-//   flagged pieces   long_redo_items_kernel lists them in sub-items of 32 bases for the plain walk (walk_kernels.hip), which gives
+//                       (what the piece to the left needs should it be flagged: worked out only for a wave's first piece and
+//                       behind a piece the wave has just flagged).
+//   flagged pieces   long_redo_items_kernel lists them in sub-items of 32 bases (8 / 16 in small batches) for the plain walk (walk_kernels.hip), which gives
 //                    their matching statistics; long_derand_kernel runs the literal recurrences over them right to left, from
 //                    xin[] of the piece to the right (runs of flagged pieces in one go).
 //

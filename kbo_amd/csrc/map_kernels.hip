@@ -26,6 +26,9 @@
 //                      4. derandomize + translate, right to left, one lane per read, in place over those bytes;
 //                      5. the characters leave in whole lines, relative_to_ref applied on the way out (the bases come from the
 //                         2-bit copy).
+//                      (direct form, round 5: a window that is in the index and that neither the anchors nor its place settle is
+//                      asked of the windows AROUND it - six entries, judged at the kernel's end; a diagonal on which every third
+//                      base mismatches is a chance seed, and its read is judged like one without a seed.)
 //   Reads it cannot finish - a base deeper than the table knows, more mismatches than a list holds, no seed and a deep match,
 //   a byte that is no base - are flagged exactly as plan_kernel<FUSE> flags them; redo_collect_kernel + the plain walk give
 //   their MS values and launch_derand_flagged their characters.  Nothing depends on a diagonal being right.
@@ -110,6 +113,15 @@ __global__ __launch_bounds__(256) void seed_pos_kernel(const uint2 *__restrict__
 
 __device__ __forceinline__ bool thr_gt(uint32_t thr, uint32_t order) { return thr > order; } // (windows order .. thr apart exist)
 constexpr uint32_t kMapWords = 10;       // 16-base words per read: reads of up to 160 bases
+// experiments of earlier rounds (KBO_MAP_X bits 0 - 4: ambiguous seeds as they come, a second filter stretch, half-window seed
+// retries, no search beside the diagonal, no look at the window one base on): compiled in only with -DKBO_MAP_EXPERIMENTS - the second
+// filter stretch alone is two more words per window live through the proof's loop.  Bits 5 and 6 (this round's rules off) stay: they sit
+// in rare paths (tools/dbg_witness.py)
+#ifdef KBO_MAP_EXPERIMENTS
+constexpr bool kMapExp = true;
+#else
+constexpr bool kMapExp = false;
+#endif
 constexpr uint32_t kMapSlack = 48;       // bytes of the byte region behind the staged stretch
 // windows that are in the index and wait for the anchors / the windows around them, per wave (two or three at 1 % substitutions, a
 // dozen at 5 %; more: their reads take the plain walk).  20: a wave of 64 reads of 150 bases then takes 13 312 bytes of LDS - 26
@@ -157,7 +169,8 @@ __device__ __forceinline__ uint32_t pack_chars16(const uint4 &v)
     return four(v.x) | (four(v.y) << 8) | (four(v.z) << 16) | (four(v.w) << 24);
 }
 
-template <int NP, bool DIRECT, int IO = 0>
+// STATS: the kernel counts its own work (kbo_set_plan_stats) - instrumentation, compiled out of the default instantiations
+template <int NP, bool DIRECT, int IO = 0, bool STATS = false>
 __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint32_t stage_bytes, uint32_t lin_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t map_lds_all[];
@@ -333,8 +346,8 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
         if (__ballot(act) == 0) break;
         if (act) {
             const uint32_t tp = seed_at(e);
-            st_lookups++;
-            if (tp != 0xFFFFFFFFu && (by_anchor || !(tp & 0x80000000u) || (a.rounds & 1u))) { // (a.rounds: experiment switches)
+            if (STATS) st_lookups++;
+            if (tp != 0xFFFFFFFFu && (by_anchor || !(tp & 0x80000000u) || (kMapExp && (a.rounds & 1u)))) { // (a.rounds: experiment switches)
                 seeded = true;
                 p0 = (by_anchor ? tp : (tp & 0x7FFFFFFFu)) - e;
             } else {
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                     have_amb = true;
                     p_amb = (tp & 0x7FFFFFFFu) - e;
                 }
-                e += (a.rounds & 4u) ? (D + 1u) / 2u : D; // (the next window shares no base with this one: whatever broke this one - a
+                e += (kMapExp && (a.rounds & 4u)) ? (D + 1u) / 2u : D; // (the next window shares no base with this one: whatever broke this one - a
                                                           // substitution in 13 reads of 100 - does not break that one too; half a window on: 225 against 220 us)
             }
         }
@@ -412,7 +425,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
             const uint32_t lo_b = 16u * g, t0 = len - 16u;
             if (lo_b + 16u > t0 && lo_b < len) tail_c += (uint32_t)__popc(mmw[g] & (t0 > lo_b ? (1u << (2u * (16u - (t0 - lo_b)))) - 1u : ~0u));
         }
-        const bool dense = seeded && len >= 32u && (tail_c >= 6u || (uint32_t)__popc(mmw[0]) >= 6u) && !(a.rounds & 8u);
+        const bool dense = seeded && len >= 32u && (tail_c >= 6u || (uint32_t)__popc(mmw[0]) >= 6u) && !(kMapExp && (a.rounds & 8u));
         const bool need2 = plannable && !has_invalid && len >= 2u * D && (!seeded || cnt > listmax || dense);
         if (__ballot(need2)) {
             uint32_t pB = 0, eb = len - 1u, tries = 0;
@@ -424,7 +437,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
             // same for its first 16 bases: the seed then came from behind the break (a substitution in the read's first window),
             // and the diagonal found beside it becomes the first one.  (a first diagonal that explains less than a third of the
             // read is a wrong seed: the table.)
-            const bool near = need2 && seeded && 10u * cnt <= 7u * len && !(a.rounds & 8u);
+            const bool near = need2 && seeded && 10u * cnt <= 7u * len && !(kMapExp && (a.rounds & 8u));
             bool front = false;
             uint32_t pA = 0;
             if (__ballot(near)) {
@@ -491,7 +504,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                 if (__ballot(act) == 0) break;
                 if (act) {
                     const uint32_t tp = seed_at(eb);
-                    st_lookups++;
+                    if (STATS) st_lookups++;
                     if (tp != 0xFFFFFFFFu) {
                         seedB = true;
                         pB = (by_anchor ? tp : (tp & 0x7FFFFFFFu)) - eb;
@@ -737,16 +750,16 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                                     const uint32_t e1 = blockmode ? e : min(e, zlo + F - 1u), e2 = blockmode ? left : max(zhi, left);
                                     const uint32_t k1 = (uint32_t)ending_at(o_soff + e1) & fmask, k2 = (uint32_t)ending_at(o_soff + e2) & fmask;
                                     fw[i][0] = a.ix.dfilt[k1 >> 5] >> (k1 & 31u);
-                                    two[i] = e2 != e1 && (a.rounds & 2u); // (a.rounds bit 1, experiment: a second stretch - fewer table look-ups, 1.4 % slower)
+                                    two[i] = kMapExp && e2 != e1 && (a.rounds & 2u); // (a.rounds bit 1, experiment: a second stretch - fewer table look-ups, 1.4 % slower)
                                     if (two[i]) fw[i][1] = a.ix.dfilt[k2 >> 5] >> (k2 & 31u);
-                                    st_filt += two[i] ? 2u : 1u;
+                                    if (STATS) st_filt += two[i] ? 2u : 1u;
                                 }
                             }
 #pragma unroll
                             for (uint32_t i = 0; i < 4u; i++)
                                 if (use[i] && !((fw[i][0] & 1u) && (!two[i] || (fw[i][1] & 1u)))) {
                                     look[i] = false; // absent: nothing to look up (bytes[i] stays 0: an absent window)
-                                    st_written++;
+                                    if (STATS) st_written++;
                                 }
                         }
                     }
@@ -756,7 +769,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                             const code_t key = (code_t)ending_at(o_soff + ee[i]) & omask;
                             bytes[i] = !a.ix.dtab_grouped ? a.ix.dtab[key]
                                                           : a.ix.dtab[NP == 16 ? dtab_grouped_addr32((uint32_t)key, ee[i] % 3u, order) : dtab_grouped_addr((uint64_t)key, ee[i] % 3u, order)];
-                            st_look++;
+                            if (STATS) st_look++;
                         }
                     }
                     bool fail = false;
@@ -773,7 +786,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; i++) {
                         if (use[i] && (bytes[i] & 0x80u)) { // the window is a suffix of a row
-                            if (have_anch && lastw[i] && t != o_junc && order < k && ee[i] >= order && !(a.rounds & 16u) &&
+                            if (have_anch && lastw[i] && t != o_junc && order < k && ee[i] >= order && !(kMapExp && (a.rounds & 16u)) &&
                                 !((bytes[i] >> base_at(o_soff + ee[i] - order)) & 1u)) {
                                 // the window that STARTS at the mismatch m (one substitution in 170 has it: its 14 bases behind m
                                 // occur elsewhere behind the read's base).  Not deeper: no string through m that ends with it has
@@ -799,7 +812,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                                 if (!deeper) {
                                     if (order + (nxt_e - e_i) - 1u > thr) ask_around(e_i);
                                 } else {
-                                    st_anch++;
+                                    if (STATS) st_anch++;
                                     const uint32_t slot = atomicAdd(pend_n, 1u);
                                     if (slot < kMapPend) pend[slot] = make_uint2(o_soff + e_i, owner | (e_i << 8) | ((nxt_e - e_i) << 16));
                                     else fail = true; // (no room: the plain walk decides)
@@ -829,7 +842,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                         // to the bases that count, min(byte, v), and suffixes of a present string are present)
                         tv[j] = !a.ix.dtab_grouped ? a.ix.dtab[key]
                                                    : a.ix.dtab[NP == 16 ? dtab_grouped_addr32((uint32_t)key, i % 3u, order) : dtab_grouped_addr((uint64_t)key, i % 3u, order)];
-                        st_look++;
+                        if (STATS) st_look++;
                     }
                 }
                 bool done = false;
@@ -855,7 +868,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                         done = !blockmode && Lv <= j;
                     }
                 }
-                st_anch += (uint32_t)__popc(satmask);
+                if (STATS) st_anch += (uint32_t)__popc(satmask);
                 unkmask |= satmask;
                 if (unkmask) spw[owner * 16u + 13u] = 1; // the owner's read goes to the plain walk
                 // (a stretch with an unknown base writes nothing; a block writes the bases it knows)
@@ -864,7 +877,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                 for (uint32_t j = 0; j < (uint32_t)NP; j++)
                     if ((wmask >> j) & 1u) {
                         so[o_soff + m + j] = (uint8_t)(outv[j >> 2] >> (8u * (j & 3u)));
-                        st_written++;
+                        if (STATS) st_written++;
                     }
                 // behind the stretch: the ramp up to the next mismatch (depth = bases since this one), k from k bases on (in place)
                 if (!blockmode && !unkmask) {
@@ -923,7 +936,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                         w_pre[q] = 0;
                         if (e_lo <= e_hi && w_ + 1u >= order && w_ < w_len) {
                             const code_t key = (code_t)ending_at(soff_ + w_) & omask;
-                            st_look++;
+                            if (STATS) st_look++;
                             w_pre[q] = !a.ix.dtab_grouped ? a.ix.dtab[key]
                                                           : a.ix.dtab[NP == 16 ? dtab_grouped_addr32((uint32_t)key, w_ % 3u, order) : dtab_grouped_addr((uint64_t)key, w_ % 3u, order)];
                         }
@@ -1155,8 +1168,8 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
         __builtin_amdgcn_wave_barrier();
         flag = flag || sp[13] != 0;
     }
-    plan_stats_add(a.pstats, kPlanStatSeedLookups, st_lookups, kPlanStatSeedExtensions, st_filt /* (this kernel: filter look-ups) */, kPlanStatMismatches, seeded ? cnt : 0u, 0, 0);
-    plan_stats_add(a.pstats, kPlanStatTabLookups, st_look, kPlanStatTabWritten, st_written, kPlanStatTabFlagged, flag ? 1u : 0u,
+    if (STATS) plan_stats_add(a.pstats, kPlanStatSeedLookups, st_lookups, kPlanStatSeedExtensions, st_filt /* (this kernel: filter look-ups) */, kPlanStatMismatches, seeded ? cnt : 0u, 0, 0);
+    if (STATS) plan_stats_add(a.pstats, kPlanStatTabLookups, st_look, kPlanStatTabWritten, st_written, kPlanStatTabFlagged, flag ? 1u : 0u,
                    kPlanStatTabAnchored, st_anch);
     const uint64_t fm = __ballot(flag), nm = __ballot(no_plan);
     if (lane == 0) {
@@ -1233,17 +1246,24 @@ hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
     const dim3 grid((n_waves + wpb - 1u) / wpb), block(64u * wpb);
     static const int env_pad = std::getenv("KBO_MAP_LDS_PAD") ? std::atoi(std::getenv("KBO_MAP_LDS_PAD")) : 0; // experiments: fewer resident waves
     const uint32_t lds = lds_wave * wpb + (uint32_t)env_pad;
+    // (the counting instantiations only while kbo_set_plan_stats is on)
+#define KBO_MAP_LAUNCH(NP_, DIRECT_, IO_)                                                                                                         \
+    do {                                                                                                                                          \
+        if (a.pstats) hipLaunchKernelGGL((map_reads_kernel<NP_, DIRECT_, IO_, true>), grid, block, lds, stream, a, stage_bytes, lin_words);       \
+        else hipLaunchKernelGGL((map_reads_kernel<NP_, DIRECT_, IO_, false>), grid, block, lds, stream, a, stage_bytes, lin_words);               \
+    } while (0)
     if (a.ix.dtab_order <= 15u) {
-        if (io == 2) hipLaunchKernelGGL((map_reads_kernel<16, true, 2>), grid, block, lds, stream, a, stage_bytes, lin_words);
-        else if (io == 1) hipLaunchKernelGGL((map_reads_kernel<16, true, 1>), grid, block, lds, stream, a, stage_bytes, lin_words);
-        else if (direct) hipLaunchKernelGGL((map_reads_kernel<16, true>), grid, block, lds, stream, a, stage_bytes, lin_words);
-        else hipLaunchKernelGGL((map_reads_kernel<16, false>), grid, block, lds, stream, a, stage_bytes, lin_words);
+        if (io == 2) KBO_MAP_LAUNCH(16, true, 2);
+        else if (io == 1) KBO_MAP_LAUNCH(16, true, 1);
+        else if (direct) KBO_MAP_LAUNCH(16, true, 0);
+        else KBO_MAP_LAUNCH(16, false, 0);
     } else {
-        if (io == 2) hipLaunchKernelGGL((map_reads_kernel<18, true, 2>), grid, block, lds, stream, a, stage_bytes, lin_words);
-        else if (io == 1) hipLaunchKernelGGL((map_reads_kernel<18, true, 1>), grid, block, lds, stream, a, stage_bytes, lin_words);
-        else if (direct) hipLaunchKernelGGL((map_reads_kernel<18, true>), grid, block, lds, stream, a, stage_bytes, lin_words);
-        else hipLaunchKernelGGL((map_reads_kernel<18, false>), grid, block, lds, stream, a, stage_bytes, lin_words);
+        if (io == 2) KBO_MAP_LAUNCH(18, true, 2);
+        else if (io == 1) KBO_MAP_LAUNCH(18, true, 1);
+        else if (direct) KBO_MAP_LAUNCH(18, true, 0);
+        else KBO_MAP_LAUNCH(18, false, 0);
     }
+#undef KBO_MAP_LAUNCH
     return hipGetLastError();
 }
 

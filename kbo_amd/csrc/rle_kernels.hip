@@ -1,5 +1,6 @@
 // rle_kernels.hip — gfx950 (MI355X, CDNA4): format::run_lengths_gapped (format.rs:143-193), the tail of kbo::find,
-// over a batch of translated sequences: count pass, two-level scan, emit pass.
+// over a batch of translated sequences: count pass, two-level scan, emit pass (reads with max_gap_len = 0: bit-mask kernels staged
+// through LDS - rle0_lds_kernel for any characters, rle0_own_kernel for the kernels' own M - X R).
 #include "device_util.hpp"
 
 #include <algorithm>
