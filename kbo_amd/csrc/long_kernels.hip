@@ -1392,8 +1392,10 @@ hipError_t launch_map_long(const DevIndexView &ix, const uint8_t *d_q, const uin
     a.fmt = fmt ? 1u : 0u;
     static const int env_x = std::getenv("KBO_LONG_X") ? std::atoi(std::getenv("KBO_LONG_X")) : 0; // experiments: phases left out (timing only)
     a.xexp = (uint32_t)env_x | (g_map_long.load() == 2 ? 64u : 0u);
-    static const int env_ppw = std::getenv("KBO_LONG_PPW") ? std::atoi(std::getenv("KBO_LONG_PPW")) : 8; // experiments: pieces per wave
-    a.ppw = (uint32_t)std::min(64, std::max(1, env_ppw));
+    // pieces per wave: consecutive pieces share a wave's set-up and hand their diagonal and text on (8 / 12 / 16 / 32 per wave on 165 000
+    // pieces: 401 / 403 / 406 / 409 Gbp/s) - as many as leave the device two rounds of waves, sixteen at most
+    static const int env_ppw = std::getenv("KBO_LONG_PPW") ? std::atoi(std::getenv("KBO_LONG_PPW")) : 0; // experiments
+    a.ppw = env_ppw > 0 ? (uint32_t)std::min(64, env_ppw) : std::min(16u, std::max(1u, L.n_slots / 8192u));
     a.ca = ix.k + 1u;
     a.subs = w + L.subs;
     a.flist = reinterpret_cast<uint32_t *>(w + L.flist);
