@@ -72,6 +72,7 @@ pub mod ffi {
         // device-resident batches on a hipStream_t (kbo_hip.h): kbo::map / matches for reads as ONE kernel; `_tail`: its second
         // pass on a second stream, beside the next batch's kernel; packed: 2-bit words in and out
         pub fn kbo_work_bytes(n_seqs: usize, total_bases: u64, max_seq_len: usize, k: u32) -> usize;
+        pub fn kbo_ms_work_bytes(n_seqs: usize, total_bases: u64, max_seq_len: usize, k: u32) -> usize;
         pub fn kbo_index_to_device(idx: *mut KboIndex, device: c_int) -> c_int;
         pub fn kbo_map_batch_dev(idx: *mut KboIndex, d_concat: *const u8, d_offsets: *const u64, n_seqs: usize, total_bases: u64,
                                  max_seq_len: usize, p: f64, format: c_int, want_ms: c_int, d_ms: *mut u8, d_chars_out: *mut u8,
@@ -261,7 +262,9 @@ pub fn call_batch(idx: &GpuIndex, seqs: &[Vec<u8>], opts: &kbo::CallOpts) -> Vec
 /// (neither is in the image this was written in: never compiled, never run).  The reference's own test inputs (index.rs:262-275,
 /// lib.rs:600-609, lib.rs:786-805): the index the crate builds, handed over by `export_sbwt_parts` -> `kbo_index_from_parts`, must
 /// give what `sbwt::StreamingIndex::matching_statistics` gives - depths AND intervals - and `matches` / `find` must give the crate's.
-#[cfg(test)]
+// (never compiled - no Rust toolchain in the image this was written in - so behind a feature of its own: a plain `cargo test` must not
+// break on a signature this module assumes wrongly.  `cargo test --features pin-tests` on a machine with the crate and a GPU.)
+#[cfg(all(test, feature = "pin-tests"))]
 mod pin_against_the_crate {
     use super::*;
 

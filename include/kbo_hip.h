@@ -338,8 +338,12 @@ int kbo_find_batch_packed(kbo_index_t *idx, const uint32_t *words, const uint64_
  * allocated with total_bases + 16 bytes or more (the in-repo callers round up to 16 and add 64).
  * The calls check what they can: they refuse total_bases + 16 > 2^32.  Sequences shorter than 3 are skipped by the fused
  * derandomize/translate kernel (the host entry points reject them like the reference).
- * d_work is device scratch of at least kbo_work_bytes(...) bytes for the batch (16-byte aligned). */
+ * d_work is device scratch of at least kbo_work_bytes(...) bytes for the batch (16-byte aligned).  Since round 5 that figure holds, for
+ * batches with sequences of more than 160 bases (max_seq_len 0 or > 160), the regions of the kernels for long sequences as well (about
+ * 0.5 B per base more): what kbo_map_batch_dev[_tail], kbo_find_batch_dev and kbo_map_stream_* check.  The walks alone - kbo_ms_batch_dev,
+ * kbo_call_walk_dev - never touch those regions and check kbo_ms_work_bytes(...) only (the round-4 figure; <= kbo_work_bytes). */
 size_t kbo_work_bytes(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k);
+size_t kbo_ms_work_bytes(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k);
 /* the same for a given index: a sharded index needs total_bases + 32 bytes more (one further shard's MS values) */
 size_t kbo_index_work_bytes(const kbo_index_t *idx, size_t n_seqs, uint64_t total_bases, size_t max_seq_len);
 /* A1 over a batch.  total_bases = offsets[n_seqs] (known to the caller; avoids a device read-back);
@@ -400,7 +404,8 @@ int kbo_map_batch_dev_tail(kbo_index_t *idx, const uint8_t *d_concat, const uint
  * exceed them.  The batch's own buffers (d_concat, d_offsets, d_chars_out) stay the caller's and must stay valid and untouched
  * until the batch is complete.
  *   kbo_map_stream_submit   enqueues kbo::map (format != 0) / kbo::matches of one device-resident batch and returns at once;
- *                           d_ms_out (optional, padded as d_chars_out): the derandomized matching statistics too, one byte a base;
+ *                           d_ms_out (optional, padded as d_chars_out): the matching statistics of every base too, one byte a base, as
+ *                           kbo_ms_batch_dev gives them (index.rs:243-256: the raw k-bounded values, NOT derandomized);
  *                           ready_stream (optional): the stream whose work so far produces the batch's inputs - the pipeline waits
  *                           for it on the device; *ticket (optional) names the batch; *fused (optional) as kbo_map_batch_dev's
  *   kbo_map_stream_wait     blocks the calling thread until that batch is complete;  kbo_map_stream_wait_on makes `stream` wait for

@@ -94,7 +94,7 @@ SYMBOLS = [
     "kbo_random_match_threshold", "kbo_matching_statistics", "kbo_derandomize_ms_vec",
     "kbo_derandomize_ms_val", "kbo_translate_ms_vec", "kbo_translate_ms_val", "kbo_matches",
     "kbo_map", "kbo_find", "kbo_run_lengths_gapped", "kbo_relative_to_ref", "kbo_free",
-    "kbo_ms_batch", "kbo_matches_batch", "kbo_map_batch", "kbo_find_batch", "kbo_work_bytes",
+    "kbo_ms_batch", "kbo_matches_batch", "kbo_map_batch", "kbo_find_batch", "kbo_work_bytes", "kbo_ms_work_bytes",
     "kbo_ms_batch_dev", "kbo_derand_translate_dev", "kbo_set_slab_bytes", "kbo_set_devices", "kbo_set_host_threads",
     "kbo_release_scratch", "kbo_run_lengths_gapped_batch", "kbo_find_batch_into", "kbo_derand_work_bytes",
     "kbo_run_lengths_work_bytes", "kbo_run_lengths_dev", "kbo_index_device_pair_bytes", "kbo_index_device_plan_bytes",
@@ -180,6 +180,7 @@ def lib():
     L.kbo_map_batch.argtypes = [vp, vp, vp, sz, dbl, C.c_int, vp]
     L.kbo_find_batch.argtypes = [vp, vp, vp, sz, C.POINTER(FindOpts), C.POINTER(C.POINTER(RLE)), vp]
     L.kbo_work_bytes.argtypes = [sz, u64, sz, C.c_uint32]; L.kbo_work_bytes.restype = sz
+    L.kbo_ms_work_bytes.argtypes = [sz, u64, sz, C.c_uint32]; L.kbo_ms_work_bytes.restype = sz
     L.kbo_ms_batch_dev.argtypes = [vp, vp, vp, sz, u64, sz, vp, vp, vp, vp, sz, vp]
     L.kbo_derand_translate_dev.argtypes = [vp, vp, sz, u64, sz, sz, vp, vp, sz, vp, sz, vp]
     L.kbo_derand_work_bytes.argtypes = [sz, u64]; L.kbo_derand_work_bytes.restype = sz

@@ -379,6 +379,8 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
     // ---- the plan structures: at once when asked for (kbo_index_to_device) or cheap, else once the copy has seen the bases that
     // pay for them (plan_break_even_bases); a copy that may not hold them walks plainly, with the same results
     const bool plan_on = plan_enabled(idx); // (this index's own option first: kbo_index_set_opts)
+    // (an explicit kbo_index_to_device after a failed build - memory may have been freed since - tries again and reports what happens)
+    if (prepare && dc->plan_failed && !dc->plan_built) dc->plan_failed = false;
     if (!dc->plan_built && !dc->plan_failed && plan_on && !idx->transient) {
         dc->bases_seen += work_bases;
         if (prepare || dc->bases_seen >= plan_break_even_bases(idx)) {

@@ -1026,6 +1026,7 @@ struct DevWork {
     bool chunked;
     uint32_t chunk, n_slots;
     size_t bytes, plan_off;
+    size_t ms_bytes;                 // what the walks alone need (kbo_ms_batch_dev, kbo_call_walk_dev: kbo_ms_work_bytes) - the regions below are kbo_map_batch_dev's / kbo_find_batch_dev's
     size_t long_off, long_bytes;     // batches with sequences of more than 160 bases: work of map_long_kernel (long_kernels.hip) ...
     size_t derand_off, derand_bytes; // ... and of the piece-wise derandomize + translate kernel behind the walk when it does not apply
 };
@@ -1042,7 +1043,7 @@ DevWork dev_work(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32
     w.plan_off = w.bytes; // work of the plan-guided walk behind it
     w.bytes += kbo::plan_work_bytes(std::max<uint64_t>(1, slots), total_bases);
     w.bytes = (w.bytes + 63) / 64 * 64;
-    w.long_off = w.derand_off = w.bytes;
+    w.long_off = w.derand_off = w.ms_bytes = w.bytes;
     w.long_bytes = w.derand_bytes = 0;
     if (max_seq_len == 0 || max_seq_len > 160) {
         w.long_bytes = (kbo::long_work_bytes(n_seqs, total_bases, k) + 63) / 64 * 64;
@@ -1057,6 +1058,11 @@ DevWork dev_work(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32
 size_t kbo_work_bytes(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k)
 {
     return dev_work(n_seqs, total_bases, max_seq_len, k).bytes;
+}
+
+size_t kbo_ms_work_bytes(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, uint32_t k)
+{
+    return dev_work(n_seqs, total_bases, max_seq_len, k).ms_bytes;
 }
 
 size_t kbo_index_work_bytes(const kbo_index_t *idx, size_t n_seqs, uint64_t total_bases, size_t max_seq_len)
@@ -1092,8 +1098,9 @@ int ms_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
         // reads: one item per sequence; batches that hold (or may hold) long sequences: chunks
         const DevWork w = dev_work(n_seqs, total_bases, max_seq_len, idx->host.k);
         const size_t shard_ms = shards.size() > 1 ? ((size_t)total_bases + 15) / 16 * 16 + 16 : 0; // one further shard's MS values
-        KBO_REQUIRE(work_bytes >= w.bytes + shard_ms, KBO_E_BAD_ARG,
-                    "d_work is smaller than kbo_work_bytes() (kbo_index_work_bytes() for a sharded index) for this batch");
+        // (the walks never touch the regions of the kernels for long sequences: only kbo_map_batch_dev / kbo_find_batch_dev ask for those)
+        KBO_REQUIRE(work_bytes >= w.ms_bytes + shard_ms, KBO_E_BAD_ARG,
+                    "d_work is smaller than kbo_ms_work_bytes() (+ one shard's MS values for a sharded index: kbo_index_work_bytes()) for this batch");
         KBO_REQUIRE(total_bases / w.chunk + n_seqs < (1ull << 28), KBO_E_UNSUPPORTED, "more than 2^28 work items per launch");
         // a batch of reads over a copy with a depth table, nothing but the MS values asked for: map_reads_kernel in the form that puts
         // the values together in LDS (k where nothing happened, the ramps behind the mismatches, the table's values right behind them),
@@ -1601,6 +1608,9 @@ int kbo_map_stream_submit(kbo_map_stream_t *m, const uint8_t *d_concat, const ui
     std::lock_guard<std::mutex> g(m->mu);
     int rc = guarded([&] {
         KBO_REQUIRE(n_seqs <= m->max_seqs && total_bases <= m->max_bases, KBO_E_BAD_ARG, "the batch exceeds what the stream's slots were made for");
+        // (the stream's queues, events and slots live on the device it was created on: a submit from a thread whose current device is another
+        // one would pair that device's copy of the index with them)
+        KBO_REQUIRE(current_device() == m->device, KBO_E_BAD_ARG, "kbo_map_stream_submit: the calling thread's current device is not the one the stream was created on");
         KBO_REQUIRE(kbo_index_work_bytes(m->idx, n_seqs, total_bases, max_seq_len) <= m->work_bytes, KBO_E_BAD_ARG,
                     "the batch needs more work memory than the stream's slots have (max_seq_len of kbo_map_stream_create)");
     });

@@ -75,12 +75,18 @@ template <bool EMIT>
 __global__ __launch_bounds__(256) void rle_kernel(const uint8_t *__restrict__ chars, const uint64_t *__restrict__ off,
                                                   uint32_t n_seqs, uint32_t max_gap_len, uint32_t *__restrict__ counts,
                                                   const uint32_t *__restrict__ sums, uint32_t *__restrict__ out,
-                                                  uint32_t capacity)
+                                                  uint32_t capacity, uint32_t min_len)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seqs) return;
     const uint64_t b = off[s];
     const uint32_t len = (uint32_t)(off[s + 1] - b);
+    // (kbo::find's tail, min_len = 3: a sequence of fewer than 3 bases has no alignment - the reference asserts, derandomize.rs:274-276 -
+    // and the kernels in front leave its bytes as they were: no run, whatever stands there)
+    if (len < min_len) {
+        if (!EMIT) counts[s] = 0;
+        return;
+    }
     const uint8_t *row = chars + b;
     const uint32_t first = EMIT ? sums[s / kScanBlock] + counts[s] : 0u; // exclusive prefix after the scan
     RleState st;
@@ -113,7 +119,7 @@ template <bool EMIT, bool SKEW>
 __global__ __launch_bounds__(64) void rle0_lds_kernel(const uint8_t *__restrict__ chars, const uint64_t *__restrict__ off,
                                                       uint32_t n_seqs, uint32_t *__restrict__ counts,
                                                       const uint32_t *__restrict__ sums, uint32_t *__restrict__ out,
-                                                      uint32_t capacity, uint32_t lds_bytes)
+                                                      uint32_t capacity, uint32_t lds_bytes, uint32_t min_len)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x;
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(64) void rle0_lds_kernel(const uint8_t *__restrict_
         n_out++;
         in_run = 0;
     };
-    for (uint32_t i0 = 0; i0 < len; i0 += 16u) {
+    for (uint32_t i0 = 0; len >= min_len && i0 < len; i0 += 16u) { // (min_len: as in rle_kernel)
         const uint32_t n = min(16u, len - i0);
         uint32_t E = 0, M = 0, D = 0, R = 0; // bit j describes character i0 + j: run breaker / match / 'D' / 'R'
 #pragma unroll
@@ -293,6 +299,7 @@ static void launch_rle_pass(const uint8_t *d_chars, const uint64_t *d_offsets, u
                             uint32_t *local, const uint32_t *sums, uint32_t *d_rles, uint32_t capacity, uint32_t max_seq_len,
                             hipStream_t stream, bool own_alphabet)
 {
+    const uint32_t min_len = own_alphabet ? 3u : 0u; // (the kernels' own characters = an alignment of kbo::find: none for fewer than 3 bases)
     if (max_seq_len > 0 && max_seq_len <= 480 && max_gap_len == 0) {
         const uint32_t lds_bytes = ((64u * max_seq_len + 15u) / 16u) * 16u + 16u;
         if (own_alphabet)
@@ -300,13 +307,13 @@ static void launch_rle_pass(const uint8_t *d_chars, const uint64_t *d_offsets, u
                                sums, d_rles, capacity, lds_bytes);
         else if (max_seq_len % 32u == 0)
             hipLaunchKernelGGL((rle0_lds_kernel<EMIT, true>), dim3((n_seqs + 63) / 64), dim3(64), lds_bytes + lds_bytes / 32u + 16u,
-                               stream, d_chars, d_offsets, n_seqs, local, sums, d_rles, capacity, lds_bytes);
+                               stream, d_chars, d_offsets, n_seqs, local, sums, d_rles, capacity, lds_bytes, min_len);
         else
             hipLaunchKernelGGL((rle0_lds_kernel<EMIT, false>), dim3((n_seqs + 63) / 64), dim3(64), lds_bytes, stream, d_chars,
-                               d_offsets, n_seqs, local, sums, d_rles, capacity, lds_bytes);
+                               d_offsets, n_seqs, local, sums, d_rles, capacity, lds_bytes, min_len);
     } else {
         hipLaunchKernelGGL((rle_kernel<EMIT>), dim3((n_seqs + 255) / 256), dim3(256), 0, stream, d_chars, d_offsets, n_seqs,
-                           max_gap_len, local, sums, d_rles, capacity);
+                           max_gap_len, local, sums, d_rles, capacity, min_len);
     }
 }
 

@@ -231,6 +231,31 @@ def test_find_over_long_sequences(oracle):
         want_recs, want_first = oracle.run_lengths_batch(exp_chars, offsets, gap)
         assert np.array_equal(np.asarray(first, dtype=np.uint64), want_first), gap
         assert np.array_equal(np.asarray(recs, dtype=np.uint64).reshape(-1, 7), want_recs), gap
+    # sequences of 1 and 2 bases in between (no alignment: derandomize.rs:274-276 asserts on fewer than 3 values - and no run, whatever the
+    # caller's buffer held: here 'M's, which the generic run-length kernels would report as runs), at both lengths of the longest sequence
+    # that decide which run-length kernel runs (<= 480: the LDS-staged one; beyond: one lane per sequence)
+    for longest in (400, 20_000):
+        part = [q for q in (_sequences(rng, contigs, 12, [200, 300, 380], 0.01, 0.0) if longest == 400 else seqs) if 161 <= len(q) <= longest][:12]
+        assert len(part) >= 6
+        mixed = []
+        for i, q in enumerate(part):
+            mixed.append(q)
+            mixed.append(ACGT[rng.integers(0, 4, 1 + i % 2)])
+        c2, o2 = _batch_of(mixed)
+        exp2 = ora.matches_batch(np.concatenate(part), np.concatenate([[0], np.cumsum([len(q) for q in part])]).astype(np.uint64), 1e-7, n_threads=threads())
+        for gap in (0, 50):
+            dev = batch.DeviceBatch(sbwt, c2, o2, device=torch.device("cuda:0"), want_ms=False)
+            dev.chars.fill_(ord("M"))
+            dev.run_find(max_gap_len=gap, runs_per_seq=4000)
+            torch.cuda.synchronize()
+            assert dev.fused
+            recs, first = dev.run_lengths_host()
+            want_recs, want_first = oracle.run_lengths_batch(exp2, np.concatenate([[0], np.cumsum([len(q) for q in part])]).astype(np.uint64), gap)
+            # (every tiny sequence follows its long one: it has the first-run index of the next long sequence and no run of its own)
+            got_first = np.asarray(first, dtype=np.uint64)
+            assert np.array_equal(got_first[0::2][:len(part) + 1], want_first), (longest, gap)
+            assert np.array_equal(got_first[1::2], want_first[1:]), (longest, gap)
+            assert np.array_equal(np.asarray(recs, dtype=np.uint64).reshape(-1, 7), want_recs), (longest, gap)
 
 
 def test_host_entry_points_over_long_sequences(oracle):
@@ -286,7 +311,37 @@ def test_map_stream_batches_in_flight(oracle):
         for (d, want, want_d), t in zip(sets, tickets):
             ms.wait(t)
             assert np.array_equal(d.chars[:d.total].cpu().numpy(), want), rnd
-            if d.want_ms:  # (d_ms_out: the derandomized matching statistics of every base too)
+            if d.want_ms:  # (d_ms_out: the matching statistics of every base too, raw as kbo_ms_batch_dev gives them)
                 assert np.array_equal(d.ms[:d.total].cpu().numpy(), want_d), rnd
     ms.sync()
     ms.close()
+
+
+def test_the_walks_need_only_their_own_work_bytes(oracle):
+    """kbo_ms_batch_dev over long sequences with a d_work of kbo_ms_work_bytes(): the regions of the kernels for long sequences that
+    kbo_work_bytes() adds (about 0.5 B per base) are kbo_map_batch_dev's / kbo_find_batch_dev's - the walks never touch them and do not
+    ask for them; kbo_map_batch_dev over the same batch still refuses the smaller buffer"""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(97)
+    contigs = _genome(rng, 300_000, contigs=2)
+    sbwt, _ = kbo_amd.build(contigs, kbo_amd.BuildOpts(k=31, num_threads=threads()))
+    ora = oracle.Index.build([c.tobytes() for c in contigs], k=31)
+    seqs = _sequences(rng, contigs, 20, [500, 3000, 20_000], 0.01, 0.002)
+    concat, offsets = _batch_of(seqs)
+    dev = batch.DeviceBatch(sbwt, concat, offsets, device=torch.device("cuda:0"), want_ms=True)
+    L = kbo_amd.lib()
+    small = int(L.kbo_ms_work_bytes(dev.n_seqs, dev.total, dev.max_len, dev.k))
+    assert small < dev.work_bytes and dev.work_bytes - small > dev.total // 4
+    full = dev.work_bytes
+    dev.work_bytes = small
+    dev.walk()
+    torch.cuda.synchronize()
+    _, exp_d = ora.matches_batch(concat, offsets, 1e-7, n_threads=threads(), want_d=True)
+    assert np.array_equal(dev.ms[:dev.total].cpu().numpy(), exp_d)
+    with pytest.raises(kbo_amd.KboError):
+        dev.run()
+    dev.work_bytes = full
+    dev.run()
+    torch.cuda.synchronize()
+    assert dev.fused
