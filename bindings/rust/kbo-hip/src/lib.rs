@@ -29,6 +29,8 @@ pub mod ffi {
     #[repr(C)] pub struct KboCallOpts { pub max_error_prob: f64, pub sbwt_build_opts: KboBuildOpts }
     #[repr(C)] pub struct KboVariant { pub query_pos: u64, pub query_chars: *const u8, pub query_len: usize,
                                        pub ref_chars: *const u8, pub ref_len: usize }
+    #[repr(C)] pub struct KboCallFlat { pub n_variants: u64, pub n_chars: u64, pub query_pos: *mut u32, pub query_len: *mut u16,
+                                        pub ref_len: *mut u16, pub chars: *mut u8 }
     pub const KBO_OPT_INHERIT: i32 = i32::MIN;
     #[repr(C)] pub struct KboIndexOpts { pub struct_size: u32, pub plan: i32, pub depth_table: i32, pub depth_table_anchors: i32,
                                          pub slab_bytes: u64, pub n_devices: i32, pub devices: [i32; 16] }
@@ -59,6 +61,9 @@ pub mod ffi {
                               rles: *mut *mut KboRle, rle_offsets: *mut u64) -> c_int;
         pub fn kbo_call_batch(idx: *mut KboIndex, concat: *const u8, offsets: *const u64, n_seqs: usize, opts: *const KboCallOpts,
                               out: *mut *mut KboVariant, var_offsets: *mut u64) -> c_int;
+        pub fn kbo_call_batch_flat(idx: *mut KboIndex, concat: *const u8, offsets: *const u64, n_seqs: usize, opts: *const KboCallOpts,
+                                   result: *mut KboCallFlat, var_offsets: *mut u64) -> c_int;
+        pub fn kbo_call_flat_free(result: *mut KboCallFlat);
         // 2-bit packed batches: a quarter of the bytes over PCIe (kbo_hip.h "packed batches")
         pub fn kbo_packed_words(offsets: *const u64, n_seqs: usize) -> usize;
         pub fn kbo_pack_reads(concat: *const u8, offsets: *const u64, n_seqs: usize, words_out: *mut u32, exc_pos: *mut u64,
@@ -247,14 +252,28 @@ pub fn call_batch(idx: &GpuIndex, seqs: &[Vec<u8>], opts: &kbo::CallOpts) -> Vec
     let o = ffi::KboCallOpts { max_error_prob: opts.max_error_prob, sbwt_build_opts: ffi::KboBuildOpts {
         k: b.k as u32, add_revcomp: b.add_revcomp as i32, num_threads: b.num_threads as u32, prefix_precalc: b.prefix_precalc as u32,
         build_select: b.build_select as i32, mem_gb: b.mem_gb as u32, dedup_batches: b.dedup_batches as i32, temp_dir: std::ptr::null() } };
-    let (mut p, mut vo) = (std::ptr::null_mut(), vec![0u64; seqs.len() + 1]);
-    check(unsafe { ffi::kbo_call_batch(idx.0, concat.as_ptr(), offsets.as_ptr(), seqs.len(), &o, &mut p, vo.as_mut_ptr()) });
-    let all = unsafe { std::slice::from_raw_parts(p, vo[seqs.len()] as usize) };
-    let out = (0..seqs.len()).map(|s| all[vo[s] as usize..vo[s + 1] as usize].iter().map(|v| kbo::variant_calling::Variant {
-        query_pos: v.query_pos as usize,
-        query_chars: unsafe { std::slice::from_raw_parts(v.query_chars, v.query_len) }.to_vec(),
-        ref_chars: unsafe { std::slice::from_raw_parts(v.ref_chars, v.ref_len) }.to_vec() }).collect()).collect();
-    unsafe { ffi::kbo_free(p as *mut c_void) };
+    // the flat form (`kbo_call_batch_flat`): the device's own order and layout, one allocation, 10 bytes per variant - the two
+    // `Vec<u8>` of every `Variant` are made from slices of `chars` here, where the reference's type asks for them
+    let mut flat = ffi::KboCallFlat { n_variants: 0, n_chars: 0, query_pos: std::ptr::null_mut(), query_len: std::ptr::null_mut(),
+                                      ref_len: std::ptr::null_mut(), chars: std::ptr::null_mut() };
+    let mut vo = vec![0u64; seqs.len() + 1];
+    check(unsafe { ffi::kbo_call_batch_flat(idx.0, concat.as_ptr(), offsets.as_ptr(), seqs.len(), &o, &mut flat, vo.as_mut_ptr()) });
+    let nv = flat.n_variants as usize;
+    let (pos, ql, rl, chars) = unsafe { (std::slice::from_raw_parts(flat.query_pos, nv), std::slice::from_raw_parts(flat.query_len, nv),
+                                         std::slice::from_raw_parts(flat.ref_len, nv), std::slice::from_raw_parts(flat.chars, flat.n_chars as usize)) };
+    let mut c = 0usize;
+    let mut out = Vec::with_capacity(seqs.len());
+    for s in 0..seqs.len() {
+        let mut vs = Vec::with_capacity((vo[s + 1] - vo[s]) as usize);
+        for v in vo[s] as usize..vo[s + 1] as usize {
+            let (a, b) = (ql[v] as usize, rl[v] as usize);
+            vs.push(kbo::variant_calling::Variant { query_pos: pos[v] as usize, query_chars: chars[c..c + a].to_vec(),
+                                                    ref_chars: chars[c + a..c + a + b].to_vec() });
+            c += a + b;
+        }
+        out.push(vs);
+    }
+    unsafe { ffi::kbo_call_flat_free(&mut flat) };
     out
 }
 

@@ -223,6 +223,21 @@ int kbo_call(kbo_index_t *query_idx, const uint8_t *ref_seq, size_t len, const k
  * equal the index's k (lib.rs:559). */
 int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                    const kbo_call_opts *opts, kbo_variant **out, uint64_t *var_offsets /* n_seqs + 1 */);
+/* The same with the variants as flat arrays in the order of (sequence, query position) - the form they leave the device in
+ * (call_emit_kernels.hip: the device sorts a slab's sites, runs resolve_variant's case analysis, variant_calling.rs:139-201, and slices
+ * the characters; 10 bytes per variant cross PCIe instead of 164 per site): no record with two pointers per variant to fill, nothing for
+ * a binding to copy.  Variant v of sequence s (v in [var_offsets[s], var_offsets[s + 1])) has query_pos[v], query_len[v] query characters
+ * followed by ref_len[v] reference characters in `chars`, the variants' characters back to back in variant order.  One allocation:
+ * kbo_call_flat_free(result).  kbo_call_batch is this + the reference's records made from it. */
+typedef struct {
+    uint64_t n_variants, n_chars;
+    uint32_t *query_pos;
+    uint16_t *query_len, *ref_len;
+    uint8_t *chars;
+} kbo_call_flat;
+int kbo_call_batch_flat(kbo_index_t *query_idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                        const kbo_call_opts *opts, kbo_call_flat *result, uint64_t *var_offsets /* n_seqs + 1 */);
+void kbo_call_flat_free(kbo_call_flat *result);
 /* The first pass of call_variants in one go, device-resident: the walk of kbo_ms_batch_dev (MS values to d_ms_out, no
  * intervals) whose lanes run the breakpoint scan on the values they produce.  Sites are 16-byte records {offset of i in
  * d_concat, offset of j, row of ms[j], 0} in KBO_CALL_LISTS lists as below; d_count needs KBO_CALL_LISTS * 64 + 64 bytes:

@@ -137,6 +137,10 @@ int kbo_set_map_long(int mode);
  * MS-emitting form, stopped behind the values; 0 = the plan-guided walk as for every other batch (also taken while kbo_set_plan_stats is
  * on: the work counters are that walk's). */
 int kbo_set_ms_one_kernel(int on);
+/* kbo_call_batch[_flat]: 1 (default) = the variants are put in order, resolved and sliced on the device (call_emit_kernels.hip: two slots
+ * on two streams, ten bytes per variant over PCIe); 0 = rounds 3 - 5's route for every slab (a record + a window per site to the host,
+ * host threads sort, resolve and slice) - what the default falls back to for a slab it cannot finish; same results (tests). */
+int kbo_set_call_device_emit(int on);
 /* inspection: what the last kbo_map_batch_dev / kbo_find_batch_dev call over sequences of more than 160 bases did when it took
  * the one kernel for sequences of any length (long_kernels.hip); arguments as for that call, synchronises `stream`.
  * out[0]: pieces, [1]: pieces whose proof failed (plain walk + literal recurrences), [2]: their sub-items; with kbo_set_plan_stats(1) [3]: seed look-ups,

@@ -55,6 +55,12 @@ class Variant(C.Structure):
                 ("ref_chars", C.POINTER(C.c_uint8)), ("ref_len", C.c_size_t)]
 
 
+class CallFlat(C.Structure):
+    """kbo_call_flat (kbo_hip.h): the variants of a batch as flat arrays, one allocation"""
+    _fields_ = [("n_variants", C.c_uint64), ("n_chars", C.c_uint64), ("query_pos", C.POINTER(C.c_uint32)),
+                ("query_len", C.POINTER(C.c_uint16)), ("ref_len", C.POINTER(C.c_uint16)), ("chars", C.POINTER(C.c_uint8))]
+
+
 OPT_INHERIT = -2147483648
 
 
@@ -98,7 +104,7 @@ SYMBOLS = [
     "kbo_ms_batch_dev", "kbo_derand_translate_dev", "kbo_set_slab_bytes", "kbo_set_devices", "kbo_set_host_threads",
     "kbo_release_scratch", "kbo_run_lengths_gapped_batch", "kbo_find_batch_into", "kbo_derand_work_bytes",
     "kbo_run_lengths_work_bytes", "kbo_run_lengths_dev", "kbo_index_device_pair_bytes", "kbo_index_device_plan_bytes",
-    "kbo_index_path_cover", "kbo_index_recovery_lines", "kbo_call_batch", "kbo_call_sites_dev", "kbo_call_walk_dev",
+    "kbo_index_path_cover", "kbo_index_recovery_lines", "kbo_call_batch", "kbo_call_batch_flat", "kbo_call_flat_free", "kbo_call_sites_dev", "kbo_call_walk_dev",
     "kbo_index_save_sbwt", "kbo_index_load_sbwt", "kbo_packed_words", "kbo_pack_reads", "kbo_unpack_matches",
     "kbo_matches_batch_packed", "kbo_find_batch_packed", "kbo_index_shards", "kbo_index_work_bytes",
     "kbo_index_device_layout", "kbo_map_batch_dev", "kbo_map_batch_dev_tail",
@@ -111,7 +117,7 @@ TUNING_SYMBOLS = [
     "kbo_walk_geometry", "kbo_set_walk_waves_per_cu", "kbo_set_walk_threads", "kbo_set_walk_rare", "kbo_set_guided_walk",
     "kbo_set_pair_steps", "kbo_set_force_big_layout", "kbo_set_seed_table_depth", "kbo_set_plan", "kbo_set_plan_tuning",
     "kbo_set_plan_unit_cap_divisor", "kbo_index_plan_holdoff", "kbo_set_walk_experiment", "kbo_plan_stats_dev", "kbo_set_plan_stats", "kbo_set_index_shards", "kbo_index_shard", "kbo_set_depth_table", "kbo_set_depth_table_anchors", "kbo_index_depth_table", "kbo_run_automaton_depths",
-    "kbo_set_stage_timing", "kbo_stage_timing_read", "kbo_set_plan_table_budget", "kbo_set_plan_lazy", "kbo_plan_flags_dev", "kbo_long_stats_dev", "kbo_set_map_long", "kbo_set_ms_one_kernel",
+    "kbo_set_stage_timing", "kbo_stage_timing_read", "kbo_set_plan_table_budget", "kbo_set_plan_lazy", "kbo_plan_flags_dev", "kbo_long_stats_dev", "kbo_set_map_long", "kbo_set_ms_one_kernel", "kbo_set_call_device_emit",
     "kbo_set_host_in_place",
 ]
 
@@ -226,6 +232,8 @@ def lib():
     L.kbo_index_path_cover.argtypes = [vp, vp, vp, vp]
     L.kbo_index_recovery_lines.argtypes = [vp, vp, C.POINTER(C.c_size_t)]
     L.kbo_call_batch.argtypes = [vp, vp, vp, sz, C.POINTER(CallOpts), C.POINTER(C.POINTER(Variant)), vp]
+    L.kbo_call_batch_flat.argtypes = [vp, vp, vp, sz, C.POINTER(CallOpts), C.POINTER(CallFlat), vp]
+    L.kbo_call_flat_free.argtypes = [C.POINTER(CallFlat)]; L.kbo_call_flat_free.restype = None
     L.kbo_call_sites_dev.argtypes = [vp, vp, vp, vp, sz, u64, sz, sz, vp, sz, vp, vp]
     L.kbo_call_walk_dev.argtypes = [vp, vp, vp, sz, u64, sz, sz, vp, vp, sz, vp, vp, sz, vp]
     L.kbo_index_device_plan_bytes.argtypes = [vp]
@@ -236,6 +244,7 @@ def lib():
     L.kbo_set_plan_lazy.argtypes = [C.c_int64]
     L.kbo_set_map_long.argtypes = [C.c_int]
     L.kbo_set_ms_one_kernel.argtypes = [C.c_int]
+    L.kbo_set_call_device_emit.argtypes = [C.c_int]
     L.kbo_map_stream_create.argtypes = [vp, C.c_int, sz, u64, sz, vp]
     L.kbo_map_stream_submit.argtypes = [vp, vp, vp, sz, u64, sz, C.c_double, C.c_int, vp, vp, vp, vp, C.POINTER(C.c_int)]
     L.kbo_map_stream_wait.argtypes = [vp, u64]

@@ -128,30 +128,48 @@ def find_batch_packed(sbwt, words, offsets, exc_pos, exc_byte, find_opts=None):
     return rles, ro
 
 
+class _FlatOwner:
+    """keeps a kbo_call_flat alive for the numpy views into it (freed with the last of them)"""
+
+    def __init__(self, flat):
+        self.flat = flat
+
+    def __del__(self):
+        try:
+            lib().kbo_call_flat_free(C.byref(self.flat))
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 def call_batch_arrays(sbwt, concat, offsets, call_opts=None):
-    """kbo_call_batch without a Python object per variant -> dict of numpy arrays: var_offsets (n_seqs + 1), query_pos,
-    query_len, ref_len (one entry per variant) and chars (per variant its query characters, then its reference
-    characters, back to back in variant order).  variants_of(result, s) turns one sequence's slice into Variant objects."""
+    """kbo::call over a batch without a Python object per variant (kbo_hip.h kbo_call_batch_flat) -> dict of numpy arrays:
+    var_offsets (n_seqs + 1), query_pos, query_len, ref_len (one entry per variant) and chars (per variant its query characters,
+    then its reference characters, back to back in variant order) - views of the library's one allocation, nothing copied.
+    variants_of(result, s) turns one sequence's slice into (query_pos, query_chars, ref_chars) tuples."""
     from . import CallOpts
     o = call_opts if call_opts is not None else CallOpts()
     co = _capi.CallOpts(o.max_error_prob, o.sbwt_build_opts._to_c())
     concat, offsets, n = _prep(concat, offsets)
     vo = np.zeros(n + 1, dtype=np.uint64)
-    p = C.POINTER(_capi.Variant)()
-    check(lib().kbo_call_batch(sbwt._h, concat.ctypes.data, offsets.ctypes.data, n, C.byref(co), C.byref(p), vo.ctypes.data))
-    nv = int(vo[-1])
-    rec = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(max(1, nv), C.sizeof(_capi.Variant) // 8))[:nv].copy()
-    total = int(rec[:, 2].sum() + rec[:, 4].sum()) if nv else 0
-    base = C.addressof(p.contents) + max(1, nv) * C.sizeof(_capi.Variant)  # (one allocation: records, then the characters)
-    chars = np.ctypeslib.as_array(C.cast(base, C.POINTER(C.c_uint8)), shape=(max(1, total),))[:total].copy()
-    lib().kbo_free(p)
-    return {"var_offsets": vo, "query_pos": rec[:, 0], "query_len": rec[:, 2], "ref_len": rec[:, 4], "chars": chars}
+    flat = _capi.CallFlat()
+    check(lib().kbo_call_batch_flat(sbwt._h, concat.ctypes.data, offsets.ctypes.data, n, C.byref(co), C.byref(flat), vo.ctypes.data))
+    owner = _FlatOwner(flat)
+    nv, nc = int(flat.n_variants), int(flat.n_chars)
+
+    def view(ptr, count, dtype):
+        if count == 0:
+            return np.zeros(0, dtype=dtype)
+        return np.ctypeslib.as_array(ptr, shape=(count,))
+
+    return {"var_offsets": vo, "query_pos": view(flat.query_pos, nv, np.uint32), "query_len": view(flat.query_len, nv, np.uint16),
+            "ref_len": view(flat.ref_len, nv, np.uint16), "chars": view(flat.chars, nc, np.uint8), "_owner": owner}
 
 
 def variants_of(res, s):
     """the variants of sequence s of a call_batch_arrays result as (query_pos, query_chars bytes, ref_chars bytes) tuples"""
     a, b = int(res["var_offsets"][s]), int(res["var_offsets"][s + 1])
-    start = np.concatenate([[0], np.cumsum(res["query_len"] + res["ref_len"])]).astype(np.int64) if "_starts" not in res else res["_starts"]
+    start = (np.concatenate([[0], np.cumsum(res["query_len"].astype(np.int64) + res["ref_len"].astype(np.int64))])
+             if "_starts" not in res else res["_starts"])
     res["_starts"] = start
     out = []
     for v in range(a, b):

@@ -363,181 +363,597 @@ private:
 
 } // namespace
 
+namespace {
+
+// The variants of a batch as they leave the library's inside: flat arrays in the order of (sequence, query position) - what
+// kbo_call_batch_flat hands out as it is and kbo_call_batch turns into the reference's records (variant_calling.rs:8-26).
+struct FlatCalls {
+    std::vector<uint32_t> pos, lens; // lens = query_len | ref_len << 16
+    std::vector<uint8_t> chars;      // per variant its query characters, then its reference characters
+};
+
+// ---- the route of rounds 3 - 5, now the fall-back for a slab the device cannot finish by itself (a lane of the walk's call mode with
+// more than four breakpoints waiting, a site list that overflowed, more sites left to the host than its list holds) and for
+// thresholds the device's second pass does not take: the first pass on the device, one 16-byte record + a window per SITE to the
+// host, host threads sort, resolve and slice.  Appends the variants of sequences [0, n_seqs) to `out`, var_count[s] = those of s.
+void call_slow(kbo_index *query_idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, const kbo_call_opts &o, size_t d,
+               uint32_t second_q, FlatCalls &out, uint64_t *var_count)
+{
+    const uint32_t k = query_idx->host.k;
+    std::vector<size_t> part_seq0;
+    // ---- second pass, per sequence, on host threads that take a slab's sites as soon as its records are on the host - while the
+    // device walks the next slabs.  (The per-sequence index of lib.rs:553 is never built: its build depends on k and add_revcomp
+    // only, both checked by the caller, so it cannot fail for one sequence and not for another; a sequence without sites yields no
+    // variants either way.)
+    struct Ref { uint32_t part, x; };
+    struct Call { uint32_t i; uint16_t q_from, q_len, r_from, r_len; Ref site; }; // characters: slices of the two k-mers
+    std::vector<std::vector<Call>> calls(n_seqs);
+    SiteWindows sw; // (declared in front of the pool: its parts outlive the tasks that read them)
+    const kbo::HostNav nav(query_idx->host);
+    const bool revcomp = o.sbwt_build_opts.add_revcomp != 0;
+    const uint32_t stride = kbo::call_gather_stride(k), kpad = (k + 15u) / 16u * 16u;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)hw, (n_seqs + 15) / 16}));
+    AsyncPool pool(nt - 1u); // (the calling thread joins in wait())
+    struct PartOrder { // a part's sites by sequence: sequence s (of the part) has xs[first[s] .. first[s + 1])
+        std::vector<uint32_t> first, xs;
+    };
+    // the sequences [a, b) of a part
+    auto resolve_block = [&, k, d, stride, kpad, revcomp](const SiteWindows::Part *part, uint32_t part_index, size_t seq0,
+                                                              std::shared_ptr<const PartOrder> po, size_t a, size_t b) {
+        const SiteRec *recs = part->recs.as<SiteRec>();
+        const uint32_t *codes = part->has_codes ? part->codes.as<uint32_t>() : nullptr;
+        RunAutomaton sam;
+        std::vector<uint32_t> dq(k), dr(k), mine;
+        std::vector<uint8_t> qk(k), rk_spelled;
+        for (size_t ls = a; ls < b; ls++) {
+            const size_t fa = po->first[ls], fb = po->first[ls + 1];
+            if (fa == fb) continue;
+            const size_t s = seq0 + ls;
+            const uint8_t *seq = concat + offsets[s];
+            const size_t len = (size_t)(offsets[s + 1] - offsets[s]);
+            mine.assign(po->xs.begin() + fa, po->xs.begin() + fb);
+            std::sort(mine.begin(), mine.end(), [&](uint32_t x, uint32_t y) { return recs[x].i < recs[y].i; });
+            std::vector<Call> &out_calls = calls[s];
+            out_calls.reserve(mine.size());
+            bool sam_built = false;
+            for (const uint32_t x : mine) {
+                const SiteRec &r = recs[x];
+                const Ref sr{part_index, x};
+                const uint32_t code = codes ? codes[x] : 0x01FFFFFFu;
+                if (!(code >> 24)) { // the device did this site: the common suffix and the two peaks are all resolve_variant reads
+                    const uint32_t rp = code & 0xFFu, qp = (code >> 8) & 0xFFu, csl = (code >> 16) & 0xFFu;
+                    size_t qf, qt, rf, rt;
+                    if (kbo::resolve_variant_peaks(k, csl, qp != 0xFFu, qp, rp != 0xFFu, rp, qf, qt, rf, rt))
+                        out_calls.push_back(Call{r.i, (uint16_t)qf, (uint16_t)(qt - qf), (uint16_t)rf, (uint16_t)(rt - rf), sr});
+                    continue;
+                }
+                if (!sam_built) { // (a site left to the host: the sequence's suffix automaton, once)
+                    sam.build(seq, len, k, revcomp);
+                    sam_built = true;
+                }
+                const uint8_t *w = part->win.as<uint8_t>() + (size_t)x * stride;
+                // query-side k-mer (variant_calling.rs:46-58, 275) and its walk against the index (:279): the MS
+                // values of the first pass, capped by the distance from the k-mer's (or the sequence's) first base
+                for (uint32_t t = 0; t < k; t++) {
+                    const int64_t pos = (int64_t)r.j - (int64_t)(k - 1u) + t;
+                    if (pos < 0) { qk[t] = '$'; dr[t] = 0; continue; } // '$': the walk restarts behind it
+                    qk[t] = seq[pos];
+                    dr[t] = std::min<uint32_t>(w[t], (uint32_t)std::min<int64_t>(t + 1u, pos + 1));
+                }
+                // matched row's k-mer (:276): from the device's path cover, or spelled here when its window crosses a path start
+                const uint8_t *rk = w + kpad;
+                if (w[2u * kpad]) {
+                    nav.access_kmer(r.lo, rk_spelled);
+                    rk = rk_spelled.data();
+                }
+                sam.depths(rk, k, dq.data()); // its walk against the sequence's own index (:280)
+                size_t qf, qt, rf, rt;
+                if (kbo::resolve_variant_ranges(qk.data(), rk, dq.data(), dr.data(), k, d, qf, qt, rf, rt)) // :282-284
+                    out_calls.push_back(Call{r.i, (uint16_t)qf, (uint16_t)(qt - qf), (uint16_t)rf, (uint16_t)(rt - rf), sr});
+            }
+        }
+    };
+    // a part: its sites by sequence (counting sort; void records - sites of items the redo pass scanned again - dropped), then
+    // blocks of its sequences as tasks of their own
+    auto on_part = [&](SiteWindows::Part *part, uint32_t part_index, size_t seq0, size_t ns) {
+        if (part->n == 0 || pool.failed()) return;
+        pool.submit([&, part, part_index, seq0, ns] {
+            const SiteRec *recs = part->recs.as<SiteRec>();
+            auto po = std::make_shared<PartOrder>();
+            po->first.assign(ns + 1, 0);
+            size_t valid = 0;
+            for (size_t x = 0; x < part->n; x++)
+                if (recs[x].seq != 0xFFFFFFFFu) { po->first[recs[x].seq + 1]++; valid++; }
+            for (size_t ls = 0; ls < ns; ls++) po->first[ls + 1] += po->first[ls];
+            po->xs.resize(valid);
+            {
+                std::vector<uint32_t> fill(po->first.begin(), po->first.end() - 1);
+                for (size_t x = 0; x < part->n; x++)
+                    if (recs[x].seq != 0xFFFFFFFFu) po->xs[fill[recs[x].seq]++] = (uint32_t)x;
+            }
+            const size_t block = 128;
+            std::shared_ptr<const PartOrder> cpo = po;
+            for (size_t a = 0; a < ns; a += block) {
+                const size_t b = std::min(ns, a + block);
+                if (po->first[a] == po->first[b]) continue;
+                pool.submit([&, part, part_index, seq0, cpo, a, b] { resolve_block(part, part_index, seq0, cpo, a, b); });
+            }
+        });
+    };
+    find_sites(query_idx, concat, offsets, n_seqs, (uint32_t)d, part_seq0, second_q, revcomp, on_part, sw);
+    pool.wait();
+    // ---- the variants, every sequence's at its own place behind what `out` holds already
+    std::vector<size_t> v0(n_seqs + 1, 0), c0(n_seqs + 1, 0);
+    for (size_t s = 0; s < n_seqs; s++) {
+        size_t ch = 0;
+        for (const Call &c : calls[s]) ch += c.q_len + c.r_len;
+        var_count[s] = calls[s].size();
+        v0[s + 1] = v0[s] + calls[s].size();
+        c0[s + 1] = c0[s] + ch;
+    }
+    const size_t vb = out.pos.size(), cb = out.chars.size();
+    out.pos.resize(vb + v0[n_seqs]);
+    out.lens.resize(vb + v0[n_seqs]);
+    out.chars.resize(cb + c0[n_seqs]);
+    const size_t piece = 256;
+    HostTeam::get().run((n_seqs + piece - 1) / piece, [&](size_t task) {
+        std::vector<uint8_t> rk_spelled;
+        for (size_t s = task * piece; s < std::min(n_seqs, (task + 1) * piece); s++) {
+            size_t w = vb + v0[s];
+            uint8_t *cp = out.chars.data() + cb + c0[s];
+            const uint8_t *seq = concat + offsets[s];
+            for (const Call &c : calls[s]) {
+                const SiteRec &r = sw.rec(c.site.part, c.site.x);
+                const uint8_t *win = sw.win(c.site.part, c.site.x);
+                out.pos[w] = c.i;
+                out.lens[w] = (uint32_t)c.q_len | ((uint32_t)c.r_len << 16);
+                for (uint32_t t = 0; t < c.q_len; t++) { // (a slice of the query-side k-mer: '$' in front of the sequence)
+                    const int64_t pos = (int64_t)r.j - (int64_t)(k - 1u) + c.q_from + t;
+                    *cp++ = pos < 0 ? (uint8_t)'$' : seq[pos];
+                }
+                const uint8_t *rk = win + sw.kpad;
+                if (win[2u * sw.kpad] && c.r_len) {
+                    nav.access_kmer(r.lo, rk_spelled);
+                    rk = rk_spelled.data();
+                }
+                std::memcpy(cp, rk + c.r_from, c.r_len);
+                cp += c.r_len;
+                w++;
+            }
+        }
+    });
+}
+
+// ---- kbo::call over a batch, the device's way: two slots of buffers on two streams take the slabs in turn; per slab ONE small read-back
+// (sixteen words: how many sites, variants, characters, sites for the host; did a list overflow) decides what is downloaded - the
+// variants themselves, in their final order and form (call_emit_kernels.hip).  While the host waits for a slab's words the other
+// slot's kernels run; the uploads are staged through pinned memory by the host team.
+struct CallSlot {
+    hipStream_t st = nullptr;
+    hipEvent_t meta_ev = nullptr, done_ev = nullptr;
+    PinBuf in, off, tab_off, meta, o_pos, o_lens, o_chars, o_vfirst, o_hrecs, o_hwin;
+    BatchOnDevice B;
+    std::vector<kbo::WalkItem> items;
+    DevBuf d_sites, d_count, d_prefix, d_meta, d_recs, d_win, d_tab, d_tab_off, d_seq_flag, d_codes;
+    DevBuf d_seq, d_site, d_scan, d_pos, d_lens, d_chars, d_vfirst, d_hlist, d_hrecs, d_hwin;
+    const Slab *slab = nullptr;
+    size_t ns = 0;
+    uint32_t cap = 0, chars_cap = 0, host_cap = 0;
+    int state = 0; // 0 free, 1 enqueued (meta on its way), 2 downloads on their way, 3 left to the slow route
+    uint32_t n_var = 0, n_chars = 0, n_host = 0;
+    void make()
+    {
+        if (st) return;
+        HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&meta_ev, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&done_ev, hipEventDisableTiming));
+    }
+    ~CallSlot()
+    {
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipEventDestroy(meta_ev);
+            (void)hipEventDestroy(done_ev);
+            (void)hipStreamDestroy(st);
+        }
+    }
+};
+
+void call_fast(kbo_index *query_idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, const kbo_call_opts &o, size_t d,
+               uint32_t second_q, FlatCalls &out, uint64_t *var_offsets, CallClock &clk)
+{
+    const uint32_t k = query_idx->host.k;
+    const bool revcomp = o.sbwt_build_opts.add_revcomp != 0;
+    const uint32_t stride = kbo::call_gather_stride(k), kpad = (k + 15u) / 16u * 16u;
+    const std::vector<Slab> slabs = make_slabs(offsets, n_seqs, slab_bytes_for(query_idx));
+    const kbo::DevIndexView view = device_view(query_idx, current_device(), nullptr, offsets[n_seqs]);
+    const size_t count_bytes = kbo::kCallSegs * 64 + 64;
+    const kbo::HostNav nav(query_idx->host);
+    HostTeam &team = HostTeam::get();
+    CallSlot slots[2];
+    double t_stage = 0, t_enq = 0, t_wait = 0, t_take = 0, t_slow = 0;
+    size_t n_slow = 0, n_host_sites = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
+
+    auto enqueue = [&](CallSlot &S, const Slab &sl) {
+        auto t0 = now();
+        S.make();
+        S.slab = &sl;
+        const size_t ns = S.ns = sl.s1 - sl.s0;
+        const uint64_t bytes = sl.b1 - sl.b0;
+        S.off.ensure((ns + 1) * 8);
+        S.tab_off.ensure((ns + 1) * 8);
+        uint64_t *off = S.off.as<uint64_t>(), *tab_off = S.tab_off.as<uint64_t>();
+        uint32_t max_slots = 0;
+        tab_off[0] = 0;
+        for (size_t s = 0; s <= ns; s++) off[s] = offsets[sl.s0 + s] - sl.b0;
+        // a table of q-mer start positions per sequence (a power of two of at least 1.5 slots per base; none for a sequence beyond
+        // 20-bit positions: its sites are the host's)
+        for (size_t s = 0; s < ns; s++) {
+            const uint64_t len = off[s + 1] - off[s];
+            uint64_t size = 0;
+            if (len > 0 && len < (1u << 20) - 1u) {
+                size = 64;
+                while (size < len + len / 2) size <<= 1;
+            }
+            tab_off[s + 1] = tab_off[s] + size;
+            max_slots = (uint32_t)std::max<uint64_t>(max_slots, size);
+        }
+        S.in.ensure(bytes + 16);
+        team.copy(S.in.p, concat + sl.b0, bytes);
+        t_stage += since(t0);
+        t0 = now();
+        const uint32_t cap = S.cap = (uint32_t)std::min<uint64_t>((bytes / 16 + 1024) / kbo::kCallSegs * kbo::kCallSegs + kbo::kCallSegs * 16, 0x7FFFFF00u);
+        const uint32_t seg_cap = cap / kbo::kCallSegs;
+        S.chars_cap = cap * 4u + 4096u;
+        S.host_cap = std::max<uint32_t>(4096u, cap / 16u);
+        S.d_sites.ensure((size_t)cap * 16);
+        S.d_count.ensure(count_bytes);
+        S.d_prefix.ensure((kbo::kCallSegs + 1) * 4);
+        S.d_meta.ensure(kbo::kCallMetaWords * 4);
+        S.meta.ensure(kbo::kCallMetaWords * 4);
+        S.d_recs.ensure((size_t)cap * 16);
+        S.d_win.ensure((size_t)cap * stride);
+        S.d_codes.ensure((size_t)cap * 4);
+        S.d_tab_off.ensure((ns + 1) * 8);
+        S.d_tab.ensure(tab_off[ns] * 4 + 16);
+        S.d_seq_flag.ensure(ns + 16);
+        const size_t seq_words = (ns + 1) + kbo::call_scan_sums_words(ns + 1) + ns + 4;
+        const size_t scan_words = (size_t)cap + 1 + kbo::call_scan_sums_words((size_t)cap + 1);
+        S.d_seq.ensure(seq_words * 4);
+        S.d_site.ensure((size_t)cap * 16);
+        S.d_scan.ensure(2 * scan_words * 4);
+        S.d_pos.ensure((size_t)cap * 4);
+        S.d_lens.ensure((size_t)cap * 4);
+        S.d_chars.ensure((size_t)S.chars_cap + 16);
+        S.d_vfirst.ensure((ns + 1) * 4);
+        S.d_hlist.ensure((size_t)S.host_cap * 4);
+        S.d_hrecs.ensure((size_t)S.host_cap * 16);
+        S.d_hwin.ensure((size_t)S.host_cap * stride);
+        hipStream_t st = S.st;
+        HIP_OK(hipMemsetAsync(S.d_count.p, 0, count_bytes, st));
+        HIP_OK(hipMemsetAsync(S.d_meta.p, 0, kbo::kCallMetaWords * 4, st));
+        const CallSink sink{S.d_sites.p, S.d_count.as<uint32_t>(), seg_cap, (uint32_t)d};
+        enqueue_walk_host(query_idx, S.in.as<uint8_t>(), off, ns, false, S.B, S.items, st, 0, nullptr, nullptr, &sink);
+        HIP_OK(kbo::launch_call_prefix(S.d_count.as<uint32_t>(), seg_cap, S.d_prefix.as<uint32_t>(), S.d_meta.as<uint32_t>(), st));
+        HIP_OK(kbo::launch_call_finalize(S.d_sites.p, S.d_count.as<uint32_t>(), S.d_prefix.as<uint32_t>(), seg_cap, seg_cap, true,
+                                         S.B.off.as<uint64_t>(), (uint32_t)ns, k, S.B.ms.as<uint8_t>(), view, S.d_recs.p, S.d_win.as<uint8_t>(), stride, st));
+        HIP_OK(hipMemcpyAsync(S.d_tab_off.p, tab_off, (ns + 1) * 8, hipMemcpyHostToDevice, st));
+        HIP_OK(kbo::launch_call_qmer_index(S.B.q.as<uint8_t>(), S.B.off.as<uint64_t>(), (uint32_t)ns, second_q, S.d_tab_off.as<uint64_t>(),
+                                           S.d_tab.as<uint32_t>(), S.d_seq_flag.as<uint8_t>(), tab_off[ns], max_slots, st));
+        const uint32_t *d_n = S.d_prefix.as<uint32_t>() + kbo::kCallSegs;
+        HIP_OK(kbo::launch_call_depths(S.d_recs.p, S.d_win.as<uint8_t>(), stride, cap, S.B.q.as<uint8_t>(), S.B.off.as<uint64_t>(), k, (uint32_t)d,
+                                       second_q, revcomp, S.d_tab_off.as<uint64_t>(), S.d_tab.as<uint32_t>(), S.d_seq_flag.as<uint8_t>(),
+                                       S.d_codes.as<uint32_t>(), st, d_n));
+        kbo::CallEmitArgs a{};
+        a.recs = S.d_recs.as<uint4>();
+        a.codes = S.d_codes.as<uint32_t>();
+        a.win = S.d_win.as<uint8_t>();
+        a.stride = stride;
+        a.kpad = kpad;
+        a.k = k;
+        a.q = S.B.q.as<uint8_t>();
+        a.off = S.B.off.as<uint64_t>();
+        a.n_seqs = (uint32_t)ns;
+        a.n_sites = d_n;
+        a.cap = cap;
+        a.seq_cnt = S.d_seq.as<uint32_t>();
+        a.seq_sums = a.seq_cnt + (ns + 1);
+        a.seq_fill = a.seq_sums + kbo::call_scan_sums_words(ns + 1);
+        a.bucket = S.d_site.as<uint32_t>();
+        a.bkey = a.bucket + cap;
+        a.sorted = a.bkey + cap;
+        a.vrec = a.sorted + cap;
+        a.vcnt = S.d_scan.as<uint32_t>();
+        a.vsums = a.vcnt + ((size_t)cap + 1);
+        a.ccnt = a.vcnt + scan_words;
+        a.csums = a.ccnt + ((size_t)cap + 1);
+        a.out_pos = S.d_pos.as<uint32_t>();
+        a.out_lens = S.d_lens.as<uint32_t>();
+        a.out_chars = S.d_chars.as<uint8_t>();
+        a.chars_cap = S.chars_cap;
+        a.seq_vfirst = S.d_vfirst.as<uint32_t>();
+        a.host_list = S.d_hlist.as<uint32_t>();
+        a.host_cap = S.host_cap;
+        a.meta = S.d_meta.as<uint32_t>();
+        HIP_OK(kbo::launch_call_emit(a, S.d_hrecs.p, S.d_hwin.as<uint8_t>(), st));
+        HIP_OK(hipMemcpyAsync(S.meta.p, S.d_meta.p, kbo::kCallMetaWords * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipEventRecord(S.meta_ev, st));
+        S.state = 1;
+        t_enq += since(t0);
+    };
+
+    // the slab's words are there: what to download (or that the slab is the slow route's)
+    auto downloads = [&](CallSlot &S) {
+        if (S.state != 1) return;
+        auto t0 = now();
+        HIP_OK(hipEventSynchronize(S.meta_ev));
+        t_wait += since(t0);
+        const uint32_t *m = S.meta.as<uint32_t>();
+        S.n_var = m[kbo::kCallMetaVariants];
+        S.n_chars = m[kbo::kCallMetaChars];
+        S.n_host = m[kbo::kCallMetaHost];
+        if (m[kbo::kCallMetaFlags] != 0 || S.n_host > S.host_cap || S.n_chars > S.chars_cap) {
+            S.state = 3;
+            return;
+        }
+        hipStream_t st = S.st;
+        S.o_vfirst.ensure((S.ns + 1) * 4);
+        HIP_OK(hipMemcpyAsync(S.o_vfirst.p, S.d_vfirst.p, (S.ns + 1) * 4, hipMemcpyDeviceToHost, st));
+        if (S.n_var) {
+            S.o_pos.ensure((size_t)S.n_var * 4);
+            S.o_lens.ensure((size_t)S.n_var * 4);
+            S.o_chars.ensure((size_t)S.n_chars + 16);
+            HIP_OK(hipMemcpyAsync(S.o_pos.p, S.d_pos.p, (size_t)S.n_var * 4, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(S.o_lens.p, S.d_lens.p, (size_t)S.n_var * 4, hipMemcpyDeviceToHost, st));
+            if (S.n_chars) HIP_OK(hipMemcpyAsync(S.o_chars.p, S.d_chars.p, S.n_chars, hipMemcpyDeviceToHost, st));
+        }
+        if (S.n_host) {
+            S.o_hrecs.ensure((size_t)S.n_host * 16);
+            S.o_hwin.ensure((size_t)S.n_host * stride);
+            HIP_OK(hipMemcpyAsync(S.o_hrecs.p, S.d_hrecs.p, (size_t)S.n_host * 16, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(S.o_hwin.p, S.d_hwin.p, (size_t)S.n_host * stride, hipMemcpyDeviceToHost, st));
+        }
+        HIP_OK(hipEventRecord(S.done_ev, st));
+        S.state = 2;
+    };
+
+    // the slab's variants behind those of the slabs in front of it
+    auto take = [&](CallSlot &S) {
+        if (S.state == 0) return;
+        downloads(S);
+        const Slab &sl = *S.slab;
+        if (S.state == 3) { // the slow route, the whole slab
+            auto t0 = now();
+            HIP_OK(hipStreamSynchronize(S.st));
+            std::vector<uint64_t> off(S.ns + 1), cnt(S.ns);
+            for (size_t s = 0; s <= S.ns; s++) off[s] = offsets[sl.s0 + s] - sl.b0;
+            call_slow(query_idx, concat + sl.b0, off.data(), S.ns, o, d, second_q, out, cnt.data());
+            for (size_t s = 0; s < S.ns; s++) var_offsets[sl.s0 + s + 1] = var_offsets[sl.s0 + s] + cnt[s];
+            S.state = 0;
+            n_slow++;
+            t_slow += since(t0);
+            return;
+        }
+        auto t0 = now();
+        HIP_OK(hipEventSynchronize(S.done_ev));
+        t_wait += since(t0);
+        t0 = now();
+        const uint32_t *vfirst = S.o_vfirst.as<uint32_t>();
+        const uint32_t *dpos = S.o_pos.as<uint32_t>(), *dlens = S.o_lens.as<uint32_t>();
+        const uint8_t *dchars = S.o_chars.as<uint8_t>();
+        const size_t vb = out.pos.size(), cb = out.chars.size();
+        if (S.n_host == 0) {
+            out.pos.resize(vb + S.n_var);
+            out.lens.resize(vb + S.n_var);
+            out.chars.resize(cb + S.n_chars);
+            if (S.n_var) {
+                team.copy(out.pos.data() + vb, dpos, (size_t)S.n_var * 4);
+                team.copy(out.lens.data() + vb, dlens, (size_t)S.n_var * 4);
+                if (S.n_chars) team.copy(out.chars.data() + cb, dchars, S.n_chars);
+            }
+            const uint64_t base = var_offsets[sl.s0];
+            for (size_t s = 0; s < S.ns; s++) var_offsets[sl.s0 + s + 1] = base + vfirst[s + 1];
+        } else {
+            // some sites are the host's (a sequence with bytes that are no bases or of 2^20 bases and more, a row whose k-mer crosses a
+            // path start, what the reference panics on): resolved here as in the slow route, then merged by query position with what
+            // the device made of the sequence's other sites
+            n_host_sites += S.n_host;
+            const SiteRec *hrecs = S.o_hrecs.as<SiteRec>();
+            const uint8_t *hwin = S.o_hwin.as<uint8_t>();
+            std::vector<uint32_t> order(S.n_host);
+            for (uint32_t x = 0; x < S.n_host; x++) order[x] = x;
+            std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+                return hrecs[x].seq != hrecs[y].seq ? hrecs[x].seq < hrecs[y].seq : hrecs[x].i < hrecs[y].i;
+            });
+            RunAutomaton sam;
+            std::vector<uint32_t> dq(k), dr(k);
+            std::vector<uint8_t> qk(k), rk_spelled;
+            size_t dv = 0, dc = 0; // the device's variants / characters taken so far
+            auto device_upto = [&](size_t v_end) { // the device's variants [dv, v_end) as they are
+                for (; dv < v_end; dv++) {
+                    const uint32_t l = dlens[dv], n = (l & 0xFFFFu) + (l >> 16);
+                    out.pos.push_back(dpos[dv]);
+                    out.lens.push_back(l);
+                    out.chars.insert(out.chars.end(), dchars + dc, dchars + dc + n);
+                    dc += n;
+                }
+            };
+            const uint64_t base = var_offsets[sl.s0];
+            size_t h = 0;
+            for (size_t ls = 0; ls < S.ns; ls++) {
+                if (h < S.n_host && hrecs[order[h]].seq == ls) {
+                    const uint8_t *seq = concat + offsets[sl.s0 + ls];
+                    const size_t len = (size_t)(offsets[sl.s0 + ls + 1] - offsets[sl.s0 + ls]);
+                    sam.build(seq, len, k, revcomp);
+                    const size_t v_end = vfirst[ls + 1];
+                    for (; h < S.n_host && hrecs[order[h]].seq == ls; h++) {
+                        const SiteRec &r = hrecs[order[h]];
+                        const uint8_t *w = hwin + (size_t)order[h] * stride;
+                        for (uint32_t t = 0; t < k; t++) { // (as in call_slow: the query-side k-mer and its walk from the first pass's values)
+                            const int64_t pos = (int64_t)r.j - (int64_t)(k - 1u) + t;
+                            if (pos < 0) { qk[t] = '$'; dr[t] = 0; continue; }
+                            qk[t] = seq[pos];
+                            dr[t] = std::min<uint32_t>(w[t], (uint32_t)std::min<int64_t>(t + 1u, pos + 1));
+                        }
+                        const uint8_t *rk = w + kpad;
+                        if (w[2u * kpad]) {
+                            nav.access_kmer(r.lo, rk_spelled);
+                            rk = rk_spelled.data();
+                        }
+                        sam.depths(rk, k, dq.data());
+                        size_t qf, qt, rf, rt;
+                        if (!kbo::resolve_variant_ranges(qk.data(), rk, dq.data(), dr.data(), k, d, qf, qt, rf, rt)) continue;
+                        while (dv < v_end && dpos[dv] < r.i) device_upto(dv + 1); // the device's variants in front of this one
+                        out.pos.push_back(r.i);
+                        out.lens.push_back((uint32_t)(qt - qf) | ((uint32_t)(rt - rf) << 16));
+                        out.chars.insert(out.chars.end(), qk.data() + qf, qk.data() + qt);
+                        out.chars.insert(out.chars.end(), rk + rf, rk + rt);
+                    }
+                    device_upto(v_end);
+                } else
+                    device_upto(vfirst[ls + 1]);
+                var_offsets[sl.s0 + ls + 1] = base + (out.pos.size() - vb);
+            }
+        }
+        S.state = 0;
+        t_take += since(t0);
+    };
+
+    var_offsets[0] = 0;
+    for (size_t i = 0; i < slabs.size(); i++) {
+        CallSlot &S = slots[i & 1], &other = slots[(i & 1) ^ 1];
+        take(S);           // slab i - 2 (its downloads were asked for one round ago)
+        enqueue(S, slabs[i]);
+        downloads(other);  // slab i - 1: its words, then its downloads - beside slab i's kernels
+    }
+    take(slots[slabs.size() & 1]);
+    take(slots[(slabs.size() & 1) ^ 1]);
+    if (clk.on)
+        std::fprintf(stderr, "[kbo timing] call: %zu slabs: staging %.1f ms, enqueue %.1f, waiting for the device %.1f, taking results %.1f, slow route %.1f (%zu slabs); %zu sites resolved on the host\n",
+                     slabs.size(), t_stage, t_enq, t_wait, t_take, t_slow, n_slow, n_host_sites);
+}
+
+std::atomic<int> g_call_device_emit{1}; // kbo_set_call_device_emit
+
+// both entry points: checks, threshold, the route
+void call_batch_flat_impl(kbo_index_t *query_idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, const kbo_call_opts *opts,
+                          FlatCalls &out, uint64_t *var_offsets)
+{
+    KBO_REQUIRE(query_idx && var_offsets, KBO_E_BAD_ARG, "null argument");
+    check_batch(concat, offsets, n_seqs);
+    kbo_call_opts o;
+    if (opts) o = *opts; else kbo_call_opts_default(&o);
+    KBO_REQUIRE(o.sbwt_build_opts.k == query_idx->host.k, KBO_E_K_MISMATCH, "assert!(sbwt_ref.k() == sbwt_query.k()) (lib.rs:559)");
+    KBO_REQUIRE(!query_idx->sharded(), KBO_E_UNSUPPORTED,
+                "intervals and the call mode need the rows of one index; this handle is a sharded index");
+    const uint32_t k = query_idx->host.k;
+    const size_t d = random_match_threshold(k, query_idx->host.n_kmers, 4, o.max_error_prob); // variant_calling.rs:260
+    CallClock clk;
+    // the second pass's values per site from the device (call_second_kernels.hip), where its q-mers can be at most as long as the
+    // threshold and positions fit its tables - and then the variants themselves (call_emit_kernels.hip)
+    static const int env_second = std::getenv("KBO_CALL_DEVICE_SECOND") ? std::atoi(std::getenv("KBO_CALL_DEVICE_SECOND")) : 1; // experiments
+    const bool env_slow = g_call_device_emit.load() == 0; // (tests, A / B: rounds 3 - 5's route for every slab)
+    const uint32_t second_q = (env_second && d >= 6 && d <= 255 && k <= 255 && k >= 2) ? (uint32_t)std::min<size_t>(12, d) : 0u;
+    var_offsets[0] = 0;
+    if (second_q && !env_slow && n_seqs > 0) call_fast(query_idx, concat, offsets, n_seqs, o, d, second_q, out, var_offsets, clk);
+    else {
+        std::vector<uint64_t> cnt(n_seqs);
+        call_slow(query_idx, concat, offsets, n_seqs, o, d, second_q, out, cnt.data());
+        for (size_t s = 0; s < n_seqs; s++) var_offsets[s + 1] = var_offsets[s] + cnt[s];
+    }
+    clk.lap("device passes + results");
+}
+
+} // namespace
+
+extern "C" int kbo_call_batch_flat(kbo_index_t *query_idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
+                                   const kbo_call_opts *opts, kbo_call_flat *result, uint64_t *var_offsets)
+{
+    return guarded([&] {
+        KBO_REQUIRE(result, KBO_E_BAD_ARG, "null argument");
+        std::memset(result, 0, sizeof(*result));
+        FlatCalls fc;
+        call_batch_flat_impl(query_idx, concat, offsets, n_seqs, opts, fc, var_offsets);
+        // one allocation: query_pos, query_len, ref_len, then the characters
+        const size_t nv = fc.pos.size(), nc = fc.chars.size();
+        const size_t a_pos = 0, a_ql = a_pos + std::max<size_t>(1, nv) * 4, a_rl = a_ql + std::max<size_t>(1, nv) * 2, a_ch = (a_rl + std::max<size_t>(1, nv) * 2 + 15) / 16 * 16;
+        uint8_t *mem = static_cast<uint8_t *>(std::malloc(a_ch + nc + 16));
+        if (!mem) throw std::bad_alloc();
+        uint32_t *pos = reinterpret_cast<uint32_t *>(mem + a_pos);
+        uint16_t *ql = reinterpret_cast<uint16_t *>(mem + a_ql), *rl = reinterpret_cast<uint16_t *>(mem + a_rl);
+        const size_t piece = 1u << 18;
+        HostTeam::get().run((nv + piece - 1) / piece, [&](size_t t) {
+            for (size_t v = t * piece; v < std::min(nv, (t + 1) * piece); v++) {
+                pos[v] = fc.pos[v];
+                ql[v] = (uint16_t)(fc.lens[v] & 0xFFFFu);
+                rl[v] = (uint16_t)(fc.lens[v] >> 16);
+            }
+        });
+        if (nc) HostTeam::get().copy(mem + a_ch, fc.chars.data(), nc);
+        result->n_variants = nv;
+        result->n_chars = nc;
+        result->query_pos = pos;
+        result->query_len = ql;
+        result->ref_len = rl;
+        result->chars = mem + a_ch;
+    });
+}
+
+extern "C" int kbo_set_call_device_emit(int on)
+{
+    g_call_device_emit = on != 0 ? 1 : 0;
+    return KBO_OK;
+}
+
+extern "C" void kbo_call_flat_free(kbo_call_flat *result)
+{
+    if (!result) return;
+    std::free(result->query_pos); // (one allocation: it starts there)
+    std::memset(result, 0, sizeof(*result));
+}
+
 extern "C" int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs,
                               const kbo_call_opts *opts, kbo_variant **out, uint64_t *var_offsets)
 {
     return guarded([&] {
-        KBO_REQUIRE(query_idx && out && var_offsets, KBO_E_BAD_ARG, "null argument");
+        KBO_REQUIRE(out, KBO_E_BAD_ARG, "null argument");
         *out = nullptr;
-        check_batch(concat, offsets, n_seqs);
-        kbo_call_opts o;
-        if (opts) o = *opts; else kbo_call_opts_default(&o);
-        KBO_REQUIRE(o.sbwt_build_opts.k == query_idx->host.k, KBO_E_K_MISMATCH,
-                    "assert!(sbwt_ref.k() == sbwt_query.k()) (lib.rs:559)");
-        KBO_REQUIRE(!query_idx->sharded(), KBO_E_UNSUPPORTED,
-                    "intervals and the call mode need the rows of one index; this handle is a sharded index");
-        const uint32_t k = query_idx->host.k;
-        const size_t d = random_match_threshold(k, query_idx->host.n_kmers, 4, o.max_error_prob); // variant_calling.rs:260
+        FlatCalls fc;
+        call_batch_flat_impl(query_idx, concat, offsets, n_seqs, opts, fc, var_offsets);
         CallClock clk;
-        // ---- first pass on the device (MS walk + breakpoint scan), the sites made ready and their windows gathered there
-        std::vector<size_t> part_seq0;
-        // the second pass's values per site from the device as well (call_second_kernels.hip), where its q-mers can be at most as
-        // long as the threshold and positions fit its tables; the host then only puts the variants together
-        static const int env_second = std::getenv("KBO_CALL_DEVICE_SECOND") ? std::atoi(std::getenv("KBO_CALL_DEVICE_SECOND")) : 1; // experiments
-        const uint32_t second_q = (env_second && d >= 6 && d <= 255 && k <= 255 && k >= 2) ? (uint32_t)std::min<size_t>(12, d) : 0u;
-        // ---- second pass, per sequence, on host threads that take a slab's sites as soon as its records are on the host - while the
-        // device walks the next slabs.  (The per-sequence index of lib.rs:553 is never built: its build depends on k and add_revcomp
-        // only, both checked above, so it cannot fail for one sequence and not for another; a sequence without sites yields no
-        // variants either way.)
-        struct Ref { uint32_t part, x; };
-        struct Call { uint32_t i; uint16_t q_from, q_len, r_from, r_len; Ref site; }; // characters: slices of the two k-mers
-        std::vector<std::vector<Call>> calls(n_seqs);
-        SiteWindows sw; // (declared in front of the pool: its parts outlive the tasks that read them)
-        const kbo::HostNav nav(query_idx->host);
-        const bool revcomp = o.sbwt_build_opts.add_revcomp != 0;
-        const uint32_t stride = kbo::call_gather_stride(k), kpad = (k + 15u) / 16u * 16u;
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)hw, (n_seqs + 15) / 16}));
-        AsyncPool pool(nt - 1u); // (the calling thread joins in wait())
-        struct PartOrder { // a part's sites by sequence: sequence s (of the part) has xs[first[s] .. first[s + 1])
-            std::vector<uint32_t> first, xs;
-        };
-        // the sequences [a, b) of a part
-        auto resolve_block = [&, k, d, stride, kpad, revcomp](const SiteWindows::Part *part, uint32_t part_index, size_t seq0,
-                                                                  std::shared_ptr<const PartOrder> po, size_t a, size_t b) {
-            const SiteRec *recs = part->recs.as<SiteRec>();
-            const uint32_t *codes = part->has_codes ? part->codes.as<uint32_t>() : nullptr;
-            RunAutomaton sam;
-            std::vector<uint32_t> dq(k), dr(k), mine;
-            std::vector<uint8_t> qk(k), rk_spelled;
-            for (size_t ls = a; ls < b; ls++) {
-                const size_t fa = po->first[ls], fb = po->first[ls + 1];
-                if (fa == fb) continue;
-                const size_t s = seq0 + ls;
-                const uint8_t *seq = concat + offsets[s];
-                const size_t len = (size_t)(offsets[s + 1] - offsets[s]);
-                mine.assign(po->xs.begin() + fa, po->xs.begin() + fb);
-                std::sort(mine.begin(), mine.end(), [&](uint32_t x, uint32_t y) { return recs[x].i < recs[y].i; });
-                std::vector<Call> &out_calls = calls[s];
-                out_calls.reserve(mine.size());
-                bool sam_built = false;
-                for (const uint32_t x : mine) {
-                    const SiteRec &r = recs[x];
-                    const Ref sr{part_index, x};
-                    const uint32_t code = codes ? codes[x] : 0x01FFFFFFu;
-                    if (!(code >> 24)) { // the device did this site: the common suffix and the two peaks are all resolve_variant reads
-                        const uint32_t rp = code & 0xFFu, qp = (code >> 8) & 0xFFu, csl = (code >> 16) & 0xFFu;
-                        size_t qf, qt, rf, rt;
-                        if (kbo::resolve_variant_peaks(k, csl, qp != 0xFFu, qp, rp != 0xFFu, rp, qf, qt, rf, rt))
-                            out_calls.push_back(Call{r.i, (uint16_t)qf, (uint16_t)(qt - qf), (uint16_t)rf, (uint16_t)(rt - rf), sr});
-                        continue;
-                    }
-                    if (!sam_built) { // (a site left to the host: the sequence's suffix automaton, once)
-                        sam.build(seq, len, k, revcomp);
-                        sam_built = true;
-                    }
-                    const uint8_t *w = part->win.as<uint8_t>() + (size_t)x * stride;
-                    // query-side k-mer (variant_calling.rs:46-58, 275) and its walk against the index (:279): the MS
-                    // values of the first pass, capped by the distance from the k-mer's (or the sequence's) first base
-                    for (uint32_t t = 0; t < k; t++) {
-                        const int64_t pos = (int64_t)r.j - (int64_t)(k - 1u) + t;
-                        if (pos < 0) { qk[t] = '$'; dr[t] = 0; continue; } // '$': the walk restarts behind it
-                        qk[t] = seq[pos];
-                        dr[t] = std::min<uint32_t>(w[t], (uint32_t)std::min<int64_t>(t + 1u, pos + 1));
-                    }
-                    // matched row's k-mer (:276): from the device's path cover, or spelled here when its window crosses a path start
-                    const uint8_t *rk = w + kpad;
-                    if (w[2u * kpad]) {
-                        nav.access_kmer(r.lo, rk_spelled);
-                        rk = rk_spelled.data();
-                    }
-                    sam.depths(rk, k, dq.data()); // its walk against the sequence's own index (:280)
-                    size_t qf, qt, rf, rt;
-                    if (kbo::resolve_variant_ranges(qk.data(), rk, dq.data(), dr.data(), k, d, qf, qt, rf, rt)) // :282-284
-                        out_calls.push_back(Call{r.i, (uint16_t)qf, (uint16_t)(qt - qf), (uint16_t)rf, (uint16_t)(rt - rf), sr});
-                }
-            }
-        };
-        // a part: its sites by sequence (counting sort; void records - sites of items the redo pass scanned again - dropped), then
-        // blocks of its sequences as tasks of their own
-        auto on_part = [&](SiteWindows::Part *part, uint32_t part_index, size_t seq0, size_t ns) {
-            if (part->n == 0 || pool.failed()) return;
-            pool.submit([&, part, part_index, seq0, ns] {
-                const SiteRec *recs = part->recs.as<SiteRec>();
-                auto po = std::make_shared<PartOrder>();
-                po->first.assign(ns + 1, 0);
-                size_t valid = 0;
-                for (size_t x = 0; x < part->n; x++)
-                    if (recs[x].seq != 0xFFFFFFFFu) { po->first[recs[x].seq + 1]++; valid++; }
-                for (size_t ls = 0; ls < ns; ls++) po->first[ls + 1] += po->first[ls];
-                po->xs.resize(valid);
-                {
-                    std::vector<uint32_t> fill(po->first.begin(), po->first.end() - 1);
-                    for (size_t x = 0; x < part->n; x++)
-                        if (recs[x].seq != 0xFFFFFFFFu) po->xs[fill[recs[x].seq]++] = (uint32_t)x;
-                }
-                const size_t block = 128;
-                std::shared_ptr<const PartOrder> cpo = po;
-                for (size_t a = 0; a < ns; a += block) {
-                    const size_t b = std::min(ns, a + block);
-                    if (po->first[a] == po->first[b]) continue;
-                    pool.submit([&, part, part_index, seq0, cpo, a, b] { resolve_block(part, part_index, seq0, cpo, a, b); });
-                }
-            });
-        };
-        find_sites(query_idx, concat, offsets, n_seqs, (uint32_t)d, part_seq0, second_q, revcomp, on_part, sw);
-        clk.lap("first pass (sites + windows; second pass of earlier slabs beside it)");
-        pool.wait();
-        clk.lap("second pass (what was left of it)");
-        // ---- one allocation: records, then the characters; filled by the host team, every sequence at its own offsets
-        var_offsets[0] = 0;
-        std::vector<size_t> char0(n_seqs + 1, 0);
-        for (size_t s = 0; s < n_seqs; s++) {
-            size_t ch = 0;
-            for (const Call &c : calls[s]) ch += c.q_len + c.r_len;
-            var_offsets[s + 1] = var_offsets[s] + calls[s].size();
-            char0[s + 1] = char0[s] + ch;
-        }
-        const size_t n_var = var_offsets[n_seqs], chars = char0[n_seqs];
-        const size_t head = std::max<size_t>(1, n_var) * sizeof(kbo_variant);
-        uint8_t *mem = static_cast<uint8_t *>(std::malloc(head + chars + 1));
+        // ---- the reference's records (variant_calling.rs:8-26): one allocation, the records, then the characters
+        const size_t nv = fc.pos.size(), nc = fc.chars.size();
+        const size_t head = std::max<size_t>(1, nv) * sizeof(kbo_variant);
+        uint8_t *mem = static_cast<uint8_t *>(std::malloc(head + nc + 1));
         if (!mem) throw std::bad_alloc();
         kbo_variant *rec = reinterpret_cast<kbo_variant *>(mem);
-        {
-            const kbo::HostNav nav(query_idx->host);
-            const size_t piece = 256;
-            HostTeam::get().run((n_seqs + piece - 1) / piece, [&](size_t task) {
-                std::vector<uint8_t> rk_spelled;
-                for (size_t s = task * piece; s < std::min(n_seqs, (task + 1) * piece); s++) {
-                    size_t w = var_offsets[s];
-                    uint8_t *cp = mem + head + char0[s];
-                    const uint8_t *seq = concat + offsets[s];
-                    for (const Call &c : calls[s]) {
-                        const SiteRec &r = sw.rec(c.site.part, c.site.x);
-                        const uint8_t *win = sw.win(c.site.part, c.site.x);
-                        rec[w].query_pos = c.i;
-                        rec[w].query_chars = cp;
-                        rec[w].query_len = c.q_len;
-                        for (uint32_t t = 0; t < c.q_len; t++) { // (a slice of the query-side k-mer: '$' in front of the sequence)
-                            const int64_t pos = (int64_t)r.j - (int64_t)(k - 1u) + c.q_from + t;
-                            *cp++ = pos < 0 ? (uint8_t)'$' : seq[pos];
-                        }
-                        rec[w].ref_chars = cp;
-                        rec[w].ref_len = c.r_len;
-                        const uint8_t *rk = win + sw.kpad;
-                        if (win[2u * sw.kpad] && c.r_len) {
-                            nav.access_kmer(r.lo, rk_spelled);
-                            rk = rk_spelled.data();
-                        }
-                        std::memcpy(cp, rk + c.r_from, c.r_len);
-                        cp += c.r_len;
-                        w++;
-                    }
-                }
-            });
-        }
+        if (nc) HostTeam::get().copy(mem + head, fc.chars.data(), nc);
+        // (where a variant's characters start: a running sum, by blocks)
+        const size_t piece = 1u << 16, nb = (nv + piece - 1) / piece;
+        std::vector<size_t> c0(nb + 1, 0);
+        HostTeam::get().run(nb, [&](size_t t) {
+            size_t sum = 0;
+            for (size_t v = t * piece; v < std::min(nv, (t + 1) * piece); v++) sum += (fc.lens[v] & 0xFFFFu) + (fc.lens[v] >> 16);
+            c0[t + 1] = sum;
+        });
+        for (size_t t = 0; t < nb; t++) c0[t + 1] += c0[t];
+        HostTeam::get().run(nb, [&](size_t t) {
+            const uint8_t *cp = mem + head + c0[t];
+            for (size_t v = t * piece; v < std::min(nv, (t + 1) * piece); v++) {
+                const uint32_t ql = fc.lens[v] & 0xFFFFu, rl = fc.lens[v] >> 16;
+                rec[v].query_pos = fc.pos[v];
+                rec[v].query_chars = cp;
+                rec[v].query_len = ql;
+                rec[v].ref_chars = cp + ql;
+                rec[v].ref_len = rl;
+                cp += ql + rl;
+            }
+        });
         *out = rec;
-        clk.lap("packing");
+        clk.lap("the reference's records");
     });
 }
 

@@ -131,12 +131,13 @@ __global__ __launch_bounds__(256) void call_depths_kernel(const uint4 *__restric
                                                           uint32_t kpad, uint32_t n_sites, const uint8_t *__restrict__ q,
                                                           const uint64_t *__restrict__ off, uint32_t k, uint32_t thr, uint32_t qlen,
                                                           uint32_t revcomp, const uint64_t *__restrict__ tab_off, const uint32_t *__restrict__ tab,
-                                                          const uint8_t *__restrict__ seq_flag, uint32_t *__restrict__ out)
+                                                          const uint8_t *__restrict__ seq_flag, uint32_t *__restrict__ out,
+                                                          const uint32_t *__restrict__ n_dev)
 {
     __shared__ uint8_t lds[4][3 * kCallMaxK];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t x = blockIdx.x * 4u + wv;
-    if (x >= n_sites) return;
+    if (x >= (n_dev ? min(*n_dev, n_sites) : n_sites)) return;
     const uint4 rec = recs[x];
     if (rec.x == 0xFFFFFFFFu) { // a void record (an item the redo pass scanned again)
         if (lane == 0) out[x] = 0xFFFFFFFFu;
@@ -260,13 +261,13 @@ hipError_t launch_call_qmer_index(const uint8_t *d_q, const uint64_t *d_off, uin
 
 hipError_t launch_call_depths(const void *d_recs, const uint8_t *d_win, uint32_t stride, uint32_t n_sites, const uint8_t *d_q,
                               const uint64_t *d_off, uint32_t k, uint32_t thr, uint32_t qlen, bool revcomp, const uint64_t *d_tab_off,
-                              const uint32_t *d_tab, const uint8_t *d_seq_flag, uint32_t *d_out, hipStream_t stream)
+                              const uint32_t *d_tab, const uint8_t *d_seq_flag, uint32_t *d_out, hipStream_t stream, const uint32_t *d_n_sites)
 {
     if (n_sites == 0) return hipSuccess;
     if (k > kCallMaxK - 1u || k < 2u) return hipErrorInvalidValue;
     const uint32_t kpad = (k + 15u) / 16u * 16u;
     hipLaunchKernelGGL(call_depths_kernel, dim3((n_sites + 3u) / 4u), dim3(256), 0, stream, static_cast<const uint4 *>(d_recs), d_win, stride, kpad,
-                       n_sites, d_q, d_off, k, thr, qlen, revcomp ? 1u : 0u, d_tab_off, d_tab, d_seq_flag, d_out);
+                       n_sites, d_q, d_off, k, thr, qlen, revcomp ? 1u : 0u, d_tab_off, d_tab, d_seq_flag, d_out, d_n_sites);
     return hipGetLastError();
 }
 

@@ -333,10 +333,43 @@ hipError_t launch_call_qmer_index(const uint8_t *d_q, const uint64_t *d_off, uin
                                   uint32_t *d_tab, uint8_t *d_seq_flag, uint64_t total_slots, uint32_t max_slots, hipStream_t stream);
 hipError_t launch_call_depths(const void *d_recs, const uint8_t *d_win, uint32_t stride, uint32_t n_sites, const uint8_t *d_q,
                               const uint64_t *d_off, uint32_t k, uint32_t thr, uint32_t qlen, bool revcomp, const uint64_t *d_tab_off,
-                              const uint32_t *d_tab, const uint8_t *d_seq_flag, uint32_t *d_out, hipStream_t stream);
+                              const uint32_t *d_tab, const uint8_t *d_seq_flag, uint32_t *d_out, hipStream_t stream,
+                              const uint32_t *d_n_sites = nullptr /* the number of sites on the device (n_sites then bounds it) */);
 hipError_t launch_call_finalize(const void *d_lists, const uint32_t *d_counts, const uint32_t *d_prefix, uint32_t seg_cap, uint32_t max_count,
                                 bool by_walk, const uint64_t *d_off, uint32_t n_seqs, uint32_t k, const uint8_t *d_ms,
                                 const DevIndexView &ix, void *d_recs, uint8_t *d_win, uint32_t stride, hipStream_t stream);
+
+// ---- the tail of kbo::call on the device (call_emit_kernels.hip): the variants of a slab's sites in the order of (sequence, query
+// position), as flat arrays.  d_meta: kCallMetaWords words
+constexpr uint32_t kCallMetaSites = 0, kCallMetaValid = 1, kCallMetaVariants = 2, kCallMetaChars = 3, kCallMetaHost = 4, kCallMetaFlags = 5,
+                   kCallMetaWorst = 6, kCallMetaWords = 16;
+constexpr uint32_t kCallMaxRank = 4096;          // sites of one sequence the device puts in order itself (more: the host's)
+constexpr uint32_t kCallNoVariant = 0xFFFFFFFFu; // per-site word: Err(ResolveVariantErr)
+constexpr uint32_t kCallHostSite = 0xFFFFFFFEu;  // ... left to the host
+struct CallEmitArgs {
+    const uint4 *recs;       // call_finalize_kernel's records {sequence, i, j, row}; first word ~0 = void
+    const uint32_t *codes;   // call_depths_kernel's word per site
+    const uint8_t *win;      // ... and windows (row characters at kpad)
+    uint32_t stride, kpad, k;
+    const uint8_t *q;        // the slab's bases
+    const uint64_t *off;     // ... and offsets
+    uint32_t n_seqs;
+    const uint32_t *n_sites; // on the device: d_prefix[kCallSegs]
+    uint32_t cap;            // what bounds it
+    uint32_t *seq_cnt, *seq_sums, *seq_fill; // n_seqs + 1 (+ scan sums), n_seqs
+    uint32_t *bucket, *bkey, *sorted, *vrec; // cap each
+    uint32_t *vcnt, *vsums, *ccnt, *csums;   // cap + 1 (+ scan sums) each
+    uint32_t *out_pos, *out_lens;            // cap: query_pos; query_len | ref_len << 16
+    uint8_t *out_chars;
+    uint32_t chars_cap;
+    uint32_t *seq_vfirst;    // n_seqs + 1: variants in front of every sequence
+    uint32_t *host_list;     // sites left to the host (indices into recs), host_cap of them at most
+    uint32_t host_cap;
+    uint32_t *meta;
+};
+inline size_t call_scan_sums_words(size_t n) { return (n + 1023) / 1024 + 1; }
+hipError_t launch_call_prefix(const uint32_t *d_counts, uint32_t seg_cap, uint32_t *d_prefix /* kCallSegs + 1 */, uint32_t *d_meta, hipStream_t stream);
+hipError_t launch_call_emit(const CallEmitArgs &a, void *d_host_recs, uint8_t *d_host_win, hipStream_t stream);
 
 // 2-bit packed reads in / packed alignments out (pack_kernels.hip): sequence s occupies ceil(len / 16) u32 words, base i in
 // bits 2 (i mod 16) of word i / 16.  uniform_wps != 0: all sequences have that many words (no prefix needed); otherwise

@@ -408,6 +408,22 @@ def test_call_batch_equals_per_sequence_call(oracle):
         n_var += len(mine)
     assert n_var > 100
     assert all(len(got[s]) == 0 for s in range(0, len(reads), 7))
+    # the flat form (kbo_call_batch_flat: what the device's tail writes, plus - for the reads with N - the host's sites merged in by
+    # query position) and rounds 3 - 5's route (every site to the host: kbo_set_call_device_emit(0)) give the same variants
+    def as_lists(res):
+        return [batch.variants_of(res, s) for s in range(len(reads))]
+    want = [[(v.query_pos, bytes(v.query_chars), bytes(v.ref_chars)) for v in got[s]] for s in range(len(reads))]
+    flat = batch.call_batch_arrays(sbwt, concat, offsets, opts)
+    assert as_lists(flat) == want and int(flat["var_offsets"][-1]) == n_var
+    try:
+        kbo_amd.lib().kbo_set_call_device_emit(0)
+        assert as_lists(batch.call_batch_arrays(sbwt, concat, offsets, opts)) == want
+    finally:
+        kbo_amd.lib().kbo_set_call_device_emit(1)
+    # ... and slabs cut everywhere (64 KiB: a few reads each, the two slots taking them in turn)
+    sbwt.set_opts(slab_bytes=64 << 10)
+    assert as_lists(batch.call_batch_arrays(sbwt, concat, offsets, opts)) == want
+    sbwt.set_opts(slab_bytes=0)
     # the sequence's own index with its reverse complements (CallOpts.sbwt_build_opts.add_revcomp): the batch - the device's second
     # pass looks the reverse strand up in the same tables - against the single-sequence entry point, which builds that index
     opts_rc = kbo_amd.CallOpts(sbwt_build_opts=kbo_amd.BuildOpts(k=k, build_select=True, add_revcomp=True))
