@@ -52,6 +52,7 @@ def parse(argv=None):
     ap.add_argument("--call", action="store_true",
                     help="time the first pass of kbo call (C5 shape, scaled): MS walk with intervals + the breakpoint scan "
                          "on the device over 10 kbp reads (defaults: --genome 100000000 --reads 10000 --read-len 10000)")
+    ap.add_argument("--no-whole-call", action="store_true", help="--call / --config C5: the first pass only (profiler passes)")
     ap.add_argument("--no-plan", action="store_true", help="plain walk kernel only (no path cover, no plan-guided walk)")
     ap.add_argument("--two-kernels", action="store_true", help="kbo_ms_batch_dev + kbo_derand_translate_dev instead of kbo_map_batch_dev "
                     "(the MS values of every base go through HBM)")

@@ -227,7 +227,7 @@ int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, const uint64_t
  * (call_emit_kernels.hip: the device sorts a slab's sites, runs resolve_variant's case analysis, variant_calling.rs:139-201, and slices
  * the characters; 10 bytes per variant cross PCIe instead of 164 per site): no record with two pointers per variant to fill, nothing for
  * a binding to copy.  Variant v of sequence s (v in [var_offsets[s], var_offsets[s + 1])) has query_pos[v], query_len[v] query characters
- * followed by ref_len[v] reference characters in `chars`, the variants' characters back to back in variant order.  One allocation:
+ * followed by ref_len[v] reference characters in `chars`, the variants' characters back to back in variant order.  Released by
  * kbo_call_flat_free(result).  kbo_call_batch is this + the reference's records made from it. */
 typedef struct {
     uint64_t n_variants, n_chars;

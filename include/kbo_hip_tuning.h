@@ -139,7 +139,8 @@ int kbo_set_map_long(int mode);
 int kbo_set_ms_one_kernel(int on);
 /* kbo_call_batch[_flat]: 1 (default) = the variants are put in order, resolved and sliced on the device (call_emit_kernels.hip: two slots
  * on two streams, ten bytes per variant over PCIe); 0 = rounds 3 - 5's route for every slab (a record + a window per site to the host,
- * host threads sort, resolve and slice) - what the default falls back to for a slab it cannot finish; same results (tests). */
+ * host threads sort, resolve and slice) - what the default falls back to for a slab it cannot finish; 2 = as 1, but the second pass's
+ * depths for k <= 64 by the kernel that serves k > 64 (call_second_kernels.hip: every lane extends its own matches); same results (tests). */
 int kbo_set_call_device_emit(int on);
 /* inspection: what the last kbo_map_batch_dev / kbo_find_batch_dev call over sequences of more than 160 bases did when it took
  * the one kernel for sequences of any length (long_kernels.hip); arguments as for that call, synchronises `stream`.

@@ -367,9 +367,42 @@ namespace {
 
 // The variants of a batch as they leave the library's inside: flat arrays in the order of (sequence, query position) - what
 // kbo_call_batch_flat hands out as it is and kbo_call_batch turns into the reference's records (variant_calling.rs:8-26).
+template <typename T> struct GrowBuf { // a vector whose storage can be handed to the caller (malloc / realloc; kbo_call_flat_free)
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    GrowBuf() = default;
+    GrowBuf(const GrowBuf &) = delete;
+    GrowBuf &operator=(const GrowBuf &) = delete;
+    ~GrowBuf() { std::free(p); }
+    size_t size() const { return n; }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    void reserve(size_t want)
+    {
+        if (want <= cap) return;
+        const size_t c = std::max<size_t>({want, cap + cap / 2, 1024});
+        T *q = static_cast<T *>(std::realloc(p, c * sizeof(T)));
+        if (!q) throw std::bad_alloc();
+        p = q;
+        cap = c;
+    }
+    void resize(size_t m) { reserve(m); n = m; }
+    void push_back(const T &v) { reserve(n + 1); p[n++] = v; }
+    void append(const T *a, const T *b) { reserve(n + (size_t)(b - a)); std::memcpy(p + n, a, (size_t)(b - a) * sizeof(T)); n += (size_t)(b - a); }
+    T *release() { T *q = p; p = nullptr; n = cap = 0; return q; }
+};
 struct FlatCalls {
-    std::vector<uint32_t> pos, lens; // lens = query_len | ref_len << 16
-    std::vector<uint8_t> chars;      // per variant its query characters, then its reference characters
+    GrowBuf<uint32_t> pos;
+    GrowBuf<uint16_t> qlen, rlen;
+    GrowBuf<uint8_t> chars; // per variant its query characters, then its reference characters
+    void push(uint32_t at, uint32_t ql, uint32_t rl)
+    {
+        pos.push_back(at);
+        qlen.push_back((uint16_t)ql);
+        rlen.push_back((uint16_t)rl);
+    }
 };
 
 // ---- the route of rounds 3 - 5, now the fall-back for a slab the device cannot finish by itself (a lane of the walk's call mode with
@@ -494,7 +527,8 @@ void call_slow(kbo_index *query_idx, const uint8_t *concat, const uint64_t *offs
     }
     const size_t vb = out.pos.size(), cb = out.chars.size();
     out.pos.resize(vb + v0[n_seqs]);
-    out.lens.resize(vb + v0[n_seqs]);
+    out.qlen.resize(vb + v0[n_seqs]);
+    out.rlen.resize(vb + v0[n_seqs]);
     out.chars.resize(cb + c0[n_seqs]);
     const size_t piece = 256;
     HostTeam::get().run((n_seqs + piece - 1) / piece, [&](size_t task) {
@@ -507,7 +541,8 @@ void call_slow(kbo_index *query_idx, const uint8_t *concat, const uint64_t *offs
                 const SiteRec &r = sw.rec(c.site.part, c.site.x);
                 const uint8_t *win = sw.win(c.site.part, c.site.x);
                 out.pos[w] = c.i;
-                out.lens[w] = (uint32_t)c.q_len | ((uint32_t)c.r_len << 16);
+                out.qlen[w] = c.q_len;
+                out.rlen[w] = c.r_len;
                 for (uint32_t t = 0; t < c.q_len; t++) { // (a slice of the query-side k-mer: '$' in front of the sequence)
                     const int64_t pos = (int64_t)r.j - (int64_t)(k - 1u) + c.q_from + t;
                     *cp++ = pos < 0 ? (uint8_t)'$' : seq[pos];
@@ -524,6 +559,8 @@ void call_slow(kbo_index *query_idx, const uint8_t *concat, const uint64_t *offs
         }
     });
 }
+
+std::atomic<int> g_call_device_emit{1}; // kbo_set_call_device_emit: 0 = the slow route for every slab, 2 = call_depths_kernel for k <= 64 too
 
 // ---- kbo::call over a batch, the device's way: two slots of buffers on two streams take the slabs in turn; per slab ONE small read-back
 // (sixteen words: how many sites, variants, characters, sites for the host; did a list overflow) decides what is downloaded - the
@@ -646,7 +683,7 @@ void call_fast(kbo_index *query_idx, const uint8_t *concat, const uint64_t *offs
         const uint32_t *d_n = S.d_prefix.as<uint32_t>() + kbo::kCallSegs;
         HIP_OK(kbo::launch_call_depths(S.d_recs.p, S.d_win.as<uint8_t>(), stride, cap, S.B.q.as<uint8_t>(), S.B.off.as<uint64_t>(), k, (uint32_t)d,
                                        second_q, revcomp, S.d_tab_off.as<uint64_t>(), S.d_tab.as<uint32_t>(), S.d_seq_flag.as<uint8_t>(),
-                                       S.d_codes.as<uint32_t>(), st, d_n));
+                                       S.d_codes.as<uint32_t>(), st, d_n, g_call_device_emit.load() == 2));
         kbo::CallEmitArgs a{};
         a.recs = S.d_recs.as<uint4>();
         a.codes = S.d_codes.as<uint32_t>();
@@ -747,12 +784,25 @@ void call_fast(kbo_index *query_idx, const uint8_t *concat, const uint64_t *offs
         const size_t vb = out.pos.size(), cb = out.chars.size();
         if (S.n_host == 0) {
             out.pos.resize(vb + S.n_var);
-            out.lens.resize(vb + S.n_var);
+            out.qlen.resize(vb + S.n_var);
+            out.rlen.resize(vb + S.n_var);
             out.chars.resize(cb + S.n_chars);
             if (S.n_var) {
-                team.copy(out.pos.data() + vb, dpos, (size_t)S.n_var * 4);
-                team.copy(out.lens.data() + vb, dlens, (size_t)S.n_var * 4);
-                if (S.n_chars) team.copy(out.chars.data() + cb, dchars, S.n_chars);
+                const size_t piece = 1u << 16, n_tasks = ((size_t)S.n_var + piece - 1) / piece;
+                uint32_t *op = out.pos.data() + vb;
+                uint16_t *oq = out.qlen.data() + vb, *orl = out.rlen.data() + vb;
+                uint8_t *oc = out.chars.data() + cb;
+                const size_t nv = S.n_var, nc = S.n_chars;
+                team.run(n_tasks, [&](size_t t) { // (out of pinned memory into the result's own arrays, the lengths apart on the way)
+                    const size_t a = t * piece, b = std::min(nv, a + piece);
+                    std::memcpy(op + a, dpos + a, (b - a) * 4);
+                    for (size_t v = a; v < b; v++) {
+                        oq[v] = (uint16_t)(dlens[v] & 0xFFFFu);
+                        orl[v] = (uint16_t)(dlens[v] >> 16);
+                    }
+                    const size_t ca = nc * a / nv, cbb = nc * b / nv; // (the characters by the same shares: any split will do)
+                    std::memcpy(oc + ca, dchars + ca, cbb - ca);
+                });
             }
             const uint64_t base = var_offsets[sl.s0];
             for (size_t s = 0; s < S.ns; s++) var_offsets[sl.s0 + s + 1] = base + vfirst[s + 1];
@@ -775,9 +825,8 @@ void call_fast(kbo_index *query_idx, const uint8_t *concat, const uint64_t *offs
             auto device_upto = [&](size_t v_end) { // the device's variants [dv, v_end) as they are
                 for (; dv < v_end; dv++) {
                     const uint32_t l = dlens[dv], n = (l & 0xFFFFu) + (l >> 16);
-                    out.pos.push_back(dpos[dv]);
-                    out.lens.push_back(l);
-                    out.chars.insert(out.chars.end(), dchars + dc, dchars + dc + n);
+                    out.push(dpos[dv], l & 0xFFFFu, l >> 16);
+                    out.chars.append(dchars + dc, dchars + dc + n);
                     dc += n;
                 }
             };
@@ -807,10 +856,9 @@ void call_fast(kbo_index *query_idx, const uint8_t *concat, const uint64_t *offs
                         size_t qf, qt, rf, rt;
                         if (!kbo::resolve_variant_ranges(qk.data(), rk, dq.data(), dr.data(), k, d, qf, qt, rf, rt)) continue;
                         while (dv < v_end && dpos[dv] < r.i) device_upto(dv + 1); // the device's variants in front of this one
-                        out.pos.push_back(r.i);
-                        out.lens.push_back((uint32_t)(qt - qf) | ((uint32_t)(rt - rf) << 16));
-                        out.chars.insert(out.chars.end(), qk.data() + qf, qk.data() + qt);
-                        out.chars.insert(out.chars.end(), rk + rf, rk + rt);
+                        out.push(r.i, (uint32_t)(qt - qf), (uint32_t)(rt - rf));
+                        out.chars.append(qk.data() + qf, qk.data() + qt);
+                        out.chars.append(rk + rf, rk + rt);
                     }
                     device_upto(v_end);
                 } else
@@ -835,8 +883,6 @@ void call_fast(kbo_index *query_idx, const uint8_t *concat, const uint64_t *offs
         std::fprintf(stderr, "[kbo timing] call: %zu slabs: staging %.1f ms, enqueue %.1f, waiting for the device %.1f, taking results %.1f, slow route %.1f (%zu slabs); %zu sites resolved on the host\n",
                      slabs.size(), t_stage, t_enq, t_wait, t_take, t_slow, n_slow, n_host_sites);
 }
-
-std::atomic<int> g_call_device_emit{1}; // kbo_set_call_device_emit
 
 // both entry points: checks, threshold, the route
 void call_batch_flat_impl(kbo_index_t *query_idx, const uint8_t *concat, const uint64_t *offsets, size_t n_seqs, const kbo_call_opts *opts,
@@ -877,41 +923,34 @@ extern "C" int kbo_call_batch_flat(kbo_index_t *query_idx, const uint8_t *concat
         std::memset(result, 0, sizeof(*result));
         FlatCalls fc;
         call_batch_flat_impl(query_idx, concat, offsets, n_seqs, opts, fc, var_offsets);
-        // one allocation: query_pos, query_len, ref_len, then the characters
+        // (the result's arrays are the ones the slabs' variants were put into: nothing is copied again)
         const size_t nv = fc.pos.size(), nc = fc.chars.size();
-        const size_t a_pos = 0, a_ql = a_pos + std::max<size_t>(1, nv) * 4, a_rl = a_ql + std::max<size_t>(1, nv) * 2, a_ch = (a_rl + std::max<size_t>(1, nv) * 2 + 15) / 16 * 16;
-        uint8_t *mem = static_cast<uint8_t *>(std::malloc(a_ch + nc + 16));
-        if (!mem) throw std::bad_alloc();
-        uint32_t *pos = reinterpret_cast<uint32_t *>(mem + a_pos);
-        uint16_t *ql = reinterpret_cast<uint16_t *>(mem + a_ql), *rl = reinterpret_cast<uint16_t *>(mem + a_rl);
-        const size_t piece = 1u << 18;
-        HostTeam::get().run((nv + piece - 1) / piece, [&](size_t t) {
-            for (size_t v = t * piece; v < std::min(nv, (t + 1) * piece); v++) {
-                pos[v] = fc.pos[v];
-                ql[v] = (uint16_t)(fc.lens[v] & 0xFFFFu);
-                rl[v] = (uint16_t)(fc.lens[v] >> 16);
-            }
-        });
-        if (nc) HostTeam::get().copy(mem + a_ch, fc.chars.data(), nc);
+        fc.pos.reserve(1);
+        fc.qlen.reserve(1);
+        fc.rlen.reserve(1);
+        fc.chars.reserve(1);
         result->n_variants = nv;
         result->n_chars = nc;
-        result->query_pos = pos;
-        result->query_len = ql;
-        result->ref_len = rl;
-        result->chars = mem + a_ch;
+        result->query_pos = fc.pos.release();
+        result->query_len = fc.qlen.release();
+        result->ref_len = fc.rlen.release();
+        result->chars = fc.chars.release();
     });
 }
 
 extern "C" int kbo_set_call_device_emit(int on)
 {
-    g_call_device_emit = on != 0 ? 1 : 0;
+    g_call_device_emit = on < 0 || on > 2 ? 1 : on;
     return KBO_OK;
 }
 
 extern "C" void kbo_call_flat_free(kbo_call_flat *result)
 {
     if (!result) return;
-    std::free(result->query_pos); // (one allocation: it starts there)
+    std::free(result->query_pos);
+    std::free(result->query_len);
+    std::free(result->ref_len);
+    std::free(result->chars);
     std::memset(result, 0, sizeof(*result));
 }
 
@@ -936,14 +975,14 @@ extern "C" int kbo_call_batch(kbo_index_t *query_idx, const uint8_t *concat, con
         std::vector<size_t> c0(nb + 1, 0);
         HostTeam::get().run(nb, [&](size_t t) {
             size_t sum = 0;
-            for (size_t v = t * piece; v < std::min(nv, (t + 1) * piece); v++) sum += (fc.lens[v] & 0xFFFFu) + (fc.lens[v] >> 16);
+            for (size_t v = t * piece; v < std::min(nv, (t + 1) * piece); v++) sum += (size_t)fc.qlen[v] + fc.rlen[v];
             c0[t + 1] = sum;
         });
         for (size_t t = 0; t < nb; t++) c0[t + 1] += c0[t];
         HostTeam::get().run(nb, [&](size_t t) {
             const uint8_t *cp = mem + head + c0[t];
             for (size_t v = t * piece; v < std::min(nv, (t + 1) * piece); v++) {
-                const uint32_t ql = fc.lens[v] & 0xFFFFu, rl = fc.lens[v] >> 16;
+                const uint32_t ql = fc.qlen[v], rl = fc.rlen[v];
                 rec[v].query_pos = fc.pos[v];
                 rec[v].query_chars = cp;
                 rec[v].query_len = ql;

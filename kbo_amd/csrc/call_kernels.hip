@@ -11,6 +11,8 @@
 // atomic per wave; the host sorts them by (sequence, i).  Integer work only.
 #include "device_util.hpp"
 
+#include <algorithm>
+
 namespace kbo {
 namespace {
 
@@ -92,13 +94,14 @@ __global__ __launch_bounds__(256) void call_finalize_kernel(const uint4 *__restr
                                                             const uint8_t *__restrict__ ms, DevIndexView ix, uint4 *__restrict__ out_recs,
                                                             uint8_t *__restrict__ out_win, uint32_t stride)
 {
-    const uint32_t g = blockIdx.y, slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
-    if (slot >= min(counts[g * 16u], seg_cap)) return;
+    const uint32_t g = blockIdx.y, lane = threadIdx.x & 63u;
+    // (the grid strides over the list: its length is only known here)
+    for (uint32_t slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; slot < min(counts[g * 16u], seg_cap); slot += (gridDim.x * blockDim.x) >> 6) {
     const uint32_t x = prefix[g] + slot;
     const uint4 v = lists[(size_t)g * seg_cap + slot];
     if (by_walk && v.x == 0xFFFFFFFFu) {
         if (lane == 0) out_recs[x] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
-        return;
+        continue;
     }
     uint32_t seq = v.x, j_off = 0, row = 0;
     uint4 rec;
@@ -141,6 +144,7 @@ __global__ __launch_bounds__(256) void call_finalize_kernel(const uint4 *__restr
     }
     const bool any_broken = __ballot(broken) != 0;
     if (lane == 0) w[2u * kpad] = any_broken ? 1 : 0;
+    }
 }
 
 } // namespace
@@ -151,7 +155,7 @@ hipError_t launch_call_finalize(const void *d_lists, const uint32_t *d_counts, c
 {
     if (max_count == 0) return hipSuccess;
     const uint32_t kpad = (k + 15u) / 16u * 16u;
-    hipLaunchKernelGGL(call_finalize_kernel, dim3((max_count + 3u) / 4u, kCallSegs), dim3(256), 0, stream, static_cast<const uint4 *>(d_lists),
+    hipLaunchKernelGGL(call_finalize_kernel, dim3(std::min((max_count + 3u) / 4u, 32u), kCallSegs), dim3(256), 0, stream, static_cast<const uint4 *>(d_lists),
                        d_counts, d_prefix, seg_cap, by_walk ? 1u : 0u, d_off, n_seqs, k, kpad, d_ms, ix, static_cast<uint4 *>(d_recs), d_win,
                        stride);
     return hipGetLastError();

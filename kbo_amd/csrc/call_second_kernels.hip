@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 
 namespace kbo {
 namespace {
@@ -45,15 +46,13 @@ __device__ __forceinline__ bool index_sequence(const uint8_t *r, uint32_t len, u
     // four start positions per lane and round: the 16 bases from the first of them on as 2-bit digits, then one shift per q-mer
     const uint32_t mask = size - 1u;
     for (uint32_t st0 = 4u * threadIdx.x; st0 < len; st0 += 4u * blockDim.x) {
-        uint64_t digits = 0;  // base st0 + m in bits 2 (15 - m)
-        uint32_t invalid = 0; // bit m: base st0 + m is no base (or lies behind the sequence)
-#pragma unroll
-        for (uint32_t m = 0; m < 16u; m++) {
-            const uint32_t c = st0 + m < len ? base_code(r[st0 + m]) : 4u;
-            digits = (digits << 2) | (c & 3u);
-            invalid |= (c > 3u ? 1u : 0u) << m;
-            if (st0 + m < len && c > 3u) mine_bad = true;
-        }
+        // (one unaligned 16-byte load - the slab's bases are padded by 16 - and pack16 instead of 16 byte loads and compare chains)
+        uint32_t code16, valid;
+        pack16(ld16u(r, st0), code16, valid);
+        const uint32_t inside = len - st0 >= 16u ? 0xFFFFu : (1u << (len - st0)) - 1u;
+        const uint64_t digits = code16;                        // base st0 + m in bits 2 (15 - m)
+        const uint32_t invalid = (~valid | ~inside) & 0xFFFFu; // bit m: base st0 + m is no base (or lies behind the sequence)
+        if (~valid & inside) mine_bad = true;
         const uint32_t span = (1u << qlen) - 1u;
 #pragma unroll
         for (uint32_t v4 = 0; v4 < 4u; v4++) {
@@ -237,6 +236,136 @@ __global__ __launch_bounds__(256) void call_depths_kernel(const uint4 *__restric
     if (lane == 0) out[x] = rpeak | (qpeak << 8) | (min(csl, 255u) << 16);
 }
 
+
+// The same for k <= 64 (what kbo is run with: 31, 51, 63): a lane per position of the k-mer as above, but an occurrence's match is not
+// extended base by base by its lane - up to t dependent byte loads from the sequence per lane, 1 900 a site - but read off its DIAGONAL:
+// the lanes whose q-mers were found on one diagonal of (k-mer position, sequence position) - nearly all of a site's, the k-mer being
+// a copy of the sequence around the variant - share one 64-bit mask of the positions where k-mer and sequence agree on it (one
+// coalesced read of k bases + a ballot), and a lane's match is the run of ones that ends at its bit.  The reverse strand the same on
+// anti-diagonals (the complement of rk[u] at s - u).  Same words as call_depths_kernel (tests run both on k = 51).
+__device__ __forceinline__ void depths64_site(uint32_t x, uint32_t lane, uint8_t *rk, const uint4 *__restrict__ recs, const uint8_t *__restrict__ win,
+                                              uint32_t stride, uint32_t kpad, const uint8_t *__restrict__ q, const uint64_t *__restrict__ off, uint32_t k,
+                                              uint32_t thr, uint32_t qlen, uint32_t revcomp, const uint64_t *__restrict__ tab_off,
+                                              const uint32_t *__restrict__ tab, const uint8_t *__restrict__ seq_flag, uint32_t *__restrict__ out)
+{
+    const uint4 rec = recs[x];
+    if (rec.x == 0xFFFFFFFFu) { // a void record (an item the redo pass scanned again)
+        if (lane == 0) out[x] = 0xFFFFFFFFu;
+        return;
+    }
+    uint8_t *dq = rk + 64, *dr = dq + 64;
+    const uint8_t *w = win + (size_t)x * stride;
+    const uint64_t b0 = off[rec.x];
+    const uint32_t len = (uint32_t)(off[rec.x + 1] - b0), j = rec.z;
+    const uint8_t *r = q + b0;
+    const uint32_t t = lane;
+    // the row's k-mer, the query-side walk's depths and where the two k-mers differ (as above)
+    uint32_t my_ch = 0, my_code = 4u;
+    bool differ = false;
+    if (t < k) {
+        my_ch = w[kpad + t];
+        my_code = base_code(my_ch);
+        rk[t] = (uint8_t)my_ch;
+        const int64_t pos = (int64_t)j - (int64_t)(k - 1u) + t;
+        uint32_t qc = '$', dv = 0;
+        if (pos >= 0) {
+            qc = r[pos];
+            dv = min((uint32_t)w[t], (uint32_t)min((int64_t)(t + 1u), pos + 1));
+        }
+        dr[t] = (uint8_t)dv;
+        differ = qc != my_ch;
+    }
+    const uint64_t dm = __ballot(differ);
+    const uint32_t hi_diff = dm ? 63u - (uint32_t)__builtin_clzll(dm) : 0xFFFFFFFFu;
+    const bool bad = __ballot(t < k && my_code > 3u) != 0;
+    const uint32_t flag_w = w[2u * kpad];
+    const uint64_t tb0 = tab_off[rec.x];
+    const uint32_t size = (uint32_t)(tab_off[rec.x + 1] - tb0);
+    const bool host_site = bad || flag_w != 0 || seq_flag[rec.x] != 0 || (size == 0 && len >= k);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (host_site) {
+        if (lane == 0) out[x] = 0x01FFFFFFu;
+        return;
+    }
+    const uint32_t mask = size ? size - 1u : 0u;
+    const uint32_t *tb = tab + tb0;
+    uint32_t best = 0;
+    const bool looks = t < k && t + 1u >= qlen && len >= k; // (a sequence shorter than k has no k-mer: its index holds nothing)
+    uint32_t code = 0, rcode = 0;
+    if (looks)
+        for (uint32_t m = 0; m < qlen; m++) {
+            const uint32_t c = base_code(rk[t + 1u - qlen + m]);
+            code = (code << 2) | c;
+            rcode |= (3u - c) << (2u * m); // reverse complement: the last base's complement first
+        }
+    for (uint32_t strand = 0; strand < (revcomp ? 2u : 1u); strand++) {
+        const uint32_t cd = strand ? rcode : code, tag = qmer_tag(cd);
+        uint32_t h = qmer_slot(cd, mask);
+        bool probing = looks;
+        while (__ballot(probing)) {
+            // every lane on to its next occurrence by tag (or the end of its chain)
+            bool cand = false;
+            int32_t diag = 0; // forward: sequence position of rk[0]; reverse: of rk[0]'s complement
+            while (probing && !cand) {
+                const uint32_t v = tb[h];
+                h = (h + 1u) & mask;
+                if (v == 0) probing = false;
+                else if ((v >> 20) == tag) {
+                    const uint32_t st = (v & 0xFFFFFu) - 1u;
+                    diag = strand ? (int32_t)(st + t) : (int32_t)st - (int32_t)(t + 1u - qlen);
+                    cand = true;
+                }
+            }
+            // the occurrences found, diagonal by diagonal
+            uint64_t pending = __ballot(cand);
+            while (pending) {
+                const uint32_t leader = (uint32_t)__builtin_ctzll(pending);
+                const int32_t dg = __shfl(diag, (int)leader);
+                const int64_t sp = strand ? (int64_t)dg - (int64_t)t : (int64_t)dg + (int64_t)t; // where this lane's k-mer base stands on it
+                bool eq = false;
+                if (t < k && sp >= 0 && sp < (int64_t)len) {
+                    const uint32_t c = base_code(r[sp]);
+                    eq = strand ? c + my_code == 3u : c == my_code;
+                }
+                const uint64_t M = __ballot(eq);
+                const bool mine = cand && diag == dg;
+                if (mine) {
+                    const uint64_t inv = ~(M << (63u - t)); // bit 63 = position t, downwards
+                    const uint32_t L = inv ? (uint32_t)__builtin_clzll(inv) : 64u;
+                    if (L >= qlen) best = max(best, L); // (shorter: the tag matched another q-mer)
+                }
+                pending &= ~__ballot(mine);
+            }
+        }
+    }
+    if (t < k) dq[t] = (uint8_t)min(best, k);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t rpeak = rightmost_peak(dq, k, thr, lane), qpeak = rightmost_peak(dr, k, thr, lane);
+    const uint32_t csl = hi_diff == 0xFFFFFFFFu ? k : k - 1u - hi_diff;
+    if (lane == 0) out[x] = rpeak | (qpeak << 8) | (min(csl, 255u) << 16);
+}
+
+// (a fixed grid that strides over the sites: their number is only known on the device - n_dev -, and a grid for the lists' capacity was
+// three empty workgroups in four)
+__global__ __launch_bounds__(256) void call_depths64_kernel(const uint4 *__restrict__ recs, const uint8_t *__restrict__ win, uint32_t stride,
+                                                            uint32_t kpad, uint32_t n_sites, const uint8_t *__restrict__ q,
+                                                            const uint64_t *__restrict__ off, uint32_t k, uint32_t thr, uint32_t qlen,
+                                                            uint32_t revcomp, const uint64_t *__restrict__ tab_off, const uint32_t *__restrict__ tab,
+                                                            const uint8_t *__restrict__ seq_flag, uint32_t *__restrict__ out,
+                                                            const uint32_t *__restrict__ n_dev)
+{
+    __shared__ uint8_t lds[4][3 * 64];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n = n_dev ? min(*n_dev, n_sites) : n_sites;
+    for (uint32_t x = blockIdx.x * 4u + wv; x < n; x += gridDim.x * 4u) {
+        depths64_site(x, lane, lds[wv], recs, win, stride, kpad, q, off, k, thr, qlen, revcomp, tab_off, tab, seq_flag, out);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 } // namespace
 
 // table sizes are the caller's (powers of two >= 64, tab_off[s + 1] - tab_off[s] slots for sequence s; 0 = none).  max_slots = the
@@ -261,11 +390,17 @@ hipError_t launch_call_qmer_index(const uint8_t *d_q, const uint64_t *d_off, uin
 
 hipError_t launch_call_depths(const void *d_recs, const uint8_t *d_win, uint32_t stride, uint32_t n_sites, const uint8_t *d_q,
                               const uint64_t *d_off, uint32_t k, uint32_t thr, uint32_t qlen, bool revcomp, const uint64_t *d_tab_off,
-                              const uint32_t *d_tab, const uint8_t *d_seq_flag, uint32_t *d_out, hipStream_t stream, const uint32_t *d_n_sites)
+                              const uint32_t *d_tab, const uint8_t *d_seq_flag, uint32_t *d_out, hipStream_t stream, const uint32_t *d_n_sites,
+                              bool per_lane)
 {
     if (n_sites == 0) return hipSuccess;
     if (k > kCallMaxK - 1u || k < 2u) return hipErrorInvalidValue;
     const uint32_t kpad = (k + 15u) / 16u * 16u;
+    if (k <= 64u && !per_lane) {
+        hipLaunchKernelGGL(call_depths64_kernel, dim3(std::min((n_sites + 3u) / 4u, 8192u)), dim3(256), 0, stream, static_cast<const uint4 *>(d_recs), d_win, stride, kpad,
+                           n_sites, d_q, d_off, k, thr, qlen, revcomp ? 1u : 0u, d_tab_off, d_tab, d_seq_flag, d_out, d_n_sites);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(call_depths_kernel, dim3((n_sites + 3u) / 4u), dim3(256), 0, stream, static_cast<const uint4 *>(d_recs), d_win, stride, kpad,
                        n_sites, d_q, d_off, k, thr, qlen, revcomp ? 1u : 0u, d_tab_off, d_tab, d_seq_flag, d_out, d_n_sites);
     return hipGetLastError();

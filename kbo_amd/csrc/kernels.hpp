@@ -334,7 +334,8 @@ hipError_t launch_call_qmer_index(const uint8_t *d_q, const uint64_t *d_off, uin
 hipError_t launch_call_depths(const void *d_recs, const uint8_t *d_win, uint32_t stride, uint32_t n_sites, const uint8_t *d_q,
                               const uint64_t *d_off, uint32_t k, uint32_t thr, uint32_t qlen, bool revcomp, const uint64_t *d_tab_off,
                               const uint32_t *d_tab, const uint8_t *d_seq_flag, uint32_t *d_out, hipStream_t stream,
-                              const uint32_t *d_n_sites = nullptr /* the number of sites on the device (n_sites then bounds it) */);
+                              const uint32_t *d_n_sites = nullptr /* the number of sites on the device (n_sites then bounds it) */,
+                              bool per_lane = false /* k <= 64 too through the kernel in which every lane extends its own matches (tests) */);
 hipError_t launch_call_finalize(const void *d_lists, const uint32_t *d_counts, const uint32_t *d_prefix, uint32_t seg_cap, uint32_t max_count,
                                 bool by_walk, const uint64_t *d_off, uint32_t n_seqs, uint32_t k, const uint8_t *d_ms,
                                 const DevIndexView &ix, void *d_recs, uint8_t *d_win, uint32_t stride, hipStream_t stream);

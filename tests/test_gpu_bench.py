@@ -108,7 +108,8 @@ def test_bench_call_line(tmp_path):
     r = _run(["--call", "--genome", "2000000", "--reads", "600", "--k", "51", "--steps", "2", "--warmup", "1"], tmp_path)
     assert r["bit_exact_vs_oracle"] is True and r["value"] > 0 and r["kernels_ms"]["ms_walk_call_mode"] > 0
     w = r["whole_call"]
-    assert w["entry_point"] == "kbo_call_batch" and w["variants"] > 600 and w["us_per_read"] > 0 and w["equal_to_oracle_call_on_sampled_reads"] == 40
+    assert w["entry_point"] == "kbo_call_batch_flat" and w["variants"] > 600 and w["us_per_read"] > 0 and w["equal_to_oracle_call_on_sampled_reads"] == 40
+    assert w["kbo_call_batch_same_offsets"] is True and w["phases_of_one_call_host_clock_ms"]["slabs"] >= 1
 
 
 def test_bench_c5_line_at_reduced_size(tmp_path):
@@ -118,7 +119,11 @@ def test_bench_c5_line_at_reduced_size(tmp_path):
     r = _run(["--config", "C5", "--genome", "3000000", "--reads", "300", "--steps", "2"], tmp_path)
     assert r["bit_exact_vs_oracle"] is True and r["value"] > 0 and "k=63" in r["metric"] and "kbo call" in r["metric"]
     ro, cb = r["roofline"], r["cpu_baseline"]
-    assert ro["bound"] == "hbm" and 0 < ro["frac"] and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3 and ro["units_per_launch"] == 300 * 10000
+    assert ro["bound"] == "hbm" and 0 < ro["frac"] < 1 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3 and ro["units_per_launch"] == 300 * 10000
+    # (priced by the walk's own bytes, counted by its kernels; the reference algorithm's bytes beside it)
+    assert sum(ro["bytes_by_part"].values()) == round(ro["algorithmic_bytes_per_base"] * 3_000_000, -3) or abs(
+        sum(ro["bytes_by_part"].values()) / 3_000_000 - ro["algorithmic_bytes_per_base"]) < 1e-2
+    assert ro["frac_reference_algorithm"] > 0 and ro["walk_counters"]["units"] > 0
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "oracle" in cb["sample"]
     assert r["whole_call"]["equal_to_oracle_call_on_sampled_reads"] == 40 and r["config"]["sites_per_step"] > 300
 

@@ -418,6 +418,8 @@ def test_call_batch_equals_per_sequence_call(oracle):
     try:
         kbo_amd.lib().kbo_set_call_device_emit(0)
         assert as_lists(batch.call_batch_arrays(sbwt, concat, offsets, opts)) == want
+        kbo_amd.lib().kbo_set_call_device_emit(2)  # (the second pass's depths by the kernel for k > 64)
+        assert as_lists(batch.call_batch_arrays(sbwt, concat, offsets, opts)) == want
     finally:
         kbo_amd.lib().kbo_set_call_device_emit(1)
     # ... and slabs cut everywhere (64 KiB: a few reads each, the two slots taking them in turn)
