@@ -155,6 +155,8 @@ def build_or_load_index(args, threads, may_build=True):
     if not may_build:
         raise SystemExit(f"bench.py: index cache {path} missing")
     sbwt, _ = kbo_amd.build([genome], kbo_amd.BuildOpts(k=args.k, num_threads=min(16, max(1, threads))))
+    if os.environ.get("KBO_BENCH_NO_CACHE") == "1":  # (a run that builds the index once and uses it once: tests)
+        return genome, sbwt
     try:
         tmp = f"{path}.{os.getpid()}.tmp"
         kindex.save_flat(tmp, sbwt)  # (computes the cover while the plan is enabled)

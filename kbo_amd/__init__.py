@@ -15,10 +15,11 @@ import numpy as np
 
 # The host batch pipeline keeps three streams per device (upload, kernels, download) next to whatever the caller uses; the HIP runtime
 # maps a process's streams onto 4 hardware queues unless told otherwise, and streams that share a queue do not overlap
-# (INTEGRATION.md "Streams and hardware queues").  Only effective before the runtime starts; a value from outside wins, and
-# KBO_KEEP_HW_QUEUES=1 leaves the variable alone altogether (a process that shares the runtime with other HIP users and wants its default).
-if not os.environ.get("KBO_KEEP_HW_QUEUES"):
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (INTEGRATION.md "Streams and hardware queues").  More queues are the APPLICATION's to ask for - GPU_MAX_HW_QUEUES=8 in its environment
+# before the runtime starts, as bench.py and the tools do - or, for a process that wants this package to do it, KBO_HW_QUEUES=8 (opt-in:
+# importing a library does not change the runtime's settings for every other HIP user of the process).
+if os.environ.get("KBO_HW_QUEUES"):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ["KBO_HW_QUEUES"])
 
 from . import _capi, derandomize, format, gap_filling, index, translate, variant_calling  # noqa: F401
 from ._capi import KboError, check, lib  # noqa: F401

@@ -127,6 +127,18 @@ constexpr uint32_t kMapSlack = 48;       // bytes of the byte region behind the 
 // dozen at 5 %; more: their reads take the plain walk).  20: a wave of 64 reads of 150 bases then takes 13 312 bytes of LDS - 26
 // allocation units of 512 - and a CU holds TWELVE of them; with 64 entries it held eleven
 constexpr uint32_t kMapPend = 20, kMapPendBytes = kMapPend * 8u + 16u;
+// the wave's LDS: [characters] [digits: lin_words + 4 words] [64 x 16 bytes of mismatch lists] [pending windows].  The characters of
+// the direct form are 2-BIT CODES (round 6: M - R X = 0 1 2 3, sixteen a word, expanded at the whole-line store) - a quarter of the
+// bytes they were: 6.1 instead of 13.3 KB a wave of 150-base reads, so that the kernel's registers (74: six waves a SIMD) and no longer
+// its LDS (twelve waves a CU) bound the resident waves - what large indexes, whose every look-up is a trip to HBM, run on (C3: time =
+// 0.96 + 15.7 / waves ms).  The other instantiation keeps a byte a base: its region holds the MS values.
+__host__ __device__ __forceinline__ uint32_t map_char_bytes(bool direct, uint32_t stage_bytes) { return direct ? ((stage_bytes >> 2) + 15u) & ~15u : stage_bytes; }
+__host__ __device__ __forceinline__ uint32_t map_wave_lds(bool direct, uint32_t stage_bytes, uint32_t lin_words)
+{
+    return (map_char_bytes(direct, stage_bytes) + 4u * (lin_words + 4u) + 1024u + kMapPendBytes + 15u) & ~15u;
+}
+// a character's code: OR-able in the order the closed form writes them ('-' first, then perhaps 'X' over it; 'R' only over 'M')
+constexpr uint32_t kCodeDash = 1u, kCodeR = 2u, kCodeX = 3u; // ('M' = 0: what a word of codes starts as)
 
 // NP = bases a stretch can take: 16 (tables of up to 15 bases: 32-bit keys) or 18 (16 / 17 bases).
 // DIRECT: the characters straight from the mismatch positions, no MS bytes at all.  Where the table's order is at most the
@@ -159,16 +171,6 @@ __device__ __forceinline__ uint32_t reverse_digits(uint32_t w)
     const uint32_t r = __builtin_bitreverse32(w);
     return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
 }
-// 16 characters of { M - X R } -> their codes 0 .. 3, first character in the lowest bits ('M' 4D, '-' 2D, 'X' 58, 'R' 52)
-__device__ __forceinline__ uint32_t pack_chars16(const uint4 &v)
-{
-    auto four = [](uint32_t x) -> uint32_t {
-        const uint32_t hi = (x >> 4) & 0x01010101u, lo = ((x >> 5) | ((x >> 4) & ~(x >> 3))) & 0x01010101u;
-        return (((lo | (hi << 1)) * 0x01041040u) >> 24) & 0xFFu;
-    };
-    return four(v.x) | (four(v.y) << 8) | (four(v.z) << 16) | (four(v.w) << 24);
-}
-
 // STATS: the kernel counts its own work (kbo_set_plan_stats) - instrumentation, compiled out of the default instantiations
 template <int NP, bool DIRECT, int IO = 0, bool STATS = false>
 __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint32_t stage_bytes, uint32_t lin_words)
@@ -176,12 +178,13 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
     extern __shared__ __attribute__((aligned(16))) uint8_t map_lds_all[];
     const uint32_t lane = threadIdx.x & 63u;
     // (the waves of a workgroup share nothing: each has its own part of the LDS and never waits for another)
-    const uint32_t wave_lds = (stage_bytes + 4u * (lin_words + 4u) + 1024u + kMapPendBytes + 15u) & ~15u; // (+ the pending windows and their counter)
+    const uint32_t wave_lds = map_wave_lds(DIRECT, stage_bytes, lin_words), char_bytes = map_char_bytes(DIRECT, stage_bytes);
     uint8_t *map_lds = map_lds_all + (threadIdx.x >> 6) * wave_lds;
     const uint32_t idx = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64u + lane;
-    uint8_t *so = map_lds;                                                       // MS bytes, then characters: the wave's stretch
-    uint32_t *lin = reinterpret_cast<uint32_t *>(map_lds + stage_bytes) + 4;     // the stretch as 2-bit digits (lin[-1] = 0)
-    uint8_t *spw = map_lds + stage_bytes + 4u * (lin_words + 4u);                // 64 x 16 bytes: mismatch positions 0 .. 12, flag, prefix
+    uint8_t *so = map_lds;                                                       // (not DIRECT) MS bytes, then characters: the wave's stretch
+    uint32_t *cw = reinterpret_cast<uint32_t *>(map_lds);                        // (DIRECT) the characters as 2-bit codes: position p of the stretch in bits 2 (p mod 16) of word p / 16
+    uint32_t *lin = reinterpret_cast<uint32_t *>(map_lds + char_bytes) + 4;      // the stretch as 2-bit digits (lin[-1] = 0)
+    uint8_t *spw = map_lds + char_bytes + 4u * (lin_words + 4u);                 // 64 x 16 bytes: mismatch positions 0 .. 12, flag, prefix
     uint8_t *sp = spw + lane * 16u;
     uint2 *pend = reinterpret_cast<uint2 *>(spw + 1024u); // DIRECT: windows that are present and wait for their exact depth (kMapPend entries)
     uint32_t *pend_n = reinterpret_cast<uint32_t *>(spw + 1024u + kMapPend * 8u);
@@ -239,8 +242,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
             const uint32_t c = c0 + lane;
             if (c < lin_words) lin[c] = c < nblk ? reverse_digits(a.qp[w_lo + c]) : 0u;
         }
-        for (uint32_t c = lane * 16u; c < span + 16u; c += 1024u)
-            *reinterpret_cast<uint4 *>(so + c) = make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);
+        for (uint32_t c = lane; 16u * c < span + 16u; c += 64u) cw[c] = 0u; // (the packed forms are DIRECT: every character starts as 'M')
         has_invalid = plannable && a.qp_exc != nullptr && a.qp_exc[idx] != 0;
     } else {
     // (six blocks per lane in flight: the loads of a stretch go out in two rounds instead of one per 1 KB (eight or eleven at a time:
@@ -264,8 +266,6 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
             uint32_t code = 0, valid = 0xFFFFu;
             if (c < nblk) {
                 const uint4 v = vv[u];
-                // DIRECT: the characters start out as what nearly all of them are - 'M', or with relative_to_ref the read's own bases
-                if (DIRECT) *reinterpret_cast<uint4 *>(so + 16u * c) = a.map_fmt ? v : make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);
                 // only the bytes of this wave's reads count: [lo, wave_hi)
                 const uint32_t b0 = base16 + 16u * c;
                 const uint32_t from = lo > b0 ? lo - b0 : 0u, to = min(16u, wave_hi - b0);
@@ -280,6 +280,9 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                 }
             }
             if (c < lin_words) lin[c] = code;
+            // DIRECT: the characters start out as what nearly all of them are - 'M' (with relative_to_ref: the read's own base, which the
+            // digits keep)
+            if (DIRECT && 4u * c < char_bytes) cw[c] = 0u;
             uint64_t bm = __ballot((valid & 0xFFFFu) != 0xFFFFu);
             while (bm) { // (rare: a byte that is no base - its read, and a neighbour that shares the block, take the plain walk)
                 const uint32_t L = (uint32_t)__ffsll((long long)bm) - 1u;
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
     }
 
     // (DIRECT) a window that is in the index and is left to the windows around it: asked for in stage 3, judged at the kernel's end
-    bool w_around = false;
+    bool w_around = false, w_unsettled = false;
     uint32_t w_e = 0, w_owner = 0, w_at = 0, w_len = 0, w_pre[6] = {0, 0, 0, 0, 0, 0};
     // ---- 3. the stretches behind the mismatches from the depth table (rule: dtab_kernels.hip), dealt out to the lanes
     uint32_t st_look = 0, st_written = 0, st_anch = 0, st_filt = 0; // (direct form: st_written = windows the filter settled)
@@ -779,6 +782,12 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                         if (order < k && (blockmode || t != o_junc) && !(a.rounds & 32u)) { // (a.rounds bit 5, experiment: off)
                             const uint32_t slot = atomicAdd(pend_n, 1u);
                             if (slot < kMapPend) pend[slot] = make_uint2(o_soff + e_, owner | (e_ << 8) | (0x7FFFu << 16));
+                            else fail = true;
+                        } else if (order < k && a.ix.seed_tab != nullptr && !(a.rounds & (32u | 128u))) {
+                            // a junction's window: nothing to ask the windows around it (their entries speak of one diagonal), but the
+                            // strings that hold it can be searched like any other's (kernel's end)
+                            const uint32_t slot = atomicAdd(pend_n, 1u);
+                            if (slot < kMapPend) pend[slot] = make_uint2(o_soff + e_, owner | (e_ << 8) | (0x7FFEu << 16));
                             else fail = true;
                         } else
                             fail = true;
@@ -910,6 +919,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                         w_at = at_e - 1u;
                     }
                 } else if (gap == 0x7FFFu) around = true;
+                else if (gap == 0x7FFEu) w_unsettled = true; // (searched at the kernel's end)
                 else {
                     const uint32_t V = dtab_anchor_depth(a.ix, e_i + 1u, [&](uint32_t tt) -> uint32_t {
                         return (0x54474341u >> (8u * base_at(at_e - tt))) & 0xFFu;
@@ -966,12 +976,23 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
         // the characters that are not 'M', segment by segment from the right (header): e = the break to the right (the read's
         // end first), dn = its segment's d, cand = the base at e waits for its left neighbour to decide between 'X' and '-'
         const int K = (int)k, T = (int)a.map_thr;
-        const uint8_t cX = a.map_fmt ? (uint8_t)'-' : (uint8_t)'X'; // (relative_to_ref: 'X' becomes '-' as well)
-        uint8_t *at = so + ooff;
+        const uint32_t cX = a.map_fmt ? kCodeDash : kCodeX; // (relative_to_ref: 'X' becomes '-' as well)
+        // (a word of codes may hold the end of one read and the head of the next - two lanes: LDS atomics, which cost what a store does)
+        auto put = [&](int i, uint32_t code) {
+            const uint32_t p_ = ooff + (uint32_t)i;
+            atomicOr(cw + (p_ >> 4), code << (2u * (p_ & 15u)));
+        };
+        auto put_dashes = [&](int i0, int i1) { // bases [i0, i1) of the read
+            const uint32_t p0_ = ooff + (uint32_t)i0, p1_ = ooff + (uint32_t)i1;
+            for (uint32_t w_ = p0_ >> 4; 16u * w_ < p1_; w_++) {
+                const uint32_t lo_ = max(p0_, 16u * w_) - 16u * w_, hi_ = min(p1_, 16u * w_ + 16u) - 16u * w_;
+                const uint32_t m_ = (hi_ >= 16u ? 0xFFFFFFFFu : (1u << (2u * hi_)) - 1u) & ~((1u << (2u * lo_)) - 1u);
+                atomicOr(cw + w_, (0x55555555u * kCodeDash) & m_);
+            }
+        };
         const bool live = plannable && !flag && len >= 3u;
         if (__ballot(live && no_plan)) { // no seed, and the table vouches for every base (<= order <= t): x <= 0 throughout
-            if (live && no_plan)
-                for (uint32_t i = 0; i < len; i++) at[i] = (uint8_t)'-';
+            if (live && no_plan) put_dashes(0, (int)len);
         }
         int e = (int)len, dn = 0;
         bool at_end = true, cand = false;
@@ -994,27 +1015,27 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                         d = (din <= -2 && jl > T) ? 0 : din;
                     }
                     const int xt = L > K ? K : jl + d; // x of the segment's last base (the left neighbour of e)
-                    if (cand) at[e] = ((e <= 1 ? K : xt) > 0) ? cX : (uint8_t)'-';
+                    if (cand) put(e, ((e <= 1 ? K : xt) > 0) ? cX : kCodeDash);
                     cand = false;
                     // the junction to the right starts with x = 1 and this segment ends above the threshold: translate_ms_val's
                     // ('R', 'R') (translate.rs:195-203; the second 'R' under translate_ms_vec's position rules, :282-288);
                     // relative_to_ref keeps the read's bases for both
                     if (!at_end && dn > 0 && dn < T && xt > T && !a.map_fmt) {
-                        at[e - 1] = (uint8_t)'R';
-                        if (e >= 2 && e < (int)len - 1) at[e] = (uint8_t)'R';
+                        put(e - 1, kCodeR);
+                        if (e >= 2 && e < (int)len - 1) put(e, kCodeR);
                     }
                     if (-d == j0) { // the segment's first base has x = 0: 'X' when next == 1 and prev > 0 (translate.rs:204-210)
                         const int next = -d + 1 <= jl ? 1 : (at_end ? 0 : dn);
                         if (next == 1) cand = true;
-                        else at[m - d] = (uint8_t)'-';
+                        else put(m - d, kCodeDash);
                     } else if (-d > j0) {
                         const int j1 = min(-d, jl); // bases with x <= 0
-                        for (int j = j0; j <= j1; j++) at[m + j] = (uint8_t)'-';
+                        put_dashes(m + j0, m + j1 + 1);
                         // the base with x = 0 whose successor has x = 1: an 'X' when it is one of the read's two first bases, whose
                         // prev is k (elsewhere its prev is the x = -1 in front of it)
                         const int pz = m - d;
                         const int nz = -d + 1 <= jl ? 1 : (-d == jl ? (at_end ? 0 : dn) : 0);
-                        if (nz == 1 && pz >= 0 && pz <= 1) at[pz] = cX;
+                        if (nz == 1 && pz >= 0 && pz <= 1) put(pz, cX);
                     }
                     dn = d + j0; // x of the base the next segment to the left ends in front of
                     e = m + j0;
@@ -1022,7 +1043,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                 }
             }
         }
-        if (cand) at[e] = cX; // (the read's first base: its prev is k)
+        if (cand) put(e, cX); // (the read's first base: its prev is k)
         (void)K;
     } else if (a.chars_out != nullptr && plannable && !flag && len >= 3u) { // (chars_out == nullptr: kbo_ms_batch_dev - the MS values were all that was asked for)
         const int K = (int)k, T = (int)a.map_thr;
@@ -1071,15 +1092,15 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
         uint32_t n_runs = 0;
         if (plannable && !flag && len >= 3u) { // (fewer than 3 bases: no alignment - the reference asserts, derandomize.rs:274-276 - and no run)
             const uint32_t b0 = ooff, b1 = ooff + len;
-            uint32_t carry = 0; // the character in front of the word was not a '-' (bit 7)
-            for (uint32_t wa = b0 & ~3u; wa < b1; wa += 4u) {
-                const uint32_t v = *reinterpret_cast<const uint32_t *>(so + wa) ^ 0x2D2D2D2Du; // zero bytes: '-'
-                uint32_t nd = (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;            // bit 7 of every byte that is not '-'
-                // bytes outside [b0, b1) count as '-'
-                const uint32_t lo_cut = wa < b0 ? b0 - wa : 0u, hi_cut = wa + 4u > b1 ? wa + 4u - b1 : 0u;
-                nd &= (0xFFFFFFFFu << (8u * lo_cut)) & (0xFFFFFFFFu >> (8u * hi_cut));
-                n_runs += (uint32_t)__popc(nd & ~((nd << 8) | carry));
-                carry = nd >> 24;
+            uint32_t carry = 0; // bit 0: the character in front of the word was not a '-'
+            for (uint32_t w_ = b0 >> 4; 16u * w_ < b1; w_++) { // sixteen characters a word
+                const uint32_t v = cw[w_];
+                uint32_t nd = ~(v & ~(v >> 1)) & 0x55555555u; // bit 2 p of every character that is not '-' (code 01)
+                // characters outside [b0, b1) count as '-'
+                const uint32_t lo_ = 16u * w_ < b0 ? b0 - 16u * w_ : 0u, hi_ = 16u * w_ + 16u > b1 ? b1 - 16u * w_ : 16u;
+                nd &= (hi_ >= 16u ? 0xFFFFFFFFu : (1u << (2u * hi_)) - 1u) & ~((1u << (2u * lo_)) - 1u);
+                n_runs += (uint32_t)__popc(nd & ~((nd << 2) | carry));
+                carry = nd >> 30;
             }
         }
         a.run_counts[idx] = n_runs;
@@ -1089,12 +1110,37 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
 
     // ---- 5. the characters leave in whole lines; format::relative_to_ref (format.rs:270-286) on the way: 'M' and 'R' keep the
     // read's base, everything else becomes '-' (flagged reads' bytes are rewritten by launch_derand_flagged)
-    if (IO == 2) { // as 2-bit words, where the read's own words stand in the batch
-        for (uint32_t c = lane; c < nwords; c += 64u) a.packed_out[w_lo + c] = pack_chars16(*reinterpret_cast<const uint4 *>(so + 16u * c));
-    } else if (DIRECT || a.chars_out != nullptr)
+    if (IO == 2) { // as 2-bit words, where the read's own words stand in the batch (the packed alphabet is M - X R: codes 2 and 3 change places)
+        for (uint32_t c = lane; c < nwords; c += 64u) {
+            const uint32_t w_ = cw[c];
+            a.packed_out[w_lo + c] = w_ ^ ((w_ >> 1) & 0x55555555u);
+        }
+    } else if (DIRECT) {
+        // sixteen codes a lane -> sixteen characters: the codes of four characters spread to a byte each select out of "M-RX" (one byte
+        // permute); with relative_to_ref the read's own bases, from the digits, where the code says 'M'
+        for (uint32_t c = lane; 16u * c < span; c += 64u) {
+            const uint32_t w_ = cw[c], dg = a.map_fmt ? lin[c] : 0u; // (relative_to_ref: bytes in, IO == 0 - the digits of block c are word c)
+            auto four = [&](uint32_t c8, uint32_t d8) -> uint32_t {
+                const uint32_t cs = (c8 | (c8 << 6) | (c8 << 12) | (c8 << 18)) & 0x03030303u;
+                if (!a.map_fmt) return __builtin_amdgcn_perm(0u, 0x58522D4Du, cs);
+                const uint32_t sel = ((d8 >> 6) & 3u) | (((d8 >> 4) & 3u) << 8) | (((d8 >> 2) & 3u) << 16) | ((d8 & 3u) << 24);
+                const uint32_t letters = __builtin_amdgcn_perm(0u, 0x54474341u, sel);
+                const uint32_t keep = (((cs | (cs >> 1)) & 0x01010101u) ^ 0x01010101u) * 0xFFu; // bytes whose code is 'M'
+                return (letters & keep) | (0x2D2D2D2Du & ~keep);
+            };
+            uint4 v;
+            v.x = four(w_ & 0xFFu, dg >> 24);
+            v.y = four((w_ >> 8) & 0xFFu, (dg >> 16) & 0xFFu);
+            v.z = four((w_ >> 16) & 0xFFu, (dg >> 8) & 0xFFu);
+            v.w = four(w_ >> 24, dg & 0xFFu);
+            const uint32_t g0 = base16 + 16u * c;
+            if (g0 >= lo && g0 + 16u <= wave_hi) __builtin_memcpy(a.chars_out + g0, &v, 16);
+            else st_range16(a.chars_out + g0, v, lo > g0 ? min(lo - g0, 16u) : 0u, min(wave_hi - g0, 16u));
+        }
+    } else if (a.chars_out != nullptr)
     for (uint32_t c = lane * 16u; c < span; c += 1024u) {
         uint4 v = *reinterpret_cast<const uint4 *>(so + c);
-        if (!DIRECT && a.map_fmt) {
+        if (a.map_fmt) {
             const uint32_t dg = lin[c >> 4];
             auto fmt4 = [&](uint32_t ch, uint32_t d8) -> uint32_t { // four characters and the four bases behind them
                 const uint32_t sel = ((d8 >> 6) & 3u) | (((d8 >> 4) & 3u) << 8) | (((d8 >> 2) & 3u) << 16) | ((d8 & 3u) << 24);
@@ -1118,7 +1164,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
     // fewer when only its extended string is absent; j = 0: the window's own bit).  Without it the read took the plain walk: every
     // seventh read of another genome, every twentieth with 5 % substitutions.  Brute-force check of the rule:
     // tests/test_proof_rule_model.py
-    if (DIRECT && __ballot(w_around)) {
+    if (DIRECT && __ballot(w_around || w_unsettled)) {
         const uint32_t order = a.ix.dtab_order, thr = a.map_thr;
         if (w_around) {
             const uint32_t soff_ = w_at - w_e, e = w_e;
@@ -1162,7 +1208,52 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
                         }
                 }
             }
-            if (!ok) spw[w_owner * 16u + 13u] = 1;
+            w_unsettled = !ok;
+        }
+        // (w_len of a junction's window: set with the others')
+        // ---- what the windows around it do not settle is SEARCHED (round 6): the strings of thr + 1 bases that hold the window end at
+        // e_lo .. e_hi - nine of them at most - and each is in the index or not: its first seed_d bases by the interval table (one load),
+        // the others by extend-right steps over the rank blocks, thr + 1 - seed_d (nine at C2) dependent rounds of two 16-byte loads, one
+        // candidate a lane, nearly all of them dead after the first round or two (a string of 14 random bases is in a 5 Mbp index one time
+        // in fifty).  None present: no string longer than thr runs through the break - the proof, exactly.  Before, such a read went to the
+        // second pass: a chain of ~ 80 dependent walk steps for two reads in a thousand, 0.12 ms whatever their number - and it still does
+        // when a candidate IS present (a true repeat of more than thr bases through a mismatch).
+        const uint32_t D_ = a.ix.seed_d;
+        const bool can_search = a.ix.seed_tab != nullptr && D_ >= 4u && D_ <= 16u && thr + 1u >= D_ && !(a.rounds & 128u); // (a.rounds bit 7, experiment: off)
+        uint64_t um = __ballot(w_unsettled);
+        if (!can_search) {
+            if (w_unsettled) spw[w_owner * 16u + 13u] = 1;
+            um = 0;
+        }
+        while (um) {
+            const int src = __builtin_ctzll(um);
+            um &= um - 1ull;
+            const uint32_t e_ = __shfl(w_e, src), at_ = __shfl(w_at, src), wl_ = __shfl(w_len, src), own_ = __shfl(w_owner, src);
+            const uint32_t soff_ = at_ - e_, c_ = thr + 1u - order;
+            const uint32_t e_lo = max(e_, thr), e_hi = min(e_ + c_, wl_ - 1u);
+            bool alive = e_lo <= e_hi && lane <= e_hi - e_lo;
+            const uint32_t first = soff_ + e_lo + lane - thr; // the candidate's first base in the stretch
+            uint32_t l_ = 0, r_ = 0;
+            if (alive) {
+                const uint32_t key = (uint32_t)ending_at(first + D_ - 1u) & (D_ >= 16u ? 0xFFFFFFFFu : (1u << (2u * D_)) - 1u);
+                const uint2 iv = a.ix.seed_tab[key];
+                if (STATS) st_look++;
+                l_ = iv.x;
+                r_ = iv.y;
+                alive = l_ < r_;
+            }
+            const uint8_t *arena_ = reinterpret_cast<const uint8_t *>(a.ix.arena);
+            for (uint32_t j_ = D_; j_ <= thr; j_++) {
+                if (__ballot(alive) == 0) break;
+                if (alive) {
+                    const uint32_t cb_ = base_at(first + j_) * a.ix.n_blocks, bl_ = div96(l_), br_ = div96(r_);
+                    const uint4 xA = ld16(arena_, (cb_ + bl_) << 4), xB = ld16(arena_, (cb_ + br_) << 4);
+                    l_ = rank_eval(xA, l_ - bl_ * 96u);
+                    r_ = rank_eval(xB, r_ - br_ * 96u);
+                    alive = l_ < r_;
+                }
+            }
+            if (__ballot(alive) != 0 && lane == 0) spw[own_ * 16u + 13u] = 1; // a string of thr + 1 bases through the break IS in the index
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1212,7 +1303,7 @@ bool map_reads_direct(const WalkArgs &a)
 }
 
 // the packed-native instantiations: the direct form only, and the characters packed only without relative_to_ref
-bool map_reads_packed_applies(const WalkArgs &a, bool packed_out) { return map_reads_applies(a) && map_reads_direct(a) && !(packed_out && a.map_fmt); }
+bool map_reads_packed_applies(const WalkArgs &a, bool packed_out) { (void)packed_out; return map_reads_applies(a) && map_reads_direct(a) && !a.map_fmt; }
 
 // the kernel + the list of the reads it could not finish (redo_collect_kernel, for the plain walk: launch_map_reads_redo)
 hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
@@ -1235,11 +1326,11 @@ hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
     static const bool env_nouni = std::getenv("KBO_MAP_NO_UNIFORM") != nullptr; // experiments
     a.uniform_len = (a.seq_off && !env_nouni && a.max_item_len != 0 && (uint64_t)a.n_items * a.max_item_len == a.q_bytes) ? a.max_item_len : 0u;
     const int io = a.qp ? (a.packed_out ? 2 : 1) : 0;
-    if (io != 0 && (!direct || (io == 2 && a.map_fmt))) return hipErrorInvalidValue; // (callers ask map_reads_packed_applies first)
+    if (io != 0 && (!direct || a.map_fmt)) return hipErrorInvalidValue; // (callers ask map_reads_packed_applies first; the packed entry points are kbo::matches: no relative_to_ref)
     // (packed: every read starts a word of the digit string and, with the characters packed as well, of the byte region)
     const uint32_t stage_bytes = io ? (64u * 16u * ((a.max_item_len + 15u) / 16u) + 32u + kMapSlack) : (64u * a.max_item_len + 16u + kMapSlack + 15u) / 16u * 16u;
     const uint32_t lin_words = stage_bytes / 16u + 4u;
-    const uint32_t lds_wave = (stage_bytes + 4u * (lin_words + 4u) + 1024u + kMapPendBytes + 15u) & ~15u;
+    const uint32_t lds_wave = map_wave_lds(direct, stage_bytes, lin_words);
     static const int env_wpb = std::getenv("KBO_MAP_WPB") ? std::atoi(std::getenv("KBO_MAP_WPB")) : 1; // experiments: waves per workgroup
     const uint32_t wpb = (uint32_t)std::min(4, std::max(1, env_wpb));
     const uint32_t n_waves = (a.n_items + 63u) / 64u;

@@ -4,6 +4,10 @@ import sys
 
 import pytest
 
+# (the suite keeps several streams busy - pipelines, tail streams, torch's own: more hardware queues than the runtime's four, asked for by
+# the application, here the test session, before anything touches the GPU: INTEGRATION.md "Streams and hardware queues")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

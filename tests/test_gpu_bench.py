@@ -92,6 +92,18 @@ def test_bench_c4_shape_strong_scaling_two_ranks(tmp_path):
     assert r["scaling"] == "strong" and "50001 x 150 bp reads in all, 25001 per GPU" in r["config"]["workload"]
 
 
+def test_bench_c4_shape_eight_ranks(tmp_path):
+    """the launch the driver makes on an 8-GPU node, executed once with world = 8 (all ranks on this box's one GPU, rendezvous over
+    gloo: functional only): --config C4's strong-scaling shards - contiguous, ceil(reads / 8) each, the last one short, tiling the
+    read set exactly - the index cache built once by the parent, the CPU quota split cores // world"""
+    r = _run(["--config", "C4", "--gpus", "8", "--genome", "300000", "--reads", "40003", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.5", "--no-extras"],
+             tmp_path, {"KBO_BENCH_ONE_GPU": "1"})
+    _check_line(r, 8)
+    assert r["scaling"] == "strong" and "40003 x 150 bp reads in all, 5001 per GPU" in r["config"]["workload"] and "x8" in r["config"]["parallelism"]
+    lo, hi = r["roofline"]["kernel_ms_per_rank"]["min"], r["roofline"]["kernel_ms_per_rank"]["max"]
+    assert 0 < lo <= hi
+
+
 def test_bench_gpus_2_spawns_two_ranks(tmp_path):
     r = _run(["--gpus", "2", "--genome", "400000", "--reads", "30000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1.5"],
              tmp_path, {"KBO_BENCH_ONE_GPU": "1"})
@@ -130,20 +142,36 @@ def test_bench_c5_line_at_reduced_size(tmp_path):
 
 def test_bench_c5_at_its_real_size(tmp_path):
     """bench.py --config C5 as it is: the 3 Gbp index, k = 63, 125 000 reads of 10 kbp - every site of the first pass against the oracle's,
-    40 sampled reads of kbo_call_batch against the oracle's literal kbo::call (>= 200 reads' sites are compared many times over: all
-    125 000).  Ten minutes and 250 GB of host memory: only when asked for (KBO_TEST_C5_FULL=1) on a box that has them; the committed
-    run of the round is profiles/r05_bench_c5.json."""
-    if not os.environ.get("KBO_TEST_C5_FULL"):
-        pytest.skip("the 3 Gbp index takes ten minutes and 250 GB of host memory to build: set KBO_TEST_C5_FULL=1 (profiles/r05_bench_c5.json is the round's run)")
+    40 sampled reads of the whole call (kbo_call_batch_flat) against the oracle's literal kbo::call.  Runs wherever the host has the
+    memory (MemAvailable >= 300 GB: the index, its device layout and the oracle's adopted parts) - no environment gate since round 6 -
+    under a time budget: the index build on the box's 16 CPUs' worth of time is what takes minutes, and a box that needs more than
+    KBO_TEST_C5_BUDGET seconds (default 640; the round's measured run: profiles/r06_c5_phases.txt) is skipped with its phases so far
+    rather than allowed to run the suite out of the driver's time.  KBO_TEST_C5_FULL=0 skips it outright."""
+    if os.environ.get("KBO_TEST_C5_FULL") == "0":
+        pytest.skip("KBO_TEST_C5_FULL=0")
     avail_gb = 0
     for ln in open("/proc/meminfo"):
         if ln.startswith("MemAvailable:"):
             avail_gb = int(ln.split()[1]) / 1e6
     if avail_gb < 300:
         pytest.skip("%.0f GB of host memory available, the 3 Gbp index and its oracle copy need 300" % avail_gb)
-    env = dict(os.environ, KBO_BENCH_CACHE_DIR=str(tmp_path))
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C5"], capture_output=True, text=True, env=env, timeout=3600)
-    assert out.returncode == 0, out.stderr[-3000:]
-    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert r["bit_exact_vs_oracle"] is True and "3000 Mbp" in r["metric"] and r["roofline"]["frac"] > 0 and r["cpu_baseline"]["value"] > 0
-    assert r["whole_call"]["equal_to_oracle_call_on_sampled_reads"] == 40
+    budget = float(os.environ.get("KBO_TEST_C5_BUDGET", "640"))
+    # (no cache file: this run builds the index once and uses it once - writing 40 GB takes a disk minutes)
+    env = dict(os.environ, KBO_BENCH_CACHE_DIR=str(tmp_path), KBO_BENCH_NO_CACHE="1")
+    err_path = os.path.join(str(tmp_path), "c5.err")
+    with open(err_path, "w") as err:
+        proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C5", "--steps", "2", "--warmup", "1"],
+                                stdout=subprocess.PIPE, stderr=err, text=True, env=env, start_new_session=True)
+        try:
+            out, _ = proc.communicate(timeout=budget)
+        except subprocess.TimeoutExpired:
+            import signal
+            os.killpg(proc.pid, signal.SIGKILL)  # (the group this test started: bench.py and nothing else)
+            proc.wait()
+            phases = [ln.strip() for ln in open(err_path) if ln.startswith("[bench C5")]
+            pytest.skip("C5 at its real size did not finish within %.0f s on this box; phases so far: %s" % (budget, "; ".join(phases[-6:])))
+    assert proc.returncode == 0, open(err_path).read()[-3000:]
+    r = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert r["bit_exact_vs_oracle"] is True and "3000 Mbp" in r["metric"] and 0 < r["roofline"]["frac"] < 1 and r["cpu_baseline"]["value"] > 0
+    assert r["whole_call"]["equal_to_oracle_call_on_sampled_reads"] == 40 and r["whole_call"]["kbo_call_batch_same_offsets"] is True
+    assert r["whole_call"]["ms"] < 450  # (VERDICT round 5 asked for <= 0.45 s per 125 k reads; 0.91 s then)

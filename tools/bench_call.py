@@ -3,6 +3,7 @@
 threads, variants packed): kbo_call_batch through the C ABI, timed per read; a sample of reads against the oracle's literal
 kbo::call.  Usage: tools/bench_call.py [G=5000000] [R=50000] [L=10000] [K=51] (environment)."""
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 import sys
 import time
 

@@ -2,6 +2,7 @@
 """End-to-end host->host rate of kbo_map_batch on the C2 workload (reads and output in host
 memory; PCIe-inclusive).  Not the bench.py metric — reported in DESIGN.md §7."""
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 import sys
 import time
 

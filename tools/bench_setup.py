@@ -5,6 +5,7 @@ reads through the plain walk and through kbo_map_batch_dev's one kernel, and the
 themselves - with the path cover laid out by this copy, and with a cover that came with the handle (an index file).
 python tools/bench_setup.py [genome sizes, comma separated]"""
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 import sys
 import time
 

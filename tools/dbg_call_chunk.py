@@ -1,6 +1,8 @@
 """kbo_call_batch (host second pass) under different chunk sizes / plan on-off: every variant against the default's."""
 import os, sys, subprocess, pickle, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 sys.path.insert(0, ROOT)
 if len(sys.argv) > 1:
     import kbo_amd

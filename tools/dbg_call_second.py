@@ -2,6 +2,8 @@
 result comes from a child process), every variant of every read, several slab sizes."""
 import os, sys, subprocess, pickle, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 sys.path.insert(0, ROOT)
 import kbo_amd
 from kbo_amd import batch, synth

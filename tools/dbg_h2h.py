@@ -1,6 +1,8 @@
 """Where bench.py's host-to-host leg loses its rate: the same leg after each stage of what bench.py does before it."""
 import os, sys, time, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 sys.path.insert(0, ROOT)
 import bench
 import kbo_amd

@@ -2,6 +2,8 @@
 KBO_HIP_LIB=kbo_amd/libkbo_hip_dbg.so python tools/dbg_plan.py)."""
 import os, sys
 import numpy as np, torch
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kbo_amd
 from kbo_amd import batch, synth

@@ -1,5 +1,7 @@
 import os, sys, ctypes as C
 import numpy as np, torch
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kbo_amd
 from kbo_amd import batch, synth

@@ -2,6 +2,7 @@
 """How many reads map_reads_kernel leaves to its second pass, by kind of read, on the C2 index: python tools/dbg_witness.py
 (KBO_MAP_X=32: present windows flag their read as before the rule that asks the windows around them)"""
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 import sys
 
 import numpy as np

@@ -1,6 +1,8 @@
 """flagged reads with one insertion, a few of them in detail"""
 import os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 sys.path.insert(0, ROOT)
 import kbo_amd
 from kbo_amd import batch, synth

@@ -4,6 +4,7 @@ every base of the first 3 Mbp against the oracle.  python tools/exp_long.py [--g
 [--steps 20] [--variants 1pct,ont,clean,5pct,big] [--no-check] [--tail]"""
 import argparse
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 import sys
 import time
 

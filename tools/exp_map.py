@@ -1,6 +1,7 @@
 """The one-kernel route of kbo_map_batch_dev against the two-kernel route on the C2 batch: parity with the oracle, time per
 step of both (same DeviceBatch, events on the stream).  python tools/exp_map.py [genome] [reads] [sub_rate] [format]"""
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 import sys
 import time
 

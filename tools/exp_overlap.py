@@ -2,6 +2,8 @@
 one batch after the other on one stream.  python tools/exp_overlap.py [genome] [reads]"""
 import os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 sys.path.insert(0, ROOT)
 import kbo_amd
 from kbo_amd import batch, synth

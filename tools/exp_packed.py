@@ -2,6 +2,8 @@
 (kbo_map_batch_dev, format = 0) on the C2 batch, device-resident: time per step, one stream and two batches in flight."""
 import os, sys, ctypes as C, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 sys.path.insert(0, ROOT)
 import kbo_amd
 from kbo_amd import batch, synth

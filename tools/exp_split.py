@@ -3,6 +3,8 @@
 Two half-batches on two streams, the second delayed by about one plan kernel, against the whole batch on one stream."""
 import os, sys, time
 import numpy as np, torch
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kbo_amd
 from kbo_amd import batch, synth

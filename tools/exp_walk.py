@@ -3,6 +3,7 @@
  (a) lanes per wave that take reads (64 / 32 / 16 / 8): what a tiling that gives several lanes to one read would have to beat;
  (b) LDS reserved per wave (0 / 5 / 10 / 20 KB, untouched): what staging a wave's MS bytes for a fused A5/A6 costs."""
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 import sys
 
 import numpy as np

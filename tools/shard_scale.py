@@ -15,6 +15,7 @@ with 1 % substitutions, some with N) through kbo_ms_batch / kbo_matches_batch / 
 Test infrastructure (it imports oracle/); prints one summary line per step.
 """
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 import resource
 import sys
 import time

@@ -3,6 +3,7 @@
 slab sizes, two-base steps on/off and gap lengths; every result is compared with the oracle.
 SECONDS= wall budget, SEED= first seed."""
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 import sys
 import time
 

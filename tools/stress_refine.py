@@ -3,6 +3,7 @@
 on variant-laden reference/query pairs of random size, variant spacing, variant length and k.  Where the
 reference would panic both sides must refuse.  SECONDS= wall budget, SEED= first seed."""
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 import sys
 import time
 

@@ -3,6 +3,7 @@
 G=genome bases, R=reads, SUB=substitution rates (comma separated), DMIN / CAP lists to sweep, GW = list of
 <guided waves per CU>:<recovery lines 0/1>."""
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 import sys
 
 import numpy as np

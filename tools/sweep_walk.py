@@ -2,6 +2,7 @@
 """GPU-side tuning sweep of the walk kernel launch geometry on the C2 workload.
 Prints walk-kernel ms (min / median over repeats) per configuration."""
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (the application asks for the hardware queues its streams need: INTEGRATION.md)
 import sys
 
 import numpy as np

@@ -10,7 +10,7 @@ import sys
 
 MAP = ("map_reads_kernel",)  # workload keys that end in ":map": the one kernel of kbo_map_batch_dev, priced on its own
 A1 = ("plan_kernel", "dtab_resolve_kernel", "dtab_stretch_kernel", "plan_count_kernel", "scan_kernel", "plan_emit_kernel", "ms_walk_guided_kernel",
-      "ms_walk_recovery_kernel", "redo_collect_kernel", "ms_walk_kernel")
+      "ms_walk_recovery_kernel", "redo_collect_kernel", "ms_walk_kernel", "call_fix_sites_kernel", "make_chunk_items_kernel", "chunk_count_kernel")
 summ, key, source = json.load(open(sys.argv[1])), sys.argv[2], sys.argv[3]
 per_step_launches = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
