@@ -98,7 +98,10 @@ def main(argv=None):
     piped = not args.two_kernels and not args.one_at_a_time
     n_pipes = max(1, args.pipelines) if piped else 1
     # (kbo::find has no entry point of that kind yet: its pipelines are pairs of torch streams here, kbo_find_batch_dev's tail stream)
-    pipes = [(stream if p == 0 else torch.cuda.Stream(device), torch.cuda.Stream(device)) for p in range(n_pipes)] if piped and args.find else None
+    # (... made by the library like kbo_map_stream's own: the tail stream - the second passes - on compute units of its own)
+    # find's tail stream carries the run-length passes over every read's characters as well - work, not a chain: plain streams (confined to
+    # 16 units: C3 511 -> 157 Gbp/s; KBO_FIND_TAIL_CUS: experiments)
+    pipes = [batch.stream_pair(device, tail_cus=int(os.environ.get("KBO_FIND_TAIL_CUS", "0"))) for p in range(n_pipes)] if piped and args.find else None
     mstream = None
     n_slabs = (n_mine + SLAB_READS - 1) // SLAB_READS
     # (slabs of equal size: the pipelines take the slabs in turn, and with 8 M + 2 M reads - C3 - one of them had four fifths of the work)
@@ -202,6 +205,9 @@ def main(argv=None):
     rle_ms = float(np.mean([sum(e[2].elapsed_time(e[3]) for e in step) for step in ev])) if args.find and args.two_kernels else None  # (else: inside the call)
     # what the timed steps left behind (formatted unless --find): the first slab of either set, for rank 0's parity gate
     timed_chars_sets = [sl[0].chars[:sl[0].total].cpu().numpy() for sl in sets] if rank == 0 else None
+    if mstream is not None:  # (its streams go back to the runtime: the legs below make their own, and streams beyond the hardware queues share them)
+        mstream.close()
+        mstream = None
     serial = None
     if piped and rank == 0 and world == 1:  # the same steps on one stream, for the record
         n_ser = max(1, min(args.steps, 10))

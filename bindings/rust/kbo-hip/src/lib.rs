@@ -64,6 +64,8 @@ pub mod ffi {
         pub fn kbo_call_batch_flat(idx: *mut KboIndex, concat: *const u8, offsets: *const u64, n_seqs: usize, opts: *const KboCallOpts,
                                    result: *mut KboCallFlat, var_offsets: *mut u64) -> c_int;
         pub fn kbo_call_flat_free(result: *mut KboCallFlat);
+        pub fn kbo_stream_pair_create(tail_cus: c_int, stream: *mut *mut c_void, tail_stream: *mut *mut c_void) -> c_int;
+        pub fn kbo_stream_pair_destroy(stream: *mut c_void, tail_stream: *mut c_void);
         // 2-bit packed batches: a quarter of the bytes over PCIe (kbo_hip.h "packed batches")
         pub fn kbo_packed_words(offsets: *const u64, n_seqs: usize) -> usize;
         pub fn kbo_pack_reads(concat: *const u8, offsets: *const u64, n_seqs: usize, words_out: *mut u32, exc_pos: *mut u64,

@@ -104,7 +104,7 @@ SYMBOLS = [
     "kbo_ms_batch_dev", "kbo_derand_translate_dev", "kbo_set_slab_bytes", "kbo_set_devices", "kbo_set_host_threads",
     "kbo_release_scratch", "kbo_run_lengths_gapped_batch", "kbo_find_batch_into", "kbo_derand_work_bytes",
     "kbo_run_lengths_work_bytes", "kbo_run_lengths_dev", "kbo_index_device_pair_bytes", "kbo_index_device_plan_bytes",
-    "kbo_index_path_cover", "kbo_index_recovery_lines", "kbo_call_batch", "kbo_call_batch_flat", "kbo_call_flat_free", "kbo_call_sites_dev", "kbo_call_walk_dev",
+    "kbo_index_path_cover", "kbo_index_recovery_lines", "kbo_call_batch", "kbo_call_batch_flat", "kbo_call_flat_free", "kbo_stream_pair_create", "kbo_stream_pair_destroy", "kbo_call_sites_dev", "kbo_call_walk_dev",
     "kbo_index_save_sbwt", "kbo_index_load_sbwt", "kbo_packed_words", "kbo_pack_reads", "kbo_unpack_matches",
     "kbo_matches_batch_packed", "kbo_find_batch_packed", "kbo_index_shards", "kbo_index_work_bytes",
     "kbo_index_device_layout", "kbo_map_batch_dev", "kbo_map_batch_dev_tail",
@@ -234,6 +234,8 @@ def lib():
     L.kbo_call_batch.argtypes = [vp, vp, vp, sz, C.POINTER(CallOpts), C.POINTER(C.POINTER(Variant)), vp]
     L.kbo_call_batch_flat.argtypes = [vp, vp, vp, sz, C.POINTER(CallOpts), C.POINTER(CallFlat), vp]
     L.kbo_call_flat_free.argtypes = [C.POINTER(CallFlat)]; L.kbo_call_flat_free.restype = None
+    L.kbo_stream_pair_create.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp)]
+    L.kbo_stream_pair_destroy.argtypes = [vp, vp]; L.kbo_stream_pair_destroy.restype = None
     L.kbo_call_sites_dev.argtypes = [vp, vp, vp, vp, sz, u64, sz, sz, vp, sz, vp, vp]
     L.kbo_call_walk_dev.argtypes = [vp, vp, vp, sz, u64, sz, sz, vp, vp, sz, vp, vp, sz, vp]
     L.kbo_index_device_plan_bytes.argtypes = [vp]

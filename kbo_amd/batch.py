@@ -365,6 +365,16 @@ class DeviceBatch:
         self.fused = bool(fused.value)
 
 
+def stream_pair(device, tail_cus=-1):
+    """(stream, tail_stream) as torch streams, made by the library (kbo_hip.h kbo_stream_pair_create): the tail stream - a batch's second
+    pass - on compute units of its own.  The pair lives as long as the process (the torch wrappers do not own the streams)."""
+    import torch
+    with torch.cuda.device(device):
+        ks, ts = C.c_void_p(), C.c_void_p()
+        check(lib().kbo_stream_pair_create(tail_cus, C.byref(ks), C.byref(ts)))
+        return torch.cuda.ExternalStream(ks.value, device=device), torch.cuda.ExternalStream(ts.value, device=device)
+
+
 class MapStream:
     """Several device-resident batches in flight through the library's own pipelines (kbo_hip.h kbo_map_stream_*): pairs of (kernel
     stream, second-pass stream) that take the batches in turn, two slots of work memory each."""

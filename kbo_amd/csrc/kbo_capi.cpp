@@ -1373,7 +1373,9 @@ struct FindTail {
 int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
                        size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
                        void *d_work, size_t work_bytes, void *stream, void *tail_stream, bool split, int *fused,
-                       const FindTail *find = nullptr)
+                       const FindTail *find = nullptr,
+                       uint32_t *fb_pinned = nullptr /* pinned word: the batch's flagged reads / pieces, written by its second pass's first kernel */,
+                       uint32_t *fb_units = nullptr /* what that number is a share of: reads, or pieces of long sequences */)
 {
     if (fused) *fused = 0;
     bool done = false, counted = false; // (counted: device_view() has seen this batch's bases for the copy's lazy plan structures)
@@ -1401,8 +1403,11 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
             counted = true;
             if (!kbo::map_long_applies(view, (uint32_t)threshold)) return;
             kbo::LongArgs la{};
+            la.host_flagged = fb_pinned;
             HIP_OK(kbo::launch_map_long(view, d_concat, d_offsets, (uint32_t)n_seqs, total_bases, (uint32_t)threshold, format != 0, d_chars_out,
                                         static_cast<uint8_t *>(d_work) + w.long_off, s, la, g_plan_stats.load()));
+            la.host_flagged = fb_pinned; // (launch_map_long fills `la`: once more behind it)
+            if (fb_units) *fb_units = (uint32_t)std::min<uint64_t>(total_bases / 900u + n_seqs, 0xFFFFFFFFu); // (about the pieces: 944 own bases each at k = 31)
             hipStream_t ts = s;
             if (split && static_cast<hipStream_t>(tail_stream) != s) {
                 ts = static_cast<hipStream_t>(tail_stream);
@@ -1442,6 +1447,8 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
         if (!a.gitems || !kbo::map_reads_applies(a)) return; // (no plan structures, or the copy is held off: two kernels)
         a.seq_off = d_offsets; // (the kernel and redo_collect_kernel read the offsets themselves: no item list is made)
         a.host_bailed = plan_state ? plan_state->bailed : nullptr; // (set by redo_collect_kernel itself: no 8-byte copy behind the launch)
+        a.host_flagged = fb_pinned;
+        if (fb_units) *fb_units = (uint32_t)n_seqs;
         // kbo::find with max_gap_len = 0: the kernel counts the runs of the reads it finishes (their characters are in LDS anyway), so
         // that format::run_lengths_gapped is one pass over the characters instead of two
         uint32_t *rle_scratch = find ? static_cast<uint32_t *>(find->d_rle_work) : nullptr;
@@ -1532,10 +1539,64 @@ int kbo_map_batch_dev_tail(kbo_index_t *idx, const uint8_t *d_concat, const uint
 }
 
 // ---- kbo_map_stream_*: pipelines of (kernel stream, second-pass stream), two slots each
+// A (kernel stream, second-pass stream) pair with the second passes on compute units of their own (16 of the device's 256 by default;
+// KBO_TAIL_CUS / tail_cus = how many, 0 = plain streams): a second pass is a chain of dependent look-ups by a few hundred waves, and
+// beside kernels that hold every wave slot of the device each link of the chain waits for a slot - 0.12 ms alone, 0.37 beside two kernels,
+// which then wait for it in turn.  The kernel stream gets the other units.  C2, two pipelines, same box: 757 -> 973 Gbp/s (8 .. 32 units;
+// 64: 884); C4 the same either way (the second passes of its slabs are work, not a chain).
+static int tail_cus_default() // compute units of a second-pass stream (KBO_TAIL_CUS; 0 = plain streams, the arrangement of rounds 4 - 5)
+{
+    static const int v = std::getenv("KBO_TAIL_CUS") ? std::atoi(std::getenv("KBO_TAIL_CUS")) : 16;
+    return v;
+}
+static void make_stream_pair(int device, int tail_cus, hipStream_t *ks, hipStream_t *ts)
+{
+    const int want = tail_cus >= 0 ? tail_cus : tail_cus_default();
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, device));
+    const int n_cu = prop.multiProcessorCount;
+    if (want <= 0 || want >= n_cu) {
+        HIP_OK(hipStreamCreateWithFlags(ks, hipStreamNonBlocking));
+        HIP_OK(hipStreamCreateWithFlags(ts, hipStreamNonBlocking));
+        return;
+    }
+    std::vector<uint32_t> mask_k((size_t)(n_cu + 31) / 32, 0u), mask_t((size_t)(n_cu + 31) / 32, 0u);
+    for (int cu = 0; cu < n_cu; cu++) (cu < want ? mask_t : mask_k)[(size_t)cu / 32] |= 1u << (cu % 32);
+    HIP_OK(hipExtStreamCreateWithCUMask(ks, (uint32_t)mask_k.size(), mask_k.data()));
+    HIP_OK(hipExtStreamCreateWithCUMask(ts, (uint32_t)mask_t.size(), mask_t.data()));
+}
+
+int kbo_stream_pair_create(int tail_cus, void **stream, void **tail_stream)
+{
+    return guarded([&] {
+        KBO_REQUIRE(stream && tail_stream, KBO_E_BAD_ARG, "null argument");
+        hipStream_t ks = nullptr, ts = nullptr;
+        make_stream_pair(current_device(), tail_cus, &ks, &ts);
+        *stream = ks;
+        *tail_stream = ts;
+    });
+}
+
+void kbo_stream_pair_destroy(void *stream, void *tail_stream)
+{
+    if (stream) (void)hipStreamDestroy(static_cast<hipStream_t>(stream));
+    if (tail_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(tail_stream));
+}
+
 struct kbo_map_stream {
     kbo_index_t *idx = nullptr;
     int device = 0;
-    struct Pipe { hipStream_t ks = nullptr, ts = nullptr; };
+    // a pipeline: the kernels' stream `ks` (all compute units but sixteen) and the second passes' stream `ts` (those sixteen), where a
+    // second pass that is a thin chain of look-ups - few reads flagged: what the latest second passes reported into `fb` - runs unhindered
+    // and hinders nobody.  A second pass that is WORK (5 % substitutions, long sequences, repeats: 3 - 4 x slower confined to 16 units) goes
+    // behind its own kernel on `ks`, beside the other pipeline's kernel.  (Further streams for such batches - plain ones, made with the
+    // stream or by the first batch that needs them - cost more than they gave: the runtime's streams share a handful of hardware queues,
+    // and with eight of the library's alive the headline fell from 866 to 563 - 615 Gbp/s, or 5 % substitutions from 245 to 133.)
+    struct Pipe {
+        hipStream_t ks = nullptr, ts = nullptr;
+        uint32_t *fb = nullptr; // pinned: [0] flagged reads / pieces of the latest second pass that started (~0: none yet)
+        uint32_t units = 0;     // ... of how many (the latest batch submitted)
+    };
     struct Slot {
         DevBuf work, ms;
         hipEvent_t done = nullptr;
@@ -1563,6 +1624,7 @@ struct kbo_map_stream {
         for (auto &p : pipes) {
             if (p.ks) (void)hipStreamDestroy(p.ks);
             if (p.ts) (void)hipStreamDestroy(p.ts);
+            if (p.fb) (void)hipHostFree(p.fb);
         }
     }
 };
@@ -1583,8 +1645,9 @@ int kbo_map_stream_create(kbo_index_t *idx, int pipelines, size_t max_seqs, uint
         m->pipes.resize((size_t)pipelines);
         m->slots.resize(2 * (size_t)pipelines);
         for (auto &p : m->pipes) {
-            HIP_OK(hipStreamCreateWithFlags(&p.ks, hipStreamNonBlocking));
-            HIP_OK(hipStreamCreateWithFlags(&p.ts, hipStreamNonBlocking));
+            make_stream_pair(m->device, -1, &p.ks, &p.ts);
+            HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&p.fb), 64, hipHostMallocDefault));
+            p.fb[0] = 0xFFFFFFFFu;
         }
         for (auto &sl : m->slots) {
             sl.work.alloc(m->work_bytes + 64);
@@ -1618,22 +1681,28 @@ int kbo_map_stream_submit(kbo_map_stream_t *m, const uint8_t *d_concat, const ui
     const uint64_t n = m->next;
     kbo_map_stream::Pipe &p = m->pipes[n % m->pipes.size()];
     kbo_map_stream::Slot &sl = m->slots[n % m->slots.size()];
+    // where the second pass goes: the confined stream while the pipeline's latest second passes had at most one read (piece) in two hundred
+    // to do - a chain of look-ups, not work - and while nothing is known yet; else behind the batch's own kernel
+    const uint32_t last_flagged = *reinterpret_cast<volatile uint32_t *>(p.fb);
+    const bool thin = tail_cus_default() > 0 && (last_flagged == 0xFFFFFFFFu || p.units == 0 || (uint64_t)last_flagged * 200u <= p.units);
+    hipStream_t kern = p.ks, tail = (thin || tail_cus_default() <= 0) ? p.ts : p.ks;
     rc = guarded([&] {
         // the slot's buffers are free again behind its last batch; the inputs are there behind what ready_stream holds so far
-        if (sl.ticket) HIP_OK(hipStreamWaitEvent(p.ks, sl.done, 0));
+        if (sl.ticket) HIP_OK(hipStreamWaitEvent(kern, sl.done, 0));
         if (ready_stream) {
             HIP_OK(hipEventRecord(m->ready, static_cast<hipStream_t>(ready_stream)));
-            HIP_OK(hipStreamWaitEvent(p.ks, m->ready, 0));
+            HIP_OK(hipStreamWaitEvent(kern, m->ready, 0));
         }
     });
     if (rc != KBO_OK) return rc;
     rc = map_batch_dev_impl(m->idx, d_concat, d_offsets, n_seqs, total_bases, max_seq_len, max_error_prob, format, d_ms_out ? 1 : 0,
-                            d_ms_out ? d_ms_out : sl.ms.as<uint8_t>(), d_chars_out, sl.work.p, m->work_bytes, p.ks, p.ts, true, fused);
+                            d_ms_out ? d_ms_out : sl.ms.as<uint8_t>(), d_chars_out, sl.work.p, m->work_bytes, kern, tail, true, fused, nullptr,
+                            p.fb, &p.units);
     if (rc != KBO_OK) return rc;
     rc = guarded([&] { // complete when both streams have come this far
-        HIP_OK(hipEventRecord(m->kdone, p.ks));
-        HIP_OK(hipStreamWaitEvent(p.ts, m->kdone, 0));
-        HIP_OK(hipEventRecord(sl.done, p.ts));
+        HIP_OK(hipEventRecord(m->kdone, kern));
+        HIP_OK(hipStreamWaitEvent(tail, m->kdone, 0));
+        HIP_OK(hipEventRecord(sl.done, tail));
     });
     if (rc != KBO_OK) return rc;
     m->next = n + 1;
@@ -1680,10 +1749,9 @@ int kbo_map_stream_sync(kbo_map_stream_t *m)
     return guarded([&] {
         KBO_REQUIRE(m, KBO_E_BAD_ARG, "null stream");
         std::lock_guard<std::mutex> g(m->mu);
-        for (auto &p : m->pipes) {
-            HIP_OK(hipStreamSynchronize(p.ks));
-            HIP_OK(hipStreamSynchronize(p.ts));
-        }
+        for (auto &p : m->pipes)
+            for (hipStream_t s : {p.ks, p.ts})
+                if (s) HIP_OK(hipStreamSynchronize(s));
     });
 }
 

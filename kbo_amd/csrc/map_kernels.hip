@@ -1225,10 +1225,20 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
             if (w_unsettled) spw[w_owner * 16u + 13u] = 1;
             um = 0;
         }
+        // (a read without a seed whose windows are in the index - a read of the genome whose head gave no seed: every one of its windows,
+        // a pending list full of them - is the second pass's as before, and so is whatever a wave has beyond two searches: a search is ten
+        // dependent rounds for the whole wave, and forty-four such reads in a million were a tenth of the kernel's time as its last waves)
+        uint32_t n_search = 0;
         while (um) {
             const int src = __builtin_ctzll(um);
             um &= um - 1ull;
             const uint32_t e_ = __shfl(w_e, src), at_ = __shfl(w_at, src), wl_ = __shfl(w_len, src), own_ = __shfl(w_owner, src);
+            const bool own_np = __shfl(no_plan ? 1u : 0u, (int)own_) != 0u;
+            if (own_np || n_search >= 2u || spw[own_ * 16u + 13u] != 0) { // (wave-uniform)
+                if (lane == 0) spw[own_ * 16u + 13u] = 1;
+                continue;
+            }
+            n_search++;
             const uint32_t soff_ = at_ - e_, c_ = thr + 1u - order;
             const uint32_t e_lo = max(e_, thr), e_hi = min(e_ + c_, wl_ - 1u);
             bool alive = e_lo <= e_hi && lane <= e_hi - e_lo;

@@ -96,10 +96,10 @@ def test_bench_c4_shape_eight_ranks(tmp_path):
     """the launch the driver makes on an 8-GPU node, executed once with world = 8 (all ranks on this box's one GPU, rendezvous over
     gloo: functional only): --config C4's strong-scaling shards - contiguous, ceil(reads / 8) each, the last one short, tiling the
     read set exactly - the index cache built once by the parent, the CPU quota split cores // world"""
-    r = _run(["--config", "C4", "--gpus", "8", "--genome", "300000", "--reads", "40003", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.5", "--no-extras"],
+    r = _run(["--config", "C4", "--gpus", "8", "--genome", "300000", "--reads", "240003", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.5", "--no-extras"],
              tmp_path, {"KBO_BENCH_ONE_GPU": "1"})
     _check_line(r, 8)
-    assert r["scaling"] == "strong" and "40003 x 150 bp reads in all, 5001 per GPU" in r["config"]["workload"] and "x8" in r["config"]["parallelism"]
+    assert r["scaling"] == "strong" and "240003 x 150 bp reads in all, 30001 per GPU" in r["config"]["workload"] and "x8" in r["config"]["parallelism"]
     lo, hi = r["roofline"]["kernel_ms_per_rank"]["min"], r["roofline"]["kernel_ms_per_rank"]["max"]
     assert 0 < lo <= hi
 
