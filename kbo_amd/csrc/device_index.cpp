@@ -236,9 +236,13 @@ void build_plan_structures(kbo_index *idx, DevCopy *dc)
         static const int env_filter = std::getenv("KBO_DEPTH_FILTER") ? std::atoi(std::getenv("KBO_DEPTH_FILTER")) : -1; // experiments
         // (round 5, C3: a filter of 14 bases - 32 MB, the Infinity Cache's rather than an L2's - by KBO_DEPTH_FILTER=14: 348 against 354
         // Gbp/s without; larger indexes keep none)
+        // (round 6: the one kernel at 24 resident waves a CU is bound by its fabric traffic on large indexes - 12.7 GB per 1.5 Gbases at C3,
+        // 5.9 TB/s - and a filter the Infinity Cache keeps pays there too: C3 with 14 / 15 bases (32 / 128 MB) 536 / 575 against 500 Gbp/s,
+        // the kernel alone 2.02 / 1.85 against 2.20 ms.  Indexes beyond the L2's 12 bases take 15: a window in eleven passes at 10^8 rows)
         uint32_t fb = 0;
-        for (uint32_t f = 6; f <= 12u; f++)
+        for (uint32_t f = 6; f <= 15u; f++)
             if (2ull * idx->host.n_sets <= (1ull << (2u * f))) { fb = f; break; }
+        if (fb > 12u) fb = 15u;
         if (env_filter >= 0) fb = (uint32_t)env_filter;
         if (fb < 6u || fb > 15u || fb + 2u > (uint32_t)order) fb = 0;
         if (fb) {
