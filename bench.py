@@ -256,7 +256,7 @@ def main(argv=None):
         L.kbo_set_plan_stats(0)
         gpu_d = dev.ms.cpu().numpy()
         cpu = b_ref = exact = ops = b_plan = model = None
-        sens = h2h = ms_var = None
+        sens = h2h = ms_var = one_shot = None
         if world == 1 and not args.no_cpu_baseline and not args.no_extras and (args.extras or not args.custom):
             # (first of the legs behind the timed region: its pinned staging buffers are made by its first call, and behind the
             # oracle's and the variants' gigabytes of host allocations they come out of scattered pages - 21 instead of 40 Gbp/s)
@@ -291,6 +291,7 @@ def main(argv=None):
             if world == 1 and not args.no_extras and (args.extras or not args.custom):
                 sens = sensitivity_leg(args, genome, sbwt, oi, torch, device, stream, n_pipes if piped else None)
                 ms_var = ms_leg(args, sbwt, oi, concat0, offsets0, torch, device, stream, n_pipes if piped else None)
+                one_shot = one_shot_map_leg(args, genome, oi) if args.genome <= 20_000_000 else None
         # fabric-side traffic and L2 misses of the A1 stage, from the committed rocprofv3 passes of this exact
         # workload and walk mode (PMC passes cannot run inside the timed region: separate runs, tools/profile_bench.sh)
         wl_key = f"{args.genome}x{n_mine}x{args.read_len}x{args.sub_rate:g}:{('map' if one_kernel else 'table' if sbwt.depth_table_order() > 0 else 'plan') if planned else 'plain'}"
@@ -470,6 +471,7 @@ def main(argv=None):
             "reference_ops_per_base": ops,
             "sensitivity": sens,
             "ms_variant": ms_var,
+            "one_shot_map": one_shot,
             "host_to_host": h2h,
         }
         print(json.dumps(result), flush=True)

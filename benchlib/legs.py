@@ -302,6 +302,45 @@ def ms_leg(args, sbwt, oi, concat, offsets, torch, device, stream, pipes):
     return out
 
 
+def one_shot_map_leg(args, genome, oi):
+    """The call shape the reference has (lib.rs:720-761): ONE ref_seq of about the genome's length mapped against an index that is built
+    for it - build, device copy and the first call all counted (a single call never reaches the bases that pay for the plan structures:
+    it takes the walk + the derandomize / translate kernels), then the same call again, then with the plan structures made up front
+    (kbo_index_to_device: what a caller with many sequences per index asks for)."""
+    import kbo_amd
+    from kbo_amd import synth
+    rng = np.random.default_rng(5)
+    n = min(len(genome), 5_000_000)
+    ref = genome[:n].copy()
+    hit = rng.random(n) < args.sub_rate
+    ref[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+    opts = kbo_amd.MapOpts(fill_gaps=False, call_variants=False, format=True)
+    t0 = time.perf_counter()
+    sb, _ = kbo_amd.build([genome], kbo_amd.BuildOpts(k=args.k, num_threads=min(16, usable_cores()[0])))
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out1 = kbo_amd.map(ref, sb, None, opts)
+    t_first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    kbo_amd.map(ref, sb, None, opts)
+    t_again = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    sb.to_device(-1)  # (the plan structures now)
+    t_plan = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out3 = kbo_amd.map(ref, sb, None, opts)
+    t_planned = time.perf_counter() - t0
+    res = {"entry_point": "kbo_build + kbo_map (fill_gaps = false, call_variants = false)", "ref_seq_bases": int(n), "index_bases": int(len(genome)),
+           "build_s": round(t_build, 3), "first_map_s": round(t_first, 3), "second_map_s": round(t_again, 4),
+           "plan_structures_s": round(t_plan, 3), "map_with_plan_structures_s": round(t_planned, 4),
+           "end_to_end_mbp_per_s": round(n / (t_build + t_first) / 1e6, 2), "same_output_with_plan_structures": bool(out1 == out3)}
+    if oi is not None:
+        exp = oi.matches_batch(ref, np.array([0, n], dtype=np.uint64), 1e-7, n_threads=usable_cores()[0])
+        from oracle import binding as ora
+        res["bit_exact_vs_oracle"] = bool(out1 == bytes(ora.relative_to_ref(ref, exp)))
+    return res
+
+
 def host_to_host_leg(args, sbwt, genome):
     """The product entry point a binding calls: kbo_map_batch over pageable host buffers (H2D, kernels, D2H in a three-stage
     slab pipeline); PCIe-inclusive, never the reported value.  4 x the batch, best of 3."""

@@ -1562,8 +1562,17 @@ static void make_stream_pair(int device, int tail_cus, hipStream_t *ks, hipStrea
     }
     std::vector<uint32_t> mask_k((size_t)(n_cu + 31) / 32, 0u), mask_t((size_t)(n_cu + 31) / 32, 0u);
     for (int cu = 0; cu < n_cu; cu++) (cu < want ? mask_t : mask_k)[(size_t)cu / 32] |= 1u << (cu % 32);
-    HIP_OK(hipExtStreamCreateWithCUMask(ks, (uint32_t)mask_k.size(), mask_k.data()));
-    HIP_OK(hipExtStreamCreateWithCUMask(ts, (uint32_t)mask_t.size(), mask_t.data()));
+    // (a runtime that refuses the masks - none seen - gets plain streams: slower, never wrong)
+    if (hipExtStreamCreateWithCUMask(ks, (uint32_t)mask_k.size(), mask_k.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        *ks = nullptr;
+        HIP_OK(hipStreamCreateWithFlags(ks, hipStreamNonBlocking));
+    }
+    if (hipExtStreamCreateWithCUMask(ts, (uint32_t)mask_t.size(), mask_t.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        *ts = nullptr;
+        HIP_OK(hipStreamCreateWithFlags(ts, hipStreamNonBlocking));
+    }
 }
 
 int kbo_stream_pair_create(int tail_cus, void **stream, void **tail_stream)

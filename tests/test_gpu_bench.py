@@ -71,6 +71,9 @@ def test_bench_line_single_process_with_extras(tmp_path):
     assert any("insertions / deletions" in n and "ONT" not in n for n in names) and any("ONT-like" in n for n in names)
     assert all(v["bit_exact_vs_oracle"] is True and v["value"] > 0 for v in r["sensitivity"])
     assert r["host_to_host"]["value"] > 0
+    # the reference's call shape: one ref_seq against an index built for it, end to end (build + device copy + the call)
+    osm = r["one_shot_map"]
+    assert osm["bit_exact_vs_oracle"] is True and osm["same_output_with_plan_structures"] is True and osm["build_s"] > 0 and osm["first_map_s"] > 0
     # the forms of the API that return the matching statistics: timed, every MS byte against the oracle
     for key in ("kbo_ms_batch_dev", "kbo_map_batch_dev_want_ms"):
         assert r["ms_variant"][key]["value"] > 0 and r["ms_variant"][key]["bit_exact_vs_oracle"] is True
