@@ -33,6 +33,10 @@ int kbo_set_guided_walk(int waves_per_cu, int recovery_lines);
  * (default 24 Mi; 0 = always, UINT64_MAX = never; applies to device copies made after the call), used by the walk from
  * matches at least min_depth deep (default 16; < 0 keeps it). */
 int kbo_set_pair_steps(uint64_t min_rows, int min_depth);
+/* tests: the rank blocks, contraction entries and two-base blocks of the index's copy on `device` (-1: the current one) - made on the
+ * device from the row bit-vectors and the LCS bytes (layout_kernels.hip) - against the host's single-threaded construction of the same
+ * layout: *n_diff = the bytes that differ.  KBO_DEVICE_LAYOUT=0 in the environment makes copies from the host's instead. */
+int kbo_index_layout_check(kbo_index_t *idx, int device, uint64_t *n_diff);
 /* Host batches (kbo_matches_batch / kbo_map_batch / kbo_find_batch and the packed forms): caller's buffers that are pinned
  * already (hipHostMalloc / hipHostRegister) are used in place - no staging copies, no host threads busy - instead of being
  * staged through the slots' own pinned buffers like pageable ones.  Default 0: staged is the faster of the two on the MI355X

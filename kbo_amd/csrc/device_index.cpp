@@ -321,23 +321,31 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
         const bool want_pairs = idx->host.n_sets >= g_pair_min_rows && !g_force_big &&
                                 est_rank * 5 + est_ent + 64 < 0xFFFFFFF0ull;
         clk::time_point t0 = clk::now();
+        // rank blocks, contraction entries and two-base blocks are made on the device from the index's own arrays (layout_kernels.hip:
+        // 1.5 bytes a row over PCIe instead of 12.7; the host's single-threaded make_device_layout was 40 s of a 54 s copy at 3 * 10^9
+        // rows); KBO_DEVICE_LAYOUT=0: the host's, uploaded - the same bytes (kbo_index_layout_check)
+        static const int env_dev_layout = std::getenv("KBO_DEVICE_LAYOUT") ? std::atoi(std::getenv("KBO_DEVICE_LAYOUT")) : 1;
+        const bool on_device = env_dev_layout != 0;
         kbo::DeviceLayout lay;
-        kbo::make_device_layout(idx->host, lay, want_pairs);
+        if (!on_device) kbo::make_device_layout(idx->host, lay, want_pairs);
+        const uint64_t n_rows = idx->host.n_sets;
+        const uint64_t lay_n_blocks = n_rows / kbo::kRankRowsPerBlock + 2;
+        const size_t lay_ent_words = 3 * (size_t)(n_rows + 1) + 4, lay_pair_words = want_pairs ? (size_t)16 * lay_n_blocks * 4 : 0;
         int prev = current_device();
         if (prev != device) HIP_OK(hipSetDevice(device));
         DevCopy *dc = new DevCopy();
         dc->setup.layout_s = since(t0);
         try {
             t0 = clk::now();
-            const size_t per = lay.n_blocks * 16;
+            const size_t per = lay_n_blocks * 16;
             // arena = rank blocks of A,C,G,T | one all-zero "null" block | contraction entries.
             // When that exceeds the 32-bit offset range (n_sets * 12 B of entries >= ~4 GiB) the
             // entries get their own allocation and 64-bit offsets ("big" kernels).
-            const size_t ent_bytes = lay.ent.size() * sizeof(uint32_t);
+            const size_t ent_bytes = lay_ent_words * sizeof(uint32_t);
             const size_t rank_bytes = per * 4 + 16;
             KBO_REQUIRE(rank_bytes < 0xFFFFFFF0ull, KBO_E_UNSUPPORTED, "rank blocks >= 4 GiB");
             dc->big = g_force_big || rank_bytes + ent_bytes >= 0xFFFFFFF0ull;
-            const size_t pair_bytes = dc->big ? 0 : lay.pair.size() * sizeof(uint32_t);
+            const size_t pair_bytes = dc->big ? 0 : lay_pair_words * sizeof(uint32_t);
             const size_t base_bytes = ((dc->big ? rank_bytes : rank_bytes + ent_bytes) + 15) / 16 * 16;
             const size_t arena_bytes = base_bytes + pair_bytes;
             if (idx->transient && !dc->big && !DevCopy::transient_arena_in_use()) {
@@ -350,21 +358,29 @@ kbo::DevIndexView device_view(kbo_index *idx, int device, DevCopy::PlanState **p
                 dc->arena.alloc(arena_bytes);
             }
             HIP_OK(hipMemset(dc->arena.p, 0, arena_bytes));
-            for (int c = 0; c < 4; c++)
-                HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + per * c, lay.rank[c].data(), per,
-                                 hipMemcpyHostToDevice));
-            if (dc->big) {
-                dc->ent.alloc(ent_bytes + 16);
-                HIP_OK(hipMemcpy(dc->ent.p, lay.ent.data(), ent_bytes, hipMemcpyHostToDevice));
+            if (dc->big) dc->ent.alloc(ent_bytes + 16);
+            uint8_t *d_ent = dc->big ? dc->ent.as<uint8_t>() : dc->arena.as<uint8_t>() + rank_bytes;
+            if (on_device) {
+                const size_t n_words = (size_t)((n_rows + 63) / 64);
+                DevBuf d_rows(4 * n_words * 8 + 64), d_lcs((size_t)n_rows + 64), d_scr(kbo::device_layout_scratch_bytes(n_rows));
+                const uint64_t *rows_dev[4];
+                for (int c = 0; c < 4; c++) {
+                    HIP_OK(hipMemcpy(d_rows.as<uint8_t>() + (size_t)c * n_words * 8, idx->host.rows[c].data(), n_words * 8, hipMemcpyHostToDevice));
+                    rows_dev[c] = reinterpret_cast<const uint64_t *>(d_rows.as<uint8_t>() + (size_t)c * n_words * 8);
+                }
+                if (n_rows) HIP_OK(hipMemcpy(d_lcs.p, idx->host.lcs.data(), (size_t)n_rows, hipMemcpyHostToDevice));
+                if (dc->big) HIP_OK(hipMemset(dc->ent.p, 0, ent_bytes + 16));
+                HIP_OK(kbo::build_device_layout(rows_dev, n_words, d_lcs.as<uint8_t>(), n_rows, idx->host.C, (uint32_t)lay_n_blocks,
+                                                dc->arena.as<uint4>(), reinterpret_cast<uint32_t *>(d_ent),
+                                                pair_bytes ? reinterpret_cast<uint4 *>(dc->arena.as<uint8_t>() + base_bytes) : nullptr, d_scr.p, nullptr));
             } else {
-                HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + rank_bytes, lay.ent.data(), ent_bytes,
-                                 hipMemcpyHostToDevice));
+                for (int c = 0; c < 4; c++)
+                    HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + per * c, lay.rank[c].data(), per, hipMemcpyHostToDevice));
+                HIP_OK(hipMemcpy(d_ent, lay.ent.data(), ent_bytes, hipMemcpyHostToDevice));
+                if (pair_bytes) HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + base_bytes, lay.pair.data(), pair_bytes, hipMemcpyHostToDevice));
             }
-            if (pair_bytes) {
-                HIP_OK(hipMemcpy(dc->arena.as<uint8_t>() + base_bytes, lay.pair.data(), pair_bytes, hipMemcpyHostToDevice));
-                dc->pair_off = (uint32_t)(base_bytes / 16);
-            }
-            dc->n_blocks = lay.n_blocks;
+            if (pair_bytes) dc->pair_off = (uint32_t)(base_bytes / 16);
+            dc->n_blocks = lay_n_blocks;
             idx->rank_bytes = per * 4;
             idx->lcs_bytes = ent_bytes;
             dc->setup.rank_bytes = rank_bytes;

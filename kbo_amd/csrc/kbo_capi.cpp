@@ -2161,6 +2161,36 @@ int kbo_index_plan_holdoff(kbo_index_t *idx, int device, uint32_t *bails, int *h
     });
 }
 
+// test hook (kbo_hip_tuning.h): the rank blocks, contraction entries and two-base blocks of the copy on `device` (made on the device:
+// layout_kernels.hip) against the host's make_device_layout -> *n_diff = bytes that differ (0: the same layout)
+int kbo_index_layout_check(kbo_index_t *idx, int device, uint64_t *n_diff)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && n_diff, KBO_E_BAD_ARG, "null argument");
+        require_unsharded(idx, "kbo_index_layout_check");
+        const int dev = device < 0 ? current_device() : device;
+        std::lock_guard<std::mutex> g(idx->mu);
+        auto it = idx->dev.find(dev);
+        KBO_REQUIRE(it != idx->dev.end(), KBO_E_BAD_ARG, "the index has no copy on that device");
+        const DevCopy &dc = *it->second;
+        kbo::DeviceLayout lay;
+        kbo::make_device_layout(idx->host, lay, dc.pair_off != 0);
+        KBO_REQUIRE(lay.n_blocks == dc.n_blocks, KBO_E_BAD_ARG, "block counts differ");
+        const size_t per = lay.n_blocks * 16, ent_bytes = lay.ent.size() * 4, pair_bytes = lay.pair.size() * 4;
+        uint64_t diff = 0;
+        auto compare = [&](const void *d_ptr, const void *h_ptr, size_t bytes) {
+            std::vector<uint8_t> got(bytes);
+            HIP_OK(hipMemcpy(got.data(), d_ptr, bytes, hipMemcpyDeviceToHost));
+            const uint8_t *want = static_cast<const uint8_t *>(h_ptr);
+            for (size_t i = 0; i < bytes; i++) diff += got[i] != want[i];
+        };
+        for (int c = 0; c < 4; c++) compare(dc.arena.as<uint8_t>() + per * c, lay.rank[c].data(), per);
+        compare(dc.big ? dc.ent.as<uint8_t>() : dc.arena.as<uint8_t>() + per * 4 + 16, lay.ent.data(), ent_bytes);
+        if (dc.pair_off) compare(dc.arena.as<uint8_t>() + (size_t)dc.pair_off * 16, lay.pair.data(), pair_bytes);
+        *n_diff = diff;
+    });
+}
+
 int kbo_index_device_layout(kbo_index_t *idx, int device, kbo_device_layout *out)
 {
     return guarded([&] {

@@ -342,6 +342,11 @@ hipError_t launch_call_finalize(const void *d_lists, const uint32_t *d_counts, c
                                 bool by_walk, const uint64_t *d_off, uint32_t n_seqs, uint32_t k, const uint8_t *d_ms,
                                 const DevIndexView &ix, void *d_recs, uint8_t *d_win, uint32_t stride, hipStream_t stream);
 
+// ---- a device copy's rank blocks / contraction entries / two-base blocks made on the device (layout_kernels.hip; formats: sbwt_index.hpp)
+size_t device_layout_scratch_bytes(uint64_t n_sets);
+hipError_t build_device_layout(const uint64_t *const d_rows[4], uint64_t n_words, const uint8_t *d_lcs, uint64_t n, const uint64_t C[4],
+                               uint32_t n_blocks, uint4 *d_rank, uint32_t *d_ent, uint4 *d_pair, void *d_scratch, hipStream_t stream);
+
 // ---- the tail of kbo::call on the device (call_emit_kernels.hip): the variants of a slab's sites in the order of (sequence, query
 // position), as flat arrays.  d_meta: kCallMetaWords words
 constexpr uint32_t kCallMetaSites = 0, kCallMetaValid = 1, kCallMetaVariants = 2, kCallMetaChars = 3, kCallMetaHost = 4, kCallMetaFlags = 5,

@@ -481,3 +481,28 @@ def test_host_batches_over_two_distinct_devices(oracle):
     for s in range(40):
         exp, _, _ = ora.call(c2[5000 * s:5000 * (s + 1)].tobytes(), 31, 1e-7)
         assert [(q, a.decode(), b.decode()) for q, a, b in per_dev[1][s]] == exp
+
+
+def test_device_made_layout_equals_the_hosts(plan_restore):
+    """a device copy's rank blocks, contraction entries and two-base blocks are made on the device from the row bit-vectors and the LCS bytes
+    (layout_kernels.hip): byte for byte the host's make_device_layout - 32-bit entries in the arena, 64-bit entries by force, two-base
+    blocks, an index with repeats (long stretches of equal LCS values) and one of a single short sequence"""
+    import ctypes as C
+    import torch
+    L = kbo_amd.lib()
+    rng = np.random.default_rng(7)
+    g = synth.genome(700_000, seed=99)
+    rep = np.concatenate([g[:200_000], np.tile(g[1000:1400], 50), g[200_000:300_000], np.full(300, ord("A"), dtype=np.uint8), g[300_000:400_000]])
+    cases = [("plain", [g], 31, 0, 0), ("pairs", [g], 31, 1, 0), ("big", [g[:300_000]], 51, 0, 1), ("repeats", [rep, g[:5000]], 21, 1, 0),
+             ("tiny", [g[:40]], 11, 0, 0), ("many short", [g[i:i + 37] for i in range(0, 20_000, 50)], 15, 1, 1)]
+    for name, seqs, k, pairs, big in cases:  # (tests/conftest.py puts the knobs back behind the test)
+        L.kbo_set_pair_steps(0 if pairs else (1 << 63), 4)
+        L.kbo_set_force_big_layout(big)
+        sbwt, _ = kbo_amd.build(seqs, kbo_amd.BuildOpts(k=k, num_threads=_threads()))
+        with torch.cuda.device(0):
+            sbwt.to_device(-1)
+            diff = C.c_uint64(123)
+            kbo_amd.check(L.kbo_index_layout_check(sbwt._h, -1, C.byref(diff)))
+        assert diff.value == 0, (name, diff.value)
+        lay = sbwt.device_layout()
+        assert bool(lay["pair_bytes"]) == bool(pairs and not big), name
