@@ -37,6 +37,9 @@ int kbo_set_pair_steps(uint64_t min_rows, int min_depth);
  * device from the row bit-vectors and the LCS bytes (layout_kernels.hip) - against the host's single-threaded construction of the same
  * layout: *n_diff = the bytes that differ.  KBO_DEVICE_LAYOUT=0 in the environment makes copies from the host's instead. */
 int kbo_index_layout_check(kbo_index_t *idx, int device, uint64_t *n_diff);
+/* tests: the handle's path cover - laid out on the device by the first copy that needed it (cover_kernels.hip) - against the host's
+ * construction (path_cover.cpp): *n_diff = entries of text / pos / node_at that differ.  KBO_DEVICE_COVER=0: the host's from the start. */
+int kbo_index_cover_check(kbo_index_t *idx, uint64_t *n_diff);
 /* Host batches (kbo_matches_batch / kbo_map_batch / kbo_find_batch and the packed forms): caller's buffers that are pinned
  * already (hipHostMalloc / hipHostRegister) are used in place - no staging copies, no host threads busy - instead of being
  * staged through the slots' own pinned buffers like pageable ones.  Default 0: staged is the faster of the two on the MI355X

@@ -117,7 +117,7 @@ TUNING_SYMBOLS = [
     "kbo_walk_geometry", "kbo_set_walk_waves_per_cu", "kbo_set_walk_threads", "kbo_set_walk_rare", "kbo_set_guided_walk",
     "kbo_set_pair_steps", "kbo_set_force_big_layout", "kbo_set_seed_table_depth", "kbo_set_plan", "kbo_set_plan_tuning",
     "kbo_set_plan_unit_cap_divisor", "kbo_index_plan_holdoff", "kbo_set_walk_experiment", "kbo_plan_stats_dev", "kbo_set_plan_stats", "kbo_set_index_shards", "kbo_index_shard", "kbo_set_depth_table", "kbo_set_depth_table_anchors", "kbo_index_depth_table", "kbo_run_automaton_depths",
-    "kbo_set_stage_timing", "kbo_stage_timing_read", "kbo_set_plan_table_budget", "kbo_set_plan_lazy", "kbo_plan_flags_dev", "kbo_long_stats_dev", "kbo_set_map_long", "kbo_set_ms_one_kernel", "kbo_set_call_device_emit", "kbo_index_layout_check",
+    "kbo_set_stage_timing", "kbo_stage_timing_read", "kbo_set_plan_table_budget", "kbo_set_plan_lazy", "kbo_plan_flags_dev", "kbo_long_stats_dev", "kbo_set_map_long", "kbo_set_ms_one_kernel", "kbo_set_call_device_emit", "kbo_index_layout_check", "kbo_index_cover_check",
     "kbo_set_host_in_place",
 ]
 
@@ -248,6 +248,7 @@ def lib():
     L.kbo_set_ms_one_kernel.argtypes = [C.c_int]
     L.kbo_set_call_device_emit.argtypes = [C.c_int]
     L.kbo_index_layout_check.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64)]
+    L.kbo_index_cover_check.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.kbo_map_stream_create.argtypes = [vp, C.c_int, sz, u64, sz, vp]
     L.kbo_map_stream_submit.argtypes = [vp, vp, vp, sz, u64, sz, C.c_double, C.c_int, vp, vp, vp, vp, C.POINTER(C.c_int)]
     L.kbo_map_stream_wait.argtypes = [vp, u64]

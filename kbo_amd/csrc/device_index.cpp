@@ -88,20 +88,53 @@ void build_plan_structures(kbo_index *idx, DevCopy *dc)
         HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&dc->plan.bailed), 64, hipHostMallocDefault));
         dc->plan.bailed[0] = dc->plan.bailed[1] = 0;
     }
+    static_assert(kbo::PathCover::kPad == kbo::kPlanPad, "text padding");
+    bool made_here = false;
     if (!idx->cover) { // (idx->mu is held)
-        idx->cover.reset(new kbo::PathCover());
-        kbo::make_path_cover(idx->host, *idx->cover);
+        // laid out on the device, straight into the copy's buffers (cover_kernels.hip: the same layout position for position; the host's
+        // pointer chase was 26 s per 10^8 rows), and kept on the host for index files and further copies; rows left without a position
+        // (cycles no head leads into) or KBO_DEVICE_COVER=0: the host's construction
+        static const int env_dev_cover = std::getenv("KBO_DEVICE_COVER") ? std::atoi(std::getenv("KBO_DEVICE_COVER")) : 1;
+        const uint64_t n_rows = idx->host.n_sets;
+        if (env_dev_cover != 0 && n_rows > 0) {
+            const size_t text_bytes = (size_t)n_rows + 2 * kbo::PathCover::kPad;
+            dc->pc_text.alloc(text_bytes + 16);
+            dc->pc_pos.alloc((size_t)n_rows * 4 + 16);
+            dc->pc_node.alloc((size_t)n_rows * 4 + 16);
+            HIP_OK(hipMemsetAsync(dc->pc_text.p, 0, text_bytes + 16, bs));
+            HIP_OK(hipMemsetAsync(dc->pc_node.p, 0, (size_t)n_rows * 4 + 16, bs));
+            const uint32_t *d_ent = dc->big ? dc->ent.as<uint32_t>()
+                                            : reinterpret_cast<const uint32_t *>(dc->arena.as<uint8_t>() + dc->n_blocks * 64 + 16);
+            bool ok = false;
+            HIP_OK(kbo::build_path_cover_device(dc->arena.as<uint4>(), d_ent, n_rows, (uint32_t)dc->n_blocks, idx->host.k, idx->host.C,
+                                                dc->pc_text.as<uint8_t>() + kbo::PathCover::kPad, dc->pc_pos.as<uint32_t>(), dc->pc_node.as<uint32_t>(), bs, &ok));
+            if (ok) {
+                idx->cover.reset(new kbo::PathCover());
+                idx->cover->text.resize(text_bytes);
+                idx->cover->pos.resize(n_rows);
+                idx->cover->node_at.resize(n_rows);
+                HIP_OK(hipMemcpy(idx->cover->text.data(), dc->pc_text.p, text_bytes, hipMemcpyDeviceToHost));
+                HIP_OK(hipMemcpy(idx->cover->pos.data(), dc->pc_pos.p, (size_t)n_rows * 4, hipMemcpyDeviceToHost));
+                HIP_OK(hipMemcpy(idx->cover->node_at.data(), dc->pc_node.p, (size_t)n_rows * 4, hipMemcpyDeviceToHost));
+                made_here = true;
+            }
+        }
+        if (!made_here) {
+            idx->cover.reset(new kbo::PathCover());
+            kbo::make_path_cover(idx->host, *idx->cover);
+        }
     }
     dc->setup.cover_s = since(t0);
     t0 = clk::now();
     const kbo::PathCover &pc = *idx->cover;
-    static_assert(kbo::PathCover::kPad == kbo::kPlanPad, "text padding");
-    dc->pc_text.alloc(pc.text.size() + 16);
-    dc->pc_pos.alloc(pc.pos.size() * 4 + 16);
-    dc->pc_node.alloc(pc.node_at.size() * 4 + 16);
-    HIP_OK(hipMemcpy(dc->pc_text.p, pc.text.data(), pc.text.size(), hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(dc->pc_pos.p, pc.pos.data(), pc.pos.size() * 4, hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(dc->pc_node.p, pc.node_at.data(), pc.node_at.size() * 4, hipMemcpyHostToDevice));
+    if (!made_here) {
+        dc->pc_text.alloc(pc.text.size() + 16);
+        dc->pc_pos.alloc(pc.pos.size() * 4 + 16);
+        dc->pc_node.alloc(pc.node_at.size() * 4 + 16);
+        HIP_OK(hipMemcpy(dc->pc_text.p, pc.text.data(), pc.text.size(), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(dc->pc_pos.p, pc.pos.data(), pc.pos.size() * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(dc->pc_node.p, pc.node_at.data(), pc.node_at.size() * 4, hipMemcpyHostToDevice));
+    }
     idx->plan_bytes = pc.text.size() + pc.pos.size() * 4 + pc.node_at.size() * 4;
     dc->setup.cover_bytes = idx->plan_bytes;
     dc->setup.upload_s += since(t0);

@@ -2191,6 +2191,27 @@ int kbo_index_layout_check(kbo_index_t *idx, int device, uint64_t *n_diff)
     });
 }
 
+// test hook (kbo_hip_tuning.h): the handle's path cover (laid out on the device when its first copy made it: cover_kernels.hip) against
+// the host's make_path_cover -> *n_diff = positions of text / pos / node_at that differ (0: the same layout); KBO_E_BAD_ARG without a cover
+int kbo_index_cover_check(kbo_index_t *idx, uint64_t *n_diff)
+{
+    return guarded([&] {
+        KBO_REQUIRE(idx && n_diff, KBO_E_BAD_ARG, "null argument");
+        require_unsharded(idx, "kbo_index_cover_check");
+        std::lock_guard<std::mutex> g(idx->mu);
+        KBO_REQUIRE((bool)idx->cover, KBO_E_BAD_ARG, "the handle has no path cover yet (kbo_index_to_device makes it)");
+        kbo::PathCover want;
+        kbo::make_path_cover(idx->host, want);
+        const kbo::PathCover &got = *idx->cover;
+        KBO_REQUIRE(got.text.size() == want.text.size() && got.pos.size() == want.pos.size() && got.node_at.size() == want.node_at.size(),
+                    KBO_E_BAD_ARG, "sizes differ");
+        uint64_t diff = 0;
+        for (size_t i = 0; i < want.text.size(); i++) diff += got.text[i] != want.text[i];
+        for (size_t i = 0; i < want.pos.size(); i++) diff += (got.pos[i] != want.pos[i]) + (got.node_at[i] != want.node_at[i]);
+        *n_diff = diff;
+    });
+}
+
 int kbo_index_device_layout(kbo_index_t *idx, int device, kbo_device_layout *out)
 {
     return guarded([&] {

@@ -347,6 +347,10 @@ size_t device_layout_scratch_bytes(uint64_t n_sets);
 hipError_t build_device_layout(const uint64_t *const d_rows[4], uint64_t n_words, const uint8_t *d_lcs, uint64_t n, const uint64_t C[4],
                                uint32_t n_blocks, uint4 *d_rank, uint32_t *d_ent, uint4 *d_pair, void *d_scratch, hipStream_t stream);
 
+// ---- the path cover laid out on the device (cover_kernels.hip; what it is: path_cover.cpp).  *ok = false: rows on cycles - the host's decides
+hipError_t build_path_cover_device(const uint4 *d_rank, const uint32_t *d_ent, uint64_t n, uint32_t n_blocks, uint32_t k, const uint64_t C[4],
+                                   uint8_t *d_text, uint32_t *d_pos, uint32_t *d_node, hipStream_t stream, bool *ok);
+
 // ---- the tail of kbo::call on the device (call_emit_kernels.hip): the variants of a slab's sites in the order of (sequence, query
 // position), as flat arrays.  d_meta: kCallMetaWords words
 constexpr uint32_t kCallMetaSites = 0, kCallMetaValid = 1, kCallMetaVariants = 2, kCallMetaChars = 3, kCallMetaHost = 4, kCallMetaFlags = 5,

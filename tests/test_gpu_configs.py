@@ -485,7 +485,7 @@ def test_host_batches_over_two_distinct_devices(oracle):
 
 def test_device_made_layout_equals_the_hosts(plan_restore):
     """a device copy's rank blocks, contraction entries and two-base blocks are made on the device from the row bit-vectors and the LCS bytes
-    (layout_kernels.hip): byte for byte the host's make_device_layout - 32-bit entries in the arena, 64-bit entries by force, two-base
+    (layout_kernels.hip), its path cover from those (cover_kernels.hip): byte for byte the host's make_device_layout / make_path_cover - 32-bit entries in the arena, 64-bit entries by force, two-base
     blocks, an index with repeats (long stretches of equal LCS values) and one of a single short sequence"""
     import ctypes as C
     import torch
@@ -494,7 +494,8 @@ def test_device_made_layout_equals_the_hosts(plan_restore):
     g = synth.genome(700_000, seed=99)
     rep = np.concatenate([g[:200_000], np.tile(g[1000:1400], 50), g[200_000:300_000], np.full(300, ord("A"), dtype=np.uint8), g[300_000:400_000]])
     cases = [("plain", [g], 31, 0, 0), ("pairs", [g], 31, 1, 0), ("big", [g[:300_000]], 51, 0, 1), ("repeats", [rep, g[:5000]], 21, 1, 0),
-             ("tiny", [g[:40]], 11, 0, 0), ("many short", [g[i:i + 37] for i in range(0, 20_000, 50)], 15, 1, 1)]
+             ("tiny", [g[:40]], 11, 0, 0), ("many short", [g[i:i + 37] for i in range(0, 20_000, 50)], 15, 1, 1),
+             ("a cycle", [np.tile(g[5000:5050], 40), g[:3000]], 13, 0, 0), ("contigs", [g[i:i + 20_000] for i in range(0, 600_000, 23_000)], 31, 0, 0)]
     for name, seqs, k, pairs, big in cases:  # (tests/conftest.py puts the knobs back behind the test)
         L.kbo_set_pair_steps(0 if pairs else (1 << 63), 4)
         L.kbo_set_force_big_layout(big)
@@ -503,6 +504,9 @@ def test_device_made_layout_equals_the_hosts(plan_restore):
             sbwt.to_device(-1)
             diff = C.c_uint64(123)
             kbo_amd.check(L.kbo_index_layout_check(sbwt._h, -1, C.byref(diff)))
+            cdiff = C.c_uint64(123)  # ... and the path cover the copy laid out on the device (cover_kernels.hip), position for position
+            kbo_amd.check(L.kbo_index_cover_check(sbwt._h, C.byref(cdiff)))
         assert diff.value == 0, (name, diff.value)
+        assert cdiff.value == 0, (name, cdiff.value)
         lay = sbwt.device_layout()
         assert bool(lay["pair_bytes"]) == bool(pairs and not big), name
