@@ -919,15 +919,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KBO_LONG_WP
                         }
                     }
                 }
+                uint32_t y_fail = x; // where the string of order + 1 bases that is in the index ends
                 if (__ballot(need_on)) { // the run's last window is present: the one inside the next stretch must not be extended by the base in front
                     if (need_on && !fail) {
                         if (STATS) st_second++;
                         if (!inv_span(x + 1u, order + 1u)) fail = present_ext(table(x + 1u, 2u), x + 1u);
+                        if (fail) y_fail = x + 1u;
                     }
                 }
-                if (__ballot(fail)) {
-                    flag = true;
-                    if (STATS) why = __ballot(fail && is_ext) ? 2u : __ballot(fail && need_back) ? 3u : 4u;
+                uint64_t fm = __ballot(fail);
+                if (fm) {
+                    // (round 6) what fails is SEARCHED, as map_reads_kernel does: order + 1 bases ending at y are in the index; the strings
+                    // of thr + 1 bases that hold them end at y .. y + cstep, one a lane - first seed_d bases by the interval table, the
+                    // rest by extend-right steps over the rank blocks - and none of them in the index is the proof, exactly (one with a byte
+                    // that is no base is absent).  Two searches a round of look-ups; more, one that finds its string, or one whose strings do
+                    // not all lie inside the region: the second pass as before
+                    const uint32_t D_ = a.ix.seed_d;
+                    const bool can_search = !(kLongExp && (a.xexp & 256u)) && a.ix.seed_tab != nullptr && D_ >= 4u && D_ <= 16u && thr + 1u >= D_ && thr + 1u <= 33u;
+                    bool unresolved = !can_search;
+                    uint32_t n_search = 0;
+                    while (fm && !unresolved) {
+                        const int src = __builtin_ctzll(fm);
+                        fm &= fm - 1ull;
+                        if (++n_search > 2u) {
+                            unresolved = true;
+                            break;
+                        }
+                        const uint32_t y = __shfl(y_fail, src);
+                        // (order + 1 bases ending at y lie inside thr + 1 bases ending at y .. y + cstep: cstep + 1 candidates; one that does not
+                        // lie inside the region cannot be looked at here: the second pass)
+                        const uint32_t e_c = y + lane; // this lane's candidate ends here
+                        const bool mine_c = lane <= cstep;
+                        const bool outside = mine_c && (e_c >= xe || e_c < r0 + thr);
+                        if (__ballot(outside)) {
+                            unresolved = true;
+                            break;
+                        }
+                        bool alive = mine_c && !inv_span(e_c, thr + 1u);
+                        const uint32_t first = e_c - thr;
+                        uint32_t l_ = 0, r_ = 0;
+                        if (alive) {
+                            const uint32_t key = (uint32_t)ending_at(first + D_ - 1u) & (D_ >= 16u ? 0xFFFFFFFFu : (1u << (2u * D_)) - 1u);
+                            const uint2 iv = a.ix.seed_tab[key];
+                            if (STATS) st_second++;
+                            l_ = iv.x;
+                            r_ = iv.y;
+                            alive = l_ < r_;
+                        }
+                        const uint8_t *arena_ = reinterpret_cast<const uint8_t *>(a.ix.arena);
+                        for (uint32_t j_ = D_; j_ <= thr; j_++) {
+                            if (__ballot(alive) == 0) break;
+                            if (alive) {
+                                const uint32_t cb_ = base_at(first + j_) * a.ix.n_blocks, bl_ = div96(l_), br_ = div96(r_);
+                                const uint4 xA = ld16(arena_, (cb_ + bl_) << 4), xB = ld16(arena_, (cb_ + br_) << 4);
+                                l_ = rank_eval(xA, l_ - bl_ * 96u);
+                                r_ = rank_eval(xB, r_ - br_ * 96u);
+                                alive = l_ < r_;
+                            }
+                        }
+                        if (__ballot(alive)) unresolved = true; // a string of thr + 1 bases that lies in no single stretch IS in the index
+                    }
+                    if (unresolved) {
+                        flag = true;
+                        if (STATS) why = __ballot(fail && is_ext) ? 2u : __ballot(fail && need_back) ? 3u : 4u;
+                    }
                 }
             }
         }
