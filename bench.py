@@ -99,9 +99,8 @@ def main(argv=None):
     n_pipes = max(1, args.pipelines) if piped else 1
     # (kbo::find has no entry point of that kind yet: its pipelines are pairs of torch streams here, kbo_find_batch_dev's tail stream)
     # (... made by the library like kbo_map_stream's own: the tail stream - the second passes - on compute units of its own)
-    # find's tail stream carries the run-length passes over every read's characters as well - work, not a chain: plain streams (confined to
-    # 16 units: C3 511 -> 157 Gbp/s; KBO_FIND_TAIL_CUS: experiments)
-    pipes = [batch.stream_pair(device, tail_cus=int(os.environ.get("KBO_FIND_TAIL_CUS", "0"))) for p in range(n_pipes)] if piped and args.find else None
+    # (... made by the library like kbo_map_stream's own: the kernels' stream kept off 32 compute units, the tail stream plain; KBO_FIND_TAIL_CUS: experiments)
+    pipes = [batch.stream_pair(device, tail_cus=int(os.environ.get("KBO_FIND_TAIL_CUS", "-1"))) for p in range(n_pipes)] if piped and args.find else None
     mstream = None
     n_slabs = (n_mine + SLAB_READS - 1) // SLAB_READS
     # (slabs of equal size: the pipelines take the slabs in turn, and with 8 M + 2 M reads - C3 - one of them had four fifths of the work)

@@ -413,10 +413,11 @@ int kbo_map_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
 int kbo_map_batch_dev_tail(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
                            size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
                            void *d_work, size_t work_bytes, void *stream, void *tail_stream, int *fused);
-/* A (stream, tail_stream) pair for kbo_map_batch_dev_tail / kbo_find_batch_dev made the way kbo_map_stream_* makes its own: the tail
- * stream confined to `tail_cus` compute units of the current device (-1: the library's default, 16; 0: two plain streams), the other
- * stream to the rest - a second pass is a chain of dependent look-ups by a few hundred waves that otherwise waits for wave slots behind
- * the kernels (C2, two such pairs: 757 -> 973 Gbp/s).  hipStream_t values; kbo_stream_pair_destroy when they are idle. */
+/* A (stream, tail_stream) pair for kbo_map_batch_dev_tail / kbo_find_batch_dev made the way kbo_map_stream_* makes its own: `stream` -
+ * the kernels' - kept off `tail_cus` compute units of the current device (-1: the library's default, 32; 0: two plain streams), the tail
+ * stream a plain one: a second pass is a chain of dependent look-ups by a few hundred waves that otherwise waits for wave slots behind
+ * kernels that hold them all; with units the kernels cannot take its workgroups start at once (C2, two such pairs: 757 -> 967 Gbp/s),
+ * and a second pass that is work still has the whole device.  hipStream_t values; kbo_stream_pair_destroy when they are idle. */
 int kbo_stream_pair_create(int tail_cus, void **stream, void **tail_stream);
 void kbo_stream_pair_destroy(void *stream, void *tail_stream);
 /* ---- several batches in flight, the library's own arrangement (what bench.py's headline is measured with): `pipelines` pairs of

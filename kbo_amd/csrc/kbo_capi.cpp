@@ -1373,9 +1373,7 @@ struct FindTail {
 int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
                        size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
                        void *d_work, size_t work_bytes, void *stream, void *tail_stream, bool split, int *fused,
-                       const FindTail *find = nullptr,
-                       uint32_t *fb_pinned = nullptr /* pinned word: the batch's flagged reads / pieces, written by its second pass's first kernel */,
-                       uint32_t *fb_units = nullptr /* what that number is a share of: reads, or pieces of long sequences */)
+                       const FindTail *find = nullptr)
 {
     if (fused) *fused = 0;
     bool done = false, counted = false; // (counted: device_view() has seen this batch's bases for the copy's lazy plan structures)
@@ -1403,11 +1401,8 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
             counted = true;
             if (!kbo::map_long_applies(view, (uint32_t)threshold)) return;
             kbo::LongArgs la{};
-            la.host_flagged = fb_pinned;
             HIP_OK(kbo::launch_map_long(view, d_concat, d_offsets, (uint32_t)n_seqs, total_bases, (uint32_t)threshold, format != 0, d_chars_out,
                                         static_cast<uint8_t *>(d_work) + w.long_off, s, la, g_plan_stats.load()));
-            la.host_flagged = fb_pinned; // (launch_map_long fills `la`: once more behind it)
-            if (fb_units) *fb_units = (uint32_t)std::min<uint64_t>(total_bases / 900u + n_seqs, 0xFFFFFFFFu); // (about the pieces: 944 own bases each at k = 31)
             hipStream_t ts = s;
             if (split && static_cast<hipStream_t>(tail_stream) != s) {
                 ts = static_cast<hipStream_t>(tail_stream);
@@ -1447,8 +1442,6 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
         if (!a.gitems || !kbo::map_reads_applies(a)) return; // (no plan structures, or the copy is held off: two kernels)
         a.seq_off = d_offsets; // (the kernel and redo_collect_kernel read the offsets themselves: no item list is made)
         a.host_bailed = plan_state ? plan_state->bailed : nullptr; // (set by redo_collect_kernel itself: no 8-byte copy behind the launch)
-        a.host_flagged = fb_pinned;
-        if (fb_units) *fb_units = (uint32_t)n_seqs;
         // kbo::find with max_gap_len = 0: the kernel counts the runs of the reads it finishes (their characters are in LDS anyway), so
         // that format::run_lengths_gapped is one pass over the characters instead of two
         uint32_t *rle_scratch = find ? static_cast<uint32_t *>(find->d_rle_work) : nullptr;
@@ -1539,14 +1532,17 @@ int kbo_map_batch_dev_tail(kbo_index_t *idx, const uint8_t *d_concat, const uint
 }
 
 // ---- kbo_map_stream_*: pipelines of (kernel stream, second-pass stream), two slots each
-// A (kernel stream, second-pass stream) pair with the second passes on compute units of their own (16 of the device's 256 by default;
-// KBO_TAIL_CUS / tail_cus = how many, 0 = plain streams): a second pass is a chain of dependent look-ups by a few hundred waves, and
-// beside kernels that hold every wave slot of the device each link of the chain waits for a slot - 0.12 ms alone, 0.37 beside two kernels,
-// which then wait for it in turn.  The kernel stream gets the other units.  C2, two pipelines, same box: 757 -> 973 Gbp/s (8 .. 32 units;
-// 64: 884); C4 the same either way (the second passes of its slabs are work, not a chain).
-static int tail_cus_default() // compute units of a second-pass stream (KBO_TAIL_CUS; 0 = plain streams, the arrangement of rounds 4 - 5)
+// A (kernel stream, second-pass stream) pair in which the KERNELS' stream is kept off some compute units (32 of the device's 256 by
+// default; KBO_TAIL_CUS / tail_cus = how many, 0 = two plain streams) and the second passes' stream is a plain one: a second pass is a
+// chain of dependent look-ups by a few hundred waves, and beside kernels that hold every wave slot of the device each link of the chain
+// waits for a slot - 0.12 ms alone, 0.37 beside two kernels, which then wait for it in turn.  With units the kernels cannot take, the
+// pass's workgroups find free slots at once - and one that is WORK (5 % substitutions, long sequences, repeats) still spreads over the
+// whole device.  C2, two pipelines, same box: plain / plain 757 Gbp/s; second passes CONFINED to 16 units of their own 973, but 5 %
+// substitutions 245 -> 76 (adaptive forms of that: LABNOTES round 6); kernels off 32 units, second passes plain: 967 and every variant at
+// or above the plain arrangement (reserved 16 / 24 / 32 / 40 / 48 units: 878 / 958 / 967 / 904 / 896 - 32 is four per XCD).
+static int tail_cus_default() // compute units the kernels' streams stay off (KBO_TAIL_CUS; 0 = plain streams, the arrangement of rounds 4 - 5)
 {
-    static const int v = std::getenv("KBO_TAIL_CUS") ? std::atoi(std::getenv("KBO_TAIL_CUS")) : 16;
+    static const int v = std::getenv("KBO_TAIL_CUS") ? std::atoi(std::getenv("KBO_TAIL_CUS")) : 32;
     return v;
 }
 static void make_stream_pair(int device, int tail_cus, hipStream_t *ks, hipStream_t *ts)
@@ -1555,23 +1551,18 @@ static void make_stream_pair(int device, int tail_cus, hipStream_t *ks, hipStrea
     hipDeviceProp_t prop;
     HIP_OK(hipGetDeviceProperties(&prop, device));
     const int n_cu = prop.multiProcessorCount;
+    HIP_OK(hipStreamCreateWithFlags(ts, hipStreamNonBlocking));
     if (want <= 0 || want >= n_cu) {
         HIP_OK(hipStreamCreateWithFlags(ks, hipStreamNonBlocking));
-        HIP_OK(hipStreamCreateWithFlags(ts, hipStreamNonBlocking));
         return;
     }
-    std::vector<uint32_t> mask_k((size_t)(n_cu + 31) / 32, 0u), mask_t((size_t)(n_cu + 31) / 32, 0u);
-    for (int cu = 0; cu < n_cu; cu++) (cu < want ? mask_t : mask_k)[(size_t)cu / 32] |= 1u << (cu % 32);
-    // (a runtime that refuses the masks - none seen - gets plain streams: slower, never wrong)
+    std::vector<uint32_t> mask_k((size_t)(n_cu + 31) / 32, 0u);
+    for (int cu = want; cu < n_cu; cu++) mask_k[(size_t)cu / 32] |= 1u << (cu % 32);
+    // (a runtime that refuses the mask - none seen - gets a plain stream: slower, never wrong)
     if (hipExtStreamCreateWithCUMask(ks, (uint32_t)mask_k.size(), mask_k.data()) != hipSuccess) {
         (void)hipGetLastError();
         *ks = nullptr;
         HIP_OK(hipStreamCreateWithFlags(ks, hipStreamNonBlocking));
-    }
-    if (hipExtStreamCreateWithCUMask(ts, (uint32_t)mask_t.size(), mask_t.data()) != hipSuccess) {
-        (void)hipGetLastError();
-        *ts = nullptr;
-        HIP_OK(hipStreamCreateWithFlags(ts, hipStreamNonBlocking));
     }
 }
 
@@ -1595,17 +1586,8 @@ void kbo_stream_pair_destroy(void *stream, void *tail_stream)
 struct kbo_map_stream {
     kbo_index_t *idx = nullptr;
     int device = 0;
-    // a pipeline: the kernels' stream `ks` (all compute units but sixteen) and the second passes' stream `ts` (those sixteen), where a
-    // second pass that is a thin chain of look-ups - few reads flagged: what the latest second passes reported into `fb` - runs unhindered
-    // and hinders nobody.  A second pass that is WORK (5 % substitutions, long sequences, repeats: 3 - 4 x slower confined to 16 units) goes
-    // behind its own kernel on `ks`, beside the other pipeline's kernel.  (Further streams for such batches - plain ones, made with the
-    // stream or by the first batch that needs them - cost more than they gave: the runtime's streams share a handful of hardware queues,
-    // and with eight of the library's alive the headline fell from 866 to 563 - 615 Gbp/s, or 5 % substitutions from 245 to 133.)
-    struct Pipe {
-        hipStream_t ks = nullptr, ts = nullptr;
-        uint32_t *fb = nullptr; // pinned: [0] flagged reads / pieces of the latest second pass that started (~0: none yet)
-        uint32_t units = 0;     // ... of how many (the latest batch submitted)
-    };
+    // a pipeline: the kernels' stream `ks` (kept off 32 compute units) and the second passes' stream `ts` (plain): make_stream_pair
+    struct Pipe { hipStream_t ks = nullptr, ts = nullptr; };
     struct Slot {
         DevBuf work, ms;
         hipEvent_t done = nullptr;
@@ -1633,7 +1615,6 @@ struct kbo_map_stream {
         for (auto &p : pipes) {
             if (p.ks) (void)hipStreamDestroy(p.ks);
             if (p.ts) (void)hipStreamDestroy(p.ts);
-            if (p.fb) (void)hipHostFree(p.fb);
         }
     }
 };
@@ -1655,8 +1636,6 @@ int kbo_map_stream_create(kbo_index_t *idx, int pipelines, size_t max_seqs, uint
         m->slots.resize(2 * (size_t)pipelines);
         for (auto &p : m->pipes) {
             make_stream_pair(m->device, -1, &p.ks, &p.ts);
-            HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&p.fb), 64, hipHostMallocDefault));
-            p.fb[0] = 0xFFFFFFFFu;
         }
         for (auto &sl : m->slots) {
             sl.work.alloc(m->work_bytes + 64);
@@ -1690,11 +1669,7 @@ int kbo_map_stream_submit(kbo_map_stream_t *m, const uint8_t *d_concat, const ui
     const uint64_t n = m->next;
     kbo_map_stream::Pipe &p = m->pipes[n % m->pipes.size()];
     kbo_map_stream::Slot &sl = m->slots[n % m->slots.size()];
-    // where the second pass goes: the confined stream while the pipeline's latest second passes had at most one read (piece) in two hundred
-    // to do - a chain of look-ups, not work - and while nothing is known yet; else behind the batch's own kernel
-    const uint32_t last_flagged = *reinterpret_cast<volatile uint32_t *>(p.fb);
-    const bool thin = tail_cus_default() > 0 && (last_flagged == 0xFFFFFFFFu || p.units == 0 || (uint64_t)last_flagged * 200u <= p.units);
-    hipStream_t kern = p.ks, tail = (thin || tail_cus_default() <= 0) ? p.ts : p.ks;
+    hipStream_t kern = p.ks, tail = p.ts;
     rc = guarded([&] {
         // the slot's buffers are free again behind its last batch; the inputs are there behind what ready_stream holds so far
         if (sl.ticket) HIP_OK(hipStreamWaitEvent(kern, sl.done, 0));
@@ -1705,8 +1680,7 @@ int kbo_map_stream_submit(kbo_map_stream_t *m, const uint8_t *d_concat, const ui
     });
     if (rc != KBO_OK) return rc;
     rc = map_batch_dev_impl(m->idx, d_concat, d_offsets, n_seqs, total_bases, max_seq_len, max_error_prob, format, d_ms_out ? 1 : 0,
-                            d_ms_out ? d_ms_out : sl.ms.as<uint8_t>(), d_chars_out, sl.work.p, m->work_bytes, kern, tail, true, fused, nullptr,
-                            p.fb, &p.units);
+                            d_ms_out ? d_ms_out : sl.ms.as<uint8_t>(), d_chars_out, sl.work.p, m->work_bytes, kern, tail, true, fused);
     if (rc != KBO_OK) return rc;
     rc = guarded([&] { // complete when both streams have come this far
         HIP_OK(hipEventRecord(m->kdone, kern));

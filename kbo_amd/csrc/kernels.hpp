@@ -155,8 +155,6 @@ struct WalkArgs {
     // is no base (nullptr: none does), and, when the characters leave packed as well, where their words go
     uint32_t *host_bailed;   // (map_reads_kernel's route: pinned host word redo_collect_kernel sets when the plan is given up - the copy's
                              // hold-off, DevCopy::PlanState::bailed - instead of an 8-byte copy behind every launch)
-    uint32_t *host_flagged;  // (pinned host word the second pass's first kernel copies the number of flagged reads to, or nullptr: what
-                             // kbo_map_stream_* chooses the next batches' second-pass stream by)
     uint32_t *run_counts;    // (kbo::find with max_gap_len == 0: the number of runs - maximal stretches without '-' - of every read the
                              // kernel finishes itself, or nullptr: format::run_lengths_gapped then needs no counting pass of its own)
     const uint64_t *seq_off; // (reads: the batch's offsets instead of the item list - item s is sequence s, whole: the list is then
@@ -419,7 +417,6 @@ struct LongArgs {
     void *subs;           // WalkItem records of the flagged pieces' sub-items
     uint32_t *flist;      // the flagged pieces, listed (qctl[2] of them)
     uint32_t sub_cap;
-    uint32_t *host_flagged; // (pinned host word for the number of flagged pieces, or nullptr: WalkArgs::host_flagged)
 };
 size_t long_work_bytes(size_t n_seqs, uint64_t total_bases, uint32_t k); // bytes of work memory of a launch (0: k too large)
 // true when the copy has what the kernel needs (depth table of fewer bases than the threshold, 2-bit text, seed positions)

@@ -1104,7 +1104,6 @@ __global__ __launch_bounds__(1024) void long_redo_items_kernel(LongArgs a, WalkI
     __shared__ uint32_t s_sub[16], s_fl[16], s_base[2];
     const uint32_t piece = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t n_fl = a.qctl[4], own_max = (kLongRegion - 2u * a.ix.k - 1u) & ~15u;
-    if (piece == 0 && a.host_flagged) *a.host_flagged = n_fl;
     uint32_t sub = kLongSub;
     for (uint32_t s_ = 8u; s_ < kLongSub; s_ <<= 1) {
         const uint64_t n = (uint64_t)n_fl * ((own_max + s_) / s_);

@@ -692,7 +692,6 @@ __global__ __launch_bounds__(1024) void redo_collect_kernel(WalkArgs a)
     // (table mode: the plan is given up when more than unit_bail items had no plan or were left unresolved by the table)
     const bool gave_up = a.table_mode ? a.qctl[4] > a.unit_bail
                                       : a.usums[(2u * a.n_items) / kScanBlock] + a.ucount[2u * a.n_items] > a.unit_bail;
-    if (idx == 0 && a.host_flagged && a.table_mode) *a.host_flagged = a.qctl[4];
     if (gave_up || a.qctl[3]) { // (block-uniform)
         if (have) reinterpret_cast<uint4 *>(list)[idx] = it;
         if (idx == 0) {
@@ -759,7 +758,6 @@ __global__ __launch_bounds__(kRedoReadsBlock) void redo_collect_reads_kernel(Wal
         return make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), (uint32_t)(o1 - o0), 0u);
     };
     const bool gave_up = a.qctl[4] > a.unit_bail;
-    if (i0 == 0 && a.host_flagged) *a.host_flagged = a.qctl[4];
     if (gave_up || a.qctl[3]) { // (block-uniform; see redo_collect_kernel)
         for (uint32_t j = 0; j < 16u; j++)
             if (i0 + j < a.n_items) reinterpret_cast<uint4 *>(list)[i0 + j] = item_of(i0 + j);
