@@ -40,6 +40,8 @@ from benchlib.call import main_call  # noqa: E402  (--call / --config C5)
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
+    import benchlib.common as _common
+    _common.CONDITION_MS = args.condition_ms
     if args.gpus > 1 and "RANK" not in os.environ and not args.call:
         # (this process never initialises a GPU: it builds the index cache and waits for its children)
         raise SystemExit(spawn_ranks(args, argv))
@@ -177,18 +179,36 @@ def main(argv=None):
     if piped and not args.find:
         every = [d for sl in sets for d in sl]
         mstream = batch.MapStream(sbwt, max(d.n_seqs for d in every), max(d.total for d in every), max(d.max_len for d in every), pipelines=n_pipes)
-    for w in range(args.warmup):
-        one_step(w)
-    sync_all()
+    # everything the timed region needs is made BEFORE the warm-up steps, so that the timed steps follow them at once: a collector
+    # run and a few hundred event objects between the two are tens of milliseconds of an idle device, and the first kernels behind
+    # an idle device run slower than the rest (its clocks) - which 20 timed steps feel
     ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in slabs] for _ in range(args.steps)]
     import ctypes as _C
-    L.kbo_set_stage_timing(1 if one_kernel else 0)  # (event records per call: the dominant kernel's own duration, live)
     import gc
     gc.collect()
     gc.disable()  # (the timed region is tens of milliseconds of enqueueing: no collector pause inside it)
+    # (event records per call: the dominant kernel's own duration, live; the library makes the events of so many calls now)
+    L.kbo_set_stage_timing((args.warmup + args.steps + 4) * len(slabs) + 1 if one_kernel else 0)
+    # the device has idled through the set-up above: the first ~15 ms of load behind that run 5 - 10 % slower than the same work later
+    # (tools/ramp_timeline.py: 20 batches behind 5 / 20 / 100 warm ones 886 / 858 / 947 Gbp/s), which --steps 20 --warmup 5 would measure
+    # instead of the path.  Untimed steps of the same workload for --condition-ms first; the line says how many
+    conditioned = 0
+    if args.condition_ms > 0:
+        t_cond = time.perf_counter()
+        for j in range(4):
+            one_step(j)
+        torch.cuda.synchronize(device)
+        per_step = max(1e-6, (time.perf_counter() - t_cond) / 4)
+        conditioned = 4 + min(4000, int(args.condition_ms * 1e-3 / per_step) + 1)  # (enqueued back to back: the warm-up steps follow with no gap)
+        for j in range(4, conditioned):
+            one_step(j)
+    for w in range(args.warmup):
+        one_step(conditioned + w)
+    sync_all()
+    L.kbo_stage_timing_read(None, None, None)  # (the untimed steps' records: forgotten)
     t0 = time.perf_counter()
     for s in range(args.steps):
-        one_step(args.warmup + s, ev[s])
+        one_step(conditioned + args.warmup + s, ev[s])
     sync_all()
     elapsed = time.perf_counter() - t0
     gc.enable()
@@ -210,6 +230,8 @@ def main(argv=None):
     serial = None
     if piped and rank == 0 and world == 1:  # the same steps on one stream, for the record
         n_ser = max(1, min(args.steps, 10))
+        condition(lambda n: [one_step(j, None, on_tail=False) for j in range(n)], 2, torch, device)  # (the parity copies above were host work)
+        sync_all()
         L.kbo_set_stage_timing(1 if one_kernel else 0)
         t1 = time.perf_counter()
         for s in range(n_ser):
@@ -428,6 +450,9 @@ def main(argv=None):
             "value": round(total_bases * args.steps / elapsed / 1e6, 1),
             "unit": "Mbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "untimed_before_warmup": {"steps": conditioned, "condition_ms": args.condition_ms,
+                                      "why": "the same steps, untimed, in front of the warm-up ones: the device leaves the idle set-up phase "
+                                             "with low clocks, and 5 warm-up steps are under 1 ms of load (--condition-ms 0: none)"},
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",

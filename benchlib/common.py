@@ -31,6 +31,9 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)  # (0.26 ms each: a timed region of 50 ms - one stall of the host does not decide the line)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--condition-ms", type=float, default=30.0,
+                    help="untimed steps of the same workload in front of the warm-up steps, for so many milliseconds: the device comes out of the idle "
+                         "set-up phase with low clocks and needs about 15 ms of load to be back at the rate a serving process sees (0: none)")
     ap.add_argument("--config", choices=sorted(PRESETS) + ["C5"], default="C2",
                     help="BASELINE.json workload: C2 = kbo map, 5 Mbp index, 1 M x 150 bp reads per GPU (the metric config); "
                          "C3 = kbo find, 100 Mbp index, 10 M reads per GPU (SURVEY.md 8(d)'s designated roofline run); "
@@ -207,6 +210,23 @@ def run_piped(devs, mstream, steps):
     return [mstream.submit(devs[i % len(devs)]) for i in range(steps)]
 
 
+CONDITION_MS = 30.0  # (bench.py sets it from --condition-ms)
+
+
+def condition(go, warmup, torch, device):
+    """The untimed steps in front of a timed region: go(n) enqueues n steps.  Four of them sized by the host's clock, then CONDITION_MS of
+    them and the warm-up steps back to back - a device that has idled through host work (set-up, an oracle comparison) runs its first
+    ~15 ms of load 5 - 10 % slower than the same work later (tools/ramp_timeline.py), and 8 warm-up steps are 1 - 2 ms"""
+    if CONDITION_MS <= 0:
+        go(warmup)
+        return
+    t0 = time.perf_counter()
+    go(4)
+    torch.cuda.synchronize(device)
+    per_step = max(1e-6, (time.perf_counter() - t0) / 4)
+    go(min(4000, int(CONDITION_MS * 1e-3 / per_step) + 1) + warmup)
+
+
 def run_batch(devs, stream, find, steps, warmup, torch, device, two_kernels=False, pipes=None):
     """warm-up + timed steps over the resident batches `devs` in turn (one, or two per pipeline of the same shape with `pipes`, see
     run_piped) -> (elapsed s, a1 ms, a5/a6 ms, rle ms | None); with kbo_map_batch_dev (not two_kernels) a1 = the whole step and a5/a6 = 0"""
@@ -221,7 +241,7 @@ def run_batch(devs, stream, find, steps, warmup, torch, device, two_kernels=Fals
             for i in range(n):
                 devs[i % len(devs)].run(stream)
             return []
-        go(warmup)
+        condition(go, warmup, torch, device)
         torch.cuda.synchronize(device)
         if mstream is not None:
             # (the host's clock between two synchronisations, as the headline's: events recorded on a torch stream beside the library's

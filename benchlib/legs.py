@@ -263,8 +263,10 @@ def ms_leg(args, sbwt, oi, concat, offsets, torch, device, stream, pipes):
     # kbo_ms_batch_dev: MS bytes out and nothing else - for reads over a copy with a depth table map_reads_kernel's MS-emitting form stopped
     # behind the values + the plain walk of the reads it leaves (one stream: the entry point has no tail stream)
     dev = batch.DeviceBatch(sbwt, concat, offsets, device=device, format=True, want_ms=True)
-    for _ in range(4):
-        dev.walk(stream)
+    def warm(n):
+        for _ in range(n):
+            dev.walk(stream)
+    condition(warm, 4, torch, device)
     torch.cuda.synchronize(device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
@@ -283,7 +285,7 @@ def ms_leg(args, sbwt, oi, concat, offsets, torch, device, stream, pipes):
     def go(n):
         for i in range(n):
             devs[i % 4].walk(streams[i % 2])
-    go(8)
+    condition(go, 8, torch, device)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     go(40)

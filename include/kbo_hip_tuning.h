@@ -164,7 +164,8 @@ int kbo_long_stats_dev(size_t n_seqs, uint64_t total_bases, size_t max_seq_len, 
 /* instrumentation (default off): while on, every kbo_map_batch_dev call that takes the one-kernel route records HIP events on its
  * stream around map_reads_kernel and behind the redo pass (three event records per call).  kbo_stage_timing_read waits for the
  * recorded calls, returns their number and the sums of the two intervals in milliseconds - the kernel itself / the reads it left
- * to the plain walk (list, walk, their derandomize + translate) - and forgets them.  bench.py prices its roofline by the first. */
+ * to the plain walk (list, walk, their derandomize + translate) - and forgets them.  bench.py prices its roofline by the first.
+ * on > 1: on, and the events of that many calls are made now instead of inside the first calls that record them. */
 int kbo_set_stage_timing(int on);
 int kbo_stage_timing_read(double *kernel_ms_sum, double *redo_ms_sum, int *n_calls);
 

@@ -1326,8 +1326,19 @@ StageEvents timing_take()
 
 int kbo_set_stage_timing(int on)
 {
-    g_stage_timing = on != 0;
-    return KBO_OK;
+    if (on <= 1) {
+        g_stage_timing = on != 0;
+        return KBO_OK;
+    }
+    // on > 1: the events of that many calls are made here, not inside the calls that are to be timed
+    return guarded([&] {
+        std::vector<StageEvents> held;
+        for (int i = 0; i < on; ++i)
+            held.push_back(timing_take());
+        std::lock_guard<std::mutex> g(g_timing_mu);
+        g_timing_pool.insert(g_timing_pool.end(), held.begin(), held.end());
+        g_stage_timing = 1;
+    });
 }
 
 int kbo_stage_timing_read(double *kernel_ms_sum, double *redo_ms_sum, int *n_calls)
@@ -1695,12 +1706,17 @@ int kbo_map_stream_submit(kbo_map_stream_t *m, const uint8_t *d_concat, const ui
 }
 
 namespace {
-// the event of the batch with this ticket while its slot has not been reused (then the batch is long complete): nullptr = complete
+// the event that says the batch with this ticket is complete: its own while its slot still holds it, else that of the next batch of
+// the same pipeline whose slot still holds it - a pipeline's batches complete in the order they were submitted (submit never blocks, so
+// a slot taken again says nothing about the batch that had it before; the pipeline's latest batch is always held)
 hipEvent_t map_stream_event(kbo_map_stream_t *m, uint64_t ticket)
 {
     KBO_REQUIRE(m && ticket >= 1 && ticket <= m->next, KBO_E_BAD_ARG, "no such batch");
-    kbo_map_stream::Slot &sl = m->slots[(ticket - 1) % m->slots.size()];
-    return sl.ticket == ticket ? sl.done : nullptr;
+    for (uint64_t t = ticket; t <= m->next; t += m->pipes.size()) {
+        kbo_map_stream::Slot &sl = m->slots[(t - 1) % m->slots.size()];
+        if (sl.ticket == t) return sl.done;
+    }
+    return nullptr; // (not reached: the pipeline's latest batch holds its slot)
 }
 } // namespace
 

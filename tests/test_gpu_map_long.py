@@ -317,6 +317,45 @@ def test_map_stream_batches_in_flight(oracle):
     ms.close()
 
 
+def test_map_stream_wait_for_a_ticket_whose_slot_was_taken_again(oracle):
+    """kbo_map_stream_submit never blocks, so more batches than the pipelines have slots can be queued: waiting for an early ticket
+    still means its batch is complete - its pipeline's later batches are behind it.  The first batch is held back by a stream that
+    sleeps (ready_stream); the wait may not return before the sleep is over"""
+    import torch
+    rng = np.random.default_rng(86)
+    contigs = _genome(rng, 200_000, contigs=1)
+    sbwt, _ = kbo_amd.build(contigs, kbo_amd.BuildOpts(k=31, num_threads=threads()))
+    sbwt.to_device(-1)
+    ora = oracle.Index.build([c.tobytes() for c in contigs], k=31)
+    dev0 = torch.device("cuda:0")
+    seqs = _sequences(rng, contigs, 2000, [150], 0.01, 0.0, 0.0, spice=False)
+    concat, offsets = _batch_of(seqs)
+    want = ora.matches_batch(concat, offsets, 1e-7, n_threads=threads())
+    devs = [batch.DeviceBatch(sbwt, concat, offsets, device=dev0, format=False, want_ms=False) for _ in range(4)]
+    ms = batch.MapStream(sbwt, devs[0].n_seqs, devs[0].total, 0, pipelines=2)
+    for d in devs:  # (routes and lazy parts settled)
+        ms.wait(ms.submit(d))
+    for d in devs:
+        d.chars.fill_(0xEE)
+    torch.cuda.synchronize(dev0)
+    held = torch.cuda.Stream(dev0)
+    with torch.cuda.stream(held):
+        torch.cuda._sleep(400_000_000)  # (about 0.2 s)
+        woke = torch.cuda.Event()
+        woke.record(held)
+    tickets = [ms.submit(devs[i % 4], ready_stream=held if i == 0 else None) for i in range(13)]
+    ms.wait(tickets[0])
+    assert woke.query(), "kbo_map_stream_wait came back before the batch could have started"
+    for v in (2, 3):  # (its pipeline's other batches whose slots were taken again)
+        ms.wait(tickets[v])
+    ms.sync()
+    for d in devs:
+        assert np.array_equal(d.chars[:d.total].cpu().numpy(), want)
+    with pytest.raises(kbo_amd.KboError):
+        ms.wait(tickets[-1] + 1)
+    ms.close()
+
+
 def test_the_walks_need_only_their_own_work_bytes(oracle):
     """kbo_ms_batch_dev over long sequences with a d_work of kbo_ms_work_bytes(): the regions of the kernels for long sequences that
     kbo_work_bytes() adds (about 0.5 B per base) are kbo_map_batch_dev's / kbo_find_batch_dev's - the walks never touch them and do not
