@@ -1479,9 +1479,14 @@ int map_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t
             if (!env_piece) a.redo_piece = 32u;
         }
         if (timing) HIP_OK(hipEventRecord(ev.e1t, ts)); // (when the second pass starts: behind the kernel and behind what `ts` held)
-        HIP_OK(kbo::launch_redo_pass(a, ts)); // (redo_collect_kernel reads the offsets as well: no item list at all)
-        HIP_OK(kbo::launch_derand_flagged(d_ms, d_offsets, (uint32_t)n_seqs, idx->host.k, (uint32_t)threshold, format ? d_concat : nullptr,
-                                          d_chars_out, a.redo, (uint32_t)max_seq_len, ts, count_in_kernel ? rle_scratch : nullptr));
+        if (kbo::map_reads_finish_applies(a)) {
+            // the reads the kernel listed, finished by one kernel: walk, derandomize + translate, characters (and their runs)
+            HIP_OK(kbo::launch_map_reads_finish(a, ts));
+        } else {
+            HIP_OK(kbo::launch_redo_pass(a, ts)); // (redo_collect_kernel reads the offsets as well: no item list at all)
+            HIP_OK(kbo::launch_derand_flagged(d_ms, d_offsets, (uint32_t)n_seqs, idx->host.k, (uint32_t)threshold, format ? d_concat : nullptr,
+                                              d_chars_out, a.redo, (uint32_t)max_seq_len, ts, count_in_kernel ? rle_scratch : nullptr));
+        }
         if (timing) {
             HIP_OK(hipEventRecord(ev.e2, ts));
             std::lock_guard<std::mutex> g(g_timing_mu);

@@ -127,7 +127,7 @@ struct WalkArgs {
     uint32_t redo_cap;     // WalkItem records the unit array holds (the redo pass's list is built there)
     uint32_t unit_bail;    // more units than this in a launch: the plan is given up, every item takes the plain walk
     uint32_t *qctl;        // [0] queue head of the guided walk, [1] entries of the redo list, [2] plan given up, [3] a walk left through its guard,
-                           // [4] (table mode) items the table could not resolve, [5] items without a plan
+                           // [4] (table mode) items the table could not resolve, [5] items without a plan, [6] entries of map_reads_kernel's list of the reads it left (finish_reads_kernel)
     uint32_t *pstats;      // work counters of the launch (kPlanStat*): kPlanStatSlots slots of 8 u32, summed by the host
     uint32_t plan_dmin;    // plan_kernel: a seed must be this deep (capped at k) before its row is trusted
     uint32_t plan_cap;     // plan_kernel: seed iterations before an item is given up as unplanned
@@ -226,6 +226,8 @@ bool map_reads_applies(const WalkArgs &a);
 // the kernel; the reads it could not finish are flagged in a.redo (launch_redo_pass walks them, launch_derand_flagged
 // translates them)
 hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream);
+bool map_reads_finish_applies(const WalkArgs &a);
+hipError_t launch_map_reads_finish(const WalkArgs &a, hipStream_t stream);
 bool map_reads_direct(const WalkArgs &a);
 bool map_reads_packed_applies(const WalkArgs &a, bool packed_out); // (a.qp set: the reads as 2-bit words; a.packed_out: the characters too)
 // packed-native batches (pack_kernels.hip): exc[s] = 1 for every read that holds a listed byte (d_exc zeroed first); the bytes of the

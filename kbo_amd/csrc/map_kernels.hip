@@ -171,6 +171,48 @@ __device__ __forceinline__ uint32_t reverse_digits(uint32_t w)
     const uint32_t r = __builtin_bitreverse32(w);
     return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
 }
+// derandomize_ms_vec + translate_ms_vec of one read, right to left, in place: `at` holds its len >= 3 matching statistics (bytes, LDS)
+// and then its characters M - X R (derand_kernels.hip has the derivation of the closed form of the 'R','R' look-ahead): x = derandomised
+// value, window (x_prev, x_cur, x_next) = x[p-1], x[p], x[p+1]
+__device__ __forceinline__ void literal_chars(uint8_t *at, uint32_t len, int K, int T)
+{
+    const uint32_t Tm1 = (uint32_t)(T - 1);
+    auto step = [&](int av, int x_cur) { return (av == K) ? K : ((av > T && x_cur < av) ? av : x_cur - 1); };
+    auto plain = [&](int x_cur, int next, int prev) -> uint32_t {
+        return x_cur <= 0 ? ((next == 1 && prev > 0) ? (uint32_t)'X' : (uint32_t)'-') : (uint32_t)'M';
+    };
+    int av = at[len - 1];
+    int x_cur = av > T ? av : 0; // derandomize.rs:282
+    int a_below = at[len - 2];
+    int x_prev = step(a_below, x_cur);
+    bool in_cur = (uint32_t)(x_cur - 1) < Tm1, gt_cur = x_cur > T;
+    at[len - 1] = (uint8_t)((gt_cur && in_cur) ? (uint32_t)'R' : plain(x_cur, x_cur, x_prev));
+    int x_next = x_cur;
+    bool in_next = in_cur;
+    x_cur = x_prev;
+    gt_cur = x_cur > T;
+    in_cur = (uint32_t)(x_cur - 1) < Tm1;
+    a_below = at[len - 3];
+#pragma unroll 4
+    for (uint32_t p = len - 2; p >= 2; p--) {
+        x_prev = step(a_below, x_cur);
+        a_below = at[p - 2];
+        const bool gt_prev = x_prev > T;
+        const bool is_r = (gt_prev && in_cur) || (gt_cur && in_next);
+        at[p] = (uint8_t)(is_r ? (uint32_t)'R' : plain(x_cur, x_next, x_prev));
+        x_next = x_cur;
+        in_next = in_cur;
+        x_cur = x_prev;
+        gt_cur = gt_prev;
+        in_cur = (uint32_t)(x_cur - 1) < Tm1;
+    }
+    x_prev = step(a_below, x_cur); // a_below == at[0]
+    at[1] = (uint8_t)((gt_cur && in_next) ? (uint32_t)'R' : plain(x_cur, x_next, K));
+    x_next = x_cur;
+    in_next = in_cur;
+    x_cur = x_prev;
+    at[0] = (uint8_t)((x_cur > T && in_next) ? (uint32_t)'R' : plain(x_cur, x_next, K));
+}
 // STATS: the kernel counts its own work (kbo_set_plan_stats) - instrumentation, compiled out of the default instantiations
 template <int NP, bool DIRECT, int IO = 0, bool STATS = false>
 __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint32_t stage_bytes, uint32_t lin_words)
@@ -232,6 +274,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
         if (have_item) a.redo[idx] = len != 0 ? 1 : 0;
         const uint64_t fm = __ballot(have_item && len != 0);
         if (lane == 0 && fm) atomicAdd(a.qctl + 4, (uint32_t)__popcll(fm));
+        if (have_item && len != 0) reinterpret_cast<uint32_t *>(a.units)[atomicAdd(a.qctl + 6, 1u)] = idx;
         return;
     }
     const uint32_t nblk = IO != 0 ? nwords : (span + 15u) >> 4;
@@ -1046,44 +1089,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
         if (cand) put(e, cX); // (the read's first base: its prev is k)
         (void)K;
     } else if (a.chars_out != nullptr && plannable && !flag && len >= 3u) { // (chars_out == nullptr: kbo_ms_batch_dev - the MS values were all that was asked for)
-        const int K = (int)k, T = (int)a.map_thr;
-        const uint32_t Tm1 = (uint32_t)(T - 1);
-        uint8_t *at = so + soff;
-        auto step = [&](int av, int x_cur) { return (av == K) ? K : ((av > T && x_cur < av) ? av : x_cur - 1); };
-        auto plain = [&](int x_cur, int next, int prev) -> uint32_t {
-            return x_cur <= 0 ? ((next == 1 && prev > 0) ? (uint32_t)'X' : (uint32_t)'-') : (uint32_t)'M';
-        };
-        int av = at[len - 1];
-        int x_cur = av > T ? av : 0; // derandomize.rs:282
-        int a_below = at[len - 2];
-        int x_prev = step(a_below, x_cur);
-        bool in_cur = (uint32_t)(x_cur - 1) < Tm1, gt_cur = x_cur > T;
-        at[len - 1] = (uint8_t)((gt_cur && in_cur) ? (uint32_t)'R' : plain(x_cur, x_cur, x_prev));
-        int x_next = x_cur;
-        bool in_next = in_cur;
-        x_cur = x_prev;
-        gt_cur = x_cur > T;
-        in_cur = (uint32_t)(x_cur - 1) < Tm1;
-        a_below = at[len - 3];
-#pragma unroll 4
-        for (uint32_t p = len - 2; p >= 2; p--) {
-            x_prev = step(a_below, x_cur);
-            a_below = at[p - 2];
-            const bool gt_prev = x_prev > T;
-            const bool is_r = (gt_prev && in_cur) || (gt_cur && in_next);
-            at[p] = (uint8_t)(is_r ? (uint32_t)'R' : plain(x_cur, x_next, x_prev));
-            x_next = x_cur;
-            in_next = in_cur;
-            x_cur = x_prev;
-            gt_cur = gt_prev;
-            in_cur = (uint32_t)(x_cur - 1) < Tm1;
-        }
-        x_prev = step(a_below, x_cur); // a_below == at[0]
-        at[1] = (uint8_t)((gt_cur && in_next) ? (uint32_t)'R' : plain(x_cur, x_next, K));
-        x_next = x_cur;
-        in_next = in_cur;
-        x_cur = x_prev;
-        at[0] = (uint8_t)((x_cur > T && in_next) ? (uint32_t)'R' : plain(x_cur, x_next, K));
+        literal_chars(so + soff, len, (int)k, (int)a.map_thr);
     }
     // kbo::find: the runs of the read (format::run_lengths_gapped with max_gap_len = 0 closes a run at every '-': rle_kernels.hip),
     // counted off the characters while they are in LDS - four at a time, a start wherever a character that is not '-' follows one
@@ -1278,6 +1284,117 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
         if (nm) atomicAdd(a.qctl + 5, (uint32_t)__popcll(nm));
     }
     if (have_item) a.redo[idx] = flag ? 1 : 0;
+    // ... and listed for finish_reads_kernel (qctl[6] counts them; the list - where the guided walk's units would be - holds every read)
+    if (flag && have_item) reinterpret_cast<uint32_t *>(a.units)[atomicAdd(a.qctl + 6, 1u)] = idx;
+}
+
+// ---- the reads map_reads_kernel could not finish, in ONE kernel behind it (round 6; before: redo_collect_kernel's list of pieces, the
+// plain walk over it, derand_flagged_kernel - three launches whose empty run alone is 0.09 ms behind a batch of a million reads, and a chain
+// of 16 + k - 1 walk steps and a lane's pass over a whole read: 0.12 ms for the two reads in ten thousand that need it at C2, two thirds
+// of the kernel's own time for a caller with one batch at a time).  R reads a wave, 64 / R lanes each: a lane walks len / (64 / R) bases of
+// its read behind k - 1 bases that only bring the state up (walk_kernels.hip's walk: extend by two rank blocks, or climb one level of the
+// LCS interval tree by two contraction entries and try again), the values go to LDS, the read's first lane runs derandomize_ms_vec +
+// translate_ms_vec over them (literal_chars), and the lanes write what was asked for: the matching statistics, the characters
+// (format::relative_to_ref on the way), the read's number of runs for kbo::find.  R by the number of such reads - one while they are fewer
+// than the launch has waves (a chain of k + 1 + len / 64 steps), four or sixteen beyond (a batch with 5 % substitutions leaves 3 % of its
+// reads) -, so that a batch's second pass is as long as its longest chain, and that is short.
+constexpr uint32_t kFinishStride = 176, kFinishMaxR = 16, kFinishWaves = 8192, kFinishLds = 2u * kFinishMaxR * kFinishStride;
+__global__ __launch_bounds__(256) void finish_reads_kernel(WalkArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t fin_lds_all[];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint8_t *lds = fin_lds_all + (threadIdx.x >> 6) * kFinishLds;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t n_f = min(a.qctl[6], a.n_items);
+    if (wave == 0 && lane == 0 && a.qctl[4] > a.unit_bail) { // most of the batch: the copy's plan is held off for the batches to come (as redo_collect_kernel)
+        a.qctl[2] = 1;
+        if (a.host_bailed) *a.host_bailed = 1u;
+    }
+    const uint32_t R = n_f <= n_waves ? 1u : (n_f <= 4u * n_waves ? 4u : kFinishMaxR), L = 64u / R;
+    const uint32_t sub = lane / L, s = lane % L;
+    const uint32_t *list = reinterpret_cast<const uint32_t *>(a.units);
+    const uint32_t n = a.ix.n, k = a.ix.k, nblk = a.ix.n_blocks, null_blk = 4u * nblk;
+    const uint8_t *arena = reinterpret_cast<const uint8_t *>(a.ix.arena);
+    const uint8_t *ent = a.ix.big ? a.ix.ent : arena + ((uint64_t)a.ix.lcs_off << 4);
+    uint8_t *qL = lds + sub * kFinishStride, *mL = lds + (kFinishMaxR + sub) * kFinishStride;
+    for (uint32_t g = wave; (uint64_t)g * R < n_f; g += n_waves) {
+        const uint32_t slot = g * R + sub;
+        uint32_t ridx = 0, len = 0;
+        uint64_t o0 = 0;
+        if (slot < n_f) {
+            ridx = list[slot];
+            o0 = a.seq_off[ridx];
+            len = (uint32_t)(a.seq_off[ridx + 1u] - o0);
+            if (len + 16u > kFinishStride) len = 0; // (cannot happen: the kernel in front of this one takes reads of up to 160 bases)
+        }
+        for (uint32_t o = 16u * s; o < len; o += 16u * L) { // (reads <= 15 bytes past the read: the batch is padded)
+            uint4 v;
+            __builtin_memcpy(&v, a.q + o0 + o, 16);
+            *reinterpret_cast<uint4 *>(qL + o) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t per = (len + L - 1u) / L;
+        const uint32_t own0 = min(s * per, len), own1 = min(own0 + per, len);
+        uint32_t i = own0 < own1 ? (own0 > k - 1u ? own0 - (k - 1u) : 0u) : own1;
+        uint32_t l = 0, r = n, d = 0;
+        while (__ballot(i < own1)) {
+            if (i < own1) {
+                const uint32_t c = decode_base(qL[i]);
+                const uint32_t cb = c < 4u ? c * nblk : null_blk, bl = c < 4u ? div96(l) : 0u, br = c < 4u ? div96(r) : 0u;
+                const uint4 xA = ld16(arena, (cb + bl) << 4), xB = ld16(arena, (cb + br) << 4);
+                const uint32_t l2 = rank_eval(xA, l - div96(l) * 96u), r2 = rank_eval(xB, r - div96(r) * 96u);
+                if (l2 < r2 || d == 0u) { // extended - or nothing left to give up: the root stays, the value is 0
+                    if (l2 < r2) {
+                        l = l2;
+                        r = r2;
+                        d = min(d + 1u, k);
+                    }
+                    if (i >= own0) mL[i] = (uint8_t)d;
+                    i++;
+                } else { // contract_left down to the level where the interval changes: max(lcs[l], lcs[r]); the side(s) that hold it move
+                    uint4 eA, eB;
+                    __builtin_memcpy(&eA, ent + (uint64_t)l * 12u, 16);
+                    __builtin_memcpy(&eB, ent + (uint64_t)r * 12u, 16);
+                    const uint32_t lv = max(eA.x, eB.x);
+                    l = lv == 0u ? 0u : (eA.x == lv ? eA.y : l);
+                    r = lv == 0u ? n : (eB.x == lv ? eB.z : r);
+                    d = lv;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (a.d_out && (a.map_want_ms || !a.chars_out))
+            for (uint32_t p = s; p < len; p += L) a.d_out[o0 + p] = mL[p];
+        if (a.chars_out) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (s == 0u && slot < n_f) {
+                uint32_t n_runs = 0;
+                if (len >= 3u) { // (fewer: no alignment - the reference asserts, derandomize.rs:274-276 -, no character, no run)
+                    literal_chars(mL, len, (int)k, (int)a.map_thr);
+                    uint32_t gap = 1; // kbo::find: a character that is no '-' behind one that is, or at the read's head
+                    for (uint32_t p = 0; p < len; p++) {
+                        const uint32_t gp = mL[p] == (uint8_t)'-' ? 1u : 0u;
+                        n_runs += gap & (gp ^ 1u);
+                        gap = gp;
+                    }
+                }
+                if (a.run_counts) a.run_counts[ridx] = n_runs;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (len >= 3u)
+                for (uint32_t p = s; p < len; p += L) {
+                    uint32_t ch = mL[p];
+                    if (a.map_fmt) ch = (ch == 'M' || ch == 'R') ? (uint32_t)qL[p] : (uint32_t)'-'; // format::relative_to_ref (format.rs:270-286)
+                    a.chars_out[o0 + p] = (uint8_t)ch;
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 } // namespace
@@ -1365,6 +1482,22 @@ hipError_t launch_map_reads(WalkArgs &a, hipStream_t stream)
         else KBO_MAP_LAUNCH(18, false, 0);
     }
 #undef KBO_MAP_LAUNCH
+    return hipGetLastError();
+}
+
+// the reads launch_map_reads' kernel left (its list: qctl[6] entries where the units would be), finished by one kernel: their matching
+// statistics where a.d_out wants them (a.map_want_ms, or no characters asked for), their characters, their runs (a.run_counts)
+bool map_reads_finish_applies(const WalkArgs &a)
+{
+    static const int env_finish = std::getenv("KBO_MAP_FINISH") ? std::atoi(std::getenv("KBO_MAP_FINISH")) : 1; // experiments: 0 = the three launches
+    return env_finish != 0 && a.seq_off != nullptr && a.qp == nullptr && a.units != nullptr && a.max_item_len != 0 && a.max_item_len <= 16u * kMapWords;
+}
+
+hipError_t launch_map_reads_finish(const WalkArgs &a, hipStream_t stream)
+{
+    if (a.n_items == 0) return hipSuccess;
+    const uint32_t waves = std::min(kFinishWaves, ((a.n_items + 63u) / 64u + 3u) & ~3u);
+    hipLaunchKernelGGL(finish_reads_kernel, dim3(waves / 4u), dim3(256), 4u * kFinishLds, stream, a);
     return hipGetLastError();
 }
 
