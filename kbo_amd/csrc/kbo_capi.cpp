@@ -1128,7 +1128,8 @@ int ms_batch_dev_impl(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t 
                 a.seq_off = d_offsets;
                 a.host_bailed = plan_state ? plan_state->bailed : nullptr;
                 HIP_OK(kbo::launch_map_reads(a, s));
-                HIP_OK(kbo::launch_redo_pass(a, s));
+                if (kbo::map_reads_finish_applies(a)) HIP_OK(kbo::launch_map_reads_finish(a, s)); // (the reads it left: their values by one kernel)
+                else HIP_OK(kbo::launch_redo_pass(a, s));
                 if (!a.host_bailed) plan_after_launch(a, s, plan_state);
                 return;
             }

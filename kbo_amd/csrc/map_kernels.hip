@@ -1299,7 +1299,7 @@ __global__ __launch_bounds__(KBO_MAP_LB) void map_reads_kernel(WalkArgs a, uint3
 // than the launch has waves (a chain of k + 1 + len / 64 steps), four or sixteen beyond (a batch with 5 % substitutions leaves 3 % of its
 // reads) -, so that a batch's second pass is as long as its longest chain, and that is short.
 constexpr uint32_t kFinishStride = 176, kFinishMaxR = 16, kFinishWaves = 8192, kFinishLds = 2u * kFinishMaxR * kFinishStride;
-__global__ __launch_bounds__(256) void finish_reads_kernel(WalkArgs a)
+__global__ __launch_bounds__(256) void finish_reads_kernel(WalkArgs a, uint32_t r1, uint32_t r4)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t fin_lds_all[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -1310,7 +1310,7 @@ __global__ __launch_bounds__(256) void finish_reads_kernel(WalkArgs a)
         a.qctl[2] = 1;
         if (a.host_bailed) *a.host_bailed = 1u;
     }
-    const uint32_t R = n_f <= n_waves ? 1u : (n_f <= 4u * n_waves ? 4u : kFinishMaxR), L = 64u / R;
+    const uint32_t R = n_f <= r1 ? 1u : (n_f <= r4 ? 4u : kFinishMaxR), L = 64u / R;
     const uint32_t sub = lane / L, s = lane % L;
     const uint32_t *list = reinterpret_cast<const uint32_t *>(a.units);
     const uint32_t n = a.ix.n, k = a.ix.k, nblk = a.ix.n_blocks, null_blk = 4u * nblk;
@@ -1497,7 +1497,11 @@ hipError_t launch_map_reads_finish(const WalkArgs &a, hipStream_t stream)
 {
     if (a.n_items == 0) return hipSuccess;
     const uint32_t waves = std::min(kFinishWaves, ((a.n_items + 63u) / 64u + 3u) & ~3u);
-    hipLaunchKernelGGL(finish_reads_kernel, dim3(waves / 4u), dim3(256), 4u * kFinishLds, stream, a);
+    // (reads a wave by their number: one up to r1, four up to r4, sixteen beyond - a read takes 64 x 34, 16 x 42 or 4 x 70 lane-steps, and
+    // beside other batches' kernels a long list costs by those, not by its chain)
+    static const int env_r1 = std::getenv("KBO_FINISH_R1") ? std::atoi(std::getenv("KBO_FINISH_R1")) : 1024; // experiments
+    static const int env_r4 = std::getenv("KBO_FINISH_R4") ? std::atoi(std::getenv("KBO_FINISH_R4")) : 4096;
+    hipLaunchKernelGGL(finish_reads_kernel, dim3(waves / 4u), dim3(256), 4u * kFinishLds, stream, a, (uint32_t)env_r1, (uint32_t)env_r4);
     return hipGetLastError();
 }
 
