@@ -100,7 +100,6 @@ def main(argv=None):
     piped = not args.two_kernels and not args.one_at_a_time
     n_pipes = max(1, args.pipelines) if piped else 1
     # (kbo::find has no entry point of that kind yet: its pipelines are pairs of torch streams here, kbo_find_batch_dev's tail stream)
-    # (... made by the library like kbo_map_stream's own: the tail stream - the second passes - on compute units of its own)
     # (... made by the library like kbo_map_stream's own: the kernels' stream kept off 32 compute units, the tail stream plain; KBO_FIND_TAIL_CUS: experiments)
     pipes = [batch.stream_pair(device, tail_cus=int(os.environ.get("KBO_FIND_TAIL_CUS", "-1"))) for p in range(n_pipes)] if piped and args.find else None
     mstream = None
@@ -431,8 +430,9 @@ def main(argv=None):
                 "kernel": "map_reads_kernel (kbo_amd/csrc/map_kernels.hip): MS -> derandomize -> translate -> relative_to_ref of every read it can finish",
                 "kernel_ms": round(map_kernel_ms, 4), "kernel_ms_per_rank": {"min": round(min(walk_all), 4), "max": round(max(walk_all), 4)},
                 "redo_pass_ms": round(map_redo_ms, 4),
-                "redo_pass": "redo_collect + ms_walk_kernel + derand_flagged over the %.2f %% of the reads the kernel leaves (a chain of dependent "
-                             "look-ups: its time is the chain's, not the reads')" % (100.0 * c["tab_unresolved"] / dev.n_seqs),
+                "redo_pass": "finish_reads_kernel over the %.2f %% of the reads the kernel leaves: a wave a read, its lanes walk pieces of it "
+                             "behind k - 1 warm-up bases (a chain of about k + 10 dependent look-ups), then derandomize + translate and the "
+                             "characters" % (100.0 * c["tab_unresolved"] / dev.n_seqs),
                 "traffic": int(traffic) if traffic else None, "traffic_source": tsrc,
                 "traffic_frac": round(traffic / k_s / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
                 "wasted_traffic": round(traffic / (b_map * bases), 3) if traffic else None,

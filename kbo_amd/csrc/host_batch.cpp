@@ -268,10 +268,16 @@ void enqueue_walk_host(kbo_index *idx, const uint8_t *concat, const uint64_t *of
                 if (count_runs) a.run_counts = map->run_counts;
                 HIP_OK(kbo::launch_map_reads(a, stream));
                 hipStream_t ts = second_pass_stream(a);
-                HIP_OK(kbo::launch_redo_pass(a, ts));
-                HIP_OK(kbo::launch_derand_flagged(B.ms.as<uint8_t>(), B.off.as<uint64_t>(), (uint32_t)n_seqs, idx->host.k, map->threshold,
-                                                  map->format ? B.q.as<uint8_t>() : nullptr, map->d_chars, a.redo, longest_seq, ts,
-                                                  count_runs ? map->run_counts : nullptr)); // (the flagged reads' runs counted on the way)
+                a.seq_off = B.off.as<uint64_t>(); // (item s is sequence s, whole: finish_reads_kernel reads the offsets)
+                if (kbo::map_reads_finish_applies(a)) {
+                    HIP_OK(kbo::launch_map_reads_finish(a, ts)); // the reads the kernel listed: walk, derandomize + translate, characters, runs
+                } else {
+                    a.seq_off = nullptr;
+                    HIP_OK(kbo::launch_redo_pass(a, ts));
+                    HIP_OK(kbo::launch_derand_flagged(B.ms.as<uint8_t>(), B.off.as<uint64_t>(), (uint32_t)n_seqs, idx->host.k, map->threshold,
+                                                      map->format ? B.q.as<uint8_t>() : nullptr, map->d_chars, a.redo, longest_seq, ts,
+                                                      count_runs ? map->run_counts : nullptr)); // (the flagged reads' runs counted on the way)
+                }
                 if (count_runs) map->counted = true;
                 plan_after_launch(a, ts, plan_state);
                 map->done = true;

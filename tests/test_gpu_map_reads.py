@@ -377,8 +377,35 @@ def test_find_on_the_device_counts_runs_in_the_kernel(oracle):
                 assert np.array_equal(np.asarray(recs, dtype=np.uint64).reshape(-1, 7), exp_r), (gap, tail is not None)
 
 
+def test_the_reads_the_kernel_leaves_in_each_of_the_finishing_kernels_shapes(oracle):
+    """finish_reads_kernel (map_kernels.hip) takes the reads map_reads_kernel lists one, four or sixteen a wave by the list's length (up to
+    1024 / up to 4096 / beyond): three batches whose lists fall into the three ranges - ragged reads with N's and lower-case bytes among
+    them -, every character (formatted and not) and, through the MS-emitting form, every matching statistic against the oracle"""
+    import torch
+    rng = np.random.default_rng(606)
+    g = synth.genome(600_000, seed=66)
+    sbwt, _ = kbo_amd.build([g], kbo_amd.BuildOpts(k=31, num_threads=threads()))
+    ora = oracle.Index.build([g.tobytes()], k=31)
+    dev0 = torch.device("cuda:0")
+
+    def take(n, lo, hi):
+        return [g[a:a + int(l)] for a, l in zip(rng.integers(0, len(g) - 200, n), rng.integers(lo, hi + 1, n))]
+    seen = []
+    for n, sub, n_rate in ((30_000, 0.01, 0.002), (60_000, 0.05, 0.01), (60_000, 0.09, 0.05)):
+        concat, offsets = _batch_of(_mutate(rng, take(n, 3, 160), sub=sub, n_rate=n_rate, lower=n_rate))
+        kbo_amd.lib().kbo_set_plan(1, 0, 0)
+        dev = batch.DeviceBatch(sbwt, concat, offsets, device=dev0, format=False, want_ms=False)
+        dev.run()
+        torch.cuda.synchronize()
+        assert dev.fused
+        seen.append(int((dev.plan_flags() != 0).sum()))
+        del dev
+        _check(oracle, ora, sbwt, concat, offsets)
+    assert 0 < seen[0] <= 1024 < seen[1] <= 4096 < seen[2], seen
+
+
 def test_a_batch_that_gives_the_plan_up_holds_the_copy_off(oracle):
-    """20 % substitutions through the one kernel (15 % of the bases differ: 22 mismatches a read, its list holds 13): most reads are left to the second pass, redo_collect_kernel gives the plan up and says
+    """20 % substitutions through the one kernel (15 % of the bases differ: 22 mismatches a read, its list holds 13): most reads are left to the second pass, whose kernel (finish_reads_kernel) gives the plan up and says
     so in the copy's pinned word; the next launches over that copy take the two kernels (exact either way) until kbo_set_plan(1, ..)."""
     import torch
     rng = np.random.default_rng(3)
