@@ -369,8 +369,8 @@ size_t kbo_index_work_bytes(const kbo_index_t *idx, size_t n_seqs, uint64_t tota
  * device.  Same results either way - provided max_seq_len, when given, is not SMALLER than the longest sequence: the
  * kernels size their work items (16-bit lengths) and LDS stretches from it; pass 0 when in doubt.
  * Reads (max_seq_len <= 160) over a copy with a depth table, intervals not asked for: ONE kernel puts the values together (k where
- * nothing happened, the ramps behind the mismatches, the table's values behind them) and the plain walk finishes the reads it leaves -
- * 320 Gbp/s at C2, 386 with resident batches in turn on two streams of the caller's (the plan-guided walk it replaces there: 242);
+ * nothing happened, the ramps behind the mismatches, the table's values behind them) and a second kernel walks the reads it leaves -
+ * 305 Gbp/s at C2, 392 with resident batches in turn on two streams of the caller's (the plan-guided walk it replaces there: 242);
  * every other batch - chunks of long sequences, intervals (d_lo_out / d_hi_out: the colexicographic intervals, index.rs:243-256),
  * sharded indexes - takes the plan-guided walk. */
 int kbo_ms_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets,
@@ -395,7 +395,7 @@ int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, siz
  * piece of a sequence, kbo_amd/csrc/long_kernels.hip: max_seq_len > 160 or 0 = unknown; any length below 4 GiB per launch).  Other
  * batches run as kbo_ms_batch_dev + kbo_derand_translate_dev (d_work carries the scratch of both).
  * d_ms: total_bases bytes + 16, 4-byte aligned: the MS value of every base when want_ms != 0 or the batch takes the two-kernel
- * route, otherwise scratch (the reads the one kernel leaves to the plain walk pass through it).  d_work / work_bytes as for
+ * route, otherwise scratch (unspecified contents).  d_work / work_bytes as for
  * kbo_ms_batch_dev; d_concat needs 16 readable bytes of slack behind the batch.  Sequences of fewer than 3 bases (the
  * reference asserts, derandomize.rs:276) have no alignment: their bytes of d_chars_out (and d_ms) are unspecified - left unwritten by the
  * two-kernel route, overwritten by the one kernel, whose stores are whole lines - and kbo_find_batch_dev reports no run for them.  *fused (optional) = 1 when the
@@ -403,13 +403,13 @@ int kbo_derand_translate_dev(const uint8_t *d_ms, const uint64_t *d_offsets, siz
 int kbo_map_batch_dev(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
                       size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
                       void *d_work, size_t work_bytes, void *stream, int *fused);
-/* The same with the second pass - the plain walk over the few reads the one kernel leaves to it (0.4 % at 1 % substitutions), a chain of
- * dependent look-ups that takes 0.13 ms however few they are - enqueued on `tail_stream`, ordered behind the kernel on `stream` by an
+/* The same with the second pass - one kernel that walks the few reads the first leaves (two in ten thousand at 1 % substitutions), a wave
+ * a read: a chain of dependent look-ups that takes 0.07 ms however few they are - enqueued on `tail_stream`, ordered behind the kernel on `stream` by an
  * event: a caller with several batches in flight (own d_ms / d_chars_out / d_work each) keeps `stream` busy with the next batch's
  * kernel meanwhile.  The batch's outputs are complete when BOTH streams have reached this point; whatever touches this batch's
  * buffers next - on either stream - has to be ordered behind `tail_stream`.  tail_stream == stream: kbo_map_batch_dev.  The two-kernel
  * route (*fused = 0) runs on `stream` alone.  Two such pairs of streams that take the batches in turn, two batches in flight on
- * each, keep the device fuller still (INTEGRATION.md "Several batches in flight"; bench.py: 747 against 587 Gbp/s at C2). */
+ * each, keep the device fuller still (INTEGRATION.md "Several batches in flight"; bench.py: 1 034 against 679 Gbp/s at C2). */
 int kbo_map_batch_dev_tail(kbo_index_t *idx, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
                            size_t max_seq_len, double max_error_prob, int format, int want_ms, uint8_t *d_ms, uint8_t *d_chars_out,
                            void *d_work, size_t work_bytes, void *stream, void *tail_stream, int *fused);
@@ -430,8 +430,11 @@ void kbo_stream_pair_destroy(void *stream, void *tail_stream);
  *                           kbo_ms_batch_dev gives them (index.rs:243-256: the raw k-bounded values, NOT derandomized);
  *                           ready_stream (optional): the stream whose work so far produces the batch's inputs - the pipeline waits
  *                           for it on the device; *ticket (optional) names the batch; *fused (optional) as kbo_map_batch_dev's
- *   kbo_map_stream_wait     blocks the calling thread until that batch is complete;  kbo_map_stream_wait_on makes `stream` wait for
- *                           it on the device instead;  kbo_map_stream_sync: every batch submitted so far */
+ *   kbo_map_stream_wait     blocks the calling thread until that batch is complete (submit never blocks, so more batches than the
+ *                           pipelines have slots may be queued: a ticket whose slot a later batch has taken is waited for through the
+ *                           next batch of its pipeline that still holds one - a pipeline's batches complete in order);
+ *                           kbo_map_stream_wait_on makes `stream` wait for it on the device instead;  kbo_map_stream_sync: every
+ *                           batch submitted so far */
 typedef struct kbo_map_stream kbo_map_stream_t;
 int kbo_map_stream_create(kbo_index_t *idx, int pipelines, size_t max_seqs, uint64_t max_bases, size_t max_seq_len, kbo_map_stream_t **out);
 int kbo_map_stream_submit(kbo_map_stream_t *ms, const uint8_t *d_concat, const uint64_t *d_offsets, size_t n_seqs, uint64_t total_bases,
