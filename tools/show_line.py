@@ -1,3 +1,5 @@
+"""The figures of bench.py lines one reads first: value, ms per step, roofline.frac, parity; kernel alone / second pass; the variants; the
+MS-emitting entry points.  python tools/show_line.py <line.json> [..]"""
 import json,sys
 for f in sys.argv[1:]:
     try:
